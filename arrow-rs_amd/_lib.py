@@ -1,0 +1,132 @@
+"""ctypes binding of libarrow_hip.so (include/arrow_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing, or no GPU is
+visible when a Context is created, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libarrow_hip.so")
+
+# status codes (include/arrow_hip.h)
+AH_OK = 0
+AH_INVALID_ARGUMENT = 1
+AH_COMPUTE_ERROR = 2
+AH_ARITHMETIC_OVERFLOW = 3
+AH_DIVIDE_BY_ZERO = 4
+AH_CAST_ERROR = 5
+AH_OFFSET_OVERFLOW = 6
+AH_NOT_YET_IMPLEMENTED = 7
+AH_PANIC = 100
+AH_HIP_ERROR = 101
+AH_OUT_OF_MEMORY = 102
+
+# physical types
+AH_BOOL, AH_INT8, AH_INT16, AH_INT32, AH_INT64 = 1, 2, 3, 4, 5
+AH_UINT8, AH_UINT16, AH_UINT32, AH_UINT64 = 6, 7, 8, 9
+AH_FLOAT32, AH_FLOAT64, AH_FIXED16, AH_FIXED32 = 10, 11, 12, 13
+AH_UTF8, AH_LARGE_UTF8, AH_FLOAT16 = 14, 15, 16
+
+AH_OUT_BORROWED = 1
+
+
+class ArrayView(C.Structure):
+    """ah_array_view / orc_view (identical layout)."""
+    _fields_ = [
+        ("type", C.c_int32),
+        ("length", C.c_int64),
+        ("null_count", C.c_int64),
+        ("values", C.c_void_p),
+        ("values_bit_offset", C.c_int64),
+        ("validity", C.c_void_p),
+        ("validity_bit_offset", C.c_int64),
+    ]
+
+
+class ArrayOut(C.Structure):
+    """ah_array_out / orc_out (identical layout)."""
+    _fields_ = [
+        ("type", C.c_int32),
+        ("length", C.c_int64),
+        ("null_count", C.c_int64),
+        ("values", C.c_void_p),
+        ("values_bytes", C.c_int64),
+        ("values_bit_offset", C.c_int64),
+        ("validity", C.c_void_p),
+        ("validity_bytes", C.c_int64),
+        ("validity_bit_offset", C.c_int64),
+        ("offsets", C.c_void_p),
+        ("offsets_bytes", C.c_int64),
+        ("flags", C.c_int32),
+    ]
+
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
+
+# every symbol include/arrow_hip.h declares: (restype, argtypes)
+_P = C.c_void_p
+_VIEW = C.POINTER(ArrayView)
+_OUT = C.POINTER(ArrayOut)
+SIGNATURES = {
+    "ah_context_create": (C.c_int32, [C.c_int, C.POINTER(_P)]),
+    "ah_context_destroy": (None, [_P]),
+    "ah_context_set_allocator": (None, [_P, ALLOC_FN, FREE_FN, _P]),
+    "ah_context_set_stream": (None, [_P, _P]),
+    "ah_context_stream": (_P, [_P]),
+    "ah_last_error": (C.c_char_p, [_P]),
+    "ah_array_release": (None, [_P, _OUT]),
+    "ah_version": (C.c_char_p, []),
+    "ah_device_alloc": (C.c_int32, [_P, C.c_size_t, C.POINTER(_P)]),
+    "ah_device_free": (None, [_P, _P]),
+    "ah_memcpy_htod": (C.c_int32, [_P, _P, _P, C.c_size_t]),
+    "ah_memcpy_dtoh": (C.c_int32, [_P, _P, _P, C.c_size_t]),
+    "ah_memset": (C.c_int32, [_P, _P, C.c_int, C.c_size_t]),
+    "ah_synchronize": (C.c_int32, [_P]),
+    "ah_pool_trim": (None, [_P]),
+    "ah_filter": (C.c_int32, [_P, _VIEW, _VIEW, _OUT]),
+    "ah_filter_predicate_build": (C.c_int32, [_P, _VIEW, C.POINTER(_P)]),
+    "ah_filter_predicate_count": (C.c_int64, [_P]),
+    "ah_filter_predicate_apply": (C.c_int32, [_P, _P, _VIEW, _OUT]),
+    "ah_filter_predicate_free": (None, [_P, _P]),
+    "ah_filter_record_batch": (C.c_int32, [_P, C.c_int32, _VIEW, _VIEW, _OUT, C.POINTER(C.c_int64)]),
+    "ah_take": (C.c_int32, [_P, _VIEW, _VIEW, C.c_int32, _OUT]),
+    "ah_arith_binary": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
+    "ah_arith_neg": (C.c_int32, [_P, _VIEW, C.c_int32, _OUT]),
+    "ah_compare": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
+    "ah_cast": (C.c_int32, [_P, _VIEW, C.c_int32, C.c_int32, _OUT]),
+    "ah_can_cast_types": (C.c_int32, [C.c_int32, C.c_int32]),
+    "ah_concat": (C.c_int32, [_P, C.c_int32, _VIEW, _OUT]),
+    "ah_bitmap_set_bits": (C.c_int32, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
+    "ah_count_set_bits": (C.c_int32, [_P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
+    "ah_profile_enable": (None, [_P, C.c_int32]),
+    "ah_profile_reset": (None, [_P]),
+    "ah_profile_get": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ah_gen_uniform_i64": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, C.c_int64]),
+    "ah_gen_uniform_i32": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_int64]),
+    "ah_gen_uniform_f64": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_double, C.c_double, C.c_int64]),
+    "ah_gen_uniform_u32": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_uint32, C.c_int64]),
+    "ah_gen_bernoulli_bits": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_double, C.c_int64]),
+    "ah_zero_null_slots": (C.c_int32, [_P, _P, C.c_int32, _P, C.c_int64]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libarrow_hip.so, binding every declared symbol. Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C arrow-rs_amd/csrc`. There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

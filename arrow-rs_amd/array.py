@@ -1,0 +1,504 @@
+"""Host-side mirror of the reference's array types for arrays living in HBM.
+
+Mirrors (names, argument meaning, error behaviour):
+  * ``ArrowError``            arrow-schema/src/error.rs:26-69
+  * ``DataType``              arrow-schema/src/datatype.rs (only the physical layouts of the hot path)
+  * ``Array`` (PrimitiveArray / BooleanArray / GenericStringArray)
+                              arrow-array/src/array/primitive_array.rs:596-601,
+                              arrow-array/src/array/boolean_array.rs:68
+  * ``Scalar`` / ``Datum``    arrow-array/src/scalar.rs:78-149
+
+Values, validity and offsets are DEVICE buffers; nothing here touches device
+bytes on the host except the explicit ``to_numpy`` / ``to_pylist`` copies.
+"""
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from . import _lib as L
+
+
+class ArrowError(Exception):
+    """ArrowError (arrow-schema/src/error.rs:26-69). ``str()`` == Rust ``Display``."""
+    variant = "ArrowError"
+    prefix = ""
+
+    def __init__(self, message):
+        super().__init__(message)
+        self.message = message
+
+    def __str__(self):
+        return f"{self.prefix}{self.message}"
+
+
+class InvalidArgumentError(ArrowError):
+    variant, prefix = "InvalidArgumentError", "Invalid argument error: "
+
+
+class ComputeError(ArrowError):
+    variant, prefix = "ComputeError", "Compute error: "
+
+
+class ArithmeticOverflow(ArrowError):
+    variant, prefix = "ArithmeticOverflow", "Arithmetic overflow: "
+
+
+class DivideByZero(ArrowError):
+    variant, prefix = "DivideByZero", ""
+
+    def __str__(self):
+        return "Divide by zero error"
+
+
+class CastError(ArrowError):
+    variant, prefix = "CastError", "Cast error: "
+
+
+class NotYetImplemented(ArrowError):
+    variant, prefix = "NotYetImplemented", "Not yet implemented: "
+
+
+class Panic(RuntimeError):
+    """The reference would ``panic!`` here (e.g. out-of-bounds take without
+    check_bounds, take.rs:447,454; offset overflow, generic_bytes_builder.rs:86-87)."""
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_STATUS = {
+    L.AH_INVALID_ARGUMENT: InvalidArgumentError,
+    L.AH_COMPUTE_ERROR: ComputeError,
+    L.AH_ARITHMETIC_OVERFLOW: ArithmeticOverflow,
+    L.AH_DIVIDE_BY_ZERO: DivideByZero,
+    L.AH_CAST_ERROR: CastError,
+    L.AH_NOT_YET_IMPLEMENTED: NotYetImplemented,
+    L.AH_OFFSET_OVERFLOW: Panic,
+    L.AH_PANIC: Panic,
+}
+
+
+def raise_for_status(status, message):
+    if status == L.AH_OK:
+        return
+    exc = _STATUS.get(status)
+    if exc is None:
+        raise HipError(f"status {status}: {message}")
+    raise exc(message)
+
+
+# --------------------------------------------------------------------- types
+class DataType:
+    """Logical type name + physical layout.  Logical types sharing a layout are
+    preserved through filter/take exactly as the reference does
+    (filter.rs:783-787, take.rs:414)."""
+
+    def __init__(self, name, physical, np_dtype):
+        self.name = name
+        self.physical = physical
+        self.np_dtype = np_dtype
+
+    def __eq__(self, other):
+        return isinstance(other, DataType) and self.name == other.name
+
+    def __hash__(self):
+        return hash(self.name)
+
+    def __repr__(self):
+        return self.name
+
+    @property
+    def width(self):
+        return {L.AH_BOOL: 0, L.AH_FIXED16: 16, L.AH_FIXED32: 32}.get(
+            self.physical, np.dtype(self.np_dtype).itemsize if self.np_dtype is not None else -1)
+
+    def is_primitive(self):
+        return self.physical not in (L.AH_BOOL, L.AH_UTF8, L.AH_LARGE_UTF8)
+
+
+Boolean = DataType("Boolean", L.AH_BOOL, np.bool_)
+Int8 = DataType("Int8", L.AH_INT8, np.int8)
+Int16 = DataType("Int16", L.AH_INT16, np.int16)
+Int32 = DataType("Int32", L.AH_INT32, np.int32)
+Int64 = DataType("Int64", L.AH_INT64, np.int64)
+UInt8 = DataType("UInt8", L.AH_UINT8, np.uint8)
+UInt16 = DataType("UInt16", L.AH_UINT16, np.uint16)
+UInt32 = DataType("UInt32", L.AH_UINT32, np.uint32)
+UInt64 = DataType("UInt64", L.AH_UINT64, np.uint64)
+Float16 = DataType("Float16", L.AH_FLOAT16, np.float16)
+Float32 = DataType("Float32", L.AH_FLOAT32, np.float32)
+Float64 = DataType("Float64", L.AH_FLOAT64, np.float64)
+Utf8 = DataType("Utf8", L.AH_UTF8, None)
+LargeUtf8 = DataType("LargeUtf8", L.AH_LARGE_UTF8, None)
+# logical types over the same physical layouts (the 14 temporal types of
+# filter.rs:1090-1174 and the Duration/Decimal128 cases of take.rs:1263-1625)
+Date32 = DataType("Date32", L.AH_INT32, np.int32)
+Date64 = DataType("Date64", L.AH_INT64, np.int64)
+Time32Second = DataType("Time32(Second)", L.AH_INT32, np.int32)
+Time32Millisecond = DataType("Time32(Millisecond)", L.AH_INT32, np.int32)
+Time64Microsecond = DataType("Time64(Microsecond)", L.AH_INT64, np.int64)
+Time64Nanosecond = DataType("Time64(Nanosecond)", L.AH_INT64, np.int64)
+DurationSecond = DataType("Duration(Second)", L.AH_INT64, np.int64)
+DurationMillisecond = DataType("Duration(Millisecond)", L.AH_INT64, np.int64)
+DurationMicrosecond = DataType("Duration(Microsecond)", L.AH_INT64, np.int64)
+DurationNanosecond = DataType("Duration(Nanosecond)", L.AH_INT64, np.int64)
+TimestampSecond = DataType("Timestamp(Second, None)", L.AH_INT64, np.int64)
+TimestampMillisecond = DataType("Timestamp(Millisecond, None)", L.AH_INT64, np.int64)
+TimestampMicrosecond = DataType("Timestamp(Microsecond, None)", L.AH_INT64, np.int64)
+TimestampNanosecond = DataType("Timestamp(Nanosecond, None)", L.AH_INT64, np.int64)
+_DEC128 = np.dtype([("lo", "<u8"), ("hi", "<i8")])
+
+
+def Decimal128(precision, scale):
+    return DataType(f"Decimal128({precision}, {scale})", L.AH_FIXED16, _DEC128)
+
+
+_PHYSICAL_DEFAULT = {
+    L.AH_BOOL: Boolean, L.AH_INT8: Int8, L.AH_INT16: Int16, L.AH_INT32: Int32, L.AH_INT64: Int64,
+    L.AH_UINT8: UInt8, L.AH_UINT16: UInt16, L.AH_UINT32: UInt32, L.AH_UINT64: UInt64,
+    L.AH_FLOAT16: Float16, L.AH_FLOAT32: Float32, L.AH_FLOAT64: Float64,
+    L.AH_UTF8: Utf8, L.AH_LARGE_UTF8: LargeUtf8,
+}
+
+
+# ------------------------------------------------------------------- context
+class Context:
+    """One ah_context (one HIP stream + pooled HBM allocator) on one GPU."""
+
+    def __init__(self, device=0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        st = self.lib.ah_context_create(int(device), C.byref(h))
+        if st != L.AH_OK:
+            raise HipError(
+                f"ah_context_create(device={device}) failed with status {st}: no usable MI355X/HIP "
+                "device. arrow_rs_amd has no CPU fallback.")
+        self.handle = h
+        self.device = device
+        self._finalizer = weakref.finalize(self, self.lib.ah_context_destroy, h)
+
+    def check(self, status):
+        if status != L.AH_OK:
+            raise_for_status(status, self.lib.ah_last_error(self.handle).decode())
+
+    def synchronize(self):
+        self.check(self.lib.ah_synchronize(self.handle))
+
+    # raw buffers
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def profile(self, on=True):
+        self.lib.ah_profile_enable(self.handle, 1 if on else 0)
+
+    def profile_reset(self):
+        self.lib.ah_profile_reset(self.handle)
+
+    def profile_get(self, kernel):
+        ms, n = C.c_double(), C.c_int64()
+        self.check(self.lib.ah_profile_get(self.handle, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def set_default_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+class DeviceBuffer:
+    """An HBM allocation owned through the context pool (the analogue of
+    ``Buffer::from_custom_allocation``, arrow-buffer/src/buffer/immutable.rs:170-176)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        ctx.check(ctx.lib.ah_device_alloc(ctx.handle, max(self.nbytes, 8), C.byref(p)))
+        self.ptr = p.value
+        self._finalizer = weakref.finalize(self, ctx.lib.ah_device_free, ctx.handle, C.c_void_p(self.ptr))
+
+    @classmethod
+    def from_numpy(cls, ctx, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = cls(ctx, arr.nbytes)
+        if arr.nbytes:
+            ctx.check(ctx.lib.ah_memcpy_htod(ctx.handle, buf.ptr, arr.ctypes.data, arr.nbytes))
+        return buf
+
+    def to_numpy(self, dtype=np.uint8, byte_offset=0, count=None):
+        dt = np.dtype(dtype)
+        n = (self.nbytes - byte_offset) // dt.itemsize if count is None else count
+        out = np.empty(n, dtype=dt)
+        if n:
+            self.ctx.check(self.ctx.lib.ah_memcpy_dtoh(self.ctx.handle, out.ctypes.data,
+                                                       self.ptr + byte_offset, n * dt.itemsize))
+        return out
+
+    # zero-copy hand-off to torch (RCCL collectives): __cuda_array_interface__ v2
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2,
+                "strides": None}
+
+
+class _OutOwner:
+    """Keeps an ah_array_out alive; releases its buffers with ah_array_release."""
+
+    def __init__(self, ctx, out, keepalive=()):
+        self.ctx = ctx
+        self.out = out
+        self.keepalive = keepalive  # inputs a BORROWED result aliases
+        self._finalizer = weakref.finalize(self, _release_out, ctx.lib, ctx.handle, out)
+
+
+def _release_out(lib, handle, out):
+    lib.ah_array_release(handle, C.byref(out))
+
+
+class _RawMem:
+    """Pointer + owner pair used by Array (owner: DeviceBuffer | _OutOwner | any keepalive)."""
+    __slots__ = ("ptr", "nbytes", "owner")
+
+    def __init__(self, ptr, nbytes, owner):
+        self.ptr, self.nbytes, self.owner = ptr, nbytes, owner
+
+
+def pack_bits(bools, bit_offset=0):
+    """LSB-first bit packing with a leading bit offset; padded to whole u64 words
+    (BooleanBuffer layout, arrow-buffer/src/buffer/boolean.rs:97-104)."""
+    bools = np.asarray(bools, dtype=bool)
+    total = bit_offset + len(bools)
+    padded = np.zeros(((total + 63) // 64) * 64, dtype=bool)
+    padded[bit_offset:total] = bools
+    return np.packbits(padded, bitorder="little")
+
+
+def unpack_bits(byts, bit_offset, length):
+    bits = np.unpackbits(np.asarray(byts, dtype=np.uint8), bitorder="little")
+    return bits[bit_offset:bit_offset + length].astype(bool)
+
+
+class Array:
+    """A PrimitiveArray<T> / BooleanArray / GenericStringArray whose buffers live in HBM.
+
+    ``values_ptr`` is already advanced by the slice offset for primitives
+    (ScalarBuffer semantics, arrow-buffer/src/buffer/scalar.rs:188-209); boolean
+    values and validity carry bit offsets (BooleanBuffer / NullBuffer)."""
+
+    def __init__(self, ctx, data_type, length, values, values_bit_offset=0, validity=None,
+                 validity_bit_offset=0, null_count=0, offsets=None):
+        self.ctx = ctx
+        self.data_type = data_type
+        self.length = int(length)
+        self.values = values            # _RawMem or None
+        self.values_bit_offset = int(values_bit_offset)
+        self.validity = validity        # _RawMem or None  (None == reference `nulls: None`)
+        self.validity_bit_offset = int(validity_bit_offset)
+        self._null_count = int(null_count)
+        self.offsets = offsets          # _RawMem or None (strings)
+
+    # ---- construction from host data
+    @classmethod
+    def from_numpy(cls, values, valid=None, data_type=None, ctx=None, bit_offset=0):
+        """values: numpy array (bool -> BooleanArray). valid: bool mask (True=valid) or None.
+        bit_offset: leading pad bits for the packed bitmaps (to exercise offsets)."""
+        ctx = ctx or default_context()
+        values = np.asarray(values)
+        if data_type is None:
+            if values.dtype == np.bool_:
+                data_type = Boolean
+            else:
+                data_type = next(dt for dt in _PHYSICAL_DEFAULT.values()
+                                 if dt.np_dtype is not None and np.dtype(dt.np_dtype) == values.dtype
+                                 and dt.physical != L.AH_BOOL)
+        n = len(values)
+        if data_type.physical == L.AH_BOOL:
+            vb = DeviceBuffer.from_numpy(ctx, pack_bits(values.astype(bool), bit_offset))
+            vmem, vbo = _RawMem(vb.ptr, vb.nbytes, vb), bit_offset
+        else:
+            vb = DeviceBuffer.from_numpy(ctx, values.astype(data_type.np_dtype, copy=False))
+            vmem, vbo = _RawMem(vb.ptr, vb.nbytes, vb), 0
+        nmem, nulls = None, 0
+        if valid is not None:
+            valid = np.asarray(valid, dtype=bool)
+            nb = DeviceBuffer.from_numpy(ctx, pack_bits(valid, bit_offset))
+            nmem = _RawMem(nb.ptr, nb.nbytes, nb)
+            nulls = int(n - valid.sum())
+        return cls(ctx, data_type, n, vmem, vbo, nmem, bit_offset if nmem else 0, nulls)
+
+    @classmethod
+    def from_pylist(cls, items, data_type, ctx=None):
+        """``PrimitiveArray::from(vec![Some(1), None, ...])``: null slots hold 0."""
+        has_null = any(x is None for x in items)
+        if data_type.physical == L.AH_BOOL:
+            vals = np.array([bool(x) if x is not None else False for x in items], dtype=bool)
+        else:
+            vals = np.array([x if x is not None else 0 for x in items], dtype=data_type.np_dtype)
+        valid = np.array([x is not None for x in items], dtype=bool) if has_null else None
+        return cls.from_numpy(vals, valid, data_type, ctx)
+
+    @classmethod
+    def _from_out(cls, ctx, out, data_type, keepalive=()):
+        owner = _OutOwner(ctx, out, keepalive)
+        vals = _RawMem(out.values, out.values_bytes, owner) if out.values else None
+        nmem = _RawMem(out.validity, out.validity_bytes, owner) if out.validity else None
+        offs = _RawMem(out.offsets, out.offsets_bytes, owner) if out.offsets else None
+        arr = cls(ctx, data_type, out.length, vals, out.values_bit_offset, nmem,
+                  out.validity_bit_offset, out.null_count, offs)
+        arr._owner = owner
+        return arr
+
+    # ---- reference API surface
+    def __len__(self):
+        return self.length
+
+    def len(self):
+        return self.length
+
+    def is_empty(self):
+        return self.length == 0
+
+    def null_count(self):
+        return self._null_count
+
+    def nulls(self):
+        """``Array::nulls()``: None when the array carries no null buffer."""
+        return self.validity
+
+    def slice(self, offset, length):
+        """``Array::slice`` (zero-copy).  Panics like the reference when out of range."""
+        if offset + length > self.length:
+            raise Panic("the length + offset of the sliced PrimitiveArray cannot exceed the existing length")
+        w = self.data_type.width
+        if self.data_type.physical == L.AH_BOOL:
+            vals, vbo = self.values, self.values_bit_offset + offset
+        elif self.values is None:
+            vals, vbo = None, 0
+        else:
+            vals = _RawMem(self.values.ptr + offset * w, length * w, self.values.owner)
+            vbo = 0
+        nulls = 0
+        if self.validity is not None:
+            cnt = C.c_int64()
+            self.ctx.check(self.ctx.lib.ah_count_set_bits(self.ctx.handle, self.validity.ptr,
+                                                          self.validity_bit_offset + offset, length,
+                                                          C.byref(cnt)))
+            nulls = length - cnt.value
+        return Array(self.ctx, self.data_type, length, vals, vbo, self.validity,
+                     self.validity_bit_offset + offset if self.validity else 0, nulls)
+
+    def view(self):
+        """The ah_array_view handed to the C ABI."""
+        v = L.ArrayView()
+        v.type = self.data_type.physical
+        v.length = self.length
+        v.null_count = self._null_count if self.validity is not None else 0
+        v.values = self.values.ptr if self.values is not None else None
+        v.values_bit_offset = self.values_bit_offset
+        v.validity = self.validity.ptr if self.validity is not None else None
+        v.validity_bit_offset = self.validity_bit_offset
+        return v
+
+    # Datum::get (arrow-array/src/scalar.rs:78-98)
+    def get(self):
+        return self, False
+
+    # ---- host copies (tests / debugging only)
+    def valid_mask(self):
+        """numpy bool mask (True = valid), all-True when there is no null buffer."""
+        if self.validity is None or self.length == 0:
+            return np.ones(self.length, dtype=bool)
+        first = self.validity_bit_offset // 8
+        nbytes = (self.validity_bit_offset % 8 + self.length + 7) // 8
+        raw = _copy_dtoh(self.ctx, self.validity.ptr + first, nbytes)
+        return unpack_bits(raw, self.validity_bit_offset % 8, self.length)
+
+    def values_numpy(self):
+        if self.length == 0:
+            if self.data_type.physical in (L.AH_UTF8, L.AH_LARGE_UTF8):
+                return []
+            return np.empty(0, dtype=self.data_type.np_dtype)
+        p = self.data_type.physical
+        if p == L.AH_BOOL:
+            first = self.values_bit_offset // 8
+            nbytes = (self.values_bit_offset % 8 + self.length + 7) // 8
+            raw = _copy_dtoh(self.ctx, self.values.ptr + first, nbytes)
+            return unpack_bits(raw, self.values_bit_offset % 8, self.length)
+        if p in (L.AH_UTF8, L.AH_LARGE_UTF8):
+            odt = np.int32 if p == L.AH_UTF8 else np.int64
+            offs = _copy_dtoh(self.ctx, self.offsets.ptr, (self.length + 1) * np.dtype(odt).itemsize).view(odt)
+            total = int(offs[-1])
+            data = _copy_dtoh(self.ctx, self.values.ptr, total).tobytes() if total else b""
+            return [data[offs[i]:offs[i + 1]].decode() for i in range(self.length)]
+        w = self.data_type.width
+        raw = _copy_dtoh(self.ctx, self.values.ptr, self.length * w)
+        return raw.view(self.data_type.np_dtype)
+
+    def to_pylist(self):
+        vals = self.values_numpy()
+        mask = self.valid_mask()
+        out = []
+        for i in range(self.length):
+            if not mask[i]:
+                out.append(None)
+            else:
+                v = vals[i]
+                out.append(v.item() if hasattr(v, "item") and self.data_type.np_dtype is not _DEC128 else v)
+        return out
+
+    def __repr__(self):
+        return f"Array<{self.data_type}>(len={self.length}, nulls={self._null_count})"
+
+
+def _copy_dtoh(ctx, ptr, nbytes):
+    out = np.empty(nbytes, dtype=np.uint8)
+    if nbytes:
+        ctx.check(ctx.lib.ah_memcpy_dtoh(ctx.handle, out.ctypes.data, ptr, nbytes))
+    return out
+
+
+class Scalar:
+    """``Scalar<T>``: a length-1 array used as a broadcast Datum
+    (arrow-array/src/scalar.rs:128-152)."""
+
+    def __init__(self, array):
+        assert array.length == 1
+        self.array = array
+
+    @classmethod
+    def new(cls, value, data_type, ctx=None):
+        """``PrimitiveArray::new_scalar(v)`` (primitive_array.rs:694-700); None -> null scalar."""
+        return cls(Array.from_pylist([value], data_type, ctx))
+
+    def get(self):
+        return self.array, True
+
+
+class RecordBatch:
+    """Minimal RecordBatch (arrow-array/src/record_batch.rs:224): named columns of equal length."""
+
+    def __init__(self, names, columns, num_rows=None):
+        self.names = list(names)
+        self.columns = list(columns)
+        self._num_rows = num_rows if num_rows is not None else (columns[0].length if columns else 0)
+
+    def num_rows(self):
+        return self._num_rows
+
+    def num_columns(self):
+        return len(self.columns)
+
+    def column(self, i):
+        return self.columns[i]

@@ -1,0 +1,10 @@
+"""arrow::compute (arrow/src/compute/mod.rs:22-40): kernels flattened."""
+from . import kernels  # noqa: F401
+from .kernels.filter import (filter, filter_record_batch, prep_null_mask_filter, FilterBuilder,  # noqa: F401
+                             FilterPredicate)
+from .kernels.take import take, take_arrays, take_record_batch, TakeOptions  # noqa: F401
+from .kernels.numeric import (add, add_wrapping, sub, sub_wrapping, mul, mul_wrapping, div, rem,  # noqa: F401
+                              neg, neg_wrapping)
+from .kernels.cmp import eq, neq, lt, lt_eq, gt, gt_eq, distinct, not_distinct  # noqa: F401
+from .kernels.cast import cast, cast_with_options, can_cast_types, CastOptions  # noqa: F401
+from .kernels.concat import concat  # noqa: F401

@@ -1,0 +1,455 @@
+// arith.hip — arrow_arith::numeric on MI355X.
+//
+// Reference path: add/add_wrapping/... (arrow-arith/src/numeric.rs:36-81) ->
+// arithmetic_op :225 -> integer_op :328 / float_op :357 -> op!/try_op! :278-317
+// -> arity::binary (arity.rs:104-135: every slot evaluated, nulls =
+// NullBuffer::union) or arity::try_binary (arity.rs:254-299: valid slots only,
+// zero elsewhere, first error aborts) / PrimitiveArray::{unary,try_unary}.
+//
+// MI355X design: the validity union is a separate word-parallel bitmap kernel
+// (1.5% of the bytes) that also yields null_count; the value kernel is a pure
+// 16-byte-per-lane stream (HBM roofline: 3 x width bytes per row).  Checked ops
+// read the freshly produced union words (offset 0) to skip null slots and report
+// the first failing row through atomicMin so the host can reproduce the
+// reference's error text ("Overflow happened on: l op r", "Divide by zero error").
+#include "common.hpp"
+
+#include <limits>
+#include <type_traits>
+
+namespace {
+
+enum { OP_ADD = 0, OP_ADD_W, OP_SUB, OP_SUB_W, OP_MUL, OP_MUL_W, OP_DIV, OP_REM, OP_NEG, OP_NEG_W };
+
+const char* op_sym(int op) {  // Display for Op (numeric.rs:203-213)
+  switch (op) {
+    case OP_ADD: case OP_ADD_W: return "+";
+    case OP_SUB: case OP_SUB_W: return "-";
+    case OP_MUL: case OP_MUL_W: return "*";
+    case OP_DIV: return "/";
+    default: return "%";
+  }
+}
+
+// element semantics: ArrowNativeTypeOp (arrow-array/src/arithmetic.rs:147-430)
+template <typename T, int OP>
+__device__ __forceinline__ bool apply(T l, T r, T* out) {  // returns false on error
+  if constexpr (std::is_floating_point<T>::value) {
+    if constexpr (OP == OP_ADD || OP == OP_ADD_W) *out = l + r;
+    else if constexpr (OP == OP_SUB || OP == OP_SUB_W) *out = l - r;
+    else if constexpr (OP == OP_MUL || OP == OP_MUL_W) *out = l * r;
+    else if constexpr (OP == OP_DIV) *out = l / r;
+    else if constexpr (OP == OP_REM) *out = fmod(l, r);
+    else *out = -l;
+    return true;
+  } else {
+    using U = typename std::make_unsigned<T>::type;
+    if constexpr (OP == OP_ADD) return !__builtin_add_overflow(l, r, out);
+    else if constexpr (OP == OP_SUB) return !__builtin_sub_overflow(l, r, out);
+    else if constexpr (OP == OP_MUL) return !__builtin_mul_overflow(l, r, out);
+    else if constexpr (OP == OP_ADD_W) { *out = (T)((U)l + (U)r); return true; }
+    else if constexpr (OP == OP_SUB_W) { *out = (T)((U)l - (U)r); return true; }
+    else if constexpr (OP == OP_MUL_W) { *out = (T)((U)l * (U)r); return true; }
+    else if constexpr (OP == OP_DIV) {
+      if (r == 0) return false;
+      if (std::is_signed<T>::value && l == std::numeric_limits<T>::min() && r == (T)-1) return false;
+      *out = (T)(l / r);
+      return true;
+    } else if constexpr (OP == OP_REM) {  // numeric.rs:345-351
+      if (r == 0) return false;
+      if (std::is_signed<T>::value && r == (T)-1) *out = 0;
+      else *out = (T)(l % r);
+      return true;
+    } else if constexpr (OP == OP_NEG) {
+      if (std::is_signed<T>::value && l == std::numeric_limits<T>::min()) return false;
+      *out = (T)(0 - (U)l);
+      return true;
+    } else {  // OP_NEG_W
+      *out = (T)(0 - (U)l);
+      return true;
+    }
+  }
+}
+
+template <typename T, int V> struct alignas(sizeof(T) * V) VecT { T e[V]; };
+
+struct ArithArgs {
+  const void* l;
+  const void* r;
+  void* out;
+  int64_t len;
+  int l_scalar, r_scalar;
+  const unsigned long long* valid;  // union words (offset 0) for checked ops, else nullptr
+  unsigned long long* first_err;
+};
+
+// CHECKED: evaluate valid slots only, zero elsewhere (try_binary / try_unary)
+template <typename T, int OP, int V, bool CHECKED>
+__global__ void __launch_bounds__(256) arith_kernel(ArithArgs a) {
+  using VT = VecT<T, V>;
+  const T* lp = (const T*)a.l;
+  const T* rp = (const T*)a.r;
+  T* op = (T*)a.out;
+  T ls = a.l_scalar ? lp[0] : T{};
+  T rs = a.r_scalar ? rp[0] : T{};
+  unsigned long long err = ~0ull;
+  const int64_t nvec = (a.len + V - 1) / V;
+  constexpr int U = 4;
+  for (int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 1; base < nvec;
+       base += (int64_t)gridDim.x * 256 * U) {
+    VT lv[U], rv[U];
+    // issue all loads of the unrolled group first
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t vi = base + (int64_t)u * gridDim.x * 256;
+      if (vi < nvec) {
+        int64_t i = vi * V;
+        if (i + V <= a.len) {
+          if (!a.l_scalar) lv[u] = *(const VT*)(lp + i);
+          if (OP < OP_NEG && !a.r_scalar) rv[u] = *(const VT*)(rp + i);
+        } else {
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            lv[u].e[e] = (!a.l_scalar && i + e < a.len) ? lp[i + e] : T{};
+            rv[u].e[e] = (OP < OP_NEG && !a.r_scalar && i + e < a.len) ? rp[i + e] : T{};
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t vi = base + (int64_t)u * gridDim.x * 256;
+      if (vi >= nvec) continue;
+      int64_t i = vi * V;
+      VT ov;
+      uint32_t vbits = 0xFFFFFFFFu;
+      if constexpr (CHECKED) {
+        if (a.valid) vbits = (uint32_t)(a.valid[i >> 6] >> (i & 63));
+      }
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        T x = a.l_scalar ? ls : lv[u].e[e];
+        T y = a.r_scalar ? rs : rv[u].e[e];
+        T o = T{};
+        if (!CHECKED || ((vbits >> e) & 1u)) {
+          bool ok = apply<T, OP>(x, y, &o);
+          if (CHECKED && !ok && i + e < a.len) {
+            unsigned long long pos = (unsigned long long)(i + e);
+            err = pos < err ? pos : err;
+            o = T{};
+          }
+        }
+        ov.e[e] = o;
+      }
+      if (i + V <= a.len) *(VT*)(op + i) = ov;
+      else
+        for (int e = 0; e < V; ++e) if (i + e < a.len) op[i + e] = ov.e[e];
+    }
+  }
+  if constexpr (CHECKED) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long other = __shfl_xor(err, o, 64);
+      err = other < err ? other : err;
+    }
+    if ((threadIdx.x & 63) == 0 && err != ~0ull) atomicMin(a.first_err, err);
+  }
+}
+
+template <typename T, int OP, bool CHECKED>
+void launch_arith_op(ah_context* ctx, const ArithArgs& a, bool aligned) {
+  constexpr int V = 16 / sizeof(T);
+  int64_t nvec = ah_ceil_div(a.len, aligned ? V : 1);
+  int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(nvec, 256 * 4), 256 * 8));
+  if (aligned) arith_kernel<T, OP, V, CHECKED><<<grid, 256, 0, ctx->stream>>>(a);
+  else arith_kernel<T, OP, 1, CHECKED><<<grid, 256, 0, ctx->stream>>>(a);
+}
+
+template <typename T>
+void launch_arith(ah_context* ctx, int op, const ArithArgs& a, bool aligned) {
+  constexpr bool F = std::is_floating_point<T>::value;
+  switch (op) {
+    case OP_ADD: launch_arith_op<T, OP_ADD, !F>(ctx, a, aligned); break;
+    case OP_ADD_W: launch_arith_op<T, OP_ADD_W, false>(ctx, a, aligned); break;
+    case OP_SUB: launch_arith_op<T, OP_SUB, !F>(ctx, a, aligned); break;
+    case OP_SUB_W: launch_arith_op<T, OP_SUB_W, false>(ctx, a, aligned); break;
+    case OP_MUL: launch_arith_op<T, OP_MUL, !F>(ctx, a, aligned); break;
+    case OP_MUL_W: launch_arith_op<T, OP_MUL_W, false>(ctx, a, aligned); break;
+    case OP_DIV: launch_arith_op<T, OP_DIV, !F>(ctx, a, aligned); break;
+    case OP_REM: launch_arith_op<T, OP_REM, !F>(ctx, a, aligned); break;
+    case OP_NEG: launch_arith_op<T, OP_NEG, !F>(ctx, a, aligned); break;
+    default: launch_arith_op<T, OP_NEG_W, false>(ctx, a, aligned); break;
+  }
+}
+
+ah_status dispatch_type(ah_context* ctx, ah_type t, int op, const ArithArgs& a, bool aligned) {
+  switch (t) {
+    case AH_INT8: launch_arith<int8_t>(ctx, op, a, aligned); break;
+    case AH_INT16: launch_arith<int16_t>(ctx, op, a, aligned); break;
+    case AH_INT32: launch_arith<int32_t>(ctx, op, a, aligned); break;
+    case AH_INT64: launch_arith<int64_t>(ctx, op, a, aligned); break;
+    case AH_UINT8: launch_arith<uint8_t>(ctx, op, a, aligned); break;
+    case AH_UINT16: launch_arith<uint16_t>(ctx, op, a, aligned); break;
+    case AH_UINT32: launch_arith<uint32_t>(ctx, op, a, aligned); break;
+    case AH_UINT64: launch_arith<uint64_t>(ctx, op, a, aligned); break;
+    case AH_FLOAT32: launch_arith<float>(ctx, op, a, aligned); break;
+    case AH_FLOAT64: launch_arith<double>(ctx, op, a, aligned); break;
+    default: return ah_fail(ctx, AH_INVALID_ARGUMENT, "unsupported arithmetic type");
+  }
+  return AH_OK;
+}
+
+bool op_checked_for(ah_type t, int op) {
+  if (ah_type_is_float(t)) return false;
+  return op == OP_ADD || op == OP_SUB || op == OP_MUL || op == OP_DIV || op == OP_REM || op == OP_NEG;
+}
+
+// read one element as i128-ish text for the error message ({:?} of a Rust int)
+ah_status read_elem_text(ah_context* ctx, ah_type t, const void* base, int64_t idx, char* buf,
+                         size_t n, bool* is_zero) {
+  int w = ah_type_width(t);
+  uint64_t raw = 0;
+  AH_HIP(ctx, hipMemcpyAsync(&raw, (const char*)base + idx * w, w, hipMemcpyDeviceToHost, ctx->stream));
+  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *is_zero = raw == 0;
+  switch (t) {
+    case AH_INT8: snprintf(buf, n, "%d", (int)(int8_t)raw); break;
+    case AH_INT16: snprintf(buf, n, "%d", (int)(int16_t)raw); break;
+    case AH_INT32: snprintf(buf, n, "%d", (int)(int32_t)raw); break;
+    case AH_INT64: snprintf(buf, n, "%lld", (long long)(int64_t)raw); break;
+    default: snprintf(buf, n, "%llu", (unsigned long long)raw); break;
+  }
+  return AH_OK;
+}
+
+void free_out_bufs(ah_context* ctx, void* ov, size_t vbytes, void* ob, size_t bbytes) {
+  ah_out_free(ctx, ov, vbytes);
+  ah_out_free(ctx, ob, bbytes);
+}
+
+}  // namespace
+
+extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_array_view* lhs,
+                                     int32_t l_s, const ah_array_view* rhs, int32_t r_s,
+                                     ah_array_out* out) {
+  if (!ctx || !lhs || !rhs || !out) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  hipSetDevice(ctx->device);
+  if (op < AH_ADD || op > AH_REM) return ah_fail(ctx, AH_INVALID_ARGUMENT, "unknown arithmetic op %d", op);
+  const ah_type t = lhs->type;
+  // arithmetic_op (numeric.rs:225-275): both sides must be the same numeric type
+  if (lhs->type != rhs->type || !(ah_type_is_integer(t) || ah_type_is_float(t)))
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "Invalid arithmetic operation: %s %s %s",
+                   ah_type_name(lhs->type), op_sym(op), ah_type_name(rhs->type));
+  const bool checked = op_checked_for(t, op);
+  const int w = ah_type_width(t);
+  out->type = t;
+  l_s = l_s != 0;
+  r_s = r_s != 0;
+
+  int64_t len;
+  BitView va{nullptr, 0}, vb{nullptr, 0};
+  bool want_valid = false, all_null = false;
+  if (l_s == r_s) {
+    // binary (arity.rs:115-123) / try_binary (:264-271)
+    if (lhs->length != rhs->length)
+      return ah_fail(ctx, AH_COMPUTE_ERROR,
+                     checked ? "Cannot perform a binary operation on arrays of different length"
+                             : "Cannot perform binary operation on arrays of different length");
+    len = lhs->length;
+    if (len == 0) return AH_OK;
+    bool lp = lhs->validity != nullptr, rp = rhs->validity != nullptr;
+    if (checked) {  // is_nullable(): null_count != 0 (arity.rs:279)
+      int64_t ln = 0, rn = 0;
+      AH_TRY(ah_resolve_null_count(ctx, lhs, &ln));
+      AH_TRY(ah_resolve_null_count(ctx, rhs, &rn));
+      want_valid = (ln != 0 || rn != 0);
+    } else {
+      want_valid = lp || rp;  // NullBuffer::union is presence-based (null.rs:79-88)
+    }
+    if (want_valid) {
+      if (lp) va = make_bitview(lhs->validity, lhs->validity_bit_offset);
+      if (rp) vb = make_bitview(rhs->validity, rhs->validity_bit_offset);
+    }
+  } else {
+    // op!/try_op! with one scalar side (numeric.rs:278-317)
+    const ah_array_view* arr = l_s ? rhs : lhs;
+    const ah_array_view* sc = l_s ? lhs : rhs;
+    len = arr->length;
+    int64_t sn = 0;
+    AH_TRY(ah_resolve_null_count(ctx, sc, &sn));
+    if (sc->length < 1) return ah_fail(ctx, AH_INVALID_ARGUMENT, "scalar datum must have length 1");
+    if (sn != 0) all_null = true;  // PrimitiveArray::new_null(len)
+    else if (arr->validity) {
+      want_valid = true;  // nulls cloned (unary / try_unary)
+      va = make_bitview(arr->validity, arr->validity_bit_offset);
+    }
+  }
+
+  size_t vbytes = (size_t)len * w, bbytes = ah_bitmap_bytes(len);
+  void* ov = nullptr;
+  void* ob = nullptr;
+  AH_TRY(ah_out_alloc(ctx, vbytes, &ov));
+  if (all_null) {
+    ah_status st = ah_out_alloc(ctx, bbytes, &ob);
+    if (st != AH_OK) {
+      ah_out_free(ctx, ov, vbytes);
+      return st;
+    }
+    hipMemsetAsync(ov, 0, vbytes, ctx->stream);
+    hipMemsetAsync(ob, 0, bbytes, ctx->stream);
+    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->length = len;
+    out->values = ov;
+    out->values_bytes = (int64_t)vbytes;
+    out->validity = (uint8_t*)ob;
+    out->validity_bytes = (int64_t)bbytes;
+    out->null_count = len;
+    return AH_OK;
+  }
+  int64_t set_bits = len;
+  if (want_valid) {
+    ah_status st = ah_out_alloc(ctx, bbytes, &ob);
+    if (st == AH_OK)
+      st = ah_bitmap_op(ctx, (va.words && vb.words) ? BM_AND : BM_COPY, va.words ? va : vb, vb,
+                        BitView{nullptr, 0}, len, (unsigned long long*)ob, &set_bits);
+    if (st != AH_OK) {
+      free_out_bufs(ctx, ov, vbytes, ob, bbytes);
+      return st;
+    }
+  }
+  unsigned long long* first_err = nullptr;
+  if (checked) {
+    ah_status st = ah_pool_alloc(ctx, 8, (void**)&first_err);
+    if (st != AH_OK) {
+      free_out_bufs(ctx, ov, vbytes, ob, bbytes);
+      return st;
+    }
+    hipMemsetAsync(first_err, 0xFF, 8, ctx->stream);
+  }
+  ArithArgs a{};
+  a.l = lhs->values;
+  a.r = rhs->values;
+  a.out = ov;
+  a.len = len;
+  a.l_scalar = (l_s != r_s) && l_s;
+  a.r_scalar = (l_s != r_s) && r_s;
+  a.valid = checked ? (const unsigned long long*)ob : nullptr;
+  a.first_err = first_err;
+  bool aligned = ((((uintptr_t)a.l) | ((uintptr_t)a.r) | ((uintptr_t)ov)) & 15) == 0;
+  if (a.l_scalar) aligned = ((((uintptr_t)a.r) | ((uintptr_t)ov)) & 15) == 0;
+  if (a.r_scalar) aligned = ((((uintptr_t)a.l) | ((uintptr_t)ov)) & 15) == 0;
+  ah_status st;
+  {
+    ah_prof_scope ps(ctx, "arith_binary");
+    st = dispatch_type(ctx, t, op, a, aligned);
+  }
+  hipError_t e = hipGetLastError();
+  if (st == AH_OK && e == hipSuccess && checked)
+    e = hipMemcpyAsync(ctx->pinned, first_err, 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  ah_pool_free(ctx, first_err);
+  if (st != AH_OK || e != hipSuccess) {
+    free_out_bufs(ctx, ov, vbytes, ob, bbytes);
+    if (st != AH_OK) return st;
+    return ah_fail(ctx, AH_HIP_ERROR, "arithmetic kernel failed: %s", hipGetErrorString(e));
+  }
+  if (checked && ctx->pinned[0] != ~0ull) {
+    int64_t pos = (int64_t)ctx->pinned[0];
+    free_out_bufs(ctx, ov, vbytes, ob, bbytes);
+    char lt[32], rt[32];
+    bool lz, rz;
+    AH_TRY(read_elem_text(ctx, t, lhs->values, a.l_scalar ? 0 : pos, lt, sizeof lt, &lz));
+    AH_TRY(read_elem_text(ctx, t, rhs->values, a.r_scalar ? 0 : pos, rt, sizeof rt, &rz));
+    if ((op == AH_DIV || op == AH_REM) && rz) return ah_fail(ctx, AH_DIVIDE_BY_ZERO, "Divide by zero error");
+    return ah_fail(ctx, AH_ARITHMETIC_OVERFLOW, "Overflow happened on: %s %s %s", lt, op_sym(op), rt);
+  }
+  out->length = len;
+  out->values = ov;
+  out->values_bytes = (int64_t)vbytes;
+  if (want_valid) {
+    out->validity = (uint8_t*)ob;
+    out->validity_bytes = (int64_t)bbytes;
+    out->null_count = len - set_bits;
+  }
+  return AH_OK;
+}
+
+extern "C" ah_status ah_arith_neg(ah_context* ctx, const ah_array_view* v, int32_t wrapping,
+                                  ah_array_out* out) {
+  if (!ctx || !v || !out) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  hipSetDevice(ctx->device);
+  const ah_type t = v->type;
+  // neg (numeric.rs:103-178): signed ints (checked) and floats; neg_wrapping
+  // (:181-186): every integer and float
+  bool ok = ah_type_is_float(t) || ah_type_is_signed(t) || (wrapping && ah_type_is_integer(t));
+  if (!ok)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "Invalid arithmetic operation: !%s", ah_type_name(t));
+  const int op = wrapping ? OP_NEG_W : OP_NEG;
+  const bool checked = op_checked_for(t, op);
+  const int w = ah_type_width(t);
+  const int64_t len = v->length;
+  out->type = t;
+  out->length = len;
+  if (len == 0) return AH_OK;
+  size_t vbytes = (size_t)len * w, bbytes = ah_bitmap_bytes(len);
+  void* ov = nullptr;
+  void* ob = nullptr;
+  AH_TRY(ah_out_alloc(ctx, vbytes, &ov));
+  int64_t set_bits = len;
+  if (v->validity) {
+    ah_status st = ah_out_alloc(ctx, bbytes, &ob);
+    if (st == AH_OK)
+      st = ah_bitmap_op(ctx, BM_COPY, make_bitview(v->validity, v->validity_bit_offset),
+                        BitView{nullptr, 0}, BitView{nullptr, 0}, len, (unsigned long long*)ob, &set_bits);
+    if (st != AH_OK) {
+      free_out_bufs(ctx, ov, vbytes, ob, bbytes);
+      return st;
+    }
+  }
+  unsigned long long* first_err = nullptr;
+  if (checked) {
+    ah_status st = ah_pool_alloc(ctx, 8, (void**)&first_err);
+    if (st != AH_OK) {
+      free_out_bufs(ctx, ov, vbytes, ob, bbytes);
+      return st;
+    }
+    hipMemsetAsync(first_err, 0xFF, 8, ctx->stream);
+  }
+  ArithArgs a{};
+  a.l = v->values;
+  a.r = v->values;
+  a.out = ov;
+  a.len = len;
+  a.valid = checked ? (const unsigned long long*)ob : nullptr;
+  a.first_err = first_err;
+  bool aligned = ((((uintptr_t)a.l) | ((uintptr_t)ov)) & 15) == 0;
+  ah_status st = dispatch_type(ctx, t, op, a, aligned);
+  hipError_t e = hipGetLastError();
+  if (st == AH_OK && e == hipSuccess && checked)
+    e = hipMemcpyAsync(ctx->pinned, first_err, 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  ah_pool_free(ctx, first_err);
+  if (st != AH_OK || e != hipSuccess) {
+    free_out_bufs(ctx, ov, vbytes, ob, bbytes);
+    if (st != AH_OK) return st;
+    return ah_fail(ctx, AH_HIP_ERROR, "neg kernel failed: %s", hipGetErrorString(e));
+  }
+  if (checked && ctx->pinned[0] != ~0ull) {
+    int64_t pos = (int64_t)ctx->pinned[0];
+    free_out_bufs(ctx, ov, vbytes, ob, bbytes);
+    char lt[32];
+    bool lz;
+    AH_TRY(read_elem_text(ctx, t, v->values, pos, lt, sizeof lt, &lz));
+    return ah_fail(ctx, AH_ARITHMETIC_OVERFLOW, "Overflow happened on: - %s", lt);
+  }
+  out->values = ov;
+  out->values_bytes = (int64_t)vbytes;
+  if (v->validity) {
+    out->validity = (uint8_t*)ob;
+    out->validity_bytes = (int64_t)bbytes;
+    out->null_count = len - set_bits;
+  }
+  return AH_OK;
+}

@@ -1,0 +1,344 @@
+// cast.hip — arrow_cast::cast on MI355X: numeric <-> numeric.
+//
+// Reference path: cast_with_options (arrow-cast/src/cast/mod.rs:790) numeric arms
+// :1578-1697 -> cast_numeric_arrays :2550-2571 -> safe: numeric_cast :2606 ->
+// PrimitiveArray::unary_opt (arrow-array/src/array/primitive_array.rs:1065-1102:
+// valid slots only, null slots 0, failed conversions become null, ALWAYS a null
+// buffer) / unsafe: try_numeric_cast :2575 -> try_unary (:990-1016: nulls cloned,
+// first failure -> CastError "Can't cast value {v:?} to type {T}").
+// num_cast == num_traits::cast (num-traits 0.2.19): int->float `as`; float->int
+// succeeds iff trunc(v) is representable; int->int range-checked.
+//
+// MI355X design: lane-per-row, 4 independent rows in flight per lane; a wave's
+// validity word is in_valid & __ballot(ok), so the output bitmap and null_count
+// come for free.  String casts live in cast_string.hip.
+#include "common.hpp"
+
+#include <charconv>
+#include <cmath>
+#include <limits>
+#include <type_traits>
+
+ah_status ah_cast_to_string(ah_context* ctx, const ah_array_view* values, ah_type to_type,
+                            ah_array_out* out);  // cast_string.hip
+
+namespace {
+
+template <typename I, typename O>
+__device__ __forceinline__ bool num_cast(I v, O* out) {
+  if constexpr (std::is_floating_point<O>::value) {
+    *out = (O)v;
+    return true;
+  } else if constexpr (std::is_floating_point<I>::value) {
+    I t = trunc(v);  // NaN fails both comparisons
+    constexpr int bits = sizeof(O) * 8 - (std::is_signed<O>::value ? 1 : 0);
+    const I hi = (I)ldexp(1.0, bits);  // 2^bits, exact in f32/f64
+    const I lo = std::is_signed<O>::value ? -hi : (I)0;
+    if (!(t >= lo && t < hi)) return false;
+    *out = (O)t;
+    return true;
+  } else {
+    if constexpr (std::is_signed<I>::value && !std::is_signed<O>::value) {
+      if (v < 0) return false;
+      using UI = typename std::make_unsigned<I>::type;
+      if (sizeof(I) > sizeof(O) && (UI)v > (UI)std::numeric_limits<O>::max()) return false;
+    } else if constexpr (!std::is_signed<I>::value && std::is_signed<O>::value) {
+      using UO = typename std::make_unsigned<O>::type;
+      if (sizeof(I) >= sizeof(O) && v > (I)(UO)std::numeric_limits<O>::max()) return false;
+    } else if constexpr (sizeof(I) > sizeof(O)) {
+      if (v < (I)std::numeric_limits<O>::min() || v > (I)std::numeric_limits<O>::max()) return false;
+    }
+    *out = (O)v;
+    return true;
+  }
+}
+
+struct CastArgs {
+  const void* in;
+  void* out;
+  BitView in_valid;  // words == nullptr: all valid
+  int64_t len;
+  unsigned long long* out_valid;    // nullptr: none
+  unsigned long long* block_valid;  // per-block valid counts (when out_valid)
+  unsigned long long* first_err;    // unsafe mode
+  int safe;
+};
+
+template <typename I, typename O>
+__global__ void __launch_bounds__(256) cast_kernel(CastArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const I* ip = (const I*)a.in;
+  O* op = (O*)a.out;
+  unsigned long long nvalid = 0, err = ~0ull;
+  for (int64_t base = (int64_t)blockIdx.x * 1024; base < a.len; base += (int64_t)gridDim.x * 1024) {
+    const int64_t wbase = base + wave * 256;
+    I v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int64_t i = wbase + k * 64 + lane;
+      v[k] = i < a.len ? ip[i] : I{};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int64_t i0 = wbase + k * 64;
+      if (i0 >= a.len) break;
+      int64_t i = i0 + lane;
+      uint64_t iv = bv_fetch64(a.in_valid, i0, a.len);
+      bool valid = (iv >> lane) & 1;
+      O o = O{};
+      bool ok = true;
+      if (valid) ok = num_cast<I, O>(v[k], &o);  // valid slots only; null slots stay 0
+      if (!ok) {
+        o = O{};
+        if (!a.safe) {
+          unsigned long long pos = (unsigned long long)i;
+          err = pos < err ? pos : err;
+        }
+      }
+      if (i < a.len) op[i] = o;
+      if (a.out_valid) {
+        uint64_t w = a.safe ? (iv & __ballot(ok)) : iv;
+        if (lane == 0) {
+          a.out_valid[i0 >> 6] = w;
+          nvalid += __popcll(w);
+        }
+      }
+    }
+  }
+  if (!a.safe) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long other = __shfl_xor(err, o, 64);
+      err = other < err ? other : err;
+    }
+    if (lane == 0 && err != ~0ull) atomicMin(a.first_err, err);
+  }
+  if (a.out_valid) {
+    __shared__ unsigned long long s[4];
+    if (lane == 0) s[wave] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) a.block_valid[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+  }
+}
+
+__global__ void __launch_bounds__(1024) cast_sum_kernel(const unsigned long long* in, int64_t n,
+                                                        unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) acc += in[i];
+  acc = wave_reduce_add64(acc);
+  __shared__ unsigned long long s[16];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int i = 0; i < 16; i++) t += s[i];
+    *out = t;
+  }
+}
+
+template <typename I>
+ah_status launch_from(ah_context* ctx, ah_type to, const CastArgs& a, int grid) {
+  switch (to) {
+    case AH_INT8: cast_kernel<I, int8_t><<<grid, 256, 0, ctx->stream>>>(a); break;
+    case AH_INT16: cast_kernel<I, int16_t><<<grid, 256, 0, ctx->stream>>>(a); break;
+    case AH_INT32: cast_kernel<I, int32_t><<<grid, 256, 0, ctx->stream>>>(a); break;
+    case AH_INT64: cast_kernel<I, int64_t><<<grid, 256, 0, ctx->stream>>>(a); break;
+    case AH_UINT8: cast_kernel<I, uint8_t><<<grid, 256, 0, ctx->stream>>>(a); break;
+    case AH_UINT16: cast_kernel<I, uint16_t><<<grid, 256, 0, ctx->stream>>>(a); break;
+    case AH_UINT32: cast_kernel<I, uint32_t><<<grid, 256, 0, ctx->stream>>>(a); break;
+    case AH_UINT64: cast_kernel<I, uint64_t><<<grid, 256, 0, ctx->stream>>>(a); break;
+    case AH_FLOAT32: cast_kernel<I, float><<<grid, 256, 0, ctx->stream>>>(a); break;
+    case AH_FLOAT64: cast_kernel<I, double><<<grid, 256, 0, ctx->stream>>>(a); break;
+    default: return ah_fail(ctx, AH_CAST_ERROR, "unsupported cast target");
+  }
+  return AH_OK;
+}
+
+bool is_numeric(ah_type t) { return ah_type_is_integer(t) || ah_type_is_float(t); }
+
+// Rust `{:?}` of a float (core::fmt float_to_general_debug): shortest digits,
+// exponential iff |v| >= 1e16 or 0 < |v| < 1e-4.  Host-side, error text only.
+template <typename F>
+std::string rust_debug_float(F v) {
+  if (v != v) return "NaN";
+  if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+  std::string s;
+  if (std::signbit(v)) s += '-';
+  if (v == 0) return s + "0.0";
+  char sci[64];
+  auto res = std::to_chars(sci, sci + sizeof sci, std::fabs(v), std::chars_format::scientific);
+  *res.ptr = 0;
+  std::string digits;
+  const char* p = sci;
+  for (; *p && *p != 'e'; ++p) if (*p != '.') digits += *p;
+  int exp10 = atoi(p + 1);
+  int nd = (int)digits.size();
+  int kk = exp10 + 1;
+  if (kk >= 17 || kk <= -4) {
+    s += digits[0];
+    if (nd > 1) s += "." + digits.substr(1);
+    return s + "e" + std::to_string(kk - 1);
+  }
+  if (kk <= 0) return s + "0." + std::string((size_t)-kk, '0') + digits;
+  if (nd <= kk) return s + digits + std::string((size_t)(kk - nd), '0') + ".0";
+  return s + digits.substr(0, (size_t)kk) + "." + digits.substr((size_t)kk);
+}
+
+ah_status elem_debug_text(ah_context* ctx, ah_type t, const void* base, int64_t idx, std::string* out) {
+  int w = ah_type_width(t);
+  uint64_t raw = 0;
+  AH_HIP(ctx, hipMemcpyAsync(&raw, (const char*)base + idx * w, w, hipMemcpyDeviceToHost, ctx->stream));
+  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  char buf[40];
+  switch (t) {
+    case AH_INT8: snprintf(buf, sizeof buf, "%d", (int)(int8_t)raw); break;
+    case AH_INT16: snprintf(buf, sizeof buf, "%d", (int)(int16_t)raw); break;
+    case AH_INT32: snprintf(buf, sizeof buf, "%d", (int)(int32_t)raw); break;
+    case AH_INT64: snprintf(buf, sizeof buf, "%lld", (long long)(int64_t)raw); break;
+    case AH_FLOAT32: {
+      float f;
+      memcpy(&f, &raw, 4);
+      *out = rust_debug_float<float>(f);
+      return AH_OK;
+    }
+    case AH_FLOAT64: {
+      double d;
+      memcpy(&d, &raw, 8);
+      *out = rust_debug_float<double>(d);
+      return AH_OK;
+    }
+    default: snprintf(buf, sizeof buf, "%llu", (unsigned long long)raw); break;
+  }
+  *out = buf;
+  return AH_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t ah_can_cast_types(ah_type from, ah_type to) {
+  if (from == to) return ah_type_width(from) >= 0 || from == AH_UTF8 || from == AH_LARGE_UTF8;
+  if (is_numeric(from) && is_numeric(to)) return 1;
+  if (is_numeric(from) && (to == AH_UTF8 || to == AH_LARGE_UTF8)) return 1;
+  return 0;
+}
+
+extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_type to_type,
+                             int32_t safe, ah_array_out* out) {
+  if (!ctx || !values || !out) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  hipSetDevice(ctx->device);
+  const ah_type from = values->type;
+  if (!ah_can_cast_types(from, to_type))
+    return ah_fail(ctx, AH_CAST_ERROR, "Casting from %s to %s not supported", ah_type_name(from),
+                   ah_type_name(to_type));
+  if (to_type == AH_UTF8 || to_type == AH_LARGE_UTF8) return ah_cast_to_string(ctx, values, to_type, out);
+  const int64_t len = values->length;
+  const int wo = ah_type_width(to_type);
+  out->type = to_type;
+  out->length = len;
+  const size_t vbytes = (size_t)len * wo, bbytes = ah_bitmap_bytes(len);
+
+  if (from == to_type) {  // cast_with_options :797-799 — a clone
+    if (len == 0) return AH_OK;
+    void* ov = nullptr;
+    AH_TRY(ah_out_alloc(ctx, vbytes, &ov));
+    hipMemcpyAsync(ov, values->values, vbytes, hipMemcpyDeviceToDevice, ctx->stream);
+    out->values = ov;
+    out->values_bytes = (int64_t)vbytes;
+    if (values->validity) {
+      void* ob = nullptr;
+      int64_t set = 0;
+      ah_status st = ah_out_alloc(ctx, bbytes, &ob);
+      if (st == AH_OK)
+        st = ah_bitmap_op(ctx, BM_COPY, make_bitview(values->validity, values->validity_bit_offset),
+                          BitView{nullptr, 0}, BitView{nullptr, 0}, len, (unsigned long long*)ob, &set);
+      if (st != AH_OK) {
+        ah_out_free(ctx, ov, vbytes);
+        ah_out_free(ctx, ob, bbytes);
+        ah_out_init(out);
+        return st;
+      }
+      out->validity = (uint8_t*)ob;
+      out->validity_bytes = (int64_t)bbytes;
+      out->null_count = len - set;
+    }
+    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AH_OK;
+  }
+
+  // safe: unary_opt ALWAYS carries a null buffer (primitive_array.rs:1098-1102);
+  // unsafe: try_unary clones the input nulls (presence-based)
+  const bool want_valid = safe || values->validity != nullptr;
+  if (len == 0) {
+    // unary_opt on an empty array still yields Some(empty NullBuffer); nothing to allocate
+    return AH_OK;
+  }
+  void* ov = nullptr;
+  void* ob = nullptr;
+  unsigned long long* aux = nullptr;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(len, 1024), 256 * 16));
+  AH_TRY(ah_out_alloc(ctx, vbytes, &ov));
+  ah_status st = AH_OK;
+  if (want_valid) st = ah_out_alloc(ctx, bbytes, &ob);
+  if (st == AH_OK) st = ah_pool_alloc(ctx, (size_t)(grid + 4) * 8, (void**)&aux);
+  if (st != AH_OK) {
+    ah_out_free(ctx, ov, vbytes);
+    ah_out_free(ctx, ob, bbytes);
+    return st;
+  }
+  hipMemsetAsync(aux, 0xFF, 8, ctx->stream);
+  CastArgs a{};
+  a.in = values->values;
+  a.out = ov;
+  a.in_valid = values->validity ? make_bitview(values->validity, values->validity_bit_offset)
+                                : BitView{nullptr, 0};
+  a.len = len;
+  a.out_valid = (unsigned long long*)ob;
+  a.block_valid = aux + 2;
+  a.first_err = aux;
+  a.safe = safe ? 1 : 0;
+  {
+    ah_prof_scope ps(ctx, "cast_numeric");
+    switch (from) {
+      case AH_INT8: st = launch_from<int8_t>(ctx, to_type, a, grid); break;
+      case AH_INT16: st = launch_from<int16_t>(ctx, to_type, a, grid); break;
+      case AH_INT32: st = launch_from<int32_t>(ctx, to_type, a, grid); break;
+      case AH_INT64: st = launch_from<int64_t>(ctx, to_type, a, grid); break;
+      case AH_UINT8: st = launch_from<uint8_t>(ctx, to_type, a, grid); break;
+      case AH_UINT16: st = launch_from<uint16_t>(ctx, to_type, a, grid); break;
+      case AH_UINT32: st = launch_from<uint32_t>(ctx, to_type, a, grid); break;
+      case AH_UINT64: st = launch_from<uint64_t>(ctx, to_type, a, grid); break;
+      case AH_FLOAT32: st = launch_from<float>(ctx, to_type, a, grid); break;
+      default: st = launch_from<double>(ctx, to_type, a, grid); break;
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (st == AH_OK && e == hipSuccess) {
+    if (want_valid) cast_sum_kernel<<<1, 1024, 0, ctx->stream>>>(a.block_valid, grid, aux + 1);
+    e = hipMemcpyAsync(ctx->pinned, aux, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  ah_pool_free(ctx, aux);
+  if (st != AH_OK || e != hipSuccess) {
+    ah_out_free(ctx, ov, vbytes);
+    ah_out_free(ctx, ob, bbytes);
+    if (st != AH_OK) return st;
+    return ah_fail(ctx, AH_HIP_ERROR, "cast kernel failed: %s", hipGetErrorString(e));
+  }
+  if (!safe && ctx->pinned[0] != ~0ull) {
+    int64_t pos = (int64_t)ctx->pinned[0];
+    ah_out_free(ctx, ov, vbytes);
+    ah_out_free(ctx, ob, bbytes);
+    std::string txt;
+    AH_TRY(elem_debug_text(ctx, from, values->values, pos, &txt));
+    return ah_fail(ctx, AH_CAST_ERROR, "Can't cast value %s to type %s", txt.c_str(), ah_type_name(to_type));
+  }
+  out->values = ov;
+  out->values_bytes = (int64_t)vbytes;
+  if (want_valid) {
+    out->validity = (uint8_t*)ob;
+    out->validity_bytes = (int64_t)bbytes;
+    out->null_count = len - (int64_t)ctx->pinned[1];
+  }
+  return AH_OK;
+}

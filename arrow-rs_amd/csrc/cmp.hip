@@ -1,0 +1,352 @@
+// cmp.hip — arrow_ord::cmp on MI355X.
+//
+// Reference path: eq/neq/lt/lt_eq/gt/gt_eq/distinct/not_distinct
+// (arrow-ord/src/cmp.rs:79-202) -> compare_op :220-382 -> apply :438-502
+// (lt_eq = !lt swapped, gt = lt swapped, gt_eq = !lt, neq = !eq) -> apply_op
+// :619-648 -> collect_bool :580-611 (64 compares -> one u64, optional negation).
+// Floats compare in IEEE totalOrder, equality is bit equality
+// (arrow-array/src/arithmetic.rs:400-410).
+//
+// MI355X design: every lane loads 16 bytes of each operand (V rows); the V
+// compare bits of all 64 lanes are collected with V __ballot's (SGPR pairs) and
+// bit-interleaved on the scalar unit into the V output words of the wave's
+// 64*V-row group — 16-byte loads AND whole-word stores without touching LDS.
+// Null handling follows compare_op's four cases with word-parallel bitmap ops.
+#include "common.hpp"
+
+#include <type_traits>
+
+namespace {
+
+enum { B_EQ = 0, B_LT = 1 };
+
+template <typename T> struct Key { using type = T; };
+template <> struct Key<double> { using type = int64_t; };
+template <> struct Key<float> { using type = int32_t; };
+
+// totalOrder key: x ^ (((x >> 63) as u64) >> 1)  (f64::total_cmp)
+__device__ __forceinline__ int64_t order_key(double v) {
+  int64_t b = __double_as_longlong(v);
+  return b ^ (int64_t)((uint64_t)(b >> 63) >> 1);
+}
+__device__ __forceinline__ int32_t order_key(float v) {
+  int32_t b = __float_as_int(v);
+  return b ^ (int32_t)((uint32_t)(b >> 31) >> 1);
+}
+template <typename T> __device__ __forceinline__ T order_key(T v) { return v; }
+__device__ __forceinline__ int64_t bits_key(double v) { return __double_as_longlong(v); }
+__device__ __forceinline__ int32_t bits_key(float v) { return __float_as_int(v); }
+template <typename T> __device__ __forceinline__ T bits_key(T v) { return v; }
+
+// place bit p of x at bit p*V
+template <int V> __device__ __forceinline__ uint64_t spread(uint64_t x);
+template <> __device__ __forceinline__ uint64_t spread<1>(uint64_t x) { return x; }
+template <> __device__ __forceinline__ uint64_t spread<2>(uint64_t x) {  // 32 -> 64
+  x &= 0xFFFFFFFFull;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+template <> __device__ __forceinline__ uint64_t spread<4>(uint64_t x) {  // 16 -> 64
+  x &= 0xFFFFull;
+  x = (x | (x << 24)) & 0x000000FF000000FFull;
+  x = (x | (x << 12)) & 0x000F000F000F000Full;
+  x = (x | (x << 6)) & 0x0303030303030303ull;
+  x = (x | (x << 3)) & 0x1111111111111111ull;
+  return x;
+}
+
+template <typename T, int V> struct alignas(sizeof(T) * V) VecT { T e[V]; };
+
+struct CmpArgs {
+  const void* l;
+  const void* r;
+  int64_t len;
+  int l_scalar, r_scalar;
+  int base;  // B_EQ / B_LT on (l, r) as given (caller already swapped)
+  int neg;
+  unsigned long long* out;
+};
+
+template <typename T, int V>
+__global__ void __launch_bounds__(256) compare_kernel(CmpArgs a) {
+  using VT = VecT<T, V>;
+  const int lane = threadIdx.x & 63;
+  const T* lp = (const T*)a.l;
+  const T* rp = (const T*)a.r;
+  T ls = a.l_scalar ? lp[0] : T{};
+  T rs = a.r_scalar ? rp[0] : T{};
+  const int64_t ngroups = (a.len + 64 * V - 1) / (64 * V);  // one wave-step = 64*V rows
+  const int64_t wave0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  const int64_t nwords = (a.len + 63) >> 6;
+  for (int64_t g = wave0; g < ngroups; g += nwaves) {
+    int64_t i = (g * 64 + lane) * V;
+    VT lv, rv;
+    if (i + V <= a.len) {
+      if (!a.l_scalar) lv = *(const VT*)(lp + i);
+      if (!a.r_scalar) rv = *(const VT*)(rp + i);
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        lv.e[e] = (!a.l_scalar && i + e < a.len) ? lp[i + e] : T{};
+        rv.e[e] = (!a.r_scalar && i + e < a.len) ? rp[i + e] : T{};
+      }
+    }
+    uint64_t ballots[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      T x = a.l_scalar ? ls : lv.e[e];
+      T y = a.r_scalar ? rs : rv.e[e];
+      bool res = a.base == B_EQ ? (bits_key(x) == bits_key(y)) : (order_key(x) < order_key(y));
+      res = res && (i + e < a.len);
+      ballots[e] = __ballot(res);
+    }
+    // word k of the group covers lanes [k*64/V, (k+1)*64/V)
+    uint64_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      uint64_t w = 0;
+#pragma unroll
+      for (int e = 0; e < V; ++e) w |= spread<V>(ballots[e] >> (k * (64 / V))) << e;
+      if (a.neg) w = ~w;  // collect_bool negates whole words, padding included (cmp.rs:590-592)
+      if (lane == k) mine = w;
+    }
+    int64_t wi = g * V + lane;
+    if (lane < V && wi < nwords) a.out[wi] = mine;
+  }
+}
+
+template <typename T>
+void launch_cmp_t(ah_context* ctx, const CmpArgs& a, bool aligned) {
+  constexpr int VV = sizeof(T) >= 4 ? 16 / sizeof(T) : 4;  // 1/2-byte types: 4 rows per lane
+  const int V = aligned ? VV : 1;
+  int64_t ngroups = ah_ceil_div(a.len, 64 * (int64_t)V);
+  int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(ngroups, 4), 256 * 16));
+  if (aligned) compare_kernel<T, VV><<<grid, 256, 0, ctx->stream>>>(a);
+  else compare_kernel<T, 1><<<grid, 256, 0, ctx->stream>>>(a);
+}
+
+// Boolean operands: word-parallel (ArrayOrd for &BooleanArray, cmp.rs:740-761: lt = !l & r)
+__global__ void __launch_bounds__(256) compare_bool_kernel(BitView l, BitView r, int64_t len,
+                                                           int l_scalar, int r_scalar, int base, int neg,
+                                                           unsigned long long* out) {
+  int64_t nwords = (len + 63) >> 6;
+  uint64_t ls = l_scalar ? (bv_get(l, 0) ? ~0ull : 0ull) : 0ull;
+  uint64_t rs = r_scalar ? (bv_get(r, 0) ? ~0ull : 0ull) : 0ull;
+  for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * 256) {
+    int64_t s = w << 6;
+    uint64_t x = l_scalar ? ls : bv_fetch64(l, s, len);
+    uint64_t y = r_scalar ? rs : bv_fetch64(r, s, len);
+    uint64_t res = base == B_EQ ? ~(x ^ y) : (~x & y);
+    int64_t rem = len - s;
+    if (rem < 64) res &= (1ull << rem) - 1;
+    out[w] = neg ? ~res : res;
+  }
+}
+
+const char* cmp_sym(int op) {  // Display for Op (cmp.rs:55-68)
+  switch (op) {
+    case AH_EQ: return "==";
+    case AH_NEQ: return "!=";
+    case AH_LT: return "<";
+    case AH_LT_EQ: return "<=";
+    case AH_GT: return ">";
+    case AH_GT_EQ: return ">=";
+    case AH_DISTINCT: return "IS DISTINCT FROM";
+    default: return "IS NOT DISTINCT FROM";
+  }
+}
+
+}  // namespace
+
+extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_view* lhs, int32_t l_s,
+                                const ah_array_view* rhs, int32_t r_s, ah_array_out* out) {
+  if (!ctx || !lhs || !rhs || !out) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  hipSetDevice(ctx->device);
+  if (op < AH_EQ || op > AH_NOT_DISTINCT) return ah_fail(ctx, AH_INVALID_ARGUMENT, "unknown comparison op %d", op);
+  l_s = l_s != 0;
+  r_s = r_s != 0;
+  // compare_op (cmp.rs:228-264)
+  if (lhs->length != rhs->length && !l_s && !r_s)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "Cannot compare arrays of different lengths, got %lld vs %lld",
+                   (long long)lhs->length, (long long)rhs->length);
+  const int64_t len = l_s ? rhs->length : lhs->length;
+  if (lhs->type != rhs->type)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "Invalid comparison operation: %s %s %s",
+                   ah_type_name(lhs->type), cmp_sym(op), ah_type_name(rhs->type));
+  const ah_type t = lhs->type;
+  if (!(t == AH_BOOL || ah_type_is_integer(t) || ah_type_is_float(t)))
+    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "comparison not supported for type %s", ah_type_name(t));
+  if ((l_s && lhs->length < 1) || (r_s && rhs->length < 1))
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "scalar datum must have length 1");
+  out->type = AH_BOOL;
+  out->length = len;
+  if (len == 0) return AH_OK;
+
+  int64_t ln = 0, rn = 0;
+  AH_TRY(ah_resolve_null_count(ctx, lhs, &ln));
+  AH_TRY(ah_resolve_null_count(ctx, rhs, &rn));
+  const bool lnul = lhs->validity && ln > 0, rnul = rhs->validity && rn > 0;  // .filter(null_count > 0)
+  const bool distinct_op = op == AH_DISTINCT || op == AH_NOT_DISTINCT;
+
+  const size_t bytes = ah_bitmap_bytes(len);
+  unsigned long long* vals = nullptr;   // comparison bits
+  unsigned long long* nb = nullptr;     // result validity
+  unsigned long long* tmp = nullptr;
+  AH_TRY(ah_out_alloc(ctx, bytes, (void**)&vals));
+  auto fail_free = [&](ah_status st) {
+    ah_out_free(ctx, vals, bytes);
+    ah_out_free(ctx, nb, bytes);
+    ah_pool_free(ctx, tmp);
+    return st;
+  };
+
+  // which cases need the value comparison at all (the reference defers it: cmp.rs:300)
+  const bool scalar_null = (lnul && l_s && !(rnul && r_s)) || (rnul && r_s && !(lnul && l_s));
+  const bool need_values = !scalar_null || (lnul && rnul && l_s == r_s);
+
+  auto run_values = [&](unsigned long long* dst) -> ah_status {
+    // apply (cmp.rs:480-488)
+    int base, neg;
+    bool swap;
+    switch (op) {
+      case AH_EQ: case AH_NOT_DISTINCT: base = B_EQ; neg = 0; swap = false; break;
+      case AH_NEQ: case AH_DISTINCT: base = B_EQ; neg = 1; swap = false; break;
+      case AH_LT: base = B_LT; neg = 0; swap = false; break;
+      case AH_LT_EQ: base = B_LT; neg = 1; swap = true; break;
+      case AH_GT: base = B_LT; neg = 0; swap = true; break;
+      default: base = B_LT; neg = 1; swap = false; break;  // GT_EQ
+    }
+    const ah_array_view* L = swap ? rhs : lhs;
+    const ah_array_view* R = swap ? lhs : rhs;
+    int Ls = swap ? r_s : l_s, Rs = swap ? l_s : r_s;
+    ah_prof_scope ps(ctx, "compare");
+    if (t == AH_BOOL) {
+      int64_t nwords = (len + 63) >> 6;
+      int grid = (int)std::min<int64_t>(4096, ah_ceil_div(nwords, 256));
+      compare_bool_kernel<<<grid, 256, 0, ctx->stream>>>(
+          make_bitview(L->values, L->values_bit_offset), make_bitview(R->values, R->values_bit_offset),
+          len, Ls, Rs, base, neg, dst);
+      return AH_OK;
+    }
+    CmpArgs a{};
+    a.l = L->values;
+    a.r = R->values;
+    a.len = len;
+    a.l_scalar = Ls;
+    a.r_scalar = Rs;
+    a.base = base;
+    a.neg = neg;
+    a.out = dst;
+    bool aligned = true;
+    if (!Ls) aligned = aligned && (((uintptr_t)a.l & 15) == 0);
+    if (!Rs) aligned = aligned && (((uintptr_t)a.r & 15) == 0);
+    switch (t) {
+      case AH_INT8: launch_cmp_t<int8_t>(ctx, a, aligned); break;
+      case AH_INT16: launch_cmp_t<int16_t>(ctx, a, aligned); break;
+      case AH_INT32: launch_cmp_t<int32_t>(ctx, a, aligned); break;
+      case AH_INT64: launch_cmp_t<int64_t>(ctx, a, aligned); break;
+      case AH_UINT8: launch_cmp_t<uint8_t>(ctx, a, aligned); break;
+      case AH_UINT16: launch_cmp_t<uint16_t>(ctx, a, aligned); break;
+      case AH_UINT32: launch_cmp_t<uint32_t>(ctx, a, aligned); break;
+      case AH_UINT64: launch_cmp_t<uint64_t>(ctx, a, aligned); break;
+      case AH_FLOAT32: launch_cmp_t<float>(ctx, a, aligned); break;
+      default: launch_cmp_t<double>(ctx, a, aligned); break;
+    }
+    return AH_OK;
+  };
+
+  BitView lv = make_bitview(lhs->validity, lhs->validity_bit_offset);
+  BitView rv = make_bitview(rhs->validity, rhs->validity_bit_offset);
+  const BitView none{nullptr, 0};
+  int64_t set_bits = len;
+  bool has_nb = false;
+  ah_status st = AH_OK;
+
+  if (lnul && rnul && l_s == r_s) {
+    // both nullable, both or neither scalar (cmp.rs:322-347)
+    if (distinct_op) {
+      st = ah_pool_alloc(ctx, bytes, (void**)&tmp);
+      if (st != AH_OK) return fail_free(st);
+      st = run_values(tmp);
+      BitView tv = make_bitview(tmp, 0);
+      if (st == AH_OK)
+        st = ah_bitmap_op(ctx, op == AH_DISTINCT ? BM_DISTINCT_BOTH : BM_NOT_DISTINCT_BOTH, lv, rv, tv, len,
+                          vals, nullptr);
+    } else {
+      st = run_values(vals);
+      if (st == AH_OK) st = ah_out_alloc(ctx, bytes, (void**)&nb);
+      if (st == AH_OK) st = ah_bitmap_op(ctx, BM_AND, lv, rv, none, len, nb, &set_bits);
+      has_nb = true;
+    }
+  } else if (lnul && rnul) {
+    // scalar is null, other side non-scalar and nullable (cmp.rs:349-356)
+    BitView av = l_s ? rv : lv;
+    if (op == AH_DISTINCT) st = ah_bitmap_op(ctx, BM_COPY, av, none, none, len, vals, nullptr);
+    else if (op == AH_NOT_DISTINCT) st = ah_bitmap_op(ctx, BM_NOT, av, none, none, len, vals, nullptr);
+    else {  // BooleanArray::new_null(len)
+      st = ah_out_alloc(ctx, bytes, (void**)&nb);
+      if (st == AH_OK) {
+        hipMemsetAsync(vals, 0, bytes, ctx->stream);
+        hipMemsetAsync(nb, 0, bytes, ctx->stream);
+        set_bits = 0;
+        has_nb = true;
+      }
+    }
+  } else if (lnul || rnul) {
+    // only one side nullable (cmp.rs:357-378)
+    const bool is_scalar = lnul ? l_s : r_s;
+    BitView nv = lnul ? lv : rv;
+    if (is_scalar) {
+      if (op == AH_DISTINCT) {  // BooleanBuffer::new_set(len)
+        st = ah_bitmap_op(ctx, BM_COPY, none, none, none, len, vals, nullptr);
+      } else if (op == AH_NOT_DISTINCT) {
+        hipMemsetAsync(vals, 0, bytes, ctx->stream);
+      } else {
+        st = ah_out_alloc(ctx, bytes, (void**)&nb);
+        if (st == AH_OK) {
+          hipMemsetAsync(vals, 0, bytes, ctx->stream);
+          hipMemsetAsync(nb, 0, bytes, ctx->stream);
+          set_bits = 0;
+          has_nb = true;
+        }
+      }
+    } else if (distinct_op) {
+      st = ah_pool_alloc(ctx, bytes, (void**)&tmp);
+      if (st != AH_OK) return fail_free(st);
+      st = run_values(tmp);
+      BitView tv = make_bitview(tmp, 0);
+      if (st == AH_OK)
+        st = ah_bitmap_op(ctx, op == AH_DISTINCT ? BM_ORNOT : BM_AND, nv, tv, none, len, vals, nullptr);
+    } else {
+      st = run_values(vals);
+      if (st == AH_OK) st = ah_out_alloc(ctx, bytes, (void**)&nb);
+      if (st == AH_OK) st = ah_bitmap_op(ctx, BM_COPY, nv, none, none, len, nb, &set_bits);
+      has_nb = true;
+    }
+  } else {
+    st = run_values(vals);  // neither side nullable (:380)
+  }
+  (void)need_values;
+  if (st != AH_OK) return fail_free(st);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    fail_free(AH_HIP_ERROR);
+    return ah_fail(ctx, AH_HIP_ERROR, "compare kernel failed: %s", hipGetErrorString(e));
+  }
+  ah_pool_free(ctx, tmp);
+  out->values = vals;
+  out->values_bytes = (int64_t)bytes;
+  if (has_nb) {
+    out->validity = (uint8_t*)nb;
+    out->validity_bytes = (int64_t)bytes;
+    out->null_count = len - set_bits;
+  }
+  return AH_OK;
+}

@@ -1,0 +1,212 @@
+// common.hpp — shared host/device plumbing for libarrow_hip.so (gfx950 only).
+//
+// Nothing here mirrors a reference file; it is the runtime the reference gets
+// from Rust's allocator/Vec (arrow-buffer/src/buffer/mutable.rs) re-thought for
+// HBM: a pooled device allocator, a device scratch arena, pinned read-back
+// slots and HIP-event kernel timing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/arrow_hip.h"
+
+// ------------------------------------------------------------------ context
+struct ah_prof_entry {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double total_ms = 0.0;
+  int64_t launches = 0;
+};
+
+struct ah_context {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // output allocator hook
+  ah_alloc_fn alloc = nullptr;
+  ah_free_fn free_ = nullptr;
+  void* user = nullptr;
+  // built-in pool: exact-size free lists of hipMalloc'd blocks
+  std::map<size_t, std::vector<void*>> pool_free;
+  std::unordered_map<void*, size_t> pool_live;  // ptr -> rounded size
+  // scratch arena (tile counts, prefix sums); grows monotonically
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  // pinned host read-back slots
+  uint64_t* pinned = nullptr;  // 64 x u64
+  // profiling
+  bool profiling = false;
+  std::map<std::string, ah_prof_entry> prof;
+};
+
+ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...);
+
+#define AH_HIP(ctx, expr)                                                                  \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return ah_fail((ctx), _e == hipErrorOutOfMemory ? AH_OUT_OF_MEMORY : AH_HIP_ERROR,   \
+                     "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__,        \
+                     __LINE__, #expr);                                                     \
+  } while (0)
+
+#define AH_TRY(expr)            \
+  do {                          \
+    ah_status _s = (expr);      \
+    if (_s != AH_OK) return _s; \
+  } while (0)
+
+// pooled device memory (internal + default output allocator)
+ah_status ah_pool_alloc(ah_context* ctx, size_t bytes, void** out);
+void ah_pool_free(ah_context* ctx, void* p);
+// output buffers honour the host allocator hook
+ah_status ah_out_alloc(ah_context* ctx, size_t bytes, void** out);
+void ah_out_free(ah_context* ctx, void* p, size_t bytes);
+// scratch arena: returns a pointer valid until the next ah_scratch call that grows it
+ah_status ah_scratch(ah_context* ctx, size_t bytes, void** out);
+
+// HIP-event bracketing of hot kernels on the launch stream
+struct ah_prof_scope {
+  ah_context* ctx;
+  hipEvent_t a = nullptr, b = nullptr;
+  const char* name;
+  ah_prof_scope(ah_context* c, const char* n) : ctx(c), name(n) {
+    if (ctx->profiling) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, ctx->stream);
+    }
+  }
+  ~ah_prof_scope() {
+    if (ctx->profiling) {
+      hipEventRecord(b, ctx->stream);
+      ctx->prof[name].pending.emplace_back(a, b);
+    }
+  }
+};
+
+static inline int64_t ah_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t ah_bitmap_bytes(int64_t bits) {  // whole u64 words, like collect_bool
+  return (size_t)ah_ceil_div(bits, 64) * 8;
+}
+
+int ah_type_width(ah_type t);  // bytes per value; 0 for AH_BOOL; -1 if not fixed-width
+const char* ah_type_name(ah_type t);  // DataType Display text ("Int64", "Float64", ...)
+bool ah_type_is_integer(ah_type t);
+bool ah_type_is_signed(ah_type t);
+bool ah_type_is_float(ah_type t);
+
+void ah_out_init(ah_array_out* out);
+
+// count valid bits of a view's validity (or trust view->null_count >= 0)
+ah_status ah_resolve_null_count(ah_context* ctx, const ah_array_view* v, int64_t* nulls);
+
+// ---------------------------------------------------------------- device side
+#ifdef __HIPCC__
+
+// A bit-packed LSB-first stream with a bit offset (BooleanBuffer,
+// arrow-buffer/src/buffer/boolean.rs:97-104) normalised to 8-byte words:
+// bit i of the stream is bit (off + i) of `words`, 0 <= off < 64.
+// words == nullptr encodes "all ones" (no null buffer).
+struct BitView {
+  const uint64_t* words;
+  int64_t off;
+};
+
+static inline BitView make_bitview(const void* bytes, int64_t bit_offset) {
+  BitView v;
+  if (!bytes) {
+    v.words = nullptr;
+    v.off = 0;
+    return v;
+  }
+  uintptr_t p = (uintptr_t)bytes + (uintptr_t)(bit_offset >> 3);
+  int64_t off = bit_offset & 7;
+  uintptr_t al = p & ~(uintptr_t)7;
+  off += (int64_t)(p - al) * 8;
+  v.words = (const uint64_t*)al;
+  v.off = off;
+  return v;
+}
+
+// bits [s, s+64) of the stream (s may be any value >= 0), bits at index >= len
+// read as 0.  Never touches a word that holds no bit below `len`.
+__device__ __forceinline__ uint64_t bv_fetch64(const BitView& v, int64_t s, int64_t len) {
+  if (s >= len) return 0;
+  if (!v.words) {
+    int64_t rem = len - s;
+    return rem >= 64 ? ~0ull : ((1ull << rem) - 1);
+  }
+  int64_t pos = v.off + s;
+  int64_t w = pos >> 6;
+  int sh = (int)(pos & 63);
+  uint64_t lo = v.words[w] >> sh;
+  if (sh) {
+    int64_t last_word = (v.off + len - 1) >> 6;
+    uint64_t hi = (w + 1 <= last_word) ? v.words[w + 1] : 0;
+    lo |= hi << (64 - sh);
+  }
+  int64_t rem = len - s;
+  if (rem < 64) lo &= (1ull << rem) - 1;
+  return lo;
+}
+
+__device__ __forceinline__ int bv_get(const BitView& v, int64_t i) {
+  if (!v.words) return 1;
+  int64_t pos = v.off + i;
+  return (int)((((const uint8_t*)v.words)[pos >> 3] >> (pos & 7)) & 1);
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+  unsigned lane = __lane_id();
+  return (1ull << lane) - 1;  // lane < 64
+}
+
+__device__ __forceinline__ int wave_reduce_add(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_reduce_add64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ int wave_scan_incl(int v) {
+  unsigned lane = __lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(v, o, 64);
+    if (lane >= (unsigned)o) v += t;
+  }
+  return v;
+}
+
+
+// ---- shared bitmap machinery (bitmap.hip)
+enum ah_bitmap_opcode {
+  BM_COPY = 0,            // a
+  BM_NOT = 1,             // ~a
+  BM_AND = 2,             // a & b
+  BM_DISTINCT_BOTH = 3,   // (a ^ b) | (a & b & c)     cmp.rs:329-335
+  BM_NOT_DISTINCT_BOTH = 4,  // ~(a | b) | (a & b & c) cmp.rs:336-343
+  BM_ORNOT = 5,           // ~a | b                    cmp.rs:366-372
+};
+// out_words[w] = op(a, b, c) over `len` bits (each input a BitView with its own
+// offset; words == nullptr reads as all-ones); bits past len are zeroed.
+// *set_bits (optional) receives the popcount of the result.  Synchronous only
+// when set_bits != nullptr.
+ah_status ah_bitmap_op(ah_context* ctx, int op, BitView a, BitView b, BitView c, int64_t len,
+                       unsigned long long* out_words, int64_t* set_bits);
+
+#endif  // __HIPCC__

@@ -1,0 +1,320 @@
+// context.hip — context, pooled HBM allocator, read-back slots, HIP-event
+// profiling and bitmap popcount.  Runtime plumbing: the reference's analogue is
+// Rust's global allocator + `MutableBuffer` (arrow-buffer/src/buffer/mutable.rs)
+// and `BooleanBuffer::count_set_bits` (arrow-buffer/src/buffer/boolean.rs).
+#include "common.hpp"
+
+ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return st;
+}
+
+int ah_type_width(ah_type t) {
+  switch (t) {
+    case AH_BOOL: return 0;
+    case AH_INT8: case AH_UINT8: return 1;
+    case AH_INT16: case AH_UINT16: case AH_FLOAT16: return 2;
+    case AH_INT32: case AH_UINT32: case AH_FLOAT32: return 4;
+    case AH_INT64: case AH_UINT64: case AH_FLOAT64: return 8;
+    case AH_FIXED16: return 16;
+    case AH_FIXED32: return 32;
+    default: return -1;
+  }
+}
+const char* ah_type_name(ah_type t) {
+  switch (t) {
+    case AH_BOOL: return "Boolean";
+    case AH_INT8: return "Int8"; case AH_INT16: return "Int16";
+    case AH_INT32: return "Int32"; case AH_INT64: return "Int64";
+    case AH_UINT8: return "UInt8"; case AH_UINT16: return "UInt16";
+    case AH_UINT32: return "UInt32"; case AH_UINT64: return "UInt64";
+    case AH_FLOAT16: return "Float16"; case AH_FLOAT32: return "Float32";
+    case AH_FLOAT64: return "Float64";
+    case AH_FIXED16: return "FixedWidth16"; case AH_FIXED32: return "FixedWidth32";
+    case AH_UTF8: return "Utf8"; case AH_LARGE_UTF8: return "LargeUtf8";
+    default: return "?";
+  }
+}
+bool ah_type_is_integer(ah_type t) { return t >= AH_INT8 && t <= AH_UINT64; }
+bool ah_type_is_signed(ah_type t) { return t >= AH_INT8 && t <= AH_INT64; }
+bool ah_type_is_float(ah_type t) { return t == AH_FLOAT32 || t == AH_FLOAT64; }
+
+void ah_out_init(ah_array_out* out) { memset(out, 0, sizeof *out); }
+
+// ------------------------------------------------------------------- pool
+static size_t pool_round(size_t bytes) {
+  if (bytes < 256) return 256;
+  if (bytes <= (1u << 20)) {  // next power of two
+    size_t r = 256;
+    while (r < bytes) r <<= 1;
+    return r;
+  }
+  return (bytes + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);
+}
+
+ah_status ah_pool_alloc(ah_context* ctx, size_t bytes, void** out) {
+  size_t r = pool_round(bytes);
+  auto it = ctx->pool_free.find(r);
+  if (it != ctx->pool_free.end() && !it->second.empty()) {
+    *out = it->second.back();
+    it->second.pop_back();
+    ctx->pool_live[*out] = r;
+    return AH_OK;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, r);
+  if (e != hipSuccess) {
+    // drop the cache and retry once
+    ah_pool_trim(ctx);
+    e = hipMalloc(&p, r);
+    if (e != hipSuccess)
+      return ah_fail(ctx, AH_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", r, hipGetErrorString(e));
+  }
+  ctx->pool_live[p] = r;
+  *out = p;
+  return AH_OK;
+}
+
+void ah_pool_free(ah_context* ctx, void* p) {
+  if (!p) return;
+  auto it = ctx->pool_live.find(p);
+  if (it == ctx->pool_live.end()) return;  // not ours
+  ctx->pool_free[it->second].push_back(p);
+  ctx->pool_live.erase(it);
+}
+
+extern "C" void ah_pool_trim(ah_context* ctx) {
+  hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->pool_free)
+    for (void* p : kv.second) hipFree(p);
+  ctx->pool_free.clear();
+}
+
+ah_status ah_out_alloc(ah_context* ctx, size_t bytes, void** out) {
+  if (bytes == 0) bytes = 8;
+  if (ctx->alloc) {
+    void* p = ctx->alloc(ctx->user, bytes);
+    if (!p) return ah_fail(ctx, AH_OUT_OF_MEMORY, "host allocator returned NULL for %zu bytes", bytes);
+    *out = p;
+    return AH_OK;
+  }
+  return ah_pool_alloc(ctx, bytes, out);
+}
+
+void ah_out_free(ah_context* ctx, void* p, size_t bytes) {
+  if (!p) return;
+  if (ctx->free_ && ctx->pool_live.find(p) == ctx->pool_live.end()) {
+    ctx->free_(ctx->user, p, bytes);
+    return;
+  }
+  ah_pool_free(ctx, p);
+}
+
+ah_status ah_scratch(ah_context* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->scratch_bytes) {
+    if (ctx->scratch) {
+      hipStreamSynchronize(ctx->stream);
+      hipFree(ctx->scratch);
+      ctx->scratch = nullptr;
+      ctx->scratch_bytes = 0;
+    }
+    size_t r = (bytes + (size_t)0xFFFFF) & ~(size_t)0xFFFFF;
+    AH_HIP(ctx, hipMalloc(&ctx->scratch, r));
+    ctx->scratch_bytes = r;
+  }
+  *out = ctx->scratch;
+  return AH_OK;
+}
+
+// ---------------------------------------------------------------- context
+extern "C" ah_status ah_context_create(int device, ah_context** out) {
+  if (!out) return AH_INVALID_ARGUMENT;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return AH_HIP_ERROR;  // fail loudly: no CPU fallback
+  if (device < 0 || device >= n) return AH_INVALID_ARGUMENT;
+  if (hipSetDevice(device) != hipSuccess) return AH_HIP_ERROR;
+  ah_context* c = new ah_context();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return AH_HIP_ERROR;
+  }
+  c->stream = c->own_stream;
+  if (hipHostMalloc((void**)&c->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+    hipStreamDestroy(c->own_stream);
+    delete c;
+    return AH_HIP_ERROR;
+  }
+  *out = c;
+  return AH_OK;
+}
+
+extern "C" void ah_context_destroy(ah_context* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  ah_profile_reset(ctx);
+  ah_pool_trim(ctx);
+  for (auto& kv : ctx->pool_live) hipFree(kv.first);
+  if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->pinned) hipHostFree(ctx->pinned);
+  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+extern "C" void ah_context_set_allocator(ah_context* ctx, ah_alloc_fn a, ah_free_fn f, void* user) {
+  ctx->alloc = a;
+  ctx->free_ = f;
+  ctx->user = user;
+}
+extern "C" void ah_context_set_stream(ah_context* ctx, void* s) {
+  ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+}
+extern "C" void* ah_context_stream(ah_context* ctx) { return (void*)ctx->stream; }
+extern "C" const char* ah_last_error(ah_context* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+extern "C" const char* ah_version(void) { return "arrow_hip 0.1.0 (gfx950)"; }
+
+extern "C" void ah_array_release(ah_context* ctx, ah_array_out* out) {
+  if (!out) return;
+  if (!(out->flags & AH_OUT_BORROWED)) {
+    ah_out_free(ctx, out->values, (size_t)out->values_bytes);
+    ah_out_free(ctx, out->validity, (size_t)out->validity_bytes);
+    ah_out_free(ctx, out->offsets, (size_t)out->offsets_bytes);
+  }
+  ah_out_init(out);
+}
+
+extern "C" ah_status ah_device_alloc(ah_context* ctx, size_t bytes, void** out) {
+  hipSetDevice(ctx->device);
+  return ah_pool_alloc(ctx, bytes ? bytes : 8, out);
+}
+extern "C" void ah_device_free(ah_context* ctx, void* p) { ah_pool_free(ctx, p); }
+extern "C" ah_status ah_memcpy_htod(ah_context* ctx, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return AH_OK;
+  AH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AH_OK;
+}
+extern "C" ah_status ah_memcpy_dtoh(ah_context* ctx, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return AH_OK;
+  AH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AH_OK;
+}
+extern "C" ah_status ah_memset(ah_context* ctx, void* dst, int value, size_t bytes) {
+  if (!bytes) return AH_OK;
+  AH_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+  return AH_OK;
+}
+extern "C" ah_status ah_synchronize(ah_context* ctx) {
+  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AH_OK;
+}
+
+// -------------------------------------------------------------- profiling
+extern "C" void ah_profile_enable(ah_context* ctx, int32_t on) { ctx->profiling = on != 0; }
+static void prof_drain(ah_context* ctx, ah_prof_entry& e) {
+  for (auto& pr : e.pending) {
+    hipEventSynchronize(pr.second);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      e.total_ms += ms;
+      e.launches += 1;
+    }
+    hipEventDestroy(pr.first);
+    hipEventDestroy(pr.second);
+  }
+  e.pending.clear();
+}
+extern "C" void ah_profile_reset(ah_context* ctx) {
+  for (auto& kv : ctx->prof) prof_drain(ctx, kv.second);
+  ctx->prof.clear();
+}
+extern "C" ah_status ah_profile_get(ah_context* ctx, const char* kernel, double* total_ms,
+                                    int64_t* launches) {
+  auto it = ctx->prof.find(kernel);
+  if (it == ctx->prof.end()) {
+    if (total_ms) *total_ms = 0;
+    if (launches) *launches = 0;
+    return AH_OK;
+  }
+  prof_drain(ctx, it->second);
+  if (total_ms) *total_ms = it->second.total_ms;
+  if (launches) *launches = it->second.launches;
+  return AH_OK;
+}
+
+// ----------------------------------------------------------- popcount kernel
+// One u64 partial per block, then a single-block finish: no same-address atomics.
+__global__ void __launch_bounds__(256) popcount_partial_kernel(BitView bits, int64_t len,
+                                                               unsigned long long* partials) {
+  int64_t nwords = (len + 63) >> 6;
+  unsigned long long acc = 0;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords;
+       w += (int64_t)gridDim.x * blockDim.x)
+    acc += __popcll(bv_fetch64(bits, w << 6, len));
+  acc = wave_reduce_add64(acc);
+  __shared__ unsigned long long s[4];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ void __launch_bounds__(1024) sum_u64_kernel(const unsigned long long* in, int64_t n,
+                                                       unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += in[i];
+  acc = wave_reduce_add64(acc);
+  __shared__ unsigned long long s[16];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int i = 0; i < 16; i++) t += s[i];
+    *out = t;
+  }
+}
+
+extern "C" ah_status ah_count_set_bits(ah_context* ctx, const uint8_t* bits, int64_t bit_offset,
+                                       int64_t len, int64_t* count) {
+  if (len <= 0 || !bits) {
+    *count = bits ? 0 : (len > 0 ? len : 0);
+    return AH_OK;
+  }
+  hipSetDevice(ctx->device);
+  int64_t nwords = (len + 63) >> 6;
+  int grid = (int)std::min<int64_t>(2048, ah_ceil_div(nwords, 256));
+  unsigned long long* part = nullptr;
+  AH_TRY(ah_pool_alloc(ctx, (size_t)(grid + 1) * 8, (void**)&part));
+  BitView bv = make_bitview(bits, bit_offset);
+  popcount_partial_kernel<<<grid, 256, 0, ctx->stream>>>(bv, len, part);
+  sum_u64_kernel<<<1, 1024, 0, ctx->stream>>>(part, grid, part + grid);
+  hipError_t e = hipMemcpyAsync(ctx->pinned, part + grid, 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  ah_pool_free(ctx, part);
+  AH_HIP(ctx, e);
+  *count = (int64_t)ctx->pinned[0];
+  return AH_OK;
+}
+
+ah_status ah_resolve_null_count(ah_context* ctx, const ah_array_view* v, int64_t* nulls) {
+  if (!v->validity) {
+    *nulls = 0;
+    return AH_OK;
+  }
+  if (v->null_count >= 0) {
+    *nulls = v->null_count;
+    return AH_OK;
+  }
+  int64_t set = 0;
+  AH_TRY(ah_count_set_bits(ctx, v->validity, v->validity_bit_offset, v->length, &set));
+  *nulls = v->length - set;
+  return AH_OK;
+}

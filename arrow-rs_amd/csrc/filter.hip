@@ -1,0 +1,584 @@
+// filter.hip — arrow_select::filter on MI355X.
+//
+// Reference path (arrow-select/src/filter.rs): filter :201 -> FilterBuilder::new
+// :256 (true_count, prep_null_mask_filter :167) -> filter_array :535 ->
+// filter_primitive :773 { filter_native :731, filter_nulls :512 { filter_bits :680,
+// count_set_bits } }.  The reference makes 4 passes over the mask (count, value
+// gather, bit gather, null count) with a tzcnt loop per set bit
+// (arrow-buffer/src/util/bit_iterator.rs:284-324).
+//
+// MI355X design (not a translation):
+//   K1 filter_count_kernel   one popcount pass over (mask & mask-validity); the
+//                            mask word IS the ballot.  Per-1024-row "chunk"
+//                            exclusive prefixes + per-group totals, one block
+//                            per 1024 chunks, LDS block scan — no atomics.
+//   K2 filter_group_scan     scans <=1024 group totals per pass -> u64 group
+//                            prefixes + K (the only number the host waits for).
+//   K3 filter_scatter_kernel one tile (<=4096 rows) per workgroup.  16-byte
+//                            coalesced value loads are issued first; wave 0
+//                            meanwhile builds the tile's word table in LDS
+//                            (mask, validity, exclusive popcount prefix).
+//                            rank(row) = prefix[word] + popc(word & below(row)),
+//                            selected values and their validity flags are
+//                            compacted in LDS, then written with coalesced
+//                            stores; validity bits are re-packed with __ballot
+//                            aligned to the global 64-bit output words (interior
+//                            words plain-stored, the two boundary words merged
+//                            with one 64-bit atomicOr each).
+//   K4 sum_u32               valid count per tile -> null_count.
+// Values are read exactly once; the mask twice (1.4% of the bytes at Int64).
+#include "common.hpp"
+
+namespace {
+
+constexpr int CHUNK_ROWS = 1024;            // count-pass granule (16 mask words)
+constexpr int GROUP_CHUNKS = 1024;          // chunks per count block
+constexpr int SCATTER_THREADS = 256;
+
+__host__ __device__ constexpr int tile_rows(int width) {
+  return width <= 8 ? 4096 : (width == 16 ? 2048 : 1024);
+}
+
+// ------------------------------------------------------------------ K1
+__global__ void __launch_bounds__(1024) filter_count_kernel(BitView mask, BitView mask_valid,
+                                                            int64_t len, uint32_t* chunk_prefix,
+                                                            uint32_t* group_total) {
+  __shared__ uint32_t s_cnt[GROUP_CHUNKS];
+  __shared__ uint32_t s_wave[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t chunk_base = (int64_t)blockIdx.x * GROUP_CHUNKS;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    int64_t chunk4 = chunk_base + wave * 64 + it * 4;  // 4 chunks = 64 words per wave step
+    int64_t s = (chunk4 * 16 + lane) << 6;
+    uint64_t m = bv_fetch64(mask, s, len);
+    if (mask_valid.words) m &= bv_fetch64(mask_valid, s, len);
+    int c = __popcll(m);
+    c += __shfl_xor(c, 1, 64);
+    c += __shfl_xor(c, 2, 64);
+    c += __shfl_xor(c, 4, 64);
+    c += __shfl_xor(c, 8, 64);
+    if ((lane & 15) == 0) s_cnt[wave * 64 + it * 4 + (lane >> 4)] = (uint32_t)c;
+  }
+  __syncthreads();
+  int v = (int)s_cnt[t];
+  int incl = wave_scan_incl(v);
+  if (lane == 63) s_wave[wave] = (uint32_t)incl;
+  __syncthreads();
+  uint32_t wbase = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) wbase += (w < wave) ? s_wave[w] : 0u;
+  int64_t nchunks = (len + CHUNK_ROWS - 1) / CHUNK_ROWS;
+  if (chunk_base + t < nchunks) chunk_prefix[chunk_base + t] = wbase + (uint32_t)(incl - v);
+  if (t == 1023) group_total[blockIdx.x] = wbase + (uint32_t)incl;
+}
+
+// ------------------------------------------------------------------ K2
+__global__ void __launch_bounds__(1024) filter_group_scan_kernel(const uint32_t* group_total,
+                                                                 int64_t ngroups,
+                                                                 unsigned long long* group_prefix,
+                                                                 unsigned long long* total_out) {
+  __shared__ unsigned long long s_wave[16];
+  __shared__ unsigned long long s_carry;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < ngroups; base += 1024) {
+    unsigned long long v = (base + t < ngroups) ? group_total[base + t] : 0ull;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      unsigned long long u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long wbase = s_carry;
+    for (int w = 0; w < wave; ++w) wbase += s_wave[w];
+    if (base + t < ngroups) group_prefix[base + t] = wbase + incl - v;
+    __syncthreads();
+    if (t == 1023) s_carry = wbase + incl;
+    __syncthreads();
+  }
+  if (t == 0) *total_out = s_carry;
+}
+
+// ------------------------------------------------------------------ K3
+template <int W> struct Elem;
+template <> struct Elem<1> { using type = uint8_t; };
+template <> struct Elem<2> { using type = uint16_t; };
+template <> struct Elem<4> { using type = uint32_t; };
+template <> struct Elem<8> { using type = uint64_t; };
+struct alignas(16) E16 { uint32_t x, y, z, w; };
+struct alignas(16) E32 { E16 a, b; };
+template <> struct Elem<16> { using type = E16; };
+template <> struct Elem<32> { using type = E32; };
+
+template <int W, int V> struct alignas((W * V >= 16) ? 16 : W * V) Vec {
+  using T = typename Elem<W>::type;
+  union { T e[V]; } u;
+};
+
+struct ScatterArgs {
+  const void* values;
+  BitView mask, mask_valid, vvalid;
+  int64_t len;  // predicate length
+  const uint32_t* chunk_prefix;
+  const unsigned long long* group_prefix;
+  void* out_values;
+  unsigned long long* out_valid;  // zero-initialised u64 words
+  uint32_t* tile_valid;           // per-tile count of valid selected rows
+};
+
+// WIDTH == 0: bit-only variant (Boolean values / validity-only): compacts the
+// `vvalid` stream; no value loads.
+template <int W, int V, bool HAS_VALID>
+__global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(ScatterArgs a) {
+  constexpr int WE = W == 0 ? 1 : W;
+  constexpr int T = tile_rows(WE);
+  constexpr int RPT = T / SCATTER_THREADS;
+  constexpr int L = RPT / V;
+  constexpr int NW = T / 64;  // mask words per tile (<= 64)
+  using ET = typename Elem<WE>::type;
+
+  __shared__ uint64_t s_m[NW];
+  __shared__ uint64_t s_v[HAS_VALID ? NW : 1];
+  __shared__ uint32_t s_base[NW];
+  __shared__ uint32_t s_total;
+  __shared__ uint32_t s_vc[4];
+  __shared__ ET s_vals[W == 0 ? 1 : T];
+  __shared__ uint8_t s_flag[HAS_VALID ? T : 1];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t tile = blockIdx.x;
+  const int64_t row0 = tile * T;
+
+  // 1. issue the value loads first (16 B per lane per load on the aligned path)
+  Vec<WE, V> regs[L];
+  if constexpr (W != 0) {
+    const ET* vp = (const ET*)a.values;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      int64_t r = row0 + (int64_t)(l * SCATTER_THREADS + t) * V;
+      if (r < a.len) regs[l] = *(const Vec<WE, V>*)(vp + r);
+    }
+  }
+
+  // 2. wave 0 builds the word table: mask, validity, exclusive popcount prefix
+  if (wave == 0) {
+    uint64_t m = 0, v = 0;
+    if (lane < NW) {
+      int64_t s = row0 + ((int64_t)lane << 6);
+      m = bv_fetch64(a.mask, s, a.len);
+      if (a.mask_valid.words) m &= bv_fetch64(a.mask_valid, s, a.len);
+      if constexpr (HAS_VALID) v = bv_fetch64(a.vvalid, s, a.len);
+    }
+    int c = __popcll(m);
+    int incl = wave_scan_incl(c);
+    if (lane < NW) {
+      s_m[lane] = m;
+      if constexpr (HAS_VALID) s_v[lane] = v;
+      s_base[lane] = (uint32_t)(incl - c);
+    }
+    if (lane == 63) s_total = (uint32_t)incl;
+  }
+  __syncthreads();
+
+  const int total = (int)s_total;
+  if (total == 0) {
+    if (HAS_VALID && t == 0) a.tile_valid[tile] = 0;
+    return;
+  }
+
+  // 3. compact selected rows into LDS
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    int r0 = (l * SCATTER_THREADS + t) * V;
+    int w = r0 >> 6, sh = r0 & 63;
+    uint64_t word = s_m[w];
+    uint32_t bits = (uint32_t)(word >> sh) & ((V == 32) ? 0xFFFFFFFFu : ((1u << V) - 1u));
+    if (bits) {
+      uint32_t base = s_base[w] + (uint32_t)__popcll(word & ((1ull << sh) - 1ull));
+      uint32_t vb = 0;
+      if constexpr (HAS_VALID) vb = (uint32_t)(s_v[w] >> sh);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        if ((bits >> e) & 1u) {
+          uint32_t pos = base + (uint32_t)__popc(bits & ((1u << e) - 1u));
+          if constexpr (W != 0) s_vals[pos] = regs[l].u.e[e];
+          if constexpr (HAS_VALID) s_flag[pos] = (uint8_t)((vb >> e) & 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // 4. coalesced write-out
+  const int64_t chunk0 = row0 / CHUNK_ROWS;
+  const int64_t ob = (int64_t)a.group_prefix[chunk0 / GROUP_CHUNKS] + a.chunk_prefix[chunk0];
+  if constexpr (W != 0) {
+    ET* op = (ET*)a.out_values + ob;
+    for (int j = t; j < total; j += SCATTER_THREADS) op[j] = s_vals[j];
+  }
+  if constexpr (HAS_VALID) {
+    const int64_t g0 = ob & ~63ll;
+    const int lead = (int)(ob - g0);
+    const int span = lead + total;
+    const int span64 = (span + 63) & ~63;
+    int vc = 0;
+    for (int q = t; q < span64; q += SCATTER_THREADS) {
+      int j = q - lead;
+      int f = (j >= 0 && j < total) ? (int)s_flag[j] : 0;
+      uint64_t word = __ballot(f);
+      if (lane == 0) {
+        int64_t wi = (g0 + q) >> 6;
+        bool interior = (q >= lead) && (q + 64 <= span);
+        if (interior) a.out_valid[wi] = word;
+        else if (word) atomicOr(&a.out_valid[wi], (unsigned long long)word);
+        vc += __popcll(word);
+      }
+    }
+    if (lane == 0) s_vc[wave] = (uint32_t)vc;
+    __syncthreads();
+    if (t == 0) a.tile_valid[tile] = s_vc[0] + s_vc[1] + s_vc[2] + s_vc[3];
+  }
+}
+
+__global__ void __launch_bounds__(1024) sum_u32_kernel(const uint32_t* in, int64_t n,
+                                                       unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) acc += in[i];
+  acc = wave_reduce_add64(acc);
+  __shared__ unsigned long long s[16];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long tot = 0;
+    for (int i = 0; i < 16; i++) tot += s[i];
+    *out = tot;
+  }
+}
+
+template <int W, bool HV>
+void launch_scatter_w(ah_context* ctx, const ScatterArgs& a, bool aligned16) {
+  constexpr int WE = W == 0 ? 1 : W;
+  constexpr int T = tile_rows(WE);
+  int64_t ntiles = ah_ceil_div(a.len, T);
+  dim3 grid((unsigned)ntiles), block(SCATTER_THREADS);
+  constexpr int VV = (W == 0) ? 16 : (W >= 16 ? 1 : 16 / W);
+  if (W == 0 || (aligned16 && VV > 1))
+    filter_scatter_kernel<W, VV, HV><<<grid, block, 0, ctx->stream>>>(a);
+  else
+    filter_scatter_kernel<W, 1, HV><<<grid, block, 0, ctx->stream>>>(a);
+}
+
+template <bool HV>
+ah_status launch_scatter(ah_context* ctx, int width, const ScatterArgs& a) {
+  bool aligned16 = (((uintptr_t)a.values) & 15) == 0;
+  switch (width) {
+    case 0: launch_scatter_w<0, HV>(ctx, a, true); break;
+    case 1: launch_scatter_w<1, HV>(ctx, a, aligned16); break;
+    case 2: launch_scatter_w<2, HV>(ctx, a, aligned16); break;
+    case 4: launch_scatter_w<4, HV>(ctx, a, aligned16); break;
+    case 8: launch_scatter_w<8, HV>(ctx, a, aligned16); break;
+    case 16: launch_scatter_w<16, HV>(ctx, a, aligned16); break;
+    case 32: launch_scatter_w<32, HV>(ctx, a, aligned16); break;
+    default: return ah_fail(ctx, AH_INVALID_ARGUMENT, "unsupported value width %d", width);
+  }
+  return AH_OK;
+}
+
+}  // namespace
+
+// FilterPredicate (filter.rs:442-449): predicate bits (borrowed), count and the
+// device-resident prefix tables that replace IterationStrategy::Indices.
+struct ah_filter_predicate {
+  BitView mask, mask_valid;
+  int64_t len = 0;
+  int64_t count = 0;
+  uint32_t* chunk_prefix = nullptr;
+  unsigned long long* group_prefix = nullptr;
+  void* block = nullptr;  // single pool allocation backing the tables
+};
+
+extern "C" ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_view* predicate,
+                                               ah_filter_predicate** out) {
+  if (!ctx || !predicate || !out) return AH_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (predicate->type != AH_BOOL)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "filter predicate must be Boolean, got %s",
+                   ah_type_name(predicate->type));
+  hipSetDevice(ctx->device);
+  auto* p = new ah_filter_predicate();
+  p->len = predicate->length;
+  p->mask = make_bitview(predicate->values, predicate->values_bit_offset);
+  // FilterBuilder::new_with_count (filter.rs:260-273): nulls -> false
+  if (predicate->validity && predicate->null_count != 0)
+    p->mask_valid = make_bitview(predicate->validity, predicate->validity_bit_offset);
+  else
+    p->mask_valid = BitView{nullptr, 0};
+  if (p->len <= 0) {
+    p->len = 0;
+    *out = p;
+    return AH_OK;
+  }
+  int64_t nchunks = ah_ceil_div(p->len, CHUNK_ROWS);
+  int64_t ngroups = ah_ceil_div(nchunks, GROUP_CHUNKS);
+  size_t b_chunk = ((size_t)nchunks * 4 + 255) & ~(size_t)255;
+  size_t b_gt = ((size_t)ngroups * 4 + 255) & ~(size_t)255;
+  size_t b_gp = ((size_t)ngroups * 8 + 255) & ~(size_t)255;
+  ah_status st = ah_pool_alloc(ctx, b_chunk + b_gt + b_gp + 256, &p->block);
+  if (st != AH_OK) {
+    delete p;
+    return st;
+  }
+  char* base = (char*)p->block;
+  p->chunk_prefix = (uint32_t*)base;
+  uint32_t* group_total = (uint32_t*)(base + b_chunk);
+  p->group_prefix = (unsigned long long*)(base + b_chunk + b_gt);
+  unsigned long long* total = (unsigned long long*)(base + b_chunk + b_gt + b_gp);
+  {
+    ah_prof_scope ps(ctx, "filter_count");
+    filter_count_kernel<<<(unsigned)ngroups, 1024, 0, ctx->stream>>>(p->mask, p->mask_valid, p->len,
+                                                                    p->chunk_prefix, group_total);
+    filter_group_scan_kernel<<<1, 1024, 0, ctx->stream>>>(group_total, ngroups, p->group_prefix,
+                                                          total);
+  }
+  hipError_t e = hipMemcpyAsync(ctx->pinned, total, 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    ah_pool_free(ctx, p->block);
+    delete p;
+    return ah_fail(ctx, AH_HIP_ERROR, "filter count failed: %s", hipGetErrorString(e));
+  }
+  p->count = (int64_t)ctx->pinned[0];
+  *out = p;
+  return AH_OK;
+}
+
+extern "C" int64_t ah_filter_predicate_count(const ah_filter_predicate* p) { return p ? p->count : 0; }
+
+extern "C" void ah_filter_predicate_free(ah_context* ctx, ah_filter_predicate* p) {
+  if (!p) return;
+  ah_pool_free(ctx, p->block);
+  delete p;
+}
+
+// compaction of one bit stream (Boolean values or a validity bitmap) by the
+// predicate: filter_bits (filter.rs:680-720).  Returns popcount of the result.
+static ah_status compact_bits(ah_context* ctx, const ah_filter_predicate* p, BitView src,
+                              uint8_t** out_bits, size_t* out_bytes, int64_t* set_bits) {
+  size_t bytes = ah_bitmap_bytes(p->count);
+  void* ob = nullptr;
+  AH_TRY(ah_out_alloc(ctx, bytes, &ob));
+  int64_t ntiles = ah_ceil_div(p->len, tile_rows(1));
+  uint32_t* tile_valid = nullptr;
+  ah_status st = ah_pool_alloc(ctx, (size_t)ntiles * 4 + 16, (void**)&tile_valid);
+  if (st != AH_OK) {
+    ah_out_free(ctx, ob, bytes);
+    return st;
+  }
+  hipMemsetAsync(ob, 0, bytes, ctx->stream);
+  ScatterArgs a{};
+  a.values = nullptr;
+  a.mask = p->mask;
+  a.mask_valid = p->mask_valid;
+  a.vvalid = src;
+  a.len = p->len;
+  a.chunk_prefix = p->chunk_prefix;
+  a.group_prefix = p->group_prefix;
+  a.out_values = nullptr;
+  a.out_valid = (unsigned long long*)ob;
+  a.tile_valid = tile_valid;
+  launch_scatter<true>(ctx, 0, a);
+  unsigned long long* tot = (unsigned long long*)(tile_valid + ((ntiles + 1) & ~1ll));
+  sum_u32_kernel<<<1, 1024, 0, ctx->stream>>>(tile_valid, ntiles, tot);
+  hipError_t e = hipMemcpyAsync(ctx->pinned, tot, 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  ah_pool_free(ctx, tile_valid);
+  if (e != hipSuccess) {
+    ah_out_free(ctx, ob, bytes);
+    return ah_fail(ctx, AH_HIP_ERROR, "filter_bits failed: %s", hipGetErrorString(e));
+  }
+  *set_bits = (int64_t)ctx->pinned[0];
+  *out_bits = (uint8_t*)ob;
+  *out_bytes = bytes;
+  return AH_OK;
+}
+
+extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_predicate* p,
+                                               const ah_array_view* values, ah_array_out* out) {
+  if (!ctx || !p || !values || !out) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  hipSetDevice(ctx->device);
+  // filter_array (filter.rs:535-541)
+  if (p->len > values->length)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT,
+                   "Filter predicate of length %lld is larger than target array of length %lld",
+                   (long long)p->len, (long long)values->length);
+  const int width = ah_type_width(values->type);
+  if (width < 0)
+    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "filter not supported for type %s",
+                   ah_type_name(values->type));
+  out->type = values->type;
+  const int64_t K = p->count;
+  // IterationStrategy::default_strategy (filter.rs:346-364)
+  if (p->len == 0 || K == 0) {  // None -> new_empty_array(data_type) :545
+    out->length = 0;
+    return AH_OK;
+  }
+  if (K == p->len) {  // All -> values.slice(0, count) :546 (zero-copy)
+    out->length = K;
+    out->values = const_cast<void*>(values->values);
+    out->values_bit_offset = values->values_bit_offset;
+    out->values_bytes = width ? K * width : 0;
+    out->flags = AH_OUT_BORROWED;
+    if (values->validity) {
+      int64_t nulls = 0;
+      if (K == values->length && values->null_count >= 0) {
+        nulls = values->null_count;
+      } else {
+        int64_t set = 0;
+        AH_TRY(ah_count_set_bits(ctx, values->validity, values->validity_bit_offset, K, &set));
+        nulls = K - set;
+      }
+      out->validity = const_cast<uint8_t*>(values->validity);
+      out->validity_bit_offset = values->validity_bit_offset;
+      out->null_count = nulls;
+    }
+    return AH_OK;
+  }
+
+  int64_t in_nulls = 0;
+  AH_TRY(ah_resolve_null_count(ctx, values, &in_nulls));
+  const bool has_valid = values->validity && in_nulls > 0;  // filter_nulls :512-517
+  BitView vvalid = has_valid ? make_bitview(values->validity, values->validity_bit_offset)
+                             : BitView{nullptr, 0};
+
+  if (values->type == AH_BOOL) {  // filter_boolean (filter.rs:723-729)
+    uint8_t* vb = nullptr;
+    size_t vbytes = 0;
+    int64_t set = 0;
+    AH_TRY(compact_bits(ctx, p, make_bitview(values->values, values->values_bit_offset), &vb,
+                        &vbytes, &set));
+    out->values = vb;
+    out->values_bytes = (int64_t)vbytes;
+    out->length = K;
+    if (has_valid) {
+      uint8_t* nb = nullptr;
+      size_t nbytes = 0;
+      int64_t nset = 0;
+      ah_status st = compact_bits(ctx, p, vvalid, &nb, &nbytes, &nset);
+      if (st != AH_OK) {
+        ah_array_release(ctx, out);
+        return st;
+      }
+      if (K - nset == 0) {
+        ah_out_free(ctx, nb, nbytes);
+      } else {
+        out->validity = nb;
+        out->validity_bytes = (int64_t)nbytes;
+        out->null_count = K - nset;
+      }
+    }
+    return AH_OK;
+  }
+
+  // filter_primitive (filter.rs:773-788)
+  const int T = tile_rows(width);
+  const int64_t ntiles = ah_ceil_div(p->len, T);
+  void* ov = nullptr;
+  size_t vbytes = (size_t)K * width;
+  AH_TRY(ah_out_alloc(ctx, vbytes, &ov));
+  void* ob = nullptr;
+  size_t bbytes = 0;
+  uint32_t* tile_valid = nullptr;
+  unsigned long long* tot = nullptr;
+  if (has_valid) {
+    bbytes = ah_bitmap_bytes(K);
+    ah_status st = ah_out_alloc(ctx, bbytes, &ob);
+    if (st == AH_OK) st = ah_pool_alloc(ctx, (size_t)ntiles * 4 + 16, (void**)&tile_valid);
+    if (st != AH_OK) {
+      ah_out_free(ctx, ov, vbytes);
+      ah_out_free(ctx, ob, bbytes);
+      return st;
+    }
+    tot = (unsigned long long*)(tile_valid + ((ntiles + 1) & ~1ll));
+    hipMemsetAsync(ob, 0, bbytes, ctx->stream);
+  }
+  ScatterArgs a{};
+  a.values = values->values;
+  a.mask = p->mask;
+  a.mask_valid = p->mask_valid;
+  a.vvalid = vvalid;
+  a.len = p->len;
+  a.chunk_prefix = p->chunk_prefix;
+  a.group_prefix = p->group_prefix;
+  a.out_values = ov;
+  a.out_valid = (unsigned long long*)ob;
+  a.tile_valid = tile_valid;
+  {
+    ah_prof_scope ps(ctx, "filter_scatter");
+    if (has_valid) launch_scatter<true>(ctx, width, a);
+    else launch_scatter<false>(ctx, width, a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && has_valid) {
+    sum_u32_kernel<<<1, 1024, 0, ctx->stream>>>(tile_valid, ntiles, tot);
+    e = hipMemcpyAsync(ctx->pinned, tot, 8, hipMemcpyDeviceToHost, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  ah_pool_free(ctx, tile_valid);
+  if (e != hipSuccess) {
+    ah_out_free(ctx, ov, vbytes);
+    ah_out_free(ctx, ob, bbytes);
+    return ah_fail(ctx, AH_HIP_ERROR, "filter scatter failed: %s", hipGetErrorString(e));
+  }
+  out->length = K;
+  out->values = ov;
+  out->values_bytes = (int64_t)vbytes;
+  if (has_valid) {
+    int64_t nulls = K - (int64_t)ctx->pinned[0];
+    if (nulls == 0) {  // filter_nulls :523-525 -> None
+      ah_out_free(ctx, ob, bbytes);
+    } else {
+      out->validity = (uint8_t*)ob;
+      out->validity_bytes = (int64_t)bbytes;
+      out->null_count = nulls;
+    }
+  }
+  return AH_OK;
+}
+
+extern "C" ah_status ah_filter(ah_context* ctx, const ah_array_view* values,
+                               const ah_array_view* predicate, ah_array_out* out) {
+  if (!ctx || !values || !predicate || !out) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  if (predicate->type == AH_BOOL && predicate->length > values->length)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT,
+                   "Filter predicate of length %lld is larger than target array of length %lld",
+                   (long long)predicate->length, (long long)values->length);
+  ah_filter_predicate* p = nullptr;
+  AH_TRY(ah_filter_predicate_build(ctx, predicate, &p));
+  ah_status st = ah_filter_predicate_apply(ctx, p, values, out);
+  ah_filter_predicate_free(ctx, p);
+  return st;
+}
+
+extern "C" ah_status ah_filter_record_batch(ah_context* ctx, int32_t n_columns,
+                                            const ah_array_view* columns,
+                                            const ah_array_view* predicate, ah_array_out* outs,
+                                            int64_t* out_rows) {
+  if (!ctx || !predicate || (n_columns > 0 && (!columns || !outs))) return AH_INVALID_ARGUMENT;
+  ah_filter_predicate* p = nullptr;
+  AH_TRY(ah_filter_predicate_build(ctx, predicate, &p));
+  ah_status st = AH_OK;
+  for (int32_t c = 0; c < n_columns; ++c) ah_out_init(&outs[c]);
+  for (int32_t c = 0; c < n_columns && st == AH_OK; ++c)
+    st = ah_filter_predicate_apply(ctx, p, &columns[c], &outs[c]);
+  if (st != AH_OK)
+    for (int32_t c = 0; c < n_columns; ++c) ah_array_release(ctx, &outs[c]);
+  if (out_rows) *out_rows = p->count;  // RecordBatch row_count = predicate.count (filter.rs:476)
+  ah_filter_predicate_free(ctx, p);
+  return st;
+}

@@ -1,0 +1,256 @@
+/*
+ * arrow_hip.h — C ABI of the MI355X-native columnar compute hot path.
+ *
+ * This is the drop-in boundary behind arrow-rs's `arrow::compute::kernels`
+ * function shapes (reference: arrow/src/compute/kernels.rs:20-27).  The
+ * reference has no FFI boundary around its kernels; the two ABI-stable
+ * surfaces it does define are foreign buffer ownership
+ * (arrow-buffer/src/buffer/immutable.rs:170-176 `Buffer::from_custom_allocation`)
+ * and the Arrow C Data Interface (arrow-data/src/ffi.rs:37-66).  A Rust shim
+ *  wraps device buffers returned from here with
+ * `from_custom_allocation` and never reads device bytes on the host: every
+ * entry point therefore returns `length` and `null_count` explicitly.
+ *
+ * Conventions
+ *  - all `values` / `validity` / `offsets` pointers are DEVICE pointers (HBM);
+ *  - bitmaps are LSB-first bit-packed with an arbitrary bit offset
+ *    (arrow-buffer/src/buffer/boolean.rs:97-104); validity == NULL means
+ *    "no nulls"; 1 = valid;
+ *  - inputs are borrowed for the duration of the call; outputs are freshly
+ *    allocated through the context allocator and owned by the caller until
+ *    `ah_array_release` (exception: AH_OUT_BORROWED zero-copy fast paths,
+ *    reference filter.rs:546 `values.slice(0, count)`);
+ *  - every entry point is synchronous at return (results usable immediately),
+ *    re-entrant across contexts; one context must not be used from two threads
+ *    at once (the reference kernels are pure functions over Send+Sync arrays —
+ *    use one context per calling thread);
+ *  - errors: integer status mirroring `ArrowError` variants
+ *    (arrow-schema/src/error.rs:26-69) + `ah_last_error()` reproducing the
+ *    reference's message text; reference *panics* map to AH_PANIC.
+ */
+#ifndef ARROW_HIP_H
+#define ARROW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AH_API __attribute__((visibility("default")))
+
+/* ---------------------------------------------------------------- status */
+typedef int32_t ah_status;
+enum {
+  AH_OK = 0,
+  AH_INVALID_ARGUMENT = 1,    /* ArrowError::InvalidArgumentError */
+  AH_COMPUTE_ERROR = 2,       /* ArrowError::ComputeError */
+  AH_ARITHMETIC_OVERFLOW = 3, /* ArrowError::ArithmeticOverflow */
+  AH_DIVIDE_BY_ZERO = 4,      /* ArrowError::DivideByZero */
+  AH_CAST_ERROR = 5,          /* ArrowError::CastError */
+  AH_OFFSET_OVERFLOW = 6,     /* "byte array offset overflow" (a panic in the ref,
+                                 arrow-array/src/builder/generic_bytes_builder.rs:86-87) */
+  AH_NOT_YET_IMPLEMENTED = 7, /* ArrowError::NotYetImplemented */
+  AH_PANIC = 100,             /* the reference would panic!(); message = panic text */
+  AH_HIP_ERROR = 101,         /* runtime failure (no reference analogue) */
+  AH_OUT_OF_MEMORY = 102
+};
+
+/* ----------------------------------------------------------------- types */
+/* Physical layouts only: logical types that share a layout (Date32, Timestamp,
+ * Duration, Decimal128...) are preserved by the host wrapper exactly as the
+ * reference preserves `data_type` (filter.rs:783-787, take.rs:414). */
+typedef int32_t ah_type;
+enum {
+  AH_BOOL = 1, /* bit-packed values */
+  AH_INT8 = 2, AH_INT16 = 3, AH_INT32 = 4, AH_INT64 = 5,
+  AH_UINT8 = 6, AH_UINT16 = 7, AH_UINT32 = 8, AH_UINT64 = 9,
+  AH_FLOAT32 = 10, AH_FLOAT64 = 11,
+  AH_FIXED16 = 12, /* 16-byte natives: i128 / Decimal128 / IntervalMonthDayNano */
+  AH_FIXED32 = 13, /* 32-byte natives: i256 / Decimal256 */
+  AH_UTF8 = 14,       /* i32 offsets (output of cast only) */
+  AH_LARGE_UTF8 = 15, /* i64 offsets (output of cast only) */
+  AH_FLOAT16 = 16     /* filter/take/concat only (bit copy) */
+};
+
+/* Borrowed view of a PrimitiveArray / BooleanArray living in HBM
+ * (reference: arrow-array/src/array/primitive_array.rs:596-601,
+ *  arrow-array/src/array/boolean_array.rs:68). */
+typedef struct ah_array_view {
+  ah_type type;
+  int64_t length;              /* rows */
+  int64_t null_count;          /* >=0 known; -1 = unknown, the library counts */
+  const void* values;          /* primitives: pointer ALREADY advanced by the slice
+                                  offset (ScalarBuffer semantics, scalar.rs:188-209),
+                                  element-aligned.  AH_BOOL: bit-packed base. */
+  int64_t values_bit_offset;   /* AH_BOOL only */
+  const uint8_t* validity;     /* NULL = no nulls */
+  int64_t validity_bit_offset;
+} ah_array_view;
+
+enum { AH_OUT_BORROWED = 1 /* buffers alias the input (zero-copy slice) */ };
+
+/* Owned result.  Freshly produced bitmaps start at bit offset 0. */
+typedef struct ah_array_out {
+  ah_type type;
+  int64_t length;
+  int64_t null_count;
+  void* values;            /* primitives: values; AH_BOOL: bit-packed; UTF8: bytes */
+  int64_t values_bytes;
+  int64_t values_bit_offset;   /* AH_BOOL only; 0 unless AH_OUT_BORROWED */
+  uint8_t* validity;       /* NULL when the result carries no null buffer */
+  int64_t validity_bytes;
+  int64_t validity_bit_offset; /* 0 unless AH_OUT_BORROWED */
+  void* offsets;           /* AH_UTF8 / AH_LARGE_UTF8 only: length+1 offsets */
+  int64_t offsets_bytes;
+  int32_t flags;
+} ah_array_out;
+
+/* --------------------------------------------------------------- context */
+typedef struct ah_context ah_context;
+typedef void* (*ah_alloc_fn)(void* user, size_t bytes); /* returns device ptr, 256B aligned */
+typedef void (*ah_free_fn)(void* user, void* ptr, size_t bytes);
+
+AH_API ah_status ah_context_create(int device, ah_context** out);
+AH_API void ah_context_destroy(ah_context* ctx);
+/* Route OUTPUT allocations through the host's allocator (the hook a Rust host
+ * uses to own results as `Buffer::from_custom_allocation`); NULL restores the
+ * built-in pooled hipMalloc allocator. */
+AH_API void ah_context_set_allocator(ah_context* ctx, ah_alloc_fn a, ah_free_fn f, void* user);
+/* Launch on a caller-provided hipStream_t (NULL = the context's own stream). */
+AH_API void ah_context_set_stream(ah_context* ctx, void* hip_stream);
+AH_API void* ah_context_stream(ah_context* ctx);
+AH_API const char* ah_last_error(ah_context* ctx);
+AH_API void ah_array_release(ah_context* ctx, ah_array_out* out);
+AH_API const char* ah_version(void);
+
+/* raw device memory helpers for hosts without their own HIP bindings */
+AH_API ah_status ah_device_alloc(ah_context* ctx, size_t bytes, void** out);
+AH_API void ah_device_free(ah_context* ctx, void* ptr);
+AH_API ah_status ah_memcpy_htod(ah_context* ctx, void* dst, const void* src, size_t bytes);
+AH_API ah_status ah_memcpy_dtoh(ah_context* ctx, void* dst, const void* src, size_t bytes);
+AH_API ah_status ah_memset(ah_context* ctx, void* dst, int value, size_t bytes);
+AH_API ah_status ah_synchronize(ah_context* ctx);
+AH_API void ah_pool_trim(ah_context* ctx); /* hipFree everything cached in the pool */
+
+/* ---------------------------------------------------------------- filter */
+/* arrow_select::filter::filter (arrow-select/src/filter.rs:201).
+ * predicate must be AH_BOOL; predicate nulls select nothing (filter.rs:167-171);
+ * predicate.length <= values.length else AH_INVALID_ARGUMENT with the text of
+ * filter.rs:537-541.  values may be any primitive type or AH_BOOL. */
+AH_API ah_status ah_filter(ah_context* ctx, const ah_array_view* values,
+                           const ah_array_view* predicate, ah_array_out* out);
+
+/* FilterBuilder::new(..).optimize().build() (filter.rs:256-324): count once,
+ * keep per-tile offsets on device, apply to many columns. */
+typedef struct ah_filter_predicate ah_filter_predicate;
+AH_API ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_view* predicate,
+                                           ah_filter_predicate** out);
+AH_API int64_t ah_filter_predicate_count(const ah_filter_predicate* p); /* FilterPredicate::count :481 */
+AH_API ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_predicate* p,
+                                           const ah_array_view* values, ah_array_out* out);
+AH_API void ah_filter_predicate_free(ah_context* ctx, ah_filter_predicate* p);
+/* filter_record_batch (filter.rs:225): one predicate, n columns. */
+AH_API ah_status ah_filter_record_batch(ah_context* ctx, int32_t n_columns,
+                                        const ah_array_view* columns,
+                                        const ah_array_view* predicate,
+                                        ah_array_out* outs, int64_t* out_rows);
+
+/* ------------------------------------------------------------------ take */
+/* arrow_select::take::take (arrow-select/src/take.rs:89).  indices.type is any
+ * of the 8 integer types; i32/i64 are reinterpreted as u32/u64, 8/16-bit are
+ * widened with `as u32` (take.rs:1030-1084).  check_bounds mirrors
+ * TakeOptions (take.rs:388-394): AH_COMPUTE_ERROR with the text of take.rs:186;
+ * unchecked OOB => AH_PANIC with the reference's panic text. */
+AH_API ah_status ah_take(ah_context* ctx, const ah_array_view* values,
+                         const ah_array_view* indices, int32_t check_bounds,
+                         ah_array_out* out);
+
+/* ----------------------------------------------------------------- arith */
+typedef int32_t ah_arith_op;
+enum {
+  AH_ADD = 0, AH_ADD_WRAPPING = 1, AH_SUB = 2, AH_SUB_WRAPPING = 3,
+  AH_MUL = 4, AH_MUL_WRAPPING = 5, AH_DIV = 6, AH_REM = 7
+};
+/* arrow_arith::numeric::{add,add_wrapping,sub,sub_wrapping,mul,mul_wrapping,div,rem}
+ * (arrow-arith/src/numeric.rs:36-81).  A Datum is (array, is_scalar)
+ * (arrow-array/src/scalar.rs:78-98): scalars are length-1 views. */
+AH_API ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op,
+                                 const ah_array_view* lhs, int32_t lhs_is_scalar,
+                                 const ah_array_view* rhs, int32_t rhs_is_scalar,
+                                 ah_array_out* out);
+/* neg / neg_wrapping (numeric.rs:103,181) */
+AH_API ah_status ah_arith_neg(ah_context* ctx, const ah_array_view* values, int32_t wrapping,
+                              ah_array_out* out);
+
+/* ------------------------------------------------------------------- cmp */
+typedef int32_t ah_cmp_op;
+enum {
+  AH_EQ = 0, AH_NEQ = 1, AH_LT = 2, AH_LT_EQ = 3, AH_GT = 4, AH_GT_EQ = 5,
+  AH_DISTINCT = 6, AH_NOT_DISTINCT = 7
+};
+/* arrow_ord::cmp::{eq,neq,lt,lt_eq,gt,gt_eq,distinct,not_distinct}
+ * (arrow-ord/src/cmp.rs:79-202).  Result type AH_BOOL; floats compare in IEEE
+ * totalOrder (arrow-array/src/arithmetic.rs:400-410). */
+AH_API ah_status ah_compare(ah_context* ctx, ah_cmp_op op,
+                            const ah_array_view* lhs, int32_t lhs_is_scalar,
+                            const ah_array_view* rhs, int32_t rhs_is_scalar,
+                            ah_array_out* out);
+
+/* ------------------------------------------------------------------ cast */
+/* arrow_cast::cast_with_options (arrow-cast/src/cast/mod.rs:790), restricted to
+ * numeric<->numeric (mod.rs:1578-1697 via cast_numeric_arrays :2550) and
+ * Float64/Float32/integers -> Utf8 / LargeUtf8 (mod.rs:1552-1553 via
+ * value_to_string, cast/string.rs:21-39).  safe mirrors CastOptions.safe. */
+AH_API ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_type to_type,
+                         int32_t safe, ah_array_out* out);
+AH_API int32_t ah_can_cast_types(ah_type from, ah_type to); /* cast/mod.rs:115 subset */
+
+/* ---------------------------------------------------------------- concat */
+/* arrow_select::concat::concat for primitives / booleans (concat.rs:334-343,
+ * :495) — also the multi-GPU reassembly primitive (bit-shifted bitmap merge,
+ * reference analogue arrow-buffer/src/util/bit_mask.rs:33 set_bits). */
+AH_API ah_status ah_concat(ah_context* ctx, int32_t n, const ah_array_view* pieces,
+                           ah_array_out* out);
+/* OR `len` bits from (src, src_bit_offset) into dst at dst_bit_offset; dst bits
+ * in range must be zero.  Returns the number of set bits copied. */
+AH_API ah_status ah_bitmap_set_bits(ah_context* ctx, uint8_t* dst, int64_t dst_bit_offset,
+                                    const uint8_t* src, int64_t src_bit_offset, int64_t len,
+                                    int64_t* set_bits);
+
+/* ------------------------------------------------------------- utilities */
+/* BooleanBuffer::count_set_bits (arrow-buffer/src/buffer/boolean.rs) on device. */
+AH_API ah_status ah_count_set_bits(ah_context* ctx, const uint8_t* bits, int64_t bit_offset,
+                                   int64_t len, int64_t* count);
+/* Kernel timing with HIP events on the context stream (for bench.py's roofline
+ * leg): when enabled, every launch of the named hot kernels is bracketed by
+ * hipEventRecord on the launch stream. */
+AH_API void ah_profile_enable(ah_context* ctx, int32_t on);
+AH_API void ah_profile_reset(ah_context* ctx);
+AH_API ah_status ah_profile_get(ah_context* ctx, const char* kernel, double* total_ms,
+                                int64_t* launches);
+
+/* Counter-based synthetic data: splitmix64 of (seed, row) so
+ * the CPU oracle reproduces any window bit-for-bit.  Test/bench support only. */
+AH_API ah_status ah_gen_uniform_i64(ah_context* ctx, int64_t* dst, int64_t n, uint64_t seed,
+                                    int64_t lo, int64_t hi_inclusive, int64_t row0);
+AH_API ah_status ah_gen_uniform_i32(ah_context* ctx, int32_t* dst, int64_t n, uint64_t seed,
+                                    int64_t row0);
+AH_API ah_status ah_gen_uniform_f64(ah_context* ctx, double* dst, int64_t n, uint64_t seed,
+                                    double lo, double hi, int64_t row0);
+AH_API ah_status ah_gen_uniform_u32(ah_context* ctx, uint32_t* dst, int64_t n, uint64_t seed,
+                                    uint32_t bound, int64_t row0);
+/* Bernoulli(p_true) bits, LSB-first, written at bit offset 0 of dst
+ * (ceil(n/64)*8 bytes; padding bits zero). */
+AH_API ah_status ah_gen_bernoulli_bits(ah_context* ctx, uint8_t* dst, int64_t n, uint64_t seed,
+                                       double p_true, int64_t row0);
+/* dst[i] = 0 where validity bit i is 0 (null slots hold 0 like the ref's
+ * FromIterator<Option<T>> bench arrays, arrow/src/util/bench_util.rs:45-60) */
+AH_API ah_status ah_zero_null_slots(ah_context* ctx, void* values, int32_t byte_width,
+                                    const uint8_t* validity, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARROW_HIP_H */

@@ -1,0 +1,1502 @@
+// oracle.cpp — CPU restatement of the arrow-rs compute hot path (see oracle.h).
+// TEST INFRASTRUCTURE ONLY: parity checker + bench.py cpu_baseline ("port").
+// Every function cites the reference file:line (under /root/reference) whose
+// algorithm and edge semantics it follows.  Scalar, single-threaded, built
+// -O3 -march=native so the compiler auto-vectorises the same loops LLVM does
+// for the reference (arrow/README.md:147-170).
+#include "oracle.h"
+
+#include <algorithm>
+#include <charconv>
+#include <cinttypes>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int32_t fail(int32_t st, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return st;
+}
+
+int type_width(int32_t t) {
+  switch (t) {
+    case ORC_BOOL: return 0;
+    case ORC_INT8: case ORC_UINT8: return 1;
+    case ORC_INT16: case ORC_UINT16: case ORC_FLOAT16: return 2;
+    case ORC_INT32: case ORC_UINT32: case ORC_FLOAT32: return 4;
+    case ORC_INT64: case ORC_UINT64: case ORC_FLOAT64: return 8;
+    case ORC_FIXED16: return 16;
+    case ORC_FIXED32: return 32;
+    default: return -1;
+  }
+}
+const char* type_name(int32_t t) {
+  switch (t) {
+    case ORC_BOOL: return "Boolean";
+    case ORC_INT8: return "Int8"; case ORC_INT16: return "Int16";
+    case ORC_INT32: return "Int32"; case ORC_INT64: return "Int64";
+    case ORC_UINT8: return "UInt8"; case ORC_UINT16: return "UInt16";
+    case ORC_UINT32: return "UInt32"; case ORC_UINT64: return "UInt64";
+    case ORC_FLOAT16: return "Float16"; case ORC_FLOAT32: return "Float32";
+    case ORC_FLOAT64: return "Float64";
+    case ORC_FIXED16: return "FixedWidth16"; case ORC_FIXED32: return "FixedWidth32";
+    case ORC_UTF8: return "Utf8"; case ORC_LARGE_UTF8: return "LargeUtf8";
+    default: return "?";
+  }
+}
+bool is_integer(int32_t t) { return t >= ORC_INT8 && t <= ORC_UINT64; }
+bool is_signed_int(int32_t t) { return t >= ORC_INT8 && t <= ORC_INT64; }
+
+// ----------------------------------------------------------------- bit_util
+// arrow-buffer/src/util/bit_util.rs:63 get_bit_raw / set_bit_raw
+inline bool get_bit(const uint8_t* d, int64_t i) { return (d[i >> 3] >> (i & 7)) & 1; }
+inline void set_bit(uint8_t* d, int64_t i) { d[i >> 3] |= (uint8_t)(1u << (i & 7)); }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t bitmap_bytes(int64_t bits) { return (size_t)ceil_div(bits, 64) * 8; }
+
+// UnalignedBitChunk::new (arrow-buffer/src/util/bit_chunk_iterator.rs:41-132):
+// optional prefix word, 8-byte-aligned middle words, optional suffix word, with
+// the lead/trailing padding bits masked off.
+struct UnalignedBitChunk {
+  int64_t lead_padding = 0, trailing_padding = 0;
+  bool has_prefix = false, has_suffix = false;
+  uint64_t prefix = 0, suffix = 0;
+  const uint64_t* chunks = nullptr;
+  int64_t nchunks = 0;
+
+  static uint64_t read_u64(const uint8_t* p, size_t n) {  // :176-181
+    uint64_t v = 0;
+    memcpy(&v, p, n < 8 ? n : 8);
+    return v;
+  }
+  static uint64_t prefix_mask(int64_t lead) { return ~((1ull << lead) - 1); }  // :184-186
+  static void suffix_mask(int64_t len, int64_t lead, uint64_t* mask, int64_t* trailing) {  // :189-199
+    int64_t trailing_bits = (len + lead) % 64;
+    if (trailing_bits == 0) {
+      *mask = ~0ull;
+      *trailing = 0;
+      return;
+    }
+    *trailing = 64 - trailing_bits;
+    *mask = (1ull << trailing_bits) - 1;
+  }
+
+  UnalignedBitChunk(const uint8_t* buffer, int64_t offset, int64_t len) {
+    if (len == 0) return;
+    int64_t byte_offset = offset / 8, offset_padding = offset % 8;
+    int64_t bytes_len = ceil_div(len + offset_padding, 8);
+    const uint8_t* buf = buffer + byte_offset;
+    uint64_t pmask = prefix_mask(offset_padding);
+    if (bytes_len <= 8) {
+      uint64_t smask;
+      suffix_mask(len, offset_padding, &smask, &trailing_padding);
+      prefix = read_u64(buf, (size_t)bytes_len) & smask & pmask;
+      has_prefix = true;
+      lead_padding = offset_padding;
+      return;
+    }
+    if (bytes_len <= 16) {
+      uint64_t smask;
+      suffix_mask(len, offset_padding, &smask, &trailing_padding);
+      prefix = read_u64(buf, 8) & pmask;
+      suffix = read_u64(buf + 8, (size_t)(bytes_len - 8)) & smask;
+      has_prefix = has_suffix = true;
+      lead_padding = offset_padding;
+      return;
+    }
+    // align_to::<u64>()
+    uintptr_t addr = (uintptr_t)buf;
+    size_t pre = (size_t)((8 - (addr & 7)) & 7);
+    size_t mid = ((size_t)bytes_len - pre) / 8;
+    size_t suf = (size_t)bytes_len - pre - mid * 8;
+    chunks = (const uint64_t*)(buf + pre);
+    nchunks = (int64_t)mid;
+    int64_t alignment_padding = 0;
+    if (offset_padding == 0 && pre == 0) {
+      // no prefix
+    } else if (pre == 0) {
+      prefix = chunks[0] & pmask;
+      has_prefix = true;
+      chunks += 1;
+      nchunks -= 1;
+    } else {
+      alignment_padding = (int64_t)(8 - pre) * 8;
+      prefix = (read_u64(buf, pre) & pmask) << alignment_padding;
+      has_prefix = true;
+    }
+    lead_padding = offset_padding + alignment_padding;
+    uint64_t smask;
+    suffix_mask(len, lead_padding, &smask, &trailing_padding);
+    if (trailing_padding == 0) {
+      // the suffix bytes (if any) cannot exist when trailing_padding == 0
+    } else if (suf == 0) {
+      suffix = chunks[nchunks - 1] & smask;
+      has_suffix = true;
+      nchunks -= 1;
+    } else {
+      suffix = read_u64(buf + pre + mid * 8, suf) & smask;
+      has_suffix = true;
+    }
+  }
+  int64_t nwords() const { return (has_prefix ? 1 : 0) + nchunks + (has_suffix ? 1 : 0); }
+  uint64_t word(int64_t i) const {
+    if (has_prefix) {
+      if (i == 0) return prefix;
+      i -= 1;
+    }
+    if (i < nchunks) return chunks[i];
+    return suffix;
+  }
+  int64_t count_ones() const {  // :169-171
+    int64_t c = 0;
+    if (has_prefix) c += __builtin_popcountll(prefix);
+    for (int64_t i = 0; i < nchunks; ++i) c += __builtin_popcountll(chunks[i]);
+    if (has_suffix) c += __builtin_popcountll(suffix);
+    return c;
+  }
+};
+
+// BitIndexIterator (arrow-buffer/src/util/bit_iterator.rs:284-324)
+struct BitIndexIterator {
+  UnalignedBitChunk c;
+  int64_t wi = 0, nw;
+  uint64_t current_chunk;
+  int64_t chunk_offset;
+  BitIndexIterator(const uint8_t* b, int64_t off, int64_t len) : c(b, off, len) {
+    nw = c.nwords();
+    current_chunk = nw > 0 ? c.word(0) : 0;
+    wi = 1;
+    chunk_offset = -c.lead_padding;
+  }
+  inline bool next(int64_t* out) {
+    for (;;) {
+      if (current_chunk != 0) {
+        int bit_pos = __builtin_ctzll(current_chunk);
+        current_chunk &= current_chunk - 1;
+        *out = chunk_offset + bit_pos;
+        return true;
+      }
+      if (wi >= nw) return false;
+      current_chunk = c.word(wi++);
+      chunk_offset += 64;
+    }
+  }
+};
+
+// BitSliceIterator (arrow-buffer/src/util/bit_iterator.rs:188-277)
+struct BitSliceIterator {
+  UnalignedBitChunk c;
+  int64_t wi = 0, nw, len;
+  int64_t current_offset;
+  uint64_t current_chunk;
+  BitSliceIterator(const uint8_t* b, int64_t off, int64_t l) : c(b, off, l), len(l) {
+    nw = c.nwords();
+    current_offset = -c.lead_padding;
+    current_chunk = nw > 0 ? c.word(0) : 0;
+    wi = 1;
+  }
+  bool advance_to_set_bit(int64_t* chunk_off, int* bit) {
+    for (;;) {
+      if (current_chunk != 0) {
+        *bit = __builtin_ctzll(current_chunk);
+        *chunk_off = current_offset;
+        return true;
+      }
+      if (wi >= nw) return false;
+      current_chunk = c.word(wi++);
+      current_offset += 64;
+    }
+  }
+  bool next(int64_t* start, int64_t* end) {
+    if (len == 0) return false;
+    int64_t start_chunk;
+    int start_bit;
+    if (!advance_to_set_bit(&start_chunk, &start_bit)) return false;
+    current_chunk |= (1ull << start_bit) - 1;
+    for (;;) {
+      if (current_chunk != ~0ull) {
+        int end_bit = __builtin_ctzll(~current_chunk);  // trailing_ones
+        current_chunk &= ~((1ull << end_bit) - 1);
+        *start = start_chunk + start_bit;
+        *end = current_offset + end_bit;
+        return true;
+      }
+      if (wi < nw) {
+        current_chunk = c.word(wi++);
+        current_offset += 64;
+      } else {
+        *start = start_chunk + start_bit;
+        *end = len;
+        len = 0;
+        return true;
+      }
+    }
+  }
+};
+
+int64_t count_set_bits(const uint8_t* bits, int64_t off, int64_t len) {
+  if (!bits) return len;
+  return UnalignedBitChunk(bits, off, len).count_ones();
+}
+
+// BooleanBufferBuilder::append_packed_range (arrow-buffer/src/builder/boolean.rs:287-301)
+// via bit_mask::set_bits (arrow-buffer/src/util/bit_mask.rs:33): copy `len` bits.
+void copy_bits(uint8_t* dst, int64_t dst_off, const uint8_t* src, int64_t src_off, int64_t len) {
+  for (int64_t i = 0; i < len; ++i)
+    if (get_bit(src, src_off + i)) set_bit(dst, dst_off + i);
+}
+
+void* xalloc(size_t n) {
+  void* p = calloc(n ? n : 8, 1);
+  if (!p) abort();
+  return p;
+}
+
+void out_init(orc_out* o) { memset(o, 0, sizeof *o); }
+
+int64_t resolve_nulls(const orc_view* v) {
+  if (!v->validity) return 0;
+  if (v->null_count >= 0) return v->null_count;
+  return v->length - count_set_bits(v->validity, v->validity_bit_offset, v->length);
+}
+
+// ------------------------------------------------------------------- filter
+enum Strategy { S_NONE, S_ALL, S_SLICES, S_INDICES };
+
+struct Predicate {  // FilterPredicate (arrow-select/src/filter.rs:442-449)
+  std::vector<uint8_t> owned;
+  const uint8_t* bits = nullptr;
+  int64_t off = 0, len = 0, count = 0;
+  Strategy strategy = S_NONE;
+};
+
+// BooleanArray::true_count (arrow-array/src/array/boolean_array.rs:175-187)
+int64_t true_count(const orc_view* p) {
+  if (p->length == 0) return 0;
+  if (!p->validity) return count_set_bits((const uint8_t*)p->values, p->values_bit_offset, p->length);
+  int64_t c = 0;
+  const uint8_t* v = (const uint8_t*)p->values;
+  for (int64_t i = 0; i < p->length; ++i)
+    c += get_bit(v, p->values_bit_offset + i) & get_bit(p->validity, p->validity_bit_offset + i);
+  return c;
+}
+
+// FilterBuilder::new_with_count (filter.rs:260-273) + default_strategy (:346-364)
+void build_predicate(const orc_view* p, Predicate* out) {
+  out->len = p->length;
+  out->count = true_count(p);
+  if (p->validity && resolve_nulls(p) != 0) {
+    // prep_null_mask_filter (filter.rs:167-171): values & validity, offset 0
+    out->owned.assign(bitmap_bytes(p->length), 0);
+    const uint8_t* v = (const uint8_t*)p->values;
+    for (int64_t i = 0; i < p->length; ++i)
+      if (get_bit(v, p->values_bit_offset + i) && get_bit(p->validity, p->validity_bit_offset + i))
+        set_bit(out->owned.data(), i);
+    out->bits = out->owned.data();
+    out->off = 0;
+  } else {
+    out->bits = (const uint8_t*)p->values;
+    out->off = p->values_bit_offset;
+  }
+  if (out->len == 0 || out->count == 0) out->strategy = S_NONE;
+  else if (out->count == out->len) out->strategy = S_ALL;
+  else if ((double)out->count / (double)out->len > 0.8) out->strategy = S_SLICES;  // :43
+  else out->strategy = S_INDICES;
+}
+
+// filter_native (filter.rs:731-770)
+template <typename T>
+void filter_native_t(const T* values, const Predicate& p, T* out) {
+  if (p.strategy == S_SLICES) {
+    BitSliceIterator it(p.bits, p.off, p.len);
+    int64_t s, e;
+    T* o = out;
+    while (it.next(&s, &e)) {
+      memcpy(o, values + s, (size_t)(e - s) * sizeof(T));
+      o += e - s;
+    }
+  } else {
+    BitIndexIterator it(p.bits, p.off, p.len);
+    int64_t idx = 0;
+    for (int64_t i = 0; i < p.count; ++i) {  // IndexIterator is trusted-len (:84-138)
+      it.next(&idx);
+      out[i] = values[idx];
+    }
+  }
+}
+struct B16 { uint64_t a, b; };
+struct B32 { uint64_t a, b, c, d; };
+
+void filter_native(const void* values, int width, const Predicate& p, void* out) {
+  switch (width) {
+    case 1: filter_native_t((const uint8_t*)values, p, (uint8_t*)out); break;
+    case 2: filter_native_t((const uint16_t*)values, p, (uint16_t*)out); break;
+    case 4: filter_native_t((const uint32_t*)values, p, (uint32_t*)out); break;
+    case 8: filter_native_t((const uint64_t*)values, p, (uint64_t*)out); break;
+    case 16: filter_native_t((const B16*)values, p, (B16*)out); break;
+    case 32: filter_native_t((const B32*)values, p, (B32*)out); break;
+  }
+}
+
+// filter_bits (filter.rs:680-720): K bits out, offset 0
+void filter_bits(const uint8_t* src, int64_t src_off, const Predicate& p, uint8_t* out) {
+  if (p.strategy == S_SLICES) {
+    BitSliceIterator it(p.bits, p.off, p.len);
+    int64_t s, e, o = 0;
+    while (it.next(&s, &e)) {
+      copy_bits(out, o, src, src_off + s, e - s);
+      o += e - s;
+    }
+  } else {
+    BitIndexIterator it(p.bits, p.off, p.len);
+    int64_t idx = 0;
+    uint64_t* words = (uint64_t*)out;
+    uint64_t packed = 0;
+    for (int64_t i = 0; i < p.count; ++i) {  // from_trusted_len_iter_bool
+      it.next(&idx);
+      packed |= (uint64_t)get_bit(src, src_off + idx) << (i & 63);
+      if ((i & 63) == 63) {
+        words[i >> 6] = packed;
+        packed = 0;
+      }
+    }
+    if (p.count & 63) words[p.count >> 6] = packed;
+  }
+}
+
+// FilterPredicate::filter_nulls (filter.rs:512-532)
+void filter_nulls(const orc_view* values, const Predicate& p, orc_out* out) {
+  if (!values->validity) return;
+  if (resolve_nulls(values) == 0) return;
+  size_t bytes = bitmap_bytes(p.count);
+  uint8_t* nb = (uint8_t*)xalloc(bytes);
+  filter_bits(values->validity, values->validity_bit_offset, p, nb);
+  int64_t null_count = p.count - count_set_bits(nb, 0, p.count);
+  if (null_count == 0) {
+    free(nb);
+    return;
+  }
+  out->validity = nb;
+  out->validity_bytes = (int64_t)bytes;
+  out->null_count = null_count;
+}
+
+int32_t filter_impl(const orc_view* values, const orc_view* pred, orc_out* out) {
+  out_init(out);
+  if (pred->type != ORC_BOOL)
+    return fail(ORC_INVALID_ARGUMENT, "filter predicate must be Boolean, got %s", type_name(pred->type));
+  // filter_array (filter.rs:535-541) — checked before anything else observable
+  if (pred->length > values->length)
+    return fail(ORC_INVALID_ARGUMENT,
+                "Filter predicate of length %lld is larger than target array of length %lld",
+                (long long)pred->length, (long long)values->length);
+  int width = type_width(values->type);
+  if (width < 0) return fail(ORC_NOT_YET_IMPLEMENTED, "filter not supported for type %s", type_name(values->type));
+  Predicate p;
+  build_predicate(pred, &p);
+  out->type = values->type;
+  if (p.strategy == S_NONE) {  // :545 new_empty_array
+    out->length = 0;
+    return ORC_OK;
+  }
+  if (p.strategy == S_ALL) {  // :546 values.slice(0, count)
+    out->length = p.count;
+    out->values = const_cast<void*>(values->values);
+    out->values_bit_offset = values->values_bit_offset;
+    out->values_bytes = width ? p.count * width : 0;
+    out->flags = 1;
+    if (values->validity) {
+      out->validity = const_cast<uint8_t*>(values->validity);
+      out->validity_bit_offset = values->validity_bit_offset;
+      out->null_count = p.count - count_set_bits(values->validity, values->validity_bit_offset, p.count);
+    }
+    return ORC_OK;
+  }
+  out->length = p.count;
+  if (values->type == ORC_BOOL) {  // filter_boolean (:723-729)
+    size_t bytes = bitmap_bytes(p.count);
+    out->values = xalloc(bytes);
+    out->values_bytes = (int64_t)bytes;
+    filter_bits((const uint8_t*)values->values, values->values_bit_offset, p, (uint8_t*)out->values);
+  } else {  // filter_primitive (:773-788)
+    out->values = xalloc((size_t)p.count * width);
+    out->values_bytes = p.count * width;
+    filter_native(values->values, width, p, out->values);
+  }
+  filter_nulls(values, p, out);
+  return ORC_OK;
+}
+
+// --------------------------------------------------------------------- take
+template <typename I> inline uint64_t to_index(I v) {  // ToIndices (take.rs:1030-1084)
+  if constexpr (sizeof(I) <= 2) {
+    if constexpr (std::is_signed<I>::value) return (uint32_t)(int32_t)v;  // `as u32` sign-extends
+    else return (uint32_t)v;
+  } else if constexpr (sizeof(I) == 4) return (uint32_t)v;  // reinterpret
+  else return (uint64_t)v;
+}
+
+struct TakePanic {
+  bool hit = false;
+  std::string msg;
+};
+
+// take_native (take.rs:432-457)
+template <typename T, typename I>
+void take_native(const T* values, int64_t values_len, const I* idx, int64_t n, const uint8_t* ivalid,
+                 int64_t ivalid_off, int64_t idx_nulls, T* out, TakePanic* panic) {
+  if (ivalid && idx_nulls > 0) {
+    for (int64_t i = 0; i < n; ++i) {
+      uint64_t ix = to_index(idx[i]);
+      if (ix < (uint64_t)values_len) out[i] = values[ix];
+      else if (!get_bit(ivalid, ivalid_off + i)) out[i] = T{};
+      else {
+        panic->hit = true;
+        char b[64];
+        snprintf(b, sizeof b, "Out-of-bounds index %llu", (unsigned long long)ix);
+        panic->msg = b;
+        return;
+      }
+    }
+  } else {
+    for (int64_t i = 0; i < n; ++i) {
+      uint64_t ix = to_index(idx[i]);
+      if (ix >= (uint64_t)values_len) {
+        panic->hit = true;
+        char b[96];
+        snprintf(b, sizeof b, "index out of bounds: the len is %lld but the index is %llu",
+                 (long long)values_len, (unsigned long long)ix);
+        panic->msg = b;
+        return;
+      }
+      out[i] = values[ix];
+    }
+  }
+}
+
+// take_bits (take.rs:459-486); `values.value(i)` asserts i < bit_len (boolean.rs:495)
+template <typename I>
+void take_bits(const uint8_t* bits, int64_t bits_off, int64_t bits_len, const I* idx, int64_t n,
+               const uint8_t* ivalid, int64_t ivalid_off, int64_t idx_nulls, uint8_t* out,
+               TakePanic* panic) {
+  if (ivalid && idx_nulls > 0) {
+    for (int64_t i = 0; i < n; ++i) {  // nulls.valid_indices()
+      if (!get_bit(ivalid, ivalid_off + i)) continue;
+      uint64_t ix = to_index(idx[i]);
+      if (ix >= (uint64_t)bits_len) {
+        panic->hit = true;
+        panic->msg = "assertion failed: idx < self.bit_len";
+        return;
+      }
+      if (get_bit(bits, bits_off + (int64_t)ix)) set_bit(out, i);
+    }
+  } else {
+    for (int64_t i = 0; i < n; ++i) {  // collect_bool
+      uint64_t ix = to_index(idx[i]);
+      if (ix >= (uint64_t)bits_len) {
+        panic->hit = true;
+        panic->msg = "assertion failed: idx < self.bit_len";
+        return;
+      }
+      if (get_bit(bits, bits_off + (int64_t)ix)) set_bit(out, i);
+    }
+  }
+}
+
+// check_bounds (take.rs:167-209)
+template <typename I>
+int32_t check_bounds(int64_t len, const I* idx, int64_t n, const uint8_t* ivalid, int64_t ivalid_off,
+                     int64_t idx_nulls) {
+  // T::Native::from_usize(len) :174
+  if ((uint64_t)len > (uint64_t)std::numeric_limits<I>::max()) return ORC_OK;
+  I l = (I)len;
+  for (int64_t i = 0; i < n; ++i) {
+    if (idx_nulls > 0 && ivalid && !get_bit(ivalid, ivalid_off + i)) continue;
+    I v = idx[i];
+    bool bad = v >= l;
+    if constexpr (std::is_signed<I>::value) bad = bad || (idx_nulls == 0 && v < 0);
+    // note: with index nulls the reference only tests `index >= len` (:184)
+    if (bad) {
+      if constexpr (std::is_signed<I>::value)
+        return fail(ORC_COMPUTE_ERROR,
+                    "Array index out of bounds, cannot get item at index %lld from %lld entries",
+                    (long long)v, (long long)len);
+      else
+        return fail(ORC_COMPUTE_ERROR,
+                    "Array index out of bounds, cannot get item at index %llu from %lld entries",
+                    (unsigned long long)v, (long long)len);
+    }
+  }
+  return ORC_OK;
+}
+
+template <typename I>
+int32_t take_typed(const orc_view* values, const orc_view* indices, int32_t cb, orc_out* out) {
+  const I* idx = (const I*)indices->values;
+  int64_t n = indices->length;
+  int64_t idx_nulls = resolve_nulls(indices);
+  const uint8_t* iv = indices->validity;
+  int64_t ivo = indices->validity_bit_offset;
+  if (cb) {
+    int32_t st = check_bounds<I>(values->length, idx, n, iv, ivo, idx_nulls);
+    if (st != ORC_OK) return st;
+  }
+  out->type = values->type;
+  if (n == 0) {  // take_impl :215-217
+    out->length = 0;
+    return ORC_OK;
+  }
+  int width = type_width(values->type);
+  TakePanic panic;
+  size_t vbytes = width ? (size_t)n * width : bitmap_bytes(n);
+  void* ov = xalloc(vbytes);
+  switch (width) {
+    case 0:  // take_boolean :489-496
+      take_bits<I>((const uint8_t*)values->values, values->values_bit_offset, values->length, idx, n,
+                   iv, ivo, idx_nulls, (uint8_t*)ov, &panic);
+      break;
+    case 1: take_native((const uint8_t*)values->values, values->length, idx, n, iv, ivo, idx_nulls, (uint8_t*)ov, &panic); break;
+    case 2: take_native((const uint16_t*)values->values, values->length, idx, n, iv, ivo, idx_nulls, (uint16_t*)ov, &panic); break;
+    case 4: take_native((const uint32_t*)values->values, values->length, idx, n, iv, ivo, idx_nulls, (uint32_t*)ov, &panic); break;
+    case 8: take_native((const uint64_t*)values->values, values->length, idx, n, iv, ivo, idx_nulls, (uint64_t*)ov, &panic); break;
+    case 16: take_native((const B16*)values->values, values->length, idx, n, iv, ivo, idx_nulls, (B16*)ov, &panic); break;
+    case 32: take_native((const B32*)values->values, values->length, idx, n, iv, ivo, idx_nulls, (B32*)ov, &panic); break;
+  }
+  if (panic.hit) {
+    free(ov);
+    return fail(ORC_PANIC, "%s", panic.msg.c_str());
+  }
+  // take_nulls (take.rs:418-430)
+  int64_t val_nulls = resolve_nulls(values);
+  uint8_t* ob = nullptr;
+  size_t bbytes = bitmap_bytes(n);
+  int64_t out_nulls = 0;
+  if (values->validity && val_nulls > 0) {
+    ob = (uint8_t*)xalloc(bbytes);
+    take_bits<I>(values->validity, values->validity_bit_offset, values->length, idx, n, iv, ivo,
+                 idx_nulls, ob, &panic);
+    if (panic.hit) {
+      free(ov);
+      free(ob);
+      return fail(ORC_PANIC, "%s", panic.msg.c_str());
+    }
+    out_nulls = n - count_set_bits(ob, 0, n);
+    if (out_nulls == 0) {  // from_unsliced_buffer (null.rs:266-270)
+      free(ob);
+      ob = nullptr;
+    }
+  } else if (iv) {  // indices.nulls().cloned() (:428) — realigned to offset 0
+    ob = (uint8_t*)xalloc(bbytes);
+    copy_bits(ob, 0, iv, ivo, n);
+    out_nulls = idx_nulls;
+  }
+  out->length = n;
+  out->values = ov;
+  out->values_bytes = (int64_t)vbytes;
+  if (ob) {
+    out->validity = ob;
+    out->validity_bytes = (int64_t)bbytes;
+    out->null_count = out_nulls;
+  }
+  return ORC_OK;
+}
+
+// -------------------------------------------------------------------- arith
+enum { OP_ADD = 0, OP_ADD_W, OP_SUB, OP_SUB_W, OP_MUL, OP_MUL_W, OP_DIV, OP_REM };
+const char* op_sym(int op) {  // Display for Op (numeric.rs:203-213)
+  switch (op) {
+    case OP_ADD: case OP_ADD_W: return "+";
+    case OP_SUB: case OP_SUB_W: return "-";
+    case OP_MUL: case OP_MUL_W: return "*";
+    case OP_DIV: return "/";
+    default: return "%";
+  }
+}
+
+template <typename T> std::string dbg(T v) {  // {:?} of a Rust integer
+  char b[32];
+  if constexpr (std::is_signed<T>::value) snprintf(b, sizeof b, "%lld", (long long)v);
+  else snprintf(b, sizeof b, "%llu", (unsigned long long)v);
+  return b;
+}
+
+// ArrowNativeTypeOp for integers (arrow-array/src/arithmetic.rs:147-284).
+// Returns ORC_OK or sets the error exactly like the reference's message.
+template <typename T>
+inline int32_t int_checked(int op, T l, T r, T* out) {
+  bool ovf = false;
+  switch (op) {
+    case OP_ADD: ovf = __builtin_add_overflow(l, r, out); break;
+    case OP_SUB: ovf = __builtin_sub_overflow(l, r, out); break;
+    case OP_MUL: ovf = __builtin_mul_overflow(l, r, out); break;
+    case OP_DIV:
+      if (r == 0) return fail(ORC_DIVIDE_BY_ZERO, "Divide by zero error");
+      if (std::is_signed<T>::value && l == std::numeric_limits<T>::min() && r == (T)-1) ovf = true;
+      else *out = (T)(l / r);
+      break;
+    case OP_REM:  // numeric.rs:345-351: zero check, then mod_wrapping
+      if (r == 0) return fail(ORC_DIVIDE_BY_ZERO, "Divide by zero error");
+      if (std::is_signed<T>::value && r == (T)-1) *out = 0;  // wrapping_rem: MIN % -1 == 0
+      else *out = (T)(l % r);
+      return ORC_OK;
+  }
+  if (ovf)
+    return fail(ORC_ARITHMETIC_OVERFLOW, "Overflow happened on: %s %s %s", dbg(l).c_str(), op_sym(op),
+                dbg(r).c_str());
+  return ORC_OK;
+}
+template <typename T>
+inline T int_wrapping(int op, T l, T r) {
+  using U = typename std::make_unsigned<T>::type;
+  switch (op) {
+    case OP_ADD_W: return (T)((U)l + (U)r);
+    case OP_SUB_W: return (T)((U)l - (U)r);
+    default: return (T)((U)l * (U)r);  // OP_MUL_W
+  }
+}
+template <typename T>
+inline T float_op(int op, T l, T r) {  // arithmetic.rs:308-430, numeric.rs:357-374
+  switch (op) {
+    case OP_ADD: case OP_ADD_W: return l + r;
+    case OP_SUB: case OP_SUB_W: return l - r;
+    case OP_MUL: case OP_MUL_W: return l * r;
+    case OP_DIV: return l / r;
+    default: return std::fmod(l, r);  // Rust `%` on floats == fmod
+  }
+}
+
+bool op_is_checked_int(int op) { return op == OP_ADD || op == OP_SUB || op == OP_MUL || op == OP_DIV || op == OP_REM; }
+
+// NullBuffer::union (arrow-buffer/src/buffer/null.rs:79-88): presence-based
+uint8_t* nulls_union(const orc_view* a, const orc_view* b, int64_t len, int64_t* null_count) {
+  if (!a->validity && !b->validity) return nullptr;
+  uint8_t* o = (uint8_t*)xalloc(bitmap_bytes(len));
+  for (int64_t i = 0; i < len; ++i) {
+    bool va = !a->validity || get_bit(a->validity, a->validity_bit_offset + i);
+    bool vb = !b->validity || get_bit(b->validity, b->validity_bit_offset + i);
+    if (va && vb) set_bit(o, i);
+  }
+  *null_count = len - count_set_bits(o, 0, len);
+  return o;
+}
+uint8_t* nulls_clone(const orc_view* a, int64_t len) {
+  if (!a->validity) return nullptr;
+  uint8_t* o = (uint8_t*)xalloc(bitmap_bytes(len));
+  copy_bits(o, 0, a->validity, a->validity_bit_offset, len);
+  return o;
+}
+
+template <typename T>
+int32_t arith_typed(int op, const orc_view* l, bool l_s, const orc_view* r, bool r_s, orc_out* out) {
+  constexpr bool is_float = std::is_floating_point<T>::value;
+  const bool checked = !is_float && op_is_checked_int(op);
+  const T* lv = (const T*)l->values;
+  const T* rv = (const T*)r->values;
+  out->type = l->type;
+  if (l_s == r_s) {
+    // arity::binary (arity.rs:104-135) / try_binary (:254-299)
+    if (l->length != r->length)
+      return fail(ORC_COMPUTE_ERROR, checked ? "Cannot perform a binary operation on arrays of different length"
+                                             : "Cannot perform binary operation on arrays of different length");
+    int64_t len = l->length;
+    out->length = len;
+    if (len == 0) return ORC_OK;
+    T* ov = (T*)xalloc((size_t)len * sizeof(T));
+    out->values = ov;
+    out->values_bytes = len * (int64_t)sizeof(T);
+    if (!checked) {
+      int64_t nc = 0;
+      uint8_t* nb = nulls_union(l, r, len, &nc);
+      for (int64_t i = 0; i < len; ++i) {
+        if constexpr (is_float) ov[i] = float_op<T>(op, lv[i], rv[i]);
+        else ov[i] = int_wrapping<T>(op, lv[i], rv[i]);
+      }
+      if (nb) {
+        out->validity = nb;
+        out->validity_bytes = (int64_t)bitmap_bytes(len);
+        out->null_count = nc;
+      }
+      return ORC_OK;
+    }
+    if constexpr (!is_float) {
+      bool nullable = resolve_nulls(l) != 0 || resolve_nulls(r) != 0;  // is_nullable()
+      int64_t nc = 0;
+      uint8_t* nb = nullable ? nulls_union(l, r, len, &nc) : nullptr;
+      for (int64_t i = 0; i < len; ++i) {
+        if (nb && !get_bit(nb, i)) continue;  // try_for_each_valid_idx: zero elsewhere
+        int32_t st = int_checked<T>(op, lv[i], rv[i], &ov[i]);
+        if (st != ORC_OK) {
+          free(nb);
+          orc_release(out);
+          return st;
+        }
+      }
+      if (nb) {
+        out->validity = nb;
+        out->validity_bytes = (int64_t)bitmap_bytes(len);
+        out->null_count = nc;
+      }
+    }
+    return ORC_OK;
+  }
+  // one scalar side: op!/try_op! macros (numeric.rs:278-317)
+  const orc_view* arr = l_s ? r : l;
+  const orc_view* sc = l_s ? l : r;
+  int64_t len = arr->length;
+  out->length = len;
+  T* ov = (T*)xalloc((size_t)len * sizeof(T));
+  out->values = ov;
+  out->values_bytes = len * (int64_t)sizeof(T);
+  if (resolve_nulls(sc) != 0) {  // PrimitiveArray::new_null(len) (primitive_array.rs:658-664)
+    out->validity = (uint8_t*)xalloc(bitmap_bytes(len));
+    out->validity_bytes = (int64_t)bitmap_bytes(len);
+    out->null_count = len;
+    return ORC_OK;
+  }
+  T s = ((const T*)sc->values)[0];
+  const T* av = (const T*)arr->values;
+  uint8_t* nb = nulls_clone(arr, len);
+  for (int64_t i = 0; i < len; ++i) {
+    T a = l_s ? s : av[i];
+    T b = l_s ? av[i] : s;
+    if constexpr (is_float) ov[i] = float_op<T>(op, a, b);  // unary (primitive_array.rs:916-925)
+    else if (!checked) ov[i] = int_wrapping<T>(op, a, b);
+    else {  // try_unary (:990-1016): valid slots only
+      if (nb && !get_bit(nb, i)) continue;
+      int32_t st = int_checked<T>(op, a, b, &ov[i]);
+      if (st != ORC_OK) {
+        free(nb);
+        orc_release(out);
+        return st;
+      }
+    }
+  }
+  if (nb) {
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(len);
+    out->null_count = len - count_set_bits(nb, 0, len);
+  }
+  return ORC_OK;
+}
+
+// ---------------------------------------------------------------------- cmp
+enum { C_EQ = 0, C_NEQ, C_LT, C_LT_EQ, C_GT, C_GT_EQ, C_DISTINCT, C_NOT_DISTINCT };
+const char* cmp_sym(int op) {  // Display for Op (arrow-ord/src/cmp.rs:55-68)
+  switch (op) {
+    case C_EQ: return "==";
+    case C_NEQ: return "!=";
+    case C_LT: return "<";
+    case C_LT_EQ: return "<=";
+    case C_GT: return ">";
+    case C_GT_EQ: return ">=";
+    case C_DISTINCT: return "IS DISTINCT FROM";
+    default: return "IS NOT DISTINCT FROM";
+  }
+}
+
+// ArrowNativeTypeOp::is_lt / is_eq (arrow-array/src/arithmetic.rs:124-127,
+// 400-410): floats use IEEE totalOrder and bitwise equality.
+template <typename T> inline bool is_lt(T a, T b) { return a < b; }
+template <typename T> inline bool is_eq(T a, T b) { return a == b; }
+inline int64_t total_key(double x) {
+  int64_t b;
+  memcpy(&b, &x, 8);
+  return b ^ (int64_t)((uint64_t)(b >> 63) >> 1);
+}
+inline int32_t total_key(float x) {
+  int32_t b;
+  memcpy(&b, &x, 4);
+  return b ^ (int32_t)((uint32_t)(b >> 31) >> 1);
+}
+template <> inline bool is_lt<double>(double a, double b) { return total_key(a) < total_key(b); }
+template <> inline bool is_lt<float>(float a, float b) { return total_key(a) < total_key(b); }
+template <> inline bool is_eq<double>(double a, double b) { return memcmp(&a, &b, 8) == 0; }
+template <> inline bool is_eq<float>(float a, float b) { return memcmp(&a, &b, 4) == 0; }
+
+struct BoolVals {  // ArrayOrd for &BooleanArray (cmp.rs:740-761): lt = !l & r
+  const uint8_t* bits;
+  int64_t off;
+};
+
+// collect_bool (cmp.rs:580-611): whole u64 words, optional negation (padding
+// bits of the last word are negated too)
+template <typename F>
+uint8_t* collect_bool(int64_t len, bool neg, F f) {
+  uint64_t* buf = (uint64_t*)xalloc(bitmap_bytes(len));
+  int64_t chunks = len / 64, rem = len % 64;
+  for (int64_t c = 0; c < chunks; ++c) {
+    uint64_t packed = 0;
+    for (int b = 0; b < 64; ++b) packed |= (uint64_t)f(c * 64 + b) << b;
+    buf[c] = neg ? ~packed : packed;
+  }
+  if (rem) {
+    uint64_t packed = 0;
+    for (int b = 0; b < rem; ++b) packed |= (uint64_t)f(chunks * 64 + b) << b;
+    buf[chunks] = neg ? ~packed : packed;
+  }
+  return (uint8_t*)buf;
+}
+
+// apply_op (cmp.rs:619-648)
+template <typename T, typename OP>
+uint8_t* apply_op(const T* l, bool l_s, const T* r, bool r_s, int64_t len, bool neg, OP op) {
+  if (!l_s && !r_s) return collect_bool(len, neg, [&](int64_t i) { return op(l[i], r[i]); });
+  if (l_s && r_s) {
+    uint8_t* o = (uint8_t*)xalloc(8);
+    if (op(l[0], r[0]) ^ neg) o[0] = 1;
+    return o;
+  }
+  if (l_s) {
+    T v = l[0];
+    return collect_bool(len, neg, [&](int64_t i) { return op(v, r[i]); });
+  }
+  T v = r[0];
+  return collect_bool(len, neg, [&](int64_t i) { return op(l[i], v); });
+}
+
+template <typename T>
+uint8_t* cmp_values(int op, const orc_view* l, bool l_s, const orc_view* r, bool r_s, int64_t len) {
+  const T* lv = (const T*)l->values;
+  const T* rv = (const T*)r->values;
+  auto eq = [](T a, T b) { return is_eq<T>(a, b); };
+  auto lt = [](T a, T b) { return is_lt<T>(a, b); };
+  switch (op) {  // apply (cmp.rs:480-488)
+    case C_EQ: case C_NOT_DISTINCT: return apply_op<T>(lv, l_s, rv, r_s, len, false, eq);
+    case C_NEQ: case C_DISTINCT: return apply_op<T>(lv, l_s, rv, r_s, len, true, eq);
+    case C_LT: return apply_op<T>(lv, l_s, rv, r_s, len, false, lt);
+    case C_LT_EQ: return apply_op<T>(rv, r_s, lv, l_s, len, true, lt);
+    case C_GT: return apply_op<T>(rv, r_s, lv, l_s, len, false, lt);
+    default: return apply_op<T>(lv, l_s, rv, r_s, len, true, lt);  // C_GT_EQ
+  }
+}
+
+uint8_t* cmp_values_bool(int op, const orc_view* l, bool l_s, const orc_view* r, bool r_s, int64_t len) {
+  const uint8_t* lb = (const uint8_t*)l->values;
+  const uint8_t* rb = (const uint8_t*)r->values;
+  int64_t lo = l->values_bit_offset, ro = r->values_bit_offset;
+  auto L = [&](int64_t i) { return get_bit(lb, lo + (l_s ? 0 : i)); };
+  auto R = [&](int64_t i) { return get_bit(rb, ro + (r_s ? 0 : i)); };
+  auto mk = [&](bool neg, auto f) { return collect_bool(len, neg, f); };
+  switch (op) {
+    case C_EQ: case C_NOT_DISTINCT: return mk(false, [&](int64_t i) { return L(i) == R(i); });
+    case C_NEQ: case C_DISTINCT: return mk(true, [&](int64_t i) { return L(i) == R(i); });
+    case C_LT: return mk(false, [&](int64_t i) { return !L(i) && R(i); });
+    case C_LT_EQ: return mk(true, [&](int64_t i) { return !R(i) && L(i); });
+    case C_GT: return mk(false, [&](int64_t i) { return !R(i) && L(i); });
+    default: return mk(true, [&](int64_t i) { return !L(i) && R(i); });
+  }
+}
+
+// ---------------------------------------------------------------------- cast
+// num_traits::cast (NumCast/ToPrimitive, num-traits 0.2.19): int->int range
+// checked; int->float `as`; float->int succeeds iff trunc(v) fits; float->float `as`.
+template <typename I, typename O>
+inline bool num_cast(I v, O* out) {
+  if constexpr (std::is_floating_point<O>::value) {
+    *out = (O)v;
+    return true;
+  } else if constexpr (std::is_floating_point<I>::value) {
+    if (v != v) return false;
+    // trunc(v) in [MIN, MAX]
+    long double t = std::trunc((long double)v);
+    if (t < (long double)std::numeric_limits<O>::min() || t > (long double)std::numeric_limits<O>::max())
+      return false;
+    *out = (O)v;
+    return true;
+  } else {
+    __int128 x = (__int128)v;
+    if (x < (__int128)std::numeric_limits<O>::min() || x > (__int128)std::numeric_limits<O>::max())
+      return false;
+    *out = (O)v;
+    return true;
+  }
+}
+
+template <typename T> std::string dbg_num(T v) {
+  if constexpr (std::is_floating_point<T>::value) {
+    char b[40];
+    int n = std::is_same<T, float>::value ? orc_format_f32((float)v, b) : orc_format_f64((double)v, b);
+    return std::string(b, (size_t)n);  // Rust {:?} of a float == shortest round-trip, "256.0"
+  } else return dbg(v);
+}
+
+// cast_numeric_arrays (arrow-cast/src/cast/mod.rs:2550-2614)
+template <typename I, typename O>
+int32_t cast_numeric(const orc_view* in, int32_t to_type, bool safe, orc_out* out) {
+  int64_t len = in->length;
+  const I* iv = (const I*)in->values;
+  O* ov = (O*)xalloc((size_t)len * sizeof(O));
+  out->type = to_type;
+  out->length = len;
+  out->values = ov;
+  out->values_bytes = len * (int64_t)sizeof(O);
+  if (safe) {
+    // numeric_cast -> PrimitiveArray::unary_opt (primitive_array.rs:1065-1102):
+    // always a null buffer; failed conversions become null
+    uint8_t* nb = (uint8_t*)xalloc(bitmap_bytes(len));
+    if (in->validity) copy_bits(nb, 0, in->validity, in->validity_bit_offset, len);
+    else for (int64_t i = 0; i < len; ++i) set_bit(nb, i);
+    int64_t nulls = in->validity ? resolve_nulls(in) : 0;
+    for (int64_t i = 0; i < len; ++i) {
+      if (!get_bit(nb, i)) continue;
+      O o;
+      if (num_cast<I, O>(iv[i], &o)) ov[i] = o;
+      else {
+        nulls += 1;
+        nb[i >> 3] &= (uint8_t)~(1u << (i & 7));
+      }
+    }
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(len);
+    out->null_count = nulls;
+    return ORC_OK;
+  }
+  // try_numeric_cast -> try_unary (primitive_array.rs:990-1016): nulls cloned
+  uint8_t* nb = nulls_clone(in, len);
+  for (int64_t i = 0; i < len; ++i) {
+    if (nb && !get_bit(nb, i)) continue;
+    O o;
+    if (!num_cast<I, O>(iv[i], &o)) {
+      free(nb);
+      orc_release(out);
+      return fail(ORC_CAST_ERROR, "Can't cast value %s to type %s", dbg_num(iv[i]).c_str(), type_name(to_type));
+    }
+    ov[i] = o;
+  }
+  if (nb) {
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(len);
+    out->null_count = len - count_set_bits(nb, 0, len);
+  }
+  return ORC_OK;
+}
+
+template <typename I>
+int32_t cast_from(const orc_view* in, int32_t to, bool safe, orc_out* out) {
+  switch (to) {
+    case ORC_INT8: return cast_numeric<I, int8_t>(in, to, safe, out);
+    case ORC_INT16: return cast_numeric<I, int16_t>(in, to, safe, out);
+    case ORC_INT32: return cast_numeric<I, int32_t>(in, to, safe, out);
+    case ORC_INT64: return cast_numeric<I, int64_t>(in, to, safe, out);
+    case ORC_UINT8: return cast_numeric<I, uint8_t>(in, to, safe, out);
+    case ORC_UINT16: return cast_numeric<I, uint16_t>(in, to, safe, out);
+    case ORC_UINT32: return cast_numeric<I, uint32_t>(in, to, safe, out);
+    case ORC_UINT64: return cast_numeric<I, uint64_t>(in, to, safe, out);
+    case ORC_FLOAT32: return cast_numeric<I, float>(in, to, safe, out);
+    case ORC_FLOAT64: return cast_numeric<I, double>(in, to, safe, out);
+  }
+  return fail(ORC_CAST_ERROR, "Casting from %s to %s not supported", type_name(in->type), type_name(to));
+}
+
+// ------------------------------------------------- float -> shortest decimal
+// The reference formats floats with the third-party `ryu` crate (1.0.23;
+// arrow-cast/src/display.rs:711-723), which is not vendored.  Shortest
+// round-trip digits come from libstdc++'s std::to_chars (itself a Ryu
+// implementation, independent of the device code); the layout below restates
+// ryu's `pretty` module: format64 / format32.
+template <typename F>
+int format_float(F v, char* out, int kk_max, int kk_min_small) {
+  if (v != v) { memcpy(out, "NaN", 3); return 3; }
+  if (std::isinf(v)) {
+    if (v < 0) { memcpy(out, "-inf", 4); return 4; }
+    memcpy(out, "inf", 3);
+    return 3;
+  }
+  int idx = 0;
+  if (std::signbit(v)) out[idx++] = '-';
+  if (v == 0) { memcpy(out + idx, "0.0", 3); return idx + 3; }
+  char sci[64];
+  auto res = std::to_chars(sci, sci + sizeof sci, std::fabs(v), std::chars_format::scientific);
+  *res.ptr = 0;
+  // parse "d.ddddde[+-]xx"
+  char digits[32];
+  int nd = 0;
+  const char* p = sci;
+  for (; *p && *p != 'e'; ++p) if (*p != '.') digits[nd++] = *p;
+  int exp10 = atoi(p + 1);       // value = d.ddd * 10^exp10
+  while (nd > 1 && digits[nd - 1] == '0') --nd;  // (to_chars never emits them, defensive)
+  int k = exp10 - (nd - 1);      // value = digits * 10^k
+  int kk = nd + k;               // 10^(kk-1) <= v < 10^kk
+  if (0 <= k && kk <= kk_max) {  // 1234e7 -> 12340000000.0
+    memcpy(out + idx, digits, nd);
+    for (int i = nd; i < kk; ++i) out[idx + i] = '0';
+    out[idx + kk] = '.';
+    out[idx + kk + 1] = '0';
+    return idx + kk + 2;
+  } else if (0 < kk && kk <= kk_max) {  // 1234e-2 -> 12.34
+    memcpy(out + idx, digits, kk);
+    out[idx + kk] = '.';
+    memcpy(out + idx + kk + 1, digits + kk, nd - kk);
+    return idx + nd + 1;
+  } else if (kk_min_small < kk && kk <= 0) {  // 1234e-6 -> 0.001234
+    out[idx] = '0';
+    out[idx + 1] = '.';
+    int offset = 2 - kk;
+    for (int i = 2; i < offset; ++i) out[idx + i] = '0';
+    memcpy(out + idx + offset, digits, nd);
+    return idx + nd + offset;
+  } else if (nd == 1) {  // 1e30
+    out[idx] = digits[0];
+    out[idx + 1] = 'e';
+    return idx + 2 + snprintf(out + idx + 2, 8, "%d", kk - 1);
+  } else {  // 1234e30 -> 1.234e33
+    out[idx] = digits[0];
+    out[idx + 1] = '.';
+    memcpy(out + idx + 2, digits + 1, nd - 1);
+    out[idx + nd + 1] = 'e';
+    return idx + nd + 2 + snprintf(out + idx + nd + 2, 8, "%d", kk - 1);
+  }
+}
+
+template <typename T>
+int format_value(T v, char* buf) {
+  if constexpr (std::is_same<T, double>::value) return orc_format_f64(v, buf);
+  else if constexpr (std::is_same<T, float>::value) return orc_format_f32(v, buf);
+  else if constexpr (std::is_signed<T>::value) return snprintf(buf, 32, "%lld", (long long)v);  // lexical_core::write (display.rs:694-707)
+  else return snprintf(buf, 32, "%llu", (unsigned long long)v);
+}
+
+// value_to_string (arrow-cast/src/cast/string.rs:21-39) into GenericStringBuilder
+template <typename T, typename OFF>
+int32_t cast_to_string(const orc_view* in, int32_t to_type, orc_out* out) {
+  int64_t len = in->length;
+  const T* iv = (const T*)in->values;
+  OFF* offs = (OFF*)xalloc((size_t)(len + 1) * sizeof(OFF));
+  std::vector<char> bytes;
+  bytes.reserve((size_t)len * 8);
+  bool any_null = false;
+  uint8_t* nb = (uint8_t*)xalloc(bitmap_bytes(len));
+  char buf[48];
+  offs[0] = 0;
+  for (int64_t i = 0; i < len; ++i) {
+    bool null = in->validity && !get_bit(in->validity, in->validity_bit_offset + i);
+    if (null) any_null = true;
+    else {
+      int n = format_value<T>(iv[i], buf);
+      bytes.insert(bytes.end(), buf, buf + n);
+      set_bit(nb, i);
+    }
+    // OffsetSize::from_usize(..).expect("byte array offset overflow")
+    // (arrow-array/src/builder/generic_bytes_builder.rs:86-87)
+    if (sizeof(OFF) == 4 && bytes.size() > (size_t)INT32_MAX) {
+      free(offs);
+      free(nb);
+      return fail(ORC_OFFSET_OVERFLOW, "byte array offset overflow");
+    }
+    offs[i + 1] = (OFF)bytes.size();
+  }
+  out->type = to_type;
+  out->length = len;
+  out->offsets = offs;
+  out->offsets_bytes = (len + 1) * (int64_t)sizeof(OFF);
+  out->values = xalloc(bytes.size());
+  memcpy(out->values, bytes.data(), bytes.size());
+  out->values_bytes = (int64_t)bytes.size();
+  if (any_null) {  // NullBufferBuilder materialises only once a null is appended
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(len);
+    out->null_count = len - count_set_bits(nb, 0, len);
+  } else free(nb);
+  return ORC_OK;
+}
+
+template <typename OFF>
+int32_t cast_to_string_dispatch(const orc_view* in, int32_t to, orc_out* out) {
+  switch (in->type) {
+    case ORC_INT8: return cast_to_string<int8_t, OFF>(in, to, out);
+    case ORC_INT16: return cast_to_string<int16_t, OFF>(in, to, out);
+    case ORC_INT32: return cast_to_string<int32_t, OFF>(in, to, out);
+    case ORC_INT64: return cast_to_string<int64_t, OFF>(in, to, out);
+    case ORC_UINT8: return cast_to_string<uint8_t, OFF>(in, to, out);
+    case ORC_UINT16: return cast_to_string<uint16_t, OFF>(in, to, out);
+    case ORC_UINT32: return cast_to_string<uint32_t, OFF>(in, to, out);
+    case ORC_UINT64: return cast_to_string<uint64_t, OFF>(in, to, out);
+    case ORC_FLOAT32: return cast_to_string<float, OFF>(in, to, out);
+    case ORC_FLOAT64: return cast_to_string<double, OFF>(in, to, out);
+  }
+  return fail(ORC_CAST_ERROR, "Casting from %s to %s not supported", type_name(in->type), type_name(to));
+}
+
+inline uint64_t splitmix64(uint64_t seed, uint64_t i) {
+  uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// neg / neg_wrapping (arrow-arith/src/numeric.rs:103-186)
+template <typename T>
+int32_t neg_typed(const orc_view* v, bool wrapping, orc_out* out) {
+  int64_t len = v->length;
+  const T* iv = (const T*)v->values;
+  T* ov = (T*)xalloc((size_t)len * sizeof(T));
+  out->type = v->type;
+  out->length = len;
+  out->values = ov;
+  out->values_bytes = len * (int64_t)sizeof(T);
+  uint8_t* nb = nulls_clone(v, len);
+  for (int64_t i = 0; i < len; ++i) {
+    if constexpr (std::is_floating_point<T>::value) ov[i] = -iv[i];
+    else if (wrapping) ov[i] = (T)(0 - (typename std::make_unsigned<T>::type)iv[i]);
+    else {
+      if (nb && !get_bit(nb, i)) continue;
+      if (iv[i] == std::numeric_limits<T>::min()) {
+        free(nb);
+        std::string s = dbg(iv[i]);
+        orc_release(out);
+        return fail(ORC_ARITHMETIC_OVERFLOW, "Overflow happened on: - %s", s.c_str());
+      }
+      ov[i] = (T)-iv[i];
+    }
+  }
+  if (nb) {
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(len);
+    out->null_count = len - count_set_bits(nb, 0, len);
+  }
+  return ORC_OK;
+}
+
+}  // namespace
+
+// =================================================================== exports
+extern "C" {
+
+const char* orc_last_error(void) { return g_err.c_str(); }
+
+void orc_release(orc_out* out) {
+  if (!out) return;
+  if (!(out->flags & 1)) {
+    free(out->values);
+    free(out->validity);
+    free(out->offsets);
+  }
+  memset(out, 0, sizeof *out);
+}
+
+int64_t orc_count_set_bits(const uint8_t* bits, int64_t off, int64_t len) {
+  return count_set_bits(bits, off, len);
+}
+int64_t orc_set_slices(const uint8_t* bits, int64_t off, int64_t len, int64_t* out, int64_t cap) {
+  BitSliceIterator it(bits, off, len);
+  int64_t s, e, n = 0;
+  while (it.next(&s, &e)) {
+    if (n < cap) {
+      out[2 * n] = s;
+      out[2 * n + 1] = e;
+    }
+    ++n;
+  }
+  return n;
+}
+int64_t orc_set_indices(const uint8_t* bits, int64_t off, int64_t len, int64_t* out, int64_t cap) {
+  BitIndexIterator it(bits, off, len);
+  int64_t i, n = 0;
+  while (it.next(&i)) {
+    if (n < cap) out[n] = i;
+    ++n;
+  }
+  return n;
+}
+
+int32_t orc_filter(const orc_view* values, const orc_view* predicate, orc_out* out) {
+  return filter_impl(values, predicate, out);
+}
+
+int32_t orc_take(const orc_view* values, const orc_view* indices, int32_t cb, orc_out* out) {
+  out_init(out);
+  if (type_width(values->type) < 0)
+    return fail(ORC_NOT_YET_IMPLEMENTED, "take not supported for type %s", type_name(values->type));
+  switch (indices->type) {  // downcast_integer_array! (take.rs:95-105)
+    case ORC_INT8: return take_typed<int8_t>(values, indices, cb, out);
+    case ORC_UINT8: return take_typed<uint8_t>(values, indices, cb, out);
+    case ORC_INT16: return take_typed<int16_t>(values, indices, cb, out);
+    case ORC_UINT16: return take_typed<uint16_t>(values, indices, cb, out);
+    case ORC_INT32: return take_typed<int32_t>(values, indices, cb, out);
+    case ORC_UINT32: return take_typed<uint32_t>(values, indices, cb, out);
+    case ORC_INT64: return take_typed<int64_t>(values, indices, cb, out);
+    case ORC_UINT64: return take_typed<uint64_t>(values, indices, cb, out);
+  }
+  return fail(ORC_INVALID_ARGUMENT, "Take only supported for integers, got %s", type_name(indices->type));
+}
+
+int32_t orc_arith(int32_t op, const orc_view* l, int32_t l_s, const orc_view* r, int32_t r_s, orc_out* out) {
+  out_init(out);
+  if (l->type != r->type || !(is_integer(l->type) || l->type == ORC_FLOAT32 || l->type == ORC_FLOAT64))
+    return fail(ORC_INVALID_ARGUMENT, "Invalid arithmetic operation: %s %s %s", type_name(l->type),
+                op_sym(op), type_name(r->type));  // numeric.rs:270-272
+  switch (l->type) {
+    case ORC_INT8: return arith_typed<int8_t>(op, l, l_s, r, r_s, out);
+    case ORC_INT16: return arith_typed<int16_t>(op, l, l_s, r, r_s, out);
+    case ORC_INT32: return arith_typed<int32_t>(op, l, l_s, r, r_s, out);
+    case ORC_INT64: return arith_typed<int64_t>(op, l, l_s, r, r_s, out);
+    case ORC_UINT8: return arith_typed<uint8_t>(op, l, l_s, r, r_s, out);
+    case ORC_UINT16: return arith_typed<uint16_t>(op, l, l_s, r, r_s, out);
+    case ORC_UINT32: return arith_typed<uint32_t>(op, l, l_s, r, r_s, out);
+    case ORC_UINT64: return arith_typed<uint64_t>(op, l, l_s, r, r_s, out);
+    case ORC_FLOAT32: return arith_typed<float>(op, l, l_s, r, r_s, out);
+    default: return arith_typed<double>(op, l, l_s, r, r_s, out);
+  }
+}
+
+int32_t orc_neg(const orc_view* v, int32_t wrapping, orc_out* out) {
+  out_init(out);
+  switch (v->type) {
+    case ORC_INT8: return neg_typed<int8_t>(v, wrapping, out);
+    case ORC_INT16: return neg_typed<int16_t>(v, wrapping, out);
+    case ORC_INT32: return neg_typed<int32_t>(v, wrapping, out);
+    case ORC_INT64: return neg_typed<int64_t>(v, wrapping, out);
+    case ORC_FLOAT32: return neg_typed<float>(v, wrapping, out);
+    case ORC_FLOAT64: return neg_typed<double>(v, wrapping, out);
+    case ORC_UINT8: if (wrapping) return neg_typed<uint8_t>(v, true, out); break;
+    case ORC_UINT16: if (wrapping) return neg_typed<uint16_t>(v, true, out); break;
+    case ORC_UINT32: if (wrapping) return neg_typed<uint32_t>(v, true, out); break;
+    case ORC_UINT64: if (wrapping) return neg_typed<uint64_t>(v, true, out); break;
+  }
+  return fail(ORC_INVALID_ARGUMENT, "Invalid arithmetic operation: !%s", type_name(v->type));
+}
+
+// compare_op (arrow-ord/src/cmp.rs:220-382)
+int32_t orc_compare(int32_t op, const orc_view* l, int32_t l_s, const orc_view* r, int32_t r_s, orc_out* out) {
+  out_init(out);
+  if (l->length != r->length && !l_s && !r_s)
+    return fail(ORC_INVALID_ARGUMENT, "Cannot compare arrays of different lengths, got %lld vs %lld",
+                (long long)l->length, (long long)r->length);
+  int64_t len = l_s ? r->length : l->length;
+  if (l->type != r->type)
+    return fail(ORC_INVALID_ARGUMENT, "Invalid comparison operation: %s %s %s", type_name(l->type),
+                cmp_sym(op), type_name(r->type));
+  out->type = ORC_BOOL;
+  out->length = len;
+  auto values = [&]() -> uint8_t* {
+    if (l->length == 0 || r->length == 0) return (uint8_t*)xalloc(bitmap_bytes(len));  // apply :445-447
+    switch (l->type) {
+      case ORC_BOOL: return cmp_values_bool(op, l, l_s, r, r_s, len);
+      case ORC_INT8: return cmp_values<int8_t>(op, l, l_s, r, r_s, len);
+      case ORC_INT16: return cmp_values<int16_t>(op, l, l_s, r, r_s, len);
+      case ORC_INT32: return cmp_values<int32_t>(op, l, l_s, r, r_s, len);
+      case ORC_INT64: return cmp_values<int64_t>(op, l, l_s, r, r_s, len);
+      case ORC_UINT8: return cmp_values<uint8_t>(op, l, l_s, r, r_s, len);
+      case ORC_UINT16: return cmp_values<uint16_t>(op, l, l_s, r, r_s, len);
+      case ORC_UINT32: return cmp_values<uint32_t>(op, l, l_s, r, r_s, len);
+      case ORC_UINT64: return cmp_values<uint64_t>(op, l, l_s, r, r_s, len);
+      case ORC_FLOAT32: return cmp_values<float>(op, l, l_s, r, r_s, len);
+      case ORC_FLOAT64: return cmp_values<double>(op, l, l_s, r, r_s, len);
+    }
+    return nullptr;
+  };
+  if (type_width(l->type) < 0 || l->type == ORC_FIXED16 || l->type == ORC_FIXED32 || l->type == ORC_FLOAT16)
+    return fail(ORC_NOT_YET_IMPLEMENTED, "comparison not supported for type %s", type_name(l->type));
+  size_t bytes = bitmap_bytes(len);
+  // nulls filtered by null_count > 0 (:345-346)
+  bool ln = l->validity && resolve_nulls(l) > 0;
+  bool rn = r->validity && resolve_nulls(r) > 0;
+  auto lbit = [&](int64_t i) { return get_bit(l->validity, l->validity_bit_offset + (l_s ? 0 : i)); };
+  auto rbit = [&](int64_t i) { return get_bit(r->validity, r->validity_bit_offset + (r_s ? 0 : i)); };
+  auto set_values = [&](uint8_t* v) {
+    out->values = v;
+    out->values_bytes = (int64_t)bytes;
+  };
+  auto all_null = [&]() {  // BooleanArray::new_null(len)
+    set_values((uint8_t*)xalloc(bytes));
+    out->validity = (uint8_t*)xalloc(bytes);
+    out->validity_bytes = (int64_t)bytes;
+    out->null_count = len;
+  };
+  if (ln && rn && (l_s == r_s)) {
+    uint8_t* v = values();
+    if (op == C_DISTINCT || op == C_NOT_DISTINCT) {
+      uint8_t* o = (uint8_t*)xalloc(bytes);
+      for (int64_t i = 0; i < len; ++i) {
+        bool a = lbit(i), b = rbit(i), n = get_bit(v, i);
+        bool res = op == C_DISTINCT ? ((a ^ b) | (a & b & n)) : ((!(a | b)) | (a & b & n));
+        if (res) set_bit(o, i);
+      }
+      free(v);
+      set_values(o);
+    } else {
+      set_values(v);
+      uint8_t* nb = (uint8_t*)xalloc(bytes);
+      for (int64_t i = 0; i < len; ++i) if (lbit(i) && rbit(i)) set_bit(nb, i);
+      out->validity = nb;
+      out->validity_bytes = (int64_t)bytes;
+      out->null_count = len - count_set_bits(nb, 0, len);
+    }
+  } else if (ln && rn) {  // scalar is null, other side non-scalar and nullable (:349-356)
+    const orc_view* a = l_s ? r : l;
+    if (op == C_DISTINCT || op == C_NOT_DISTINCT) {
+      uint8_t* o = (uint8_t*)xalloc(bytes);
+      for (int64_t i = 0; i < len; ++i) {
+        bool va = get_bit(a->validity, a->validity_bit_offset + i);
+        if (op == C_DISTINCT ? va : !va) set_bit(o, i);
+      }
+      set_values(o);
+    } else all_null();
+  } else if (ln || rn) {  // only one side nullable (:357-378)
+    const orc_view* nside = ln ? l : r;
+    bool is_scalar = ln ? l_s : r_s;
+    if (is_scalar) {
+      if (op == C_DISTINCT) {
+        uint8_t* o = (uint8_t*)xalloc(bytes);
+        for (int64_t i = 0; i < len; ++i) set_bit(o, i);
+        set_values(o);
+      } else if (op == C_NOT_DISTINCT) set_values((uint8_t*)xalloc(bytes));
+      else all_null();
+    } else {
+      uint8_t* v = values();
+      auto nbit = [&](int64_t i) { return get_bit(nside->validity, nside->validity_bit_offset + i); };
+      if (op == C_DISTINCT || op == C_NOT_DISTINCT) {
+        uint8_t* o = (uint8_t*)xalloc(bytes);
+        for (int64_t i = 0; i < len; ++i) {
+          bool res = op == C_DISTINCT ? (!nbit(i) | get_bit(v, i)) : (nbit(i) & get_bit(v, i));
+          if (res) set_bit(o, i);
+        }
+        free(v);
+        set_values(o);
+      } else {
+        set_values(v);
+        uint8_t* nb = (uint8_t*)xalloc(bytes);
+        for (int64_t i = 0; i < len; ++i) if (nbit(i)) set_bit(nb, i);
+        out->validity = nb;
+        out->validity_bytes = (int64_t)bytes;
+        out->null_count = len - count_set_bits(nb, 0, len);
+      }
+    }
+  } else {
+    set_values(values());
+  }
+  return ORC_OK;
+}
+
+int32_t orc_cast(const orc_view* in, int32_t to, int32_t safe, orc_out* out) {
+  out_init(out);
+  if (to == ORC_UTF8) return cast_to_string_dispatch<int32_t>(in, to, out);
+  if (to == ORC_LARGE_UTF8) return cast_to_string_dispatch<int64_t>(in, to, out);
+  if (in->type == to) {  // cast_with_options :797-799 — clone
+    int w = type_width(to);
+    if (w <= 0) return fail(ORC_CAST_ERROR, "Casting from %s to %s not supported", type_name(in->type), type_name(to));
+    out->type = to;
+    out->length = in->length;
+    out->values = xalloc((size_t)in->length * w);
+    memcpy(out->values, in->values, (size_t)in->length * w);
+    out->values_bytes = in->length * w;
+    if (in->validity) {
+      out->validity = nulls_clone(in, in->length);
+      out->validity_bytes = (int64_t)bitmap_bytes(in->length);
+      out->null_count = resolve_nulls(in);
+    }
+    return ORC_OK;
+  }
+  switch (in->type) {
+    case ORC_INT8: return cast_from<int8_t>(in, to, safe, out);
+    case ORC_INT16: return cast_from<int16_t>(in, to, safe, out);
+    case ORC_INT32: return cast_from<int32_t>(in, to, safe, out);
+    case ORC_INT64: return cast_from<int64_t>(in, to, safe, out);
+    case ORC_UINT8: return cast_from<uint8_t>(in, to, safe, out);
+    case ORC_UINT16: return cast_from<uint16_t>(in, to, safe, out);
+    case ORC_UINT32: return cast_from<uint32_t>(in, to, safe, out);
+    case ORC_UINT64: return cast_from<uint64_t>(in, to, safe, out);
+    case ORC_FLOAT32: return cast_from<float>(in, to, safe, out);
+    case ORC_FLOAT64: return cast_from<double>(in, to, safe, out);
+  }
+  return fail(ORC_CAST_ERROR, "Casting from %s to %s not supported", type_name(in->type), type_name(to));
+}
+
+// concat for primitives / booleans (arrow-select/src/concat.rs:334-343, :495)
+int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out) {
+  out_init(out);
+  if (n <= 0) return fail(ORC_INVALID_ARGUMENT, "concat requires input of at least one array");
+  int32_t t = pieces[0].type;
+  int w = type_width(t);
+  if (w < 0) return fail(ORC_NOT_YET_IMPLEMENTED, "concat not supported for type %s", type_name(t));
+  int64_t total = 0;
+  bool any_valid_buf = false;
+  for (int i = 0; i < n; ++i) {
+    if (pieces[i].type != t)
+      return fail(ORC_INVALID_ARGUMENT, "It is not possible to concatenate arrays of different data types (%s, %s).",
+                  type_name(t), type_name(pieces[i].type));
+    total += pieces[i].length;
+    // NullBufferBuilder: a buffer materialises only if some piece has nulls
+    if (pieces[i].validity && resolve_nulls(&pieces[i]) > 0) any_valid_buf = true;
+  }
+  out->type = t;
+  out->length = total;
+  size_t vbytes = w ? (size_t)total * w : bitmap_bytes(total);
+  out->values = xalloc(vbytes);
+  out->values_bytes = (int64_t)vbytes;
+  uint8_t* nb = any_valid_buf ? (uint8_t*)xalloc(bitmap_bytes(total)) : nullptr;
+  int64_t pos = 0;
+  for (int i = 0; i < n; ++i) {
+    const orc_view* p = &pieces[i];
+    if (w) memcpy((char*)out->values + (size_t)pos * w, p->values, (size_t)p->length * w);
+    else copy_bits((uint8_t*)out->values, pos, (const uint8_t*)p->values, p->values_bit_offset, p->length);
+    if (nb) {
+      if (p->validity) copy_bits(nb, pos, p->validity, p->validity_bit_offset, p->length);
+      else for (int64_t j = 0; j < p->length; ++j) set_bit(nb, pos + j);
+    }
+    pos += p->length;
+  }
+  if (nb) {
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(total);
+    out->null_count = total - count_set_bits(nb, 0, total);
+  }
+  return ORC_OK;
+}
+
+int32_t orc_format_f64(double v, char* buf) { return format_float<double>(v, buf, 16, -5); }
+int32_t orc_format_f32(float v, char* buf) { return format_float<float>(v, buf, 13, -6); }
+
+void orc_gen_uniform_i64(int64_t* dst, int64_t n, uint64_t seed, int64_t lo, int64_t hi, int64_t row0) {
+  uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;
+  for (int64_t i = 0; i < n; ++i) {
+    uint64_t r = splitmix64(seed, (uint64_t)(row0 + i));
+    dst[i] = range ? (int64_t)((uint64_t)lo + (uint64_t)(((unsigned __int128)r * range) >> 64)) : (int64_t)r;
+  }
+}
+void orc_gen_uniform_i32(int32_t* dst, int64_t n, uint64_t seed, int64_t row0) {
+  for (int64_t i = 0; i < n; ++i) dst[i] = (int32_t)(uint32_t)splitmix64(seed, (uint64_t)(row0 + i));
+}
+void orc_gen_uniform_u32(uint32_t* dst, int64_t n, uint64_t seed, uint32_t bound, int64_t row0) {
+  for (int64_t i = 0; i < n; ++i) {
+    uint32_t r = (uint32_t)(splitmix64(seed, (uint64_t)(row0 + i)) >> 32);
+    dst[i] = bound ? (uint32_t)(((uint64_t)r * bound) >> 32) : r;
+  }
+}
+void orc_gen_uniform_f64(double* dst, int64_t n, uint64_t seed, double lo, double hi, int64_t row0) {
+  double span = hi - lo;
+  for (int64_t i = 0; i < n; ++i) {
+    uint64_t r = splitmix64(seed, (uint64_t)(row0 + i));
+    double u = (double)(r >> 11) * 0x1.0p-53;
+    dst[i] = std::fma(u, span, lo);
+  }
+}
+void orc_gen_bernoulli_bits(uint8_t* dst, int64_t n, uint64_t seed, double p_true, int64_t row0) {
+  double p = p_true < 0 ? 0 : (p_true > 1 ? 1 : p_true);
+  uint64_t threshold = (uint64_t)(p * 9007199254740992.0);
+  memset(dst, 0, bitmap_bytes(n));
+  for (int64_t i = 0; i < n; ++i)
+    if ((splitmix64(seed, (uint64_t)(row0 + i)) >> 11) < threshold) set_bit(dst, i);
+}
+void orc_zero_null_slots(void* values, int32_t w, const uint8_t* validity, int64_t n) {
+  if (!validity) return;
+  for (int64_t i = 0; i < n; ++i)
+    if (!get_bit(validity, i)) memset((char*)values + (size_t)i * w, 0, (size_t)w);
+}
+
+}  // extern "C"

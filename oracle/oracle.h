@@ -1,0 +1,104 @@
+/*
+ * oracle.h — CPU oracle for the arrow-rs compute hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a scalar, single-threaded C++ restatement
+ * of the reference's algorithms (apache/arrow-rs 59.2.0) — same pass structure,
+ * same edge semantics — used as (a) the parity checker for the HIP path in
+ * tests/, __graft_entry__.smoke() and (b) bench.py's `cpu_baseline` leg
+ * (kind "port").  Nothing under arrow-rs_amd/ may include, link or call it.
+ *
+ * Parity pinning: the reference is Rust-only and there is no Rust toolchain in
+ * this image, so oracle/_ref cannot be built.  The oracle is pinned against
+ * every inline golden vector the reference's own tests hold for this path
+ * (tests/golden/ *.json, transcribed from the files cited there) and
+ * cross-checked against pyarrow (Arrow C++) where semantics coincide.
+ * Float64->Utf8 follows the published Ryu algorithm (ryu crate 1.0.23, not
+ * vendored under /root/reference): beyond the five values the reference's tests
+ * pin, that arm is "parity unpinned" by the reference itself; it is
+ * additionally checked against CPython's repr() shortest-digit output.
+ *
+ * Struct layouts intentionally equal include/arrow_hip.h's ah_array_view /
+ * ah_array_out so one ctypes definition serves both sides; pointers here are
+ * HOST pointers.
+ */
+#ifndef ARROW_ORACLE_H
+#define ARROW_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same numbering as AH_* */
+enum {
+  ORC_OK = 0, ORC_INVALID_ARGUMENT = 1, ORC_COMPUTE_ERROR = 2, ORC_ARITHMETIC_OVERFLOW = 3,
+  ORC_DIVIDE_BY_ZERO = 4, ORC_CAST_ERROR = 5, ORC_OFFSET_OVERFLOW = 6, ORC_NOT_YET_IMPLEMENTED = 7,
+  ORC_PANIC = 100
+};
+enum {
+  ORC_BOOL = 1, ORC_INT8 = 2, ORC_INT16 = 3, ORC_INT32 = 4, ORC_INT64 = 5, ORC_UINT8 = 6,
+  ORC_UINT16 = 7, ORC_UINT32 = 8, ORC_UINT64 = 9, ORC_FLOAT32 = 10, ORC_FLOAT64 = 11,
+  ORC_FIXED16 = 12, ORC_FIXED32 = 13, ORC_UTF8 = 14, ORC_LARGE_UTF8 = 15, ORC_FLOAT16 = 16
+};
+
+typedef struct orc_view {
+  int32_t type;
+  int64_t length;
+  int64_t null_count; /* -1: count it */
+  const void* values;
+  int64_t values_bit_offset;
+  const uint8_t* validity;
+  int64_t validity_bit_offset;
+} orc_view;
+
+typedef struct orc_out {
+  int32_t type;
+  int64_t length;
+  int64_t null_count;
+  void* values;
+  int64_t values_bytes;
+  int64_t values_bit_offset;
+  uint8_t* validity;
+  int64_t validity_bytes;
+  int64_t validity_bit_offset;
+  void* offsets;
+  int64_t offsets_bytes;
+  int32_t flags; /* 1 = borrowed (zero-copy slice of the input) */
+} orc_out;
+
+const char* orc_last_error(void);
+void orc_release(orc_out* out);
+
+int64_t orc_count_set_bits(const uint8_t* bits, int64_t bit_offset, int64_t len);
+/* BitSliceIterator / BitIndexIterator: write up to cap entries, return the count */
+int64_t orc_set_slices(const uint8_t* bits, int64_t bit_offset, int64_t len, int64_t* out_pairs,
+                       int64_t cap);
+int64_t orc_set_indices(const uint8_t* bits, int64_t bit_offset, int64_t len, int64_t* out_idx,
+                        int64_t cap);
+
+int32_t orc_filter(const orc_view* values, const orc_view* predicate, orc_out* out);
+int32_t orc_take(const orc_view* values, const orc_view* indices, int32_t check_bounds, orc_out* out);
+int32_t orc_arith(int32_t op, const orc_view* lhs, int32_t lhs_scalar, const orc_view* rhs,
+                  int32_t rhs_scalar, orc_out* out);
+int32_t orc_neg(const orc_view* values, int32_t wrapping, orc_out* out);
+int32_t orc_compare(int32_t op, const orc_view* lhs, int32_t lhs_scalar, const orc_view* rhs,
+                    int32_t rhs_scalar, orc_out* out);
+int32_t orc_cast(const orc_view* values, int32_t to_type, int32_t safe, orc_out* out);
+int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out);
+
+/* format one f64/f32 the way ryu::Buffer::format does; returns the length */
+int32_t orc_format_f64(double v, char* buf /* >= 32 */);
+int32_t orc_format_f32(float v, char* buf /* >= 32 */);
+
+/* host twins of the device generators in arrow-rs_amd/csrc/gen.hip */
+void orc_gen_uniform_i64(int64_t* dst, int64_t n, uint64_t seed, int64_t lo, int64_t hi, int64_t row0);
+void orc_gen_uniform_i32(int32_t* dst, int64_t n, uint64_t seed, int64_t row0);
+void orc_gen_uniform_u32(uint32_t* dst, int64_t n, uint64_t seed, uint32_t bound, int64_t row0);
+void orc_gen_uniform_f64(double* dst, int64_t n, uint64_t seed, double lo, double hi, int64_t row0);
+void orc_gen_bernoulli_bits(uint8_t* dst, int64_t n, uint64_t seed, double p_true, int64_t row0);
+void orc_zero_null_slots(void* values, int32_t byte_width, const uint8_t* validity, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

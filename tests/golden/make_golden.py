@@ -1,0 +1,264 @@
+"""Writes tests/golden/*.json: the inline golden vectors of the reference's own unit
+tests for the hot path, TRANSCRIBED by hand from the cited Rust test bodies
+(the reference is Rust-only and cannot run here; nothing below executes it).
+Each case cites the reference test (file:line under /root/reference).
+
+    python tests/golden/make_golden.py      # regenerates the JSON files
+"""
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+N = None
+T, F = True, False
+
+
+def arr(t, data, slice=None):
+    d = {"type": t, "data": data}
+    if slice:
+        d["slice"] = slice
+    return d
+
+
+filter_cases = []
+filter_cases.append(dict(name="doc_example", source="arrow-select/src/filter.rs:195-199",
+                         values=arr("Int32", [5, 6, 7, 8, 9]), predicate=arr("Boolean", [T, F, F, T, F]),
+                         expected=arr("Int32", [5, 8])))
+for t in ["Date32", "Date64", "Time32(Second)", "Time32(Millisecond)", "Time64(Microsecond)",
+          "Time64(Nanosecond)", "Duration(Second)", "Duration(Millisecond)", "Duration(Microsecond)",
+          "Duration(Nanosecond)", "Timestamp(Second, None)", "Timestamp(Millisecond, None)",
+          "Timestamp(Microsecond, None)", "Timestamp(Nanosecond, None)"]:
+    filter_cases.append(dict(name=f"temporal_{t}", source="arrow-select/src/filter.rs:1090-1174",
+                             values=arr(t, [1, 2, 3, 4]), predicate=arr("Boolean", [T, F, T, F]),
+                             expected=arr(t, [1, 3])))
+filter_cases.append(dict(name="test_filter_array_slice", source="arrow-select/src/filter.rs:1177",
+                         values=arr("Int32", [5, 6, 7, 8, 9], [1, 4]), predicate=arr("Boolean", [T, F, F, T]),
+                         expected=arr("Int32", [6, 9])))
+# test_filter_array_low_density (:1191): 1..=65 then [66, 67]; mask true at value 65 and 67
+vals = list(range(1, 66)) + [66, 67]
+mask = [(v % 65 == 0) for v in range(1, 66)] + [F, T]
+filter_cases.append(dict(name="test_filter_array_low_density", source="arrow-select/src/filter.rs:1191",
+                         values=arr("Int32", vals), predicate=arr("Boolean", mask), expected=arr("Int32", [65, 67])))
+# test_filter_array_high_density (:1207): [1, null, 3..=65] ++ [66, null, 67, null];
+# mask [T x64, F] ++ [F, T, T, T]; expects len 67, null_count 3
+vals = [1, N] + list(range(3, 66)) + [66, N, 67, N]
+mask = [T] * 64 + [F] + [F, T, T, T]
+exp = [1, N] + list(range(3, 65)) + [N, 67, N]
+assert len(vals) == 69 and len(mask) == 69 and len(exp) == 67 and sum(x is None for x in exp) == 3
+filter_cases.append(dict(name="test_filter_array_high_density", source="arrow-select/src/filter.rs:1207",
+                         values=arr("Int32", vals), predicate=arr("Boolean", mask), expected=arr("Int32", exp),
+                         expected_null_count=3))
+filter_cases.append(dict(name="test_filter_primitive_array_with_null", source="arrow-select/src/filter.rs:1244",
+                         values=arr("Int32", [5, N]), predicate=arr("Boolean", [F, T]), expected=arr("Int32", [N])))
+filter_cases.append(dict(name="test_filter_array_slice_with_null", source="arrow-select/src/filter.rs:1414",
+                         values=arr("Int32", [5, N, 7, 8, 9], [1, 4]), predicate=arr("Boolean", [T, F, F, T]),
+                         expected=arr("Int32", [N, 9])))
+filter_cases.append(dict(name="test_null_mask", source="arrow-select/src/filter.rs:1718",
+                         values=arr("Int64", [1, 2, N]), predicate=arr("Boolean", [T, T, N]),
+                         expected=arr("Int64", [1, 2])))
+filter_cases.append(dict(name="test_fast_path_all_true", source="arrow-select/src/filter.rs:1738",
+                         values=arr("Int64", [1, 2, N]), predicate=arr("Boolean", [T, T, T]),
+                         expected=arr("Int64", [1, 2, N])))
+filter_cases.append(dict(name="test_fast_path_all_false", source="arrow-select/src/filter.rs:1738",
+                         values=arr("Int64", [1, 2, N]), predicate=arr("Boolean", [F, F, F]),
+                         expected=arr("Int64", [])))
+filter_cases.append(dict(name="filter_boolean", source="arrow-select/src/filter.rs:723-729 (filter_boolean; "
+                         "values as in take.rs:1627)",
+                         values=arr("Boolean", [F, N, T, F, N]), predicate=arr("Boolean", [T, T, T, F, T]),
+                         expected=arr("Boolean", [F, N, T, N])))
+filter_cases.append(dict(name="oversized_predicate", source="arrow-select/src/filter.rs:536-541",
+                         values=arr("Int32", [1, 2, 3]), predicate=arr("Boolean", [T, F, T, T]),
+                         error="InvalidArgumentError",
+                         message="Filter predicate of length 4 is larger than target array of length 3"))
+filter_cases.append(dict(name="test_filter_record_batch_no_columns", source="arrow-select/src/filter.rs:1727",
+                         record_batch_rows=100, predicate=arr("Boolean", [T, T, N]), expected_rows=2))
+# test_slices (:1758): 10 T, 30 F, 20 T, 17 F, 4 T
+m = [T] * 10 + [F] * 30 + [T] * 20 + [F] * 17 + [T] * 4
+filter_cases.append(dict(name="test_slices", source="arrow-select/src/filter.rs:1758", mask=m,
+                         slices=[[0, 10], [40, 60], [77, 81]],
+                         sliced=dict(offset=7, length=len(m) - 10, slices=[[0, 3], [33, 53], [70, 71]])))
+
+take_cases = []
+take_cases.append(dict(name="non_null_indices", source="arrow-select/src/take.rs:1295",
+                       values=arr("Int8", [N, 3, 5, 2, 3, N]), indices=arr("UInt32", [0, 5, 3, 1, 4, 2]),
+                       expected=arr("Int8", [N, N, 2, 3, 3, 5])))
+take_cases.append(dict(name="non_null_values", source="arrow-select/src/take.rs:1307",
+                       values=arr("Int8", [0, 1, 2, 3, 4]), indices=arr("UInt32", [3, N, 1, 3, 2]),
+                       expected=arr("Int8", [3, N, 1, 3, 2])))
+take_cases.append(dict(name="non_null", source="arrow-select/src/take.rs:1319",
+                       values=arr("Int8", [0, 3, 5, 2, 3, 1]), indices=arr("UInt32", [0, 5, 3, 1, 4, 2]),
+                       expected=arr("Int8", [0, 1, 2, 3, 3, 5])))
+take_cases.append(dict(name="nullable_indices_non_null_values_with_offset", source="arrow-select/src/take.rs:1331",
+                       values=arr("Int64", [0, 10, 20, 30, 40, 50]),
+                       indices=arr("UInt32", [0, 1, 2, 3, N, N], [2, 4]), expected=arr("Int64", [20, 30, N, N])))
+take_cases.append(dict(name="nullable_indices_nullable_values_with_offset", source="arrow-select/src/take.rs:1351",
+                       values=arr("Int64", [N, N, 20, 30, 40, 50]),
+                       indices=arr("UInt32", [0, 1, 2, 3, N, N], [2, 4]), expected=arr("Int64", [20, 30, N, N])))
+for t in ["Int8", "Int16", "Int32", "Int64", "UInt8", "UInt16", "UInt32", "UInt64", "Float32", "Float64",
+          "Date32", "Date64", "Time32(Second)", "Time64(Nanosecond)", "Duration(Second)",
+          "Timestamp(Millisecond, None)"]:
+    take_cases.append(dict(name=f"test_take_primitive_{t}", source="arrow-select/src/take.rs:1371-1551",
+                           values=arr(t, [0, N, 2, 3, N]), indices=arr("UInt32", [3, N, 1, 3, 2]),
+                           expected=arr(t, [3, N, N, 3, 2])))
+for it in ["Int64", "Int16", "UInt64", "UInt8", "Int8", "UInt16", "Int32"]:
+    take_cases.append(dict(name=f"index_type_{it}", source="arrow-select/src/take.rs:1553-1625",
+                           values=arr("Int64", [0, N, 2, -15, N]), indices=arr(it, [3, N, 1, 3, 2]),
+                           expected=arr("Int64", [-15, N, N, -15, 2])))
+take_cases.append(dict(name="index_int64_f32", source="arrow-select/src/take.rs:1553-1596",
+                       values=arr("Float32", [0.0, N, 2.21, -3.1, N]), indices=arr("Int64", [3, N, 1, 3, 2]),
+                       expected=arr("Float32", [-3.1, N, N, -3.1, 2.21])))
+take_cases.append(dict(name="test_take_bool", source="arrow-select/src/take.rs:1627",
+                       values=arr("Boolean", [F, N, T, F, N]), indices=arr("UInt32", [3, N, 1, 3, 2]),
+                       expected=arr("Boolean", [F, N, N, F, T])))
+take_cases.append(dict(name="test_take_bool_nullable_index", source="arrow-select/src/take.rs:1639",
+                       values=arr("Boolean", [T, N, F]),
+                       indices=dict(type="UInt32", raw=[99, 0, 999, 1, 9999, 2], valid=[F, T, F, T, F, T]),
+                       expected=arr("Boolean", [N, T, N, N, N, F])))
+take_cases.append(dict(name="test_take_bool_nullable_index_nonnull_values", source="arrow-select/src/take.rs:1662",
+                       values=arr("Boolean", [T, T, F]),
+                       indices=dict(type="UInt32", raw=[99, 0, 999, 1, 9999, 2], valid=[F, T, F, T, F, T]),
+                       expected=arr("Boolean", [N, T, N, T, N, F])))
+take_cases.append(dict(name="test_take_null_indices", source="arrow-select/src/take.rs:2686-2699",
+                       values=arr("Int32", [1, 23, 4, 5]),
+                       indices=dict(type="Int32", raw=[1, 2, 400, 400], valid=[T, T, F, F]),
+                       expected=arr("Int32", [23, 4, N, N])))
+take_cases.append(dict(name="test_take_out_of_bounds", source="arrow-select/src/take.rs:2408-2420",
+                       values=arr("Int64", [0, N, 2, 3, N]), indices=arr("UInt32", [3, N, 1, 3, 6]),
+                       check_bounds=True, error="ComputeError",
+                       message="Array index out of bounds, cannot get item at index 6 from 5 entries"))
+take_cases.append(dict(name="test_take_out_of_bounds_panic", source="arrow-select/src/take.rs:2423-2434",
+                       values=arr("Int64", [0, 1, 2, 3]), indices=arr("UInt32", [1000]),
+                       panic="index out of bounds: the len is 4 but the index is 1000"))
+take_cases.append(dict(name="check_bounds_message", source="arrow-select/src/take.rs:2457-2466 (NullArray(5) "
+                       "replaced by an Int32 array of 5 rows: the message depends only on len)",
+                       values=arr("Int32", [0, 0, 0, 0, 0]), indices=arr("UInt32", [0, N, 15]), check_bounds=True,
+                       error="ComputeError",
+                       message="Array index out of bounds, cannot get item at index 15 from 5 entries"))
+take_cases.append(dict(name="empty_indices", source="arrow-select/src/take.rs:215-217",
+                       values=arr("Int32", [1, 2, 3]), indices=arr("UInt32", []), expected=arr("Int32", [])))
+
+arith_cases = []
+a, b = [4, 3, 5, -6, 100], [6, 2, 5, -7, 3]
+for op, exp in [("add", [10, 5, 10, -13, 103]), ("sub", [-2, 1, 0, 1, 97]), ("div", [0, 1, 1, 0, 33]),
+                ("mul", [24, 6, 25, 42, 300]), ("rem", [4, 1, 0, -6, 1])]:
+    arith_cases.append(dict(name=f"test_integer_{op}", source="arrow-arith/src/numeric.rs:1296-1316", op=op,
+                            lhs=arr("Int32", a), rhs=arr("Int32", b), expected=arr("Int32", exp)))
+arith_cases.append(dict(name="test_integer_nulls", source="arrow-arith/src/numeric.rs:1318-1322", op="add",
+                        lhs=arr("Int8", [2, N, 45]), rhs=arr("Int8", [5, 3, N]), expected=arr("Int8", [7, N, N])))
+arith_cases.append(dict(name="u8_add_overflow", source="arrow-arith/src/numeric.rs:1324-1330", op="add",
+                        lhs=arr("UInt8", [56, 5, 3]), rhs=arr("UInt8", [200, 2, 5]), error="ArithmeticOverflow",
+                        message="Overflow happened on: 56 + 200",
+                        display="Arithmetic overflow: Overflow happened on: 56 + 200"))
+arith_cases.append(dict(name="u8_add_wrapping", source="arrow-arith/src/numeric.rs:1332-1333", op="add_wrapping",
+                        lhs=arr("UInt8", [56, 5, 3]), rhs=arr("UInt8", [200, 2, 5]), expected=arr("UInt8", [0, 7, 8])))
+arith_cases.append(dict(name="u8_sub_overflow", source="arrow-arith/src/numeric.rs:1335-1339", op="sub",
+                        lhs=arr("UInt8", [34, 5, 3]), rhs=arr("UInt8", [200, 2, 5]), error="ArithmeticOverflow",
+                        message="Overflow happened on: 34 - 200"))
+arith_cases.append(dict(name="u8_sub_wrapping", source="arrow-arith/src/numeric.rs:1341-1342", op="sub_wrapping",
+                        lhs=arr("UInt8", [34, 5, 3]), rhs=arr("UInt8", [200, 2, 5]), expected=arr("UInt8", [90, 3, 254])))
+arith_cases.append(dict(name="u8_mul_overflow", source="arrow-arith/src/numeric.rs:1344-1348", op="mul",
+                        lhs=arr("UInt8", [34, 5, 3]), rhs=arr("UInt8", [200, 2, 5]), error="ArithmeticOverflow",
+                        message="Overflow happened on: 34 * 200"))
+arith_cases.append(dict(name="u8_mul_wrapping", source="arrow-arith/src/numeric.rs:1350-1351", op="mul_wrapping",
+                        lhs=arr("UInt8", [34, 5, 3]), rhs=arr("UInt8", [200, 2, 5]), expected=arr("UInt8", [144, 10, 15])))
+arith_cases.append(dict(name="i16_min_div_neg1", source="arrow-arith/src/numeric.rs:1353-1358", op="div",
+                        lhs=arr("Int16", [-32768]), rhs=arr("Int16", [-1]), error="ArithmeticOverflow",
+                        message="Overflow happened on: -32768 / -1"))
+arith_cases.append(dict(name="i16_min_rem_neg1", source="arrow-arith/src/numeric.rs:1347-1350", op="rem",
+                        lhs=arr("Int16", [-32768]), rhs=arr("Int16", [-1]), expected=arr("Int16", [0])))
+arith_cases.append(dict(name="i16_div_zero", source="arrow-arith/src/numeric.rs:1353-1361", op="div",
+                        lhs=arr("Int16", [21]), rhs=arr("Int16", [0]), error="DivideByZero",
+                        message="Divide by zero error", display="Divide by zero error"))
+arith_cases.append(dict(name="i16_rem_zero", source="arrow-arith/src/numeric.rs:1353-1361", op="rem",
+                        lhs=arr("Int16", [21]), rhs=arr("Int16", [0]), error="DivideByZero",
+                        message="Divide by zero error"))
+FMAX = 3.4028234663852886e38
+fa = [1.0, FMAX, 6.0, -4.0, -1.0, 0.0]
+fb = [1.0, FMAX, FMAX, -3.0, 45.0, 0.0]
+arith_cases.append(dict(name="test_float_add", source="arrow-arith/src/numeric.rs:1364-1372", op="add",
+                        lhs=arr("Float32", fa), rhs=arr("Float32", fb),
+                        expected=arr("Float32", [2.0, "inf", FMAX, -7.0, 44.0, 0.0])))
+arith_cases.append(dict(name="test_float_sub", source="arrow-arith/src/numeric.rs:1374-1377", op="sub",
+                        lhs=arr("Float32", fa), rhs=arr("Float32", fb),
+                        expected=arr("Float32", [0.0, 0.0, -FMAX, -1.0, -46.0, 0.0])))
+arith_cases.append(dict(name="test_float_mul", source="arrow-arith/src/numeric.rs:1379-1382", op="mul",
+                        lhs=arr("Float32", fa), rhs=arr("Float32", fb),
+                        expected=arr("Float32", [1.0, "inf", "inf", 12.0, -45.0, 0.0])))
+arith_cases.append(dict(name="test_float_rem", source="arrow-arith/src/numeric.rs:1391-1397", op="rem",
+                        lhs=arr("Float32", fa), rhs=arr("Float32", fb),
+                        expected=arr("Float32", [0.0, 0.0, 6.0, -1.0, -1.0, "nan"])))
+arith_cases.append(dict(name="type_mismatch", source="arrow-arith/src/numeric.rs:270-272", op="add",
+                        lhs=arr("Int32", [1]), rhs=arr("Int64", [1]), error="InvalidArgumentError",
+                        message="Invalid arithmetic operation: Int32 + Int64"))
+
+cmp_cases = []
+eights = [8] * 10
+seq = [6, 7, 8, 9, 10, 6, 7, 8, 9, 10]
+cmp_cases.append(dict(name="i64_lt", source="arrow-ord/src/comparison.rs:526", op="lt",
+                      lhs=arr("Int64", eights), rhs=arr("Int64", seq),
+                      expected=arr("Boolean", [F, F, F, T, T, F, F, F, T, T])))
+cmp_cases.append(dict(name="i64_lt_eq", source="arrow-ord/src/comparison.rs:650", op="lt_eq",
+                      lhs=arr("Int64", eights), rhs=arr("Int64", seq),
+                      expected=arr("Boolean", [F, F, T, T, T, F, F, T, T, T])))
+cmp_cases.append(dict(name="i64_lt_scalar", source="arrow-ord/src/comparison.rs:612", op="lt",
+                      lhs=arr("Int64", seq), rhs_scalar=dict(type="Int64", value=8),
+                      expected=arr("Boolean", [T, T, F, F, F, T, T, F, F, F])))
+cmp_cases.append(dict(name="i64_lt_nulls", source="arrow-ord/src/comparison.rs:622", op="lt",
+                      lhs=arr("Int64", [N, N, 1, 1, N, N, 2, 2]), rhs=arr("Int64", [N, 1, N, 1, N, 3, N, 3]),
+                      expected=arr("Boolean", [N, N, N, F, N, N, N, T])))
+cmp_cases.append(dict(name="i64_lt_scalar_nulls", source="arrow-ord/src/comparison.rs:640", op="lt",
+                      lhs=arr("Int64", [N, 1, 2, 3, N, 1, 2, 3, 2, N]), rhs_scalar=dict(type="Int64", value=2),
+                      expected=arr("Boolean", [N, T, F, F, N, T, F, F, F, N])))
+fl = ["nan", 7.0, 8.0, 8.0, 11.0, "nan"]
+fr = ["nan", "nan", 8.0, 9.0, 10.0, 1.0]
+cmp_cases.append(dict(name="f64_lt_total_order", source="arrow-ord/src/comparison.rs:2525-2534", op="lt",
+                      lhs=arr("Float64", fl), rhs=arr("Float64", fr), expected=arr("Boolean", [F, T, F, T, F, F])))
+cmp_cases.append(dict(name="f64_lt_eq_total_order", source="arrow-ord/src/comparison.rs:2525-2534", op="lt_eq",
+                      lhs=arr("Float64", fl), rhs=arr("Float64", fr), expected=arr("Boolean", [T, T, T, T, F, F])))
+cmp_cases.append(dict(name="f32_lt_total_order", source="arrow-ord/src/comparison.rs:2525-2534", op="lt",
+                      lhs=arr("Float32", fl), rhs=arr("Float32", fr), expected=arr("Boolean", [F, T, F, T, F, F])))
+el = ["nan", 7.0, 8.0, 8.0, 10.0]
+er = ["nan", "nan", 8.0, 8.0, 10.0]
+cmp_cases.append(dict(name="f64_eq", source="arrow-ord/src/comparison.rs:2494-2501", op="eq",
+                      lhs=arr("Float64", el), rhs=arr("Float64", er), expected=arr("Boolean", [T, F, T, T, T])))
+cmp_cases.append(dict(name="f64_neq", source="arrow-ord/src/comparison.rs:2494-2501", op="neq",
+                      lhs=arr("Float64", el), rhs=arr("Float64", er), expected=arr("Boolean", [F, T, F, F, F])))
+cmp_cases.append(dict(name="test_length_of_result_buffer", source="arrow-ord/src/comparison.rs:791-803", op="gt_eq",
+                      lhs=arr("Int8", [1] * 130), rhs=arr("Int8", [1] * 130), expected=arr("Boolean", [T] * 130)))
+cmp_cases.append(dict(name="length_mismatch", source="arrow-ord/src/cmp.rs:228-232", op="eq",
+                      lhs=arr("Int32", [1, 2]), rhs=arr("Int32", [1]), error="InvalidArgumentError",
+                      message="Cannot compare arrays of different lengths, got 2 vs 1"))
+cmp_cases.append(dict(name="type_mismatch", source="arrow-ord/src/cmp.rs:260-264", op="lt",
+                      lhs=arr("Int32", [1]), rhs=arr("Int64", [1]), error="InvalidArgumentError",
+                      message="Invalid comparison operation: Int32 < Int64"))
+
+cast_cases = []
+I64MIN, I64MAX = -9223372036854775808, 9223372036854775807
+cast_cases.append(dict(name="test_cast_from_int64_to_f64", source="arrow-cast/src/cast/mod.rs:8449-8480",
+                       values=arr("Int64", [I64MIN, -2147483648, -32768, -128, 0, 127, 32767, 2147483647, I64MAX]),
+                       to="Float64",
+                       expected=arr("Float64", [-9223372036854775808.0, -2147483648.0, -32768.0, -128.0, 0.0, 127.0,
+                                                32767.0, 2147483647.0, 9223372036854775808.0])))
+cast_cases.append(dict(name="test_cast_from_int64_to_i32", source="arrow-cast/src/cast/mod.rs:8449-8480",
+                       values=arr("Int64", [I64MIN, -2147483648, -32768, -128, 0, 127, 32767, 2147483647, I64MAX]),
+                       to="Int32",
+                       expected=arr("Int32", [N, -2147483648, -32768, -128, 0, 127, 32767, 2147483647, N])))
+cast_cases.append(dict(name="test_cast_from_int64_to_u8", source="arrow-cast/src/cast/mod.rs:8449-8480",
+                       values=arr("Int64", [I64MIN, -2147483648, -32768, -128, 0, 127, 32767, 2147483647, I64MAX]),
+                       to="UInt8", expected=arr("UInt8", [N, N, N, N, 0, 127, N, N, N])))
+cast_cases.append(dict(name="f64_to_utf8_pinned", source="arrow-cast/src/cast/mod.rs:4857-4876; "
+                       "arrow-cast/src/pretty.rs:865-899; arrow-csv/src/writer.rs:705",
+                       values=arr("Float64", [1.5, 2.5, N, 3.2234, 123.564532, -556132.25]), to="Utf8",
+                       expected=arr("Utf8", ["1.5", "2.5", N, "3.2234", "123.564532", "-556132.25"])))
+cast_cases.append(dict(name="i64_to_f64_to_utf8_chain", source="arrow-cast/src/cast/mod.rs:8449-8480 values through "
+                       "display.rs:711-723 (ryu pretty layout; digits pinned by the Float64 expectations above)",
+                       values=arr("Float64", [-9223372036854775808.0, -2147483648.0, 0.0, 127.0, 9223372036854775808.0]),
+                       to="Utf8",
+                       expected=arr("Utf8", ["-9.223372036854776e18", "-2147483648.0", "0.0", "127.0",
+                                             "9.223372036854776e18"])))
+
+for name, cases in [("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
+                    ("cast", cast_cases)]:
+    with open(os.path.join(HERE, f"{name}.json"), "w") as f:
+        json.dump({"reference": "apache/arrow-rs 59.2.0", "cases": cases}, f, indent=1)
+    print(name, len(cases))

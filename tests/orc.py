@@ -1,0 +1,337 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) + a tiny host array model.
+
+TEST INFRASTRUCTURE ONLY — never imported by the product package."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+import arrow_rs_amd as A
+from arrow_rs_amd import _lib as L
+
+View, Out = L.ArrayView, L.ArrayOut
+
+NP = {L.AH_INT8: np.int8, L.AH_INT16: np.int16, L.AH_INT32: np.int32, L.AH_INT64: np.int64,
+      L.AH_UINT8: np.uint8, L.AH_UINT16: np.uint16, L.AH_UINT32: np.uint32, L.AH_UINT64: np.uint64,
+      L.AH_FLOAT32: np.float32, L.AH_FLOAT64: np.float64, L.AH_FLOAT16: np.float16}
+
+TYPES = {t.name: t for t in [
+    A.Boolean, A.Int8, A.Int16, A.Int32, A.Int64, A.UInt8, A.UInt16, A.UInt32, A.UInt64, A.Float32,
+    A.Float64, A.Utf8, A.LargeUtf8, A.Date32, A.Date64, A.Time32Second, A.Time32Millisecond,
+    A.Time64Microsecond, A.Time64Nanosecond, A.DurationSecond, A.DurationMillisecond,
+    A.DurationMicrosecond, A.DurationNanosecond, A.TimestampSecond, A.TimestampMillisecond,
+    A.TimestampMicrosecond, A.TimestampNanosecond]}
+
+
+class HostArray:
+    """values: numpy array (bool for Boolean, list[str] for strings); valid: bool mask or None
+    (None == the array carries no null buffer)."""
+
+    def __init__(self, data_type, values, valid=None):
+        self.data_type = data_type
+        self.values = values
+        self.valid = None if valid is None else np.asarray(valid, dtype=bool)
+
+    def __len__(self):
+        return len(self.values)
+
+    @property
+    def null_count(self):
+        return 0 if self.valid is None else int(len(self.valid) - self.valid.sum())
+
+    def slice(self, off, n):
+        return HostArray(self.data_type, self.values[off:off + n],
+                         None if self.valid is None else self.valid[off:off + n])
+
+    def to_pylist(self):
+        out = []
+        for i in range(len(self)):
+            if self.valid is not None and not self.valid[i]:
+                out.append(None)
+            else:
+                v = self.values[i]
+                out.append(v.item() if hasattr(v, "item") else v)
+        return out
+
+    @classmethod
+    def from_pylist(cls, items, data_type):
+        has_null = any(x is None for x in items)
+        if data_type.physical == L.AH_BOOL:
+            vals = np.array([bool(x) if x is not None else False for x in items], dtype=bool)
+        elif data_type.physical in (L.AH_UTF8, L.AH_LARGE_UTF8):
+            vals = [x if x is not None else "" for x in items]
+        else:
+            def conv(x):
+                if x is None:
+                    return 0
+                if isinstance(x, str):
+                    return float(x)
+                return x
+            vals = np.array([conv(x) for x in items], dtype=data_type.np_dtype)
+        valid = np.array([x is not None for x in items], dtype=bool) if has_null else None
+        return cls(data_type, vals, valid)
+
+    def to_device(self, ctx=None, bit_offset=0):
+        return A.Array.from_numpy(self.values, self.valid, self.data_type, ctx, bit_offset=bit_offset)
+
+    @classmethod
+    def from_device(cls, arr):
+        return cls(arr.data_type, arr.values_numpy(), arr.valid_mask() if arr.validity is not None else None)
+
+
+class _Held:
+    """An orc_view plus the numpy buffers keeping its pointers alive."""
+
+    def __init__(self, host, bit_offset=0, elem_offset=0):
+        t = host.data_type.physical
+        v = View()
+        v.type = t
+        v.length = len(host)
+        v.null_count = -1
+        self.bufs = []
+        if t == L.AH_BOOL:
+            packed = A.pack_bits(host.values, bit_offset)
+            self.bufs.append(packed)
+            v.values = packed.ctypes.data
+            v.values_bit_offset = bit_offset
+        else:
+            # elem_offset leading garbage elements so the pointer is not 16-byte aligned
+            raw = np.concatenate([np.zeros(elem_offset, dtype=host.values.dtype), host.values])
+            raw = np.ascontiguousarray(raw)
+            self.bufs.append(raw)
+            v.values = raw.ctypes.data + elem_offset * raw.dtype.itemsize
+        if host.valid is not None:
+            nb = A.pack_bits(host.valid, bit_offset)
+            self.bufs.append(nb)
+            v.validity = nb.ctypes.data
+            v.validity_bit_offset = bit_offset
+        self.view = v
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.orc_last_error.restype = C.c_char_p
+        VP, OP = C.POINTER(View), C.POINTER(Out)
+        lib.orc_release.argtypes = [OP]
+        lib.orc_filter.argtypes = [VP, VP, OP]
+        lib.orc_take.argtypes = [VP, VP, C.c_int32, OP]
+        lib.orc_arith.argtypes = [C.c_int32, VP, C.c_int32, VP, C.c_int32, OP]
+        lib.orc_neg.argtypes = [VP, C.c_int32, OP]
+        lib.orc_compare.argtypes = [C.c_int32, VP, C.c_int32, VP, C.c_int32, OP]
+        lib.orc_cast.argtypes = [VP, C.c_int32, C.c_int32, OP]
+        lib.orc_concat.argtypes = [C.c_int32, VP, OP]
+        lib.orc_count_set_bits.restype = C.c_int64
+        lib.orc_count_set_bits.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        for f in (lib.orc_set_slices, lib.orc_set_indices):
+            f.restype = C.c_int64
+            f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
+        lib.orc_format_f64.argtypes = [C.c_double, C.c_char_p]
+        lib.orc_format_f32.argtypes = [C.c_float, C.c_char_p]
+        lib.orc_gen_uniform_i64.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, C.c_int64]
+        lib.orc_gen_uniform_i32.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64]
+        lib.orc_gen_uniform_u32.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_int64]
+        lib.orc_gen_uniform_f64.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_double, C.c_int64]
+        lib.orc_gen_bernoulli_bits.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int64]
+        lib.orc_zero_null_slots.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+
+    # ---- plumbing
+    def _raise(self, st):
+        A.array.raise_for_status(st, self.lib.orc_last_error().decode())
+
+    def _collect(self, out, data_type):
+        """orc_out -> HostArray (copies, then releases)."""
+        n = out.length
+        t = data_type.physical
+        valid = None
+        if out.validity:
+            raw = np.ctypeslib.as_array(C.cast(out.validity, C.POINTER(C.c_uint8)),
+                                        shape=((out.validity_bit_offset + n + 7) // 8,))
+            valid = A.unpack_bits(raw, out.validity_bit_offset, n).copy()
+        if n == 0:
+            vals = [] if t in (L.AH_UTF8, L.AH_LARGE_UTF8) else np.empty(0, dtype=data_type.np_dtype)
+        elif t == L.AH_BOOL:
+            nbytes = (out.values_bit_offset + n + 7) // 8
+            raw = np.ctypeslib.as_array(C.cast(out.values, C.POINTER(C.c_uint8)), shape=(nbytes,))
+            vals = A.unpack_bits(raw, out.values_bit_offset, n).copy()
+        elif t in (L.AH_UTF8, L.AH_LARGE_UTF8):
+            odt = np.int32 if t == L.AH_UTF8 else np.int64
+            offs = np.ctypeslib.as_array(C.cast(out.offsets, C.POINTER(C.c_uint8)),
+                                         shape=(out.offsets_bytes,)).view(odt).copy()
+            data = C.string_at(out.values, out.values_bytes) if out.values_bytes else b""
+            vals = [data[offs[i]:offs[i + 1]].decode() for i in range(n)]
+        else:
+            w = data_type.width
+            raw = np.ctypeslib.as_array(C.cast(out.values, C.POINTER(C.c_uint8)), shape=(n * w,))
+            vals = raw.view(data_type.np_dtype).copy()
+        res = HostArray(data_type, vals, valid)
+        res.reported_null_count = out.null_count
+        self.lib.orc_release(C.byref(out))
+        return res
+
+    # ---- reference-shaped entry points
+    def filter(self, values, predicate, bit_offset=0, elem_offset=0):
+        hv, hp = _Held(values, bit_offset, elem_offset), _Held(predicate, bit_offset)
+        out = Out()
+        st = self.lib.orc_filter(C.byref(hv.view), C.byref(hp.view), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, values.data_type)
+
+    def take(self, values, indices, check_bounds=False, bit_offset=0):
+        hv, hi = _Held(values, bit_offset), _Held(indices, bit_offset)
+        out = Out()
+        st = self.lib.orc_take(C.byref(hv.view), C.byref(hi.view), int(check_bounds), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, values.data_type)
+
+    def arith(self, op, lhs, rhs, l_scalar=False, r_scalar=False, bit_offset=0):
+        hl, hr = _Held(lhs, bit_offset), _Held(rhs, bit_offset)
+        out = Out()
+        st = self.lib.orc_arith(op, C.byref(hl.view), int(l_scalar), C.byref(hr.view), int(r_scalar), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, lhs.data_type)
+
+    def neg(self, values, wrapping=False):
+        hv = _Held(values)
+        out = Out()
+        st = self.lib.orc_neg(C.byref(hv.view), int(wrapping), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, values.data_type)
+
+    def compare(self, op, lhs, rhs, l_scalar=False, r_scalar=False, bit_offset=0):
+        hl, hr = _Held(lhs, bit_offset), _Held(rhs, bit_offset)
+        out = Out()
+        st = self.lib.orc_compare(op, C.byref(hl.view), int(l_scalar), C.byref(hr.view), int(r_scalar), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, A.Boolean)
+
+    def cast(self, values, to_type, safe=True, bit_offset=0):
+        hv = _Held(values, bit_offset)
+        out = Out()
+        st = self.lib.orc_cast(C.byref(hv.view), to_type.physical, int(safe), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, to_type)
+
+    def concat(self, arrays):
+        held = [_Held(a) for a in arrays]
+        views = (View * len(arrays))(*[h.view for h in held])
+        out = Out()
+        st = self.lib.orc_concat(len(arrays), views, C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, arrays[0].data_type)
+
+    def set_slices(self, mask, bit_offset=0):
+        packed = A.pack_bits(mask, bit_offset)
+        buf = np.zeros(2 * (len(mask) + 1), dtype=np.int64)
+        n = self.lib.orc_set_slices(packed.ctypes.data, bit_offset, len(mask), buf.ctypes.data, len(mask) + 1)
+        return [tuple(int(x) for x in buf[2 * i:2 * i + 2]) for i in range(n)]
+
+    def set_indices(self, mask, bit_offset=0):
+        packed = A.pack_bits(mask, bit_offset)
+        buf = np.zeros(len(mask) + 1, dtype=np.int64)
+        n = self.lib.orc_set_indices(packed.ctypes.data, bit_offset, len(mask), buf.ctypes.data, len(mask) + 1)
+        return [int(x) for x in buf[:n]]
+
+    def count_set_bits(self, mask, bit_offset=0):
+        packed = A.pack_bits(mask, bit_offset)
+        return self.lib.orc_count_set_bits(packed.ctypes.data, bit_offset, len(mask))
+
+    def format_f64(self, v):
+        b = C.create_string_buffer(64)
+        n = self.lib.orc_format_f64(float(v), b)
+        return b.raw[:n].decode()
+
+    def format_f32(self, v):
+        b = C.create_string_buffer(64)
+        n = self.lib.orc_format_f32(float(np.float32(v)), b)
+        return b.raw[:n].decode()
+
+    # host twins of the device generators
+    def gen_i64(self, n, seed, lo, hi, row0=0):
+        a = np.empty(n, dtype=np.int64)
+        self.lib.orc_gen_uniform_i64(a.ctypes.data, n, seed, lo, hi, row0)
+        return a
+
+    def gen_i32(self, n, seed, row0=0):
+        a = np.empty(n, dtype=np.int32)
+        self.lib.orc_gen_uniform_i32(a.ctypes.data, n, seed, row0)
+        return a
+
+    def gen_u32(self, n, seed, bound, row0=0):
+        a = np.empty(n, dtype=np.uint32)
+        self.lib.orc_gen_uniform_u32(a.ctypes.data, n, seed, bound, row0)
+        return a
+
+    def gen_f64(self, n, seed, lo, hi, row0=0):
+        a = np.empty(n, dtype=np.float64)
+        self.lib.orc_gen_uniform_f64(a.ctypes.data, n, seed, lo, hi, row0)
+        return a
+
+    def gen_bits(self, n, seed, p, row0=0):
+        a = np.zeros(((n + 63) // 64) * 8, dtype=np.uint8)
+        self.lib.orc_gen_bernoulli_bits(a.ctypes.data, n, seed, p, row0)
+        return A.unpack_bits(a, 0, n)
+
+
+def load(path):
+    return Oracle(C.CDLL(path))
+
+
+# --------------------------------------------------------------- comparisons
+def assert_logical_eq(got, exp, msg=""):
+    """Arrow logical equality (arrow-data/src/equal/mod.rs:161-166, equal/primitive.rs:28-98):
+    type, length, null_count, validity bits, and value BYTES at valid slots only."""
+    assert got.data_type == exp.data_type, f"{msg} type {got.data_type} != {exp.data_type}"
+    assert len(got) == len(exp), f"{msg} len {len(got)} != {len(exp)}"
+    gv = got.valid if got.valid is not None else np.ones(len(got), dtype=bool)
+    ev = exp.valid if exp.valid is not None else np.ones(len(exp), dtype=bool)
+    assert np.array_equal(gv, ev), f"{msg} validity differs at {np.nonzero(gv != ev)[0][:10]}"
+    if isinstance(exp.values, list):
+        for i in range(len(exp)):
+            if ev[i]:
+                assert got.values[i] == exp.values[i], f"{msg} row {i}: {got.values[i]!r} != {exp.values[i]!r}"
+        return
+    g = np.asarray(got.values)
+    e = np.asarray(exp.values)
+    if g.dtype == np.bool_:
+        assert np.array_equal(g[ev], e[ev]), f"{msg} boolean values differ"
+        return
+    gb = g.view(np.uint8).reshape(len(g), -1) if len(g) else g
+    eb = e.view(np.uint8).reshape(len(e), -1) if len(e) else e
+    if len(g):
+        bad = np.nonzero((gb != eb).any(axis=1) & ev)[0]
+        assert len(bad) == 0, f"{msg} values differ at rows {bad[:10]}: {g[bad[:5]]} vs {e[bad[:5]]}"
+
+
+def assert_same_nulls_presence(got, exp, msg=""):
+    """`nulls().is_some()` and null_count observably identical to the reference."""
+    assert (got.valid is None) == (exp.valid is None), \
+        f"{msg} null buffer presence: got {got.valid is not None}, expected {exp.valid is not None}"
+    assert got.null_count == exp.null_count, f"{msg} null_count {got.null_count} != {exp.null_count}"
+
+
+def load_golden(name):
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", f"{name}.json")) as f:
+        return json.load(f)["cases"]
+
+
+def golden_array(spec):
+    """JSON array spec -> HostArray (applies the optional slice)."""
+    dt = TYPES[spec["type"]]
+    if "raw" in spec:
+        vals = np.array(spec["raw"], dtype=dt.np_dtype)
+        h = HostArray(dt, vals, np.array(spec["valid"], dtype=bool))
+    else:
+        h = HostArray.from_pylist(spec["data"], dt)
+    if "slice" in spec:
+        h = h.slice(*spec["slice"])
+    return h
