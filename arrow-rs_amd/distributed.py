@@ -1,0 +1,145 @@
+"""Row-range sharding of a column across the GPUs of one node + RCCL reassembly.
+
+The reference has no parallelism of any kind (kernels are synchronous pure functions,
+SURVEY.md §2); this module is new capability required by the north star: a RecordBatch is
+split by contiguous row range (``RecordBatch::slice`` semantics,
+arrow-array/src/record_batch.rs:681), each GPU runs the single-GPU kernels on its range, and
+the global result is the in-order concatenation of the shard results — the oracle for which is
+``arrow_select::concat`` (arrow-select/src/concat.rs:495, primitives :334-343).
+
+There is ONE exchange step, an all-gatherv with counts known only after the filter:
+
+  1. all-gather of (len, null_count, has_validity) per rank  (3 x i64)
+  2. values: every rank receives each peer's piece DIRECTLY at its final offset with grouped
+     point-to-point send/recv (``batch_isend_irecv`` -> ncclGroupStart/End): xGMI is a
+     point-to-point fabric (7 links per GPU), so a direct exchange drives all links at once
+     whereas a ring all-gather is bound by one link.  RCCL has no native all-gatherv.
+  3. validity: pieces land at bit offset sum(len_<r), generally not byte aligned, so they are
+     gathered into a staging buffer and merged by the funnel-shift kernel
+     (``ah_bitmap_set_bits``; reference analogue arrow-buffer/src/util/bit_mask.rs:33).
+
+One process per GPU (``torch.distributed``, backend "nccl" == RCCL on ROCm).  torch is only
+used for the collective; device memory stays owned by the arrow_hip context.
+"""
+import ctypes as C
+
+from . import _lib as L
+from .array import Array, DeviceBuffer, _RawMem, NotYetImplemented
+
+
+def shard_range(n_rows, rank, world, align=64):
+    """Rows [start, end) owned by ``rank``: contiguous, boundaries rounded to a multiple of
+    ``align`` rows so input bitmaps split on word boundaries."""
+    per = -(-n_rows // world)
+    per = -(-per // align) * align
+    start = min(n_rows, rank * per)
+    end = min(n_rows, start + per)
+    return start, end
+
+
+def exclusive_offsets(sizes):
+    offs, acc = [], 0
+    for s in sizes:
+        offs.append(acc)
+        acc += int(s)
+    return offs, acc
+
+
+def all_gatherv_bytes(dist, local, out, offsets, sizes, group=None):
+    """Every rank ends with ``out[offsets[r]:offsets[r]+sizes[r]] == rank r's local`` for all r.
+    ``local`` / ``out`` are 1-D uint8 tensors (CUDA with nccl, CPU with gloo)."""
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    if sizes[rank]:
+        out[offsets[rank]:offsets[rank] + sizes[rank]].copy_(local[:sizes[rank]])
+    if world == 1:
+        return
+    ops = []
+    for step in range(1, world):  # stagger peers so every link is busy in both directions
+        dst = (rank + step) % world
+        src = (rank - step) % world
+        if sizes[rank]:
+            ops.append(dist.P2POp(dist.isend, local[:sizes[rank]], dst, group))
+        if sizes[src]:
+            ops.append(dist.P2POp(dist.irecv, out[offsets[src]:offsets[src] + sizes[src]], src, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+class _CudaView:
+    """Zero-copy hand-off of an arrow_hip device range to torch (__cuda_array_interface__ v2)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1",
+                                         "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class Communicator:
+    """RCCL-backed reassembly of row-sharded results for one arrow_hip context."""
+
+    def __init__(self, ctx, dist, group=None):
+        import torch
+        self.torch, self.dist, self.ctx, self.group = torch, dist, ctx, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = torch.device("cuda", ctx.device)
+
+    def _tensor(self, ptr, nbytes):
+        if nbytes == 0:
+            return self.torch.empty(0, dtype=self.torch.uint8, device=self.device)
+        return self.torch.as_tensor(_CudaView(ptr, nbytes), device=self.device)
+
+    def all_gatherv(self, array):
+        """Concatenation of every rank's ``array`` in rank order, materialised on every rank
+        (== arrow_select::concat of the shard results)."""
+        torch, dist, ctx = self.torch, self.dist, self.ctx
+        dt = array.data_type
+        w = dt.width
+        if w <= 0:
+            raise NotYetImplemented(f"all_gatherv of {dt}")
+        has_v = 1 if (array.validity is not None and array.null_count() > 0) else 0
+        mine = torch.tensor([array.length, array.null_count(), has_v], dtype=torch.int64, device=self.device)
+        allc = torch.empty((self.world, 3), dtype=torch.int64, device=self.device)
+        ctx.synchronize()  # array's producer kernels ran on the context stream
+        dist.all_gather_into_tensor(allc, mine, group=self.group)
+        counts = allc.cpu().tolist()
+        lens = [c[0] for c in counts]
+        row_offs, total = exclusive_offsets(lens)
+        any_valid = any(c[2] for c in counts)
+
+        # values: straight to their final offsets
+        out_vals = DeviceBuffer(ctx, max(total * w, 8))
+        local = self._tensor(array.values.ptr, array.length * w) if array.length else self._tensor(0, 0)
+        out_t = self._tensor(out_vals.ptr, total * w)
+        all_gatherv_bytes(dist, local, out_t, [o * w for o in row_offs], [n * w for n in lens], self.group)
+
+        vmem, nulls = None, 0
+        if any_valid:
+            lib, h = ctx.lib, ctx.handle
+            pbytes = [((n + 63) // 64) * 8 for n in lens]
+            poffs, ptotal = exclusive_offsets(pbytes)
+            # local validity packed at bit offset 0 (all ones if this shard carries no nulls)
+            mine_bits = DeviceBuffer(ctx, max(pbytes[self.rank], 8))
+            ctx.check(lib.ah_memset(h, mine_bits.ptr, 0, mine_bits.nbytes))
+            if array.length:
+                src = array.validity.ptr if has_v else None
+                ctx.check(lib.ah_bitmap_set_bits(h, mine_bits.ptr, 0, src,
+                                                 array.validity_bit_offset if has_v else 0, array.length, None))
+            ctx.synchronize()
+            staging = DeviceBuffer(ctx, max(ptotal, 8))
+            all_gatherv_bytes(dist, self._tensor(mine_bits.ptr, pbytes[self.rank]),
+                              self._tensor(staging.ptr, ptotal), poffs, pbytes, self.group)
+            torch.cuda.synchronize(self.device)
+            out_valid = DeviceBuffer(ctx, ((total + 63) // 64) * 8)
+            ctx.check(lib.ah_memset(h, out_valid.ptr, 0, out_valid.nbytes))
+            for r in range(self.world):
+                if lens[r]:
+                    ctx.check(lib.ah_bitmap_set_bits(h, out_valid.ptr, row_offs[r], staging.ptr + poffs[r], 0,
+                                                     lens[r], None))
+            ctx.synchronize()
+            nulls = sum(c[1] for c in counts)
+            vmem = _RawMem(out_valid.ptr, out_valid.nbytes, out_valid)
+        else:
+            torch.cuda.synchronize(self.device)
+        return Array(ctx, dt, total, _RawMem(out_vals.ptr, total * w, out_vals), 0, vmem, 0, nulls)

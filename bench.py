@@ -1,0 +1,308 @@
+#!/usr/bin/env python
+"""bench.py — the hot-path benchmark (BASELINE.json metric: Mrows/s + achieved HBM GB/s,
+filter->take on 1e9-row Int64 with 10% nulls, 1/2/4/8 GPUs).
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already
+resident in HBM: ``filter(values, predicate)`` followed by ``take(values, indices)`` through
+the C ABI (libarrow_hip.so), exactly as an engine calling ``arrow::compute::kernels`` would.
+Default workload = BASELINE.json configs[1]: Int64 x 1e9 rows, Bernoulli(0.9) validity,
+Bernoulli(0.1) predicate, 1e8 uniform UInt32 take indices.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU (weak scaling): every rank owns one 1e9-row shard of an N x 1e9-row column
+(row-range sharding), filters/takes locally, then the filtered shard results are
+reassembled on every rank with an all-gatherv over RCCL (north_star).  ``value`` includes the
+reassembly; ``local_value`` is the same run's rate without it.
+
+Other workloads (for the per-kernel roofline table in DESIGN.md): --workload arith|cmp|cast|cast_string.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable copy
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
+    p.add_argument("--selectivity", type=float, default=0.1)
+    p.add_argument("--valid", type=float, default=0.9)
+    p.add_argument("--workload", default="filter_take",
+                   choices=["filter_take", "arith", "cmp", "cast", "cast_string"])
+    p.add_argument("--reassemble", default="auto", choices=["auto", "none", "allgatherv"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
+    return p.parse_args()
+
+
+def mk_array(A, ctx, dt, n, vals, valid=None, nulls=0):
+    R = A.array._RawMem
+    return A.Array(ctx, dt, n, R(vals.ptr, vals.nbytes, vals), 0,
+                   R(valid.ptr, valid.nbytes, valid) if valid is not None else None, 0, nulls)
+
+
+def count_bits(ctx, buf, n):
+    c = C.c_int64()
+    ctx.check(ctx.lib.ah_count_set_bits(ctx.handle, buf.ptr, 0, n, C.byref(c)))
+    return c.value
+
+
+def gen_i64_column(A, ctx, n, seed, p_valid, row0, lo=-2**63, hi=2**63 - 1):
+    lib, h = ctx.lib, ctx.handle
+    vals = ctx.alloc(n * 8)
+    valid = ctx.alloc(((n + 63) // 64) * 8)
+    ctx.check(lib.ah_gen_uniform_i64(h, vals.ptr, n, seed, lo, hi, row0))
+    ctx.check(lib.ah_gen_bernoulli_bits(h, valid.ptr, n, seed + 1, p_valid, row0))
+    ctx.check(lib.ah_zero_null_slots(h, vals.ptr, 8, valid.ptr, n))
+    return mk_array(A, ctx, A.Int64, n, vals, valid, n - count_bits(ctx, valid, n))
+
+
+def gen_f64_column(A, ctx, n, seed, p_valid, row0):
+    lib, h = ctx.lib, ctx.handle
+    vals = ctx.alloc(n * 8)
+    valid = ctx.alloc(((n + 63) // 64) * 8)
+    ctx.check(lib.ah_gen_uniform_f64(h, vals.ptr, n, seed, -1e6, 1e6, row0))
+    ctx.check(lib.ah_gen_bernoulli_bits(h, valid.ptr, n, seed + 1, p_valid, row0))
+    ctx.check(lib.ah_zero_null_slots(h, vals.ptr, 8, valid.ptr, n))
+    return mk_array(A, ctx, A.Float64, n, vals, valid, n - count_bits(ctx, valid, n))
+
+
+def gen_predicate(A, ctx, n, seed, p_true, row0):
+    bits = ctx.alloc(((n + 63) // 64) * 8)
+    ctx.check(ctx.lib.ah_gen_bernoulli_bits(ctx.handle, bits.ptr, n, seed, p_true, row0))
+    return mk_array(A, ctx, A.Boolean, n, bits)
+
+
+def cpu_baseline_filter_take(args):
+    """The oracle (a scalar port of the reference's algorithm) timed on ONE host core over a
+    bounded sample of the same workload.  Reported baseline, never the thing shipped."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import arrow_rs_amd as A
+    import orc
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so):
+        return None
+    oracle = orc.load(so)
+    n = args.cpu_sample_rows
+    vals = oracle.gen_i64(n, 42, -2**63, 2**63 - 1)
+    valid = oracle.gen_bits(n, 43, args.valid)
+    mask = oracle.gen_bits(n, 44, args.selectivity)
+    vals[~valid] = 0
+    idx = oracle.gen_u32(max(1, int(n * args.selectivity)), 45, n)
+    hv = orc.HostArray(A.Int64, vals, valid)
+    hm = orc.HostArray(A.Boolean, mask)
+    hi = orc.HostArray(A.UInt32, idx)
+    # pre-pack once (packing is harness cost, not kernel cost)
+    hvh, hmh, hih = orc._Held(hv), orc._Held(hm), orc._Held(hi)
+    reps, t_total = 0, 0.0
+    while t_total < 8.0 and reps < 50:
+        out = orc.Out()
+        t0 = time.perf_counter()
+        st = oracle.lib.orc_filter(C.byref(hvh.view), C.byref(hmh.view), C.byref(out))
+        t1 = time.perf_counter()
+        assert st == 0
+        oracle.lib.orc_release(C.byref(out))
+        out = orc.Out()
+        t2 = time.perf_counter()
+        st = oracle.lib.orc_take(C.byref(hvh.view), C.byref(hih.view), 0, C.byref(out))
+        t3 = time.perf_counter()
+        assert st == 0
+        oracle.lib.orc_release(C.byref(out))
+        t_total += (t1 - t0) + (t3 - t2)
+        reps += 1
+    mrows = n * reps / t_total / 1e6
+    return {"value": round(mrows, 2), "unit": "Mrows/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x (filter + take) on {n} Int64 rows, {int(n * args.selectivity)} u32 indices, "
+                      f"same generators/densities; oracle/liboracle.so single thread; "
+                      f"host has {os.cpu_count()} cores"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    import arrow_rs_amd as A
+    from arrow_rs_amd import compute as K
+    ctx = A.Context(local_rank)
+    A.set_default_context(ctx)
+    n = args.rows
+    row0 = rank * n  # this rank's row range of the global column
+    reassemble = world > 1 and args.reassemble in ("auto", "allgatherv")
+    comm = None
+    if world > 1:
+        from arrow_rs_amd import distributed as D
+        comm = D.Communicator(ctx, dist)
+
+    def sync_all():
+        ctx.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    wl = args.workload
+    extra = {}
+    if wl == "filter_take":
+        col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
+        pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
+        nidx = max(1, int(n * args.selectivity))
+        ib = ctx.alloc(nidx * 4)
+        ctx.check(ctx.lib.ah_gen_uniform_u32(ctx.handle, ib.ptr, nidx, 45 + rank, n if n < 2**32 else 0, 0))
+        idx = mk_array(A, ctx, A.UInt32, nidx, ib)
+        state = {}
+
+        def step(with_reassembly):
+            f = K.filter(col, pred)
+            t = K.take(col, idx)
+            state["k"], state["fn"], state["tn"] = f.length, f.null_count(), t.null_count()
+            if with_reassembly:
+                g = comm.all_gatherv(f)
+                state["gk"] = g.length
+            return f, t
+
+        kernels = ["filter_count", "filter_scatter", "take_gather"]
+        dominant = "filter_scatter"
+    elif wl in ("arith", "cmp"):
+        a = gen_f64_column(A, ctx, n, 52, args.valid, row0)
+        b = gen_f64_column(A, ctx, n, 62, args.valid, row0)
+        fn = K.add_wrapping if wl == "arith" else K.lt
+        step = lambda _r: fn(a, b)
+        kernels = ["arith_binary" if wl == "arith" else "compare"]
+        dominant = kernels[0]
+    else:
+        n = min(n, 1 << 29) if args.rows == 1_000_000_000 else n
+        src = gen_i64_column(A, ctx, n, 42, args.valid, row0, -10**6, 10**6)
+        if wl == "cast":
+            step = lambda _r: K.cast(src, A.Float64)
+            kernels = ["cast_numeric"]
+        else:
+            f64 = K.cast(src, A.Float64)
+            step = lambda _r: K.cast(f64, A.LargeUtf8)
+            kernels = ["cast_string_len", "cast_string_write"]
+        dominant = kernels[-1]
+
+    for _ in range(args.warmup):
+        step(reassemble)
+    ctx.profile(True)
+    ctx.profile_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(reassemble)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    prof = {k: ctx.profile_get(k) for k in kernels}
+    ctx.profile(False)
+
+    local_elapsed = None
+    if reassemble:  # same run, same data, without the exchange step
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(False)
+        sync_all()
+        local_elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        tt = torch.tensor([elapsed, local_elapsed or 0.0], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, local_elapsed = float(tt[0]), (float(tt[1]) if reassemble else None)
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = n * world * args.steps / elapsed / 1e6
+        dom_ms, dom_n = prof[dominant]
+        dom_avg_ms = dom_ms / max(dom_n, 1)
+        if wl == "filter_take":
+            k = state["k"]
+            has_valid_out = state["fn"] > 0
+            # values + validity + mask read once, K values (+ K bits) written once
+            alg_bytes = n * 8 + 2 * ((n + 7) // 8) + k * 8 + (((k + 7) // 8) if has_valid_out else 0)
+            take_bytes = idx.length * (4 + 8 + 8) + 2 * ((idx.length + 7) // 8)
+            step_alg = alg_bytes + take_bytes
+            tk_ms, tk_n = prof["take_gather"]
+            extra = {
+                "filter_selected_rows": k, "filter_null_count": state["fn"],
+                "take_indices": idx.length,
+                "filter_scatter_ms": round(dom_avg_ms, 4),
+                "filter_count_ms": round(prof["filter_count"][0] / max(prof["filter_count"][1], 1), 4),
+                "take_gather_ms": round(tk_ms / max(tk_n, 1), 4),
+                "take_algorithmic_GBps": round(take_bytes / (tk_ms / max(tk_n, 1) * 1e-3) / 1e9, 1) if tk_n else None,
+                "step_algorithmic_GBps": round(step_alg / (ms_step * 1e-3) / 1e9, 1),
+            }
+            workload = (f"configs[1]: filter()+take() on {n}-row Int64 per GPU, {args.valid:.0%} valid, "
+                        f"{args.selectivity:.0%} selectivity, {idx.length} uniform UInt32 take indices")
+            metric = "filter_take_Mrows_per_s"
+            dtype = "int64"
+        else:
+            per_row = {"arith": 24.375, "cmp": 16.5, "cast": 16.25}.get(wl)
+            if per_row is None:  # cast_string: input + offsets + bytes + validity
+                o = out
+                alg_bytes = n * 8 + (n + 7) // 8 + (n + 1) * 8 + o.values.nbytes + (n + 7) // 8
+                dom_ms_all = sum(prof[k][0] for k in kernels) / max(prof[kernels[0]][1], 1)
+                dom_avg_ms = dom_ms_all
+            else:
+                alg_bytes = int(per_row * n)
+            workload = {"arith": "configs[2]: add_wrapping Float64+Float64 with NullBuffers",
+                        "cmp": "configs[2]: lt Float64<Float64 with NullBuffers",
+                        "cast": "configs[3]: cast Int64->Float64",
+                        "cast_string": "configs[3]: cast Float64->LargeUtf8"}[wl] + f", {n} rows per GPU"
+            metric = f"{wl}_Mrows_per_s"
+            dtype = "f64"
+        achieved = alg_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+        line = {
+            "metric": metric, "value": round(value, 1), "unit": "Mrows/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            "data": "synthetic",
+            "config": {"workload": workload, "rows_per_gpu": n, "parallelism": f"row-sharded x{world}",
+                       "reassemble": ("allgatherv" if reassemble else "none")},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom_n},
+        }
+        if local_elapsed:
+            line["local_value"] = round(n * world * args.steps / local_elapsed / 1e6, 1)
+            line["local_ms_per_step"] = round(local_elapsed / args.steps * 1e3, 4)
+        line.update(extra)
+        if not args.no_cpu_baseline and world == 1 and wl == "filter_take":
+            try:
+                cb = cpu_baseline_filter_take(args)
+                if cb:
+                    line["cpu_baseline"] = cb
+            except Exception as ex:  # never lose the GPU line to a baseline hiccup
+                line["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,276 @@
+// arrow_hip.hpp — C++17 host-side mirror of `arrow::compute::kernels` over the C ABI.
+//
+// The reference is compiled (Rust) code and no Rust toolchain exists in this image, so the
+// host side above the C ABI is C++: same function names, argument order, option structs and
+// error behaviour as the reference (`Result<ArrayRef, ArrowError>` becomes a thrown
+// `ArrowError`, a reference panic becomes a thrown `Panic`).  Header-only; needs only
+// arrow_hip.h and libarrow_hip.so (no HIP headers, no torch).
+//
+//   arrow_hip::compute::filter            arrow-select/src/filter.rs:201
+//   arrow_hip::compute::filter_record_batch                        :225
+//   arrow_hip::compute::FilterBuilder / FilterPredicate            :248-533
+//   arrow_hip::compute::take / TakeOptions arrow-select/src/take.rs:89, :388
+//   arrow_hip::compute::{add,add_wrapping,sub,...,rem,neg,neg_wrapping}
+//                                         arrow-arith/src/numeric.rs:36-186
+//   arrow_hip::compute::{eq,neq,lt,lt_eq,gt,gt_eq,distinct,not_distinct}
+//                                         arrow-ord/src/cmp.rs:79-202
+//   arrow_hip::compute::cast / cast_with_options / CastOptions
+//                                         arrow-cast/src/cast/mod.rs:347,:790,:95
+//   arrow_hip::compute::concat            arrow-select/src/concat.rs:495
+#pragma once
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "arrow_hip.h"
+
+namespace arrow_hip {
+
+// ArrowError (arrow-schema/src/error.rs:26-69); what() == Rust Display
+class ArrowError : public std::runtime_error {
+ public:
+  ArrowError(ah_status code, std::string msg)
+      : std::runtime_error(prefix(code) + (code == AH_DIVIDE_BY_ZERO ? std::string() : msg)),
+        code_(code), message_(std::move(msg)) {}
+  ah_status code() const { return code_; }
+  const std::string& message() const { return message_; }
+
+ private:
+  static std::string prefix(ah_status c) {
+    switch (c) {
+      case AH_INVALID_ARGUMENT: return "Invalid argument error: ";
+      case AH_COMPUTE_ERROR: return "Compute error: ";
+      case AH_ARITHMETIC_OVERFLOW: return "Arithmetic overflow: ";
+      case AH_DIVIDE_BY_ZERO: return "Divide by zero error";
+      case AH_CAST_ERROR: return "Cast error: ";
+      case AH_NOT_YET_IMPLEMENTED: return "Not yet implemented: ";
+      default: return "";
+    }
+  }
+  ah_status code_;
+  std::string message_;
+};
+// the reference would panic!() (OOB take without check_bounds, offset overflow)
+class Panic : public std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+// One HIP stream + pooled HBM allocator; one per calling thread.
+class Context {
+ public:
+  explicit Context(int device = 0) {
+    if (ah_context_create(device, &h_) != AH_OK)
+      throw std::runtime_error("ah_context_create failed: no usable MI355X (no CPU fallback)");
+  }
+  ~Context() { ah_context_destroy(h_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  ah_context* handle() const { return h_; }
+  void check(ah_status st) const {
+    if (st == AH_OK) return;
+    std::string m = ah_last_error(h_);
+    if (st == AH_PANIC || st == AH_OFFSET_OVERFLOW) throw Panic(m);
+    throw ArrowError(st, m);
+  }
+
+ private:
+  ah_context* h_ = nullptr;
+};
+
+// An array whose buffers live in HBM (PrimitiveArray<T> / BooleanArray / StringArray).
+// Owns an ah_array_out, or borrows a caller-described view.
+class Array {
+ public:
+  Array(std::shared_ptr<Context> ctx, const ah_array_out& out, std::vector<std::shared_ptr<Array>> keep = {})
+      : ctx_(std::move(ctx)), out_(out), owned_(true), keep_(std::move(keep)) {
+    view_.type = out.type;
+    view_.length = out.length;
+    view_.null_count = out.validity ? out.null_count : 0;
+    view_.values = out.values;
+    view_.values_bit_offset = out.values_bit_offset;
+    view_.validity = out.validity;
+    view_.validity_bit_offset = out.validity_bit_offset;
+  }
+  // wrap device memory the caller owns (kept alive by the caller)
+  Array(std::shared_ptr<Context> ctx, const ah_array_view& v) : ctx_(std::move(ctx)), view_(v) {
+    std::memset(&out_, 0, sizeof out_);
+  }
+  ~Array() {
+    if (owned_) ah_array_release(ctx_->handle(), &out_);
+  }
+  Array(const Array&) = delete;
+  Array& operator=(const Array&) = delete;
+
+  ah_type data_type() const { return view_.type; }
+  int64_t len() const { return view_.length; }
+  bool is_empty() const { return view_.length == 0; }
+  int64_t null_count() const { return view_.validity ? view_.null_count : 0; }
+  bool has_nulls_buffer() const { return view_.validity != nullptr; }  // nulls().is_some()
+  const ah_array_view& view() const { return view_; }
+  const void* offsets() const { return out_.offsets; }
+  const std::shared_ptr<Context>& context() const { return ctx_; }
+  // copy `bytes` of the values buffer to the host (debug / tests)
+  void values_to_host(void* dst, size_t bytes) const {
+    ctx_->check(ah_memcpy_dtoh(ctx_->handle(), dst, view_.values, bytes));
+  }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  ah_array_view view_{};
+  ah_array_out out_{};
+  bool owned_ = false;
+  std::vector<std::shared_ptr<Array>> keep_;
+};
+using ArrayRef = std::shared_ptr<Array>;
+
+// Datum (arrow-array/src/scalar.rs:78-98): an array, or a length-1 array used as a scalar
+struct Datum {
+  ArrayRef array;
+  bool is_scalar = false;
+  Datum(ArrayRef a) : array(std::move(a)) {}  // NOLINT: arrays convert implicitly, like &dyn Datum
+  Datum(ArrayRef a, bool scalar) : array(std::move(a)), is_scalar(scalar) {}
+};
+inline Datum Scalar(ArrayRef one_element_array) { return Datum(std::move(one_element_array), true); }
+
+struct RecordBatch {  // arrow-array/src/record_batch.rs:224 (columns only)
+  std::vector<ArrayRef> columns;
+  int64_t num_rows = 0;
+};
+
+namespace compute {
+
+inline ArrayRef wrap(const ArrayRef& like, const ah_array_out& out, std::vector<ArrayRef> keep = {}) {
+  return std::make_shared<Array>(like->context(), out, std::move(keep));
+}
+
+// ---- filter (arrow-select/src/filter.rs)
+inline ArrayRef filter(const ArrayRef& values, const ArrayRef& predicate) {
+  ah_array_out out;
+  values->context()->check(ah_filter(values->context()->handle(), &values->view(), &predicate->view(), &out));
+  return wrap(values, out, {values});
+}
+
+class FilterPredicate {  // filter.rs:442-533
+ public:
+  FilterPredicate(ArrayRef predicate, ah_filter_predicate* p) : predicate_(std::move(predicate)), p_(p) {}
+  ~FilterPredicate() { ah_filter_predicate_free(predicate_->context()->handle(), p_); }
+  FilterPredicate(const FilterPredicate&) = delete;
+  int64_t count() const { return ah_filter_predicate_count(p_); }
+  ArrayRef filter(const ArrayRef& values) const {
+    ah_array_out out;
+    values->context()->check(
+        ah_filter_predicate_apply(values->context()->handle(), p_, &values->view(), &out));
+    return wrap(values, out, {values});
+  }
+  RecordBatch filter_record_batch(const RecordBatch& rb) const {
+    RecordBatch o;
+    for (auto& c : rb.columns) o.columns.push_back(filter(c));
+    o.num_rows = count();
+    return o;
+  }
+
+ private:
+  ArrayRef predicate_;
+  ah_filter_predicate* p_;
+};
+
+class FilterBuilder {  // filter.rs:248-324
+ public:
+  explicit FilterBuilder(ArrayRef predicate) : predicate_(std::move(predicate)) {}
+  FilterBuilder& optimize() { return *this; }  // device predicates always carry prefix tables
+  std::unique_ptr<FilterPredicate> build() {
+    ah_filter_predicate* p = nullptr;
+    predicate_->context()->check(
+        ah_filter_predicate_build(predicate_->context()->handle(), &predicate_->view(), &p));
+    return std::make_unique<FilterPredicate>(predicate_, p);
+  }
+
+ private:
+  ArrayRef predicate_;
+};
+
+inline RecordBatch filter_record_batch(const RecordBatch& rb, const ArrayRef& predicate) {
+  return FilterBuilder(predicate).optimize().build()->filter_record_batch(rb);
+}
+
+// ---- take (arrow-select/src/take.rs)
+struct TakeOptions {  // take.rs:388-394
+  bool check_bounds = false;
+};
+inline ArrayRef take(const ArrayRef& values, const ArrayRef& indices, TakeOptions options = {}) {
+  ah_array_out out;
+  values->context()->check(ah_take(values->context()->handle(), &values->view(), &indices->view(),
+                                   options.check_bounds ? 1 : 0, &out));
+  return wrap(values, out);
+}
+
+// ---- numeric (arrow-arith/src/numeric.rs)
+inline ArrayRef arith(ah_arith_op op, const Datum& l, const Datum& r) {
+  ah_array_out out;
+  auto& ctx = l.array->context();
+  ctx->check(ah_arith_binary(ctx->handle(), op, &l.array->view(), l.is_scalar, &r.array->view(),
+                             r.is_scalar, &out));
+  return wrap(l.array, out);
+}
+inline ArrayRef add(const Datum& l, const Datum& r) { return arith(AH_ADD, l, r); }
+inline ArrayRef add_wrapping(const Datum& l, const Datum& r) { return arith(AH_ADD_WRAPPING, l, r); }
+inline ArrayRef sub(const Datum& l, const Datum& r) { return arith(AH_SUB, l, r); }
+inline ArrayRef sub_wrapping(const Datum& l, const Datum& r) { return arith(AH_SUB_WRAPPING, l, r); }
+inline ArrayRef mul(const Datum& l, const Datum& r) { return arith(AH_MUL, l, r); }
+inline ArrayRef mul_wrapping(const Datum& l, const Datum& r) { return arith(AH_MUL_WRAPPING, l, r); }
+inline ArrayRef div(const Datum& l, const Datum& r) { return arith(AH_DIV, l, r); }
+inline ArrayRef rem(const Datum& l, const Datum& r) { return arith(AH_REM, l, r); }
+inline ArrayRef neg(const ArrayRef& a) {
+  ah_array_out out;
+  a->context()->check(ah_arith_neg(a->context()->handle(), &a->view(), 0, &out));
+  return wrap(a, out);
+}
+inline ArrayRef neg_wrapping(const ArrayRef& a) {
+  ah_array_out out;
+  a->context()->check(ah_arith_neg(a->context()->handle(), &a->view(), 1, &out));
+  return wrap(a, out);
+}
+
+// ---- cmp (arrow-ord/src/cmp.rs)
+inline ArrayRef compare(ah_cmp_op op, const Datum& l, const Datum& r) {
+  ah_array_out out;
+  auto& ctx = l.array->context();
+  ctx->check(ah_compare(ctx->handle(), op, &l.array->view(), l.is_scalar, &r.array->view(), r.is_scalar, &out));
+  return wrap(l.array, out);
+}
+inline ArrayRef eq(const Datum& l, const Datum& r) { return compare(AH_EQ, l, r); }
+inline ArrayRef neq(const Datum& l, const Datum& r) { return compare(AH_NEQ, l, r); }
+inline ArrayRef lt(const Datum& l, const Datum& r) { return compare(AH_LT, l, r); }
+inline ArrayRef lt_eq(const Datum& l, const Datum& r) { return compare(AH_LT_EQ, l, r); }
+inline ArrayRef gt(const Datum& l, const Datum& r) { return compare(AH_GT, l, r); }
+inline ArrayRef gt_eq(const Datum& l, const Datum& r) { return compare(AH_GT_EQ, l, r); }
+inline ArrayRef distinct(const Datum& l, const Datum& r) { return compare(AH_DISTINCT, l, r); }
+inline ArrayRef not_distinct(const Datum& l, const Datum& r) { return compare(AH_NOT_DISTINCT, l, r); }
+
+// ---- cast (arrow-cast/src/cast/mod.rs)
+struct CastOptions {  // cast/mod.rs:95-111
+  bool safe = true;
+};
+inline bool can_cast_types(ah_type from, ah_type to) { return ah_can_cast_types(from, to) != 0; }
+inline ArrayRef cast_with_options(const ArrayRef& a, ah_type to, const CastOptions& o) {
+  ah_array_out out;
+  a->context()->check(ah_cast(a->context()->handle(), &a->view(), to, o.safe ? 1 : 0, &out));
+  return wrap(a, out);
+}
+inline ArrayRef cast(const ArrayRef& a, ah_type to) { return cast_with_options(a, to, CastOptions{}); }
+
+// ---- concat (arrow-select/src/concat.rs)
+inline ArrayRef concat(const std::vector<ArrayRef>& arrays) {
+  if (arrays.empty()) throw ArrowError(AH_INVALID_ARGUMENT, "concat requires input of at least one array");
+  std::vector<ah_array_view> views;
+  for (auto& a : arrays) views.push_back(a->view());
+  ah_array_out out;
+  arrays[0]->context()->check(ah_concat(arrays[0]->context()->handle(), (int32_t)views.size(), views.data(), &out));
+  return wrap(arrays[0], out);
+}
+
+}  // namespace compute
+}  // namespace arrow_hip

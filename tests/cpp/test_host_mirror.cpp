@@ -1,0 +1,130 @@
+// C++ host-mirror test (include/arrow_hip.hpp): reads like the reference's own unit tests
+// (arrow-select/src/filter.rs:195-199, take.rs:1307, numeric.rs:1324-1333, cmp comparison.rs:526).
+// Built and run by tests/test_gpu_parity.py::test_cpp_host_mirror on the GPU box:
+//   g++ -std=c++17 -Iinclude tests/cpp/test_host_mirror.cpp -Larrow-rs_amd/lib -larrow_hip
+#include <cassert>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "arrow_hip.hpp"
+
+using namespace arrow_hip;
+
+struct Uploaded {
+  std::shared_ptr<Context> ctx;
+  void* vals = nullptr;
+  void* valid = nullptr;
+  ~Uploaded() {
+    ah_device_free(ctx->handle(), vals);
+    ah_device_free(ctx->handle(), valid);
+  }
+};
+
+template <typename T>
+static ArrayRef upload(const std::shared_ptr<Context>& ctx, ah_type t, const std::vector<T>& v,
+                       const std::vector<bool>* valid, std::vector<std::shared_ptr<Uploaded>>& keep) {
+  auto u = std::make_shared<Uploaded>();
+  u->ctx = ctx;
+  ctx->check(ah_device_alloc(ctx->handle(), v.size() * sizeof(T) + 8, &u->vals));
+  ctx->check(ah_memcpy_htod(ctx->handle(), u->vals, v.data(), v.size() * sizeof(T)));
+  ah_array_view view{};
+  view.type = t;
+  view.length = (int64_t)v.size();
+  view.values = u->vals;
+  if (valid) {
+    std::vector<uint8_t> bits((v.size() + 63) / 64 * 8, 0);
+    int64_t nulls = 0;
+    for (size_t i = 0; i < v.size(); ++i) {
+      if ((*valid)[i]) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+      else ++nulls;
+    }
+    ctx->check(ah_device_alloc(ctx->handle(), bits.size(), &u->valid));
+    ctx->check(ah_memcpy_htod(ctx->handle(), u->valid, bits.data(), bits.size()));
+    view.validity = (const uint8_t*)u->valid;
+    view.null_count = nulls;
+  }
+  keep.push_back(u);
+  return std::make_shared<Array>(ctx, view);
+}
+
+static ArrayRef upload_bool(const std::shared_ptr<Context>& ctx, const std::vector<bool>& v,
+                            std::vector<std::shared_ptr<Uploaded>>& keep) {
+  auto u = std::make_shared<Uploaded>();
+  u->ctx = ctx;
+  std::vector<uint8_t> bits((v.size() + 63) / 64 * 8, 0);
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i]) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+  ctx->check(ah_device_alloc(ctx->handle(), bits.size(), &u->vals));
+  ctx->check(ah_memcpy_htod(ctx->handle(), u->vals, bits.data(), bits.size()));
+  ah_array_view view{};
+  view.type = AH_BOOL;
+  view.length = (int64_t)v.size();
+  view.values = u->vals;
+  keep.push_back(u);
+  return std::make_shared<Array>(ctx, view);
+}
+
+template <typename T>
+static std::vector<T> download(const ArrayRef& a) {
+  std::vector<T> out((size_t)a->len());
+  if (a->len()) a->values_to_host(out.data(), out.size() * sizeof(T));
+  return out;
+}
+
+int main() {
+  auto ctx = std::make_shared<Context>(0);
+  std::vector<std::shared_ptr<Uploaded>> keep;
+
+  // filter doc example (filter.rs:195-199)
+  auto a = upload<int32_t>(ctx, AH_INT32, {5, 6, 7, 8, 9}, nullptr, keep);
+  auto p = upload_bool(ctx, {true, false, false, true, false}, keep);
+  auto c = compute::filter(a, p);
+  assert(c->len() == 2 && (download<int32_t>(c) == std::vector<int32_t>{5, 8}));
+
+  // take with a null index (take.rs:1307)
+  auto v8 = upload<int8_t>(ctx, AH_INT8, {0, 1, 2, 3, 4}, nullptr, keep);
+  std::vector<bool> iv{true, false, true, true, true};
+  auto idx = upload<uint32_t>(ctx, AH_UINT32, {3, 0, 1, 3, 2}, &iv, keep);
+  auto t = compute::take(v8, idx);
+  assert(t->len() == 5 && t->null_count() == 1);
+  auto tv = download<int8_t>(t);
+  assert(tv[0] == 3 && tv[2] == 1 && tv[3] == 3 && tv[4] == 2);
+
+  // checked vs wrapping u8 add (numeric.rs:1324-1333)
+  auto x = upload<uint8_t>(ctx, AH_UINT8, {56, 5, 3}, nullptr, keep);
+  auto y = upload<uint8_t>(ctx, AH_UINT8, {200, 2, 5}, nullptr, keep);
+  bool threw = false;
+  try {
+    compute::add(x, y);
+  } catch (const ArrowError& e) {
+    threw = std::string(e.what()) == "Arithmetic overflow: Overflow happened on: 56 + 200";
+  }
+  assert(threw);
+  assert((download<uint8_t>(compute::add_wrapping(x, y)) == std::vector<uint8_t>{0, 7, 8}));
+
+  // lt against a scalar (comparison.rs:612)
+  auto s64 = upload<int64_t>(ctx, AH_INT64, {6, 7, 8, 9, 10, 6, 7, 8, 9, 10}, nullptr, keep);
+  auto eight = upload<int64_t>(ctx, AH_INT64, {8}, nullptr, keep);
+  auto l = compute::lt(s64, Scalar(eight));
+  uint64_t word = 0;
+  l->values_to_host(&word, 8);
+  assert((word & 0x3FF) == 0b0001100011);  // [T,T,F,F,F,T,T,F,F,F]
+
+  // OOB take panics like the reference (take.rs:2423)
+  auto four = upload<int64_t>(ctx, AH_INT64, {0, 1, 2, 3}, nullptr, keep);
+  auto big = upload<uint32_t>(ctx, AH_UINT32, {1000}, nullptr, keep);
+  threw = false;
+  try {
+    compute::take(four, big);
+  } catch (const Panic& e) {
+    threw = std::string(e.what()) == "index out of bounds: the len is 4 but the index is 1000";
+  }
+  assert(threw);
+
+  // cast Int64 -> Float64 always carries a null buffer in safe mode
+  auto f = compute::cast(s64, AH_FLOAT64);
+  assert(f->has_nulls_buffer() && f->null_count() == 0 && download<double>(f)[4] == 10.0);
+  std::puts("CPP_HOST_MIRROR_OK");
+  return 0;
+}
