@@ -42,7 +42,7 @@ struct ah_context {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   // pinned host read-back slots
-  uint64_t* pinned = nullptr;  // 64 x u64
+  uint64_t* pinned = nullptr;  // 256 x u64
   // profiling
   bool profiling = false;
   std::map<std::string, ah_prof_entry> prof;

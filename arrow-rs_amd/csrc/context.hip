@@ -147,7 +147,7 @@ extern "C" ah_status ah_context_create(int device, ah_context** out) {
     return AH_HIP_ERROR;
   }
   c->stream = c->own_stream;
-  if (hipHostMalloc((void**)&c->pinned, 64 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&c->pinned, 256 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
     hipStreamDestroy(c->own_stream);
     delete c;
     return AH_HIP_ERROR;

@@ -18,15 +18,23 @@
 //                            coalesced value loads are issued first; wave 0
 //                            meanwhile builds the tile's word table in LDS
 //                            (mask, validity, exclusive popcount prefix).
-//                            rank(row) = prefix[word] + popc(word & below(row)),
-//                            selected values and their validity flags are
-//                            compacted in LDS, then written with coalesced
-//                            stores; validity bits are re-packed with __ballot
-//                            aligned to the global 64-bit output words (interior
-//                            words plain-stored, the two boundary words merged
-//                            with one 64-bit atomicOr each).
-//   K4 sum_u32               valid count per tile -> null_count.
-// Values are read exactly once; the mask twice (1.4% of the bytes at Int64).
+//                            rank(row) = prefix[word] + popc(word & below(row)).
+//                            Selected values and their validity flags are
+//                            compacted through a 16 KiB LDS stage (2048 rows
+//                            per chunk, so 8 workgroups stay resident per CU;
+//                            a tile with more selected rows loops over chunks
+//                            while the values stay in registers) and leave
+//                            with coalesced stores; validity bits are
+//                            re-packed with __ballot aligned to the global
+//                            64-bit output words (interior words plain-stored,
+//                            boundary words merged with a 64-bit atomicOr).
+//                            Below ~12% selectivity the 16-byte loads are
+//                            predicated on "any row of this lane selected":
+//                            128-byte lines without a selected row are never
+//                            fetched (18.5% of them at 10% selectivity).
+//                            Valid-row counts go to 64 atomic slots (one add
+//                            per tile) -> null_count without a reduce pass.
+// Values are read at most once; the mask twice (1.4% of the bytes at Int64).
 #include "common.hpp"
 
 namespace {
@@ -126,19 +134,32 @@ struct ScatterArgs {
   const uint32_t* chunk_prefix;
   const unsigned long long* group_prefix;
   void* out_values;
-  unsigned long long* out_valid;  // zero-initialised u64 words
-  uint32_t* tile_valid;           // per-tile count of valid selected rows
+  unsigned long long* out_valid;   // zero-initialised u64 words
+  unsigned long long* valid_slots; // VALID_SLOTS zero-initialised counters (valid selected rows)
+  int xcd_remap;                   // 1: tiles that share output lines stay on one XCD
+  int64_t ntiles;
 };
+
+constexpr int VALID_SLOTS = 64;
+
+// staging capacity in elements: 16 KiB of LDS per workgroup => 8 workgroups / CU
+__host__ __device__ constexpr int stage_cap(int width) {
+  return width <= 8 ? 2048 : (width == 16 ? 1024 : 512);
+}
 
 // WIDTH == 0: bit-only variant (Boolean values / validity-only): compacts the
 // `vvalid` stream; no value loads.
-template <int W, int V, bool HAS_VALID>
+// SKIP: predicate each 16-byte load on "any of its rows selected" so cache lines
+// with no selected row are never fetched (pays below ~30% selectivity).
+template <int W, int V, bool HAS_VALID, bool SKIP>
 __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(ScatterArgs a) {
   constexpr int WE = W == 0 ? 1 : W;
   constexpr int T = tile_rows(WE);
+  constexpr int CAP = stage_cap(WE);
   constexpr int RPT = T / SCATTER_THREADS;
   constexpr int L = RPT / V;
   constexpr int NW = T / 64;  // mask words per tile (<= 64)
+  constexpr uint32_t VMASK = (V >= 32) ? 0xFFFFFFFFu : ((1u << V) - 1u);
   using ET = typename Elem<WE>::type;
 
   __shared__ uint64_t s_m[NW];
@@ -146,16 +167,26 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
   __shared__ uint32_t s_base[NW];
   __shared__ uint32_t s_total;
   __shared__ uint32_t s_vc[4];
-  __shared__ ET s_vals[W == 0 ? 1 : T];
-  __shared__ uint8_t s_flag[HAS_VALID ? T : 1];
+  constexpr int EPV = (W == 0 || W >= 16) ? 1 : 16 / W;  // elements per 16-byte store
+  __shared__ __attribute__((aligned(16))) ET s_vals[W == 0 ? 1 : CAP + EPV];
+  __shared__ uint8_t s_flag[HAS_VALID ? CAP : 1];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int64_t tile = blockIdx.x;
+  // XCD-aware tile mapping: workgroup b lands on XCD b % 8 (observed dispatch order,
+  // used for speed only), so XCD x walks the contiguous tile range [x*per, (x+1)*per):
+  // neighbouring tiles, which share output cache lines and boundary bitmap words,
+  // meet in ONE L2 instead of ping-ponging dirty lines between XCDs.
+  int64_t tile = blockIdx.x;
+  if (a.xcd_remap) {
+    const int64_t per = (a.ntiles + 7) >> 3;
+    tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= a.ntiles || (int64_t)(blockIdx.x >> 3) >= per) return;
+  }
   const int64_t row0 = tile * T;
 
-  // 1. issue the value loads first (16 B per lane per load on the aligned path)
+  // 1. value loads (16 B per lane per load on the aligned path) go out first
   Vec<WE, V> regs[L];
-  if constexpr (W != 0) {
+  if constexpr (W != 0 && !SKIP) {
     const ET* vp = (const ET*)a.values;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -185,107 +216,146 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
   __syncthreads();
 
   const int total = (int)s_total;
-  if (total == 0) {
-    if (HAS_VALID && t == 0) a.tile_valid[tile] = 0;
-    return;
+  if (total == 0) return;
+
+  if constexpr (W != 0 && SKIP) {
+    const ET* vp = (const ET*)a.values;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      int r0 = (l * SCATTER_THREADS + t) * V;
+      uint32_t bits = (uint32_t)(s_m[r0 >> 6] >> (r0 & 63)) & VMASK;
+      if (bits) regs[l] = *(const Vec<WE, V>*)(vp + row0 + r0);
+    }
   }
 
-  // 3. compact selected rows into LDS
+  const int64_t chunk0 = row0 / CHUNK_ROWS;
+  const int64_t ob = (int64_t)a.group_prefix[chunk0 / GROUP_CHUNKS] + a.chunk_prefix[chunk0];
+  int vc = 0;
+
+  for (int p0 = 0; p0 < total; p0 += CAP) {
+    const int phase = (int)((ob + p0) & (EPV - 1));
+    // 3. compact the selected rows whose output position falls in [p0, p0+CAP) into LDS
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
-    int r0 = (l * SCATTER_THREADS + t) * V;
-    int w = r0 >> 6, sh = r0 & 63;
-    uint64_t word = s_m[w];
-    uint32_t bits = (uint32_t)(word >> sh) & ((V == 32) ? 0xFFFFFFFFu : ((1u << V) - 1u));
-    if (bits) {
-      uint32_t base = s_base[w] + (uint32_t)__popcll(word & ((1ull << sh) - 1ull));
-      uint32_t vb = 0;
-      if constexpr (HAS_VALID) vb = (uint32_t)(s_v[w] >> sh);
+    for (int l = 0; l < L; ++l) {
+      int r0 = (l * SCATTER_THREADS + t) * V;
+      int w = r0 >> 6, sh = r0 & 63;
+      uint64_t word = s_m[w];
+      uint32_t bits = (uint32_t)(word >> sh) & VMASK;
+      if (bits) {
+        uint32_t base = s_base[w] + (uint32_t)__popcll(word & ((1ull << sh) - 1ull)) - (uint32_t)p0;
+        uint32_t vb = 0;
+        if constexpr (HAS_VALID) vb = (uint32_t)(s_v[w] >> sh);
 #pragma unroll
-      for (int e = 0; e < V; ++e) {
-        if ((bits >> e) & 1u) {
-          uint32_t pos = base + (uint32_t)__popc(bits & ((1u << e) - 1u));
-          if constexpr (W != 0) s_vals[pos] = regs[l].u.e[e];
-          if constexpr (HAS_VALID) s_flag[pos] = (uint8_t)((vb >> e) & 1u);
+        for (int e = 0; e < V; ++e) {
+          if ((bits >> e) & 1u) {
+            uint32_t pos = base + (uint32_t)__popc(bits & ((1u << e) - 1u));
+            if (pos < (uint32_t)CAP) {  // unsigned: also rejects positions before p0
+              if constexpr (W != 0) s_vals[pos + phase] = regs[l].u.e[e];
+              if constexpr (HAS_VALID) s_flag[pos] = (uint8_t)((vb >> e) & 1u);
+            }
+          }
         }
       }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 
-  // 4. coalesced write-out
-  const int64_t chunk0 = row0 / CHUNK_ROWS;
-  const int64_t ob = (int64_t)a.group_prefix[chunk0 / GROUP_CHUNKS] + a.chunk_prefix[chunk0];
-  if constexpr (W != 0) {
-    ET* op = (ET*)a.out_values + ob;
-    for (int j = t; j < total; j += SCATTER_THREADS) op[j] = s_vals[j];
-  }
-  if constexpr (HAS_VALID) {
-    const int64_t g0 = ob & ~63ll;
-    const int lead = (int)(ob - g0);
-    const int span = lead + total;
-    const int span64 = (span + 63) & ~63;
-    int vc = 0;
-    for (int q = t; q < span64; q += SCATTER_THREADS) {
-      int j = q - lead;
-      int f = (j >= 0 && j < total) ? (int)s_flag[j] : 0;
-      uint64_t word = __ballot(f);
-      if (lane == 0) {
-        int64_t wi = (g0 + q) >> 6;
-        bool interior = (q >= lead) && (q + 64 <= span);
-        if (interior) a.out_valid[wi] = word;
-        else if (word) atomicOr(&a.out_valid[wi], (unsigned long long)word);
-        vc += __popcll(word);
+    // 4. coalesced write-out of this chunk
+    const int cnt = (total - p0) < CAP ? (total - p0) : CAP;
+    const int64_t cb = ob + p0;
+    if constexpr (W != 0) {
+      ET* op = (ET*)a.out_values + cb;
+      if constexpr (EPV > 1) {
+        // 16-byte stores: LDS slot = output position + phase, so LDS vectors and global
+        // vectors share their 16-byte alignment; ragged head/tail go element-wise
+        const int first = phase, last = phase + cnt;          // LDS element range [first, last)
+        const int vfirst = (first + EPV - 1) / EPV, vlast = last / EPV;  // whole vectors
+        ET* gbase = op - phase;                               // 16-byte aligned
+        if (vfirst < vlast) {
+          for (int j = vfirst + t; j < vlast; j += SCATTER_THREADS)
+            *(Vec<WE, EPV>*)(gbase + j * EPV) = *(const Vec<WE, EPV>*)(s_vals + j * EPV);
+          if (t < vfirst * EPV - first) gbase[first + t] = s_vals[first + t];
+          if (t < last - vlast * EPV) gbase[vlast * EPV + t] = s_vals[vlast * EPV + t];
+        } else {
+          for (int j = first + t; j < last; j += SCATTER_THREADS) gbase[j] = s_vals[j];
+        }
+      } else {
+        for (int j = t; j < cnt; j += SCATTER_THREADS) op[j] = s_vals[j];
       }
     }
+    if constexpr (HAS_VALID) {
+      const int64_t g0 = cb & ~63ll;
+      const int lead = (int)(cb - g0);
+      const int span = lead + cnt;
+      const int span64 = (span + 63) & ~63;
+      for (int q = t; q < span64; q += SCATTER_THREADS) {
+        int j = q - lead;
+        int f = (j >= 0 && j < cnt) ? (int)s_flag[j] : 0;
+        uint64_t word = __ballot(f);
+        if (lane == 0) {
+          int64_t wi = (g0 + q) >> 6;
+          // EVERY word goes through atomicOr (buffer pre-zeroed): tiles share their boundary
+          // words, and mixing plain stores with L2 atomics on one cache line costs 0.5 ms
+          // per 1e9 rows on MI355X (measured), while atomics alone are free.
+          if (word) atomicOr(&a.out_valid[wi], (unsigned long long)word);
+          vc += __popcll(word);
+        }
+      }
+    }
+    if (p0 + CAP < total) __syncthreads();  // LDS is reused by the next chunk
+  }
+  if constexpr (HAS_VALID) {
     if (lane == 0) s_vc[wave] = (uint32_t)vc;
     __syncthreads();
-    if (t == 0) a.tile_valid[tile] = s_vc[0] + s_vc[1] + s_vc[2] + s_vc[3];
-  }
-}
-
-__global__ void __launch_bounds__(1024) sum_u32_kernel(const uint32_t* in, int64_t n,
-                                                       unsigned long long* out) {
-  unsigned long long acc = 0;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) acc += in[i];
-  acc = wave_reduce_add64(acc);
-  __shared__ unsigned long long s[16];
-  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long tot = 0;
-    for (int i = 0; i < 16; i++) tot += s[i];
-    *out = tot;
+    if (t == 0) {
+      uint32_t c = s_vc[0] + s_vc[1] + s_vc[2] + s_vc[3];
+      if (c) atomicAdd(&a.valid_slots[tile & (VALID_SLOTS - 1)], (unsigned long long)c);
+    }
   }
 }
 
 template <int W, bool HV>
-void launch_scatter_w(ah_context* ctx, const ScatterArgs& a, bool aligned16) {
+void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, bool skip) {
   constexpr int WE = W == 0 ? 1 : W;
   constexpr int T = tile_rows(WE);
-  int64_t ntiles = ah_ceil_div(a.len, T);
-  dim3 grid((unsigned)ntiles), block(SCATTER_THREADS);
+  int64_t ntiles = ah_ceil_div(a_in.len, T);
+  ScatterArgs a = a_in;
+  a.ntiles = ntiles;
+  static const char* xr = getenv("AH_FILTER_XCD");
+  a.xcd_remap = (xr && xr[0] == '0') ? 0 : 1;
+  dim3 grid((unsigned)(a.xcd_remap ? 8 * ((ntiles + 7) / 8) : ntiles)), block(SCATTER_THREADS);
   constexpr int VV = (W == 0) ? 16 : (W >= 16 ? 1 : 16 / W);
-  if (W == 0 || (aligned16 && VV > 1))
-    filter_scatter_kernel<W, VV, HV><<<grid, block, 0, ctx->stream>>>(a);
-  else
-    filter_scatter_kernel<W, 1, HV><<<grid, block, 0, ctx->stream>>>(a);
+  if constexpr (W == 0) {
+    filter_scatter_kernel<W, VV, HV, false><<<grid, block, 0, ctx->stream>>>(a);
+  } else if (aligned16 || VV == 1) {
+    if (skip) filter_scatter_kernel<W, VV, HV, true><<<grid, block, 0, ctx->stream>>>(a);
+    else filter_scatter_kernel<W, VV, HV, false><<<grid, block, 0, ctx->stream>>>(a);
+  } else {
+    filter_scatter_kernel<W, 1, HV, false><<<grid, block, 0, ctx->stream>>>(a);
+  }
 }
 
 template <bool HV>
-ah_status launch_scatter(ah_context* ctx, int width, const ScatterArgs& a) {
+ah_status launch_scatter(ah_context* ctx, int width, const ScatterArgs& a, bool skip) {
   bool aligned16 = (((uintptr_t)a.values) & 15) == 0;
   switch (width) {
-    case 0: launch_scatter_w<0, HV>(ctx, a, true); break;
-    case 1: launch_scatter_w<1, HV>(ctx, a, aligned16); break;
-    case 2: launch_scatter_w<2, HV>(ctx, a, aligned16); break;
-    case 4: launch_scatter_w<4, HV>(ctx, a, aligned16); break;
-    case 8: launch_scatter_w<8, HV>(ctx, a, aligned16); break;
-    case 16: launch_scatter_w<16, HV>(ctx, a, aligned16); break;
-    case 32: launch_scatter_w<32, HV>(ctx, a, aligned16); break;
+    case 0: launch_scatter_w<0, HV>(ctx, a, true, false); break;
+    case 1: launch_scatter_w<1, HV>(ctx, a, aligned16, skip); break;
+    case 2: launch_scatter_w<2, HV>(ctx, a, aligned16, skip); break;
+    case 4: launch_scatter_w<4, HV>(ctx, a, aligned16, skip); break;
+    case 8: launch_scatter_w<8, HV>(ctx, a, aligned16, skip); break;
+    case 16: launch_scatter_w<16, HV>(ctx, a, aligned16, skip); break;
+    case 32: launch_scatter_w<32, HV>(ctx, a, aligned16, skip); break;
     default: return ah_fail(ctx, AH_INVALID_ARGUMENT, "unsupported value width %d", width);
   }
   return AH_OK;
+}
+
+// load predication pays when most 128-byte lines hold no selected row; tunable for experiments
+bool use_skip(int64_t count, int64_t len) {
+  static const char* env = getenv("AH_FILTER_SKIP");  // "0" / "1" force, unset = heuristic
+  if (env && env[0] == '0') return false;
+  if (env && env[0] == '1') return true;
+  return (double)count < 0.12 * (double)len;
 }
 
 }  // namespace
@@ -371,14 +441,14 @@ static ah_status compact_bits(ah_context* ctx, const ah_filter_predicate* p, Bit
   size_t bytes = ah_bitmap_bytes(p->count);
   void* ob = nullptr;
   AH_TRY(ah_out_alloc(ctx, bytes, &ob));
-  int64_t ntiles = ah_ceil_div(p->len, tile_rows(1));
-  uint32_t* tile_valid = nullptr;
-  ah_status st = ah_pool_alloc(ctx, (size_t)ntiles * 4 + 16, (void**)&tile_valid);
+  unsigned long long* slots = nullptr;
+  ah_status st = ah_pool_alloc(ctx, VALID_SLOTS * 8, (void**)&slots);
   if (st != AH_OK) {
     ah_out_free(ctx, ob, bytes);
     return st;
   }
   hipMemsetAsync(ob, 0, bytes, ctx->stream);
+  hipMemsetAsync(slots, 0, VALID_SLOTS * 8, ctx->stream);
   ScatterArgs a{};
   a.values = nullptr;
   a.mask = p->mask;
@@ -389,18 +459,18 @@ static ah_status compact_bits(ah_context* ctx, const ah_filter_predicate* p, Bit
   a.group_prefix = p->group_prefix;
   a.out_values = nullptr;
   a.out_valid = (unsigned long long*)ob;
-  a.tile_valid = tile_valid;
-  launch_scatter<true>(ctx, 0, a);
-  unsigned long long* tot = (unsigned long long*)(tile_valid + ((ntiles + 1) & ~1ll));
-  sum_u32_kernel<<<1, 1024, 0, ctx->stream>>>(tile_valid, ntiles, tot);
-  hipError_t e = hipMemcpyAsync(ctx->pinned, tot, 8, hipMemcpyDeviceToHost, ctx->stream);
+  a.valid_slots = slots;
+  launch_scatter<true>(ctx, 0, a, false);
+  hipError_t e = hipMemcpyAsync(ctx->pinned, slots, VALID_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  ah_pool_free(ctx, tile_valid);
+  ah_pool_free(ctx, slots);
   if (e != hipSuccess) {
     ah_out_free(ctx, ob, bytes);
     return ah_fail(ctx, AH_HIP_ERROR, "filter_bits failed: %s", hipGetErrorString(e));
   }
-  *set_bits = (int64_t)ctx->pinned[0];
+  int64_t setb = 0;
+  for (int i = 0; i < VALID_SLOTS; ++i) setb += (int64_t)ctx->pinned[i];
+  *set_bits = setb;
   *out_bits = (uint8_t*)ob;
   *out_bytes = bytes;
   return AH_OK;
@@ -485,26 +555,23 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
   }
 
   // filter_primitive (filter.rs:773-788)
-  const int T = tile_rows(width);
-  const int64_t ntiles = ah_ceil_div(p->len, T);
   void* ov = nullptr;
   size_t vbytes = (size_t)K * width;
   AH_TRY(ah_out_alloc(ctx, vbytes, &ov));
   void* ob = nullptr;
   size_t bbytes = 0;
-  uint32_t* tile_valid = nullptr;
-  unsigned long long* tot = nullptr;
+  unsigned long long* slots = nullptr;
   if (has_valid) {
     bbytes = ah_bitmap_bytes(K);
     ah_status st = ah_out_alloc(ctx, bbytes, &ob);
-    if (st == AH_OK) st = ah_pool_alloc(ctx, (size_t)ntiles * 4 + 16, (void**)&tile_valid);
+    if (st == AH_OK) st = ah_pool_alloc(ctx, VALID_SLOTS * 8, (void**)&slots);
     if (st != AH_OK) {
       ah_out_free(ctx, ov, vbytes);
       ah_out_free(ctx, ob, bbytes);
       return st;
     }
-    tot = (unsigned long long*)(tile_valid + ((ntiles + 1) & ~1ll));
     hipMemsetAsync(ob, 0, bbytes, ctx->stream);
+    hipMemsetAsync(slots, 0, VALID_SLOTS * 8, ctx->stream);
   }
   ScatterArgs a{};
   a.values = values->values;
@@ -516,19 +583,18 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
   a.group_prefix = p->group_prefix;
   a.out_values = ov;
   a.out_valid = (unsigned long long*)ob;
-  a.tile_valid = tile_valid;
+  a.valid_slots = slots;
+  const bool skip = use_skip(K, p->len);
   {
     ah_prof_scope ps(ctx, "filter_scatter");
-    if (has_valid) launch_scatter<true>(ctx, width, a);
-    else launch_scatter<false>(ctx, width, a);
+    if (has_valid) launch_scatter<true>(ctx, width, a, skip);
+    else launch_scatter<false>(ctx, width, a, skip);
   }
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess && has_valid) {
-    sum_u32_kernel<<<1, 1024, 0, ctx->stream>>>(tile_valid, ntiles, tot);
-    e = hipMemcpyAsync(ctx->pinned, tot, 8, hipMemcpyDeviceToHost, ctx->stream);
-  }
+  if (e == hipSuccess && has_valid)
+    e = hipMemcpyAsync(ctx->pinned, slots, VALID_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  ah_pool_free(ctx, tile_valid);
+  ah_pool_free(ctx, slots);
   if (e != hipSuccess) {
     ah_out_free(ctx, ov, vbytes);
     ah_out_free(ctx, ob, bbytes);
@@ -538,7 +604,9 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
   out->values = ov;
   out->values_bytes = (int64_t)vbytes;
   if (has_valid) {
-    int64_t nulls = K - (int64_t)ctx->pinned[0];
+    int64_t validc = 0;
+    for (int i = 0; i < VALID_SLOTS; ++i) validc += (int64_t)ctx->pinned[i];
+    int64_t nulls = K - validc;
     if (nulls == 0) {  // filter_nulls :523-525 -> None
       ah_out_free(ctx, ob, bbytes);
     } else {

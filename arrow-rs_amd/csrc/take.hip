@@ -52,7 +52,7 @@ struct TakeArgs {
   unsigned long long* first_oob;    // atomicMin of first out-of-bounds position
 };
 
-template <int W, typename IDX, bool OUT_VALID>
+template <int W, typename IDX, bool OUT_VALID, int KU>
 __global__ void __launch_bounds__(256) take_kernel(TakeArgs a) {
   using ET = typename Elem<W == 0 ? 1 : W>::type;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -63,24 +63,24 @@ __global__ void __launch_bounds__(256) take_kernel(TakeArgs a) {
   unsigned long long nvalid = 0;
   unsigned long long oob = ~0ull;
 
-  for (int64_t base = (int64_t)blockIdx.x * 1024; base < a.n; base += (int64_t)gridDim.x * 1024) {
-    const int64_t wbase = base + wave * 256;
-    uint64_t ix[4];
-    bool live[4];
+  for (int64_t base = (int64_t)blockIdx.x * (256 * KU); base < a.n; base += (int64_t)gridDim.x * (256 * KU)) {
+    const int64_t wbase = base + wave * (64 * KU);
+    uint64_t ix[KU];
+    bool live[KU];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < KU; ++k) {
       int64_t i = wbase + k * 64 + lane;
       live[k] = i < a.n;
       ix[k] = live[k] ? to_index(idx[i]) : 0;
     }
-    uint64_t iv[4];
+    uint64_t iv[KU];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) iv[k] = bv_fetch64(a.ivalid, wbase + k * 64, a.n);
+    for (int k = 0; k < KU; ++k) iv[k] = bv_fetch64(a.ivalid, wbase + k * 64, a.n);
 
-    ET v[4];
-    int vb[4];
+    ET v[KU];
+    int vb[KU];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < KU; ++k) {
       bool ivalid = (iv[k] >> lane) & 1;
       bool inb = ix[k] < (uint64_t)a.values_len;
       // take_native :432-457: in-bounds always gathers (even under a null
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) take_kernel(TakeArgs a) {
       vb[k] = live[k] ? valid : 0;
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < KU; ++k) {
       int64_t i = wbase + k * 64 + lane;
       if constexpr (W != 0) {
         if (live[k]) out[i] = v[k];
@@ -175,8 +175,15 @@ __global__ void __launch_bounds__(1024) sum_u64_kernel2(const unsigned long long
 
 template <int W, typename IDX>
 void launch_take_wi(ah_context* ctx, const TakeArgs& a, bool out_valid, int grid) {
-  if (out_valid) take_kernel<W, IDX, true><<<grid, 256, 0, ctx->stream>>>(a);
-  else take_kernel<W, IDX, false><<<grid, 256, 0, ctx->stream>>>(a);
+  static const char* ku = getenv("AH_TAKE_KU");
+  if (ku && ku[0] == '8' && W == 8) {
+    int g2 = std::max(1, grid / 2);
+    if (out_valid) take_kernel<W, IDX, true, 8><<<g2, 256, 0, ctx->stream>>>(a);
+    else take_kernel<W, IDX, false, 8><<<g2, 256, 0, ctx->stream>>>(a);
+    return;
+  }
+  if (out_valid) take_kernel<W, IDX, true, 4><<<grid, 256, 0, ctx->stream>>>(a);
+  else take_kernel<W, IDX, false, 4><<<grid, 256, 0, ctx->stream>>>(a);
 }
 
 template <int W>
