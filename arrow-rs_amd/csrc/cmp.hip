@@ -71,6 +71,8 @@ struct CmpArgs {
   unsigned long long* out;
 };
 
+constexpr int CMP_G = 4;  // 64*V-row groups per wave: 2*CMP_G 16-byte loads in flight per lane
+
 template <typename T, int V>
 __global__ void __launch_bounds__(256) compare_kernel(CmpArgs a) {
   using VT = VecT<T, V>;
@@ -79,44 +81,53 @@ __global__ void __launch_bounds__(256) compare_kernel(CmpArgs a) {
   const T* rp = (const T*)a.r;
   T ls = a.l_scalar ? lp[0] : T{};
   T rs = a.r_scalar ? rp[0] : T{};
-  const int64_t ngroups = (a.len + 64 * V - 1) / (64 * V);  // one wave-step = 64*V rows
+  const int64_t ngroups = (a.len + 64 * V - 1) / (64 * V);  // one group = 64*V rows = V output words
   const int64_t wave0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
   const int64_t nwords = (a.len + 63) >> 6;
-  for (int64_t g = wave0; g < ngroups; g += nwaves) {
-    int64_t i = (g * 64 + lane) * V;
-    VT lv, rv;
-    if (i + V <= a.len) {
-      if (!a.l_scalar) lv = *(const VT*)(lp + i);
-      if (!a.r_scalar) rv = *(const VT*)(rp + i);
-    } else {
+  for (int64_t g0 = wave0 * CMP_G; g0 < ngroups; g0 += nwaves * CMP_G) {
+    VT lv[CMP_G], rv[CMP_G];
 #pragma unroll
-      for (int e = 0; e < V; ++e) {
-        lv.e[e] = (!a.l_scalar && i + e < a.len) ? lp[i + e] : T{};
-        rv.e[e] = (!a.r_scalar && i + e < a.len) ? rp[i + e] : T{};
+    for (int gi = 0; gi < CMP_G; ++gi) {  // all loads of the wave's CMP_G groups go out first
+      int64_t i = ((g0 + gi) * 64 + lane) * V;
+      if (i + V <= a.len) {
+        if (!a.l_scalar) lv[gi] = *(const VT*)(lp + i);
+        if (!a.r_scalar) rv[gi] = *(const VT*)(rp + i);
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          lv[gi].e[e] = (!a.l_scalar && i + e < a.len) ? lp[i + e] : T{};
+          rv[gi].e[e] = (!a.r_scalar && i + e < a.len) ? rp[i + e] : T{};
+        }
       }
     }
-    uint64_t ballots[V];
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      T x = a.l_scalar ? ls : lv.e[e];
-      T y = a.r_scalar ? rs : rv.e[e];
-      bool res = a.base == B_EQ ? (bits_key(x) == bits_key(y)) : (order_key(x) < order_key(y));
-      res = res && (i + e < a.len);
-      ballots[e] = __ballot(res);
+    for (int gi = 0; gi < CMP_G; ++gi) {
+      const int64_t g = g0 + gi;
+      if (g >= ngroups) break;
+      const int64_t i = (g * 64 + lane) * V;
+      uint64_t ballots[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        T x = a.l_scalar ? ls : lv[gi].e[e];
+        T y = a.r_scalar ? rs : rv[gi].e[e];
+        bool res = a.base == B_EQ ? (bits_key(x) == bits_key(y)) : (order_key(x) < order_key(y));
+        res = res && (i + e < a.len);
+        ballots[e] = __ballot(res);
+      }
+      // word k of the group covers lanes [k*64/V, (k+1)*64/V)
+      uint64_t mine = 0;
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        uint64_t w = 0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) w |= spread<V>(ballots[e] >> (k * (64 / V))) << e;
+        if (a.neg) w = ~w;  // collect_bool negates whole words, padding included (cmp.rs:590-592)
+        if (lane == k) mine = w;
+      }
+      int64_t wi = g * V + lane;
+      if (lane < V && wi < nwords) a.out[wi] = mine;
     }
-    // word k of the group covers lanes [k*64/V, (k+1)*64/V)
-    uint64_t mine = 0;
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      uint64_t w = 0;
-#pragma unroll
-      for (int e = 0; e < V; ++e) w |= spread<V>(ballots[e] >> (k * (64 / V))) << e;
-      if (a.neg) w = ~w;  // collect_bool negates whole words, padding included (cmp.rs:590-592)
-      if (lane == k) mine = w;
-    }
-    int64_t wi = g * V + lane;
-    if (lane < V && wi < nwords) a.out[wi] = mine;
   }
 }
 
@@ -125,7 +136,7 @@ void launch_cmp_t(ah_context* ctx, const CmpArgs& a, bool aligned) {
   constexpr int VV = sizeof(T) >= 4 ? 16 / sizeof(T) : 4;  // 1/2-byte types: 4 rows per lane
   const int V = aligned ? VV : 1;
   int64_t ngroups = ah_ceil_div(a.len, 64 * (int64_t)V);
-  int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(ngroups, 4), 256 * 16));
+  int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(ngroups, 4 * CMP_G), (int64_t)1 << 30));
   if (aligned) compare_kernel<T, VV><<<grid, 256, 0, ctx->stream>>>(a);
   else compare_kernel<T, 1><<<grid, 256, 0, ctx->stream>>>(a);
 }

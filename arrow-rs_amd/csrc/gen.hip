@@ -67,6 +67,12 @@ __global__ void zero_nulls_kernel(T* v, const unsigned long long* valid, int64_t
     if (!((valid[i >> 6] >> (i & 63)) & 1)) v[i] = T{};
 }
 
+__global__ void gen_iota_u32_kernel(uint32_t* dst, int64_t n, uint32_t start) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = start + (uint32_t)i;
+}
+
 int gen_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(n, 256), 256 * 32)); }
 
 }  // namespace
@@ -128,6 +134,14 @@ extern "C" ah_status ah_zero_null_slots(ah_context* ctx, void* values, int32_t b
     case 8: zero_nulls_kernel<uint64_t><<<g, 256, 0, ctx->stream>>>((uint64_t*)values, v, n); break;
     default: return ah_fail(ctx, AH_INVALID_ARGUMENT, "unsupported byte width %d", byte_width);
   }
+  AH_HIP(ctx, hipGetLastError());
+  return AH_OK;
+}
+
+extern "C" ah_status ah_gen_iota_u32(ah_context* ctx, uint32_t* dst, int64_t n, uint32_t start) {
+  if (n <= 0) return AH_OK;
+  hipSetDevice(ctx->device);
+  gen_iota_u32_kernel<<<gen_grid(n), 256, 0, ctx->stream>>>(dst, n, start);
   AH_HIP(ctx, hipGetLastError());
   return AH_OK;
 }

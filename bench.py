@@ -174,6 +174,12 @@ def main():
         ib = ctx.alloc(nidx * 4)
         ctx.check(ctx.lib.ah_gen_uniform_u32(ctx.handle, ib.ptr, nidx, 45 + rank, n if n < 2**32 else 0, 0))
         idx = mk_array(A, ctx, A.UInt32, nidx, ib)
+        # variant (ii) of SURVEY §8d 2b: sorted indices = positions selected by the predicate
+        # (what a filter->indices->take pipeline feeds take); timed outside the step, reported as extra
+        iota = ctx.alloc(n * 4)
+        ctx.check(ctx.lib.ah_gen_iota_u32(ctx.handle, iota.ptr, n, 0)) if n < 2**32 else None
+        sorted_idx = K.filter(mk_array(A, ctx, A.UInt32, n, iota), pred) if n < 2**32 else None
+        del iota
         state = {}
 
         def step(with_reassembly):
@@ -233,6 +239,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, local_elapsed = float(tt[0]), (float(tt[1]) if reassemble else None)
 
+    sorted_ms = None
+    if wl == "filter_take" and sorted_idx is not None:
+        ctx.profile(True)
+        ctx.profile_reset()
+        for _ in range(3):
+            ts = K.take(col, sorted_idx)
+        sorted_ms = ctx.profile_get("take_gather")
+        sorted_ms = sorted_ms[0] / max(sorted_ms[1], 1)
+        ctx.profile(False)
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = n * world * args.steps / elapsed / 1e6
@@ -246,7 +262,19 @@ def main():
             take_bytes = idx.length * (4 + 8 + 8) + 2 * ((idx.length + 7) // 8)
             step_alg = alg_bytes + take_bytes
             tk_ms, tk_n = prof["take_gather"]
+            tk_avg = tk_ms / max(tk_n, 1)
+            # random 8-byte gathers pull one 128-byte L2 line each (rocprofv3 FETCH_SIZE, profiles/):
+            # line traffic is the physical bound of this kernel, algorithmic bytes are 8/128 of it
+            take_line_bytes = idx.length * 128 + idx.length * 4 + idx.length * 8
+            rf_filter = {"bound": "hbm", "kernel": "filter_scatter", "achieved": round(alg_bytes / (dom_avg_ms * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(alg_bytes / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom_n}
             extra = {
+                "roofline_filter_scatter": rf_filter,
+                "take_line_traffic_GBps_model": round(take_line_bytes / (tk_avg * 1e-3) / 1e9, 1) if tk_n else None,
+                "take_sorted_indices_ms": round(sorted_ms, 4) if sorted_ms else None,
                 "filter_selected_rows": k, "filter_null_count": state["fn"],
                 "take_indices": idx.length,
                 "filter_scatter_ms": round(dom_avg_ms, 4),
@@ -274,6 +302,9 @@ def main():
                         "cast_string": "configs[3]: cast Float64->LargeUtf8"}[wl] + f", {n} rows per GPU"
             metric = f"{wl}_Mrows_per_s"
             dtype = "f64"
+        if wl == "filter_take" and tk_avg > dom_avg_ms:
+            # the time-dominant kernel of the step is the random gather: report IT as `roofline`
+            dominant, dom_avg_ms, dom_n, alg_bytes = "take_gather", tk_avg, tk_n, take_bytes
         achieved = alg_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
         line = {
             "metric": metric, "value": round(value, 1), "unit": "Mrows/s", "n_gpus": world,

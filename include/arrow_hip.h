@@ -241,6 +241,8 @@ AH_API ah_status ah_gen_uniform_f64(ah_context* ctx, double* dst, int64_t n, uin
                                     double lo, double hi, int64_t row0);
 AH_API ah_status ah_gen_uniform_u32(ah_context* ctx, uint32_t* dst, int64_t n, uint64_t seed,
                                     uint32_t bound, int64_t row0);
+/* dst[i] = start + i (row positions, e.g. to turn a predicate into take indices) */
+AH_API ah_status ah_gen_iota_u32(ah_context* ctx, uint32_t* dst, int64_t n, uint32_t start);
 /* Bernoulli(p_true) bits, LSB-first, written at bit offset 0 of dst
  * (ceil(n/64)*8 bytes; padding bits zero). */
 AH_API ah_status ah_gen_bernoulli_bits(ah_context* ctx, uint8_t* dst, int64_t n, uint64_t seed,

@@ -7,7 +7,7 @@ for l in sys.stdin:
     elif 'rror' in l: print(l.strip())
 "
 done
-echo "== take without value nulls"; python bench.py --steps 5 --warmup 2 --no-cpu-baseline --valid 1.0 2>/dev/null | python -c "
+exit 0
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
