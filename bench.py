@@ -32,6 +32,24 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable copy
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json,
+    produced by tools/collect_profiles.sh + tools/profile_summary.py: FETCH_SIZE and WRITE_SIZE in
+    separate passes, FETCH doubled for wide coalesced reads as MI355X_MICROARCH.md prescribes).
+    Only valid for the exact default workload the counters were collected on; else null."""
+    if not (args.workload == "filter_take" and args.rows == 1_000_000_000 and args.selectivity == 0.1
+            and args.valid == 0.9):
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["hbm_bytes_per_launch"].get(kernel)
+    except Exception:
+        return None
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -269,7 +287,7 @@ def main():
             rf_filter = {"bound": "hbm", "kernel": "filter_scatter", "achieved": round(alg_bytes / (dom_avg_ms * 1e-3) / 1e9, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(alg_bytes / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": pmc_traffic("filter_scatter", args), "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom_n}
             extra = {
                 "roofline_filter_scatter": rf_filter,
@@ -315,7 +333,7 @@ def main():
                        "reassemble": ("allgatherv" if reassemble else "none")},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": pmc_traffic(dominant, args), "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom_n},
         }
         if local_elapsed:
