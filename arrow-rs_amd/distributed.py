@@ -93,7 +93,10 @@ class Communicator:
     def all_gatherv(self, array):
         """Concatenation of every rank's ``array`` in rank order, materialised on every rank
         (== arrow_select::concat of the shard results)."""
+        import time as _t
         torch, dist, ctx = self.torch, self.dist, self.ctx
+        tm = {}
+        _t0 = _t.perf_counter()
         dt = array.data_type
         w = dt.width
         if w <= 0:
@@ -104,6 +107,7 @@ class Communicator:
         ctx.synchronize()  # array's producer kernels ran on the context stream
         dist.all_gather_into_tensor(allc, mine, group=self.group)
         counts = allc.cpu().tolist()
+        tm["counts"] = _t.perf_counter() - _t0
         lens = [c[0] for c in counts]
         row_offs, total = exclusive_offsets(lens)
         any_valid = any(c[2] for c in counts)
@@ -113,6 +117,7 @@ class Communicator:
         local = self._tensor(array.values.ptr, array.length * w) if array.length else self._tensor(0, 0)
         out_t = self._tensor(out_vals.ptr, total * w)
         all_gatherv_bytes(dist, local, out_t, [o * w for o in row_offs], [n * w for n in lens], self.group)
+        tm["values"] = _t.perf_counter() - _t0
 
         vmem, nulls = None, 0
         if any_valid:
@@ -142,4 +147,6 @@ class Communicator:
             vmem = _RawMem(out_valid.ptr, out_valid.nbytes, out_valid)
         else:
             torch.cuda.synchronize(self.device)
+        tm["total"] = _t.perf_counter() - _t0
+        self.timings = {k: round(v * 1e3, 3) for k, v in tm.items()}
         return Array(ctx, dt, total, _RawMem(out_vals.ptr, total * w, out_vals), 0, vmem, 0, nulls)
