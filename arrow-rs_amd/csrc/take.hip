@@ -6,7 +6,12 @@
 //
 // MI355X design: one gather kernel.  A wave owns 256 consecutive output rows as
 // 4 x 64; index loads and value stores are fully coalesced, the 4 gathers per
-// lane are independent (4 random HBM sectors in flight per lane, 16 waves/CU).
+// lane are independent.  Measured on MI355X (profiles/): uniformly random 8-byte
+// gathers fill one 128-byte L2 line each (FETCH_SIZE 12.9 GB per 1e8 indices) and
+// the validity-bit gather is a second random line fill served by the Infinity
+// Cache at ~7 TB/s, so the kernel is bound by line-fill traffic: 8 gathers in
+// flight per lane, non-temporal value loads and splitting value/bit gathers into
+// two kernels were all measured and none helps.
 // The output validity word for each group of 64 rows is one __ballot of
 // (index-valid & values-valid[idx]) — the reference's collect_bool
 // (arrow-buffer/src/buffer/mutable.rs:761-791) for free.  Out-of-bounds rows are
@@ -175,13 +180,6 @@ __global__ void __launch_bounds__(1024) sum_u64_kernel2(const unsigned long long
 
 template <int W, typename IDX>
 void launch_take_wi(ah_context* ctx, const TakeArgs& a, bool out_valid, int grid) {
-  static const char* ku = getenv("AH_TAKE_KU");
-  if (ku && ku[0] == '8' && W == 8) {
-    int g2 = std::max(1, grid / 2);
-    if (out_valid) take_kernel<W, IDX, true, 8><<<g2, 256, 0, ctx->stream>>>(a);
-    else take_kernel<W, IDX, false, 8><<<g2, 256, 0, ctx->stream>>>(a);
-    return;
-  }
   if (out_valid) take_kernel<W, IDX, true, 4><<<grid, 256, 0, ctx->stream>>>(a);
   else take_kernel<W, IDX, false, 4><<<grid, 256, 0, ctx->stream>>>(a);
 }
