@@ -95,6 +95,8 @@ SIGNATURES = {
     "ah_arith_binary": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
     "ah_arith_neg": (C.c_int32, [_P, _VIEW, C.c_int32, _OUT]),
     "ah_compare": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
+    "ah_boolean_binary": (C.c_int32, [_P, C.c_int32, _VIEW, _VIEW, _OUT]),
+    "ah_boolean_unary": (C.c_int32, [_P, C.c_int32, _VIEW, _OUT]),
     "ah_cast": (C.c_int32, [_P, _VIEW, C.c_int32, C.c_int32, _OUT]),
     "ah_can_cast_types": (C.c_int32, [C.c_int32, C.c_int32]),
     "ah_concat": (C.c_int32, [_P, C.c_int32, _VIEW, _OUT]),

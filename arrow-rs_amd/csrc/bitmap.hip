@@ -10,7 +10,7 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) bitmap_op_kernel(int op, BitView a, BitView b, BitView c,
+__global__ void __launch_bounds__(256) bitmap_op_kernel(int op, BitView a, BitView b, BitView c, BitView d,
                                                         int64_t len, unsigned long long* out,
                                                         unsigned long long* partials) {
   int64_t nwords = (len + 63) >> 6;
@@ -30,6 +30,19 @@ __global__ void __launch_bounds__(256) bitmap_op_kernel(int op, BitView a, BitVi
       case BM_NOT_DISTINCT_BOTH: {
         uint64_t y = bv_fetch64(b, s, len), e = bv_fetch64(c, s, len);
         r = ~(x | y) | (x & y & e);
+        break;
+      }
+      case BM_OR: r = x | bv_fetch64(b, s, len); break;
+      case BM_ANDNOT: r = x & ~bv_fetch64(b, s, len); break;
+      case BM_OR_NOTB: r = x | ~bv_fetch64(b, s, len); break;
+      case BM_KLEENE_AND_NULLS: {
+        uint64_t y = bv_fetch64(b, s, len), z = bv_fetch64(c, s, len), w4 = bv_fetch64(d, s, len);
+        r = (x | (z & ~w4)) & (z | (x & ~y));
+        break;
+      }
+      case BM_KLEENE_OR_NULLS: {
+        uint64_t y = bv_fetch64(b, s, len), z = bv_fetch64(c, s, len), w4 = bv_fetch64(d, s, len);
+        r = (x | (z & w4)) & (z | (x & y));
         break;
       }
       default: r = ~x | bv_fetch64(b, s, len); break;  // BM_ORNOT
@@ -88,7 +101,7 @@ __global__ void __launch_bounds__(256) set_bits_kernel(unsigned long long* dst, 
 }  // namespace
 
 ah_status ah_bitmap_op(ah_context* ctx, int op, BitView a, BitView b, BitView c, int64_t len,
-                       unsigned long long* out_words, int64_t* set_bits) {
+                       unsigned long long* out_words, int64_t* set_bits, BitView d) {
   if (len <= 0) {
     if (set_bits) *set_bits = 0;
     return AH_OK;
@@ -97,7 +110,7 @@ ah_status ah_bitmap_op(ah_context* ctx, int op, BitView a, BitView b, BitView c,
   int grid = (int)std::min<int64_t>(4096, ah_ceil_div(nwords, 256));
   unsigned long long* part = nullptr;
   if (set_bits) AH_TRY(ah_pool_alloc(ctx, (size_t)(grid + 1) * 8, (void**)&part));
-  bitmap_op_kernel<<<grid, 256, 0, ctx->stream>>>(op, a, b, c, len, out_words, part);
+  bitmap_op_kernel<<<grid, 256, 0, ctx->stream>>>(op, a, b, c, d, len, out_words, part);
   if (set_bits) {
     bm_sum_kernel<<<1, 1024, 0, ctx->stream>>>(part, grid, part + grid);
     hipError_t e = hipMemcpyAsync(ctx->pinned + 8, part + grid, 8, hipMemcpyDeviceToHost, ctx->stream);

@@ -201,12 +201,17 @@ enum ah_bitmap_opcode {
   BM_DISTINCT_BOTH = 3,   // (a ^ b) | (a & b & c)     cmp.rs:329-335
   BM_NOT_DISTINCT_BOTH = 4,  // ~(a | b) | (a & b & c) cmp.rs:336-343
   BM_ORNOT = 5,           // ~a | b                    cmp.rs:366-372
+  BM_OR = 6,              // a | b
+  BM_ANDNOT = 7,          // a & ~b                    boolean.rs:291 and_not
+  BM_OR_NOTB = 8,         // a | ~b                    boolean.rs:88 (and_kleene, one nullable side)
+  BM_KLEENE_AND_NULLS = 9,   // (a | (c & ~d)) & (c | (a & ~b))   boolean.rs:121
+  BM_KLEENE_OR_NULLS = 10,   // (a | (c & d)) & (c | (a & b))     boolean.rs:213
 };
 // out_words[w] = op(a, b, c) over `len` bits (each input a BitView with its own
 // offset; words == nullptr reads as all-ones); bits past len are zeroed.
 // *set_bits (optional) receives the popcount of the result.  Synchronous only
 // when set_bits != nullptr.
 ah_status ah_bitmap_op(ah_context* ctx, int op, BitView a, BitView b, BitView c, int64_t len,
-                       unsigned long long* out_words, int64_t* set_bits);
+                       unsigned long long* out_words, int64_t* set_bits, BitView d = BitView{nullptr, 0});
 
 #endif  // __HIPCC__

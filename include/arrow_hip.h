@@ -198,6 +198,22 @@ AH_API ah_status ah_compare(ah_context* ctx, ah_cmp_op op,
                             const ah_array_view* rhs, int32_t rhs_is_scalar,
                             ah_array_out* out);
 
+/* --------------------------------------------------------------- boolean */
+typedef int32_t ah_boolean_op;
+enum {
+  AH_BOOL_AND = 0, AH_BOOL_OR = 1, AH_BOOL_AND_NOT = 2, AH_BOOL_AND_KLEENE = 3, AH_BOOL_OR_KLEENE = 4,
+  AH_BOOL_NOT = 10, AH_BOOL_IS_NULL = 11, AH_BOOL_IS_NOT_NULL = 12
+};
+/* arrow_arith::boolean::{and,or,and_not,and_kleene,or_kleene} (arrow-arith/src/boolean.rs:60-300):
+ * both inputs AH_BOOL of equal length, else AH_COMPUTE_ERROR "Cannot perform bitwise operation on
+ * arrays of different length". */
+AH_API ah_status ah_boolean_binary(ah_context* ctx, ah_boolean_op op, const ah_array_view* left,
+                                   const ah_array_view* right, ah_array_out* out);
+/* not (boolean.rs:310, AH_BOOL input), is_null / is_not_null (:327,:347, any type; the result
+ * never carries a null buffer). */
+AH_API ah_status ah_boolean_unary(ah_context* ctx, ah_boolean_op op, const ah_array_view* values,
+                                  ah_array_out* out);
+
 /* ------------------------------------------------------------------ cast */
 /* arrow_cast::cast_with_options (arrow-cast/src/cast/mod.rs:790), restricted to
  * numeric<->numeric (mod.rs:1578-1697 via cast_numeric_arrays :2550) and

@@ -14,6 +14,8 @@
 //                                         arrow-arith/src/numeric.rs:36-186
 //   arrow_hip::compute::{eq,neq,lt,lt_eq,gt,gt_eq,distinct,not_distinct}
 //                                         arrow-ord/src/cmp.rs:79-202
+//   arrow_hip::compute::{and_,or_,and_not,and_kleene,or_kleene,not_,is_null,is_not_null}
+//                                         arrow-arith/src/boolean.rs:60-360
 //   arrow_hip::compute::cast / cast_with_options / CastOptions
 //                                         arrow-cast/src/cast/mod.rs:347,:790,:95
 //   arrow_hip::compute::concat            arrow-select/src/concat.rs:495
@@ -249,6 +251,26 @@ inline ArrayRef gt(const Datum& l, const Datum& r) { return compare(AH_GT, l, r)
 inline ArrayRef gt_eq(const Datum& l, const Datum& r) { return compare(AH_GT_EQ, l, r); }
 inline ArrayRef distinct(const Datum& l, const Datum& r) { return compare(AH_DISTINCT, l, r); }
 inline ArrayRef not_distinct(const Datum& l, const Datum& r) { return compare(AH_NOT_DISTINCT, l, r); }
+
+// ---- boolean (arrow-arith/src/boolean.rs); `and`/`or`/`not` are C++ alternative tokens -> trailing underscore
+inline ArrayRef boolean_binary(ah_boolean_op op, const ArrayRef& l, const ArrayRef& r) {
+  ah_array_out out;
+  l->context()->check(ah_boolean_binary(l->context()->handle(), op, &l->view(), &r->view(), &out));
+  return wrap(l, out);
+}
+inline ArrayRef boolean_unary(ah_boolean_op op, const ArrayRef& v) {
+  ah_array_out out;
+  v->context()->check(ah_boolean_unary(v->context()->handle(), op, &v->view(), &out));
+  return wrap(v, out);
+}
+inline ArrayRef and_(const ArrayRef& l, const ArrayRef& r) { return boolean_binary(AH_BOOL_AND, l, r); }
+inline ArrayRef or_(const ArrayRef& l, const ArrayRef& r) { return boolean_binary(AH_BOOL_OR, l, r); }
+inline ArrayRef and_not(const ArrayRef& l, const ArrayRef& r) { return boolean_binary(AH_BOOL_AND_NOT, l, r); }
+inline ArrayRef and_kleene(const ArrayRef& l, const ArrayRef& r) { return boolean_binary(AH_BOOL_AND_KLEENE, l, r); }
+inline ArrayRef or_kleene(const ArrayRef& l, const ArrayRef& r) { return boolean_binary(AH_BOOL_OR_KLEENE, l, r); }
+inline ArrayRef not_(const ArrayRef& v) { return boolean_unary(AH_BOOL_NOT, v); }
+inline ArrayRef is_null(const ArrayRef& v) { return boolean_unary(AH_BOOL_IS_NULL, v); }
+inline ArrayRef is_not_null(const ArrayRef& v) { return boolean_unary(AH_BOOL_IS_NOT_NULL, v); }
 
 // ---- cast (arrow-cast/src/cast/mod.rs)
 struct CastOptions {  // cast/mod.rs:95-111

@@ -1383,6 +1383,89 @@ int32_t orc_compare(int32_t op, const orc_view* l, int32_t l_s, const orc_view* 
   return ORC_OK;
 }
 
+// arrow_arith::boolean (arrow-arith/src/boolean.rs): and/or/and_not :256-300 via
+// binary_boolean_kernel :224 (nulls = NullBuffer::union), and_kleene :60-151, or_kleene :156-222
+int32_t orc_boolean_binary(int32_t op, const orc_view* l, const orc_view* r, orc_out* out) {
+  out_init(out);
+  if (l->type != ORC_BOOL || r->type != ORC_BOOL)
+    return fail(ORC_INVALID_ARGUMENT, "boolean kernels need Boolean inputs, got %s and %s", type_name(l->type), type_name(r->type));
+  if (l->length != r->length)
+    return fail(ORC_COMPUTE_ERROR, "Cannot perform bitwise operation on arrays of different length");
+  int64_t len = l->length;
+  out->type = ORC_BOOL;
+  out->length = len;
+  if (len == 0) return ORC_OK;
+  size_t bytes = bitmap_bytes(len);
+  uint8_t* vals = (uint8_t*)xalloc(bytes);
+  const uint8_t* lb = (const uint8_t*)l->values;
+  const uint8_t* rb = (const uint8_t*)r->values;
+  auto LV = [&](int64_t i) { return get_bit(lb, l->values_bit_offset + i); };
+  auto RV = [&](int64_t i) { return get_bit(rb, r->values_bit_offset + i); };
+  auto LN = [&](int64_t i) { return get_bit(l->validity, l->validity_bit_offset + i); };
+  auto RN = [&](int64_t i) { return get_bit(r->validity, r->validity_bit_offset + i); };
+  for (int64_t i = 0; i < len; ++i) {
+    bool a = LV(i), b = RV(i), v;
+    switch (op) {
+      case 0: case 3: v = a && b; break;
+      case 2: v = a && !b; break;
+      default: v = a || b; break;
+    }
+    if (v) set_bit(vals, i);
+  }
+  out->values = vals;
+  out->values_bytes = (int64_t)bytes;
+  if (!l->validity && !r->validity) return ORC_OK;
+  uint8_t* nb = (uint8_t*)xalloc(bytes);
+  for (int64_t i = 0; i < len; ++i) {
+    bool n;
+    if (op == 3 || op == 4) {
+      bool is_and = op == 3;
+      if (l->validity && r->validity) {
+        bool a = LN(i), b = LV(i), c = RN(i), d = RV(i);
+        n = is_and ? ((a | (c & !d)) & (c | (a & !b))) : ((a | (c & d)) & (c | (a & b)));
+      } else if (l->validity) n = is_and ? (LN(i) | !RV(i)) : (LN(i) | RV(i));
+      else n = is_and ? (RN(i) | !LV(i)) : (RN(i) | LV(i));
+    } else {
+      n = (!l->validity || LN(i)) && (!r->validity || RN(i));
+    }
+    if (n) set_bit(nb, i);
+  }
+  out->validity = nb;
+  out->validity_bytes = (int64_t)bytes;
+  out->null_count = len - count_set_bits(nb, 0, len);
+  return ORC_OK;
+}
+
+// not :310, is_null :327, is_not_null :347
+int32_t orc_boolean_unary(int32_t op, const orc_view* v, orc_out* out) {
+  out_init(out);
+  if (op == 10 && v->type != ORC_BOOL)
+    return fail(ORC_INVALID_ARGUMENT, "not() needs a Boolean input, got %s", type_name(v->type));
+  int64_t len = v->length;
+  out->type = ORC_BOOL;
+  out->length = len;
+  if (len == 0) return ORC_OK;
+  size_t bytes = bitmap_bytes(len);
+  uint8_t* vals = (uint8_t*)xalloc(bytes);
+  out->values = vals;
+  out->values_bytes = (int64_t)bytes;
+  for (int64_t i = 0; i < len; ++i) {
+    bool b;
+    if (op == 10) b = !get_bit((const uint8_t*)v->values, v->values_bit_offset + i);
+    else {
+      bool valid = !v->validity || get_bit(v->validity, v->validity_bit_offset + i);
+      b = op == 11 ? !valid : valid;
+    }
+    if (b) set_bit(vals, i);
+  }
+  if (op == 10 && v->validity) {
+    out->validity = nulls_clone(v, len);
+    out->validity_bytes = (int64_t)bytes;
+    out->null_count = len - count_set_bits(out->validity, 0, len);
+  }
+  return ORC_OK;
+}
+
 int32_t orc_cast(const orc_view* in, int32_t to, int32_t safe, orc_out* out) {
   out_init(out);
   if (to == ORC_UTF8) return cast_to_string_dispatch<int32_t>(in, to, out);

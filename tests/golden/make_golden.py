@@ -257,7 +257,39 @@ cast_cases.append(dict(name="i64_to_f64_to_utf8_chain", source="arrow-cast/src/c
                        expected=arr("Utf8", ["-9.223372036854776e18", "-2147483648.0", "0.0", "127.0",
                                              "9.223372036854776e18"])))
 
-for name, cases in [("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
+bool_cases = []
+A4, B4 = [F, F, T, T], [F, T, F, T]
+bool_cases.append(dict(name="test_bool_array_and", source="arrow-arith/src/boolean.rs:364", op="and",
+                       lhs=arr("Boolean", A4), rhs=arr("Boolean", B4), expected=arr("Boolean", [F, F, F, T])))
+bool_cases.append(dict(name="test_bool_array_or", source="arrow-arith/src/boolean.rs:375", op="or",
+                       lhs=arr("Boolean", A4), rhs=arr("Boolean", B4), expected=arr("Boolean", [F, T, T, T])))
+bool_cases.append(dict(name="test_bool_array_and_not", source="arrow-arith/src/boolean.rs:386", op="and_not",
+                       lhs=arr("Boolean", A4), rhs=arr("Boolean", B4), expected=arr("Boolean", [F, F, T, F])))
+A9 = [N, N, N, F, F, F, T, T, T]
+B9 = [N, F, T, N, F, T, N, F, T]
+bool_cases.append(dict(name="test_bool_array_or_nulls", source="arrow-arith/src/boolean.rs:422", op="or",
+                       lhs=arr("Boolean", A9), rhs=arr("Boolean", B9), expected=arr("Boolean", [N, N, N, N, F, T, N, T, T])))
+bool_cases.append(dict(name="test_bool_array_and_kleene_nulls", source="arrow-arith/src/boolean.rs:473", op="and_kleene",
+                       lhs=arr("Boolean", A9), rhs=arr("Boolean", B9), expected=arr("Boolean", [N, F, N, F, F, F, N, F, T])))
+bool_cases.append(dict(name="test_bool_array_or_kleene_nulls", source="arrow-arith/src/boolean.rs:514", op="or_kleene",
+                       lhs=arr("Boolean", A9), rhs=arr("Boolean", B9), expected=arr("Boolean", [N, N, T, N, F, T, T, T, T])))
+bool_cases.append(dict(name="and_kleene_doc_example", source="arrow-arith/src/boolean.rs:47-51", op="and_kleene",
+                       lhs=arr("Boolean", [T, F, N]), rhs=arr("Boolean", [N, N, N]), expected=arr("Boolean", [N, F, N])))
+bool_cases.append(dict(name="test_boolean_array_kleene_no_remainder", source="arrow-arith/src/boolean.rs:451-458", op="or_kleene",
+                       lhs=arr("Boolean", [T] * 1024), rhs=arr("Boolean", [N] * 1024), expected=arr("Boolean", [T] * 1024)))
+bool_cases.append(dict(name="test_bool_array_not", source="arrow-arith/src/boolean.rs:621", op="not",
+                       lhs=arr("Boolean", [F, T]), expected=arr("Boolean", [T, F])))
+bool_cases.append(dict(name="test_bool_array_not_sliced", source="arrow-arith/src/boolean.rs:631", op="not",
+                       lhs=arr("Boolean", [N, T, F, N, T], [1, 4]), expected=arr("Boolean", [F, T, N, F])))
+bool_cases.append(dict(name="test_nullable_array_is_null", source="arrow-arith/src/boolean.rs:835", op="is_null",
+                       lhs=arr("Int32", [1, N, 3, N]), expected=arr("Boolean", [F, T, F, T]), no_null_buffer=True))
+bool_cases.append(dict(name="test_nullable_array_is_not_null", source="arrow-arith/src/boolean.rs:878", op="is_not_null",
+                       lhs=arr("Int32", [1, N, 3, N]), expected=arr("Boolean", [T, F, T, F]), no_null_buffer=True))
+bool_cases.append(dict(name="length_mismatch", source="arrow-arith/src/boolean.rs:233-237", op="and",
+                       lhs=arr("Boolean", [T, F]), rhs=arr("Boolean", [T]), error="ComputeError",
+                       message="Cannot perform bitwise operation on arrays of different length"))
+
+for name, cases in [("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
                     ("cast", cast_cases)]:
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump({"reference": "apache/arrow-rs 59.2.0", "cases": cases}, f, indent=1)

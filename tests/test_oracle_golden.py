@@ -338,3 +338,24 @@ def test_host_generators_are_deterministic(oracle):
     assert 0.09 < bits.mean() < 0.11
     f = oracle.gen_f64(1000, 44, -1e6, 1e6)
     assert f.min() >= -1e6 and f.max() < 1e6
+
+
+# ------------------------------------------------------------------ boolean
+BOOL_BIN = {"and": 0, "or": 1, "and_not": 2, "and_kleene": 3, "or_kleene": 4}
+BOOL_UN = {"not": 10, "is_null": 11, "is_not_null": 12}
+
+
+@pytest.mark.parametrize("case", load_golden("boolean"), ids=lambda c: c["name"])
+@pytest.mark.parametrize("bit_offset", [0, 5])
+def test_boolean_golden(oracle, case, bit_offset):
+    l = golden_array(case["lhs"])
+    if case["op"] in BOOL_UN:
+        got = oracle.boolean_unary(BOOL_UN[case["op"]], l, bit_offset)
+    else:
+        r = golden_array(case["rhs"])
+        if "error" in case:
+            return expect_err(case, lambda: oracle.boolean_binary(BOOL_BIN[case["op"]], l, r))
+        got = oracle.boolean_binary(BOOL_BIN[case["op"]], l, r, bit_offset)
+    assert_logical_eq(got, golden_array(case["expected"]), case["name"])
+    if case.get("no_null_buffer"):
+        assert got.valid is None
