@@ -91,6 +91,8 @@ SIGNATURES = {
     "ah_filter_predicate_apply": (C.c_int32, [_P, _P, _VIEW, _OUT]),
     "ah_filter_predicate_free": (None, [_P, _P]),
     "ah_filter_record_batch": (C.c_int32, [_P, C.c_int32, _VIEW, _VIEW, _OUT, C.POINTER(C.c_int64)]),
+    "ah_filter_predicate_apply_into": (C.c_int32, [_P, _P, _VIEW, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "ah_copy_rows_into": (C.c_int32, [_P, _VIEW, C.c_int64, C.c_int64, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "ah_take": (C.c_int32, [_P, _VIEW, _VIEW, C.c_int32, _OUT]),
     "ah_arith_binary": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
     "ah_arith_neg": (C.c_int32, [_P, _VIEW, C.c_int32, _OUT]),

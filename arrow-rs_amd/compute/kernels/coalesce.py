@@ -1,0 +1,174 @@
+"""arrow::compute::BatchCoalescer == arrow_select::coalesce::BatchCoalescer
+(arrow-select/src/coalesce.rs:148-700), primitive columns (coalesce/primitive.rs).
+
+The host state machine (exact-size output batches, in input order, optional large-batch bypass)
+is restated here; the data movement happens in HBM:
+  * ``copy_rows``                 -> ``ah_copy_rows_into`` (D2D copy + funnel-shift bitmap merge)
+  * ``copy_rows_by_filter_from``  -> ``ah_filter_predicate_apply_into``: the filter scatters
+    straight into the in-progress buffers (no intermediate filtered array, no second copy).
+The reference only fuses when ``selected <= len/16`` (coalesce.rs:45-54, a CPU cache trade-off);
+on the GPU the fused scatter is never slower than filter-then-copy, so it is used whenever the
+selected rows fit the in-progress batch — the sequence of completed batches is identical.
+"""
+import ctypes as C
+from collections import deque
+
+from ... import _lib as L
+from ...array import (Array, Boolean, DeviceBuffer, RecordBatch, InvalidArgumentError, NotYetImplemented,
+                      _RawMem)
+from .filter import FilterBuilder
+from .take import take_record_batch
+
+
+class _InProgress:
+    """InProgressPrimitiveArray (coalesce/primitive.rs:28-52): values + NullBufferBuilder."""
+
+    def __init__(self, ctx, data_type, batch_size):
+        if not data_type.is_primitive() or data_type.width <= 0:
+            raise NotYetImplemented(f"BatchCoalescer column type {data_type}")
+        self.ctx, self.data_type, self.batch_size = ctx, data_type, batch_size
+        self.values = None
+        self.validity = None
+        self.nulls = 0
+
+    def ensure_capacity(self):  # allocate on first write (primitive.rs:57-61)
+        if self.values is None:
+            self.values = DeviceBuffer(self.ctx, max(self.batch_size * self.data_type.width, 8))
+            self.validity = DeviceBuffer(self.ctx, ((self.batch_size + 63) // 64) * 8)
+            self.ctx.check(self.ctx.lib.ah_memset(self.ctx.handle, self.validity.ptr, 0, self.validity.nbytes))
+
+    def copy_rows(self, source, offset, length, at):
+        self.ensure_capacity()
+        n = C.c_int64()
+        v = source.view()
+        self.ctx.check(self.ctx.lib.ah_copy_rows_into(self.ctx.handle, C.byref(v), offset, length,
+                                                      self.values.ptr, self.validity.ptr, at, C.byref(n)))
+        self.nulls += n.value
+
+    def copy_rows_by_filter_from(self, source, predicate, at):
+        self.ensure_capacity()
+        n = C.c_int64()
+        v = source.view()
+        self.ctx.check(self.ctx.lib.ah_filter_predicate_apply_into(
+            self.ctx.handle, predicate._h, C.byref(v), self.values.ptr, self.validity.ptr, at, C.byref(n)))
+        self.nulls += n.value
+
+    def finish(self, rows):
+        w = self.data_type.width
+        vals = _RawMem(self.values.ptr, rows * w, self.values)
+        # NullBufferBuilder::finish: a buffer only if a null was ever appended
+        nmem = _RawMem(self.validity.ptr, self.validity.nbytes, self.validity) if self.nulls else None
+        arr = Array(self.ctx, self.data_type, rows, vals, 0, nmem, 0, self.nulls)
+        self.values = self.validity = None
+        self.nulls = 0
+        return arr
+
+
+class BatchCoalescer:
+    """``BatchCoalescer::new(schema, target_batch_size)``; schema = (names, data types)."""
+
+    def __init__(self, names, data_types, target_batch_size, ctx=None):
+        from ...array import default_context
+        self.ctx = ctx or default_context()
+        self.names = list(names)
+        self.data_types = list(data_types)
+        self.target_batch_size = int(target_batch_size)
+        self.in_progress = [_InProgress(self.ctx, dt, self.target_batch_size) for dt in self.data_types]
+        self.buffered_rows = 0
+        self.completed = deque()
+        self.biggest_coalesce_batch_size = None
+
+    @classmethod
+    def new(cls, names, data_types, target_batch_size, ctx=None):
+        return cls(names, data_types, target_batch_size, ctx)
+
+    def with_biggest_coalesce_batch_size(self, limit):
+        self.biggest_coalesce_batch_size = limit
+        return self
+
+    def set_biggest_coalesce_batch_size(self, limit):
+        self.biggest_coalesce_batch_size = limit
+
+    def get_buffered_rows(self):
+        return self.buffered_rows
+
+    def is_empty(self):
+        return self.buffered_rows == 0 and not self.completed
+
+    def has_completed_batch(self):
+        return bool(self.completed)
+
+    def next_completed_batch(self):
+        return self.completed.popleft() if self.completed else None
+
+    # ---- coalesce.rs:229
+    def push_batch_with_filter(self, batch, filter):
+        if filter.data_type != Boolean:
+            raise InvalidArgumentError(f"filter predicate must be Boolean, got {filter.data_type}")
+        filter_len, rows = filter.length, batch.num_rows()
+        if filter_len > rows:
+            raise InvalidArgumentError(
+                f"Filter predicate of length {filter_len} is larger than target array of length {rows}")
+        predicate = FilterBuilder.new(filter).optimize().build()  # one count pass for all columns
+        selected = predicate.count()
+        if selected == 0:
+            return
+        if selected == rows and filter_len == rows:
+            return self.push_batch(batch)
+        if batch.num_columns() != len(self.in_progress):
+            raise InvalidArgumentError(
+                f"Batch has {batch.num_columns()} columns but BatchCoalescer expects {len(self.in_progress)}")
+        exceeds = self.biggest_coalesce_batch_size is not None and selected > self.biggest_coalesce_batch_size
+        does_not_fit = selected > self.target_batch_size - self.buffered_rows
+        if exceeds or does_not_fit:  # materialise, then split across output batches
+            return self.push_batch(predicate.filter_record_batch(batch))
+        for ip, col in zip(self.in_progress, batch.columns):
+            ip.copy_rows_by_filter_from(col, predicate, self.buffered_rows)
+        self.buffered_rows += selected
+        if self.buffered_rows >= self.target_batch_size:
+            self.finish_buffered_batch()
+
+    # ---- coalesce.rs:257
+    def push_batch_with_indices(self, batch, indices):
+        return self.push_batch(take_record_batch(batch, indices))
+
+    # ---- coalesce.rs:296-525
+    def push_batch(self, batch):
+        batch_size = batch.num_rows()
+        if batch_size == 0:
+            return
+        limit = self.biggest_coalesce_batch_size
+        if limit is not None and batch_size > limit:
+            if self.buffered_rows == 0:          # case 1: bypass
+                self.completed.append(batch)
+                return
+            if self.buffered_rows > limit:       # case 2: flush, then bypass
+                self.finish_buffered_batch()
+                self.completed.append(batch)
+                return
+        if batch.num_columns() != len(self.in_progress):
+            raise InvalidArgumentError(
+                f"Batch has {batch.num_columns()} columns but BatchCoalescer expects {len(self.in_progress)}")
+        num_rows, offset = batch_size, 0
+        while num_rows > self.target_batch_size - self.buffered_rows:
+            remaining = self.target_batch_size - self.buffered_rows
+            for ip, col in zip(self.in_progress, batch.columns):
+                ip.copy_rows(col, offset, remaining, self.buffered_rows)
+            self.buffered_rows += remaining
+            offset += remaining
+            num_rows -= remaining
+            self.finish_buffered_batch()
+        if num_rows > 0:
+            for ip, col in zip(self.in_progress, batch.columns):
+                ip.copy_rows(col, offset, num_rows, self.buffered_rows)
+        self.buffered_rows += num_rows
+        if self.buffered_rows >= self.target_batch_size:
+            self.finish_buffered_batch()
+
+    # ---- coalesce.rs:536
+    def finish_buffered_batch(self):
+        if self.buffered_rows == 0:
+            return
+        cols = [ip.finish(self.buffered_rows) for ip in self.in_progress]
+        self.completed.append(RecordBatch(self.names, cols, num_rows=self.buffered_rows))
+        self.buffered_rows = 0

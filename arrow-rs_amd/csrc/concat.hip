@@ -85,3 +85,32 @@ extern "C" ah_status ah_concat(ah_context* ctx, int32_t n, const ah_array_view* 
   }
   return AH_OK;
 }
+
+// InProgressPrimitiveArray::copy_rows (arrow-select/src/coalesce/primitive.rs): append rows
+// [offset, offset+len) of `src` to an in-progress builder at row `dst_row_offset`.
+extern "C" ah_status ah_copy_rows_into(ah_context* ctx, const ah_array_view* src, int64_t offset, int64_t len,
+                                       void* dst_values, uint8_t* dst_validity, int64_t dst_row_offset,
+                                       int64_t* appended_nulls) {
+  if (!ctx || !src || !dst_values || !dst_validity) return AH_INVALID_ARGUMENT;
+  hipSetDevice(ctx->device);
+  if (appended_nulls) *appended_nulls = 0;
+  const int w = ah_type_width(src->type);
+  if (w <= 0)
+    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "copy_rows not supported for type %s", ah_type_name(src->type));
+  if (offset < 0 || len < 0 || offset + len > src->length)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "copy_rows range [%lld, %lld) exceeds source length %lld",
+                   (long long)offset, (long long)(offset + len), (long long)src->length);
+  if (len == 0) return AH_OK;
+  ah_prof_scope ps(ctx, "copy_rows");
+  AH_HIP(ctx, hipMemcpyAsync((char*)dst_values + (size_t)dst_row_offset * w,
+                             (const char*)src->values + (size_t)offset * w, (size_t)len * w,
+                             hipMemcpyDeviceToDevice, ctx->stream));
+  int64_t set = len;
+  // a source without a null buffer appends `len` valid rows (NullBufferBuilder::append_n_non_nulls)
+  AH_TRY(ah_bitmap_set_bits(ctx, dst_validity, dst_row_offset, src->validity,
+                            src->validity ? src->validity_bit_offset + offset : 0, len,
+                            src->validity ? &set : nullptr));
+  if (!src->validity) AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (appended_nulls) *appended_nulls = len - set;
+  return AH_OK;
+}

@@ -137,6 +137,7 @@ struct ScatterArgs {
   unsigned long long* out_valid;   // zero-initialised u64 words
   unsigned long long* valid_slots; // VALID_SLOTS zero-initialised counters (valid selected rows)
   int xcd_remap;                   // 1: tiles that share output lines stay on one XCD
+  int64_t out_base;                // rows already present in the destination (fused filter-into-builder)
   int64_t ntiles;
 };
 
@@ -229,7 +230,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
   }
 
   const int64_t chunk0 = row0 / CHUNK_ROWS;
-  const int64_t ob = (int64_t)a.group_prefix[chunk0 / GROUP_CHUNKS] + a.chunk_prefix[chunk0];
+  const int64_t ob = a.out_base + (int64_t)a.group_prefix[chunk0 / GROUP_CHUNKS] + a.chunk_prefix[chunk0];
   int vc = 0;
 
   for (int p0 = 0; p0 < total; p0 += CAP) {
@@ -614,6 +615,73 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
       out->validity_bytes = (int64_t)bbytes;
       out->null_count = nulls;
     }
+  }
+  return AH_OK;
+}
+
+// InProgressPrimitiveArray::copy_rows_by_filter_from (arrow-select/src/coalesce/primitive.rs): the
+// filter scatters straight into an in-progress builder at row `dst_row_offset` — no intermediate
+// array (BatchCoalescer::push_batch_with_filter, arrow-select/src/coalesce.rs:229).  The bitmap
+// words are merged with atomicOr, so any destination bit offset works.
+extern "C" ah_status ah_filter_predicate_apply_into(ah_context* ctx, const ah_filter_predicate* p,
+                                                    const ah_array_view* values, void* dst_values,
+                                                    uint8_t* dst_validity, int64_t dst_row_offset,
+                                                    int64_t* appended_nulls) {
+  if (!ctx || !p || !values || !dst_values || !dst_validity) return AH_INVALID_ARGUMENT;
+  hipSetDevice(ctx->device);
+  if (appended_nulls) *appended_nulls = 0;
+  if (p->len > values->length)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT,
+                   "Filter predicate of length %lld is larger than target array of length %lld",
+                   (long long)p->len, (long long)values->length);
+  const int width = ah_type_width(values->type);
+  if (width <= 0)
+    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "fused filter copy not supported for type %s",
+                   ah_type_name(values->type));
+  if (((uintptr_t)dst_validity & 7) != 0)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "builder validity must be 8-byte aligned");
+  const int64_t K = p->count;
+  if (p->len == 0 || K == 0) return AH_OK;
+  int64_t in_nulls = 0;
+  AH_TRY(ah_resolve_null_count(ctx, values, &in_nulls));
+  const bool has_valid = values->validity && in_nulls > 0;
+  unsigned long long* slots = nullptr;
+  if (has_valid) {
+    AH_TRY(ah_pool_alloc(ctx, VALID_SLOTS * 8, (void**)&slots));
+    hipMemsetAsync(slots, 0, VALID_SLOTS * 8, ctx->stream);
+  }
+  ScatterArgs a{};
+  a.values = values->values;
+  a.mask = p->mask;
+  a.mask_valid = p->mask_valid;
+  a.vvalid = has_valid ? make_bitview(values->validity, values->validity_bit_offset) : BitView{nullptr, 0};
+  a.len = p->len;
+  a.chunk_prefix = p->chunk_prefix;
+  a.group_prefix = p->group_prefix;
+  a.out_values = dst_values;
+  a.out_valid = (unsigned long long*)dst_validity;
+  a.valid_slots = slots;
+  a.out_base = dst_row_offset;
+  const bool skip = use_skip(K, p->len);
+  {
+    ah_prof_scope ps(ctx, "filter_scatter");
+    if (has_valid) launch_scatter<true>(ctx, width, a, skip);
+    else launch_scatter<false>(ctx, width, a, skip);
+  }
+  hipError_t e = hipGetLastError();
+  ah_status st = AH_OK;
+  if (e == hipSuccess && !has_valid)  // source without nulls: the appended rows are all valid
+    st = ah_bitmap_set_bits(ctx, dst_validity, dst_row_offset, nullptr, 0, K, nullptr);
+  if (e == hipSuccess && has_valid)
+    e = hipMemcpyAsync(ctx->pinned, slots, VALID_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  ah_pool_free(ctx, slots);
+  if (st != AH_OK) return st;
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "fused filter copy failed: %s", hipGetErrorString(e));
+  if (has_valid && appended_nulls) {
+    int64_t validc = 0;
+    for (int i = 0; i < VALID_SLOTS; ++i) validc += (int64_t)ctx->pinned[i];
+    *appended_nulls = K - validc;
   }
   return AH_OK;
 }

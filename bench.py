@@ -50,6 +50,48 @@ def pmc_traffic(kernel, args):
         return None
 
 
+def _splitmix64(seed, rows):
+    """numpy twin of the device generator (arrow-rs_amd/csrc/gen.hip) for arbitrary row numbers."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (rows.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def verify_filter_take(A, ctx, args, n, row0, f, t, idx):
+    """Full-size parity (the oracle cannot hold 1e9 rows): filter is order preserving, so the
+    oracle's result on the first / last W input rows must equal the head / tail of the device
+    output; take rows are checked against values re-derived from the counter-based generators."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import orc
+    oracle = orc.load(os.path.join(ROOT, "oracle", "liboracle.so"))
+    W = min(n, 1 << 22)
+    res = {}
+    for name, start in (("head", 0), ("tail", n - W)):
+        vals = oracle.gen_i64(W, 42, -2**63, 2**63 - 1, row0=row0 + start)
+        valid = oracle.gen_bits(W, 43, args.valid, row0=row0 + start)
+        mask = oracle.gen_bits(W, 44, args.selectivity, row0=row0 + start)
+        vals[~valid] = 0
+        exp = oracle.filter(orc.HostArray(A.Int64, vals, valid), orc.HostArray(A.Boolean, mask))
+        k = len(exp)
+        got = f.slice(0, k) if name == "head" else f.slice(f.length - k, k)
+        orc.assert_logical_eq(orc.HostArray.from_device(got), exp, f"filter {name} window")
+        res[f"filter_{name}_rows_checked"] = k
+    m = min(idx.length, 1 << 20)
+    rows = idx.slice(0, m).values_numpy().astype(np.uint64)
+    gvals = _splitmix64(42, rows + np.uint64(row0)).view(np.int64)
+    thr = np.uint64(int(max(0.0, min(1.0, args.valid)) * 9007199254740992.0))
+    gvalid = (_splitmix64(43, rows + np.uint64(row0)) >> np.uint64(11)) < thr
+    gvals = np.where(gvalid, gvals, 0)
+    orc.assert_logical_eq(orc.HostArray.from_device(t.slice(0, m)), orc.HostArray(A.Int64, gvals, gvalid),
+                          "take sample")
+    res["take_rows_checked"] = m
+    return res
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -59,9 +101,13 @@ def parse():
     p.add_argument("--selectivity", type=float, default=0.1)
     p.add_argument("--valid", type=float, default=0.9)
     p.add_argument("--workload", default="filter_take",
-                   choices=["filter_take", "arith", "cmp", "cast", "cast_string"])
+                   choices=["filter_take", "arith", "cmp", "cast", "cast_string", "coalesce"])
+    p.add_argument("--batch-rows", type=int, default=1 << 24, help="coalesce workload: rows per pushed batch")
     p.add_argument("--reassemble", default="auto", choices=["auto", "none", "allgatherv"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--verify", action="store_true",
+                   help="filter_take: check the full-size outputs against the oracle on head/tail windows "
+                        "and the take output against the counter-based generators on a sample")
     p.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
     return p.parse_args()
 
@@ -247,6 +293,34 @@ def main():
 
         kernels = ["filter_count", "filter_scatter", "take_gather"]
         dominant = "filter_scatter"
+    elif wl == "coalesce":
+        # BatchCoalescer::push_batch_with_filter over a stream of batches —
+        # the filter scatters straight into the in-progress output batch (no intermediate array)
+        col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
+        col2 = gen_f64_column(A, ctx, n, 52, args.valid, row0)
+        pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
+        br = min(args.batch_rows, n)
+        nb = n // br
+        target = max(1, int(br * args.selectivity * 4))
+        batches = [(A.RecordBatch(["a", "b"], [col.slice(i * br, br), col2.slice(i * br, br)]), pred.slice(i * br, br))
+                   for i in range(nb)]
+        state = {}
+
+        def step(_r):
+            co = K.BatchCoalescer.new(["a", "b"], [A.Int64, A.Float64], target, ctx)
+            out_rows = 0
+            for rb, f in batches:
+                co.push_batch_with_filter(rb, f)
+                while co.has_completed_batch():
+                    out_rows += co.next_completed_batch().num_rows()
+            co.finish_buffered_batch()
+            while co.has_completed_batch():
+                out_rows += co.next_completed_batch().num_rows()
+            state["out_rows"] = out_rows
+            return out_rows
+
+        kernels = ["filter_count", "filter_scatter", "copy_rows"]
+        dominant = "filter_scatter"
     elif wl in ("arith", "cmp"):
         a = gen_f64_column(A, ctx, n, 52, args.valid, row0)
         b = gen_f64_column(A, ctx, n, 62, args.valid, row0)
@@ -293,6 +367,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, local_elapsed = float(tt[0]), (float(tt[1]) if reassemble else None)
 
+    verified = None
+    if wl == "filter_take" and args.verify:
+        f, t = out
+        verified = verify_filter_take(A, ctx, args, n, row0, f, t, idx)
     sorted_ms = None
     if wl == "filter_take" and sorted_idx is not None:
         ctx.profile(True)
@@ -343,7 +421,13 @@ def main():
             dtype = "int64"
         else:
             per_row = {"arith": 24.375, "cmp": 16.5, "cast": 16.25}.get(wl)
-            if per_row is None:  # cast_string: input + offsets + bytes + validity
+            if wl == "coalesce":
+                k = state["out_rows"]
+                # two columns share one predicate: 2 x (values + validity) + mask in, 2 x (K values + K bits) out
+                alg_bytes = 2 * (n * 8 + (n + 7) // 8) + (n + 7) // 8 + 2 * (k * 8 + (k + 7) // 8)
+                dom_avg_ms = sum(prof[kk][0] for kk in kernels) / max(args.steps, 1)  # all launches of one step
+                dom_n = args.steps
+            elif per_row is None:  # cast_string: input + offsets + bytes + validity
                 o = out
                 alg_bytes = n * 8 + (n + 7) // 8 + (n + 1) * 8 + o.values.nbytes + (n + 7) // 8
                 dom_ms_all = sum(prof[k][0] for k in kernels) / max(prof[kernels[0]][1], 1)
@@ -353,7 +437,9 @@ def main():
             workload = {"arith": "configs[2]: add_wrapping Float64+Float64 with NullBuffers",
                         "cmp": "configs[2]: lt Float64<Float64 with NullBuffers",
                         "cast": "configs[3]: cast Int64->Float64",
-                        "cast_string": "configs[3]: cast Float64->LargeUtf8"}[wl] + f", {n} rows per GPU"
+                        "cast_string": "configs[3]: cast Float64->LargeUtf8",
+                        "coalesce": f"SURVEY 8f-1: BatchCoalescer.push_batch_with_filter, Int64+Float64, "
+                                    f"{args.batch_rows}-row batches"}[wl] + f", {n} rows per GPU"
             metric = f"{wl}_Mrows_per_s"
             dtype = "f64"
         if wl == "filter_take" and tk_avg > dom_avg_ms:
@@ -374,6 +460,8 @@ def main():
         }
         if comm is not None and getattr(comm, "timings", None):
             line["reassemble_last_ms"] = comm.timings
+        if verified:
+            line["verified_vs_oracle"] = verified
         line["kernel_avg_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
         if local_elapsed:
             line["local_value"] = round(n * world * args.steps / local_elapsed / 1e6, 1)

@@ -157,6 +157,20 @@ AH_API ah_status ah_filter_record_batch(ah_context* ctx, int32_t n_columns,
                                         const ah_array_view* predicate,
                                         ah_array_out* outs, int64_t* out_rows);
 
+/* ------------------------------------------------------- coalesce support */
+/* The two device primitives behind arrow_select::coalesce::BatchCoalescer
+ * (arrow-select/src/coalesce.rs:148-330; host state machine in the mirrors):
+ * InProgressPrimitiveArray::copy_rows_by_filter_from and ::copy_rows
+ * (arrow-select/src/coalesce/primitive.rs).  dst_validity is the builder's bitmap: 8-byte
+ * aligned, capacity >= target rows, zero in the range being appended to. */
+AH_API ah_status ah_filter_predicate_apply_into(ah_context* ctx, const ah_filter_predicate* p,
+                                                const ah_array_view* values, void* dst_values,
+                                                uint8_t* dst_validity, int64_t dst_row_offset,
+                                                int64_t* appended_nulls);
+AH_API ah_status ah_copy_rows_into(ah_context* ctx, const ah_array_view* src, int64_t offset, int64_t len,
+                                   void* dst_values, uint8_t* dst_validity, int64_t dst_row_offset,
+                                   int64_t* appended_nulls);
+
 /* ------------------------------------------------------------------ take */
 /* arrow_select::take::take (arrow-select/src/take.rs:89).  indices.type is any
  * of the 8 integer types; i32/i64 are reinterpreted as u32/u64, 8/16-bit are
