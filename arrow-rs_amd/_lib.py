@@ -18,6 +18,7 @@ AH_DIVIDE_BY_ZERO = 4
 AH_CAST_ERROR = 5
 AH_OFFSET_OVERFLOW = 6
 AH_NOT_YET_IMPLEMENTED = 7
+AH_OFFSET_OVERFLOW_ERROR = 8
 AH_PANIC = 100
 AH_HIP_ERROR = 101
 AH_OUT_OF_MEMORY = 102
@@ -41,6 +42,7 @@ class ArrayView(C.Structure):
         ("values_bit_offset", C.c_int64),
         ("validity", C.c_void_p),
         ("validity_bit_offset", C.c_int64),
+        ("offsets", C.c_void_p),
     ]
 
 

@@ -55,6 +55,10 @@ class CastError(ArrowError):
     variant, prefix = "CastError", "Cast error: "
 
 
+class OffsetOverflowError(ArrowError):
+    variant, prefix = "OffsetOverflowError", "Offset overflow error: "
+
+
 class NotYetImplemented(ArrowError):
     variant, prefix = "NotYetImplemented", "Not yet implemented: "
 
@@ -75,6 +79,7 @@ _STATUS = {
     L.AH_DIVIDE_BY_ZERO: DivideByZero,
     L.AH_CAST_ERROR: CastError,
     L.AH_NOT_YET_IMPLEMENTED: NotYetImplemented,
+    L.AH_OFFSET_OVERFLOW_ERROR: OffsetOverflowError,
     L.AH_OFFSET_OVERFLOW: Panic,
     L.AH_PANIC: Panic,
 }
@@ -342,12 +347,37 @@ class Array:
     def from_pylist(cls, items, data_type, ctx=None):
         """``PrimitiveArray::from(vec![Some(1), None, ...])``: null slots hold 0."""
         has_null = any(x is None for x in items)
+        valid = np.array([x is not None for x in items], dtype=bool) if has_null else None
+        if data_type.physical in (L.AH_UTF8, L.AH_LARGE_UTF8):
+            return cls.from_strings([x if x is not None else "" for x in items], valid, data_type, ctx)
         if data_type.physical == L.AH_BOOL:
             vals = np.array([bool(x) if x is not None else False for x in items], dtype=bool)
         else:
             vals = np.array([x if x is not None else 0 for x in items], dtype=data_type.np_dtype)
-        valid = np.array([x is not None for x in items], dtype=bool) if has_null else None
         return cls.from_numpy(vals, valid, data_type, ctx)
+
+    @classmethod
+    def from_strings(cls, strings, valid=None, data_type=None, ctx=None, bit_offset=0):
+        """GenericStringArray: offsets (i32 / i64) + bytes (+ validity).  Null slots may carry
+        bytes (the reference copies them through filter, filter.rs:890-892)."""
+        ctx = ctx or default_context()
+        data_type = data_type or Utf8
+        odt = np.int32 if data_type.physical == L.AH_UTF8 else np.int64
+        enc = [x.encode() if isinstance(x, str) else bytes(x) for x in strings]
+        offs = np.zeros(len(enc) + 1, dtype=odt)
+        if enc:
+            offs[1:] = np.cumsum([len(b) for b in enc])
+        data = np.frombuffer(b"".join(enc), dtype=np.uint8) if enc else np.empty(0, dtype=np.uint8)
+        ob = DeviceBuffer.from_numpy(ctx, offs)
+        db = DeviceBuffer.from_numpy(ctx, data)
+        nmem, nulls = None, 0
+        if valid is not None:
+            valid = np.asarray(valid, dtype=bool)
+            nb = DeviceBuffer.from_numpy(ctx, pack_bits(valid, bit_offset))
+            nmem = _RawMem(nb.ptr, nb.nbytes, nb)
+            nulls = int(len(enc) - valid.sum())
+        return cls(ctx, data_type, len(enc), _RawMem(db.ptr, db.nbytes, db), 0, nmem,
+                   bit_offset if nmem else 0, nulls, _RawMem(ob.ptr, ob.nbytes, ob))
 
     @classmethod
     def _from_out(cls, ctx, out, data_type, keepalive=()):
@@ -382,7 +412,13 @@ class Array:
         if offset + length > self.length:
             raise Panic("the length + offset of the sliced PrimitiveArray cannot exceed the existing length")
         w = self.data_type.width
-        if self.data_type.physical == L.AH_BOOL:
+        offs = self.offsets
+        if self.data_type.physical in (L.AH_UTF8, L.AH_LARGE_UTF8):
+            ow = 4 if self.data_type.physical == L.AH_UTF8 else 8
+            vals, vbo = self.values, 0
+            if offs is not None:
+                offs = _RawMem(offs.ptr + offset * ow, (length + 1) * ow, offs.owner)
+        elif self.data_type.physical == L.AH_BOOL:
             vals, vbo = self.values, self.values_bit_offset + offset
         elif self.values is None:
             vals, vbo = None, 0
@@ -397,7 +433,7 @@ class Array:
                                                           C.byref(cnt)))
             nulls = length - cnt.value
         return Array(self.ctx, self.data_type, length, vals, vbo, self.validity,
-                     self.validity_bit_offset + offset if self.validity else 0, nulls)
+                     self.validity_bit_offset + offset if self.validity else 0, nulls, offs)
 
     def view(self):
         """The ah_array_view handed to the C ABI."""
@@ -409,6 +445,7 @@ class Array:
         v.values_bit_offset = self.values_bit_offset
         v.validity = self.validity.ptr if self.validity is not None else None
         v.validity_bit_offset = self.validity_bit_offset
+        v.offsets = self.offsets.ptr if self.offsets is not None else None
         return v
 
     # Datum::get (arrow-array/src/scalar.rs:78-98)
@@ -439,9 +476,9 @@ class Array:
         if p in (L.AH_UTF8, L.AH_LARGE_UTF8):
             odt = np.int32 if p == L.AH_UTF8 else np.int64
             offs = _copy_dtoh(self.ctx, self.offsets.ptr, (self.length + 1) * np.dtype(odt).itemsize).view(odt)
-            total = int(offs[-1])
-            data = _copy_dtoh(self.ctx, self.values.ptr, total).tobytes() if total else b""
-            return [data[offs[i]:offs[i + 1]].decode() for i in range(self.length)]
+            base, total = int(offs[0]), int(offs[-1])
+            data = _copy_dtoh(self.ctx, self.values.ptr + base, total - base).tobytes() if total > base else b""
+            return [data[offs[i] - base:offs[i + 1] - base].decode() for i in range(self.length)]
         w = self.data_type.width
         raw = _copy_dtoh(self.ctx, self.values.ptr, self.length * w)
         return raw.view(self.data_type.np_dtype)

@@ -107,6 +107,12 @@ bool ah_type_is_float(ah_type t);
 
 void ah_out_init(ah_array_out* out);
 
+// strings.hip: byte ranges -> (offsets, bytes); take for Utf8 / LargeUtf8
+ah_status ah_ranges_to_strings(ah_context* ctx, bool large, const uint8_t* src, const void* starts,
+                               const void* ends, int64_t k, bool overflow_is_error, ah_array_out* out);
+ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_array_view* indices,
+                        ah_array_out* out);
+
 // count valid bits of a view's validity (or trust view->null_count >= 0)
 ah_status ah_resolve_null_count(ah_context* ctx, const ah_array_view* v, int64_t* nulls);
 

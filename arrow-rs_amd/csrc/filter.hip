@@ -487,12 +487,25 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
     return ah_fail(ctx, AH_INVALID_ARGUMENT,
                    "Filter predicate of length %lld is larger than target array of length %lld",
                    (long long)p->len, (long long)values->length);
-  const int width = ah_type_width(values->type);
+  const bool is_string = values->type == AH_UTF8 || values->type == AH_LARGE_UTF8;
+  const int width = is_string ? 0 : ah_type_width(values->type);
   if (width < 0)
     return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "filter not supported for type %s",
                    ah_type_name(values->type));
   out->type = values->type;
   const int64_t K = p->count;
+  if (is_string && !values->offsets)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "string array view without offsets");
+  if (is_string && (p->len == 0 || K == 0)) {  // new_empty_array: offsets = [0]
+    const size_t ow = values->type == AH_UTF8 ? 4 : 8;
+    void* offs = nullptr;
+    AH_TRY(ah_out_alloc(ctx, ow, &offs));
+    hipMemsetAsync(offs, 0, ow, ctx->stream);
+    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->offsets = offs;
+    out->offsets_bytes = (int64_t)ow;
+    return AH_OK;
+  }
   // IterationStrategy::default_strategy (filter.rs:346-364)
   if (p->len == 0 || K == 0) {  // None -> new_empty_array(data_type) :545
     out->length = 0;
@@ -503,6 +516,7 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
     out->values = const_cast<void*>(values->values);
     out->values_bit_offset = values->values_bit_offset;
     out->values_bytes = width ? K * width : 0;
+    out->offsets = const_cast<void*>(values->offsets);  // strings: the same offsets, first K+1 entries
     out->flags = AH_OUT_BORROWED;
     if (values->validity) {
       int64_t nulls = 0;
@@ -525,6 +539,45 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
   const bool has_valid = values->validity && in_nulls > 0;  // filter_nulls :512-517
   BitView vvalid = has_valid ? make_bitview(values->validity, values->validity_bit_offset)
                              : BitView{nullptr, 0};
+
+  if (is_string) {  // filter_bytes (filter.rs:890-928): ranges of the selected rows -> new offsets + bytes
+    const bool large = values->type == AH_LARGE_UTF8;
+    ah_array_view ov{};
+    ov.type = large ? AH_INT64 : AH_INT32;
+    ov.length = values->length;
+    ov.values = values->offsets;
+    ah_array_out s_out{}, e_out{};
+    AH_TRY(ah_filter_predicate_apply(ctx, p, &ov, &s_out));
+    ov.values = (const char*)values->offsets + (large ? 8 : 4);
+    ah_status st = ah_filter_predicate_apply(ctx, p, &ov, &e_out);
+    if (st == AH_OK)
+      st = ah_ranges_to_strings(ctx, large, (const uint8_t*)values->values, s_out.values, e_out.values, K, false, out);
+    ah_array_release(ctx, &s_out);
+    ah_array_release(ctx, &e_out);
+    if (st != AH_OK) {
+      ah_out_init(out);
+      return st;
+    }
+    out->type = values->type;
+    out->length = K;
+    if (has_valid) {
+      uint8_t* nb = nullptr;
+      size_t nbytes = 0;
+      int64_t nset = 0;
+      st = compact_bits(ctx, p, vvalid, &nb, &nbytes, &nset);
+      if (st != AH_OK) {
+        ah_array_release(ctx, out);
+        return st;
+      }
+      if (K - nset == 0) ah_out_free(ctx, nb, nbytes);
+      else {
+        out->validity = nb;
+        out->validity_bytes = (int64_t)nbytes;
+        out->null_count = K - nset;
+      }
+    }
+    return AH_OK;
+  }
 
   if (values->type == AH_BOOL) {  // filter_boolean (filter.rs:723-729)
     uint8_t* vb = nullptr;

@@ -1,0 +1,363 @@
+// strings.hip — Utf8 / LargeUtf8 columns through filter and take.
+//
+// Reference: filter_bytes (arrow-select/src/filter.rs:790-928: offsets rebuilt from the selected
+// rows' lengths, bytes copied row by row — null slots with a non-zero length are copied too) and
+// take_bytes (arrow-select/src/take.rs:499-627: output nulls get zero-length slots; i32 offsets
+// past i32::MAX => ArrowError::OffsetOverflowError(capacity)).
+//
+// MI355X design: both become "ranges -> strings":
+//   1. the selected rows' [start, end) byte ranges are produced by the EXISTING kernels —
+//      filter: the primitive scatter kernel run on offsets[0..n) and offsets[1..n+1);
+//      take:   take_ranges_kernel (index -> range, zero length under an output null);
+//   2. range_scan: lengths -> exclusive scan -> new offsets (1024-row blocks, u64 block totals,
+//      single-block scan of the totals, add-back) — the grand total sizes the byte buffer;
+//   3. gather_bytes_kernel: 256 output rows per workgroup; their destination offsets sit in LDS,
+//      every thread walks the tile's OUTPUT bytes (coalesced stores) and finds its source row with
+//      an 8-step binary search in LDS.
+#include "common.hpp"
+
+#include <type_traits>
+
+namespace {
+
+template <typename OFF>
+__global__ void __launch_bounds__(1024) range_scan_local_kernel(const OFF* starts, const OFF* ends, int64_t k,
+                                                                OFF* dst_off, unsigned long long* block_total) {
+  __shared__ unsigned long long s_wave[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 1024 + t;
+  unsigned long long v = i < k ? (unsigned long long)(ends[i] - starts[i]) : 0ull;
+  unsigned long long incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned long long u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned long long base = 0;
+  for (int w = 0; w < wave; ++w) base += s_wave[w];
+  if (i < k) dst_off[i] = (OFF)(base + incl - v);  // block-local; the block base is added by range_scan_add
+  if (t == 1023) block_total[blockIdx.x] = base + incl;
+}
+
+__global__ void __launch_bounds__(1024) range_scan_blocks_kernel(const unsigned long long* block_total,
+                                                                 int64_t nblocks, unsigned long long* block_base,
+                                                                 unsigned long long* total_out) {
+  __shared__ unsigned long long s_wave[16];
+  __shared__ unsigned long long s_carry;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < nblocks; b0 += 1024) {
+    unsigned long long v = (b0 + t < nblocks) ? block_total[b0 + t] : 0ull;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      unsigned long long u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long wbase = s_carry;
+    for (int w = 0; w < wave; ++w) wbase += s_wave[w];
+    if (b0 + t < nblocks) block_base[b0 + t] = wbase + incl - v;
+    __syncthreads();
+    if (t == 1023) s_carry = wbase + incl;
+    __syncthreads();
+  }
+  if (t == 0) *total_out = s_carry;
+}
+
+template <typename OFF>
+__global__ void __launch_bounds__(256) range_scan_add_kernel(OFF* dst_off, int64_t k,
+                                                             const unsigned long long* block_base,
+                                                             const unsigned long long* total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= k; i += (int64_t)gridDim.x * 256) {
+    if (i < k) dst_off[i] = (OFF)((unsigned long long)dst_off[i] + block_base[i >> 10]);
+    else dst_off[k] = (OFF)*total;
+  }
+}
+
+template <typename OFF>
+__global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t* src, const OFF* starts,
+                                                           const OFF* dst_off, int64_t k, uint8_t* dst) {
+  __shared__ unsigned long long s_dst[257];
+  __shared__ unsigned long long s_src[256];
+  const int t = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * 256;
+  const int rows = (int)((k - r0) < 256 ? (k - r0) : 256);
+  if (t < rows) {
+    s_dst[t] = (unsigned long long)dst_off[r0 + t];
+    s_src[t] = (unsigned long long)starts[r0 + t];
+  }
+  if (t == 0) s_dst[rows] = (unsigned long long)dst_off[r0 + rows];
+  __syncthreads();
+  const unsigned long long b0 = s_dst[0], b1 = s_dst[rows];
+  for (unsigned long long b = b0 + t; b < b1; b += 256) {
+    int lo = 0, hi = rows - 1;  // last row whose dst offset <= b (skips empty rows)
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (s_dst[mid] <= b) lo = mid;
+      else hi = mid - 1;
+    }
+    dst[b] = src[s_src[lo] + (b - s_dst[lo])];
+  }
+}
+
+// indices -> source ranges (take_bytes, take.rs:499-627).  Output nulls (when out_valid != nullptr)
+// produce empty ranges; a valid out-of-bounds index is reported through first_oob.
+template <typename OFF, typename IDX>
+__global__ void __launch_bounds__(256) take_ranges_kernel(const OFF* offsets, int64_t nvalues, const IDX* idx,
+                                                          int64_t n, const unsigned long long* out_valid,
+                                                          OFF* starts, OFF* ends, unsigned long long* first_oob) {
+  unsigned long long oob = ~0ull;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    OFF s = 0, e = 0;
+    bool live = !out_valid || ((out_valid[i >> 6] >> (i & 63)) & 1ull);
+    if (live) {
+      uint64_t ix;
+      IDX raw = idx[i];
+      if constexpr (sizeof(IDX) <= 2 && std::is_signed<IDX>::value) ix = (uint32_t)(int32_t)raw;
+      else if constexpr (sizeof(IDX) == 4) ix = (uint32_t)raw;
+      else ix = (uint64_t)raw;
+      if (ix >= (uint64_t)nvalues) {
+        if ((unsigned long long)i < oob) oob = (unsigned long long)i;
+      } else {
+        s = offsets[ix];
+        e = offsets[ix + 1];
+      }
+    }
+    starts[i] = s;
+    ends[i] = e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long other = __shfl_xor(oob, o, 64);
+    oob = other < oob ? other : oob;
+  }
+  if ((threadIdx.x & 63) == 0 && oob != ~0ull) atomicMin(first_oob, oob);
+}
+
+template <typename OFF>
+ah_status ranges_to_strings_t(ah_context* ctx, const uint8_t* src, const OFF* starts, const OFF* ends, int64_t k,
+                              bool overflow_is_error, void** out_offsets, size_t* offsets_bytes,
+                              void** out_data, size_t* data_bytes) {
+  const size_t ob = (size_t)(k + 1) * sizeof(OFF);
+  void* offs = nullptr;
+  AH_TRY(ah_out_alloc(ctx, ob, &offs));
+  const int64_t nblocks = ah_ceil_div(std::max<int64_t>(k, 1), 1024);
+  unsigned long long* scratch = nullptr;
+  ah_status st = ah_pool_alloc(ctx, (size_t)(2 * nblocks + 2) * 8, (void**)&scratch);
+  if (st != AH_OK) {
+    ah_out_free(ctx, offs, ob);
+    return st;
+  }
+  unsigned long long* block_total = scratch;
+  unsigned long long* block_base = scratch + nblocks;
+  unsigned long long* total = scratch + 2 * nblocks;
+  {
+    ah_prof_scope ps(ctx, "string_ranges_scan");
+    range_scan_local_kernel<OFF><<<(unsigned)nblocks, 1024, 0, ctx->stream>>>(starts, ends, k, (OFF*)offs, block_total);
+    range_scan_blocks_kernel<<<1, 1024, 0, ctx->stream>>>(block_total, nblocks, block_base, total);
+    int g = (int)std::min<int64_t>(ah_ceil_div(k + 1, 256), 4096);
+    range_scan_add_kernel<OFF><<<g, 256, 0, ctx->stream>>>((OFF*)offs, k, block_base, total);
+  }
+  hipError_t e = hipMemcpyAsync(ctx->pinned, total, 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  ah_pool_free(ctx, scratch);
+  if (e != hipSuccess) {
+    ah_out_free(ctx, offs, ob);
+    return ah_fail(ctx, AH_HIP_ERROR, "string offset scan failed: %s", hipGetErrorString(e));
+  }
+  const uint64_t total_bytes = ctx->pinned[0];
+  if (sizeof(OFF) == 4 && total_bytes > (uint64_t)INT32_MAX) {
+    ah_out_free(ctx, offs, ob);
+    // take_bytes: T::Offset::from_usize(capacity).ok_or_else(OffsetOverflowError(capacity)) (take.rs:521)
+    if (overflow_is_error) return ah_fail(ctx, AH_OFFSET_OVERFLOW_ERROR, "%llu", (unsigned long long)total_bytes);
+    return ah_fail(ctx, AH_PANIC, "illegal offset range");  // filter.rs:838
+  }
+  void* data = nullptr;
+  st = ah_out_alloc(ctx, (size_t)total_bytes, &data);
+  if (st != AH_OK) {
+    ah_out_free(ctx, offs, ob);
+    return st;
+  }
+  if (total_bytes) {
+    ah_prof_scope ps(ctx, "string_gather_bytes");
+    gather_bytes_kernel<OFF><<<(unsigned)ah_ceil_div(k, 256), 256, 0, ctx->stream>>>(src, starts, (const OFF*)offs, k,
+                                                                                   (uint8_t*)data);
+  }
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    ah_out_free(ctx, offs, ob);
+    ah_out_free(ctx, data, (size_t)total_bytes);
+    return ah_fail(ctx, AH_HIP_ERROR, "string gather failed: %s", hipGetErrorString(e));
+  }
+  *out_offsets = offs;
+  *offsets_bytes = ob;
+  *out_data = data;
+  *data_bytes = (size_t)total_bytes;
+  return AH_OK;
+}
+
+template <typename OFF>
+ah_status launch_take_ranges(ah_context* ctx, const ah_array_view* values, const ah_array_view* indices,
+                             const unsigned long long* out_valid, OFF* starts, OFF* ends,
+                             unsigned long long* first_oob) {
+  const int64_t n = indices->length;
+  int g = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(n, 256), 8192));
+  const OFF* off = (const OFF*)values->offsets;
+#define AH_TR(IDX) take_ranges_kernel<OFF, IDX><<<g, 256, 0, ctx->stream>>>(off, values->length, (const IDX*)indices->values, n, out_valid, starts, ends, first_oob)
+  switch (indices->type) {
+    case AH_INT8: AH_TR(int8_t); break;
+    case AH_UINT8: AH_TR(uint8_t); break;
+    case AH_INT16: AH_TR(int16_t); break;
+    case AH_UINT16: AH_TR(uint16_t); break;
+    case AH_INT32: AH_TR(int32_t); break;
+    case AH_UINT32: AH_TR(uint32_t); break;
+    case AH_INT64: AH_TR(int64_t); break;
+    case AH_UINT64: AH_TR(uint64_t); break;
+    default: return ah_fail(ctx, AH_INVALID_ARGUMENT, "Take only supported for integers, got %s", ah_type_name(indices->type));
+  }
+#undef AH_TR
+  return AH_OK;
+}
+
+}  // namespace
+
+// ranges [starts[i], ends[i]) of `src` (device arrays of the offset type) -> offsets + bytes
+ah_status ah_ranges_to_strings(ah_context* ctx, bool large, const uint8_t* src, const void* starts,
+                               const void* ends, int64_t k, bool overflow_is_error, ah_array_out* out) {
+  void* offs = nullptr;
+  void* data = nullptr;
+  size_t ob = 0, db = 0;
+  if (large)
+    AH_TRY(ranges_to_strings_t<int64_t>(ctx, src, (const int64_t*)starts, (const int64_t*)ends, k, overflow_is_error,
+                                        &offs, &ob, &data, &db));
+  else
+    AH_TRY(ranges_to_strings_t<int32_t>(ctx, src, (const int32_t*)starts, (const int32_t*)ends, k, overflow_is_error,
+                                        &offs, &ob, &data, &db));
+  out->offsets = offs;
+  out->offsets_bytes = (int64_t)ob;
+  out->values = data;
+  out->values_bytes = (int64_t)db;
+  return AH_OK;
+}
+
+// take_bytes (arrow-select/src/take.rs:499-627)
+ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_array_view* indices,
+                        ah_array_out* out) {
+  const bool large = values->type == AH_LARGE_UTF8;
+  const int64_t n = indices->length;
+  const size_t ow = large ? 8 : 4;
+  out->type = values->type;
+  if (n == 0) {  // take_impl :215-217 -> new_empty_array: offsets = [0]
+    void* offs = nullptr;
+    AH_TRY(ah_out_alloc(ctx, ow, &offs));
+    hipMemsetAsync(offs, 0, ow, ctx->stream);
+    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->offsets = offs;
+    out->offsets_bytes = (int64_t)ow;
+    return AH_OK;
+  }
+  if (!values->offsets) return ah_fail(ctx, AH_INVALID_ARGUMENT, "string array view without offsets");
+  // take_nulls (take.rs:418-430) through the Boolean take kernel on the validity bits
+  int64_t val_nulls = 0, idx_nulls = 0;
+  AH_TRY(ah_resolve_null_count(ctx, values, &val_nulls));
+  AH_TRY(ah_resolve_null_count(ctx, indices, &idx_nulls));
+  ah_array_out nb{};
+  uint8_t* out_valid = nullptr;
+  size_t vbytes = 0;
+  int64_t out_nulls = 0;
+  if (values->validity && val_nulls > 0) {
+    ah_array_view bits{};
+    bits.type = AH_BOOL;
+    bits.length = values->length;
+    bits.values = values->validity;
+    bits.values_bit_offset = values->validity_bit_offset;
+    ah_status st = ah_take(ctx, &bits, indices, 0, &nb);  // OOB -> "assertion failed: idx < self.bit_len"
+    if (st != AH_OK) return st;
+    int64_t set = 0;
+    st = ah_count_set_bits(ctx, (const uint8_t*)nb.values, 0, n, &set);
+    if (st != AH_OK) {
+      ah_array_release(ctx, &nb);
+      return st;
+    }
+    out_nulls = n - set;
+    if (out_nulls > 0) {  // keep the value bits as the output validity
+      out_valid = (uint8_t*)nb.values;
+      vbytes = (size_t)nb.values_bytes;
+      nb.values = nullptr;
+    }
+    ah_array_release(ctx, &nb);
+  } else if (indices->validity) {  // indices.nulls().cloned()
+    vbytes = ah_bitmap_bytes(n);
+    AH_TRY(ah_out_alloc(ctx, vbytes, (void**)&out_valid));
+    int64_t set = 0;
+    ah_status st = ah_bitmap_op(ctx, BM_COPY, make_bitview(indices->validity, indices->validity_bit_offset),
+                                BitView{nullptr, 0}, BitView{nullptr, 0}, n, (unsigned long long*)out_valid, &set);
+    if (st != AH_OK) {
+      ah_out_free(ctx, out_valid, vbytes);
+      return st;
+    }
+    out_nulls = n - set;
+  }
+  // ranges: only valid output slots are visited when the output has nulls (take.rs:553-577)
+  char* tmp = nullptr;
+  ah_status st = ah_pool_alloc(ctx, 2 * (size_t)n * ow + 16, (void**)&tmp);
+  if (st != AH_OK) {
+    ah_out_free(ctx, out_valid, vbytes);
+    return st;
+  }
+  void* starts = tmp;
+  void* ends = tmp + (((size_t)n * ow + 7) & ~(size_t)7);
+  unsigned long long* first_oob = nullptr;
+  st = ah_pool_alloc(ctx, 8, (void**)&first_oob);
+  if (st == AH_OK) {
+    hipMemsetAsync(first_oob, 0xFF, 8, ctx->stream);
+    const unsigned long long* ov = out_nulls > 0 ? (const unsigned long long*)out_valid : nullptr;
+    ah_prof_scope ps(ctx, "string_take_ranges");
+    st = large ? launch_take_ranges<int64_t>(ctx, values, indices, ov, (int64_t*)starts, (int64_t*)ends, first_oob)
+               : launch_take_ranges<int32_t>(ctx, values, indices, ov, (int32_t*)starts, (int32_t*)ends, first_oob);
+  }
+  if (st == AH_OK) {
+    hipError_t e = hipMemcpyAsync(ctx->pinned + 16, first_oob, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "take ranges failed: %s", hipGetErrorString(e));
+  }
+  ah_pool_free(ctx, first_oob);
+  if (st == AH_OK && ctx->pinned[16] != ~0ull) {
+    // `input_offsets[index]` / `input_offsets[index + 1]` bounds panic (take.rs:518-519): the slice
+    // has values.len()+1 entries, so index == len passes the first access and fails the second
+    int w = ah_type_width(indices->type);
+    uint64_t raw = 0;
+    hipMemcpy(&raw, (const char*)indices->values + (int64_t)ctx->pinned[16] * w, w, hipMemcpyDeviceToHost);
+    uint64_t ix;
+    switch (indices->type) {
+      case AH_INT8: ix = (uint32_t)(int32_t)(int8_t)raw; break;
+      case AH_INT16: ix = (uint32_t)(int32_t)(int16_t)raw; break;
+      case AH_INT32: ix = (uint32_t)raw; break;
+      default: ix = raw; break;
+    }
+    uint64_t bad = ix == (uint64_t)values->length ? ix + 1 : ix;
+    st = ah_fail(ctx, AH_PANIC, "index out of bounds: the len is %lld but the index is %llu",
+                 (long long)values->length + 1, (unsigned long long)bad);
+  }
+  if (st == AH_OK) st = ah_ranges_to_strings(ctx, large, (const uint8_t*)values->values, starts, ends, n, true, out);
+  ah_pool_free(ctx, tmp);
+  if (st != AH_OK) {
+    ah_out_free(ctx, out_valid, vbytes);
+    return st;
+  }
+  out->length = n;
+  if (out_valid && (out_nulls > 0 || !(values->validity && val_nulls > 0))) {
+    out->validity = out_valid;
+    out->validity_bytes = (int64_t)vbytes;
+    out->null_count = out_nulls;
+  } else {
+    ah_out_free(ctx, out_valid, vbytes);
+  }
+  return AH_OK;
+}

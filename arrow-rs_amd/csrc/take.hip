@@ -251,8 +251,9 @@ extern "C" ah_status ah_take(ah_context* ctx, const ah_array_view* values,
   if (!ah_type_is_integer(indices->type))
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "Take only supported for integers, got %s",
                    ah_type_name(indices->type));
+  const bool is_string = values->type == AH_UTF8 || values->type == AH_LARGE_UTF8;
   const int width = ah_type_width(values->type);
-  if (width < 0)
+  if (width < 0 && !is_string)
     return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "take not supported for type %s",
                    ah_type_name(values->type));
   const int64_t n = indices->length;
@@ -313,6 +314,12 @@ extern "C" ah_status ah_take(ah_context* ctx, const ah_array_view* values,
     }
   }
 
+  if (is_string) {  // take_bytes (take.rs:499)
+    ah_pool_free(ctx, flags);
+    ah_status st = ah_take_bytes(ctx, values, indices, out);
+    if (st != AH_OK) ah_out_init(out);
+    return st;
+  }
   if (n == 0) {  // take_impl :215-217
     ah_pool_free(ctx, flags);
     out->length = 0;

@@ -101,7 +101,7 @@ def parse():
     p.add_argument("--selectivity", type=float, default=0.1)
     p.add_argument("--valid", type=float, default=0.9)
     p.add_argument("--workload", default="filter_take",
-                   choices=["filter_take", "arith", "cmp", "cast", "cast_string", "coalesce"])
+                   choices=["filter_take", "arith", "cmp", "cast", "cast_string", "coalesce", "string_filter_take"])
     p.add_argument("--batch-rows", type=int, default=1 << 24, help="coalesce workload: rows per pushed batch")
     p.add_argument("--reassemble", default="auto", choices=["auto", "none", "allgatherv"])
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -321,6 +321,27 @@ def main():
 
         kernels = ["filter_count", "filter_scatter", "copy_rows"]
         dominant = "filter_scatter"
+    elif wl == "string_filter_take":
+        # LargeUtf8 column (the config-4 cast output) through filter and take
+        n = min(n, 1 << 27) if args.rows == 1_000_000_000 else n
+        src = gen_i64_column(A, ctx, n, 42, args.valid, row0, -10**6, 10**6)
+        scol = K.cast(K.cast(src, A.Float64), A.LargeUtf8)
+        pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
+        nidx = max(1, int(n * args.selectivity))
+        ib = ctx.alloc(nidx * 4)
+        ctx.check(ctx.lib.ah_gen_uniform_u32(ctx.handle, ib.ptr, nidx, 45, n, 0))
+        idx = mk_array(A, ctx, A.UInt32, nidx, ib)
+        state = {}
+
+        def step(_r):
+            f = K.filter(scol, pred)
+            t = K.take(scol, idx)
+            state["fbytes"], state["tbytes"], state["k"] = f.values.nbytes, t.values.nbytes, f.length
+            return f, t
+
+        kernels = ["filter_count", "filter_scatter", "string_ranges_scan", "string_gather_bytes", "string_take_ranges",
+                   "take_gather"]
+        dominant = "string_gather_bytes"
     elif wl in ("arith", "cmp"):
         a = gen_f64_column(A, ctx, n, 52, args.valid, row0)
         b = gen_f64_column(A, ctx, n, 62, args.valid, row0)
@@ -421,7 +442,14 @@ def main():
             dtype = "int64"
         else:
             per_row = {"arith": 24.375, "cmp": 16.5, "cast": 16.25}.get(wl)
-            if wl == "coalesce":
+            if wl == "string_filter_take":
+                k = state["k"]
+                # filter: offsets + validity + mask in, K+1 offsets + bytes out; take: idx + ranges in, offsets + bytes out
+                alg_bytes = (n + 1) * 8 + 2 * ((n + 7) // 8) + (k + 1) * 8 + 2 * state["fbytes"] + \
+                    idx.length * (4 + 16 + 8) + 2 * state["tbytes"]
+                dom_avg_ms = sum(prof[kk][0] for kk in kernels) / max(args.steps, 1)
+                dom_n = args.steps
+            elif wl == "coalesce":
                 k = state["out_rows"]
                 # two columns share one predicate: 2 x (values + validity) + mask in, 2 x (K values + K bits) out
                 alg_bytes = 2 * (n * 8 + (n + 7) // 8) + (n + 7) // 8 + 2 * (k * 8 + (k + 7) // 8)
@@ -438,6 +466,7 @@ def main():
                         "cmp": "configs[2]: lt Float64<Float64 with NullBuffers",
                         "cast": "configs[3]: cast Int64->Float64",
                         "cast_string": "configs[3]: cast Float64->LargeUtf8",
+                        "string_filter_take": "SURVEY 8f-3: filter + take on a LargeUtf8 column (cast output)",
                         "coalesce": f"SURVEY 8f-1: BatchCoalescer.push_batch_with_filter, Int64+Float64, "
                                     f"{args.batch_rows}-row batches"}[wl] + f", {n} rows per GPU"
             metric = f"{wl}_Mrows_per_s"

@@ -52,6 +52,7 @@ enum {
   AH_OFFSET_OVERFLOW = 6,     /* "byte array offset overflow" (a panic in the ref,
                                  arrow-array/src/builder/generic_bytes_builder.rs:86-87) */
   AH_NOT_YET_IMPLEMENTED = 7, /* ArrowError::NotYetImplemented */
+  AH_OFFSET_OVERFLOW_ERROR = 8, /* ArrowError::OffsetOverflowError(n): message is the number */
   AH_PANIC = 100,             /* the reference would panic!(); message = panic text */
   AH_HIP_ERROR = 101,         /* runtime failure (no reference analogue) */
   AH_OUT_OF_MEMORY = 102
@@ -69,8 +70,8 @@ enum {
   AH_FLOAT32 = 10, AH_FLOAT64 = 11,
   AH_FIXED16 = 12, /* 16-byte natives: i128 / Decimal128 / IntervalMonthDayNano */
   AH_FIXED32 = 13, /* 32-byte natives: i256 / Decimal256 */
-  AH_UTF8 = 14,       /* i32 offsets (output of cast only) */
-  AH_LARGE_UTF8 = 15, /* i64 offsets (output of cast only) */
+  AH_UTF8 = 14,       /* i32 offsets: output of cast; input/output of filter, take */
+  AH_LARGE_UTF8 = 15, /* i64 offsets */
   AH_FLOAT16 = 16     /* filter/take/concat only (bit copy) */
 };
 
@@ -87,6 +88,8 @@ typedef struct ah_array_view {
   int64_t values_bit_offset;   /* AH_BOOL only */
   const uint8_t* validity;     /* NULL = no nulls */
   int64_t validity_bit_offset;
+  const void* offsets;         /* AH_UTF8 (i32) / AH_LARGE_UTF8 (i64) only: length+1 offsets,
+                                  pointer already advanced by the slice offset; `values` = byte data */
 } ah_array_view;
 
 enum { AH_OUT_BORROWED = 1 /* buffers alias the input (zero-copy slice) */ };

@@ -49,6 +49,7 @@ class ArrowError : public std::runtime_error {
       case AH_DIVIDE_BY_ZERO: return "Divide by zero error";
       case AH_CAST_ERROR: return "Cast error: ";
       case AH_NOT_YET_IMPLEMENTED: return "Not yet implemented: ";
+      case AH_OFFSET_OVERFLOW_ERROR: return "Offset overflow error: ";
       default: return "";
     }
   }
@@ -95,6 +96,7 @@ class Array {
     view_.values_bit_offset = out.values_bit_offset;
     view_.validity = out.validity;
     view_.validity_bit_offset = out.validity_bit_offset;
+    view_.offsets = out.offsets;
   }
   // wrap device memory the caller owns (kept alive by the caller)
   Array(std::shared_ptr<Context> ctx, const ah_array_view& v) : ctx_(std::move(ctx)), view_(v) {

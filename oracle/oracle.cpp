@@ -17,6 +17,7 @@
 #include <limits>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -379,6 +380,47 @@ void filter_bits(const uint8_t* src, int64_t src_off, const Predicate& p, uint8_
   }
 }
 
+// filter_bytes (filter.rs:890-928): offsets from the selected rows' lengths (extend_offsets_idx /
+// extend_offsets_slices), then the bytes (extend_idx / extend_slices); null slots are copied too
+template <typename OFF>
+void filter_bytes(const orc_view* values, const Predicate& p, orc_out* out) {
+  const OFF* so = (const OFF*)values->offsets;
+  const uint8_t* sv = (const uint8_t*)values->values;
+  OFF* d_off = (OFF*)xalloc((size_t)(p.count + 1) * sizeof(OFF));
+  OFF cur = 0;
+  int64_t j = 0;
+  d_off[0] = 0;
+  std::vector<int64_t> rows;
+  rows.reserve((size_t)p.count);
+  if (p.strategy == S_SLICES) {
+    BitSliceIterator it(p.bits, p.off, p.len);
+    int64_t s, e;
+    while (it.next(&s, &e)) for (int64_t i = s; i < e; ++i) rows.push_back(i);
+  } else {
+    BitIndexIterator it(p.bits, p.off, p.len);
+    int64_t idx = 0;
+    for (int64_t i = 0; i < p.count; ++i) {
+      it.next(&idx);
+      rows.push_back(idx);
+    }
+  }
+  for (int64_t r : rows) {
+    cur += so[r + 1] - so[r];
+    d_off[++j] = cur;
+  }
+  uint8_t* dv = (uint8_t*)xalloc((size_t)cur);
+  size_t w = 0;
+  for (int64_t r : rows) {
+    size_t n = (size_t)(so[r + 1] - so[r]);
+    memcpy(dv + w, sv + so[r], n);
+    w += n;
+  }
+  out->offsets = d_off;
+  out->offsets_bytes = (p.count + 1) * (int64_t)sizeof(OFF);
+  out->values = dv;
+  out->values_bytes = (int64_t)cur;
+}
+
 // FilterPredicate::filter_nulls (filter.rs:512-532)
 void filter_nulls(const orc_view* values, const Predicate& p, orc_out* out) {
   if (!values->validity) return;
@@ -405,13 +447,18 @@ int32_t filter_impl(const orc_view* values, const orc_view* pred, orc_out* out) 
     return fail(ORC_INVALID_ARGUMENT,
                 "Filter predicate of length %lld is larger than target array of length %lld",
                 (long long)pred->length, (long long)values->length);
-  int width = type_width(values->type);
+  const bool is_string = values->type == ORC_UTF8 || values->type == ORC_LARGE_UTF8;
+  int width = is_string ? 0 : type_width(values->type);
   if (width < 0) return fail(ORC_NOT_YET_IMPLEMENTED, "filter not supported for type %s", type_name(values->type));
   Predicate p;
   build_predicate(pred, &p);
   out->type = values->type;
   if (p.strategy == S_NONE) {  // :545 new_empty_array
     out->length = 0;
+    if (is_string) {
+      out->offsets_bytes = values->type == ORC_UTF8 ? 4 : 8;
+      out->offsets = xalloc((size_t)out->offsets_bytes);
+    }
     return ORC_OK;
   }
   if (p.strategy == S_ALL) {  // :546 values.slice(0, count)
@@ -419,6 +466,7 @@ int32_t filter_impl(const orc_view* values, const orc_view* pred, orc_out* out) 
     out->values = const_cast<void*>(values->values);
     out->values_bit_offset = values->values_bit_offset;
     out->values_bytes = width ? p.count * width : 0;
+    out->offsets = const_cast<void*>(values->offsets);
     out->flags = 1;
     if (values->validity) {
       out->validity = const_cast<uint8_t*>(values->validity);
@@ -428,7 +476,10 @@ int32_t filter_impl(const orc_view* values, const orc_view* pred, orc_out* out) 
     return ORC_OK;
   }
   out->length = p.count;
-  if (values->type == ORC_BOOL) {  // filter_boolean (:723-729)
+  if (is_string) {
+    if (values->type == ORC_UTF8) filter_bytes<int32_t>(values, p, out);
+    else filter_bytes<int64_t>(values, p, out);
+  } else if (values->type == ORC_BOOL) {  // filter_boolean (:723-729)
     size_t bytes = bitmap_bytes(p.count);
     out->values = xalloc(bytes);
     out->values_bytes = (int64_t)bytes;
@@ -545,6 +596,83 @@ int32_t check_bounds(int64_t len, const I* idx, int64_t n, const uint8_t* ivalid
   return ORC_OK;
 }
 
+// take_bytes (take.rs:499-627)
+template <typename OFF, typename I>
+int32_t take_bytes(const orc_view* values, const orc_view* indices, orc_out* out) {
+  const I* idx = (const I*)indices->values;
+  const int64_t n = indices->length;
+  const int64_t idx_nulls = resolve_nulls(indices);
+  const uint8_t* iv = indices->validity;
+  const int64_t ivo = indices->validity_bit_offset;
+  const OFF* so = (const OFF*)values->offsets;
+  const uint8_t* sv = (const uint8_t*)values->values;
+  TakePanic panic;
+  // take_nulls (take.rs:418-430)
+  uint8_t* ob = nullptr;
+  size_t bbytes = bitmap_bytes(n);
+  int64_t out_nulls = 0;
+  if (values->validity && resolve_nulls(values) > 0) {
+    ob = (uint8_t*)xalloc(bbytes);
+    take_bits<I>(values->validity, values->validity_bit_offset, values->length, idx, n, iv, ivo, idx_nulls, ob, &panic);
+    if (panic.hit) {
+      free(ob);
+      return fail(ORC_PANIC, "%s", panic.msg.c_str());
+    }
+    out_nulls = n - count_set_bits(ob, 0, n);
+    if (out_nulls == 0) {
+      free(ob);
+      ob = nullptr;
+    }
+  } else if (iv) {
+    ob = (uint8_t*)xalloc(bbytes);
+    copy_bits(ob, 0, iv, ivo, n);
+    out_nulls = idx_nulls;
+  }
+  OFF* d_off = (OFF*)xalloc((size_t)(n + 1) * sizeof(OFF));
+  uint64_t capacity = 0;
+  std::vector<std::pair<int64_t, int64_t>> ranges;
+  const int64_t off_len = values->length + 1;  // input_offsets.len()
+  for (int64_t i = 0; i < n; ++i) {
+    bool live = out_nulls == 0 || get_bit(ob, i);  // nullable path only visits valid output slots
+    if (live) {
+      uint64_t ix = to_index(idx[i]);
+      // input_offsets[index] then input_offsets[index + 1] (bounds-checked slice indexing)
+      uint64_t bad = ix >= (uint64_t)off_len ? ix : (ix + 1 >= (uint64_t)off_len ? ix + 1 : ~0ull);
+      if (bad != ~0ull) {
+        free(ob);
+        free(d_off);
+        return fail(ORC_PANIC, "index out of bounds: the len is %lld but the index is %llu", (long long)off_len,
+                    (unsigned long long)bad);
+      }
+      capacity += (uint64_t)(so[ix + 1] - so[ix]);
+      if (sizeof(OFF) == 4 && capacity > (uint64_t)INT32_MAX) {
+        free(ob);
+        free(d_off);
+        return fail(ORC_OFFSET_OVERFLOW_ERROR, "%llu", (unsigned long long)capacity);
+      }
+      ranges.emplace_back((int64_t)so[ix], (int64_t)so[ix + 1]);
+    }
+    d_off[i + 1] = (OFF)capacity;
+  }
+  uint8_t* dv = (uint8_t*)xalloc((size_t)capacity);
+  size_t w = 0;
+  for (auto& r : ranges) {
+    memcpy(dv + w, sv + r.first, (size_t)(r.second - r.first));
+    w += (size_t)(r.second - r.first);
+  }
+  out->length = n;
+  out->offsets = d_off;
+  out->offsets_bytes = (n + 1) * (int64_t)sizeof(OFF);
+  out->values = dv;
+  out->values_bytes = (int64_t)capacity;
+  if (ob) {
+    out->validity = ob;
+    out->validity_bytes = (int64_t)bbytes;
+    out->null_count = out_nulls;
+  }
+  return ORC_OK;
+}
+
 template <typename I>
 int32_t take_typed(const orc_view* values, const orc_view* indices, int32_t cb, orc_out* out) {
   const I* idx = (const I*)indices->values;
@@ -557,10 +685,18 @@ int32_t take_typed(const orc_view* values, const orc_view* indices, int32_t cb, 
     if (st != ORC_OK) return st;
   }
   out->type = values->type;
+  const bool is_string = values->type == ORC_UTF8 || values->type == ORC_LARGE_UTF8;
   if (n == 0) {  // take_impl :215-217
     out->length = 0;
+    if (is_string) {
+      out->offsets_bytes = values->type == ORC_UTF8 ? 4 : 8;
+      out->offsets = xalloc((size_t)out->offsets_bytes);
+    }
     return ORC_OK;
   }
+  if (is_string)
+    return values->type == ORC_UTF8 ? take_bytes<int32_t, I>(values, indices, out)
+                                    : take_bytes<int64_t, I>(values, indices, out);
   int width = type_width(values->type);
   TakePanic panic;
   size_t vbytes = width ? (size_t)n * width : bitmap_bytes(n);
@@ -1220,7 +1356,7 @@ int32_t orc_filter(const orc_view* values, const orc_view* predicate, orc_out* o
 
 int32_t orc_take(const orc_view* values, const orc_view* indices, int32_t cb, orc_out* out) {
   out_init(out);
-  if (type_width(values->type) < 0)
+  if (type_width(values->type) < 0 && values->type != ORC_UTF8 && values->type != ORC_LARGE_UTF8)
     return fail(ORC_NOT_YET_IMPLEMENTED, "take not supported for type %s", type_name(values->type));
   switch (indices->type) {  // downcast_integer_array! (take.rs:95-105)
     case ORC_INT8: return take_typed<int8_t>(values, indices, cb, out);

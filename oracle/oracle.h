@@ -33,6 +33,7 @@ extern "C" {
 enum {
   ORC_OK = 0, ORC_INVALID_ARGUMENT = 1, ORC_COMPUTE_ERROR = 2, ORC_ARITHMETIC_OVERFLOW = 3,
   ORC_DIVIDE_BY_ZERO = 4, ORC_CAST_ERROR = 5, ORC_OFFSET_OVERFLOW = 6, ORC_NOT_YET_IMPLEMENTED = 7,
+  ORC_OFFSET_OVERFLOW_ERROR = 8,
   ORC_PANIC = 100
 };
 enum {
@@ -49,6 +50,7 @@ typedef struct orc_view {
   int64_t values_bit_offset;
   const uint8_t* validity;
   int64_t validity_bit_offset;
+  const void* offsets; /* ORC_UTF8 / ORC_LARGE_UTF8: length+1 offsets; values = byte data */
 } orc_view;
 
 typedef struct orc_out {

@@ -78,7 +78,24 @@ filter_cases.append(dict(name="test_slices", source="arrow-select/src/filter.rs:
                          slices=[[0, 10], [40, 60], [77, 81]],
                          sliced=dict(offset=7, length=len(m) - 10, slices=[[0, 3], [33, 53], [70, 71]])))
 
+filter_cases.append(dict(name="test_filter_string_array_simple", source="arrow-select/src/filter.rs:1233",
+                         values=arr("Utf8", ["hello", " ", "world", "!"]), predicate=arr("Boolean", [T, F, T, F]),
+                         expected=arr("Utf8", ["hello", "world"])))
+filter_cases.append(dict(name="test_filter_string_array_with_null", source="arrow-select/src/filter.rs:1254",
+                         values=arr("Utf8", ["hello", N, "world", N]), predicate=arr("Boolean", [T, F, F, T]),
+                         expected=arr("Utf8", ["hello", N])))
+filter_cases.append(dict(name="filter_large_string_with_null", source="arrow-select/src/filter.rs:1254 (LargeUtf8 arm :558)",
+                         values=arr("LargeUtf8", ["hello", N, "world", N]), predicate=arr("Boolean", [T, F, F, T]),
+                         expected=arr("LargeUtf8", ["hello", N])))
+
 take_cases = []
+for st in ["Utf8", "LargeUtf8"]:
+    take_cases.append(dict(name=f"test_take_string_{st}", source="arrow-select/src/take.rs:1702-1733",
+                           values=arr(st, ["one", N, "three", "four", "five"]), indices=arr("UInt32", [3, N, 1, 3, 4]),
+                           expected=arr(st, ["four", N, N, "four", "five"])))
+take_cases.append(dict(name="test_take_slice_string", source="arrow-select/src/take.rs:1736-1743",
+                       values=arr("Utf8", ["hello", N, "world", N, "hi"]),
+                       indices=arr("Int32", [0, 1, N, 0, 2], [1, 4]), expected=arr("Utf8", [N, N, "hello", "world"])))
 take_cases.append(dict(name="non_null_indices", source="arrow-select/src/take.rs:1295",
                        values=arr("Int8", [N, 3, 5, 2, 3, N]), indices=arr("UInt32", [0, 5, 3, 1, 4, 2]),
                        expected=arr("Int8", [N, N, 2, 3, 3, 5])))

@@ -73,6 +73,8 @@ class HostArray:
         return cls(data_type, vals, valid)
 
     def to_device(self, ctx=None, bit_offset=0):
+        if isinstance(self.values, list):
+            return A.Array.from_strings(self.values, self.valid, self.data_type, ctx, bit_offset=bit_offset)
         return A.Array.from_numpy(self.values, self.valid, self.data_type, ctx, bit_offset=bit_offset)
 
     @classmethod
@@ -90,7 +92,18 @@ class _Held:
         v.length = len(host)
         v.null_count = -1
         self.bufs = []
-        if t == L.AH_BOOL:
+        if t in (L.AH_UTF8, L.AH_LARGE_UTF8):
+            odt = np.int32 if t == L.AH_UTF8 else np.int64
+            enc = [x.encode() if isinstance(x, str) else bytes(x) for x in host.values]
+            # elem_offset leading rows emulate a sliced array (offsets pointer advanced, first offset > 0)
+            pad = [b"zz"] * elem_offset
+            offs = np.zeros(len(enc) + len(pad) + 1, dtype=odt)
+            offs[1:] = np.cumsum([len(b) for b in pad + enc]) if (pad or enc) else 0
+            data = np.frombuffer(b"".join(pad + enc) + b"\0", dtype=np.uint8).copy()
+            self.bufs += [offs, data]
+            v.values = data.ctypes.data
+            v.offsets = offs.ctypes.data + elem_offset * offs.dtype.itemsize
+        elif t == L.AH_BOOL:
             packed = A.pack_bits(host.values, bit_offset)
             self.bufs.append(packed)
             v.values = packed.ctypes.data
@@ -160,9 +173,10 @@ class Oracle:
         elif t in (L.AH_UTF8, L.AH_LARGE_UTF8):
             odt = np.int32 if t == L.AH_UTF8 else np.int64
             offs = np.ctypeslib.as_array(C.cast(out.offsets, C.POINTER(C.c_uint8)),
-                                         shape=(out.offsets_bytes,)).view(odt).copy()
-            data = C.string_at(out.values, out.values_bytes) if out.values_bytes else b""
-            vals = [data[offs[i]:offs[i + 1]].decode() for i in range(n)]
+                                         shape=((n + 1) * np.dtype(odt).itemsize,)).view(odt).copy()
+            base, end = int(offs[0]), int(offs[-1])
+            data = C.string_at(out.values + base, end - base) if end > base else b""
+            vals = [data[offs[i] - base:offs[i + 1] - base].decode() for i in range(n)]
         else:
             w = data_type.width
             raw = np.ctypeslib.as_array(C.cast(out.values, C.POINTER(C.c_uint8)), shape=(n * w,))
@@ -181,8 +195,8 @@ class Oracle:
             self._raise(st)
         return self._collect(out, values.data_type)
 
-    def take(self, values, indices, check_bounds=False, bit_offset=0):
-        hv, hi = _Held(values, bit_offset), _Held(indices, bit_offset)
+    def take(self, values, indices, check_bounds=False, bit_offset=0, elem_offset=0):
+        hv, hi = _Held(values, bit_offset, elem_offset), _Held(indices, bit_offset)
         out = Out()
         st = self.lib.orc_take(C.byref(hv.view), C.byref(hi.view), int(check_bounds), C.byref(out))
         if st:

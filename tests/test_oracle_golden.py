@@ -40,6 +40,9 @@ def test_filter_golden(oracle, case, bit_offset):
         return expect_err(case, lambda: oracle.filter(v, p, bit_offset))
     got = oracle.filter(v, p, bit_offset, elem_offset=1 if bit_offset else 0)
     assert_logical_eq(got, golden_array(case["expected"]), case["name"])
+    if isinstance(v.values, list):  # string columns: also against the pure-Python model
+        keep = p.values & (p.valid if p.valid is not None else True)
+        assert got.to_pylist() == [x for x, k in zip(v.to_pylist()[:len(p)], keep) if k]
     if "expected_null_count" in case:
         assert got.null_count == case["expected_null_count"]
 
@@ -359,3 +362,46 @@ def test_boolean_golden(oracle, case, bit_offset):
     assert_logical_eq(got, golden_array(case["expected"]), case["name"])
     if case.get("no_null_buffer"):
         assert got.valid is None
+
+
+def _rand_strings(rng, n, maxlen=12):
+    alphabet = list("abcdefghijklmnopqrstuvwxyz0123456789 é漢")
+    return ["".join(rng.choice(alphabet, int(rng.integers(0, maxlen)))) for _ in range(n)]
+
+
+def test_fuzz_string_filter_take_vs_model(oracle):
+    """filter_bytes / take_bytes (filter.rs:890-928, take.rs:499-627) against list comprehensions;
+    null slots keep their bytes through filter; take gives null outputs zero-length slots."""
+    rng = np.random.default_rng(17)
+    for it in range(40):
+        n = int(rng.integers(1, 300))
+        dt = A.Utf8 if it % 2 else A.LargeUtf8
+        vals = _rand_strings(rng, n)
+        valid = (rng.random(n) < 0.8) if it % 3 else None
+        h = HostArray(dt, vals, valid)
+        m = HostArray(A.Boolean, rng.random(n) < rng.random(), (rng.random(n) < 0.9) if it % 4 == 0 else None)
+        got = oracle.filter(h, m, bit_offset=it % 5, elem_offset=it % 3)
+        keep = m.values & (m.valid if m.valid is not None else True)
+        exp_vals = [v for v, k in zip(vals, keep) if k]
+        exp_valid = valid[keep] if valid is not None else None
+        if exp_valid is not None and exp_valid.all():
+            exp_valid = None
+        if keep.all():
+            exp_valid = valid
+        assert_logical_eq(got, HostArray(dt, exp_vals, exp_valid), f"filter {it}")
+        assert got.values == exp_vals or got.valid is not None  # bytes of null slots are copied as well
+        k = int(rng.integers(0, 200))
+        idx = rng.integers(0, n, k).astype(np.uint32)
+        ivalid = (rng.random(k) < 0.85) if it % 2 == 0 else None
+        got = oracle.take(h, HostArray(A.UInt32, idx, ivalid), elem_offset=it % 2)
+        ev = [(valid is None or valid[j]) and (ivalid is None or ivalid[i]) for i, j in enumerate(idx)]
+        exp = [vals[j] if ok else None for ok, j in zip(ev, idx)]
+        assert got.to_pylist() == exp, f"take {it}"
+        if got.valid is not None and k:
+            assert all(s == "" for s, ok in zip(got.values, got.valid) if not ok) or got.null_count == 0
+    with pytest.raises(A.Panic) as ei:
+        oracle.take(HostArray(A.Utf8, ["a", "b"]), HostArray(A.UInt32, np.array([2], dtype=np.uint32)))
+    assert str(ei.value) == "index out of bounds: the len is 3 but the index is 3"
+    with pytest.raises(A.Panic) as ei:
+        oracle.take(HostArray(A.Utf8, ["a", "b"]), HostArray(A.UInt32, np.array([7], dtype=np.uint32)))
+    assert str(ei.value) == "index out of bounds: the len is 3 but the index is 7"
