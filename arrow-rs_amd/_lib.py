@@ -101,6 +101,7 @@ SIGNATURES = {
     "ah_compare": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
     "ah_boolean_binary": (C.c_int32, [_P, C.c_int32, _VIEW, _VIEW, _OUT]),
     "ah_boolean_unary": (C.c_int32, [_P, C.c_int32, _VIEW, _OUT]),
+    "ah_nullif": (C.c_int32, [_P, _VIEW, _VIEW, _OUT]),
     "ah_cast": (C.c_int32, [_P, _VIEW, C.c_int32, C.c_int32, _OUT]),
     "ah_can_cast_types": (C.c_int32, [C.c_int32, C.c_int32]),
     "ah_concat": (C.c_int32, [_P, C.c_int32, _VIEW, _OUT]),

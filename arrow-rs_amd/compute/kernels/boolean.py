@@ -72,3 +72,12 @@ def _and_validity(filter_array):
     return and_(Array(filter_array.ctx, Boolean, filter_array.length, filter_array.values,
                       filter_array.values_bit_offset),
                 is_not_null(filter_array))
+
+
+def nullif(left, right):
+    """``arrow_select::nullif::nullif`` (arrow-select/src/nullif.rs:60): zero-copy values, new nulls."""
+    ctx = left.ctx
+    out = L.ArrayOut()
+    lv, rv = left.view(), right.view()
+    ctx.check(ctx.lib.ah_nullif(ctx.handle, C.byref(lv), C.byref(rv), C.byref(out)))
+    return Array._from_out(ctx, out, left.data_type, keepalive=(left,))

@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(256) bitmap_op_kernel(int op, BitView a, BitVi
       case BM_OR: r = x | bv_fetch64(b, s, len); break;
       case BM_ANDNOT: r = x & ~bv_fetch64(b, s, len); break;
       case BM_OR_NOTB: r = x | ~bv_fetch64(b, s, len); break;
+      case BM_NULLIF: r = x & ~(bv_fetch64(b, s, len) & bv_fetch64(c, s, len)); break;
       case BM_KLEENE_AND_NULLS: {
         uint64_t y = bv_fetch64(b, s, len), z = bv_fetch64(c, s, len), w4 = bv_fetch64(d, s, len);
         r = (x | (z & ~w4)) & (z | (x & ~y));

@@ -126,3 +126,48 @@ extern "C" ah_status ah_boolean_unary(ah_context* ctx, ah_boolean_op op, const a
   }
   return AH_OK;
 }
+
+// arrow_select::nullif::nullif (arrow-select/src/nullif.rs:60-121): the values (and offsets) are
+// shared with `left` (zero copy, AH_OUT_BORROWED_VALUES); only the null buffer is new:
+// validity = left_validity & !(right_values & right_validity), always present.
+extern "C" ah_status ah_nullif(ah_context* ctx, const ah_array_view* left, const ah_array_view* right,
+                               ah_array_out* out) {
+  if (!ctx || !left || !right || !out) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  hipSetDevice(ctx->device);
+  if (right->type != AH_BOOL)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "nullif needs a Boolean right-hand side, got %s", ah_type_name(right->type));
+  if (left->length != right->length)
+    return ah_fail(ctx, AH_COMPUTE_ERROR, "Cannot perform comparison operation on arrays of different length");
+  const int64_t len = left->length;
+  out->type = left->type;
+  out->length = len;
+  out->values = const_cast<void*>(left->values);
+  out->values_bit_offset = left->values_bit_offset;
+  out->offsets = const_cast<void*>(left->offsets);
+  out->flags = AH_OUT_BORROWED_VALUES;
+  if (len == 0) {  // make_array(left_data) unchanged
+    out->flags = AH_OUT_BORROWED;
+    out->validity = const_cast<uint8_t*>(left->validity);
+    out->validity_bit_offset = left->validity_bit_offset;
+    return AH_OK;
+  }
+  const size_t bytes = ah_bitmap_bytes(len);
+  unsigned long long* nb = nullptr;
+  AH_TRY(ah_out_alloc(ctx, bytes, (void**)&nb));
+  const BitView none{nullptr, 0};
+  int64_t set = 0;
+  ah_status st = ah_bitmap_op(ctx, BM_NULLIF, left->validity ? make_bitview(left->validity, left->validity_bit_offset) : none,
+                              make_bitview(right->values, right->values_bit_offset),
+                              right->validity ? make_bitview(right->validity, right->validity_bit_offset) : none,
+                              len, nb, &set);
+  if (st != AH_OK) {
+    ah_out_free(ctx, nb, bytes);
+    ah_out_init(out);
+    return st;
+  }
+  out->validity = (uint8_t*)nb;
+  out->validity_bytes = (int64_t)bytes;
+  out->null_count = len - set;
+  return AH_OK;
+}

@@ -212,6 +212,7 @@ enum ah_bitmap_opcode {
   BM_OR_NOTB = 8,         // a | ~b                    boolean.rs:88 (and_kleene, one nullable side)
   BM_KLEENE_AND_NULLS = 9,   // (a | (c & ~d)) & (c | (a & ~b))   boolean.rs:121
   BM_KLEENE_OR_NULLS = 10,   // (a | (c & d)) & (c | (a & b))     boolean.rs:213
+  BM_NULLIF = 11,            // a & ~(b & c)                      nullif.rs:54-56
 };
 // out_words[w] = op(a, b, c) over `len` bits (each input a BitView with its own
 // offset; words == nullptr reads as all-ones); bits past len are zeroed.

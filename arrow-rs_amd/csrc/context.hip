@@ -184,9 +184,11 @@ extern "C" const char* ah_version(void) { return "arrow_hip 0.1.0 (gfx950)"; }
 extern "C" void ah_array_release(ah_context* ctx, ah_array_out* out) {
   if (!out) return;
   if (!(out->flags & AH_OUT_BORROWED)) {
-    ah_out_free(ctx, out->values, (size_t)out->values_bytes);
+    if (!(out->flags & AH_OUT_BORROWED_VALUES)) {
+      ah_out_free(ctx, out->values, (size_t)out->values_bytes);
+      ah_out_free(ctx, out->offsets, (size_t)out->offsets_bytes);
+    }
     ah_out_free(ctx, out->validity, (size_t)out->validity_bytes);
-    ah_out_free(ctx, out->offsets, (size_t)out->offsets_bytes);
   }
   ah_out_init(out);
 }

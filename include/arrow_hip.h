@@ -92,7 +92,10 @@ typedef struct ah_array_view {
                                   pointer already advanced by the slice offset; `values` = byte data */
 } ah_array_view;
 
-enum { AH_OUT_BORROWED = 1 /* buffers alias the input (zero-copy slice) */ };
+enum {
+  AH_OUT_BORROWED = 1,        /* every buffer aliases the input (zero-copy slice) */
+  AH_OUT_BORROWED_VALUES = 2  /* values/offsets alias the input, validity is owned (nullif) */
+};
 
 /* Owned result.  Freshly produced bitmaps start at bit offset 0. */
 typedef struct ah_array_out {
@@ -230,6 +233,11 @@ AH_API ah_status ah_boolean_binary(ah_context* ctx, ah_boolean_op op, const ah_a
  * never carries a null buffer). */
 AH_API ah_status ah_boolean_unary(ah_context* ctx, ah_boolean_op op, const ah_array_view* values,
                                   ah_array_out* out);
+
+/* arrow_select::nullif::nullif (arrow-select/src/nullif.rs:60): values shared with `left`
+ * (AH_OUT_BORROWED_VALUES), new validity = left_validity & !(right_values & right_validity). */
+AH_API ah_status ah_nullif(ah_context* ctx, const ah_array_view* left, const ah_array_view* right,
+                           ah_array_out* out);
 
 /* ------------------------------------------------------------------ cast */
 /* arrow_cast::cast_with_options (arrow-cast/src/cast/mod.rs:790), restricted to

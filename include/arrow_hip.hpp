@@ -273,6 +273,11 @@ inline ArrayRef or_kleene(const ArrayRef& l, const ArrayRef& r) { return boolean
 inline ArrayRef not_(const ArrayRef& v) { return boolean_unary(AH_BOOL_NOT, v); }
 inline ArrayRef is_null(const ArrayRef& v) { return boolean_unary(AH_BOOL_IS_NULL, v); }
 inline ArrayRef is_not_null(const ArrayRef& v) { return boolean_unary(AH_BOOL_IS_NOT_NULL, v); }
+inline ArrayRef nullif(const ArrayRef& l, const ArrayRef& r) {  // arrow-select/src/nullif.rs:60
+  ah_array_out out;
+  l->context()->check(ah_nullif(l->context()->handle(), &l->view(), &r->view(), &out));
+  return wrap(l, out, {l});
+}
 
 // ---- cast (arrow-cast/src/cast/mod.rs)
 struct CastOptions {  // cast/mod.rs:95-111

@@ -1318,9 +1318,11 @@ const char* orc_last_error(void) { return g_err.c_str(); }
 void orc_release(orc_out* out) {
   if (!out) return;
   if (!(out->flags & 1)) {
-    free(out->values);
+    if (!(out->flags & 2)) {
+      free(out->values);
+      free(out->offsets);
+    }
     free(out->validity);
-    free(out->offsets);
   }
   memset(out, 0, sizeof *out);
 }
@@ -1599,6 +1601,37 @@ int32_t orc_boolean_unary(int32_t op, const orc_view* v, orc_out* out) {
     out->validity_bytes = (int64_t)bytes;
     out->null_count = len - count_set_bits(out->validity, 0, len);
   }
+  return ORC_OK;
+}
+
+// nullif (arrow-select/src/nullif.rs:60-121); flags 2 = values/offsets borrowed, validity owned
+int32_t orc_nullif(const orc_view* l, const orc_view* r, orc_out* out) {
+  out_init(out);
+  if (l->length != r->length)
+    return fail(ORC_COMPUTE_ERROR, "Cannot perform comparison operation on arrays of different length");
+  int64_t len = l->length;
+  out->type = l->type;
+  out->length = len;
+  out->values = const_cast<void*>(l->values);
+  out->values_bit_offset = l->values_bit_offset;
+  out->offsets = const_cast<void*>(l->offsets);
+  out->flags = 2;
+  if (len == 0) {
+    out->flags = 1;
+    out->validity = const_cast<uint8_t*>(l->validity);
+    out->validity_bit_offset = l->validity_bit_offset;
+    return ORC_OK;
+  }
+  uint8_t* nb = (uint8_t*)xalloc(bitmap_bytes(len));
+  const uint8_t* rv = (const uint8_t*)r->values;
+  for (int64_t i = 0; i < len; ++i) {
+    bool lv = !l->validity || get_bit(l->validity, l->validity_bit_offset + i);
+    bool rr = get_bit(rv, r->values_bit_offset + i) && (!r->validity || get_bit(r->validity, r->validity_bit_offset + i));
+    if (lv && !rr) set_bit(nb, i);
+  }
+  out->validity = nb;
+  out->validity_bytes = (int64_t)bitmap_bytes(len);
+  out->null_count = len - count_set_bits(nb, 0, len);
   return ORC_OK;
 }
 

@@ -88,6 +88,7 @@ int32_t orc_compare(int32_t op, const orc_view* lhs, int32_t lhs_scalar, const o
 /* arrow_arith::boolean: op numbering as AH_BOOL_* */
 int32_t orc_boolean_binary(int32_t op, const orc_view* l, const orc_view* r, orc_out* out);
 int32_t orc_boolean_unary(int32_t op, const orc_view* v, orc_out* out);
+int32_t orc_nullif(const orc_view* left, const orc_view* right, orc_out* out);
 int32_t orc_cast(const orc_view* values, int32_t to_type, int32_t safe, orc_out* out);
 int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out);
 

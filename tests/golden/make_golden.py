@@ -306,6 +306,16 @@ bool_cases.append(dict(name="length_mismatch", source="arrow-arith/src/boolean.r
                        lhs=arr("Boolean", [T, F]), rhs=arr("Boolean", [T]), error="ComputeError",
                        message="Cannot perform bitwise operation on arrays of different length"))
 
+bool_cases.append(dict(name="test_nullif_int_array", source="arrow-select/src/nullif.rs:126-142", op="nullif",
+                       lhs=arr("Int32", [15, N, 8, 1, 9]), rhs=arr("Boolean", [F, N, T, F, N]),
+                       expected=arr("Int32", [15, N, N, 1, 9])))
+bool_cases.append(dict(name="test_nullif_int_array_offset", source="arrow-select/src/nullif.rs:160-190", op="nullif",
+                       lhs=arr("Int32", [N, 15, 8, 1, 9], [1, 3]), rhs=arr("Boolean", [F, F, F, N, T, F, N], [2, 3]),
+                       expected=arr("Int32", [15, 8, N])))
+bool_cases.append(dict(name="test_nullif_string", source="arrow-select/src/nullif.rs:192-215", op="nullif",
+                       lhs=arr("Utf8", ["hello", N, "world", "a", "b"]), rhs=arr("Boolean", [T, T, F, T, N]),
+                       expected=arr("Utf8", [N, N, "world", N, "b"])))
+
 for name, cases in [("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
                     ("cast", cast_cases)]:
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:

@@ -136,6 +136,7 @@ class Oracle:
         lib.orc_cast.argtypes = [VP, C.c_int32, C.c_int32, OP]
         lib.orc_boolean_binary.argtypes = [C.c_int32, VP, VP, OP]
         lib.orc_boolean_unary.argtypes = [C.c_int32, VP, OP]
+        lib.orc_nullif.argtypes = [VP, VP, OP]
         lib.orc_concat.argtypes = [C.c_int32, VP, OP]
         lib.orc_count_set_bits.restype = C.c_int64
         lib.orc_count_set_bits.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
@@ -250,6 +251,14 @@ class Oracle:
         if st:
             self._raise(st)
         return self._collect(out, A.Boolean)
+
+    def nullif(self, left, right, bit_offset=0):
+        hl, hr = _Held(left, bit_offset), _Held(right, bit_offset)
+        out = Out()
+        st = self.lib.orc_nullif(C.byref(hl.view), C.byref(hr.view), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, left.data_type)
 
     def concat(self, arrays):
         held = [_Held(a) for a in arrays]

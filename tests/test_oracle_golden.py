@@ -352,7 +352,9 @@ BOOL_UN = {"not": 10, "is_null": 11, "is_not_null": 12}
 @pytest.mark.parametrize("bit_offset", [0, 5])
 def test_boolean_golden(oracle, case, bit_offset):
     l = golden_array(case["lhs"])
-    if case["op"] in BOOL_UN:
+    if case["op"] == "nullif":
+        got = oracle.nullif(l, golden_array(case["rhs"]), bit_offset)
+    elif case["op"] in BOOL_UN:
         got = oracle.boolean_unary(BOOL_UN[case["op"]], l, bit_offset)
     else:
         r = golden_array(case["rhs"])
