@@ -2,8 +2,8 @@
 //
 // Nothing here mirrors a reference file; it is the runtime the reference gets
 // from Rust's allocator/Vec (arrow-buffer/src/buffer/mutable.rs) re-thought for
-// HBM: a pooled device allocator, a device scratch arena, pinned read-back
-// slots and HIP-event kernel timing.
+// HBM: a pooled device allocator, pinned read-back slots and HIP-event kernel
+// timing.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -38,9 +38,6 @@ struct ah_context {
   // built-in pool: exact-size free lists of hipMalloc'd blocks
   std::map<size_t, std::vector<void*>> pool_free;
   std::unordered_map<void*, size_t> pool_live;  // ptr -> rounded size
-  // scratch arena (tile counts, prefix sums); grows monotonically
-  void* scratch = nullptr;
-  size_t scratch_bytes = 0;
   // pinned host read-back slots
   uint64_t* pinned = nullptr;  // 256 x u64
   // profiling
@@ -71,8 +68,6 @@ void ah_pool_free(ah_context* ctx, void* p);
 // output buffers honour the host allocator hook
 ah_status ah_out_alloc(ah_context* ctx, size_t bytes, void** out);
 void ah_out_free(ah_context* ctx, void* p, size_t bytes);
-// scratch arena: returns a pointer valid until the next ah_scratch call that grows it
-ah_status ah_scratch(ah_context* ctx, size_t bytes, void** out);
 
 // HIP-event bracketing of hot kernels on the launch stream
 struct ah_prof_scope {
@@ -172,16 +167,6 @@ __device__ __forceinline__ int bv_get(const BitView& v, int64_t i) {
   return (int)((((const uint8_t*)v.words)[pos >> 3] >> (pos & 7)) & 1);
 }
 
-__device__ __forceinline__ uint64_t lanemask_lt() {
-  unsigned lane = __lane_id();
-  return (1ull << lane) - 1;  // lane < 64
-}
-
-__device__ __forceinline__ int wave_reduce_add(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 __device__ __forceinline__ unsigned long long wave_reduce_add64(unsigned long long v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -115,22 +115,6 @@ void ah_out_free(ah_context* ctx, void* p, size_t bytes) {
   ah_pool_free(ctx, p);
 }
 
-ah_status ah_scratch(ah_context* ctx, size_t bytes, void** out) {
-  if (bytes > ctx->scratch_bytes) {
-    if (ctx->scratch) {
-      hipStreamSynchronize(ctx->stream);
-      hipFree(ctx->scratch);
-      ctx->scratch = nullptr;
-      ctx->scratch_bytes = 0;
-    }
-    size_t r = (bytes + (size_t)0xFFFFF) & ~(size_t)0xFFFFF;
-    AH_HIP(ctx, hipMalloc(&ctx->scratch, r));
-    ctx->scratch_bytes = r;
-  }
-  *out = ctx->scratch;
-  return AH_OK;
-}
-
 // ---------------------------------------------------------------- context
 extern "C" ah_status ah_context_create(int device, ah_context** out) {
   if (!out) return AH_INVALID_ARGUMENT;
@@ -163,7 +147,6 @@ extern "C" void ah_context_destroy(ah_context* ctx) {
   ah_profile_reset(ctx);
   ah_pool_trim(ctx);
   for (auto& kv : ctx->pool_live) hipFree(kv.first);
-  if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;

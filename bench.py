@@ -286,9 +286,12 @@ def main():
             f = K.filter(col, pred)
             t = K.take(col, idx)
             state["k"], state["fn"], state["tn"] = f.length, f.null_count(), t.null_count()
-            if with_reassembly:
-                g = comm.all_gatherv(f)
-                state["gk"] = g.length
+            if with_reassembly and not state.get("reassemble_error"):
+                try:
+                    g = comm.all_gatherv(f)
+                    state["gk"] = g.length
+                except Exception as ex:  # keep the run alive: report local-only numbers + the error
+                    state["reassemble_error"] = repr(ex)[:300]
             return f, t
 
         kernels = ["filter_count", "filter_scatter", "take_gather"]
@@ -487,6 +490,8 @@ def main():
                          "traffic": pmc_traffic(dominant, args), "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom_n},
         }
+        if wl == "filter_take" and state.get("reassemble_error"):
+            line["config"]["reassemble"] = "failed: " + state["reassemble_error"]
         if comm is not None and getattr(comm, "timings", None):
             line["reassemble_last_ms"] = comm.timings
         if verified:
