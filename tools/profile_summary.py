@@ -38,7 +38,9 @@ out = [f"# rocprofv3 evidence, round {tag} (MI355X, ROCm 7.2)\n",
 
 for sub, title in [("trace", "filter + take step (bench.py default)"), ("trace_arith", "add_wrapping f64"),
                    ("trace_cmp", "lt f64"), ("trace_cast", "cast Int64->Float64"),
-                   ("trace_cast_string", "cast Float64->LargeUtf8")]:
+                   ("trace_cast_string", "cast Float64->LargeUtf8"),
+                   ("trace_coalesce", "BatchCoalescer.push_batch_with_filter (2 columns, 2^24-row batches)"),
+                   ("trace_string_filter_take", "filter + take on a LargeUtf8 column (2^27 rows)")]:
     p = os.path.join(src, sub, "bench_kernel_stats.csv")
     if not os.path.exists(p):
         continue
@@ -97,6 +99,40 @@ if pm:
     json.dump({"source": f"profiles/{tag}_FETCH_SIZE_per_kernel.csv + {tag}_WRITE_SIZE_per_kernel.csv",
                "workload": "bench.py default (1e9 Int64 rows, 10% nulls, 10% selectivity, 1e8 random u32 indices)",
                "hbm_bytes_per_launch": traffic}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+# streaming kernels of the other workloads: FETCH x2 + WRITE
+extra = []
+for wl, kern in [("arith", "arith_kernel"), ("cmp", "compare_kernel")]:
+    vals = {}
+    for sub, cname in [(f"fetch_{wl}", "FETCH_SIZE"), (f"write_{wl}", "WRITE_SIZE")]:
+        p = os.path.join(src, sub, "bench_counter_collection.csv")
+        if os.path.exists(p):
+            xs = [float(r["Counter_Value"]) for r in csv.DictReader(open(p)) if kern in r["Kernel_Name"]]
+            if xs:
+                vals[cname] = sum(xs) / len(xs)
+    if len(vals) == 2:
+        tot = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
+        extra.append(f"| {kern} ({wl}, 1e9 f64 rows) | {vals['FETCH_SIZE']:.0f} | {vals['WRITE_SIZE']:.0f} | {tot/1e9:.2f} GB | wide coalesced reads: FETCH x2 |")
+if extra:
+    out.append("## HBM traffic of the other streaming kernels (PMC)\n")
+    out.append("| kernel | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes per launch (corrected) | note |")
+    out.append("|---|---|---|---|---|")
+    out += extra
+    out.append("")
+p = os.path.join(src, "sq", "bench_counter_collection.csv")
+if os.path.exists(p):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(p)):
+        k = short(r["Kernel_Name"])
+        if k.startswith(("filter_scatter", "take_kernel", "filter_count")):
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out.append("## SQ counters, filter + take step (quad-cycles summed over waves)\n")
+    names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+             "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]
+    out.append("| kernel | " + " | ".join(n.replace("SQ_", "") for n in names) + " |")
+    out.append("|---|" + "---|" * len(names))
+    for k, v in agg.items():
+        out.append(f"| {k} | " + " | ".join(f"{sum(v[n])/max(len(v[n]),1):.3g}" if n in v else "-" for n in names) + " |")
+    out.append("")
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(out) + "\n")
 for f in ["bench_plain.json"]:
     if os.path.exists(os.path.join(src, f)):
