@@ -50,48 +50,6 @@ def pmc_traffic(kernel, args):
         return None
 
 
-def _splitmix64(seed, rows):
-    """numpy twin of the device generator (arrow-rs_amd/csrc/gen.hip) for arbitrary row numbers."""
-    import numpy as np
-    with np.errstate(over="ignore"):
-        z = np.uint64(seed) + (rows.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        return z ^ (z >> np.uint64(31))
-
-
-def verify_filter_take(A, ctx, args, n, row0, f, t, idx):
-    """Full-size parity (the oracle cannot hold 1e9 rows): filter is order preserving, so the
-    oracle's result on the first / last W input rows must equal the head / tail of the device
-    output; take rows are checked against values re-derived from the counter-based generators."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
-    import orc
-    oracle = orc.load(os.path.join(ROOT, "oracle", "liboracle.so"))
-    W = min(n, 1 << 22)
-    res = {}
-    for name, start in (("head", 0), ("tail", n - W)):
-        vals = oracle.gen_i64(W, 42, -2**63, 2**63 - 1, row0=row0 + start)
-        valid = oracle.gen_bits(W, 43, args.valid, row0=row0 + start)
-        mask = oracle.gen_bits(W, 44, args.selectivity, row0=row0 + start)
-        vals[~valid] = 0
-        exp = oracle.filter(orc.HostArray(A.Int64, vals, valid), orc.HostArray(A.Boolean, mask))
-        k = len(exp)
-        got = f.slice(0, k) if name == "head" else f.slice(f.length - k, k)
-        orc.assert_logical_eq(orc.HostArray.from_device(got), exp, f"filter {name} window")
-        res[f"filter_{name}_rows_checked"] = k
-    m = min(idx.length, 1 << 20)
-    rows = idx.slice(0, m).values_numpy().astype(np.uint64)
-    gvals = _splitmix64(42, rows + np.uint64(row0)).view(np.int64)
-    thr = np.uint64(int(max(0.0, min(1.0, args.valid)) * 9007199254740992.0))
-    gvalid = (_splitmix64(43, rows + np.uint64(row0)) >> np.uint64(11)) < thr
-    gvals = np.where(gvalid, gvals, 0)
-    orc.assert_logical_eq(orc.HostArray.from_device(t.slice(0, m)), orc.HostArray(A.Int64, gvals, gvalid),
-                          "take sample")
-    res["take_rows_checked"] = m
-    return res
-
-
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -105,9 +63,6 @@ def parse():
     p.add_argument("--batch-rows", type=int, default=1 << 24, help="coalesce workload: rows per pushed batch")
     p.add_argument("--reassemble", default="auto", choices=["auto", "none", "allgatherv"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--verify", action="store_true",
-                   help="filter_take: check the full-size outputs against the oracle on head/tail windows "
-                        "and the take output against the counter-based generators on a sample")
     p.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
     return p.parse_args()
 
@@ -391,10 +346,6 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, local_elapsed = float(tt[0]), (float(tt[1]) if reassemble else None)
 
-    verified = None
-    if wl == "filter_take" and args.verify:
-        f, t = out
-        verified = verify_filter_take(A, ctx, args, n, row0, f, t, idx)
     sorted_ms = None
     if wl == "filter_take" and sorted_idx is not None:
         ctx.profile(True)
@@ -494,8 +445,6 @@ def main():
             line["config"]["reassemble"] = "failed: " + state["reassemble_error"]
         if comm is not None and getattr(comm, "timings", None):
             line["reassemble_last_ms"] = comm.timings
-        if verified:
-            line["verified_vs_oracle"] = verified
         line["kernel_avg_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
         if local_elapsed:
             line["local_value"] = round(n * world * args.steps / local_elapsed / 1e6, 1)

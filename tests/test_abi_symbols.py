@@ -61,3 +61,32 @@ def test_product_does_not_reference_oracle():
                 if re.search(r"liboracle|oracle/|orc_\w+\(|import orc\b", txt):
                     offenders.append(os.path.join(d, f))
     assert not offenders, offenders
+
+
+def test_header_is_valid_c99(tmp_path):
+    """include/arrow_hip.h is a C header (the FFI boundary): it must compile as plain C and link
+    against the shared library without any C++ or HIP header."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "arrow_hip.h"\n'
+                   '#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '  ah_array_view v = {0}; ah_array_out o = {0};\n'
+                   '  v.type = AH_INT64; (void)o;\n'
+                   '  printf("%s %d %d\\n", ah_version(), (int)sizeof(ah_array_view), ah_can_cast_types(AH_INT64, AH_FLOAT64));\n'
+                   '  return v.type == AH_INT64 ? 0 : 1;\n'
+                   '}\n')
+    import arrow_rs_amd as A
+    libdir = os.path.dirname(A._lib.LIB_PATH)
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src),
+                           "-L" + libdir, "-larrow_hip", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and out.stdout.startswith("arrow_hip") and out.stdout.strip().endswith(" 1"), out
+
+
+def test_cpp_host_mirror_compiles():
+    """include/arrow_hip.hpp + the C++ mirror test compile with plain g++ (no HIP headers)."""
+    import subprocess
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp")])
