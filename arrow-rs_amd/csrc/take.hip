@@ -145,13 +145,16 @@ __global__ void __launch_bounds__(256) take_kernel(TakeArgs a) {
 // (or negative).  Signed indices compare in their own type, not reinterpreted.
 template <typename IDX>
 __global__ void __launch_bounds__(256) check_bounds_kernel(const IDX* idx, BitView ivalid, int64_t n,
-                                                           int64_t len, unsigned long long* first_bad) {
+                                                           int64_t len, int check_negative,
+                                                           unsigned long long* first_bad) {
   unsigned long long bad = ~0ull;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     IDX r = idx[i];
     bool valid = bv_get(ivalid, i);
     bool isbad;
-    if constexpr (std::is_signed<IDX>::value) isbad = r < 0 || (int64_t)r >= len;
+    // with index nulls the reference only tests `index >= len` (take.rs:183-191); negatives are
+    // caught there only by the no-null fold (:193-195)
+    if constexpr (std::is_signed<IDX>::value) isbad = (check_negative && r < 0) || (int64_t)r >= len;
     else isbad = (uint64_t)r >= (uint64_t)len;
     if (valid && isbad && (unsigned long long)i < bad) bad = (unsigned long long)i;
   }
@@ -217,9 +220,9 @@ ah_status launch_take(ah_context* ctx, int width, ah_type it, const TakeArgs& a,
 
 template <typename IDX>
 void launch_cb(ah_context* ctx, const ah_array_view* ind, BitView iv, int64_t len,
-               unsigned long long* first, int grid) {
+               unsigned long long* first, int grid, int check_negative) {
   check_bounds_kernel<IDX><<<grid, 256, 0, ctx->stream>>>((const IDX*)ind->values, iv, ind->length,
-                                                          len, first);
+                                                          len, check_negative, first);
 }
 
 // value of an index slot, as the reference would print it
@@ -283,14 +286,14 @@ extern "C" ah_status ah_take(ah_context* ctx, const ah_array_view* values,
       hipMemsetAsync(flags, 0xFF, 8, ctx->stream);
       int g = (int)std::min<int64_t>(ah_ceil_div(n, 256), 4096);
       switch (indices->type) {
-        case AH_INT8: launch_cb<int8_t>(ctx, indices, ivalid, values->length, flags, g); break;
-        case AH_UINT8: launch_cb<uint8_t>(ctx, indices, ivalid, values->length, flags, g); break;
-        case AH_INT16: launch_cb<int16_t>(ctx, indices, ivalid, values->length, flags, g); break;
-        case AH_UINT16: launch_cb<uint16_t>(ctx, indices, ivalid, values->length, flags, g); break;
-        case AH_INT32: launch_cb<int32_t>(ctx, indices, ivalid, values->length, flags, g); break;
-        case AH_UINT32: launch_cb<uint32_t>(ctx, indices, ivalid, values->length, flags, g); break;
-        case AH_INT64: launch_cb<int64_t>(ctx, indices, ivalid, values->length, flags, g); break;
-        default: launch_cb<uint64_t>(ctx, indices, ivalid, values->length, flags, g); break;
+        case AH_INT8: launch_cb<int8_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
+        case AH_UINT8: launch_cb<uint8_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
+        case AH_INT16: launch_cb<int16_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
+        case AH_UINT16: launch_cb<uint16_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
+        case AH_INT32: launch_cb<int32_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
+        case AH_UINT32: launch_cb<uint32_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
+        case AH_INT64: launch_cb<int64_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
+        default: launch_cb<uint64_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
       }
       hipError_t e = hipMemcpyAsync(ctx->pinned, flags, 8, hipMemcpyDeviceToHost, ctx->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

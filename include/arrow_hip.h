@@ -149,7 +149,9 @@ AH_API ah_status ah_filter(ah_context* ctx, const ah_array_view* values,
                            const ah_array_view* predicate, ah_array_out* out);
 
 /* FilterBuilder::new(..).optimize().build() (filter.rs:256-324): count once,
- * keep per-tile offsets on device, apply to many columns. */
+ * keep per-tile offsets on device, apply to many columns.  The handle BORROWS the
+ * predicate's device buffers (the Rust FilterPredicate holds an Arc clone): they
+ * must stay alive until ah_filter_predicate_free. */
 typedef struct ah_filter_predicate ah_filter_predicate;
 AH_API ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_view* predicate,
                                            ah_filter_predicate** out);
