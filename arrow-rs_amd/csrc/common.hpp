@@ -38,6 +38,7 @@ struct ah_context {
   // built-in pool: exact-size free lists of hipMalloc'd blocks
   std::map<size_t, std::vector<void*>> pool_free;
   std::unordered_map<void*, size_t> pool_live;  // ptr -> rounded size
+  std::unordered_map<void*, size_t> redzones;   // AH_DEBUG_REDZONE: ptr -> requested size
   // pinned host read-back slots
   uint64_t* pinned = nullptr;  // 256 x u64
   // profiling

@@ -95,8 +95,24 @@ extern "C" void ah_pool_trim(ah_context* ctx) {
   ctx->pool_free.clear();
 }
 
+// Debug redzones (AH_DEBUG_REDZONE=1): every pooled output buffer gets a 256-byte canary right
+// after its requested size (the pool rounds sizes up, which would otherwise hide small kernel
+// overruns); the canary is verified when the buffer is released.  The GPU-side analogue of the
+// reference's Miri / force_validate runs.
+static bool redzone_on() {
+  static const char* e = getenv("AH_DEBUG_REDZONE");
+  return e && e[0] == '1';
+}
+static constexpr size_t RZ = 256;
+
 ah_status ah_out_alloc(ah_context* ctx, size_t bytes, void** out) {
   if (bytes == 0) bytes = 8;
+  if (!ctx->alloc && redzone_on()) {
+    AH_TRY(ah_pool_alloc(ctx, bytes + RZ, out));
+    ctx->redzones[*out] = bytes;
+    AH_HIP(ctx, hipMemsetAsync((char*)*out + bytes, 0xA5, RZ, ctx->stream));
+    return AH_OK;
+  }
   if (ctx->alloc) {
     void* p = ctx->alloc(ctx->user, bytes);
     if (!p) return ah_fail(ctx, AH_OUT_OF_MEMORY, "host allocator returned NULL for %zu bytes", bytes);
@@ -108,6 +124,19 @@ ah_status ah_out_alloc(ah_context* ctx, size_t bytes, void** out) {
 
 void ah_out_free(ah_context* ctx, void* p, size_t bytes) {
   if (!p) return;
+  auto rz = ctx->redzones.find(p);
+  if (rz != ctx->redzones.end()) {
+    unsigned char tail[RZ];
+    hipStreamSynchronize(ctx->stream);
+    if (hipMemcpy(tail, (char*)p + rz->second, RZ, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (size_t i = 0; i < RZ; ++i)
+        if (tail[i] != 0xA5) {
+          fprintf(stderr, "arrow_hip: REDZONE CORRUPTED: buffer %p of %zu bytes overrun at +%zu\n", p, rz->second, i);
+          abort();
+        }
+    }
+    ctx->redzones.erase(rz);
+  }
   if (ctx->free_ && ctx->pool_live.find(p) == ctx->pool_live.end()) {
     ctx->free_(ctx->user, p, bytes);
     return;
