@@ -103,10 +103,10 @@ class Communicator:
             raise NotYetImplemented(f"all_gatherv of {dt}")
         has_v = 1 if (array.validity is not None and array.null_count() > 0) else 0
         mine = torch.tensor([array.length, array.null_count(), has_v], dtype=torch.int64, device=self.device)
-        allc = torch.empty((self.world, 3), dtype=torch.int64, device=self.device)
+        allc = torch.empty(self.world * 3, dtype=torch.int64, device=self.device)  # flat: gloo and nccl agree
         ctx.synchronize()  # array's producer kernels ran on the context stream
         dist.all_gather_into_tensor(allc, mine, group=self.group)
-        counts = allc.cpu().tolist()
+        counts = allc.view(self.world, 3).cpu().tolist()
         tm["counts"] = _t.perf_counter() - _t0
         lens = [c[0] for c in counts]
         row_offs, total = exclusive_offsets(lens)

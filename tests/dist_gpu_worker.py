@@ -1,0 +1,42 @@
+"""Worker for tests/test_gpu_parity.py::test_communicator_two_ranks_one_gpu: rank r of a 2-rank job,
+BOTH ranks on GPU 0 (the box has one GPU), transport = gloo with device tensors.  Everything except
+the transport is the production path: device filter per shard, Communicator.all_gatherv with direct
+placement of value pieces and the funnel-shift bitmap merge at a non-aligned bit offset."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import arrow_rs_amd as A  # noqa: E402
+from arrow_rs_amd import compute as K, distributed as D  # noqa: E402
+import orc  # noqa: E402
+from orc import HostArray  # noqa: E402
+
+rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+oracle = orc.load(os.path.join(ROOT, "oracle", "liboracle.so"))
+ctx = A.Context(0)
+comm = D.Communicator(ctx, dist)
+n = 1_000_003
+for case, (p_valid, sel, dt) in enumerate([(0.9, 0.1, A.Int64), (1.0, 0.37, A.Float64), (0.5, 0.9, A.Int32)]):
+    vals = oracle.gen_i64(n, 42 + case, -2**40, 2**40)
+    valid = oracle.gen_bits(n, 43 + case, p_valid) if p_valid < 1 else None
+    mask = oracle.gen_bits(n, 44 + case, sel)
+    vals = vals.astype(dt.np_dtype)
+    s, e = D.shard_range(n, rank, world)
+    shard = HostArray(dt, vals[s:e], None if valid is None else valid[s:e])
+    f = K.filter(shard.to_device(ctx), HostArray(A.Boolean, mask[s:e]).to_device(ctx))
+    g = comm.all_gatherv(f)
+    exp = oracle.filter(HostArray(dt, vals, valid), HostArray(A.Boolean, mask))
+    got = HostArray.from_device(g)
+    orc.assert_logical_eq(got, exp, f"rank {rank} case {case}")
+    assert g.null_count() == exp.null_count and (g.nulls() is None) == (exp.valid is None)
+dist.barrier()
+dist.destroy_process_group()
+print("RANK_OK", rank)
