@@ -19,6 +19,7 @@ AH_CAST_ERROR = 5
 AH_OFFSET_OVERFLOW = 6
 AH_NOT_YET_IMPLEMENTED = 7
 AH_OFFSET_OVERFLOW_ERROR = 8
+AH_C_DATA_INTERFACE = 9
 AH_PANIC = 100
 AH_HIP_ERROR = 101
 AH_OUT_OF_MEMORY = 102
@@ -63,6 +64,26 @@ class ArrayOut(C.Structure):
         ("flags", C.c_int32),
     ]
 
+
+class FFI_ArrowSchema(C.Structure):
+    """struct ArrowSchema (arrow-schema/src/ffi.rs:76-98)."""
+
+
+FFI_ArrowSchema._fields_ = [
+    ("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_void_p), ("flags", C.c_int64),
+    ("n_children", C.c_int64), ("children", C.POINTER(C.POINTER(FFI_ArrowSchema))),
+    ("dictionary", C.POINTER(FFI_ArrowSchema)), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class FFI_ArrowArray(C.Structure):
+    """struct ArrowArray (arrow-data/src/ffi.rs:37-66)."""
+
+
+FFI_ArrowArray._fields_ = [
+    ("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+    ("n_children", C.c_int64), ("buffers", C.POINTER(C.c_void_p)),
+    ("children", C.POINTER(C.POINTER(FFI_ArrowArray))), ("dictionary", C.POINTER(FFI_ArrowArray)),
+    ("release", C.c_void_p), ("private_data", C.c_void_p)]
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -117,6 +138,10 @@ SIGNATURES = {
     "ah_gen_iota_u32": (C.c_int32, [_P, _P, C.c_int64, C.c_uint32]),
     "ah_gen_bernoulli_bits": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_double, C.c_int64]),
     "ah_zero_null_slots": (C.c_int32, [_P, _P, C.c_int32, _P, C.c_int64]),
+    "ah_type_from_format": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int32)]),
+    "ah_format_of_type": (C.c_char_p, [C.c_int32]),
+    "ah_import_c_data": (C.c_int32, [_P, C.POINTER(FFI_ArrowArray), C.POINTER(FFI_ArrowSchema), _OUT]),
+    "ah_export_c_data": (C.c_int32, [_P, _VIEW, C.c_char_p, C.POINTER(FFI_ArrowArray), C.POINTER(FFI_ArrowSchema)]),
 }
 
 _lib = None

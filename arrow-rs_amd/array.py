@@ -59,6 +59,10 @@ class OffsetOverflowError(ArrowError):
     variant, prefix = "OffsetOverflowError", "Offset overflow error: "
 
 
+class CDataInterfaceError(ArrowError):
+    variant, prefix = "CDataInterface", "C Data interface error: "
+
+
 class NotYetImplemented(ArrowError):
     variant, prefix = "NotYetImplemented", "Not yet implemented: "
 
@@ -80,6 +84,7 @@ _STATUS = {
     L.AH_CAST_ERROR: CastError,
     L.AH_NOT_YET_IMPLEMENTED: NotYetImplemented,
     L.AH_OFFSET_OVERFLOW_ERROR: OffsetOverflowError,
+    L.AH_C_DATA_INTERFACE: CDataInterfaceError,
     L.AH_OFFSET_OVERFLOW: Panic,
     L.AH_PANIC: Panic,
 }
@@ -389,6 +394,16 @@ class Array:
                   out.validity_bit_offset, out.null_count, offs)
         arr._owner = owner
         return arr
+
+    # ---- Arrow C Data Interface / pyarrow (arrow-array/src/ffi.rs:231-254, arrow-pyarrow/src/lib.rs:199-257)
+    @classmethod
+    def from_pyarrow(cls, pa_array, ctx=None):
+        from . import ffi
+        return ffi.from_pyarrow(pa_array, ctx)
+
+    def to_pyarrow(self):
+        from . import ffi
+        return ffi.to_pyarrow(self)
 
     # ---- reference API surface
     def __len__(self):

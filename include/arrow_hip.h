@@ -53,6 +53,7 @@ enum {
                                  arrow-array/src/builder/generic_bytes_builder.rs:86-87) */
   AH_NOT_YET_IMPLEMENTED = 7, /* ArrowError::NotYetImplemented */
   AH_OFFSET_OVERFLOW_ERROR = 8, /* ArrowError::OffsetOverflowError(n): message is the number */
+  AH_C_DATA_INTERFACE = 9,    /* ArrowError::CDataInterface */
   AH_PANIC = 100,             /* the reference would panic!(); message = panic text */
   AH_HIP_ERROR = 101,         /* runtime failure (no reference analogue) */
   AH_OUT_OF_MEMORY = 102
@@ -294,6 +295,69 @@ AH_API ah_status ah_gen_bernoulli_bits(ah_context* ctx, uint8_t* dst, int64_t n,
  * FromIterator<Option<T>> bench arrays, arrow/src/util/bench_util.rs:45-60) */
 AH_API ah_status ah_zero_null_slots(ah_context* ctx, void* values, int32_t byte_width,
                                     const uint8_t* validity, int64_t n);
+
+/* ------------------------------------------------ Arrow C Data Interface */
+/* The second ABI-stable surface of the reference (arrow-data/src/ffi.rs:37-66
+ * `FFI_ArrowArray`, arrow-schema/src/ffi.rs:76-98 `FFI_ArrowSchema`).  The struct
+ * definitions are the Arrow specification's, under its own include guard so
+ * they coexist with any other copy in the host program. */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+#define ARROW_FLAG_DICTIONARY_ORDERED 1
+#define ARROW_FLAG_NULLABLE 2
+#define ARROW_FLAG_MAP_KEYS_SORTED 4
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+
+/* `DataType::try_from(&FFI_ArrowSchema)` (arrow-schema/src/ffi.rs:492-700) reduced
+ * to the physical layout: "l" / "tsu:UTC" / "tDn" -> AH_INT64, "d:38,10" ->
+ * AH_FIXED16, "u" -> AH_UTF8 ...  The logical type stays with the host, which hands the
+ * same format string back to ah_export_c_data.  Unknown formats: AH_C_DATA_INTERFACE
+ * with the reference text; layouts this library has no kernels for (nested,
+ * dictionary, views, binary): AH_NOT_YET_IMPLEMENTED. */
+AH_API ah_status ah_type_from_format(ah_context* ctx, const char* format, ah_type* out);
+/* Default format string of a physical type ("l" for AH_INT64, "d:38,0" for AH_FIXED16...). */
+AH_API const char* ah_format_of_type(ah_type t);
+
+/* `from_ffi(array, &schema)` (arrow-array/src/ffi.rs:237-254): a HOST-resident
+ * C-Data array becomes a device-resident array (one H2D copy per buffer on the
+ * context stream; the rows [offset, offset+length) only).  `array` and `schema`
+ * stay owned by the caller (borrowed like every other input); the result is
+ * owned like any kernel output.  null_count -1 is counted on the device
+ * (`null_count_opt`, arrow-data/src/ffi.rs:327); a present validity buffer is
+ * kept even when null_count == 0, an absent one stays absent. */
+AH_API ah_status ah_import_c_data(ah_context* ctx, const struct ArrowArray* array,
+                                  const struct ArrowSchema* schema, ah_array_out* out);
+/* `to_ffi(&data)` (arrow-array/src/ffi.rs:231-235): device array -> host-resident
+ * C-Data structs whose release callbacks free the host copies.  `format` NULL =
+ * the physical type's default; otherwise it must map to `values->type`.
+ * Like `FFI_ArrowArray::new` (arrow-data/src/ffi.rs:133-212) the null buffer is
+ * re-aligned to the exported offset (always 0 here), n_buffers follows the spec
+ * (2, or 3 for strings) and buffers[0] is NULL when there is no null buffer. */
+AH_API ah_status ah_export_c_data(ah_context* ctx, const ah_array_view* values, const char* format,
+                                  struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,7 @@ class ArrowError : public std::runtime_error {
       case AH_CAST_ERROR: return "Cast error: ";
       case AH_NOT_YET_IMPLEMENTED: return "Not yet implemented: ";
       case AH_OFFSET_OVERFLOW_ERROR: return "Offset overflow error: ";
+      case AH_C_DATA_INTERFACE: return "C Data interface error: ";
       default: return "";
     }
   }
@@ -302,4 +303,19 @@ inline ArrayRef concat(const std::vector<ArrayRef>& arrays) {
 }
 
 }  // namespace compute
+
+// Arrow C Data Interface (arrow-array/src/ffi.rs:231-254).  `from_ffi` copies a host-resident
+// producer array into HBM (the producer keeps ownership of its structs); `to_ffi` fills structs
+// whose release callbacks free host copies of the device buffers.
+namespace ffi {
+inline ArrayRef from_ffi(const std::shared_ptr<Context>& ctx, const ArrowArray& array, const ArrowSchema& schema) {
+  ah_array_out out;
+  ctx->check(ah_import_c_data(ctx->handle(), &array, &schema, &out));
+  return std::make_shared<Array>(ctx, out);
+}
+// `format` keeps the logical type ("tsu:UTC", "d:38,10"); nullptr = default of the physical type
+inline void to_ffi(const ArrayRef& a, ArrowArray* out_array, ArrowSchema* out_schema, const char* format = nullptr) {
+  a->context()->check(ah_export_c_data(a->context()->handle(), &a->view(), format, out_array, out_schema));
+}
+}  // namespace ffi
 }  // namespace arrow_hip

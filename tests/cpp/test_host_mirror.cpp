@@ -126,5 +126,41 @@ int main() {
   auto f = compute::cast(s64, AH_FLOAT64);
   assert(f->has_nulls_buffer() && f->null_count() == 0 && download<double>(f)[4] == 10.0);
   std::puts("CPP_HOST_MIRROR_OK");
+  // C Data Interface round trip (arrow-array/src/ffi.rs:231-254): host producer -> HBM -> filter -> host
+  {
+    static const int64_t host_vals[6] = {10, 20, 30, 40, 50, 60};
+    static const uint8_t host_valid[1] = {0b00101110};  // rows 1,2,3,5 valid
+    const void* bufs[2] = {host_valid, host_vals};
+    ArrowArray in{};
+    in.length = 4; in.null_count = -1; in.offset = 1; in.n_buffers = 2; in.buffers = bufs;
+    in.release = [](ArrowArray*) {};
+    ArrowSchema sch{};
+    sch.format = "tsu:UTC"; sch.name = ""; sch.flags = ARROW_FLAG_NULLABLE;
+    sch.release = [](ArrowSchema*) {};
+    auto dev = ffi::from_ffi(ctx, in, sch);  // rows 1..4 = [20,30,40,N]
+    assert(dev->len() == 4 && dev->null_count() == 1 && dev->data_type() == AH_INT64);
+    auto m = upload_bool(ctx, {true, false, true, true}, keep);
+    auto f = compute::filter(dev, m);
+    ArrowArray oa{};
+    ArrowSchema os{};
+    ffi::to_ffi(f, &oa, &os, sch.format);
+    assert(oa.length == 3 && oa.null_count == 1 && oa.offset == 0 && oa.n_buffers == 2);
+    assert(std::string(os.format) == "tsu:UTC");
+    const int64_t* ov = static_cast<const int64_t*>(oa.buffers[1]);
+    const uint8_t* ob = static_cast<const uint8_t*>(oa.buffers[0]);
+    assert(ov[0] == 20 && ov[1] == 40 && (ob[0] & 7) == 0b011);
+    oa.release(&oa);
+    os.release(&os);
+    assert(oa.release == nullptr && os.release == nullptr);
+    bool bad = false;
+    sch.format = "+l";
+    try {
+      ffi::from_ffi(ctx, in, sch);
+    } catch (const ArrowError& e) {
+      bad = e.code() == AH_NOT_YET_IMPLEMENTED;
+    }
+    assert(bad);
+  }
+
   return 0;
 }

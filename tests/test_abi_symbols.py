@@ -90,3 +90,35 @@ def test_cpp_host_mirror_compiles():
     import subprocess
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp")])
+
+
+def test_c_data_format_mapping():
+    """ah_type_from_format: DataType::try_from(&FFI_ArrowSchema) reduced to physical layouts
+    (arrow-schema/src/ffi.rs:492-700).  Pure host logic: needs no GPU and no context."""
+    import ctypes as C
+    import arrow_rs_amd as A
+    L = A._lib
+    lib = L.load()
+    cases = {
+        "b": L.AH_BOOL, "c": L.AH_INT8, "C": L.AH_UINT8, "s": L.AH_INT16, "S": L.AH_UINT16, "i": L.AH_INT32,
+        "I": L.AH_UINT32, "l": L.AH_INT64, "L": L.AH_UINT64, "e": L.AH_FLOAT16, "f": L.AH_FLOAT32,
+        "g": L.AH_FLOAT64, "u": L.AH_UTF8, "U": L.AH_LARGE_UTF8, "z": L.AH_UTF8, "Z": L.AH_LARGE_UTF8,
+        "tdD": L.AH_INT32, "tdm": L.AH_INT64, "tts": L.AH_INT32, "ttm": L.AH_INT32, "ttu": L.AH_INT64,
+        "ttn": L.AH_INT64, "tDs": L.AH_INT64, "tDn": L.AH_INT64, "tiM": L.AH_INT32, "tiD": L.AH_INT64,
+        "tin": L.AH_FIXED16, "tss:": L.AH_INT64, "tsu:UTC": L.AH_INT64, "tsn:America/New_York": L.AH_INT64,
+        "d:38,10": L.AH_FIXED16, "d:9,2,32": L.AH_INT32, "d:18,2,64": L.AH_INT64, "d:38,10,128": L.AH_FIXED16,
+        "d:76,10,256": L.AH_FIXED32, "w:16": L.AH_FIXED16, "w:32": L.AH_FIXED32,
+    }
+    for fmt, want in cases.items():
+        t = C.c_int32(0)
+        assert lib.ah_type_from_format(None, fmt.encode(), C.byref(t)) == L.AH_OK, fmt
+        assert t.value == want, fmt
+    t = C.c_int32(0)
+    for fmt in ("+l", "+s", "vu", "vz", "n", "w:3"):
+        assert lib.ah_type_from_format(None, fmt.encode(), C.byref(t)) == L.AH_NOT_YET_IMPLEMENTED, fmt
+    for fmt in ("x", "d:1", "d:a,b", "d:10,2,512", "tsx:", ""):
+        assert lib.ah_type_from_format(None, fmt.encode(), C.byref(t)) == L.AH_C_DATA_INTERFACE, fmt
+    for phys in range(1, 17):
+        fmt = lib.ah_format_of_type(phys)
+        assert fmt is not None
+        assert lib.ah_type_from_format(None, fmt, C.byref(t)) == L.AH_OK and t.value == phys
