@@ -65,6 +65,11 @@ class ArrayOut(C.Structure):
     ]
 
 
+class Scalar(C.Structure):
+    """ah_scalar / orc_scalar (identical layout)."""
+    _fields_ = [("type", C.c_int32), ("is_valid", C.c_int32), ("bytes", C.c_uint8 * 32)]
+
+
 class FFI_ArrowSchema(C.Structure):
     """struct ArrowSchema (arrow-schema/src/ffi.rs:76-98)."""
 
@@ -138,6 +143,7 @@ SIGNATURES = {
     "ah_gen_iota_u32": (C.c_int32, [_P, _P, C.c_int64, C.c_uint32]),
     "ah_gen_bernoulli_bits": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_double, C.c_int64]),
     "ah_zero_null_slots": (C.c_int32, [_P, _P, C.c_int32, _P, C.c_int64]),
+    "ah_aggregate": (C.c_int32, [_P, C.c_int32, _VIEW, C.POINTER(Scalar)]),
     "ah_type_from_format": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int32)]),
     "ah_format_of_type": (C.c_char_p, [C.c_int32]),
     "ah_import_c_data": (C.c_int32, [_P, C.POINTER(FFI_ArrowArray), C.POINTER(FFI_ArrowSchema), _OUT]),

@@ -10,3 +10,6 @@ from .kernels.cast import cast, cast_with_options, can_cast_types, CastOptions  
 from .kernels.concat import concat  # noqa: F401
 from .kernels.boolean import (and_, or_, and_not, and_kleene, or_kleene, not_, is_null, is_not_null, nullif)  # noqa: F401
 from .kernels.coalesce import BatchCoalescer  # noqa: F401
+from .kernels import aggregate  # noqa: F401  (sum/min/max shadow builtins: use ``compute.aggregate.sum`` …)
+from .kernels.aggregate import (sum_checked, product, product_checked, bit_and, bit_or, bit_xor,  # noqa: F401
+                                min_boolean, max_boolean, bool_and, bool_or)

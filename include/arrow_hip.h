@@ -263,6 +263,28 @@ AH_API ah_status ah_bitmap_set_bits(ah_context* ctx, uint8_t* dst, int64_t dst_b
                                     const uint8_t* src, int64_t src_bit_offset, int64_t len,
                                     int64_t* set_bits);
 
+/* ------------------------------------------------------------- aggregate */
+/* arrow_arith::aggregate (arrow-arith/src/aggregate.rs): `sum` :943, `sum_checked` :897,
+ * `product` :953, `product_checked` :963, `min` :1012, `max` :1027, `bit_and/bit_or/bit_xor`
+ * :776-873; on AH_BOOL, AH_AGG_MIN / AH_AGG_MAX are `min_boolean` / `max_boolean` (:372,:430)
+ * = `bool_and` / `bool_or` (:880-889).  `Option<T::Native>`: is_valid == 0 is `None`
+ * (empty or all-null input).  Integer sum/product wrap; min/max use the total order for floats
+ * (NaN above +inf, -NaN below -inf); the *_checked forms fail like the reference's sequential
+ * loop, i.e. when a PREFIX overflows, with its "Overflow happened on: {acc} + {value}" text.
+ * Float sums/products are a fixed tree reduction (the reference's own association order depends
+ * on its compile-time vector width, :300-307). */
+typedef int32_t ah_agg_op;
+enum {
+  AH_AGG_SUM = 0, AH_AGG_SUM_CHECKED = 1, AH_AGG_PRODUCT = 2, AH_AGG_PRODUCT_CHECKED = 3,
+  AH_AGG_MIN = 4, AH_AGG_MAX = 5, AH_AGG_BIT_AND = 6, AH_AGG_BIT_OR = 7, AH_AGG_BIT_XOR = 8
+};
+typedef struct ah_scalar {
+  ah_type type;
+  int32_t is_valid;  /* 0 = None */
+  uint8_t bytes[32]; /* little-endian native value (AH_BOOL: one byte 0/1) */
+} ah_scalar;
+AH_API ah_status ah_aggregate(ah_context* ctx, ah_agg_op op, const ah_array_view* values, ah_scalar* out);
+
 /* ------------------------------------------------------------- utilities */
 /* BooleanBuffer::count_set_bits (arrow-buffer/src/buffer/boolean.rs) on device. */
 AH_API ah_status ah_count_set_bits(ah_context* ctx, const uint8_t* bits, int64_t bit_offset,

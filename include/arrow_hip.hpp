@@ -22,6 +22,7 @@
 #pragma once
 #include <cstring>
 #include <memory>
+#include <optional>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -301,6 +302,29 @@ inline ArrayRef concat(const std::vector<ArrayRef>& arrays) {
   arrays[0]->context()->check(ah_concat(arrays[0]->context()->handle(), (int32_t)views.size(), views.data(), &out));
   return wrap(arrays[0], out);
 }
+
+// ---- aggregate (arrow-arith/src/aggregate.rs): std::optional<T> mirrors Option<T::Native>
+template <typename T> inline std::optional<T> aggregate(ah_agg_op op, const ArrayRef& a) {
+  ah_scalar s;
+  a->context()->check(ah_aggregate(a->context()->handle(), op, &a->view(), &s));
+  if (!s.is_valid) return std::nullopt;
+  T v;
+  std::memcpy(&v, s.bytes, sizeof(T));
+  return v;
+}
+template <typename T> inline std::optional<T> sum(const ArrayRef& a) { return aggregate<T>(AH_AGG_SUM, a); }
+template <typename T> inline std::optional<T> sum_checked(const ArrayRef& a) { return aggregate<T>(AH_AGG_SUM_CHECKED, a); }
+template <typename T> inline std::optional<T> product(const ArrayRef& a) { return aggregate<T>(AH_AGG_PRODUCT, a); }
+template <typename T> inline std::optional<T> product_checked(const ArrayRef& a) { return aggregate<T>(AH_AGG_PRODUCT_CHECKED, a); }
+template <typename T> inline std::optional<T> min(const ArrayRef& a) { return aggregate<T>(AH_AGG_MIN, a); }
+template <typename T> inline std::optional<T> max(const ArrayRef& a) { return aggregate<T>(AH_AGG_MAX, a); }
+template <typename T> inline std::optional<T> bit_and(const ArrayRef& a) { return aggregate<T>(AH_AGG_BIT_AND, a); }
+template <typename T> inline std::optional<T> bit_or(const ArrayRef& a) { return aggregate<T>(AH_AGG_BIT_OR, a); }
+template <typename T> inline std::optional<T> bit_xor(const ArrayRef& a) { return aggregate<T>(AH_AGG_BIT_XOR, a); }
+inline std::optional<bool> min_boolean(const ArrayRef& a) { return aggregate<bool>(AH_AGG_MIN, a); }
+inline std::optional<bool> max_boolean(const ArrayRef& a) { return aggregate<bool>(AH_AGG_MAX, a); }
+inline std::optional<bool> bool_and(const ArrayRef& a) { return min_boolean(a); }
+inline std::optional<bool> bool_or(const ArrayRef& a) { return max_boolean(a); }
 
 }  // namespace compute
 

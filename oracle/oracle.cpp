@@ -1308,6 +1308,178 @@ int32_t neg_typed(const orc_view* v, bool wrapping, orc_out* out) {
   return ORC_OK;
 }
 
+// ---------------------------------------------------------------- aggregate
+// arrow-arith/src/aggregate.rs.  Accumulators :51-177, lane kernels :179-297, dispatch :317-361.
+enum { G_SUM = 0, G_SUM_CHECKED, G_PRODUCT, G_PRODUCT_CHECKED, G_MIN, G_MAX, G_BIT_AND, G_BIT_OR, G_BIT_XOR };
+
+template <typename T> struct TotalOrderLimits {  // MIN_TOTAL_ORDER / MAX_TOTAL_ORDER (arithmetic.rs:45-56)
+  static T min() { return std::numeric_limits<T>::min(); }
+  static T max() { return std::numeric_limits<T>::max(); }
+};
+template <> struct TotalOrderLimits<double> {  // -NaN / +NaN with every payload bit set
+  static double from(uint64_t b) { double d; memcpy(&d, &b, 8); return d; }
+  static double min() { return from(0xFFFFFFFFFFFFFFFFull); }
+  static double max() { return from(0x7FFFFFFFFFFFFFFFull); }
+};
+template <> struct TotalOrderLimits<float> {
+  static float from(uint32_t b) { float d; memcpy(&d, &b, 4); return d; }
+  static float min() { return from(0xFFFFFFFFu); }
+  static float max() { return from(0x7FFFFFFFu); }
+};
+template <typename T> inline T agg_add(T a, T b) {
+  if constexpr (std::is_floating_point<T>::value) return a + b;
+  else return int_wrapping<T>(OP_ADD_W, a, b);
+}
+template <typename T> inline T agg_mul(T a, T b) {
+  if constexpr (std::is_floating_point<T>::value) return a * b;
+  else return int_wrapping<T>(OP_MUL_W, a, b);
+}
+template <typename T, int KIND> struct Acc {  // NumericAccumulator (:32-42)
+  T v;
+  Acc() {
+    if (KIND == G_SUM) v = T(0);
+    else if (KIND == G_PRODUCT) v = T(1);
+    else if (KIND == G_MIN) v = TotalOrderLimits<T>::max();
+    else v = TotalOrderLimits<T>::min();
+  }
+  void accumulate(T x) {
+    if (KIND == G_SUM) v = agg_add<T>(v, x);
+    else if (KIND == G_PRODUCT) v = agg_mul<T>(v, x);
+    else if (KIND == G_MIN) v = is_lt<T>(x, v) ? x : v;
+    else v = is_lt<T>(v, x) ? x : v;  // is_gt
+  }
+  void accumulate_nullable(T x, bool valid) {
+    if (valid) accumulate(x);  // select(valid, op(acc, x), acc)
+  }
+  void merge(const Acc& o) { accumulate(o.v); }  // Sum/Product: op with other; Min/Max: accumulate(other)
+};
+
+template <typename T, int KIND> T reduce_accumulators(std::vector<Acc<T, KIND>>& acc) {  // :179-197
+  size_t len = acc.size();
+  while (len >= 2) {
+    size_t mid = len / 2;
+    for (size_t i = 0; i < mid; ++i) acc[i].merge(acc[mid + i]);
+    len /= 2;
+  }
+  return acc[0].v;
+}
+template <typename T, int KIND> T aggregate_nonnull_simple(const T* v, int64_t n) {  // :222-231
+  Acc<T, KIND> a;
+  for (int64_t i = 0; i < n; ++i) a.accumulate(v[i]);
+  return a.v;
+}
+template <typename T, int KIND> T aggregate_nonnull_lanes(const T* v, int64_t n, int lanes) {  // :234-251
+  std::vector<Acc<T, KIND>> acc(lanes);
+  int64_t full = n / lanes * lanes;
+  for (int64_t i = 0; i < full; i += lanes)
+    for (int l = 0; l < lanes; ++l) acc[l].accumulate(v[i + l]);
+  for (int64_t i = full; i < n; ++i) acc[i - full].accumulate(v[i]);
+  return reduce_accumulators<T, KIND>(acc);
+}
+template <typename T, int KIND>
+T aggregate_nullable_lanes(const T* v, int64_t n, const uint8_t* bits, int64_t off, int lanes) {  // :254-297
+  // 64-row validity chunks, each cut into `lanes`-wide groups; the tail (< 64 rows) the same way with
+  // a final partial group feeding acc[0..rem) — identical to indexing lane = (row % 64) % lanes.
+  std::vector<Acc<T, KIND>> acc(lanes);
+  for (int64_t i = 0; i < n; ++i) acc[(i % 64) % lanes].accumulate_nullable(v[i], get_bit(bits, off + i));
+  return reduce_accumulators<T, KIND>(acc);
+}
+inline int lanes_for(int vector_bytes, size_t width) {  // the `match` at :329-337 / :345-353
+  int q = (int)(vector_bytes / width);
+  switch (q) {
+    case 64: case 32: case 16: case 8: case 4: case 2: return q;
+    default: return 1;
+  }
+}
+
+template <typename T> void store_scalar(orc_scalar* out, T v) {
+  out->is_valid = 1;
+  memcpy(out->bytes, &v, sizeof(T));
+}
+
+template <typename T, int KIND> int32_t aggregate_numeric(const orc_view* a, int vector_bytes, orc_scalar* out) {
+  const int64_t nulls = resolve_nulls(a), n = a->length;
+  if (nulls == n) return ORC_OK;  // None (:320-323), also the empty array
+  const T* v = (const T*)a->values;
+  if (a->validity && nulls > 0) {
+    store_scalar<T>(out, aggregate_nullable_lanes<T, KIND>(v, n, a->validity, a->validity_bit_offset,
+                                                            lanes_for(vector_bytes, sizeof(T))));
+  } else if (std::is_floating_point<T>::value) {
+    int lanes = lanes_for(vector_bytes * 2, sizeof(T));  // PREFERRED_VECTOR_SIZE_NON_NULL (:310)
+    store_scalar<T>(out, lanes > 1 ? aggregate_nonnull_lanes<T, KIND>(v, n, lanes)
+                                   : aggregate_nonnull_simple<T, KIND>(v, n));
+  } else {
+    store_scalar<T>(out, aggregate_nonnull_simple<T, KIND>(v, n));
+  }
+  return ORC_OK;
+}
+
+// sum_checked / product_checked (:897-933, :963-1001): strictly sequential over the valid slots
+template <typename T> int32_t aggregate_checked(int kind, const orc_view* a, orc_scalar* out) {
+  const int64_t nulls = resolve_nulls(a), n = a->length;
+  if (nulls == n) return ORC_OK;
+  const T* v = (const T*)a->values;
+  T acc = kind == G_SUM_CHECKED ? T(0) : T(1);
+  for (int64_t i = 0; i < n; ++i) {
+    if (a->validity && !get_bit(a->validity, a->validity_bit_offset + i)) continue;
+    if constexpr (std::is_floating_point<T>::value) {
+      acc = kind == G_SUM_CHECKED ? acc + v[i] : acc * v[i];  // float *_checked never fails
+    } else {
+      T r;
+      int32_t st = int_checked<T>(kind == G_SUM_CHECKED ? OP_ADD : OP_MUL, acc, v[i], &r);
+      if (st != ORC_OK) return st;
+      acc = r;
+    }
+  }
+  store_scalar<T>(out, acc);
+  return ORC_OK;
+}
+
+// bit_and / bit_or / bit_xor (:776-873)
+template <typename T> int32_t aggregate_bits(int kind, const orc_view* a, orc_scalar* out) {
+  const int64_t nulls = resolve_nulls(a), n = a->length;
+  if (nulls == n) return ORC_OK;
+  using U = typename std::make_unsigned<T>::type;
+  const U* v = (const U*)a->values;
+  U r = kind == G_BIT_AND ? (U)~(U)0 : (U)0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (a->validity && !get_bit(a->validity, a->validity_bit_offset + i)) continue;
+    r = kind == G_BIT_AND ? (U)(r & v[i]) : kind == G_BIT_OR ? (U)(r | v[i]) : (U)(r ^ v[i]);
+  }
+  store_scalar<U>(out, r);
+  return ORC_OK;
+}
+
+template <typename T> int32_t aggregate_dispatch(int op, const orc_view* a, int vb, orc_scalar* out) {
+  switch (op) {
+    case G_SUM: return aggregate_numeric<T, G_SUM>(a, vb, out);
+    case G_PRODUCT: return aggregate_numeric<T, G_PRODUCT>(a, vb, out);
+    case G_MIN: return aggregate_numeric<T, G_MIN>(a, vb, out);
+    case G_MAX: return aggregate_numeric<T, G_MAX>(a, vb, out);
+    case G_SUM_CHECKED: case G_PRODUCT_CHECKED: return aggregate_checked<T>(op, a, out);
+    default:
+      if constexpr (std::is_integral<T>::value) return aggregate_bits<T>(op, a, out);
+      return fail(ORC_INVALID_ARGUMENT, "bitwise aggregates need an integer type");
+  }
+}
+
+// min_boolean / max_boolean (= bool_and / bool_or) (:372-457, :880-889)
+int32_t aggregate_boolean(int op, const orc_view* a, orc_scalar* out) {
+  const int64_t nulls = resolve_nulls(a), n = a->length;
+  if (nulls == n) return ORC_OK;
+  const uint8_t* v = (const uint8_t*)a->values;
+  bool any_true = false, any_false = false;
+  for (int64_t i = 0; i < n; ++i) {
+    if (a->validity && !get_bit(a->validity, a->validity_bit_offset + i)) continue;
+    if (get_bit(v, a->values_bit_offset + i)) any_true = true;
+    else any_false = true;
+  }
+  if (op == G_MIN) store_scalar<uint8_t>(out, any_false ? 0 : 1);
+  else if (op == G_MAX) store_scalar<uint8_t>(out, any_true ? 1 : 0);
+  else return fail(ORC_INVALID_ARGUMENT, "only min/max (bool_and/bool_or) aggregate a BooleanArray");
+  return ORC_OK;
+}
+
 }  // namespace
 
 // =================================================================== exports
@@ -1667,6 +1839,26 @@ int32_t orc_cast(const orc_view* in, int32_t to, int32_t safe, orc_out* out) {
     case ORC_FLOAT64: return cast_from<double>(in, to, safe, out);
   }
   return fail(ORC_CAST_ERROR, "Casting from %s to %s not supported", type_name(in->type), type_name(to));
+}
+
+int32_t orc_aggregate(int32_t op, const orc_view* a, int32_t vector_bytes, orc_scalar* out) {
+  memset(out, 0, sizeof *out);
+  out->type = a->type;
+  const int vb = vector_bytes ? vector_bytes : 16;
+  switch (a->type) {
+    case ORC_BOOL: return aggregate_boolean(op, a, out);
+    case ORC_INT8: return aggregate_dispatch<int8_t>(op, a, vb, out);
+    case ORC_INT16: return aggregate_dispatch<int16_t>(op, a, vb, out);
+    case ORC_INT32: return aggregate_dispatch<int32_t>(op, a, vb, out);
+    case ORC_INT64: return aggregate_dispatch<int64_t>(op, a, vb, out);
+    case ORC_UINT8: return aggregate_dispatch<uint8_t>(op, a, vb, out);
+    case ORC_UINT16: return aggregate_dispatch<uint16_t>(op, a, vb, out);
+    case ORC_UINT32: return aggregate_dispatch<uint32_t>(op, a, vb, out);
+    case ORC_UINT64: return aggregate_dispatch<uint64_t>(op, a, vb, out);
+    case ORC_FLOAT32: return aggregate_dispatch<float>(op, a, vb, out);
+    case ORC_FLOAT64: return aggregate_dispatch<double>(op, a, vb, out);
+  }
+  return fail(ORC_NOT_YET_IMPLEMENTED, "aggregate of %s", type_name(a->type));
 }
 
 // concat for primitives / booleans (arrow-select/src/concat.rs:334-343, :495)

@@ -92,6 +92,17 @@ int32_t orc_nullif(const orc_view* left, const orc_view* right, orc_out* out);
 int32_t orc_cast(const orc_view* values, int32_t to_type, int32_t safe, orc_out* out);
 int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out);
 
+/* arrow_arith::aggregate (arrow-arith/src/aggregate.rs): op numbering as AH_AGG_*.
+ * `vector_bytes` is the reference's compile-time PREFERRED_VECTOR_SIZE (:300-307): 16 for the
+ * default x86_64 target, 32 with AVX, 64 with AVX-512; 0 = 16.  It only changes the association
+ * order of FLOAT sums/products (every other result is order-independent). */
+typedef struct orc_scalar {
+  int32_t type;
+  int32_t is_valid; /* 0 = None */
+  uint8_t bytes[32];
+} orc_scalar;
+int32_t orc_aggregate(int32_t op, const orc_view* values, int32_t vector_bytes, orc_scalar* out);
+
 /* format one f64/f32 the way ryu::Buffer::format does; returns the length */
 int32_t orc_format_f64(double v, char* buf /* >= 32 */);
 int32_t orc_format_f32(float v, char* buf /* >= 32 */);

@@ -162,5 +162,25 @@ int main() {
     assert(bad);
   }
 
+  // aggregates (aggregate.rs:1039-1118, :1315)
+  {
+    std::vector<bool> nv{false, true, true, false, true};
+    auto an = upload<int32_t>(ctx, AH_INT32, {0, 2, 3, 0, 5}, &nv, keep);
+    assert(compute::sum<int32_t>(an).value() == 10 && compute::product<int32_t>(an).value() == 30);
+    assert(compute::min<int32_t>(an).value() == 2 && compute::max<int32_t>(an).value() == 5);
+    std::vector<bool> none{false, false, false};
+    auto alln = upload<int32_t>(ctx, AH_INT32, {1, 2, 3}, &none, keep);
+    assert(!compute::sum<int32_t>(alln).has_value());
+    auto big = upload<int32_t>(ctx, AH_INT32, {2147483647, 2}, nullptr, keep);
+    assert(compute::product<int32_t>(big).value() == -2);
+    bool ov = false;
+    try {
+      compute::product_checked<int32_t>(big);
+    } catch (const ArrowError& e) {
+      ov = std::string(e.what()) == "Arithmetic overflow: Overflow happened on: 2147483647 * 2";
+    }
+    assert(ov);
+  }
+
   return 0;
 }

@@ -316,7 +316,103 @@ bool_cases.append(dict(name="test_nullif_string", source="arrow-select/src/nulli
                        lhs=arr("Utf8", ["hello", N, "world", "a", "b"]), rhs=arr("Boolean", [T, T, F, T, N]),
                        expected=arr("Utf8", [N, N, "world", N, "b"])))
 
-for name, cases in [("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
+
+# ---------------------------------------------------------------- aggregate (arrow-arith/src/aggregate.rs tests)
+agg_cases = []
+A_ = "arrow-arith/src/aggregate.rs"
+
+
+def agg(name, line, op, values, expected, **kw):
+    agg_cases.append(dict(name=name, source=f"{A_}:{line}", op=op, values=values, expected=expected, **kw))
+
+
+agg("test_primitive_array_sum", 1039, "sum", arr("Int32", [1, 2, 3, 4, 5]), 15)
+agg("test_primitive_array_float_sum", 1045, "sum", arr("Float64", [1.1, 2.2, 3.3, 4.4, 5.5]), 16.5)
+agg("test_primitive_array_product", 1051, "product", arr("Int32", [1, 2, 3, 4, 5]), 120)
+agg("test_primitive_array_float_product", 1057, "product", arr("Float64", [1.0, 2.0, 3.0, 4.0, 5.0]), 120.0)
+agg("test_primitive_array_product_with_nulls", 1063, "product", arr("Int32", [N, 2, 3, N, 5]), 30)
+agg("test_primitive_array_product_all_nulls", 1069, "product", arr("Int32", [N, N, N]), None)
+agg("test_primitive_array_product_empty", 1075, "product", arr("Int32", []), None)
+agg("test_primitive_array_product_checked", 1081, "product_checked", arr("Int32", [1, 2, 3, 4, 5]), 120)
+agg("test_primitive_array_product_checked_with_nulls", 1087, "product_checked", arr("Int32", [N, 2, 3, N, 5]), 30)
+agg("test_primitive_array_product_checked_all_nulls", 1093, "product_checked", arr("Int32", [N, N, N]), None)
+agg("test_product_overflow", 1099, "product", arr("Int32", [2147483647, 2]), -2)
+agg("test_product_checked_overflow", 1106, "product_checked", arr("Int32", [2147483647, 2]), None,
+    error="ArithmeticOverflow", message="Overflow happened on: 2147483647 * 2")
+agg("test_primitive_array_sum_with_nulls", 1112, "sum", arr("Int32", [N, 2, 3, N, 5]), 10)
+agg("test_primitive_array_sum_all_nulls", 1118, "sum", arr("Int32", [N, N, N]), None)
+third = [bool(x % 3 == 0) for x in range(1, 101)]
+for t, line in (("Float64", 1124), ("Float32", 1139), ("Int64", 1154), ("Int32", 1166), ("Int16", 1177)):
+    fl = t.startswith("Float")
+    vals = [float(x) if fl else x for x in range(1, 101)]
+    agg(f"test_primitive_array_sum_large_{t}", line, "sum", arr(t, vals), float(5050) if fl else 5050)
+    # "non-zero values at the invalid indices": raw values + validity
+    tot = sum(x for x in range(1, 101) if x % 3 == 0)
+    agg(f"test_primitive_array_sum_large_{t}_nullable", line, "sum", dict(type=t, raw=vals, valid=third),
+        float(tot) if fl else tot)
+agg("test_primitive_array_sum_large_8", 1188, "sum", arr("UInt8", list(range(1, 101))), 5050 % 256)
+agg("test_primitive_array_sum_large_8_nullable", 1188, "sum", dict(type="UInt8", raw=list(range(1, 101)), valid=third),
+    sum(x for x in range(1, 101) if x % 3 == 0) % 256)
+agg("test_primitive_array_bit_and", 1211, "bit_and", arr("Int32", [1, 2, 3, 4, 5]), 0)
+agg("test_primitive_array_bit_and_with_nulls", 1217, "bit_and", arr("Int32", [N, 2, 3, N, N]), 2)
+agg("test_primitive_array_bit_and_all_nulls", 1223, "bit_and", arr("Int32", [N, N, N]), None)
+agg("test_primitive_array_bit_or", 1229, "bit_or", arr("Int32", [1, 2, 3, 4, 5]), 7)
+agg("test_primitive_array_bit_or_with_nulls", 1235, "bit_or", arr("Int32", [N, 2, 3, N, 5]), 7)
+agg("test_primitive_array_bit_or_all_nulls", 1241, "bit_or", arr("Int32", [N, N, N]), None)
+agg("test_primitive_array_bit_xor", 1247, "bit_xor", arr("Int32", [1, 2, 3, 4, 5]), 1)
+agg("test_primitive_array_bit_xor_with_nulls", 1253, "bit_xor", arr("Int32", [N, 2, 3, N, 5]), 4)
+agg("test_primitive_array_bit_xor_all_nulls", 1259, "bit_xor", arr("Int32", [N, N, N]), None)
+agg("test_primitive_array_bool_and", 1265, "min", arr("Boolean", [T, F, T, F, T]), False)
+agg("test_primitive_array_bool_and_with_nulls", 1271, "min", arr("Boolean", [N, T, T, N, T]), True)
+agg("test_primitive_array_bool_and_all_nulls", 1277, "min", arr("Boolean", [N, N, N]), None)
+agg("test_primitive_array_bool_or", 1283, "max", arr("Boolean", [T, F, T, F, T]), True)
+agg("test_primitive_array_bool_or_with_nulls", 1289, "max", arr("Boolean", [N, F, F, N, F]), False)
+agg("test_primitive_array_bool_or_all_nulls", 1295, "max", arr("Boolean", [N, N, N]), None)
+for op, want in (("min", 5), ("max", 9)):
+    agg(f"test_primitive_array_min_max_{op}", 1301, op, arr("Int32", [5, 6, 7, 8, 9]), want)
+    agg(f"test_primitive_array_min_max_with_nulls_{op}", 1308, op, arr("Int32", [5, N, N, 8, 9]), want)
+agg("test_primitive_min_max_1_min", 1315, "min", arr("Int32", [N, N, 5, 2]), 2)
+agg("test_primitive_min_max_1_max", 1315, "max", arr("Int32", [N, N, 5, 2]), 5)
+f256 = [float(i + 1) for i in range(256)]
+agg("float_large_nonnull_min", 1322, "min", arr("Float64", f256), 1.0)
+agg("float_large_nonnull_max", 1322, "max", arr("Float64", f256), 256.0)
+agg("float_large_nonnull_max_255", 1322, "max", arr("Float64", f256[:255]), 255.0)
+agg("float_large_nonnull_max_257", 1322, "max", arr("Float64", f256 + [257.0]), 257.0)
+n3 = [None if (i + 1) % 3 == 0 else float(i + 1) for i in range(256)]
+agg("float_large_nullable_min", 1336, "min", arr("Float64", n3), 1.0)
+agg("float_large_nullable_max", 1336, "max", arr("Float64", n3), 256.0)
+edge = [None if i in (0, 255) else float(i + 1) for i in range(256)]
+agg("float_large_nullable_boundary_nulls_min", 1350, "min", arr("Float64", edge), 2.0)
+agg("float_large_nullable_boundary_nulls_max", 1350, "max", arr("Float64", edge), 255.0)
+single = [float(i) if i == 100 else None for i in range(256)]
+agg("float_large_nullable_single_min", 1363, "min", arr("Float64", single), 100.0)
+agg("float_large_nullable_single_max", 1363, "max", arr("Float64", single), 100.0)
+for nm, v in (("neg_inf", "-inf"), ("f64_min", -1.7976931348623157e308), ("f64_max", 1.7976931348623157e308), ("inf", "inf")):
+    for op in ("min", "max"):
+        agg(f"float_edge_{nm}_{op}", 1381, op, arr("Float64", [v] * 100), v)
+for op in ("min", "max"):
+    agg(f"float_all_nans_{op}", 1400, op, arr("Float64", ["nan"] * 100), "nan")
+# test_primitive_min_max_float_negative_nan (:1407): max is +NaN, min is -NaN (total order)
+agg("float_negative_nan_max", 1407, "max", arr("Float64", ["-inf", "nan", "inf", "-nan"]), "nan")
+agg("float_negative_nan_min", 1407, "min", arr("Float64", ["-inf", "nan", "inf", "-nan"]), "-nan")
+first = ["nan"] + [float(i) for i in range(1, 100)]
+last = [float(i + 1) for i in range(99)] + ["nan"]
+agg("float_first_nan_nonnull_min", 1420, "min", arr("Float64", first), 1.0)
+agg("float_first_nan_nonnull_max", 1420, "max", arr("Float64", first), "nan")
+agg("float_last_nan_nonnull_min", 1435, "min", arr("Float64", last), 1.0)
+agg("float_last_nan_nonnull_max", 1435, "max", arr("Float64", last), "nan")
+firstn = ["nan" if i == 0 else (None if i % 2 == 0 else float(i)) for i in range(100)]
+lastn = ["nan" if i == 99 else (None if i % 2 == 0 else float(i)) for i in range(100)]
+agg("float_first_nan_nullable_min", 1450, "min", arr("Float64", firstn), 1.0)
+agg("float_first_nan_nullable_max", 1450, "max", arr("Float64", firstn), "nan")
+agg("float_last_nan_nullable_min", 1467, "min", arr("Float64", lastn), 1.0)
+agg("float_last_nan_nullable_max", 1467, "max", arr("Float64", lastn), "nan")
+mix = [{0: "-inf", 1: -1.7976931348623157e308, 2: 1.7976931348623157e308, 4: "inf", 5: "nan"}.get(i % 10, float(i))
+       for i in range(100)]
+agg("float_inf_and_nans_min", 1484, "min", arr("Float64", mix), "-inf")
+agg("float_inf_and_nans_max", 1484, "max", arr("Float64", mix), "nan")
+
+for name, cases in [("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
                     ("cast", cast_cases)]:
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump({"reference": "apache/arrow-rs 59.2.0", "cases": cases}, f, indent=1)

@@ -122,6 +122,20 @@ class _Held:
         self.view = v
 
 
+class ScalarOut(C.Structure):
+    """orc_scalar / ah_scalar (identical layout)."""
+    _fields_ = [("type", C.c_int32), ("is_valid", C.c_int32), ("bytes", C.c_uint8 * 32)]
+
+    def value(self, np_dtype):
+        if not self.is_valid:
+            return None
+        return np.frombuffer(bytes(self.bytes), dtype=np_dtype, count=1)[0]
+
+
+AGG_OPS = {"sum": 0, "sum_checked": 1, "product": 2, "product_checked": 3, "min": 4, "max": 5,
+           "bit_and": 6, "bit_or": 7, "bit_xor": 8}
+
+
 class Oracle:
     def __init__(self, lib):
         self.lib = lib
@@ -138,6 +152,7 @@ class Oracle:
         lib.orc_boolean_unary.argtypes = [C.c_int32, VP, OP]
         lib.orc_nullif.argtypes = [VP, VP, OP]
         lib.orc_concat.argtypes = [C.c_int32, VP, OP]
+        lib.orc_aggregate.argtypes = [C.c_int32, VP, C.c_int32, C.POINTER(ScalarOut)]
         lib.orc_count_set_bits.restype = C.c_int64
         lib.orc_count_set_bits.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
         for f in (lib.orc_set_slices, lib.orc_set_indices):
@@ -259,6 +274,16 @@ class Oracle:
         if st:
             self._raise(st)
         return self._collect(out, left.data_type)
+
+    def aggregate(self, op, values, vector_bytes=0, bit_offset=0):
+        """arrow_arith::aggregate::{sum,min,max,...}: numpy scalar or None."""
+        hv = _Held(values, bit_offset)
+        out = ScalarOut()
+        st = self.lib.orc_aggregate(AGG_OPS[op] if isinstance(op, str) else op, C.byref(hv.view), vector_bytes,
+                                    C.byref(out))
+        if st:
+            self._raise(st)
+        return out.value(np.uint8 if values.data_type.physical == L.AH_BOOL else values.data_type.np_dtype)
 
     def concat(self, arrays):
         held = [_Held(a) for a in arrays]

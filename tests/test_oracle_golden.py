@@ -407,3 +407,27 @@ def test_fuzz_string_filter_take_vs_model(oracle):
     with pytest.raises(A.Panic) as ei:
         oracle.take(HostArray(A.Utf8, ["a", "b"]), HostArray(A.UInt32, np.array([7], dtype=np.uint32)))
     assert str(ei.value) == "index out of bounds: the len is 3 but the index is 7"
+
+
+# ---------------------------------------------------------------- aggregate
+def _same_scalar(got, want, dt):
+    """Bitwise for floats (NaN sign matters: total order), plain equality otherwise."""
+    if want is None or got is None:
+        return got is None and want is None
+    if isinstance(want, str):
+        want = float(want)
+    w = np.array([want]).astype(np.uint8 if dt.physical == A._lib.AH_BOOL else dt.np_dtype)
+    if w.dtype.kind == "f" and np.isnan(w[0]):  # golden says "nan" / "-nan": class + sign, not payload
+        return bool(np.isnan(got)) and bool(np.signbit(got)) == bool(np.signbit(w[0]))
+    return w.tobytes() == np.array([got]).astype(w.dtype).tobytes()
+
+
+@pytest.mark.parametrize("case", load_golden("aggregate"), ids=lambda c: c["name"])
+@pytest.mark.parametrize("bit_offset", [0, 5])
+@pytest.mark.parametrize("vector_bytes", [16, 32, 64])
+def test_aggregate_golden(oracle, case, bit_offset, vector_bytes):
+    v = golden_array(case["values"])
+    if "error" in case:
+        return expect_err(case, lambda: oracle.aggregate(case["op"], v, vector_bytes, bit_offset))
+    got = oracle.aggregate(case["op"], v, vector_bytes, bit_offset)
+    assert _same_scalar(got, case["expected"], v.data_type), (got, case["expected"])
