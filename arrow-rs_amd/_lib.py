@@ -29,6 +29,7 @@ AH_BOOL, AH_INT8, AH_INT16, AH_INT32, AH_INT64 = 1, 2, 3, 4, 5
 AH_UINT8, AH_UINT16, AH_UINT32, AH_UINT64 = 6, 7, 8, 9
 AH_FLOAT32, AH_FLOAT64, AH_FIXED16, AH_FIXED32 = 10, 11, 12, 13
 AH_UTF8, AH_LARGE_UTF8, AH_FLOAT16 = 14, 15, 16
+AH_UTF8_VIEW, AH_BINARY_VIEW = 17, 18
 
 AH_OUT_BORROWED = 1
 

@@ -121,7 +121,7 @@ class DataType:
 
     @property
     def width(self):
-        return {L.AH_BOOL: 0, L.AH_FIXED16: 16, L.AH_FIXED32: 32}.get(
+        return {L.AH_BOOL: 0, L.AH_FIXED16: 16, L.AH_FIXED32: 32, L.AH_UTF8_VIEW: 16, L.AH_BINARY_VIEW: 16}.get(
             self.physical, np.dtype(self.np_dtype).itemsize if self.np_dtype is not None else -1)
 
     def is_primitive(self):
@@ -142,6 +142,12 @@ Float32 = DataType("Float32", L.AH_FLOAT32, np.float32)
 Float64 = DataType("Float64", L.AH_FLOAT64, np.float64)
 Utf8 = DataType("Utf8", L.AH_UTF8, None)
 LargeUtf8 = DataType("LargeUtf8", L.AH_LARGE_UTF8, None)
+# ByteView (arrow-data/src/byte_view.rs): u128 = length:i32 | prefix:4 bytes | buffer_index:i32 | offset:i32,
+# or length + up to 12 inlined bytes
+_VIEW = np.dtype([("length", "<i4"), ("prefix", "<u4"), ("buffer_index", "<i4"), ("offset", "<i4")])
+Utf8View = DataType("Utf8View", L.AH_UTF8_VIEW, _VIEW)
+BinaryView = DataType("BinaryView", L.AH_BINARY_VIEW, _VIEW)
+MAX_INLINE_VIEW_LEN = 12
 # logical types over the same physical layouts (the 14 temporal types of
 # filter.rs:1090-1174 and the Duration/Decimal128 cases of take.rs:1263-1625)
 Date32 = DataType("Date32", L.AH_INT32, np.int32)
@@ -318,6 +324,7 @@ class Array:
         self.validity_bit_offset = int(validity_bit_offset)
         self._null_count = int(null_count)
         self.offsets = offsets          # _RawMem or None (strings)
+        self.data_buffers = None        # view arrays: the variadic data buffers (list of DeviceBuffer)
 
     # ---- construction from host data
     @classmethod
@@ -385,6 +392,43 @@ class Array:
                    bit_offset if nmem else 0, nulls, _RawMem(ob.ptr, ob.nbytes, ob))
 
     @classmethod
+    def from_string_views(cls, items, data_type=None, ctx=None, bit_offset=0, block_size=8192):
+        """StringViewArray / BinaryViewArray from str / bytes / None items, built the way
+        GenericByteViewBuilder does (byte_view_array.rs:81-133): values <= 12 bytes are inlined, longer ones
+        are appended to data blocks of ``block_size`` bytes and referenced by (buffer_index, offset)."""
+        ctx = ctx or default_context()
+        data_type = data_type or Utf8View
+        views = np.zeros(len(items), dtype=_VIEW)
+        raw = views.view(np.uint8).reshape(len(items), 16)
+        blocks, cur = [], bytearray()
+        for i, it in enumerate(items):
+            if it is None:
+                continue
+            b = it.encode() if isinstance(it, str) else bytes(it)
+            views["length"][i] = len(b)
+            if len(b) <= MAX_INLINE_VIEW_LEN:
+                raw[i, 4:4 + len(b)] = np.frombuffer(b, dtype=np.uint8)
+            else:
+                if len(cur) + len(b) > block_size and cur:
+                    blocks.append(bytes(cur))
+                    cur = bytearray()
+                raw[i, 4:8] = np.frombuffer(b[:4], dtype=np.uint8)
+                views["buffer_index"][i] = len(blocks)
+                views["offset"][i] = len(cur)
+                cur += b
+        if cur:
+            blocks.append(bytes(cur))
+        valid = np.array([x is not None for x in items], dtype=bool) if any(x is None for x in items) else None
+        vb = DeviceBuffer.from_numpy(ctx, views.view(np.uint8))
+        nmem, nulls = None, 0
+        if valid is not None:
+            nb = DeviceBuffer.from_numpy(ctx, pack_bits(valid, bit_offset))
+            nmem, nulls = _RawMem(nb.ptr, nb.nbytes, nb), int(len(items) - valid.sum())
+        arr = cls(ctx, data_type, len(items), _RawMem(vb.ptr, vb.nbytes, vb), 0, nmem, bit_offset if nmem else 0, nulls)
+        arr.data_buffers = [DeviceBuffer.from_numpy(ctx, np.frombuffer(b, dtype=np.uint8)) for b in blocks]
+        return arr
+
+    @classmethod
     def _from_out(cls, ctx, out, data_type, keepalive=()):
         owner = _OutOwner(ctx, out, keepalive)
         vals = _RawMem(out.values, out.values_bytes, owner) if out.values else None
@@ -393,6 +437,10 @@ class Array:
         arr = cls(ctx, data_type, out.length, vals, out.values_bit_offset, nmem,
                   out.validity_bit_offset, out.null_count, offs)
         arr._owner = owner
+        if data_type.physical in (L.AH_UTF8_VIEW, L.AH_BINARY_VIEW):
+            # filter_byte_view / take_byte_view: same buffer list on the result (filter.rs:937, take.rs:638)
+            src = next((k for k in keepalive if getattr(k, "data_buffers", None) is not None), None)
+            arr.data_buffers = src.data_buffers if src is not None else []
         return arr
 
     # ---- Arrow C Data Interface / pyarrow (arrow-array/src/ffi.rs:231-254, arrow-pyarrow/src/lib.rs:199-257)
@@ -447,8 +495,10 @@ class Array:
                                                           self.validity_bit_offset + offset, length,
                                                           C.byref(cnt)))
             nulls = length - cnt.value
-        return Array(self.ctx, self.data_type, length, vals, vbo, self.validity,
-                     self.validity_bit_offset + offset if self.validity else 0, nulls, offs)
+        out = Array(self.ctx, self.data_type, length, vals, vbo, self.validity,
+                    self.validity_bit_offset + offset if self.validity else 0, nulls, offs)
+        out.data_buffers = self.data_buffers
+        return out
 
     def view(self):
         """The ah_array_view handed to the C ABI."""
@@ -496,6 +546,19 @@ class Array:
             return [data[offs[i] - base:offs[i + 1] - base].decode() for i in range(self.length)]
         w = self.data_type.width
         raw = _copy_dtoh(self.ctx, self.values.ptr, self.length * w)
+        if p in (L.AH_UTF8_VIEW, L.AH_BINARY_VIEW):  # value_unchecked (byte_view_array.rs:337-352)
+            views = raw.view(_VIEW)
+            bufs = [b.to_numpy().tobytes() for b in (self.data_buffers or [])]
+            out = []
+            for i in range(self.length):
+                n = int(views["length"][i])
+                if n <= MAX_INLINE_VIEW_LEN:
+                    b = raw[i * 16 + 4:i * 16 + 4 + n].tobytes()
+                else:
+                    o = int(views["offset"][i])
+                    b = bufs[int(views["buffer_index"][i])][o:o + n]
+                out.append(b.decode() if p == L.AH_UTF8_VIEW else b)
+            return out
         return raw.view(self.data_type.np_dtype)
 
     def to_pylist(self):

@@ -22,7 +22,7 @@ def take(values, indices, options=None):
     vv, iv = values.view(), indices.view()
     ctx.check(ctx.lib.ah_take(ctx.handle, C.byref(vv), C.byref(iv), 1 if options.check_bounds else 0,
                               C.byref(out)))
-    return Array._from_out(ctx, out, values.data_type)
+    return Array._from_out(ctx, out, values.data_type, keepalive=(values,) if values.data_buffers is not None else ())
 
 
 def take_arrays(arrays, indices, options=None):

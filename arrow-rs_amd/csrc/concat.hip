@@ -18,7 +18,8 @@ extern "C" ah_status ah_concat(ah_context* ctx, int32_t n, const ah_array_view* 
   if (n <= 0) return ah_fail(ctx, AH_INVALID_ARGUMENT, "concat requires input of at least one array");
   const ah_type t = pieces[0].type;
   const int w = ah_type_width(t);
-  if (w < 0) return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "concat not supported for type %s", ah_type_name(t));
+  if (w < 0 || t == AH_UTF8_VIEW || t == AH_BINARY_VIEW)  // views: buffer indices would need renumbering
+    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "concat not supported for type %s", ah_type_name(t));
   int64_t total = 0;
   bool any_nulls = false;
   for (int i = 0; i < n; ++i) {

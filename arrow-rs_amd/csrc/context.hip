@@ -21,7 +21,7 @@ int ah_type_width(ah_type t) {
     case AH_INT16: case AH_UINT16: case AH_FLOAT16: return 2;
     case AH_INT32: case AH_UINT32: case AH_FLOAT32: return 4;
     case AH_INT64: case AH_UINT64: case AH_FLOAT64: return 8;
-    case AH_FIXED16: return 16;
+    case AH_FIXED16: case AH_UTF8_VIEW: case AH_BINARY_VIEW: return 16;
     case AH_FIXED32: return 32;
     default: return -1;
   }
@@ -37,6 +37,7 @@ const char* ah_type_name(ah_type t) {
     case AH_FLOAT64: return "Float64";
     case AH_FIXED16: return "FixedWidth16"; case AH_FIXED32: return "FixedWidth32";
     case AH_UTF8: return "Utf8"; case AH_LARGE_UTF8: return "LargeUtf8";
+    case AH_UTF8_VIEW: return "Utf8View"; case AH_BINARY_VIEW: return "BinaryView";
     default: return "?";
   }
 }

@@ -73,7 +73,12 @@ enum {
   AH_FIXED32 = 13, /* 32-byte natives: i256 / Decimal256 */
   AH_UTF8 = 14,       /* i32 offsets: output of cast; input/output of filter, take */
   AH_LARGE_UTF8 = 15, /* i64 offsets */
-  AH_FLOAT16 = 16     /* filter/take/concat only (bit copy) */
+  AH_FLOAT16 = 16,    /* filter/take/concat only (bit copy); min/max aggregates */
+  /* GenericByteViewArray (arrow-array/src/array/byte_view_array.rs): `values` = the 16-byte views.
+   * filter / take / nullif copy views unchanged and the host keeps the SAME variadic data-buffer list
+   * on the result (filter.rs:931-944 `filter_byte_view`, take.rs:630-640 `take_byte_view`), so the data
+   * buffers never enter the C ABI.  concat is refused (it would have to renumber buffer indices). */
+  AH_UTF8_VIEW = 17, AH_BINARY_VIEW = 18
 };
 
 /* Borrowed view of a PrimitiveArray / BooleanArray living in HBM
