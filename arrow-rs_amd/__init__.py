@@ -10,5 +10,6 @@ from .array import (Array, Scalar, RecordBatch, Context, DeviceBuffer, DataType,
                     default_context, set_default_context, pack_bits, unpack_bits, Panic, HipError)
 from . import compute  # noqa: F401
 from . import ffi  # noqa: F401
+from . import ipc  # noqa: F401
 
 __version__ = "0.1.0"

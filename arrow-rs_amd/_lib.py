@@ -20,6 +20,8 @@ AH_OFFSET_OVERFLOW = 6
 AH_NOT_YET_IMPLEMENTED = 7
 AH_OFFSET_OVERFLOW_ERROR = 8
 AH_C_DATA_INTERFACE = 9
+AH_IPC_ERROR = 10
+AH_PARSE_ERROR = 11
 AH_PANIC = 100
 AH_HIP_ERROR = 101
 AH_OUT_OF_MEMORY = 102
@@ -69,6 +71,11 @@ class ArrayOut(C.Structure):
 class Scalar(C.Structure):
     """ah_scalar / orc_scalar (identical layout)."""
     _fields_ = [("type", C.c_int32), ("is_valid", C.c_int32), ("bytes", C.c_uint8 * 32)]
+
+
+class IpcField(C.Structure):
+    """ah_ipc_field"""
+    _fields_ = [("name", C.c_char_p), ("format", C.c_char_p), ("nullable", C.c_int32)]
 
 
 class FFI_ArrowSchema(C.Structure):
@@ -145,6 +152,14 @@ SIGNATURES = {
     "ah_gen_bernoulli_bits": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_double, C.c_int64]),
     "ah_zero_null_slots": (C.c_int32, [_P, _P, C.c_int32, _P, C.c_int64]),
     "ah_aggregate": (C.c_int32, [_P, C.c_int32, _VIEW, C.POINTER(Scalar)]),
+    "ah_ipc_schema_message": (C.c_int32, [_P, C.c_int32, C.POINTER(IpcField), C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "ah_ipc_decode_schema": (C.c_int32, [_P, C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.POINTER(IpcField))]),
+    "ah_ipc_encode_batch": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int64, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64),
+                                        C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "ah_ipc_decode_batch": (C.c_int32, [_P, C.c_char_p, C.c_int64, _P, C.c_int64, C.c_int32, C.POINTER(IpcField), _OUT,
+                                        C.POINTER(C.c_int64)]),
+    "ah_ipc_message_info": (C.c_int32, [_P, C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "ah_host_free": (None, [_P]),
     "ah_type_from_format": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int32)]),
     "ah_format_of_type": (C.c_char_p, [C.c_int32]),
     "ah_import_c_data": (C.c_int32, [_P, C.POINTER(FFI_ArrowArray), C.POINTER(FFI_ArrowSchema), _OUT]),

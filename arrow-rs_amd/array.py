@@ -63,6 +63,14 @@ class CDataInterfaceError(ArrowError):
     variant, prefix = "CDataInterface", "C Data interface error: "
 
 
+class IpcError(ArrowError):
+    variant, prefix = "IpcError", "Ipc error: "
+
+
+class ParseError(ArrowError):
+    variant, prefix = "ParseError", "Parser error: "
+
+
 class NotYetImplemented(ArrowError):
     variant, prefix = "NotYetImplemented", "Not yet implemented: "
 
@@ -85,6 +93,8 @@ _STATUS = {
     L.AH_NOT_YET_IMPLEMENTED: NotYetImplemented,
     L.AH_OFFSET_OVERFLOW_ERROR: OffsetOverflowError,
     L.AH_C_DATA_INTERFACE: CDataInterfaceError,
+    L.AH_IPC_ERROR: IpcError,
+    L.AH_PARSE_ERROR: ParseError,
     L.AH_OFFSET_OVERFLOW: Panic,
     L.AH_PANIC: Panic,
 }

@@ -1,0 +1,726 @@
+// Arrow IPC record-batch framing for device-resident batches.
+//
+// Reference: arrow-ipc/src/writer.rs — `IpcDataGenerator::record_batch_to_bytes` :1006-1075, `write_array_data`
+// :2364-2500 (validity always written, all-ones when absent :2383-2391; values truncated to the slice :2331-2346;
+// byte-array offsets rebased and data cut to the referenced range :2277-2290; Boolean bit_slice :2483-2489),
+// `encode_sink_buffer` :2657-2684 (each buffer padded to `alignment`), `MetadataLayout` :138-162 and
+// `write_continuation` :188-222 (0xFFFFFFFF + padded metadata length), schema encoding arrow-ipc/src/convert.rs;
+// arrow-ipc/src/reader.rs — `create_primitive_array` :264-297 (validity dropped when null_count == 0),
+// `read_buffer` :59-77, alignment fix-up `align_buffers` :301.  Flatbuffers layouts: format/Message.fbs,
+// format/Schema.fbs (flatc is not in this image: the tiny builder/reader below is hand-written).
+//
+// MI355X shape: the metadata (a few hundred bytes) is built on the host; the BODY is assembled in HBM — one
+// contiguous device buffer holding every column buffer at its aligned slot (D2D copies, funnel-shifted bitmaps,
+// rebased offsets) — so a batch leaves the GPU as ONE transfer (D2H, or one RCCL send), and an incoming body is
+// decoded by pointer arithmetic into zero-copy views of the received buffer.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------ flatbuffers: writer (grows downward)
+class FbBuilder {
+ public:
+  FbBuilder() : buf_(1024), head_(1024) {}
+  uint32_t size() const { return (uint32_t)(buf_.size() - head_); }
+  const uint8_t* data() const { return buf_.data() + head_; }
+
+  void prep(size_t sz, size_t additional) {
+    if (sz > minalign_) minalign_ = sz;
+    const size_t pad = (~(size() + additional) + 1) & (sz - 1);
+    ensure(pad + sz + additional);
+    head_ -= pad;
+    memset(buf_.data() + head_, 0, pad);
+  }
+  template <typename T> void push(T v) {
+    prep(sizeof(T), 0);
+    head_ -= sizeof(T);
+    memcpy(buf_.data() + head_, &v, sizeof(T));
+  }
+  uint32_t refer_to(uint32_t off) {
+    prep(4, 0);
+    return size() - off + 4;
+  }
+  uint32_t create_string(const std::string& s) {
+    prep(4, s.size() + 1);
+    ensure(s.size() + 1);
+    head_ -= s.size() + 1;
+    memcpy(buf_.data() + head_, s.c_str(), s.size() + 1);
+    push<uint32_t>((uint32_t)s.size());
+    return size();
+  }
+  uint32_t create_struct_vector(const void* p, size_t n, size_t elem, size_t align) {
+    prep(4, n * elem);
+    prep(align, n * elem);
+    ensure(n * elem);
+    head_ -= n * elem;
+    if (n) memcpy(buf_.data() + head_, p, n * elem);
+    push<uint32_t>((uint32_t)n);
+    return size();
+  }
+  uint32_t create_offset_vector(const std::vector<uint32_t>& offs) {
+    prep(4, offs.size() * 4);
+    for (size_t i = offs.size(); i-- > 0;) push<uint32_t>(refer_to(offs[i]));
+    push<uint32_t>((uint32_t)offs.size());
+    return size();
+  }
+  void start_table() {
+    fields_.clear();
+    obj_start_ = size();
+  }
+  template <typename T> void add_scalar(int id, T v, T def) {
+    if (v == def) return;
+    push<T>(v);
+    fields_.push_back({id, size()});
+  }
+  void add_offset(int id, uint32_t off) {
+    if (!off) return;
+    push<uint32_t>(refer_to(off));
+    fields_.push_back({id, size()});
+  }
+  uint32_t end_table() {
+    push<int32_t>(0);
+    const uint32_t table_off = size();
+    int max_id = -1;
+    for (auto& f : fields_) max_id = std::max(max_id, f.id);
+    const uint16_t vt_size = (uint16_t)(4 + 2 * (max_id + 1));
+    for (int id = max_id; id >= 0; --id) {
+      uint16_t off = 0;
+      for (auto& f : fields_)
+        if (f.id == id) off = (uint16_t)(table_off - f.off);
+      push<uint16_t>(off);
+    }
+    push<uint16_t>((uint16_t)(table_off - obj_start_));
+    push<uint16_t>(vt_size);
+    const int32_t so = (int32_t)(size() - table_off);
+    memcpy(buf_.data() + buf_.size() - table_off, &so, 4);
+    return table_off;
+  }
+  void finish(uint32_t root) {
+    prep(minalign_ < 8 ? 8 : minalign_, 4);
+    push<uint32_t>(refer_to(root));
+  }
+
+ private:
+  struct F {
+    int id;
+    uint32_t off;
+  };
+  void ensure(size_t need) {
+    if (head_ >= need) return;
+    const size_t old = buf_.size(), used = old - head_;
+    size_t cap = old * 2;
+    while (cap - used < need) cap *= 2;
+    std::vector<uint8_t> nb(cap);
+    memcpy(nb.data() + cap - used, buf_.data() + head_, used);
+    buf_.swap(nb);
+    head_ = cap - used;
+  }
+  std::vector<uint8_t> buf_;
+  size_t head_;
+  size_t minalign_ = 1;
+  std::vector<F> fields_;
+  uint32_t obj_start_ = 0;
+};
+
+// ------------------------------------------------------------------ flatbuffers: bounds-checked reader
+struct FbView {
+  const uint8_t* p;
+  size_t n;
+  bool ok = true;
+  template <typename T> T rd(size_t at) {
+    T v{};
+    if (at + sizeof(T) > n) {
+      ok = false;
+      return v;
+    }
+    memcpy(&v, p + at, sizeof(T));
+    return v;
+  }
+  size_t root() { return rd<uint32_t>(0); }
+  // position of field `id` inside the table at `t`, 0 if absent
+  size_t field(size_t t, int id) {
+    const int32_t so = rd<int32_t>(t);
+    const size_t vt = (size_t)((int64_t)t - so);
+    const uint16_t vts = rd<uint16_t>(vt);
+    if ((size_t)(4 + 2 * id) >= vts) return 0;
+    const uint16_t off = rd<uint16_t>(vt + 4 + 2 * id);
+    return off ? t + off : 0;
+  }
+  template <typename T> T scalar(size_t t, int id, T def) {
+    const size_t f = field(t, id);
+    return f ? rd<T>(f) : def;
+  }
+  size_t indirect(size_t t, int id) {  // table / vector / string position, 0 if absent
+    const size_t f = field(t, id);
+    return f ? f + rd<uint32_t>(f) : 0;
+  }
+  uint32_t vec_len(size_t v) { return v ? rd<uint32_t>(v) : 0; }
+  size_t vec_table(size_t v, uint32_t i) {
+    const size_t e = v + 4 + 4 * (size_t)i;
+    return e + rd<uint32_t>(e);
+  }
+  std::string str(size_t s) {
+    if (!s) return std::string();
+    const uint32_t len = rd<uint32_t>(s);
+    if (s + 4 + len > n) {
+      ok = false;
+      return std::string();
+    }
+    return std::string((const char*)p + s + 4, len);
+  }
+};
+
+// Schema.fbs `union Type` ordinals and friends
+enum { T_NONE = 0, T_Null, T_Int, T_FloatingPoint, T_Binary, T_Utf8, T_Bool, T_Decimal, T_Date, T_Time, T_Timestamp,
+       T_Interval, T_List, T_Struct, T_Union, T_FixedSizeBinary, T_FixedSizeList, T_Map, T_Duration, T_LargeBinary,
+       T_LargeUtf8, T_LargeList, T_RunEndEncoded, T_BinaryView, T_Utf8View };
+enum { H_NONE = 0, H_Schema = 1, H_DictionaryBatch = 2, H_RecordBatch = 3 };
+constexpr int16_t METADATA_V5 = 4;
+
+const char* const UNITS = "smun";  // TimeUnit SECOND, MILLISECOND, MICROSECOND, NANOSECOND
+
+// C-Data format string -> (Type ordinal, type table) — the schema language of this C ABI (arrow-schema/src/ffi.rs)
+ah_status type_from_format(ah_context* ctx, FbBuilder& b, const std::string& f, uint8_t* tt, uint32_t* toff) {
+  auto int_t = [&](int bits, bool sg) {
+    b.start_table();
+    b.add_scalar<int32_t>(0, bits, 0);
+    b.add_scalar<uint8_t>(1, sg, 0);
+    *tt = T_Int;
+    *toff = b.end_table();
+  };
+  auto empty = [&](uint8_t t) {
+    b.start_table();
+    *tt = t;
+    *toff = b.end_table();
+  };
+  auto unit_of = [&](char c, int16_t* u) {
+    const char* p = strchr(UNITS, c);
+    if (!p || !c) return false;
+    *u = (int16_t)(p - UNITS);
+    return true;
+  };
+  if (f == "c") return int_t(8, true), AH_OK;
+  if (f == "C") return int_t(8, false), AH_OK;
+  if (f == "s") return int_t(16, true), AH_OK;
+  if (f == "S") return int_t(16, false), AH_OK;
+  if (f == "i") return int_t(32, true), AH_OK;
+  if (f == "I") return int_t(32, false), AH_OK;
+  if (f == "l") return int_t(64, true), AH_OK;
+  if (f == "L") return int_t(64, false), AH_OK;
+  if (f == "e" || f == "f" || f == "g") {
+    b.start_table();
+    b.add_scalar<int16_t>(0, f == "e" ? 0 : f == "f" ? 1 : 2, 0);
+    *tt = T_FloatingPoint;
+    *toff = b.end_table();
+    return AH_OK;
+  }
+  if (f == "b") return empty(T_Bool), AH_OK;
+  if (f == "u") return empty(T_Utf8), AH_OK;
+  if (f == "U") return empty(T_LargeUtf8), AH_OK;
+  if (f == "z") return empty(T_Binary), AH_OK;
+  if (f == "Z") return empty(T_LargeBinary), AH_OK;
+  if (f == "tdD" || f == "tdm") {
+    b.start_table();
+    b.add_scalar<int16_t>(0, f == "tdD" ? 0 : 1, 1);
+    *tt = T_Date;
+    *toff = b.end_table();
+    return AH_OK;
+  }
+  int16_t u;
+  if (f.size() == 3 && f[0] == 't' && f[1] == 't' && unit_of(f[2], &u)) {
+    b.start_table();
+    b.add_scalar<int16_t>(0, u, 1);
+    b.add_scalar<int32_t>(1, u < 2 ? 32 : 64, 32);
+    *tt = T_Time;
+    *toff = b.end_table();
+    return AH_OK;
+  }
+  if (f.size() == 3 && f[0] == 't' && f[1] == 'D' && unit_of(f[2], &u)) {
+    b.start_table();
+    b.add_scalar<int16_t>(0, u, 1);
+    *tt = T_Duration;
+    *toff = b.end_table();
+    return AH_OK;
+  }
+  if (f.size() >= 4 && f[0] == 't' && f[1] == 's' && f[3] == ':' && unit_of(f[2], &u)) {
+    const std::string tz = f.substr(4);
+    const uint32_t tzo = tz.empty() ? 0 : b.create_string(tz);
+    b.start_table();
+    b.add_scalar<int16_t>(0, u, 0);
+    b.add_offset(1, tzo);
+    *tt = T_Timestamp;
+    *toff = b.end_table();
+    return AH_OK;
+  }
+  if (f == "tiM" || f == "tiD" || f == "tin") {
+    b.start_table();
+    b.add_scalar<int16_t>(0, f == "tiM" ? 0 : f == "tiD" ? 1 : 2, 0);
+    *tt = T_Interval;
+    *toff = b.end_table();
+    return AH_OK;
+  }
+  if (f.rfind("d:", 0) == 0) {
+    int p = 0, s = 0, bits = 128;
+    const int got = sscanf(f.c_str(), "d:%d,%d,%d", &p, &s, &bits);
+    if (got >= 2) {
+      b.start_table();
+      b.add_scalar<int32_t>(0, p, 0);
+      b.add_scalar<int32_t>(1, s, 0);
+      b.add_scalar<int32_t>(2, bits, 128);
+      *tt = T_Decimal;
+      *toff = b.end_table();
+      return AH_OK;
+    }
+  }
+  if (f.rfind("w:", 0) == 0) {
+    b.start_table();
+    b.add_scalar<int32_t>(0, atoi(f.c_str() + 2), 0);
+    *tt = T_FixedSizeBinary;
+    *toff = b.end_table();
+    return AH_OK;
+  }
+  return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "IPC encoding of the C Data format \"%s\"", f.c_str());
+}
+
+// type table -> C-Data format string
+ah_status format_from_type(ah_context* ctx, FbView& v, uint8_t tt, size_t t, std::string* out) {
+  switch (tt) {
+    case T_Int: {
+      const int bits = v.scalar<int32_t>(t, 0, 0);
+      const bool sg = v.scalar<uint8_t>(t, 1, 0);
+      const char* s = bits == 8 ? "cC" : bits == 16 ? "sS" : bits == 32 ? "iI" : bits == 64 ? "lL" : nullptr;
+      if (!s) return ah_fail(ctx, AH_IPC_ERROR, "Unexpected bit width %d for an Int type", bits);
+      *out = std::string(1, s[sg ? 0 : 1]);
+      return AH_OK;
+    }
+    case T_FloatingPoint: *out = std::string(1, "efg"[v.scalar<int16_t>(t, 0, 0) % 3]); return AH_OK;
+    case T_Bool: *out = "b"; return AH_OK;
+    case T_Utf8: *out = "u"; return AH_OK;
+    case T_LargeUtf8: *out = "U"; return AH_OK;
+    case T_Binary: *out = "z"; return AH_OK;
+    case T_LargeBinary: *out = "Z"; return AH_OK;
+    case T_Date: *out = v.scalar<int16_t>(t, 0, 1) == 0 ? "tdD" : "tdm"; return AH_OK;
+    case T_Time: *out = std::string("tt") + UNITS[v.scalar<int16_t>(t, 0, 1) & 3]; return AH_OK;
+    case T_Duration: *out = std::string("tD") + UNITS[v.scalar<int16_t>(t, 0, 1) & 3]; return AH_OK;
+    case T_Timestamp:
+      *out = std::string("ts") + UNITS[v.scalar<int16_t>(t, 0, 0) & 3] + ":" + v.str(v.indirect(t, 1));
+      return AH_OK;
+    case T_Interval: {
+      const int u = v.scalar<int16_t>(t, 0, 0);
+      *out = u == 0 ? "tiM" : u == 1 ? "tiD" : "tin";
+      return AH_OK;
+    }
+    case T_Decimal: {
+      const int p = v.scalar<int32_t>(t, 0, 0), s = v.scalar<int32_t>(t, 1, 0), bits = v.scalar<int32_t>(t, 2, 128);
+      *out = "d:" + std::to_string(p) + "," + std::to_string(s) + (bits == 128 ? "" : "," + std::to_string(bits));
+      return AH_OK;
+    }
+    case T_FixedSizeBinary: *out = "w:" + std::to_string(v.scalar<int32_t>(t, 0, 0)); return AH_OK;
+    default:
+      return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "IPC field type %d (nested / dictionary / view) has no device kernels",
+                     (int)tt);
+  }
+}
+
+int64_t pad_to(int64_t len, int64_t alignment) { return (len + alignment - 1) & ~(alignment - 1); }
+
+// [continuation][padded metadata length][flatbuffer][padding]  (writer.rs:138-162, :188-222)
+ah_status frame_message(ah_context* ctx, const FbBuilder& b, int32_t alignment, uint8_t** out, int64_t* out_len) {
+  const int64_t meta = b.size();
+  const int64_t header = pad_to(meta + 8, alignment);
+  uint8_t* m = (uint8_t*)calloc(1, (size_t)header);
+  if (!m) return ah_fail(ctx, AH_OUT_OF_MEMORY, "host allocation of %lld bytes failed", (long long)header);
+  const uint32_t cont = 0xFFFFFFFFu;
+  const int32_t mlen = (int32_t)(header - 8);
+  memcpy(m, &cont, 4);
+  memcpy(m + 4, &mlen, 4);
+  memcpy(m + 8, b.data(), (size_t)meta);
+  *out = m;
+  *out_len = header;
+  return AH_OK;
+}
+
+// the flatbuffer inside a framed message: accepts the 8-byte (V5) and the legacy 4-byte prefix
+ah_status unframe(ah_context* ctx, const uint8_t* msg, int64_t len, FbView* v) {
+  if (!msg || len < 8) return ah_fail(ctx, AH_IPC_ERROR, "message shorter than its length prefix");
+  uint32_t first;
+  memcpy(&first, msg, 4);
+  const int64_t prefix = first == 0xFFFFFFFFu ? 8 : 4;
+  int32_t mlen;
+  memcpy(&mlen, msg + prefix - 4, 4);
+  if (mlen <= 0 || prefix + mlen > len) return ah_fail(ctx, AH_IPC_ERROR, "metadata length %d exceeds the message", mlen);
+  v->p = msg + prefix;
+  v->n = (size_t)mlen;
+  return AH_OK;
+}
+
+__global__ void rebase_offsets32(const int32_t* in, int32_t* out, int64_t n, int32_t first) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] - first;
+}
+__global__ void rebase_offsets64(const int64_t* in, int64_t* out, int64_t n, int64_t first) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] - first;
+}
+
+struct BufSlot {
+  int64_t offset, length;
+};
+
+}  // namespace
+
+extern "C" void ah_host_free(void* p) { free(p); }
+
+extern "C" ah_status ah_ipc_schema_message(ah_context* ctx, int32_t n_fields, const ah_ipc_field* fields,
+                                           int32_t alignment, uint8_t** out, int64_t* out_len) {
+  if (!out || !out_len || (n_fields > 0 && !fields)) return AH_INVALID_ARGUMENT;  // ctx may be NULL (host only)
+  if (alignment != 8 && alignment != 16 && alignment != 32 && alignment != 64)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "Alignment should be 8, 16, 32, or 64.");  // writer.rs:92
+  FbBuilder b;
+  std::vector<uint32_t> foffs;
+  for (int i = 0; i < n_fields; ++i) {
+    uint8_t tt;
+    uint32_t toff;
+    AH_TRY(type_from_format(ctx, b, fields[i].format ? fields[i].format : "", &tt, &toff));
+    const uint32_t name = b.create_string(fields[i].name ? fields[i].name : "");
+    const uint32_t children = b.create_offset_vector({});
+    b.start_table();
+    b.add_offset(0, name);
+    b.add_scalar<uint8_t>(1, fields[i].nullable ? 1 : 0, 0);
+    b.add_scalar<uint8_t>(2, tt, 0);
+    b.add_offset(3, toff);
+    b.add_offset(5, children);
+    foffs.push_back(b.end_table());
+  }
+  const uint32_t fvec = b.create_offset_vector(foffs);
+  b.start_table();
+  b.add_offset(1, fvec);
+  const uint32_t schema = b.end_table();
+  b.start_table();
+  b.add_scalar<int16_t>(0, METADATA_V5, 0);
+  b.add_scalar<uint8_t>(1, H_Schema, 0);
+  b.add_offset(2, schema);
+  b.finish(b.end_table());
+  return frame_message(ctx, b, alignment, out, out_len);
+}
+
+extern "C" ah_status ah_ipc_decode_schema(ah_context* ctx, const uint8_t* msg, int64_t len, int32_t* n_fields,
+                                          ah_ipc_field** fields) {
+  if (!n_fields || !fields) return AH_INVALID_ARGUMENT;  // ctx may be NULL (host only)
+  FbView v{};
+  AH_TRY(unframe(ctx, msg, len, &v));
+  const size_t m = v.root();
+  if (v.scalar<uint8_t>(m, 1, 0) != H_Schema) return ah_fail(ctx, AH_IPC_ERROR, "Not expecting a schema when messages are read");
+  const size_t schema = v.indirect(m, 2);
+  if (!schema) return ah_fail(ctx, AH_IPC_ERROR, "Unable to read IPC message as schema");
+  if (v.scalar<int16_t>(schema, 0, 0) != 0) return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "big-endian IPC streams");
+  const size_t fvec = v.indirect(schema, 1);
+  const uint32_t n = v.vec_len(fvec);
+  std::vector<std::string> names(n), fmts(n);
+  std::vector<int> nullable(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const size_t f = v.vec_table(fvec, i);
+    if (v.field(f, 4)) return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "dictionary-encoded IPC fields have no device kernels");
+    names[i] = v.str(v.indirect(f, 0));
+    nullable[i] = v.scalar<uint8_t>(f, 1, 0);
+    AH_TRY(format_from_type(ctx, v, v.scalar<uint8_t>(f, 2, 0), v.indirect(f, 3), &fmts[i]));
+  }
+  if (!v.ok) return ah_fail(ctx, AH_PARSE_ERROR, "Unable to get root as message: truncated flatbuffer");
+  // one allocation: the field array followed by the strings (freed with ah_host_free)
+  size_t bytes = sizeof(ah_ipc_field) * std::max<uint32_t>(n, 1);
+  for (uint32_t i = 0; i < n; ++i) bytes += names[i].size() + fmts[i].size() + 2;
+  char* blob = (char*)malloc(bytes);
+  if (!blob) return ah_fail(ctx, AH_OUT_OF_MEMORY, "host allocation failed");
+  ah_ipc_field* out = (ah_ipc_field*)blob;
+  char* s = blob + sizeof(ah_ipc_field) * std::max<uint32_t>(n, 1);
+  for (uint32_t i = 0; i < n; ++i) {
+    out[i].name = s;
+    memcpy(s, names[i].c_str(), names[i].size() + 1);
+    s += names[i].size() + 1;
+    out[i].format = s;
+    memcpy(s, fmts[i].c_str(), fmts[i].size() + 1);
+    s += fmts[i].size() + 1;
+    out[i].nullable = nullable[i];
+  }
+  *n_fields = (int32_t)n;
+  *fields = out;
+  return AH_OK;
+}
+
+extern "C" ah_status ah_ipc_encode_batch(ah_context* ctx, int32_t n_cols, const ah_array_view* cols, int64_t num_rows,
+                                         int32_t alignment, uint8_t** out_meta, int64_t* out_meta_len,
+                                         void** out_body, int64_t* out_body_len) {
+  if (!ctx || !out_meta || !out_meta_len || !out_body || !out_body_len || (n_cols > 0 && !cols))
+    return AH_INVALID_ARGUMENT;
+  if (alignment != 8 && alignment != 16 && alignment != 32 && alignment != 64)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "Alignment should be 8, 16, 32, or 64.");
+  hipSetDevice(ctx->device);
+  *out_meta = nullptr;
+  *out_body = nullptr;
+
+  // pass 1: sizes.  Strings need their first / last offset (two scalars per column, one D2H each way).
+  struct Col {
+    int64_t nulls, first = 0, last = 0;
+    BufSlot slot[3];
+    int nbuf;
+  };
+  std::vector<Col> cs((size_t)n_cols);
+  std::vector<int64_t> fieldnodes;
+  std::vector<int64_t> bufmeta;
+  int64_t off = 0;
+  for (int c = 0; c < n_cols; ++c) {
+    const ah_array_view& a = cols[c];
+    const ah_type t = a.type;
+    const int64_t n = a.length;
+    if (n != num_rows)
+      return ah_fail(ctx, AH_INVALID_ARGUMENT, "all columns in a record batch must have the same length");
+    Col& k = cs[c];
+    AH_TRY(ah_resolve_null_count(ctx, &a, &k.nulls));
+    const bool is_str = t == AH_UTF8 || t == AH_LARGE_UTF8;
+    const int w = ah_type_width(t);
+    if (!is_str && w < 0) return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "IPC encoding of %s", ah_type_name(t));
+    if (t == AH_UTF8_VIEW || t == AH_BINARY_VIEW)
+      return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "IPC encoding of %s (variadic buffers stay with the host)", ah_type_name(t));
+    int64_t lens[3];
+    lens[0] = (n + 7) / 8;  // validity: always present in the body (writer.rs:2380-2392)
+    if (is_str) {
+      const int ow = t == AH_UTF8 ? 4 : 8;
+      if (n > 0) {
+        AH_HIP(ctx, hipMemcpyAsync(ctx->pinned, a.offsets, ow, hipMemcpyDeviceToHost, ctx->stream));
+        AH_HIP(ctx, hipMemcpyAsync(ctx->pinned + 1, (const char*)a.offsets + n * ow, ow, hipMemcpyDeviceToHost, ctx->stream));
+        AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        k.first = ow == 4 ? (int64_t)(int32_t)ctx->pinned[0] : (int64_t)ctx->pinned[0];
+        k.last = ow == 4 ? (int64_t)(int32_t)ctx->pinned[1] : (int64_t)ctx->pinned[1];
+      }
+      lens[1] = (n + 1) * ow;  // an empty array still carries the single offset 0 (:2278-2284)
+      lens[2] = k.last - k.first;
+      k.nbuf = 3;
+    } else {
+      lens[1] = t == AH_BOOL ? (n + 7) / 8 : n * w;
+      k.nbuf = 2;
+    }
+    fieldnodes.push_back(n);
+    fieldnodes.push_back(k.nulls);
+    for (int i = 0; i < k.nbuf; ++i) {
+      k.slot[i] = {off, lens[i]};
+      bufmeta.push_back(off);
+      bufmeta.push_back(lens[i]);
+      off += pad_to(lens[i], alignment);
+    }
+  }
+  const int64_t body_len = pad_to(off, alignment);
+
+  // pass 2: the body, assembled in HBM
+  void* body = nullptr;
+  AH_TRY(ah_out_alloc(ctx, (size_t)std::max<int64_t>(body_len, 8), &body));
+  auto fail = [&](ah_status st) {
+    ah_out_free(ctx, body, (size_t)std::max<int64_t>(body_len, 8));
+    return st;
+  };
+  uint8_t* B = (uint8_t*)body;
+  auto hip_fail = [&](hipError_t e) { return fail(ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in IPC encode", hipGetErrorString(e))); };
+  for (int c = 0; c < n_cols; ++c) {
+    const ah_array_view& a = cols[c];
+    const Col& k = cs[c];
+    const int64_t n = a.length;
+    hipError_t e = hipSuccess;
+    // zero the pads (and the last partial word of each bitmap slot) first: cheap, keeps the body deterministic
+    for (int i = 0; i < k.nbuf && e == hipSuccess; ++i) {
+      const int64_t padded = pad_to(k.slot[i].length, alignment);
+      const int64_t tail = std::min<int64_t>(padded, (k.slot[i].length & ~7ll));
+      if (padded > tail) e = hipMemsetAsync(B + k.slot[i].offset + tail, 0, (size_t)(padded - tail), ctx->stream);
+    }
+    if (e != hipSuccess) return hip_fail(e);
+    auto put_bits = [&](const void* bits, int64_t bit_off, const BufSlot& s) -> ah_status {
+      if (n == 0) return AH_OK;
+      if (!bits) {  // no null buffer: all-ones bytes (with_bitset(num_bytes, true))
+        hipError_t e2 = hipMemsetAsync(B + s.offset, 0xFF, (size_t)s.length, ctx->stream);
+        return e2 == hipSuccess ? AH_OK : ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in IPC encode", hipGetErrorString(e2));
+      }
+      if ((bit_off & 7) == 0) {
+        hipError_t e2 = hipMemcpyAsync(B + s.offset, (const uint8_t*)bits + bit_off / 8, (size_t)s.length,
+                                       hipMemcpyDeviceToDevice, ctx->stream);
+        return e2 == hipSuccess ? AH_OK : ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in IPC encode", hipGetErrorString(e2));
+      }
+      // BooleanBuffer::sliced / bit_slice: funnel shift to bit 0 (slots are >= 8-byte aligned and padded)
+      return ah_bitmap_op(ctx, BM_COPY, make_bitview(bits, bit_off), BitView{nullptr, 0}, BitView{nullptr, 0}, n,
+                          (unsigned long long*)(B + s.offset), nullptr);
+    };
+    ah_status st = put_bits(a.validity && k.nulls > 0 ? a.validity : nullptr, a.validity_bit_offset, k.slot[0]);
+    if (st != AH_OK) return fail(st);
+    const ah_type t = a.type;
+    if (t == AH_BOOL) {
+      if (n > 0 && !a.values) return fail(ah_fail(ctx, AH_INVALID_ARGUMENT, "null values pointer"));
+      st = put_bits(a.values, a.values_bit_offset, k.slot[1]);
+      if (st != AH_OK) return fail(st);
+    } else if (t == AH_UTF8 || t == AH_LARGE_UTF8) {
+      const int ow = t == AH_UTF8 ? 4 : 8;
+      if (n == 0) {
+        e = hipMemsetAsync(B + k.slot[1].offset, 0, ow, ctx->stream);
+      } else if (k.first == 0) {
+        e = hipMemcpyAsync(B + k.slot[1].offset, a.offsets, (size_t)k.slot[1].length, hipMemcpyDeviceToDevice, ctx->stream);
+      } else {  // reencode_offsets (:2246-2270)
+        const int64_t cnt = n + 1;
+        const int grid = (int)((cnt + 255) / 256);
+        if (ow == 4)
+          hipLaunchKernelGGL(rebase_offsets32, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t*)a.offsets,
+                             (int32_t*)(B + k.slot[1].offset), cnt, (int32_t)k.first);
+        else
+          hipLaunchKernelGGL(rebase_offsets64, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)a.offsets,
+                             (int64_t*)(B + k.slot[1].offset), cnt, k.first);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess && k.slot[2].length > 0)
+        e = hipMemcpyAsync(B + k.slot[2].offset, (const uint8_t*)a.values + k.first, (size_t)k.slot[2].length,
+                           hipMemcpyDeviceToDevice, ctx->stream);
+      if (e != hipSuccess) return hip_fail(e);
+    } else if (k.slot[1].length > 0) {
+      e = hipMemcpyAsync(B + k.slot[1].offset, a.values, (size_t)k.slot[1].length, hipMemcpyDeviceToDevice, ctx->stream);
+      if (e != hipSuccess) return hip_fail(e);
+    }
+  }
+  {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return hip_fail(e);
+  }
+
+  // metadata: Message{V5, RecordBatch{length, nodes, buffers}, bodyLength}
+  FbBuilder b;
+  const uint32_t bufs = b.create_struct_vector(bufmeta.data(), bufmeta.size() / 2, 16, 8);
+  const uint32_t nodes = b.create_struct_vector(fieldnodes.data(), fieldnodes.size() / 2, 16, 8);
+  b.start_table();
+  b.add_scalar<int64_t>(0, num_rows, 0);
+  b.add_offset(1, nodes);
+  b.add_offset(2, bufs);
+  const uint32_t rb = b.end_table();
+  b.start_table();
+  b.add_scalar<int16_t>(0, METADATA_V5, 0);
+  b.add_scalar<uint8_t>(1, H_RecordBatch, 0);
+  b.add_offset(2, rb);
+  b.add_scalar<int64_t>(3, body_len, 0);
+  b.finish(b.end_table());
+  ah_status st = frame_message(ctx, b, alignment, out_meta, out_meta_len);
+  if (st != AH_OK) return fail(st);
+  *out_body = body;
+  *out_body_len = body_len;
+  return AH_OK;
+}
+
+extern "C" ah_status ah_ipc_decode_batch(ah_context* ctx, const uint8_t* msg, int64_t msg_len, const void* body,
+                                         int64_t body_len, int32_t n_fields, const ah_ipc_field* fields,
+                                         ah_array_out* out_cols, int64_t* num_rows) {
+  if (!ctx || !out_cols || !num_rows || (n_fields > 0 && !fields)) return AH_INVALID_ARGUMENT;
+  hipSetDevice(ctx->device);
+  for (int i = 0; i < n_fields; ++i) ah_out_init(&out_cols[i]);
+  FbView v{};
+  AH_TRY(unframe(ctx, msg, msg_len, &v));
+  const size_t m = v.root();
+  const uint8_t ht = v.scalar<uint8_t>(m, 1, 0);
+  if (ht == H_DictionaryBatch) return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "IPC dictionary batches have no device kernels");
+  if (ht != H_RecordBatch) return ah_fail(ctx, AH_IPC_ERROR, "Expecting a record batch message, got header type %d", (int)ht);
+  const int64_t declared = v.scalar<int64_t>(m, 3, 0);
+  if (declared > body_len)
+    return ah_fail(ctx, AH_IPC_ERROR, "message body of %lld bytes, %lld announced", (long long)body_len, (long long)declared);
+  const size_t rb = v.indirect(m, 2);
+  if (!rb) return ah_fail(ctx, AH_IPC_ERROR, "Unable to read IPC message as record batch");
+  if (v.field(rb, 3)) return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "compressed IPC bodies (LZ4_FRAME / ZSTD) are not decoded on the device");
+  const int64_t rows = v.scalar<int64_t>(rb, 0, 0);
+  const size_t nodes = v.indirect(rb, 1), bufs = v.indirect(rb, 2);
+  const uint32_t n_nodes = v.vec_len(nodes), n_bufs = v.vec_len(bufs);
+  if (!v.ok) return ah_fail(ctx, AH_PARSE_ERROR, "Unable to get root as message: truncated flatbuffer");
+  uint32_t ni = 0, bi = 0;
+  auto fail = [&](ah_status st) {
+    for (int i = 0; i < n_fields; ++i) ah_array_release(ctx, &out_cols[i]);
+    return st;
+  };
+  const uint8_t* B = (const uint8_t*)body;
+  for (int c = 0; c < n_fields; ++c) {
+    ah_type t;
+    ah_status st = ah_type_from_format(ctx, fields[c].format, &t);
+    if (st != AH_OK) return fail(st);
+    const bool is_str = t == AH_UTF8 || t == AH_LARGE_UTF8;
+    const uint32_t want = is_str ? 3 : 2;
+    if (ni >= n_nodes) return fail(ah_fail(ctx, AH_IPC_ERROR, "Invalid data for schema. Field %d refers to node index %u but only %u in schema", c, ni, n_nodes));
+    if (bi + want > n_bufs) return fail(ah_fail(ctx, AH_IPC_ERROR, "Buffer count mismatched with metadata"));
+    const int64_t len = v.rd<int64_t>(nodes + 4 + 16 * (size_t)ni), nulls = v.rd<int64_t>(nodes + 4 + 16 * (size_t)ni + 8);
+    ++ni;
+    BufSlot s[3];
+    for (uint32_t i = 0; i < want; ++i, ++bi) {
+      s[i].offset = v.rd<int64_t>(bufs + 4 + 16 * (size_t)bi);
+      s[i].length = v.rd<int64_t>(bufs + 4 + 16 * (size_t)bi + 8);
+      if (s[i].offset < 0 || s[i].length < 0 || s[i].offset + s[i].length > body_len)
+        return fail(ah_fail(ctx, AH_IPC_ERROR, "buffer %u of field %d lies outside the message body", i, c));
+    }
+    if (len != rows) return fail(ah_fail(ctx, AH_IPC_ERROR, "field %d has %lld rows, the batch %lld", c, (long long)len, (long long)rows));
+    const int w = is_str ? (t == AH_UTF8 ? 4 : 8) : ah_type_width(t);
+    // minimum sizes, so a kernel can never be pointed past the body
+    const int64_t need1 = is_str ? (len + 1) * w : (t == AH_BOOL ? (len + 7) / 8 : len * w);
+    if ((nulls > 0 && s[0].length < (len + 7) / 8) || (len > 0 && s[1].length < need1))
+      return fail(ah_fail(ctx, AH_IPC_ERROR, "buffer of field %d is shorter than its %lld rows need", c, (long long)len));
+    ah_array_out& o = out_cols[c];
+    o.type = t;
+    o.length = len;
+    o.null_count = nulls;
+    // natural alignment of the device kernels' loads; foreign writers (8-byte alignment) can violate 16/32
+    const int align = is_str ? w : (t == AH_BOOL ? 1 : std::min(w, 16));
+    const bool aligned = (((uintptr_t)(B + s[1].offset)) % (size_t)align) == 0;
+    if (aligned) {  // zero-copy views of the body
+      o.flags = AH_OUT_BORROWED;
+      if (nulls > 0) {
+        o.validity = (uint8_t*)(B + s[0].offset);
+        o.validity_bytes = s[0].length;
+      }
+      if (is_str) {
+        o.offsets = (void*)(B + s[1].offset);
+        o.offsets_bytes = s[1].length;
+        o.values = (void*)(B + s[2].offset);
+        o.values_bytes = s[2].length;
+      } else {
+        o.values = (void*)(B + s[1].offset);
+        o.values_bytes = s[1].length;
+      }
+    } else {  // `align_buffers` (reader.rs:301): copy the column into fresh, aligned allocations
+      auto dup = [&](const BufSlot& sl, void** dst, int64_t* bytes) -> ah_status {
+        const size_t cap = (size_t)std::max<int64_t>(pad_to(sl.length, 8) + 8, 16);
+        AH_TRY(ah_out_alloc(ctx, cap, dst));
+        *bytes = (int64_t)cap;
+        if (sl.length) AH_HIP(ctx, hipMemcpyAsync(*dst, B + sl.offset, (size_t)sl.length, hipMemcpyDeviceToDevice, ctx->stream));
+        return AH_OK;
+      };
+      void* p = nullptr;
+      if (nulls > 0) {
+        st = dup(s[0], &p, &o.validity_bytes);
+        o.validity = (uint8_t*)p;
+        if (st != AH_OK) return fail(st);
+      }
+      st = dup(s[1], is_str ? &o.offsets : &o.values, is_str ? &o.offsets_bytes : &o.values_bytes);
+      if (st == AH_OK && is_str) st = dup(s[2], &o.values, &o.values_bytes);
+      if (st != AH_OK) return fail(st);
+    }
+  }
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return fail(ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in IPC decode", hipGetErrorString(e)));
+  if (!v.ok) return fail(ah_fail(ctx, AH_PARSE_ERROR, "Unable to get root as message: truncated flatbuffer"));
+  *num_rows = rows;
+  return AH_OK;
+}
+
+// header type and body length of a framed message: what a stream reader needs before it fetches the body
+extern "C" ah_status ah_ipc_message_info(ah_context* ctx, const uint8_t* msg, int64_t len, int32_t* header_type,
+                                         int64_t* body_len) {
+  if (!header_type || !body_len) return AH_INVALID_ARGUMENT;  // ctx may be NULL (host only)
+  FbView v{};
+  AH_TRY(unframe(ctx, msg, len, &v));
+  const size_t m = v.root();
+  *header_type = v.scalar<uint8_t>(m, 1, 0);
+  *body_len = v.scalar<int64_t>(m, 3, 0);
+  if (!v.ok) return ah_fail(ctx, AH_PARSE_ERROR, "Unable to get root as message: truncated flatbuffer");
+  return AH_OK;
+}

@@ -1,0 +1,216 @@
+"""arrow::ipc for device-resident record batches — the mirror of ``arrow_ipc::writer::StreamWriter`` /
+``arrow_ipc::reader::StreamReader`` (arrow-ipc/src/writer.rs:1419-1600, reader.rs:1380-1560) over the C ABI's
+``ah_ipc_*`` entry points.
+
+The body of every RecordBatch message is assembled (encode) or received (decode) as ONE contiguous HBM
+buffer: writing a stream is one D2H copy per batch, reading one H2D copy per batch after which the columns
+are zero-copy views of that buffer; between GPUs the same body is what ``distributed.Communicator`` ships.
+"""
+import ctypes as C
+import io
+
+import numpy as np
+
+from . import _lib as L
+from . import array as A
+from . import ffi
+
+CONTINUATION = b"\xff\xff\xff\xff"
+
+
+class Field:
+    """arrow_schema::Field (name, data_type, nullable)."""
+
+    def __init__(self, name, data_type, nullable=True):
+        self.name, self.data_type, self.nullable = name, data_type, nullable
+
+    def __eq__(self, o):
+        return (self.name, self.data_type, self.nullable) == (o.name, o.data_type, o.nullable)
+
+    def __repr__(self):
+        return f"Field({self.name!r}, {self.data_type}, nullable={self.nullable})"
+
+
+class Schema:
+    def __init__(self, fields):
+        self.fields = list(fields)
+
+    @classmethod
+    def of(cls, batch):
+        return cls([Field(n, c.data_type, True) for n, c in zip(batch.names, batch.columns)])
+
+    @property
+    def names(self):
+        return [f.name for f in self.fields]
+
+    def __eq__(self, o):
+        return self.fields == o.fields
+
+    def _c_fields(self, ctx):
+        n = len(self.fields)
+        arr = (L.IpcField * max(n, 1))()
+        keep = []
+        for i, f in enumerate(self.fields):
+            fmt = ffi.format_of(f.data_type) or ctx.lib.ah_format_of_type(f.data_type.physical).decode()
+            nb, fb = f.name.encode(), fmt.encode()
+            keep += [nb, fb]
+            arr[i].name, arr[i].format, arr[i].nullable = nb, fb, 1 if f.nullable else 0
+        return arr, keep
+
+
+def _take_host_bytes(ctx, ptr, n):
+    data = C.string_at(ptr, n)
+    ctx.lib.ah_host_free(ptr)
+    return data
+
+
+def schema_to_bytes(schema, ctx=None, alignment=64):
+    """Framed Schema message (``IpcDataGenerator::schema_to_bytes``)."""
+    ctx = ctx or A.default_context()
+    arr, _keep = schema._c_fields(ctx)
+    out, n = C.c_void_p(), C.c_int64()
+    ctx.check(ctx.lib.ah_ipc_schema_message(ctx.handle, len(schema.fields), arr, alignment, C.byref(out), C.byref(n)))
+    return _take_host_bytes(ctx, out, n.value)
+
+
+def schema_from_bytes(msg, ctx=None):
+    ctx = ctx or A.default_context()
+    n, fields = C.c_int32(), C.POINTER(L.IpcField)()
+    ctx.check(ctx.lib.ah_ipc_decode_schema(ctx.handle, msg, len(msg), C.byref(n), C.byref(fields)))
+    try:
+        return Schema([Field(fields[i].name.decode(), ffi.data_type_from_format(ctx, fields[i].format.decode()),
+                             bool(fields[i].nullable)) for i in range(n.value)])
+    finally:
+        ctx.lib.ah_host_free(fields)
+
+
+class _Body:
+    """Owner of an encoded message body in HBM (released through the context allocator)."""
+
+    def __init__(self, ctx, ptr, nbytes):
+        self.ctx, self.ptr, self.nbytes = ctx, ptr, nbytes
+        out = L.ArrayOut()
+        out.values, out.values_bytes = ptr, max(nbytes, 8)
+        self._owner = A._OutOwner(ctx, out)
+
+    def to_bytes(self):
+        host = np.empty(self.nbytes, dtype=np.uint8)
+        if self.nbytes:
+            self.ctx.check(self.ctx.lib.ah_memcpy_dtoh(self.ctx.handle, host.ctypes.data, self.ptr, self.nbytes))
+        return host.tobytes()
+
+
+def encode_batch(batch, alignment=64):
+    """``record_batch_to_bytes``: (framed metadata bytes, body in HBM)."""
+    cols = batch.columns
+    ctx = cols[0].ctx if cols else A.default_context()
+    views = (L.ArrayView * max(len(cols), 1))()
+    for i, c in enumerate(cols):
+        views[i] = c.view()
+    meta, mlen, body, blen = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+    ctx.check(ctx.lib.ah_ipc_encode_batch(ctx.handle, len(cols), views, batch.num_rows(), alignment, C.byref(meta),
+                                          C.byref(mlen), C.byref(body), C.byref(blen)))
+    return _take_host_bytes(ctx, meta, mlen.value), _Body(ctx, body.value, blen.value)
+
+
+def decode_batch(meta, body_ptr, body_len, schema, ctx=None, keepalive=()):
+    """``RecordBatchDecoder``: columns are zero-copy views of the device body (kept alive by ``keepalive``)."""
+    ctx = ctx or A.default_context()
+    n = len(schema.fields)
+    arr, _keep = schema._c_fields(ctx)
+    outs = (L.ArrayOut * max(n, 1))()
+    rows = C.c_int64()
+    ctx.check(ctx.lib.ah_ipc_decode_batch(ctx.handle, meta, len(meta), body_ptr, body_len, n, arr, outs, C.byref(rows)))
+    cols = []
+    for i, f in enumerate(schema.fields):
+        o = L.ArrayOut()
+        C.memmove(C.byref(o), C.byref(outs[i]), C.sizeof(L.ArrayOut))
+        cols.append(A.Array._from_out(ctx, o, f.data_type, keepalive=tuple(keepalive)))
+    return A.RecordBatch(schema.names, cols, rows.value)
+
+
+class StreamWriter:
+    """``StreamWriter::try_new(writer, &schema)`` / ``write`` / ``finish`` (writer.rs:1419-1600)."""
+
+    def __init__(self, sink, schema, ctx=None, alignment=64):
+        self.sink, self.schema, self.alignment = sink, schema, alignment
+        self.ctx = ctx or A.default_context()
+        self.finished = False
+        sink.write(schema_to_bytes(schema, self.ctx, alignment))
+
+    def write(self, batch):
+        if self.finished:
+            raise A.IpcError("Cannot write record batch to stream writer as it is closed")
+        if [c.data_type for c in batch.columns] != [f.data_type for f in self.schema.fields]:
+            raise A.InvalidArgumentError("batch schema does not match the stream schema")
+        meta, body = encode_batch(batch, self.alignment)
+        self.sink.write(meta)
+        self.sink.write(body.to_bytes())
+
+    def finish(self):
+        if self.finished:
+            raise A.IpcError("Cannot write footer to stream writer as it is closed")
+        self.sink.write(CONTINUATION + b"\x00\x00\x00\x00")
+        self.finished = True
+
+
+class StreamReader:
+    """``StreamReader::try_new(reader, None)`` (reader.rs:1380): iterate device RecordBatches."""
+
+    def __init__(self, source, ctx=None):
+        self.src = io.BytesIO(source) if isinstance(source, (bytes, bytearray, memoryview)) else source
+        self.ctx = ctx or A.default_context()
+        first = self._next_message()
+        if first is None:
+            raise A.IpcError("Unexpected end of stream before the schema message")
+        self.schema = schema_from_bytes(first, self.ctx)
+
+    def _next_message(self):
+        head = self.src.read(4)
+        if len(head) < 4:
+            return None  # end of file without an EOS marker is accepted like the reference (reader.rs:1518)
+        if head == CONTINUATION:
+            size = self.src.read(4)
+            if len(size) < 4:
+                return None
+            head += size
+        else:
+            size = head  # legacy framing: a bare length
+        n = int.from_bytes(size, "little", signed=True)
+        if n == 0:
+            return None  # end-of-stream marker
+        meta = self.src.read(n)
+        if len(meta) < n:
+            raise A.IpcError("Unexpected end of stream inside a message")
+        return head + meta
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        ctx = self.ctx
+        while True:
+            msg = self._next_message()
+            if msg is None:
+                raise StopIteration
+            ht, blen = C.c_int32(), C.c_int64()
+            ctx.check(ctx.lib.ah_ipc_message_info(ctx.handle, msg, len(msg), C.byref(ht), C.byref(blen)))
+            body = self.src.read(blen.value)
+            if len(body) < blen.value:
+                raise A.IpcError("Unexpected end of stream inside a message body")
+            if ht.value == 1:
+                raise A.IpcError("Not expecting a schema when messages are read")
+            dev = A.DeviceBuffer.from_numpy(ctx, np.frombuffer(body, dtype=np.uint8)) if blen.value else A.DeviceBuffer(ctx, 8)
+            return decode_batch(msg, dev.ptr, blen.value, self.schema, ctx, keepalive=(dev,))
+
+
+def write_stream(batches, schema=None, ctx=None, alignment=64):
+    """All batches as one IPC stream (bytes)."""
+    batches = list(batches)
+    schema = schema or Schema.of(batches[0])
+    sink = io.BytesIO()
+    w = StreamWriter(sink, schema, ctx, alignment)
+    for b in batches:
+        w.write(b)
+    w.finish()
+    return sink.getvalue()

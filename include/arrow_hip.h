@@ -54,6 +54,8 @@ enum {
   AH_NOT_YET_IMPLEMENTED = 7, /* ArrowError::NotYetImplemented */
   AH_OFFSET_OVERFLOW_ERROR = 8, /* ArrowError::OffsetOverflowError(n): message is the number */
   AH_C_DATA_INTERFACE = 9,    /* ArrowError::CDataInterface */
+  AH_IPC_ERROR = 10,          /* ArrowError::IpcError */
+  AH_PARSE_ERROR = 11,        /* ArrowError::ParseError */
   AH_PANIC = 100,             /* the reference would panic!(); message = panic text */
   AH_HIP_ERROR = 101,         /* runtime failure (no reference analogue) */
   AH_OUT_OF_MEMORY = 102
@@ -385,6 +387,49 @@ AH_API ah_status ah_import_c_data(ah_context* ctx, const struct ArrowArray* arra
  * (2, or 3 for strings) and buffers[0] is NULL when there is no null buffer. */
 AH_API ah_status ah_export_c_data(ah_context* ctx, const ah_array_view* values, const char* format,
                                   struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+
+/* ------------------------------------------------------------- Arrow IPC */
+/* Record-batch framing of the Arrow IPC format (arrow-ipc/src/writer.rs, reader.rs; format/Message.fbs,
+ * format/Schema.fbs) for batches whose buffers live in HBM.  A message is a small host-side metadata block
+ * ([0xFFFFFFFF][padded length][flatbuffer][padding], writer.rs:138-222) plus a BODY; here the body is ONE
+ * contiguous device buffer, so a batch moves as a single transfer (D2H, or one RCCL send between GPUs) and an
+ * incoming body is decoded into zero-copy views.  The schema language is the C Data format string
+ * (ah_type_from_format).  Scope: the fixed-width, Boolean and (Large)Utf8/Binary layouts this library has
+ * kernels for; dictionaries, nested types, views and compressed bodies are AH_NOT_YET_IMPLEMENTED. */
+typedef struct ah_ipc_field {
+  const char* name;
+  const char* format; /* C Data format string: "l", "g", "tsu:UTC", "d:38,10", "u", ... */
+  int32_t nullable;
+} ah_ipc_field;
+/* Message header ordinals of format/Message.fbs */
+enum { AH_IPC_SCHEMA = 1, AH_IPC_DICTIONARY_BATCH = 2, AH_IPC_RECORD_BATCH = 3 };
+
+/* `IpcDataGenerator::schema_to_bytes` (writer.rs): framed Schema message; free with ah_host_free. */
+AH_API ah_status ah_ipc_schema_message(ah_context* ctx, int32_t n_fields, const ah_ipc_field* fields,
+                                       int32_t alignment, uint8_t** out, int64_t* out_len);
+/* Framed Schema message -> fields.  `*fields` is one allocation (array + strings): ah_host_free(*fields). */
+AH_API ah_status ah_ipc_decode_schema(ah_context* ctx, const uint8_t* msg, int64_t len, int32_t* n_fields,
+                                      ah_ipc_field** fields);
+/* `record_batch_to_bytes` (writer.rs:1006): framed RecordBatch metadata on the host (ah_host_free) and the body
+ * in HBM (owned through the context allocator: ah_device_free / the host allocator hook).  Per column, as
+ * `write_array_data` (:2364): validity always present (all ones when the array has no null buffer), bitmaps
+ * re-aligned to bit 0, values cut to the slice, string offsets rebased to 0 and data cut to the referenced
+ * range; every buffer padded to `alignment` (8/16/32/64; the reference defaults to 64). */
+AH_API ah_status ah_ipc_encode_batch(ah_context* ctx, int32_t n_cols, const ah_array_view* cols, int64_t num_rows,
+                                     int32_t alignment, uint8_t** out_meta, int64_t* out_meta_len,
+                                     void** out_body, int64_t* out_body_len);
+/* `RecordBatchDecoder` (reader.rs:88-300): framed metadata (host) + body (DEVICE pointer) -> one array per
+ * field.  Results are AH_OUT_BORROWED views into `body` (keep it alive) unless a foreign writer left a buffer
+ * under-aligned for its type, in which case that column is copied (reader.rs:301 `align_buffers`).  The
+ * validity view is dropped when null_count == 0 (reader.rs:271). */
+AH_API ah_status ah_ipc_decode_batch(ah_context* ctx, const uint8_t* msg, int64_t msg_len, const void* body,
+                                     int64_t body_len, int32_t n_fields, const ah_ipc_field* fields,
+                                     ah_array_out* out_cols, int64_t* num_rows);
+/* Header type (AH_IPC_*) and bodyLength of a framed message: what a stream reader needs before it fetches
+ * the body. */
+AH_API ah_status ah_ipc_message_info(ah_context* ctx, const uint8_t* msg, int64_t len, int32_t* header_type,
+                                     int64_t* body_len);
+AH_API void ah_host_free(void* p);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,8 @@ class ArrowError : public std::runtime_error {
       case AH_NOT_YET_IMPLEMENTED: return "Not yet implemented: ";
       case AH_OFFSET_OVERFLOW_ERROR: return "Offset overflow error: ";
       case AH_C_DATA_INTERFACE: return "C Data interface error: ";
+      case AH_IPC_ERROR: return "Ipc error: ";
+      case AH_PARSE_ERROR: return "Parser error: ";
       default: return "";
     }
   }

@@ -122,3 +122,66 @@ def test_c_data_format_mapping():
         fmt = lib.ah_format_of_type(phys)
         assert fmt is not None
         assert lib.ah_type_from_format(None, fmt, C.byref(t)) == L.AH_OK and t.value == phys
+
+
+def _ipc_schema_cases():
+    import pyarrow as pa
+    return pa.schema([
+        pa.field("i8", pa.int8()), pa.field("u16", pa.uint16(), nullable=False), pa.field("i32", pa.int32()),
+        pa.field("u64", pa.uint64()), pa.field("f16", pa.float16()), pa.field("f32", pa.float32()),
+        pa.field("f64", pa.float64(), nullable=False), pa.field("b", pa.bool_()), pa.field("s", pa.string()),
+        pa.field("ls", pa.large_string()), pa.field("bin", pa.binary()), pa.field("lbin", pa.large_binary()),
+        pa.field("d32", pa.date32()), pa.field("d64", pa.date64()), pa.field("t32s", pa.time32("s")),
+        pa.field("t32ms", pa.time32("ms")), pa.field("t64us", pa.time64("us")), pa.field("t64ns", pa.time64("ns")),
+        pa.field("ts_s", pa.timestamp("s")), pa.field("ts_us_utc", pa.timestamp("us", tz="UTC")),
+        pa.field("ts_ns_ny", pa.timestamp("ns", tz="America/New_York")), pa.field("dur_ms", pa.duration("ms")),
+        pa.field("dur_ns", pa.duration("ns")), pa.field("dec128", pa.decimal128(20, 3)),
+        pa.field("dec256", pa.decimal256(50, 7)), pa.field("mdn", pa.month_day_nano_interval()),
+        pa.field("fsb16", pa.binary(16)), pa.field("", pa.int64()), pa.field("ünïcode ✓", pa.int64()),
+    ])
+
+
+def test_ipc_schema_message_round_trips_through_pyarrow():
+    """Host-only half of the IPC boundary: our hand-written flatbuffers against Arrow C++'s verifier/reader, and
+    Arrow C++'s writer against our reader (arrow-ipc/src/convert.rs `schema_to_fb` / `fb_to_schema`)."""
+    import ctypes as C
+    import pyarrow as pa
+    import arrow_rs_amd as A
+    L = A._lib
+    lib = L.load()
+    sch = _ipc_schema_cases()
+    # pyarrow -> ours
+    msg = sch.serialize().to_pybytes()
+    n, fields = C.c_int32(), C.POINTER(L.IpcField)()
+    assert lib.ah_ipc_decode_schema(None, msg, len(msg), C.byref(n), C.byref(fields)) == L.AH_OK
+    got = [(fields[i].name.decode(), fields[i].format.decode(), bool(fields[i].nullable)) for i in range(n.value)]
+    lib.ah_host_free(fields)
+    want_fmt = ["c", "S", "i", "L", "e", "f", "g", "b", "u", "U", "z", "Z", "tdD", "tdm", "tts", "ttm", "ttu", "ttn",
+                "tss:", "tsu:UTC", "tsn:America/New_York", "tDm", "tDn", "d:20,3", "d:50,7,256", "tin", "w:16", "l", "l"]
+    assert got == [(f.name, fmt, f.nullable) for f, fmt in zip(sch, want_fmt)]
+    # ours -> pyarrow, at every legal alignment
+    for alignment in (8, 16, 32, 64):
+        arr = (L.IpcField * len(got))()
+        keep = [(nm.encode(), fm.encode()) for nm, fm, _ in got]
+        for i, (nm, fm) in enumerate(keep):
+            arr[i].name, arr[i].format, arr[i].nullable = nm, fm, 1 if got[i][2] else 0
+        out, ln = C.c_void_p(), C.c_int64()
+        assert lib.ah_ipc_schema_message(None, len(got), arr, alignment, C.byref(out), C.byref(ln)) == L.AH_OK
+        blob = C.string_at(out, ln.value)
+        lib.ah_host_free(out)
+        assert ln.value % alignment == 0 and blob[:4] == b"\xff" * 4
+        assert int.from_bytes(blob[4:8], "little") == ln.value - 8
+        back = pa.ipc.read_schema(pa.py_buffer(blob))
+        assert back.equals(sch), back
+        ht, bl = C.c_int32(), C.c_int64()
+        assert lib.ah_ipc_message_info(None, blob, len(blob), C.byref(ht), C.byref(bl)) == L.AH_OK
+        assert (ht.value, bl.value) == (1, 0)
+    out, ln = C.c_void_p(), C.c_int64()
+    assert lib.ah_ipc_schema_message(None, 0, None, 12, C.byref(out), C.byref(ln)) == L.AH_INVALID_ARGUMENT
+    # nested / dictionary schemas are refused, truncated metadata is a parse/ipc error, never a crash
+    for bad in (pa.schema([pa.field("l", pa.list_(pa.int32()))]), pa.schema([pa.field("d", pa.dictionary(pa.int8(), pa.string()))])):
+        m = bad.serialize().to_pybytes()
+        assert lib.ah_ipc_decode_schema(None, m, len(m), C.byref(n), C.byref(fields)) == L.AH_NOT_YET_IMPLEMENTED
+    for cut in (3, 8, 20, len(msg) // 2):
+        st = lib.ah_ipc_decode_schema(None, msg[:cut], cut, C.byref(n), C.byref(fields))
+        assert st in (L.AH_IPC_ERROR, L.AH_PARSE_ERROR), (cut, st)

@@ -1,0 +1,176 @@
+"""Arrow IPC framing of device-resident record batches (arrow-ipc/src/writer.rs, reader.rs).
+The peer is pyarrow (Arrow C++): it must read what we write and we must read what it writes — the same
+cross-implementation check the reference runs against the arrow-testing integration files."""
+import ctypes as C
+import decimal
+import io
+
+import numpy as np
+import pytest
+
+import arrow_rs_amd as A
+from arrow_rs_amd import compute as K, ffi, ipc
+
+pa = pytest.importorskip("pyarrow")
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(n, seed=0):
+    rng = np.random.default_rng(seed)
+    m = lambda p=0.8: ~(rng.random(n) < p)  # noqa: E731
+    i64 = rng.integers(-2**40, 2**40, n)
+    return pa.table({
+        "i8": pa.array(rng.integers(-128, 127, n, dtype=np.int8), mask=m()),
+        "u16": pa.array(rng.integers(0, 65535, n, dtype=np.uint16)),
+        "i32": pa.array(rng.integers(-2**31, 2**31 - 1, n, dtype=np.int32), mask=m(0.5)),
+        "i64": pa.array(i64, mask=m()),
+        "f32": pa.array(rng.standard_normal(n).astype(np.float32), mask=m()),
+        "f64": pa.array(rng.standard_normal(n)),
+        "b": pa.array(rng.random(n) < 0.5, mask=m()),
+        "bnn": pa.array(rng.random(n) < 0.5),
+        "s": pa.array([None if i % 7 == 0 else "v" * (i % 19) + str(i) for i in range(n)]),
+        "ls": pa.array([("x" * (i % 5)) for i in range(n)], type=pa.large_string()),
+        "bin": pa.array([None if i % 5 == 0 else bytes([i % 256]) * (i % 9) for i in range(n)], type=pa.binary()),
+        "ts": pa.array(i64, mask=m()).view(pa.timestamp("us", tz="UTC")),
+        "d32": pa.array(rng.integers(0, 20000, n, dtype=np.int32), mask=m()).view(pa.date32()),
+        "dec": pa.array([None if i % 11 == 0 else decimal.Decimal(int(v)).scaleb(-3) for i, v in enumerate(i64)],
+                        type=pa.decimal128(20, 3)),
+        "allnull": pa.array([None] * n, type=pa.int32()),
+    })
+
+
+def _device_batches(tbl, ctx, max_chunksize):
+    return [ffi.from_pyarrow(b, ctx) for b in tbl.to_batches(max_chunksize=max_chunksize)]
+
+
+@pytest.mark.parametrize("alignment", [8, 64])
+def test_pyarrow_reads_our_stream(ctx, alignment):
+    tbl = _table(5000, 1)
+    batches = _device_batches(tbl, ctx, 1777)
+    stream = ipc.write_stream(batches, ctx=ctx, alignment=alignment)
+    back = pa.ipc.open_stream(stream).read_all()
+    assert back.schema.equals(tbl.schema)
+    assert back.equals(tbl)
+    back.validate(full=True)
+
+
+def test_we_read_pyarrows_stream(ctx):
+    tbl = _table(4000, 2)
+    legacy = pa.ipc.IpcWriteOptions(use_legacy_format=True, metadata_version=pa.ipc.MetadataVersion.V4)
+    for opts in (pa.ipc.IpcWriteOptions(), legacy):  # V5 framing and the pre-0.15 bare-length prefix
+        sink = io.BytesIO()
+        with pa.ipc.new_stream(sink, tbl.schema, options=opts) as w:
+            for b in tbl.to_batches(max_chunksize=999):
+                w.write_batch(b)
+            w.write_batch(tbl.slice(17, 1234).to_batches()[0])  # sliced columns: offsets / bitmaps re-based by the writer
+            w.write_batch(tbl.slice(0, 0).to_batches(max_chunksize=10)[0] if tbl.slice(0, 0).to_batches() else
+                          pa.RecordBatch.from_pylist([], schema=tbl.schema))
+        rdr = ipc.StreamReader(sink.getvalue(), ctx)
+        assert [f.name for f in rdr.schema.fields] == tbl.schema.names
+        got = [ffi.to_pyarrow(b) for b in rdr]
+        want = tbl.to_batches(max_chunksize=999) + [tbl.slice(17, 1234).to_batches()[0]]
+        assert len(got) == len(want) + 1 and got[-1].num_rows == 0
+        for g, w_ in zip(got, want):
+            assert g.equals(w_)
+
+
+def test_sliced_device_arrays_are_rebased(ctx):
+    """write_array_data truncates values to the slice, re-aligns bitmaps to bit 0 and rebases string offsets
+    (writer.rs:2246-2290,:2331-2346,:2483-2489)."""
+    tbl = _table(3000, 3)
+    rb = ffi.from_pyarrow(tbl.to_batches()[0], ctx)
+    for off, ln in ((1, 2999), (13, 100), (64, 640), (2999, 1), (5, 0)):
+        sl = A.RecordBatch(rb.names, [c.slice(off, ln) for c in rb.columns], ln)
+        back = pa.ipc.open_stream(ipc.write_stream([sl], ctx=ctx)).read_all()
+        assert back.equals(tbl.slice(off, ln)), (off, ln)
+
+
+def test_device_round_trip_is_zero_copy(ctx):
+    """encode -> (metadata, one HBM body) -> decode: every column is a view into the body."""
+    tbl = _table(2048, 4)
+    rb = ffi.from_pyarrow(tbl.to_batches()[0], ctx)
+    meta, body = ipc.encode_batch(rb, 64)
+    assert len(meta) % 64 == 0 and body.nbytes % 64 == 0
+    dec = ipc.decode_batch(meta, body.ptr, body.nbytes, ipc.Schema.of(rb), ctx, keepalive=(body,))
+    assert dec.num_rows() == 2048
+    for name, c, orig in zip(rb.names, dec.columns, rb.columns):
+        assert body.ptr <= c.values.ptr < body.ptr + body.nbytes, name
+        assert c.values.ptr % 64 == 0
+        if c.validity is not None:
+            assert body.ptr <= c.validity.ptr < body.ptr + body.nbytes and c.validity_bit_offset == 0
+        assert (c.validity is None) == (orig.null_count() == 0)  # reader.rs:271: dropped when null_count == 0
+        assert c.null_count() == orig.null_count()
+    assert ffi.to_pyarrow(dec).equals(tbl.to_batches()[0])
+    # the views feed kernels directly
+    f = K.filter(dec.columns[3], dec.columns[7])
+    assert f.to_pyarrow().equals(tbl["i64"].combine_chunks().filter(tbl["bnn"].combine_chunks()))
+
+
+def test_underaligned_foreign_buffers_are_copied(ctx):
+    """A body whose 16-byte values land on an 8-byte boundary (legal for an 8-byte-aligning writer): the column
+    is copied into aligned memory like `align_buffers` (reader.rs:301) instead of being viewed."""
+    n = 101  # validity = 13 bytes -> padded to 16; then i8 column of 101 bytes -> 104: decimals start at 8 mod 16
+    tbl = pa.table({"a": pa.array(np.arange(n, dtype=np.int8)),
+                    "d": pa.array([decimal.Decimal(i) for i in range(n)], type=pa.decimal128(10, 0))})
+    sink = io.BytesIO()
+    with pa.ipc.new_stream(sink, tbl.schema) as w:
+        w.write_table(tbl)
+    got = [ffi.to_pyarrow(b) for b in ipc.StreamReader(sink.getvalue(), ctx)]
+    assert pa.Table.from_batches(got).equals(tbl)
+
+
+def test_unsupported_and_malformed(ctx):
+    tbl = pa.table({"a": pa.array(range(100))})
+    for codec in ("lz4", "zstd"):
+        sink = io.BytesIO()
+        try:
+            with pa.ipc.new_stream(sink, tbl.schema, options=pa.ipc.IpcWriteOptions(compression=codec)) as w:
+                w.write_table(tbl)
+        except pa.ArrowNotImplementedError:
+            continue
+        with pytest.raises(A.array.NotYetImplemented):
+            list(ipc.StreamReader(sink.getvalue(), ctx))
+    d = pa.table({"d": pa.array(["a", "b", "a"]).dictionary_encode()})
+    sink = io.BytesIO()
+    with pa.ipc.new_stream(sink, d.schema) as w:
+        w.write_table(d)
+    with pytest.raises(A.array.NotYetImplemented):
+        ipc.StreamReader(sink.getvalue(), ctx)
+    good = ipc.write_stream([ffi.from_pyarrow(tbl.to_batches()[0], ctx)], ctx=ctx)
+    with pytest.raises(A.array.IpcError):
+        list(ipc.StreamReader(good[:len(good) - 300], ctx))  # body cut short
+    rb = ffi.from_pyarrow(tbl.to_batches()[0], ctx)
+    meta, body = ipc.encode_batch(rb)
+    with pytest.raises(A.array.IpcError):  # body shorter than the metadata announces
+        ipc.decode_batch(meta, body.ptr, body.nbytes - 64, ipc.Schema.of(rb), ctx)
+    wrong = ipc.Schema([ipc.Field("a", A.Int64), ipc.Field("b", A.Int64)])
+    with pytest.raises(A.array.IpcError):  # more fields than nodes
+        ipc.decode_batch(meta, body.ptr, body.nbytes, wrong, ctx)
+    with pytest.raises(A.array.InvalidArgumentError, match="Alignment should be 8, 16, 32, or 64."):
+        ipc.encode_batch(rb, alignment=24)
+    w = ipc.StreamWriter(io.BytesIO(), ipc.Schema.of(rb), ctx)
+    w.finish()
+    with pytest.raises(A.array.IpcError):
+        w.write(rb)
+
+
+def test_large_batch_moves_as_one_body(ctx, oracle):
+    """2^24 rows x (Int64 + Float64 + Boolean): the body is one allocation whose size is the sum of the padded
+    buffers, and a filter on the decoded views equals the filter on the originals."""
+    n = 1 << 24
+    from orc import HostArray
+    vals = oracle.gen_i64(n, 5, -10**9, 10**9)
+    valid = oracle.gen_bits(n, 6, 0.9)
+    mask = oracle.gen_bits(n, 7, 0.1)
+    a = HostArray(A.Int64, vals, valid).to_device(ctx, bit_offset=3)
+    b = HostArray(A.Float64, vals.astype(np.float64)).to_device(ctx)
+    m = HostArray(A.Boolean, mask).to_device(ctx, bit_offset=5)
+    rb = A.RecordBatch(["a", "b", "m"], [a, b, m], n)
+    meta, body = ipc.encode_batch(rb)
+    assert body.nbytes == 4 * (n // 8) + 2 * n * 8  # validity of a, b (all ones), m + m's value bits; 2 x 8-byte values
+    dec = ipc.decode_batch(meta, body.ptr, body.nbytes, ipc.Schema.of(rb), ctx, keepalive=(body,))
+    got = K.filter(dec.columns[0], dec.columns[2])
+    want = K.filter(a, m)
+    assert got.length == want.length and got.null_count() == want.null_count()
+    assert np.array_equal(got.values_numpy(), want.values_numpy()) and np.array_equal(got.valid_mask(), want.valid_mask())
