@@ -118,6 +118,7 @@ SIGNATURES = {
     "ah_device_free": (None, [_P, _P]),
     "ah_memcpy_htod": (C.c_int32, [_P, _P, _P, C.c_size_t]),
     "ah_memcpy_dtoh": (C.c_int32, [_P, _P, _P, C.c_size_t]),
+    "ah_memcpy_dtod": (C.c_int32, [_P, _P, _P, C.c_size_t]),
     "ah_memset": (C.c_int32, [_P, _P, C.c_int, C.c_size_t]),
     "ah_synchronize": (C.c_int32, [_P]),
     "ah_pool_trim": (None, [_P]),

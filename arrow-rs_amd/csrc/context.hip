@@ -217,6 +217,12 @@ extern "C" ah_status ah_memcpy_htod(ah_context* ctx, void* dst, const void* src,
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AH_OK;
 }
+extern "C" ah_status ah_memcpy_dtod(ah_context* ctx, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return AH_OK;
+  AH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AH_OK;
+}
 extern "C" ah_status ah_memcpy_dtoh(ah_context* ctx, void* dst, const void* src, size_t bytes) {
   if (!bytes) return AH_OK;
   AH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -18,6 +18,11 @@ There is ONE exchange step, an all-gatherv with counts known only after the filt
      gathered into a staging buffer and merged by the funnel-shift kernel
      (``ah_bitmap_set_bits``; reference analogue arrow-buffer/src/util/bit_mask.rs:33).
 
+``Communicator.all_gather_batches`` is the multi-column form: every rank frames its RecordBatch as ONE Arrow
+IPC message (``ipc.encode_batch``: all buffers of all columns in one contiguous HBM body, metadata appended),
+one grouped exchange moves the messages, and each peer's batch is decoded as zero-copy views of the receive
+buffer — a "chunked" result (one batch per rank, in rank order), which is what ``BatchCoalescer`` consumes.
+
 One process per GPU (``torch.distributed``, backend "nccl" == RCCL on ROCm).  torch is only
 used for the collective; device memory stays owned by the arrow_hip context.
 """
@@ -89,6 +94,39 @@ class Communicator:
         if nbytes == 0:
             return self.torch.empty(0, dtype=self.torch.uint8, device=self.device)
         return self.torch.as_tensor(_CudaView(ptr, nbytes), device=self.device)
+
+    def all_gather_batches(self, batch, alignment=64):
+        """Every rank's RecordBatch, in rank order, as zero-copy views into one receive buffer.
+        One count exchange + one grouped send/recv per call, however many columns the batch has."""
+        from . import ipc
+        torch, dist, ctx = self.torch, self.dist, self.ctx
+        meta, body = ipc.encode_batch(batch, alignment)
+        mlen = len(meta)
+        # message = body | metadata (metadata is a multiple of `alignment`, so the next slot stays aligned)
+        msg = DeviceBuffer(ctx, max(body.nbytes + mlen, 8))
+        lib, h = ctx.lib, ctx.handle
+        ctx.check(lib.ah_memcpy_dtod(h, msg.ptr, body.ptr, body.nbytes))
+        mbuf = (C.c_char * mlen).from_buffer_copy(meta)
+        ctx.check(lib.ah_memcpy_htod(h, msg.ptr + body.nbytes, mbuf, mlen))
+        mine = torch.tensor([body.nbytes, mlen], dtype=torch.int64, device=self.device)
+        allc = torch.empty(self.world * 2, dtype=torch.int64, device=self.device)
+        ctx.synchronize()
+        dist.all_gather_into_tensor(allc, mine, group=self.group)
+        counts = allc.view(self.world, 2).cpu().tolist()
+        sizes = [b + m for b, m in counts]
+        offs, total = exclusive_offsets(sizes)
+        recv = DeviceBuffer(ctx, max(total, 8))
+        all_gatherv_bytes(dist, self._tensor(msg.ptr, sizes[self.rank]), self._tensor(recv.ptr, total), offs, sizes,
+                          self.group)
+        torch.cuda.synchronize(self.device)
+        schema = ipc.Schema.of(batch)
+        out = []
+        for r in range(self.world):
+            blen, ml = counts[r]
+            host = (C.c_char * ml)()
+            ctx.check(lib.ah_memcpy_dtoh(h, host, recv.ptr + offs[r] + blen, ml))
+            out.append(ipc.decode_batch(bytes(host), recv.ptr + offs[r], blen, schema, ctx, keepalive=(recv,)))
+        return out
 
     def all_gatherv(self, array):
         """Concatenation of every rank's ``array`` in rank order, materialised on every rank

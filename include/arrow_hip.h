@@ -144,6 +144,7 @@ AH_API ah_status ah_device_alloc(ah_context* ctx, size_t bytes, void** out);
 AH_API void ah_device_free(ah_context* ctx, void* ptr);
 AH_API ah_status ah_memcpy_htod(ah_context* ctx, void* dst, const void* src, size_t bytes);
 AH_API ah_status ah_memcpy_dtoh(ah_context* ctx, void* dst, const void* src, size_t bytes);
+AH_API ah_status ah_memcpy_dtod(ah_context* ctx, void* dst, const void* src, size_t bytes);
 AH_API ah_status ah_memset(ah_context* ctx, void* dst, int value, size_t bytes);
 AH_API ah_status ah_synchronize(ah_context* ctx);
 AH_API void ah_pool_trim(ah_context* ctx); /* hipFree everything cached in the pool */

@@ -37,6 +37,24 @@ for case, (p_valid, sel, dt) in enumerate([(0.9, 0.1, A.Int64), (1.0, 0.37, A.Fl
     got = HostArray.from_device(g)
     orc.assert_logical_eq(got, exp, f"rank {rank} case {case}")
     assert g.null_count() == exp.null_count and (g.nulls() is None) == (exp.valid is None)
+# multi-column form: one IPC-framed message per rank, decoded as zero-copy views (chunked result)
+vals = oracle.gen_i64(n, 77, -10**9, 10**9)
+valid = oracle.gen_bits(n, 78, 0.9)
+mask = oracle.gen_bits(n, 79, 0.2)
+strs = [None if i % 13 == 0 else f"r{i}" * (i % 4) for i in range(20_000)]
+s, e = D.shard_range(n, rank, world)
+ss, se = D.shard_range(len(strs), rank, world)
+cols = [HostArray(A.Int64, vals[s:e], valid[s:e]).to_device(ctx, 3), HostArray(A.Float64, vals[s:e].astype(np.float64)).to_device(ctx)]
+rb = K.filter_record_batch(A.RecordBatch(["a", "b"], cols), HostArray(A.Boolean, mask[s:e]).to_device(ctx))
+parts = comm.all_gather_batches(rb)
+assert len(parts) == world
+exp_a = oracle.filter(HostArray(A.Int64, vals, valid), HostArray(A.Boolean, mask))
+exp_b = oracle.filter(HostArray(A.Float64, vals.astype(np.float64)), HostArray(A.Boolean, mask))
+orc.assert_logical_eq(HostArray.from_device(K.concat([p.columns[0] for p in parts])), exp_a, f"rank {rank} ipc a")
+orc.assert_logical_eq(HostArray.from_device(K.concat([p.columns[1] for p in parts])), exp_b, f"rank {rank} ipc b")
+sb = A.RecordBatch(["s"], [A.Array.from_strings([x or "" for x in strs[ss:se]], [x is not None for x in strs[ss:se]], ctx=ctx)])
+got = [x for p in comm.all_gather_batches(sb) for x in p.columns[0].to_pylist()]
+assert got == strs, f"rank {rank} ipc strings"
 dist.barrier()
 dist.destroy_process_group()
 print("RANK_OK", rank)
