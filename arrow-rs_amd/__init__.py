@@ -11,5 +11,6 @@ from .array import (Array, Scalar, RecordBatch, Context, DeviceBuffer, DataType,
 from . import compute  # noqa: F401
 from . import ffi  # noqa: F401
 from . import ipc  # noqa: F401
+from . import selection  # noqa: F401
 
 __version__ = "0.1.0"

@@ -153,6 +153,11 @@ SIGNATURES = {
     "ah_gen_bernoulli_bits": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_double, C.c_int64]),
     "ah_zero_null_slots": (C.c_int32, [_P, _P, C.c_int32, _P, C.c_int64]),
     "ah_aggregate": (C.c_int32, [_P, C.c_int32, _VIEW, C.POINTER(Scalar)]),
+    "ah_selection_and_then": (C.c_int32, [_P, _VIEW, _VIEW, _OUT]),
+    "ah_selection_combine": (C.c_int32, [_P, C.c_int32, _VIEW, _VIEW, _OUT]),
+    "ah_selection_boundaries": (C.c_int32, [_P, _VIEW, _OUT]),
+    "ah_selection_from_boundaries": (C.c_int32, [_P, _VIEW, C.c_int64, _OUT]),
+    "ah_selection_find_nth_set_bit": (C.c_int32, [_P, _VIEW, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     "ah_ipc_schema_message": (C.c_int32, [_P, C.c_int32, C.POINTER(IpcField), C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "ah_ipc_decode_schema": (C.c_int32, [_P, C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.POINTER(IpcField))]),
     "ah_ipc_encode_batch": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int64, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64),

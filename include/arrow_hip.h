@@ -389,6 +389,33 @@ AH_API ah_status ah_import_c_data(ah_context* ctx, const struct ArrowArray* arra
 AH_API ah_status ah_export_c_data(ah_context* ctx, const ah_array_view* values, const char* format,
                                   struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 
+/* ---------------------------------------------------------- row selection */
+/* parquet `RowSelection`, bitmap-backed form (parquet/src/arrow/arrow_reader/selection/): the structure the
+ * parquet reader's row-filter loop (arrow_reader/read_plan.rs) builds from predicate results and chains with
+ * `and_then` — the largest in-tree caller of `filter`.  Masks are AH_BOOL views WITHOUT nulls (a null count
+ * > 0 is the reference's `assert_eq!(filter.null_count(), 0)` panic, mod.rs:318).
+ *  and_then      : `RowSelection::and_then` on masks (algebra.rs:392-436): out[i] = mask[i] & other[rank(i)];
+ *                  other->length must equal the number of set bits of mask (reference panic texts otherwise);
+ *                  all-true `other` returns the input zero-copy (AH_OUT_BORROWED).
+ *  combine       : op 0 `intersection`, 1 `union` (algebra.rs:267-349): over the common prefix, the longer
+ *                  side's tail passes through.
+ *  boundaries    : the RLE form (`mask_to_selectors`, boolean.rs:172-190) as ascending Int64 positions p with
+ *                  bit[p] != bit[p-1] (bit[-1] = 0): runs alternate skip/select starting with a skip run that
+ *                  is empty when the first boundary is 0.
+ *  from_boundaries: the inverse (`From<Vec<RowSelector>>`, `from_consecutive_ranges` mod.rs:326).
+ *  find_nth_set_bit: `BooleanBuffer::find_nth_set_bit_position(start, n)` (arrow-buffer/src/buffer/
+ *                  boolean.rs:445): one past the n-th (1-based) set bit at or after start, else length — the
+ *                  primitive under `offset` / `limit` / `trim` (boolean.rs:281-309). */
+AH_API ah_status ah_selection_and_then(ah_context* ctx, const ah_array_view* mask, const ah_array_view* other,
+                                       ah_array_out* out);
+AH_API ah_status ah_selection_combine(ah_context* ctx, int32_t op, const ah_array_view* l, const ah_array_view* r,
+                                      ah_array_out* out);
+AH_API ah_status ah_selection_boundaries(ah_context* ctx, const ah_array_view* mask, ah_array_out* out);
+AH_API ah_status ah_selection_from_boundaries(ah_context* ctx, const ah_array_view* bounds, int64_t total_rows,
+                                              ah_array_out* out);
+AH_API ah_status ah_selection_find_nth_set_bit(ah_context* ctx, const ah_array_view* mask, int64_t start, int64_t n,
+                                               int64_t* pos);
+
 /* ------------------------------------------------------------- Arrow IPC */
 /* Record-batch framing of the Arrow IPC format (arrow-ipc/src/writer.rs, reader.rs; format/Message.fbs,
  * format/Schema.fbs) for batches whose buffers live in HBM.  A message is a small host-side metadata block

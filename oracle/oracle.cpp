@@ -1861,6 +1861,57 @@ int32_t orc_aggregate(int32_t op, const orc_view* a, int32_t vector_bytes, orc_s
   return fail(ORC_NOT_YET_IMPLEMENTED, "aggregate of %s", type_name(a->type));
 }
 
+// ---- parquet RowSelection on masks
+int32_t orc_selection_and_then(const orc_view* m, const orc_view* o, orc_out* out) {  // and_then_masks
+  out_init(out);
+  const uint8_t* mb = (const uint8_t*)m->values;
+  const uint8_t* ob = (const uint8_t*)o->values;
+  const int64_t selected = count_set_bits(mb, m->values_bit_offset, m->length);
+  if (o->length < selected) return fail(ORC_PANIC, "selection contains less than the number of selected rows");
+  if (o->length > selected) return fail(ORC_PANIC, "selection exceeds the number of selected rows");
+  out->type = ORC_BOOL;
+  out->length = m->length;
+  uint8_t* r = (uint8_t*)xalloc(bitmap_bytes(m->length));
+  out->values = r;
+  out->values_bytes = (int64_t)bitmap_bytes(m->length);
+  int64_t ordinal = 0;  // walk the set positions of `mask`, consuming one bit of `other` each
+  for (int64_t i = 0; i < m->length; ++i)
+    if (get_bit(mb, m->values_bit_offset + i)) {
+      if (get_bit(ob, o->values_bit_offset + ordinal)) set_bit(r, i);
+      ++ordinal;
+    }
+  return ORC_OK;
+}
+
+int32_t orc_selection_combine(int32_t op, const orc_view* l, const orc_view* r, orc_out* out) {
+  out_init(out);
+  const orc_view* longer = l->length > r->length ? l : r;  // combine_unequal_length_masks :319-349
+  const orc_view* shorter = longer == l ? r : l;
+  out->type = ORC_BOOL;
+  out->length = longer->length;
+  uint8_t* res = (uint8_t*)xalloc(bitmap_bytes(longer->length));
+  out->values = res;
+  out->values_bytes = (int64_t)bitmap_bytes(longer->length);
+  const uint8_t* lb = (const uint8_t*)longer->values;
+  const uint8_t* sb = (const uint8_t*)shorter->values;
+  for (int64_t i = 0; i < longer->length; ++i) {
+    bool v = get_bit(lb, longer->values_bit_offset + i);
+    if (i < shorter->length) {
+      const bool w = get_bit(sb, shorter->values_bit_offset + i);
+      v = op == 0 ? (v && w) : (v || w);
+    }
+    if (v) set_bit(res, i);
+  }
+  return ORC_OK;
+}
+
+int64_t orc_find_nth_set_bit(const uint8_t* bits, int64_t off, int64_t len, int64_t start, int64_t n) {
+  if (n == 0) return start;
+  for (int64_t i = start; i < len; ++i)
+    if (get_bit(bits, off + i) && --n == 0) return i + 1;
+  return len;
+}
+
 // concat for primitives / booleans (arrow-select/src/concat.rs:334-343, :495)
 int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out) {
   out_init(out);

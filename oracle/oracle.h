@@ -103,6 +103,14 @@ typedef struct orc_scalar {
 } orc_scalar;
 int32_t orc_aggregate(int32_t op, const orc_view* values, int32_t vector_bytes, orc_scalar* out);
 
+/* parquet RowSelection, bitmap-backed form (parquet/src/arrow/arrow_reader/selection/): masks are ORC_BOOL views
+ * without nulls.  and_then: algebra.rs:392-436 (panic texts as ORC_PANIC); combine op 0 = intersect_masks,
+ * 1 = union_masks (:267-349, the longer side's tail passes through); find_nth_set_bit_position:
+ * arrow-buffer/src/buffer/boolean.rs:445-455. */
+int32_t orc_selection_and_then(const orc_view* mask, const orc_view* other, orc_out* out);
+int32_t orc_selection_combine(int32_t op, const orc_view* l, const orc_view* r, orc_out* out);
+int64_t orc_find_nth_set_bit(const uint8_t* bits, int64_t bit_offset, int64_t len, int64_t start, int64_t n);
+
 /* format one f64/f32 the way ryu::Buffer::format does; returns the length */
 int32_t orc_format_f64(double v, char* buf /* >= 32 */);
 int32_t orc_format_f32(float v, char* buf /* >= 32 */);

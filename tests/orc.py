@@ -153,6 +153,10 @@ class Oracle:
         lib.orc_nullif.argtypes = [VP, VP, OP]
         lib.orc_concat.argtypes = [C.c_int32, VP, OP]
         lib.orc_aggregate.argtypes = [C.c_int32, VP, C.c_int32, C.POINTER(ScalarOut)]
+        lib.orc_selection_and_then.argtypes = [VP, VP, OP]
+        lib.orc_selection_combine.argtypes = [C.c_int32, VP, VP, OP]
+        lib.orc_find_nth_set_bit.restype = C.c_int64
+        lib.orc_find_nth_set_bit.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
         lib.orc_count_set_bits.restype = C.c_int64
         lib.orc_count_set_bits.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
         for f in (lib.orc_set_slices, lib.orc_set_indices):
@@ -284,6 +288,26 @@ class Oracle:
         if st:
             self._raise(st)
         return out.value(np.uint8 if values.data_type.physical == L.AH_BOOL else values.data_type.np_dtype)
+
+    def selection_and_then(self, mask, other, bit_offset=0):
+        hm, ho = _Held(mask, bit_offset), _Held(other, bit_offset)
+        out = Out()
+        st = self.lib.orc_selection_and_then(C.byref(hm.view), C.byref(ho.view), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, A.Boolean)
+
+    def selection_combine(self, op, left, right, bit_offset=0):
+        hl, hr = _Held(left, bit_offset), _Held(right, bit_offset)
+        out = Out()
+        st = self.lib.orc_selection_combine(op, C.byref(hl.view), C.byref(hr.view), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, A.Boolean)
+
+    def find_nth_set_bit(self, mask, start, n, bit_offset=0):
+        packed = A.pack_bits(np.asarray(mask, dtype=bool), bit_offset)
+        return int(self.lib.orc_find_nth_set_bit(packed.ctypes.data, bit_offset, len(mask), start, n))
 
     def concat(self, arrays):
         held = [_Held(a) for a in arrays]

@@ -431,3 +431,32 @@ def test_aggregate_golden(oracle, case, bit_offset, vector_bytes):
         return expect_err(case, lambda: oracle.aggregate(case["op"], v, vector_bytes, bit_offset))
     got = oracle.aggregate(case["op"], v, vector_bytes, bit_offset)
     assert _same_scalar(got, case["expected"], v.data_type), (got, case["expected"])
+
+
+# ---------------------------------------------------------------- parquet RowSelection (oracle pinned on the
+# reference's own unit tests, transcribed in tests/selection_cases.py)
+import selection_cases  # noqa: E402
+from selection_model import ModelSelection  # noqa: E402
+
+
+@pytest.mark.parametrize("case", selection_cases.ALL_CASES, ids=lambda f: f.__name__)
+def test_selection_reference_cases_on_the_oracle(oracle, case):
+    ModelSelection.oracle = oracle
+    case(ModelSelection)
+
+
+def test_selection_and_then_fuzz_recipe(oracle):
+    """algebra.rs:583-612 `test_and_fuzz`, verbatim recipe, oracle vs the naive definition."""
+    ModelSelection.oracle = oracle
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        a_len = int(rng.integers(10, 100))
+        a = rng.random(a_len) < 0.2
+        b = rng.random(int(a.sum())) < 0.8
+        exp = np.zeros(a_len, bool)
+        it = iter(b)
+        for i, x in enumerate(a):
+            if x and next(it):
+                exp[i] = True
+        got = ModelSelection(a).and_then(ModelSelection(b))
+        assert got == ModelSelection(exp) and got.total_row_count() == a_len
