@@ -1,0 +1,62 @@
+"""Wall-clock timings (synchronous C-ABI calls, median of 5) of the SURVEY §8f rows that have no bench.py
+workload: RowSelection algebra at 2^30 rows, IPC encode/decode of a 2^28-row 3-column batch.  One JSON line."""
+import json
+import os
+import statistics
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import arrow_rs_amd as A  # noqa: E402
+from arrow_rs_amd import ipc  # noqa: E402
+from arrow_rs_amd.selection import RowSelection  # noqa: E402
+import bench  # noqa: E402
+
+ctx = A.Context(0)
+A.set_default_context(ctx)
+
+
+def med(fn, reps=5):
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return round(statistics.median(ts) * 1e3, 3)
+
+
+res = {}
+n = 1 << 30
+buf = ctx.alloc(n // 8)
+ctx.check(ctx.lib.ah_gen_bernoulli_bits(ctx.handle, buf.ptr, n, 11, 0.1, 0))
+s = RowSelection(A.Array(ctx, A.Boolean, n, A.array._RawMem(buf.ptr, n // 8, buf)))
+k = s.row_count()
+ob = ctx.alloc((k + 63) // 64 * 8)
+ctx.check(ctx.lib.ah_gen_bernoulli_bits(ctx.handle, ob.ptr, k, 12, 0.5, 0))
+o = RowSelection(A.Array(ctx, A.Boolean, k, A.array._RawMem(ob.ptr, ob.nbytes, ob)))
+res["selection_rows"] = n
+res["and_then_ms"] = med(lambda: s.and_then(o))
+res["intersection_ms"] = med(lambda: s.intersection(s))
+res["boundaries_ms"] = med(lambda: s.boundaries())
+res["boundaries"] = s.boundaries().length
+res["find_nth_ms"] = med(lambda: s._find_nth(k // 2))
+b = s.boundaries()
+res["from_boundaries_ms"] = med(lambda: RowSelection.from_boundaries.__func__(RowSelection, [], 0, ctx) if False else
+                                ctx.check(ctx.lib.ah_selection_from_boundaries(
+                                    ctx.handle, __import__("ctypes").byref(b.view()), n,
+                                    __import__("ctypes").byref(A._lib.ArrayOut()))))
+del s, o, b, buf, ob
+
+m = 1 << 28
+a = bench.gen_i64_column(A, ctx, m, 42, 0.9, 0)
+f = bench.gen_f64_column(A, ctx, m, 52, 0.9, 0)
+p = bench.gen_predicate(A, ctx, m, 44, 0.1, 0)
+rb = A.RecordBatch(["a", "f", "p"], [a, f, p], m)
+meta, body = ipc.encode_batch(rb)
+res["ipc_rows"], res["ipc_body_bytes"] = m, body.nbytes
+res["ipc_encode_ms"] = med(lambda: ipc.encode_batch(rb))
+res["ipc_encode_GBps"] = round(2 * body.nbytes / (res["ipc_encode_ms"] * 1e-3) / 1e9, 1)  # read + write
+sch = ipc.Schema.of(rb)
+res["ipc_decode_ms"] = med(lambda: ipc.decode_batch(meta, body.ptr, body.nbytes, sch, ctx, keepalive=(body,)))
+print(json.dumps(res))

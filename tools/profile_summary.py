@@ -40,7 +40,8 @@ for sub, title in [("trace", "filter + take step (bench.py default)"), ("trace_a
                    ("trace_cmp", "lt f64"), ("trace_cast", "cast Int64->Float64"),
                    ("trace_cast_string", "cast Float64->LargeUtf8"),
                    ("trace_coalesce", "BatchCoalescer.push_batch_with_filter (2 columns, 2^24-row batches)"),
-                   ("trace_string_filter_take", "filter + take on a LargeUtf8 column (2^27 rows)")]:
+                   ("trace_string_filter_take", "filter + take on a LargeUtf8 column (2^27 rows)"),
+                   ("trace_aggregate", "sum + min + max of an Int64 column (1e9 rows, 10 % nulls)")]:
     p = os.path.join(src, sub, "bench_kernel_stats.csv")
     if not os.path.exists(p):
         continue
@@ -101,7 +102,7 @@ if pm:
                "hbm_bytes_per_launch": traffic}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 # streaming kernels of the other workloads: FETCH x2 + WRITE
 extra = []
-for wl, kern in [("arith", "arith_kernel"), ("cmp", "compare_kernel")]:
+for wl, kern in [("arith", "arith_kernel"), ("cmp", "compare_kernel"), ("aggregate", "agg_kernel")]:
     vals = {}
     for sub, cname in [(f"fetch_{wl}", "FETCH_SIZE"), (f"write_{wl}", "WRITE_SIZE")]:
         p = os.path.join(src, sub, "bench_counter_collection.csv")
@@ -109,9 +110,10 @@ for wl, kern in [("arith", "arith_kernel"), ("cmp", "compare_kernel")]:
             xs = [float(r["Counter_Value"]) for r in csv.DictReader(open(p)) if kern in r["Kernel_Name"]]
             if xs:
                 vals[cname] = sum(xs) / len(xs)
-    if len(vals) == 2:
+    if "FETCH_SIZE" in vals:
+        vals.setdefault("WRITE_SIZE", 0.0)
         tot = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
-        extra.append(f"| {kern} ({wl}, 1e9 f64 rows) | {vals['FETCH_SIZE']:.0f} | {vals['WRITE_SIZE']:.0f} | {tot/1e9:.2f} GB | wide coalesced reads: FETCH x2 |")
+        extra.append(f"| {kern} ({wl}, 1e9 rows) | {vals['FETCH_SIZE']:.0f} | {vals['WRITE_SIZE']:.0f} | {tot/1e9:.2f} GB | wide coalesced reads: FETCH x2 |")
 if extra:
     out.append("## HBM traffic of the other streaming kernels (PMC)\n")
     out.append("| kernel | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes per launch (corrected) | note |")
@@ -134,6 +136,17 @@ if os.path.exists(p):
         out.append(f"| {k} | " + " | ".join(f"{sum(v[n])/max(len(v[n]),1):.3g}" if n in v else "-" for n in names) + " |")
     out.append("")
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(out) + "\n")
+nr = os.path.join(src, "next_rows.json")
+if os.path.exists(nr):
+    for l in open(nr):
+        if l.startswith("{"):
+            d = json.loads(l)
+            with open(os.path.join(dst, f"{tag}_summary.md"), "a") as fsum:
+                fsum.write("\n## SURVEY §8f rows without a bench workload (tools/next_rows_time.py, wall clock of the "
+                           "synchronous C-ABI call, median of 5)\n\n| quantity | value |\n|---|---|\n")
+                for k, v in d.items():
+                    fsum.write(f"| {k} | {v} |\n")
+            shutil.copy(nr, os.path.join(dst, f"{tag}_next_rows.json"))
 for f in ["bench_plain.json"]:
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
