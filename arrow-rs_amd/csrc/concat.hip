@@ -10,6 +10,103 @@
 // arrow-buffer/src/util/bit_mask.rs:33 set_bits).
 #include "common.hpp"
 
+#include <vector>
+
+namespace {
+
+// GenericByteBuilder::append_array (arrow-array/src/builder/generic_bytes_builder.rs:169-206): offsets shifted so
+// the piece continues at the builder's next offset
+template <typename O>
+__global__ void shift_offsets_kernel(const O* in, O* out, int64_t n, O first, O base) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (O)(in[i] - first + base);
+}
+
+// concat_bytes (arrow-select/src/concat.rs:355-368)
+ah_status concat_strings(ah_context* ctx, int32_t n, const ah_array_view* pieces, bool any_nulls, int64_t total,
+                         ah_array_out* out) {
+  const ah_type t = pieces[0].type;
+  const int ow = t == AH_UTF8 ? 4 : 8;
+  std::vector<int64_t> first(n, 0), last(n, 0);
+  for (int i0 = 0; i0 < n; i0 += 64) {  // 2 scalars per piece through the pinned slots, 64 pieces per round trip
+    const int cnt = std::min(64, n - i0);
+    for (int j = 0; j < cnt; ++j) {
+      const ah_array_view& p = pieces[i0 + j];
+      ctx->pinned[2 * j] = ctx->pinned[2 * j + 1] = 0;
+      if (p.length == 0) continue;
+      AH_HIP(ctx, hipMemcpyAsync(ctx->pinned + 2 * j, p.offsets, ow, hipMemcpyDeviceToHost, ctx->stream));
+      AH_HIP(ctx, hipMemcpyAsync(ctx->pinned + 2 * j + 1, (const char*)p.offsets + p.length * ow, ow,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    }
+    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < cnt; ++j) {
+      first[i0 + j] = ow == 4 ? (int64_t)(int32_t)ctx->pinned[2 * j] : (int64_t)ctx->pinned[2 * j];
+      last[i0 + j] = ow == 4 ? (int64_t)(int32_t)ctx->pinned[2 * j + 1] : (int64_t)ctx->pinned[2 * j + 1];
+    }
+  }
+  int64_t bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    bytes += last[i] - first[i];
+    if (ow == 4 && bytes > INT32_MAX)  // :185-189 `OffsetOverflowError(shift + last offset)`
+      return ah_fail(ctx, AH_OFFSET_OVERFLOW_ERROR, "%lld", (long long)bytes);
+  }
+  const size_t obytes = (size_t)(total + 1) * ow, dbytes = (size_t)std::max<int64_t>(bytes, 8);
+  const size_t bbytes = any_nulls ? ah_bitmap_bytes(total) : 0;
+  void *oo = nullptr, *od = nullptr, *ob = nullptr;
+  ah_status st = ah_out_alloc(ctx, obytes, &oo);
+  if (st == AH_OK) st = ah_out_alloc(ctx, dbytes, &od);
+  if (st == AH_OK && any_nulls) st = ah_out_alloc(ctx, bbytes, &ob);
+  auto cleanup = [&](ah_status s) {
+    ah_out_free(ctx, oo, obytes);
+    ah_out_free(ctx, od, dbytes);
+    ah_out_free(ctx, ob, bbytes);
+    return s;
+  };
+  if (st != AH_OK) return cleanup(st);
+  if (any_nulls) hipMemsetAsync(ob, 0, bbytes, ctx->stream);
+  int64_t pos = 0, base = 0, valid_total = 0;
+  ah_prof_scope ps(ctx, "concat");
+  for (int i = 0; i < n && st == AH_OK; ++i) {
+    const ah_array_view& p = pieces[i];
+    if (p.length == 0) continue;
+    const int64_t cnt = p.length + 1;
+    const unsigned grid = (unsigned)((cnt + 255) / 256);
+    if (ow == 4)
+      hipLaunchKernelGGL(shift_offsets_kernel<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int32_t*)p.offsets,
+                         (int32_t*)oo + pos, cnt, (int32_t)first[i], (int32_t)base);
+    else
+      hipLaunchKernelGGL(shift_offsets_kernel<int64_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)p.offsets,
+                         (int64_t*)oo + pos, cnt, first[i], base);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && last[i] > first[i])
+      e = hipMemcpyAsync((char*)od + base, (const char*)p.values + first[i], (size_t)(last[i] - first[i]),
+                         hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "concat copy failed: %s", hipGetErrorString(e));
+    if (st == AH_OK && any_nulls) {
+      int64_t set = 0;
+      st = ah_bitmap_set_bits(ctx, (uint8_t*)ob, pos, p.validity, p.validity_bit_offset, p.length, &set);
+      valid_total += set;
+    }
+    pos += p.length;
+    base += last[i] - first[i];
+  }
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (st == AH_OK && e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "concat failed: %s", hipGetErrorString(e));
+  if (st != AH_OK) return cleanup(st);
+  out->offsets = oo;
+  out->offsets_bytes = (int64_t)obytes;
+  out->values = od;
+  out->values_bytes = (int64_t)dbytes;
+  if (any_nulls) {
+    out->validity = (uint8_t*)ob;
+    out->validity_bytes = (int64_t)bbytes;
+    out->null_count = total - valid_total;
+  }
+  return AH_OK;
+}
+
+}  // namespace
+
 extern "C" ah_status ah_concat(ah_context* ctx, int32_t n, const ah_array_view* pieces,
                                ah_array_out* out) {
   if (!ctx || !out || (n > 0 && !pieces)) return AH_INVALID_ARGUMENT;
@@ -18,7 +115,8 @@ extern "C" ah_status ah_concat(ah_context* ctx, int32_t n, const ah_array_view* 
   if (n <= 0) return ah_fail(ctx, AH_INVALID_ARGUMENT, "concat requires input of at least one array");
   const ah_type t = pieces[0].type;
   const int w = ah_type_width(t);
-  if (w < 0 || t == AH_UTF8_VIEW || t == AH_BINARY_VIEW)  // views: buffer indices would need renumbering
+  const bool is_str = t == AH_UTF8 || t == AH_LARGE_UTF8;
+  if ((w < 0 && !is_str) || t == AH_UTF8_VIEW || t == AH_BINARY_VIEW)  // views: buffer indices would need renumbering
     return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "concat not supported for type %s", ah_type_name(t));
   int64_t total = 0;
   bool any_nulls = false;
@@ -35,6 +133,11 @@ extern "C" ah_status ah_concat(ah_context* ctx, int32_t n, const ah_array_view* 
   out->type = t;
   out->length = total;
   if (total == 0) return AH_OK;
+  if (is_str) {
+    ah_status st = concat_strings(ctx, n, pieces, any_nulls, total, out);
+    if (st != AH_OK) ah_out_init(out);
+    return st;
+  }
   size_t vbytes = w ? (size_t)total * w : ah_bitmap_bytes(total);
   size_t bbytes = any_nulls ? ah_bitmap_bytes(total) : 0;
   void* ov = nullptr;

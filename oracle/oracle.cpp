@@ -1918,7 +1918,8 @@ int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out) {
   if (n <= 0) return fail(ORC_INVALID_ARGUMENT, "concat requires input of at least one array");
   int32_t t = pieces[0].type;
   int w = type_width(t);
-  if (w < 0) return fail(ORC_NOT_YET_IMPLEMENTED, "concat not supported for type %s", type_name(t));
+  const bool is_str = t == ORC_UTF8 || t == ORC_LARGE_UTF8;
+  if (w < 0 && !is_str) return fail(ORC_NOT_YET_IMPLEMENTED, "concat not supported for type %s", type_name(t));
   int64_t total = 0;
   bool any_valid_buf = false;
   for (int i = 0; i < n; ++i) {
@@ -1931,6 +1932,48 @@ int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out) {
   }
   out->type = t;
   out->length = total;
+  if (is_str) {  // concat_bytes (concat.rs:355-368) -> GenericByteBuilder::append_array (generic_bytes_builder.rs:169-206)
+    if (total == 0) return ORC_OK;
+    const int ow = t == ORC_UTF8 ? 4 : 8;
+    auto off = [&](const orc_view* p, int64_t i) -> int64_t {
+      return ow == 4 ? (int64_t)((const int32_t*)p->offsets)[i] : ((const int64_t*)p->offsets)[i];
+    };
+    int64_t bytes = 0;
+    for (int i = 0; i < n; ++i) {
+      if (pieces[i].length == 0) continue;
+      bytes += off(&pieces[i], pieces[i].length) - off(&pieces[i], 0);
+      if (ow == 4 && bytes > INT32_MAX) return fail(ORC_OFFSET_OVERFLOW_ERROR, "%lld", (long long)bytes);
+    }
+    out->offsets = xalloc((size_t)(total + 1) * ow);
+    out->offsets_bytes = (total + 1) * ow;
+    out->values = xalloc((size_t)(bytes ? bytes : 8));
+    out->values_bytes = bytes ? bytes : 8;
+    uint8_t* nb = any_valid_buf ? (uint8_t*)xalloc(bitmap_bytes(total)) : nullptr;
+    int64_t pos = 0, base = 0;
+    for (int i = 0; i < n; ++i) {
+      const orc_view* p = &pieces[i];
+      if (p->length == 0) continue;
+      const int64_t first = off(p, 0);
+      for (int64_t j = 0; j <= p->length; ++j) {
+        const int64_t v = off(p, j) - first + base;
+        if (ow == 4) ((int32_t*)out->offsets)[pos + j] = (int32_t)v;
+        else ((int64_t*)out->offsets)[pos + j] = v;
+      }
+      memcpy((char*)out->values + base, (const char*)p->values + first, (size_t)(off(p, p->length) - first));
+      if (nb) {
+        if (p->validity) copy_bits(nb, pos, p->validity, p->validity_bit_offset, p->length);
+        else for (int64_t j = 0; j < p->length; ++j) set_bit(nb, pos + j);
+      }
+      pos += p->length;
+      base += off(p, p->length) - first;
+    }
+    if (nb) {
+      out->validity = nb;
+      out->validity_bytes = (int64_t)bitmap_bytes(total);
+      out->null_count = total - count_set_bits(nb, 0, total);
+    }
+    return ORC_OK;
+  }
   size_t vbytes = w ? (size_t)total * w : bitmap_bytes(total);
   out->values = xalloc(vbytes);
   out->values_bytes = (int64_t)vbytes;

@@ -412,7 +412,29 @@ mix = [{0: "-inf", 1: -1.7976931348623157e308, 2: 1.7976931348623157e308, 4: "in
 agg("float_inf_and_nans_min", 1484, "min", arr("Float64", mix), "-inf")
 agg("float_inf_and_nans_max", 1484, "max", arr("Float64", mix), "nan")
 
-for name, cases in [("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
+
+# ---------------------------------------------------------------- concat (arrow-select/src/concat.rs tests)
+concat_cases = [
+    dict(name="test_concat_string_arrays", source="arrow-select/src/concat.rs:832-853",
+         pieces=[arr("Utf8", ["hello", "world"]), arr("Utf8", ["2", "3", "4"]), arr("Utf8", ["foo", "bar", N, "baz"])],
+         expected=arr("Utf8", ["hello", "world", "2", "3", "4", "foo", "bar", N, "baz"])),
+    dict(name="test_concat_large_string_arrays", source="arrow-select/src/concat.rs:832-853 (LargeUtf8 instantiation)",
+         pieces=[arr("LargeUtf8", ["hello", "world"]), arr("LargeUtf8", ["2", "3", "4"]), arr("LargeUtf8", ["foo", "bar", N, "baz"])],
+         expected=arr("LargeUtf8", ["hello", "world", "2", "3", "4", "foo", "bar", N, "baz"])),
+    dict(name="test_concat_primitive_arrays", source="arrow-select/src/concat.rs:880-904",
+         pieces=[arr("Int64", [-1, -1, 2, N, N]), arr("Int64", [101, 102, 103, N]), arr("Int64", [256, 512, 1024])],
+         expected=arr("Int64", [-1, -1, 2, N, N, 101, 102, 103, N, 256, 512, 1024])),
+    dict(name="test_concat_primitive_array_slices", source="arrow-select/src/concat.rs:907-927",
+         pieces=[arr("Int64", [-1, -1, 2, N, N], [1, 3]), arr("Int64", [101, 102, 103, N], [1, 3])],
+         expected=arr("Int64", [-1, 2, N, 102, 103, N])),
+    dict(name="test_concat_boolean_primitive_arrays", source="arrow-select/src/concat.rs:930-958",
+         pieces=[arr("Boolean", [T, T, F, N, N, F]), arr("Boolean", [N, F, T, F])],
+         expected=arr("Boolean", [T, T, F, N, N, F, N, F, T, F])),
+    dict(name="string_slices", source="arrow-select/src/concat.rs:1140-1170 (test_string_array_slices recipe)",
+         pieces=[arr("Utf8", ["hello", "A", "B", "C"], [1, 3]), arr("Utf8", ["D", "E", N, "F"], [2, 2])],
+         expected=arr("Utf8", ["A", "B", "C", N, "F"])),
+]
+for name, cases in [("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
                     ("cast", cast_cases)]:
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump({"reference": "apache/arrow-rs 59.2.0", "cases": cases}, f, indent=1)

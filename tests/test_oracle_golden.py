@@ -460,3 +460,10 @@ def test_selection_and_then_fuzz_recipe(oracle):
                 exp[i] = True
         got = ModelSelection(a).and_then(ModelSelection(b))
         assert got == ModelSelection(exp) and got.total_row_count() == a_len
+
+
+# ------------------------------------------------------------------- concat
+@pytest.mark.parametrize("case", load_golden("concat"), ids=lambda c: c["name"])
+def test_concat_golden(oracle, case):
+    got = oracle.concat([golden_array(p) for p in case["pieces"]])
+    assert_logical_eq(got, golden_array(case["expected"]), case["name"])
