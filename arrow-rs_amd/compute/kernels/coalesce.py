@@ -1,5 +1,7 @@
 """arrow::compute::BatchCoalescer == arrow_select::coalesce::BatchCoalescer
-(arrow-select/src/coalesce.rs:148-700), primitive columns (coalesce/primitive.rs).
+(arrow-select/src/coalesce.rs:148-700): primitive columns (coalesce/primitive.rs) through the fused
+filter-into-builder path, every other supported layout (Boolean, Utf8, LargeUtf8) through the reference's
+generic buffer-and-concat implementation (coalesce/generic.rs).
 
 The host state machine (exact-size output batches, in input order, optional large-batch bypass)
 is restated here; the data movement happens in HBM:
@@ -64,6 +66,34 @@ class _InProgress:
         return arr
 
 
+class _InProgressGeneric:
+    """GenericInProgressArray (coalesce/generic.rs:32-108): buffers slices / filtered arrays, `concat` on finish."""
+
+    def __init__(self, ctx, data_type, batch_size):
+        if data_type.physical not in (L.AH_BOOL, L.AH_UTF8, L.AH_LARGE_UTF8):
+            raise NotYetImplemented(f"BatchCoalescer column type {data_type}")
+        self.ctx, self.data_type = ctx, data_type
+        self.buffered = []
+
+    def copy_rows(self, source, offset, length, at):
+        self.buffered.append(source.slice(offset, length))
+
+    def copy_rows_by_filter_from(self, source, predicate, at):
+        self.buffered.append(predicate.filter(source))
+
+    def finish(self, rows):
+        from .concat import concat
+        arr = self.buffered[0] if len(self.buffered) == 1 else concat(self.buffered)
+        self.buffered = []
+        return arr
+
+
+def _in_progress(ctx, data_type, batch_size):  # `create_in_progress_array` (coalesce.rs:673-700)
+    if data_type.is_primitive() and data_type.width > 0 and data_type.physical not in (L.AH_UTF8_VIEW, L.AH_BINARY_VIEW):
+        return _InProgress(ctx, data_type, batch_size)
+    return _InProgressGeneric(ctx, data_type, batch_size)
+
+
 class BatchCoalescer:
     """``BatchCoalescer::new(schema, target_batch_size)``; schema = (names, data types)."""
 
@@ -73,7 +103,7 @@ class BatchCoalescer:
         self.names = list(names)
         self.data_types = list(data_types)
         self.target_batch_size = int(target_batch_size)
-        self.in_progress = [_InProgress(self.ctx, dt, self.target_batch_size) for dt in self.data_types]
+        self.in_progress = [_in_progress(self.ctx, dt, self.target_batch_size) for dt in self.data_types]
         self.buffered_rows = 0
         self.completed = deque()
         self.biggest_coalesce_batch_size = None

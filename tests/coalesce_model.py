@@ -19,6 +19,8 @@ def _concat(a, b):
         av = a.valid if a.valid is not None else np.ones(len(a), dtype=bool)
         bv = b.valid if b.valid is not None else np.ones(len(b), dtype=bool)
         valid = np.concatenate([av, bv])
+    if isinstance(a.values, list) or isinstance(b.values, list):  # strings
+        return HostArray(a.data_type, list(a.values) + list(b.values), valid)
     return HostArray(a.data_type, np.concatenate([a.values, b.values]), valid)
 
 
