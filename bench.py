@@ -186,6 +186,11 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (tests/test_gpu_parity.py::test_bench_two_ranks_one_gpu): every rank on GPU 0 and a transport
+    # that allows it.  The driver never sets these: one rank per GPU over RCCL ("nccl") is the product path.
+    backend = os.environ.get("AH_BENCH_BACKEND", "nccl")
+    if os.environ.get("AH_BENCH_SHARED_GPU") == "1":
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
@@ -199,7 +204,10 @@ def main():
         if world == 1 and "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import arrow_rs_amd as A
     from arrow_rs_amd import compute as K
