@@ -1,0 +1,415 @@
+// arrow_ord::sort::sort_to_indices on MI355X — the producer of the indices `take` consumes.
+//
+// Reference: arrow-ord/src/sort.rs — `sort_to_indices` :276-330, `partition_validity` :193-255 (valid and null
+// row numbers, each ascending), `sort_primitive` :341-352 / `sort_boolean` :325-339 (pairs (index, value) ordered
+// by `T::Native::compare`, i.e. IEEE totalOrder for floats), `sort_impl` :639-672 (descending = reversed
+// comparator; nulls first or last, null rows in ascending row order; `limit` keeps a prefix).
+// The reference sorts with `sort_unstable_by`: the order of equal keys is unspecified there.  This kernel is a
+// STABLE least-significant-digit radix sort, so equal keys stay in ascending row order (also under `descending`),
+// which is what every tie in the reference's own tests shows (sort.rs:1625-1895).
+//
+// Pipeline (all in HBM):
+//   1. valid / null row numbers: iota filtered by the validity bitmap and by its complement (filter kernels);
+//   2. keys: every valid value mapped to an unsigned integer whose order is the requested order (sign flip for
+//      signed ints; floats: negative -> ~bits, positive -> bits ^ sign; descending -> ~key);
+//   3. one pass computes all digit histograms (they do not depend on the order), so passes whose digit is the
+//      same for every key are skipped outright (an Int64 column of small values sorts in 3 passes, not 8);
+//   4. per remaining 8-bit digit: per-workgroup histogram -> exclusive scan -> stable scatter.  The scatter ranks
+//      keys inside a wave with 8 ballots ("which lanes hold my digit") + mbcnt, stages the tile digit-sorted in
+//      LDS and writes runs of equal digits contiguously.
+// HBM traffic per pass: keys read twice, (key, index) pairs written once: 8+12+12 = 32 B/row for 64-bit keys.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int RS_BLOCK = 256;
+constexpr int RS_ITER = 16;
+constexpr int RS_TILE = RS_BLOCK * RS_ITER;  // 4096 pairs per tile
+constexpr int RS_MAX_BLOCKS = 2048;
+
+// exclusive scan of one int per thread across the 256-thread workgroup
+__device__ __forceinline__ int block_excl_scan_256(int v, int* total, int* sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int incl = wave_scan_incl(v);
+  if (lane == 63) sm[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < RS_BLOCK / 64; ++w) {
+    if (w < wave) base += sm[w];
+    tot += sm[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+// raw W-byte value (zero-extended) -> unsigned key in the requested order; mode 0 unsigned, 1 signed, 2 float
+template <int W, typename KT> __device__ __forceinline__ KT order_key(KT b, int mode, bool desc) {
+  constexpr KT sign = (KT)1 << (W * 8 - 1);
+  constexpr KT mask = (W == 8 || W == 4) ? ~(KT)0 : (((KT)1 << (W * 8 - 1)) << 1) - 1;
+  KT k = mode == 0 ? b : mode == 1 ? (b ^ sign) : ((b & sign) ? (~b & mask) : (b ^ sign));
+  return desc ? (~k & mask) : k;
+}
+
+template <int W, typename KT>
+__global__ void sort_keys_kernel(const void* values, const uint32_t* rows, int64_t m, int mode, int desc,
+                                 KT* keys, uint32_t* idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t r = rows ? rows[i] : (uint32_t)i;
+  KT raw;
+  if constexpr (W == 8) raw = ((const uint64_t*)values)[r];
+  else if constexpr (W == 4) raw = ((const uint32_t*)values)[r];
+  else if constexpr (W == 2) raw = ((const uint16_t*)values)[r];
+  else raw = ((const uint8_t*)values)[r];
+  keys[i] = order_key<W, KT>(raw, mode, desc != 0);
+  if (!rows) idx[i] = r;  // with nulls the row numbers ARE the initial index column
+}
+
+// Boolean values: key = bit (or its complement)
+__global__ void sort_bool_keys_kernel(BitView bits, int64_t len, const uint32_t* rows, int64_t m, int desc,
+                                      uint32_t* keys, uint32_t* idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t r = rows ? rows[i] : (uint32_t)i;
+  keys[i] = (uint32_t)bv_get(bits, r) ^ (desc ? 1u : 0u);
+  if (!rows) idx[i] = r;
+}
+
+__global__ void iota_u32_kernel(uint32_t* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (uint32_t)i;
+}
+
+// all digit histograms of the key column at once: hist[pass][256]
+template <typename KT, int PASSES>
+__global__ __launch_bounds__(RS_BLOCK) void rs_digit_census_kernel(const KT* keys, int64_t m, unsigned long long* hist) {
+  __shared__ unsigned int sm[PASSES][256];
+  for (int i = threadIdx.x; i < PASSES * 256; i += RS_BLOCK) (&sm[0][0])[i] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * RS_BLOCK + threadIdx.x; i < m; i += (int64_t)gridDim.x * RS_BLOCK) {
+    const KT k = keys[i];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) atomicAdd(&sm[p][(k >> (8 * p)) & 255], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PASSES * 256; i += RS_BLOCK) {
+    const unsigned int c = (&sm[0][0])[i];
+    if (c) atomicAdd(&hist[i], (unsigned long long)c);
+  }
+}
+
+// per-workgroup histogram of one digit over the workgroup's contiguous run of tiles: out[d * nblocks + b]
+template <typename KT>
+__global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const KT* keys, int64_t m, int shift, int64_t tiles_per_block,
+                                                          unsigned int* out) {
+  __shared__ unsigned int sm[256];
+  sm[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t begin = (int64_t)blockIdx.x * tiles_per_block * RS_TILE;
+  const int64_t end = min(m, begin + tiles_per_block * RS_TILE);
+  for (int64_t i = begin + threadIdx.x; i < end; i += RS_BLOCK) atomicAdd(&sm[(keys[i] >> shift) & 255], 1u);
+  __syncthreads();
+  out[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = sm[threadIdx.x];
+}
+
+// exclusive scan of n = 256 * nblocks counters in place (digit-major order); one workgroup
+__global__ __launch_bounds__(RS_BLOCK) void rs_scan_kernel(unsigned int* h, int n) {
+  __shared__ unsigned int part[RS_BLOCK];
+  const int per = (n + RS_BLOCK - 1) / RS_BLOCK;
+  const int b = threadIdx.x * per, e = min(n, b + per);
+  unsigned int s = 0;
+  for (int i = b; i < e; ++i) s += h[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int acc = 0;
+    for (int i = 0; i < RS_BLOCK; ++i) {
+      const unsigned int t = part[i];
+      part[i] = acc;
+      acc += t;
+    }
+  }
+  __syncthreads();
+  unsigned int acc = part[threadIdx.x];
+  for (int i = b; i < e; ++i) {
+    const unsigned int t = h[i];
+    h[i] = acc;
+    acc += t;
+  }
+}
+
+template <typename KT>
+__global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const KT* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
+                                                             int64_t m, int shift, int64_t tiles_per_block,
+                                                             const unsigned int* __restrict__ offsets,
+                                                             KT* __restrict__ keys_out, uint32_t* __restrict__ idx_out) {
+  __shared__ KT skey[RS_TILE];
+  __shared__ uint32_t sidx[RS_TILE];
+  __shared__ unsigned int wcnt[RS_BLOCK / 64][256];  // per-wave digit counts of the current tile
+  __shared__ unsigned int tpre[256];                 // exclusive prefix over digits inside the tile
+  __shared__ unsigned int tcnt[256];
+  __shared__ unsigned int running[256];              // next global output slot of each digit for this workgroup
+  __shared__ int scan_sm[RS_BLOCK / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  running[threadIdx.x] = offsets[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
+  const int64_t first_tile = (int64_t)blockIdx.x * tiles_per_block;
+  for (int64_t t = 0; t < tiles_per_block; ++t) {
+    const int64_t base = (first_tile + t) * RS_TILE;
+    if (base >= m) break;
+#pragma unroll
+    for (int w = 0; w < RS_BLOCK / 64; ++w) wcnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    KT key[RS_ITER];
+    uint32_t val[RS_ITER];
+    unsigned int local[RS_ITER];
+    // phase A: stable rank of every pair among the pairs of its wave that share its digit
+#pragma unroll
+    for (int it = 0; it < RS_ITER; ++it) {
+      const int64_t p = base + (int64_t)wave * (RS_ITER * 64) + it * 64 + lane;
+      const bool active = p < m;
+      key[it] = active ? keys_in[p] : (KT)0;
+      val[it] = active ? idx_in[p] : 0u;
+      const unsigned d = (unsigned)((key[it] >> shift) & 255);
+      unsigned long long peers = __ballot(active);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned long long mb = __ballot((d >> b) & 1u);
+        peers &= ((d >> b) & 1u) ? mb : ~mb;
+      }
+      const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
+      unsigned basec = 0;
+      if (active) basec = wcnt[wave][d];
+      __builtin_amdgcn_wave_barrier();
+      if (active && below == 0) wcnt[wave][d] = basec + (unsigned)__popcll(peers);  // first lane of each group
+      __builtin_amdgcn_wave_barrier();
+      local[it] = basec + below;
+    }
+    __syncthreads();
+    // phase B: digit totals of the tile, prefix over digits, per-wave bases
+    {
+      const int d = threadIdx.x;
+      unsigned tot = 0;
+#pragma unroll
+      for (int w = 0; w < RS_BLOCK / 64; ++w) {
+        const unsigned c = wcnt[w][d];
+        wcnt[w][d] = tot;  // becomes: pairs with digit d in earlier waves
+        tot += c;
+      }
+      tcnt[d] = tot;
+      int total;
+      tpre[d] = (unsigned)block_excl_scan_256((int)tot, &total, scan_sm);
+    }
+    __syncthreads();
+    // phase C: stage the tile digit-sorted in LDS
+#pragma unroll
+    for (int it = 0; it < RS_ITER; ++it) {
+      const int64_t p = base + (int64_t)wave * (RS_ITER * 64) + it * 64 + lane;
+      if (p < m) {
+        const unsigned d = (unsigned)((key[it] >> shift) & 255);
+        const unsigned pos = tpre[d] + wcnt[wave][d] + local[it];
+        skey[pos] = key[it];
+        sidx[pos] = val[it];
+      }
+    }
+    __syncthreads();
+    // phase D: runs of equal digits go out contiguously
+    const int64_t in_tile = min((int64_t)RS_TILE, m - base);
+    for (int q = threadIdx.x; q < in_tile; q += RS_BLOCK) {
+      const KT k = skey[q];
+      const unsigned d = (unsigned)((k >> shift) & 255);
+      const size_t dst = (size_t)running[d] + (q - tpre[d]);
+      keys_out[dst] = k;
+      idx_out[dst] = sidx[q];
+    }
+    __syncthreads();
+    running[threadIdx.x] += tcnt[threadIdx.x];
+    __syncthreads();
+  }
+}
+
+struct Scratch {
+  ah_context* ctx;
+  std::vector<void*> ptrs;
+  ~Scratch() {
+    for (void* p : ptrs) ah_pool_free(ctx, p);
+  }
+  ah_status get(size_t bytes, void** out) {
+    AH_TRY(ah_pool_alloc(ctx, bytes ? bytes : 8, out));
+    ptrs.push_back(*out);
+    return AH_OK;
+  }
+};
+
+// stable LSD radix sort of (keys, idx) pairs; result pointers come back in *keys / *idx
+template <typename KT, int PASSES>
+ah_status radix_sort_pairs(ah_context* ctx, Scratch& sc, KT** keys, uint32_t** idx, int64_t m) {
+  if (m <= 1) return AH_OK;
+  KT* kb = nullptr;
+  uint32_t* ib = nullptr;
+  unsigned long long* census = nullptr;
+  unsigned int* hist = nullptr;
+  AH_TRY(sc.get((size_t)m * sizeof(KT), (void**)&kb));
+  AH_TRY(sc.get((size_t)m * 4, (void**)&ib));
+  AH_TRY(sc.get(PASSES * 256 * 8, (void**)&census));
+  const int64_t ntiles = ah_ceil_div(m, RS_TILE);
+  const int nblocks = (int)std::min<int64_t>(ntiles, RS_MAX_BLOCKS);
+  const int64_t tiles_per_block = ah_ceil_div(ntiles, nblocks);
+  AH_TRY(sc.get((size_t)256 * nblocks * 4, (void**)&hist));
+  AH_HIP(ctx, hipMemsetAsync(census, 0, PASSES * 256 * 8, ctx->stream));
+  hipLaunchKernelGGL((rs_digit_census_kernel<KT, PASSES>), dim3((unsigned)std::min<int64_t>(ah_ceil_div(m, RS_BLOCK), 2048)),
+                     dim3(RS_BLOCK), 0, ctx->stream, *keys, m, census);
+  std::vector<unsigned long long> host((size_t)PASSES * 256);
+  AH_HIP(ctx, hipMemcpyAsync(host.data(), census, PASSES * 256 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  KT* kin = *keys;
+  uint32_t* iin = *idx;
+  for (int p = 0; p < PASSES; ++p) {
+    bool trivial = false;  // every key has the same digit: the pass would be the identity
+    for (int d = 0; d < 256; ++d) trivial |= host[(size_t)p * 256 + d] == (unsigned long long)m;
+    if (trivial) continue;
+    ah_prof_scope ps(ctx, "sort_radix_pass");
+    hipLaunchKernelGGL((rs_hist_kernel<KT>), dim3(nblocks), dim3(RS_BLOCK), 0, ctx->stream, kin, m, 8 * p, tiles_per_block, hist);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(RS_BLOCK), 0, ctx->stream, hist, 256 * nblocks);
+    hipLaunchKernelGGL((rs_scatter_kernel<KT>), dim3(nblocks), dim3(RS_BLOCK), 0, ctx->stream, kin, iin, m, 8 * p,
+                       tiles_per_block, hist, kb, ib);
+    std::swap(kin, kb);
+    std::swap(iin, ib);
+  }
+  AH_HIP(ctx, hipGetLastError());
+  *keys = kin;
+  *idx = iin;
+  return AH_OK;
+}
+
+}  // namespace
+
+extern "C" ah_status ah_sort_to_indices(ah_context* ctx, const ah_array_view* v, int32_t descending, int32_t nulls_first,
+                                        int64_t limit, ah_array_out* out) {
+  if (!ctx || !v || !out) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  hipSetDevice(ctx->device);
+  out->type = AH_UINT32;
+  const ah_type t = v->type;
+  const int64_t n = v->length;
+  const int w = ah_type_width(t);
+  const bool ok = t == AH_BOOL || ah_type_is_integer(t) || t == AH_FLOAT16 || t == AH_FLOAT32 || t == AH_FLOAT64;
+  if (!ok) return ah_fail(ctx, AH_COMPUTE_ERROR, "Sort not supported for data type %s", ah_type_name(t));  // sort.rs:324
+  if (n == 0 || limit == 0) return AH_OK;  // :281-283
+  if (n > (int64_t)UINT32_MAX) return ah_fail(ctx, AH_INVALID_ARGUMENT, "sort_to_indices returns UInt32 indices: %lld rows do not fit", (long long)n);
+  int64_t nulls = 0;
+  AH_TRY(ah_resolve_null_count(ctx, v, &nulls));
+  const bool has_nulls = v->validity && nulls > 0;
+  const int64_t m = n - nulls;
+  const int64_t lim = limit < 0 ? n : std::min(limit, n);
+  Scratch sc{ctx, {}};
+  auto grid = [](int64_t k) { return dim3((unsigned)std::max<int64_t>(1, ah_ceil_div(k, 256))); };
+
+  // 1. partition_validity (:193): ascending valid rows and ascending null rows
+  ah_array_out valid_rows, null_rows;
+  ah_out_init(&valid_rows);
+  ah_out_init(&null_rows);
+  struct Rel {
+    ah_context* c;
+    ah_array_out *a, *b;
+    ~Rel() {
+      ah_array_release(c, a);
+      ah_array_release(c, b);
+    }
+  } rel{ctx, &valid_rows, &null_rows};
+  if (has_nulls) {
+    uint32_t* iota = nullptr;
+    AH_TRY(sc.get((size_t)n * 4, (void**)&iota));
+    hipLaunchKernelGGL(iota_u32_kernel, grid(n), dim3(256), 0, ctx->stream, iota, n);
+    ah_array_view rows{}, pred{};
+    rows.type = AH_UINT32;
+    rows.length = n;
+    rows.values = iota;
+    pred.type = AH_BOOL;
+    pred.length = n;
+    pred.values = v->validity;
+    pred.values_bit_offset = v->validity_bit_offset;
+    AH_TRY(ah_filter(ctx, &rows, &pred, &valid_rows));
+    ah_array_out inv;
+    AH_TRY(ah_boolean_unary(ctx, AH_BOOL_NOT, &pred, &inv));
+    ah_array_view ip{};
+    ip.type = AH_BOOL;
+    ip.length = n;
+    ip.values = inv.values;
+    ip.values_bit_offset = inv.values_bit_offset;
+    ah_status st = ah_filter(ctx, &rows, &ip, &null_rows);
+    ah_array_release(ctx, &inv);
+    AH_TRY(st);
+    if (valid_rows.length != m || null_rows.length != nulls)
+      return ah_fail(ctx, AH_INVALID_ARGUMENT, "null_count %lld does not match the validity bitmap", (long long)nulls);
+  }
+  const uint32_t* rows = has_nulls ? (const uint32_t*)valid_rows.values : nullptr;
+
+  // 2. keys (+ initial index column) of the valid rows, 3./4. stable radix sort
+  uint32_t* sorted = nullptr;
+  if (m > 0) {
+    uint32_t* idx = nullptr;
+    if (has_nulls) {
+      AH_TRY(sc.get((size_t)m * 4, (void**)&idx));
+      AH_HIP(ctx, hipMemcpyAsync(idx, rows, (size_t)m * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+      AH_TRY(sc.get((size_t)m * 4, (void**)&idx));
+    }
+    const int mode = (t == AH_FLOAT16 || t == AH_FLOAT32 || t == AH_FLOAT64) ? 2 : ah_type_is_signed(t) ? 1 : 0;
+    if (w == 8) {
+      uint64_t* keys = nullptr;
+      AH_TRY(sc.get((size_t)m * 8, (void**)&keys));
+      hipLaunchKernelGGL((sort_keys_kernel<8, uint64_t>), grid(m), dim3(256), 0, ctx->stream, v->values, rows, m, mode,
+                         descending, keys, idx);
+      AH_TRY((radix_sort_pairs<uint64_t, 8>(ctx, sc, &keys, &idx, m)));
+    } else {
+      uint32_t* keys = nullptr;
+      AH_TRY(sc.get((size_t)m * 4, (void**)&keys));
+      if (t == AH_BOOL) {
+        hipLaunchKernelGGL(sort_bool_keys_kernel, grid(m), dim3(256), 0, ctx->stream,
+                           make_bitview(v->values, v->values_bit_offset), n, rows, m, descending, keys, idx);
+        AH_TRY((radix_sort_pairs<uint32_t, 1>(ctx, sc, &keys, &idx, m)));
+      } else if (w == 4) {
+        hipLaunchKernelGGL((sort_keys_kernel<4, uint32_t>), grid(m), dim3(256), 0, ctx->stream, v->values, rows, m, mode,
+                           descending, keys, idx);
+        AH_TRY((radix_sort_pairs<uint32_t, 4>(ctx, sc, &keys, &idx, m)));
+      } else if (w == 2) {
+        hipLaunchKernelGGL((sort_keys_kernel<2, uint32_t>), grid(m), dim3(256), 0, ctx->stream, v->values, rows, m, mode,
+                           descending, keys, idx);
+        AH_TRY((radix_sort_pairs<uint32_t, 2>(ctx, sc, &keys, &idx, m)));
+      } else {
+        hipLaunchKernelGGL((sort_keys_kernel<1, uint32_t>), grid(m), dim3(256), 0, ctx->stream, v->values, rows, m, mode,
+                           descending, keys, idx);
+        AH_TRY((radix_sort_pairs<uint32_t, 1>(ctx, sc, &keys, &idx, m)));
+      }
+    }
+    sorted = idx;
+  }
+
+  // 5. sort_impl (:656-671): nulls first or last, then the limit
+  void* res = nullptr;
+  AH_TRY(ah_out_alloc(ctx, (size_t)lim * 4, &res));
+  uint32_t* o = (uint32_t*)res;
+  hipError_t e = hipSuccess;
+  const int64_t n_first = nulls_first ? nulls : m;
+  const uint32_t* first = nulls_first ? (const uint32_t*)null_rows.values : sorted;
+  const uint32_t* second = nulls_first ? sorted : (const uint32_t*)null_rows.values;
+  const int64_t a = std::min(lim, n_first), b = lim - a;
+  if (a > 0) e = hipMemcpyAsync(o, first, (size_t)a * 4, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess && b > 0) e = hipMemcpyAsync(o + a, second, (size_t)b * 4, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    ah_out_free(ctx, res, (size_t)lim * 4);
+    return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in sort_to_indices", hipGetErrorString(e));
+  }
+  out->length = lim;
+  out->values = res;
+  out->values_bytes = lim * 4;
+  return AH_OK;
+}

@@ -389,6 +389,17 @@ AH_API ah_status ah_import_c_data(ah_context* ctx, const struct ArrowArray* arra
 AH_API ah_status ah_export_c_data(ah_context* ctx, const ah_array_view* values, const char* format,
                                   struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 
+/* ------------------------------------------------------------------ sort */
+/* arrow_ord::sort::sort_to_indices (arrow-ord/src/sort.rs:276): UInt32 row numbers that order `values`
+ * (`SortOptions { descending, nulls_first }`, arrow-schema/src/lib.rs:87; `limit` < 0 = None) — the usual
+ * producer of the indices `ah_take` consumes (`sort` / `sort_limit` = take(values, sort_to_indices(...)),
+ * sort.rs:56-177).  Integers, floats (IEEE totalOrder, like `lt`) and Boolean; null rows keep ascending row
+ * order at the front or the back (`sort_impl` :639-672).  The reference uses an unstable sort, so the order of
+ * equal keys is unspecified there: this implementation is STABLE (equal keys in ascending row order, also when
+ * descending), which is the order every tie in the reference's own tests shows. */
+AH_API ah_status ah_sort_to_indices(ah_context* ctx, const ah_array_view* values, int32_t descending,
+                                    int32_t nulls_first, int64_t limit, ah_array_out* out);
+
 /* ---------------------------------------------------------- row selection */
 /* parquet `RowSelection`, bitmap-backed form (parquet/src/arrow/arrow_reader/selection/): the structure the
  * parquet reader's row-filter loop (arrow_reader/read_plan.rs) builds from predicate results and chains with

@@ -328,6 +328,22 @@ inline std::optional<bool> max_boolean(const ArrayRef& a) { return aggregate<boo
 inline std::optional<bool> bool_and(const ArrayRef& a) { return min_boolean(a); }
 inline std::optional<bool> bool_or(const ArrayRef& a) { return max_boolean(a); }
 
+// ---- sort (arrow-ord/src/sort.rs)
+struct SortOptions {  // arrow-schema/src/lib.rs:87; default ASC NULLS FIRST
+  bool descending = false;
+  bool nulls_first = true;
+};
+inline ArrayRef sort_to_indices(const ArrayRef& values, SortOptions options = {}, int64_t limit = -1) {
+  ah_array_out out;
+  values->context()->check(ah_sort_to_indices(values->context()->handle(), &values->view(), options.descending,
+                                              options.nulls_first, limit, &out));
+  return wrap(values, out);
+}
+inline ArrayRef sort(const ArrayRef& values, SortOptions options = {}) { return take(values, sort_to_indices(values, options)); }
+inline ArrayRef sort_limit(const ArrayRef& values, SortOptions options, int64_t limit) {
+  return take(values, sort_to_indices(values, options, limit));
+}
+
 }  // namespace compute
 
 // Arrow C Data Interface (arrow-array/src/ffi.rs:231-254).  `from_ffi` copies a host-resident

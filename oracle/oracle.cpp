@@ -1480,6 +1480,13 @@ int32_t aggregate_boolean(int op, const orc_view* a, orc_scalar* out) {
   return ORC_OK;
 }
 
+template <typename T>
+void sort_valid_typed(const orc_view* a, std::vector<uint32_t>& valid, bool desc) {
+  const T* v = (const T*)a->values;
+  if (!desc) std::stable_sort(valid.begin(), valid.end(), [v](uint32_t x, uint32_t y) { return is_lt<T>(v[x], v[y]); });
+  else std::stable_sort(valid.begin(), valid.end(), [v](uint32_t x, uint32_t y) { return is_lt<T>(v[y], v[x]); });
+}
+
 }  // namespace
 
 // =================================================================== exports
@@ -1910,6 +1917,64 @@ int64_t orc_find_nth_set_bit(const uint8_t* bits, int64_t off, int64_t len, int6
   for (int64_t i = start; i < len; ++i)
     if (get_bit(bits, off + i) && --n == 0) return i + 1;
   return len;
+}
+
+// sort_to_indices (arrow-ord/src/sort.rs:276-300): partition_validity :193-255, sort_primitive :341-352,
+// sort_boolean :325-339, sort_impl :639-672
+int32_t orc_sort_to_indices(const orc_view* a, int32_t desc, int32_t nulls_first, int64_t limit, orc_out* out) {
+  out_init(out);
+  out->type = ORC_UINT32;
+  const int64_t n = a->length;
+  if (n == 0 || limit == 0) return ORC_OK;
+  std::vector<uint32_t> valid, nulls;
+  const bool has_nulls = a->validity && resolve_nulls(a) > 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (has_nulls && !get_bit(a->validity, a->validity_bit_offset + i)) nulls.push_back((uint32_t)i);
+    else valid.push_back((uint32_t)i);
+  }
+  switch (a->type) {
+    case ORC_BOOL: {
+      const uint8_t* b = (const uint8_t*)a->values;
+      const int64_t off = a->values_bit_offset;
+      auto val = [b, off](uint32_t i) { return get_bit(b, off + i); };
+      if (!desc) std::stable_sort(valid.begin(), valid.end(), [&](uint32_t x, uint32_t y) { return val(x) < val(y); });
+      else std::stable_sort(valid.begin(), valid.end(), [&](uint32_t x, uint32_t y) { return val(y) < val(x); });
+      break;
+    }
+    case ORC_INT8: sort_valid_typed<int8_t>(a, valid, desc); break;
+    case ORC_INT16: sort_valid_typed<int16_t>(a, valid, desc); break;
+    case ORC_INT32: sort_valid_typed<int32_t>(a, valid, desc); break;
+    case ORC_INT64: sort_valid_typed<int64_t>(a, valid, desc); break;
+    case ORC_UINT8: sort_valid_typed<uint8_t>(a, valid, desc); break;
+    case ORC_UINT16: sort_valid_typed<uint16_t>(a, valid, desc); break;
+    case ORC_UINT32: sort_valid_typed<uint32_t>(a, valid, desc); break;
+    case ORC_UINT64: sort_valid_typed<uint64_t>(a, valid, desc); break;
+    case ORC_FLOAT32: sort_valid_typed<float>(a, valid, desc); break;
+    case ORC_FLOAT64: sort_valid_typed<double>(a, valid, desc); break;
+    case ORC_FLOAT16: {  // total order on the 16 raw bits
+      const uint16_t* v = (const uint16_t*)a->values;
+      auto key = [v](uint32_t i) { const uint16_t b = v[i]; return (uint16_t)((b & 0x8000) ? ~b : (b ^ 0x8000)); };
+      if (!desc) std::stable_sort(valid.begin(), valid.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
+      else std::stable_sort(valid.begin(), valid.end(), [&](uint32_t x, uint32_t y) { return key(y) < key(x); });
+      break;
+    }
+    default: return fail(ORC_COMPUTE_ERROR, "Sort not supported for data type %s", type_name(a->type));
+  }
+  const int64_t len = (int64_t)valid.size() + (int64_t)nulls.size();
+  const int64_t lim = limit < 0 ? len : std::min(limit, len);
+  uint32_t* o = (uint32_t*)xalloc((size_t)std::max<int64_t>(lim, 1) * 4);
+  int64_t k = 0;
+  if (nulls_first) {
+    for (size_t i = 0; i < nulls.size() && k < lim; ++i) o[k++] = nulls[i];
+    for (size_t i = 0; i < valid.size() && k < lim; ++i) o[k++] = valid[i];
+  } else {
+    for (size_t i = 0; i < valid.size() && k < lim; ++i) o[k++] = valid[i];
+    for (size_t i = 0; i < nulls.size() && k < lim; ++i) o[k++] = nulls[i];
+  }
+  out->length = lim;
+  out->values = o;
+  out->values_bytes = std::max<int64_t>(lim, 1) * 4;
+  return ORC_OK;
 }
 
 // concat for primitives / booleans (arrow-select/src/concat.rs:334-343, :495)

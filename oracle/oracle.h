@@ -111,6 +111,13 @@ int32_t orc_selection_and_then(const orc_view* mask, const orc_view* other, orc_
 int32_t orc_selection_combine(int32_t op, const orc_view* l, const orc_view* r, orc_out* out);
 int64_t orc_find_nth_set_bit(const uint8_t* bits, int64_t bit_offset, int64_t len, int64_t start, int64_t n);
 
+/* arrow_ord::sort::sort_to_indices (arrow-ord/src/sort.rs:276): UInt32 indices; limit < 0 = None.  The
+ * reference sorts with `sort_unstable_by`, so the order of equal keys is unspecified there; this restatement
+ * (and the device) use the stable order — equal keys stay in ascending index order, under the reversed comparator
+ * too — which is also what every tie in the reference's own tests shows (sort.rs:1625-1895). */
+int32_t orc_sort_to_indices(const orc_view* values, int32_t descending, int32_t nulls_first, int64_t limit,
+                            orc_out* out);
+
 /* format one f64/f32 the way ryu::Buffer::format does; returns the length */
 int32_t orc_format_f64(double v, char* buf /* >= 32 */);
 int32_t orc_format_f32(float v, char* buf /* >= 32 */);

@@ -182,5 +182,15 @@ int main() {
     assert(ov);
   }
 
+  // sort_to_indices (sort.rs:1626-1631, :1769-1778)
+  {
+    std::vector<bool> sv{false, true, true, true, true, false};
+    auto sa = upload<int32_t>(ctx, AH_INT32, {0, 0, 2, -1, 0, 0}, &sv, keep);
+    assert((download<uint32_t>(compute::sort_to_indices(sa)) == std::vector<uint32_t>{0, 5, 3, 1, 4, 2}));
+    compute::SortOptions dnf{true, true};
+    assert((download<uint32_t>(compute::sort_to_indices(sa, dnf)) == std::vector<uint32_t>{0, 5, 2, 1, 4, 3}));
+    assert(compute::sort_to_indices(sa, dnf, 3)->len() == 3);
+  }
+
   return 0;
 }

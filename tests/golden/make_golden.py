@@ -434,7 +434,56 @@ concat_cases = [
          pieces=[arr("Utf8", ["hello", "A", "B", "C"], [1, 3]), arr("Utf8", ["D", "E", N, "F"], [2, 2])],
          expected=arr("Utf8", ["A", "B", "C", N, "F"])),
 ]
-for name, cases in [("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
+
+# ---------------------------------------------------------------- sort_to_indices (arrow-ord/src/sort.rs tests)
+sort_cases = []
+S_ = "arrow-ord/src/sort.rs"
+base_i = [N, 0, 2, -1, 0, N]
+for t in ("Int8", "Int16", "Int32", "Int64"):
+    sort_cases.append(dict(name=f"primitives_default_{t}", source=f"{S_}:1626-1649", values=arr(t, base_i),
+                           expected=[0, 5, 3, 1, 4, 2]))
+    sort_cases.append(dict(name=f"primitives_desc_{t}", source=f"{S_}:1690-1725", values=arr(t, base_i), descending=True,
+                           nulls_first=False, expected=[2, 1, 4, 3, 0, 5]))
+    sort_cases.append(dict(name=f"primitives_desc_nulls_first_{t}", source=f"{S_}:1769-1805", values=arr(t, base_i),
+                           descending=True, nulls_first=True, expected=[0, 5, 2, 1, 4, 3]))
+for t in ("Float32", "Float64"):
+    sort_cases.append(dict(name=f"primitives_default_{t}", source=f"{S_}:1664-1687",
+                           values=arr(t, [N, -0.05, 2.225, -1.01, -0.05, N]), expected=[0, 5, 3, 1, 4, 2]))
+    sort_cases.append(dict(name=f"primitives_desc_{t}", source=f"{S_}:1741-1766",
+                           values=arr(t, [N, 0.005, 20.22, -10.3, 0.005, N]), descending=True, nulls_first=False,
+                           expected=[2, 1, 4, 3, 0, 5]))
+    sort_cases.append(dict(name=f"primitives_desc_nulls_first_{t}", source=f"{S_}:1821-1850",
+                           values=arr(t, [N, 0.1, 0.2, -1.3, 0.01, N]), descending=True, nulls_first=True,
+                           expected=[0, 5, 2, 1, 4, 3]))
+sort_cases += [
+    dict(name="limit_valid_less_than_limit_nulls_last", source=f"{S_}:1853-1862", values=arr("Float64", [2.0, N, N, 1.0]),
+         descending=False, nulls_first=False, limit=3, expected=[3, 0, 1]),
+    dict(name="limit_valid_less_than_limit_nulls_first", source=f"{S_}:1864-1872", values=arr("Float64", [2.0, N, N, 1.0]),
+         descending=False, nulls_first=True, limit=3, expected=[1, 2, 3]),
+    dict(name="more_nulls_than_limit_nulls_first", source=f"{S_}:1875-1883", values=arr("Float64", [1.0, N, N, N]),
+         descending=False, nulls_first=True, limit=2, expected=[1, 2]),
+    dict(name="more_nulls_than_limit_nulls_last", source=f"{S_}:1885-1893", values=arr("Float64", [1.0, N, N, N]),
+         descending=False, nulls_first=False, limit=2, expected=[0, 1]),
+    dict(name="test_sort_to_indices_primitive_more_nulls_than_limit", source=f"{S_}:1897-1907",
+         values=arr("Int32", [N, N, 3, N, 1, N, 2]), descending=False, nulls_first=False, limit=2, expected=[4, 6]),
+]
+bools = [N, F, T, T, F, N]
+sort_cases += [
+    dict(name="boolean_default", source=f"{S_}:1912-1917", values=arr("Boolean", bools), expected=[0, 5, 1, 4, 2, 3]),
+    dict(name="boolean_desc", source=f"{S_}:1920-1928", values=arr("Boolean", bools), descending=True, nulls_first=False,
+         expected=[2, 3, 1, 4, 0, 5]),
+    dict(name="boolean_desc_nulls_first", source=f"{S_}:1931-1939", values=arr("Boolean", bools), descending=True,
+         nulls_first=True, expected=[0, 5, 2, 3, 1, 4]),
+    dict(name="boolean_desc_nulls_first_limit", source=f"{S_}:1942-1950", values=arr("Boolean", bools), descending=True,
+         nulls_first=True, limit=3, expected=[0, 5, 2]),
+    dict(name="boolean_limit_nulls_last", source=f"{S_}:1953-1961", values=arr("Boolean", [T, N, N, F]), descending=False,
+         nulls_first=False, limit=3, expected=[3, 0, 1]),
+    dict(name="boolean_limit_nulls_first", source=f"{S_}:1963-1971", values=arr("Boolean", [T, N, N, F]), descending=False,
+         nulls_first=True, limit=3, expected=[1, 2, 3]),
+    dict(name="boolean_more_nulls_than_limit", source=f"{S_}:1974-1982", values=arr("Boolean", [T, N, N, N]),
+         descending=False, nulls_first=True, limit=2, expected=[1, 2]),
+]
+for name, cases in [("sort", sort_cases), ("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
                     ("cast", cast_cases)]:
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump({"reference": "apache/arrow-rs 59.2.0", "cases": cases}, f, indent=1)

@@ -153,6 +153,7 @@ class Oracle:
         lib.orc_nullif.argtypes = [VP, VP, OP]
         lib.orc_concat.argtypes = [C.c_int32, VP, OP]
         lib.orc_aggregate.argtypes = [C.c_int32, VP, C.c_int32, C.POINTER(ScalarOut)]
+        lib.orc_sort_to_indices.argtypes = [VP, C.c_int32, C.c_int32, C.c_int64, OP]
         lib.orc_selection_and_then.argtypes = [VP, VP, OP]
         lib.orc_selection_combine.argtypes = [C.c_int32, VP, VP, OP]
         lib.orc_find_nth_set_bit.restype = C.c_int64
@@ -288,6 +289,15 @@ class Oracle:
         if st:
             self._raise(st)
         return out.value(np.uint8 if values.data_type.physical == L.AH_BOOL else values.data_type.np_dtype)
+
+    def sort_to_indices(self, values, descending=False, nulls_first=True, limit=None, bit_offset=0):
+        hv = _Held(values, bit_offset)
+        out = Out()
+        st = self.lib.orc_sort_to_indices(C.byref(hv.view), int(descending), int(nulls_first),
+                                          -1 if limit is None else int(limit), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, A.UInt32)
 
     def selection_and_then(self, mask, other, bit_offset=0):
         hm, ho = _Held(mask, bit_offset), _Held(other, bit_offset)

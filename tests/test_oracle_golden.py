@@ -467,3 +467,12 @@ def test_selection_and_then_fuzz_recipe(oracle):
 def test_concat_golden(oracle, case):
     got = oracle.concat([golden_array(p) for p in case["pieces"]])
     assert_logical_eq(got, golden_array(case["expected"]), case["name"])
+
+
+# ------------------------------------------------------------------- sort_to_indices
+@pytest.mark.parametrize("case", load_golden("sort"), ids=lambda c: c["name"])
+@pytest.mark.parametrize("bit_offset", [0, 3])
+def test_sort_to_indices_golden(oracle, case, bit_offset):
+    got = oracle.sort_to_indices(golden_array(case["values"]), case.get("descending", False), case.get("nulls_first", True),
+                                 case.get("limit"), bit_offset)
+    assert got.valid is None and got.values.tolist() == case["expected"]
