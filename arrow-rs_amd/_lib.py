@@ -154,6 +154,7 @@ SIGNATURES = {
     "ah_zero_null_slots": (C.c_int32, [_P, _P, C.c_int32, _P, C.c_int64]),
     "ah_aggregate": (C.c_int32, [_P, C.c_int32, _VIEW, C.POINTER(Scalar)]),
     "ah_sort_to_indices": (C.c_int32, [_P, _VIEW, C.c_int32, C.c_int32, C.c_int64, _OUT]),
+    "ah_lexsort_to_indices": (C.c_int32, [_P, C.c_int32, _VIEW, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64, _OUT]),
     "ah_selection_and_then": (C.c_int32, [_P, _VIEW, _VIEW, _OUT]),
     "ah_selection_combine": (C.c_int32, [_P, C.c_int32, _VIEW, _VIEW, _OUT]),
     "ah_selection_boundaries": (C.c_int32, [_P, _VIEW, _OUT]),

@@ -13,4 +13,5 @@ from .kernels.coalesce import BatchCoalescer  # noqa: F401
 from .kernels import aggregate  # noqa: F401  (sum/min/max shadow builtins: use ``compute.aggregate.sum`` …)
 from .kernels.aggregate import (sum_checked, product, product_checked, bit_and, bit_or, bit_xor,  # noqa: F401
                                 min_boolean, max_boolean, bool_and, bool_or)
-from .kernels.sort import sort, sort_limit, sort_to_indices, SortOptions, partition, Partitions  # noqa: F401
+from .kernels.sort import (sort, sort_limit, sort_to_indices, SortOptions, SortColumn, lexsort, lexsort_to_indices,  # noqa: F401
+                           partition, Partitions)

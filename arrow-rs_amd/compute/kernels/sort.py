@@ -39,6 +39,37 @@ def sort_limit(values, options=None, limit=None):
     return take(values, sort_to_indices(values, options, limit))
 
 
+@dataclass
+class SortColumn:
+    """sort.rs:870-874"""
+    values: object
+    options: SortOptions = None
+
+
+def lexsort_to_indices(columns, limit=None):
+    """sort.rs:939: UInt32 row numbers ordering the rows by columns[0], then columns[1], ..."""
+    from ...array import InvalidArgumentError
+    if not columns:
+        raise InvalidArgumentError("Sort requires at least one column")
+    ctx = columns[0].values.ctx
+    n = len(columns)
+    views = (L.ArrayView * n)()
+    desc, nf = (C.c_int32 * n)(), (C.c_int32 * n)()
+    for i, c in enumerate(columns):
+        o = c.options or SortOptions()
+        views[i], desc[i], nf[i] = c.values.view(), int(o.descending), int(o.nulls_first)
+    out = L.ArrayOut()
+    ctx.check(ctx.lib.ah_lexsort_to_indices(ctx.handle, n, views, desc, nf, -1 if limit is None else int(limit),
+                                            C.byref(out)))
+    return Array._from_out(ctx, out, UInt32)
+
+
+def lexsort(columns, limit=None):
+    """sort.rs:926: every column taken by the lexicographic order."""
+    idx = lexsort_to_indices(columns, limit)
+    return [take(c.values, idx) for c in columns]
+
+
 class Partitions:
     """partition.rs:31-80: boundaries between runs of equal rows (of already sorted columns)."""
 

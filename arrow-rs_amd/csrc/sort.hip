@@ -60,12 +60,18 @@ template <int W, typename KT> __device__ __forceinline__ KT order_key(KT b, int 
   return desc ? (~k & mask) : k;
 }
 
+// `nulls_to_zero` (lexsort): null rows get one constant key, so the stable key passes leave them in the order the
+// later columns gave them; the 1-bit null pass then moves them as a block
 template <int W, typename KT>
 __global__ void sort_keys_kernel(const void* values, const uint32_t* rows, int64_t m, int mode, int desc,
-                                 KT* keys, uint32_t* idx) {
+                                 KT* keys, uint32_t* idx, BitView nulls_to_zero = BitView{nullptr, 0}) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const uint32_t r = rows ? rows[i] : (uint32_t)i;
+  if (nulls_to_zero.words && !bv_get(nulls_to_zero, r)) {
+    keys[i] = 0;
+    return;
+  }
   KT raw;
   if constexpr (W == 8) raw = ((const uint64_t*)values)[r];
   else if constexpr (W == 4) raw = ((const uint32_t*)values)[r];
@@ -77,12 +83,24 @@ __global__ void sort_keys_kernel(const void* values, const uint32_t* rows, int64
 
 // Boolean values: key = bit (or its complement)
 __global__ void sort_bool_keys_kernel(BitView bits, int64_t len, const uint32_t* rows, int64_t m, int desc,
-                                      uint32_t* keys, uint32_t* idx) {
+                                      uint32_t* keys, uint32_t* idx, BitView nulls_to_zero = BitView{nullptr, 0}) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const uint32_t r = rows ? rows[i] : (uint32_t)i;
+  if (nulls_to_zero.words && !bv_get(nulls_to_zero, r)) {
+    keys[i] = 0;
+    return;
+  }
   keys[i] = (uint32_t)bv_get(bits, r) ^ (desc ? 1u : 0u);
   if (!rows) idx[i] = r;
+}
+
+// lexsort: digit 0 / 1 that puts the null rows of a column first or last (rows taken in the current order)
+__global__ void sort_null_keys_kernel(BitView valid, const uint32_t* rows, int64_t m, int nulls_first, uint32_t* keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const unsigned is_null = bv_get(valid, rows[i]) ? 0u : 1u;
+  keys[i] = nulls_first ? (is_null ^ 1u) : is_null;
 }
 
 __global__ void iota_u32_kernel(uint32_t* out, int64_t n) {
@@ -409,6 +427,101 @@ extern "C" ah_status ah_sort_to_indices(ah_context* ctx, const ah_array_view* v,
   if (e != hipSuccess) {
     ah_out_free(ctx, res, (size_t)lim * 4);
     return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in sort_to_indices", hipGetErrorString(e));
+  }
+  out->length = lim;
+  out->values = res;
+  out->values_bytes = lim * 4;
+  return AH_OK;
+}
+
+namespace {
+
+// stable sort of the row order `*idx` (n rows) by one column: keys gathered in the current order, radix passes,
+// then one more stable 1-bit pass that moves the column's null rows to the front / back
+ah_status sort_rows_by_column(ah_context* ctx, const ah_array_view* v, bool desc, bool nulls_first, uint32_t* idx_buf,
+                              int64_t n) {
+  Scratch sc{ctx, {}};  // this column's temporaries go back to the pool when it is done (same stream: safe)
+  uint32_t* cur = idx_buf;
+  uint32_t** idx = &cur;
+  const ah_type t = v->type;
+  const int w = ah_type_width(t);
+  const bool ok = t == AH_BOOL || ah_type_is_integer(t) || t == AH_FLOAT16 || t == AH_FLOAT32 || t == AH_FLOAT64;
+  if (!ok) return ah_fail(ctx, AH_COMPUTE_ERROR, "Sort not supported for data type %s", ah_type_name(t));
+  const dim3 grid((unsigned)std::max<int64_t>(1, ah_ceil_div(n, 256)));
+  const int mode = (t == AH_FLOAT16 || t == AH_FLOAT32 || t == AH_FLOAT64) ? 2 : ah_type_is_signed(t) ? 1 : 0;
+  int64_t nulls = 0;
+  AH_TRY(ah_resolve_null_count(ctx, v, &nulls));
+  const bool has_nulls = v->validity && nulls > 0;
+  const BitView nz = has_nulls ? make_bitview(v->validity, v->validity_bit_offset) : BitView{nullptr, 0};
+  if (w == 8) {
+    uint64_t* keys = nullptr;
+    AH_TRY(sc.get((size_t)n * 8, (void**)&keys));
+    hipLaunchKernelGGL((sort_keys_kernel<8, uint64_t>), grid, dim3(256), 0, ctx->stream, v->values, *idx, n, mode, (int)desc, keys, *idx, nz);
+    AH_TRY((radix_sort_pairs<uint64_t, 8>(ctx, sc, &keys, idx, n)));
+  } else {
+    uint32_t* keys = nullptr;
+    AH_TRY(sc.get((size_t)n * 4, (void**)&keys));
+    if (t == AH_BOOL) {
+      hipLaunchKernelGGL(sort_bool_keys_kernel, grid, dim3(256), 0, ctx->stream, make_bitview(v->values, v->values_bit_offset),
+                         n, *idx, n, (int)desc, keys, *idx, nz);
+      AH_TRY((radix_sort_pairs<uint32_t, 1>(ctx, sc, &keys, idx, n)));
+    } else if (w == 4) {
+      hipLaunchKernelGGL((sort_keys_kernel<4, uint32_t>), grid, dim3(256), 0, ctx->stream, v->values, *idx, n, mode, (int)desc, keys, *idx, nz);
+      AH_TRY((radix_sort_pairs<uint32_t, 4>(ctx, sc, &keys, idx, n)));
+    } else if (w == 2) {
+      hipLaunchKernelGGL((sort_keys_kernel<2, uint32_t>), grid, dim3(256), 0, ctx->stream, v->values, *idx, n, mode, (int)desc, keys, *idx, nz);
+      AH_TRY((radix_sort_pairs<uint32_t, 2>(ctx, sc, &keys, idx, n)));
+    } else {
+      hipLaunchKernelGGL((sort_keys_kernel<1, uint32_t>), grid, dim3(256), 0, ctx->stream, v->values, *idx, n, mode, (int)desc, keys, *idx, nz);
+      AH_TRY((radix_sort_pairs<uint32_t, 1>(ctx, sc, &keys, idx, n)));
+    }
+  }
+  if (has_nulls) {
+    uint32_t* nk = nullptr;
+    AH_TRY(sc.get((size_t)n * 4, (void**)&nk));
+    hipLaunchKernelGGL(sort_null_keys_kernel, grid, dim3(256), 0, ctx->stream, make_bitview(v->validity, v->validity_bit_offset),
+                       *idx, n, (int)nulls_first, nk);
+    AH_TRY((radix_sort_pairs<uint32_t, 1>(ctx, sc, &nk, idx, n)));
+  }
+  if (cur != idx_buf) AH_HIP(ctx, hipMemcpyAsync(idx_buf, cur, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  return AH_OK;
+}
+
+}  // namespace
+
+// lexsort_to_indices (arrow-ord/src/sort.rs:939-1020) as a least-significant-COLUMN-first chain of stable sorts:
+// the last column orders the rows first, every earlier column re-sorts them stably, so rows equal on a column
+// keep the order the later columns gave them.  Rows equal on every column stay in ascending row order (the
+// reference's `sort_unstable_by` / top-k heap leave that order open).
+extern "C" ah_status ah_lexsort_to_indices(ah_context* ctx, int32_t n_cols, const ah_array_view* cols,
+                                           const int32_t* descending, const int32_t* nulls_first, int64_t limit,
+                                           ah_array_out* out) {
+  if (!ctx || !out || (n_cols > 0 && (!cols || !descending || !nulls_first))) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  hipSetDevice(ctx->device);
+  out->type = AH_UINT32;
+  if (n_cols <= 0) return ah_fail(ctx, AH_INVALID_ARGUMENT, "Sort requires at least one column");  // :944-948
+  if (n_cols == 1) return ah_sort_to_indices(ctx, &cols[0], descending[0], nulls_first[0], limit, out);  // :949-953
+  const int64_t n = cols[0].length;
+  for (int c = 1; c < n_cols; ++c)
+    if (cols[c].length != n) return ah_fail(ctx, AH_COMPUTE_ERROR, "lexical sort columns have different row counts");
+  const int64_t lim = limit < 0 ? n : std::min(limit, n);
+  if (lim == 0) return AH_OK;
+  if (n > (int64_t)UINT32_MAX) return ah_fail(ctx, AH_INVALID_ARGUMENT, "lexsort_to_indices returns UInt32 indices: %lld rows do not fit", (long long)n);
+  Scratch sc{ctx, {}};
+  uint32_t* idx = nullptr;
+  AH_TRY(sc.get((size_t)n * 4, (void**)&idx));
+  hipLaunchKernelGGL(iota_u32_kernel, dim3((unsigned)ah_ceil_div(n, 256)), dim3(256), 0, ctx->stream, idx, n);
+  for (int c = n_cols - 1; c >= 0; --c) {
+    AH_TRY(sort_rows_by_column(ctx, &cols[c], descending[c] != 0, nulls_first[c] != 0, idx, n));
+  }
+  void* res = nullptr;
+  AH_TRY(ah_out_alloc(ctx, (size_t)lim * 4, &res));
+  hipError_t e = hipMemcpyAsync(res, idx, (size_t)lim * 4, hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    ah_out_free(ctx, res, (size_t)lim * 4);
+    return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in lexsort_to_indices", hipGetErrorString(e));
   }
   out->length = lim;
   out->values = res;

@@ -400,6 +400,13 @@ AH_API ah_status ah_export_c_data(ah_context* ctx, const ah_array_view* values, 
 AH_API ah_status ah_sort_to_indices(ah_context* ctx, const ah_array_view* values, int32_t descending,
                                     int32_t nulls_first, int64_t limit, ah_array_out* out);
 
+/* arrow_ord::sort::lexsort_to_indices (sort.rs:939): rows ordered by cols[0], ties by cols[1], ... — a chain of
+ * stable single-column sorts from the last column to the first.  One column delegates to ah_sort_to_indices
+ * (:949); rows equal on every column stay in ascending row order.  `lexsort` = ah_take per column. */
+AH_API ah_status ah_lexsort_to_indices(ah_context* ctx, int32_t n_cols, const ah_array_view* cols,
+                                       const int32_t* descending, const int32_t* nulls_first, int64_t limit,
+                                       ah_array_out* out);
+
 /* ---------------------------------------------------------- row selection */
 /* parquet `RowSelection`, bitmap-backed form (parquet/src/arrow/arrow_reader/selection/): the structure the
  * parquet reader's row-filter loop (arrow_reader/read_plan.rs) builds from predicate results and chains with

@@ -7,6 +7,7 @@
 #include "oracle.h"
 
 #include <algorithm>
+#include <functional>
 #include <charconv>
 #include <cinttypes>
 #include <cmath>
@@ -1974,6 +1975,75 @@ int32_t orc_sort_to_indices(const orc_view* a, int32_t desc, int32_t nulls_first
   out->length = lim;
   out->values = o;
   out->values_bytes = std::max<int64_t>(lim, 1) * 4;
+  return ORC_OK;
+}
+
+int32_t orc_lexsort_to_indices(int32_t n_cols, const orc_view* cols, const int32_t* desc, const int32_t* nulls_first,
+                               int64_t limit, orc_out* out) {
+  out_init(out);
+  out->type = ORC_UINT32;
+  if (n_cols <= 0) return fail(ORC_INVALID_ARGUMENT, "Sort requires at least one column");
+  if (n_cols == 1) return orc_sort_to_indices(&cols[0], desc[0], nulls_first[0], limit, out);
+  const int64_t n = cols[0].length;
+  for (int c = 1; c < n_cols; ++c)
+    if (cols[c].length != n) return fail(ORC_COMPUTE_ERROR, "lexical sort columns have different row counts");
+  const int64_t lim = limit < 0 ? n : std::min(limit, n);
+  if (lim == 0) return ORC_OK;
+  // per column: -1 / 0 / +1 on two valid rows (ascending), as T::Native::compare
+  std::vector<std::function<int(uint32_t, uint32_t)>> cmp((size_t)n_cols);
+  for (int c = 0; c < n_cols; ++c) {
+    const orc_view* a = &cols[c];
+    switch (a->type) {
+#define ORC_CMP_CASE(TAG, T)                                                                          \
+  case TAG: {                                                                                         \
+    const T* v = (const T*)a->values;                                                                 \
+    cmp[c] = [v](uint32_t x, uint32_t y) { return is_lt<T>(v[x], v[y]) ? -1 : is_lt<T>(v[y], v[x]) ? 1 : 0; }; \
+    break;                                                                                            \
+  }
+      ORC_CMP_CASE(ORC_INT8, int8_t)
+      ORC_CMP_CASE(ORC_INT16, int16_t)
+      ORC_CMP_CASE(ORC_INT32, int32_t)
+      ORC_CMP_CASE(ORC_INT64, int64_t)
+      ORC_CMP_CASE(ORC_UINT8, uint8_t)
+      ORC_CMP_CASE(ORC_UINT16, uint16_t)
+      ORC_CMP_CASE(ORC_UINT32, uint32_t)
+      ORC_CMP_CASE(ORC_UINT64, uint64_t)
+      ORC_CMP_CASE(ORC_FLOAT32, float)
+      ORC_CMP_CASE(ORC_FLOAT64, double)
+#undef ORC_CMP_CASE
+      case ORC_BOOL: {
+        const uint8_t* b = (const uint8_t*)a->values;
+        const int64_t off = a->values_bit_offset;
+        cmp[c] = [b, off](uint32_t x, uint32_t y) { return (int)get_bit(b, off + x) - (int)get_bit(b, off + y); };
+        break;
+      }
+      default: return fail(ORC_COMPUTE_ERROR, "Sort not supported for data type %s", type_name(a->type));
+    }
+  }
+  std::vector<bool> has_nulls((size_t)n_cols);
+  for (int c = 0; c < n_cols; ++c) has_nulls[c] = cols[c].validity && resolve_nulls(&cols[c]) > 0;
+  auto less = [&](uint32_t x, uint32_t y) {
+    for (int c = 0; c < n_cols; ++c) {
+      const orc_view* a = &cols[c];
+      const bool vx = !has_nulls[c] || get_bit(a->validity, a->validity_bit_offset + x);
+      const bool vy = !has_nulls[c] || get_bit(a->validity, a->validity_bit_offset + y);
+      int r;
+      if (!vx && !vy) r = 0;
+      else if (!vx) r = nulls_first[c] ? -1 : 1;
+      else if (!vy) r = nulls_first[c] ? 1 : -1;
+      else r = desc[c] ? -cmp[c](x, y) : cmp[c](x, y);
+      if (r) return r < 0;
+    }
+    return false;
+  };
+  std::vector<uint32_t> idx((size_t)n);
+  for (int64_t i = 0; i < n; ++i) idx[i] = (uint32_t)i;
+  std::stable_sort(idx.begin(), idx.end(), less);
+  uint32_t* o = (uint32_t*)xalloc((size_t)lim * 4);
+  memcpy(o, idx.data(), (size_t)lim * 4);
+  out->length = lim;
+  out->values = o;
+  out->values_bytes = lim * 4;
   return ORC_OK;
 }
 

@@ -118,6 +118,11 @@ int64_t orc_find_nth_set_bit(const uint8_t* bits, int64_t bit_offset, int64_t le
 int32_t orc_sort_to_indices(const orc_view* values, int32_t descending, int32_t nulls_first, int64_t limit,
                             orc_out* out);
 
+/* lexsort_to_indices (sort.rs:939) with `make_comparator` semantics per column (null == null, null before / after
+ * valid by nulls_first, descending reverses valid comparisons); stable, so fully equal rows keep row order. */
+int32_t orc_lexsort_to_indices(int32_t n_cols, const orc_view* cols, const int32_t* descending,
+                               const int32_t* nulls_first, int64_t limit, orc_out* out);
+
 /* format one f64/f32 the way ryu::Buffer::format does; returns the length */
 int32_t orc_format_f64(double v, char* buf /* >= 32 */);
 int32_t orc_format_f32(float v, char* buf /* >= 32 */);

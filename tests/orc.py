@@ -154,6 +154,7 @@ class Oracle:
         lib.orc_concat.argtypes = [C.c_int32, VP, OP]
         lib.orc_aggregate.argtypes = [C.c_int32, VP, C.c_int32, C.POINTER(ScalarOut)]
         lib.orc_sort_to_indices.argtypes = [VP, C.c_int32, C.c_int32, C.c_int64, OP]
+        lib.orc_lexsort_to_indices.argtypes = [C.c_int32, VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64, OP]
         lib.orc_selection_and_then.argtypes = [VP, VP, OP]
         lib.orc_selection_combine.argtypes = [C.c_int32, VP, VP, OP]
         lib.orc_find_nth_set_bit.restype = C.c_int64
@@ -295,6 +296,18 @@ class Oracle:
         out = Out()
         st = self.lib.orc_sort_to_indices(C.byref(hv.view), int(descending), int(nulls_first),
                                           -1 if limit is None else int(limit), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, A.UInt32)
+
+    def lexsort_to_indices(self, columns, limit=None):
+        """columns: [(HostArray, descending, nulls_first)]"""
+        held = [_Held(c[0]) for c in columns]
+        views = (View * len(columns))(*[h.view for h in held])
+        desc = (C.c_int32 * len(columns))(*[int(c[1]) for c in columns])
+        nf = (C.c_int32 * len(columns))(*[int(c[2]) for c in columns])
+        out = Out()
+        st = self.lib.orc_lexsort_to_indices(len(columns), views, desc, nf, -1 if limit is None else int(limit), C.byref(out))
         if st:
             self._raise(st)
         return self._collect(out, A.UInt32)

@@ -133,3 +133,63 @@ def test_partition(ctx):
     assert K.partition([f]).ranges() == [(0, 2), (2, 4), (4, 5), (5, 6)]   # bitwise distinct: -0.0 != 0.0, NaN == NaN
     with pytest.raises(A.array.InvalidArgumentError):
         K.partition([])
+
+
+# ------------------------------------------------------------------ lexsort
+def _lex_cols(ctx, hs, opts):
+    return [K.SortColumn(h.to_device(ctx, bit_offset=i + 1), K.SortOptions(*o)) for i, (h, o) in enumerate(zip(hs, opts))]
+
+
+def test_lexsort_reference_cases(ctx, oracle):
+    """sort.rs:4109-4160 `test_lex_sort_mixed_types` (numeric part), :4061 single column, :4090 unaligned rows."""
+    i64 = lambda xs: HostArray.from_pylist(xs, A.Int64)
+    u32 = lambda xs: HostArray.from_pylist(xs, A.UInt32)
+    hs = [i64([0, 2, -1, 0]), u32([101, 8, 7, 102]), i64([-1, -2, -3, -4])]
+    cols = [K.SortColumn(h.to_device(ctx)) for h in hs]
+    got = K.lexsort(cols)
+    assert [c.to_pylist() for c in got] == [[-1, 0, 0, 2], [7, 101, 102, 8], [-3, -1, -4, -2]]
+    assert [c.to_pylist() for c in K.lexsort(cols, 2)] == [[-1, 0], [7, 101], [-3, -1]]
+    one = [K.SortColumn(i64([17, 2, -1, 0]).to_device(ctx))]
+    assert K.lexsort(one)[0].to_pylist() == [-1, 0, 2, 17]
+    assert K.lexsort(one, 3)[0].to_pylist() == [-1, 0, 2]
+    with pytest.raises(A.array.ComputeError, match="lexical sort columns have different row counts"):
+        K.lexsort([K.SortColumn(i64([None, -1]).to_device(ctx)), K.SortColumn(i64([5]).to_device(ctx))])
+    with pytest.raises(A.array.InvalidArgumentError, match="Sort requires at least one column"):
+        K.lexsort_to_indices([])
+    # the null-ordering cases of :4190-4290 with the string column replaced by integers of the same order
+    a = i64([None, -1, 2, None])
+    b = i64([1, 3, 2, None])  # "foo" < "hello" < "world" -> 1 < 2 < 3
+    dn = (True, True)
+    got = K.lexsort(_lex_cols(ctx, [a, b], [dn, dn]))
+    assert [c.to_pylist() for c in got] == [[None, None, 2, -1], [None, 1, 2, 3]]
+    dl = (True, False)
+    got = K.lexsort(_lex_cols(ctx, [a, b], [dl, dl]))
+    assert [c.to_pylist() for c in got] == [[2, -1, None, None], [2, 3, 1, None]]
+    a = i64([None, -1, 2, -1, None])
+    b = i64([2, 1, 4, 3, None])  # "bar" < "foo" < "hello" < "world" -> 1 < 2 < 3 < 4
+    got = K.lexsort(_lex_cols(ctx, [a, b], [(False, False), (True, True)]))
+    assert [c.to_pylist() for c in got] == [[-1, -1, 2, None, None], [3, 1, 4, None, 2]]
+    assert [c.to_pylist() for c in K.lexsort(_lex_cols(ctx, [a, b], [(False, False), (True, True)]), 10)] == \
+        [[-1, -1, 2, None, None], [3, 1, 4, None, 2]]
+
+
+def test_lexsort_fuzz(ctx, oracle):
+    """2-4 columns of mixed types, few distinct values (so later columns matter), nulls, every option mix:
+    exact index equality with the oracle's stable lexicographic sort."""
+    rng = np.random.default_rng(17)
+    types = [A.Int8, A.Int64, A.UInt16, A.Float64, A.Float32, A.Boolean, A.Int32, A.UInt64]
+    for trial in range(40):
+        n = int(rng.choice([1, 2, 100, 4097, 20_000]))
+        k = int(rng.integers(2, 5))
+        hs, opts = [], []
+        for c in range(k):
+            dt = types[int(rng.integers(0, len(types)))]
+            vals = _vals(rng, dt, n, True)
+            valid = (rng.random(n) < 0.8) if rng.random() < 0.6 else None
+            hs.append(HostArray(dt, vals, valid))
+            opts.append((bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+        lim = None if trial % 3 else int(rng.integers(0, n + 2))
+        want = oracle.lexsort_to_indices([(h, o[0], o[1]) for h, o in zip(hs, opts)], lim)
+        got = K.lexsort_to_indices(_lex_cols(ctx, hs, opts), lim)
+        g = got.values_numpy() if got.length else np.zeros(0, np.uint32)
+        assert np.array_equal(g, want.values), (trial, n, k, opts, lim)
