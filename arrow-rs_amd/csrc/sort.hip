@@ -188,13 +188,21 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const KT* __restri
     KT key[RS_ITER];
     uint32_t val[RS_ITER];
     unsigned int local[RS_ITER];
-    // phase A: stable rank of every pair among the pairs of its wave that share its digit
+    // phase A0: all loads of the tile first, so 2*RS_ITER requests per lane are in flight at once (issuing each
+    // load right before its ranking step serialised RS_ITER memory round trips per tile: 4.3 -> 2.9 ms per pass for
+    // everything but the stores)
 #pragma unroll
     for (int it = 0; it < RS_ITER; ++it) {
       const int64_t p = base + (int64_t)wave * (RS_ITER * 64) + it * 64 + lane;
       const bool active = p < m;
       key[it] = active ? keys_in[p] : (KT)0;
       val[it] = active ? idx_in[p] : 0u;
+    }
+    // phase A: stable rank of every pair among the pairs of its wave that share its digit
+#pragma unroll
+    for (int it = 0; it < RS_ITER; ++it) {
+      const int64_t p = base + (int64_t)wave * (RS_ITER * 64) + it * 64 + lane;
+      const bool active = p < m;
       const unsigned d = (unsigned)((key[it] >> shift) & 255);
       unsigned long long peers = __ballot(active);
 #pragma unroll
