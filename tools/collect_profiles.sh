@@ -14,7 +14,7 @@ for wl in arith cmp aggregate; do
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$wl -o bench -- python bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/write_$wl.log
 done
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/sq -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/sq.log
-for wl in arith cmp cast cast_string coalesce string_filter_take aggregate; do
+for wl in arith cmp cast cast_string coalesce string_filter_take aggregate sort; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o bench -- python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_$wl.json 2> $OUT/trace_$wl.log
 done
 python tools/next_rows_time.py > $OUT/next_rows.json 2> $OUT/next_rows.log

@@ -41,7 +41,8 @@ for sub, title in [("trace", "filter + take step (bench.py default)"), ("trace_a
                    ("trace_cast_string", "cast Float64->LargeUtf8"),
                    ("trace_coalesce", "BatchCoalescer.push_batch_with_filter (2 columns, 2^24-row batches)"),
                    ("trace_string_filter_take", "filter + take on a LargeUtf8 column (2^27 rows)"),
-                   ("trace_aggregate", "sum + min + max of an Int64 column (1e9 rows, 10 % nulls)")]:
+                   ("trace_aggregate", "sum + min + max of an Int64 column (1e9 rows, 10 % nulls)"),
+                   ("trace_sort", "sort_to_indices of a full-range Int64 column (2^29 rows, 10 % nulls)")]:
     p = os.path.join(src, sub, "bench_kernel_stats.csv")
     if not os.path.exists(p):
         continue
