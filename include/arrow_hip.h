@@ -389,6 +389,13 @@ AH_API ah_status ah_import_c_data(ah_context* ctx, const struct ArrowArray* arra
 AH_API ah_status ah_export_c_data(ah_context* ctx, const ah_array_view* values, const char* format,
                                   struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 
+/* ------------------------------------------------------------------- zip */
+/* arrow_select::zip::zip (arrow-select/src/zip.rs:99): out[i] = mask[i] ? truthy[i] : falsy[i]; a null mask row
+ * selects `falsy`; either side may be a length-1 scalar (`Datum::get()`).  Fixed-width and Boolean layouts.
+ * The result carries a null buffer iff an input has nulls.  Error texts of :115-140. */
+AH_API ah_status ah_zip(ah_context* ctx, const ah_array_view* mask, const ah_array_view* truthy, int32_t truthy_is_scalar,
+                        const ah_array_view* falsy, int32_t falsy_is_scalar, ah_array_out* out);
+
 /* ------------------------------------------------------------------ sort */
 /* arrow_ord::sort::sort_to_indices (arrow-ord/src/sort.rs:276): UInt32 row numbers that order `values`
  * (`SortOptions { descending, nulls_first }`, arrow-schema/src/lib.rs:87; `limit` < 0 = None) — the usual

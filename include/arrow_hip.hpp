@@ -328,6 +328,14 @@ inline std::optional<bool> max_boolean(const ArrayRef& a) { return aggregate<boo
 inline std::optional<bool> bool_and(const ArrayRef& a) { return min_boolean(a); }
 inline std::optional<bool> bool_or(const ArrayRef& a) { return max_boolean(a); }
 
+// ---- zip (arrow-select/src/zip.rs:99)
+inline ArrayRef zip(const ArrayRef& mask, const Datum& truthy, const Datum& falsy) {
+  ah_array_out out;
+  mask->context()->check(ah_zip(mask->context()->handle(), &mask->view(), &truthy.array->view(), truthy.is_scalar,
+                                &falsy.array->view(), falsy.is_scalar, &out));
+  return wrap(truthy.array, out);
+}
+
 // ---- sort (arrow-ord/src/sort.rs)
 struct SortOptions {  // arrow-schema/src/lib.rs:87; default ASC NULLS FIRST
   bool descending = false;

@@ -2047,6 +2047,47 @@ int32_t orc_lexsort_to_indices(int32_t n_cols, const orc_view* cols, const int32
   return ORC_OK;
 }
 
+// zip (arrow-select/src/zip.rs:99-200): argument checks :115-140; nulls in the mask select `falsy`
+// (maybe_prep_null_mask_filter); the output carries a null buffer iff an input has nulls (MutableArrayData)
+int32_t orc_zip(const orc_view* mask, const orc_view* t, int32_t ts, const orc_view* f, int32_t fs, orc_out* out) {
+  out_init(out);
+  if (t->type != f->type) return fail(ORC_INVALID_ARGUMENT, "arguments need to have the same data type");
+  if (ts && t->length != 1) return fail(ORC_INVALID_ARGUMENT, "scalar arrays must have 1 element");
+  if (!ts && t->length != mask->length) return fail(ORC_INVALID_ARGUMENT, "all arrays should have the same length");
+  if (fs && f->length != 1) return fail(ORC_INVALID_ARGUMENT, "scalar arrays must have 1 element");
+  if (!fs && f->length != mask->length) return fail(ORC_INVALID_ARGUMENT, "all arrays should have the same length");
+  const int w = type_width(t->type);
+  if (w < 0) return fail(ORC_NOT_YET_IMPLEMENTED, "zip of %s", type_name(t->type));
+  const int64_t n = mask->length;
+  out->type = t->type;
+  out->length = n;
+  if (n == 0) return ORC_OK;
+  const bool any_nulls = resolve_nulls(t) > 0 || resolve_nulls(f) > 0;
+  const size_t vbytes = w ? (size_t)n * w : bitmap_bytes(n);
+  out->values = xalloc(vbytes);
+  out->values_bytes = (int64_t)vbytes;
+  uint8_t* nb = any_nulls ? (uint8_t*)xalloc(bitmap_bytes(n)) : nullptr;
+  const uint8_t* mv = (const uint8_t*)mask->values;
+  int64_t valid_count = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    bool m = get_bit(mv, mask->values_bit_offset + i);
+    if (mask->validity && !get_bit(mask->validity, mask->validity_bit_offset + i)) m = false;
+    const orc_view* src = m ? t : f;
+    const int64_t j = (m ? ts : fs) ? 0 : i;
+    if (w) memcpy((char*)out->values + (size_t)i * w, (const char*)src->values + (size_t)j * w, (size_t)w);
+    else if (get_bit((const uint8_t*)src->values, src->values_bit_offset + j)) set_bit((uint8_t*)out->values, i);
+    const bool valid = !src->validity || get_bit(src->validity, src->validity_bit_offset + j);
+    if (nb && valid) set_bit(nb, i);
+    valid_count += valid;
+  }
+  if (nb) {
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(n);
+    out->null_count = n - valid_count;
+  }
+  return ORC_OK;
+}
+
 // concat for primitives / booleans (arrow-select/src/concat.rs:334-343, :495)
 int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out) {
   out_init(out);

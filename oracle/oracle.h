@@ -123,6 +123,11 @@ int32_t orc_sort_to_indices(const orc_view* values, int32_t descending, int32_t 
 int32_t orc_lexsort_to_indices(int32_t n_cols, const orc_view* cols, const int32_t* descending,
                                const int32_t* nulls_first, int64_t limit, orc_out* out);
 
+/* arrow_select::zip::zip (arrow-select/src/zip.rs:99): out[i] = mask[i] (null = false) ? truthy : falsy; either side may
+ * be a length-1 scalar.  Fixed-width and Boolean layouts. */
+int32_t orc_zip(const orc_view* mask, const orc_view* truthy, int32_t truthy_scalar, const orc_view* falsy,
+                int32_t falsy_scalar, orc_out* out);
+
 /* format one f64/f32 the way ryu::Buffer::format does; returns the length */
 int32_t orc_format_f64(double v, char* buf /* >= 32 */);
 int32_t orc_format_f32(float v, char* buf /* >= 32 */);

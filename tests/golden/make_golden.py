@@ -483,7 +483,43 @@ sort_cases += [
     dict(name="boolean_more_nulls_than_limit", source=f"{S_}:1974-1982", values=arr("Boolean", [T, N, N, N]),
          descending=False, nulls_first=True, limit=2, expected=[1, 2]),
 ]
-for name, cases in [("sort", sort_cases), ("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
+
+# ---------------------------------------------------------------- zip (arrow-select/src/zip.rs tests)
+Z_ = "arrow-select/src/zip.rs"
+za = arr("Int32", [5, N, 7, N, 1])
+zb = arr("Int32", [N, 3, 6, 7, 3])
+m1, m2 = arr("Boolean", [T, T, F, F, T]), arr("Boolean", [F, F, T, T, F])
+s42, s123, snull = arr("Int32", [42]), arr("Int32", [123]), arr("Int32", [N])
+mnull = dict(type="Boolean", raw=[T, T, F, T, F, F], valid=[T, T, T, F, T, T])
+zip_cases = [
+    dict(name="test_zip_kernel_one", source=f"{Z_}:870", mask=m1, truthy=za, falsy=zb, expected=arr("Int32", [5, N, 6, 7, 1])),
+    dict(name="test_zip_kernel_two", source=f"{Z_}:881", mask=m2, truthy=za, falsy=zb, expected=arr("Int32", [N, 3, 7, N, 3])),
+    dict(name="scalar_falsy_1", source=f"{Z_}:892", mask=m1, truthy=za, falsy=s42, falsy_scalar=True, expected=arr("Int32", [5, N, 42, 42, 1])),
+    dict(name="scalar_falsy_2", source=f"{Z_}:905", mask=m2, truthy=za, falsy=s42, falsy_scalar=True, expected=arr("Int32", [42, 42, 7, N, 42])),
+    dict(name="scalar_truthy_1", source=f"{Z_}:918", mask=m1, truthy=s42, truthy_scalar=True, falsy=za, expected=arr("Int32", [42, 42, 7, N, 42])),
+    dict(name="scalar_truthy_2", source=f"{Z_}:931", mask=m2, truthy=s42, truthy_scalar=True, falsy=za, expected=arr("Int32", [5, N, 42, 42, 1])),
+    dict(name="scalar_both_ends_true", source=f"{Z_}:944", mask=m1, truthy=s42, truthy_scalar=True, falsy=s123, falsy_scalar=True,
+         expected=arr("Int32", [42, 42, 123, 123, 42])),
+    dict(name="scalar_both_ends_false", source=f"{Z_}:956", mask=arr("Boolean", [T, T, F, T, F, F]), truthy=s42, truthy_scalar=True,
+         falsy=s123, falsy_scalar=True, expected=arr("Int32", [42, 42, 123, 42, 123, 123])),
+    dict(name="scalar_none_1", source=f"{Z_}:975", mask=m1, truthy=s42, truthy_scalar=True, falsy=snull, falsy_scalar=True,
+         expected=arr("Int32", [42, 42, N, N, 42])),
+    dict(name="scalar_none_2", source=f"{Z_}:987", mask=m2, truthy=s42, truthy_scalar=True, falsy=snull, falsy_scalar=True,
+         expected=arr("Int32", [N, N, 42, 42, N])),
+    dict(name="scalar_both_null", source=f"{Z_}:999", mask=m2, truthy=snull, truthy_scalar=True, falsy=snull, falsy_scalar=True,
+         expected=arr("Int32", [N, N, N, N, N])),
+    dict(name="mask_nulls_are_false_arrays", source=f"{Z_}:1011", mask=mnull, truthy=arr("Int32", [1, 2, 3, 4, 5, 6]),
+         falsy=arr("Int32", [7, 8, 9, 10, 11, 12]), expected=arr("Int32", [1, 2, 9, 10, 11, 12])),
+    dict(name="mask_nulls_are_false_scalars", source=f"{Z_}:1038", mask=mnull, truthy=s42, truthy_scalar=True, falsy=s123,
+         falsy_scalar=True, expected=arr("Int32", [42, 42, 123, 123, 123, 123])),
+    dict(name="type_mismatch", source=f"{Z_}:115-119", mask=m1, truthy=za, falsy=arr("Int64", [1, 2, 3, 4, 5]),
+         error="InvalidArgumentError", message="arguments need to have the same data type"),
+    dict(name="length_mismatch", source=f"{Z_}:126-130", mask=m1, truthy=arr("Int32", [1, 2]), falsy=zb,
+         error="InvalidArgumentError", message="all arrays should have the same length"),
+    dict(name="scalar_len", source=f"{Z_}:121-125", mask=m1, truthy=arr("Int32", [1, 2]), truthy_scalar=True, falsy=zb,
+         error="InvalidArgumentError", message="scalar arrays must have 1 element"),
+]
+for name, cases in [("zip", zip_cases), ("sort", sort_cases), ("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
                     ("cast", cast_cases)]:
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump({"reference": "apache/arrow-rs 59.2.0", "cases": cases}, f, indent=1)

@@ -155,6 +155,7 @@ class Oracle:
         lib.orc_aggregate.argtypes = [C.c_int32, VP, C.c_int32, C.POINTER(ScalarOut)]
         lib.orc_sort_to_indices.argtypes = [VP, C.c_int32, C.c_int32, C.c_int64, OP]
         lib.orc_lexsort_to_indices.argtypes = [C.c_int32, VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64, OP]
+        lib.orc_zip.argtypes = [VP, VP, C.c_int32, VP, C.c_int32, OP]
         lib.orc_selection_and_then.argtypes = [VP, VP, OP]
         lib.orc_selection_combine.argtypes = [C.c_int32, VP, VP, OP]
         lib.orc_find_nth_set_bit.restype = C.c_int64
@@ -311,6 +312,15 @@ class Oracle:
         if st:
             self._raise(st)
         return self._collect(out, A.UInt32)
+
+    def zip(self, mask, truthy, falsy, truthy_scalar=False, falsy_scalar=False, bit_offset=0):
+        hm, ht, hf = _Held(mask, bit_offset), _Held(truthy, bit_offset), _Held(falsy, bit_offset)
+        out = Out()
+        st = self.lib.orc_zip(C.byref(hm.view), C.byref(ht.view), int(truthy_scalar), C.byref(hf.view), int(falsy_scalar),
+                              C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, truthy.data_type)
 
     def selection_and_then(self, mask, other, bit_offset=0):
         hm, ho = _Held(mask, bit_offset), _Held(other, bit_offset)

@@ -476,3 +476,14 @@ def test_sort_to_indices_golden(oracle, case, bit_offset):
     got = oracle.sort_to_indices(golden_array(case["values"]), case.get("descending", False), case.get("nulls_first", True),
                                  case.get("limit"), bit_offset)
     assert got.valid is None and got.values.tolist() == case["expected"]
+
+
+# ------------------------------------------------------------------- zip
+@pytest.mark.parametrize("case", load_golden("zip"), ids=lambda c: c["name"])
+@pytest.mark.parametrize("bit_offset", [0, 5])
+def test_zip_golden(oracle, case, bit_offset):
+    m, t, f = golden_array(case["mask"]), golden_array(case["truthy"]), golden_array(case["falsy"])
+    run = lambda: oracle.zip(m, t, f, case.get("truthy_scalar", False), case.get("falsy_scalar", False), bit_offset)  # noqa: E731
+    if "error" in case:
+        return expect_err(case, run)
+    assert_logical_eq(run(), golden_array(case["expected"]), case["name"])
