@@ -174,6 +174,68 @@ const char* cmp_sym(int op) {  // Display for Op (cmp.rs:55-68)
 
 }  // namespace
 
+namespace {
+
+// ArrayOrd for &GenericByteArray (arrow-ord/src/cmp.rs:783-830): eq = same length and bytes, lt = bytewise
+// lexicographic.  Lane per row; 8 bytes at a time (big-endian compare of unaligned words), byte tail; the result
+// word of a wave's 64 rows is a ballot.
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+template <typename O>
+__global__ __launch_bounds__(256) void compare_bytes_kernel(const O* lo, const uint8_t* ld, const O* ro, const uint8_t* rd,
+                                                           int64_t len, int l_scalar, int r_scalar, int base, int neg,
+                                                           unsigned long long* out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwords = (len + 63) >> 6;
+  const int64_t wave0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t w = wave0; w < nwords; w += nwaves) {
+    const int64_t row = w * 64 + lane;
+    bool res = false;
+    if (row < len) {
+      const int64_t li = l_scalar ? 0 : row, ri = r_scalar ? 0 : row;
+      const int64_t a0 = (int64_t)lo[li], b0 = (int64_t)ro[ri];
+      const int64_t na = (int64_t)lo[li + 1] - a0, nb = (int64_t)ro[ri + 1] - b0;
+      const uint8_t* pa = ld + a0;
+      const uint8_t* pb = rd + b0;
+      if (base == B_EQ && na != nb) {
+        res = false;
+      } else {
+        const int64_t n = na < nb ? na : nb;
+        int64_t i = 0;
+        int c = 0;  // sign of the first differing position
+        for (; i + 8 <= n; i += 8) {
+          const uint64_t x = load_u64_unaligned(pa + i), y = load_u64_unaligned(pb + i);
+          if (x != y) {
+            const uint64_t bx = __builtin_bswap64(x), by = __builtin_bswap64(y);
+            c = bx < by ? -1 : 1;
+            break;
+          }
+        }
+        if (c == 0)
+          for (; i < n; ++i) {
+            const int d = (int)pa[i] - (int)pb[i];
+            if (d) {
+              c = d < 0 ? -1 : 1;
+              break;
+            }
+          }
+        res = base == B_EQ ? (c == 0) : (c < 0 || (c == 0 && na < nb));
+      }
+      res = res != (neg != 0);
+    } else {
+      res = neg != 0;  // collect_bool: negated padding bits are ones (cmp.rs:600-607)
+    }
+    const unsigned long long word = __ballot(res);
+    if (lane == 0) out[w] = word;
+  }
+}
+
+}  // namespace
+
 extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_view* lhs, int32_t l_s,
                                 const ah_array_view* rhs, int32_t r_s, ah_array_out* out) {
   if (!ctx || !lhs || !rhs || !out) return AH_INVALID_ARGUMENT;
@@ -191,7 +253,8 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "Invalid comparison operation: %s %s %s",
                    ah_type_name(lhs->type), cmp_sym(op), ah_type_name(rhs->type));
   const ah_type t = lhs->type;
-  if (!(t == AH_BOOL || ah_type_is_integer(t) || ah_type_is_float(t)))
+  const bool is_bytes = t == AH_UTF8 || t == AH_LARGE_UTF8;
+  if (!(t == AH_BOOL || ah_type_is_integer(t) || ah_type_is_float(t) || is_bytes))
     return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "comparison not supported for type %s", ah_type_name(t));
   if ((l_s && lhs->length < 1) || (r_s && rhs->length < 1))
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "scalar datum must have length 1");
@@ -237,6 +300,19 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
     const ah_array_view* R = swap ? lhs : rhs;
     int Ls = swap ? r_s : l_s, Rs = swap ? l_s : r_s;
     ah_prof_scope ps(ctx, "compare");
+    if (is_bytes) {
+      const int64_t nwords = (len + 63) >> 6;
+      const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(256 * 16, ah_ceil_div(nwords, 4)));
+      if (t == AH_UTF8)
+        compare_bytes_kernel<int32_t><<<grid, 256, 0, ctx->stream>>>((const int32_t*)L->offsets, (const uint8_t*)L->values,
+                                                                     (const int32_t*)R->offsets, (const uint8_t*)R->values, len,
+                                                                     Ls, Rs, base, neg, dst);
+      else
+        compare_bytes_kernel<int64_t><<<grid, 256, 0, ctx->stream>>>((const int64_t*)L->offsets, (const uint8_t*)L->values,
+                                                                     (const int64_t*)R->offsets, (const uint8_t*)R->values, len,
+                                                                     Ls, Rs, base, neg, dst);
+      return AH_OK;
+    }
     if (t == AH_BOOL) {
       int64_t nwords = (len + 63) >> 6;
       int grid = (int)std::min<int64_t>(4096, ah_ceil_div(nwords, 256));

@@ -1039,6 +1039,42 @@ uint8_t* cmp_values_bool(int op, const orc_view* l, bool l_s, const orc_view* r,
   }
 }
 
+// ArrayOrd for &GenericByteArray (arrow-ord/src/cmp.rs:783-830): is_eq = same bytes, is_lt = bytewise lexicographic
+uint8_t* cmp_values_bytes(int op, const orc_view* l, bool l_s, const orc_view* r, bool r_s, int64_t len) {
+  const int ow = l->type == ORC_UTF8 ? 4 : 8;
+  auto off = [ow](const orc_view* a, int64_t i) -> int64_t {
+    return ow == 4 ? (int64_t)((const int32_t*)a->offsets)[i] : ((const int64_t*)a->offsets)[i];
+  };
+  auto get = [&](const orc_view* a, bool sc, int64_t i, const uint8_t** p, int64_t* n) {
+    const int64_t j = sc ? 0 : i;
+    *p = (const uint8_t*)a->values + off(a, j);
+    *n = off(a, j + 1) - off(a, j);
+  };
+  auto eq = [&](const orc_view* a, bool as, const orc_view* b, bool bs, int64_t i) {
+    const uint8_t *pa, *pb;
+    int64_t na, nb;
+    get(a, as, i, &pa, &na);
+    get(b, bs, i, &pb, &nb);
+    return na == nb && (na == 0 || memcmp(pa, pb, (size_t)na) == 0);
+  };
+  auto lt = [&](const orc_view* a, bool as, const orc_view* b, bool bs, int64_t i) {
+    const uint8_t *pa, *pb;
+    int64_t na, nb;
+    get(a, as, i, &pa, &na);
+    get(b, bs, i, &pb, &nb);
+    const int c = std::min(na, nb) ? memcmp(pa, pb, (size_t)std::min(na, nb)) : 0;
+    return c < 0 || (c == 0 && na < nb);
+  };
+  switch (op) {  // apply (cmp.rs:480-488)
+    case C_EQ: case C_NOT_DISTINCT: return collect_bool(len, false, [&](int64_t i) { return eq(l, l_s, r, r_s, i); });
+    case C_NEQ: case C_DISTINCT: return collect_bool(len, true, [&](int64_t i) { return eq(l, l_s, r, r_s, i); });
+    case C_LT: return collect_bool(len, false, [&](int64_t i) { return lt(l, l_s, r, r_s, i); });
+    case C_LT_EQ: return collect_bool(len, true, [&](int64_t i) { return lt(r, r_s, l, l_s, i); });
+    case C_GT: return collect_bool(len, false, [&](int64_t i) { return lt(r, r_s, l, l_s, i); });
+    default: return collect_bool(len, true, [&](int64_t i) { return lt(l, l_s, r, r_s, i); });
+  }
+}
+
 // ---------------------------------------------------------------------- cast
 // num_traits::cast (NumCast/ToPrimitive, num-traits 0.2.19): int->int range
 // checked; int->float `as`; float->int succeeds iff trunc(v) fits; float->float `as`.
@@ -1615,10 +1651,12 @@ int32_t orc_compare(int32_t op, const orc_view* l, int32_t l_s, const orc_view* 
       case ORC_UINT64: return cmp_values<uint64_t>(op, l, l_s, r, r_s, len);
       case ORC_FLOAT32: return cmp_values<float>(op, l, l_s, r, r_s, len);
       case ORC_FLOAT64: return cmp_values<double>(op, l, l_s, r, r_s, len);
+      case ORC_UTF8: case ORC_LARGE_UTF8: return cmp_values_bytes(op, l, l_s, r, r_s, len);
     }
     return nullptr;
   };
-  if (type_width(l->type) < 0 || l->type == ORC_FIXED16 || l->type == ORC_FIXED32 || l->type == ORC_FLOAT16)
+  const bool is_bytes = l->type == ORC_UTF8 || l->type == ORC_LARGE_UTF8;
+  if ((type_width(l->type) < 0 && !is_bytes) || l->type == ORC_FIXED16 || l->type == ORC_FIXED32 || l->type == ORC_FLOAT16)
     return fail(ORC_NOT_YET_IMPLEMENTED, "comparison not supported for type %s", type_name(l->type));
   size_t bytes = bitmap_bytes(len);
   // nulls filtered by null_count > 0 (:345-346)

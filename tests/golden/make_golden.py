@@ -519,7 +519,27 @@ zip_cases = [
     dict(name="scalar_len", source=f"{Z_}:121-125", mask=m1, truthy=arr("Int32", [1, 2]), truthy_scalar=True, falsy=zb,
          error="InvalidArgumentError", message="scalar arrays must have 1 element"),
 ]
-for name, cases in [("zip", zip_cases), ("sort", sort_cases), ("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
+
+# ---------------------------------------------------------------- string compare (arrow-ord/src/comparison.rs:1246-1432)
+C_ = "arrow-ord/src/comparison.rs"
+names4 = ["arrow", "datafusion", "flight", "parquet"]
+cmp_utf8_cases = [
+    dict(name="test_utf8_array_eq", source=f"{C_}:1246", op="eq", lhs=["arrow"] * 4, rhs=["arrow", "parquet", "datafusion", "flight"],
+         expected=[T, F, F, F]),
+    dict(name="test_utf8_array_eq_scalar", source=f"{C_}:1260", op="eq", lhs=["arrow", "parquet", "datafusion", "flight"],
+         rhs_scalar="arrow", expected=[T, F, F, F]),
+    dict(name="test_utf8_array_neq", source=f"{C_}:1282", op="neq", lhs=["arrow"] * 4, rhs=["arrow", "parquet", "datafusion", "flight"],
+         expected=[F, T, T, T]),
+    dict(name="test_utf8_array_neq_scalar", source=f"{C_}:1296", op="neq", lhs=["arrow", "parquet", "datafusion", "flight"],
+         rhs_scalar="arrow", expected=[F, T, T, T]),
+]
+for opname, line, exp in (("lt", 1311, [T, T, F, F]), ("lt_eq", 1347, [T, T, T, F]), ("gt", 1376, [F, F, F, T]),
+                          ("gt_eq", 1412, [F, F, T, T])):
+    cmp_utf8_cases.append(dict(name=f"test_utf8_array_{opname}", source=f"{C_}:{line}", op=opname, lhs=names4,
+                               rhs=["flight"] * 4, expected=exp))
+    cmp_utf8_cases.append(dict(name=f"test_utf8_array_{opname}_scalar", source=f"{C_}:{line + 14}", op=opname, lhs=names4,
+                               rhs_scalar="flight", expected=exp))
+for name, cases in [("cmp_utf8", cmp_utf8_cases), ("zip", zip_cases), ("sort", sort_cases), ("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
                     ("cast", cast_cases)]:
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump({"reference": "apache/arrow-rs 59.2.0", "cases": cases}, f, indent=1)

@@ -487,3 +487,17 @@ def test_zip_golden(oracle, case, bit_offset):
     if "error" in case:
         return expect_err(case, run)
     assert_logical_eq(run(), golden_array(case["expected"]), case["name"])
+
+
+# ------------------------------------------------------------------- string compare
+@pytest.mark.parametrize("case", load_golden("cmp_utf8"), ids=lambda c: c["name"])
+@pytest.mark.parametrize("dt", [A.Utf8, A.LargeUtf8], ids=repr)
+def test_cmp_utf8_golden(oracle, case, dt):
+    l = HostArray(dt, list(case["lhs"]))
+    rs = "rhs_scalar" in case
+    r = HostArray(dt, [case["rhs_scalar"]] if rs else list(case["rhs"]))
+    got = oracle.compare(CMP[case["op"]], l, r, r_scalar=rs)
+    assert got.valid is None and got.values.tolist() == case["expected"]
+    if not rs:  # x10, like the reference's macro (comparison.rs:146-161)
+        got = oracle.compare(CMP[case["op"]], HostArray(dt, list(case["lhs"]) * 10), HostArray(dt, list(case["rhs"]) * 10))
+        assert got.values.tolist() == case["expected"] * 10
