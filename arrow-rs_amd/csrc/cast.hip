@@ -21,6 +21,7 @@
 
 ah_status ah_cast_to_string(ah_context* ctx, const ah_array_view* values, ah_type to_type,
                             ah_array_out* out);  // cast_string.hip
+ah_status ah_cast_bool(ah_context* ctx, const ah_array_view* values, ah_type to_type, ah_array_out* out);  // cast_bool.hip
 
 namespace {
 
@@ -218,6 +219,7 @@ ah_status elem_debug_text(ah_context* ctx, ah_type t, const void* base, int64_t 
 extern "C" int32_t ah_can_cast_types(ah_type from, ah_type to) {
   if (from == to) return ah_type_width(from) >= 0 || from == AH_UTF8 || from == AH_LARGE_UTF8;
   if (is_numeric(from) && is_numeric(to)) return 1;
+  if ((from == AH_BOOL && is_numeric(to)) || (is_numeric(from) && to == AH_BOOL)) return 1;  // cast/mod.rs:254-255
   if (is_numeric(from) && (to == AH_UTF8 || to == AH_LARGE_UTF8)) return 1;
   return 0;
 }
@@ -232,6 +234,7 @@ extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_ty
     return ah_fail(ctx, AH_CAST_ERROR, "Casting from %s to %s not supported", ah_type_name(from),
                    ah_type_name(to_type));
   if (to_type == AH_UTF8 || to_type == AH_LARGE_UTF8) return ah_cast_to_string(ctx, values, to_type, out);
+  if ((from == AH_BOOL) != (to_type == AH_BOOL)) return ah_cast_bool(ctx, values, to_type, out);
   const int64_t len = values->length;
   const int wo = ah_type_width(to_type);
   out->type = to_type;

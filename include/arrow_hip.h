@@ -254,7 +254,8 @@ AH_API ah_status ah_nullif(ah_context* ctx, const ah_array_view* left, const ah_
 /* arrow_cast::cast_with_options (arrow-cast/src/cast/mod.rs:790), restricted to
  * numeric<->numeric (mod.rs:1578-1697 via cast_numeric_arrays :2550) and
  * Float64/Float32/integers -> Utf8 / LargeUtf8 (mod.rs:1552-1553 via
- * value_to_string, cast/string.rs:21-39).  safe mirrors CastOptions.safe. */
+ * value_to_string, cast/string.rs:21-39), and Boolean <-> numeric (mod.rs:1243-1290:
+ * `value != 0`; true -> 1, false -> 0).  safe mirrors CastOptions.safe. */
 AH_API ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_type to_type,
                          int32_t safe, ah_array_out* out);
 AH_API int32_t ah_can_cast_types(ah_type from, ah_type to); /* cast/mod.rs:115 subset */

@@ -1524,6 +1524,60 @@ void sort_valid_typed(const orc_view* a, std::vector<uint32_t>& valid, bool desc
   else std::stable_sort(valid.begin(), valid.end(), [v](uint32_t x, uint32_t y) { return is_lt<T>(v[y], v[x]); });
 }
 
+// Boolean <-> numeric (arrow-cast/src/cast/mod.rs:1243-1290): numeric_to_bool_cast :2661 (value != default; a null
+// buffer only if a null was appended), bool_to_numeric_cast :2704 (true -> 1, false -> 0, null slots default;
+// from_trusted_len_iter always builds a null buffer)
+template <typename T> int32_t cast_num_to_bool(const orc_view* in, orc_out* out) {
+  const int64_t n = in->length;
+  out->type = ORC_BOOL;
+  out->length = n;
+  const T* v = (const T*)in->values;
+  uint8_t* vals = (uint8_t*)xalloc(bitmap_bytes(n));
+  const bool has_nulls = in->validity && resolve_nulls(in) > 0;
+  uint8_t* nb = has_nulls ? (uint8_t*)xalloc(bitmap_bytes(n)) : nullptr;
+  int64_t nulls = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (has_nulls && !get_bit(in->validity, in->validity_bit_offset + i)) {
+      ++nulls;
+      continue;
+    }
+    if (nb) set_bit(nb, i);
+    if (v[i] != T{}) set_bit(vals, i);
+  }
+  out->values = vals;
+  out->values_bytes = (int64_t)bitmap_bytes(n);
+  if (nb) {
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(n);
+    out->null_count = nulls;
+  }
+  return ORC_OK;
+}
+template <typename T> int32_t cast_bool_to_num(const orc_view* in, int32_t to, orc_out* out) {
+  const int64_t n = in->length;
+  out->type = to;
+  out->length = n;
+  T* o = (T*)xalloc((size_t)std::max<int64_t>(n, 1) * sizeof(T));
+  uint8_t* nb = (uint8_t*)xalloc(bitmap_bytes(n));
+  int64_t nulls = 0;
+  const uint8_t* b = (const uint8_t*)in->values;
+  for (int64_t i = 0; i < n; ++i) {
+    if (in->validity && !get_bit(in->validity, in->validity_bit_offset + i)) {
+      o[i] = T{};
+      ++nulls;
+      continue;
+    }
+    set_bit(nb, i);
+    o[i] = get_bit(b, in->values_bit_offset + i) ? (T)1 : T{};
+  }
+  out->values = o;
+  out->values_bytes = std::max<int64_t>(n, 1) * (int64_t)sizeof(T);
+  out->validity = nb;
+  out->validity_bytes = (int64_t)bitmap_bytes(n);
+  out->null_count = nulls;
+  return ORC_OK;
+}
+
 }  // namespace
 
 // =================================================================== exports
@@ -1855,6 +1909,36 @@ int32_t orc_nullif(const orc_view* l, const orc_view* r, orc_out* out) {
 
 int32_t orc_cast(const orc_view* in, int32_t to, int32_t safe, orc_out* out) {
   out_init(out);
+  if (in->type == ORC_BOOL && to != ORC_BOOL) {
+    switch (to) {
+      case ORC_INT8: return cast_bool_to_num<int8_t>(in, to, out);
+      case ORC_INT16: return cast_bool_to_num<int16_t>(in, to, out);
+      case ORC_INT32: return cast_bool_to_num<int32_t>(in, to, out);
+      case ORC_INT64: return cast_bool_to_num<int64_t>(in, to, out);
+      case ORC_UINT8: return cast_bool_to_num<uint8_t>(in, to, out);
+      case ORC_UINT16: return cast_bool_to_num<uint16_t>(in, to, out);
+      case ORC_UINT32: return cast_bool_to_num<uint32_t>(in, to, out);
+      case ORC_UINT64: return cast_bool_to_num<uint64_t>(in, to, out);
+      case ORC_FLOAT32: return cast_bool_to_num<float>(in, to, out);
+      case ORC_FLOAT64: return cast_bool_to_num<double>(in, to, out);
+    }
+    return fail(ORC_CAST_ERROR, "Casting from %s to %s not supported", type_name(in->type), type_name(to));
+  }
+  if (to == ORC_BOOL && in->type != ORC_BOOL) {
+    switch (in->type) {
+      case ORC_INT8: return cast_num_to_bool<int8_t>(in, out);
+      case ORC_INT16: return cast_num_to_bool<int16_t>(in, out);
+      case ORC_INT32: return cast_num_to_bool<int32_t>(in, out);
+      case ORC_INT64: return cast_num_to_bool<int64_t>(in, out);
+      case ORC_UINT8: return cast_num_to_bool<uint8_t>(in, out);
+      case ORC_UINT16: return cast_num_to_bool<uint16_t>(in, out);
+      case ORC_UINT32: return cast_num_to_bool<uint32_t>(in, out);
+      case ORC_UINT64: return cast_num_to_bool<uint64_t>(in, out);
+      case ORC_FLOAT32: return cast_num_to_bool<float>(in, out);
+      case ORC_FLOAT64: return cast_num_to_bool<double>(in, out);
+    }
+    return fail(ORC_CAST_ERROR, "Casting from %s to %s not supported", type_name(in->type), type_name(to));
+  }
   if (to == ORC_UTF8) return cast_to_string_dispatch<int32_t>(in, to, out);
   if (to == ORC_LARGE_UTF8) return cast_to_string_dispatch<int64_t>(in, to, out);
   if (in->type == to) {  // cast_with_options :797-799 — clone
