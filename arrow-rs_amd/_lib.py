@@ -98,6 +98,14 @@ FFI_ArrowArray._fields_ = [
     ("children", C.POINTER(C.POINTER(FFI_ArrowArray))), ("dictionary", C.POINTER(FFI_ArrowArray)),
     ("release", C.c_void_p), ("private_data", C.c_void_p)]
 
+class FFI_ArrowDeviceArray(C.Structure):
+    """struct ArrowDeviceArray (Arrow C Device Data Interface)."""
+    _fields_ = [("array", FFI_ArrowArray), ("device_id", C.c_int64), ("device_type", C.c_int32), ("sync_event", C.c_void_p),
+                ("reserved", C.c_int64 * 3)]
+
+
+ARROW_DEVICE_ROCM = 10
+
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -172,6 +180,8 @@ SIGNATURES = {
     "ah_type_from_format": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int32)]),
     "ah_format_of_type": (C.c_char_p, [C.c_int32]),
     "ah_import_c_data": (C.c_int32, [_P, C.POINTER(FFI_ArrowArray), C.POINTER(FFI_ArrowSchema), _OUT]),
+    "ah_export_c_device_data": (C.c_int32, [_P, _VIEW, _OUT, C.c_char_p, C.POINTER(FFI_ArrowDeviceArray), C.POINTER(FFI_ArrowSchema)]),
+    "ah_import_c_device_data": (C.c_int32, [_P, C.POINTER(FFI_ArrowDeviceArray), C.POINTER(FFI_ArrowSchema), _VIEW]),
     "ah_export_c_data": (C.c_int32, [_P, _VIEW, C.c_char_p, C.POINTER(FFI_ArrowArray), C.POINTER(FFI_ArrowSchema)]),
 }
 

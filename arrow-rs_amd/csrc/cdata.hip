@@ -396,3 +396,169 @@ extern "C" ah_status ah_export_c_data(ah_context* ctx, const ah_array_view* v, c
   os->private_data = nullptr;
   return AH_OK;
 }
+
+// ------------------------------------------------------------------ Arrow C Device Data Interface
+namespace {
+
+struct DeviceArrayPrivate {
+  const void* buffers[3] = {nullptr, nullptr, nullptr};
+  ah_context* ctx = nullptr;
+  ah_array_out owned{};       // buffers that moved in (flags / pointers as the kernel returned them)
+  void* realigned[2] = {nullptr, nullptr};  // re-aligned validity / Boolean bitmaps (pool allocations)
+};
+void release_device_array(struct ArrowArray* a) {
+  if (!a || !a->release) return;
+  auto* p = static_cast<DeviceArrayPrivate*>(a->private_data);
+  if (p) {
+    if (p->ctx) {
+      hipSetDevice(p->ctx->device);
+      ah_array_release(p->ctx, &p->owned);
+      for (void* r : p->realigned)
+        if (r) ah_pool_free(p->ctx, r);
+    }
+    delete p;
+  }
+  a->release = nullptr;
+  a->private_data = nullptr;
+}
+
+// device bitmap [bit_offset, bit_offset+len) as a pointer to a bit-0-aligned bitmap (re-aligned copy if needed)
+ah_status aligned_bits(ah_context* ctx, const void* bits, int64_t bit_offset, int64_t len, const void** out, void** owned) {
+  *owned = nullptr;
+  if ((bit_offset & 7) == 0) {
+    *out = static_cast<const uint8_t*>(bits) + bit_offset / 8;
+    return AH_OK;
+  }
+  void* tmp = nullptr;
+  AH_TRY(ah_pool_alloc(ctx, ah_bitmap_bytes(len), &tmp));
+  ah_status st = ah_bitmap_op(ctx, BM_COPY, make_bitview(bits, bit_offset), BitView{nullptr, 0}, BitView{nullptr, 0}, len,
+                              (unsigned long long*)tmp, nullptr);
+  if (st == AH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "bitmap re-alignment failed");
+  if (st != AH_OK) {
+    ah_pool_free(ctx, tmp);
+    return st;
+  }
+  *out = tmp;
+  *owned = tmp;
+  return AH_OK;
+}
+
+}  // namespace
+
+extern "C" ah_status ah_export_c_device_data(ah_context* ctx, const ah_array_view* v, ah_array_out* owned,
+                                             const char* format, struct ArrowDeviceArray* od, struct ArrowSchema* os) {
+  if (!ctx || !v || !od || !os) return AH_INVALID_ARGUMENT;
+  hipSetDevice(ctx->device);
+  const ah_type t = v->type;
+  if (format) {
+    ah_type ft;
+    AH_TRY(type_from_format(ctx, format, &ft));
+    const bool same = ft == t || (ah_type_width(ft) > 0 && ah_type_width(ft) == ah_type_width(t));
+    if (!same) return ah_fail(ctx, AH_C_DATA_INTERFACE, "format \"%s\" does not describe the physical layout %s", format, ah_type_name(t));
+  } else if (!(format = ah_format_of_type(t))) {
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "unknown array type %d", (int)t);
+  }
+  if (t == AH_UTF8_VIEW || t == AH_BINARY_VIEW)
+    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "device export of %s (variadic buffers stay with the host)", ah_type_name(t));
+  const int64_t len = v->length;
+  const bool is_str = t == AH_UTF8 || t == AH_LARGE_UTF8;
+  auto* priv = new DeviceArrayPrivate();
+  priv->ctx = ctx;
+  auto fail = [&](ah_status st) {
+    for (void* r : priv->realigned)
+      if (r) ah_pool_free(ctx, r);
+    delete priv;
+    return st;
+  };
+  int64_t nulls = 0;
+  ah_status st = ah_resolve_null_count(ctx, v, &nulls);
+  if (st != AH_OK) return fail(st);
+  if (v->validity && len > 0) {
+    st = aligned_bits(ctx, v->validity, v->validity_bit_offset, len, &priv->buffers[0], &priv->realigned[0]);
+    if (st != AH_OK) return fail(st);
+  }
+  if (t == AH_BOOL) {
+    if (len > 0) {
+      st = aligned_bits(ctx, v->values, v->values_bit_offset, len, &priv->buffers[1], &priv->realigned[1]);
+      if (st != AH_OK) return fail(st);
+    }
+  } else if (is_str) {
+    priv->buffers[1] = v->offsets;
+    priv->buffers[2] = v->values;
+  } else {
+    priv->buffers[1] = v->values;
+  }
+  char* fmt = strdup(format);
+  if (!fmt) return fail(ah_fail(ctx, AH_OUT_OF_MEMORY, "host allocation failed"));
+  if (owned) {  // the buffers move into the exported struct
+    priv->owned = *owned;
+    ah_out_init(owned);
+  } else {
+    ah_out_init(&priv->owned);
+  }
+  memset(od, 0, sizeof *od);
+  od->array.length = len;
+  od->array.null_count = v->validity ? nulls : 0;
+  od->array.offset = 0;
+  od->array.n_buffers = is_str ? 3 : 2;
+  od->array.buffers = priv->buffers;
+  od->array.release = release_device_array;
+  od->array.private_data = priv;
+  od->device_id = ctx->device;
+  od->device_type = ARROW_DEVICE_ROCM;
+  od->sync_event = nullptr;
+  os->format = fmt;
+  os->name = "";
+  os->metadata = nullptr;
+  os->flags = ARROW_FLAG_NULLABLE;
+  os->n_children = 0;
+  os->children = nullptr;
+  os->dictionary = nullptr;
+  os->release = release_host_schema;
+  os->private_data = nullptr;
+  return AH_OK;
+}
+
+extern "C" ah_status ah_import_c_device_data(ah_context* ctx, const struct ArrowDeviceArray* d, const struct ArrowSchema* schema,
+                                             ah_array_view* out) {
+  if (!ctx || !d || !schema || !out) return AH_INVALID_ARGUMENT;
+  hipSetDevice(ctx->device);
+  memset(out, 0, sizeof *out);
+  const struct ArrowArray* a = &d->array;
+  if (!a->release) return ah_fail(ctx, AH_C_DATA_INTERFACE, "The ArrowArray has already been released");
+  if (d->device_type != ARROW_DEVICE_ROCM && d->device_type != ARROW_DEVICE_ROCM_HOST)
+    return ah_fail(ctx, AH_C_DATA_INTERFACE, "device type %d is not ROCm memory", (int)d->device_type);
+  if (d->device_type == ARROW_DEVICE_ROCM && d->device_id != ctx->device)
+    return ah_fail(ctx, AH_C_DATA_INTERFACE, "array lives on device %lld, the context on device %d", (long long)d->device_id, ctx->device);
+  ah_type t;
+  AH_TRY(type_from_format(ctx, schema->format, &t));
+  if (schema->dictionary || a->dictionary)
+    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "dictionary-encoded C Data arrays have no device kernels");
+  const bool is_str = t == AH_UTF8 || t == AH_LARGE_UTF8;
+  const int64_t want = is_str ? 3 : 2;
+  if (a->n_buffers != want)
+    return ah_fail(ctx, AH_C_DATA_INTERFACE,
+                   "The datatype \"%s\" expects %lld buffers, but requested %lld. Please verify that the C data "
+                   "interface is correctly implemented.", ah_type_name(t), (long long)want, (long long)a->n_buffers);
+  if (a->length < 0 || a->offset < 0) return ah_fail(ctx, AH_C_DATA_INTERFACE, "negative length or offset");
+  if (d->sync_event)  // the producer's work must be visible to kernels this context launches
+    AH_HIP(ctx, hipStreamWaitEvent(ctx->stream, *static_cast<hipEvent_t*>(d->sync_event), 0));
+  const int64_t off = a->offset, len = a->length;
+  out->type = t;
+  out->length = len;
+  out->validity = static_cast<const uint8_t*>(a->buffers[0]);
+  out->validity_bit_offset = out->validity ? off : 0;
+  out->null_count = out->validity ? a->null_count : 0;  // -1 stays "unknown": counted on first use
+  if (len > 0 && !a->buffers[1]) return ah_fail(ctx, AH_C_DATA_INTERFACE, "The external buffer at position 1 is null.");
+  if (t == AH_BOOL) {
+    out->values = a->buffers[1];
+    out->values_bit_offset = off;
+  } else if (is_str) {
+    const int ow = t == AH_UTF8 ? 4 : 8;
+    out->offsets = a->buffers[1] ? static_cast<const uint8_t*>(a->buffers[1]) + off * ow : nullptr;
+    out->values = a->buffers[2];
+  } else {
+    out->values = a->buffers[1] ? static_cast<const uint8_t*>(a->buffers[1]) + off * ah_type_width(t) : nullptr;
+  }
+  return AH_OK;
+}

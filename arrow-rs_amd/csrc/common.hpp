@@ -39,6 +39,11 @@ struct ah_context {
   std::map<size_t, std::vector<void*>> pool_free;
   std::unordered_map<void*, size_t> pool_live;  // ptr -> rounded size
   std::unordered_map<void*, size_t> redzones;   // AH_DEBUG_REDZONE: ptr -> requested size
+  struct hook_entry {
+    ah_free_fn free_;
+    void* user;
+  };
+  std::unordered_map<void*, hook_entry> hook_live;  // outputs handed out by the host allocator hook, with THEIR free
   // pinned host read-back slots
   uint64_t* pinned = nullptr;  // 256 x u64
   // profiling

@@ -117,6 +117,9 @@ ah_status ah_out_alloc(ah_context* ctx, size_t bytes, void** out) {
   if (ctx->alloc) {
     void* p = ctx->alloc(ctx->user, bytes);
     if (!p) return ah_fail(ctx, AH_OUT_OF_MEMORY, "host allocator returned NULL for %zu bytes", bytes);
+    // remembered explicitly: the host may carve its memory out of a block it got from ah_device_alloc, so "not a
+    // pool pointer" is not a safe test for "came from the hook"
+    ctx->hook_live[p] = ah_context::hook_entry{ctx->free_, ctx->user};
     *out = p;
     return AH_OK;
   }
@@ -138,8 +141,11 @@ void ah_out_free(ah_context* ctx, void* p, size_t bytes) {
     }
     ctx->redzones.erase(rz);
   }
-  if (ctx->free_ && ctx->pool_live.find(p) == ctx->pool_live.end()) {
-    ctx->free_(ctx->user, p, bytes);
+  auto hk = ctx->hook_live.find(p);
+  if (hk != ctx->hook_live.end()) {
+    const ah_context::hook_entry e = hk->second;  // freed by the allocator that made it, even if the hook changed since
+    ctx->hook_live.erase(hk);
+    if (e.free_) e.free_(e.user, p, bytes);
     return;
   }
   ah_pool_free(ctx, p);

@@ -127,3 +127,55 @@ def to_pyarrow(obj):
         return pa.RecordBatch.from_arrays([to_pyarrow(c) for c in obj.columns], names=list(obj.names))
     ex = to_ffi(obj)
     return pa.Array._import_from_c(C.addressof(ex.array), C.addressof(ex.schema))
+
+
+# ---- Arrow C Device Data Interface (zero-copy, ROCm) ------------------------------------------
+class _ExportedDevice:
+    """Owns an (ArrowDeviceArray, ArrowSchema) pair; `keepalive` pins a borrowed source array."""
+
+    def __init__(self, keepalive=None):
+        self.array, self.schema = L.FFI_ArrowDeviceArray(), FFI_ArrowSchema()
+        self.keepalive = keepalive
+
+    def release(self):
+        if self.array.array.release:
+            C.CFUNCTYPE(None, C.c_void_p)(self.array.array.release)(C.addressof(self.array.array))
+        if self.schema.release:
+            C.CFUNCTYPE(None, C.c_void_p)(self.schema.release)(C.addressof(self.schema))
+        self.keepalive = None
+
+    def __del__(self):
+        self.release()
+
+
+def to_device_ffi(array):
+    """Zero-copy export as `struct ArrowDeviceArray` (device_type ARROW_DEVICE_ROCM): the exported struct borrows
+    the array's HBM buffers (kept alive by the returned holder)."""
+    ctx = array.ctx
+    ex = _ExportedDevice(keepalive=array)
+    fmt = format_of(array.data_type)
+    v = array.view()
+    ctx.check(ctx.lib.ah_export_c_device_data(ctx.handle, C.byref(v), None, fmt.encode() if fmt else None,
+                                              C.byref(ex.array), C.byref(ex.schema)))
+    return ex
+
+
+def from_device_ffi(dev_array, schema, ctx=None, keepalive=None):
+    """Zero-copy import of a ROCm-resident `ArrowDeviceArray`: an Array viewing the producer's buffers
+    (`keepalive` = whatever owns them)."""
+    ctx = ctx or A.default_context()
+    view = L.ArrayView()
+    ctx.check(ctx.lib.ah_import_c_device_data(ctx.handle, C.byref(dev_array), C.byref(schema), C.byref(view)))
+    dt = data_type_from_format(ctx, schema.format.decode())
+    n = view.length
+    w = dt.width
+    mem = lambda p, nb: A._RawMem(p, nb, keepalive) if p else None  # noqa: E731
+    vals = mem(view.values, (n * w) if w > 0 else 0)
+    nulls = view.null_count
+    arr = A.Array(ctx, dt, n, vals, view.values_bit_offset, mem(view.validity, (view.validity_bit_offset + n + 7) // 8),
+                  view.validity_bit_offset, max(nulls, 0), mem(view.offsets, 0))
+    if view.validity and nulls < 0:  # "not yet computed": count on the device
+        cnt = C.c_int64()
+        ctx.check(ctx.lib.ah_count_set_bits(ctx.handle, view.validity, view.validity_bit_offset, n, C.byref(cnt)))
+        arr._null_count = n - cnt.value
+    return arr

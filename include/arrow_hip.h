@@ -390,6 +390,39 @@ AH_API ah_status ah_import_c_data(ah_context* ctx, const struct ArrowArray* arra
 AH_API ah_status ah_export_c_data(ah_context* ctx, const ah_array_view* values, const char* format,
                                   struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 
+/* -------------------------------------------- Arrow C Device Data Interface */
+/* The device-aware extension of the C Data Interface (Arrow specification, "C Device data interface"): the same
+ * ArrowArray, whose buffer pointers are DEVICE pointers, plus the device it lives on and an optional event to wait
+ * for.  arrow-rs has no counterpart (its ffi module is host-only, arrow-array/src/ffi.rs); this is the zero-copy
+ * hand-off between this library and any other ROCm producer / consumer. */
+#ifndef ARROW_C_DEVICE_DATA_INTERFACE
+#define ARROW_C_DEVICE_DATA_INTERFACE
+typedef int32_t ArrowDeviceType;
+#define ARROW_DEVICE_CPU 1
+#define ARROW_DEVICE_ROCM 10
+#define ARROW_DEVICE_ROCM_HOST 11
+struct ArrowDeviceArray {
+  struct ArrowArray array;
+  int64_t device_id;
+  ArrowDeviceType device_type;
+  void* sync_event; /* ROCm: hipEvent_t*, or NULL when the data is already complete */
+  int64_t reserved[3];
+};
+#endif
+/* Zero-copy export of a device array.  Values / offsets / data buffers are exported by pointer; a validity (or
+ * Boolean value) bitmap that does not start on bit 0 is re-aligned into a fresh device buffer first
+ * (`align_nulls`, arrow-data/src/ffi.rs:104), so `array.offset` is always 0.  If `owned` is non-NULL its buffers
+ * MOVE into the exported struct (the release callback frees them through the context, which must outlive it) and
+ * `*owned` is cleared; otherwise the export borrows `values` and the caller keeps the source alive.
+ * sync_event is NULL: every entry point of this library is synchronous at return. */
+AH_API ah_status ah_export_c_device_data(ah_context* ctx, const ah_array_view* values, ah_array_out* owned,
+                                         const char* format, struct ArrowDeviceArray* out_array,
+                                         struct ArrowSchema* out_schema);
+/* Zero-copy import: a borrowed view of a ROCm-resident ArrowDeviceArray on this context's device (the producer
+ * keeps ownership; waits for `sync_event` on the context stream when one is given). */
+AH_API ah_status ah_import_c_device_data(ah_context* ctx, const struct ArrowDeviceArray* array,
+                                         const struct ArrowSchema* schema, ah_array_view* out_view);
+
 /* ------------------------------------------------------------------- zip */
 /* arrow_select::zip::zip (arrow-select/src/zip.rs:99): out[i] = mask[i] ? truthy[i] : falsy[i]; a null mask row
  * selects `falsy`; either side may be a length-1 scalar (`Datum::get()`).  Fixed-width and Boolean layouts.

@@ -184,3 +184,102 @@ def test_to_ffi_struct_fields_and_release(ctx):
     assert nn.array.null_count == 0 and not nn.array.buffers[0]  # no null buffer -> NULL (ffi.rs:170-178)
     s = ffi.to_ffi(A.Array.from_strings(["a", "", "ccc"], [True, False, True], ctx=ctx))
     assert s.array.n_buffers == 3 and s.schema.format == b"u"
+
+
+# ------------------------------------------------------------------ C Device Data Interface
+def test_device_interface_zero_copy_round_trip(ctx, oracle):
+    """ArrowDeviceArray export / import: same HBM pointers on both sides, device_type ROCM, no sync event; bit
+    offsets are re-aligned for the exported struct (offset 0) and honoured on import."""
+    from orc import HostArray
+    rng = np.random.default_rng(5)
+    n = 10_000
+    h = HostArray(A.Int64, rng.integers(-2**60, 2**60, n), rng.random(n) < 0.8)
+    d = h.to_device(ctx)                      # validity at bit offset 0: exported by pointer
+    ex = ffi.to_device_ffi(d)
+    da = ex.array
+    assert (da.device_type, da.device_id, da.sync_event) == (ffi.L.ARROW_DEVICE_ROCM, ctx.device, None)
+    assert (da.array.length, da.array.null_count, da.array.offset, da.array.n_buffers) == (n, h.null_count, 0, 2)
+    assert da.array.buffers[1] == d.values.ptr and da.array.buffers[0] == d.validity.ptr
+    assert ex.schema.format == b"l"
+    back = ffi.from_device_ffi(da, ex.schema, ctx, keepalive=ex)
+    assert back.values.ptr == d.values.ptr and back.null_count() == h.null_count
+    mask = HostArray(A.Boolean, rng.random(n) < 0.3)
+    check = K.filter(back, mask.to_device(ctx))
+    import orc
+    orc.assert_logical_eq(HostArray.from_device(check), oracle.filter(h, mask), "filter on imported view")
+    # consumer-side offset: a producer that slices by `offset` (values AND validity shift together)
+    da.array.offset = 77
+    da.array.length = 1000
+    da.array.null_count = -1
+    sl = ffi.from_device_ffi(da, ex.schema, ctx, keepalive=ex)
+    orc.assert_logical_eq(HostArray.from_device(sl), h.slice(77, 1000), "offset import")
+    assert sl.null_count() == h.slice(77, 1000).null_count
+    da.array.offset, da.array.length, da.array.null_count = 0, n, h.null_count
+    # sliced / bit-offset source: values by pointer, validity re-aligned into a fresh buffer
+    s = h.to_device(ctx, bit_offset=5).slice(13, 5000)
+    ex2 = ffi.to_device_ffi(s)
+    assert ex2.array.array.offset == 0 and ex2.array.array.buffers[1] == s.values.ptr
+    assert ex2.array.array.buffers[0] != s.validity.ptr
+    orc.assert_logical_eq(HostArray.from_device(ffi.from_device_ffi(ex2.array, ex2.schema, ctx, keepalive=ex2)),
+                          h.slice(13, 5000), "re-aligned validity")
+    # strings and booleans
+    strs = A.Array.from_strings([f"s{i}" * (i % 3) for i in range(500)], [i % 4 != 0 for i in range(500)], ctx=ctx)
+    ex3 = ffi.to_device_ffi(strs)
+    assert ex3.array.array.n_buffers == 3 and ex3.schema.format == b"u"
+    assert ffi.from_device_ffi(ex3.array, ex3.schema, ctx, keepalive=ex3).to_pylist() == strs.to_pylist()
+    b = HostArray(A.Boolean, rng.random(999) < 0.5, rng.random(999) < 0.9).to_device(ctx, bit_offset=3)
+    ex4 = ffi.to_device_ffi(b)
+    assert ffi.from_device_ffi(ex4.array, ex4.schema, ctx, keepalive=ex4).to_pylist() == b.to_pylist()
+    # errors: wrong device type / id, released struct
+    da.device_type = 2  # CUDA
+    with pytest.raises(A.CDataInterfaceError, match="not ROCm memory"):
+        ffi.from_device_ffi(da, ex.schema, ctx)
+    da.device_type, da.device_id = ffi.L.ARROW_DEVICE_ROCM, ctx.device + 1
+    with pytest.raises(A.CDataInterfaceError, match="lives on device"):
+        ffi.from_device_ffi(da, ex.schema, ctx)
+    da.device_id = ctx.device
+    ex.release()
+    assert not ex.array.array.release
+    with pytest.raises(A.CDataInterfaceError):
+        ffi.from_device_ffi(ex.array, ex.schema, ctx)
+
+
+def test_device_interface_moves_ownership(ctx):
+    """`owned` != NULL: the kernel result's buffers move into the ArrowDeviceArray and are freed by its release
+    callback (checked through the allocator hook: every buffer handed out is freed exactly once)."""
+    L = A._lib
+    live = {}
+    arena = ctx.alloc(4 << 20)  # sub-allocated by the hook: pointers the library's own pool has never seen
+    top = [0]
+
+    @L.ALLOC_FN
+    def alloc(user, nbytes):
+        off = (top[0] + 255) & ~255
+        top[0] = off + nbytes
+        live[arena.ptr + off] = nbytes
+        return arena.ptr + off
+
+    @L.FREE_FN
+    def free(user, ptr, nbytes):
+        assert live.pop(ptr) == nbytes
+
+    vals = A.Array.from_numpy(np.arange(5000, dtype=np.int64), np.arange(5000) % 3 != 0, ctx=ctx)
+    mask = A.Array.from_numpy(np.arange(5000) % 2 == 0, ctx=ctx)
+    ctx.lib.ah_context_set_allocator(ctx.handle, alloc, free, None)
+    try:
+        out = L.ArrayOut()
+        vv, mv = vals.view(), mask.view()
+        ctx.check(ctx.lib.ah_filter(ctx.handle, C.byref(vv), C.byref(mv), C.byref(out)))
+        assert len(live) == 2  # values + validity of the result
+        res_view = L.ArrayView()
+        res_view.type, res_view.length, res_view.null_count = out.type, out.length, out.null_count
+        res_view.values, res_view.validity = out.values, out.validity
+        dev, sch = L.FFI_ArrowDeviceArray(), ffi.FFI_ArrowSchema()
+        ctx.check(ctx.lib.ah_export_c_device_data(ctx.handle, C.byref(res_view), C.byref(out), None, C.byref(dev), C.byref(sch)))
+        assert not out.values and not out.validity and len(live) == 2      # moved, nothing freed yet
+        assert dev.array.length == 2500 and dev.array.buffers[1] in live
+        C.CFUNCTYPE(None, C.c_void_p)(dev.array.release)(C.addressof(dev.array))
+        assert live == {} and not dev.array.release
+        C.CFUNCTYPE(None, C.c_void_p)(sch.release)(C.addressof(sch))
+    finally:
+        ctx.lib.ah_context_set_allocator(ctx.handle, L.ALLOC_FN(0), L.FREE_FN(0), None)
