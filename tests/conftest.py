@@ -15,6 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A clean checkout has no built artefacts (*.so is git-ignored): build the HIP library (hipcc cross-compiles
+    without a GPU) before collection imports the package.  The product itself never builds or falls back."""
+    lib = os.path.join(ROOT, "arrow-rs_amd", "lib", "libarrow_hip.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "arrow-rs_amd", "csrc"), "-j", str(min(16, os.cpu_count() or 4))])
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (oracle/liboracle.so) — test infrastructure only."""
