@@ -161,6 +161,7 @@ SIGNATURES = {
     "ah_gen_bernoulli_bits": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_double, C.c_int64]),
     "ah_zero_null_slots": (C.c_int32, [_P, _P, C.c_int32, _P, C.c_int64]),
     "ah_aggregate": (C.c_int32, [_P, C.c_int32, _VIEW, C.POINTER(Scalar)]),
+    "ah_interleave": (C.c_int32, [_P, C.c_int32, _VIEW, _VIEW, _VIEW, _OUT]),
     "ah_zip": (C.c_int32, [_P, _VIEW, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
     "ah_sort_to_indices": (C.c_int32, [_P, _VIEW, C.c_int32, C.c_int32, C.c_int64, _OUT]),
     "ah_lexsort_to_indices": (C.c_int32, [_P, C.c_int32, _VIEW, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64, _OUT]),

@@ -16,3 +16,4 @@ from .kernels.aggregate import (sum_checked, product, product_checked, bit_and, 
 from .kernels.sort import (sort, sort_limit, sort_to_indices, SortOptions, SortColumn, lexsort, lexsort_to_indices,  # noqa: F401
                            partition, Partitions)
 from .kernels.zip import zip  # noqa: F401,A004
+from .kernels.interleave import interleave, interleave_record_batch  # noqa: F401

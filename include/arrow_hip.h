@@ -423,6 +423,14 @@ AH_API ah_status ah_export_c_device_data(ah_context* ctx, const ah_array_view* v
 AH_API ah_status ah_import_c_device_data(ah_context* ctx, const struct ArrowDeviceArray* array,
                                          const struct ArrowSchema* schema, ah_array_view* out_view);
 
+/* ------------------------------------------------------------ interleave */
+/* arrow_select::interleave::interleave (arrow-select/src/interleave.rs:74): out[i] = arrays[array_index[i]][row_index[i]]
+ * — `take` across several arrays of one type (merge, repartition).  The reference's `&[(usize, usize)]` is two
+ * UInt32 device arrays here.  Fixed-width and Boolean layouts; a null buffer iff some input has nulls; an
+ * out-of-range pair is the reference's slice-indexing panic (AH_PANIC). */
+AH_API ah_status ah_interleave(ah_context* ctx, int32_t n_arrays, const ah_array_view* arrays,
+                               const ah_array_view* array_index, const ah_array_view* row_index, ah_array_out* out);
+
 /* ------------------------------------------------------------------- zip */
 /* arrow_select::zip::zip (arrow-select/src/zip.rs:99): out[i] = mask[i] ? truthy[i] : falsy[i]; a null mask row
  * selects `falsy`; either side may be a length-1 scalar (`Datum::get()`).  Fixed-width and Boolean layouts.

@@ -2210,6 +2210,52 @@ int32_t orc_zip(const orc_view* mask, const orc_view* t, int32_t ts, const orc_v
   return ORC_OK;
 }
 
+int32_t orc_interleave(int32_t n, const orc_view* arrays, const uint32_t* ai, const uint32_t* ri, int64_t m, orc_out* out) {
+  out_init(out);
+  if (n <= 0) return fail(ORC_INVALID_ARGUMENT, "interleave requires input of at least one array");
+  const int32_t t = arrays[0].type;
+  for (int i = 1; i < n; ++i)
+    if (arrays[i].type != t)
+      return fail(ORC_INVALID_ARGUMENT, "It is not possible to interleave arrays of different data types (%s and %s)",
+                  type_name(t), type_name(arrays[i].type));
+  const int w = type_width(t);
+  if (w < 0) return fail(ORC_NOT_YET_IMPLEMENTED, "interleave of %s", type_name(t));
+  out->type = t;
+  out->length = m;
+  if (m == 0) return ORC_OK;
+  bool any_nulls = false;
+  for (int i = 0; i < n; ++i) any_nulls |= arrays[i].validity && resolve_nulls(&arrays[i]) > 0;
+  const size_t vbytes = w ? (size_t)m * w : bitmap_bytes(m);
+  out->values = xalloc(vbytes);
+  out->values_bytes = (int64_t)vbytes;
+  uint8_t* nb = any_nulls ? (uint8_t*)xalloc(bitmap_bytes(m)) : nullptr;
+  int64_t valid_count = 0;
+  for (int64_t i = 0; i < m; ++i) {
+    if (ai[i] >= (uint32_t)n) {
+      free(nb);
+      orc_release(out);
+      return fail(ORC_PANIC, "index out of bounds: the len is %d but the index is %u", n, ai[i]);
+    }
+    const orc_view* s = &arrays[ai[i]];
+    if ((int64_t)ri[i] >= s->length) {
+      free(nb);
+      orc_release(out);
+      return fail(ORC_PANIC, "index out of bounds: the len is %lld but the index is %u", (long long)s->length, ri[i]);
+    }
+    if (w) memcpy((char*)out->values + (size_t)i * w, (const char*)s->values + (size_t)ri[i] * w, (size_t)w);
+    else if (get_bit((const uint8_t*)s->values, s->values_bit_offset + ri[i])) set_bit((uint8_t*)out->values, i);
+    const bool valid = !s->validity || get_bit(s->validity, s->validity_bit_offset + ri[i]);
+    if (nb && valid) set_bit(nb, i);
+    valid_count += valid;
+  }
+  if (nb) {
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(m);
+    out->null_count = m - valid_count;
+  }
+  return ORC_OK;
+}
+
 // concat for primitives / booleans (arrow-select/src/concat.rs:334-343, :495)
 int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out) {
   out_init(out);

@@ -128,6 +128,11 @@ int32_t orc_lexsort_to_indices(int32_t n_cols, const orc_view* cols, const int32
 int32_t orc_zip(const orc_view* mask, const orc_view* truthy, int32_t truthy_scalar, const orc_view* falsy,
                 int32_t falsy_scalar, orc_out* out);
 
+/* arrow_select::interleave::interleave (arrow-select/src/interleave.rs:74) for fixed-width / Boolean arrays;
+ * indices as two UInt32 arrays (array, row). */
+int32_t orc_interleave(int32_t n, const orc_view* arrays, const uint32_t* array_index, const uint32_t* row_index,
+                       int64_t n_indices, orc_out* out);
+
 /* format one f64/f32 the way ryu::Buffer::format does; returns the length */
 int32_t orc_format_f64(double v, char* buf /* >= 32 */);
 int32_t orc_format_f32(float v, char* buf /* >= 32 */);

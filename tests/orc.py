@@ -156,6 +156,7 @@ class Oracle:
         lib.orc_sort_to_indices.argtypes = [VP, C.c_int32, C.c_int32, C.c_int64, OP]
         lib.orc_lexsort_to_indices.argtypes = [C.c_int32, VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64, OP]
         lib.orc_zip.argtypes = [VP, VP, C.c_int32, VP, C.c_int32, OP]
+        lib.orc_interleave.argtypes = [C.c_int32, VP, C.c_void_p, C.c_void_p, C.c_int64, OP]
         lib.orc_selection_and_then.argtypes = [VP, VP, OP]
         lib.orc_selection_combine.argtypes = [C.c_int32, VP, VP, OP]
         lib.orc_find_nth_set_bit.restype = C.c_int64
@@ -312,6 +313,18 @@ class Oracle:
         if st:
             self._raise(st)
         return self._collect(out, A.UInt32)
+
+    def interleave(self, arrays, indices):
+        """indices: [(array, row)]"""
+        held = [_Held(a) for a in arrays]
+        views = (View * max(len(arrays), 1))(*[h.view for h in held])
+        ai = np.array([p[0] for p in indices], dtype=np.uint32)
+        ri = np.array([p[1] for p in indices], dtype=np.uint32)
+        out = Out()
+        st = self.lib.orc_interleave(len(arrays), views, ai.ctypes.data, ri.ctypes.data, len(indices), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, arrays[0].data_type)
 
     def zip(self, mask, truthy, falsy, truthy_scalar=False, falsy_scalar=False, bit_offset=0):
         hm, ht, hf = _Held(mask, bit_offset), _Held(truthy, bit_offset), _Held(falsy, bit_offset)
