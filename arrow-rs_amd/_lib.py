@@ -140,6 +140,7 @@ SIGNATURES = {
     "ah_copy_rows_into": (C.c_int32, [_P, _VIEW, C.c_int64, C.c_int64, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "ah_take": (C.c_int32, [_P, _VIEW, _VIEW, C.c_int32, _OUT]),
     "ah_arith_binary": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
+    "ah_bitwise_not": (C.c_int32, [_P, _VIEW, _OUT]),
     "ah_arith_neg": (C.c_int32, [_P, _VIEW, C.c_int32, _OUT]),
     "ah_compare": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
     "ah_boolean_binary": (C.c_int32, [_P, C.c_int32, _VIEW, _VIEW, _OUT]),

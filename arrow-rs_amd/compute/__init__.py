@@ -17,3 +17,6 @@ from .kernels.sort import (sort, sort_limit, sort_to_indices, SortOptions, SortC
                            partition, Partitions)
 from .kernels.zip import zip  # noqa: F401,A004
 from .kernels.interleave import interleave, interleave_record_batch  # noqa: F401
+from .kernels.bitwise import (bitwise_and, bitwise_or, bitwise_xor, bitwise_shift_left, bitwise_shift_right,  # noqa: F401
+                              bitwise_and_not, bitwise_not, bitwise_and_scalar, bitwise_or_scalar, bitwise_xor_scalar,
+                              bitwise_shift_left_scalar, bitwise_shift_right_scalar)

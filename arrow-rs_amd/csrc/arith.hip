@@ -19,7 +19,10 @@
 
 namespace {
 
-enum { OP_ADD = 0, OP_ADD_W, OP_SUB, OP_SUB_W, OP_MUL, OP_MUL_W, OP_DIV, OP_REM, OP_NEG, OP_NEG_W };
+enum { OP_ADD = 0, OP_ADD_W, OP_SUB, OP_SUB_W, OP_MUL, OP_MUL_W, OP_DIV, OP_REM, OP_NEG, OP_NEG_W,
+       // arrow_arith::bitwise (arrow-arith/src/bitwise.rs:42-135), integers only
+       OP_BAND, OP_BOR, OP_BXOR, OP_SHL, OP_SHR, OP_BANDNOT, OP_BNOT };
+constexpr bool op_is_unary(int op) { return op == OP_NEG || op == OP_NEG_W || op == OP_BNOT; }
 
 const char* op_sym(int op) {  // Display for Op (numeric.rs:203-213)
   switch (op) {
@@ -27,6 +30,13 @@ const char* op_sym(int op) {  // Display for Op (numeric.rs:203-213)
     case OP_SUB: case OP_SUB_W: return "-";
     case OP_MUL: case OP_MUL_W: return "*";
     case OP_DIV: return "/";
+    case OP_REM: return "%";
+    case OP_BAND: return "&";
+    case OP_BOR: return "|";
+    case OP_BXOR: return "^";
+    case OP_SHL: return "<<";
+    case OP_SHR: return ">>";
+    case OP_BANDNOT: return "&!";
     default: return "%";
   }
 }
@@ -63,6 +73,17 @@ __device__ __forceinline__ bool apply(T l, T r, T* out) {  // returns false on e
     } else if constexpr (OP == OP_NEG) {
       if (std::is_signed<T>::value && l == std::numeric_limits<T>::min()) return false;
       *out = (T)(0 - (U)l);
+      return true;
+    } else if constexpr (OP == OP_BAND) { *out = (T)(l & r); return true; }
+    else if constexpr (OP == OP_BOR) { *out = (T)(l | r); return true; }
+    else if constexpr (OP == OP_BXOR) { *out = (T)(l ^ r); return true; }
+    else if constexpr (OP == OP_BANDNOT) { *out = (T)(l & ~r); return true; }
+    else if constexpr (OP == OP_BNOT) { *out = (T)~l; return true; }
+    else if constexpr (OP == OP_SHL) {  // wrapping_shl(b as usize as u32): the count is taken modulo the bit width
+      *out = (T)((U)l << ((unsigned)(U)r & (sizeof(T) * 8 - 1)));
+      return true;
+    } else if constexpr (OP == OP_SHR) {  // wrapping_shr: arithmetic for signed types
+      *out = (T)(l >> ((unsigned)(U)r & (sizeof(T) * 8 - 1)));
       return true;
     } else {  // OP_NEG_W
       *out = (T)(0 - (U)l);
@@ -106,12 +127,12 @@ __global__ void __launch_bounds__(256) arith_kernel(ArithArgs a) {
         int64_t i = vi * V;
         if (i + V <= a.len) {
           if (!a.l_scalar) lv[u] = *(const VT*)(lp + i);
-          if (OP < OP_NEG && !a.r_scalar) rv[u] = *(const VT*)(rp + i);
+          if (!op_is_unary(OP) && !a.r_scalar) rv[u] = *(const VT*)(rp + i);
         } else {
 #pragma unroll
           for (int e = 0; e < V; ++e) {
             lv[u].e[e] = (!a.l_scalar && i + e < a.len) ? lp[i + e] : T{};
-            rv[u].e[e] = (OP < OP_NEG && !a.r_scalar && i + e < a.len) ? rp[i + e] : T{};
+            rv[u].e[e] = (!op_is_unary(OP) && !a.r_scalar && i + e < a.len) ? rp[i + e] : T{};
           }
         }
       }
@@ -180,7 +201,20 @@ void launch_arith(ah_context* ctx, int op, const ArithArgs& a, bool aligned) {
     case OP_DIV: launch_arith_op<T, OP_DIV, !F>(ctx, a, aligned); break;
     case OP_REM: launch_arith_op<T, OP_REM, !F>(ctx, a, aligned); break;
     case OP_NEG: launch_arith_op<T, OP_NEG, !F>(ctx, a, aligned); break;
-    default: launch_arith_op<T, OP_NEG_W, false>(ctx, a, aligned); break;
+    case OP_NEG_W: launch_arith_op<T, OP_NEG_W, false>(ctx, a, aligned); break;
+    default:
+      if constexpr (!F) {
+        switch (op) {
+          case OP_BAND: launch_arith_op<T, OP_BAND, false>(ctx, a, aligned); break;
+          case OP_BOR: launch_arith_op<T, OP_BOR, false>(ctx, a, aligned); break;
+          case OP_BXOR: launch_arith_op<T, OP_BXOR, false>(ctx, a, aligned); break;
+          case OP_SHL: launch_arith_op<T, OP_SHL, false>(ctx, a, aligned); break;
+          case OP_SHR: launch_arith_op<T, OP_SHR, false>(ctx, a, aligned); break;
+          case OP_BANDNOT: launch_arith_op<T, OP_BANDNOT, false>(ctx, a, aligned); break;
+          default: launch_arith_op<T, OP_BNOT, false>(ctx, a, aligned); break;
+        }
+      }
+      break;
   }
 }
 
@@ -237,10 +271,12 @@ extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_a
   if (!ctx || !lhs || !rhs || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
-  if (op < AH_ADD || op > AH_REM) return ah_fail(ctx, AH_INVALID_ARGUMENT, "unknown arithmetic op %d", op);
+  if (op < AH_ADD || op > AH_BIT_AND_NOT) return ah_fail(ctx, AH_INVALID_ARGUMENT, "unknown arithmetic op %d", op);
+  const bool bitwise = op >= AH_BIT_AND;
+  if (bitwise) op = OP_BAND + (op - AH_BIT_AND);  // public 8..13 -> internal OP_BAND..OP_BANDNOT
   const ah_type t = lhs->type;
-  // arithmetic_op (numeric.rs:225-275): both sides must be the same numeric type
-  if (lhs->type != rhs->type || !(ah_type_is_integer(t) || ah_type_is_float(t)))
+  // arithmetic_op (numeric.rs:225-275): both sides must be the same numeric type; bitwise.rs: integers
+  if (lhs->type != rhs->type || !(ah_type_is_integer(t) || (ah_type_is_float(t) && !bitwise)))
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "Invalid arithmetic operation: %s %s %s",
                    ah_type_name(lhs->type), op_sym(op), ah_type_name(rhs->type));
   const bool checked = op_checked_for(t, op);
@@ -377,6 +413,8 @@ extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_a
   return AH_OK;
 }
 
+static ah_status arith_unary(ah_context* ctx, const ah_array_view* v, int op, ah_array_out* out);
+
 extern "C" ah_status ah_arith_neg(ah_context* ctx, const ah_array_view* v, int32_t wrapping,
                                   ah_array_out* out) {
   if (!ctx || !v || !out) return AH_INVALID_ARGUMENT;
@@ -388,7 +426,21 @@ extern "C" ah_status ah_arith_neg(ah_context* ctx, const ah_array_view* v, int32
   bool ok = ah_type_is_float(t) || ah_type_is_signed(t) || (wrapping && ah_type_is_integer(t));
   if (!ok)
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "Invalid arithmetic operation: !%s", ah_type_name(t));
-  const int op = wrapping ? OP_NEG_W : OP_NEG;
+  return arith_unary(ctx, v, wrapping ? OP_NEG_W : OP_NEG, out);
+}
+
+// bitwise_not (arrow-arith/src/bitwise.rs:113-120): `unary`, nulls cloned
+extern "C" ah_status ah_bitwise_not(ah_context* ctx, const ah_array_view* v, ah_array_out* out) {
+  if (!ctx || !v || !out) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  hipSetDevice(ctx->device);
+  if (!ah_type_is_integer(v->type))
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "Invalid arithmetic operation: !%s", ah_type_name(v->type));
+  return arith_unary(ctx, v, OP_BNOT, out);
+}
+
+static ah_status arith_unary(ah_context* ctx, const ah_array_view* v, int op, ah_array_out* out) {
+  const ah_type t = v->type;
   const bool checked = op_checked_for(t, op);
   const int w = ah_type_width(t);
   const int64_t len = v->length;

@@ -35,13 +35,22 @@ constexpr int RS_ITER = RS_ITER_N;
 constexpr int RS_TILE = RS_BLOCK * RS_ITER;  // 4096 pairs per tile
 constexpr int RS_MAX_BLOCKS = 2048;
 
-// exclusive scan of one int per thread across the 256-thread workgroup
-__device__ __forceinline__ int block_excl_scan_256(int v, int* total, int* sm) {
+// exclusive scan of one counter per thread across the 256-thread workgroup (unsigned: totals reach 2^32 - 1 pairs)
+__device__ __forceinline__ unsigned wave_scan_incl_u(unsigned v) {
+  const unsigned lane = __lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = (unsigned)__shfl_up((int)v, o, 64);
+    if (lane >= (unsigned)o) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ unsigned block_excl_scan_256(unsigned v, unsigned* total, unsigned* sm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int incl = wave_scan_incl(v);
+  const unsigned incl = wave_scan_incl_u(v);
   if (lane == 63) sm[wave] = incl;
   __syncthreads();
-  int base = 0, tot = 0;
+  unsigned base = 0, tot = 0;
 #pragma unroll
   for (int w = 0; w < RS_BLOCK / 64; ++w) {
     if (w < wave) base += sm[w];
@@ -143,20 +152,20 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist_kernel(const KT* keys, int64
 // one workgroup per digit: exclusive scan of that digit's per-workgroup counts in place + the digit total.
 // (A single workgroup scanning all 256 * nblocks counters took 0.77 ms per pass.)
 __global__ __launch_bounds__(RS_BLOCK) void rs_scan_kernel(unsigned int* h, int nblocks, unsigned int* digit_total) {
-  __shared__ int sm[RS_BLOCK / 64];
+  __shared__ unsigned sm[RS_BLOCK / 64];
   unsigned int* row = h + (size_t)blockIdx.x * nblocks;
   const int per = (nblocks + RS_BLOCK - 1) / RS_BLOCK;
   const int b = threadIdx.x * per, e = min(nblocks, b + per);
   unsigned int s = 0;
   for (int i = b; i < e; ++i) s += row[i];
-  int total;
-  unsigned int acc = (unsigned int)block_excl_scan_256((int)s, &total, sm);
+  unsigned total;
+  unsigned int acc = block_excl_scan_256(s, &total, sm);
   for (int i = b; i < e; ++i) {
     const unsigned int t = row[i];
     row[i] = acc;
     acc += t;
   }
-  if (threadIdx.x == 0) digit_total[blockIdx.x] = (unsigned int)total;
+  if (threadIdx.x == 0) digit_total[blockIdx.x] = total;
 }
 
 template <typename KT>
@@ -171,12 +180,12 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const KT* __restri
   __shared__ unsigned int tpre[256];                 // exclusive prefix over digits inside the tile
   __shared__ unsigned int tcnt[256];
   __shared__ unsigned int running[256];              // next global output slot of each digit for this workgroup
-  __shared__ int scan_sm[RS_BLOCK / 64];
+  __shared__ unsigned scan_sm[RS_BLOCK / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {  // first output slot of digit d for this workgroup = (pairs with smaller digits) + (digit d in earlier workgroups)
-    int total;
-    const int dbase = block_excl_scan_256((int)digit_total[threadIdx.x], &total, scan_sm);
-    running[threadIdx.x] = (unsigned)dbase + offsets[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
+    unsigned total;
+    const unsigned dbase = block_excl_scan_256(digit_total[threadIdx.x], &total, scan_sm);
+    running[threadIdx.x] = dbase + offsets[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
   }
   const int64_t first_tile = (int64_t)blockIdx.x * tiles_per_block;
   for (int64_t t = 0; t < tiles_per_block; ++t) {
@@ -230,8 +239,8 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_scatter_kernel(const KT* __restri
         tot += c;
       }
       tcnt[d] = tot;
-      int total;
-      tpre[d] = (unsigned)block_excl_scan_256((int)tot, &total, scan_sm);
+      unsigned total;
+      tpre[d] = block_excl_scan_256(tot, &total, scan_sm);
     }
     __syncthreads();
     // phase C: stage the tile digit-sorted in LDS

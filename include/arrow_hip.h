@@ -202,7 +202,11 @@ AH_API ah_status ah_take(ah_context* ctx, const ah_array_view* values,
 typedef int32_t ah_arith_op;
 enum {
   AH_ADD = 0, AH_ADD_WRAPPING = 1, AH_SUB = 2, AH_SUB_WRAPPING = 3,
-  AH_MUL = 4, AH_MUL_WRAPPING = 5, AH_DIV = 6, AH_REM = 7
+  AH_MUL = 4, AH_MUL_WRAPPING = 5, AH_DIV = 6, AH_REM = 7,
+  /* arrow_arith::bitwise::{bitwise_and, bitwise_or, bitwise_xor, bitwise_shift_left, bitwise_shift_right,
+   * bitwise_and_not} and their `_scalar` forms (arrow-arith/src/bitwise.rs:42-205); integer types only; shift
+   * counts are taken modulo the bit width (`wrapping_shl` / `wrapping_shr`) */
+  AH_BIT_AND = 8, AH_BIT_OR = 9, AH_BIT_XOR = 10, AH_BIT_SHIFT_LEFT = 11, AH_BIT_SHIFT_RIGHT = 12, AH_BIT_AND_NOT = 13
 };
 /* arrow_arith::numeric::{add,add_wrapping,sub,sub_wrapping,mul,mul_wrapping,div,rem}
  * (arrow-arith/src/numeric.rs:36-81).  A Datum is (array, is_scalar)
@@ -211,6 +215,8 @@ AH_API ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op,
                                  const ah_array_view* lhs, int32_t lhs_is_scalar,
                                  const ah_array_view* rhs, int32_t rhs_is_scalar,
                                  ah_array_out* out);
+/* bitwise_not (arrow-arith/src/bitwise.rs:113) */
+AH_API ah_status ah_bitwise_not(ah_context* ctx, const ah_array_view* values, ah_array_out* out);
 /* neg / neg_wrapping (numeric.rs:103,181) */
 AH_API ah_status ah_arith_neg(ah_context* ctx, const ah_array_view* values, int32_t wrapping,
                               ah_array_out* out);

@@ -1578,6 +1578,59 @@ template <typename T> int32_t cast_bool_to_num(const orc_view* in, int32_t to, o
   return ORC_OK;
 }
 
+// arrow_arith::bitwise (bitwise.rs:42-135): `binary` (all slots, nulls = presence-based union) / `unary` (nulls cloned)
+template <typename T>
+int32_t bitwise_typed(int op, const orc_view* l, bool l_s, const orc_view* r, bool r_s, orc_out* out) {
+  using U = typename std::make_unsigned<T>::type;
+  auto f = [op](T a, T b) -> T {
+    const unsigned sh = (unsigned)(U)b & (sizeof(T) * 8 - 1);  // wrapping_shl/shr(b as usize as u32)
+    switch (op) {
+      case 8: return (T)(a & b);
+      case 9: return (T)(a | b);
+      case 10: return (T)(a ^ b);
+      case 11: return (T)((U)a << sh);
+      case 12: return (T)(a >> sh);
+      case 13: return (T)(a & ~b);
+      default: return (T)~a;
+    }
+  };
+  out->type = l->type;
+  const T* lv = (const T*)l->values;
+  const T* rv = (const T*)r->values;
+  if (op == 14 || l_s != r_s) {  // unary / `_scalar` forms
+    const orc_view* arr = (op == 14 || !l_s) ? l : r;
+    const int64_t len = arr->length;
+    out->length = len;
+    T* ov = (T*)xalloc((size_t)std::max<int64_t>(len, 1) * sizeof(T));
+    out->values = ov;
+    out->values_bytes = std::max<int64_t>(len, 1) * (int64_t)sizeof(T);
+    for (int64_t i = 0; i < len; ++i) ov[i] = f(l_s ? lv[0] : lv[i], (op == 14) ? T{} : (r_s ? rv[0] : rv[i]));
+    uint8_t* nb = nulls_clone(arr, len);
+    if (nb) {
+      out->validity = nb;
+      out->validity_bytes = (int64_t)bitmap_bytes(len);
+      out->null_count = len - count_set_bits(nb, 0, len);
+    }
+    return ORC_OK;
+  }
+  if (l->length != r->length) return fail(ORC_COMPUTE_ERROR, "Cannot perform binary operation on arrays of different length");
+  const int64_t len = l->length;
+  out->length = len;
+  if (len == 0) return ORC_OK;
+  T* ov = (T*)xalloc((size_t)len * sizeof(T));
+  out->values = ov;
+  out->values_bytes = len * (int64_t)sizeof(T);
+  for (int64_t i = 0; i < len; ++i) ov[i] = f(lv[i], rv[i]);
+  int64_t nc = 0;
+  uint8_t* nb = nulls_union(l, r, len, &nc);
+  if (nb) {
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(len);
+    out->null_count = nc;
+  }
+  return ORC_OK;
+}
+
 }  // namespace
 
 // =================================================================== exports
@@ -2254,6 +2307,23 @@ int32_t orc_interleave(int32_t n, const orc_view* arrays, const uint32_t* ai, co
     out->null_count = m - valid_count;
   }
   return ORC_OK;
+}
+
+int32_t orc_bitwise(int32_t op, const orc_view* l, int32_t l_s, const orc_view* r, int32_t r_s, orc_out* out) {
+  out_init(out);
+  if (op != 14 && l->type != r->type)
+    return fail(ORC_INVALID_ARGUMENT, "Invalid arithmetic operation: %s & %s", type_name(l->type), type_name(r->type));
+  switch (l->type) {
+    case ORC_INT8: return bitwise_typed<int8_t>(op, l, l_s, r, r_s, out);
+    case ORC_INT16: return bitwise_typed<int16_t>(op, l, l_s, r, r_s, out);
+    case ORC_INT32: return bitwise_typed<int32_t>(op, l, l_s, r, r_s, out);
+    case ORC_INT64: return bitwise_typed<int64_t>(op, l, l_s, r, r_s, out);
+    case ORC_UINT8: return bitwise_typed<uint8_t>(op, l, l_s, r, r_s, out);
+    case ORC_UINT16: return bitwise_typed<uint16_t>(op, l, l_s, r, r_s, out);
+    case ORC_UINT32: return bitwise_typed<uint32_t>(op, l, l_s, r, r_s, out);
+    case ORC_UINT64: return bitwise_typed<uint64_t>(op, l, l_s, r, r_s, out);
+  }
+  return fail(ORC_INVALID_ARGUMENT, "Invalid arithmetic operation: bitwise on %s", type_name(l->type));
 }
 
 // concat for primitives / booleans (arrow-select/src/concat.rs:334-343, :495)

@@ -133,6 +133,11 @@ int32_t orc_zip(const orc_view* mask, const orc_view* truthy, int32_t truthy_sca
 int32_t orc_interleave(int32_t n, const orc_view* arrays, const uint32_t* array_index, const uint32_t* row_index,
                        int64_t n_indices, orc_out* out);
 
+/* arrow_arith::bitwise (arrow-arith/src/bitwise.rs:42-205): op 8 and, 9 or, 10 xor, 11 shift_left, 12 shift_right,
+ * 13 and_not (numbering as AH_BIT_*), 14 not (unary: rhs ignored); integers only; `binary` / `unary` null rules. */
+int32_t orc_bitwise(int32_t op, const orc_view* lhs, int32_t lhs_scalar, const orc_view* rhs, int32_t rhs_scalar,
+                    orc_out* out);
+
 /* format one f64/f32 the way ryu::Buffer::format does; returns the length */
 int32_t orc_format_f64(double v, char* buf /* >= 32 */);
 int32_t orc_format_f32(float v, char* buf /* >= 32 */);

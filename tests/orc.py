@@ -156,6 +156,7 @@ class Oracle:
         lib.orc_sort_to_indices.argtypes = [VP, C.c_int32, C.c_int32, C.c_int64, OP]
         lib.orc_lexsort_to_indices.argtypes = [C.c_int32, VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64, OP]
         lib.orc_zip.argtypes = [VP, VP, C.c_int32, VP, C.c_int32, OP]
+        lib.orc_bitwise.argtypes = [C.c_int32, VP, C.c_int32, VP, C.c_int32, OP]
         lib.orc_interleave.argtypes = [C.c_int32, VP, C.c_void_p, C.c_void_p, C.c_int64, OP]
         lib.orc_selection_and_then.argtypes = [VP, VP, OP]
         lib.orc_selection_combine.argtypes = [C.c_int32, VP, VP, OP]
@@ -313,6 +314,16 @@ class Oracle:
         if st:
             self._raise(st)
         return self._collect(out, A.UInt32)
+
+    def bitwise(self, op, lhs, rhs=None, l_scalar=False, r_scalar=False, bit_offset=0):
+        """op: 8 and, 9 or, 10 xor, 11 shl, 12 shr, 13 and_not, 14 not"""
+        rhs = lhs if rhs is None else rhs
+        hl, hr = _Held(lhs, bit_offset), _Held(rhs, bit_offset)
+        out = Out()
+        st = self.lib.orc_bitwise(op, C.byref(hl.view), int(l_scalar), C.byref(hr.view), int(r_scalar), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, lhs.data_type)
 
     def interleave(self, arrays, indices):
         """indices: [(array, row)]"""
