@@ -328,6 +328,29 @@ inline std::optional<bool> max_boolean(const ArrayRef& a) { return aggregate<boo
 inline std::optional<bool> bool_and(const ArrayRef& a) { return min_boolean(a); }
 inline std::optional<bool> bool_or(const ArrayRef& a) { return max_boolean(a); }
 
+// ---- bitwise (arrow-arith/src/bitwise.rs)
+inline ArrayRef bitwise_and(const Datum& l, const Datum& r) { return arith((ah_arith_op)AH_BIT_AND, l, r); }
+inline ArrayRef bitwise_or(const Datum& l, const Datum& r) { return arith((ah_arith_op)AH_BIT_OR, l, r); }
+inline ArrayRef bitwise_xor(const Datum& l, const Datum& r) { return arith((ah_arith_op)AH_BIT_XOR, l, r); }
+inline ArrayRef bitwise_shift_left(const Datum& l, const Datum& r) { return arith((ah_arith_op)AH_BIT_SHIFT_LEFT, l, r); }
+inline ArrayRef bitwise_shift_right(const Datum& l, const Datum& r) { return arith((ah_arith_op)AH_BIT_SHIFT_RIGHT, l, r); }
+inline ArrayRef bitwise_and_not(const Datum& l, const Datum& r) { return arith((ah_arith_op)AH_BIT_AND_NOT, l, r); }
+inline ArrayRef bitwise_not(const ArrayRef& a) {
+  ah_array_out out;
+  a->context()->check(ah_bitwise_not(a->context()->handle(), &a->view(), &out));
+  return wrap(a, out);
+}
+
+// ---- interleave (arrow-select/src/interleave.rs:74); indices = (array, row) pairs as two UInt32 device arrays
+inline ArrayRef interleave(const std::vector<ArrayRef>& values, const ArrayRef& array_index, const ArrayRef& row_index) {
+  std::vector<ah_array_view> views;
+  for (auto& v : values) views.push_back(v->view());
+  ah_array_out out;
+  array_index->context()->check(ah_interleave(array_index->context()->handle(), (int32_t)views.size(), views.data(),
+                                              &array_index->view(), &row_index->view(), &out));
+  return std::make_shared<Array>(array_index->context(), out);
+}
+
 // ---- zip (arrow-select/src/zip.rs:99)
 inline ArrayRef zip(const ArrayRef& mask, const Datum& truthy, const Datum& falsy) {
   ah_array_out out;
@@ -347,12 +370,60 @@ inline ArrayRef sort_to_indices(const ArrayRef& values, SortOptions options = {}
                                               options.nulls_first, limit, &out));
   return wrap(values, out);
 }
+struct SortColumn {  // sort.rs:870
+  ArrayRef values;
+  SortOptions options;
+};
+inline ArrayRef lexsort_to_indices(const std::vector<SortColumn>& columns, int64_t limit = -1) {
+  if (columns.empty()) throw ArrowError(AH_INVALID_ARGUMENT, "Sort requires at least one column");
+  std::vector<ah_array_view> views;
+  std::vector<int32_t> desc, nf;
+  for (auto& c : columns) {
+    views.push_back(c.values->view());
+    desc.push_back(c.options.descending);
+    nf.push_back(c.options.nulls_first);
+  }
+  ah_array_out out;
+  auto ctx = columns[0].values->context();
+  ctx->check(ah_lexsort_to_indices(ctx->handle(), (int32_t)views.size(), views.data(), desc.data(), nf.data(), limit, &out));
+  return std::make_shared<Array>(ctx, out);
+}
 inline ArrayRef sort(const ArrayRef& values, SortOptions options = {}) { return take(values, sort_to_indices(values, options)); }
 inline ArrayRef sort_limit(const ArrayRef& values, SortOptions options, int64_t limit) {
   return take(values, sort_to_indices(values, options, limit));
 }
 
 }  // namespace compute
+
+// parquet RowSelection on device bitmaps (parquet/src/arrow/arrow_reader/selection/mod.rs): masks are Boolean arrays
+// without nulls
+namespace selection {
+inline ArrayRef and_then(const ArrayRef& mask, const ArrayRef& other) {
+  ah_array_out out;
+  mask->context()->check(ah_selection_and_then(mask->context()->handle(), &mask->view(), &other->view(), &out));
+  return compute::wrap(mask, out, {mask});
+}
+inline ArrayRef intersection(const ArrayRef& l, const ArrayRef& r) {
+  ah_array_out out;
+  l->context()->check(ah_selection_combine(l->context()->handle(), 0, &l->view(), &r->view(), &out));
+  return compute::wrap(l, out);
+}
+inline ArrayRef union_(const ArrayRef& l, const ArrayRef& r) {
+  ah_array_out out;
+  l->context()->check(ah_selection_combine(l->context()->handle(), 1, &l->view(), &r->view(), &out));
+  return compute::wrap(l, out);
+}
+inline ArrayRef boundaries(const ArrayRef& mask) {  // run starts (Int64): the RLE form
+  ah_array_out out;
+  mask->context()->check(ah_selection_boundaries(mask->context()->handle(), &mask->view(), &out));
+  return compute::wrap(mask, out);
+}
+inline int64_t find_nth_set_bit(const ArrayRef& mask, int64_t start, int64_t n) {
+  int64_t pos = 0;
+  mask->context()->check(ah_selection_find_nth_set_bit(mask->context()->handle(), &mask->view(), start, n, &pos));
+  return pos;
+}
+}  // namespace selection
 
 // Arrow C Data Interface (arrow-array/src/ffi.rs:231-254).  `from_ffi` copies a host-resident
 // producer array into HBM (the producer keeps ownership of its structs); `to_ffi` fills structs

@@ -192,5 +192,28 @@ int main() {
     assert(compute::sort_to_indices(sa, dnf, 3)->len() == 3);
   }
 
+  // bitwise, lexsort, interleave, row selection through the mirror
+  {
+    auto bx = upload<uint64_t>(ctx, AH_UINT64, {1, 2, 4, 8}, nullptr, keep);
+    auto by = upload<uint64_t>(ctx, AH_UINT64, {5, 10, 15, 20}, nullptr, keep);
+    assert((download<uint64_t>(compute::bitwise_shift_left(bx, by)) == std::vector<uint64_t>{32, 2048, 131072, 8388608}));
+    assert((download<uint64_t>(compute::bitwise_and_not(by, bx)) == std::vector<uint64_t>{4, 8, 11, 20}));
+    auto k1 = upload<int64_t>(ctx, AH_INT64, {0, 2, -1, 0}, nullptr, keep);   // sort.rs:4109 test_lex_sort_mixed_types
+    auto k2 = upload<uint32_t>(ctx, AH_UINT32, {101, 8, 7, 102}, nullptr, keep);
+    auto li = compute::lexsort_to_indices({{k1, {}}, {k2, {}}});
+    assert((download<uint32_t>(li) == std::vector<uint32_t>{2, 0, 3, 1}));
+    auto ia = upload<int32_t>(ctx, AH_INT32, {1, 2, 3, 4}, nullptr, keep);   // interleave.rs:941
+    auto ib = upload<int32_t>(ctx, AH_INT32, {5, 6, 7}, nullptr, keep);
+    auto ic = upload<int32_t>(ctx, AH_INT32, {8, 9, 10}, nullptr, keep);
+    auto ai = upload<uint32_t>(ctx, AH_UINT32, {0, 0, 2, 2, 1}, nullptr, keep);
+    auto ri = upload<uint32_t>(ctx, AH_UINT32, {3, 3, 2, 0, 1}, nullptr, keep);
+    assert((download<int32_t>(compute::interleave({ia, ib, ic}, ai, ri)) == std::vector<int32_t>{4, 4, 10, 8, 6}));
+    auto outer = upload_bool(ctx, {false, true, true, false, true, false, true}, keep);  // algebra.rs:680
+    auto inner = upload_bool(ctx, {true, false, true, false}, keep);
+    auto sel = selection::and_then(outer, inner);
+    assert(sel->len() == 7 && selection::find_nth_set_bit(sel, 0, 2) == 5);
+    assert((download<int64_t>(selection::boundaries(sel)) == std::vector<int64_t>{1, 2, 4, 5}));
+  }
+
   return 0;
 }
