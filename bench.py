@@ -59,7 +59,7 @@ def parse():
     p.add_argument("--selectivity", type=float, default=0.1)
     p.add_argument("--valid", type=float, default=0.9)
     p.add_argument("--workload", default="filter_take",
-                   choices=["filter_take", "arith", "cmp", "cast", "cast_string", "coalesce", "string_filter_take", "aggregate", "sort"])
+                   choices=["filter_take", "arith", "cmp", "cast", "cast_string", "coalesce", "string_filter_take", "aggregate", "sort", "record_batch"])
     p.add_argument("--batch-rows", type=int, default=1 << 24, help="coalesce workload: rows per pushed batch")
     p.add_argument("--reassemble", default="auto", choices=["auto", "none", "allgatherv"])
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -340,6 +340,25 @@ def main():
         step = lambda _r: (G.sum(col), G.min(col), G.max(col))
         kernels = ["aggregate"]
         dominant = "aggregate"
+    elif wl == "record_batch":
+        # BASELINE configs[4] shape: RecordBatch {Int64, Float64, each with validity} + one mask per shard;
+        # filter_record_batch (one count pass, two scatters), then at N>1 ONE IPC-framed exchange of both columns
+        cola = gen_i64_column(A, ctx, n, 42, args.valid, row0)
+        colb = gen_f64_column(A, ctx, n, 52, args.valid, row0)
+        pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
+        rb = A.RecordBatch(["a", "b"], [cola, colb], n)
+        state = {}
+
+        def step(with_reassembly):
+            f = K.filter_record_batch(rb, pred)
+            state["k"] = f.num_rows()
+            if with_reassembly:
+                parts = comm.all_gather_batches(f)
+                state["gk"] = sum(p.num_rows() for p in parts)
+            return f
+
+        kernels = ["filter_count", "filter_scatter"]
+        dominant = "filter_scatter"
     elif wl == "sort":
         # the producer of take's indices: sort_to_indices of the full-range Int64 column (8 radix passes)
         n = min(n, 1 << 29) if args.rows == 1_000_000_000 else n
@@ -464,6 +483,9 @@ def main():
                 alg_bytes = 2 * (n * 8 + (n + 7) // 8) + (n + 7) // 8 + 2 * (k * 8 + (k + 7) // 8)
                 dom_avg_ms = sum(prof[kk][0] for kk in kernels) / max(args.steps, 1)  # all launches of one step
                 dom_n = args.steps
+            elif wl == "record_batch":
+                k = state["k"]  # per scatter launch: one column + its validity + the mask in, K values + K bits out
+                alg_bytes = n * 8 + 2 * ((n + 7) // 8) + k * 8 + (k + 7) // 8
             elif wl == "sort":
                 m_valid = n - col.null_count()
                 alg_bytes = m_valid * 32  # per radix pass: keys read twice, (key, index) pairs written once
@@ -480,13 +502,15 @@ def main():
                         "cmp": "configs[2]: lt Float64<Float64 with NullBuffers",
                         "cast": "configs[3]: cast Int64->Float64",
                         "cast_string": "configs[3]: cast Float64->LargeUtf8",
+                        "record_batch": "configs[4] shape: filter_record_batch on {Int64, Float64} with NullBuffers"
+                                        + (" + IPC-framed all_gather_batches" if reassemble else ""),
                         "sort": "arrow_ord sort_to_indices of a full-range Int64 column with NullBuffer (stable LSD radix)",
                         "aggregate": "SURVEY 8f-4: sum + min + max of an Int64 column with NullBuffer",
                         "string_filter_take": "SURVEY 8f-3: filter + take on a LargeUtf8 column (cast output)",
                         "coalesce": f"SURVEY 8f-1: BatchCoalescer.push_batch_with_filter, Int64+Float64, "
                                     f"{args.batch_rows}-row batches"}[wl] + f", {n} rows per GPU"
             metric = f"{wl}_Mrows_per_s"
-            dtype = "int64" if wl in ("aggregate", "sort") else "f64"
+            dtype = "int64" if wl in ("aggregate", "sort") else "int64+f64" if wl == "record_batch" else "f64"
         if wl == "filter_take" and tk_avg > dom_avg_ms:
             # the time-dominant kernel of the step is the random gather: report IT as `roofline`
             dominant, dom_avg_ms, dom_n, alg_bytes = "take_gather", tk_avg, tk_n, take_bytes
