@@ -118,6 +118,9 @@ SIGNATURES = {
     "ah_context_destroy": (None, [_P]),
     "ah_context_set_allocator": (None, [_P, ALLOC_FN, FREE_FN, _P]),
     "ah_context_set_stream": (None, [_P, _P]),
+    "ah_context_set_deferred": (None, [_P, C.c_int32]),
+    "ah_context_deferred": (C.c_int32, [_P]),
+    "ah_array_resolve": (C.c_int32, [_P, _P]),
     "ah_context_stream": (_P, [_P]),
     "ah_last_error": (C.c_char_p, [_P]),
     "ah_array_release": (None, [_P, _OUT]),

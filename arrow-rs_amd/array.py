@@ -212,6 +212,33 @@ class Context:
     def synchronize(self):
         self.check(self.lib.ah_synchronize(self.handle))
 
+    # opt-in asynchronous mode (ah_context_set_deferred, include/arrow_hip.h): infallible fixed-shape kernels
+    # only enqueue; their results carry an unknown null count that Array.null_count() resolves lazily
+    def set_deferred(self, on=True):
+        self.lib.ah_context_set_deferred(self.handle, 1 if on else 0)
+
+    @property
+    def deferred(self):
+        return bool(self.lib.ah_context_deferred(self.handle))
+
+    def deferred_mode(self):
+        """``with ctx.deferred_mode(): ...`` — deferred inside, synchronised and back to synchronous after."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self):
+                self.prev = ctx.deferred
+                ctx.set_deferred(True)
+                return ctx
+
+            def __exit__(self, *exc):
+                ctx.set_deferred(self.prev)
+                if not self.prev:
+                    ctx.synchronize()
+                return False
+
+        return _Scope()
+
     # raw buffers
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
@@ -474,6 +501,14 @@ class Array:
         return self.length == 0
 
     def null_count(self):
+        if self._null_count < 0:  # result of a deferred call: counted on first use (synchronises the stream)
+            if self.validity is None:
+                self._null_count = 0
+            else:
+                cnt = C.c_int64()
+                self.ctx.check(self.ctx.lib.ah_count_set_bits(self.ctx.handle, self.validity.ptr,
+                                                              self.validity_bit_offset, self.length, C.byref(cnt)))
+                self._null_count = self.length - cnt.value
         return self._null_count
 
     def nulls(self):

@@ -336,7 +336,7 @@ extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_a
     }
     hipMemsetAsync(ov, 0, vbytes, ctx->stream);
     hipMemsetAsync(ob, 0, bbytes, ctx->stream);
-    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AH_HIP(ctx, ah_end_of_call_sync(ctx));
     out->length = len;
     out->values = ov;
     out->values_bytes = (int64_t)vbytes;
@@ -350,7 +350,7 @@ extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_a
     ah_status st = ah_out_alloc(ctx, bbytes, &ob);
     if (st == AH_OK)
       st = ah_bitmap_op(ctx, (va.words && vb.words) ? BM_AND : BM_COPY, va.words ? va : vb, vb,
-                        BitView{nullptr, 0}, len, (unsigned long long*)ob, &set_bits);
+                        BitView{nullptr, 0}, len, (unsigned long long*)ob, checked ? &set_bits : AH_COUNT(ctx, &set_bits));
     if (st != AH_OK) {
       free_out_bufs(ctx, ov, vbytes, ob, bbytes);
       return st;
@@ -385,7 +385,8 @@ extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_a
   hipError_t e = hipGetLastError();
   if (st == AH_OK && e == hipSuccess && checked)
     e = hipMemcpyAsync(ctx->pinned, first_err, 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  // checked ops report device-side errors, so they stay synchronous even in deferred mode
+  if (e == hipSuccess) e = checked ? hipStreamSynchronize(ctx->stream) : ah_end_of_call_sync(ctx);
   ah_pool_free(ctx, first_err);
   if (st != AH_OK || e != hipSuccess) {
     free_out_bufs(ctx, ov, vbytes, ob, bbytes);
@@ -408,7 +409,7 @@ extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_a
   if (want_valid) {
     out->validity = (uint8_t*)ob;
     out->validity_bytes = (int64_t)bbytes;
-    out->null_count = len - set_bits;
+    out->null_count = checked ? len - set_bits : ah_nulls(ctx, len, set_bits);
   }
   return AH_OK;
 }
@@ -456,7 +457,8 @@ static ah_status arith_unary(ah_context* ctx, const ah_array_view* v, int op, ah
     ah_status st = ah_out_alloc(ctx, bbytes, &ob);
     if (st == AH_OK)
       st = ah_bitmap_op(ctx, BM_COPY, make_bitview(v->validity, v->validity_bit_offset),
-                        BitView{nullptr, 0}, BitView{nullptr, 0}, len, (unsigned long long*)ob, &set_bits);
+                        BitView{nullptr, 0}, BitView{nullptr, 0}, len, (unsigned long long*)ob,
+                        checked ? &set_bits : AH_COUNT(ctx, &set_bits));
     if (st != AH_OK) {
       free_out_bufs(ctx, ov, vbytes, ob, bbytes);
       return st;
@@ -483,7 +485,7 @@ static ah_status arith_unary(ah_context* ctx, const ah_array_view* v, int op, ah
   hipError_t e = hipGetLastError();
   if (st == AH_OK && e == hipSuccess && checked)
     e = hipMemcpyAsync(ctx->pinned, first_err, 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = checked ? hipStreamSynchronize(ctx->stream) : ah_end_of_call_sync(ctx);
   ah_pool_free(ctx, first_err);
   if (st != AH_OK || e != hipSuccess) {
     free_out_bufs(ctx, ov, vbytes, ob, bbytes);
@@ -503,7 +505,7 @@ static ah_status arith_unary(ah_context* ctx, const ah_array_view* v, int op, ah
   if (v->validity) {
     out->validity = (uint8_t*)ob;
     out->validity_bytes = (int64_t)bbytes;
-    out->null_count = len - set_bits;
+    out->null_count = checked ? len - set_bits : ah_nulls(ctx, len, set_bits);
   }
   return AH_OK;
 }

@@ -45,19 +45,19 @@ extern "C" ah_status ah_boolean_binary(ah_context* ctx, ah_boolean_op op, const 
       if (op == AH_BOOL_AND_KLEENE || op == AH_BOOL_OR_KLEENE) {
         const bool is_and = op == AH_BOOL_AND_KLEENE;
         if (l->validity && r->validity)
-          st = ah_bitmap_op(ctx, is_and ? BM_KLEENE_AND_NULLS : BM_KLEENE_OR_NULLS, ln, lv, rn, len, nb, &set, rv);
+          st = ah_bitmap_op(ctx, is_and ? BM_KLEENE_AND_NULLS : BM_KLEENE_OR_NULLS, ln, lv, rn, len, nb, AH_COUNT(ctx, &set), rv);
         else if (l->validity)  // nulls(left) | !values(right)   resp.   nulls(left) | values(right)
-          st = ah_bitmap_op(ctx, is_and ? BM_OR_NOTB : BM_OR, ln, rv, none, len, nb, &set);
+          st = ah_bitmap_op(ctx, is_and ? BM_OR_NOTB : BM_OR, ln, rv, none, len, nb, AH_COUNT(ctx, &set));
         else
-          st = ah_bitmap_op(ctx, is_and ? BM_OR_NOTB : BM_OR, rn, lv, none, len, nb, &set);
+          st = ah_bitmap_op(ctx, is_and ? BM_OR_NOTB : BM_OR, rn, lv, none, len, nb, AH_COUNT(ctx, &set));
       } else {
         st = ah_bitmap_op(ctx, (l->validity && r->validity) ? BM_AND : BM_COPY, l->validity ? ln : rn, rn, none,
-                          len, nb, &set);
+                          len, nb, AH_COUNT(ctx, &set));
       }
     }
   }
   hipError_t e = hipSuccess;
-  if (st == AH_OK) e = hipStreamSynchronize(ctx->stream);
+  if (st == AH_OK) e = ah_end_of_call_sync(ctx);
   if (st != AH_OK || e != hipSuccess) {
     ah_out_free(ctx, vals, bytes);
     ah_out_free(ctx, nb, bytes);
@@ -69,7 +69,7 @@ extern "C" ah_status ah_boolean_binary(ah_context* ctx, ah_boolean_op op, const 
   if (has_nb) {
     out->validity = (uint8_t*)nb;
     out->validity_bytes = (int64_t)bytes;
-    out->null_count = len - set;
+    out->null_count = ah_nulls(ctx, len, set);
   }
   return AH_OK;
 }
@@ -100,7 +100,7 @@ extern "C" ah_status ah_boolean_unary(ah_context* ctx, ah_boolean_op op, const a
       has_nb = true;
       st = ah_out_alloc(ctx, bytes, (void**)&nb);
       if (st == AH_OK)
-        st = ah_bitmap_op(ctx, BM_COPY, make_bitview(v->validity, v->validity_bit_offset), none, none, len, nb, &set);
+        st = ah_bitmap_op(ctx, BM_COPY, make_bitview(v->validity, v->validity_bit_offset), none, none, len, nb, AH_COUNT(ctx, &set));
     }
   } else if (!v->validity) {  // logical_nulls() == None
     if (op == AH_BOOL_IS_NULL) hipMemsetAsync(vals, 0, bytes, ctx->stream);
@@ -110,7 +110,7 @@ extern "C" ah_status ah_boolean_unary(ah_context* ctx, ah_boolean_op op, const a
                       make_bitview(v->validity, v->validity_bit_offset), none, none, len, vals, nullptr);
   }
   hipError_t e = hipSuccess;
-  if (st == AH_OK) e = hipStreamSynchronize(ctx->stream);
+  if (st == AH_OK) e = ah_end_of_call_sync(ctx);
   if (st != AH_OK || e != hipSuccess) {
     ah_out_free(ctx, vals, bytes);
     ah_out_free(ctx, nb, bytes);
@@ -122,7 +122,7 @@ extern "C" ah_status ah_boolean_unary(ah_context* ctx, ah_boolean_op op, const a
   if (has_nb) {
     out->validity = (uint8_t*)nb;
     out->validity_bytes = (int64_t)bytes;
-    out->null_count = len - set;
+    out->null_count = ah_nulls(ctx, len, set);
   }
   return AH_OK;
 }
@@ -160,7 +160,7 @@ extern "C" ah_status ah_nullif(ah_context* ctx, const ah_array_view* left, const
   ah_status st = ah_bitmap_op(ctx, BM_NULLIF, left->validity ? make_bitview(left->validity, left->validity_bit_offset) : none,
                               make_bitview(right->values, right->values_bit_offset),
                               right->validity ? make_bitview(right->validity, right->validity_bit_offset) : none,
-                              len, nb, &set);
+                              len, nb, AH_COUNT(ctx, &set));
   if (st != AH_OK) {
     ah_out_free(ctx, nb, bytes);
     ah_out_init(out);
@@ -168,6 +168,6 @@ extern "C" ah_status ah_nullif(ah_context* ctx, const ah_array_view* left, const
   }
   out->validity = (uint8_t*)nb;
   out->validity_bytes = (int64_t)bytes;
-  out->null_count = len - set;
+  out->null_count = ah_nulls(ctx, len, set);
   return AH_OK;
 }

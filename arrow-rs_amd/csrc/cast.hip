@@ -254,7 +254,8 @@ extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_ty
       ah_status st = ah_out_alloc(ctx, bbytes, &ob);
       if (st == AH_OK)
         st = ah_bitmap_op(ctx, BM_COPY, make_bitview(values->validity, values->validity_bit_offset),
-                          BitView{nullptr, 0}, BitView{nullptr, 0}, len, (unsigned long long*)ob, &set);
+                          BitView{nullptr, 0}, BitView{nullptr, 0}, len, (unsigned long long*)ob,
+                          AH_COUNT(ctx, &set));
       if (st != AH_OK) {
         ah_out_free(ctx, ov, vbytes);
         ah_out_free(ctx, ob, bbytes);
@@ -263,9 +264,9 @@ extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_ty
       }
       out->validity = (uint8_t*)ob;
       out->validity_bytes = (int64_t)bbytes;
-      out->null_count = len - set;
+      out->null_count = ah_nulls(ctx, len, set);
     }
-    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AH_HIP(ctx, ah_end_of_call_sync(ctx));
     return AH_OK;
   }
 
@@ -317,6 +318,17 @@ extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_ty
   }
   hipError_t e = hipGetLastError();
   if (st == AH_OK && e == hipSuccess) {
+    // safe mode cannot fail, so in deferred mode it returns here with the null count unknown;
+    // unsafe mode reports the first failing value and stays synchronous
+    if (safe && ctx->deferred) {
+      ah_pool_free(ctx, aux);
+      out->values = ov;
+      out->values_bytes = (int64_t)vbytes;
+      out->validity = (uint8_t*)ob;
+      out->validity_bytes = (int64_t)bbytes;
+      out->null_count = -1;
+      return AH_OK;
+    }
     if (want_valid) cast_sum_kernel<<<1, 1024, 0, ctx->stream>>>(a.block_valid, grid, aux + 1);
     e = hipMemcpyAsync(ctx->pinned, aux, 16, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

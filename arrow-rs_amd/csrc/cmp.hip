@@ -262,10 +262,23 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
   out->length = len;
   if (len == 0) return AH_OK;
 
-  int64_t ln = 0, rn = 0;
-  AH_TRY(ah_resolve_null_count(ctx, lhs, &ln));
-  AH_TRY(ah_resolve_null_count(ctx, rhs, &rn));
-  const bool lnul = lhs->validity && ln > 0, rnul = rhs->validity && rn > 0;  // .filter(null_count > 0)
+  // .filter(null_count > 0).  Deferred mode: an array side whose null count is still unknown counts as
+  // nullable instead of being counted (a host sync); the result bits are the same, the validity is kept.
+  auto nullable = [&](const ah_array_view* v, bool is_scalar, bool* yes) -> ah_status {
+    *yes = false;
+    if (!v->validity) return AH_OK;
+    if (ctx->deferred && !is_scalar && v->null_count < 0) {
+      *yes = true;
+      return AH_OK;
+    }
+    int64_t n = 0;
+    AH_TRY(ah_resolve_null_count(ctx, v, &n));
+    *yes = n > 0;
+    return AH_OK;
+  };
+  bool lnul = false, rnul = false;
+  AH_TRY(nullable(lhs, l_s, &lnul));
+  AH_TRY(nullable(rhs, r_s, &rnul));
   const bool distinct_op = op == AH_DISTINCT || op == AH_NOT_DISTINCT;
 
   const size_t bytes = ah_bitmap_bytes(len);
@@ -352,6 +365,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
   BitView rv = make_bitview(rhs->validity, rhs->validity_bit_offset);
   const BitView none{nullptr, 0};
   int64_t set_bits = len;
+  bool count_known = !ctx->deferred;  // deferred: only the all-null results know their count
   bool has_nb = false;
   ah_status st = AH_OK;
 
@@ -368,7 +382,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
     } else {
       st = run_values(vals);
       if (st == AH_OK) st = ah_out_alloc(ctx, bytes, (void**)&nb);
-      if (st == AH_OK) st = ah_bitmap_op(ctx, BM_AND, lv, rv, none, len, nb, &set_bits);
+      if (st == AH_OK) st = ah_bitmap_op(ctx, BM_AND, lv, rv, none, len, nb, AH_COUNT(ctx, &set_bits));
       has_nb = true;
     }
   } else if (lnul && rnul) {
@@ -382,6 +396,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
         hipMemsetAsync(vals, 0, bytes, ctx->stream);
         hipMemsetAsync(nb, 0, bytes, ctx->stream);
         set_bits = 0;
+        count_known = true;
         has_nb = true;
       }
     }
@@ -400,6 +415,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
           hipMemsetAsync(vals, 0, bytes, ctx->stream);
           hipMemsetAsync(nb, 0, bytes, ctx->stream);
           set_bits = 0;
+          count_known = true;
           has_nb = true;
         }
       }
@@ -413,7 +429,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
     } else {
       st = run_values(vals);
       if (st == AH_OK) st = ah_out_alloc(ctx, bytes, (void**)&nb);
-      if (st == AH_OK) st = ah_bitmap_op(ctx, BM_COPY, nv, none, none, len, nb, &set_bits);
+      if (st == AH_OK) st = ah_bitmap_op(ctx, BM_COPY, nv, none, none, len, nb, AH_COUNT(ctx, &set_bits));
       has_nb = true;
     }
   } else {
@@ -422,7 +438,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
   (void)need_values;
   if (st != AH_OK) return fail_free(st);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_end_of_call_sync(ctx);
   if (e != hipSuccess) {
     fail_free(AH_HIP_ERROR);
     return ah_fail(ctx, AH_HIP_ERROR, "compare kernel failed: %s", hipGetErrorString(e));
@@ -433,7 +449,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
   if (has_nb) {
     out->validity = (uint8_t*)nb;
     out->validity_bytes = (int64_t)bytes;
-    out->null_count = len - set_bits;
+    out->null_count = count_known ? len - set_bits : -1;
   }
   return AH_OK;
 }

@@ -46,6 +46,8 @@ struct ah_context {
   std::unordered_map<void*, hook_entry> hook_live;  // outputs handed out by the host allocator hook, with THEIR free
   // pinned host read-back slots
   uint64_t* pinned = nullptr;  // 256 x u64
+  // deferred mode (ah_context_set_deferred): infallible fixed-shape kernels skip the end-of-call sync
+  bool deferred = false;
   // profiling
   bool profiling = false;
   std::map<std::string, ah_prof_entry> prof;
@@ -67,6 +69,18 @@ ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...);
     ah_status _s = (expr);      \
     if (_s != AH_OK) return _s; \
   } while (0)
+
+// Deferred mode plumbing.  A call that can run deferred hands AH_COUNT(ctx, &n) to the helpers that
+// would read a popcount back (nullptr = no read-back), ends with ah_end_of_call_sync() and reports
+// ah_nulls(): len - set_bits, or -1 when nothing was read back.  Scratch blocks go back to the
+// context's pool right after the enqueue: the pool is per context = per stream, so reuse is stream-ordered.
+#define AH_COUNT(ctx, ptr) ((ctx)->deferred ? nullptr : (ptr))
+static inline hipError_t ah_end_of_call_sync(ah_context* ctx) {
+  return ctx->deferred ? hipSuccess : hipStreamSynchronize(ctx->stream);
+}
+static inline int64_t ah_nulls(const ah_context* ctx, int64_t len, int64_t set_bits) {
+  return ctx->deferred ? -1 : len - set_bits;
+}
 
 // pooled device memory (internal + default output allocator)
 ah_status ah_pool_alloc(ah_context* ctx, size_t bytes, void** out);

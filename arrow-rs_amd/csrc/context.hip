@@ -197,6 +197,12 @@ extern "C" void ah_context_set_stream(ah_context* ctx, void* s) {
   ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
 }
 extern "C" void* ah_context_stream(ah_context* ctx) { return (void*)ctx->stream; }
+extern "C" void ah_context_set_deferred(ah_context* ctx, int32_t on) {
+  if (!ctx) return;
+  if (ctx->deferred && !on) hipStreamSynchronize(ctx->stream);  // leaving deferred mode: everything enqueued is done
+  ctx->deferred = on != 0;
+}
+extern "C" int32_t ah_context_deferred(const ah_context* ctx) { return ctx && ctx->deferred; }
 extern "C" const char* ah_last_error(ah_context* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 extern "C" const char* ah_version(void) { return "arrow_hip 0.1.0 (gfx950)"; }
 
@@ -242,6 +248,21 @@ extern "C" ah_status ah_memset(ah_context* ctx, void* dst, int value, size_t byt
 }
 extern "C" ah_status ah_synchronize(ah_context* ctx) {
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AH_OK;
+}
+
+extern "C" ah_status ah_array_resolve(ah_context* ctx, ah_array_out* out) {
+  if (!ctx || !out) return AH_INVALID_ARGUMENT;
+  hipSetDevice(ctx->device);
+  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (out->null_count >= 0) return AH_OK;
+  if (!out->validity) {
+    out->null_count = 0;
+    return AH_OK;
+  }
+  int64_t set = 0;
+  AH_TRY(ah_count_set_bits(ctx, out->validity, out->validity_bit_offset, out->length, &set));
+  out->null_count = out->length - set;
   return AH_OK;
 }
 

@@ -438,7 +438,7 @@ extern "C" void ah_filter_predicate_free(ah_context* ctx, ah_filter_predicate* p
 // compaction of one bit stream (Boolean values or a validity bitmap) by the
 // predicate: filter_bits (filter.rs:680-720).  Returns popcount of the result.
 static ah_status compact_bits(ah_context* ctx, const ah_filter_predicate* p, BitView src,
-                              uint8_t** out_bits, size_t* out_bytes, int64_t* set_bits) {
+                              uint8_t** out_bits, size_t* out_bytes, int64_t* set_bits, bool defer = false) {
   size_t bytes = ah_bitmap_bytes(p->count);
   void* ob = nullptr;
   AH_TRY(ah_out_alloc(ctx, bytes, &ob));
@@ -462,6 +462,13 @@ static ah_status compact_bits(ah_context* ctx, const ah_filter_predicate* p, Bit
   a.out_valid = (unsigned long long*)ob;
   a.valid_slots = slots;
   launch_scatter<true>(ctx, 0, a, false);
+  if (defer) {  // no read-back: the caller reports the count as unknown
+    ah_pool_free(ctx, slots);
+    *set_bits = -1;
+    *out_bits = (uint8_t*)ob;
+    *out_bytes = bytes;
+    return AH_OK;
+  }
   hipError_t e = hipMemcpyAsync(ctx->pinned, slots, VALID_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   ah_pool_free(ctx, slots);
@@ -494,6 +501,9 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
                    ah_type_name(values->type));
   out->type = values->type;
   const int64_t K = p->count;
+  // deferred mode covers fixed-width and Boolean values: K is known from the predicate, so nothing
+  // needs reading back; strings size their byte buffer from the data and stay synchronous
+  const bool defer = ctx->deferred && !is_string;
   if (is_string && !values->offsets)
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "string array view without offsets");
   if (is_string && (p->len == 0 || K == 0)) {  // new_empty_array: offsets = [0]
@@ -522,6 +532,8 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
       int64_t nulls = 0;
       if (K == values->length && values->null_count >= 0) {
         nulls = values->null_count;
+      } else if (defer) {
+        nulls = -1;
       } else {
         int64_t set = 0;
         AH_TRY(ah_count_set_bits(ctx, values->validity, values->validity_bit_offset, K, &set));
@@ -535,7 +547,8 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
   }
 
   int64_t in_nulls = 0;
-  AH_TRY(ah_resolve_null_count(ctx, values, &in_nulls));
+  if (defer && values->null_count < 0) in_nulls = values->validity ? 1 : 0;  // unknown: treat as nullable, no count
+  else AH_TRY(ah_resolve_null_count(ctx, values, &in_nulls));
   const bool has_valid = values->validity && in_nulls > 0;  // filter_nulls :512-517
   BitView vvalid = has_valid ? make_bitview(values->validity, values->validity_bit_offset)
                              : BitView{nullptr, 0};
@@ -584,7 +597,7 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
     size_t vbytes = 0;
     int64_t set = 0;
     AH_TRY(compact_bits(ctx, p, make_bitview(values->values, values->values_bit_offset), &vb,
-                        &vbytes, &set));
+                        &vbytes, &set, defer));
     out->values = vb;
     out->values_bytes = (int64_t)vbytes;
     out->length = K;
@@ -592,17 +605,17 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
       uint8_t* nb = nullptr;
       size_t nbytes = 0;
       int64_t nset = 0;
-      ah_status st = compact_bits(ctx, p, vvalid, &nb, &nbytes, &nset);
+      ah_status st = compact_bits(ctx, p, vvalid, &nb, &nbytes, &nset, defer);
       if (st != AH_OK) {
         ah_array_release(ctx, out);
         return st;
       }
-      if (K - nset == 0) {
+      if (!defer && K - nset == 0) {
         ah_out_free(ctx, nb, nbytes);
       } else {
         out->validity = nb;
         out->validity_bytes = (int64_t)nbytes;
-        out->null_count = K - nset;
+        out->null_count = defer ? -1 : K - nset;
       }
     }
     return AH_OK;
@@ -645,9 +658,9 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
     else launch_scatter<false>(ctx, width, a, skip);
   }
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess && has_valid)
+  if (e == hipSuccess && has_valid && !defer)
     e = hipMemcpyAsync(ctx->pinned, slots, VALID_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess && !defer) e = hipStreamSynchronize(ctx->stream);
   ah_pool_free(ctx, slots);
   if (e != hipSuccess) {
     ah_out_free(ctx, ov, vbytes);
@@ -657,7 +670,11 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
   out->length = K;
   out->values = ov;
   out->values_bytes = (int64_t)vbytes;
-  if (has_valid) {
+  if (has_valid && defer) {
+    out->validity = (uint8_t*)ob;
+    out->validity_bytes = (int64_t)bbytes;
+    out->null_count = -1;
+  } else if (has_valid) {
     int64_t validc = 0;
     for (int i = 0; i < VALID_SLOTS; ++i) validc += (int64_t)ctx->pinned[i];
     int64_t nulls = K - validc;

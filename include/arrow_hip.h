@@ -135,6 +135,22 @@ AH_API void ah_context_set_allocator(ah_context* ctx, ah_alloc_fn a, ah_free_fn 
 /* Launch on a caller-provided hipStream_t (NULL = the context's own stream). */
 AH_API void ah_context_set_stream(ah_context* ctx, void* hip_stream);
 AH_API void* ah_context_stream(ah_context* ctx);
+/* Opt-in asynchronous ("deferred") mode.  The reference's kernels are synchronous functions; ours are too
+ * by default: every entry point returns with its result complete and `null_count` known.  With deferred mode
+ * on, the entry points whose output SHAPE does not depend on the data and that cannot fail on the device —
+ * ah_arith_binary / ah_arith_neg for the wrapping, floating-point and bitwise ops, ah_bitwise_not, ah_compare,
+ * ah_boolean_binary / ah_boolean_unary, ah_cast between numeric types in safe mode, and
+ * ah_filter_predicate_apply on fixed-width and Boolean values (the row count comes from the predicate) — only
+ * ENQUEUE their kernels on the context's stream and return at once: no host synchronisation, `null_count = -1`
+ * ("unknown", the C Data Interface's convention; every entry point accepts -1 on its inputs) and the validity
+ * buffer kept even where the synchronous call would have dropped an all-valid one.  Results may be passed
+ * straight to further calls on the same context (stream order).  Before reading them from the host, another
+ * stream or another context call ah_synchronize(); ah_array_resolve() does that and fills in null_count.
+ * Every other entry point (data-dependent sizes, device-side errors to report) stays synchronous. */
+AH_API void ah_context_set_deferred(ah_context* ctx, int32_t on);
+AH_API int32_t ah_context_deferred(const ah_context* ctx);
+/* ah_synchronize + count the nulls of a deferred result (null_count < 0) on the device. */
+AH_API ah_status ah_array_resolve(ah_context* ctx, ah_array_out* out);
 AH_API const char* ah_last_error(ah_context* ctx);
 AH_API void ah_array_release(ah_context* ctx, ah_array_out* out);
 AH_API const char* ah_version(void);

@@ -76,6 +76,11 @@ class Context {
   Context(const Context&) = delete;
   Context& operator=(const Context&) = delete;
   ah_context* handle() const { return h_; }
+  // opt-in asynchronous mode (ah_context_set_deferred): infallible fixed-shape kernels only enqueue;
+  // Array::null_count() of such a result counts lazily
+  void set_deferred(bool on) { ah_context_set_deferred(h_, on ? 1 : 0); }
+  bool deferred() const { return ah_context_deferred(h_) != 0; }
+  void synchronize() const { check(ah_synchronize(h_)); }
   void check(ah_status st) const {
     if (st == AH_OK) return;
     std::string m = ah_last_error(h_);
@@ -115,7 +120,15 @@ class Array {
   ah_type data_type() const { return view_.type; }
   int64_t len() const { return view_.length; }
   bool is_empty() const { return view_.length == 0; }
-  int64_t null_count() const { return view_.validity ? view_.null_count : 0; }
+  int64_t null_count() const {
+    if (!view_.validity) return 0;
+    if (view_.null_count < 0) {  // deferred result: counted (and the stream synchronised) on first use
+      int64_t set = 0;
+      ctx_->check(ah_count_set_bits(ctx_->handle(), view_.validity, view_.validity_bit_offset, view_.length, &set));
+      view_.null_count = view_.length - set;
+    }
+    return view_.null_count;
+  }
   bool has_nulls_buffer() const { return view_.validity != nullptr; }  // nulls().is_some()
   const ah_array_view& view() const { return view_; }
   const void* offsets() const { return out_.offsets; }
@@ -127,7 +140,7 @@ class Array {
 
  private:
   std::shared_ptr<Context> ctx_;
-  ah_array_view view_{};
+  mutable ah_array_view view_{};
   ah_array_out out_{};
   bool owned_ = false;
   std::vector<std::shared_ptr<Array>> keep_;

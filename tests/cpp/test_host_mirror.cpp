@@ -215,5 +215,25 @@ int main() {
     assert((download<int64_t>(selection::boundaries(sel)) == std::vector<int64_t>{1, 2, 4, 5}));
   }
 
+  // deferred mode: kernels only enqueue, results chain on the stream, null_count() counts lazily
+  {
+    const std::vector<bool> v1{true, false, true, true}, v2{true, true, false, true};
+    auto p = upload<int64_t>(ctx, AH_INT64, {1, 2, 3, 4}, &v1, keep);
+    auto q = upload<int64_t>(ctx, AH_INT64, {10, 20, 30, 40}, &v2, keep);
+    ctx->set_deferred(true);
+    assert(ctx->deferred());
+    auto s = compute::add_wrapping(p, q);
+    assert(s->view().null_count == -1 && s->has_nulls_buffer());
+    auto m = compute::lt(s, q);                 // consumes the deferred result without a host sync
+    auto f = compute::cast(s, AH_FLOAT64);
+    ctx->set_deferred(false);                   // synchronises
+    assert(!ctx->deferred());
+    assert(s->null_count() == 2 && m->null_count() == 2 && f->null_count() == 2);
+    auto sv = download<int64_t>(s);
+    assert(sv[0] == 11 && sv[3] == 44);
+    auto fv = download<double>(f);
+    assert(fv[0] == 11.0 && fv[3] == 44.0);
+  }
+
   return 0;
 }
