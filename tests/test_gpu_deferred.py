@@ -242,3 +242,48 @@ def test_deferred_small_batches_are_cheaper(ctx):
     assert_logical_eq(host(r_def), host(r_sync), "deferred chain result")
     print(f"8192-row chain of 3 kernels: synchronous {t_sync * 1e6:.1f} us, deferred {t_def * 1e6:.1f} us")
     assert t_def < t_sync * 1.1
+
+
+def test_deferred_chain_captured_in_a_hip_graph(ctx, oracle):
+    """Deferred calls make no host synchronisation and (with a warm pool) no hipMalloc, so a chain of them can be
+    stream-captured into a hipGraph and replayed on new input bytes: the launch-bound small-batch loop as ONE
+    graph launch.  torch is only the capture/replay plumbing (torch.cuda.CUDAGraph = hipGraph on ROCm)."""
+    import torch
+    rng = np.random.default_rng(19)
+    n = 8192
+    ha, hb = _cols(rng, n, A.Int64, 0.9), _cols(rng, n, A.Int64, 0.9)
+    gctx = A.Context(0)
+    stream = torch.cuda.Stream()
+    gctx.lib.ah_context_set_stream(gctx.handle, stream.cuda_stream)
+    da, db = ha.to_device(gctx), hb.to_device(gctx)
+
+    def chain():
+        return K.cast(K.add_wrapping(K.mul_wrapping(da, db), da), A.Float64)
+
+    gctx.set_deferred(True)
+    try:
+        warm = [chain() for _ in range(2)]  # fill the pool with every block size the chain needs
+        gctx.synchronize()
+        del warm
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            out = chain()
+        # new input bytes behind the same device pointers, then replay
+        ha2 = HostArray(A.Int64, rng.integers(-2**40, 2**40, n), ha.valid)
+        gctx.check(gctx.lib.ah_memcpy_htod(gctx.handle, da.values.ptr, np.ascontiguousarray(ha2.values).ctypes.data, n * 8))
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+    finally:
+        gctx.set_deferred(False)
+        gctx.lib.ah_context_set_stream(gctx.handle, None)
+    exp = oracle.cast(oracle.arith(1, oracle.arith(5, ha2, hb), ha2), A.Float64)
+    same(out, exp, "graph replay")
+
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(500):
+        graph.replay()
+    torch.cuda.synchronize()
+    print(f"hipGraph replay of the 3-kernel chain: {(time.perf_counter() - t0) / 500 * 1e6:.1f} us per chain")
