@@ -154,6 +154,14 @@ take_cases.append(dict(name="check_bounds_message", source="arrow-select/src/tak
 take_cases.append(dict(name="empty_indices", source="arrow-select/src/take.rs:215-217",
                        values=arr("Int32", [1, 2, 3]), indices=arr("UInt32", []), expected=arr("Int32", [])))
 
+# test_take_decimal128_non_null_indices / test_take_decimal128 (take.rs:1263-1293): 16-byte natives
+take_cases.append(dict(name="test_take_decimal128_non_null_indices", source="arrow-select/src/take.rs:1263-1276",
+                       values=arr("Decimal128(10, 5)", [N, 3, 5, 2, 3, N]), indices=arr("UInt32", [0, 5, 3, 1, 4, 2]),
+                       expected=arr("Decimal128(10, 5)", [N, N, 2, 3, 3, 5])))
+take_cases.append(dict(name="test_take_decimal128", source="arrow-select/src/take.rs:1279-1292",
+                       values=arr("Decimal128(10, 5)", [0, 1, 2, 3, 4]), indices=arr("UInt32", [3, N, 1, 3, 2]),
+                       expected=arr("Decimal128(10, 5)", [3, N, 1, 3, 2])))
+
 arith_cases = []
 a, b = [4, 3, 5, -6, 100], [6, 2, 5, -7, 3]
 for op, exp in [("add", [10, 5, 10, -13, 103]), ("sub", [-2, 1, 0, 1, 97]), ("div", [0, 1, 1, 0, 33]),
@@ -208,6 +216,22 @@ arith_cases.append(dict(name="type_mismatch", source="arrow-arith/src/numeric.rs
                         lhs=arr("Int32", [1]), rhs=arr("Int64", [1]), error="InvalidArgumentError",
                         message="Invalid arithmetic operation: Int32 + Int64"))
 
+# arity.rs tests (arrow-arith/src/arity.rs:460-540): the closures are `l + r`, i.e. add / add_wrapping without overflow
+for opn in ["add", "add_wrapping"]:
+    arith_cases.append(dict(name=f"test_binary_mut_{opn}", source="arrow-arith/src/arity.rs:460-467 (test_binary_mut), "
+                            ":489-496 (test_try_binary_mut)", op=opn, lhs=arr("Int32", [15, 14, 9, 8, 1]),
+                            rhs=arr("Int32", [1, N, 3, N, 5]), expected=arr("Int32", [16, N, 12, N, 6])))
+    arith_cases.append(dict(name=f"test_try_binary_mut_no_nulls_{opn}", source="arrow-arith/src/arity.rs:498-502", op=opn,
+                            lhs=arr("Int32", [15, 14, 9, 8, 1]), rhs=arr("Int32", [1, 2, 3, 4, 5]),
+                            expected=arr("Int32", [16, 16, 12, 12, 6])))
+    arith_cases.append(dict(name=f"test_binary_mut_null_buffer_{opn}", source="arrow-arith/src/arity.rs:470-486", op=opn,
+                            lhs=arr("Int32", [3, 4, 5, 6, N]),
+                            rhs=dict(type="Int32", raw=[10, 11, 12, 13, 14], valid=[T, T, T, T, T]),
+                            expected=arr("Int32", [13, 15, 17, 19, N])))
+    arith_cases.append(dict(name=f"test_try_binary_mut_all_valid_null_buffers_{opn}", source="arrow-arith/src/arity.rs:521-531",
+                            op=opn, lhs=dict(type="Int32", raw=[1, 2], valid=[T, T]),
+                            rhs=dict(type="Int32", raw=[10, 20], valid=[T, T]), expected=arr("Int32", [11, 22])))
+
 cmp_cases = []
 eights = [8] * 10
 seq = [6, 7, 8, 9, 10, 6, 7, 8, 9, 10]
@@ -240,14 +264,124 @@ cmp_cases.append(dict(name="f64_eq", source="arrow-ord/src/comparison.rs:2494-25
                       lhs=arr("Float64", el), rhs=arr("Float64", er), expected=arr("Boolean", [T, F, T, T, T])))
 cmp_cases.append(dict(name="f64_neq", source="arrow-ord/src/comparison.rs:2494-2501", op="neq",
                       lhs=arr("Float64", el), rhs=arr("Float64", er), expected=arr("Boolean", [F, T, F, F, F])))
+# the reference only asserts the LENGTH of the result buffer (130 is not a multiple of 64); 1 >= 2 is false
 cmp_cases.append(dict(name="test_length_of_result_buffer", source="arrow-ord/src/comparison.rs:791-803", op="gt_eq",
-                      lhs=arr("Int8", [1] * 130), rhs=arr("Int8", [1] * 130), expected=arr("Boolean", [T] * 130)))
+                      lhs=arr("Int8", [1] * 130), rhs=arr("Int8", [2] * 130), expected=arr("Boolean", [F] * 130)))
 cmp_cases.append(dict(name="length_mismatch", source="arrow-ord/src/cmp.rs:228-232", op="eq",
                       lhs=arr("Int32", [1, 2]), rhs=arr("Int32", [1]), error="InvalidArgumentError",
                       message="Cannot compare arrays of different lengths, got 2 vs 1"))
 cmp_cases.append(dict(name="type_mismatch", source="arrow-ord/src/cmp.rs:260-264", op="lt",
                       lhs=arr("Int32", [1]), rhs=arr("Int64", [1]), error="InvalidArgumentError",
                       message="Invalid comparison operation: Int32 < Int64"))
+
+# --- the cmp_i64! / cmp_i64_scalar! matrix (comparison.rs:201-790; each case is also run x10-replicated by the tests)
+def cmp_case(name, line, op, lhs, rhs=None, expected=None, t="Int64", **kw):
+    d = dict(name=name, source=f"arrow-ord/src/comparison.rs:{line}", op=op, lhs=arr(t, lhs) if isinstance(lhs, list) else lhs,
+             expected=arr("Boolean", expected))
+    if rhs is not None:
+        d["rhs"] = arr(t, rhs) if isinstance(rhs, list) else rhs
+    d.update(kw)
+    cmp_cases.append(d)
+
+
+def sc(t, v):
+    return dict(type=t, value=v)
+
+
+cmp_case("test_primitive_array_eq", "201-210", "eq", eights, seq, [F, F, T, F, F, F, F, T, F, F])
+for tt in ["Timestamp(Second, None)", "Time32(Second)", "Time32(Millisecond)", "Time64(Microsecond)", "Time64(Nanosecond)"]:
+    cmp_case(f"test_primitive_array_eq_{tt}", "211-250", "eq", eights, seq, [F, F, T, F, F, F, F, T, F, F], t=tt)
+cmp_case("test_primitive_array_eq_scalar", "291-298", "eq", seq, expected=[F, F, T, F, F, F, F, T, F, F], rhs_scalar=sc("Int64", 8))
+cmp_case("test_primitive_array_eq_with_slice", "301-311", "eq", arr("Int32", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10], [5, 5]),
+         arr("Int32", [6, 7, 8, 8, 10]), [T, T, T, F, T])
+cmp_case("test_primitive_array_eq_scalar_with_slice", "314-322", "eq", arr("Int32", [1, N, 2, 3], [1, 3]),
+         expected=[N, T, F], rhs_scalar=sc("Int32", 2))
+cmp_case("test_primitive_array_neq", "325-332", "neq", eights, seq, [T, T, F, T, T, T, T, F, T, T])
+cmp_case("test_primitive_array_neq_scalar", "343-350", "neq", seq, expected=[T, T, F, T, T, T, T, F, T, T], rhs_scalar=sc("Int64", 8))
+BA, BB = [T, F, F, T, T, N], [T, T, F, F, N, F]
+for op, line, e in [("eq", "353-366", [T, F, T, F, N, N]), ("neq", "368-381", [F, T, F, T, N, N]),
+                    ("lt", "383-396", [F, T, F, F, N, N]), ("lt_eq", "398-411", [T, T, T, F, N, N]),
+                    ("gt", "413-426", [F, F, F, T, N, N]), ("gt_eq", "428-441", [T, F, T, T, N, N])]:
+    cmp_case(f"test_boolean_array_{op}", line, op, BA, BB, e, t="Boolean")
+for op, line, ef, et in [("eq", "443-453", [F, T, N], [T, F, N]), ("neq", "456-467", [T, F, N], [F, T, N]),
+                         ("lt", "470-482", [F, F, N], [F, T, N]), ("lt_eq", "485-496", [F, T, N], [T, T, N]),
+                         ("gt", "499-509", [T, F, N], [F, F, N]), ("gt_eq", "512-523", [T, T, N], [T, F, N])]:
+    cmp_case(f"test_boolean_array_{op}_scalar_false", line, op, [T, F, N], expected=ef, t="Boolean", rhs_scalar=sc("Boolean", F))
+    cmp_case(f"test_boolean_array_{op}_scalar_true", line, op, [T, F, N], expected=et, t="Boolean", rhs_scalar=sc("Boolean", T))
+cmp_case("test_primitive_array_lt_eq_scalar", "660-667", "lt_eq", seq, expected=[T, T, T, F, F, T, T, T, F, F], rhs_scalar=sc("Int64", 8))
+cmp_case("test_primitive_array_lt_eq_nulls", "670-677", "lt_eq", [N, N, 1, N, N, 1, N, N, 1], [N, 1, 0, N, 1, 2, N, N, 3],
+         [N, N, F, N, N, T, N, N, T])
+cmp_case("test_primitive_array_lt_eq_scalar_nulls", "680-687", "lt_eq", [N, 1, 2, N, 1, 2, N, 1, 2],
+         expected=[N, T, F, N, T, F, N, T, F], rhs_scalar=sc("Int64", 1))
+cmp_case("test_primitive_array_gt", "690-697", "gt", eights, seq, [T, T, F, F, F, T, T, F, F, F])
+cmp_case("test_primitive_array_gt_scalar", "700-707", "gt", seq, expected=[F, F, F, T, T, F, F, F, T, T], rhs_scalar=sc("Int64", 8))
+cmp_case("test_primitive_array_gt_nulls", "710-717", "gt", [N, N, 1, N, N, 2, N, N, 3], [N, 1, 1, N, 1, 1, N, 1, 1],
+         [N, N, F, N, N, T, N, N, T])
+cmp_case("test_primitive_array_gt_scalar_nulls", "720-727", "gt", [N, 1, 2, N, 1, 2, N, 1, 2],
+         expected=[N, F, T, N, F, T, N, F, T], rhs_scalar=sc("Int64", 1))
+cmp_case("test_primitive_array_gt_eq", "730-737", "gt_eq", eights, seq, [T, T, T, F, F, T, T, T, F, F])
+cmp_case("test_primitive_array_gt_eq_scalar", "740-747", "gt_eq", seq, expected=[F, F, T, T, T, F, F, T, T, T], rhs_scalar=sc("Int64", 8))
+cmp_case("test_primitive_array_gt_eq_nulls", "750-757", "gt_eq", [N, N, 1, N, 1, 2, N, N, 1], [N, 1, N, N, 1, 1, N, 2, 2],
+         [N, N, N, N, T, T, N, N, F])
+cmp_case("test_primitive_array_gt_eq_scalar_nulls", "760-767", "gt_eq", [N, 1, 2, N, 2, 3, N, 3, 4],
+         expected=[N, F, T, N, T, T, N, T, T], rhs_scalar=sc("Int64", 2))
+cmp_case("test_primitive_array_compare_slice", "770-778", "lt", arr("Int32", list(range(100)), [50, 50]),
+         arr("Int32", list(range(100, 200)), [50, 50]), [T] * 50)
+cmp_case("test_primitive_array_compare_scalar_slice", "781-788", "lt", arr("Int32", list(range(100)), [50, 50]),
+         expected=[T] * 50, rhs_scalar=sc("Int32", 200))
+# --- NaN under the total order, gt / gt_eq and NaN scalars (comparison.rs:2538-2658)
+for ft in ["Float32", "Float64"]:
+    cmp_case(f"{ft}_gt_total_order", "2538-2566", "gt", fl, fr, [F, F, F, F, T, T], t=ft)
+    cmp_case(f"{ft}_gt_eq_total_order", "2538-2566", "gt_eq", fl, fr, [T, F, T, F, T, T], t=ft)
+    nan_l = ["nan", 7.0, 8.0, 8.0, 10.0]
+    for op, line, e in [("eq", "2569-2595", [T, F, F, F, F]), ("neq", "2569-2595", [F, T, T, T, T]),
+                        ("lt", "2598-2625", [F, T, T, T, T]), ("lt_eq", "2598-2625", [T, T, T, T, T]),
+                        ("gt", "2628-2658", [F, F, F, F, F]), ("gt_eq", "2628-2658", [T, F, F, F, F])]:
+        cmp_case(f"{ft}_{op}_nan_scalar", line, op, nan_l, expected=e, t=ft, rhs_scalar=sc(ft, "nan"))
+cmp_case("f32_eq", "2475-2503", "eq", el, er, [T, F, T, T, T], t="Float32")
+cmp_case("f32_neq", "2475-2503", "neq", el, er, [F, T, F, F, F], t="Float32")
+cmp_case("f32_lt_eq_total_order", "2506-2535", "lt_eq", fl, fr, [T, T, T, T, F, F], t="Float32")
+
+
+# --- arrow-ord/src/cmp.rs tests: distinct / not_distinct and scalar-vs-scalar (:1028-1170)
+def cmp_rs(name, line, op, expected, **kw):
+    d = dict(name=name, source=f"arrow-ord/src/cmp.rs:{line}", op=op, expected=arr("Boolean", expected))
+    d.update(kw)
+    cmp_cases.append(d)
+
+
+cmp_rs("is_distinct_from_non_nulls", "1028-1040", "distinct", [T, T, F, T, T], lhs=arr("Int32", [0, 1, 2, 3, 4]), rhs=arr("Int32", [4, 3, 2, 1, 0]))
+cmp_rs("is_not_distinct_from_non_nulls", "1028-1040", "not_distinct", [F, F, T, F, F], lhs=arr("Int32", [0, 1, 2, 3, 4]),
+       rhs=arr("Int32", [4, 3, 2, 1, 0]))
+DL = dict(type="Int32", raw=[0, 0, 1, 3, 0, 0], valid=[T, T, F, T, T, T])   # values under the null slot are NOT zero
+DR = dict(type="Int32", raw=[0] * 6, valid=[T, F, F, F, T, F])
+cmp_rs("is_distinct_from_nulls", "1043-1066", "distinct", [F, T, F, T, F, T], lhs=DL, rhs=DR)
+cmp_rs("is_not_distinct_from_nulls", "1043-1066", "not_distinct", [T, F, T, F, T, F], lhs=DL, rhs=DR)
+S12, SNULL = sc("Int32", 12), sc("Int32", N)
+cmp_rs("test_distinct_scalar_12_12", "1069-1074", "distinct", [F], lhs_scalar=S12, rhs_scalar=S12)
+cmp_rs("test_not_distinct_scalar_12_12", "1069-1074", "not_distinct", [T], lhs_scalar=S12, rhs_scalar=S12)
+# a scalar against a length-1 null ARRAY, both orders (:1076-1082)
+cmp_rs("test_distinct_scalar_vs_null_array", "1076-1082", "distinct", [T], lhs_scalar=S12, rhs=arr("Int32", [N]))
+cmp_rs("test_not_distinct_scalar_vs_null_array", "1076-1082", "not_distinct", [F], lhs_scalar=S12, rhs=arr("Int32", [N]))
+cmp_rs("test_distinct_null_array_vs_scalar", "1076-1082", "distinct", [T], lhs=arr("Int32", [N]), rhs_scalar=S12)
+cmp_rs("test_not_distinct_null_array_vs_scalar", "1076-1082", "not_distinct", [F], lhs=arr("Int32", [N]), rhs_scalar=S12)
+cmp_rs("test_distinct_scalar_vs_null_scalar", "1084-1086", "distinct", [T], lhs_scalar=S12, rhs_scalar=SNULL)
+cmp_rs("test_not_distinct_scalar_vs_null_scalar", "1084-1086", "not_distinct", [F], lhs_scalar=S12, rhs_scalar=SNULL)
+cmp_rs("test_distinct_null_scalars", "1088-1089", "distinct", [F], lhs_scalar=SNULL, rhs_scalar=SNULL)
+cmp_rs("test_not_distinct_null_scalars", "1088-1089", "not_distinct", [T], lhs_scalar=SNULL, rhs_scalar=SNULL)
+DA = dict(type="Int32", raw=[0, 1, 2, 3], valid=[F, F, T, T])
+for sname, sv, lines, e_d, e_nd in [("null", N, "1091-1102", [F, F, T, T], [T, T, F, F]),
+                                    ("1", 1, "1104-1110", [T, T, T, T], [F, F, F, F]),
+                                    ("3", 3, "1112-1118", [T, T, T, F], [F, F, F, T])]:
+    cmp_rs(f"test_distinct_array_vs_scalar_{sname}", lines, "distinct", e_d, lhs=DA, rhs_scalar=sc("Int32", sv))
+    cmp_rs(f"test_distinct_scalar_{sname}_vs_array", lines, "distinct", e_d, lhs_scalar=sc("Int32", sv), rhs=DA)
+    cmp_rs(f"test_not_distinct_array_vs_scalar_{sname}", lines, "not_distinct", e_nd, lhs=DA, rhs_scalar=sc("Int32", sv))
+    cmp_rs(f"test_not_distinct_scalar_{sname}_vs_array", lines, "not_distinct", e_nd, lhs_scalar=sc("Int32", sv), rhs=DA)
+S54 = sc("Int32", 54)
+cmp_rs("test_scalar_negation_eq", "1151-1160", "eq", [T], lhs_scalar=S54, rhs_scalar=S54)
+cmp_rs("test_scalar_negation_neq", "1151-1160", "neq", [F], lhs_scalar=S54, rhs_scalar=S54)
+cmp_rs("test_scalar_empty_array_vs_scalar", "1162-1170", "eq", [], lhs=arr("Int32", []), rhs_scalar=sc("Int32", 23))
+cmp_rs("test_scalar_empty_scalar_vs_array", "1162-1170", "eq", [], lhs_scalar=sc("Int32", 23), rhs=arr("Int32", []))
 
 cast_cases = []
 I64MIN, I64MAX = -9223372036854775808, 9223372036854775807
@@ -273,6 +407,117 @@ cast_cases.append(dict(name="i64_to_f64_to_utf8_chain", source="arrow-cast/src/c
                        to="Utf8",
                        expected=arr("Utf8", ["-9.223372036854776e18", "-2147483648.0", "0.0", "127.0",
                                              "9.223372036854776e18"])))
+
+# The reference's numeric cast matrices (arrow-cast/src/cast/mod.rs:7821-8990): one array of range-edge values per
+# source type, cast to every numeric type in safe mode; out-of-range results are null.  `get_cast_values` (:8965)
+# prints each value with Rust `{:?}`, i.e. shortest round-trip digits, so a printed float pins exactly one value
+# ("-2147483600.0" as f32 IS -2147483648f32): the strings are transcribed as literals and parsed at the target width.
+U64MAX = 18446744073709551615
+CAST_MATRIX = [
+    ("test_cast_from_f64", "7821-7989", "Float64",
+     [-9223372036854775808.0, -2147483648.0, -32768.0, -128.0, 0.0, 255.0, 65535.0, 4294967295.0, 18446744073709551616.0], {
+        "Float64": [-9223372036854776000.0, -2147483648.0, -32768.0, -128.0, 0.0, 255.0, 65535.0, 4294967295.0,
+                    18446744073709552000.0],
+        "Float32": [-9223372000000000000.0, -2147483600.0, -32768.0, -128.0, 0.0, 255.0, 65535.0, 4294967300.0,
+                    18446744000000000000.0],
+        "Int64": [-9223372036854775808, -2147483648, -32768, -128, 0, 255, 65535, 4294967295, N],
+        "Int32": [N, -2147483648, -32768, -128, 0, 255, 65535, N, N],
+        "Int16": [N, N, -32768, -128, 0, 255, N, N, N],
+        "Int8": [N, N, N, -128, 0, N, N, N, N],
+        "UInt64": [N, N, N, N, 0, 255, 65535, 4294967295, N],
+        "UInt32": [N, N, N, N, 0, 255, 65535, 4294967295, N],
+        "UInt16": [N, N, N, N, 0, 255, 65535, N, N],
+        "UInt8": [N, N, N, N, 0, 255, N, N, N]}),
+    ("test_cast_from_f32", "7991-8134", "Float32",
+     [-2147483648.0, -2147483648.0, -32768.0, -128.0, 0.0, 255.0, 65535.0, 4294967296.0, 4294967296.0], {
+        "Float64": [-2147483648.0, -2147483648.0, -32768.0, -128.0, 0.0, 255.0, 65535.0, 4294967296.0, 4294967296.0],
+        "Float32": [-2147483600.0, -2147483600.0, -32768.0, -128.0, 0.0, 255.0, 65535.0, 4294967300.0, 4294967300.0],
+        "Int64": [-2147483648, -2147483648, -32768, -128, 0, 255, 65535, 4294967296, 4294967296],
+        "Int32": [-2147483648, -2147483648, -32768, -128, 0, 255, 65535, N, N],
+        "Int16": [N, N, -32768, -128, 0, 255, N, N, N],
+        "Int8": [N, N, N, -128, 0, N, N, N, N],
+        "UInt64": [N, N, N, N, 0, 255, 65535, 4294967296, 4294967296],
+        "UInt32": [N, N, N, N, 0, 255, 65535, N, N],
+        "UInt16": [N, N, N, N, 0, 255, 65535, N, N],
+        "UInt8": [N, N, N, N, 0, 255, N, N, N]}),
+    ("test_cast_from_uint64", "8136-8228", "UInt64", [0, 255, 65535, 4294967295, U64MAX], {
+        "Float64": [0.0, 255.0, 65535.0, 4294967295.0, 18446744073709552000.0],
+        "Float32": [0.0, 255.0, 65535.0, 4294967300.0, 18446744000000000000.0],
+        "Int64": [0, 255, 65535, 4294967295, N],
+        "Int32": [0, 255, 65535, N, N],
+        "Int16": [0, 255, N, N, N],
+        "Int8": [0, N, N, N, N],
+        "UInt64": [0, 255, 65535, 4294967295, U64MAX],
+        "UInt32": [0, 255, 65535, 4294967295, N],
+        "UInt16": [0, 255, 65535, N, N],
+        "UInt8": [0, 255, N, N, N]}),
+    ("test_cast_from_uint32", "8230-8312", "UInt32", [0, 255, 65535, 4294967295], {
+        "Float64": [0.0, 255.0, 65535.0, 4294967295.0],
+        "Float32": [0.0, 255.0, 65535.0, 4294967300.0],
+        "Int64": [0, 255, 65535, 4294967295],
+        "Int32": [0, 255, 65535, N],
+        "Int16": [0, 255, N, N],
+        "Int8": [0, N, N, N],
+        "UInt64": [0, 255, 65535, 4294967295],
+        "UInt32": [0, 255, 65535, 4294967295],
+        "UInt16": [0, 255, 65535, N],
+        "UInt8": [0, 255, N, N]}),
+    ("test_cast_from_uint16", "8314-8380", "UInt16", [0, 255, 65535], {
+        "Float64": [0.0, 255.0, 65535.0], "Float32": [0.0, 255.0, 65535.0],
+        "Int64": [0, 255, 65535], "Int32": [0, 255, 65535], "Int16": [0, 255, N], "Int8": [0, N, N],
+        "UInt64": [0, 255, 65535], "UInt32": [0, 255, 65535], "UInt16": [0, 255, 65535], "UInt8": [0, 255, N]}),
+    ("test_cast_from_uint8", "8382-8447", "UInt8", [0, 255], {
+        "Float64": [0.0, 255.0], "Float32": [0.0, 255.0],
+        "Int64": [0, 255], "Int32": [0, 255], "Int16": [0, 255], "Int8": [0, N],
+        "UInt64": [0, 255], "UInt32": [0, 255], "UInt16": [0, 255], "UInt8": [0, 255]}),
+    ("test_cast_from_int64", "8449-8590", "Int64",
+     [I64MIN, -2147483648, -32768, -128, 0, 127, 32767, 2147483647, I64MAX], {
+        "Float32": [-9223372000000000000.0, -2147483600.0, -32768.0, -128.0, 0.0, 127.0, 32767.0, 2147483600.0,
+                    9223372000000000000.0],
+        "Int64": [I64MIN, -2147483648, -32768, -128, 0, 127, 32767, 2147483647, I64MAX],
+        "Int16": [N, N, -32768, -128, 0, 127, 32767, N, N],
+        "Int8": [N, N, N, -128, 0, 127, N, N, N],
+        "UInt64": [N, N, N, N, 0, 127, 32767, 2147483647, I64MAX],
+        "UInt32": [N, N, N, N, 0, 127, 32767, 2147483647, N],
+        "UInt16": [N, N, N, N, 0, 127, 32767, N, N]}),
+    ("test_cast_from_int32", "8592-8710", "Int32", [-2147483648, -32768, -128, 0, 127, 32767, 2147483647], {
+        "Float64": [-2147483648.0, -32768.0, -128.0, 0.0, 127.0, 32767.0, 2147483647.0],
+        "Float32": [-2147483600.0, -32768.0, -128.0, 0.0, 127.0, 32767.0, 2147483600.0],
+        "Int16": [N, -32768, -128, 0, 127, 32767, N],
+        "Int8": [N, N, -128, 0, 127, N, N],
+        "UInt64": [N, N, N, 0, 127, 32767, 2147483647],
+        "UInt32": [N, N, N, 0, 127, 32767, 2147483647],
+        "UInt16": [N, N, N, 0, 127, 32767, N],
+        "UInt8": [N, N, N, 0, 127, N, N]}),
+    ("test_cast_from_int16", "8712-8803", "Int16", [-32768, -128, 0, 127, 32767], {
+        "Float64": [-32768.0, -128.0, 0.0, 127.0, 32767.0], "Float32": [-32768.0, -128.0, 0.0, 127.0, 32767.0],
+        "Int64": [-32768, -128, 0, 127, 32767], "Int32": [-32768, -128, 0, 127, 32767],
+        "Int16": [-32768, -128, 0, 127, 32767], "Int8": [N, -128, 0, 127, N],
+        "UInt64": [N, N, 0, 127, 32767], "UInt32": [N, N, 0, 127, 32767], "UInt16": [N, N, 0, 127, 32767],
+        "UInt8": [N, N, 0, 127, N]}),
+    ("test_cast_from_int8", "8830-8958", "Int8", [-128, 0, 127], {
+        "Float64": [-128.0, 0.0, 127.0], "Float32": [-128.0, 0.0, 127.0],
+        "Int64": [-128, 0, 127], "Int32": [-128, 0, 127], "Int16": [-128, 0, 127], "Int8": [-128, 0, 127],
+        "UInt64": [N, 0, 127], "UInt32": [N, 0, 127], "UInt16": [N, 0, 127], "UInt8": [N, 0, 127]}),
+]
+for tname, lines, src_t, src, targets in CAST_MATRIX:
+    for to_t, exp in targets.items():
+        cast_cases.append(dict(name=f"{tname}_to_{to_t}", source=f"arrow-cast/src/cast/mod.rs:{lines}",
+                               values=arr(src_t, src), to=to_t, expected=arr(to_t, exp)))
+# test_cast_int32_to_u8_with_error (:4715): the unsafe form reports the first value that does not fit
+cast_cases.append(dict(name="test_cast_int32_to_u8_with_error", source="arrow-cast/src/cast/mod.rs:4713-4726 (#[should_panic(expected = ...)])",
+                       values=arr("Int32", [-5, 6, -7, 8, 100000000]), to="UInt8", safe=False, error="CastError",
+                       message="Can't cast value -5 to type UInt8"))
+cast_cases.append(dict(name="test_cast_i32_to_u8_sliced", source="arrow-cast/src/cast/mod.rs:4728-4739",
+                       values=arr("Int32", [-5, 6, -7, 8, 100000000], [2, 3]), to="UInt8",
+                       expected=arr("UInt8", [N, 8, N])))
+cast_cases.append(dict(name="test_cast_i32_to_i32", source="arrow-cast/src/cast/mod.rs:4742-4751",
+                       values=arr("Int32", [5, 6, 7, 8, 9]), to="Int32", expected=arr("Int32", [5, 6, 7, 8, 9])))
+# test_cast_bool_to_i32 / _to_f64 (:5006, :5046) and test_cast_i32_to_bool-style arms (cast/mod.rs:254-255)
+cast_cases.append(dict(name="test_cast_bool_to_i32", source="arrow-cast/src/cast/mod.rs:5006-5014",
+                       values=arr("Boolean", [T, F, N]), to="Int32", expected=arr("Int32", [1, 0, N])))
+cast_cases.append(dict(name="test_cast_bool_to_f64", source="arrow-cast/src/cast/mod.rs:5046-5054",
+                       values=arr("Boolean", [T, F, N]), to="Float64", expected=arr("Float64", [1.0, 0.0, N])))
 
 bool_cases = []
 A4, B4 = [F, F, T, T], [F, T, F, T]

@@ -21,7 +21,7 @@ TYPES = {t.name: t for t in [
     A.Float64, A.Utf8, A.LargeUtf8, A.Date32, A.Date64, A.Time32Second, A.Time32Millisecond,
     A.Time64Microsecond, A.Time64Nanosecond, A.DurationSecond, A.DurationMillisecond,
     A.DurationMicrosecond, A.DurationNanosecond, A.TimestampSecond, A.TimestampMillisecond,
-    A.TimestampMicrosecond, A.TimestampNanosecond]}
+    A.TimestampMicrosecond, A.TimestampNanosecond, A.Decimal128(10, 5)]}
 
 
 class HostArray:
@@ -61,6 +61,11 @@ class HostArray:
             vals = np.array([bool(x) if x is not None else False for x in items], dtype=bool)
         elif data_type.physical in (L.AH_UTF8, L.AH_LARGE_UTF8):
             vals = [x if x is not None else "" for x in items]
+        elif data_type.physical == L.AH_FIXED16:  # Decimal128: i128 little-endian as (lo: u64, hi: i64)
+            vals = np.zeros(len(items), dtype=data_type.np_dtype)
+            for i, x in enumerate(items):
+                x = 0 if x is None else int(x)
+                vals[i] = (x & 0xFFFFFFFFFFFFFFFF, x >> 64)
         else:
             def conv(x):
                 if x is None:

@@ -190,24 +190,29 @@ def test_arith_scalar_and_null_rules(oracle):
 
 
 # --------------------------------------------------------------------- cmp
+def _cmp_operand(case, side):
+    """(HostArray, is_scalar) of one side of a cmp golden: `lhs` / `rhs` arrays or `lhs_scalar` / `rhs_scalar`."""
+    if side + "_scalar" in case:
+        sc = case[side + "_scalar"]
+        return HostArray.from_pylist([sc["value"]], orc.TYPES[sc["type"]]), True
+    return golden_array(case[side]), False
+
+
 @pytest.mark.parametrize("case", load_golden("cmp"), ids=lambda c: c["name"])
 def test_cmp_golden(oracle, case):
-    l = golden_array(case["lhs"])
     op = CMP[case["op"]]
-    if "rhs_scalar" in case:
-        r = HostArray.from_pylist([case["rhs_scalar"]["value"]], orc.TYPES[case["rhs_scalar"]["type"]])
-        rs = True
-    else:
-        r, rs = golden_array(case["rhs"]), False
+    (l, ls), (r, rs) = _cmp_operand(case, "lhs"), _cmp_operand(case, "rhs")
     if "error" in case:
-        return expect_err(case, lambda: oracle.compare(op, l, r, r_scalar=rs))
+        return expect_err(case, lambda: oracle.compare(op, l, r, l_scalar=ls, r_scalar=rs))
     exp = golden_array(case["expected"])
-    assert_logical_eq(oracle.compare(op, l, r, r_scalar=rs), exp, case["name"])
-    if not rs:  # "larger x10 copy to cover the chunked part" (comparison.rs:146-161)
-        l10 = HostArray(l.data_type, np.tile(l.values, 10), None if l.valid is None else np.tile(l.valid, 10))
-        r10 = HostArray(r.data_type, np.tile(r.values, 10), None if r.valid is None else np.tile(r.valid, 10))
+    assert_logical_eq(oracle.compare(op, l, r, l_scalar=ls, r_scalar=rs), exp, case["name"])
+    if len(exp) and not (ls and rs):  # "larger x10 copy to cover the chunked part" (comparison.rs:146-161, :190-198)
+        def x10(h, is_scalar):
+            if is_scalar:
+                return h
+            return HostArray(h.data_type, np.tile(h.values, 10), None if h.valid is None else np.tile(h.valid, 10))
         e10 = HostArray(A.Boolean, np.tile(exp.values, 10), None if exp.valid is None else np.tile(exp.valid, 10))
-        assert_logical_eq(oracle.compare(op, l10, r10), e10, case["name"] + " x10")
+        assert_logical_eq(oracle.compare(op, x10(l, ls), x10(r, rs), l_scalar=ls, r_scalar=rs), e10, case["name"] + " x10")
 
 
 def test_cmp_total_order_and_distinct(oracle):
@@ -232,7 +237,9 @@ def test_cmp_total_order_and_distinct(oracle):
 @pytest.mark.parametrize("case", load_golden("cast"), ids=lambda c: c["name"])
 def test_cast_golden(oracle, case):
     v = golden_array(case["values"])
-    got = oracle.cast(v, orc.TYPES[case["to"]])
+    if "error" in case:
+        return expect_err(case, lambda: oracle.cast(v, orc.TYPES[case["to"]], safe=case.get("safe", True)))
+    got = oracle.cast(v, orc.TYPES[case["to"]], safe=case.get("safe", True))
     assert_logical_eq(got, golden_array(case["expected"]), case["name"])
 
 
