@@ -555,34 +555,52 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
 
   if (is_string) {  // filter_bytes (filter.rs:890-928): ranges of the selected rows -> new offsets + bytes
     const bool large = values->type == AH_LARGE_UTF8;
+    // Two primitive scatters over offsets[0..n) and offsets[1..n+1) give the selected rows' [start, end).
+    // The first one also carries the column's validity, so the null buffer is compacted by the same pass
+    // (filter_nulls :512-532) instead of a third walk over the predicate.  Both run deferred: the only
+    // host round trip of the string path is the byte total inside ah_ranges_to_strings.
     ah_array_view ov{};
     ov.type = large ? AH_INT64 : AH_INT32;
     ov.length = values->length;
     ov.values = values->offsets;
+    if (has_valid) {
+      ov.validity = values->validity;
+      ov.validity_bit_offset = values->validity_bit_offset;
+      ov.null_count = in_nulls;
+    }
     ah_array_out s_out{}, e_out{};
-    AH_TRY(ah_filter_predicate_apply(ctx, p, &ov, &s_out));
+    const bool was_deferred = ctx->deferred;
+    ctx->deferred = true;
+    ah_status st = ah_filter_predicate_apply(ctx, p, &ov, &s_out);
     ov.values = (const char*)values->offsets + (large ? 8 : 4);
-    ah_status st = ah_filter_predicate_apply(ctx, p, &ov, &e_out);
+    ov.validity = nullptr;
+    ov.null_count = 0;
+    if (st == AH_OK) st = ah_filter_predicate_apply(ctx, p, &ov, &e_out);
+    ctx->deferred = was_deferred;
     if (st == AH_OK)
       st = ah_ranges_to_strings(ctx, large, (const uint8_t*)values->values, s_out.values, e_out.values, K, false, out);
+    uint8_t* nb = s_out.validity;  // ownership moves to `out`
+    const size_t nbytes = (size_t)s_out.validity_bytes;
+    s_out.validity = nullptr;
+    s_out.validity_bytes = 0;
     ah_array_release(ctx, &s_out);
     ah_array_release(ctx, &e_out);
     if (st != AH_OK) {
+      ah_out_free(ctx, nb, nbytes);
       ah_out_init(out);
       return st;
     }
     out->type = values->type;
     out->length = K;
-    if (has_valid) {
-      uint8_t* nb = nullptr;
-      size_t nbytes = 0;
-      int64_t nset = 0;
-      st = compact_bits(ctx, p, vvalid, &nb, &nbytes, &nset);
+    if (nb) {
+      int64_t nset = 0;  // ah_ranges_to_strings synchronised the stream: the bitmap is complete
+      st = ah_count_set_bits(ctx, nb, 0, K, &nset);
       if (st != AH_OK) {
+        ah_out_free(ctx, nb, nbytes);
         ah_array_release(ctx, out);
         return st;
       }
-      if (K - nset == 0) ah_out_free(ctx, nb, nbytes);
+      if (K - nset == 0) ah_out_free(ctx, nb, nbytes);  // filter_nulls :523-525 -> None
       else {
         out->validity = nb;
         out->validity_bytes = (int64_t)nbytes;

@@ -134,38 +134,72 @@ __global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t* src, c
   }
 }
 
-// indices -> source ranges (take_bytes, take.rs:499-627).  Output nulls (when out_valid != nullptr)
-// produce empty ranges; a valid out-of-bounds index is reported through first_oob.
+// indices -> source ranges (take_bytes, take.rs:499-627) and, in the same pass, the output validity
+// (take_nulls, take.rs:418-430: index validity AND values.validity[index]) as one ballot word per wave.
+// Output nulls produce empty ranges (take.rs:553-577); a valid out-of-bounds index is reported through
+// first_oob.  counters[0] = first OOB position, counters[1] = number of valid output slots.
 template <typename OFF, typename IDX>
 __global__ void __launch_bounds__(256) take_ranges_kernel(const OFF* offsets, int64_t nvalues, const IDX* idx,
-                                                          int64_t n, const unsigned long long* out_valid,
-                                                          OFF* starts, OFF* ends, unsigned long long* first_oob) {
-  unsigned long long oob = ~0ull;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    OFF s = 0, e = 0;
-    bool live = !out_valid || ((out_valid[i >> 6] >> (i & 63)) & 1ull);
-    if (live) {
-      uint64_t ix;
-      IDX raw = idx[i];
-      if constexpr (sizeof(IDX) <= 2 && std::is_signed<IDX>::value) ix = (uint32_t)(int32_t)raw;
-      else if constexpr (sizeof(IDX) == 4) ix = (uint32_t)raw;
-      else ix = (uint64_t)raw;
-      if (ix >= (uint64_t)nvalues) {
-        if ((unsigned long long)i < oob) oob = (unsigned long long)i;
-      } else {
-        s = offsets[ix];
-        e = offsets[ix + 1];
+                                                          int64_t n, BitView ivalid, BitView vvalid,
+                                                          unsigned long long* out_valid, OFF* starts, OFF* ends,
+                                                          unsigned long long* counters) {
+  constexpr int KU = 4;  // independent gathers in flight per lane: the offsets pair and the validity bit of 4 rows
+  unsigned long long oob = ~0ull, nvalid = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t base = (int64_t)blockIdx.x * (256 * KU); base < n; base += (int64_t)gridDim.x * (256 * KU)) {
+    const int64_t wbase = base + wave * (64 * KU);
+    uint64_t ix[KU];
+    bool live[KU], inb[KU];
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int64_t i = wbase + k * 64 + lane;
+      live[k] = i < n && bv_get(ivalid, i);
+      ix[k] = 0;
+      if (live[k]) {
+        IDX raw = idx[i];
+        if constexpr (sizeof(IDX) <= 2 && std::is_signed<IDX>::value) ix[k] = (uint32_t)(int32_t)raw;
+        else if constexpr (sizeof(IDX) == 4) ix[k] = (uint32_t)raw;
+        else ix[k] = (uint64_t)raw;
+      }
+      inb[k] = ix[k] < (uint64_t)nvalues;
+    }
+    OFF s[KU], e[KU];
+    int vb[KU];
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {  // the three gathers of a row do not depend on each other
+      s[k] = 0;
+      e[k] = 0;
+      vb[k] = 0;
+      if (live[k] && inb[k]) {
+        s[k] = offsets[ix[k]];
+        e[k] = offsets[ix[k] + 1];
+        vb[k] = bv_get(vvalid, (int64_t)ix[k]);
       }
     }
-    starts[i] = s;
-    ends[i] = e;
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int64_t i = wbase + k * 64 + lane;
+      if (live[k] && !inb[k] && (unsigned long long)i < oob) oob = (unsigned long long)i;
+      if (i < n) {
+        starts[i] = vb[k] ? s[k] : (OFF)0;
+        ends[i] = vb[k] ? e[k] : (OFF)0;
+      }
+      const unsigned long long w = __ballot(vb[k]);
+      if (lane == 0 && wbase + k * 64 < n) {
+        if (out_valid) out_valid[(wbase + k * 64) >> 6] = w;
+        nvalid += __popcll(w);
+      }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     unsigned long long other = __shfl_xor(oob, o, 64);
     oob = other < oob ? other : oob;
   }
-  if ((threadIdx.x & 63) == 0 && oob != ~0ull) atomicMin(first_oob, oob);
+  if (lane == 0) {
+    if (oob != ~0ull) atomicMin(&counters[0], oob);
+    if (nvalid) atomicAdd(&counters[1], nvalid);
+  }
 }
 
 template <typename OFF>
@@ -233,12 +267,12 @@ ah_status ranges_to_strings_t(ah_context* ctx, const uint8_t* src, const OFF* st
 
 template <typename OFF>
 ah_status launch_take_ranges(ah_context* ctx, const ah_array_view* values, const ah_array_view* indices,
-                             const unsigned long long* out_valid, OFF* starts, OFF* ends,
-                             unsigned long long* first_oob) {
+                             BitView ivalid, BitView vvalid, unsigned long long* out_valid, OFF* starts, OFF* ends,
+                             unsigned long long* counters) {
   const int64_t n = indices->length;
-  int g = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(n, 256), 8192));
+  int g = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(n, 1024), 8192));
   const OFF* off = (const OFF*)values->offsets;
-#define AH_TR(IDX) take_ranges_kernel<OFF, IDX><<<g, 256, 0, ctx->stream>>>(off, values->length, (const IDX*)indices->values, n, out_valid, starts, ends, first_oob)
+#define AH_TR(IDX) take_ranges_kernel<OFF, IDX><<<g, 256, 0, ctx->stream>>>(off, values->length, (const IDX*)indices->values, n, ivalid, vvalid, out_valid, starts, ends, counters)
   switch (indices->type) {
     case AH_INT8: AH_TR(int8_t); break;
     case AH_UINT8: AH_TR(uint8_t); break;
@@ -292,48 +326,21 @@ ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_a
     return AH_OK;
   }
   if (!values->offsets) return ah_fail(ctx, AH_INVALID_ARGUMENT, "string array view without offsets");
-  // take_nulls (take.rs:418-430) through the Boolean take kernel on the validity bits
+  // take_nulls (take.rs:418-430) is fused into the ranges pass: one kernel gathers the offsets pair and the
+  // validity bit of each index, one 16-byte read-back brings the first OOB position and the valid count
   int64_t val_nulls = 0, idx_nulls = 0;
   AH_TRY(ah_resolve_null_count(ctx, values, &val_nulls));
   AH_TRY(ah_resolve_null_count(ctx, indices, &idx_nulls));
-  ah_array_out nb{};
+  const bool values_nullable = values->validity && val_nulls > 0;
+  const BitView none{nullptr, 0};
+  const BitView ivalid = (indices->validity && idx_nulls > 0) ? make_bitview(indices->validity, indices->validity_bit_offset) : none;
+  const BitView vvalid = values_nullable ? make_bitview(values->validity, values->validity_bit_offset) : none;
   uint8_t* out_valid = nullptr;
   size_t vbytes = 0;
-  int64_t out_nulls = 0;
-  if (values->validity && val_nulls > 0) {
-    ah_array_view bits{};
-    bits.type = AH_BOOL;
-    bits.length = values->length;
-    bits.values = values->validity;
-    bits.values_bit_offset = values->validity_bit_offset;
-    ah_status st = ah_take(ctx, &bits, indices, 0, &nb);  // OOB -> "assertion failed: idx < self.bit_len"
-    if (st != AH_OK) return st;
-    int64_t set = 0;
-    st = ah_count_set_bits(ctx, (const uint8_t*)nb.values, 0, n, &set);
-    if (st != AH_OK) {
-      ah_array_release(ctx, &nb);
-      return st;
-    }
-    out_nulls = n - set;
-    if (out_nulls > 0) {  // keep the value bits as the output validity
-      out_valid = (uint8_t*)nb.values;
-      vbytes = (size_t)nb.values_bytes;
-      nb.values = nullptr;
-    }
-    ah_array_release(ctx, &nb);
-  } else if (indices->validity) {  // indices.nulls().cloned()
+  if (values_nullable || indices->validity) {
     vbytes = ah_bitmap_bytes(n);
     AH_TRY(ah_out_alloc(ctx, vbytes, (void**)&out_valid));
-    int64_t set = 0;
-    ah_status st = ah_bitmap_op(ctx, BM_COPY, make_bitview(indices->validity, indices->validity_bit_offset),
-                                BitView{nullptr, 0}, BitView{nullptr, 0}, n, (unsigned long long*)out_valid, &set);
-    if (st != AH_OK) {
-      ah_out_free(ctx, out_valid, vbytes);
-      return st;
-    }
-    out_nulls = n - set;
   }
-  // ranges: only valid output slots are visited when the output has nulls (take.rs:553-577)
   char* tmp = nullptr;
   ah_status st = ah_pool_alloc(ctx, 2 * (size_t)n * ow + 16, (void**)&tmp);
   if (st != AH_OK) {
@@ -342,37 +349,45 @@ ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_a
   }
   void* starts = tmp;
   void* ends = tmp + (((size_t)n * ow + 7) & ~(size_t)7);
-  unsigned long long* first_oob = nullptr;
-  st = ah_pool_alloc(ctx, 8, (void**)&first_oob);
+  unsigned long long* counters = nullptr;
+  st = ah_pool_alloc(ctx, 16, (void**)&counters);
   if (st == AH_OK) {
-    hipMemsetAsync(first_oob, 0xFF, 8, ctx->stream);
-    const unsigned long long* ov = out_nulls > 0 ? (const unsigned long long*)out_valid : nullptr;
+    hipMemsetAsync(counters, 0xFF, 8, ctx->stream);
+    hipMemsetAsync(counters + 1, 0, 8, ctx->stream);
     ah_prof_scope ps(ctx, "string_take_ranges");
-    st = large ? launch_take_ranges<int64_t>(ctx, values, indices, ov, (int64_t*)starts, (int64_t*)ends, first_oob)
-               : launch_take_ranges<int32_t>(ctx, values, indices, ov, (int32_t*)starts, (int32_t*)ends, first_oob);
+    st = large ? launch_take_ranges<int64_t>(ctx, values, indices, ivalid, vvalid, (unsigned long long*)out_valid,
+                                             (int64_t*)starts, (int64_t*)ends, counters)
+               : launch_take_ranges<int32_t>(ctx, values, indices, ivalid, vvalid, (unsigned long long*)out_valid,
+                                             (int32_t*)starts, (int32_t*)ends, counters);
   }
   if (st == AH_OK) {
-    hipError_t e = hipMemcpyAsync(ctx->pinned + 16, first_oob, 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipMemcpyAsync(ctx->pinned + 16, counters, 16, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "take ranges failed: %s", hipGetErrorString(e));
   }
-  ah_pool_free(ctx, first_oob);
+  ah_pool_free(ctx, counters);
+  const int64_t out_nulls = st == AH_OK ? n - (int64_t)ctx->pinned[17] : 0;
   if (st == AH_OK && ctx->pinned[16] != ~0ull) {
-    // `input_offsets[index]` / `input_offsets[index + 1]` bounds panic (take.rs:518-519): the slice
-    // has values.len()+1 entries, so index == len passes the first access and fails the second
-    int w = ah_type_width(indices->type);
-    uint64_t raw = 0;
-    hipMemcpy(&raw, (const char*)indices->values + (int64_t)ctx->pinned[16] * w, w, hipMemcpyDeviceToHost);
-    uint64_t ix;
-    switch (indices->type) {
-      case AH_INT8: ix = (uint32_t)(int32_t)(int8_t)raw; break;
-      case AH_INT16: ix = (uint32_t)(int32_t)(int16_t)raw; break;
-      case AH_INT32: ix = (uint32_t)raw; break;
-      default: ix = raw; break;
+    if (values_nullable) {
+      // take_nulls runs first in the reference: take_bits -> BooleanBuffer::value asserts (boolean.rs:495)
+      st = ah_fail(ctx, AH_PANIC, "assertion failed: idx < self.bit_len");
+    } else {
+      // `input_offsets[index]` / `input_offsets[index + 1]` bounds panic (take.rs:518-519): the slice
+      // has values.len()+1 entries, so index == len passes the first access and fails the second
+      int w = ah_type_width(indices->type);
+      uint64_t raw = 0;
+      hipMemcpy(&raw, (const char*)indices->values + (int64_t)ctx->pinned[16] * w, w, hipMemcpyDeviceToHost);
+      uint64_t ix;
+      switch (indices->type) {
+        case AH_INT8: ix = (uint32_t)(int32_t)(int8_t)raw; break;
+        case AH_INT16: ix = (uint32_t)(int32_t)(int16_t)raw; break;
+        case AH_INT32: ix = (uint32_t)raw; break;
+        default: ix = raw; break;
+      }
+      uint64_t bad = ix == (uint64_t)values->length ? ix + 1 : ix;
+      st = ah_fail(ctx, AH_PANIC, "index out of bounds: the len is %lld but the index is %llu",
+                   (long long)values->length + 1, (unsigned long long)bad);
     }
-    uint64_t bad = ix == (uint64_t)values->length ? ix + 1 : ix;
-    st = ah_fail(ctx, AH_PANIC, "index out of bounds: the len is %lld but the index is %llu",
-                 (long long)values->length + 1, (unsigned long long)bad);
   }
   if (st == AH_OK) st = ah_ranges_to_strings(ctx, large, (const uint8_t*)values->values, starts, ends, n, true, out);
   ah_pool_free(ctx, tmp);
@@ -381,7 +396,7 @@ ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_a
     return st;
   }
   out->length = n;
-  if (out_valid && (out_nulls > 0 || !(values->validity && val_nulls > 0))) {
+  if (out_valid && (out_nulls > 0 || !values_nullable)) {  // take_nulls drops an all-valid result; index nulls are cloned
     out->validity = out_valid;
     out->validity_bytes = (int64_t)vbytes;
     out->null_count = out_nulls;
