@@ -7,7 +7,7 @@ from .kernels.numeric import (add, add_wrapping, sub, sub_wrapping, mul, mul_wra
                               neg, neg_wrapping)
 from .kernels.cmp import eq, neq, lt, lt_eq, gt, gt_eq, distinct, not_distinct  # noqa: F401
 from .kernels.cast import cast, cast_with_options, can_cast_types, CastOptions  # noqa: F401
-from .kernels.concat import concat  # noqa: F401
+from .kernels.concat import concat, concat_batches  # noqa: F401
 from .kernels.boolean import (and_, or_, and_not, and_kleene, or_kleene, not_, is_null, is_not_null, nullif)  # noqa: F401
 from .kernels.coalesce import BatchCoalescer  # noqa: F401
 from .kernels import aggregate  # noqa: F401  (sum/min/max shadow builtins: use ``compute.aggregate.sum`` …)

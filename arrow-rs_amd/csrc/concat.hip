@@ -10,6 +10,8 @@
 // arrow-buffer/src/util/bit_mask.rs:33 set_bits).
 #include "common.hpp"
 
+#include <algorithm>
+
 #include <vector>
 
 namespace {
@@ -120,11 +122,24 @@ extern "C" ah_status ah_concat(ah_context* ctx, int32_t n, const ah_array_view* 
     return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "concat not supported for type %s", ah_type_name(t));
   int64_t total = 0;
   bool any_nulls = false;
+  for (int i = 1; i < n; ++i) {
+    if (pieces[i].type == t) continue;
+    // concat.rs:505-535: up to 10 unique data types in order of appearance, ", ..." once an 11th shows up
+    std::string msg = std::string("It is not possible to concatenate arrays of different data types (") + ah_type_name(t);
+    std::vector<int32_t> seen{(int32_t)t};
+    for (int j = 0; j < n; ++j) {
+      const bool unique = std::find(seen.begin(), seen.end(), (int32_t)pieces[j].type) == seen.end();
+      if (unique) seen.push_back((int32_t)pieces[j].type);
+      if (seen.size() == 11) {
+        msg += ", ...";
+        break;
+      }
+      if (unique) msg += std::string(", ") + ah_type_name(pieces[j].type);
+    }
+    msg += ").";
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "%s", msg.c_str());
+  }
   for (int i = 0; i < n; ++i) {
-    if (pieces[i].type != t)
-      return ah_fail(ctx, AH_INVALID_ARGUMENT,
-                     "It is not possible to concatenate arrays of different data types (%s, %s).",
-                     ah_type_name(t), ah_type_name(pieces[i].type));
     total += pieces[i].length;
     int64_t nulls = 0;
     AH_TRY(ah_resolve_null_count(ctx, &pieces[i], &nulls));

@@ -318,6 +318,24 @@ inline ArrayRef concat(const std::vector<ArrayRef>& arrays) {
   return wrap(arrays[0], out);
 }
 
+// concat_batches (arrow-select/src/concat.rs:607): column i = concat of the batches' i-th columns; with no
+// columns the row counts are summed (:612-617)
+inline RecordBatch concat_batches(size_t n_fields, const std::vector<const RecordBatch*>& batches) {
+  RecordBatch out;
+  if (n_fields == 0) {
+    for (auto* b : batches) out.num_rows += b->num_rows;
+    return out;
+  }
+  if (batches.empty()) return out;
+  for (size_t i = 0; i < n_fields; ++i) {
+    std::vector<ArrayRef> col;
+    for (auto* b : batches) col.push_back(b->columns.at(i));
+    out.columns.push_back(concat(col));
+  }
+  out.num_rows = out.columns[0]->len();
+  return out;
+}
+
 // ---- aggregate (arrow-arith/src/aggregate.rs): std::optional<T> mirrors Option<T::Native>
 template <typename T> inline std::optional<T> aggregate(ah_agg_op op, const ArrayRef& a) {
   ah_scalar s;

@@ -2336,10 +2336,24 @@ int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out) {
   if (w < 0 && !is_str) return fail(ORC_NOT_YET_IMPLEMENTED, "concat not supported for type %s", type_name(t));
   int64_t total = 0;
   bool any_valid_buf = false;
+  for (int i = 1; i < n; ++i) {
+    if (pieces[i].type == t) continue;
+    // concat.rs:505-535: up to 10 unique data types in order of appearance, ", ..." once an 11th shows up
+    std::string msg = std::string("It is not possible to concatenate arrays of different data types (") + type_name(t);
+    std::vector<int32_t> seen{t};
+    for (int j = 0; j < n; ++j) {
+      const bool unique = std::find(seen.begin(), seen.end(), pieces[j].type) == seen.end();
+      if (unique) seen.push_back(pieces[j].type);
+      if (seen.size() == 11) {
+        msg += ", ...";
+        break;
+      }
+      if (unique) msg += std::string(", ") + type_name(pieces[j].type);
+    }
+    msg += ").";
+    return fail(ORC_INVALID_ARGUMENT, "%s", msg.c_str());
+  }
   for (int i = 0; i < n; ++i) {
-    if (pieces[i].type != t)
-      return fail(ORC_INVALID_ARGUMENT, "It is not possible to concatenate arrays of different data types (%s, %s).",
-                  type_name(t), type_name(pieces[i].type));
     total += pieces[i].length;
     // NullBufferBuilder: a buffer materialises only if some piece has nulls
     if (pieces[i].validity && resolve_nulls(&pieces[i]) > 0) any_valid_buf = true;

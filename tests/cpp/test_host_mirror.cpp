@@ -215,6 +215,20 @@ int main() {
     assert((download<int64_t>(selection::boundaries(sel)) == std::vector<int64_t>{1, 2, 4, 5}));
   }
 
+  // concat_batches (concat.rs:607)
+  {
+    RecordBatch r1, r2;
+    r1.columns = {upload<int32_t>(ctx, AH_INT32, {1, 2}, nullptr, keep)};
+    r1.num_rows = 2;
+    r2.columns = {upload<int32_t>(ctx, AH_INT32, {3, 4}, nullptr, keep)};
+    r2.num_rows = 2;
+    auto cb = compute::concat_batches(1, {&r1, &r2});
+    assert(cb.num_rows == 4 && (download<int32_t>(cb.columns[0]) == std::vector<int32_t>{1, 2, 3, 4}));
+    RecordBatch n1, n2;
+    n1.num_rows = n2.num_rows = 100;
+    assert(compute::concat_batches(0, {&n1, &n2}).num_rows == 200);
+  }
+
   // deferred mode: kernels only enqueue, results chain on the stream, null_count() counts lazily
   {
     const std::vector<bool> v1{true, false, true, true}, v2{true, true, false, true};

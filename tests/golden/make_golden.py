@@ -675,6 +675,33 @@ concat_cases = [
     dict(name="test_concat_boolean_primitive_arrays", source="arrow-select/src/concat.rs:930-958",
          pieces=[arr("Boolean", [T, T, F, N, N, F]), arr("Boolean", [N, F, T, F])],
          expected=arr("Boolean", [T, T, F, N, N, F, N, F, T, F])),
+    dict(name="test_concat_incompatible_datatypes", source="arrow-select/src/concat.rs:731-746",
+         pieces=[arr("Int64", [-1, 2, N]), arr("Utf8", ["hello", "bar", "world"]), arr("Utf8", ["hey", "", "you"]),
+                 arr("Int32", [-1, 2, N])], error="InvalidArgumentError",
+         message="It is not possible to concatenate arrays of different data types (Int64, Utf8, Int32)."),
+    dict(name="test_concat_10_incompatible_datatypes_should_include_all_of_them", source="arrow-select/src/concat.rs:749-772",
+         pieces=[arr("Int64", [-1, 2, N]), arr("Utf8", ["hello", "bar", "world"]), arr("Utf8", ["hey", "", "you"]),
+                 arr("Int32", [-1, 2, N]), arr("Int8", [-1, 2, N]), arr("Int16", [-1, 2, N]), arr("UInt8", [1, 2, N]),
+                 arr("UInt16", [1, 2, N]), arr("UInt32", [1, 2, N]), arr("UInt16", [1, 2, N]), arr("UInt64", [1, 2, N]),
+                 arr("Float32", [1.0, 2.0, N])], error="InvalidArgumentError",
+         message="It is not possible to concatenate arrays of different data types (Int64, Utf8, Int32, Int8, Int16, UInt8, "
+                 "UInt16, UInt32, UInt64, Float32)."),
+    dict(name="test_concat_11_incompatible_datatypes_should_only_include_10", source="arrow-select/src/concat.rs:775-799",
+         pieces=[arr("Int64", [-1, 2, N]), arr("Utf8", ["hello", "bar", "world"]), arr("Utf8", ["hey", "", "you"]),
+                 arr("Int32", [-1, 2, N]), arr("Int8", [-1, 2, N]), arr("Int16", [-1, 2, N]), arr("UInt8", [1, 2, N]),
+                 arr("UInt16", [1, 2, N]), arr("UInt32", [1, 2, N]), arr("UInt16", [1, 2, N]), arr("UInt64", [1, 2, N]),
+                 arr("Float32", [1.0, 2.0, N]), arr("Float64", [1.0, 2.0, N])], error="InvalidArgumentError",
+         message="It is not possible to concatenate arrays of different data types (Int64, Utf8, Int32, Int8, Int16, UInt8, "
+                 "UInt16, UInt32, UInt64, Float32, ...)."),
+    dict(name="test_concat_13_incompatible_datatypes_should_not_include_all_of_them",
+         source="arrow-select/src/concat.rs:803-829 (Float16 piece replaced by LargeUtf8: the message stops before it either way)",
+         pieces=[arr("Int64", [-1, 2, N]), arr("Utf8", ["hello", "bar", "world"]), arr("Utf8", ["hey", "", "you"]),
+                 arr("Int32", [-1, 2, N]), arr("Int8", [-1, 2, N]), arr("Int16", [-1, 2, N]), arr("UInt8", [1, 2, N]),
+                 arr("UInt16", [1, 2, N]), arr("UInt32", [1, 2, N]), arr("UInt16", [1, 2, N]), arr("UInt64", [1, 2, N]),
+                 arr("Float32", [1.0, 2.0, N]), arr("Float64", [1.0, 2.0, N]), arr("LargeUtf8", [N, N, N]),
+                 arr("Boolean", [T, F, N])], error="InvalidArgumentError",
+         message="It is not possible to concatenate arrays of different data types (Int64, Utf8, Int32, Int8, Int16, UInt8, "
+                 "UInt16, UInt32, UInt64, Float32, ...)."),
     dict(name="string_slices", source="arrow-select/src/concat.rs:1140-1170 (test_string_array_slices recipe)",
          pieces=[arr("Utf8", ["hello", "A", "B", "C"], [1, 3]), arr("Utf8", ["D", "E", N, "F"], [2, 2])],
          expected=arr("Utf8", ["A", "B", "C", N, "F"])),

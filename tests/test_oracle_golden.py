@@ -472,6 +472,8 @@ def test_selection_and_then_fuzz_recipe(oracle):
 # ------------------------------------------------------------------- concat
 @pytest.mark.parametrize("case", load_golden("concat"), ids=lambda c: c["name"])
 def test_concat_golden(oracle, case):
+    if "error" in case:
+        return expect_err(case, lambda: oracle.concat([golden_array(p) for p in case["pieces"]]))
     got = oracle.concat([golden_array(p) for p in case["pieces"]])
     assert_logical_eq(got, golden_array(case["expected"]), case["name"])
 
