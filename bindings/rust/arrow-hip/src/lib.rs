@@ -1,0 +1,373 @@
+//! arrow-hip — `arrow::compute::kernels`-shaped functions whose arrays live in MI355X HBM.
+//!
+//! NOT COMPILED in the image this repository is developed in (no Rust toolchain there); see ../README.md.
+//! Every function is a thin call into `libarrow_hip.so` (declarations: `arrow-hip-sys`, generated from
+//! `include/arrow_hip.h`).  Names, argument order and error behaviour follow the reference:
+//!
+//! | here | reference |
+//! |---|---|
+//! | [`filter`], [`FilterPredicate`] | `arrow_select::filter::{filter, FilterBuilder, FilterPredicate}` (arrow-select/src/filter.rs:201,:248) |
+//! | [`take`] | `arrow_select::take::take` (arrow-select/src/take.rs:89) |
+//! | [`add`], [`add_wrapping`], … [`rem`], [`neg`] | `arrow_arith::numeric` (arrow-arith/src/numeric.rs:36-186) |
+//! | [`eq`] … [`not_distinct`] | `arrow_ord::cmp` (arrow-ord/src/cmp.rs:79-202) |
+//! | [`cast`], [`cast_with_options`] | `arrow_cast::cast` (arrow-cast/src/cast/mod.rs:347,:790) |
+//! | [`and`], [`or`], [`not`], [`is_null`], … | `arrow_arith::boolean` (arrow-arith/src/boolean.rs:60-360) |
+//! | [`concat`] | `arrow_select::concat::concat` (arrow-select/src/concat.rs:495) |
+//! | [`DeviceArray::from_host`], [`DeviceArray::to_host`] | `arrow::ffi::{to_ffi, from_ffi}` (arrow-array/src/ffi.rs:231-254) |
+use std::ffi::CStr;
+use std::mem::MaybeUninit;
+use std::ptr;
+use std::sync::Arc;
+
+use arrow::array::{make_array, Array, ArrayData, ArrayRef};
+use arrow::datatypes::DataType;
+use arrow::error::ArrowError;
+use arrow::ffi::{from_ffi, to_ffi, FFI_ArrowArray, FFI_ArrowSchema};
+use arrow_hip_sys as sys;
+
+/// One HIP stream + pooled HBM allocator on one GPU; use one per calling thread.
+pub struct Context {
+    raw: *mut sys::ah_context,
+}
+
+// the library serialises nothing: a context is used by one thread at a time
+unsafe impl Send for Context {}
+
+impl Context {
+    pub fn new(device: i32) -> Result<Arc<Self>, ArrowError> {
+        let mut raw = ptr::null_mut();
+        let st = unsafe { sys::ah_context_create(device, &mut raw) };
+        if st != sys::AH_OK {
+            return Err(ArrowError::ExternalError(
+                format!("ah_context_create(device={device}) failed with status {st}: no usable MI355X").into(),
+            ));
+        }
+        Ok(Arc::new(Self { raw }))
+    }
+
+    /// Opt-in asynchronous calls (`ah_context_set_deferred`, include/arrow_hip.h).
+    pub fn set_deferred(&self, on: bool) {
+        unsafe { sys::ah_context_set_deferred(self.raw, on as i32) }
+    }
+
+    pub fn synchronize(&self) -> Result<(), ArrowError> {
+        self.check(unsafe { sys::ah_synchronize(self.raw) })
+    }
+
+    fn message(&self) -> String {
+        unsafe { CStr::from_ptr(sys::ah_last_error(self.raw)) }.to_string_lossy().into_owned()
+    }
+
+    /// status -> `ArrowError` with the reference's message text; reference panics stay panics.
+    fn check(&self, st: sys::ah_status) -> Result<(), ArrowError> {
+        match st {
+            sys::AH_OK => Ok(()),
+            sys::AH_INVALID_ARGUMENT => Err(ArrowError::InvalidArgumentError(self.message())),
+            sys::AH_COMPUTE_ERROR => Err(ArrowError::ComputeError(self.message())),
+            sys::AH_ARITHMETIC_OVERFLOW => Err(ArrowError::ArithmeticOverflow(self.message())),
+            sys::AH_DIVIDE_BY_ZERO => Err(ArrowError::DivideByZero),
+            sys::AH_CAST_ERROR => Err(ArrowError::CastError(self.message())),
+            sys::AH_NOT_YET_IMPLEMENTED => Err(ArrowError::NotYetImplemented(self.message())),
+            sys::AH_OFFSET_OVERFLOW_ERROR => {
+                Err(ArrowError::OffsetOverflowError(self.message().parse().unwrap_or(usize::MAX)))
+            }
+            sys::AH_C_DATA_INTERFACE => Err(ArrowError::CDataInterface(self.message())),
+            sys::AH_IPC_ERROR => Err(ArrowError::IpcError(self.message())),
+            sys::AH_PARSE_ERROR => Err(ArrowError::ParseError(self.message())),
+            sys::AH_OFFSET_OVERFLOW | sys::AH_PANIC => panic!("{}", self.message()),
+            _ => Err(ArrowError::ExternalError(self.message().into())),
+        }
+    }
+}
+
+impl Drop for Context {
+    fn drop(&mut self) {
+        unsafe { sys::ah_context_destroy(self.raw) }
+    }
+}
+
+/// An array whose buffers live in HBM.  Owns an `ah_array_out`; the logical `DataType` travels on the host
+/// exactly as the reference carries `data_type` through filter / take (filter.rs:783-787, take.rs:414).
+pub struct DeviceArray {
+    ctx: Arc<Context>,
+    out: sys::ah_array_out,
+    data_type: DataType,
+    /// inputs a zero-copy result still points into (AH_OUT_BORROWED / AH_OUT_BORROWED_VALUES)
+    _keep: Vec<Arc<DeviceArray>>,
+}
+
+impl Drop for DeviceArray {
+    fn drop(&mut self) {
+        unsafe { sys::ah_array_release(self.ctx.raw, &mut self.out) }
+    }
+}
+
+impl DeviceArray {
+    pub fn len(&self) -> usize {
+        self.out.length as usize
+    }
+
+    pub fn is_empty(&self) -> bool {
+        self.out.length == 0
+    }
+
+    pub fn data_type(&self) -> &DataType {
+        &self.data_type
+    }
+
+    /// `Array::null_count`; a deferred result (-1) is counted on first use.
+    pub fn null_count(&mut self) -> Result<usize, ArrowError> {
+        if self.out.null_count < 0 {
+            self.ctx.check(unsafe { sys::ah_array_resolve(self.ctx.raw, &mut self.out) })?;
+        }
+        Ok(self.out.null_count as usize)
+    }
+
+    fn view(&self) -> sys::ah_array_view {
+        sys::ah_array_view {
+            type_: self.out.type_,
+            length: self.out.length,
+            null_count: if self.out.validity.is_null() { 0 } else { self.out.null_count },
+            values: self.out.values,
+            values_bit_offset: self.out.values_bit_offset,
+            validity: self.out.validity,
+            validity_bit_offset: self.out.validity_bit_offset,
+            offsets: self.out.offsets,
+        }
+    }
+
+    /// Host array -> HBM through the C Data Interface (`to_ffi`, then `ah_import_c_data` = `from_ffi` on the device).
+    pub fn from_host(ctx: &Arc<Context>, array: &dyn Array) -> Result<Arc<Self>, ArrowError> {
+        let (ffi_array, ffi_schema) = to_ffi(&array.to_data())?;
+        let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+        ctx.check(unsafe {
+            sys::ah_import_c_data(
+                ctx.raw,
+                &ffi_array as *const FFI_ArrowArray as *const sys::ArrowArray,
+                &ffi_schema as *const FFI_ArrowSchema as *const sys::ArrowSchema,
+                out.as_mut_ptr(),
+            )
+        })?;
+        Ok(Arc::new(Self { ctx: ctx.clone(), out: unsafe { out.assume_init() }, data_type: array.data_type().clone(), _keep: vec![] }))
+    }
+
+    /// HBM -> host array (`ah_export_c_data` fills FFI structs whose release callbacks free the host copies).
+    pub fn to_host(&self) -> Result<ArrayRef, ArrowError> {
+        let schema = FFI_ArrowSchema::try_from(&self.data_type)?;
+        let (mut out_array, mut out_schema) = (FFI_ArrowArray::empty(), FFI_ArrowSchema::empty());
+        let view = self.view();
+        self.ctx.check(unsafe {
+            sys::ah_export_c_data(
+                self.ctx.raw,
+                &view,
+                schema.format().as_ptr() as *const _,
+                &mut out_array as *mut FFI_ArrowArray as *mut sys::ArrowArray,
+                &mut out_schema as *mut FFI_ArrowSchema as *mut sys::ArrowSchema,
+            )
+        })?;
+        let data: ArrayData = unsafe { from_ffi(out_array, &out_schema)? };
+        Ok(make_array(data))
+    }
+}
+
+fn wrap(like: &Arc<DeviceArray>, out: sys::ah_array_out, data_type: DataType, inputs: &[&Arc<DeviceArray>]) -> Arc<DeviceArray> {
+    let borrowed = out.flags & (sys::AH_OUT_BORROWED | sys::AH_OUT_BORROWED_VALUES) != 0;
+    let keep = if borrowed { inputs.iter().map(|a| (*a).clone()).collect() } else { vec![] };
+    Arc::new(DeviceArray { ctx: like.ctx.clone(), out, data_type, _keep: keep })
+}
+
+/// `Datum::get()` (arrow-array/src/scalar.rs:78-98): an array, or a length-1 array standing for a scalar.
+pub enum Datum<'a> {
+    Array(&'a Arc<DeviceArray>),
+    Scalar(&'a Arc<DeviceArray>),
+}
+
+impl<'a> Datum<'a> {
+    fn get(&self) -> (&'a Arc<DeviceArray>, i32) {
+        match self {
+            Datum::Array(a) => (a, 0),
+            Datum::Scalar(a) => (a, 1),
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- filter / take
+/// `arrow_select::filter::filter` (filter.rs:201)
+pub fn filter(values: &Arc<DeviceArray>, predicate: &Arc<DeviceArray>) -> Result<Arc<DeviceArray>, ArrowError> {
+    let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+    let (v, p) = (values.view(), predicate.view());
+    values.ctx.check(unsafe { sys::ah_filter(values.ctx.raw, &v, &p, out.as_mut_ptr()) })?;
+    Ok(wrap(values, unsafe { out.assume_init() }, values.data_type.clone(), &[values]))
+}
+
+/// `FilterBuilder::new(p).optimize().build()` (filter.rs:256-324): count once, apply to many columns.
+pub struct FilterPredicate {
+    ctx: Arc<Context>,
+    raw: *mut sys::ah_filter_predicate,
+    _mask: Arc<DeviceArray>,
+}
+
+impl FilterPredicate {
+    pub fn new(predicate: &Arc<DeviceArray>) -> Result<Self, ArrowError> {
+        let mut raw = ptr::null_mut();
+        let p = predicate.view();
+        predicate.ctx.check(unsafe { sys::ah_filter_predicate_build(predicate.ctx.raw, &p, &mut raw) })?;
+        Ok(Self { ctx: predicate.ctx.clone(), raw, _mask: predicate.clone() })
+    }
+
+    /// `FilterPredicate::count` (filter.rs:481)
+    pub fn count(&self) -> usize {
+        unsafe { sys::ah_filter_predicate_count(self.raw) as usize }
+    }
+
+    /// `FilterPredicate::filter` (filter.rs:473)
+    pub fn filter(&self, values: &Arc<DeviceArray>) -> Result<Arc<DeviceArray>, ArrowError> {
+        let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+        let v = values.view();
+        self.ctx.check(unsafe { sys::ah_filter_predicate_apply(self.ctx.raw, self.raw, &v, out.as_mut_ptr()) })?;
+        Ok(wrap(values, unsafe { out.assume_init() }, values.data_type.clone(), &[values]))
+    }
+}
+
+impl Drop for FilterPredicate {
+    fn drop(&mut self) {
+        unsafe { sys::ah_filter_predicate_free(self.ctx.raw, self.raw) }
+    }
+}
+
+/// `TakeOptions { check_bounds }` (take.rs:388)
+#[derive(Default, Clone, Copy)]
+pub struct TakeOptions {
+    pub check_bounds: bool,
+}
+
+/// `arrow_select::take::take` (take.rs:89)
+pub fn take(values: &Arc<DeviceArray>, indices: &Arc<DeviceArray>, options: Option<TakeOptions>) -> Result<Arc<DeviceArray>, ArrowError> {
+    let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+    let (v, i) = (values.view(), indices.view());
+    let check = options.unwrap_or_default().check_bounds as i32;
+    values.ctx.check(unsafe { sys::ah_take(values.ctx.raw, &v, &i, check, out.as_mut_ptr()) })?;
+    Ok(wrap(values, unsafe { out.assume_init() }, values.data_type.clone(), &[values]))
+}
+
+// ------------------------------------------------------------------------------------------- numeric / cmp
+fn arith(op: i32, lhs: &Datum, rhs: &Datum) -> Result<Arc<DeviceArray>, ArrowError> {
+    let ((l, ls), (r, rs)) = (lhs.get(), rhs.get());
+    let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+    let (lv, rv) = (l.view(), r.view());
+    l.ctx.check(unsafe { sys::ah_arith_binary(l.ctx.raw, op, &lv, ls, &rv, rs, out.as_mut_ptr()) })?;
+    Ok(wrap(l, unsafe { out.assume_init() }, l.data_type.clone(), &[]))
+}
+
+macro_rules! arith_fn {
+    ($($(#[$doc:meta])* $name:ident => $op:ident),* $(,)?) => {$(
+        $(#[$doc])*
+        pub fn $name(lhs: &Datum, rhs: &Datum) -> Result<Arc<DeviceArray>, ArrowError> { arith(sys::$op, lhs, rhs) }
+    )*};
+}
+arith_fn! {
+    /// `arrow_arith::numeric::add` (numeric.rs:36): checked for integers
+    add => AH_ADD,
+    /// `add_wrapping` (numeric.rs:41)
+    add_wrapping => AH_ADD_WRAPPING,
+    sub => AH_SUB, sub_wrapping => AH_SUB_WRAPPING, mul => AH_MUL, mul_wrapping => AH_MUL_WRAPPING,
+    div => AH_DIV, rem => AH_REM,
+}
+
+/// `neg` / `neg_wrapping` (numeric.rs:103,:181)
+pub fn neg(values: &Arc<DeviceArray>, wrapping: bool) -> Result<Arc<DeviceArray>, ArrowError> {
+    let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+    let v = values.view();
+    values.ctx.check(unsafe { sys::ah_arith_neg(values.ctx.raw, &v, wrapping as i32, out.as_mut_ptr()) })?;
+    Ok(wrap(values, unsafe { out.assume_init() }, values.data_type.clone(), &[]))
+}
+
+fn compare(op: i32, lhs: &Datum, rhs: &Datum) -> Result<Arc<DeviceArray>, ArrowError> {
+    let ((l, ls), (r, rs)) = (lhs.get(), rhs.get());
+    let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+    let (lv, rv) = (l.view(), r.view());
+    l.ctx.check(unsafe { sys::ah_compare(l.ctx.raw, op, &lv, ls, &rv, rs, out.as_mut_ptr()) })?;
+    Ok(wrap(l, unsafe { out.assume_init() }, DataType::Boolean, &[]))
+}
+
+macro_rules! cmp_fn {
+    ($($name:ident => $op:ident),* $(,)?) => {$(
+        /// `arrow_ord::cmp` (cmp.rs:79-202): Boolean result, totalOrder for floats
+        pub fn $name(lhs: &Datum, rhs: &Datum) -> Result<Arc<DeviceArray>, ArrowError> { compare(sys::$op, lhs, rhs) }
+    )*};
+}
+cmp_fn! { eq => AH_EQ, neq => AH_NEQ, lt => AH_LT, lt_eq => AH_LT_EQ, gt => AH_GT, gt_eq => AH_GT_EQ,
+          distinct => AH_DISTINCT, not_distinct => AH_NOT_DISTINCT }
+
+// ------------------------------------------------------------------------------------------- boolean
+fn boolean_binary(op: i32, l: &Arc<DeviceArray>, r: &Arc<DeviceArray>) -> Result<Arc<DeviceArray>, ArrowError> {
+    let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+    let (lv, rv) = (l.view(), r.view());
+    l.ctx.check(unsafe { sys::ah_boolean_binary(l.ctx.raw, op, &lv, &rv, out.as_mut_ptr()) })?;
+    Ok(wrap(l, unsafe { out.assume_init() }, DataType::Boolean, &[]))
+}
+
+fn boolean_unary(op: i32, v: &Arc<DeviceArray>) -> Result<Arc<DeviceArray>, ArrowError> {
+    let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+    let vv = v.view();
+    v.ctx.check(unsafe { sys::ah_boolean_unary(v.ctx.raw, op, &vv, out.as_mut_ptr()) })?;
+    Ok(wrap(v, unsafe { out.assume_init() }, DataType::Boolean, &[]))
+}
+
+/// `arrow_arith::boolean::and` (boolean.rs:260)
+pub fn and(l: &Arc<DeviceArray>, r: &Arc<DeviceArray>) -> Result<Arc<DeviceArray>, ArrowError> { boolean_binary(sys::AH_BOOL_AND, l, r) }
+/// `or` (boolean.rs:277)
+pub fn or(l: &Arc<DeviceArray>, r: &Arc<DeviceArray>) -> Result<Arc<DeviceArray>, ArrowError> { boolean_binary(sys::AH_BOOL_OR, l, r) }
+/// `and_kleene` (boolean.rs:60)
+pub fn and_kleene(l: &Arc<DeviceArray>, r: &Arc<DeviceArray>) -> Result<Arc<DeviceArray>, ArrowError> { boolean_binary(sys::AH_BOOL_AND_KLEENE, l, r) }
+/// `or_kleene` (boolean.rs:156)
+pub fn or_kleene(l: &Arc<DeviceArray>, r: &Arc<DeviceArray>) -> Result<Arc<DeviceArray>, ArrowError> { boolean_binary(sys::AH_BOOL_OR_KLEENE, l, r) }
+/// `not` (boolean.rs:310)
+pub fn not(v: &Arc<DeviceArray>) -> Result<Arc<DeviceArray>, ArrowError> { boolean_unary(sys::AH_BOOL_NOT, v) }
+/// `is_null` (boolean.rs:327)
+pub fn is_null(v: &Arc<DeviceArray>) -> Result<Arc<DeviceArray>, ArrowError> { boolean_unary(sys::AH_BOOL_IS_NULL, v) }
+/// `is_not_null` (boolean.rs:347)
+pub fn is_not_null(v: &Arc<DeviceArray>) -> Result<Arc<DeviceArray>, ArrowError> { boolean_unary(sys::AH_BOOL_IS_NOT_NULL, v) }
+
+// ------------------------------------------------------------------------------------------- cast / concat
+/// `CastOptions { safe, .. }` (cast/mod.rs:95-111)
+#[derive(Clone, Copy)]
+pub struct CastOptions {
+    pub safe: bool,
+}
+
+impl Default for CastOptions {
+    fn default() -> Self {
+        Self { safe: true }
+    }
+}
+
+fn physical(ctx: &Context, t: &DataType) -> Result<sys::ah_type, ArrowError> {
+    let schema = FFI_ArrowSchema::try_from(t)?;
+    let mut out = 0;
+    ctx.check(unsafe { sys::ah_type_from_format(ctx.raw, schema.format().as_ptr() as *const _, &mut out) })?;
+    Ok(out)
+}
+
+/// `arrow_cast::cast_with_options` (cast/mod.rs:790), the numeric and ->Utf8/LargeUtf8 arms
+pub fn cast_with_options(values: &Arc<DeviceArray>, to_type: &DataType, options: &CastOptions) -> Result<Arc<DeviceArray>, ArrowError> {
+    let to = physical(&values.ctx, to_type)?;
+    let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+    let v = values.view();
+    values.ctx.check(unsafe { sys::ah_cast(values.ctx.raw, &v, to, options.safe as i32, out.as_mut_ptr()) })?;
+    Ok(wrap(values, unsafe { out.assume_init() }, to_type.clone(), &[]))
+}
+
+/// `arrow_cast::cast` (cast/mod.rs:347)
+pub fn cast(values: &Arc<DeviceArray>, to_type: &DataType) -> Result<Arc<DeviceArray>, ArrowError> {
+    cast_with_options(values, to_type, &CastOptions::default())
+}
+
+/// `arrow_select::concat::concat` (concat.rs:495); also the multi-GPU reassembly primitive
+pub fn concat(arrays: &[&Arc<DeviceArray>]) -> Result<Arc<DeviceArray>, ArrowError> {
+    let first = arrays.first().ok_or_else(|| ArrowError::InvalidArgumentError("concat requires input of at least one array".into()))?;
+    let views: Vec<sys::ah_array_view> = arrays.iter().map(|a| a.view()).collect();
+    let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+    first.ctx.check(unsafe { sys::ah_concat(first.ctx.raw, views.len() as i32, views.as_ptr(), out.as_mut_ptr()) })?;
+    Ok(wrap(first, unsafe { out.assume_init() }, first.data_type.clone(), &[]))
+}

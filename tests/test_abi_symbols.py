@@ -35,6 +35,30 @@ def test_binding_covers_header():
     assert lib.ah_version().startswith(b"arrow_hip")
 
 
+def test_rust_sys_bindings_are_current():
+    """bindings/rust/arrow-hip-sys/src/lib.rs is generated from the header (tools/gen_rust_sys.py): it must be up to
+    date, declare every exported symbol, mirror the struct layouts field for field, and every `sys::` name the
+    hand-written safe crate uses must exist in it.  (No Rust toolchain here: this is the only check it gets.)"""
+    import importlib.util
+    import arrow_rs_amd as A
+    spec = importlib.util.spec_from_file_location("gen_rust_sys", os.path.join(ROOT, "tools", "gen_rust_sys.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(gen.OUT).read()
+    assert committed == gen.generate(), "run `python tools/gen_rust_sys.py`"
+    declared = re.findall(r"pub fn (ah_\w+)\(", committed)
+    assert sorted(declared) == declared_symbols()
+    # struct layouts: same field names, in order, as the ctypes mirror the GPU tests run through
+    for rust_name, ct in [("ah_array_view", A._lib.ArrayView), ("ah_array_out", A._lib.ArrayOut)]:
+        body = re.search(r"pub struct %s \{(.*?)\}" % rust_name, committed, flags=re.S).group(1)
+        fields = [f.rstrip("_") for f in re.findall(r"pub (\w+):", body)]
+        assert fields == [f[0] for f in ct._fields_], rust_name
+    safe = open(os.path.join(ROOT, "bindings", "rust", "arrow-hip", "src", "lib.rs")).read()
+    used = set(re.findall(r"sys::(\w+)", safe))
+    known = set(re.findall(r"pub (?:fn|const|struct|type) (\w+)", committed))
+    assert used <= known, f"safe crate uses undeclared names: {sorted(used - known)}"
+
+
 def test_no_cpu_fallback_without_gpu():
     """Product path must fail loudly when no HIP device is usable."""
     import arrow_rs_amd as A
