@@ -179,6 +179,27 @@ def cpu_baseline_filter_take(args):
                                 "sample": f"3 x (filter + take), {T} threads x {per} rows"}
     except Exception as ex:
         res["all_cores"] = {"error": repr(ex)}
+    # independent sanity line: Arrow C++ through pyarrow on the same sample.  A different
+    # implementation (filter/take semantics coincide) — NOT the reference and not the baseline.
+    try:
+        import pyarrow as pa
+        import pyarrow.compute as pc
+        pv = pa.array(vals, mask=~valid)
+        pm = pa.array(mask)
+        pi = pa.array(idx)
+        pc.take(pc.filter(pv, pm), pa.array([0], type=pa.uint32()))  # warm
+        reps2, t2 = 0, 0.0
+        while t2 < 3.0 and reps2 < 20:
+            t0 = time.perf_counter()
+            pc.filter(pv, pm)
+            pc.take(pv, pi)
+            t2 += time.perf_counter() - t0
+            reps2 += 1
+        res["arrow_cpp_sanity"] = {"value": round(n * reps2 / t2 / 1e6, 2), "unit": "Mrows/s",
+                                   "what": f"pyarrow {pa.__version__} pc.filter + pc.take on the same {n}-row sample: "
+                                           "Arrow C++, not the reference", "threads": pa.cpu_count()}
+    except Exception as ex:
+        res["arrow_cpp_sanity"] = {"error": repr(ex)}
     return res
 
 
