@@ -78,6 +78,12 @@ class IpcField(C.Structure):
     _fields_ = [("name", C.c_char_p), ("format", C.c_char_p), ("nullable", C.c_int32)]
 
 
+class IpcBlock(C.Structure):
+    """ah_ipc_block == File.fbs `struct Block`"""
+    _fields_ = [("offset", C.c_int64), ("meta_data_length", C.c_int32), ("reserved_", C.c_int32),
+                ("body_length", C.c_int64)]
+
+
 class FFI_ArrowSchema(C.Structure):
     """struct ArrowSchema (arrow-schema/src/ffi.rs:76-98)."""
 
@@ -181,6 +187,11 @@ SIGNATURES = {
     "ah_ipc_decode_batch": (C.c_int32, [_P, C.c_char_p, C.c_int64, _P, C.c_int64, C.c_int32, C.POINTER(IpcField), _OUT,
                                         C.POINTER(C.c_int64)]),
     "ah_ipc_message_info": (C.c_int32, [_P, C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "ah_ipc_file_footer": (C.c_int32, [_P, C.c_int32, C.POINTER(IpcField), C.c_int32, C.POINTER(IpcBlock),
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "ah_ipc_decode_footer": (C.c_int32, [_P, C.c_char_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                         C.POINTER(C.POINTER(IpcField)), C.POINTER(C.c_int32),
+                                         C.POINTER(C.POINTER(IpcBlock))]),
     "ah_host_free": (None, [_P]),
     "ah_type_from_format": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int32)]),
     "ah_format_of_type": (C.c_char_p, [C.c_int32]),

@@ -378,12 +378,9 @@ struct BufSlot {
 
 extern "C" void ah_host_free(void* p) { free(p); }
 
-extern "C" ah_status ah_ipc_schema_message(ah_context* ctx, int32_t n_fields, const ah_ipc_field* fields,
-                                           int32_t alignment, uint8_t** out, int64_t* out_len) {
-  if (!out || !out_len || (n_fields > 0 && !fields)) return AH_INVALID_ARGUMENT;  // ctx may be NULL (host only)
-  if (alignment != 8 && alignment != 16 && alignment != 32 && alignment != 64)
-    return ah_fail(ctx, AH_INVALID_ARGUMENT, "Alignment should be 8, 16, 32, or 64.");  // writer.rs:92
-  FbBuilder b;
+// the Schema table (Schema.fbs) of `fields`; shared by the stream's Schema message and the file Footer
+static ah_status build_schema_table(ah_context* ctx, FbBuilder& b, int32_t n_fields, const ah_ipc_field* fields,
+                                    uint32_t* schema_off) {
   std::vector<uint32_t> foffs;
   for (int i = 0; i < n_fields; ++i) {
     uint8_t tt;
@@ -402,7 +399,18 @@ extern "C" ah_status ah_ipc_schema_message(ah_context* ctx, int32_t n_fields, co
   const uint32_t fvec = b.create_offset_vector(foffs);
   b.start_table();
   b.add_offset(1, fvec);
-  const uint32_t schema = b.end_table();
+  *schema_off = b.end_table();
+  return AH_OK;
+}
+
+extern "C" ah_status ah_ipc_schema_message(ah_context* ctx, int32_t n_fields, const ah_ipc_field* fields,
+                                           int32_t alignment, uint8_t** out, int64_t* out_len) {
+  if (!out || !out_len || (n_fields > 0 && !fields)) return AH_INVALID_ARGUMENT;  // ctx may be NULL (host only)
+  if (alignment != 8 && alignment != 16 && alignment != 32 && alignment != 64)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "Alignment should be 8, 16, 32, or 64.");  // writer.rs:92
+  FbBuilder b;
+  uint32_t schema = 0;
+  AH_TRY(build_schema_table(ctx, b, n_fields, fields, &schema));
   b.start_table();
   b.add_scalar<int16_t>(0, METADATA_V5, 0);
   b.add_scalar<uint8_t>(1, H_Schema, 0);
@@ -411,15 +419,8 @@ extern "C" ah_status ah_ipc_schema_message(ah_context* ctx, int32_t n_fields, co
   return frame_message(ctx, b, alignment, out, out_len);
 }
 
-extern "C" ah_status ah_ipc_decode_schema(ah_context* ctx, const uint8_t* msg, int64_t len, int32_t* n_fields,
-                                          ah_ipc_field** fields) {
-  if (!n_fields || !fields) return AH_INVALID_ARGUMENT;  // ctx may be NULL (host only)
-  FbView v{};
-  AH_TRY(unframe(ctx, msg, len, &v));
-  const size_t m = v.root();
-  if (v.scalar<uint8_t>(m, 1, 0) != H_Schema) return ah_fail(ctx, AH_IPC_ERROR, "Not expecting a schema when messages are read");
-  const size_t schema = v.indirect(m, 2);
-  if (!schema) return ah_fail(ctx, AH_IPC_ERROR, "Unable to read IPC message as schema");
+// Schema table at `schema` -> one malloc'd block: the field array followed by its strings (ah_host_free)
+static ah_status read_schema_table(ah_context* ctx, FbView& v, size_t schema, int32_t* n_fields, ah_ipc_field** fields) {
   if (v.scalar<int16_t>(schema, 0, 0) != 0) return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "big-endian IPC streams");
   const size_t fvec = v.indirect(schema, 1);
   const uint32_t n = v.vec_len(fvec);
@@ -433,7 +434,6 @@ extern "C" ah_status ah_ipc_decode_schema(ah_context* ctx, const uint8_t* msg, i
     AH_TRY(format_from_type(ctx, v, v.scalar<uint8_t>(f, 2, 0), v.indirect(f, 3), &fmts[i]));
   }
   if (!v.ok) return ah_fail(ctx, AH_PARSE_ERROR, "Unable to get root as message: truncated flatbuffer");
-  // one allocation: the field array followed by the strings (freed with ah_host_free)
   size_t bytes = sizeof(ah_ipc_field) * std::max<uint32_t>(n, 1);
   for (uint32_t i = 0; i < n; ++i) bytes += names[i].size() + fmts[i].size() + 2;
   char* blob = (char*)malloc(bytes);
@@ -451,6 +451,96 @@ extern "C" ah_status ah_ipc_decode_schema(ah_context* ctx, const uint8_t* msg, i
   }
   *n_fields = (int32_t)n;
   *fields = out;
+  return AH_OK;
+}
+
+extern "C" ah_status ah_ipc_decode_schema(ah_context* ctx, const uint8_t* msg, int64_t len, int32_t* n_fields,
+                                          ah_ipc_field** fields) {
+  if (!n_fields || !fields) return AH_INVALID_ARGUMENT;  // ctx may be NULL (host only)
+  FbView v{};
+  AH_TRY(unframe(ctx, msg, len, &v));
+  const size_t m = v.root();
+  if (v.scalar<uint8_t>(m, 1, 0) != H_Schema) return ah_fail(ctx, AH_IPC_ERROR, "Not expecting a schema when messages are read");
+  const size_t schema = v.indirect(m, 2);
+  if (!schema) return ah_fail(ctx, AH_IPC_ERROR, "Unable to read IPC message as schema");
+  return read_schema_table(ctx, v, schema, n_fields, fields);
+}
+
+// ---- IPC FILE format: [ARROW1 + pad][stream messages][EOS][Footer flatbuffer][i32 footer length][ARROW1]
+static const char ARROW_MAGIC[6] = {'A', 'R', 'R', 'O', 'W', '1'};
+static_assert(sizeof(ah_ipc_block) == 24, "File.fbs struct Block is 24 bytes");
+
+extern "C" ah_status ah_ipc_file_footer(ah_context* ctx, int32_t n_fields, const ah_ipc_field* fields, int32_t n_blocks,
+                                        const ah_ipc_block* blocks, uint8_t** out, int64_t* out_len) {
+  if (!out || !out_len || (n_fields > 0 && !fields) || (n_blocks > 0 && !blocks)) return AH_INVALID_ARGUMENT;
+  // FileWriter::finish (writer.rs:1724-1768): dictionaries and recordBatches vectors first, then the schema
+  FbBuilder b;
+  std::vector<ah_ipc_block> clean((size_t)std::max(n_blocks, 0));
+  for (int i = 0; i < n_blocks; ++i) {  // struct padding is zero on the wire
+    clean[i] = ah_ipc_block{};
+    clean[i].offset = blocks[i].offset;
+    clean[i].meta_data_length = blocks[i].meta_data_length;
+    clean[i].body_length = blocks[i].body_length;
+  }
+  const uint32_t dicts = b.create_struct_vector(nullptr, 0, sizeof(ah_ipc_block), 8);
+  const uint32_t recs = b.create_struct_vector(clean.data(), clean.size(), sizeof(ah_ipc_block), 8);
+  uint32_t schema = 0;
+  AH_TRY(build_schema_table(ctx, b, n_fields, fields, &schema));
+  b.start_table();
+  b.add_scalar<int16_t>(0, METADATA_V5, 0);
+  b.add_offset(1, schema);
+  b.add_offset(2, dicts);
+  b.add_offset(3, recs);
+  b.finish(b.end_table());
+  const int64_t flen = b.size();
+  uint8_t* m = (uint8_t*)malloc((size_t)flen + 10);
+  if (!m) return ah_fail(ctx, AH_OUT_OF_MEMORY, "host allocation of %lld bytes failed", (long long)flen + 10);
+  memcpy(m, b.data(), (size_t)flen);
+  const int32_t l32 = (int32_t)flen;
+  memcpy(m + flen, &l32, 4);
+  memcpy(m + flen + 4, ARROW_MAGIC, 6);
+  *out = m;
+  *out_len = flen + 10;
+  return AH_OK;
+}
+
+extern "C" ah_status ah_ipc_decode_footer(ah_context* ctx, const uint8_t* tail, int64_t tail_len, int64_t* footer_len,
+                                          int32_t* n_fields, ah_ipc_field** fields, int32_t* n_blocks,
+                                          ah_ipc_block** blocks) {
+  if (!tail || !footer_len) return AH_INVALID_ARGUMENT;
+  // read_footer_length (reader.rs:944-956): the last 10 bytes are [i32 footer length]["ARROW1"]
+  if (tail_len < 10 || memcmp(tail + tail_len - 6, ARROW_MAGIC, 6) != 0)
+    return ah_fail(ctx, AH_PARSE_ERROR, "Arrow file does not contain correct footer");
+  int32_t flen;
+  memcpy(&flen, tail + tail_len - 10, 4);
+  if (flen < 0) return ah_fail(ctx, AH_PARSE_ERROR, "Invalid footer length: %d", flen);
+  *footer_len = flen;
+  if (!n_fields) return AH_OK;  // first call with the last 10 bytes only: the caller now knows how much to read
+  if (!fields || !n_blocks || !blocks) return AH_INVALID_ARGUMENT;
+  if ((int64_t)flen + 10 > tail_len)
+    return ah_fail(ctx, AH_PARSE_ERROR, "Unable to get root as footer: %lld bytes given, the footer needs %lld",
+                   (long long)tail_len, (long long)flen + 10);
+  FbView v{};
+  v.p = tail + tail_len - 10 - flen;
+  v.n = (size_t)flen;
+  const size_t f = v.root();
+  const size_t schema = v.indirect(f, 1);
+  if (!schema || !v.ok) return ah_fail(ctx, AH_PARSE_ERROR, "Unable to get root as footer: no schema");
+  if (v.vec_len(v.indirect(f, 2)) != 0)
+    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "dictionary batches in IPC files have no device kernels");
+  const size_t rv = v.indirect(f, 3);
+  const uint32_t nb = v.vec_len(rv);
+  if (rv && rv + 4 + (size_t)nb * sizeof(ah_ipc_block) > v.n) return ah_fail(ctx, AH_PARSE_ERROR, "Unable to get root as footer: truncated block vector");
+  ah_ipc_block* bl = (ah_ipc_block*)malloc(sizeof(ah_ipc_block) * std::max<uint32_t>(nb, 1));
+  if (!bl) return ah_fail(ctx, AH_OUT_OF_MEMORY, "host allocation failed");
+  if (nb) memcpy(bl, v.p + rv + 4, (size_t)nb * sizeof(ah_ipc_block));
+  ah_status st = read_schema_table(ctx, v, schema, n_fields, fields);
+  if (st != AH_OK) {
+    free(bl);
+    return st;
+  }
+  *n_blocks = (int32_t)nb;
+  *blocks = bl;
   return AH_OK;
 }
 

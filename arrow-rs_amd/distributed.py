@@ -187,4 +187,9 @@ class Communicator:
             torch.cuda.synchronize(self.device)
         tm["total"] = _t.perf_counter() - _t0
         self.timings = {k: round(v * 1e3, 3) for k, v in tm.items()}
+        # what this rank pushed to EACH peer and pulled in total (values + packed validity), for per-link rates
+        sent = array.length * w + (((array.length + 63) // 64) * 8 if any_valid else 0)
+        recv = (total - array.length) * w + (sum(((n + 63) // 64) * 8 for n in lens) - ((array.length + 63) // 64) * 8
+                                              if any_valid else 0)
+        self.last_exchange = {"peers": self.world - 1, "bytes_to_each_peer": int(sent), "bytes_received": int(recv)}
         return Array(ctx, dt, total, _RawMem(out_vals.ptr, total * w, out_vals), 0, vmem, 0, nulls)

@@ -1,6 +1,6 @@
-"""arrow::ipc for device-resident record batches — the mirror of ``arrow_ipc::writer::StreamWriter`` /
-``arrow_ipc::reader::StreamReader`` (arrow-ipc/src/writer.rs:1419-1600, reader.rs:1380-1560) over the C ABI's
-``ah_ipc_*`` entry points.
+"""arrow::ipc for device-resident record batches — the mirror of ``arrow_ipc::writer::{StreamWriter, FileWriter}``
+/ ``arrow_ipc::reader::{StreamReader, FileReader}`` (arrow-ipc/src/writer.rs:1419-1768, reader.rs:944-1560) over the
+C ABI's ``ah_ipc_*`` entry points.
 
 The body of every RecordBatch message is assembled (encode) or received (decode) as ONE contiguous HBM
 buffer: writing a stream is one D2H copy per batch, reading one H2D copy per batch after which the columns
@@ -16,6 +16,7 @@ from . import array as A
 from . import ffi
 
 CONTINUATION = b"\xff\xff\xff\xff"
+ARROW_MAGIC = b"ARROW1"
 
 
 class Field:
@@ -210,6 +211,129 @@ def write_stream(batches, schema=None, ctx=None, alignment=64):
     schema = schema or Schema.of(batches[0])
     sink = io.BytesIO()
     w = StreamWriter(sink, schema, ctx, alignment)
+    for b in batches:
+        w.write(b)
+    w.finish()
+    return sink.getvalue()
+
+
+# ------------------------------------------------------------------------------------------------ file format
+def _pad(n, alignment):
+    return (-n) % alignment
+
+
+class FileWriter:
+    """``FileWriter::try_new(writer, &schema)`` / ``write`` / ``finish`` (writer.rs:1645-1768): "ARROW1" + padding,
+    the schema message, one framed message + body per batch (their positions recorded as ``Block``s), the
+    end-of-stream marker and the footer trailer built by ``ah_ipc_file_footer``."""
+
+    def __init__(self, sink, schema, ctx=None, alignment=64):
+        self.sink, self.schema, self.alignment = sink, schema, alignment
+        self.ctx = ctx or A.default_context()
+        self.finished = False
+        self.blocks = []
+        header = ARROW_MAGIC + b"\x00" * _pad(len(ARROW_MAGIC), alignment)
+        sink.write(header)
+        msg = schema_to_bytes(schema, self.ctx, alignment)
+        sink.write(msg)
+        self.block_offsets = len(header) + len(msg)
+
+    def write(self, batch):
+        if self.finished:
+            raise A.IpcError("Cannot write record batch to file writer as it is closed")
+        if [c.data_type for c in batch.columns] != [f.data_type for f in self.schema.fields]:
+            raise A.InvalidArgumentError("batch schema does not match the file schema")
+        meta, body = encode_batch(batch, self.alignment)
+        self.sink.write(meta)
+        self.sink.write(body.to_bytes())
+        self.blocks.append((self.block_offsets, len(meta), body.nbytes))
+        self.block_offsets += len(meta) + body.nbytes
+
+    def finish(self):
+        if self.finished:
+            raise A.IpcError("Cannot write footer to file writer as it is closed")
+        self.sink.write(CONTINUATION + b"\x00\x00\x00\x00")
+        self.sink.write(file_footer(self.schema, self.blocks, self.ctx))
+        self.finished = True
+
+
+def file_footer(schema, blocks, ctx=None):
+    """Footer trailer of an IPC file: [Footer flatbuffer][i32 length]["ARROW1"]; ``blocks`` = (offset, metadata
+    length, body length) per record batch."""
+    ctx = ctx or A.default_context()
+    arr, _keep = schema._c_fields(ctx)
+    bl = (L.IpcBlock * max(len(blocks), 1))()
+    for i, (off, mlen, blen) in enumerate(blocks):
+        bl[i].offset, bl[i].meta_data_length, bl[i].body_length = off, mlen, blen
+    out, n = C.c_void_p(), C.c_int64()
+    ctx.check(ctx.lib.ah_ipc_file_footer(ctx.handle, len(schema.fields), arr, len(blocks), bl, C.byref(out), C.byref(n)))
+    return _take_host_bytes(ctx, out, n.value)
+
+
+def read_footer(tail, ctx=None):
+    """``read_footer_length`` + the Footer (reader.rs:944-1260) from the last bytes of a file:
+    (Schema, [(offset, metadata length, body length)], footer length).  With only the last 10 bytes it returns
+    (None, None, footer length) so the caller knows how much more to read."""
+    ctx = ctx or A.default_context()
+    flen = C.c_int64()
+    tail = bytes(tail)
+    ctx.check(ctx.lib.ah_ipc_decode_footer(ctx.handle, tail, len(tail), C.byref(flen), None, None, None, None))
+    if len(tail) < flen.value + 10:
+        return None, None, flen.value
+    n, fields, nb, blocks = C.c_int32(), C.POINTER(L.IpcField)(), C.c_int32(), C.POINTER(L.IpcBlock)()
+    ctx.check(ctx.lib.ah_ipc_decode_footer(ctx.handle, tail, len(tail), C.byref(flen), C.byref(n), C.byref(fields),
+                                           C.byref(nb), C.byref(blocks)))
+    try:
+        schema = Schema([Field(fields[i].name.decode(), ffi.data_type_from_format(ctx, fields[i].format.decode()),
+                               bool(fields[i].nullable)) for i in range(n.value)])
+        bl = [(blocks[i].offset, blocks[i].meta_data_length, blocks[i].body_length) for i in range(nb.value)]
+    finally:
+        ctx.lib.ah_host_free(fields)
+        ctx.lib.ah_host_free(blocks)
+    return schema, bl, flen.value
+
+
+class FileReader:
+    """``FileReader::try_new(reader, None)`` (reader.rs:1290-1370): random access to the record batches of an IPC
+    file through its footer; every batch is one H2D copy of its body, the columns are views of it."""
+
+    def __init__(self, source, ctx=None):
+        self.src = io.BytesIO(source) if isinstance(source, (bytes, bytearray, memoryview)) else source
+        self.ctx = ctx or A.default_context()
+        # like the reference (reader.rs:1226-1260) only the TRAILING magic is checked: the header is never read
+        size = self.src.seek(0, io.SEEK_END)
+        _, _, flen = read_footer(self._read_at(size - 10, 10) if size >= 10 else b"", self.ctx)
+        self.schema, self.blocks, _ = read_footer(self._read_at(size - 10 - flen, flen + 10), self.ctx)
+
+    def _read_at(self, pos, n):
+        self.src.seek(max(pos, 0))
+        return self.src.read(n)
+
+    def num_batches(self):
+        return len(self.blocks)
+
+    def read_batch(self, i):
+        ctx = self.ctx
+        off, mlen, blen = self.blocks[i]
+        msg = self._read_at(off, mlen)
+        if len(msg) < mlen:
+            raise A.IpcError("Unexpected end of file inside a message")
+        body = self._read_at(off + mlen, blen)
+        if len(body) < blen:
+            raise A.IpcError("Unexpected end of file inside a message body")
+        dev = A.DeviceBuffer.from_numpy(ctx, np.frombuffer(body, dtype=np.uint8)) if blen else A.DeviceBuffer(ctx, 8)
+        return decode_batch(msg, dev.ptr, blen, self.schema, ctx, keepalive=(dev,))
+
+    def __iter__(self):
+        return (self.read_batch(i) for i in range(len(self.blocks)))
+
+
+def write_file(batches, schema=None, ctx=None, alignment=64):
+    """All batches as one IPC file (bytes)."""
+    batches = list(batches)
+    schema = schema or Schema.of(batches[0])
+    sink = io.BytesIO()
+    w = FileWriter(sink, schema, ctx, alignment)
     for b in batches:
         w.write(b)
     w.finish()

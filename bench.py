@@ -552,6 +552,14 @@ def main():
             line["config"]["reassemble"] = "failed: " + state["reassemble_error"]
         if comm is not None and getattr(comm, "timings", None):
             line["reassemble_last_ms"] = comm.timings
+            ex = getattr(comm, "last_exchange", None)
+            if ex and ex["peers"] and comm.timings.get("total"):
+                # GB/s per xGMI link = what one rank pushes to ONE peer over the exchange time of the
+                # last step (each peer sits on its own link; 7 links x ~153 GB/s per MI355X); egress = all peers
+                secs = comm.timings["total"] * 1e-3
+                line["exchange"] = dict(ex, per_link_GBps=round(ex["bytes_to_each_peer"] / secs / 1e9, 2),
+                                        egress_GBps=round(ex["bytes_to_each_peer"] * ex["peers"] / secs / 1e9, 2),
+                                        ingress_GBps=round(ex["bytes_received"] / secs / 1e9, 2))
         line["kernel_avg_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
         if local_elapsed:
             line["local_value"] = round(n * world * args.steps / local_elapsed / 1e6, 1)

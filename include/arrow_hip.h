@@ -521,6 +521,15 @@ typedef struct ah_ipc_field {
 /* Message header ordinals of format/Message.fbs */
 enum { AH_IPC_SCHEMA = 1, AH_IPC_DICTIONARY_BATCH = 2, AH_IPC_RECORD_BATCH = 3 };
 
+/* File.fbs `struct Block`: where a message sits in an IPC FILE (offset of its continuation marker from the start
+ * of the file, framed metadata length, body length). */
+typedef struct ah_ipc_block {
+  int64_t offset;
+  int32_t meta_data_length;
+  int32_t reserved_; /* struct padding, zero on the wire */
+  int64_t body_length;
+} ah_ipc_block;
+
 /* `IpcDataGenerator::schema_to_bytes` (writer.rs): framed Schema message; free with ah_host_free. */
 AH_API ah_status ah_ipc_schema_message(ah_context* ctx, int32_t n_fields, const ah_ipc_field* fields,
                                        int32_t alignment, uint8_t** out, int64_t* out_len);
@@ -546,6 +555,21 @@ AH_API ah_status ah_ipc_decode_batch(ah_context* ctx, const uint8_t* msg, int64_
  * the body. */
 AH_API ah_status ah_ipc_message_info(ah_context* ctx, const uint8_t* msg, int64_t len, int32_t* header_type,
                                      int64_t* body_len);
+
+/* The Arrow IPC FILE format (`FileWriter` arrow-ipc/src/writer.rs:1645-1768, `read_footer_length` / `FileDecoder`
+ * arrow-ipc/src/reader.rs:944-1260) = "ARROW1" + padding, the same framed messages as the stream, an end-of-stream
+ * marker, then the trailer these two functions build and parse: [Footer flatbuffer (File.fbs: version, schema,
+ * dictionaries = [], recordBatches = [Block])][i32 footer length]["ARROW1"].  Host-only (ctx may be NULL).
+ * ah_ipc_file_footer returns that trailer (free with ah_host_free).  ah_ipc_decode_footer takes the LAST tail_len
+ * bytes of a file: with n_fields == NULL it only reports the footer length from the last 10 bytes (so the caller
+ * knows how much to read); otherwise it needs the last footer_len + 10 bytes and returns the schema fields
+ * (one block, ah_host_free) and the record-batch blocks (ah_host_free).  Errors carry the reference's text
+ * ("Arrow file does not contain correct footer", "Invalid footer length: N"). */
+AH_API ah_status ah_ipc_file_footer(ah_context* ctx, int32_t n_fields, const ah_ipc_field* fields, int32_t n_blocks,
+                                    const ah_ipc_block* blocks, uint8_t** out, int64_t* out_len);
+AH_API ah_status ah_ipc_decode_footer(ah_context* ctx, const uint8_t* tail, int64_t tail_len, int64_t* footer_len,
+                                      int32_t* n_fields, ah_ipc_field** fields, int32_t* n_blocks,
+                                      ah_ipc_block** blocks);
 AH_API void ah_host_free(void* p);
 
 #ifdef __cplusplus

@@ -209,3 +209,105 @@ def test_ipc_schema_message_round_trips_through_pyarrow():
     for cut in (3, 8, 20, len(msg) // 2):
         st = lib.ah_ipc_decode_schema(None, msg[:cut], cut, C.byref(n), C.byref(fields))
         assert st in (L.AH_IPC_ERROR, L.AH_PARSE_ERROR), (cut, st)
+
+
+def test_ipc_file_footer_against_pyarrow():
+    """Host-only half of the IPC FILE format (FileWriter::finish writer.rs:1724, read_footer_length reader.rs:944):
+    (1) our footer parser on files written by Arrow C++ — schema, block count, and every Block must point at a
+    framed message whose metadata length and body length agree with the message itself;
+    (2) our footer builder under Arrow C++'s reader — a file assembled from pyarrow's own stream messages, our
+    Block offsets and our trailer must read back batch for batch."""
+    import ctypes as C
+    import io
+    import pyarrow as pa
+    import arrow_rs_amd as A
+    L = A._lib
+    lib = L.load()
+    sch = pa.schema([pa.field("a", pa.int64()), pa.field("b", pa.float64(), nullable=False), pa.field("s", pa.large_utf8()),
+                     pa.field("t", pa.timestamp("us", "UTC")), pa.field("f", pa.bool_())])
+    batches = [pa.record_batch([pa.array([1, None, 3], pa.int64()), pa.array([1.5, 2.5, 3.5]), pa.array(["x", None, "zz"], pa.large_utf8()),
+                                pa.array([1, 2, None], pa.timestamp("us", "UTC")), pa.array([True, None, False])], schema=sch),
+               pa.record_batch([pa.array([], pa.int64()), pa.array([], pa.float64()), pa.array([], pa.large_utf8()),
+                                pa.array([], pa.timestamp("us", "UTC")), pa.array([], pa.bool_())], schema=sch),
+               pa.record_batch([pa.array(list(range(100)), pa.int64()), pa.array([float(i) for i in range(100)]),
+                                pa.array([str(i) for i in range(100)], pa.large_utf8()),
+                                pa.array(list(range(100)), pa.timestamp("us", "UTC")), pa.array([i % 3 == 0 for i in range(100)])], schema=sch)]
+
+    def parse(tail):
+        flen = C.c_int64()
+        st = lib.ah_ipc_decode_footer(None, tail, len(tail), C.byref(flen), None, None, None, None)
+        if st != L.AH_OK:
+            return st, None, None, None
+        n, fields, nb, blocks = C.c_int32(), C.POINTER(L.IpcField)(), C.c_int32(), C.POINTER(L.IpcBlock)()
+        st = lib.ah_ipc_decode_footer(None, tail, len(tail), C.byref(flen), C.byref(n), C.byref(fields), C.byref(nb), C.byref(blocks))
+        if st != L.AH_OK:
+            return st, None, None, flen.value
+        f = [(fields[i].name.decode(), fields[i].format.decode(), bool(fields[i].nullable)) for i in range(n.value)]
+        b = [(blocks[i].offset, blocks[i].meta_data_length, blocks[i].body_length) for i in range(nb.value)]
+        lib.ah_host_free(fields)
+        lib.ah_host_free(blocks)
+        return st, f, b, flen.value
+
+    # (1) Arrow C++ writes, we parse
+    sink = io.BytesIO()
+    with pa.ipc.new_file(sink, sch) as w:
+        for b in batches:
+            w.write_batch(b)
+    data = sink.getvalue()
+    st, fields, blocks, flen = parse(data[-10:])          # the last 10 bytes alone: footer length, then "need more"
+    assert st == L.AH_PARSE_ERROR and flen == int.from_bytes(data[-10:-6], "little")
+    st, fields, blocks, flen2 = parse(data[-(flen + 10):])
+    assert st == L.AH_OK and flen2 == flen
+    assert fields == [("a", "l", True), ("b", "g", False), ("s", "U", True), ("t", "tsu:UTC", True), ("f", "b", True)]
+    assert len(blocks) == len(batches)
+    for off, mlen, blen in blocks:
+        assert data[off:off + 4] == b"\xff" * 4 and int.from_bytes(data[off + 4:off + 8], "little") == mlen - 8
+        ht, bl = C.c_int32(), C.c_int64()
+        msg = data[off:off + mlen]
+        assert lib.ah_ipc_message_info(None, msg, len(msg), C.byref(ht), C.byref(bl)) == L.AH_OK
+        assert (ht.value, bl.value) == (3, blen)
+    # malformed trailers: the reference's texts (reader.rs:944-956)
+    flen_c = C.c_int64()
+    assert lib.ah_ipc_decode_footer(None, data[:-1], len(data) - 1, C.byref(flen_c), None, None, None, None) == L.AH_PARSE_ERROR
+    assert lib.ah_last_error(None) in (b"no context", b"Arrow file does not contain correct footer")
+    bad = data[:-10] + (-5).to_bytes(4, "little", signed=True) + b"ARROW1"
+    assert lib.ah_ipc_decode_footer(None, bad, len(bad), C.byref(flen_c), None, None, None, None) == L.AH_PARSE_ERROR
+
+    # (2) we build the trailer, Arrow C++ reads the file
+    stream = io.BytesIO()
+    with pa.ipc.new_stream(stream, sch) as w:
+        for b in batches:
+            w.write_batch(b)
+    sdata = stream.getvalue()
+    pos, msgs = 0, []
+    while pos < len(sdata):  # walk [0xFFFFFFFF][len][metadata][body]
+        assert sdata[pos:pos + 4] == b"\xff" * 4
+        mlen = int.from_bytes(sdata[pos + 4:pos + 8], "little")
+        if mlen == 0:
+            break
+        ht, bl = C.c_int32(), C.c_int64()
+        m = sdata[pos:pos + 8 + mlen]
+        assert lib.ah_ipc_message_info(None, m, len(m), C.byref(ht), C.byref(bl)) == L.AH_OK
+        msgs.append((ht.value, pos, 8 + mlen, bl.value))
+        pos += 8 + mlen + bl.value
+    assert [m[0] for m in msgs] == [1, 3, 3, 3]
+    header = b"ARROW1\x00\x00"
+    bl = (L.IpcBlock * 3)()
+    for i, (_, p, mlen, blen) in enumerate(msgs[1:]):
+        bl[i].offset, bl[i].meta_data_length, bl[i].body_length = len(header) + p, mlen, blen
+    arr = (L.IpcField * len(fields))()
+    keep = [(nm.encode(), fm.encode()) for nm, fm, _ in fields]
+    for i, (nm, fm) in enumerate(keep):
+        arr[i].name, arr[i].format, arr[i].nullable = nm, fm, 1 if fields[i][2] else 0
+    out, ln = C.c_void_p(), C.c_int64()
+    assert lib.ah_ipc_file_footer(None, len(fields), arr, 3, bl, C.byref(out), C.byref(ln)) == L.AH_OK
+    trailer = C.string_at(out, ln.value)
+    lib.ah_host_free(out)
+    assert trailer[-6:] == b"ARROW1" and int.from_bytes(trailer[-10:-6], "little") == ln.value - 10
+    mine = header + sdata[:pos] + b"\xff\xff\xff\xff\x00\x00\x00\x00" + trailer
+    rd = pa.ipc.open_file(pa.py_buffer(mine))
+    assert rd.schema.equals(sch) and rd.num_record_batches == 3
+    for i, b in enumerate(batches):
+        assert rd.get_batch(i).equals(b)
+    st, f2, b2, _ = parse(mine[-(ln.value):])            # and our parser on our own trailer
+    assert st == L.AH_OK and f2 == fields and b2 == [(bl[i].offset, bl[i].meta_data_length, bl[i].body_length) for i in range(3)]

@@ -174,3 +174,46 @@ def test_large_batch_moves_as_one_body(ctx, oracle):
     want = K.filter(a, m)
     assert got.length == want.length and got.null_count() == want.null_count()
     assert np.array_equal(got.values_numpy(), want.values_numpy()) and np.array_equal(got.valid_mask(), want.valid_mask())
+
+
+@pytest.mark.parametrize("alignment", [8, 64])
+def test_ipc_file_format_both_directions(ctx, alignment):
+    """FileWriter / FileReader (writer.rs:1645-1768, reader.rs:944-1370): pyarrow opens the file we write from
+    device batches (random access through OUR footer); we open the file pyarrow writes (random access through ITS
+    footer), every batch one H2D copy of its body."""
+    tbl = _table(6000, 5)
+    batches = _device_batches(tbl, ctx, 2048)
+    data = ipc.write_file(batches, ctx=ctx, alignment=alignment)
+    assert data[:6] == b"ARROW1" and data[-6:] == b"ARROW1"
+    rd = pa.ipc.open_file(pa.py_buffer(data))
+    assert rd.schema.equals(tbl.schema) and rd.num_record_batches == len(batches)
+    want = tbl.to_batches(max_chunksize=2048)
+    for i in (2, 0, 1):  # random access
+        assert rd.get_batch(i).equals(want[i])
+    assert rd.read_all().equals(tbl)
+    # our reader on our own file, and on Arrow C++'s file
+    mine = ipc.FileReader(data, ctx)
+    assert mine.num_batches() == len(batches) and [f.name for f in mine.schema.fields] == tbl.schema.names
+    assert ffi.to_pyarrow(mine.read_batch(1)).equals(want[1])
+    sink = io.BytesIO()
+    with pa.ipc.new_file(sink, tbl.schema) as w:
+        for b in want:
+            w.write_batch(b)
+    theirs = ipc.FileReader(sink.getvalue(), ctx)
+    assert theirs.num_batches() == len(want)
+    for i in (2, 0, 1):
+        assert ffi.to_pyarrow(theirs.read_batch(i)).equals(want[i])
+    assert [ffi.to_pyarrow(b).num_rows for b in theirs] == [b.num_rows for b in want]
+    # closed writer / bad magic: the reference's texts
+    w = ipc.FileWriter(io.BytesIO(), ipc.Schema.of(batches[0]), ctx)
+    w.finish()
+    with pytest.raises(A.IpcError) as ei:
+        w.write(batches[0])
+    assert ei.value.message == "Cannot write record batch to file writer as it is closed"
+    with pytest.raises(A.IpcError) as ei:
+        w.finish()
+    assert ei.value.message == "Cannot write footer to file writer as it is closed"
+    assert ipc.FileReader(b"NOTARROW" + data[8:], ctx).num_batches() == len(batches)  # the header magic is never read
+    with pytest.raises(A.ParseError) as ei:
+        ipc.FileReader(data[:-3] + b"XYZ", ctx)
+    assert ei.value.message == "Arrow file does not contain correct footer"

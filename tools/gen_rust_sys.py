@@ -24,7 +24,7 @@ BASE = {
     "ah_boolean_op": "ah_boolean_op", "ah_agg_op": "ah_agg_op", "ArrowDeviceType": "ArrowDeviceType",
     # opaque / struct types keep their names
     "ah_context": "ah_context", "ah_filter_predicate": "ah_filter_predicate", "ah_array_view": "ah_array_view",
-    "ah_array_out": "ah_array_out", "ah_scalar": "ah_scalar", "ah_ipc_field": "ah_ipc_field",
+    "ah_array_out": "ah_array_out", "ah_scalar": "ah_scalar", "ah_ipc_field": "ah_ipc_field", "ah_ipc_block": "ah_ipc_block",
     "ArrowArray": "ArrowArray", "ArrowSchema": "ArrowSchema", "ArrowDeviceArray": "ArrowDeviceArray",
     "ah_alloc_fn": "ah_alloc_fn", "ah_free_fn": "ah_free_fn",
 }
