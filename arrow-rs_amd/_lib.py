@@ -187,6 +187,8 @@ SIGNATURES = {
     "ah_ipc_decode_batch": (C.c_int32, [_P, C.c_char_p, C.c_int64, _P, C.c_int64, C.c_int32, C.POINTER(IpcField), _OUT,
                                         C.POINTER(C.c_int64)]),
     "ah_ipc_message_info": (C.c_int32, [_P, C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "ah_string_like": (C.c_int32, [_P, C.c_int32, C.POINTER(ArrayView), C.POINTER(ArrayView), C.c_int32, C.POINTER(ArrayOut)]),
+    "ah_string_length": (C.c_int32, [_P, C.POINTER(ArrayView), C.c_int32, C.POINTER(ArrayOut)]),
     "ah_ipc_file_footer": (C.c_int32, [_P, C.c_int32, C.POINTER(IpcField), C.c_int32, C.POINTER(IpcBlock),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "ah_ipc_decode_footer": (C.c_int32, [_P, C.c_char_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32),

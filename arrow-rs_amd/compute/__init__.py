@@ -20,3 +20,4 @@ from .kernels.interleave import interleave, interleave_record_batch  # noqa: F40
 from .kernels.bitwise import (bitwise_and, bitwise_or, bitwise_xor, bitwise_shift_left, bitwise_shift_right,  # noqa: F401
                               bitwise_and_not, bitwise_not, bitwise_and_scalar, bitwise_or_scalar, bitwise_xor_scalar,
                               bitwise_shift_left_scalar, bitwise_shift_right_scalar)
+from .kernels.like import like, nlike, starts_with, ends_with, contains, length, bit_length  # noqa: F401,E402

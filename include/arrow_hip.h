@@ -272,6 +272,22 @@ AH_API ah_status ah_boolean_unary(ah_context* ctx, ah_boolean_op op, const ah_ar
 AH_API ah_status ah_nullif(ah_context* ctx, const ah_array_view* left, const ah_array_view* right,
                            ah_array_out* out);
 
+/* ------------------------------------------------- string predicates / length */
+/* arrow_string::like::{like, nlike, starts_with, ends_with, contains} (arrow-string/src/like.rs:83-205) on
+ * AH_UTF8 / AH_LARGE_UTF8 values against a SCALAR pattern of the same type (a length-1 array, Datum::get()):
+ * `%` = any run of characters, `_` = exactly one character, `\x` = literal x, a trailing `\` = a literal
+ * backslash (Predicate::like / regex_like, arrow-string/src/predicate.rs:44-306); starts_with / ends_with /
+ * contains take the needle literally.  Boolean result, input nulls cloned (BooleanArray::from_unary), a null
+ * pattern gives an all-null result (like.rs:314).  Per-row pattern arrays and the case-insensitive forms
+ * (ilike: Unicode case folding) are AH_NOT_YET_IMPLEMENTED. */
+typedef int32_t ah_like_op;
+enum { AH_LIKE = 0, AH_NLIKE = 1, AH_STARTS_WITH = 2, AH_ENDS_WITH = 3, AH_CONTAINS = 4 };
+AH_API ah_status ah_string_like(ah_context* ctx, ah_like_op op, const ah_array_view* values,
+                                const ah_array_view* pattern, int32_t pattern_is_scalar, ah_array_out* out);
+/* arrow_string::length::{length, bit_length} (arrow-string/src/length.rs:58,:130) for AH_UTF8 (Int32 result) /
+ * AH_LARGE_UTF8 (Int64): byte length of every value (x8 when `bits`), nulls cloned. */
+AH_API ah_status ah_string_length(ah_context* ctx, const ah_array_view* values, int32_t bits, ah_array_out* out);
+
 /* ------------------------------------------------------------------ cast */
 /* arrow_cast::cast_with_options (arrow-cast/src/cast/mod.rs:790), restricted to
  * numeric<->numeric (mod.rs:1578-1697 via cast_numeric_arrays :2550) and

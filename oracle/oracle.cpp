@@ -1929,6 +1929,213 @@ int32_t orc_boolean_unary(int32_t op, const orc_view* v, orc_out* out) {
   return ORC_OK;
 }
 
+// ------------------------------------------------------------------ string predicates (arrow-string)
+// like / nlike / starts_with / ends_with / contains against a scalar pattern: like_op (like.rs:218) -> op_scalar
+// (:349) -> Predicate::{like, contains, StartsWith, EndsWith} (predicate.rs:44-120).  The reference hands
+// everything that is not Eq / StartsWith / EndsWith / Contains to the `regex` crate (regex 1.x, not under
+// /root/reference); the only constructs regex_like (predicate.rs:246-306) ever emits are literal characters,
+// `.` and `.*` with dot-matches-newline, and the two anchors, so they are matched here by a backtracking
+// matcher over code points — deliberately NOT the two-pointer walk the device uses.
+namespace {
+struct LikeRegex {
+  struct Tok { int kind; uint32_t cp; };  // 0 literal, 1 `.`, 2 `.*`
+  std::vector<Tok> toks;
+  bool anchored_start = true, anchored_end = true;
+};
+
+inline int utf8_decode(const uint8_t* p, int64_t n, uint32_t* cp) {
+  if (n <= 0) return 0;
+  const uint8_t b = p[0];
+  int len = b < 0x80 ? 1 : (b < 0xE0 ? 2 : (b < 0xF0 ? 3 : 4));
+  if (len > n) len = (int)n;
+  uint32_t c = len == 1 ? b : (b & (0xFF >> (len + 1)));
+  for (int i = 1; i < len; ++i) c = (c << 6) | (p[i] & 0x3F);
+  *cp = c;
+  return len;
+}
+
+// regex_like (predicate.rs:246-306), kept as tokens instead of a regex string
+LikeRegex regex_like(const std::string& pattern) {
+  LikeRegex r;
+  std::vector<uint32_t> chars;
+  for (int64_t i = 0; i < (int64_t)pattern.size();) {
+    uint32_t cp = 0;
+    i += utf8_decode((const uint8_t*)pattern.data() + i, (int64_t)pattern.size() - i, &cp);
+    chars.push_back(cp);
+  }
+  size_t i = 0;
+  if (!chars.empty() && chars[0] == '%') {  // a leading % drops the `^` instead of emitting `^.*`
+    r.anchored_start = false;
+    i = 1;
+  }
+  for (; i < chars.size(); ++i) {
+    const uint32_t c = chars[i];
+    if (c == '\\') {
+      if (i + 1 < chars.size()) r.toks.push_back({0, chars[++i]});
+      else r.toks.push_back({0, '\\'});  // trailing backslash: literal
+    } else if (c == '%') {
+      r.toks.push_back({2, 0});
+    } else if (c == '_') {
+      r.toks.push_back({1, 0});
+    } else {
+      r.toks.push_back({0, c});
+    }
+  }
+  if (!r.toks.empty() && r.toks.back().kind == 2) {  // a trailing `.*` is dropped together with the `$`
+    r.toks.pop_back();
+    r.anchored_end = false;
+  }
+  return r;
+}
+
+bool regex_match_here(const LikeRegex& r, size_t ti, const uint8_t* s, int64_t n, int64_t si) {
+  if (ti == r.toks.size()) return !r.anchored_end || si == n;
+  const auto& t = r.toks[ti];
+  if (t.kind == 2) {
+    for (int64_t k = si;;) {
+      if (regex_match_here(r, ti + 1, s, n, k)) return true;
+      if (k >= n) return false;
+      uint32_t cp;
+      k += utf8_decode(s + k, n - k, &cp);
+    }
+  }
+  if (si >= n) return false;
+  uint32_t cp;
+  const int l = utf8_decode(s + si, n - si, &cp);
+  if (t.kind == 0 && cp != t.cp) return false;
+  return regex_match_here(r, ti + 1, s, n, si + l);
+}
+
+bool regex_is_match(const LikeRegex& r, const uint8_t* s, int64_t n) {
+  if (r.anchored_start) return regex_match_here(r, 0, s, n, 0);
+  for (int64_t k = 0;;) {  // unanchored: a match may start at any character
+    if (regex_match_here(r, 0, s, n, k)) return true;
+    if (k >= n) return false;
+    uint32_t cp;
+    k += utf8_decode(s + k, n - k, &cp);
+  }
+}
+
+bool contains_like_pattern(const std::string& p) { return p.find_first_of("%_\\") != std::string::npos; }
+
+struct LikePredicate {  // Predicate (predicate.rs:28-42)
+  enum { EQ, STARTS, ENDS, CONTAINS, REGEX } kind = EQ;
+  std::string needle;
+  LikeRegex re;
+  bool evaluate(const uint8_t* s, int64_t n) const {
+    const int64_t m = (int64_t)needle.size();
+    switch (kind) {
+      case EQ: return n == m && (m == 0 || memcmp(s, needle.data(), (size_t)m) == 0);
+      case STARTS: return m <= n && (m == 0 || memcmp(s, needle.data(), (size_t)m) == 0);
+      case ENDS: return m <= n && (m == 0 || memcmp(s + n - m, needle.data(), (size_t)m) == 0);
+      case CONTAINS:
+        if (m == 0) return true;
+        for (int64_t i = 0; i + m <= n; ++i)
+          if (memcmp(s + i, needle.data(), (size_t)m) == 0) return true;
+        return false;
+      default: return regex_is_match(re, s, n);
+    }
+  }
+};
+
+// Predicate::like (predicate.rs:46-64)
+LikePredicate predicate_like(const std::string& p) {
+  LikePredicate r;
+  auto ends_pct = [](const std::string& x) { return !x.empty() && x.back() == '%'; };
+  auto starts_pct = [](const std::string& x) { return !x.empty() && x.front() == '%'; };
+  if (!contains_like_pattern(p)) {
+    r.kind = LikePredicate::EQ;
+    r.needle = p;
+  } else if (ends_pct(p) && !contains_like_pattern(p.substr(0, p.size() - 1))) {
+    r.kind = LikePredicate::STARTS;
+    r.needle = p.substr(0, p.size() - 1);
+  } else if (starts_pct(p) && !contains_like_pattern(p.substr(1))) {
+    r.kind = LikePredicate::ENDS;
+    r.needle = p.substr(1);
+  } else if (starts_pct(p) && ends_pct(p) && p.size() >= 2 && !contains_like_pattern(p.substr(1, p.size() - 2))) {
+    r.kind = LikePredicate::CONTAINS;
+    r.needle = p.substr(1, p.size() - 2);
+  } else {
+    r.kind = LikePredicate::REGEX;
+    r.re = regex_like(p);
+  }
+  return r;
+}
+}  // namespace
+
+// op: 0 like, 1 nlike, 2 starts_with, 3 ends_with, 4 contains; `pattern` is a length-1 array (Scalar)
+int32_t orc_string_like(int32_t op, const orc_view* v, const orc_view* pattern, orc_out* out) {
+  out_init(out);
+  static const char* names[] = {"LIKE", "NLIKE", "STARTS_WITH", "ENDS_WITH", "CONTAINS"};
+  if (!(v->type == ORC_UTF8 || v->type == ORC_LARGE_UTF8) || pattern->type != v->type)
+    return fail(ORC_INVALID_ARGUMENT, "Invalid string/binary operation: %s %s %s", type_name(v->type), names[op],
+                type_name(pattern->type));
+  const int64_t len = v->length;
+  out->type = ORC_BOOL;
+  out->length = len;
+  if (len == 0) return ORC_OK;
+  const size_t bytes = bitmap_bytes(len);
+  uint8_t* vals = (uint8_t*)xalloc(bytes);
+  out->values = vals;
+  out->values_bytes = (int64_t)bytes;
+  if (pattern->validity && !get_bit(pattern->validity, pattern->validity_bit_offset)) {  // new_null(len) (like.rs:314)
+    out->validity = (uint8_t*)xalloc(bytes);
+    out->validity_bytes = (int64_t)bytes;
+    out->null_count = len;
+    return ORC_OK;
+  }
+  const int ow = v->type == ORC_UTF8 ? 4 : 8;
+  auto off = [ow](const orc_view* a, int64_t i) -> int64_t {
+    return ow == 4 ? (int64_t)((const int32_t*)a->offsets)[i] : ((const int64_t*)a->offsets)[i];
+  };
+  const std::string pat((const char*)pattern->values + off(pattern, 0), (size_t)(off(pattern, 1) - off(pattern, 0)));
+  LikePredicate pred;
+  bool neg = false;
+  switch (op) {  // op_scalar (like.rs:349-361)
+    case 0: pred = predicate_like(pat); break;
+    case 1: pred = predicate_like(pat); neg = true; break;
+    case 2: pred.kind = LikePredicate::STARTS; pred.needle = pat; break;
+    case 3: pred.kind = LikePredicate::ENDS; pred.needle = pat; break;
+    default: pred.kind = LikePredicate::CONTAINS; pred.needle = pat; break;
+  }
+  for (int64_t i = 0; i < len; ++i) {  // BooleanArray::from_unary: every slot is evaluated, nulls are cloned
+    const int64_t a = off(v, i), b = off(v, i + 1);
+    if (pred.evaluate((const uint8_t*)v->values + a, b - a) != neg) set_bit(vals, i);
+  }
+  if (v->validity) {
+    out->validity = nulls_clone(v, len);
+    out->validity_bytes = (int64_t)bytes;
+    out->null_count = len - count_set_bits(out->validity, 0, len);
+  }
+  return ORC_OK;
+}
+
+// length / bit_length (arrow-string/src/length.rs:35-46,:58-110)
+int32_t orc_string_length(const orc_view* v, int32_t bits, orc_out* out) {
+  out_init(out);
+  if (!(v->type == ORC_UTF8 || v->type == ORC_LARGE_UTF8))
+    return fail(ORC_COMPUTE_ERROR, "length not supported for %s", type_name(v->type));
+  const int64_t len = v->length;
+  const bool large = v->type == ORC_LARGE_UTF8;
+  out->type = large ? ORC_INT64 : ORC_INT32;
+  out->length = len;
+  if (len == 0) return ORC_OK;
+  const size_t vb = (size_t)len * (large ? 8 : 4);
+  void* o = xalloc(vb);
+  for (int64_t i = 0; i < len; ++i) {
+    if (large) ((int64_t*)o)[i] = (((const int64_t*)v->offsets)[i + 1] - ((const int64_t*)v->offsets)[i]) * (bits ? 8 : 1);
+    else ((int32_t*)o)[i] = (((const int32_t*)v->offsets)[i + 1] - ((const int32_t*)v->offsets)[i]) * (bits ? 8 : 1);
+  }
+  out->values = o;
+  out->values_bytes = (int64_t)vb;
+  if (v->validity) {
+    out->validity = nulls_clone(v, len);
+    out->validity_bytes = (int64_t)bitmap_bytes(len);
+    out->null_count = len - count_set_bits(out->validity, 0, len);
+  }
+  return ORC_OK;
+}
+
 // nullif (arrow-select/src/nullif.rs:60-121); flags 2 = values/offsets borrowed, validity owned
 int32_t orc_nullif(const orc_view* l, const orc_view* r, orc_out* out) {
   out_init(out);

@@ -88,6 +88,11 @@ int32_t orc_compare(int32_t op, const orc_view* lhs, int32_t lhs_scalar, const o
 /* arrow_arith::boolean: op numbering as AH_BOOL_* */
 int32_t orc_boolean_binary(int32_t op, const orc_view* l, const orc_view* r, orc_out* out);
 int32_t orc_boolean_unary(int32_t op, const orc_view* v, orc_out* out);
+/* arrow_string::like::{like,nlike,starts_with,ends_with,contains} with a scalar pattern (arrow-string/src/like.rs:83-205,
+ * predicate.rs:44-306); op: 0 like, 1 nlike, 2 starts_with, 3 ends_with, 4 contains. */
+int32_t orc_string_like(int32_t op, const orc_view* values, const orc_view* pattern, orc_out* out);
+/* arrow_string::length::{length, bit_length} (arrow-string/src/length.rs:58,:130) */
+int32_t orc_string_length(const orc_view* values, int32_t bits, orc_out* out);
 int32_t orc_nullif(const orc_view* left, const orc_view* right, orc_out* out);
 int32_t orc_cast(const orc_view* values, int32_t to_type, int32_t safe, orc_out* out);
 int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out);

@@ -811,7 +811,50 @@ for opname, line, exp in (("lt", 1311, [T, T, F, F]), ("lt_eq", 1347, [T, T, T, 
                                rhs=["flight"] * 4, expected=exp))
     cmp_utf8_cases.append(dict(name=f"test_utf8_array_{opname}_scalar", source=f"{C_}:{line + 14}", op=opname, lhs=names4,
                                rhs_scalar="flight", expected=exp))
-for name, cases in [("cmp_utf8", cmp_utf8_cases), ("zip", zip_cases), ("sort", sort_cases), ("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
+# ---------------------------------------------------------------- like (arrow-string/src/like.rs tests, scalar patterns)
+LK = "arrow-string/src/like.rs"
+like_cases = []
+
+
+def lk(name, values, pattern, op, expected):
+    like_cases.append(dict(name=name, source=f"{LK} ({name})", values=values, pattern=pattern, op=op, expected=expected))
+
+
+A5 = ["arrow", "parrow", "arrows", "arr", "arrow long string longer than 12 bytes"]
+lk("test_utf8_array_like_scalar_escape_testing", ["varchar(255)", "int(255)longer than 12 bytes", "varchar", "int"], "%(%)%", "like",
+   [T, T, F, F])
+lk("test_utf8_array_like_scalar_escape_regex", [".*", "a", "*"], ".*", "like", [T, F, F])
+lk("test_utf8_array_like_scalar_escape_regex_dot", [".", "a", "*"], ".", "like", [T, F, F])
+lk("test_utf8_array_like_scalar", ["arrow", "parquet", "datafusion", "flight", "long string arrow test 12 bytes"], "%ar%", "like",
+   [T, T, F, F, T])
+lk("test_utf8_array_like_scalar_start", A5, "arrow%", "like", [T, F, T, F, T])
+lk("test_utf8_and_binary_array_starts_with_scalar_start", A5, "arrow", "starts_with", [T, F, T, F, T])
+lk("test_utf8_array_like_scalar_end", A5, "%arrow", "like", [T, T, F, F, F])
+lk("test_utf8_and_binary_array_ends_with_scalar_end", A5, "arrow", "ends_with", [T, T, F, F, F])
+lk("test_utf8_array_like_scalar_equals", A5, "arrow", "like", [T, F, F, F, F])
+lk("test_utf8_array_like_scalar_one", ["arrow", "arrows", "parrow", "arr", "arrow long string longer than 12 bytes"], "arrow_", "like",
+   [F, T, F, F, F])
+lk("test_utf8_scalar_like_escape", ["a%", "a\\x", "arrow long string longer than 12 bytes"], "a\\%", "like", [T, F, F])
+lk("test_utf8_scalar_like_escape_contains", ["ba%", "ba\\x", "arrow long string longer than 12 bytes"], "%a\\%", "like", [T, F, F])
+lk("test_utf8_array_nlike_escape_testing", ["varchar(255)", "int(255) arrow long string longer than 12 bytes", "varchar", "int"],
+   "%(%)%", "nlike", [F, F, T, T])
+lk("test_utf8_array_nlike_scalar_escape_regex", [".*", "a", "*"], ".*", "nlike", [F, T, T])
+lk("test_utf8_array_nlike_scalar_escape_regex_dot", [".", "a", "*"], ".", "nlike", [F, T, T])
+lk("test_utf8_array_nlike_scalar", ["arrow", "parquet", "datafusion", "flight", "arrow long string longer than 12 bytes"], "%ar%",
+   "nlike", [F, F, T, T, F])
+lk("test_utf8_array_nlike_scalar_start", A5, "arrow%", "nlike", [F, T, F, T, F])
+lk("test_utf8_array_nlike_scalar_end", A5, "%arrow", "nlike", [F, F, T, T, T])
+lk("test_utf8_array_nlike_scalar_equals", A5, "arrow", "nlike", [F, T, T, T, T])
+lk("test_utf8_array_nlike_scalar_one", ["arrow", "arrows", "parrow", "arr", "arrow long string longer than 12 bytes"], "arrow_", "nlike",
+   [T, F, T, T, T])
+MB = ["sdlkdfFooßsdfs", "sdlkdfFooSSdggs", "sdlkdfFoosssdsd", "FooS", "Foos", "ﬀooSS", "ﬀooß", "😃sadlksffofsSsh😈klF",
+      "😱slgffoesSsh😈klF", "FFKoSS", "longer than 12 bytes FFKoSS"]
+lk("test_uff8_array_like_multibyte", MB, "%Ssh😈klF", "like", [F, F, F, F, F, F, F, T, T, F, F])
+NL = ["Earth", "Fire", "Water", "Air", N, "Air", "bbbbb\nAir"]
+lk("test_utf8_scalar_nullable_like", NL, "Air", "like", [F, F, F, T, N, T, F])
+lk("test_utf8_scalar_nullable_nlike", NL, "%a%r%", "nlike", [F, T, F, T, N, T, T])
+
+for name, cases in [("like", like_cases), ("cmp_utf8", cmp_utf8_cases), ("zip", zip_cases), ("sort", sort_cases), ("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
                     ("cast", cast_cases)]:
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump({"reference": "apache/arrow-rs 59.2.0", "cases": cases}, f, indent=1)

@@ -289,6 +289,26 @@ class Oracle:
             self._raise(st)
         return self._collect(out, left.data_type)
 
+    def string_like(self, op, values, pattern, bit_offset=0):
+        """op: 0 like, 1 nlike, 2 starts_with, 3 ends_with, 4 contains (or the name); pattern: str or None (null scalar)."""
+        op = {"like": 0, "nlike": 1, "starts_with": 2, "ends_with": 3, "contains": 4}.get(op, op)
+        hv = _Held(values, bit_offset)
+        hp = _Held(HostArray(values.data_type, [pattern if pattern is not None else ""],
+                             None if pattern is not None else np.array([False])))
+        out = Out()
+        st = self.lib.orc_string_like(op, C.byref(hv.view), C.byref(hp.view), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, A.Boolean)
+
+    def string_length(self, values, bits=False, bit_offset=0):
+        hv = _Held(values, bit_offset)
+        out = Out()
+        st = self.lib.orc_string_length(C.byref(hv.view), int(bits), C.byref(out))
+        if st:
+            self._raise(st)
+        return self._collect(out, A.Int32 if values.data_type.physical == L.AH_UTF8 else A.Int64)
+
     def aggregate(self, op, values, vector_bytes=0, bit_offset=0):
         """arrow_arith::aggregate::{sum,min,max,...}: numpy scalar or None."""
         hv = _Held(values, bit_offset)

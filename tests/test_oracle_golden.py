@@ -510,3 +510,68 @@ def test_cmp_utf8_golden(oracle, case, dt):
     if not rs:  # x10, like the reference's macro (comparison.rs:146-161)
         got = oracle.compare(CMP[case["op"]], HostArray(dt, list(case["lhs"]) * 10), HostArray(dt, list(case["rhs"]) * 10))
         assert got.values.tolist() == case["expected"] * 10
+
+
+# ------------------------------------------------------------------- like (arrow-string)
+@pytest.mark.parametrize("case", load_golden("like"), ids=lambda c: c["name"])
+@pytest.mark.parametrize("dt", [A.Utf8, A.LargeUtf8], ids=str)
+def test_like_golden(oracle, case, dt):
+    v = HostArray.from_pylist(case["values"], dt)
+    got = oracle.string_like(case["op"], v, case["pattern"])
+    assert_logical_eq(got, HostArray.from_pylist(case["expected"], A.Boolean), case["name"])
+    assert (got.valid is None) == (v.valid is None)  # from_unary clones the input's null buffer
+
+
+def _py_regex_like(pattern):
+    """regex_like (arrow-string/src/predicate.rs:246-306) restated over Python's `re`: an independent regex engine
+    for the constructs the reference emits (the oracle has its own small matcher; this pins it)."""
+    import re
+    out, chars, i = [], list(pattern), 0
+    if chars and chars[0] == "%":
+        i = 1
+    else:
+        out.append("^")
+    while i < len(chars):
+        c = chars[i]
+        if c == "\\":
+            if i + 1 < len(chars):
+                out.append(re.escape(chars[i + 1]))
+                i += 1
+            else:
+                out.append(re.escape("\\"))
+        elif c == "%":
+            out.append(".*")
+        elif c == "_":
+            out.append(".")
+        else:
+            out.append(re.escape(c))
+        i += 1
+    if out and out[-1] == ".*":
+        out.pop()
+    else:
+        out.append(r"\Z")
+    return re.compile("".join(out), re.DOTALL)
+
+
+def test_like_oracle_agrees_with_a_real_regex_engine(oracle):
+    rng = np.random.default_rng(7)
+    alphabet = ["a", "b", "%", "_", "\\", ".", "*", "(", "ß", "😈", "\n", "ab"]
+    for it in range(400):
+        pat = "".join(rng.choice(alphabet, int(rng.integers(0, 7))))
+        rows = ["".join(rng.choice(["a", "b", "%", "_", "\\", ".", "*", "(", "ß", "😈", "\n"], int(rng.integers(0, 9)))) for _ in range(40)]
+        v = HostArray.from_pylist(rows, A.Utf8)
+        rx = _py_regex_like(pat)
+        want = [rx.search(r) is not None for r in rows]
+        assert oracle.string_like("like", v, pat).to_pylist() == want, (pat, rows)
+        assert oracle.string_like("nlike", v, pat).to_pylist() == [not w for w in want], pat
+    # the literal-needle forms against Python's own string methods
+    rows = ["", "a", "ab", "ba", "aab%", "%_", "ßß", "xß😈"]
+    v = HostArray.from_pylist(rows, A.LargeUtf8)
+    for needle in ["", "a", "ab", "%", "_", "ß", "😈", "ß😈"]:
+        assert oracle.string_like("starts_with", v, needle).to_pylist() == [r.startswith(needle) for r in rows]
+        assert oracle.string_like("ends_with", v, needle).to_pylist() == [r.endswith(needle) for r in rows]
+        assert oracle.string_like("contains", v, needle).to_pylist() == [needle in r for r in rows]
+    nulls = oracle.string_like("like", HostArray.from_pylist(["a", None], A.Utf8), None)
+    assert nulls.to_pylist() == [None, None] and nulls.null_count == 2
+    assert oracle.string_length(HostArray.from_pylist(["hello", None, "", "ß😈"], A.Utf8)).to_pylist() == [5, None, 0, 6]
+    assert oracle.string_length(HostArray.from_pylist(["hello", "ß"], A.LargeUtf8), bits=True).to_pylist() == [40, 16]
