@@ -20,11 +20,33 @@ namespace {
 
 enum : uint16_t { TOK_ANY1 = 256, TOK_STAR = 257 };  // 0..255 = that literal byte
 
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
 __device__ __forceinline__ int utf8_len(uint8_t lead) {
   return lead < 0x80 ? 1 : (lead < 0xE0 ? 2 : (lead < 0xF0 ? 3 : 4));
 }
 
-__device__ bool like_match(const uint8_t* s, int64_t n, const uint16_t* pat, int m) {
+// the row's bytes: either a pointer into HBM or, for rows of at most 32 bytes, four registers (no memory access
+// inside the matching loop: the byte-at-a-time walk is a chain of dependent loads otherwise — 3.7 ms for `%99%`
+// over 2^27 rows with global byte loads, 2.9 ms with the rows staged in LDS)
+struct MemBytes {
+  const uint8_t* p;
+  __device__ __forceinline__ uint8_t operator[](int64_t i) const { return p[i]; }
+};
+struct RegBytes {
+  uint64_t r0, r1, r2, r3;
+  __device__ __forceinline__ uint8_t operator[](int64_t i) const {
+    const uint64_t w = i < 16 ? (i < 8 ? r0 : r1) : (i < 24 ? r2 : r3);
+    return (uint8_t)(w >> ((i & 7) * 8));
+  }
+};
+
+template <typename B>
+__device__ __forceinline__ bool like_match(const B& s, int64_t n, const uint16_t* pat, int m) {
   int64_t i = 0, star_i = 0;
   int p = 0, star_p = -1;
   while (i < n) {
@@ -51,6 +73,14 @@ __device__ bool like_match(const uint8_t* s, int64_t n, const uint16_t* pat, int
   return p == m;
 }
 
+// up to 8 bytes at p, never touching memory at or past `end`
+__device__ __forceinline__ uint64_t load_tail(const uint8_t* p, const uint8_t* end) {
+  if (p + 8 <= end) return load_u64_unaligned(p);
+  uint64_t v = 0;
+  for (int k = 0; p + k < end; ++k) v |= (uint64_t)p[k] << (8 * k);
+  return v;
+}
+
 template <typename O>
 __global__ __launch_bounds__(256) void like_kernel(const O* offs, const uint8_t* data, int64_t len, const uint16_t* pat,
                                                    int m, int neg, unsigned long long* out) {
@@ -61,12 +91,24 @@ __global__ __launch_bounds__(256) void like_kernel(const O* offs, const uint8_t*
   const int lane = threadIdx.x & 63;
   const int64_t nwords = (len + 63) >> 6;
   const int64_t wave0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  const uint8_t* data_end = data + (int64_t)offs[len];
   for (int64_t w = wave0; w < nwords; w += nwaves) {
     const int64_t row = w * 64 + lane;
     bool res = false;
     if (row < len) {
-      const int64_t a0 = (int64_t)offs[row];
-      res = like_match(data + a0, (int64_t)offs[row + 1] - a0, pp, m) != (neg != 0);
+      const int64_t a0 = (int64_t)offs[row], n = (int64_t)offs[row + 1] - a0;
+      const uint8_t* sp = data + a0;
+      if (n <= 32) {
+        RegBytes rb;
+        rb.r0 = n > 0 ? load_tail(sp, data_end) : 0;
+        rb.r1 = n > 8 ? load_tail(sp + 8, data_end) : 0;
+        rb.r2 = n > 16 ? load_tail(sp + 16, data_end) : 0;
+        rb.r3 = n > 24 ? load_tail(sp + 24, data_end) : 0;
+        res = like_match(rb, n, pp, m);
+      } else {
+        res = like_match(MemBytes{sp}, n, pp, m);
+      }
+      res = res != (neg != 0);
     }
     const unsigned long long word = __ballot(res);
     if (lane == 0) out[w] = word;
@@ -207,7 +249,7 @@ extern "C" ah_status ah_string_like(ah_context* ctx, ah_like_op op, const ah_arr
   {
     ah_prof_scope ps(ctx, "string_like");
     const int64_t nwords = (len + 63) >> 6;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(256 * 16, ah_ceil_div(nwords, 4)));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(256 * 32, ah_ceil_div(nwords, 4)));
     const int neg = op == AH_NLIKE;
     if (t == AH_UTF8)
       like_kernel<int32_t><<<grid, 256, 0, ctx->stream>>>((const int32_t*)values->offsets, (const uint8_t*)values->values, len,

@@ -1988,28 +1988,38 @@ LikeRegex regex_like(const std::string& pattern) {
   return r;
 }
 
-bool regex_match_here(const LikeRegex& r, size_t ti, const uint8_t* s, int64_t n, int64_t si) {
+// `dead` memoises (token, position) pairs already shown not to match, which keeps the backtracking polynomial
+// (the regex crate the reference uses is linear-time; an exponential oracle would only be a test hazard)
+bool regex_match_here(const LikeRegex& r, size_t ti, const uint8_t* s, int64_t n, int64_t si, std::vector<uint8_t>& dead) {
   if (ti == r.toks.size()) return !r.anchored_end || si == n;
+  uint8_t& d = dead[ti * (size_t)(n + 1) + (size_t)si];
+  if (d) return false;
   const auto& t = r.toks[ti];
+  bool ok = false;
   if (t.kind == 2) {
     for (int64_t k = si;;) {
-      if (regex_match_here(r, ti + 1, s, n, k)) return true;
-      if (k >= n) return false;
+      if (regex_match_here(r, ti + 1, s, n, k, dead)) {
+        ok = true;
+        break;
+      }
+      if (k >= n) break;
       uint32_t cp;
       k += utf8_decode(s + k, n - k, &cp);
     }
+  } else if (si < n) {
+    uint32_t cp;
+    const int l = utf8_decode(s + si, n - si, &cp);
+    ok = (t.kind == 1 || cp == t.cp) && regex_match_here(r, ti + 1, s, n, si + l, dead);
   }
-  if (si >= n) return false;
-  uint32_t cp;
-  const int l = utf8_decode(s + si, n - si, &cp);
-  if (t.kind == 0 && cp != t.cp) return false;
-  return regex_match_here(r, ti + 1, s, n, si + l);
+  if (!ok) d = 1;
+  return ok;
 }
 
 bool regex_is_match(const LikeRegex& r, const uint8_t* s, int64_t n) {
-  if (r.anchored_start) return regex_match_here(r, 0, s, n, 0);
+  std::vector<uint8_t> dead((r.toks.size() + 1) * (size_t)(n + 1), 0);
+  if (r.anchored_start) return regex_match_here(r, 0, s, n, 0, dead);
   for (int64_t k = 0;;) {  // unanchored: a match may start at any character
-    if (regex_match_here(r, 0, s, n, k)) return true;
+    if (regex_match_here(r, 0, s, n, k, dead)) return true;
     if (k >= n) return false;
     uint32_t cp;
     k += utf8_decode(s + k, n - k, &cp);

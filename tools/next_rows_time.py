@@ -59,4 +59,17 @@ res["ipc_encode_ms"] = med(lambda: ipc.encode_batch(rb))
 res["ipc_encode_GBps"] = round(2 * body.nbytes / (res["ipc_encode_ms"] * 1e-3) / 1e9, 1)  # read + write
 sch = ipc.Schema.of(rb)
 res["ipc_decode_ms"] = med(lambda: ipc.decode_batch(meta, body.ptr, body.nbytes, sch, ctx, keepalive=(body,)))
+del a, f, p, rb, body
+
+# string predicates on the config-4 cast output (LargeUtf8, ~9 bytes per row): offsets + bytes read once, 1 bit/row out
+from arrow_rs_amd import compute as K  # noqa: E402
+ns = 1 << 27
+src = bench.gen_i64_column(A, ctx, ns, 42, 0.9, 0, -10**6, 10**6)
+scol = K.cast(K.cast(src, A.Float64), A.LargeUtf8)
+res["like_rows"], res["like_text_bytes"] = ns, scol.values.nbytes
+for name, fn, pat in (("like_contains", K.like, "%99%"), ("like_prefix", K.like, "-1%"), ("like_general", K.like, "%1_3%.0"),
+                      ("starts_with", K.starts_with, "12"), ("length", lambda c, _p: K.length(c), None)):
+    res[name + "_ms"] = med(lambda: fn(scol, pat))
+alg = scol.values.nbytes + (ns + 1) * 8 + ns // 8
+res["like_contains_GBps"] = round(alg / (res["like_contains_ms"] * 1e-3) / 1e9, 1)
 print(json.dumps(res))
