@@ -292,8 +292,11 @@ AH_API ah_status ah_string_length(ah_context* ctx, const ah_array_view* values, 
 /* arrow_cast::cast_with_options (arrow-cast/src/cast/mod.rs:790), restricted to
  * numeric<->numeric (mod.rs:1578-1697 via cast_numeric_arrays :2550) and
  * Float64/Float32/integers -> Utf8 / LargeUtf8 (mod.rs:1552-1553 via
- * value_to_string, cast/string.rs:21-39), and Boolean <-> numeric (mod.rs:1243-1290:
- * `value != 0`; true -> 1, false -> 0).  safe mirrors CastOptions.safe. */
+ * value_to_string, cast/string.rs:21-39), Boolean <-> numeric (mod.rs:1243-1290:
+ * `value != 0`; true -> 1, false -> 0), and Utf8 / LargeUtf8 -> integers / Float32 / Float64
+ * (parse_string, cast/string.rs:66-120 -> Parser::parse, parse.rs:446-528: text that does not parse becomes
+ * null in safe mode — a null buffer is always attached — and AH_CAST_ERROR "Cannot cast string '..' to value
+ * of <T> type" for the first such row otherwise; floats are correctly rounded).  safe mirrors CastOptions.safe. */
 AH_API ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_type to_type,
                          int32_t safe, ah_array_out* out);
 AH_API int32_t ah_can_cast_types(ah_type from, ah_type to); /* cast/mod.rs:115 subset */

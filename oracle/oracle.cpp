@@ -1634,6 +1634,164 @@ int32_t bitwise_typed(int op, const orc_view* l, bool l_s, const orc_view* r, bo
 }  // namespace
 
 // =================================================================== exports
+namespace {
+
+// ---- Utf8 / LargeUtf8 -> numeric (arrow-cast/src/cast/string.rs:66-120 parse_string -> Parser::parse, parse.rs:446-528)
+bool is_ascii_ws(uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == 0x0C || c == '\r'; }  // u8::is_ascii_whitespace
+bool is_dec_digit(uint8_t c) { return c >= '0' && c <= '9'; }
+
+// atoi::FromRadix10SignedChecked (atoi 3.1.0): optional sign, then every following digit with checked arithmetic;
+// returns the number of bytes used and whether the value survived
+template <typename T>
+size_t atoi_signed_checked(const uint8_t* t, size_t n, bool* some, T* value) {
+  size_t i = 0;
+  bool neg = false;
+  if (n > 0 && (t[0] == '+' || t[0] == '-')) {
+    neg = t[0] == '-';
+    i = 1;
+  }
+  T acc = 0;
+  bool ok = true;
+  for (; i < n && is_dec_digit(t[i]); ++i) {
+    const T d = (T)(t[i] - '0');
+    if (ok && __builtin_mul_overflow(acc, (T)10, &acc)) ok = false;
+    if (ok && (neg ? __builtin_sub_overflow(acc, d, &acc) : __builtin_add_overflow(acc, d, &acc))) ok = false;
+  }
+  *some = ok;
+  *value = acc;
+  return i;
+}
+
+// parser_primitive! (parse.rs:492-516)
+template <typename T>
+bool parse_native_int(const uint8_t* raw, size_t n, T* out) {
+  auto last_is_digit = [&]() { return n > 0 && is_dec_digit(raw[n - 1]); };
+  if (!last_is_digit()) {
+    while (n > 0 && is_ascii_ws(raw[n - 1])) --n;  // trim_ascii_end
+    if (!last_is_digit()) return false;
+  }
+  bool some;
+  T v;
+  if (atoi_signed_checked<T>(raw, n, &some, &v) == n && some) {
+    *out = v;
+    return true;
+  }
+  while (n > 0 && is_ascii_ws(raw[0])) {  // trim_ascii_start
+    ++raw;
+    --n;
+  }
+  if (atoi_signed_checked<T>(raw, n, &some, &v) == n && some) {
+    *out = v;
+    return true;
+  }
+  return false;
+}
+
+// lexical_core::parse::<f32 | f64> (lexical-core 1.0.6, standard format; sources not under /root/reference — the
+// grammar is restated from its documentation): [+-] (digits [. digits*] | . digits) [(e|E) [+-] digits], or
+// case-insensitive nan / inf / infinity after the sign; the whole text must be consumed.  The VALUE is the correctly
+// rounded float, which glibc's strtod / strtof also produce: they do the arithmetic here.
+template <typename F>
+bool lexical_parse_float(const uint8_t* t, size_t n, F* out) {
+  size_t i = 0;
+  if (n == 0) return false;
+  bool neg = false;
+  if (t[0] == '+' || t[0] == '-') {
+    neg = t[0] == '-';
+    i = 1;
+  }
+  const size_t body = i;
+  size_t digits = 0;
+  while (i < n && is_dec_digit(t[i])) ++i, ++digits;
+  if (i < n && t[i] == '.') {
+    ++i;
+    while (i < n && is_dec_digit(t[i])) ++i, ++digits;
+  }
+  if (digits == 0) {
+    std::string low;
+    for (size_t k = body; k < n; ++k) low += (char)tolower(t[k]);
+    F v;
+    if (low == "nan") v = std::numeric_limits<F>::quiet_NaN();
+    else if (low == "inf" || low == "infinity") v = std::numeric_limits<F>::infinity();
+    else return false;
+    *out = neg ? -v : v;
+    return true;
+  }
+  if (i < n && (t[i] == 'e' || t[i] == 'E')) {
+    ++i;
+    if (i < n && (t[i] == '+' || t[i] == '-')) ++i;
+    size_t ed = 0;
+    while (i < n && is_dec_digit(t[i])) ++i, ++ed;
+    if (ed == 0) return false;
+  }
+  if (i != n) return false;
+  const std::string z((const char*)t, n);
+  *out = sizeof(F) == 8 ? (F)strtod(z.c_str(), nullptr) : (F)strtof(z.c_str(), nullptr);
+  return true;
+}
+
+// Float32Type / Float64Type::parse (parse.rs:458-475): the text, then the text trimmed on both sides
+template <typename F>
+bool parse_native_float(const uint8_t* raw, size_t n, F* out) {
+  if (lexical_parse_float<F>(raw, n, out)) return true;
+  while (n > 0 && is_ascii_ws(raw[0])) ++raw, --n;
+  while (n > 0 && is_ascii_ws(raw[n - 1])) --n;
+  return lexical_parse_float<F>(raw, n, out);
+}
+
+template <typename T>
+bool parse_native(const uint8_t* raw, size_t n, T* out) {
+  if constexpr (std::is_floating_point<T>::value) return parse_native_float<T>(raw, n, out);
+  else return parse_native_int<T>(raw, n, out);
+}
+
+// parse_string_iter (string.rs:87-120)
+template <typename T>
+int32_t parse_string(const orc_view* in, int32_t to, int32_t safe, orc_out* out) {
+  const int64_t len = in->length;
+  const bool large = in->type == ORC_LARGE_UTF8;
+  out->type = to;
+  out->length = len;
+  if (len == 0) return ORC_OK;
+  auto off = [&](int64_t i) -> int64_t { return large ? ((const int64_t*)in->offsets)[i] : (int64_t)((const int32_t*)in->offsets)[i]; };
+  T* vals = (T*)xalloc((size_t)len * sizeof(T));
+  uint8_t* nb = safe ? (uint8_t*)xalloc(bitmap_bytes(len)) : nullptr;
+  for (int64_t i = 0; i < len; ++i) {
+    const bool valid = !in->validity || get_bit(in->validity, in->validity_bit_offset + i);
+    T v{};
+    if (valid) {
+      const int64_t a = off(i), b = off(i + 1);
+      const bool ok = parse_native<T>((const uint8_t*)in->values + a, (size_t)(b - a), &v);
+      if (!ok) {
+        v = T{};
+        if (!safe) {
+          const std::string text((const char*)in->values + a, (size_t)(b - a));
+          free(vals);
+          return fail(ORC_CAST_ERROR, "Cannot cast string '%s' to value of %s type", text.c_str(), type_name(to));
+        }
+      } else if (nb) {
+        set_bit(nb, i);
+      }
+    }
+    vals[i] = v;
+  }
+  out->values = vals;
+  out->values_bytes = len * (int64_t)sizeof(T);
+  if (safe) {  // from_trusted_len_iter: always a null buffer
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(len);
+    out->null_count = len - count_set_bits(nb, 0, len);
+  } else if (in->validity) {  // try_new(values, nulls().cloned())
+    out->validity = nulls_clone(in, len);
+    out->validity_bytes = (int64_t)bitmap_bytes(len);
+    out->null_count = len - count_set_bits(out->validity, 0, len);
+  }
+  return ORC_OK;
+}
+
+
+}  // namespace
+
 extern "C" {
 
 const char* orc_last_error(void) { return g_err.c_str(); }
@@ -2179,6 +2337,21 @@ int32_t orc_nullif(const orc_view* l, const orc_view* r, orc_out* out) {
 
 int32_t orc_cast(const orc_view* in, int32_t to, int32_t safe, orc_out* out) {
   out_init(out);
+  if ((in->type == ORC_UTF8 || in->type == ORC_LARGE_UTF8) && to != ORC_UTF8 && to != ORC_LARGE_UTF8) {
+    switch (to) {
+      case ORC_INT8: return parse_string<int8_t>(in, to, safe, out);
+      case ORC_INT16: return parse_string<int16_t>(in, to, safe, out);
+      case ORC_INT32: return parse_string<int32_t>(in, to, safe, out);
+      case ORC_INT64: return parse_string<int64_t>(in, to, safe, out);
+      case ORC_UINT8: return parse_string<uint8_t>(in, to, safe, out);
+      case ORC_UINT16: return parse_string<uint16_t>(in, to, safe, out);
+      case ORC_UINT32: return parse_string<uint32_t>(in, to, safe, out);
+      case ORC_UINT64: return parse_string<uint64_t>(in, to, safe, out);
+      case ORC_FLOAT32: return parse_string<float>(in, to, safe, out);
+      case ORC_FLOAT64: return parse_string<double>(in, to, safe, out);
+    }
+    return fail(ORC_CAST_ERROR, "Casting from %s to %s not supported", type_name(in->type), type_name(to));
+  }
   if (in->type == ORC_BOOL && to != ORC_BOOL) {
     switch (to) {
       case ORC_INT8: return cast_bool_to_num<int8_t>(in, to, out);

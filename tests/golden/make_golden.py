@@ -519,6 +519,41 @@ cast_cases.append(dict(name="test_cast_bool_to_i32", source="arrow-cast/src/cast
 cast_cases.append(dict(name="test_cast_bool_to_f64", source="arrow-cast/src/cast/mod.rs:5046-5054",
                        values=arr("Boolean", [T, F, N]), to="Float64", expected=arr("Float64", [1.0, 0.0, N])))
 
+# Utf8 / LargeUtf8 -> numeric: Parser::parse through parse_string (arrow-cast/src/cast/string.rs:66-120)
+for st in ("Utf8", "LargeUtf8"):
+    cast_cases.append(dict(name=f"test_cast_utf8_to_i32_{st}", source="arrow-cast/src/cast/mod.rs:4879-4889",
+                           values=arr(st, ["5", "6", "seven", "8", "9.1"]), to="Int32", expected=arr("Int32", [5, 6, N, 8, N])))
+    # test_cast_utf8view_to_f32 / test_cast_string_to_f16 (:4904, :4915) use these texts; 4.56 and 8.9 are the
+    # nearest Float32 values, written here as their exact decimal expansions
+    cast_cases.append(dict(name=f"test_cast_string_to_f32_{st}", source="arrow-cast/src/cast/mod.rs:4904-4913",
+                           values=arr(st, ["3", "4.56", "seven", "8.9"]), to="Float32",
+                           expected=arr("Float32", [3.0, 4.559999942779541015625, N, 8.89999961853027343750])))
+    cast_cases.append(dict(name=f"test_cast_string_to_integral_overflow_{st}", source="arrow-cast/src/cast/mod.rs:5337-5354",
+                           values=arr(st, ["123", "-123", "86374", N]), to="Int16", expected=arr("Int16", [123, -123, N, N])))
+cast_cases.append(dict(name="test_cast_with_options_utf8_to_i32", source="arrow-cast/src/cast/mod.rs:4944-4964",
+                       values=arr("Utf8", ["5", "6", "seven", "8", "9.1"]), to="Int32", safe=False, error="CastError",
+                       message="Cannot cast string 'seven' to value of Int32 type"))
+# test_parse_empty (parse.rs:2882-2897) and test_parse_prefix_white_space (:2911-2955), one array per target type
+cast_cases.append(dict(name="test_parse_empty_ints", source="arrow-cast/src/parse.rs:2882-2897",
+                       values=arr("Utf8", ["", "+"]), to="Int32", expected=arr("Int32", [N, N])))
+for to_t in ("Int64", "UInt32", "UInt64"):
+    cast_cases.append(dict(name=f"test_parse_empty_{to_t}", source="arrow-cast/src/parse.rs:2882-2897",
+                           values=arr("Utf8", ["", "+"]), to=to_t, expected=arr(to_t, [N, N])))
+for to_t in ("Float32", "Float64"):
+    cast_cases.append(dict(name=f"test_parse_empty_{to_t}", source="arrow-cast/src/parse.rs:2882-2897",
+                           values=arr("Utf8", ["", "+"]), to=to_t, expected=arr(to_t, [N, N])))
+cast_cases.append(dict(name="test_parse_white_space_f64", source="arrow-cast/src/parse.rs:2911-2955",
+                       values=arr("Utf8", [" 1.5", "\t\n 20.54", "\n2.5", "\n-942.5423", "\n\t\n\t\n40.5123", " 1.5",
+                                           "\n\t\n\t\n-40.5123", " -1.5", "1.5 ", "40.5123\n", "40.5123\n\t\n\t\n", "-942.5423\t",
+                                           " 1.5 ", "\t\n 20.54 \t", "\n-942.5423\n", "1.5abc", "40.5123x"]), to="Float64",
+                       expected=arr("Float64", [1.5, 20.54, 2.5, -942.5423, 40.5123, 1.5, -40.5123, -1.5, 1.5, 40.5123, 40.5123,
+                                                -942.5423, 1.5, 20.54, -942.5423, N, N])))
+cast_cases.append(dict(name="test_parse_white_space_i32", source="arrow-cast/src/parse.rs:2911-2955",
+                       values=arr("Utf8", [" 3", "          30", "\n \n 100", " \n25", "\t800", "\t  \n \t 851", "\t\n\t\n\n\n\t1",
+                                           " \n-25", "\t-800", "3 ", "30          ", "-25 \n", "800\t", " 3 ", "\n \n 100 \n",
+                                           "\t-800\t\n", "30x", "100px", "-25!", "3j", "3"]), to="Int32",
+                       expected=arr("Int32", [3, 30, 100, 25, 800, 851, 1, -25, -800, 3, 30, -25, 800, 3, 100, -800, N, N, N, N, 3])))
+
 bool_cases = []
 A4, B4 = [F, F, T, T], [F, T, F, T]
 bool_cases.append(dict(name="test_bool_array_and", source="arrow-arith/src/boolean.rs:364", op="and",

@@ -71,5 +71,18 @@ for name, fn, pat in (("like_contains", K.like, "%99%"), ("like_prefix", K.like,
                       ("starts_with", K.starts_with, "12"), ("length", lambda c, _p: K.length(c), None)):
     res[name + "_ms"] = med(lambda: fn(scol, pat))
 alg = scol.values.nbytes + (ns + 1) * 8 + ns // 8
+
+# Utf8 -> numeric (cast_parse.hip): the config-4 text parsed back; offsets + text + validity in, 8 B + 1 bit out
+res["parse_f64_ms"] = med(lambda: K.cast(scol, A.Float64))
+res["parse_f64_GBps"] = round((alg + ns * 8 + ns // 8) / (res["parse_f64_ms"] * 1e-3) / 1e9, 1)
+itext = K.cast(src, A.LargeUtf8)
+res["parse_i64_text_bytes"] = itext.values.nbytes
+res["parse_i64_ms"] = med(lambda: K.cast(itext, A.Int64))
+res["parse_i64_GBps"] = round((itext.values.nbytes + (ns + 1) * 8 + ns // 8 + ns * 8 + ns // 8) / (res["parse_i64_ms"] * 1e-3) / 1e9, 1)
+res["parse_i32_ms"] = med(lambda: K.cast(itext, A.Int32))
+wide = K.cast(K.cast(bench.gen_i64_column(A, ctx, ns, 43, 0.9, 0), A.Float64), A.LargeUtf8)  # 17-digit exponent forms
+res["parse_f64_wide_text_bytes"] = wide.values.nbytes
+res["parse_f64_wide_ms"] = med(lambda: K.cast(wide, A.Float64))
+del itext, wide
 res["like_contains_GBps"] = round(alg / (res["like_contains_ms"] * 1e-3) / 1e9, 1)
 print(json.dumps(res))
