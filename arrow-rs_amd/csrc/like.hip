@@ -44,6 +44,12 @@ struct RegBytes {
     return (uint8_t)(w >> ((i & 7) * 8));
   }
 };
+struct Reg2Bytes {  // rows of at most 16 bytes (most numeric text): one select per byte instead of three
+  uint64_t r0, r1;
+  __device__ __forceinline__ uint8_t operator[](int64_t i) const {
+    return (uint8_t)((i < 8 ? r0 : r1) >> ((i & 7) * 8));
+  }
+};
 
 template <typename B>
 __device__ __forceinline__ bool like_match(const B& s, int64_t n, const uint16_t* pat, int m) {
@@ -98,7 +104,12 @@ __global__ __launch_bounds__(256) void like_kernel(const O* offs, const uint8_t*
     if (row < len) {
       const int64_t a0 = (int64_t)offs[row], n = (int64_t)offs[row + 1] - a0;
       const uint8_t* sp = data + a0;
-      if (n <= 32) {
+      if (n <= 16) {
+        Reg2Bytes rb;
+        rb.r0 = n > 0 ? load_tail(sp, data_end) : 0;
+        rb.r1 = n > 8 ? load_tail(sp + 8, data_end) : 0;
+        res = like_match(rb, n, pp, m);
+      } else if (n <= 32) {
         RegBytes rb;
         rb.r0 = n > 0 ? load_tail(sp, data_end) : 0;
         rb.r1 = n > 8 ? load_tail(sp + 8, data_end) : 0;
