@@ -174,6 +174,8 @@ SIGNATURES = {
     "ah_interleave": (C.c_int32, [_P, C.c_int32, _VIEW, _VIEW, _VIEW, _OUT]),
     "ah_zip": (C.c_int32, [_P, _VIEW, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
     "ah_sort_to_indices": (C.c_int32, [_P, _VIEW, C.c_int32, C.c_int32, C.c_int64, _OUT]),
+    "ah_rank": (C.c_int32, [_P, _VIEW, C.c_int32, C.c_int32, _OUT]),
+    "ah_shift": (C.c_int32, [_P, _VIEW, C.c_int64, _OUT]),
     "ah_lexsort_to_indices": (C.c_int32, [_P, C.c_int32, _VIEW, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64, _OUT]),
     "ah_selection_and_then": (C.c_int32, [_P, _VIEW, _VIEW, _OUT]),
     "ah_selection_combine": (C.c_int32, [_P, C.c_int32, _VIEW, _VIEW, _OUT]),

@@ -21,3 +21,5 @@ from .kernels.bitwise import (bitwise_and, bitwise_or, bitwise_xor, bitwise_shif
                               bitwise_and_not, bitwise_not, bitwise_and_scalar, bitwise_or_scalar, bitwise_xor_scalar,
                               bitwise_shift_left_scalar, bitwise_shift_right_scalar)
 from .kernels.like import like, nlike, starts_with, ends_with, contains, length, bit_length  # noqa: F401,E402
+from .kernels.window import shift  # noqa: F401,E402
+from .kernels.rank import rank, rank_array  # noqa: F401,E402

@@ -233,3 +233,95 @@ extern "C" ah_status ah_copy_rows_into(ah_context* ctx, const ah_array_view* src
   if (appended_nulls) *appended_nulls = len - set;
   return AH_OK;
 }
+
+// arrow_select::window::shift (arrow-select/src/window.rs:56-80): offset 0 is a clone (zero copy), |offset| >= len
+// (or i64::MIN) is new_null_array(len), otherwise concat(nulls(k), slice(0, len - k)) for a right shift or
+// concat(slice(k, len - k), nulls(k)) for a left shift.  Built exactly that way: the null piece is a zeroed
+// scratch array, the data piece a sub-view, and ah_concat does the copies and the bit-shifted validity merge.
+extern "C" ah_status ah_shift(ah_context* ctx, const ah_array_view* values, int64_t offset, ah_array_out* out) {
+  if (!ctx || !values || !out) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  hipSetDevice(ctx->device);
+  const ah_type t = values->type;
+  const int w = ah_type_width(t);
+  const bool is_str = t == AH_UTF8 || t == AH_LARGE_UTF8;
+  if ((w < 0 && !is_str) || t == AH_UTF8_VIEW || t == AH_BINARY_VIEW)
+    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "shift not supported for type %s", ah_type_name(t));
+  const int64_t len = values->length;
+  out->type = t;
+  out->length = len;
+  if (offset == 0) {  // make_array(array.to_data()): the same buffers
+    out->values = const_cast<void*>(values->values);
+    out->values_bit_offset = values->values_bit_offset;
+    out->values_bytes = w > 0 ? len * w : 0;
+    out->offsets = const_cast<void*>(values->offsets);
+    out->flags = AH_OUT_BORROWED;
+    if (values->validity) {
+      int64_t nulls = 0;
+      AH_TRY(ah_resolve_null_count(ctx, values, &nulls));
+      out->validity = const_cast<uint8_t*>(values->validity);
+      out->validity_bit_offset = values->validity_bit_offset;
+      out->null_count = nulls;
+    }
+    return AH_OK;
+  }
+  if (len == 0) return AH_OK;
+  const size_t ow = t == AH_UTF8 ? 4 : 8;
+  const bool all_null = offset == INT64_MIN || (offset < 0 ? -offset : offset) >= len;
+  if (all_null) {  // new_null_array: zeroed values / offsets, every validity bit clear
+    const size_t vbytes = is_str ? 0 : (w ? (size_t)len * w : ah_bitmap_bytes(len));
+    const size_t bbytes = ah_bitmap_bytes(len), obytes = is_str ? (size_t)(len + 1) * ow : 0;
+    void *ov = nullptr, *ob = nullptr, *oo = nullptr;
+    ah_status st = ah_out_alloc(ctx, std::max<size_t>(vbytes, 8), &ov);
+    if (st == AH_OK) st = ah_out_alloc(ctx, bbytes, &ob);
+    if (st == AH_OK && is_str) st = ah_out_alloc(ctx, obytes, &oo);
+    hipError_t e = hipSuccess;
+    if (st == AH_OK) e = hipMemsetAsync(ov, 0, std::max<size_t>(vbytes, 8), ctx->stream);
+    if (st == AH_OK && e == hipSuccess) e = hipMemsetAsync(ob, 0, bbytes, ctx->stream);
+    if (st == AH_OK && e == hipSuccess && oo) e = hipMemsetAsync(oo, 0, obytes, ctx->stream);
+    if (st == AH_OK && e == hipSuccess) e = ah_end_of_call_sync(ctx);
+    if (st == AH_OK && e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in shift", hipGetErrorString(e));
+    if (st != AH_OK) {
+      ah_out_free(ctx, ov, std::max<size_t>(vbytes, 8));
+      ah_out_free(ctx, ob, bbytes);
+      ah_out_free(ctx, oo, obytes);
+      return st;
+    }
+    out->values = ov;
+    out->values_bytes = (int64_t)vbytes;
+    out->validity = (uint8_t*)ob;
+    out->validity_bytes = (int64_t)bbytes;
+    out->offsets = oo;
+    out->offsets_bytes = (int64_t)obytes;
+    out->null_count = len;
+    return AH_OK;
+  }
+  const int64_t k = offset < 0 ? -offset : offset, keep = len - k, first = offset > 0 ? 0 : k;
+  // the null piece
+  const size_t zbytes = std::max<size_t>({is_str ? (size_t)(k + 1) * ow : (w ? (size_t)k * w : ah_bitmap_bytes(k)), ah_bitmap_bytes(k), (size_t)8});
+  void* zeros = nullptr;
+  AH_TRY(ah_pool_alloc(ctx, zbytes, &zeros));
+  hipMemsetAsync(zeros, 0, zbytes, ctx->stream);
+  ah_array_view nullp{};
+  nullp.type = t;
+  nullp.length = k;
+  nullp.null_count = k;
+  nullp.values = zeros;
+  nullp.validity = (const uint8_t*)zeros;
+  nullp.offsets = is_str ? zeros : nullptr;
+  // the data piece: Array::slice(first, keep)
+  ah_array_view data = *values;
+  data.length = keep;
+  data.null_count = -1;
+  if (is_str) data.offsets = (const uint8_t*)values->offsets + (size_t)first * ow;
+  else if (w == 0) data.values_bit_offset = values->values_bit_offset + first;
+  else data.values = (const uint8_t*)values->values + (size_t)first * w;
+  if (values->validity) data.validity_bit_offset = values->validity_bit_offset + first;
+  else data.null_count = 0;
+  ah_array_view pieces[2];
+  pieces[0] = offset > 0 ? nullp : data;
+  pieces[1] = offset > 0 ? data : nullp;
+  const ah_status st = ah_concat(ctx, 2, pieces, out);
+  ah_pool_free(ctx, zeros);  // the pool is stream-ordered: safe right after the enqueue
+  return st;
+}

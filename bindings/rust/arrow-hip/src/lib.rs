@@ -13,6 +13,8 @@
 //! | [`cast`], [`cast_with_options`] | `arrow_cast::cast` (arrow-cast/src/cast/mod.rs:347,:790) |
 //! | [`and`], [`or`], [`not`], [`is_null`], … | `arrow_arith::boolean` (arrow-arith/src/boolean.rs:60-360) |
 //! | [`concat`] | `arrow_select::concat::concat` (arrow-select/src/concat.rs:495) |
+//! | [`shift`] | `arrow_select::window::shift` (arrow-select/src/window.rs:56) |
+//! | [`rank`] | `arrow_ord::rank::rank` (arrow-ord/src/rank.rs:58) |
 //! | [`DeviceArray::from_host`], [`DeviceArray::to_host`] | `arrow::ffi::{to_ffi, from_ffi}` (arrow-array/src/ffi.rs:231-254) |
 use std::ffi::CStr;
 use std::mem::MaybeUninit;
@@ -20,6 +22,7 @@ use std::ptr;
 use std::sync::Arc;
 
 use arrow::array::{make_array, Array, ArrayData, ArrayRef};
+use arrow::compute::SortOptions;
 use arrow::datatypes::DataType;
 use arrow::error::ArrowError;
 use arrow::ffi::{from_ffi, to_ffi, FFI_ArrowArray, FFI_ArrowSchema};
@@ -370,4 +373,22 @@ pub fn concat(arrays: &[&Arc<DeviceArray>]) -> Result<Arc<DeviceArray>, ArrowErr
     let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
     first.ctx.check(unsafe { sys::ah_concat(first.ctx.raw, views.len() as i32, views.as_ptr(), out.as_mut_ptr()) })?;
     Ok(wrap(first, unsafe { out.assume_init() }, first.data_type.clone(), &[]))
+}
+
+/// `arrow_select::window::shift` (window.rs:56): positive offsets shift right, vacated slots are null
+pub fn shift(values: &Arc<DeviceArray>, offset: i64) -> Result<Arc<DeviceArray>, ArrowError> {
+    let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+    let v = values.view();
+    values.ctx.check(unsafe { sys::ah_shift(values.ctx.raw, &v, offset, out.as_mut_ptr()) })?;
+    Ok(wrap(values, unsafe { out.assume_init() }, values.data_type.clone(), &[values]))
+}
+
+/// `arrow_ord::rank::rank` (rank.rs:58), the ranks left on the device as a `UInt32` array (the reference's
+/// `Vec<u32>` is `to_host()` of it)
+pub fn rank(values: &Arc<DeviceArray>, options: Option<SortOptions>) -> Result<Arc<DeviceArray>, ArrowError> {
+    let o = options.unwrap_or_default();
+    let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+    let v = values.view();
+    values.ctx.check(unsafe { sys::ah_rank(values.ctx.raw, &v, o.descending as i32, o.nulls_first as i32, out.as_mut_ptr()) })?;
+    Ok(wrap(values, unsafe { out.assume_init() }, DataType::UInt32, &[]))
 }

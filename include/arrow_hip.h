@@ -307,6 +307,10 @@ AH_API int32_t ah_can_cast_types(ah_type from, ah_type to); /* cast/mod.rs:115 s
  * reference analogue arrow-buffer/src/util/bit_mask.rs:33 set_bits). */
 AH_API ah_status ah_concat(ah_context* ctx, int32_t n, const ah_array_view* pieces,
                            ah_array_out* out);
+/* arrow_select::window::shift (arrow-select/src/window.rs:56-80): positive offsets shift right, negative left,
+ * vacated slots are null; offset 0 returns the input's buffers (AH_OUT_BORROWED); |offset| >= length gives an
+ * all-null array of the same type. */
+AH_API ah_status ah_shift(ah_context* ctx, const ah_array_view* values, int64_t offset, ah_array_out* out);
 /* OR `len` bits from (src, src_bit_offset) into dst at dst_bit_offset; dst bits
  * in range must be zero.  Returns the number of set bits copied. */
 AH_API ah_status ah_bitmap_set_bits(ah_context* ctx, uint8_t* dst, int64_t dst_bit_offset,
@@ -489,6 +493,13 @@ AH_API ah_status ah_zip(ah_context* ctx, const ah_array_view* mask, const ah_arr
  * descending), which is the order every tie in the reference's own tests shows. */
 AH_API ah_status ah_sort_to_indices(ah_context* ctx, const ah_array_view* values, int32_t descending,
                                     int32_t nulls_first, int64_t limit, ah_array_out* out);
+
+/* arrow_ord::rank::rank (arrow-ord/src/rank.rs:58): UInt32 rank of every row in the sorted order (1-based), equal
+ * values sharing the highest of their ranks, null rows sharing one rank before (nulls_first) or after all values.
+ * Never null.  Integers, Float32 / Float64 (totalOrder equality) and Boolean; the reference's Vec<u32> result is
+ * the values buffer of the output. */
+AH_API ah_status ah_rank(ah_context* ctx, const ah_array_view* values, int32_t descending, int32_t nulls_first,
+                         ah_array_out* out);
 
 /* arrow_ord::sort::lexsort_to_indices (sort.rs:939): rows ordered by cols[0], ties by cols[1], ... — a chain of
  * stable single-column sorts from the last column to the first.  One column delegates to ah_sort_to_indices

@@ -419,6 +419,18 @@ inline ArrayRef lexsort_to_indices(const std::vector<SortColumn>& columns, int64
   ctx->check(ah_lexsort_to_indices(ctx->handle(), (int32_t)views.size(), views.data(), desc.data(), nf.data(), limit, &out));
   return std::make_shared<Array>(ctx, out);
 }
+// arrow_ord::rank::rank (rank.rs:58): UInt32 ranks, never null (the reference's Vec<u32>)
+inline ArrayRef rank(const ArrayRef& values, SortOptions options = {}) {
+  ah_array_out out;
+  values->context()->check(ah_rank(values->context()->handle(), &values->view(), options.descending, options.nulls_first, &out));
+  return wrap(values, out);
+}
+// arrow_select::window::shift (window.rs:56)
+inline ArrayRef shift(const ArrayRef& values, int64_t offset) {
+  ah_array_out out;
+  values->context()->check(ah_shift(values->context()->handle(), &values->view(), offset, &out));
+  return wrap(values, out, {values});
+}
 inline ArrayRef sort(const ArrayRef& values, SortOptions options = {}) { return take(values, sort_to_indices(values, options)); }
 inline ArrayRef sort_limit(const ArrayRef& values, SortOptions options, int64_t limit) {
   return take(values, sort_to_indices(values, options, limit));

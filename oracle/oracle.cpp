@@ -2543,6 +2543,87 @@ int32_t orc_sort_to_indices(const orc_view* a, int32_t desc, int32_t nulls_first
   return ORC_OK;
 }
 
+// rank (arrow-ord/src/rank.rs:58-160): primitive_rank :72-87 + rank_impl :119-160, followed literally — sort the
+// valid (value, row) pairs, reverse when descending, walk backwards handing out `valid_rank` and lowering it by the size
+// of each finished run of equal values; nulls get `null_rank`.  boolean_rank :182-245 computes the same from three
+// counts and is restated separately.
+int32_t orc_rank(const orc_view* a, int32_t desc, int32_t nulls_first, orc_out* out) {
+  out_init(out);
+  out->type = ORC_UINT32;
+  const int64_t len = a->length;
+  if (len == 0) return ORC_OK;
+  const bool has_nulls = a->validity && resolve_nulls(a) > 0;  // nulls.filter(|n| n.null_count() > 0)
+  uint32_t* o = (uint32_t*)xalloc((size_t)len * 4);
+  out->length = len;
+  out->values = o;
+  out->values_bytes = len * 4;
+  if (a->type == ORC_BOOL) {
+    const uint8_t* b = (const uint8_t*)a->values;
+    uint32_t null_count = 0, true_count = 0;
+    for (int64_t i = 0; i < len; ++i) {
+      const bool valid = !has_nulls || get_bit(a->validity, a->validity_bit_offset + i);
+      if (!valid) ++null_count;
+      else if (get_bit(b, a->values_bit_offset + i)) ++true_count;
+    }
+    const uint32_t false_count = (uint32_t)len - null_count - true_count;
+    uint32_t r[3];  // [false, true, null]
+    if (desc && nulls_first) r[0] = null_count + true_count + false_count, r[1] = null_count + true_count, r[2] = null_count;
+    else if (desc) r[0] = true_count + false_count, r[1] = true_count, r[2] = true_count + false_count + null_count;
+    else if (nulls_first) r[0] = null_count + false_count, r[1] = null_count + false_count + true_count, r[2] = null_count;
+    else r[0] = false_count, r[1] = false_count + true_count, r[2] = false_count + true_count + null_count;
+    for (int64_t i = 0; i < len; ++i) {
+      const bool valid = !has_nulls || get_bit(a->validity, a->validity_bit_offset + i);
+      o[i] = r[!valid ? 2 : (get_bit(b, a->values_bit_offset + i) ? 1 : 0)];
+    }
+    return ORC_OK;
+  }
+  std::vector<uint32_t> valid;
+  for (int64_t i = 0; i < len; ++i)
+    if (!has_nulls || get_bit(a->validity, a->validity_bit_offset + i)) valid.push_back((uint32_t)i);
+  std::function<bool(uint32_t, uint32_t)> lt, eq;
+  switch (a->type) {
+#define ORC_RANK_CASE(TAG, T)                                                          \
+  case TAG: {                                                                          \
+    const T* v = (const T*)a->values;                                                  \
+    lt = [v](uint32_t x, uint32_t y) { return is_lt<T>(v[x], v[y]); };                 \
+    eq = [v](uint32_t x, uint32_t y) { return !is_lt<T>(v[x], v[y]) && !is_lt<T>(v[y], v[x]); }; \
+    break;                                                                             \
+  }
+    ORC_RANK_CASE(ORC_INT8, int8_t)
+    ORC_RANK_CASE(ORC_INT16, int16_t)
+    ORC_RANK_CASE(ORC_INT32, int32_t)
+    ORC_RANK_CASE(ORC_INT64, int64_t)
+    ORC_RANK_CASE(ORC_UINT8, uint8_t)
+    ORC_RANK_CASE(ORC_UINT16, uint16_t)
+    ORC_RANK_CASE(ORC_UINT32, uint32_t)
+    ORC_RANK_CASE(ORC_UINT64, uint64_t)
+    ORC_RANK_CASE(ORC_FLOAT32, float)
+    ORC_RANK_CASE(ORC_FLOAT64, double)
+#undef ORC_RANK_CASE
+    default:
+      free(o);
+      out_init(out);
+      return fail(ORC_COMPUTE_ERROR, "%s not supported in rank", type_name(a->type));
+  }
+  std::sort(valid.begin(), valid.end(), lt);  // sort_unstable_by: ties are merged below, their order does not matter
+  if (desc) std::reverse(valid.begin(), valid.end());
+  uint32_t valid_rank = nulls_first ? (uint32_t)len : (uint32_t)valid.size();
+  const uint32_t null_rank = nulls_first ? (uint32_t)(len - (int64_t)valid.size()) : (uint32_t)len;
+  for (int64_t i = 0; i < len; ++i) o[i] = null_rank;
+  if (!valid.empty()) o[valid.back()] = valid_rank;
+  uint32_t count = 1;
+  for (size_t k = valid.size(); k-- > 1;) {  // windows(2).rev(): w = [valid[k-1], valid[k]]
+    if (eq(valid[k - 1], valid[k])) {
+      ++count;
+    } else {
+      valid_rank -= count;
+      count = 1;
+    }
+    o[valid[k - 1]] = valid_rank;
+  }
+  return ORC_OK;
+}
+
 int32_t orc_lexsort_to_indices(int32_t n_cols, const orc_view* cols, const int32_t* desc, const int32_t* nulls_first,
                                int64_t limit, orc_out* out) {
   out_init(out);

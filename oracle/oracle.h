@@ -125,6 +125,7 @@ int32_t orc_sort_to_indices(const orc_view* values, int32_t descending, int32_t 
 
 /* lexsort_to_indices (sort.rs:939) with `make_comparator` semantics per column (null == null, null before / after
  * valid by nulls_first, descending reverses valid comparisons); stable, so fully equal rows keep row order. */
+int32_t orc_rank(const orc_view* a, int32_t desc, int32_t nulls_first, orc_out* out);
 int32_t orc_lexsort_to_indices(int32_t n_cols, const orc_view* cols, const int32_t* descending,
                                const int32_t* nulls_first, int64_t limit, orc_out* out);
 

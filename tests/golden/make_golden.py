@@ -889,8 +889,51 @@ NL = ["Earth", "Fire", "Water", "Air", N, "Air", "bbbbb\nAir"]
 lk("test_utf8_scalar_nullable_like", NL, "Air", "like", [F, F, F, T, N, T, F])
 lk("test_utf8_scalar_nullable_nlike", NL, "%a%r%", "nlike", [F, T, F, T, N, T, T])
 
+# ---------------------------------------------------------------- rank (arrow-ord/src/rank.rs tests) and shift (window.rs tests)
+RK = "arrow-ord/src/rank.rs"
+rank_cases = []
+OPTS = {"default": (F, T), "descending": (T, T), "nulls_last": (F, F), "nulls_last_descending": (T, F)}
+R_PRIM = arr("Int32", [1, 1, N, 3, 3, 4])
+for oname, exp in (("default", [3, 3, 1, 5, 5, 6]), ("descending", [6, 6, 1, 4, 4, 2]), ("nulls_last", [2, 2, 6, 4, 4, 5]),
+                   ("nulls_last_descending", [5, 5, 6, 3, 3, 1])):
+    rank_cases.append(dict(name=f"test_primitive_{oname}", source=f"{RK}:248-275", op="rank", values=R_PRIM,
+                           descending=OPTS[oname][0], nulls_first=OPTS[oname][1], expected=exp))
+# "Test with non-zero null values" (:277-281): the slots under the nulls hold 3, 5, 5
+rank_cases.append(dict(name="test_primitive_nonzero_null_values", source=f"{RK}:277-281", op="rank",
+                       values=arr("Int32", [1, 4, 3, 4, 5, 5]), validity=[T, T, F, T, F, F], descending=F, nulls_first=T,
+                       expected=[4, 6, 3, 6, 3, 3]))
+R_NB = arr("Boolean", [T, T, N, F, F])
+for oname, exp in (("default", [5, 5, 1, 3, 3]), ("descending", [3, 3, 1, 5, 5]), ("nulls_last", [4, 4, 5, 2, 2]),
+                   ("nulls_last_descending", [2, 2, 5, 4, 4])):
+    rank_cases.append(dict(name=f"test_nullable_booleans_{oname}", source=f"{RK}:293-325", op="rank", values=R_NB,
+                           descending=OPTS[oname][0], nulls_first=OPTS[oname][1], expected=exp))
+rank_cases.append(dict(name="test_nullable_booleans_nonzero_null_values", source=f"{RK}:327-331", op="rank",
+                       values=arr("Boolean", [T, T, T, F, F]), validity=[T, T, F, T, T], descending=F, nulls_first=T,
+                       expected=[5, 5, 1, 3, 3]))
+R_B = arr("Boolean", [T, F, F, F, T])
+for oname, exp in (("default", [5, 3, 3, 3, 5]), ("descending", [2, 5, 5, 5, 2]), ("nulls_last", [5, 3, 3, 3, 5]),
+                   ("nulls_last_descending", [2, 5, 5, 5, 2])):
+    rank_cases.append(dict(name=f"test_booleans_{oname}", source=f"{RK}:334-362", op="rank", values=R_B,
+                           descending=OPTS[oname][0], nulls_first=OPTS[oname][1], expected=exp))
+WN = "arrow-select/src/window.rs"
+S3 = arr("Int32", [1, N, 4])
+F3 = arr("Float64", [1.0, N, 4.0])
+for name, lines, values, off, exp in (
+        ("doc_shift_right_1", "37-39", S3, 1, arr("Int32", [N, 1, N])), ("doc_shift_left_1", "42-44", S3, -1, arr("Int32", [N, 4, N])),
+        ("doc_shift_0", "47-49", S3, 0, arr("Int32", [1, N, 4])), ("doc_shift_right_3", "52-54", S3, 3, arr("Int32", [N, N, N])),
+        ("test_shift_neg", "88-93", S3, -1, arr("Int32", [N, 4, N])), ("test_shift_pos", "96-101", S3, 1, arr("Int32", [N, 1, N])),
+        ("test_shift_neg_float64", "104-109", F3, -1, arr("Float64", [N, 4.0, N])),
+        ("test_shift_pos_float64", "112-117", F3, 1, arr("Float64", [N, 1.0, N])),
+        ("test_shift_nil", "146-151", S3, 0, arr("Int32", [1, N, 4])),
+        ("test_shift_boundary_pos", "154-159", S3, 3, arr("Int32", [N, N, N])),
+        ("test_shift_boundary_neg", "162-167", S3, -3, arr("Int32", [N, N, N])),
+        ("test_shift_boundary_neg_min", "170-175", S3, -2**63, arr("Int32", [N, N, N])),
+        ("test_shift_large_pos", "178-183", S3, 1000, arr("Int32", [N, N, N])),
+        ("test_shift_large_neg", "186-191", S3, -1000, arr("Int32", [N, N, N]))):
+    rank_cases.append(dict(name=name, source=f"{WN}:{lines}", op="shift", values=values, offset=off, expected=exp))
+
 for name, cases in [("like", like_cases), ("cmp_utf8", cmp_utf8_cases), ("zip", zip_cases), ("sort", sort_cases), ("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
-                    ("cast", cast_cases)]:
+                    ("cast", cast_cases), ("rank_shift", rank_cases)]:
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump({"reference": "apache/arrow-rs 59.2.0", "cases": cases}, f, indent=1)
     print(name, len(cases))

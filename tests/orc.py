@@ -159,6 +159,7 @@ class Oracle:
         lib.orc_concat.argtypes = [C.c_int32, VP, OP]
         lib.orc_aggregate.argtypes = [C.c_int32, VP, C.c_int32, C.POINTER(ScalarOut)]
         lib.orc_sort_to_indices.argtypes = [VP, C.c_int32, C.c_int32, C.c_int64, OP]
+        lib.orc_rank.argtypes = [VP, C.c_int32, C.c_int32, OP]
         lib.orc_lexsort_to_indices.argtypes = [C.c_int32, VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int64, OP]
         lib.orc_zip.argtypes = [VP, VP, C.c_int32, VP, C.c_int32, OP]
         lib.orc_bitwise.argtypes = [C.c_int32, VP, C.c_int32, VP, C.c_int32, OP]
@@ -327,6 +328,34 @@ class Oracle:
         if st:
             self._raise(st)
         return self._collect(out, A.UInt32)
+
+    def rank(self, values, descending=False, nulls_first=True, bit_offset=0):
+        """arrow_ord::rank::rank (arrow-ord/src/rank.rs:58) -> numpy uint32"""
+        hv = _Held(values, bit_offset)
+        out = Out()
+        st = self.lib.orc_rank(C.byref(hv.view), int(descending), int(nulls_first), C.byref(out))
+        if st:
+            self._raise(st)
+        return np.asarray(self._collect(out, A.UInt32).values, dtype=np.uint32)
+
+    def shift(self, values, offset):
+        """arrow_select::window::shift (arrow-select/src/window.rs:56-80), restated over the oracle's `concat`:
+        offset 0 -> the array itself; |offset| >= len (or i64::MIN) -> new_null_array; otherwise nulls ++ slice
+        (right shift) or slice ++ nulls (left shift)."""
+        n = len(values)
+        if offset == 0:
+            return values
+        dt = values.data_type
+        def nulls(k):
+            if isinstance(values.values, list):
+                return HostArray(dt, [""] * k, np.zeros(k, dtype=bool))
+            return HostArray(dt, np.zeros(k, dtype=np.asarray(values.values).dtype), np.zeros(k, dtype=bool))
+        if offset == -2**63 or abs(offset) >= n:
+            return nulls(n)
+        k = abs(offset)
+        if offset > 0:
+            return self.concat([nulls(k), values.slice(0, n - k)])
+        return self.concat([values.slice(k, n - k), nulls(k)])
 
     def lexsort_to_indices(self, columns, limit=None):
         """columns: [(HostArray, descending, nulls_first)]"""
