@@ -68,10 +68,11 @@ extern "C" ah_status ah_rank(ah_context* ctx, const ah_array_view* v, int32_t de
   const ah_type t = v->type;
   const int64_t n = v->length;
   const int w = ah_type_width(t);
-  if (t == AH_UTF8 || t == AH_LARGE_UTF8 || t == AH_UTF8_VIEW || t == AH_BINARY_VIEW)  // can_rank :31-44 accepts them
-    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "rank of %s (no device sort for byte arrays)", ah_type_name(t));
+  if (t == AH_UTF8_VIEW || t == AH_BINARY_VIEW)  // can_rank :31-44 accepts them
+    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "rank of %s (no device sort for view arrays)", ah_type_name(t));
   if (t == AH_FLOAT16) return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "rank of Float16 (no device comparison kernel)");
-  const bool ok = t == AH_BOOL || ah_type_is_integer(t) || t == AH_FLOAT32 || t == AH_FLOAT64;
+  const bool is_str = t == AH_UTF8 || t == AH_LARGE_UTF8;  // bytes_rank :90-101
+  const bool ok = is_str || t == AH_BOOL || ah_type_is_integer(t) || t == AH_FLOAT32 || t == AH_FLOAT64;
   if (!ok) return ah_fail(ctx, AH_COMPUTE_ERROR, "%s not supported in rank", ah_type_name(t));  // :68
   if (n == 0) return AH_OK;
   if (n > (int64_t)UINT32_MAX)  // `values.len().try_into().unwrap()` :77
@@ -119,7 +120,8 @@ extern "C" ah_status ah_rank(ah_context* ctx, const ah_array_view* v, int32_t de
     if (m > 1) {
       ah_array_view a = view_of(sorted.out), b = a;
       a.length = b.length = m - 1;
-      if (w == 0) b.values_bit_offset = a.values_bit_offset + 1;
+      if (is_str) b.offsets = (const uint8_t*)a.offsets + (t == AH_UTF8 ? 4 : 8);
+      else if (w == 0) b.values_bit_offset = a.values_bit_offset + 1;
       else b.values = (const uint8_t*)a.values + w;
       st = ah_compare(ctx, AH_NEQ, &a, 0, &b, 0, &edge.out);
       if (st != AH_OK) return fail_free(st);

@@ -117,6 +117,61 @@ __global__ void iota_u32_kernel(uint32_t* out, int64_t n) {
   if (i < n) out[i] = (uint32_t)i;
 }
 
+// ---- Utf8 / LargeUtf8 (sort_bytes, arrow-ord/src/sort.rs: `a.cmp(b)` on &[u8] = bytewise lexicographic, a proper
+// prefix first).  A string column is sorted as a chain of fixed-width key columns, least significant first:
+// the byte length, then bytes [8j, 8j+8) as one big-endian u64 (zero padded) for j = last .. 0.  Zero padding makes
+// a proper prefix compare <= its extensions on every chunk and the length column breaks exactly those ties
+// (the extension is longer), so the chain reproduces the bytewise order, NUL bytes included.
+template <typename OFF>
+__global__ void string_max_len_kernel(const OFF* offs, int64_t n, unsigned long long* out) {
+  unsigned long long mx = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long l = (unsigned long long)(offs[i + 1] - offs[i]);
+    mx = l > mx ? l : mx;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(mx, o, 64);
+    mx = other > mx ? other : mx;
+  }
+  if ((threadIdx.x & 63) == 0 && mx) atomicMax(out, mx);
+}
+
+template <typename OFF>
+__global__ void string_len_keys_kernel(const OFF* offs, const uint32_t* rows, int64_t m, int desc, uint64_t* keys, BitView nulls_to_zero) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t r = rows[i];
+  if (nulls_to_zero.words && !bv_get(nulls_to_zero, r)) {
+    keys[i] = 0;
+    return;
+  }
+  const uint64_t l = (uint64_t)(offs[r + 1] - offs[r]);
+  keys[i] = desc ? ~l : l;
+}
+
+template <typename OFF>
+__global__ void string_chunk_keys_kernel(const OFF* offs, const uint8_t* data, const uint32_t* rows, int64_t m, int64_t byte0,
+                                         int desc, uint64_t* keys, BitView nulls_to_zero) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t r = rows[i];
+  if (nulls_to_zero.words && !bv_get(nulls_to_zero, r)) {
+    keys[i] = 0;
+    return;
+  }
+  const int64_t a = (int64_t)offs[r], n = (int64_t)offs[r + 1] - a;
+  uint64_t k = 0;
+  if (byte0 + 8 <= n) {
+    uint64_t raw;
+    __builtin_memcpy(&raw, data + a + byte0, 8);
+    k = __builtin_bswap64(raw);
+  } else {
+    for (int b = 0; b < 8; ++b) k = (k << 8) | (byte0 + b < n ? (uint64_t)data[a + byte0 + b] : 0ull);
+  }
+  keys[i] = desc ? ~k : k;
+}
+
 // all digit histograms of the key column at once: hist[pass][256]
 template <typename KT, int PASSES>
 __global__ __launch_bounds__(RS_BLOCK) void rs_digit_census_kernel(const KT* keys, int64_t m, unsigned long long* hist) {
@@ -327,6 +382,9 @@ ah_status radix_sort_pairs(ah_context* ctx, Scratch& sc, KT** keys, uint32_t** i
 
 }  // namespace
 
+static ah_status lexsort_chain(ah_context* ctx, int32_t n_cols, const ah_array_view* cols, const int32_t* descending,
+                               const int32_t* nulls_first, int64_t limit, ah_array_out* out);
+
 extern "C" ah_status ah_sort_to_indices(ah_context* ctx, const ah_array_view* v, int32_t descending, int32_t nulls_first,
                                         int64_t limit, ah_array_out* out) {
   if (!ctx || !v || !out) return AH_INVALID_ARGUMENT;
@@ -336,6 +394,10 @@ extern "C" ah_status ah_sort_to_indices(ah_context* ctx, const ah_array_view* v,
   const ah_type t = v->type;
   const int64_t n = v->length;
   const int w = ah_type_width(t);
+  if (t == AH_UTF8 || t == AH_LARGE_UTF8) {  // sort_bytes: the chained key-column sort the lexsort path implements
+    const int32_t d = descending != 0, nf = nulls_first != 0;
+    return lexsort_chain(ctx, 1, v, &d, &nf, limit, out);
+  }
   const bool ok = t == AH_BOOL || ah_type_is_integer(t) || t == AH_FLOAT16 || t == AH_FLOAT32 || t == AH_FLOAT64;
   if (!ok) return ah_fail(ctx, AH_COMPUTE_ERROR, "Sort not supported for data type %s", ah_type_name(t));  // sort.rs:324
   if (n == 0 || limit == 0) return AH_OK;  // :281-283
@@ -462,7 +524,8 @@ ah_status sort_rows_by_column(ah_context* ctx, const ah_array_view* v, bool desc
   uint32_t** idx = &cur;
   const ah_type t = v->type;
   const int w = ah_type_width(t);
-  const bool ok = t == AH_BOOL || ah_type_is_integer(t) || t == AH_FLOAT16 || t == AH_FLOAT32 || t == AH_FLOAT64;
+  const bool is_str = t == AH_UTF8 || t == AH_LARGE_UTF8;
+  const bool ok = is_str || t == AH_BOOL || ah_type_is_integer(t) || t == AH_FLOAT16 || t == AH_FLOAT32 || t == AH_FLOAT64;
   if (!ok) return ah_fail(ctx, AH_COMPUTE_ERROR, "Sort not supported for data type %s", ah_type_name(t));
   const dim3 grid((unsigned)std::max<int64_t>(1, ah_ceil_div(n, 256)));
   const int mode = (t == AH_FLOAT16 || t == AH_FLOAT32 || t == AH_FLOAT64) ? 2 : ah_type_is_signed(t) ? 1 : 0;
@@ -470,7 +533,34 @@ ah_status sort_rows_by_column(ah_context* ctx, const ah_array_view* v, bool desc
   AH_TRY(ah_resolve_null_count(ctx, v, &nulls));
   const bool has_nulls = v->validity && nulls > 0;
   const BitView nz = has_nulls ? make_bitview(v->validity, v->validity_bit_offset) : BitView{nullptr, 0};
-  if (w == 8) {
+  if (is_str) {
+    if (!v->offsets) return ah_fail(ctx, AH_INVALID_ARGUMENT, "string array view without offsets");
+    const bool large = t == AH_LARGE_UTF8;
+    unsigned long long* dmax = nullptr;
+    AH_TRY(sc.get(8, (void**)&dmax));
+    AH_HIP(ctx, hipMemsetAsync(dmax, 0, 8, ctx->stream));
+    const dim3 rgrid((unsigned)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(n, 256), 4096)));
+    if (large) hipLaunchKernelGGL(string_max_len_kernel<int64_t>, rgrid, dim3(256), 0, ctx->stream, (const int64_t*)v->offsets, n, dmax);
+    else hipLaunchKernelGGL(string_max_len_kernel<int32_t>, rgrid, dim3(256), 0, ctx->stream, (const int32_t*)v->offsets, n, dmax);
+    unsigned long long max_len = 0;
+    AH_HIP(ctx, hipMemcpyAsync(&max_len, dmax, 8, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t* keys = nullptr;
+    AH_TRY(sc.get((size_t)n * 8, (void**)&keys));
+    const uint8_t* data = (const uint8_t*)v->values;
+    {  // least significant: the length
+      uint64_t* k = keys;
+      if (large) hipLaunchKernelGGL(string_len_keys_kernel<int64_t>, grid, dim3(256), 0, ctx->stream, (const int64_t*)v->offsets, *idx, n, (int)desc, k, nz);
+      else hipLaunchKernelGGL(string_len_keys_kernel<int32_t>, grid, dim3(256), 0, ctx->stream, (const int32_t*)v->offsets, *idx, n, (int)desc, k, nz);
+      AH_TRY((radix_sort_pairs<uint64_t, 8>(ctx, sc, &k, idx, n)));
+    }
+    for (int64_t j = (int64_t)((max_len + 7) / 8) - 1; j >= 0; --j) {  // 8-byte chunks, last to first
+      uint64_t* k = keys;
+      if (large) hipLaunchKernelGGL(string_chunk_keys_kernel<int64_t>, grid, dim3(256), 0, ctx->stream, (const int64_t*)v->offsets, data, *idx, n, j * 8, (int)desc, k, nz);
+      else hipLaunchKernelGGL(string_chunk_keys_kernel<int32_t>, grid, dim3(256), 0, ctx->stream, (const int32_t*)v->offsets, data, *idx, n, j * 8, (int)desc, k, nz);
+      AH_TRY((radix_sort_pairs<uint64_t, 8>(ctx, sc, &k, idx, n)));
+    }
+  } else if (w == 8) {
     uint64_t* keys = nullptr;
     AH_TRY(sc.get((size_t)n * 8, (void**)&keys));
     hipLaunchKernelGGL((sort_keys_kernel<8, uint64_t>), grid, dim3(256), 0, ctx->stream, v->values, *idx, n, mode, (int)desc, keys, *idx, nz);
@@ -519,6 +609,11 @@ extern "C" ah_status ah_lexsort_to_indices(ah_context* ctx, int32_t n_cols, cons
   out->type = AH_UINT32;
   if (n_cols <= 0) return ah_fail(ctx, AH_INVALID_ARGUMENT, "Sort requires at least one column");  // :944-948
   if (n_cols == 1) return ah_sort_to_indices(ctx, &cols[0], descending[0], nulls_first[0], limit, out);  // :949-953
+  return lexsort_chain(ctx, n_cols, cols, descending, nulls_first, limit, out);
+}
+
+static ah_status lexsort_chain(ah_context* ctx, int32_t n_cols, const ah_array_view* cols, const int32_t* descending,
+                               const int32_t* nulls_first, int64_t limit, ah_array_out* out) {
   const int64_t n = cols[0].length;
   for (int c = 1; c < n_cols; ++c)
     if (cols[c].length != n) return ah_fail(ctx, AH_COMPUTE_ERROR, "lexical sort columns have different row counts");

@@ -487,7 +487,8 @@ AH_API ah_status ah_zip(ah_context* ctx, const ah_array_view* mask, const ah_arr
 /* arrow_ord::sort::sort_to_indices (arrow-ord/src/sort.rs:276): UInt32 row numbers that order `values`
  * (`SortOptions { descending, nulls_first }`, arrow-schema/src/lib.rs:87; `limit` < 0 = None) — the usual
  * producer of the indices `ah_take` consumes (`sort` / `sort_limit` = take(values, sort_to_indices(...)),
- * sort.rs:56-177).  Integers, floats (IEEE totalOrder, like `lt`) and Boolean; null rows keep ascending row
+ * sort.rs:56-177).  Integers, floats (IEEE totalOrder, like `lt`), Boolean and Utf8 / LargeUtf8 (bytewise, a
+ * proper prefix first: `sort_bytes`); null rows keep ascending row
  * order at the front or the back (`sort_impl` :639-672).  The reference uses an unstable sort, so the order of
  * equal keys is unspecified there: this implementation is STABLE (equal keys in ascending row order, also when
  * descending), which is the order every tie in the reference's own tests shows. */
@@ -496,7 +497,8 @@ AH_API ah_status ah_sort_to_indices(ah_context* ctx, const ah_array_view* values
 
 /* arrow_ord::rank::rank (arrow-ord/src/rank.rs:58): UInt32 rank of every row in the sorted order (1-based), equal
  * values sharing the highest of their ranks, null rows sharing one rank before (nulls_first) or after all values.
- * Never null.  Integers, Float32 / Float64 (totalOrder equality) and Boolean; the reference's Vec<u32> result is
+ * Never null.  Integers, Float32 / Float64 (totalOrder equality), Boolean and Utf8 / LargeUtf8; the reference's
+ * Vec<u32> result is
  * the values buffer of the output. */
 AH_API ah_status ah_rank(ah_context* ctx, const ah_array_view* values, int32_t descending, int32_t nulls_first,
                          ah_array_out* out);

@@ -2485,6 +2485,20 @@ int64_t orc_find_nth_set_bit(const uint8_t* bits, int64_t off, int64_t len, int6
   return len;
 }
 
+
+// &[u8] Ord (sort_bytes / bytes_rank): bytewise lexicographic, a proper prefix first
+struct BytesCol {
+  const orc_view* a;
+  bool large;
+  explicit BytesCol(const orc_view* v) : a(v), large(v->type == ORC_LARGE_UTF8) {}
+  int64_t off(int64_t i) const { return large ? ((const int64_t*)a->offsets)[i] : (int64_t)((const int32_t*)a->offsets)[i]; }
+  int cmp(uint32_t x, uint32_t y) const {
+    const int64_t ax = off(x), nx = off(x + 1) - ax, ay = off(y), ny = off(y + 1) - ay;
+    const int c = memcmp((const uint8_t*)a->values + ax, (const uint8_t*)a->values + ay, (size_t)std::min(nx, ny));
+    return c ? (c < 0 ? -1 : 1) : (nx < ny ? -1 : nx > ny ? 1 : 0);
+  }
+};
+
 // sort_to_indices (arrow-ord/src/sort.rs:276-300): partition_validity :193-255, sort_primitive :341-352,
 // sort_boolean :325-339, sort_impl :639-672
 int32_t orc_sort_to_indices(const orc_view* a, int32_t desc, int32_t nulls_first, int64_t limit, orc_out* out) {
@@ -2522,6 +2536,13 @@ int32_t orc_sort_to_indices(const orc_view* a, int32_t desc, int32_t nulls_first
       auto key = [v](uint32_t i) { const uint16_t b = v[i]; return (uint16_t)((b & 0x8000) ? ~b : (b ^ 0x8000)); };
       if (!desc) std::stable_sort(valid.begin(), valid.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
       else std::stable_sort(valid.begin(), valid.end(), [&](uint32_t x, uint32_t y) { return key(y) < key(x); });
+      break;
+    }
+    case ORC_UTF8:
+    case ORC_LARGE_UTF8: {  // sort_bytes (sort.rs): values.cmp as &[u8]
+      const BytesCol bc(a);
+      if (!desc) std::stable_sort(valid.begin(), valid.end(), [&](uint32_t x, uint32_t y) { return bc.cmp(x, y) < 0; });
+      else std::stable_sort(valid.begin(), valid.end(), [&](uint32_t x, uint32_t y) { return bc.cmp(y, x) < 0; });
       break;
     }
     default: return fail(ORC_COMPUTE_ERROR, "Sort not supported for data type %s", type_name(a->type));
@@ -2600,6 +2621,13 @@ int32_t orc_rank(const orc_view* a, int32_t desc, int32_t nulls_first, orc_out* 
     ORC_RANK_CASE(ORC_FLOAT32, float)
     ORC_RANK_CASE(ORC_FLOAT64, double)
 #undef ORC_RANK_CASE
+    case ORC_UTF8:
+    case ORC_LARGE_UTF8: {  // bytes_rank :90-101
+      const BytesCol bc(a);
+      lt = [bc](uint32_t x, uint32_t y) { return bc.cmp(x, y) < 0; };
+      eq = [bc](uint32_t x, uint32_t y) { return bc.cmp(x, y) == 0; };
+      break;
+    }
     default:
       free(o);
       out_init(out);
@@ -2661,6 +2689,12 @@ int32_t orc_lexsort_to_indices(int32_t n_cols, const orc_view* cols, const int32
         const uint8_t* b = (const uint8_t*)a->values;
         const int64_t off = a->values_bit_offset;
         cmp[c] = [b, off](uint32_t x, uint32_t y) { return (int)get_bit(b, off + x) - (int)get_bit(b, off + y); };
+        break;
+      }
+      case ORC_UTF8:
+      case ORC_LARGE_UTF8: {
+        const BytesCol bc(a);
+        cmp[c] = [bc](uint32_t x, uint32_t y) { return bc.cmp(x, y); };
         break;
       }
       default: return fail(ORC_COMPUTE_ERROR, "Sort not supported for data type %s", type_name(a->type));

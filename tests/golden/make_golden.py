@@ -791,6 +791,44 @@ sort_cases += [
          descending=False, nulls_first=True, limit=2, expected=[1, 2]),
 ]
 
+# test_sort_to_indices_strings (:3055-3180), for both offset widths
+STR6 = [N, "bad", "sad", N, "glad", "-ad"]
+for st in ("Utf8", "LargeUtf8"):
+    sort_cases += [
+        dict(name=f"strings_default_{st}", source=f"{S_}:3056-3068", values=arr(st, STR6), expected=[0, 3, 5, 1, 4, 2]),
+        dict(name=f"strings_desc_nulls_last_{st}", source=f"{S_}:3070-3085", values=arr(st, STR6), descending=True, nulls_first=False,
+             expected=[2, 4, 1, 5, 0, 3]),
+        dict(name=f"strings_asc_nulls_first_{st}", source=f"{S_}:3087-3102", values=arr(st, STR6), descending=False, nulls_first=True,
+             expected=[0, 3, 5, 1, 4, 2]),
+        dict(name=f"strings_desc_nulls_first_{st}", source=f"{S_}:3104-3119", values=arr(st, STR6), descending=True, nulls_first=True,
+             expected=[0, 3, 2, 4, 1, 5]),
+        dict(name=f"strings_desc_nulls_first_limit_{st}", source=f"{S_}:3121-3136", values=arr(st, STR6), descending=True,
+             nulls_first=True, limit=3, expected=[0, 3, 2]),
+        dict(name=f"strings_limit_nulls_last_{st}", source=f"{S_}:3139-3148", values=arr(st, ["def", N, N, "abc"]),
+             descending=False, nulls_first=False, limit=3, expected=[3, 0, 1]),
+        dict(name=f"strings_limit_nulls_first_{st}", source=f"{S_}:3150-3158", values=arr(st, ["def", N, N, "abc"]),
+             descending=False, nulls_first=True, limit=3, expected=[1, 2, 3]),
+        dict(name=f"strings_more_nulls_than_limit_first_{st}", source=f"{S_}:3161-3169", values=arr(st, ["def", N, N, N]),
+             descending=False, nulls_first=True, limit=2, expected=[1, 2]),
+        dict(name=f"strings_more_nulls_than_limit_last_{st}", source=f"{S_}:3171-3179", values=arr(st, ["def", N, N, N]),
+             descending=False, nulls_first=False, limit=2, expected=[0, 1]),
+    ]
+# test_sort_strings (:3182-3320): expected VALUES there; as indices of the stable order here (no ties in these inputs)
+L1, L2 = "long string longer than 12 bytes", "lang string longer than 12 bytes"
+STR8 = [N, "bad", "sad", L1, N, "glad", L2, "-ad"]
+STR8B = [N, "bad", L1, "sad", N, "glad", L2, "-ad"]
+sort_cases += [
+    dict(name="test_sort_strings_default", source=f"{S_}:3183-3206", values=arr("Utf8", STR8), expected=[0, 4, 7, 1, 5, 6, 3, 2]),
+    dict(name="test_sort_strings_desc_nulls_last", source=f"{S_}:3208-3234", values=arr("Utf8", STR8), descending=True,
+         nulls_first=False, expected=[2, 3, 6, 5, 1, 7, 0, 4]),
+    dict(name="test_sort_strings_asc_nulls_first", source=f"{S_}:3236-3262", values=arr("Utf8", STR8B), descending=False,
+         nulls_first=True, expected=[0, 4, 7, 1, 5, 6, 2, 3]),
+    dict(name="test_sort_strings_desc_nulls_first", source=f"{S_}:3264-3290", values=arr("Utf8", STR8B), descending=True,
+         nulls_first=True, expected=[0, 4, 3, 2, 6, 5, 1, 7]),
+    dict(name="test_sort_strings_desc_nulls_first_limit", source=f"{S_}:3292-3309", values=arr("Utf8", STR8B), descending=True,
+         nulls_first=True, limit=3, expected=[0, 4, 3]),
+]
+
 # ---------------------------------------------------------------- zip (arrow-select/src/zip.rs tests)
 Z_ = "arrow-select/src/zip.rs"
 za = arr("Int32", [5, N, 7, N, 1])
@@ -915,6 +953,15 @@ for oname, exp in (("default", [5, 3, 3, 3, 5]), ("descending", [2, 5, 5, 5, 2])
                    ("nulls_last_descending", [2, 5, 5, 5, 2])):
     rank_cases.append(dict(name=f"test_booleans_{oname}", source=f"{RK}:334-362", op="rank", values=R_B,
                            descending=OPTS[oname][0], nulls_first=OPTS[oname][1], expected=exp))
+for st in ("Utf8", "LargeUtf8"):
+    rank_cases.append(dict(name=f"test_bytes_{st}", source=f"{RK}:365-374", op="rank", values=arr(st, ["foo", "fo", "bar", "bar"]),
+                           descending=F, nulls_first=T, expected=[4, 3, 2, 2]))
+rank_cases.append(dict(name="doc_example_strings", source=f"{RK}:51-56", op="rank", values=arr("Utf8", ["foo", N, "foo", N, "bar"]),
+                       descending=F, nulls_first=T, expected=[5, 2, 5, 2, 3]))
+# test_string_view_with_nulls (:396-405) — the same values as a Utf8 array
+rank_cases.append(dict(name="test_string_with_nulls", source=f"{RK}:396-405", op="rank",
+                       values=arr("Utf8", ["a string longer than twelve bytes", "bar", N, "a string longer than twelve bytes"]),
+                       descending=F, nulls_first=T, expected=[3, 4, 1, 3]))
 WN = "arrow-select/src/window.rs"
 S3 = arr("Int32", [1, N, 4])
 F3 = arr("Float64", [1.0, N, 4.0])

@@ -58,8 +58,7 @@ def test_rank_edges(ctx, oracle):
     assert K.rank(allnull.to_device(ctx), K.SortOptions(False, False)).tolist() == [5] * 5
     same = HostArray(A.Float64, np.full(10_000, 2.5))
     assert K.rank(same.to_device(ctx)).tolist() == [10_000] * 10_000  # one run: every row shares the top rank
-    with pytest.raises(A.array.NotYetImplemented):
-        K.rank(A.Array.from_strings(["foo", "fo"], None, A.Utf8, ctx))
+    assert K.rank(A.Array.from_strings(["foo", "fo", "bar", "bar"], None, A.Utf8, ctx)).tolist() == [4, 3, 2, 2]  # test_bytes
     r = K.rank_array(HostArray(A.Int32, np.array([3, 1, 2], dtype=np.int32)).to_device(ctx))
     assert r.data_type == A.UInt32 and r.validity is None and r.to_pylist() == [3, 1, 2]
 

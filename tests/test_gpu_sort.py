@@ -85,8 +85,10 @@ def test_sort_and_sort_limit(ctx, oracle):
         orc.assert_logical_eq(HostArray.from_device(top), want.slice(0, 100), f"sort_limit {desc} {nf}")
     assert K.sort_to_indices(A.Array.from_numpy(np.zeros(0, np.int32), ctx=ctx)).length == 0
     assert K.sort_to_indices(d, None, 0).length == 0
+    assert K.sort_to_indices(A.Array.from_strings(["b", "a"], ctx=ctx)).values_numpy().tolist() == [1, 0]
+    dec = A.Decimal128(10, 2)
     with pytest.raises(A.array.ComputeError, match="Sort not supported for data type"):
-        K.sort_to_indices(A.Array.from_strings(["b", "a"], ctx=ctx))
+        K.sort_to_indices(HostArray(dec, np.zeros(3, dtype=dec.np_dtype)).to_device(ctx))
     assert str(K.SortOptions()) == "ASC NULLS FIRST" and str(K.SortOptions(True, False)) == "DESC NULLS LAST"
 
 
@@ -193,3 +195,57 @@ def test_lexsort_fuzz(ctx, oracle):
         got = K.lexsort_to_indices(_lex_cols(ctx, hs, opts), lim)
         g = got.values_numpy() if got.length else np.zeros(0, np.uint32)
         assert np.array_equal(g, want.values), (trial, n, k, opts, lim)
+
+
+# ------------------------------------------------------------------ Utf8 / LargeUtf8 (sort_bytes: bytewise, prefix first)
+def _strings(rng, n, kind):
+    if kind == "short":      # many ties, lengths 0..3
+        alpha = ["a", "b", "", "ab", "ba", "a\x00", "\x00", "ß", "aa", "b\x00a"]
+        return [str(alpha[i]) for i in rng.integers(0, len(alpha), n)]
+    if kind == "prefix":     # long common prefixes: the order is decided in the 3rd / 4th 8-byte chunk
+        base = "shared-prefix-of-24-bytes"
+        return [base[: int(rng.integers(0, 25))] + "".join(rng.choice(list("xyz\x00"), int(rng.integers(0, 12)))) for _ in range(n)]
+    return ["".join(rng.choice(list("abcdefghij😈é"), int(rng.integers(0, 20)))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("dt", [A.Utf8, A.LargeUtf8], ids=repr)
+@pytest.mark.parametrize("kind", ["short", "prefix", "random"])
+def test_sort_strings_fuzz(ctx, oracle, dt, kind):
+    rng = np.random.default_rng(77)
+    for n in (1, 2, 64, 4097, 20_000):
+        rows = _strings(rng, n, kind)
+        for p_valid in (None, 0.8):
+            valid = None if p_valid is None else rng.random(n) < p_valid
+            h = HostArray(dt, rows, valid)
+            d = h.to_device(ctx)
+            for desc, nf in OPTS:
+                want = oracle.sort_to_indices(h, desc, nf)
+                got = K.sort_to_indices(d, K.SortOptions(desc, nf))
+                assert np.array_equal(got.values_numpy(), want.values), (dt, kind, n, p_valid, desc, nf)
+            lim = int(rng.integers(0, n + 2))
+            want = oracle.sort_to_indices(h, False, False, lim)
+            got = K.sort_to_indices(d, K.SortOptions(False, False), lim)
+            assert np.array_equal(got.values_numpy() if got.length else np.zeros(0, np.uint32), want.values), (kind, n, "limit", lim)
+            # rank on the same column (bytes_rank, rank.rs:90-101)
+            assert np.array_equal(K.rank(d), oracle.rank(h)), (kind, n, "rank")
+            assert np.array_equal(K.rank(d, K.SortOptions(True, False)), oracle.rank(h, True, False)), (kind, n, "rank desc")
+    h = HostArray(dt, _strings(rng, 3000, "prefix"), rng.random(3000) < 0.9)
+    d = h.to_device(ctx).slice(700, 1500)
+    assert np.array_equal(K.sort_to_indices(d).values_numpy(), oracle.sort_to_indices(h.slice(700, 1500)).values), "sliced"
+    s = K.sort(h.to_device(ctx), K.SortOptions(True, True))  # sort = take(values, sort_to_indices)
+    want = oracle.take(h, HostArray(A.UInt32, oracle.sort_to_indices(h, True, True).values))
+    orc.assert_logical_eq(HostArray.from_device(s), want, "sort values")
+
+
+def test_lexsort_with_string_columns(ctx, oracle):
+    rng = np.random.default_rng(78)
+    n = 6000
+    names = HostArray(A.Utf8, [str(x) for x in rng.choice(["ann", "bob", "", "anna", "an", "bo"], n)], rng.random(n) < 0.9)
+    ints = HostArray(A.Int32, rng.integers(0, 4, n).astype(np.int32), rng.random(n) < 0.9)
+    tags = HostArray(A.LargeUtf8, _strings(rng, n, "short"))
+    dn, di, dt_ = names.to_device(ctx), ints.to_device(ctx), tags.to_device(ctx)
+    for opts in ([(False, True), (True, False), (False, False)], [(True, True), (False, True), (True, False)]):
+        cols = [K.SortColumn(dn, K.SortOptions(*opts[0])), K.SortColumn(di, K.SortOptions(*opts[1])), K.SortColumn(dt_, K.SortOptions(*opts[2]))]
+        want = oracle.lexsort_to_indices([(names, *opts[0]), (ints, *opts[1]), (tags, *opts[2])])
+        got = K.lexsort_to_indices(cols)
+        assert np.array_equal(got.values_numpy(), want.values), opts
