@@ -548,6 +548,12 @@ def main():
                          "traffic": pmc_traffic(dominant, args), "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom_n},
         }
+        tr = line["roofline"]["traffic"]
+        if tr and dom_avg_ms > 0:
+            # what the memory system actually moved for this kernel (PMC bytes per launch / measured launch time): for the
+            # random gather this is the physically binding number — one 128-byte line per 8-byte value
+            line["roofline"]["traffic_GBps"] = round(tr / (dom_avg_ms * 1e-3) / 1e9, 1)
+            line["roofline"]["traffic_frac"] = round(tr / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         if wl == "filter_take" and state.get("reassemble_error"):
             line["config"]["reassemble"] = "failed: " + state["reassemble_error"]
         if comm is not None and getattr(comm, "timings", None):
