@@ -33,7 +33,16 @@ AH_FLOAT32, AH_FLOAT64, AH_FIXED16, AH_FIXED32 = 10, 11, 12, 13
 AH_UTF8, AH_LARGE_UTF8, AH_FLOAT16 = 14, 15, 16
 AH_UTF8_VIEW, AH_BINARY_VIEW = 17, 18
 
+# logical ids of ah_data_type (the casts whose arithmetic depends on the logical type)
+AH_DT_DATE32, AH_DT_DATE64, AH_DT_TIME32, AH_DT_TIME64, AH_DT_TIMESTAMP, AH_DT_DURATION = 32, 33, 34, 35, 36, 37
+
 AH_OUT_BORROWED = 1
+
+
+class DataTypeDesc(C.Structure):
+    """ah_data_type / orc_data_type (identical layout)."""
+    _fields_ = [("id", C.c_int32), ("unit", C.c_int32), ("has_tz", C.c_int32), ("tz_offset_seconds", C.c_int32),
+                ("precision", C.c_int32), ("scale", C.c_int32)]
 
 
 class ArrayView(C.Structure):
@@ -157,6 +166,8 @@ SIGNATURES = {
     "ah_nullif": (C.c_int32, [_P, _VIEW, _VIEW, _OUT]),
     "ah_cast": (C.c_int32, [_P, _VIEW, C.c_int32, C.c_int32, _OUT]),
     "ah_can_cast_types": (C.c_int32, [C.c_int32, C.c_int32]),
+    "ah_cast_with_types": (C.c_int32, [_P, _VIEW, C.POINTER(DataTypeDesc), C.POINTER(DataTypeDesc), C.c_int32, _OUT]),
+    "ah_can_cast_data_types": (C.c_int32, [C.POINTER(DataTypeDesc), C.POINTER(DataTypeDesc)]),
     "ah_concat": (C.c_int32, [_P, C.c_int32, _VIEW, _OUT]),
     "ah_bitmap_set_bits": (C.c_int32, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     "ah_count_set_bits": (C.c_int32, [_P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),

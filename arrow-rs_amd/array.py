@@ -115,10 +115,25 @@ class DataType:
     preserved through filter/take exactly as the reference does
     (filter.rs:783-787, take.rs:414)."""
 
-    def __init__(self, name, physical, np_dtype):
+    def __init__(self, name, physical, np_dtype, logical=None):
         self.name = name
         self.physical = physical
         self.np_dtype = np_dtype
+        # (AH_DT_* id, TimeUnit, timezone text or None) for the types whose CAST arithmetic depends on the
+        # logical type (include/arrow_hip.h ah_data_type); None = the physical type says it all
+        self.logical = logical
+
+    def descriptor(self):
+        """``ah_data_type`` of this type.  A Timestamp's zone must be a fixed offset (``Tz::from_str`` without the
+        reference's optional chrono-tz feature, arrow-array/src/timezone.rs:280-290)."""
+        d = L.DataTypeDesc()
+        if self.logical is None:
+            d.id = self.physical
+            return d
+        d.id, d.unit, tz = self.logical
+        if tz is not None:
+            d.has_tz, d.tz_offset_seconds = 1, parse_fixed_offset(tz)
+        return d
 
     def __eq__(self, other):
         return isinstance(other, DataType) and self.name == other.name
@@ -160,20 +175,56 @@ BinaryView = DataType("BinaryView", L.AH_BINARY_VIEW, _VIEW)
 MAX_INLINE_VIEW_LEN = 12
 # logical types over the same physical layouts (the 14 temporal types of
 # filter.rs:1090-1174 and the Duration/Decimal128 cases of take.rs:1263-1625)
-Date32 = DataType("Date32", L.AH_INT32, np.int32)
-Date64 = DataType("Date64", L.AH_INT64, np.int64)
-Time32Second = DataType("Time32(Second)", L.AH_INT32, np.int32)
-Time32Millisecond = DataType("Time32(Millisecond)", L.AH_INT32, np.int32)
-Time64Microsecond = DataType("Time64(Microsecond)", L.AH_INT64, np.int64)
-Time64Nanosecond = DataType("Time64(Nanosecond)", L.AH_INT64, np.int64)
-DurationSecond = DataType("Duration(Second)", L.AH_INT64, np.int64)
-DurationMillisecond = DataType("Duration(Millisecond)", L.AH_INT64, np.int64)
-DurationMicrosecond = DataType("Duration(Microsecond)", L.AH_INT64, np.int64)
-DurationNanosecond = DataType("Duration(Nanosecond)", L.AH_INT64, np.int64)
-TimestampSecond = DataType("Timestamp(Second, None)", L.AH_INT64, np.int64)
-TimestampMillisecond = DataType("Timestamp(Millisecond, None)", L.AH_INT64, np.int64)
-TimestampMicrosecond = DataType("Timestamp(Microsecond, None)", L.AH_INT64, np.int64)
-TimestampNanosecond = DataType("Timestamp(Nanosecond, None)", L.AH_INT64, np.int64)
+SECOND, MILLISECOND, MICROSECOND, NANOSECOND = 0, 1, 2, 3  # TimeUnit (AH_SECOND ..)
+_UNIT = ["Second", "Millisecond", "Microsecond", "Nanosecond"]
+
+
+def parse_fixed_offset(tz):
+    """``parse_fixed_offset`` (arrow-array/src/timezone.rs:25-49): "+09:00", "-09" or "+0930" -> seconds east of UTC;
+    anything else is the reference's ParseError for builds without chrono-tz."""
+    b = tz.encode()
+    if len(b) == 6 and b[3:4] == b":":
+        digits = b[1:3] + b[4:6]
+    elif len(b) == 5:
+        digits = b[1:5]
+    elif len(b) == 3:
+        digits = b[1:3] + b"00"
+    else:
+        digits = b"x"
+    if not digits.isdigit() or b[0:1] not in (b"+", b"-"):
+        raise ParseError(f'Invalid timezone "{tz}": only offset based timezones supported without chrono-tz feature')
+    secs = int(digits[0:2]) * 3600 + int(digits[2:4]) * 60
+    if secs >= 86400:  # FixedOffset::east_opt / west_opt
+        raise ParseError(f'Invalid timezone "{tz}": only offset based timezones supported without chrono-tz feature')
+    return secs if b[0:1] == b"+" else -secs
+
+
+def Timestamp(unit, tz=None):
+    """``DataType::Timestamp(unit, tz)``; the name is the reference's Debug form."""
+    z = "None" if tz is None else f'Some("{tz}")'
+    return DataType(f"Timestamp({_UNIT[unit]}, {z})", L.AH_INT64, np.int64, (L.AH_DT_TIMESTAMP, unit, tz))
+
+
+def Duration(unit):
+    return DataType(f"Duration({_UNIT[unit]})", L.AH_INT64, np.int64, (L.AH_DT_DURATION, unit, None))
+
+
+def Time32(unit):
+    return DataType(f"Time32({_UNIT[unit]})", L.AH_INT32, np.int32, (L.AH_DT_TIME32, unit, None))
+
+
+def Time64(unit):
+    return DataType(f"Time64({_UNIT[unit]})", L.AH_INT64, np.int64, (L.AH_DT_TIME64, unit, None))
+
+
+Date32 = DataType("Date32", L.AH_INT32, np.int32, (L.AH_DT_DATE32, 0, None))
+Date64 = DataType("Date64", L.AH_INT64, np.int64, (L.AH_DT_DATE64, 0, None))
+Time32Second, Time32Millisecond = Time32(SECOND), Time32(MILLISECOND)
+Time64Microsecond, Time64Nanosecond = Time64(MICROSECOND), Time64(NANOSECOND)
+DurationSecond, DurationMillisecond = Duration(SECOND), Duration(MILLISECOND)
+DurationMicrosecond, DurationNanosecond = Duration(MICROSECOND), Duration(NANOSECOND)
+TimestampSecond, TimestampMillisecond = Timestamp(SECOND), Timestamp(MILLISECOND)
+TimestampMicrosecond, TimestampNanosecond = Timestamp(MICROSECOND), Timestamp(NANOSECOND)
 _DEC128 = np.dtype([("lo", "<u8"), ("hi", "<i8")])
 
 

@@ -1,5 +1,7 @@
 """arrow::compute::kernels::cast == arrow_cast::cast (arrow-cast/src/cast/mod.rs:347,:790),
-restricted to the hot path: numeric<->numeric and numeric->Utf8/LargeUtf8."""
+restricted to the hot path: numeric <-> numeric, numeric <-> Utf8 / LargeUtf8, Boolean <-> numeric, and the temporal
+arms (Date32 / Date64 / Time32 / Time64 / Timestamp / Duration among themselves and to / from the numbers,
+cast/mod.rs:1700-2260), which go through ``ah_cast_with_types`` because their arithmetic depends on the logical type."""
 import ctypes as C
 from dataclasses import dataclass
 
@@ -15,7 +17,10 @@ class CastOptions:
 
 def can_cast_types(from_type, to_type):
     """``can_cast_types`` (cast/mod.rs:115), hot-path subset."""
-    return bool(L.load().ah_can_cast_types(from_type.physical, to_type.physical))
+    if from_type.logical is None and to_type.logical is None:
+        return bool(L.load().ah_can_cast_types(from_type.physical, to_type.physical))
+    f, t = from_type.descriptor(), to_type.descriptor()
+    return bool(L.load().ah_can_cast_data_types(C.byref(f), C.byref(t)))
 
 
 def cast_with_options(array, to_type, cast_options):
@@ -23,8 +28,13 @@ def cast_with_options(array, to_type, cast_options):
     ctx = array.ctx
     out = L.ArrayOut()
     v = array.view()
-    ctx.check(ctx.lib.ah_cast(ctx.handle, C.byref(v), to_type.physical, int(cast_options.safe),
-                              C.byref(out)))
+    if array.data_type.logical is None and to_type.logical is None:
+        ctx.check(ctx.lib.ah_cast(ctx.handle, C.byref(v), to_type.physical, int(cast_options.safe),
+                                  C.byref(out)))
+    else:
+        f, t = array.data_type.descriptor(), to_type.descriptor()  # a named zone raises the reference's ParseError
+        ctx.check(ctx.lib.ah_cast_with_types(ctx.handle, C.byref(v), C.byref(f), C.byref(t),
+                                             int(cast_options.safe), C.byref(out)))
     return Array._from_out(ctx, out, to_type)
 
 

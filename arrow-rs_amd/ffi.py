@@ -43,6 +43,16 @@ def data_type_from_format(ctx, fmt):
     type where array.py has one, otherwise an opaque logical type that remembers its format."""
     if fmt in _NAMED:
         return _NAMED[fmt]
+    if fmt[:3] in ("tss", "tsm", "tsu", "tsn") and fmt[3:4] == ":":
+        # Timestamp with a zone (arrow-schema/src/ffi.rs:640-664).  Fixed offsets become a typed Timestamp the cast
+        # kernels understand; a named zone stays opaque (layout and format string survive, casts refuse it).
+        try:
+            A.parse_fixed_offset(fmt[4:])
+            dt = A.Timestamp("smun".index(fmt[2]), fmt[4:])
+            dt.format = fmt
+            return dt
+        except A.ParseError:
+            pass
     phys = C.c_int32(0)
     ctx.check(ctx.lib.ah_type_from_format(ctx.handle, fmt.encode(), C.byref(phys)))
     if fmt.startswith("d:"):

@@ -352,12 +352,49 @@ fn physical(ctx: &Context, t: &DataType) -> Result<sys::ah_type, ArrowError> {
     Ok(out)
 }
 
-/// `arrow_cast::cast_with_options` (cast/mod.rs:790), the numeric and ->Utf8/LargeUtf8 arms
+/// `DataType` -> `ah_data_type` for the casts whose arithmetic depends on the logical type; `None` = the physical
+/// type says it all.  Zones go through `arrow_array::timezone::Tz` exactly as the reference's arms do; without
+/// chrono-tz that accepts fixed offsets only, which is what the C ABI carries.
+fn logical(t: &DataType) -> Result<Option<sys::ah_data_type>, ArrowError> {
+    use arrow_schema::TimeUnit::*;
+    let unit = |u: &arrow_schema::TimeUnit| match u {
+        Second => sys::AH_SECOND,
+        Millisecond => sys::AH_MILLISECOND,
+        Microsecond => sys::AH_MICROSECOND,
+        Nanosecond => sys::AH_NANOSECOND,
+    };
+    let d = |id, unit, has_tz, tz_offset_seconds| sys::ah_data_type { id, unit, has_tz, tz_offset_seconds, precision: 0, scale: 0 };
+    Ok(Some(match t {
+        DataType::Date32 => d(sys::AH_DT_DATE32, 0, 0, 0),
+        DataType::Date64 => d(sys::AH_DT_DATE64, 0, 0, 0),
+        DataType::Time32(u) => d(sys::AH_DT_TIME32, unit(u), 0, 0),
+        DataType::Time64(u) => d(sys::AH_DT_TIME64, unit(u), 0, 0),
+        DataType::Duration(u) => d(sys::AH_DT_DURATION, unit(u), 0, 0),
+        DataType::Timestamp(u, None) => d(sys::AH_DT_TIMESTAMP, unit(u), 0, 0),
+        DataType::Timestamp(u, Some(tz)) => {
+            use chrono::{Offset, TimeZone};
+            let tz: arrow_array::timezone::Tz = tz.parse()?;
+            // a fixed-offset zone has the same offset at every instant
+            let secs = tz.offset_from_utc_datetime(&chrono::DateTime::UNIX_EPOCH.naive_utc()).fix().local_minus_utc();
+            d(sys::AH_DT_TIMESTAMP, unit(u), 1, secs)
+        }
+        _ => return Ok(None),
+    }))
+}
+
+/// `arrow_cast::cast_with_options` (cast/mod.rs:790): the numeric, Boolean, Utf8 / LargeUtf8 and temporal arms
 pub fn cast_with_options(values: &Arc<DeviceArray>, to_type: &DataType, options: &CastOptions) -> Result<Arc<DeviceArray>, ArrowError> {
     let to = physical(&values.ctx, to_type)?;
     let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
     let v = values.view();
-    values.ctx.check(unsafe { sys::ah_cast(values.ctx.raw, &v, to, options.safe as i32, out.as_mut_ptr()) })?;
+    match (logical(values.data_type())?, logical(to_type)?) {
+        (None, None) => values.ctx.check(unsafe { sys::ah_cast(values.ctx.raw, &v, to, options.safe as i32, out.as_mut_ptr()) })?,
+        (f, t) => {
+            let plain = |id| sys::ah_data_type { id, unit: 0, has_tz: 0, tz_offset_seconds: 0, precision: 0, scale: 0 };
+            let (f, t) = (f.unwrap_or(plain(v.type_)), t.unwrap_or(plain(to)));
+            values.ctx.check(unsafe { sys::ah_cast_with_types(values.ctx.raw, &v, &f, &t, options.safe as i32, out.as_mut_ptr()) })?
+        }
+    }
     Ok(wrap(values, unsafe { out.assume_init() }, to_type.clone(), &[]))
 }
 

@@ -301,6 +301,46 @@ AH_API ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_type t
                          int32_t safe, ah_array_out* out);
 AH_API int32_t ah_can_cast_types(ah_type from, ah_type to); /* cast/mod.rs:115 subset */
 
+/* The casts whose ARITHMETIC depends on the logical type (arrow-cast/src/cast/mod.rs:1700-2260, the "temporal casts"
+ * block): the physical ah_type alone cannot tell Timestamp(Second) from Timestamp(Millisecond), so these take the
+ * reference's DataType as a small descriptor.  `id` is an ah_type for the plain types (AH_INT32, AH_FLOAT64, ...,
+ * the other fields 0) or one of AH_DT_*; `unit` is the TimeUnit of Time32 / Time64 / Timestamp / Duration; a
+ * Timestamp's timezone is carried as a FIXED UTC offset in seconds (`has_tz`, `tz_offset_seconds`: "+05:45" = 20700 —
+ * the only zones the reference parses without its optional chrono-tz feature, arrow-array/src/timezone.rs); a host
+ * with a zone database resolves named zones itself.  `precision` / `scale` are reserved for the decimal arms. */
+typedef int32_t ah_time_unit;
+enum { AH_SECOND = 0, AH_MILLISECOND = 1, AH_MICROSECOND = 2, AH_NANOSECOND = 3 };
+enum {
+  AH_DT_DATE32 = 32,    /* i32 days since the epoch */
+  AH_DT_DATE64 = 33,    /* i64 milliseconds since the epoch */
+  AH_DT_TIME32 = 34,    /* i32, unit = second | millisecond */
+  AH_DT_TIME64 = 35,    /* i64, unit = microsecond | nanosecond */
+  AH_DT_TIMESTAMP = 36, /* i64 since the epoch in `unit`, optional fixed-offset zone */
+  AH_DT_DURATION = 37   /* i64 in `unit` */
+};
+typedef struct ah_data_type {
+  int32_t id;
+  ah_time_unit unit;
+  int32_t has_tz;
+  int32_t tz_offset_seconds;
+  int32_t precision;
+  int32_t scale;
+} ah_data_type;
+/* arrow_cast::cast_with_options for (from, to) pairs where either side is AH_DT_*; everything else is forwarded to
+ * ah_cast.  `values->type` must be the physical layout of `from` (AH_INT32 for Date32 / Time32, AH_INT64 for the
+ * rest).  Arm by arm as the reference: reinterpreting arms clone; unit up-scaling is `checked_mul` (safe: overflow
+ * becomes null and a null buffer is always attached, unary_opt; unsafe: AH_ARITHMETIC_OVERFLOW "Overflow happened
+ * on: {v} * {k}", or the wrapping `x * k` where the reference writes it unchecked); down-scaling is truncating `/`;
+ * Date64 -> Date32 is `i32::try_from(x / 86_400_000)` (AH_CAST_ERROR "Cannot cast Date64 value {x} to Date32 without
+ * overflow"); Timestamp -> Date32 / Time32 / Time64 go through chrono's calendar (0.4.45, not vendored: floor
+ * division into days since 1970-01-01, valid for NaiveDate::MIN..=MAX = -262143-01-01..=+262142-12-31, local to
+ * the source zone) and fail in BOTH modes with "Cannot convert {type} {x} to datetime" / "Failed to create naive
+ * time with {type} {x}" (try_unary, :633-659, :615-631); a zone-less Timestamp cast to a zoned one keeps the wall
+ * clock (adjust_timestamp_to_timezone :2629; unsafe failure: "Cannot cast timezone to different timezone"). */
+AH_API ah_status ah_cast_with_types(ah_context* ctx, const ah_array_view* values, const ah_data_type* from,
+                                    const ah_data_type* to, int32_t safe, ah_array_out* out);
+AH_API int32_t ah_can_cast_data_types(const ah_data_type* from, const ah_data_type* to); /* cast/mod.rs:115 */
+
 /* ---------------------------------------------------------------- concat */
 /* arrow_select::concat::concat for primitives / booleans (concat.rs:334-343,
  * :495) — also the multi-GPU reassembly primitive (bit-shifted bitmap merge,

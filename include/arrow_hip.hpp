@@ -307,6 +307,26 @@ inline ArrayRef cast_with_options(const ArrayRef& a, ah_type to, const CastOptio
   return wrap(a, out);
 }
 inline ArrayRef cast(const ArrayRef& a, ah_type to) { return cast_with_options(a, to, CastOptions{}); }
+// The temporal arms (cast/mod.rs:1700-2260) need the logical types: DataType::Timestamp(unit, tz) etc. as ah_data_type.
+inline ah_data_type plain_type(ah_type t) { return ah_data_type{t, 0, 0, 0, 0, 0}; }
+inline ah_data_type date32() { return ah_data_type{AH_DT_DATE32, 0, 0, 0, 0, 0}; }
+inline ah_data_type date64() { return ah_data_type{AH_DT_DATE64, 0, 0, 0, 0, 0}; }
+inline ah_data_type time32(ah_time_unit u) { return ah_data_type{AH_DT_TIME32, u, 0, 0, 0, 0}; }
+inline ah_data_type time64(ah_time_unit u) { return ah_data_type{AH_DT_TIME64, u, 0, 0, 0, 0}; }
+inline ah_data_type duration(ah_time_unit u) { return ah_data_type{AH_DT_DURATION, u, 0, 0, 0, 0}; }
+inline ah_data_type timestamp(ah_time_unit u) { return ah_data_type{AH_DT_TIMESTAMP, u, 0, 0, 0, 0}; }
+inline ah_data_type timestamp(ah_time_unit u, int32_t tz_offset_seconds) {  // a fixed-offset zone, "+05:45" = 20700
+  return ah_data_type{AH_DT_TIMESTAMP, u, 1, tz_offset_seconds, 0, 0};
+}
+inline bool can_cast_types(const ah_data_type& from, const ah_data_type& to) { return ah_can_cast_data_types(&from, &to) != 0; }
+inline ArrayRef cast_with_options(const ArrayRef& a, const ah_data_type& from, const ah_data_type& to, const CastOptions& o) {
+  ah_array_out out;
+  a->context()->check(ah_cast_with_types(a->context()->handle(), &a->view(), &from, &to, o.safe ? 1 : 0, &out));
+  return wrap(a, out);
+}
+inline ArrayRef cast(const ArrayRef& a, const ah_data_type& from, const ah_data_type& to) {
+  return cast_with_options(a, from, to, CastOptions{});
+}
 
 // ---- concat (arrow-select/src/concat.rs)
 inline ArrayRef concat(const std::vector<ArrayRef>& arrays) {

@@ -2414,6 +2414,406 @@ int32_t orc_cast(const orc_view* in, int32_t to, int32_t safe, orc_out* out) {
   return fail(ORC_CAST_ERROR, "Casting from %s to %s not supported", type_name(in->type), type_name(to));
 }
 
+}  // extern "C"
+
+// ------------------------------------------------------------ temporal casts
+// cast_with_options, the "temporal casts" arms (arrow-cast/src/cast/mod.rs:1700-2260), restated arm by arm with
+// the reference's own recursion (`cast_with_options(&cast_with_options(array, &Int32)?, &Int64)`), on top of literal
+// restatements of PrimitiveArray::unary / unary_opt / try_unary (arrow-array/src/array/primitive_array.rs:861,
+// :1065, :990).  Calendar: chrono 0.4.45 (Cargo.lock:854; not under /root/reference) — DateTime::from_timestamp
+// splits seconds with div_euclid / rem_euclid and accepts the day iff its proleptic-Gregorian YEAR lies in
+// NaiveDate's MIN_YEAR..=MAX_YEAR = -262143..=262142; here the year is recovered with the civil-from-days
+// algorithm (Howard Hinnant's public-domain date algorithms), not with precomputed day bounds.
+namespace {
+
+enum { DT_DATE32 = 32, DT_DATE64 = 33, DT_TIME32 = 34, DT_TIME64 = 35, DT_TIMESTAMP = 36, DT_DURATION = 37 };
+enum { U_S = 0, U_MS = 1, U_US = 2, U_NS = 3 };
+const int64_t MILLISECONDS = 1000, MICROSECONDS = 1000000, NANOSECONDS = 1000000000;
+const int64_t SECONDS_IN_DAY = 86400, MILLISECONDS_IN_DAY = SECONDS_IN_DAY * MILLISECONDS,
+              MICROSECONDS_IN_DAY = SECONDS_IN_DAY * MICROSECONDS, NANOSECONDS_IN_DAY = SECONDS_IN_DAY * NANOSECONDS;
+
+int64_t div_euclid(int64_t a, int64_t b) { int64_t q = a / b; return (a % b < 0) ? q - 1 : q; }  // b > 0
+int64_t rem_euclid(int64_t a, int64_t b) { int64_t r = a % b; return r < 0 ? r + b : r; }
+
+int64_t year_of_day(int64_t days_since_epoch) {  // civil_from_days, year only
+  __int128 z = (__int128)days_since_epoch + 719468;
+  __int128 era = (z >= 0 ? z : z - 146096) / 146097;
+  int64_t doe = (int64_t)(z - era * 146097);
+  int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  int64_t mp = (5 * doy + 2) / 153;
+  int64_t m = mp < 10 ? mp + 3 : mp - 9;
+  return (int64_t)(yoe + era * 400) + (m <= 2);
+}
+
+struct NaiveDateTime { int64_t day; int64_t sod; int64_t nanos; };  // days since 1970-01-01, second of day, nanosecond
+
+// chrono DateTime::from_timestamp(secs, nsecs)
+bool from_timestamp(int64_t secs, int64_t nsecs, NaiveDateTime* o) {
+  int64_t days = div_euclid(secs, 86400);
+  int64_t y = year_of_day(days);
+  if (y < -262143 || y > 262142) return false;
+  *o = {days, rem_euclid(secs, 86400), nsecs};
+  return true;
+}
+// as_datetime::<TimestampXType> (temporal_conversions.rs:141-216)
+bool as_datetime_ts(int unit, int64_t v, NaiveDateTime* o) {
+  switch (unit) {
+    case U_S: return from_timestamp(v, 0, o);
+    case U_MS: return from_timestamp(div_euclid(v, MILLISECONDS), rem_euclid(v, MILLISECONDS) * MICROSECONDS, o);
+    case U_US: return from_timestamp(div_euclid(v, MICROSECONDS), rem_euclid(v, MICROSECONDS) * MILLISECONDS, o);
+    default: return from_timestamp(div_euclid(v, NANOSECONDS), rem_euclid(v, NANOSECONDS), o);
+  }
+}
+// Utc.from_utc_datetime(&naive).with_timezone(&tz) for a fixed offset: the local wall clock
+NaiveDateTime with_offset(NaiveDateTime d, int64_t off) {
+  int64_t s = d.day * 86400 + d.sod + off;
+  return {div_euclid(s, 86400), rem_euclid(s, 86400), d.nanos};
+}
+
+const char* ts_type_name(int unit) {
+  static const char* n[] = {"arrow_array::types::TimestampSecondType", "arrow_array::types::TimestampMillisecondType",
+                            "arrow_array::types::TimestampMicrosecondType", "arrow_array::types::TimestampNanosecondType"};
+  return n[unit];
+}
+const char* unit_disp(int u) { static const char* n[] = {"s", "ms", "\xC2\xB5s", "ns"}; return (u >= 0 && u < 4) ? n[u] : "?"; }
+std::string dt_text(const orc_data_type* t) {
+  char b[96];
+  switch (t->id) {
+    case DT_DATE32: return "Date32";
+    case DT_DATE64: return "Date64";
+    case DT_TIME32: snprintf(b, sizeof b, "Time32(%s)", unit_disp(t->unit)); return b;
+    case DT_TIME64: snprintf(b, sizeof b, "Time64(%s)", unit_disp(t->unit)); return b;
+    case DT_DURATION: snprintf(b, sizeof b, "Duration(%s)", unit_disp(t->unit)); return b;
+    case DT_TIMESTAMP:
+      if (t->has_tz) {
+        int o = t->tz_offset_seconds, ao = o < 0 ? -o : o;
+        snprintf(b, sizeof b, "Timestamp(%s, \"%c%02d:%02d\")", unit_disp(t->unit), o < 0 ? '-' : '+', ao / 3600, ao / 60 % 60);
+      } else snprintf(b, sizeof b, "Timestamp(%s)", unit_disp(t->unit));
+      return b;
+    default: return type_name(t->id);
+  }
+}
+
+template <typename O>
+O* start_out(const orc_view* in, int32_t to, orc_out* out) {
+  O* ov = (O*)xalloc((size_t)in->length * sizeof(O));
+  out->type = to;
+  out->length = in->length;
+  out->values = ov;
+  out->values_bytes = in->length * (int64_t)sizeof(O);
+  return ov;
+}
+void attach_nulls(orc_out* out, uint8_t* nb, int64_t len) {
+  if (!nb) return;
+  out->validity = nb;
+  out->validity_bytes = (int64_t)bitmap_bytes(len);
+  out->null_count = len - count_set_bits(nb, 0, len);
+}
+
+// PrimitiveArray::unary (:861): `op` on EVERY slot, nulls cloned
+template <typename I, typename O, typename F>
+int32_t prim_unary(const orc_view* in, int32_t to, orc_out* out, F op) {
+  const I* iv = (const I*)in->values;
+  O* ov = start_out<O>(in, to, out);
+  for (int64_t i = 0; i < in->length; ++i) ov[i] = op(iv[i]);
+  attach_nulls(out, nulls_clone(in, in->length), in->length);
+  return ORC_OK;
+}
+// PrimitiveArray::unary_opt (:1065): valid slots only, None becomes null, a null buffer is always attached
+template <typename I, typename O, typename F>
+int32_t prim_unary_opt(const orc_view* in, int32_t to, orc_out* out, F op) {
+  const int64_t len = in->length;
+  const I* iv = (const I*)in->values;
+  O* ov = start_out<O>(in, to, out);
+  uint8_t* nb = (uint8_t*)xalloc(bitmap_bytes(len));
+  for (int64_t i = 0; i < len; ++i) {
+    if (in->validity && !get_bit(in->validity, in->validity_bit_offset + i)) continue;
+    O o;
+    if (op(iv[i], &o)) {
+      ov[i] = o;
+      set_bit(nb, i);
+    }
+  }
+  out->validity = nb;
+  out->validity_bytes = (int64_t)bitmap_bytes(len);
+  out->null_count = len - count_set_bits(nb, 0, len);
+  return ORC_OK;
+}
+// PrimitiveArray::try_unary (:990): valid slots only, first Err returned, nulls cloned
+template <typename I, typename O, typename F>
+int32_t prim_try_unary(const orc_view* in, int32_t to, orc_out* out, F op) {
+  const int64_t len = in->length;
+  const I* iv = (const I*)in->values;
+  O* ov = start_out<O>(in, to, out);
+  for (int64_t i = 0; i < len; ++i) {
+    if (in->validity && !get_bit(in->validity, in->validity_bit_offset + i)) continue;
+    int32_t st = op(iv[i], &ov[i]);
+    if (st != ORC_OK) {
+      orc_release(out);
+      return st;
+    }
+  }
+  attach_nulls(out, nulls_clone(in, len), len);
+  return ORC_OK;
+}
+
+orc_view view_of_out(const orc_out* o) {
+  orc_view v{};
+  v.type = o->type;
+  v.length = o->length;
+  v.null_count = o->validity ? o->null_count : 0;
+  v.values = o->values;
+  v.validity = o->validity;
+  v.validity_bit_offset = o->validity_bit_offset;
+  return v;
+}
+
+// checked_mul for safe, mul_checked (ArithmeticOverflow text) otherwise, in the width of O
+template <typename I, typename O>
+int32_t scale_up(const orc_view* in, int32_t to, int64_t k, bool safe, orc_out* out) {
+  auto mul = [k](I x, O* o) {
+    __int128 p = (__int128)x * (__int128)k;
+    if (p < (__int128)std::numeric_limits<O>::min() || p > (__int128)std::numeric_limits<O>::max()) return false;
+    *o = (O)p;
+    return true;
+  };
+  if (safe) return prim_unary_opt<I, O>(in, to, out, mul);
+  return prim_try_unary<I, O>(in, to, out, [&](I x, O* o) -> int32_t {
+    if (mul(x, o)) return ORC_OK;
+    return fail(ORC_ARITHMETIC_OVERFLOW, "Overflow happened on: %lld * %lld", (long long)x, (long long)k);
+  });
+}
+
+bool needs_unit(int id) { return id == DT_TIME32 || id == DT_TIME64 || id == DT_TIMESTAMP || id == DT_DURATION; }
+bool unit_valid(const orc_data_type* t) {
+  if (t->unit < U_S || t->unit > U_NS) return false;
+  if (t->id == DT_TIME32) return t->unit <= U_MS;
+  if (t->id == DT_TIME64) return t->unit >= U_US;
+  return true;
+}
+bool dt_is_numeric(int id) { return is_integer(id) || id == ORC_FLOAT32 || id == ORC_FLOAT64; }
+int64_t time_unit_multiple(int u) { static const int64_t m[] = {1, 1000, 1000000, 1000000000}; return m[u]; }
+orc_data_type plain(int id) { orc_data_type t{}; t.id = id; return t; }
+orc_data_type with_unit(int id, int unit) { orc_data_type t{}; t.id = id; t.unit = unit; return t; }
+bool dt_equal(const orc_data_type* a, const orc_data_type* b) {
+  if (a->id != b->id) return false;
+  if (!needs_unit(a->id)) return true;
+  if (a->unit != b->unit) return false;
+  if (a->id == DT_TIMESTAMP) return a->has_tz == b->has_tz && (!a->has_tz || a->tz_offset_seconds == b->tz_offset_seconds);
+  return true;
+}
+
+int32_t cast_temporal(const orc_view* in, const orc_data_type* from, const orc_data_type* to, bool safe, orc_out* out);
+
+// `cast_with_options(&cast_with_options(array, &mid, ..)?, to, ..)`
+int32_t cast_via(const orc_view* in, const orc_data_type* from, orc_data_type mid, const orc_data_type* to, bool safe,
+                 orc_out* out) {
+  orc_out tmp;
+  int32_t st = cast_temporal(in, from, &mid, safe, &tmp);
+  if (st != ORC_OK) return st;
+  orc_view v = view_of_out(&tmp);
+  st = cast_temporal(&v, &mid, to, safe, out);
+  orc_release(&tmp);
+  return st;
+}
+// a computed array (already in `tmp`, of logical type `mid`) handed to `cast_with_options(&array, to_type, ..)`
+int32_t then_cast(orc_out* tmp, orc_data_type mid, const orc_data_type* to, bool safe, orc_out* out) {
+  orc_view v = view_of_out(tmp);
+  int32_t st = cast_temporal(&v, &mid, to, safe, out);
+  orc_release(tmp);
+  return st;
+}
+
+// adjust_timestamp_to_timezone (mod.rs:2629-2649) for a fixed-offset zone
+int32_t adjust_timestamp_to_timezone(const orc_view* in, int unit, int64_t off, bool safe, orc_out* out) {
+  auto adjust = [unit, off](int64_t o, int64_t* r) {
+    NaiveDateTime local;
+    if (!as_datetime_ts(unit, o, &local)) return false;
+    // local - offset.fix(): must stay a NaiveDateTime (the reference would panic past the calendar's ends)
+    NaiveDateTime shifted = with_offset(local, -off);
+    int64_t y = year_of_day(shifted.day);
+    if (y < -262143 || y > 262142) return false;
+    // T::from_naive_datetime(.., None): checked arithmetic back into the unit
+    __int128 v = (__int128)o - (__int128)off * time_unit_multiple(unit);
+    if (v < (__int128)INT64_MIN || v > (__int128)INT64_MAX) return false;
+    *r = (int64_t)v;
+    return true;
+  };
+  if (safe) return prim_unary_opt<int64_t, int64_t>(in, ORC_INT64, out, adjust);
+  return prim_try_unary<int64_t, int64_t>(in, ORC_INT64, out, [&](int64_t o, int64_t* r) -> int32_t {
+    if (adjust(o, r)) return ORC_OK;
+    return fail(ORC_CAST_ERROR, "Cannot cast timezone to different timezone");
+  });
+}
+
+int32_t cast_temporal(const orc_view* in, const orc_data_type* from, const orc_data_type* to, bool safe, orc_out* out) {
+  out_init(out);
+  const int F = from->id, T = to->id;
+  auto unsupported = [&] {
+    return fail(ORC_CAST_ERROR, "Casting from %s to %s not supported", dt_text(from).c_str(), dt_text(to).c_str());
+  };
+  if ((needs_unit(F) && !unit_valid(from)) || (needs_unit(T) && !unit_valid(to))) return unsupported();
+  const bool f_temporal = F >= DT_DATE32, t_temporal = T >= DT_DATE32;
+  if (!f_temporal && !t_temporal) return orc_cast(in, T, safe, out);
+  auto reinterpret = [&](int32_t phys) { return orc_cast(in, phys, safe, out); };  // same-width clone
+  if (dt_equal(from, to)) return reinterpret(in->type);  // mod.rs:797-799
+
+  // mod.rs:1701-1761
+  if (F == ORC_INT32 && (T == DT_DATE32 || T == DT_TIME32)) return reinterpret(ORC_INT32);
+  if (F == ORC_INT32 && T == DT_DATE64) return cast_via(in, from, plain(DT_DATE32), to, safe, out);
+  if ((F == DT_DATE32 || F == DT_TIME32) && T == ORC_INT32) return reinterpret(ORC_INT32);
+  if ((F == DT_DATE32 || F == DT_TIME32) && T == ORC_INT64) return cast_via(in, from, plain(ORC_INT32), to, safe, out);
+  if (F == ORC_INT64 && (T == DT_DATE64 || T == DT_TIME64)) return reinterpret(ORC_INT64);
+  if (F == ORC_INT64 && T == DT_DATE32) return cast_via(in, from, plain(ORC_INT32), to, safe, out);
+  if ((F == DT_DATE64 || F == DT_TIME64) && T == ORC_INT64) return reinterpret(ORC_INT64);
+  if (F == DT_DATE64 && T == ORC_INT32) return cast_via(in, from, plain(ORC_INT64), to, safe, out);
+  // mod.rs:1762-1781
+  if (F == DT_DATE32 && T == DT_DATE64)
+    return prim_unary<int32_t, int64_t>(in, ORC_INT64, out, [](int32_t x) { return (int64_t)((uint64_t)(int64_t)x * (uint64_t)MILLISECONDS_IN_DAY); });
+  if (F == DT_DATE64 && T == DT_DATE32) {
+    auto f = [](int64_t x, int32_t* o) {
+      int64_t q = x / MILLISECONDS_IN_DAY;
+      if (q < INT32_MIN || q > INT32_MAX) return false;
+      *o = (int32_t)q;
+      return true;
+    };
+    if (safe) return prim_unary_opt<int64_t, int32_t>(in, ORC_INT32, out, f);
+    return prim_try_unary<int64_t, int32_t>(in, ORC_INT32, out, [&](int64_t x, int32_t* o) -> int32_t {
+      if (f(x, o)) return ORC_OK;
+      return fail(ORC_CAST_ERROR, "Cannot cast Date64 value %lld to Date32 without overflow", (long long)x);
+    });
+  }
+  // mod.rs:1783-1851, one arm per unit pair
+  if (F == DT_TIME32 && T == DT_TIME32) {
+    if (from->unit == U_S) return scale_up<int32_t, int32_t>(in, ORC_INT32, MILLISECONDS, safe, out);
+    return prim_unary<int32_t, int32_t>(in, ORC_INT32, out, [](int32_t x) { return x / (int32_t)MILLISECONDS; });
+  }
+  if (F == DT_TIME32 && T == DT_TIME64) {
+    int64_t k = from->unit == U_S ? (to->unit == U_US ? MICROSECONDS : NANOSECONDS)
+                                  : (to->unit == U_US ? MICROSECONDS / MILLISECONDS : NANOSECONDS / MILLISECONDS);
+    return prim_unary<int32_t, int64_t>(in, ORC_INT64, out, [k](int32_t x) { return (int64_t)x * k; });
+  }
+  if (F == DT_TIME64 && T == DT_TIME32) {
+    int64_t k = from->unit == U_US ? (to->unit == U_S ? MICROSECONDS : MICROSECONDS / MILLISECONDS)
+                                   : (to->unit == U_S ? NANOSECONDS : NANOSECONDS / MILLISECONDS);
+    return prim_unary<int64_t, int32_t>(in, ORC_INT32, out, [k](int64_t x) { return (int32_t)(uint32_t)(uint64_t)(x / k); });
+  }
+  if (F == DT_TIME64 && T == DT_TIME64) {
+    if (from->unit == U_US)  // `x * (NANOSECONDS / MICROSECONDS)`: a release build wraps
+      return prim_unary<int64_t, int64_t>(in, ORC_INT64, out, [](int64_t x) { return (int64_t)((uint64_t)x * 1000u); });
+    return prim_unary<int64_t, int64_t>(in, ORC_INT64, out, [](int64_t x) { return x / (NANOSECONDS / MICROSECONDS); });
+  }
+  // mod.rs:1854-1878: Timestamp -> numeric reinterprets as Int64 first; numeric -> Timestamp casts to Int64 first
+  if ((F == DT_TIMESTAMP || F == DT_DURATION) && dt_is_numeric(T)) return orc_cast(in, T, safe, out);
+  if (dt_is_numeric(F) && (T == DT_TIMESTAMP || T == DT_DURATION)) return orc_cast(in, ORC_INT64, safe, out);
+  // mod.rs:1880-1937 / :2257-2279
+  if ((F == DT_TIMESTAMP && T == DT_TIMESTAMP) || (F == DT_DURATION && T == DT_DURATION)) {
+    const int64_t from_size = time_unit_multiple(from->unit), to_size = time_unit_multiple(to->unit);
+    orc_out conv;
+    out_init(&conv);
+    int32_t st;
+    if (from_size > to_size) {
+      const int64_t divisor = from_size / to_size;
+      st = prim_unary<int64_t, int64_t>(in, ORC_INT64, &conv, [divisor](int64_t o) { return o / divisor; });
+    } else if (from_size == to_size) {
+      st = orc_cast(in, ORC_INT64, safe, &conv);
+    } else {
+      st = scale_up<int64_t, int64_t>(in, ORC_INT64, to_size / from_size, safe, &conv);
+    }
+    if (st != ORC_OK) return st;
+    if (F == DT_TIMESTAMP && !from->has_tz && to->has_tz) {
+      orc_view v = view_of_out(&conv);
+      st = adjust_timestamp_to_timezone(&v, to->unit, to->tz_offset_seconds, safe, out);
+      orc_release(&conv);
+      return st;
+    }
+    *out = conv;
+    return ORC_OK;
+  }
+  if (F == DT_TIMESTAMP && T == DT_DATE32) {  // timestamp_to_date32, mod.rs:633-659
+    const int unit = from->unit;
+    const int64_t off = from->has_tz ? from->tz_offset_seconds : 0;
+    return prim_try_unary<int64_t, int32_t>(in, ORC_INT32, out, [&](int64_t x, int32_t* o) -> int32_t {
+      NaiveDateTime d;
+      if (!as_datetime_ts(unit, x, &d)) return fail(ORC_CAST_ERROR, "Cannot convert %s %lld to datetime", ts_type_name(unit), (long long)x);
+      *o = (int32_t)with_offset(d, off).day;  // Date32Type::from_naive_date
+      return ORC_OK;
+    });
+  }
+  if (F == DT_TIMESTAMP && T == DT_DATE64) {  // mod.rs:1950-1973
+    switch (from->unit) {
+      case U_S: return scale_up<int64_t, int64_t>(in, ORC_INT64, MILLISECONDS, safe, out);
+      case U_MS: return reinterpret(ORC_INT64);
+      case U_US: return prim_unary<int64_t, int64_t>(in, ORC_INT64, out, [](int64_t x) { return x / (MICROSECONDS / MILLISECONDS); });
+      default: return prim_unary<int64_t, int64_t>(in, ORC_INT64, out, [](int64_t x) { return x / (NANOSECONDS / MILLISECONDS); });
+    }
+  }
+  if (F == DT_TIMESTAMP && (T == DT_TIME32 || T == DT_TIME64)) {  // mod.rs:1974-2165
+    const int unit = from->unit, tunit = to->unit;
+    const int64_t off = from->has_tz ? from->tz_offset_seconds : 0;
+    auto time_of = [&](int64_t x, NaiveDateTime* t) -> int32_t {  // as_time_res_with_timezone :615-631
+      NaiveDateTime d;
+      if (!as_datetime_ts(unit, x, &d)) return fail(ORC_CAST_ERROR, "Failed to create naive time with %s %lld", ts_type_name(unit), (long long)x);
+      *t = with_offset(d, off);
+      return ORC_OK;
+    };
+    if (T == DT_TIME32)
+      return prim_try_unary<int64_t, int32_t>(in, ORC_INT32, out, [&](int64_t x, int32_t* o) -> int32_t {
+        NaiveDateTime t{};
+        int32_t st = time_of(x, &t);
+        if (st != ORC_OK) return st;
+        // time_to_time32s / time_to_time32ms (temporal_conversions.rs:113-124)
+        *o = tunit == U_S ? (int32_t)t.sod : (int32_t)(t.sod * MILLISECONDS + t.nanos * MILLISECONDS / NANOSECONDS);
+        return ORC_OK;
+      });
+    return prim_try_unary<int64_t, int64_t>(in, ORC_INT64, out, [&](int64_t x, int64_t* o) -> int32_t {
+      NaiveDateTime t{};
+      int32_t st = time_of(x, &t);
+      if (st != ORC_OK) return st;
+      // time_to_time64us / time_to_time64ns (:127-139)
+      *o = tunit == U_US ? t.sod * MICROSECONDS + t.nanos * MICROSECONDS / NANOSECONDS : t.sod * NANOSECONDS + t.nanos;
+      return ORC_OK;
+    });
+  }
+  if (F == DT_DATE64 && T == DT_TIMESTAMP) {  // mod.rs:2166-2194
+    orc_out tmp;
+    out_init(&tmp);
+    int32_t st;
+    switch (to->unit) {
+      case U_S: st = prim_unary<int64_t, int64_t>(in, ORC_INT64, &tmp, [](int64_t x) { return x / MILLISECONDS; }); break;
+      case U_MS: st = orc_cast(in, ORC_INT64, safe, &tmp); break;
+      case U_US: st = prim_unary<int64_t, int64_t>(in, ORC_INT64, &tmp, [](int64_t x) { return (int64_t)((uint64_t)x * (uint64_t)(MICROSECONDS / MILLISECONDS)); }); break;
+      default: st = prim_unary<int64_t, int64_t>(in, ORC_INT64, &tmp, [](int64_t x) { return (int64_t)((uint64_t)x * (uint64_t)(NANOSECONDS / MILLISECONDS)); }); break;
+    }
+    if (st != ORC_OK) return st;
+    return then_cast(&tmp, with_unit(DT_TIMESTAMP, to->unit), to, safe, out);
+  }
+  if (F == DT_DATE32 && T == DT_TIMESTAMP) {  // mod.rs:2195-2234
+    orc_out tmp;
+    out_init(&tmp);
+    int32_t st;
+    switch (to->unit) {
+      case U_S: st = prim_unary<int32_t, int64_t>(in, ORC_INT64, &tmp, [](int32_t x) { return (int64_t)x * SECONDS_IN_DAY; }); break;
+      case U_MS: st = prim_unary<int32_t, int64_t>(in, ORC_INT64, &tmp, [](int32_t x) { return (int64_t)x * MILLISECONDS_IN_DAY; }); break;
+      case U_US: st = scale_up<int32_t, int64_t>(in, ORC_INT64, MICROSECONDS_IN_DAY, safe, &tmp); break;
+      default: st = scale_up<int32_t, int64_t>(in, ORC_INT64, NANOSECONDS_IN_DAY, safe, &tmp); break;
+    }
+    if (st != ORC_OK) return st;
+    return then_cast(&tmp, with_unit(DT_TIMESTAMP, to->unit), to, safe, out);
+  }
+  return unsupported();
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t orc_cast_with_types(const orc_view* in, const orc_data_type* from, const orc_data_type* to, int32_t safe,
+                            orc_out* out) {
+  return cast_temporal(in, from, to, safe != 0, out);
+}
+
 int32_t orc_aggregate(int32_t op, const orc_view* a, int32_t vector_bytes, orc_scalar* out) {
   memset(out, 0, sizeof *out);
   out->type = a->type;

@@ -95,6 +95,19 @@ int32_t orc_string_like(int32_t op, const orc_view* values, const orc_view* patt
 int32_t orc_string_length(const orc_view* values, int32_t bits, orc_out* out);
 int32_t orc_nullif(const orc_view* left, const orc_view* right, orc_out* out);
 int32_t orc_cast(const orc_view* values, int32_t to_type, int32_t safe, orc_out* out);
+/* cast_with_options for pairs where either side is a temporal logical type (arrow-cast/src/cast/mod.rs:1700-2260);
+ * the descriptor has include/arrow_hip.h's ah_data_type layout (id: ORC_* or 32 Date32, 33 Date64, 34 Time32,
+ * 35 Time64, 36 Timestamp, 37 Duration; unit 0 s, 1 ms, 2 us, 3 ns; zones as fixed offsets). */
+typedef struct orc_data_type {
+  int32_t id;
+  int32_t unit;
+  int32_t has_tz;
+  int32_t tz_offset_seconds;
+  int32_t precision;
+  int32_t scale;
+} orc_data_type;
+int32_t orc_cast_with_types(const orc_view* values, const orc_data_type* from, const orc_data_type* to, int32_t safe,
+                            orc_out* out);
 int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out);
 
 /* arrow_arith::aggregate (arrow-arith/src/aggregate.rs): op numbering as AH_AGG_*.

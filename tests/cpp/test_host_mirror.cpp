@@ -125,6 +125,16 @@ int main() {
   // cast Int64 -> Float64 always carries a null buffer in safe mode
   auto f = compute::cast(s64, AH_FLOAT64);
   assert(f->has_nulls_buffer() && f->null_count() == 0 && download<double>(f)[4] == 10.0);
+  // temporal arm: Date32 -> Timestamp(s, "+05:45") keeps the wall clock (cast/mod.rs:7067-7086); the way back is the date
+  {
+    auto d32 = upload<int32_t>(ctx, AH_INT32, {18628, 18993}, nullptr, keep);
+    assert(compute::can_cast_types(compute::date32(), compute::timestamp(AH_SECOND, 20700)));
+    assert(!compute::can_cast_types(compute::date32(), compute::time32(AH_SECOND)));
+    auto ts = compute::cast(d32, compute::date32(), compute::timestamp(AH_SECOND, 20700));
+    assert((download<int64_t>(ts) == std::vector<int64_t>{1609438500, 1640974500}));
+    auto back = compute::cast(ts, compute::timestamp(AH_SECOND, 20700), compute::date32());
+    assert((download<int32_t>(back) == std::vector<int32_t>{18628, 18993}));
+  }
   std::puts("CPP_HOST_MIRROR_OK");
   // C Data Interface round trip (arrow-array/src/ffi.rs:231-254): host producer -> HBM -> filter -> host
   {

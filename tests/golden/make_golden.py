@@ -979,8 +979,138 @@ for name, lines, values, off, exp in (
         ("test_shift_large_neg", "186-191", S3, -1000, arr("Int32", [N, N, N]))):
     rank_cases.append(dict(name=name, source=f"{WN}:{lines}", op="shift", values=values, offset=off, expected=exp))
 
+# ---------------------------------------------------------------- temporal casts
+# arrow-cast/src/cast/mod.rs tests of the "temporal casts" arms (:1700-2260).  Types are written in the reference's
+# Debug form; zones are the fixed offsets the tests use.  Where a test builds its input by parsing strings (marked
+# "derived"), the epoch values below were computed from those strings by hand (and re-checked with Python's datetime
+# in tests/test_temporal_cast_cpu.py); where it only asserts `is_err()` / `contains(..)`, the full message is the
+# format string of the cited arm.
+CM = "arrow-cast/src/cast/mod.rs"
+I64MAX = 2**63 - 1
+tcast_cases = []
+
+
+def TS(unit, tz=None):
+    return f"Timestamp({unit}, None)" if tz is None else f'Timestamp({unit}, Some("{tz}"))'
+
+
+def tcast(name, lines, values, to, expected=None, safe=True, **kw):
+    d = dict(name=name, source=f"{CM}:{lines}", values=values, to=to, safe=safe, **kw)
+    if expected is not None:
+        d["expected"] = arr(to, expected)
+    tcast_cases.append(d)
+
+
+tcast("test_cast_date32_to_date64", "5296-5303", arr("Date32", [10000, 17890]), "Date64", [864000000000, 1545696000000])
+tcast("test_cast_date64_to_date32", "5306-5314", arr("Date64", [864000000005, 1545696000001, N]), "Date32", [10000, 17890, N])
+tcast("test_cast_date64_to_date32_overflow_safe", "5317-5323", arr("Date64", [I64MAX]), "Date32", [N])
+tcast("test_cast_date64_to_date32_overflow_unsafe", "5325-5333", arr("Date64", [I64MAX]), "Date32", safe=F,
+      error="CastError", message=f"Cannot cast Date64 value {I64MAX} to Date32 without overflow")
+tcast("test_cast_date32_to_int32", "6618-6624", arr("Date32", [10000, 17890]), "Int32", [10000, 17890])
+tcast("test_cast_int32_to_date32", "6627-6633", arr("Int32", [10000, 17890]), "Date32", [10000, 17890])
+tcast("test_cast_timestamp_to_date32", "6636-6645", arr(TS("Millisecond", "+00:00"), [864000000005, 1545696000001, N]),
+      "Date32", [10000, 17890, N])
+# derived: "1970-01-01T00:00:01" / "1970-01-01T23:59:59" read in -07:00, "2020-03-01T02:00:23+00:00"
+tcast("test_cast_timestamp_to_date32_zone", "6647-6665 (derived)",
+      arr(TS("Millisecond", "-07:00"), [25201000, 111599000, N, 1583028023000]), "Date32", [0, 0, N, 18321])
+tcast("test_cast_timestamp_to_date64_ms", "6667-6675", arr(TS("Millisecond"), [864000000005, 1545696000001, N]), "Date64",
+      [864000000005, 1545696000001, N])
+tcast("test_cast_timestamp_to_date64_s", "6677-6681", arr(TS("Second"), [864000000005, 1545696000001]), "Date64",
+      [864000000005000, 1545696000001000])
+tcast("test_cast_timestamp_to_date64_overflow_safe", "6683-6686", arr(TS("Second"), [I64MAX]), "Date64", [N])
+tcast("test_cast_timestamp_to_date64_overflow_unsafe", "6687-6694", arr(TS("Second"), [I64MAX]), "Date64", safe=F,
+      error="ArithmeticOverflow", message=f"Overflow happened on: {I64MAX} * 1000")
+for unit, k in (("Second", 1), ("Millisecond", 10**3), ("Microsecond", 10**6), ("Nanosecond", 10**9)):
+    src = arr(TS(unit, "+01:00"), [86405 * k, 1 * k, N])
+    tcast(f"test_cast_timestamp_to_time64_{unit}_us", "6697-6755", src, "Time64(Microsecond)", [3605000000, 3601000000, N])
+    tcast(f"test_cast_timestamp_to_time64_{unit}_ns", "6697-6755", src, "Time64(Nanosecond)", [3605000000000, 3601000000000, N])
+    tcast(f"test_cast_timestamp_to_time32_{unit}_s", "6770-6830", src, "Time32(Second)", [3605, 3601, N])
+    tcast(f"test_cast_timestamp_to_time32_{unit}_ms", "6770-6830", src, "Time32(Millisecond)", [3605000, 3601000, N])
+for to in ("Time64(Microsecond)", "Time64(Nanosecond)", "Time32(Second)", "Time32(Millisecond)"):
+    # `cast(..)` = safe mode, and still an error: the arm is try_unary in both modes
+    tcast(f"test_cast_timestamp_to_{to}_overflow", "6757-6766, 6832-6840", arr(TS("Second", "+01:00"), [I64MAX]), to,
+          error="CastError", message=f"Failed to create naive time with arrow_array::types::TimestampSecondType {I64MAX}")
+tcast("test_cast_timestamp_to_time64_millisecond_unsupported", "6765-6766", arr(TS("Second", "+01:00"), [I64MAX]),
+      "Time64(Millisecond)", error="CastError",
+      message='Casting from Timestamp(s, "+01:00") to Time64(ms) not supported')
+# derived: "2000-01-01T00:00:00.123456789" / "2010-01-01T00:00:00.123456789"
+tcast("test_cast_timestamp_with_timezone_1", "6843-6862 (derived)",
+      arr(TS("Nanosecond"), [946684800123456789, 1262304000123456789, N]), TS("Microsecond", "+0700"),
+      [946659600123456, 1262278800123456, N])
+tcast("test_cast_timestamp_with_timezone_2", "6864-6890 (derived)",
+      arr(TS("Millisecond", "+0700"), [946684800123, 1262304000123, N]), TS("Nanosecond"),
+      [946684800123000000, 1262304000123000000, N])
+tcast("test_cast_timestamp_with_timezone_3", "6892-6917 (derived)",
+      arr(TS("Microsecond", "+0700"), [946684800123456, 1262304000123456, N]), TS("Second", "-08:00"),
+      [946684800, 1262304000, N])
+D64 = arr("Date64", [864000000005, 1545696000001, N])
+for unit, lines, exp in (("Second", "6919-6927", [864000000, 1545696000, N]), ("Millisecond", "6929-6940", [864000000005, 1545696000001, N]),
+                         ("Microsecond", "6942-6953", [864000000005000, 1545696000001000, N]),
+                         ("Nanosecond", "6955-6966", [864000000005000000, 1545696000001000000, N])):
+    tcast(f"test_cast_date64_to_timestamp_{unit}", lines, D64, TS(unit), exp)
+tcast("test_cast_timestamp_to_i64", "6968-6978", arr(TS("Millisecond", "+00:00"), [864000000005, 1545696000001, N]), "Int64",
+      [864000000005, 1545696000001, N])
+D32 = arr("Date32", [18628, 18993, N])
+for unit, k, l32, l64 in (("Second", 1, "7067-7086", "7151-7170"), ("Millisecond", 10**3, "7088-7107", "7172-7191"),
+                          ("Microsecond", 10**6, "7109-7128", "7193-7212"), ("Nanosecond", 10**9, "7130-7149", "7214-7233")):
+    tcast(f"test_cast_date32_to_timestamp_with_timezone_{unit}", l32, D32, TS(unit, "+0545"), [1609438500 * k, 1640974500 * k, N])
+    tcast(f"test_cast_date64_to_timestamp_with_timezone_{unit}", l64, D64, TS(unit, "+0545"),
+          [863979300 * k + 5 * (k // 1000), 1545675300 * k + 1 * (k // 1000), N])
+tcast("test_cast_between_timestamps", "7323-7331", arr(TS("Millisecond"), [864000003005, 1545696002001, N]), TS("Second"),
+      [864000003, 1545696002, N])
+for u in ("Nanosecond", "Microsecond", "Millisecond", "Second"):
+    tcast(f"test_cast_duration_to_i64_{u}", "7334-7350", arr(f"Duration({u})", [5, 6, 7, 8, 100000000]), "Int64", [5, 6, 7, 8, 100000000])
+UM = {"Second": 1, "Millisecond": 10**3, "Microsecond": 10**6, "Nanosecond": 10**9}
+for fu in UM:
+    for tu in UM:
+        if fu == tu:
+            continue
+        v1, v2 = 8640003005, 1696002001
+        if UM[fu] >= UM[tu]:
+            e = [v1 // (UM[fu] // UM[tu]), v2 // (UM[fu] // UM[tu]), N]
+        else:
+            e = [v1 * (UM[tu] // UM[fu]), v2 * (UM[tu] // UM[fu]), N]
+        tcast(f"test_cast_between_durations_{fu}_{tu}", "7353-7404", arr(f"Duration({fu})", [v1, v2, N]), f"Duration({tu})", e)
+DS = arr("Duration(Second)", [I64MAX, 8640203410378005, 10241096, N])
+tcast("test_cast_duration_overflow_to_null", "7406-7417", DS, "Duration(Nanosecond)", [N, N, 10241096000000000, N])
+tcast("test_cast_duration_to_int64", "7419-7431", DS, "Int64", [I64MAX, 8640203410378005, 10241096, N])
+tcast("test_cast_duration_to_int32", "7432-7437", DS, "Int32", [N, N, 10241096, N])
+for unit, k, lines in (("Second", 1, "11680-11688"), ("Millisecond", 10**3, "11691-11702"), ("Microsecond", 10**6, "11705-11716"),
+                       ("Nanosecond", 10**9, "11719-11730")):
+    tcast(f"test_cast_date32_to_timestamp_{unit}", lines, D32, TS(unit), [1609459200 * k, 1640995200 * k, N])
+MDM = I64MAX // 86_400_000_000
+tcast("test_cast_date32_to_timestamp_us_overflow_safe", "11733-11752", arr("Date32", [MDM, MDM + 1, N]), TS("Microsecond"),
+      [MDM * 86_400_000_000, N, N])
+tcast("test_cast_date32_to_timestamp_us_overflow_unsafe", "11733-11746", arr("Date32", [MDM, MDM + 1, N]), TS("Microsecond"), safe=F,
+      error="ArithmeticOverflow", message=f"Overflow happened on: {MDM + 1} * 86400000000")
+tcast("test_cast_date32_to_timestamp_ns_overflow_safe", "11755-11775", arr("Date32", [106751, 106752, N]), TS("Nanosecond"),
+      [106751 * 86_400_000_000_000, N, N])
+tcast("test_cast_date32_to_timestamp_ns_overflow_unsafe", "11755-11769", arr("Date32", [106751, 106752, N]), TS("Nanosecond"), safe=F,
+      error="ArithmeticOverflow", message="Overflow happened on: 106752 * 86400000000000")
+# derived: "1900-01-03 23:59:59", "1969-12-31 00:00:01", "1989-12-31 00:00:01" -> ns / 1_000_000 (truncating)
+tcast("test_cast_below_unixtimestamp", "12418-12456 (derived)",
+      arr(TS("Millisecond", "+00:00"), [-2208729601000, -86399000, 631065601000]), "Date32", [-25565, -1, 7304])
+tcast("test_cast_time32_second_to_int64", "14056-14077", arr("Time32(Second)", [1000, 2000, 3000]), "Int64", [1000, 2000, 3000])
+tcast("test_cast_time32_millisecond_to_int64", "14080-14101", arr("Time32(Millisecond)", [1000, 2000, 3000]), "Int64", [1000, 2000, 3000])
+tcast("test_cast_time32_millisecond_to_time64_nanosecond", "14104-14113", arr("Time32(Millisecond)", [1000, 2000, N, 43200000]),
+      "Time64(Nanosecond)", [1000000000, 2000000000, N, 43200000000000])
+tcast("test_cast_time32_millisecond_to_time64_microsecond", "14116-14125", arr("Time32(Millisecond)", [1000, 2000, N, 43200000]),
+      "Time64(Microsecond)", [1000000, 2000000, N, 43200000000])
+tcast("test_cast_time32_second_to_time64_nanosecond", "14128-14136", arr("Time32(Second)", [1, 60, N, 43200]),
+      "Time64(Nanosecond)", [1000000000, 60000000000, N, 43200000000000])
+tcast("test_cast_time32_second_to_time64_microsecond", "14139-14147", arr("Time32(Second)", [1, 60, N, 43200]),
+      "Time64(Microsecond)", [1000000, 60000000, N, 43200000000])
+tcast("test_cast_time32_second_to_time32_millisecond_overflow_safe", "14150-14155", arr("Time32(Second)", [2**31 - 1]),
+      "Time32(Millisecond)", [N])
+tcast("test_cast_time32_second_to_time32_millisecond_overflow_unsafe", "14156-14164", arr("Time32(Second)", [2**31 - 1]),
+      "Time32(Millisecond)", safe=F, error="ArithmeticOverflow", message="Overflow happened on: 2147483647 * 1000")
+for t in ("Int8", "Int16", "Int32", "Int64", "UInt8", "UInt16", "UInt32", "UInt64"):
+    tcast(f"test_cast_integer_to_timestamp_{t}", "5056-5094", arr(t, [2, 10, N]), TS("Microsecond"), [2, 10, N])
+    tcast(f"test_cast_timestamp_to_integer_{t}", "5097-5123", arr(TS("Millisecond", "+00:00"), [5, 1, N]), t, [5, 1, N])
+
+
 for name, cases in [("like", like_cases), ("cmp_utf8", cmp_utf8_cases), ("zip", zip_cases), ("sort", sort_cases), ("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
-                    ("cast", cast_cases), ("rank_shift", rank_cases)]:
+                    ("cast", cast_cases), ("rank_shift", rank_cases), ("cast_temporal", tcast_cases)]:
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump({"reference": "apache/arrow-rs 59.2.0", "cases": cases}, f, indent=1)
     print(name, len(cases))

@@ -1,0 +1,167 @@
+"""Temporal casts on the device (-m gpu): ``ah_cast_with_types`` through the Python mirror's ``cast`` /
+``cast_with_options`` against the reference's test vectors (tests/golden/cast_temporal.json) and against the oracle on
+every (from, to, safe) pair — values, validity, null-buffer presence, error kind and text — with validity bitmaps at
+non-zero bit offsets, sliced inputs, sizes that straddle the kernel's 1024-row block, and a property check at 2^26 rows.
+Integer work: bit-exact."""
+import itertools
+
+import numpy as np
+import pytest
+
+import arrow_rs_amd as A
+from arrow_rs_amd import compute as K
+from orc import HostArray, golden_array, load_golden, lookup_type, assert_logical_eq, assert_same_nulls_presence
+from test_oracle_golden import ERR
+from test_temporal_cast_cpu import all_types, _edge_values, I32, I64, MULT, UNITS
+
+pytestmark = pytest.mark.gpu
+
+
+def host(arr):
+    return HostArray.from_device(arr)
+
+
+def check_exact(got_dev, exp, msg=""):
+    got = host(got_dev)
+    assert_logical_eq(got, exp, msg)
+    assert_same_nulls_presence(got, exp, msg)
+    assert got_dev.null_count() == exp.null_count, f"{msg} reported null_count"
+
+
+@pytest.mark.parametrize("case", load_golden("cast_temporal"), ids=lambda c: c["name"])
+def test_cast_temporal_golden(ctx, case):
+    v = golden_array(case["values"]).to_device(ctx)
+    to = lookup_type(case["to"])
+    opts = K.CastOptions(safe=case["safe"])
+    if "error" in case:
+        with pytest.raises(ERR[case["error"]]) as ei:
+            K.cast_with_options(v, to, opts)
+        assert ei.value.message == case["message"]
+        return
+    got = K.cast_with_options(v, to, opts)
+    assert got.data_type == to
+    assert_logical_eq(host(got), golden_array(case["expected"]), case["name"])
+
+
+def _values_for(rng, f, n):
+    if f.np_dtype == np.int32:
+        rnd = rng.integers(I32.min, I32.max, n, dtype=np.int64)
+    else:
+        rnd = np.concatenate([rng.integers(I64.min, I64.max, n // 2, dtype=np.int64),
+                              rng.integers(-4 * 10**12, 4 * 10**12, n - n // 2, dtype=np.int64)])
+    return np.array(_edge_values(f) + [int(x) for x in rnd], dtype=f.np_dtype)
+
+
+def test_every_pair_matches_the_oracle(ctx, oracle):
+    rng = np.random.default_rng(17)
+    types = all_types(zones=(None, "+05:45"))
+    n_ok = n_err = 0
+    for f, t in itertools.product(types, types):
+        if f.logical is None and t.logical is None:
+            continue
+        vals = _values_for(rng, f, 2200)  # > 2 blocks of 1024 rows, ragged tail
+        benign = np.array([int(x) for x in rng.integers(-10**5, 10**5, 1500)], dtype=f.np_dtype)
+        for with_nulls, bit_offset in ((False, 0), (True, 3)):
+            for data in (vals, benign):
+                valid = (rng.random(len(data)) < 0.85) if with_nulls else None
+                h = HostArray(f, data, valid)
+                d = h.to_device(ctx, bit_offset=bit_offset)
+                for safe in (True, False):
+                    tag = f"{f} -> {t} safe={safe} nulls={with_nulls} off={bit_offset} n={len(data)}"
+                    try:
+                        exp = oracle.cast_with_types(h, t, safe=safe)
+                    except A.array.ArrowError as e:
+                        with pytest.raises(type(e)) as ei:
+                            K.cast_with_options(d, t, K.CastOptions(safe=safe))
+                        assert ei.value.message == e.message, tag
+                        n_err += 1
+                        continue
+                    check_exact(K.cast_with_options(d, t, K.CastOptions(safe=safe)), exp, tag)
+                    n_ok += 1
+    assert n_ok > 1500 and n_err > 300, (n_ok, n_err)
+
+
+def test_sliced_inputs_and_empty(ctx, oracle):
+    rng = np.random.default_rng(4)
+    vals = rng.integers(-10**12, 10**12, 5000, dtype=np.int64)
+    h = HostArray(A.Timestamp(A.MILLISECOND, "+05:45"), vals, rng.random(5000) < 0.7)
+    d = h.to_device(ctx)
+    for off, ln in ((0, 5000), (1, 4999), (63, 1000), (64, 64), (1027, 2049), (4999, 1), (17, 0)):
+        hs = h.slice(off, ln)
+        for to in (A.Date32, A.Time32Millisecond, A.Timestamp(A.NANOSECOND), A.Timestamp(A.SECOND, "-08:00"), A.Int32):
+            check_exact(K.cast(d.slice(off, ln), to), oracle.cast_with_types(hs, to), f"slice({off},{ln}) -> {to}")
+    e = HostArray(A.Date32, np.empty(0, dtype=np.int32))
+    for to in (A.Date64, A.Timestamp(A.MICROSECOND), A.Timestamp(A.SECOND, "+01:00")):
+        got = K.cast(e.to_device(ctx), to)
+        assert len(got) == 0 and got.data_type == to
+
+
+def test_first_failure_is_reported(ctx, oracle):
+    """try_unary stops at the FIRST failing valid row; failing rows under nulls are skipped."""
+    n = 50_000
+    vals = np.arange(n, dtype=np.int64)
+    vals[[40_001, 12_345, 30_000]] = [I64.max, I64.max - 7, I64.min]
+    valid = np.ones(n, dtype=bool)
+    h = HostArray(A.TimestampSecond, vals, valid)
+    with pytest.raises(A.array.ArithmeticOverflow) as ei:
+        K.cast_with_options(h.to_device(ctx), A.TimestampMillisecond, K.CastOptions(safe=False))
+    assert ei.value.message == f"Overflow happened on: {I64.max - 7} * 1000"
+    valid[12_345] = False
+    h = HostArray(A.TimestampSecond, vals, valid)
+    with pytest.raises(A.array.CastError) as ei:
+        K.cast(h.to_device(ctx), A.Date32)  # safe mode, still an error (try_unary in both modes)
+    assert ei.value.message == f"Cannot convert arrow_array::types::TimestampSecondType {I64.min} to datetime"
+    got = K.cast(h.to_device(ctx), A.TimestampNanosecond)  # safe: overflow -> null
+    check_exact(got, oracle.cast_with_types(h, A.TimestampNanosecond))
+    assert got.null_count() == 3  # the null row and the two overflowing ones
+
+
+def test_cast_with_types_rejects_a_mismatched_layout(ctx):
+    import ctypes as C
+    from arrow_rs_amd import _lib as L
+    d = HostArray(A.Int64, np.arange(4, dtype=np.int64)).to_device(ctx)
+    v, f, t, out = d.view(), A.Date32.descriptor(), A.Date64.descriptor(), L.ArrayOut()  # Date32 is an i32 layout
+    st = ctx.lib.ah_cast_with_types(ctx.handle, C.byref(v), C.byref(f), C.byref(t), 1, C.byref(out))
+    assert st == L.AH_INVALID_ARGUMENT
+    with pytest.raises(A.array.CastError) as ei:
+        K.cast(HostArray(A.Date32, np.arange(4, dtype=np.int32)).to_device(ctx), A.Time32Second)
+    assert ei.value.message == "Casting from Date32 to Time32(s) not supported"
+
+
+def test_deferred_temporal_casts(ctx, oracle):
+    rng = np.random.default_rng(8)
+    h = HostArray(A.Date32, rng.integers(-10**5, 10**5, 10_000).astype(np.int32), rng.random(10_000) < 0.9)
+    d = h.to_device(ctx)
+    with ctx.deferred_mode():
+        a = K.cast(d, A.Timestamp(A.MICROSECOND))            # checked multiply, safe: infallible shape
+        b = K.cast(a, A.Timestamp(A.SECOND))                 # truncating divide
+        c = K.cast(b, A.Timestamp(A.SECOND, "+05:45"))       # zone adjust, safe
+        e = K.cast(c, A.Date64)
+    x = oracle.cast_with_types(h, A.Timestamp(A.MICROSECOND))
+    y = oracle.cast_with_types(x, A.Timestamp(A.SECOND))
+    z = oracle.cast_with_types(y, A.Timestamp(A.SECOND, "+05:45"))
+    w = oracle.cast_with_types(z, A.Date64)
+    check_exact(e, w, "deferred chain")
+    check_exact(c, z, "deferred chain (zone)")
+
+
+def test_large_round_trips(ctx):
+    """2^26 rows: Date32 -> Timestamp(ms) -> Date32 is the identity, Timestamp(us) -> (Date32, Time64(us)) splits and
+    recombines exactly, and unit up-then-down scaling returns the input."""
+    n = 1 << 26
+    rng = np.random.default_rng(99)
+    days = rng.integers(-700_000, 700_000, n).astype(np.int32)
+    d = HostArray(A.Date32, days).to_device(ctx)
+    ts = K.cast(d, A.TimestampMillisecond)
+    back = K.cast(ts, A.Date32)
+    assert np.array_equal(back.values_numpy(), days)
+    us = rng.integers(-(10**17), 10**17, n, dtype=np.int64)
+    t = HostArray(A.TimestampMicrosecond, us).to_device(ctx)
+    date = K.cast(t, A.Date32).values_numpy().astype(np.int64)
+    tod = K.cast(t, A.Time64Microsecond).values_numpy()
+    assert tod.min() >= 0 and tod.max() < 86_400_000_000
+    assert np.array_equal(date * 86_400_000_000 + tod, us)
+    s = HostArray(A.DurationSecond, rng.integers(-(10**9), 10**9, n, dtype=np.int64)).to_device(ctx)
+    up = K.cast(s, A.DurationNanosecond)
+    assert up.null_count() == 0
+    assert np.array_equal(K.cast(up, A.DurationSecond).values_numpy(), s.values_numpy())

@@ -21,10 +21,10 @@ BASE = {
     "uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "uint64_t": "u64",
     # i32 aliases of the header
     "ah_status": "ah_status", "ah_type": "ah_type", "ah_arith_op": "ah_arith_op", "ah_cmp_op": "ah_cmp_op",
-    "ah_boolean_op": "ah_boolean_op", "ah_agg_op": "ah_agg_op", "ah_like_op": "ah_like_op", "ArrowDeviceType": "ArrowDeviceType",
+    "ah_boolean_op": "ah_boolean_op", "ah_agg_op": "ah_agg_op", "ah_like_op": "ah_like_op", "ah_time_unit": "ah_time_unit", "ArrowDeviceType": "ArrowDeviceType",
     # opaque / struct types keep their names
     "ah_context": "ah_context", "ah_filter_predicate": "ah_filter_predicate", "ah_array_view": "ah_array_view",
-    "ah_array_out": "ah_array_out", "ah_scalar": "ah_scalar", "ah_ipc_field": "ah_ipc_field", "ah_ipc_block": "ah_ipc_block",
+    "ah_array_out": "ah_array_out", "ah_scalar": "ah_scalar", "ah_data_type": "ah_data_type", "ah_ipc_field": "ah_ipc_field", "ah_ipc_block": "ah_ipc_block",
     "ArrowArray": "ArrowArray", "ArrowSchema": "ArrowSchema", "ArrowDeviceArray": "ArrowDeviceArray",
     "ah_alloc_fn": "ah_alloc_fn", "ah_free_fn": "ah_free_fn",
 }
