@@ -35,6 +35,7 @@ AH_UTF8_VIEW, AH_BINARY_VIEW = 17, 18
 
 # logical ids of ah_data_type (the casts whose arithmetic depends on the logical type)
 AH_DT_DATE32, AH_DT_DATE64, AH_DT_TIME32, AH_DT_TIME64, AH_DT_TIMESTAMP, AH_DT_DURATION = 32, 33, 34, 35, 36, 37
+AH_DT_INTERVAL = 38
 
 AH_OUT_BORROWED = 1
 
@@ -158,6 +159,8 @@ SIGNATURES = {
     "ah_copy_rows_into": (C.c_int32, [_P, _VIEW, C.c_int64, C.c_int64, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "ah_take": (C.c_int32, [_P, _VIEW, _VIEW, C.c_int32, _OUT]),
     "ah_arith_binary": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
+    "ah_arith_with_types": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, C.POINTER(DataTypeDesc), _VIEW, C.c_int32,
+                                        C.POINTER(DataTypeDesc), _OUT, C.POINTER(DataTypeDesc)]),
     "ah_bitwise_not": (C.c_int32, [_P, _VIEW, _OUT]),
     "ah_arith_neg": (C.c_int32, [_P, _VIEW, C.c_int32, _OUT]),
     "ah_compare": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),

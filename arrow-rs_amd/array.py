@@ -217,6 +217,25 @@ def Time64(unit):
     return DataType(f"Time64({_UNIT[unit]})", L.AH_INT64, np.int64, (L.AH_DT_TIME64, unit, None))
 
 
+def data_type_from_descriptor(d, like=None):
+    """``ah_data_type`` -> DataType.  `like` supplies what the descriptor cannot carry: the zone TEXT of a Timestamp
+    result (``array.with_timezone_opt(l.timezone())``, numeric.rs:536)."""
+    if d.id == L.AH_DT_TIMESTAMP:
+        tz = like.logical[2] if (like is not None and like.logical and like.logical[0] == L.AH_DT_TIMESTAMP) else None
+        return Timestamp(d.unit, tz)
+    if d.id == L.AH_DT_DURATION:
+        return Duration(d.unit)
+    if d.id == L.AH_DT_TIME32:
+        return Time32(d.unit)
+    if d.id == L.AH_DT_TIME64:
+        return Time64(d.unit)
+    if d.id == L.AH_DT_DATE32:
+        return Date32
+    if d.id == L.AH_DT_DATE64:
+        return Date64
+    return like if (like is not None and like.physical == d.id) else _PHYSICAL_DEFAULT[d.id]
+
+
 Date32 = DataType("Date32", L.AH_INT32, np.int32, (L.AH_DT_DATE32, 0, None))
 Date64 = DataType("Date64", L.AH_INT64, np.int64, (L.AH_DT_DATE64, 0, None))
 Time32Second, Time32Millisecond = Time32(SECOND), Time32(MILLISECOND)

@@ -1,8 +1,12 @@
 """arrow::compute::kernels::numeric == arrow_arith::numeric (arrow-arith/src/numeric.rs:36-186).
-All binary kernels take two ``Datum`` (``Array`` or ``Scalar``)."""
+All binary kernels take two ``Datum`` (``Array`` or ``Scalar``).  When an operand is a temporal logical type the
+result type follows ``arithmetic_op`` / ``timestamp_op`` / ``duration_op`` / ``date_op`` (numeric.rs:225-275, :426-537,
+:877-932): Timestamp - Timestamp is a Duration, Timestamp +- Duration keeps the zone, Date32 - Date32 is Duration(Second),
+and the library answers every other pair with the reference's InvalidArgumentError text."""
 import ctypes as C
 
 from ... import _lib as L
+from ... import array as _A
 from ...array import Array
 
 ADD, ADD_WRAPPING, SUB, SUB_WRAPPING, MUL, MUL_WRAPPING, DIV, REM = range(8)
@@ -14,9 +18,16 @@ def _binary(op, lhs, rhs):
     ctx = l.ctx
     out = L.ArrayOut()
     lv, rv = l.view(), r.view()
-    ctx.check(ctx.lib.ah_arith_binary(ctx.handle, op, C.byref(lv), int(l_s), C.byref(rv), int(r_s),
-                                      C.byref(out)))
-    return Array._from_out(ctx, out, l.data_type)
+    if l.data_type.logical is None and r.data_type.logical is None:
+        ctx.check(ctx.lib.ah_arith_binary(ctx.handle, op, C.byref(lv), int(l_s), C.byref(rv), int(r_s),
+                                          C.byref(out)))
+        return Array._from_out(ctx, out, l.data_type)
+    lt, rt, ot = l.data_type.descriptor(), r.data_type.descriptor(), L.DataTypeDesc()
+    ctx.check(ctx.lib.ah_arith_with_types(ctx.handle, op, C.byref(lv), int(l_s), C.byref(lt), C.byref(rv), int(r_s),
+                                          C.byref(rt), C.byref(out), C.byref(ot)))
+    # Duration + Timestamp swaps inside the library: the zone text comes from whichever side is the Timestamp
+    like = l.data_type if l.data_type.logical and l.data_type.logical[0] == ot.id else r.data_type
+    return Array._from_out(ctx, out, _A.data_type_from_descriptor(ot, like))
 
 
 def add(lhs, rhs):

@@ -258,8 +258,32 @@ fn arith(op: i32, lhs: &Datum, rhs: &Datum) -> Result<Arc<DeviceArray>, ArrowErr
     let ((l, ls), (r, rs)) = (lhs.get(), rhs.get());
     let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
     let (lv, rv) = (l.view(), r.view());
-    l.ctx.check(unsafe { sys::ah_arith_binary(l.ctx.raw, op, &lv, ls, &rv, rs, out.as_mut_ptr()) })?;
-    Ok(wrap(l, unsafe { out.assume_init() }, l.data_type.clone(), &[]))
+    let (lt, rt) = (logical(&l.data_type)?, logical(&r.data_type)?);
+    if lt.is_none() && rt.is_none() {
+        l.ctx.check(unsafe { sys::ah_arith_binary(l.ctx.raw, op, &lv, ls, &rv, rs, out.as_mut_ptr()) })?;
+        return Ok(wrap(l, unsafe { out.assume_init() }, l.data_type.clone(), &[]));
+    }
+    // temporal operands: the library applies arithmetic_op's type rules (numeric.rs:225-275) and names the result type
+    let plain = |id| sys::ah_data_type { id, unit: 0, has_tz: 0, tz_offset_seconds: 0, precision: 0, scale: 0 };
+    let (lt, rt) = (lt.unwrap_or(plain(lv.type_)), rt.unwrap_or(plain(rv.type_)));
+    let mut ot = plain(0);
+    l.ctx.check(unsafe { sys::ah_arith_with_types(l.ctx.raw, op, &lv, ls, &lt, &rv, rs, &rt, out.as_mut_ptr(), &mut ot) })?;
+    let unit = |u| match u {
+        sys::AH_SECOND => arrow_schema::TimeUnit::Second,
+        sys::AH_MILLISECOND => arrow_schema::TimeUnit::Millisecond,
+        sys::AH_MICROSECOND => arrow_schema::TimeUnit::Microsecond,
+        _ => arrow_schema::TimeUnit::Nanosecond,
+    };
+    let result_type = match ot.id {
+        sys::AH_DT_DURATION => DataType::Duration(unit(ot.unit)),
+        // `array.with_timezone_opt(l.timezone())` (numeric.rs:536): the zone text of whichever side is the Timestamp
+        sys::AH_DT_TIMESTAMP => match (&l.data_type, &r.data_type) {
+            (t @ DataType::Timestamp(_, _), _) | (_, t @ DataType::Timestamp(_, _)) => t.clone(),
+            _ => DataType::Timestamp(unit(ot.unit), None),
+        },
+        _ => l.data_type.clone(),
+    };
+    Ok(wrap(l, unsafe { out.assume_init() }, result_type, &[]))
 }
 
 macro_rules! arith_fn {

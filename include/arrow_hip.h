@@ -121,6 +121,35 @@ typedef struct ah_array_out {
   int32_t flags;
 } ah_array_out;
 
+/* Logical types.  The casts and the arithmetic whose result depends on the LOGICAL type (arrow-cast/src/cast/mod.rs:
+ * 1700-2260, the "temporal casts"; arrow-arith/src/numeric.rs:426-932) cannot work from the physical ah_type alone —
+ * it cannot tell Timestamp(Second) from Timestamp(Millisecond) — so ah_cast_with_types / ah_arith_with_types take the
+ * reference's DataType as a small descriptor.  `id` is an ah_type for the plain types (AH_INT32, AH_FLOAT64, ...,
+ * the other fields 0) or one of AH_DT_*; `unit` is the TimeUnit of Time32 / Time64 / Timestamp / Duration; a
+ * Timestamp's timezone is carried as a FIXED UTC offset in seconds (`has_tz`, `tz_offset_seconds`: "+05:45" = 20700 —
+ * the only zones the reference parses without its optional chrono-tz feature, arrow-array/src/timezone.rs); a host
+ * with a zone database resolves named zones itself.  `precision` / `scale` are reserved for the decimal arms. */
+typedef int32_t ah_time_unit;
+enum { AH_SECOND = 0, AH_MILLISECOND = 1, AH_MICROSECOND = 2, AH_NANOSECOND = 3 };
+enum {
+  AH_DT_DATE32 = 32,    /* i32 days since the epoch */
+  AH_DT_DATE64 = 33,    /* i64 milliseconds since the epoch */
+  AH_DT_TIME32 = 34,    /* i32, unit = second | millisecond */
+  AH_DT_TIME64 = 35,    /* i64, unit = microsecond | nanosecond */
+  AH_DT_TIMESTAMP = 36, /* i64 since the epoch in `unit`, optional fixed-offset zone */
+  AH_DT_DURATION = 37,  /* i64 in `unit` */
+  AH_DT_INTERVAL = 38   /* unit = 0 YearMonth (i32) | 1 DayTime (8 bytes) | 2 MonthDayNano (16 bytes); named only so that
+                           ah_arith_with_types can refuse it with the reference's type text: no kernel takes intervals yet */
+};
+typedef struct ah_data_type {
+  int32_t id;
+  ah_time_unit unit;
+  int32_t has_tz;
+  int32_t tz_offset_seconds;
+  int32_t precision;
+  int32_t scale;
+} ah_data_type;
+
 /* --------------------------------------------------------------- context */
 typedef struct ah_context ah_context;
 typedef void* (*ah_alloc_fn)(void* user, size_t bytes); /* returns device ptr, 256B aligned */
@@ -231,6 +260,18 @@ AH_API ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op,
                                  const ah_array_view* lhs, int32_t lhs_is_scalar,
                                  const ah_array_view* rhs, int32_t rhs_is_scalar,
                                  ah_array_out* out);
+/* The same entry points when an operand is a temporal logical type (`arithmetic_op` numeric.rs:225-275, `timestamp_op`
+ * :426-537, `duration_op` :877-895, `date_op` :898-932).  The result TYPE depends on the pair and is written to
+ * `out_type`: Timestamp(u) - Timestamp(u) = Duration(u); Timestamp(u, tz) +- Duration(u) = Timestamp(u, tz);
+ * Duration(u) +- Duration(u); Date64 - Date64 = Duration(ms); Date32 - Date32 = Duration(s) (`(l - r) * 86400`,
+ * infallible); Duration + Timestamp swaps.  All of them are CHECKED i64 arithmetic, also through the *_WRAPPING ops
+ * (the reference calls add_checked / sub_checked whatever the Op): AH_ARITHMETIC_OVERFLOW "Overflow happened on:
+ * {l} + {r}".  Everything else is the reference's AH_INVALID_ARGUMENT text ("Invalid timestamp arithmetic operation:
+ * Timestamp(s) * Duration(s)", "Invalid arithmetic operation: Int64 + Timestamp(ms)", ...); the Interval arms are
+ * AH_NOT_YET_IMPLEMENTED.  Plain numeric pairs are forwarded to ah_arith_binary. */
+AH_API ah_status ah_arith_with_types(ah_context* ctx, ah_arith_op op, const ah_array_view* lhs, int32_t lhs_is_scalar,
+                                     const ah_data_type* lhs_type, const ah_array_view* rhs, int32_t rhs_is_scalar,
+                                     const ah_data_type* rhs_type, ah_array_out* out, ah_data_type* out_type);
 /* bitwise_not (arrow-arith/src/bitwise.rs:113) */
 AH_API ah_status ah_bitwise_not(ah_context* ctx, const ah_array_view* values, ah_array_out* out);
 /* neg / neg_wrapping (numeric.rs:103,181) */
@@ -301,31 +342,6 @@ AH_API ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_type t
                          int32_t safe, ah_array_out* out);
 AH_API int32_t ah_can_cast_types(ah_type from, ah_type to); /* cast/mod.rs:115 subset */
 
-/* The casts whose ARITHMETIC depends on the logical type (arrow-cast/src/cast/mod.rs:1700-2260, the "temporal casts"
- * block): the physical ah_type alone cannot tell Timestamp(Second) from Timestamp(Millisecond), so these take the
- * reference's DataType as a small descriptor.  `id` is an ah_type for the plain types (AH_INT32, AH_FLOAT64, ...,
- * the other fields 0) or one of AH_DT_*; `unit` is the TimeUnit of Time32 / Time64 / Timestamp / Duration; a
- * Timestamp's timezone is carried as a FIXED UTC offset in seconds (`has_tz`, `tz_offset_seconds`: "+05:45" = 20700 —
- * the only zones the reference parses without its optional chrono-tz feature, arrow-array/src/timezone.rs); a host
- * with a zone database resolves named zones itself.  `precision` / `scale` are reserved for the decimal arms. */
-typedef int32_t ah_time_unit;
-enum { AH_SECOND = 0, AH_MILLISECOND = 1, AH_MICROSECOND = 2, AH_NANOSECOND = 3 };
-enum {
-  AH_DT_DATE32 = 32,    /* i32 days since the epoch */
-  AH_DT_DATE64 = 33,    /* i64 milliseconds since the epoch */
-  AH_DT_TIME32 = 34,    /* i32, unit = second | millisecond */
-  AH_DT_TIME64 = 35,    /* i64, unit = microsecond | nanosecond */
-  AH_DT_TIMESTAMP = 36, /* i64 since the epoch in `unit`, optional fixed-offset zone */
-  AH_DT_DURATION = 37   /* i64 in `unit` */
-};
-typedef struct ah_data_type {
-  int32_t id;
-  ah_time_unit unit;
-  int32_t has_tz;
-  int32_t tz_offset_seconds;
-  int32_t precision;
-  int32_t scale;
-} ah_data_type;
 /* arrow_cast::cast_with_options for (from, to) pairs where either side is AH_DT_*; everything else is forwarded to
  * ah_cast.  `values->type` must be the physical layout of `from` (AH_INT32 for Date32 / Time32, AH_INT64 for the
  * rest).  Arm by arm as the reference: reinterpreting arms clone; unit up-scaling is `checked_mul` (safe: overflow

@@ -327,6 +327,16 @@ inline ArrayRef cast_with_options(const ArrayRef& a, const ah_data_type& from, c
 inline ArrayRef cast(const ArrayRef& a, const ah_data_type& from, const ah_data_type& to) {
   return cast_with_options(a, from, to, CastOptions{});
 }
+// numeric.rs with temporal operands (timestamp_op :426, duration_op :877, date_op :898): the result's logical type
+// is returned through `out_type` (Timestamp - Timestamp = Duration, Timestamp +- Duration keeps the zone, ...).
+inline ArrayRef arith(ah_arith_op op, const Datum& l, const ah_data_type& lt, const Datum& r, const ah_data_type& rt,
+                      ah_data_type* out_type) {
+  ah_array_out out;
+  auto& ctx = l.array->context();
+  ctx->check(ah_arith_with_types(ctx->handle(), op, &l.array->view(), l.is_scalar, &lt, &r.array->view(), r.is_scalar, &rt,
+                                 &out, out_type));
+  return wrap(l.array, out);
+}
 
 // ---- concat (arrow-select/src/concat.rs)
 inline ArrayRef concat(const std::vector<ArrayRef>& arrays) {

@@ -2807,11 +2807,116 @@ int32_t cast_temporal(const orc_view* in, const orc_data_type* from, const orc_d
 
 }  // namespace
 
+// --------------------------------------------------- temporal arithmetic (types)
+// arithmetic_op's type rules for temporal operands (arrow-arith/src/numeric.rs:225-275) with timestamp_op
+// (:426-537), duration_op (:877-895) and the Date - Date arms of date_op (:898-932).  Interval arms: not restated.
+namespace {
+enum { DT_INTERVAL = 38 };
+const char* op_display(int op) {  // numeric.rs:203-213
+  switch (op) { case 0: case 1: return "+"; case 2: case 3: return "-"; case 4: case 5: return "*"; case 6: return "/"; default: return "%"; }
+}
+std::string arith_dt_text(const orc_data_type* t) {
+  if (t->id == DT_INTERVAL) {
+    static const char* n[] = {"YearMonth", "DayTime", "MonthDayNano"};
+    return std::string("Interval(") + n[t->unit % 3] + ")";
+  }
+  return dt_text(t);
+}
+int32_t arith_temporal(int op, const orc_view* l, bool l_s, const orc_data_type* lt, const orc_view* r, bool r_s,
+                       const orc_data_type* rt, orc_out* out, orc_data_type* ot) {
+  out_init(out);
+  const int L = lt->id, R = rt->id;
+  const bool add = op == 0 || op == 1, sub = op == 2 || op == 3, commutative = add || op == 4 || op == 5;
+  auto logical = [](int id) { return id >= DT_DATE32; };
+  if (!logical(L) && !logical(R)) {
+    *ot = *lt;
+    return orc_arith(op, l, l_s, r, r_s, out);
+  }
+  const std::string ls = arith_dt_text(lt), rs = arith_dt_text(rt);
+  auto nyi = [&] { return fail(ORC_NOT_YET_IMPLEMENTED, "%s %s %s: interval arithmetic is not built on the device", ls.c_str(), op_display(op), rs.c_str()); };
+  if (L == DT_TIMESTAMP) {
+    if (sub && R == DT_TIMESTAMP && rt->unit == lt->unit) {  // :440-443 try_op_ref!(T::Duration, .. l.sub_checked(r))
+      *ot = with_unit(DT_DURATION, lt->unit);
+      return orc_arith(2, l, l_s, r, r_s, out);
+    }
+    if (R == DT_DURATION && rt->unit == lt->unit && (add || sub)) {  // :445-452, result keeps the left zone (:536)
+      *ot = *lt;
+      return orc_arith(add ? 0 : 2, l, l_s, r, r_s, out);
+    }
+    if (R == DT_INTERVAL && (add || sub)) return nyi();
+    return fail(ORC_INVALID_ARGUMENT, "Invalid timestamp arithmetic operation: %s %s %s", ls.c_str(), op_display(op), rs.c_str());
+  }
+  if (L == DT_DURATION && R == DT_DURATION && lt->unit == rt->unit) {
+    if (add || sub) {
+      *ot = *lt;
+      return orc_arith(add ? 0 : 2, l, l_s, r, r_s, out);
+    }
+    return fail(ORC_INVALID_ARGUMENT, "Invalid duration arithmetic operation: %s %s %s", ls.c_str(), op_display(op), rs.c_str());
+  }
+  if (L == DT_INTERVAL && (R == DT_INTERVAL ? rt->unit == lt->unit : (R == ORC_INT64 || (R == ORC_FLOAT64 && lt->unit == 2)))) return nyi();
+  if (L == DT_DATE32 || L == DT_DATE64) {
+    if (sub && R == L) {
+      if (L == DT_DATE64) {  // :926-930
+        *ot = with_unit(DT_DURATION, U_MS);
+        return orc_arith(2, l, l_s, r, r_s, out);
+      }
+      // :913-924 op_ref!(DurationSecondType, .., ((l as i64) - (r as i64)) * NUM_SECONDS_IN_DAY): `binary` / `unary`
+      *ot = with_unit(DT_DURATION, U_S);
+      const int32_t* lv = (const int32_t*)l->values;
+      const int32_t* rv = (const int32_t*)r->values;
+      auto f = [](int32_t a, int32_t b) { return ((int64_t)a - (int64_t)b) * 86400; };
+      if (l_s != r_s) {
+        const orc_view* arr = l_s ? r : l;
+        const orc_view* sc = l_s ? l : r;
+        const int64_t len = arr->length;
+        int64_t* ov = start_out<int64_t>(arr, ORC_INT64, out);
+        if (resolve_nulls(sc) != 0) {  // new_null(len)
+          memset(ov, 0, (size_t)len * 8);
+          out->validity = (uint8_t*)xalloc(bitmap_bytes(len));
+          out->validity_bytes = (int64_t)bitmap_bytes(len);
+          out->null_count = len;
+          return ORC_OK;
+        }
+        for (int64_t i = 0; i < len; ++i) ov[i] = l_s ? f(lv[0], rv[i]) : f(lv[i], rv[0]);
+        attach_nulls(out, nulls_clone(arr, len), len);
+        return ORC_OK;
+      }
+      if (l->length != r->length) return fail(ORC_COMPUTE_ERROR, "Cannot perform binary operation on arrays of different length");
+      const int64_t len = l->length;
+      int64_t* ov = start_out<int64_t>(l, ORC_INT64, out);
+      for (int64_t i = 0; i < len; ++i) ov[i] = f(lv[i], rv[i]);
+      if (l->validity || r->validity) {  // NullBuffer::union: presence-based
+        uint8_t* nb = (uint8_t*)xalloc(bitmap_bytes(len));
+        for (int64_t i = 0; i < len; ++i) {
+          bool a = !l->validity || get_bit(l->validity, l->validity_bit_offset + i);
+          bool b = !r->validity || get_bit(r->validity, r->validity_bit_offset + i);
+          if (a && b) set_bit(nb, i);
+        }
+        attach_nulls(out, nb, len);
+      }
+      return ORC_OK;
+    }
+    if (R == DT_INTERVAL && (add || sub)) return nyi();
+    return fail(ORC_INVALID_ARGUMENT, "Invalid date arithmetic operation: %s %s %s", ls.c_str(), op_display(op), rs.c_str());
+  }
+  if ((L == DT_DURATION || L == DT_INTERVAL) && (R == DT_DATE32 || R == DT_DATE64 || R == DT_TIMESTAMP) && commutative)
+    return arith_temporal(op, r, r_s, rt, l, l_s, lt, out, ot);  // :263-265
+  if (((L == ORC_INT64 && R == DT_INTERVAL) || (L == ORC_FLOAT64 && R == DT_INTERVAL && rt->unit == 2)) && op == 4) return nyi();
+  return fail(ORC_INVALID_ARGUMENT, "Invalid arithmetic operation: %s %s %s", ls.c_str(), op_display(op), rs.c_str());
+}
+}  // namespace
+
 extern "C" {
 
 int32_t orc_cast_with_types(const orc_view* in, const orc_data_type* from, const orc_data_type* to, int32_t safe,
                             orc_out* out) {
   return cast_temporal(in, from, to, safe != 0, out);
+}
+
+int32_t orc_arith_with_types(int32_t op, const orc_view* lhs, int32_t lhs_scalar, const orc_data_type* lhs_type,
+                             const orc_view* rhs, int32_t rhs_scalar, const orc_data_type* rhs_type, orc_out* out,
+                             orc_data_type* out_type) {
+  return arith_temporal(op, lhs, lhs_scalar != 0, lhs_type, rhs, rhs_scalar != 0, rhs_type, out, out_type);
 }
 
 int32_t orc_aggregate(int32_t op, const orc_view* a, int32_t vector_bytes, orc_scalar* out) {

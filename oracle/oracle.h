@@ -108,6 +108,11 @@ typedef struct orc_data_type {
 } orc_data_type;
 int32_t orc_cast_with_types(const orc_view* values, const orc_data_type* from, const orc_data_type* to, int32_t safe,
                             orc_out* out);
+/* arithmetic_op's type rules for temporal operands (arrow-arith/src/numeric.rs:225-275, :426-537, :877-932): op as
+ * AH_ADD..AH_REM; the result's logical type is written to out_type. */
+int32_t orc_arith_with_types(int32_t op, const orc_view* lhs, int32_t lhs_scalar, const orc_data_type* lhs_type,
+                             const orc_view* rhs, int32_t rhs_scalar, const orc_data_type* rhs_type, orc_out* out,
+                             orc_data_type* out_type);
 int32_t orc_concat(int32_t n, const orc_view* pieces, orc_out* out);
 
 /* arrow_arith::aggregate (arrow-arith/src/aggregate.rs): op numbering as AH_AGG_*.

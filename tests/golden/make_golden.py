@@ -1109,8 +1109,48 @@ for t in ("Int8", "Int16", "Int32", "Int64", "UInt8", "UInt16", "UInt32", "UInt6
     tcast(f"test_cast_timestamp_to_integer_{t}", "5097-5123", arr(TS("Millisecond", "+00:00"), [5, 1, N]), t, [5, 1, N])
 
 
+# ------------------------------------------------------------- temporal arithmetic
+# arrow-arith/src/numeric.rs tests with temporal operands (no intervals): ops as AH_ADD=0, AH_ADD_WRAPPING=1, AH_SUB=2,
+# AH_SUB_WRAPPING=3, AH_MUL=4, AH_MUL_WRAPPING=5, AH_DIV=6, AH_REM=7.
+NM = "arrow-arith/src/numeric.rs"
+tarith_cases = []
+
+
+def tarith(name, lines, op, lhs, rhs, expected=None, **kw):
+    d = dict(name=name, source=f"{NM}:{lines}", op=op, lhs=lhs, rhs=rhs, **kw)
+    if expected is not None:
+        d["expected"] = expected
+    tarith_cases.append(d)
+
+
+for u in ("Second", "Millisecond", "Microsecond", "Nanosecond"):
+    a = arr(TS(u), [2000000, 434030324, 53943340])
+    b = arr(TS(u), [329593, 59349, 694994])
+    dur = arr(f"Duration({u})", [1670407, 433970975, 53248346])
+    tarith(f"test_timestamp_sub_{u}", "1548-1556", 2, a, b, dur)
+    tarith(f"test_timestamp_add_duration_{u}", "1558-1559", 0, b, dur, a)
+    tarith(f"test_duration_add_timestamp_{u}", "1561-1562", 0, dur, b, a)
+    da, db = arr(f"Duration({u})", [1000, 4394, -3944]), arr(f"Duration({u})", [4, -5, -243])
+    tarith(f"test_duration_add_{u}", "1972-1977", 0, da, db, arr(f"Duration({u})", [1004, 4389, -4187]))
+    tarith(f"test_duration_sub_{u}", "1978-1979", 2, da, db, arr(f"Duration({u})", [996, 4399, -3701]))
+    sym = {4: "*", 6: "/", 7: "%"}
+    for op in (4, 6, 7):
+        us = {"Second": "s", "Millisecond": "ms", "Microsecond": "µs", "Nanosecond": "ns"}[u]
+        tarith(f"test_duration_invalid_{op}_{u}", "1981-1997", op, da, db, error="InvalidArgumentError",
+               message=f"Invalid duration arithmetic operation: Duration({us}) {sym[op]} Duration({us})")
+    tarith(f"test_duration_overflow_{u}", "1999-2006", 0, arr(f"Duration({u})", [I64MAX]), arr(f"Duration({u})", [1]),
+           error="ArithmeticOverflow", message=f"Overflow happened on: {I64MAX} + 1",
+           display=f"Arithmetic overflow: Overflow happened on: {I64MAX} + 1")
+tarith("test_date32_sub", "2110-2116", 2, arr("Date32", [-2**31, 2**31 - 1, 23, 7684]), arr("Date32", [-2**31, -2**31, -2, 45]),
+       arr("Duration(Second)", [0, 371085174288000, 2160000, 660009600]))
+tarith("test_date64_sub", "2118-2124", 2, arr("Date64", [4343, 76676, 3434]), arr("Date64", [3, -5, 5]),
+       arr("Duration(Millisecond)", [4340, 76681, 3429]))
+tarith("test_date64_sub_overflow", "2126-2133", 2, arr("Date64", [I64MAX]), arr("Date64", [-1]), error="ArithmeticOverflow",
+       message=f"Overflow happened on: {I64MAX} - -1", display=f"Arithmetic overflow: Overflow happened on: {I64MAX} - -1")
+
+
 for name, cases in [("like", like_cases), ("cmp_utf8", cmp_utf8_cases), ("zip", zip_cases), ("sort", sort_cases), ("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
-                    ("cast", cast_cases), ("rank_shift", rank_cases), ("cast_temporal", tcast_cases)]:
+                    ("cast", cast_cases), ("rank_shift", rank_cases), ("cast_temporal", tcast_cases), ("arith_temporal", tarith_cases)]:
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:
         json.dump({"reference": "apache/arrow-rs 59.2.0", "cases": cases}, f, indent=1)
     print(name, len(cases))

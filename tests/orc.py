@@ -168,6 +168,7 @@ class Oracle:
         lib.orc_cast.argtypes = [VP, C.c_int32, C.c_int32, OP]
         DP = C.POINTER(L.DataTypeDesc)
         lib.orc_cast_with_types.argtypes = [VP, DP, DP, C.c_int32, OP]
+        lib.orc_arith_with_types.argtypes = [C.c_int32, VP, C.c_int32, DP, VP, C.c_int32, DP, OP, DP]
         lib.orc_boolean_binary.argtypes = [C.c_int32, VP, VP, OP]
         lib.orc_boolean_unary.argtypes = [C.c_int32, VP, OP]
         lib.orc_nullif.argtypes = [VP, VP, OP]
@@ -280,6 +281,18 @@ class Oracle:
         if st:
             self._raise(st)
         return self._collect(out, to_type)
+
+    def arith_with_types(self, op, lhs, rhs, l_scalar=False, r_scalar=False, bit_offset=0):
+        """arithmetic_op with temporal operands (oracle.cpp arith_temporal); the result carries its logical type."""
+        hl, hr = _Held(lhs, bit_offset), _Held(rhs, bit_offset)
+        out, ot = Out(), L.DataTypeDesc()
+        lt, rt = lhs.data_type.descriptor(), rhs.data_type.descriptor()
+        st = self.lib.orc_arith_with_types(op, C.byref(hl.view), int(l_scalar), C.byref(lt), C.byref(hr.view), int(r_scalar),
+                                           C.byref(rt), C.byref(out), C.byref(ot))
+        if st:
+            self._raise(st)
+        like = lhs.data_type if lhs.data_type.logical and lhs.data_type.logical[0] == ot.id else rhs.data_type
+        return self._collect(out, A.array.data_type_from_descriptor(ot, like))
 
     def cast_with_types(self, values, to_type, safe=True, bit_offset=0):
         """cast_with_options where either side is a temporal logical type (oracle.cpp cast_temporal)."""

@@ -165,3 +165,80 @@ def test_large_round_trips(ctx):
     up = K.cast(s, A.DurationNanosecond)
     assert up.null_count() == 0
     assert np.array_equal(K.cast(up, A.DurationSecond).values_numpy(), s.values_numpy())
+
+
+# ------------------------------------------------------- temporal arithmetic
+ARITH_FN = {0: K.add, 1: K.add_wrapping, 2: K.sub, 3: K.sub_wrapping, 4: K.mul, 5: K.mul_wrapping, 6: K.div, 7: K.rem}
+
+
+@pytest.mark.parametrize("case", load_golden("arith_temporal"), ids=lambda c: c["name"])
+def test_arith_temporal_golden(ctx, case):
+    l, r = golden_array(case["lhs"]).to_device(ctx), golden_array(case["rhs"]).to_device(ctx)
+    if "error" in case:
+        with pytest.raises(ERR[case["error"]]) as ei:
+            ARITH_FN[case["op"]](l, r)
+        assert ei.value.message == case["message"]
+        assert str(ei.value) == case.get("display", str(ei.value))
+        return
+    for op in (case["op"], case["op"] + 1):  # the *_wrapping forms are checked as well
+        got = ARITH_FN[op](l, r)
+        exp = golden_array(case["expected"])
+        assert got.data_type == exp.data_type, case["name"]
+        assert_logical_eq(host(got), exp, case["name"])
+
+
+def test_arith_temporal_matches_the_oracle(ctx, oracle):
+    rng = np.random.default_rng(23)
+    ts, tz = A.TimestampMicrosecond, A.Timestamp(A.MICROSECOND, "-08:00")
+    pairs = [(ts, ts, (2, 3)), (tz, ts, (2, 3)), (tz, A.DurationMicrosecond, (0, 1, 2, 3)), (A.DurationMicrosecond, tz, (0, 1)),
+             (A.DurationNanosecond, A.DurationNanosecond, (0, 1, 2, 3)), (A.Date64, A.Date64, (2, 3)), (A.Date32, A.Date32, (2, 3))]
+    n = 3000
+    for lt, rt, ops in pairs:
+        def column(t, with_nulls):
+            if t.np_dtype == np.int32:
+                v = rng.integers(I32.min, I32.max, n, dtype=np.int64).astype(np.int32)
+            else:
+                v = rng.integers(-2**61, 2**61, n, dtype=np.int64)  # sums and differences stay inside i64
+            return HostArray(t, v, (rng.random(n) < 0.8) if with_nulls else None)
+        for ln, rn in ((False, False), (True, False), (True, True)):
+            hl, hr = column(lt, ln), column(rt, rn)
+            dl, dr = hl.to_device(ctx, bit_offset=5 if ln else 0), hr.to_device(ctx)
+            for op in ops:
+                exp = oracle.arith_with_types(op, hl, hr)
+                got = ARITH_FN[op](dl, dr)
+                assert got.data_type == exp.data_type, (lt, rt, op)
+                check_exact(got, exp, f"{lt} {op} {rt} nulls={ln},{rn}")
+            # scalar operands (Datum): a length-1 array on either side, and a null scalar
+            for sc_valid in (True, False):
+                hs = HostArray(rt, hr.values[:1], None if sc_valid else np.array([False]))
+                exp = oracle.arith_with_types(ops[0], hl, hs, r_scalar=True)
+                got = ARITH_FN[ops[0]](dl, A.Scalar(hs.to_device(ctx)))
+                assert got.data_type == exp.data_type
+                check_exact(got, exp, f"{lt} {ops[0]} scalar {rt} valid={sc_valid}")
+    # overflow is reported for the first failing valid row, through the wrapping entry point too
+    big = HostArray(ts, np.array([1, I64.max, I64.min, 5], dtype=np.int64), np.array([True, False, True, True]))
+    one = HostArray(A.DurationMicrosecond, np.array([1, 1, 1, 1], dtype=np.int64))
+    with pytest.raises(A.array.ArithmeticOverflow) as ei:
+        K.sub_wrapping(big.to_device(ctx), one.to_device(ctx))
+    assert ei.value.message == f"Overflow happened on: {I64.min} - 1"
+    check_exact(K.add_wrapping(big.to_device(ctx), one.to_device(ctx)), oracle.arith_with_types(1, big, one))
+
+
+def test_arith_temporal_refusals(ctx):
+    ts, tz = A.TimestampSecond, A.Timestamp(A.SECOND, "+05:45")
+    one = lambda t: HostArray.from_pylist([10, None, 30], t).to_device(ctx)  # noqa: E731
+    for fn, l, r, msg in (
+            (K.mul, ts, A.DurationSecond, "Invalid timestamp arithmetic operation: Timestamp(s) * Duration(s)"),
+            (K.add, ts, ts, "Invalid timestamp arithmetic operation: Timestamp(s) + Timestamp(s)"),
+            (K.sub, ts, A.TimestampMillisecond, "Invalid timestamp arithmetic operation: Timestamp(s) - Timestamp(ms)"),
+            (K.add, tz, A.Int64, 'Invalid timestamp arithmetic operation: Timestamp(s, "+05:45") + Int64'),
+            (K.sub, A.DurationSecond, ts, "Invalid arithmetic operation: Duration(s) - Timestamp(s)"),
+            (K.add, A.DurationSecond, A.DurationMillisecond, "Invalid arithmetic operation: Duration(s) + Duration(ms)"),
+            (K.div, A.DurationSecond, A.DurationSecond, "Invalid duration arithmetic operation: Duration(s) / Duration(s)"),
+            (K.add, A.Date32, A.Date32, "Invalid date arithmetic operation: Date32 + Date32"),
+            (K.add, A.DurationSecond, A.Date32, "Invalid date arithmetic operation: Date32 + Duration(s)"),
+            (K.add, A.Int64, ts, "Invalid arithmetic operation: Int64 + Timestamp(s)"),
+            (K.add, A.Time32Second, A.Time32Second, "Invalid arithmetic operation: Time32(s) + Time32(s)")):
+        with pytest.raises(A.array.InvalidArgumentError) as ei:
+            fn(one(l), one(r))
+        assert ei.value.message == msg

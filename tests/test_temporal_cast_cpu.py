@@ -275,3 +275,50 @@ def test_named_zone_is_the_reference_parse_error():
     for bad in ("0900", "+9", "+09:0", "+0a:00", "UTC", "+24:00", ""):
         with pytest.raises(A.array.ParseError):
             A.parse_fixed_offset(bad)
+
+
+# ------------------------------------------------------- temporal arithmetic
+@pytest.mark.parametrize("case", load_golden("arith_temporal"), ids=lambda c: c["name"])
+def test_arith_temporal_golden(oracle, case):
+    l, r = golden_array(case["lhs"]), golden_array(case["rhs"])
+    if "error" in case:
+        return expect_err(case, lambda: oracle.arith_with_types(case["op"], l, r))
+    got = oracle.arith_with_types(case["op"], l, r)
+    assert_logical_eq(got, golden_array(case["expected"]), case["name"])
+    # *_wrapping entry points are checked too (timestamp_op / duration_op call add_checked / sub_checked)
+    assert_logical_eq(oracle.arith_with_types(case["op"] + 1, l, r), golden_array(case["expected"]), case["name"] + " wrapping")
+
+
+def test_arith_temporal_type_rules_on_the_oracle(oracle):
+    ts, tz = A.TimestampSecond, A.Timestamp(A.SECOND, "+05:45")
+    one = lambda t: HostArray.from_pylist([10, None, 30], t)  # noqa: E731
+    # result types
+    assert oracle.arith_with_types(2, one(tz), one(ts)).data_type == A.DurationSecond
+    assert oracle.arith_with_types(0, one(tz), one(A.DurationSecond)).data_type == tz      # the left zone is kept
+    assert oracle.arith_with_types(1, one(A.DurationSecond), one(tz)).data_type == tz      # Duration + Timestamp swaps
+    assert oracle.arith_with_types(2, one(A.Date32), one(A.Date32)).data_type == A.DurationSecond
+    assert oracle.arith_with_types(3, one(A.Date64), one(A.Date64)).data_type == A.DurationMillisecond
+    # the reference's refusals (numeric.rs:528-533, :886-890, :963-967, :270-272)
+    for op, l, r, msg in (
+            (4, ts, A.DurationSecond, "Invalid timestamp arithmetic operation: Timestamp(s) * Duration(s)"),
+            (0, ts, ts, "Invalid timestamp arithmetic operation: Timestamp(s) + Timestamp(s)"),
+            (2, ts, A.TimestampMillisecond, "Invalid timestamp arithmetic operation: Timestamp(s) - Timestamp(ms)"),
+            (0, ts, A.DurationMillisecond, "Invalid timestamp arithmetic operation: Timestamp(s) + Duration(ms)"),
+            (0, tz, A.Int64, 'Invalid timestamp arithmetic operation: Timestamp(s, "+05:45") + Int64'),
+            (2, A.DurationSecond, ts, "Invalid arithmetic operation: Duration(s) - Timestamp(s)"),
+            (0, A.DurationSecond, A.DurationMillisecond, "Invalid arithmetic operation: Duration(s) + Duration(ms)"),
+            (0, A.Date32, A.Date32, "Invalid date arithmetic operation: Date32 + Date32"),
+            (2, A.Date32, A.Date64, "Invalid date arithmetic operation: Date32 - Date64"),
+            (0, A.DurationSecond, A.Date32, "Invalid date arithmetic operation: Date32 + Duration(s)"),
+            (0, A.Int64, ts, "Invalid arithmetic operation: Int64 + Timestamp(s)"),
+            (0, A.Time32Second, A.Time32Second, "Invalid arithmetic operation: Time32(s) + Time32(s)")):
+        with pytest.raises(A.array.InvalidArgumentError) as ei:
+            oracle.arith_with_types(op, one(l), one(r))
+        assert ei.value.message == msg
+    # null rules are try_op!'s: union of the nulls; a null scalar gives an all-null result
+    got = oracle.arith_with_types(2, HostArray.from_pylist([5, None, 7], ts), HostArray.from_pylist([1, 2, None], ts))
+    assert got.to_pylist() == [4, None, None]
+    got = oracle.arith_with_types(2, one(A.Date32), HostArray.from_pylist([None], A.Date32), r_scalar=True)
+    assert got.to_pylist() == [None, None, None] and got.data_type == A.DurationSecond
+    got = oracle.arith_with_types(2, one(A.Date32), HostArray.from_pylist([3], A.Date32), r_scalar=True)
+    assert got.to_pylist() == [7 * 86400, None, 27 * 86400]
