@@ -37,30 +37,42 @@ struct TArgs {
   TParams p;
 };
 
-template <typename I, typename O>
+template <typename I, typename O, int OP>
 __global__ void __launch_bounds__(256) tcast_kernel(TArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const I* ip = (const I*)a.in;
   O* op = (O*)a.out;
   unsigned long long nvalid = 0, err = ~0ull;
-  for (int64_t base = (int64_t)blockIdx.x * 1024; base < a.len; base += (int64_t)gridDim.x * 1024) {
+  // The closures cost 100-300 SIMD cycles per 64 rows (64-bit multiplies are quarter rate), so the next tile's values
+  // and validity words are requested BEFORE the current tile is computed: without this software prefetch a wave has
+  // nothing in flight while it computes and compute time adds to memory time instead of hiding under it.
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  I v[4], nv[4];
+  uint64_t iv[4], niv[4];
+  auto load_tile = [&](int64_t base, I (&tv)[4], uint64_t (&tiv)[4]) {
     const int64_t wbase = base + wave * 256;
-    I v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       int64_t i = wbase + k * 64 + lane;
-      v[k] = i < a.len ? ip[i] : I{};
+      tv[k] = i < a.len ? ip[i] : I{};
+      tiv[k] = bv_fetch64(a.in_valid, wbase + k * 64, a.len);
     }
+  };
+  int64_t base = (int64_t)blockIdx.x * 1024;
+  if (base < a.len) load_tile(base, v, iv);
+  for (; base < a.len; base += stride) {
+    const int64_t wbase = base + wave * 256;
+    const bool more = base + stride < a.len;
+    if (more) load_tile(base + stride, nv, niv);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       int64_t i0 = wbase + k * 64;
       if (i0 >= a.len) break;
       int64_t i = i0 + lane;
-      uint64_t iv = bv_fetch64(a.in_valid, i0, a.len);
-      bool valid = (iv >> lane) & 1;
+      bool valid = (iv[k] >> lane) & 1;
       O o = O{};
       bool ok = true;
-      if (valid || (a.all_slots && i < a.len)) ok = tc_row<I, O>(a.p, v[k], &o);
+      if (valid || (a.all_slots && i < a.len)) ok = tc_row_op<I, O, OP>(a.p, v[k], &o);
       if (!ok) {
         o = O{};
         if (!a.fail_is_null) {
@@ -70,11 +82,18 @@ __global__ void __launch_bounds__(256) tcast_kernel(TArgs a) {
       }
       if (i < a.len) op[i] = o;
       if (a.out_valid) {
-        uint64_t w = a.fail_is_null ? (iv & __ballot(ok)) : iv;
+        uint64_t w = a.fail_is_null ? (iv[k] & __ballot(ok)) : iv[k];
         if (lane == 0) {
           a.out_valid[i0 >> 6] = w;
           nvalid += __popcll(w);
         }
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = nv[k];
+        iv[k] = niv[k];
       }
     }
   }
@@ -129,6 +148,38 @@ ah_status source_value_text(ah_context* ctx, ah_type t, const void* base, int64_
   return AH_OK;
 }
 
+// one instantiation per (arm, layout pair) the planner can produce
+template <int OP>
+bool launch_op(ah_context* ctx, ah_type from, ah_type to, const TArgs& a, int grid) {
+  constexpr bool in32 = OP == T_MUL_WRAP || OP == T_MUL_CHECKED || OP == T_DIV;                  // Date32 / Time32 sources
+  constexpr bool out32 = OP == T_MUL_CHECKED || OP == T_DIV || OP == T_DIV_TRY_I32 || OP == T_TS_DATE32 || OP == T_TS_TIME;
+  constexpr bool out64 = OP != T_DIV_TRY_I32 && OP != T_TS_DATE32;
+  if constexpr (in32 && out32 && OP != T_MUL_WRAP) {
+    if (from == AH_INT32 && to == AH_INT32) return tcast_kernel<int32_t, int32_t, OP><<<grid, 256, 0, ctx->stream>>>(a), true;
+  }
+  if constexpr (in32 && out64 && OP != T_DIV) {
+    if (from == AH_INT32 && to == AH_INT64) return tcast_kernel<int32_t, int64_t, OP><<<grid, 256, 0, ctx->stream>>>(a), true;
+  }
+  if constexpr (out32 && OP != T_MUL_CHECKED) {
+    if (from == AH_INT64 && to == AH_INT32) return tcast_kernel<int64_t, int32_t, OP><<<grid, 256, 0, ctx->stream>>>(a), true;
+  }
+  if constexpr (out64) {
+    if (from == AH_INT64 && to == AH_INT64) return tcast_kernel<int64_t, int64_t, OP><<<grid, 256, 0, ctx->stream>>>(a), true;
+  }
+  return false;  // a layout pair the planner never produces for this arm
+}
+bool launch_step(ah_context* ctx, ah_type from, ah_type to, const TArgs& a, int grid) {
+  switch (a.p.op) {
+    case T_MUL_WRAP: return launch_op<T_MUL_WRAP>(ctx, from, to, a, grid);
+    case T_MUL_CHECKED: return launch_op<T_MUL_CHECKED>(ctx, from, to, a, grid);
+    case T_DIV: return launch_op<T_DIV>(ctx, from, to, a, grid);
+    case T_DIV_TRY_I32: return launch_op<T_DIV_TRY_I32>(ctx, from, to, a, grid);
+    case T_TS_DATE32: return launch_op<T_TS_DATE32>(ctx, from, to, a, grid);
+    case T_TS_TIME: return launch_op<T_TS_TIME>(ctx, from, to, a, grid);
+    default: return launch_op<T_TZ_ADJUST>(ctx, from, to, a, grid);
+  }
+}
+
 ah_status run_kernel_step(ah_context* ctx, const ah_array_view* values, const Step& step, int32_t safe,
                           ah_array_out* out) {
   ah_out_init(out);
@@ -166,14 +217,12 @@ ah_status run_kernel_step(ah_context* ctx, const ah_array_view* values, const St
   a.first_err = aux;
   a.all_slots = step.mode == Step::UNARY;
   a.fail_is_null = (fail_is_null || step.mode == Step::UNARY) ? 1 : 0;  // UNARY steps cannot fail
+  bool launched = false;
   {
     ah_prof_scope ps(ctx, "cast_temporal");
-    if (from == AH_INT32 && to == AH_INT32) tcast_kernel<int32_t, int32_t><<<grid, 256, 0, ctx->stream>>>(a);
-    else if (from == AH_INT32) tcast_kernel<int32_t, int64_t><<<grid, 256, 0, ctx->stream>>>(a);
-    else if (to == AH_INT32) tcast_kernel<int64_t, int32_t><<<grid, 256, 0, ctx->stream>>>(a);
-    else tcast_kernel<int64_t, int64_t><<<grid, 256, 0, ctx->stream>>>(a);
+    launched = launch_step(ctx, from, to, a, grid);
   }
-  hipError_t e = hipGetLastError();
+  hipError_t e = launched ? hipGetLastError() : hipErrorInvalidValue;
   const bool can_fail = step.mode != Step::UNARY && !fail_is_null;
   if (e == hipSuccess) {
     // infallible shapes run deferred like the safe numeric casts (cast.hip)

@@ -48,72 +48,122 @@ struct TParams {
   int64_t off;   // zone offset in seconds
   int64_t tmul;  // T_TS_TIME: out = second_of_day * tmul + nanos / ndiv
   int64_t ndiv;
+  int64_t sub_to_ns;  // nanoseconds per source tick = 1e9 / mult
+  int64_t lo, hi;     // T_TS_*: the ticks of chrono's first and last representable second (unused for nanoseconds)
+  int64_t ratio;      // T_TS_TIME: target ticks per source tick (tmul >= mult) or source ticks per target tick
 };
 
-TC_FN int64_t tc_floor_div(int64_t a, int64_t b) {  // b > 0
-  int64_t q = a / b;
-  return (a % b < 0) ? q - 1 : q;
+// Every divisor the arms use is one of a handful of constants, so the divisions are written against COMPILE-TIME
+// divisors (the compiler turns them into a multiply-high and shifts) behind a switch on the kernel argument — a
+// uniform scalar branch.  A 64-bit division by a run-time value is a ~60-instruction software routine on gfx950 and
+// made the first version of this kernel issue-bound at 27-42 % of the HBM peak.
+template <int64_t D>
+TC_FN int64_t tc_fdiv_c(int64_t a) {  // floor(a / D), D > 0  (i64::div_euclid)
+  int64_t q = a / D;
+  return (a - q * D < 0) ? q - 1 : q;
 }
-TC_FN int64_t tc_floor_mod(int64_t a, int64_t b) {  // b > 0
-  int64_t r = a % b;
-  return r < 0 ? r + b : r;
+TC_FN int64_t tc_div_trunc(int64_t a, int64_t d) {  // Rust `/`
+  switch (d) {
+    case 1: return a;
+    case 1000: return a / 1000;
+    case 1000000: return a / 1000000;
+    case 1000000000: return a / 1000000000;
+    case 86400000: return a / 86400000;
+    default: return a / d;
+  }
 }
+// split_second (temporal_conversions.rs:213-216): whole seconds (div_euclid) and the remaining ticks (rem_euclid)
+TC_FN void tc_split_second(int64_t x, int64_t mult, int64_t* sec, int64_t* sub) {
+  switch (mult) {
+    case 1: *sec = x; break;
+    case 1000: *sec = tc_fdiv_c<1000>(x); break;
+    case 1000000: *sec = tc_fdiv_c<1000000>(x); break;
+    default: *sec = tc_fdiv_c<1000000000>(x); break;
+  }
+  *sub = x - *sec * mult;
+}
+// DateTime::from_timestamp accepts the second iff its day is a NaiveDate: one range test on the seconds
+constexpr int64_t kMinSec = kMinDay * 86400, kMaxSec = kMaxDay * 86400 + 86399;
 
 template <typename O>
 TC_FN O tc_wrap_to(int64_t v) {
   return (O)(typename std::make_unsigned<O>::type)(uint64_t)v;  // Rust `as`: keep the low bits
 }
 
+// One arm's closure.  OP is a template parameter so that each launch carries the code of its own arm only.
+template <typename I, typename O, int OP>
+TC_FN bool tc_row_op(const TParams& a, I v, O* o) {
+  const int64_t x = (int64_t)v;
+  if constexpr (OP == T_MUL_WRAP) {
+    *o = tc_wrap_to<O>((int64_t)((uint64_t)x * (uint64_t)a.k));
+    return true;
+  } else if constexpr (OP == T_MUL_CHECKED) {
+    long long p;
+    if (__builtin_mul_overflow((long long)x, (long long)a.k, &p)) return false;
+    if (sizeof(O) == 4 && (p < INT32_MIN || p > INT32_MAX)) return false;
+    *o = (O)p;
+    return true;
+  } else if constexpr (OP == T_DIV) {
+    *o = tc_wrap_to<O>(tc_div_trunc(x, a.k));
+    return true;
+  } else if constexpr (OP == T_DIV_TRY_I32) {
+    int64_t q = tc_div_trunc(x, a.k);
+    if (q < INT32_MIN || q > INT32_MAX) return false;
+    *o = (O)q;
+    return true;
+  } else if constexpr (OP == T_TS_DATE32 || OP == T_TS_TIME) {
+    // as_datetime(x) in the source zone.  seconds = div_euclid(x, mult), day = div_euclid(seconds + off, 86400) folds
+    // into ONE floor division of the shifted tick count by the ticks of a day; the calendar range test is a compare
+    // on x (nanoseconds never leave the calendar: +-292 years).
+    if (a.mult != 1000000000 && (x < a.lo || x > a.hi)) return false;
+    long long xs;
+    int64_t day, tod;
+    if (__builtin_add_overflow((long long)x, (long long)(a.off * a.mult), &xs)) {
+      // within a zone offset of the i64 ends (nanoseconds only): the two-step form cannot overflow
+      int64_t sec, sub;
+      tc_split_second(x, a.mult, &sec, &sub);
+      day = tc_fdiv_c<86400>(sec + a.off);
+      tod = (sec + a.off - day * 86400) * a.mult + sub;
+    } else {
+      switch (a.mult) {
+        case 1: day = tc_fdiv_c<86400ll>(xs); break;
+        case 1000: day = tc_fdiv_c<86400000ll>(xs); break;
+        case 1000000: day = tc_fdiv_c<86400000000ll>(xs); break;
+        default: day = tc_fdiv_c<86400000000000ll>(xs); break;
+      }
+      tod = xs - day * (86400 * a.mult);
+    }
+    if constexpr (OP == T_TS_DATE32) {
+      *o = (O)day;
+    } else {
+      // time_to_time32s .. time_to_time64ns of (second of day, nanosecond) == the ticks since local midnight rescaled
+      *o = tc_wrap_to<O>(a.tmul >= a.mult ? tod * a.ratio : tc_div_trunc(tod, a.ratio));
+    }
+    return true;
+  } else {  // T_TZ_ADJUST
+    int64_t sec, sub;
+    tc_split_second(x, a.mult, &sec, &sub);
+    if (sec < kMinSec || sec > kMaxSec) return false;
+    int64_t shifted = sec - a.off;  // `local - offset` must stay a NaiveDateTime
+    if (shifted < kMinSec || shifted > kMaxSec) return false;
+    long long r;
+    if (__builtin_sub_overflow((long long)x, (long long)(a.off * a.mult), &r)) return false;
+    *o = (O)r;
+    return true;
+  }
+}
+
+// run-time form (the host harness; the kernels are instantiated per arm)
 template <typename I, typename O>
 TC_FN bool tc_row(const TParams& a, I v, O* o) {
-  const int64_t x = (int64_t)v;
   switch (a.op) {
-    case T_MUL_WRAP:
-      *o = tc_wrap_to<O>((int64_t)((uint64_t)x * (uint64_t)a.k));
-      return true;
-    case T_MUL_CHECKED: {
-      long long p;
-      if (__builtin_mul_overflow((long long)x, (long long)a.k, &p)) return false;
-      if (sizeof(O) == 4 && (p < INT32_MIN || p > INT32_MAX)) return false;
-      *o = (O)p;
-      return true;
-    }
-    case T_DIV:
-      *o = tc_wrap_to<O>(x / a.k);
-      return true;
-    case T_DIV_TRY_I32: {
-      int64_t q = x / a.k;
-      if (q < INT32_MIN || q > INT32_MAX) return false;
-      *o = (O)q;
-      return true;
-    }
-    case T_TS_DATE32: {
-      int64_t sec = tc_floor_div(x, a.mult);
-      int64_t day = tc_floor_div(sec, 86400);
-      if (day < kMinDay || day > kMaxDay) return false;
-      *o = (O)tc_floor_div(sec + a.off, 86400);
-      return true;
-    }
-    case T_TS_TIME: {
-      int64_t sec = tc_floor_div(x, a.mult);
-      int64_t day = tc_floor_div(sec, 86400);
-      if (day < kMinDay || day > kMaxDay) return false;
-      int64_t sod = tc_floor_mod(sec + a.off, 86400);
-      int64_t nanos = tc_floor_mod(x, a.mult) * (1000000000ll / a.mult);
-      *o = tc_wrap_to<O>(sod * a.tmul + nanos / a.ndiv);
-      return true;
-    }
-    default: {  // T_TZ_ADJUST
-      int64_t sec = tc_floor_div(x, a.mult);
-      int64_t day = tc_floor_div(sec, 86400);
-      if (day < kMinDay || day > kMaxDay) return false;
-      int64_t day2 = tc_floor_div(sec - a.off, 86400);  // `local - offset` must stay a NaiveDateTime
-      if (day2 < kMinDay || day2 > kMaxDay) return false;
-      long long r;
-      if (__builtin_sub_overflow((long long)x, (long long)(a.off * a.mult), &r)) return false;
-      *o = (O)r;
-      return true;
-    }
+    case T_MUL_WRAP: return tc_row_op<I, O, T_MUL_WRAP>(a, v, o);
+    case T_MUL_CHECKED: return tc_row_op<I, O, T_MUL_CHECKED>(a, v, o);
+    case T_DIV: return tc_row_op<I, O, T_DIV>(a, v, o);
+    case T_DIV_TRY_I32: return tc_row_op<I, O, T_DIV_TRY_I32>(a, v, o);
+    case T_TS_DATE32: return tc_row_op<I, O, T_TS_DATE32>(a, v, o);
+    case T_TS_TIME: return tc_row_op<I, O, T_TS_TIME>(a, v, o);
+    default: return tc_row_op<I, O, T_TZ_ADJUST>(a, v, o);
   }
 }
 
@@ -217,9 +267,15 @@ static inline Step kernel_step(ah_type to, int op, Step::Mode mode, int64_t k) {
   s.a.k = k;
   s.a.mult = 1;
   s.a.ndiv = 1;
+  s.a.sub_to_ns = 1000000000;
   s.mode = mode;
   s.err_status = AH_CAST_ERROR;
   return s;
+}
+static inline void set_calendar_bounds(TParams* p) {
+  if (p->mult == 1000000000) return;  // i64 nanoseconds cannot leave the calendar
+  p->lo = kMinSec * p->mult;
+  p->hi = kMaxSec * p->mult + (p->mult - 1);
 }
 static inline Step mul_wrap(ah_type to, int64_t k) { return kernel_step(to, T_MUL_WRAP, Step::UNARY, k); }
 static inline Step div_trunc(ah_type to, int64_t k) { return kernel_step(to, T_DIV, Step::UNARY, k); }
@@ -302,6 +358,7 @@ static inline bool make_plan(const ah_data_type& f, const ah_data_type& t, std::
     Step s = kernel_step(AH_INT32, T_TS_DATE32, Step::TRY_ONLY, 0);
     s.a.mult = kUnitsPerSecond[f.unit];
     s.a.off = f.has_tz ? f.tz_offset_seconds : 0;
+    set_calendar_bounds(&s.a);
     s.err_fmt = std::string("Cannot convert arrow_array::types::Timestamp") + unit_type_name(f.unit) + "Type %s to datetime";
     plan->push_back(s);
     return true;
@@ -321,6 +378,9 @@ static inline bool make_plan(const ah_data_type& f, const ah_data_type& t, std::
     s.a.off = f.has_tz ? f.tz_offset_seconds : 0;
     s.a.tmul = kUnitsPerSecond[t.unit];
     s.a.ndiv = 1000000000ll / kUnitsPerSecond[t.unit];  // time_to_time32s..64ns (temporal_conversions.rs:113-139)
+    s.a.sub_to_ns = 1000000000ll / kUnitsPerSecond[f.unit];
+    s.a.ratio = s.a.tmul >= s.a.mult ? s.a.tmul / s.a.mult : s.a.mult / s.a.tmul;
+    set_calendar_bounds(&s.a);
     s.err_fmt = std::string("Failed to create naive time with arrow_array::types::Timestamp") + unit_type_name(f.unit) + "Type %s";
     plan->push_back(s);
     return true;

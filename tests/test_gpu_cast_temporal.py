@@ -89,7 +89,11 @@ def test_sliced_inputs_and_empty(ctx, oracle):
     for off, ln in ((0, 5000), (1, 4999), (63, 1000), (64, 64), (1027, 2049), (4999, 1), (17, 0)):
         hs = h.slice(off, ln)
         for to in (A.Date32, A.Time32Millisecond, A.Timestamp(A.NANOSECOND), A.Timestamp(A.SECOND, "-08:00"), A.Int32):
-            check_exact(K.cast(d.slice(off, ln), to), oracle.cast_with_types(hs, to), f"slice({off},{ln}) -> {to}")
+            got, exp = K.cast(d.slice(off, ln), to), oracle.cast_with_types(hs, to)
+            if ln == 0:  # an empty result owns no buffers on the device (the reference's is Some(empty NullBuffer))
+                assert len(got) == 0 and got.data_type == to
+                continue
+            check_exact(got, exp, f"slice({off},{ln}) -> {to}")
     e = HostArray(A.Date32, np.empty(0, dtype=np.int32))
     for to in (A.Date64, A.Timestamp(A.MICROSECOND), A.Timestamp(A.SECOND, "+01:00")):
         got = K.cast(e.to_device(ctx), to)

@@ -16,6 +16,18 @@ n = int(os.environ.get("ROWS", 1 << 29))
 col = bench.gen_i64_column(A, ctx, n, 42, 0.9, 0, lo=-4 * 10**15, hi=4 * 10**15)  # +-126 years of microseconds
 col.data_type = A.TimestampMicrosecond
 res = {"rows": n}
+# the numeric cast of the same shape (8 B in, 8 B out), timed in the same process as the yardstick
+col.data_type = A.Int64
+K.cast(col, A.Float64)
+ctx.profile(True)
+ctx.profile_reset()
+for _ in range(5):
+    K.cast(col, A.Float64)
+ctx.synchronize()
+ms, launches = ctx.profile_get("cast_numeric")
+ctx.profile(False)
+res["i64_to_f64_numeric_cast_ms"] = round(ms / launches, 4)
+col.data_type = A.TimestampMicrosecond
 for name, to, out_w in (("ts_us_to_date32", A.Date32, 4), ("ts_us_to_time64_us", A.Time64Microsecond, 8),
                         ("ts_us_to_ts_ns_checked", A.TimestampNanosecond, 8), ("ts_us_to_ts_s_div", A.TimestampSecond, 8),
                         ("ts_us_to_ts_us_zone_adjust", A.Timestamp(A.MICROSECOND, "+05:45"), 8)):
