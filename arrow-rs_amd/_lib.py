@@ -35,7 +35,7 @@ AH_UTF8_VIEW, AH_BINARY_VIEW = 17, 18
 
 # logical ids of ah_data_type (the casts whose arithmetic depends on the logical type)
 AH_DT_DATE32, AH_DT_DATE64, AH_DT_TIME32, AH_DT_TIME64, AH_DT_TIMESTAMP, AH_DT_DURATION = 32, 33, 34, 35, 36, 37
-AH_DT_INTERVAL = 38
+AH_DT_INTERVAL, AH_DT_DECIMAL128 = 38, 39
 
 AH_OUT_BORROWED = 1
 

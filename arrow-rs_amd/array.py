@@ -130,7 +130,9 @@ class DataType:
         if self.logical is None:
             d.id = self.physical
             return d
-        d.id, d.unit, tz = self.logical
+        d.id, d.unit, tz = self.logical[:3]
+        if len(self.logical) == 5:
+            d.precision, d.scale = self.logical[3:]
         if tz is not None:
             d.has_tz, d.tz_offset_seconds = 1, parse_fixed_offset(tz)
         return d
@@ -223,6 +225,8 @@ def data_type_from_descriptor(d, like=None):
     if d.id == L.AH_DT_TIMESTAMP:
         tz = like.logical[2] if (like is not None and like.logical and like.logical[0] == L.AH_DT_TIMESTAMP) else None
         return Timestamp(d.unit, tz)
+    if d.id == L.AH_DT_DECIMAL128:
+        return Decimal128(d.precision, d.scale)
     if d.id == L.AH_DT_DURATION:
         return Duration(d.unit)
     if d.id == L.AH_DT_TIME32:
@@ -248,7 +252,8 @@ _DEC128 = np.dtype([("lo", "<u8"), ("hi", "<i8")])
 
 
 def Decimal128(precision, scale):
-    return DataType(f"Decimal128({precision}, {scale})", L.AH_FIXED16, _DEC128)
+    return DataType(f"Decimal128({precision}, {scale})", L.AH_FIXED16, _DEC128,
+                    (L.AH_DT_DECIMAL128, 0, None, precision, scale))
 
 
 _PHYSICAL_DEFAULT = {

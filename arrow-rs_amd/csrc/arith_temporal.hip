@@ -13,6 +13,10 @@
 #include "common.hpp"
 #include "temporal_cast.hpp"
 
+ah_status ah_decimal_arith(ah_context* ctx, ah_arith_op op, const char* op_sym, const ah_array_view* lhs, int32_t l_s,
+                           const ah_data_type* lt, const ah_array_view* rhs, int32_t r_s, const ah_data_type* rt,
+                           ah_array_out* out, ah_data_type* out_type);  // arith_decimal.hip
+
 namespace {
 
 using namespace tc;
@@ -31,6 +35,11 @@ bool is_sub(ah_arith_op op) { return op == AH_SUB || op == AH_SUB_WRAPPING; }
 bool commutative(ah_arith_op op) { return is_add(op) || op == AH_MUL || op == AH_MUL_WRAPPING; }  // numeric.rs:215-222
 
 std::string arith_type_text(const ah_data_type& t) {
+  if (t.id == AH_DT_DECIMAL128) {
+    char b[48];
+    snprintf(b, sizeof b, "Decimal128(%d, %d)", t.precision, t.scale);
+    return b;
+  }
   if (t.id == AH_DT_INTERVAL) {
     static const char* n[] = {"YearMonth", "DayTime", "MonthDayNano"};
     return std::string("Interval(") + ((t.unit >= 0 && t.unit < 3) ? n[t.unit] : "?") + ")";
@@ -99,7 +108,7 @@ extern "C" ah_status ah_arith_with_types(ah_context* ctx, ah_arith_op op, const 
   hipSetDevice(ctx->device);
   if (op < AH_ADD || op > AH_REM) return ah_fail(ctx, AH_INVALID_ARGUMENT, "unknown arithmetic op %d", op);
   const int32_t L = lt->id, R = rt->id;
-  auto logical = [](int32_t id) { return is_temporal(id) || id == AH_DT_INTERVAL; };
+  auto logical = [](int32_t id) { return is_temporal(id) || id == AH_DT_INTERVAL || id == AH_DT_DECIMAL128; };
   if (!logical(L) && !logical(R)) {
     *out_type = *lt;
     return ah_arith_binary(ctx, op, lhs, l_s, rhs, r_s, out);
@@ -107,6 +116,8 @@ extern "C" ah_status ah_arith_with_types(ah_context* ctx, ah_arith_op op, const 
   if ((is_temporal(L) && lhs->type != physical_of(*lt)) || (is_temporal(R) && rhs->type != physical_of(*rt)))
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "operand layout does not match its logical type (%s as %s, %s as %s)",
                    arith_type_text(*lt).c_str(), ah_type_name(lhs->type), arith_type_text(*rt).c_str(), ah_type_name(rhs->type));
+  // (Decimal128(_, _), Decimal128(_, _)) => decimal_op  (numeric.rs:259)
+  if (L == AH_DT_DECIMAL128 && R == AH_DT_DECIMAL128) return ah_decimal_arith(ctx, op, op_text(op), lhs, l_s, lt, rhs, r_s, rt, out, out_type);
   const std::string ls = arith_type_text(*lt), rs = arith_type_text(*rt);
   auto checked_i64 = [&](ah_arith_op checked_op, const ah_data_type& result) {
     *out_type = result;

@@ -276,6 +276,7 @@ fn arith(op: i32, lhs: &Datum, rhs: &Datum) -> Result<Arc<DeviceArray>, ArrowErr
     };
     let result_type = match ot.id {
         sys::AH_DT_DURATION => DataType::Duration(unit(ot.unit)),
+        sys::AH_DT_DECIMAL128 => DataType::Decimal128(ot.precision as u8, ot.scale as i8),  // decimal_op's Hive-rule result type
         // `array.with_timezone_opt(l.timezone())` (numeric.rs:536): the zone text of whichever side is the Timestamp
         sys::AH_DT_TIMESTAMP => match (&l.data_type, &r.data_type) {
             (t @ DataType::Timestamp(_, _), _) | (_, t @ DataType::Timestamp(_, _)) => t.clone(),
@@ -394,6 +395,7 @@ fn logical(t: &DataType) -> Result<Option<sys::ah_data_type>, ArrowError> {
         DataType::Time32(u) => d(sys::AH_DT_TIME32, unit(u), 0, 0),
         DataType::Time64(u) => d(sys::AH_DT_TIME64, unit(u), 0, 0),
         DataType::Duration(u) => d(sys::AH_DT_DURATION, unit(u), 0, 0),
+        DataType::Decimal128(p, s) => sys::ah_data_type { id: sys::AH_DT_DECIMAL128, unit: 0, has_tz: 0, tz_offset_seconds: 0, precision: *p as i32, scale: *s as i32 },
         DataType::Timestamp(u, None) => d(sys::AH_DT_TIMESTAMP, unit(u), 0, 0),
         DataType::Timestamp(u, Some(tz)) => {
             use chrono::{Offset, TimeZone};

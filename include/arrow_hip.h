@@ -138,6 +138,7 @@ enum {
   AH_DT_TIME64 = 35,    /* i64, unit = microsecond | nanosecond */
   AH_DT_TIMESTAMP = 36, /* i64 since the epoch in `unit`, optional fixed-offset zone */
   AH_DT_DURATION = 37,  /* i64 in `unit` */
+  AH_DT_DECIMAL128 = 39, /* i128 (AH_FIXED16) with `precision` / `scale` */
   AH_DT_INTERVAL = 38   /* unit = 0 YearMonth (i32) | 1 DayTime (8 bytes) | 2 MonthDayNano (16 bytes); named only so that
                            ah_arith_with_types can refuse it with the reference's type text: no kernel takes intervals yet */
 };
@@ -268,7 +269,13 @@ AH_API ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op,
  * (the reference calls add_checked / sub_checked whatever the Op): AH_ARITHMETIC_OVERFLOW "Overflow happened on:
  * {l} + {r}".  Everything else is the reference's AH_INVALID_ARGUMENT text ("Invalid timestamp arithmetic operation:
  * Timestamp(s) * Duration(s)", "Invalid arithmetic operation: Int64 + Timestamp(ms)", ...); the Interval arms are
- * AH_NOT_YET_IMPLEMENTED.  Plain numeric pairs are forwarded to ah_arith_binary. */
+ * AH_NOT_YET_IMPLEMENTED.  Plain numeric pairs are forwarded to ah_arith_binary.
+ * Decimal128 (both operands AH_DT_DECIMAL128 over AH_FIXED16 values; `decimal_op` numeric.rs:971-1103): the scales are
+ * aligned with checked powers of ten and every row is `l.mul_checked(l_mul)? op (r.mul_checked(r_mul)?)` over i128;
+ * out_type carries the Hive-rule result type (add / sub: scale max(s1, s2), precision max(s1, s2) + max(p1 - s1,
+ * p2 - s2) + 1; mul: p1 + p2 + 1, s1 + s2 — "Output scale of .. would exceed max scale of 38" otherwise; div: scale
+ * s1 + 4; rem: scale max(s1, s2); precision capped at 38).  Errors are the reference's: "Overflow happened on: {a} *
+ * {b}" for the row that fails first, "Overflow happened on: 10 ^ 39", "Divide by zero error". */
 AH_API ah_status ah_arith_with_types(ah_context* ctx, ah_arith_op op, const ah_array_view* lhs, int32_t lhs_is_scalar,
                                      const ah_data_type* lhs_type, const ah_array_view* rhs, int32_t rhs_is_scalar,
                                      const ah_data_type* rhs_type, ah_array_out* out, ah_data_type* out_type);

@@ -2816,12 +2816,166 @@ const char* op_display(int op) {  // numeric.rs:203-213
   switch (op) { case 0: case 1: return "+"; case 2: case 3: return "-"; case 4: case 5: return "*"; case 6: return "/"; default: return "%"; }
 }
 std::string arith_dt_text(const orc_data_type* t) {
+  if (t->id == 39) {
+    char b[48];
+    snprintf(b, sizeof b, "Decimal128(%d, %d)", t->precision, t->scale);
+    return b;
+  }
   if (t->id == DT_INTERVAL) {
     static const char* n[] = {"YearMonth", "DayTime", "MonthDayNano"};
     return std::string("Interval(") + n[t->unit % 3] + ")";
   }
   return dt_text(t);
 }
+// decimal_op (arrow-arith/src/numeric.rs:971-1103) on Decimal128, with the compiler's native __int128 arithmetic
+// (__builtin_*_overflow = i128::checked_*): restated arm by arm, independent of the device's limb arithmetic.
+typedef __int128 oi128;
+std::string i128_dbg(oi128 v) {
+  if (v == 0) return "0";
+  unsigned __int128 u = v < 0 ? (unsigned __int128)0 - (unsigned __int128)v : (unsigned __int128)v;
+  std::string digits;
+  while (u) { digits.insert(digits.begin(), (char)('0' + (int)(u % 10))); u /= 10; }
+  return (v < 0 ? "-" : "") + digits;
+}
+bool pow10_checked_orc(int64_t exp, oi128* out) {  // 10.pow_checked(exp as u32)
+  oi128 v = 1;
+  if (exp < 0) return false;  // a negative difference as u32 is astronomically large
+  for (int64_t i = 0; i < exp; ++i) if (__builtin_mul_overflow(v, (oi128)10, &v)) return false;
+  *out = v;
+  return true;
+}
+oi128 pow10_wrapping_orc(uint32_t exp) {
+  unsigned __int128 v = 1;
+  for (uint32_t i = 0; i < exp && i < 200; ++i) v *= 10;
+  return (oi128)v;
+}
+int sat8(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
+enum { DT_DECIMAL128 = 39 };
+
+int32_t decimal_op(int op, const orc_view* l, bool l_s, const orc_data_type* lt, const orc_view* r, bool r_s,
+                   const orc_data_type* rt, orc_out* out, orc_data_type* ot) {
+  const int p1 = lt->precision, s1 = lt->scale, p2 = rt->precision, s2 = rt->scale;
+  char lname[48], rname[48];
+  snprintf(lname, sizeof lname, "Decimal128(%d, %d)", p1, s1);
+  snprintf(rname, sizeof rname, "Decimal128(%d, %d)", p2, s2);
+  const bool add = op == 0 || op == 1, sub = op == 2 || op == 3, mul = op == 4 || op == 5;
+  oi128 l_mul = 1, r_mul = 1;
+  int result_precision, result_scale;
+  bool equal_scale_fast_path = false;
+  if (add || sub) {
+    result_scale = std::max(s1, s2);
+    int whole = std::max((int)(int8_t)p1 - s1, (int)(int8_t)p2 - s2);
+    result_precision = std::min(std::min((int)(uint8_t)(int8_t)sat8(result_scale + (int8_t)whole) + 1, 255), 38);
+    if (!pow10_checked_orc(result_scale - s1, &l_mul)) return fail(ORC_ARITHMETIC_OVERFLOW, "Overflow happened on: 10 ^ %d", result_scale - s1);
+    if (!pow10_checked_orc(result_scale - s2, &r_mul)) return fail(ORC_ARITHMETIC_OVERFLOW, "Overflow happened on: 10 ^ %d", result_scale - s2);
+    equal_scale_fast_path = s1 == s2;
+  } else if (mul) {
+    result_precision = std::min(std::min(p1 + std::min(p2 + 1, 255), 255), 38);
+    result_scale = sat8(s1 + s2);
+    if (result_scale > 38)
+      return fail(ORC_INVALID_ARGUMENT, "Output scale of %s %s %s would exceed max scale of 38", lname, op_display(op), rname);
+  } else if (op == 6) {
+    result_scale = std::min(sat8(s1 + 4), 38);
+    int mul_pow = (int8_t)(result_scale - s1 + s2);
+    result_precision = std::min((int)(uint8_t)(int8_t)sat8(mul_pow + (int8_t)p1), 38);
+    if (mul_pow > 0) {
+      if (!pow10_checked_orc(mul_pow, &l_mul)) return fail(ORC_ARITHMETIC_OVERFLOW, "Overflow happened on: 10 ^ %d", mul_pow);
+    } else if (mul_pow < 0) {
+      int e = (uint8_t)(int8_t)(-mul_pow);
+      if (!pow10_checked_orc(e, &r_mul)) return fail(ORC_ARITHMETIC_OVERFLOW, "Overflow happened on: 10 ^ %d", e);
+    }
+  } else {
+    result_scale = std::max(s1, s2);
+    int whole = std::min((int)(int8_t)p1 - s1, (int)(int8_t)p2 - s2);
+    result_precision = std::min((int)(uint8_t)(int8_t)sat8(result_scale + (int8_t)whole), 38);
+    l_mul = pow10_wrapping_orc((uint32_t)(result_scale - s1));
+    r_mul = pow10_wrapping_orc((uint32_t)(result_scale - s2));
+  }
+  // one row: l.mul_checked(l_mul)?.<op>_checked(r.mul_checked(r_mul)?)
+  auto row = [&](oi128 a, oi128 b, oi128* o) -> int32_t {
+    oi128 x = a, y = b;
+    if (!mul && !equal_scale_fast_path) {
+      if (__builtin_mul_overflow(a, l_mul, &x)) return fail(ORC_ARITHMETIC_OVERFLOW, "Overflow happened on: %s * %s", i128_dbg(a).c_str(), i128_dbg(l_mul).c_str());
+      if (__builtin_mul_overflow(b, r_mul, &y)) return fail(ORC_ARITHMETIC_OVERFLOW, "Overflow happened on: %s * %s", i128_dbg(b).c_str(), i128_dbg(r_mul).c_str());
+    }
+    bool ovf;
+    if (add) ovf = __builtin_add_overflow(x, y, o);
+    else if (sub) ovf = __builtin_sub_overflow(x, y, o);
+    else if (mul) ovf = __builtin_mul_overflow(x, y, o);
+    else {
+      if (y == 0) return fail(ORC_DIVIDE_BY_ZERO, "Divide by zero error");
+      const oi128 mn = (oi128)((unsigned __int128)1 << 127);
+      ovf = (x == mn && y == -1);
+      if (!ovf) *o = op == 6 ? x / y : x % y;
+    }
+    if (ovf) return fail(ORC_ARITHMETIC_OVERFLOW, "Overflow happened on: %s %s %s", i128_dbg(x).c_str(), op_display(op), i128_dbg(y).c_str());
+    return ORC_OK;
+  };
+  const oi128* lv = (const oi128*)l->values;
+  const oi128* rv = (const oi128*)r->values;
+  auto load = [](const oi128* p, int64_t i) { oi128 v; memcpy(&v, (const char*)p + i * 16, 16); return v; };  // unaligned-safe
+  int64_t len;
+  uint8_t* nb = nullptr;
+  if (l_s != r_s) {  // try_op! with one scalar side
+    const orc_view* arr = l_s ? r : l;
+    const orc_view* sc = l_s ? l : r;
+    len = arr->length;
+    out->type = ORC_FIXED16;
+    out->length = len;
+    out->values = xalloc((size_t)len * 16);
+    out->values_bytes = len * 16;
+    if (resolve_nulls(sc) != 0) {
+      out->validity = (uint8_t*)xalloc(bitmap_bytes(len));
+      out->validity_bytes = (int64_t)bitmap_bytes(len);
+      out->null_count = len;
+    } else {
+      nb = nulls_clone(arr, len);
+      for (int64_t i = 0; i < len; ++i) {
+        if (nb && !get_bit(nb, i)) continue;
+        oi128 o;
+        int32_t st = l_s ? row(load(lv, 0), load(rv, i), &o) : row(load(lv, i), load(rv, 0), &o);
+        if (st != ORC_OK) { free(nb); orc_release(out); return st; }
+        memcpy((char*)out->values + i * 16, &o, 16);
+      }
+      attach_nulls(out, nb, len);
+    }
+  } else {
+    if (l->length != r->length) return fail(ORC_COMPUTE_ERROR, "Cannot perform a binary operation on arrays of different length");
+    len = l->length;
+    out->type = ORC_FIXED16;
+    out->length = len;
+    out->values = xalloc((size_t)len * 16);
+    out->values_bytes = len * 16;
+    if (resolve_nulls(l) != 0 || resolve_nulls(r) != 0) {  // try_binary: is_nullable()
+      nb = (uint8_t*)xalloc(bitmap_bytes(len));
+      for (int64_t i = 0; i < len; ++i) {
+        bool a = !l->validity || get_bit(l->validity, l->validity_bit_offset + i);
+        bool b = !r->validity || get_bit(r->validity, r->validity_bit_offset + i);
+        if (a && b) set_bit(nb, i);
+      }
+    }
+    for (int64_t i = 0; i < len; ++i) {
+      if (nb && !get_bit(nb, i)) continue;
+      oi128 o;
+      int32_t st = row(load(lv, i), load(rv, i), &o);
+      if (st != ORC_OK) { free(nb); orc_release(out); return st; }
+      memcpy((char*)out->values + i * 16, &o, 16);
+    }
+    attach_nulls(out, nb, len);
+  }
+  // .with_precision_and_scale(result_precision, result_scale)? — after the rows
+  int32_t bad = ORC_OK;
+  if (result_precision == 0) bad = fail(ORC_INVALID_ARGUMENT, "precision cannot be 0, has to be between [1, 38]");
+  else if (result_scale > 38) bad = fail(ORC_INVALID_ARGUMENT, "scale %d is greater than max 38", result_scale);
+  else if (result_scale > 0 && result_scale > result_precision)
+    bad = fail(ORC_INVALID_ARGUMENT, "scale %d is greater than precision %d", result_scale, result_precision);
+  if (bad != ORC_OK) { orc_release(out); return bad; }
+  *ot = *lt;
+  ot->precision = result_precision;
+  ot->scale = result_scale;
+  return ORC_OK;
+}
+
 int32_t arith_temporal(int op, const orc_view* l, bool l_s, const orc_data_type* lt, const orc_view* r, bool r_s,
                        const orc_data_type* rt, orc_out* out, orc_data_type* ot) {
   out_init(out);
@@ -2832,6 +2986,7 @@ int32_t arith_temporal(int op, const orc_view* l, bool l_s, const orc_data_type*
     *ot = *lt;
     return orc_arith(op, l, l_s, r, r_s, out);
   }
+  if (L == DT_DECIMAL128 && R == DT_DECIMAL128) return decimal_op(op, l, l_s, lt, r, r_s, rt, out, ot);
   const std::string ls = arith_dt_text(lt), rs = arith_dt_text(rt);
   auto nyi = [&] { return fail(ORC_NOT_YET_IMPLEMENTED, "%s %s %s: interval arithmetic is not built on the device", ls.c_str(), op_display(op), rs.c_str()); };
   if (L == DT_TIMESTAMP) {

@@ -1149,6 +1149,29 @@ tarith("test_date64_sub_overflow", "2126-2133", 2, arr("Date64", [I64MAX]), arr(
        message=f"Overflow happened on: {I64MAX} - -1", display=f"Arithmetic overflow: Overflow happened on: {I64MAX} - -1")
 
 
+# test_decimal (numeric.rs:1400-1481) and test_decimal256_same_scale_add_sub's Decimal128 analogue: ops 0 add, 2 sub, 4 mul, 6 div, 7 rem
+DA = arr("Decimal128(12, 3)", [15, 0, -577, 334, -78, 3])
+DB = arr("Decimal128(12, 1)", [54, 34, -356, 3, 6, 745])
+for name, op, t, exp in (("add", 0, "Decimal128(15, 3)", [5415, 3400, -36177, 634, 522, 74503]),
+                         ("sub", 2, "Decimal128(15, 3)", [-5385, -3400, 35023, 34, -678, -74497]),
+                         ("mul", 4, "Decimal128(25, 4)", [810, 0, 205412, 1002, -468, 2235]),
+                         ("div", 6, "Decimal128(17, 7)", [27777, 0, 162078, 11133333, -1300000, 402]),
+                         ("rem", 7, "Decimal128(12, 3)", [15, 0, -577, 34, -78, 3])):
+    tarith(f"test_decimal_{name}", "1400-1440", op, DA, DB, arr(t, exp))
+tarith("test_decimal_mul_scale_exceeds", "1442-1452", 4, arr("Decimal128(3, 3)", [1]), arr("Decimal128(37, 37)", [1]),
+       error="InvalidArgumentError", message="Output scale of Decimal128(3, 3) * Decimal128(37, 37) would exceed max scale of 38",
+       display="Invalid argument error: Output scale of Decimal128(3, 3) * Decimal128(37, 37) would exceed max scale of 38")
+tarith("test_decimal_pow_overflow", "1454-1458", 0, arr("Decimal128(3, -2)", [1]), arr("Decimal128(37, 37)", [1]),
+       error="ArithmeticOverflow", message="Overflow happened on: 10 ^ 39", display="Arithmetic overflow: Overflow happened on: 10 ^ 39")
+tarith("test_decimal_scale_mul_overflow", "1460-1467", 0, arr("Decimal128(3, -1)", [10]), arr("Decimal128(37, 37)", [1]),
+       error="ArithmeticOverflow", message="Overflow happened on: 10 * 100000000000000000000000000000000000000",
+       display="Arithmetic overflow: Overflow happened on: 10 * 100000000000000000000000000000000000000")
+tarith("test_decimal_div_by_zero", "1469-1473", 6, arr("Decimal128(3, -1)", [10]), arr("Decimal128(1, 1)", [0]),
+       error="DivideByZero", message="Divide by zero error", display="Divide by zero error")
+tarith("test_decimal_rem_by_zero", "1474-1475", 7, arr("Decimal128(3, -1)", [10]), arr("Decimal128(1, 1)", [0]),
+       error="DivideByZero", message="Divide by zero error", display="Divide by zero error")
+
+
 for name, cases in [("like", like_cases), ("cmp_utf8", cmp_utf8_cases), ("zip", zip_cases), ("sort", sort_cases), ("concat", concat_cases), ("aggregate", agg_cases), ("boolean", bool_cases), ("filter", filter_cases), ("take", take_cases), ("arith", arith_cases), ("cmp", cmp_cases),
                     ("cast", cast_cases), ("rank_shift", rank_cases), ("cast_temporal", tcast_cases), ("arith_temporal", tarith_cases)]:
     with open(os.path.join(HERE, f"{name}.json"), "w") as f:

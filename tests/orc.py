@@ -31,6 +31,9 @@ def lookup_type(name):
     if name.startswith("Timestamp(") and 'Some("' in name:
         unit = ["Second", "Millisecond", "Microsecond", "Nanosecond"].index(name[len("Timestamp("):name.index(",")])
         return A.Timestamp(unit, name[name.index('Some("') + 6:name.rindex('"')])
+    if name.startswith("Decimal128("):
+        p_, s_ = name[len("Decimal128("):-1].split(",")
+        return A.Decimal128(int(p_), int(s_))
     for ctor in ("Time32", "Time64", "Duration"):  # units the reference's tests use to provoke "not supported"
         if name.startswith(ctor + "("):
             return getattr(A, ctor)(["Second", "Millisecond", "Microsecond", "Nanosecond"].index(name[len(ctor) + 1:-1]))

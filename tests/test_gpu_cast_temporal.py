@@ -184,7 +184,7 @@ def test_arith_temporal_golden(ctx, case):
         assert ei.value.message == case["message"]
         assert str(ei.value) == case.get("display", str(ei.value))
         return
-    for op in (case["op"], case["op"] + 1):  # the *_wrapping forms are checked as well
+    for op in ((case["op"], case["op"] + 1) if case["op"] in (0, 2, 4) else (case["op"],)):  # *_wrapping is checked too
         got = ARITH_FN[op](l, r)
         exp = golden_array(case["expected"])
         assert got.data_type == exp.data_type, case["name"]
@@ -246,3 +246,96 @@ def test_arith_temporal_refusals(ctx):
         with pytest.raises(A.array.InvalidArgumentError) as ei:
             fn(one(l), one(r))
         assert ei.value.message == msg
+
+
+# ----------------------------------------------------------- Decimal128 arithmetic
+from test_temporal_cast_cpu import decimal_model, decimal_operands, dec_values  # noqa: E402
+
+
+def test_decimal_arith_matches_the_oracle(ctx, oracle):
+    rng = np.random.default_rng(41)
+    n = 2500
+    for (lt, rt, digits) in (((12, 3), (12, 1), 12), ((20, 0), (20, 0), 18), ((38, 10), (38, 2), 24), ((38, 6), (38, 6), 30),
+                             ((10, -2), (15, 4), 10)):
+        L_, R_ = A.Decimal128(*lt), A.Decimal128(*rt)
+        lv, rv = decimal_operands(rng, n, digits), decimal_operands(rng, n, digits)
+        rv = [v if v != 0 else 7 for v in rv]
+        for ln, rn in ((False, False), (True, True)):
+            hl = HostArray(L_, HostArray.from_pylist(lv, L_).values, (rng.random(n) < 0.8) if ln else None)
+            hr = HostArray(R_, HostArray.from_pylist(rv, R_).values, (rng.random(n) < 0.8) if rn else None)
+            dl, dr = hl.to_device(ctx, bit_offset=3 if ln else 0), hr.to_device(ctx)
+            def same(op, ho_l, ho_r, dv_l, dv_r, tag, **flags):
+                try:
+                    exp = oracle.arith_with_types(op, ho_l, ho_r, **flags)
+                except A.array.ArrowError as e:
+                    with pytest.raises(type(e)) as ei:
+                        ARITH_FN[op](dv_l, dv_r)
+                    assert ei.value.message == e.message, tag
+                    return
+                got = ARITH_FN[op](dv_l, dv_r)
+                assert got.data_type == exp.data_type, tag
+                check_exact(got, exp, tag)
+            for op in range(8):
+                same(op, hl, hr, dl, dr, f"{L_} {op} {R_} nulls={ln}")
+            # one scalar side, valid and null
+            for sc_valid in (True, False):
+                hs = HostArray(R_, hr.values[:1], None if sc_valid else np.array([False]))
+                ds = A.Scalar(hs.to_device(ctx))
+                same(0, hl, hs, dl, ds, f"{L_} + scalar valid={sc_valid}", r_scalar=True)
+                same(4, hs, hl, ds, dl, f"scalar * {L_} valid={sc_valid}", l_scalar=True)
+                same(6, hl, hs, dl, ds, f"{L_} / scalar valid={sc_valid}", r_scalar=True)
+
+
+def test_decimal_arith_errors_name_the_first_failing_row(ctx, oracle):
+    big = 10**37
+    L_, R_ = A.Decimal128(38, 0), A.Decimal128(38, 2)
+    vals = [1, big * 2, -big * 5, 3]
+    hl = HostArray(L_, HostArray.from_pylist(vals, L_).values, np.array([True, False, True, True]))
+    hr = HostArray.from_pylist([5, 5, 5, 5], R_)
+    for op, fn in ((0, K.add), (6, K.div), (7, K.rem)):
+        with pytest.raises(A.array.ArithmeticOverflow) as ei:
+            fn(hl.to_device(ctx), hr.to_device(ctx))
+        with pytest.raises(A.array.ArithmeticOverflow) as eo:
+            oracle.arith_with_types(op, hl, hr)
+        assert ei.value.message == eo.value.message
+    assert eo.value.message == "Overflow happened on: -50000000000000000000000000000000000000 * 100"
+    z = HostArray.from_pylist([1, 0, 2], A.Decimal128(5, 1))
+    with pytest.raises(A.array.DivideByZero) as ei:
+        K.div(HostArray.from_pylist([1, 2, 3], A.Decimal128(5, 1)).to_device(ctx), z.to_device(ctx))
+    assert ei.value.message == "Divide by zero error"
+    with pytest.raises(A.array.InvalidArgumentError) as ei:
+        K.add(z.to_device(ctx), HostArray.from_pylist([1, 2, 3], A.Int64).to_device(ctx))
+    assert ei.value.message == "Invalid arithmetic operation: Decimal128(5, 1) + Int64"
+
+
+def test_decimal_arith_large_vs_exact_python(ctx):
+    """2^22 rows: every row of add / mul / div against exact Python integers (vectorised through object arrays)."""
+    n = 1 << 22
+    rng = np.random.default_rng(43)
+    lt, rt = (20, 4), (18, 2)
+    l = rng.integers(-10**17, 10**17, n, dtype=np.int64)
+    r = rng.integers(-10**15, 10**15, n, dtype=np.int64)
+    r[r == 0] = 1
+
+    def as_dec(v, t):
+        vals = np.zeros(n, dtype=t.np_dtype)
+        vals["lo"] = v.view(np.uint64)
+        vals["hi"] = np.where(v < 0, -1, 0)
+        return HostArray(t, vals).to_device(ctx)
+    dl, dr = as_dec(l, A.Decimal128(*lt)), as_dec(r, A.Decimal128(*rt))
+    lo, ro = l.astype(object), r.astype(object)
+    for fn, exp, et in ((K.add, lo + ro * 100, (21, 4)), (K.sub, lo - ro * 100, (21, 4)), (K.mul, lo * ro, (38, 6)),
+                        (K.rem, None, None), (K.div, None, (26, 8))):
+        got = fn(dl, dr)
+        v = got.values_numpy()
+        gv = v["lo"].astype(object) + (v["hi"].astype(object) << 64)
+        if fn is K.div:
+            num, den = lo * 10**6, ro
+            q = np.abs(num) // np.abs(den)
+            exp = np.where((num < 0) != (den < 0), -q, q)
+        elif fn is K.rem:
+            num, den = lo, ro * 100
+            m = np.abs(num) % np.abs(den)
+            exp, et = np.where(num < 0, -m, m), (20, 4)
+        assert got.data_type == A.Decimal128(*et), (fn.__name__, got.data_type)
+        assert (gv == exp).all(), fn.__name__

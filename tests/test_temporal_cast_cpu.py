@@ -285,8 +285,8 @@ def test_arith_temporal_golden(oracle, case):
         return expect_err(case, lambda: oracle.arith_with_types(case["op"], l, r))
     got = oracle.arith_with_types(case["op"], l, r)
     assert_logical_eq(got, golden_array(case["expected"]), case["name"])
-    # *_wrapping entry points are checked too (timestamp_op / duration_op call add_checked / sub_checked)
-    assert_logical_eq(oracle.arith_with_types(case["op"] + 1, l, r), golden_array(case["expected"]), case["name"] + " wrapping")
+    if case["op"] in (0, 2, 4):  # the *_wrapping entry points are checked too (add_checked / sub_checked / mul_checked)
+        assert_logical_eq(oracle.arith_with_types(case["op"] + 1, l, r), golden_array(case["expected"]), case["name"] + " wrapping")
 
 
 def test_arith_temporal_type_rules_on_the_oracle(oracle):
@@ -322,3 +322,96 @@ def test_arith_temporal_type_rules_on_the_oracle(oracle):
     assert got.to_pylist() == [None, None, None] and got.data_type == A.DurationSecond
     got = oracle.arith_with_types(2, one(A.Date32), HostArray.from_pylist([3], A.Date32), r_scalar=True)
     assert got.to_pylist() == [7 * 86400, None, 27 * 86400]
+
+
+# ----------------------------------------------------------- Decimal128 arithmetic
+I128_MIN, I128_MAX = -(1 << 127), (1 << 127) - 1
+
+
+def test_decimal_limb_arithmetic_header_on_host(tmp_path):
+    """arrow-rs_amd/csrc/decimal_arith.hpp (checked 128-bit multiply and long division on 64-bit limbs — the device
+    runtime has neither) against the compiler's native __int128 arithmetic."""
+    exe = str(tmp_path / "decimal_arith_host_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-o", exe,
+                    os.path.join(ROOT, "tests", "cpp", "decimal_arith_host_test.cpp")], check=True)
+    r = subprocess.run([exe, "300000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr
+    assert int(r.stdout.split()[1]) > 2_000_000
+
+
+def decimal_model(op, l, lt, r, rt):
+    """decimal_op (numeric.rs:971-1103) in exact Python integers: (result precision, scale, value) or an error tuple."""
+    (p1, s1), (p2, s2) = lt, rt
+    chk = lambda v: I128_MIN <= v <= I128_MAX  # noqa: E731
+    if op in (0, 1, 2, 3):
+        rs = max(s1, s2)
+        prec = min(rs + max(p1 - s1, p2 - s2) + 1, 38)
+        lm, rm = 10 ** (rs - s1), 10 ** (rs - s2)
+        if s1 != s2:
+            if not chk(l * lm):
+                return ("ArithmeticOverflow", f"Overflow happened on: {l} * {lm}")
+            if not chk(r * rm):
+                return ("ArithmeticOverflow", f"Overflow happened on: {r} * {rm}")
+            l, r = l * lm, r * rm
+        v = l + r if op < 2 else l - r
+        sym = "+" if op < 2 else "-"
+    elif op in (4, 5):
+        prec, rs, v, sym = min(p1 + p2 + 1, 38), s1 + s2, l * r, "*"
+    elif op == 6:
+        rs = min(s1 + 4, 38)
+        mp = rs - s1 + s2
+        prec = min(mp + p1, 38)
+        lm, rm = (10 ** mp, 1) if mp > 0 else (1, 10 ** -mp)
+        if not chk(l * lm):
+            return ("ArithmeticOverflow", f"Overflow happened on: {l} * {lm}")
+        if not chk(r * rm):
+            return ("ArithmeticOverflow", f"Overflow happened on: {r} * {rm}")
+        l, r, sym = l * lm, r * rm, "/"
+        if r == 0:
+            return ("DivideByZero", "Divide by zero error")
+        v = abs(l) // abs(r) * (1 if (l < 0) == (r < 0) else -1)
+    else:
+        rs = max(s1, s2)
+        prec = min(rs + min(p1 - s1, p2 - s2), 38)
+        lm, rm = 10 ** (rs - s1), 10 ** (rs - s2)
+        if not chk(l * lm):
+            return ("ArithmeticOverflow", f"Overflow happened on: {l} * {lm}")
+        if not chk(r * rm):
+            return ("ArithmeticOverflow", f"Overflow happened on: {r} * {rm}")
+        l, r, sym = l * lm, r * rm, "%"
+        if r == 0:
+            return ("DivideByZero", "Divide by zero error")
+        v = abs(l) % abs(r) * (1 if l >= 0 else -1)
+    if not chk(v):
+        return ("ArithmeticOverflow", f"Overflow happened on: {l} {sym} {r}")
+    return (prec, rs, v)
+
+
+def decimal_operands(rng, n, digits):
+    return [int(rng.integers(-9, 10)) * 10 ** int(rng.integers(0, digits)) + int(rng.integers(-10**9, 10**9)) for _ in range(n)]
+
+
+def dec_values(h):
+    return [int(lo) | (int(hi) << 64) for lo, hi in zip(h.values["lo"], h.values["hi"])]
+
+
+def test_oracle_decimal_vs_exact_python_integers(oracle):
+    rng = np.random.default_rng(31)
+    for (lt, rt, digits) in (((12, 3), (12, 1), 12), ((20, 0), (20, 0), 20), ((38, 10), (38, 2), 30), ((38, 0), (38, 0), 38),
+                             ((10, -2), (15, 4), 10), ((38, 20), (38, 18), 36)):
+        L_, R_ = A.Decimal128(*lt), A.Decimal128(*rt)
+        for op in range(8):
+            for _ in range(40):
+                l, r = decimal_operands(rng, 1, digits)[0], decimal_operands(rng, 1, digits)[0]
+                if rng.random() < 0.1:
+                    r = 0
+                exp = decimal_model(op, l, lt, r, rt)
+                hl, hr = HostArray.from_pylist([l], L_), HostArray.from_pylist([r], R_)
+                if isinstance(exp[0], str):
+                    with pytest.raises(getattr(A.array, exp[0])) as ei:
+                        oracle.arith_with_types(op, hl, hr)
+                    assert ei.value.message == exp[1], (op, l, r, lt, rt)
+                else:
+                    got = oracle.arith_with_types(op, hl, hr)
+                    assert got.data_type == A.Decimal128(exp[0], exp[1]), (op, lt, rt, got.data_type)
+                    assert dec_values(got) == [exp[2]], (op, l, r, lt, rt)
