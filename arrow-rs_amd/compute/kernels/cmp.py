@@ -3,7 +3,7 @@ Floats compare in IEEE totalOrder; equality is bitwise (arrow-array/src/arithmet
 import ctypes as C
 
 from ... import _lib as L
-from ...array import Array, Boolean
+from ...array import Array, Boolean, InvalidArgumentError
 
 EQ, NEQ, LT, LT_EQ, GT, GT_EQ, DISTINCT, NOT_DISTINCT = range(8)
 
@@ -14,6 +14,10 @@ def _compare(op, lhs, rhs):
     ctx = l.ctx
     out = L.ArrayOut()
     lv, rv = l.view(), r.view()
+    if l.data_type.physical == L.AH_FIXED16 and l.data_type != r.data_type:
+        # compare_op (cmp.rs:243-249): the logical types must agree — Decimal128(12, 3) vs Decimal128(12, 1) is refused
+        sym = ["==", "!=", "<", "<=", ">", ">=", "IS DISTINCT FROM", "IS NOT DISTINCT FROM"][op]
+        raise InvalidArgumentError(f"Invalid comparison operation: {l.data_type} {sym} {r.data_type}")
     ctx.check(ctx.lib.ah_compare(ctx.handle, op, C.byref(lv), int(l_s), C.byref(rv), int(r_s),
                                  C.byref(out)))
     return Array._from_out(ctx, out, Boolean)

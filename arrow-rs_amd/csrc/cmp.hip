@@ -254,7 +254,9 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
                    ah_type_name(lhs->type), cmp_sym(op), ah_type_name(rhs->type));
   const ah_type t = lhs->type;
   const bool is_bytes = t == AH_UTF8 || t == AH_LARGE_UTF8;
-  if (!(t == AH_BOOL || ah_type_is_integer(t) || ah_type_is_float(t) || is_bytes))
+  // AH_FIXED16 compares as i128 (Decimal128; the host checks that precision and scale agree, compare_op cmp.rs:243-249).
+  // IntervalMonthDayNano shares the layout but orders by (months, days, nanoseconds): its host must not come here.
+  if (!(t == AH_BOOL || ah_type_is_integer(t) || ah_type_is_float(t) || is_bytes || t == AH_FIXED16))
     return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "comparison not supported for type %s", ah_type_name(t));
   if ((l_s && lhs->length < 1) || (r_s && rhs->length < 1))
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "scalar datum must have length 1");
@@ -356,6 +358,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
       case AH_UINT32: launch_cmp_t<uint32_t>(ctx, a, aligned); break;
       case AH_UINT64: launch_cmp_t<uint64_t>(ctx, a, aligned); break;
       case AH_FLOAT32: launch_cmp_t<float>(ctx, a, aligned); break;
+      case AH_FIXED16: launch_cmp_t<__int128>(ctx, a, aligned); break;
       default: launch_cmp_t<double>(ctx, a, aligned); break;
     }
     return AH_OK;

@@ -293,7 +293,9 @@ enum {
 };
 /* arrow_ord::cmp::{eq,neq,lt,lt_eq,gt,gt_eq,distinct,not_distinct}
  * (arrow-ord/src/cmp.rs:79-202).  Result type AH_BOOL; floats compare in IEEE
- * totalOrder (arrow-array/src/arithmetic.rs:400-410). */
+ * totalOrder (arrow-array/src/arithmetic.rs:400-410).  AH_FIXED16 operands compare as i128 (Decimal128: the host
+ * checks that precision and scale agree, as compare_op does); IntervalMonthDayNano shares the layout but not the
+ * order and must not be passed. */
 AH_API ah_status ah_compare(ah_context* ctx, ah_cmp_op op,
                             const ah_array_view* lhs, int32_t lhs_is_scalar,
                             const ah_array_view* rhs, int32_t rhs_is_scalar,

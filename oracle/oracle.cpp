@@ -1022,6 +1022,23 @@ uint8_t* cmp_values(int op, const orc_view* l, bool l_s, const orc_view* r, bool
   }
 }
 
+// ArrayOrd for &[i128] (Decimal128; arrow-ord/src/cmp.rs:713-738): is_eq / is_lt of the native, loaded bytewise
+// (host test buffers need not be 16-byte aligned)
+uint8_t* cmp_values_i128(int op, const orc_view* l, bool l_s, const orc_view* r, bool r_s, int64_t len) {
+  auto at = [](const orc_view* v, bool sc, int64_t i) { __int128 x; memcpy(&x, (const char*)v->values + (sc ? 0 : i) * 16, 16); return x; };
+  auto L = [&](int64_t i) { return at(l, l_s, i); };
+  auto R = [&](int64_t i) { return at(r, r_s, i); };
+  auto mk = [&](bool neg, auto f) { return collect_bool(len, neg, f); };
+  switch (op) {
+    case C_EQ: case C_NOT_DISTINCT: return mk(false, [&](int64_t i) { return L(i) == R(i); });
+    case C_NEQ: case C_DISTINCT: return mk(true, [&](int64_t i) { return L(i) == R(i); });
+    case C_LT: return mk(false, [&](int64_t i) { return L(i) < R(i); });
+    case C_LT_EQ: return mk(true, [&](int64_t i) { return R(i) < L(i); });
+    case C_GT: return mk(false, [&](int64_t i) { return R(i) < L(i); });
+    default: return mk(true, [&](int64_t i) { return L(i) < R(i); });
+  }
+}
+
 uint8_t* cmp_values_bool(int op, const orc_view* l, bool l_s, const orc_view* r, bool r_s, int64_t len) {
   const uint8_t* lb = (const uint8_t*)l->values;
   const uint8_t* rb = (const uint8_t*)r->values;
@@ -1917,11 +1934,12 @@ int32_t orc_compare(int32_t op, const orc_view* l, int32_t l_s, const orc_view* 
       case ORC_FLOAT32: return cmp_values<float>(op, l, l_s, r, r_s, len);
       case ORC_FLOAT64: return cmp_values<double>(op, l, l_s, r, r_s, len);
       case ORC_UTF8: case ORC_LARGE_UTF8: return cmp_values_bytes(op, l, l_s, r, r_s, len);
+      case ORC_FIXED16: return cmp_values_i128(op, l, l_s, r, r_s, len);
     }
     return nullptr;
   };
   const bool is_bytes = l->type == ORC_UTF8 || l->type == ORC_LARGE_UTF8;
-  if ((type_width(l->type) < 0 && !is_bytes) || l->type == ORC_FIXED16 || l->type == ORC_FIXED32 || l->type == ORC_FLOAT16)
+  if ((type_width(l->type) < 0 && !is_bytes) || l->type == ORC_FIXED32 || l->type == ORC_FLOAT16)
     return fail(ORC_NOT_YET_IMPLEMENTED, "comparison not supported for type %s", type_name(l->type));
   size_t bytes = bitmap_bytes(len);
   // nulls filtered by null_count > 0 (:345-346)

@@ -339,3 +339,29 @@ def test_decimal_arith_large_vs_exact_python(ctx):
             exp, et = np.where(num < 0, -m, m), (20, 4)
         assert got.data_type == A.Decimal128(*et), (fn.__name__, got.data_type)
         assert (gv == exp).all(), fn.__name__
+
+
+def test_decimal_compare_matches_the_oracle(ctx, oracle):
+    """cmp on Decimal128 (i128 order): every operator, nulls on either side, scalars, words that straddle 64 rows."""
+    rng = np.random.default_rng(47)
+    t = A.Decimal128(38, 4)
+    n = 5003
+    lv = decimal_operands(rng, n, 36)
+    rv = decimal_operands(rng, n, 36)
+    rv[:600] = lv[:600]
+    lv[600:608] = [0, -1, 1, (1 << 127) - 1, -(1 << 127), 1 << 64, -(1 << 64), (1 << 64) - 1]
+    rv[600:608] = [0, 1, -1, -(1 << 127), (1 << 127) - 1, (1 << 64) - 1, -(1 << 64) + 1, 1 << 64]
+    CMP_FN = [K.eq, K.neq, K.lt, K.lt_eq, K.gt, K.gt_eq, K.distinct, K.not_distinct]
+    for ln, rn in ((False, False), (True, False), (True, True)):
+        hl = HostArray(t, HostArray.from_pylist(lv, t).values, (rng.random(n) < 0.8) if ln else None)
+        hr = HostArray(t, HostArray.from_pylist(rv, t).values, (rng.random(n) < 0.8) if rn else None)
+        dl, dr = hl.to_device(ctx, bit_offset=5 if ln else 0), hr.to_device(ctx)
+        for op, fn in enumerate(CMP_FN):
+            check_exact(fn(dl, dr), oracle.compare(op, hl, hr), f"decimal cmp {op} nulls={ln},{rn}")
+        hs = HostArray(t, hr.values[:1])
+        for op, fn in enumerate(CMP_FN):
+            check_exact(fn(dl, A.Scalar(hs.to_device(ctx))), oracle.compare(op, hl, hs, r_scalar=True), f"decimal cmp scalar {op}")
+            check_exact(fn(dl.slice(3, 4000), dr.slice(3, 4000)), oracle.compare(op, hl.slice(3, 4000), hr.slice(3, 4000)), f"sliced {op}")
+    with pytest.raises(A.array.InvalidArgumentError) as ei:
+        K.lt(dl, HostArray.from_pylist(rv, A.Decimal128(38, 2)).to_device(ctx))
+    assert ei.value.message == "Invalid comparison operation: Decimal128(38, 4) < Decimal128(38, 2)"

@@ -415,3 +415,16 @@ def test_oracle_decimal_vs_exact_python_integers(oracle):
                     got = oracle.arith_with_types(op, hl, hr)
                     assert got.data_type == A.Decimal128(exp[0], exp[1]), (op, lt, rt, got.data_type)
                     assert dec_values(got) == [exp[2]], (op, l, r, lt, rt)
+
+
+def test_oracle_decimal_compare_vs_python(oracle):
+    rng = np.random.default_rng(37)
+    t = A.Decimal128(38, 4)
+    l = decimal_operands(rng, 400, 36) + [0, -1, 1, I128_MAX, I128_MIN, 1 << 64, -(1 << 64), (1 << 64) - 1]
+    r = decimal_operands(rng, 400, 36) + [0, 1, -1, I128_MIN, I128_MAX, (1 << 64) - 1, -(1 << 64) + 1, 1 << 64]
+    r[:50] = l[:50]
+    hl, hr = HostArray.from_pylist(l, t), HostArray.from_pylist(r, t)
+    import operator
+    for op, f in enumerate((operator.eq, operator.ne, operator.lt, operator.le, operator.gt, operator.ge, operator.ne, operator.eq)):
+        got = oracle.compare(op, hl, hr)
+        assert got.to_pylist() == [f(a, b) for a, b in zip(l, r)], op
