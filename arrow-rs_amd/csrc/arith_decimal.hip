@@ -208,3 +208,160 @@ ah_status ah_decimal_arith(ah_context* ctx, ah_arith_op op, const char* op_sym, 
   }
   return AH_OK;
 }
+
+// ------------------------------------------------------------------ Decimal128 -> Decimal128 cast
+// cast_decimal_to_decimal_same_type (arrow-cast/src/cast/decimal.rs:448-489).  One launch, 16 B in / 16 B out per row;
+// the three array-level shapes of apply_decimal_cast (:351-377): `unary` when every input fits (all slots, nulls
+// cloned), `unary_opt` in safe mode (failures become nulls, a null buffer is always attached), `try_unary` otherwise
+// (nulls cloned, the first failing valid row is the error).
+namespace {
+
+struct DCastArgs {
+  const Raw16* in;
+  Raw16* out;
+  BitView in_valid;
+  int64_t len;
+  unsigned long long* out_valid;
+  unsigned long long* block_valid;
+  unsigned long long* first_err;
+  int all_slots, fail_is_null;
+  CParams p;
+};
+
+__global__ void __launch_bounds__(256) dcast_kernel(DCastArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long nvalid = 0, err = ~0ull;
+  for (int64_t base = (int64_t)blockIdx.x * 512; base < a.len; base += (int64_t)gridDim.x * 512) {
+    const int64_t wbase = base + wave * 128;
+    Raw16 v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      int64_t i = wbase + k * 64 + lane;
+      v[k] = i < a.len ? a.in[i] : Raw16{0, 0};
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int64_t i0 = wbase + k * 64;
+      if (i0 >= a.len) break;
+      const int64_t i = i0 + lane;
+      const uint64_t iv = bv_fetch64(a.in_valid, i0, a.len);
+      const bool valid = (iv >> lane) & 1;
+      i128 o = 0;
+      int stage = 0;
+      bool ok = true;
+      if (valid || (a.all_slots && i < a.len)) ok = dcast_row(a.p, to_i128(v[k]), &o, &stage);
+      if (!ok) {
+        o = 0;
+        if (!a.fail_is_null) err = (unsigned long long)i < err ? (unsigned long long)i : err;
+      }
+      if (i < a.len) a.out[i] = from_i128(o);
+      if (a.out_valid) {
+        const uint64_t w = a.fail_is_null ? (iv & __ballot(ok)) : iv;
+        if (lane == 0) {
+          a.out_valid[i0 >> 6] = w;
+          nvalid += __popcll(w);
+        }
+      }
+    }
+  }
+  if (!a.fail_is_null) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long other = __shfl_xor(err, o, 64);
+      err = other < err ? other : err;
+    }
+    if (lane == 0 && err != ~0ull) atomicMin(a.first_err, err);
+  }
+  if (a.out_valid) {
+    __shared__ unsigned long long s[4];
+    if (lane == 0) s[wave] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) a.block_valid[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+  }
+}
+
+__global__ void __launch_bounds__(256) dcast_sum_kernel(const unsigned long long* in, int64_t n, unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) acc += in[i];
+  acc = wave_reduce_add64(acc);
+  __shared__ unsigned long long s[4];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = s[0] + s[1] + s[2] + s[3];
+}
+
+}  // namespace
+
+// called by ah_cast_with_types (cast_temporal.hip) when both types are AH_DT_DECIMAL128
+ah_status ah_decimal_cast(ah_context* ctx, const ah_array_view* values, const ah_data_type* from, const ah_data_type* to,
+                          int32_t safe, ah_array_out* out) {
+  ah_out_init(out);
+  if (values->type != AH_FIXED16) return ah_fail(ctx, AH_INVALID_ARGUMENT, "Decimal128 values are 16-byte (AH_FIXED16)");
+  CPlan plan = make_decimal_cast_plan(*from, *to);
+  if (plan.status != AH_OK) return ah_fail(ctx, plan.status, "%s", plan.message.c_str());
+  const int64_t len = values->length;
+  out->type = AH_FIXED16;
+  out->length = len;
+  const bool unary = plan.p.mode == C_CLONE || plan.p.infallible;
+  const bool fail_is_null = !unary && safe;
+  const bool want_valid = fail_is_null || values->validity != nullptr;
+  if (len == 0) {
+    if (plan.post_status != AH_OK) return ah_fail(ctx, plan.post_status, "%s", plan.post_message.c_str());
+    return AH_OK;
+  }
+  const size_t vbytes = (size_t)len * 16, bbytes = ah_bitmap_bytes(len);
+  void* ov = nullptr;
+  void* ob = nullptr;
+  unsigned long long* aux = nullptr;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(len, 512), 256 * 16));
+  AH_TRY(ah_out_alloc(ctx, vbytes, &ov));
+  auto release = [&] {
+    ah_out_free(ctx, ov, vbytes);
+    ah_out_free(ctx, ob, bbytes);
+    ah_out_init(out);
+  };
+  ah_status st = AH_OK;
+  if (want_valid) st = ah_out_alloc(ctx, bbytes, &ob);
+  if (st == AH_OK) st = ah_pool_alloc(ctx, (size_t)(grid + 4) * 8, (void**)&aux);
+  if (st != AH_OK) return release(), st;
+  hipMemsetAsync(aux, 0xFF, 8, ctx->stream);
+  DCastArgs a{};
+  a.in = (const Raw16*)values->values;
+  a.out = (Raw16*)ov;
+  a.in_valid = values->validity ? make_bitview(values->validity, values->validity_bit_offset) : BitView{nullptr, 0};
+  a.len = len;
+  a.out_valid = (unsigned long long*)ob;
+  a.block_valid = aux + 2;
+  a.first_err = aux;
+  a.all_slots = unary;
+  a.fail_is_null = (fail_is_null || unary) ? 1 : 0;
+  a.p = plan.p;
+  {
+    ah_prof_scope ps(ctx, "cast_decimal");
+    dcast_kernel<<<grid, 256, 0, ctx->stream>>>(a);
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && want_valid) dcast_sum_kernel<<<1, 256, 0, ctx->stream>>>(a.block_valid, grid, aux + 1);
+  if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, aux, 16, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  ah_pool_free(ctx, aux);
+  if (e != hipSuccess) return release(), ah_fail(ctx, AH_HIP_ERROR, "decimal cast kernel failed: %s", hipGetErrorString(e));
+  if (!a.fail_is_null && ctx->pinned[0] != ~0ull) {
+    const int64_t pos = (int64_t)ctx->pinned[0];
+    release();
+    i128 x = 0;
+    AH_TRY(fetch_i128(ctx, values->values, pos, &x));
+    std::string msg;
+    ah_status es = dcast_row_error(plan.p, *to, x, &msg);
+    return ah_fail(ctx, es, "%s", msg.c_str());
+  }
+  if (plan.post_status != AH_OK) return release(), ah_fail(ctx, plan.post_status, "%s", plan.post_message.c_str());
+  out->values = ov;
+  out->values_bytes = (int64_t)vbytes;
+  if (want_valid) {
+    out->validity = (uint8_t*)ob;
+    out->validity_bytes = (int64_t)bbytes;
+    out->null_count = len - (int64_t)ctx->pinned[1];
+  }
+  return AH_OK;
+}

@@ -278,4 +278,142 @@ static inline ah_status row_error(const DParams& p, int fail, i128 l, i128 r, i1
   }
 }
 
+
+// ------------------------------------------------------------------ Decimal128 -> Decimal128 casts
+// cast_decimal_to_decimal_same_type (arrow-cast/src/cast/decimal.rs:448-489) with make_upscaler (:161-198),
+// make_downscaler (:210-267) and apply_decimal_cast (:351-377).
+enum CMode : int { C_CLONE = 0, C_UP = 1, C_DOWN = 2, C_ZEROS = 3 };
+struct CParams {
+  int mode;
+  int infallible;  // the `unary` path: every input fits, no precision test
+  i128 k;          // 10^delta: multiplier (C_UP) or divisor (C_DOWN)
+  i128 half;       // C_DOWN: k / 2
+  i128 max_v;      // 10^output_precision - 1 (is_valid_decimal_precision)
+};
+
+// one row; false = the value cannot be represented (safe: null; unsafe: the first such row is the error).
+// *stage: 1 = the rescale itself overflowed ("Overflowing on"), 2 = the precision test failed ("too large / too small")
+DA_FN bool dcast_row(const CParams& p, i128 x, i128* out, int* stage) {
+  i128 v = x;
+  if (p.mode == C_UP) {
+    if (p.infallible) {
+      *out = (i128)((u128)x * (u128)p.k);  // mul_wrapping
+      return true;
+    }
+    if (!da_mul_checked(x, p.k, &v)) {
+      *stage = 1;
+      return false;
+    }
+  } else if (p.mode == C_DOWN) {
+    i128 d, r;
+    da_divrem(x, p.k, &d, &r);  // k >= 10: div_wrapping / mod_wrapping cannot overflow
+    if (x >= 0 ? r >= p.half : r <= -p.half) d += (x >= 0 ? 1 : -1);  // round half away from zero
+    v = d;
+    if (p.infallible) {
+      *out = v;
+      return true;
+    }
+  } else if (p.mode == C_ZEROS) {
+    *out = 0;
+    return true;
+  }
+  if (v > p.max_v || v < -p.max_v) {
+    *stage = 2;
+    return false;
+  }
+  *out = v;
+  return true;
+}
+
+struct CPlan {
+  CParams p;
+  ah_status status;  // raised before any row (upscale beyond the table)
+  std::string message;
+  ah_status post_status;  // with_precision_and_scale(output)?
+  std::string post_message;
+};
+
+static inline CPlan make_decimal_cast_plan(const ah_data_type& from, const ah_data_type& to) {
+  CPlan c{};
+  c.status = c.post_status = AH_OK;
+  const int ip = from.precision, is = from.scale, op = to.precision, os = to.scale;
+  i128 maxv = 0;
+  pow10_checked(op >= 0 && op <= 38 ? op : 0, &maxv);
+  c.p.max_v = maxv - 1;  // MAX_DECIMAL128_FOR_EACH_PRECISION[op]
+  c.p.k = 1;
+  if (is == os && ip <= op) {
+    c.p.mode = C_CLONE;
+  } else if (is <= os) {
+    const int delta = (int8_t)(os - is);
+    if (delta < 0 || delta > 38 || !pow10_checked(delta, &c.p.k)) {  // MAX_FOR_EACH_PRECISION.get(delta) is None
+      c.status = AH_CAST_ERROR;
+      c.message = "Cannot cast to Decimal128(" + std::to_string(op) + ", " + std::to_string(os) + "). Value overflows for output scale";
+      return c;
+    }
+    c.p.mode = C_UP;
+    c.p.infallible = ((int8_t)ip + delta) <= (int8_t)op;
+  } else {
+    const int delta = (int8_t)(is - os);
+    if (delta < 0 || delta > 38 || !pow10_checked(delta, &c.p.k)) {
+      c.p.mode = C_ZEROS;  // every value rounds to zero
+      c.p.infallible = 1;
+    } else {
+      c.p.mode = C_DOWN;
+      c.p.half = c.p.k / 2;
+      c.p.infallible = ((int8_t)ip - delta) < (int8_t)op;
+    }
+  }
+  if (op == 0) {
+    c.post_status = AH_INVALID_ARGUMENT;
+    c.post_message = "precision cannot be 0, has to be between [1, 38]";
+  } else if (op > kMaxPrecision) {
+    c.post_status = AH_INVALID_ARGUMENT;
+    c.post_message = "precision " + std::to_string(op) + " is greater than max 38";
+  } else if (os > kMaxScale) {
+    c.post_status = AH_INVALID_ARGUMENT;
+    c.post_message = "scale " + std::to_string(os) + " is greater than max 38";
+  } else if (os > 0 && os > op) {
+    c.post_status = AH_INVALID_ARGUMENT;
+    c.post_message = "scale " + std::to_string(os) + " is greater than precision " + std::to_string(op);
+  }
+  return c;
+}
+
+// format_decimal_str_internal (arrow-data/src/decimal.rs:1137-1167)
+static inline std::string format_decimal_str(const std::string& value_str, size_t precision, int scale, bool safe_decimal) {
+  const bool neg = !value_str.empty() && value_str[0] == '-';
+  const std::string sign = neg ? "-" : "", rest = neg ? value_str.substr(1) : value_str;
+  const size_t bound = safe_decimal ? (precision < rest.size() ? precision : rest.size()) + sign.size() : value_str.size();
+  const std::string v = value_str.substr(0, bound);
+  if (scale == 0) return v;
+  if (scale < 0) return v + std::string((size_t)(-scale), '0');
+  if (rest.size() > (size_t)scale) return v.substr(0, v.size() - (size_t)scale) + "." + v.substr(v.size() - (size_t)scale);
+  return sign + "0." + std::string((size_t)scale - rest.size(), '0') + rest;
+}
+
+// the unsafe-mode error of the first failing row (decimal.rs:330-349; validate_decimal128_precision, arrow-data/src/decimal.rs:1024-1061)
+static inline ah_status dcast_row_error(const CParams& p, const ah_data_type& to, i128 x, std::string* msg) {
+  i128 v = 0;
+  int stage = 0;
+  dcast_row(p, x, &v, &stage);
+  if (stage == 1) {
+    *msg = "Cannot cast to Decimal128(" + std::to_string(to.precision) + ", " + std::to_string(to.scale) + "). Overflowing on " + i128_text(x);
+    return AH_CAST_ERROR;
+  }
+  // recompute the rescaled value that failed the precision test
+  i128 r = x;
+  if (p.mode == C_UP) da_mul_checked(x, p.k, &r);
+  else if (p.mode == C_DOWN) {
+    i128 d, rem;
+    da_divrem(x, p.k, &d, &rem);
+    if (x >= 0 ? rem >= p.half : rem <= -p.half) d += (x >= 0 ? 1 : -1);
+    r = d;
+  }
+  const bool large = r > p.max_v;
+  *msg = format_decimal_str(i128_text(r), (size_t)to.precision, to.scale, false) + (large ? " is too large" : " is too small") +
+         " to store in a Decimal128 of precision " + std::to_string(to.precision) + (large ? ". Max is " : ". Min is ") +
+         format_decimal_str(i128_text(large ? p.max_v : -p.max_v), (size_t)to.precision, to.scale, true);
+  return AH_INVALID_ARGUMENT;
+}
+
 }  // namespace da

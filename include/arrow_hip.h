@@ -361,7 +361,12 @@ AH_API int32_t ah_can_cast_types(ah_type from, ah_type to); /* cast/mod.rs:115 s
  * division into days since 1970-01-01, valid for NaiveDate::MIN..=MAX = -262143-01-01..=+262142-12-31, local to
  * the source zone) and fail in BOTH modes with "Cannot convert {type} {x} to datetime" / "Failed to create naive
  * time with {type} {x}" (try_unary, :633-659, :615-631); a zone-less Timestamp cast to a zoned one keeps the wall
- * clock (adjust_timestamp_to_timezone :2629; unsafe failure: "Cannot cast timezone to different timezone"). */
+ * clock (adjust_timestamp_to_timezone :2629; unsafe failure: "Cannot cast timezone to different timezone").
+ * Two AH_DT_DECIMAL128 descriptors (values AH_FIXED16) select cast_decimal_to_decimal_same_type (cast/decimal.rs:448-489):
+ * rescale by 10^(scale difference), rounding half away from zero when the scale shrinks; a value that does not fit
+ * the output precision is null in safe mode and, otherwise, AH_INVALID_ARGUMENT "{v} is too large to store in a
+ * Decimal128 of precision {p}. Max is {max}" / AH_CAST_ERROR "Cannot cast to Decimal128(p, s). Overflowing on {x}".
+ * Casts between decimals and other types are AH_NOT_YET_IMPLEMENTED. */
 AH_API ah_status ah_cast_with_types(ah_context* ctx, const ah_array_view* values, const ah_data_type* from,
                                     const ah_data_type* to, int32_t safe, ah_array_out* out);
 AH_API int32_t ah_can_cast_data_types(const ah_data_type* from, const ah_data_type* to); /* cast/mod.rs:115 */

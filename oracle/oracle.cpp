@@ -2994,6 +2994,109 @@ int32_t decimal_op(int op, const orc_view* l, bool l_s, const orc_data_type* lt,
   return ORC_OK;
 }
 
+// cast_decimal_to_decimal_same_type (arrow-cast/src/cast/decimal.rs:448-489) for Decimal128, native __int128
+std::string fmt_decimal(const std::string& value_str, size_t precision, int scale, bool safe_decimal) {  // decimal.rs:1137-1167
+  bool neg = !value_str.empty() && value_str[0] == '-';
+  std::string sign = neg ? "-" : "", rest = neg ? value_str.substr(1) : value_str;
+  size_t bound = safe_decimal ? std::min(precision, rest.size()) + sign.size() : value_str.size();
+  std::string v = value_str.substr(0, bound);
+  if (scale == 0) return v;
+  if (scale < 0) return v + std::string((size_t)-scale, '0');
+  if (rest.size() > (size_t)scale) return v.substr(0, v.size() - scale) + "." + v.substr(v.size() - scale);
+  return sign + "0." + std::string((size_t)scale - rest.size(), '0') + rest;
+}
+int32_t cast_decimal128(const orc_view* in, const orc_data_type* from, const orc_data_type* to, bool safe, orc_out* out) {
+  const int ip = from->precision, is = from->scale, op = to->precision, os = to->scale;
+  const int64_t len = in->length;
+  auto at = [&](int64_t i) { oi128 x; memcpy(&x, (const char*)in->values + i * 16, 16); return x; };
+  oi128 max_v = 0;
+  { oi128 t = 1; for (int i = 0; i < std::min(std::max(op, 0), 38); ++i) t *= 10; max_v = t - 1; }
+  auto valid_precision = [&](oi128 v) { return op <= 38 && v <= max_v && v >= -max_v; };
+  auto start = [&] {
+    out->type = ORC_FIXED16;
+    out->length = len;
+    out->values = xalloc((size_t)len * 16);
+    out->values_bytes = len * 16;
+  };
+  auto put = [&](int64_t i, oi128 v) { memcpy((char*)out->values + i * 16, &v, 16); };
+  std::function<bool(oi128, oi128*)> f_fallible;
+  bool infallible = false, clone = false, zeros = false;
+  oi128 k = 1;
+  if (is == os && ip <= op) clone = true;
+  else if (is <= os) {
+    int delta = (int8_t)(os - is);
+    if (delta < 0 || delta > 38)
+      return fail(ORC_CAST_ERROR, "Cannot cast to Decimal128(%d, %d). Value overflows for output scale", op, os);
+    for (int i = 0; i < delta; ++i) k *= 10;
+    f_fallible = [k](oi128 x, oi128* o) { return !__builtin_mul_overflow(x, k, o); };
+    infallible = ((int8_t)ip + delta) <= (int8_t)op;
+  } else {
+    int delta = (int8_t)(is - os);
+    if (delta < 0 || delta > 38) zeros = true;
+    else {
+      for (int i = 0; i < delta; ++i) k *= 10;
+      const oi128 half = k / 2;
+      f_fallible = [k, half](oi128 x, oi128* o) {
+        oi128 d = x / k, r = x % k;
+        if (x >= 0 && r >= half) d += 1;
+        else if (x < 0 && r <= -half) d -= 1;
+        *o = d;
+        return true;
+      };
+      infallible = ((int8_t)ip - delta) < (int8_t)op;
+    }
+  }
+  start();
+  uint8_t* nb = nullptr;
+  if (clone || zeros || infallible) {  // array.clone() / zeros with the nulls / array.unary(f_infallible): every slot
+    for (int64_t i = 0; i < len; ++i) {
+      oi128 x = at(i), o = x;
+      if (zeros) o = 0;
+      else if (!clone) {
+        if (is <= os) o = (oi128)((unsigned __int128)x * (unsigned __int128)k);  // mul_wrapping
+        else f_fallible(x, &o);
+      }
+      put(i, o);
+    }
+    nb = nulls_clone(in, len);
+  } else if (safe) {  // unary_opt(f(x).filter(is_valid_decimal_precision))
+    nb = (uint8_t*)xalloc(bitmap_bytes(len));
+    for (int64_t i = 0; i < len; ++i) {
+      if (in->validity && !get_bit(in->validity, in->validity_bit_offset + i)) continue;
+      oi128 o;
+      if (f_fallible(at(i), &o) && valid_precision(o)) { put(i, o); set_bit(nb, i); }
+    }
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(len);
+    out->null_count = len - count_set_bits(nb, 0, len);
+    nb = nullptr;
+  } else {  // try_unary
+    for (int64_t i = 0; i < len; ++i) {
+      if (in->validity && !get_bit(in->validity, in->validity_bit_offset + i)) continue;
+      oi128 x = at(i), o;
+      int32_t st = ORC_OK;
+      if (!f_fallible(x, &o)) st = fail(ORC_CAST_ERROR, "Cannot cast to Decimal128(%d, %d). Overflowing on %s", op, os, i128_dbg(x).c_str());
+      else if (o > max_v)
+        st = fail(ORC_INVALID_ARGUMENT, "%s is too large to store in a Decimal128 of precision %d. Max is %s",
+                  fmt_decimal(i128_dbg(o), op, os, false).c_str(), op, fmt_decimal(i128_dbg(max_v), op, os, true).c_str());
+      else if (o < -max_v)
+        st = fail(ORC_INVALID_ARGUMENT, "%s is too small to store in a Decimal128 of precision %d. Min is %s",
+                  fmt_decimal(i128_dbg(o), op, os, false).c_str(), op, fmt_decimal(i128_dbg(-max_v), op, os, true).c_str());
+      if (st != ORC_OK) { orc_release(out); return st; }
+      put(i, o);
+    }
+    nb = nulls_clone(in, len);
+  }
+  if (nb) attach_nulls(out, nb, len);
+  int32_t bad = ORC_OK;  // with_precision_and_scale(output_precision, output_scale)?
+  if (op == 0) bad = fail(ORC_INVALID_ARGUMENT, "precision cannot be 0, has to be between [1, 38]");
+  else if (op > 38) bad = fail(ORC_INVALID_ARGUMENT, "precision %d is greater than max 38", op);
+  else if (os > 38) bad = fail(ORC_INVALID_ARGUMENT, "scale %d is greater than max 38", os);
+  else if (os > 0 && os > op) bad = fail(ORC_INVALID_ARGUMENT, "scale %d is greater than precision %d", os, op);
+  if (bad != ORC_OK) { orc_release(out); return bad; }
+  return ORC_OK;
+}
+
 int32_t arith_temporal(int op, const orc_view* l, bool l_s, const orc_data_type* lt, const orc_view* r, bool r_s,
                        const orc_data_type* rt, orc_out* out, orc_data_type* ot) {
   out_init(out);
@@ -3083,6 +3186,10 @@ extern "C" {
 
 int32_t orc_cast_with_types(const orc_view* in, const orc_data_type* from, const orc_data_type* to, int32_t safe,
                             orc_out* out) {
+  if (from->id == 39 && to->id == 39) {
+    out_init(out);
+    return cast_decimal128(in, from, to, safe != 0, out);
+  }
   return cast_temporal(in, from, to, safe != 0, out);
 }
 

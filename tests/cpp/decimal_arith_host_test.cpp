@@ -82,6 +82,47 @@ int main(int argc, char** argv) {
     i128 d = random_value();
     if (d != 0) check(DParams{D_DIV + (int)(rng() & 1), 0, 1, 1}, d * (i128)(rng() % 1000) + (i128)(rng() % 7), d);
   }
+  // dcast_row against a direct statement with native `/`, `%` and __builtin_mul_overflow
+  for (int mode = C_UP; mode <= C_DOWN; ++mode)
+    for (int delta = 0; delta <= 38; ++delta)
+      for (int prec = 1; prec <= 38; prec += 3)
+        for (int inf = 0; inf <= 1; ++inf) {
+          CParams c{};
+          c.mode = mode;
+          c.infallible = inf;
+          pow10_checked(delta, &c.k);
+          if (mode == C_DOWN && delta == 0) continue;
+          c.half = c.k / 2;
+          i128 mx;
+          pow10_checked(prec, &mx);
+          c.max_v = mx - 1;
+          for (size_t e = 0; e < edges.size() + 40; ++e) {
+            i128 x = e < edges.size() ? edges[e] : random_value();
+            i128 got = 0, exp = 0;
+            int stage = 0;
+            bool ok = dcast_row(c, x, &got, &stage), eok = true;
+            if (mode == C_UP) {
+              if (inf) exp = (i128)((u128)x * (u128)c.k);
+              else eok = !__builtin_mul_overflow(x, c.k, &exp);
+            } else {
+              i128 d = x / c.k, r = x % c.k;
+              if (x >= 0 && r >= c.half) d += 1;
+              if (x < 0 && r <= -c.half) d -= 1;
+              exp = d;
+            }
+            if (eok && !inf && (exp > c.max_v || exp < -c.max_v)) eok = false;
+            ++cases;
+            if (ok != eok || (ok && got != exp)) {
+              if (fails++ < 10) fprintf(stderr, "cast mismatch mode=%d delta=%d prec=%d inf=%d x=%s\n", mode, delta, prec, inf, i128_text(x).c_str());
+            }
+          }
+        }
+  if (format_decimal_str("12345", 5, 2, true) != "123.45" || format_decimal_str("-5", 5, 3, true) != "-0.005" ||
+      format_decimal_str("-12345678", 5, 2, true) != "-123.45" || format_decimal_str("12", 5, -2, false) != "1200" ||
+      format_decimal_str("-1234", 4, 0, false) != "-1234") {
+    fprintf(stderr, "format_decimal_str wrong\n");
+    return 1;
+  }
   // i128_text against snprintf on the halves
   if (i128_text(MINV) != "-170141183460469231731687303715884105728" || i128_text(MAXV) != "170141183460469231731687303715884105727" ||
       i128_text(0) != "0" || i128_text(-42) != "-42") {

@@ -365,3 +365,38 @@ def test_decimal_compare_matches_the_oracle(ctx, oracle):
     with pytest.raises(A.array.InvalidArgumentError) as ei:
         K.lt(dl, HostArray.from_pylist(rv, A.Decimal128(38, 2)).to_device(ctx))
     assert ei.value.message == "Invalid comparison operation: Decimal128(38, 4) < Decimal128(38, 2)"
+
+
+def test_decimal_to_decimal_cast_matches_the_oracle(ctx, oracle):
+    """cast_decimal_to_decimal_same_type: widening, narrowing with half-away-from-zero rounding, precision overflow to
+    null (safe) or the reference's error (unsafe), the infallible `unary` shapes, clone, and scale drops past 38 digits."""
+    rng = np.random.default_rng(59)
+    shapes = [((10, 2), (12, 4)), ((10, 2), (11, 4)), ((20, 4), (10, 1)), ((20, 4), (18, 1)), ((38, 10), (38, 20)), ((38, 0), (38, 0)),
+              ((10, 3), (5, 3)), ((38, 30), (10, 0)), ((12, 5), (12, 5)), ((9, 2), (20, 2)), ((38, 38), (38, -2)), ((5, -3), (38, 38))]
+    n = 2100
+    for ft, tt in shapes:
+        F, T = A.Decimal128(*ft), A.Decimal128(*tt)
+        digits = min(ft[0], 37)
+        vals = [int(rng.integers(-9, 10)) * 10 ** int(rng.integers(0, digits)) + int(rng.integers(-10**6, 10**6)) for _ in range(n)]
+        vals[:10] = [0, 5, -5, 15, -15, 49, 50, -50, 10 ** digits - 1, -(10 ** digits - 1)]
+        benign = [int(v) for v in rng.integers(-9999, 9999, n)]
+        for data in (vals, benign):
+            for with_nulls in (False, True):
+                h = HostArray(F, HostArray.from_pylist(data, F).values, (rng.random(n) < 0.85) if with_nulls else None)
+                d = h.to_device(ctx, bit_offset=3 if with_nulls else 0)
+                for safe in (True, False):
+                    tag = f"{F} -> {T} safe={safe} nulls={with_nulls}"
+                    try:
+                        exp = oracle.cast_with_types(h, T, safe=safe)
+                    except A.array.ArrowError as e:
+                        with pytest.raises(type(e)) as ei:
+                            K.cast_with_options(d, T, K.CastOptions(safe=safe))
+                        assert ei.value.message == e.message, tag
+                        continue
+                    got = K.cast_with_options(d, T, K.CastOptions(safe=safe))
+                    assert got.data_type == T
+                    check_exact(got, exp, tag)
+    with pytest.raises(A.array.InvalidArgumentError) as ei:
+        K.cast_with_options(HostArray.from_pylist([1, 123456, 7], A.Decimal128(10, 3)).to_device(ctx), A.Decimal128(5, 3), K.CastOptions(safe=False))
+    assert ei.value.message == "123.456 is too large to store in a Decimal128 of precision 5. Max is 99.999"
+    assert K.can_cast_types(A.Decimal128(10, 3), A.Decimal128(5, 0)) and not K.can_cast_types(A.Decimal128(10, 3), A.Int64)

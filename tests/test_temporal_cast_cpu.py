@@ -428,3 +428,68 @@ def test_oracle_decimal_compare_vs_python(oracle):
     for op, f in enumerate((operator.eq, operator.ne, operator.lt, operator.le, operator.gt, operator.ge, operator.ne, operator.eq)):
         got = oracle.compare(op, hl, hr)
         assert got.to_pylist() == [f(a, b) for a, b in zip(l, r)], op
+
+
+# ----------------------------------------------------------- Decimal128 -> Decimal128 cast
+def decimal_cast_model(x, ft, tt, safe):
+    """cast_decimal_to_decimal_same_type (cast/decimal.rs:448-489) in exact Python integers: value, None (null) or an error tuple."""
+    (ip, is_), (op, os) = ft, tt
+    mx = 10 ** op - 1
+    if is_ == os and ip <= op:
+        return x
+    if is_ <= os:
+        k = 10 ** (os - is_)
+        v = x * k
+        if ip + (os - is_) <= op:
+            return ((v + (1 << 127)) % (1 << 128)) - (1 << 127)
+        if not (I128_MIN <= v <= I128_MAX):
+            return None if safe else ("CastError", f"Cannot cast to Decimal128({op}, {os}). Overflowing on {x}")
+    else:
+        k = 10 ** (is_ - os)
+        d, r = abs(x) // k, abs(x) % k
+        if r >= k // 2:
+            d += 1
+        v = d if x >= 0 else -d
+        if ip - (is_ - os) < op:
+            return v
+    if -mx <= v <= mx:
+        return v
+    return None if safe else ("InvalidArgumentError", "too large" if v > mx else "too small")
+
+
+def test_oracle_decimal_cast_vs_exact_python_integers(oracle):
+    rng = np.random.default_rng(53)
+    shapes = [((10, 2), (12, 4)), ((10, 2), (11, 4)), ((20, 4), (10, 1)), ((20, 4), (18, 1)), ((38, 10), (38, 20)), ((38, 0), (38, 0)),
+              ((10, 3), (5, 3)), ((38, 30), (10, 0)), ((12, 5), (12, 5)), ((9, 2), (20, 2))]
+    for ft, tt in shapes:
+        F, T = A.Decimal128(*ft), A.Decimal128(*tt)
+        vals = [int(rng.integers(-9, 10)) * 10 ** int(rng.integers(0, ft[0])) + int(rng.integers(-10**6, 10**6)) for _ in range(300)]
+        vals += [0, 5, -5, 15, -15, 49, 50, -50, 10 ** ft[0] - 1, -(10 ** ft[0] - 1)]
+        valid = rng.random(len(vals)) < 0.85
+        h = HostArray(F, HostArray.from_pylist(vals, F).values, valid)
+        exp = [decimal_cast_model(v, ft, tt, True) if ok else None for v, ok in zip(vals, valid)]
+        got = oracle.cast_with_types(h, T, safe=True)
+        gv = dec_values(got)
+        gvalid = got.valid if got.valid is not None else np.ones(len(vals), dtype=bool)
+        assert [v if ok else None for v, ok in zip(gv, gvalid)] == exp, (ft, tt)
+        # unsafe: the first failing valid row is the error
+        errs = [decimal_cast_model(v, ft, tt, False) for v, ok in zip(vals, valid) if ok]
+        first = next((e for e in errs if isinstance(e, tuple)), None)
+        if first is None:
+            unsafe = oracle.cast_with_types(h, T, safe=False)
+            uv = unsafe.valid if unsafe.valid is not None else np.ones(len(vals), dtype=bool)
+            assert [v if ok else None for v, ok in zip(dec_values(unsafe), uv)] == exp, (ft, tt)
+        else:
+            with pytest.raises(getattr(A.array, first[0])) as ei:
+                oracle.cast_with_types(h, T, safe=False)
+            assert first[1] in ei.value.message
+    # the reference's own texts (decimal.rs:330-349, arrow-data/src/decimal.rs:1036-1057)
+    with pytest.raises(A.array.InvalidArgumentError) as ei:
+        oracle.cast_with_types(HostArray.from_pylist([123456], A.Decimal128(10, 3)), A.Decimal128(5, 3), safe=False)
+    assert ei.value.message == "123.456 is too large to store in a Decimal128 of precision 5. Max is 99.999"
+    with pytest.raises(A.array.InvalidArgumentError) as ei:
+        oracle.cast_with_types(HostArray.from_pylist([-123456], A.Decimal128(10, 3)), A.Decimal128(5, 3), safe=False)
+    assert ei.value.message == "-123.456 is too small to store in a Decimal128 of precision 5. Min is -99.999"
+    with pytest.raises(A.array.CastError) as ei:
+        oracle.cast_with_types(HostArray.from_pylist([10**37], A.Decimal128(38, 0)), A.Decimal128(38, 5), safe=False)
+    assert ei.value.message == f"Cannot cast to Decimal128(38, 5). Overflowing on {10**37}"
