@@ -365,3 +365,149 @@ ah_status ah_decimal_cast(ah_context* ctx, const ah_array_view* values, const ah
   }
   return AH_OK;
 }
+
+// ------------------------------------------------------------------ integer -> Decimal128 cast
+// cast_integer_to_decimal (arrow-cast/src/cast/mod.rs:366-443): 1..8 B in, 16 B out per row; safe = unary_opt (a null
+// buffer is always attached), unsafe = try_unary; a scale factor that does not exist in the source type = `unary` zeros.
+namespace {
+
+template <typename I>
+__global__ void __launch_bounds__(256) icast_kernel(const I* in, Raw16* out, BitView in_valid, int64_t len,
+                                                    unsigned long long* out_valid, unsigned long long* block_valid,
+                                                    unsigned long long* first_err, int all_slots, int fail_is_null, IParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long nvalid = 0, err = ~0ull;
+  for (int64_t base = (int64_t)blockIdx.x * 1024; base < len; base += (int64_t)gridDim.x * 1024) {
+    const int64_t wbase = base + wave * 256;
+    I v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int64_t i = wbase + k * 64 + lane;
+      v[k] = i < len ? in[i] : I{};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i0 = wbase + k * 64;
+      if (i0 >= len) break;
+      const int64_t i = i0 + lane;
+      const uint64_t iv = bv_fetch64(in_valid, i0, len);
+      const bool valid = (iv >> lane) & 1;
+      i128 o = 0;
+      int stage = 0;
+      bool ok = true;
+      if (valid || (all_slots && i < len)) ok = icast_row(p, (i128)v[k], &o, &stage);
+      if (!ok) {
+        o = 0;
+        if (!fail_is_null) err = (unsigned long long)i < err ? (unsigned long long)i : err;
+      }
+      if (i < len) out[i] = from_i128(o);
+      if (out_valid) {
+        const uint64_t w = fail_is_null ? (iv & __ballot(ok)) : iv;
+        if (lane == 0) {
+          out_valid[i0 >> 6] = w;
+          nvalid += __popcll(w);
+        }
+      }
+    }
+  }
+  if (!fail_is_null) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long other = __shfl_xor(err, o, 64);
+      err = other < err ? other : err;
+    }
+    if (lane == 0 && err != ~0ull) atomicMin(first_err, err);
+  }
+  if (out_valid) {
+    __shared__ unsigned long long s[4];
+    if (lane == 0) s[wave] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) block_valid[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+  }
+}
+
+}  // namespace
+
+// called by ah_cast_with_types when `from` is a plain integer type and `to` is AH_DT_DECIMAL128
+ah_status ah_int_to_decimal_cast(ah_context* ctx, const ah_array_view* values, const ah_data_type* to, int32_t safe,
+                                 ah_array_out* out) {
+  ah_out_init(out);
+  const ah_type t = values->type;
+  if (!ah_type_is_integer(t)) return ah_fail(ctx, AH_INVALID_ARGUMENT, "integer -> Decimal128 needs integer values");
+  const int w = ah_type_width(t);
+  const bool sg = ah_type_is_signed(t);
+  const u128 src_max = sg ? (((u128)1 << (8 * w - 1)) - 1) : (((u128)1 << (8 * w)) - 1);
+  IPlan plan = make_int_to_decimal_plan(src_max, *to);
+  if (plan.status != AH_OK) return ah_fail(ctx, plan.status, "%s", plan.message.c_str());
+  const int64_t len = values->length;
+  out->type = AH_FIXED16;
+  out->length = len;
+  const bool unary = plan.p.mode == I_ZEROS;
+  const bool fail_is_null = !unary && safe;
+  const bool want_valid = fail_is_null || values->validity != nullptr;
+  if (len == 0) {
+    if (plan.post_status != AH_OK) return ah_fail(ctx, plan.post_status, "%s", plan.post_message.c_str());
+    return AH_OK;
+  }
+  const size_t vbytes = (size_t)len * 16, bbytes = ah_bitmap_bytes(len);
+  void* ov = nullptr;
+  void* ob = nullptr;
+  unsigned long long* aux = nullptr;
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(len, 1024), 256 * 16));
+  AH_TRY(ah_out_alloc(ctx, vbytes, &ov));
+  auto release = [&] {
+    ah_out_free(ctx, ov, vbytes);
+    ah_out_free(ctx, ob, bbytes);
+    ah_out_init(out);
+  };
+  ah_status st = AH_OK;
+  if (want_valid) st = ah_out_alloc(ctx, bbytes, &ob);
+  if (st == AH_OK) st = ah_pool_alloc(ctx, (size_t)(grid + 4) * 8, (void**)&aux);
+  if (st != AH_OK) return release(), st;
+  hipMemsetAsync(aux, 0xFF, 8, ctx->stream);
+  const BitView inv = values->validity ? make_bitview(values->validity, values->validity_bit_offset) : BitView{nullptr, 0};
+  const int fin = (fail_is_null || unary) ? 1 : 0;
+#define AH_ICAST(T) icast_kernel<T><<<grid, 256, 0, ctx->stream>>>((const T*)values->values, (Raw16*)ov, inv, len, (unsigned long long*)ob, aux + 2, aux, unary ? 1 : 0, fin, plan.p)
+  {
+    ah_prof_scope ps(ctx, "cast_int_decimal");
+    switch (t) {
+      case AH_INT8: AH_ICAST(int8_t); break;
+      case AH_INT16: AH_ICAST(int16_t); break;
+      case AH_INT32: AH_ICAST(int32_t); break;
+      case AH_INT64: AH_ICAST(int64_t); break;
+      case AH_UINT8: AH_ICAST(uint8_t); break;
+      case AH_UINT16: AH_ICAST(uint16_t); break;
+      case AH_UINT32: AH_ICAST(uint32_t); break;
+      default: AH_ICAST(uint64_t); break;
+    }
+  }
+#undef AH_ICAST
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && want_valid) dcast_sum_kernel<<<1, 256, 0, ctx->stream>>>(aux + 2, grid, aux + 1);
+  if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, aux, 16, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  ah_pool_free(ctx, aux);
+  if (e != hipSuccess) return release(), ah_fail(ctx, AH_HIP_ERROR, "integer -> decimal cast kernel failed: %s", hipGetErrorString(e));
+  if (!fin && ctx->pinned[0] != ~0ull) {
+    const int64_t pos = (int64_t)ctx->pinned[0];
+    release();
+    uint64_t raw = 0;
+    AH_HIP(ctx, hipMemcpyAsync(&raw, (const char*)values->values + pos * w, w, hipMemcpyDeviceToHost, ctx->stream));
+    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    i128 x;
+    if (sg) x = w == 1 ? (i128)(int8_t)raw : w == 2 ? (i128)(int16_t)raw : w == 4 ? (i128)(int32_t)raw : (i128)(int64_t)raw;
+    else x = (i128)(u128)raw;
+    std::string msg;
+    ah_status es = icast_row_error(plan.p, *to, x, &msg);
+    return ah_fail(ctx, es, "%s", msg.c_str());
+  }
+  if (plan.post_status != AH_OK) return release(), ah_fail(ctx, plan.post_status, "%s", plan.post_message.c_str());
+  out->values = ov;
+  out->values_bytes = (int64_t)vbytes;
+  if (want_valid) {
+    out->validity = (uint8_t*)ob;
+    out->validity_bytes = (int64_t)bbytes;
+    out->null_count = len - (int64_t)ctx->pinned[1];
+  }
+  return AH_OK;
+}

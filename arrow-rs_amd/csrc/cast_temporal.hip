@@ -274,11 +274,16 @@ ah_status not_supported(ah_context* ctx, const ah_data_type& f, const ah_data_ty
 ah_status ah_decimal_cast(ah_context* ctx, const ah_array_view* values, const ah_data_type* from, const ah_data_type* to,
                           int32_t safe, ah_array_out* out);  // arith_decimal.hip
 
+ah_status ah_int_to_decimal_cast(ah_context* ctx, const ah_array_view* values, const ah_data_type* to, int32_t safe,
+                                 ah_array_out* out);  // arith_decimal.hip
+static bool plain_integer(int32_t id) { return id >= AH_INT8 && id <= AH_UINT64; }
+
 static bool cast_not_built(int32_t id) { return id == AH_DT_DECIMAL128 || id == AH_DT_INTERVAL; }
 
 extern "C" int32_t ah_can_cast_data_types(const ah_data_type* from, const ah_data_type* to) {
   if (!from || !to) return 0;
   if (from->id == AH_DT_DECIMAL128 && to->id == AH_DT_DECIMAL128) return 1;  // cast/mod.rs:178-181
+  if (plain_integer(from->id) && to->id == AH_DT_DECIMAL128) return 1;          // :183-192
   if (cast_not_built(from->id) || cast_not_built(to->id)) return 0;
   if (!is_temporal(from->id) && !is_temporal(to->id)) return ah_can_cast_types((ah_type)from->id, (ah_type)to->id);
   std::vector<Step> plan;
@@ -291,6 +296,10 @@ extern "C" ah_status ah_cast_with_types(ah_context* ctx, const ah_array_view* va
   ah_out_init(out);
   hipSetDevice(ctx->device);
   if (from->id == AH_DT_DECIMAL128 && to->id == AH_DT_DECIMAL128) return ah_decimal_cast(ctx, values, from, to, safe, out);
+  if (plain_integer(from->id) && to->id == AH_DT_DECIMAL128) {
+    if (values->type != (ah_type)from->id) return ah_fail(ctx, AH_INVALID_ARGUMENT, "values do not have the layout `from` names");
+    return ah_int_to_decimal_cast(ctx, values, to, safe, out);
+  }
   if (cast_not_built(from->id) || cast_not_built(to->id))
     return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "decimal <-> non-decimal and interval casts are not built on the device");
   if (!is_temporal(from->id) && !is_temporal(to->id)) {

@@ -416,4 +416,103 @@ static inline ah_status dcast_row_error(const CParams& p, const ah_data_type& to
   return AH_INVALID_ARGUMENT;
 }
 
+
+// ------------------------------------------------------------------ integer -> Decimal128 casts
+// cast_integer_to_decimal (arrow-cast/src/cast/mod.rs:366-443).  scale >= 0: `v as i128` * 10^scale, checked, then the
+// precision test; scale < 0: v / 10^|scale| IN THE SOURCE TYPE (truncating; a factor that does not fit the source type
+// makes every result zero), then the precision test.
+enum IMode : int { I_MUL = 0, I_DIV = 1, I_ZEROS = 2 };
+struct IParams {
+  int mode;
+  i128 k;      // 10^|scale|
+  i128 max_v;  // 10^precision - 1
+};
+// stage: 1 = the multiply overflowed, 2 = the precision test failed
+DA_FN bool icast_row(const IParams& p, i128 x, i128* out, int* stage) {
+  i128 v;
+  if (p.mode == I_MUL) {
+    if (!da_mul_checked(x, p.k, &v)) {
+      *stage = 1;
+      return false;
+    }
+  } else if (p.mode == I_DIV) {
+    i128 r;
+    da_divrem(x, p.k, &v, &r);
+  } else {
+    *out = 0;
+    return true;
+  }
+  if (v > p.max_v || v < -p.max_v) {
+    *stage = 2;
+    return false;
+  }
+  *out = v;
+  return true;
+}
+
+struct IPlan {
+  IParams p;
+  ah_status status;
+  std::string message;
+  ah_status post_status;
+  std::string post_message;
+};
+// `src_max` = the source type's MAX (decides whether 10^|scale| exists in the source type)
+static inline IPlan make_int_to_decimal_plan(u128 src_max, const ah_data_type& to) {
+  IPlan c{};
+  c.status = c.post_status = AH_OK;
+  const int op = to.precision, os = to.scale;
+  i128 maxv = 0;
+  pow10_checked(op >= 0 && op <= 38 ? op : 0, &maxv);
+  c.p.max_v = maxv - 1;
+  c.p.k = 1;
+  const int a = os < 0 ? -os : os;
+  if (os < 0) {
+    i128 k = 0;
+    if (!pow10_checked(a, &k) || (u128)k > src_max) c.p.mode = I_ZEROS;  // T::Native 10.pow_checked(..) is None
+    else {
+      c.p.mode = I_DIV;
+      c.p.k = k;
+    }
+  } else {
+    if (!pow10_checked(a, &c.p.k)) {
+      c.status = AH_CAST_ERROR;
+      c.message = "Cannot cast to \"Decimal128\"(" + std::to_string(op) + ", " + std::to_string(os) + "). The scale causes overflow.";
+      return c;
+    }
+    c.p.mode = I_MUL;
+  }
+  if (op == 0) {
+    c.post_status = AH_INVALID_ARGUMENT;
+    c.post_message = "precision cannot be 0, has to be between [1, 38]";
+  } else if (op > kMaxPrecision) {
+    c.post_status = AH_INVALID_ARGUMENT;
+    c.post_message = "precision " + std::to_string(op) + " is greater than max 38";
+  } else if (os > kMaxScale) {
+    c.post_status = AH_INVALID_ARGUMENT;
+    c.post_message = "scale " + std::to_string(os) + " is greater than max 38";
+  } else if (os > 0 && os > op) {
+    c.post_status = AH_INVALID_ARGUMENT;
+    c.post_message = "scale " + std::to_string(os) + " is greater than precision " + std::to_string(op);
+  }
+  return c;
+}
+static inline ah_status icast_row_error(const IParams& p, const ah_data_type& to, i128 x, std::string* msg) {
+  i128 v = 0;
+  int stage = 0;
+  icast_row(p, x, &v, &stage);
+  if (stage == 1) {  // `.and_then(|v| v.mul_checked(scale_factor))?` keeps mul_checked's own error
+    *msg = "Overflow happened on: " + i128_text(x) + " * " + i128_text(p.k);
+    return AH_ARITHMETIC_OVERFLOW;
+  }
+  i128 r = x, rem;
+  if (p.mode == I_MUL) da_mul_checked(x, p.k, &r);
+  else da_divrem(x, p.k, &r, &rem);
+  const bool large = r > p.max_v;
+  *msg = format_decimal_str(i128_text(r), (size_t)to.precision, to.scale, false) + (large ? " is too large" : " is too small") +
+         " to store in a Decimal128 of precision " + std::to_string(to.precision) + (large ? ". Max is " : ". Min is ") +
+         format_decimal_str(i128_text(large ? p.max_v : -p.max_v), (size_t)to.precision, to.scale, true);
+  return AH_INVALID_ARGUMENT;
+}
+
 }  // namespace da

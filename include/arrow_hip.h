@@ -366,7 +366,9 @@ AH_API int32_t ah_can_cast_types(ah_type from, ah_type to); /* cast/mod.rs:115 s
  * rescale by 10^(scale difference), rounding half away from zero when the scale shrinks; a value that does not fit
  * the output precision is null in safe mode and, otherwise, AH_INVALID_ARGUMENT "{v} is too large to store in a
  * Decimal128 of precision {p}. Max is {max}" / AH_CAST_ERROR "Cannot cast to Decimal128(p, s). Overflowing on {x}".
- * Casts between decimals and other types are AH_NOT_YET_IMPLEMENTED. */
+ * A plain integer `from` with an AH_DT_DECIMAL128 `to` is cast_integer_to_decimal (cast/mod.rs:366-443): v * 10^scale
+ * checked (AH_ARITHMETIC_OVERFLOW "Overflow happened on: {v} * {10^s}"), or v / 10^|scale| in the source type for a
+ * negative scale, then the precision test.  The other decimal casts are AH_NOT_YET_IMPLEMENTED. */
 AH_API ah_status ah_cast_with_types(ah_context* ctx, const ah_array_view* values, const ah_data_type* from,
                                     const ah_data_type* to, int32_t safe, ah_array_out* out);
 AH_API int32_t ah_can_cast_data_types(const ah_data_type* from, const ah_data_type* to); /* cast/mod.rs:115 */

@@ -3097,6 +3097,86 @@ int32_t cast_decimal128(const orc_view* in, const orc_data_type* from, const orc
   return ORC_OK;
 }
 
+// cast_integer_to_decimal (arrow-cast/src/cast/mod.rs:366-443) to Decimal128
+template <typename T>
+int32_t cast_int_to_decimal128(const orc_view* in, const orc_data_type* to, bool safe, orc_out* out) {
+  const int precision = to->precision, scale = to->scale;
+  const int64_t len = in->length;
+  const T* iv = (const T*)in->values;
+  oi128 max_v = 0;
+  { oi128 t = 1; for (int i = 0; i < std::min(std::max(precision, 0), 38); ++i) t *= 10; max_v = t - 1; }
+  out->type = ORC_FIXED16;
+  out->length = len;
+  out->values = xalloc((size_t)len * 16);
+  out->values_bytes = len * 16;
+  auto put = [&](int64_t i, oi128 v) { memcpy((char*)out->values + i * 16, &v, 16); };
+  auto precision_error = [&](oi128 v) {
+    if (v > max_v)
+      return fail(ORC_INVALID_ARGUMENT, "%s is too large to store in a Decimal128 of precision %d. Max is %s",
+                  fmt_decimal(i128_dbg(v), precision, scale, false).c_str(), precision, fmt_decimal(i128_dbg(max_v), precision, scale, true).c_str());
+    return fail(ORC_INVALID_ARGUMENT, "%s is too small to store in a Decimal128 of precision %d. Min is %s",
+                fmt_decimal(i128_dbg(v), precision, scale, false).c_str(), precision, fmt_decimal(i128_dbg(-max_v), precision, scale, true).c_str());
+  };
+  std::function<int32_t(T, oi128*)> row;  // ORC_OK, or the error already set through fail()
+  bool zeros = false;
+  if (scale < 0) {
+    T factor = 1;  // T::Native::usize_as(10).pow_checked(scale.unsigned_abs())
+    bool some = true;
+    for (int i = 0; i < -scale && some; ++i) some = !__builtin_mul_overflow(factor, (T)10, &factor);
+    if (!some) zeros = true;
+    else row = [=](T v, oi128* o) -> int32_t {
+      oi128 q = (oi128)(T)(v / factor);
+      if (q > max_v || q < -max_v) return precision_error(q);
+      *o = q;
+      return ORC_OK;
+    };
+  } else {
+    oi128 factor = 1;
+    for (int i = 0; i < scale; ++i)
+      if (__builtin_mul_overflow(factor, (oi128)10, &factor)) {
+        orc_release(out);
+        return fail(ORC_CAST_ERROR, "Cannot cast to \"Decimal128\"(%d, %d). The scale causes overflow.", precision, scale);
+      }
+    row = [=](T v, oi128* o) -> int32_t {
+      oi128 r;
+      if (__builtin_mul_overflow((oi128)v, factor, &r))
+        return fail(ORC_ARITHMETIC_OVERFLOW, "Overflow happened on: %s * %s", i128_dbg((oi128)v).c_str(), i128_dbg(factor).c_str());
+      if (r > max_v || r < -max_v) return precision_error(r);
+      *o = r;
+      return ORC_OK;
+    };
+  }
+  if (zeros) {  // array.unary(|_| ZERO)
+    attach_nulls(out, nulls_clone(in, len), len);
+  } else if (safe) {  // unary_opt
+    uint8_t* nb = (uint8_t*)xalloc(bitmap_bytes(len));
+    for (int64_t i = 0; i < len; ++i) {
+      if (in->validity && !get_bit(in->validity, in->validity_bit_offset + i)) continue;
+      oi128 o;
+      if (row(iv[i], &o) == ORC_OK) { put(i, o); set_bit(nb, i); }
+    }
+    out->validity = nb;
+    out->validity_bytes = (int64_t)bitmap_bytes(len);
+    out->null_count = len - count_set_bits(nb, 0, len);
+  } else {  // try_unary
+    for (int64_t i = 0; i < len; ++i) {
+      if (in->validity && !get_bit(in->validity, in->validity_bit_offset + i)) continue;
+      oi128 o;
+      int32_t st = row(iv[i], &o);
+      if (st != ORC_OK) { orc_release(out); return st; }
+      put(i, o);
+    }
+    attach_nulls(out, nulls_clone(in, len), len);
+  }
+  int32_t bad = ORC_OK;
+  if (precision == 0) bad = fail(ORC_INVALID_ARGUMENT, "precision cannot be 0, has to be between [1, 38]");
+  else if (precision > 38) bad = fail(ORC_INVALID_ARGUMENT, "precision %d is greater than max 38", precision);
+  else if (scale > 38) bad = fail(ORC_INVALID_ARGUMENT, "scale %d is greater than max 38", scale);
+  else if (scale > 0 && scale > precision) bad = fail(ORC_INVALID_ARGUMENT, "scale %d is greater than precision %d", scale, precision);
+  if (bad != ORC_OK) { orc_release(out); return bad; }
+  return ORC_OK;
+}
+
 int32_t arith_temporal(int op, const orc_view* l, bool l_s, const orc_data_type* lt, const orc_view* r, bool r_s,
                        const orc_data_type* rt, orc_out* out, orc_data_type* ot) {
   out_init(out);
@@ -3189,6 +3269,19 @@ int32_t orc_cast_with_types(const orc_view* in, const orc_data_type* from, const
   if (from->id == 39 && to->id == 39) {
     out_init(out);
     return cast_decimal128(in, from, to, safe != 0, out);
+  }
+  if (is_integer(from->id) && to->id == 39) {
+    out_init(out);
+    switch (from->id) {
+      case ORC_INT8: return cast_int_to_decimal128<int8_t>(in, to, safe != 0, out);
+      case ORC_INT16: return cast_int_to_decimal128<int16_t>(in, to, safe != 0, out);
+      case ORC_INT32: return cast_int_to_decimal128<int32_t>(in, to, safe != 0, out);
+      case ORC_INT64: return cast_int_to_decimal128<int64_t>(in, to, safe != 0, out);
+      case ORC_UINT8: return cast_int_to_decimal128<uint8_t>(in, to, safe != 0, out);
+      case ORC_UINT16: return cast_int_to_decimal128<uint16_t>(in, to, safe != 0, out);
+      case ORC_UINT32: return cast_int_to_decimal128<uint32_t>(in, to, safe != 0, out);
+      default: return cast_int_to_decimal128<uint64_t>(in, to, safe != 0, out);
+    }
   }
   return cast_temporal(in, from, to, safe != 0, out);
 }

@@ -400,3 +400,35 @@ def test_decimal_to_decimal_cast_matches_the_oracle(ctx, oracle):
         K.cast_with_options(HostArray.from_pylist([1, 123456, 7], A.Decimal128(10, 3)).to_device(ctx), A.Decimal128(5, 3), K.CastOptions(safe=False))
     assert ei.value.message == "123.456 is too large to store in a Decimal128 of precision 5. Max is 99.999"
     assert K.can_cast_types(A.Decimal128(10, 3), A.Decimal128(5, 0)) and not K.can_cast_types(A.Decimal128(10, 3), A.Int64)
+
+
+def test_int_to_decimal_cast_matches_the_oracle(ctx, oracle):
+    """cast_integer_to_decimal: every integer type x scales (positive, zero, negative, beyond the source type) x modes."""
+    from test_temporal_cast_cpu import INT_TYPES, int_column
+    rng = np.random.default_rng(67)
+    n = 2300
+    for src in INT_TYPES:
+        for data in (int_column(rng, src, n), rng.integers(0, 100, n).astype(src.np_dtype)):
+            for with_nulls in (False, True):
+                h = HostArray(src, data, (rng.random(n) < 0.85) if with_nulls else None)
+                d = h.to_device(ctx, bit_offset=3 if with_nulls else 0)
+                for tt in ((38, 0), (38, 10), (20, 2), (10, 0), (5, 2), (38, 30), (10, -2), (38, -19), (38, -20), (3, -1)):
+                    T = A.Decimal128(*tt)
+                    for safe in (True, False):
+                        tag = f"{src} -> {T} safe={safe} nulls={with_nulls}"
+                        try:
+                            exp = oracle.cast_with_types(h, T, safe=safe)
+                        except A.array.ArrowError as e:
+                            with pytest.raises(type(e)) as ei:
+                                K.cast_with_options(d, T, K.CastOptions(safe=safe))
+                            assert ei.value.message == e.message, tag
+                            continue
+                        got = K.cast_with_options(d, T, K.CastOptions(safe=safe))
+                        assert got.data_type == T
+                        check_exact(got, exp, tag)
+    assert K.can_cast_types(A.Int64, A.Decimal128(20, 2)) and not K.can_cast_types(A.Float64, A.Decimal128(20, 2))
+    # the cast feeds decimal arithmetic without leaving the device: (int -> decimal) * decimal
+    price = K.cast(HostArray.from_pylist([3, None, 12], A.Int32).to_device(ctx), A.Decimal128(10, 2))
+    qty = HostArray.from_pylist([250, 100, 50], A.Decimal128(6, 1)).to_device(ctx)
+    total = K.mul(price, qty)
+    assert total.data_type == A.Decimal128(17, 3) and host(total).to_pylist()[0] is not None

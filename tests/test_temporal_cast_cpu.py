@@ -493,3 +493,53 @@ def test_oracle_decimal_cast_vs_exact_python_integers(oracle):
     with pytest.raises(A.array.CastError) as ei:
         oracle.cast_with_types(HostArray.from_pylist([10**37], A.Decimal128(38, 0)), A.Decimal128(38, 5), safe=False)
     assert ei.value.message == f"Cannot cast to Decimal128(38, 5). Overflowing on {10**37}"
+
+
+# ----------------------------------------------------------- integer -> Decimal128 cast
+INT_TYPES = [A.Int8, A.Int16, A.Int32, A.Int64, A.UInt8, A.UInt16, A.UInt32, A.UInt64]
+
+
+def int_to_decimal_model(v, src, tt):
+    """cast_integer_to_decimal (cast/mod.rs:366-443), safe mode, in exact Python integers: value or None."""
+    p, s = tt
+    mx = 10 ** p - 1
+    if s < 0:
+        k = 10 ** -s
+        if k > np.iinfo(src.np_dtype).max:
+            return 0
+        r = abs(v) // k * (1 if v >= 0 else -1)
+    else:
+        r = v * 10 ** s
+        if not (I128_MIN <= r <= I128_MAX):
+            return None
+    return r if -mx <= r <= mx else None
+
+
+def int_column(rng, t, n):
+    info = np.iinfo(t.np_dtype)
+    v = rng.integers(info.min, info.max, n, dtype=np.int64 if info.min < 0 else np.uint64).astype(t.np_dtype)
+    v[:6] = [0, 1, info.max, info.min, info.max // 10, 99 if info.max >= 99 else 9]
+    return v
+
+
+def test_oracle_int_to_decimal_vs_exact_python_integers(oracle):
+    rng = np.random.default_rng(61)
+    for src in INT_TYPES:
+        vals = int_column(rng, src, 200)
+        valid = rng.random(200) < 0.85
+        h = HostArray(src, vals, valid)
+        for tt in ((38, 0), (38, 10), (20, 2), (10, 0), (5, 2), (38, 30), (10, -2), (38, -19), (38, -20), (3, -1)):
+            got = oracle.cast_with_types(h, A.Decimal128(*tt), safe=True)
+            exp = [int_to_decimal_model(int(v), src, tt) if ok else None for v, ok in zip(vals, valid)]
+            gvalid = got.valid if got.valid is not None else np.ones(200, dtype=bool)
+            assert [v if ok else None for v, ok in zip(dec_values(got), gvalid)] == exp, (src, tt)
+    h = HostArray.from_pylist([1, 123456, 7], A.Int32)
+    with pytest.raises(A.array.InvalidArgumentError) as ei:
+        oracle.cast_with_types(h, A.Decimal128(5, 0), safe=False)
+    assert ei.value.message == "123456 is too large to store in a Decimal128 of precision 5. Max is 99999"
+    with pytest.raises(A.array.ArithmeticOverflow) as ei:
+        oracle.cast_with_types(HostArray.from_pylist([2**62], A.Int64), A.Decimal128(38, 30), safe=False)
+    assert ei.value.message == f"Overflow happened on: {2**62} * {10**30}"
+    # test_cast_integer_to_decimal-style literals (cast/mod.rs: Int32 [1, 2, 3, 4, 5, None] -> Decimal128(38, 6))
+    got = oracle.cast_with_types(HostArray.from_pylist([1, 2, 3, 4, 5, None], A.Int32), A.Decimal128(38, 6))
+    assert dec_values(got)[:5] == [1000000, 2000000, 3000000, 4000000, 5000000] and got.valid.tolist() == [True] * 5 + [False]
