@@ -252,8 +252,7 @@ ah_status run_agg(ah_context* ctx, const ah_array_view* v, bool has_valid, void*
   }
   hipLaunchKernelGGL((agg_final<A, K>), dim3(1), dim3(AGG_BLOCK), 0, ctx->stream, partials, f.grid, result);
   AH_HIP(ctx, hipGetLastError());
-  AH_HIP(ctx, hipMemcpyAsync(ctx->pinned, result, sizeof(A), hipMemcpyDeviceToHost, ctx->stream));
-  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  AH_HIP(ctx, ah_d2h_wait(ctx, ctx->pinned, result, sizeof(A)));
   A r;
   memcpy(&r, ctx->pinned, sizeof(A));
   uint64_t raw = 0;
@@ -561,8 +560,7 @@ ah_status run_checked(ah_context* ctx, const ah_array_view* v, bool has_valid, v
   else
     hipLaunchKernelGGL(sum_walk, dim3(1), dim3(1), 0, ctx->stream, partials, f.grid, rg, res);
   AH_HIP(ctx, hipGetLastError());
-  AH_HIP(ctx, hipMemcpyAsync(ctx->pinned, res, sizeof(CheckedResult), hipMemcpyDeviceToHost, ctx->stream));
-  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  AH_HIP(ctx, ah_d2h_wait(ctx, ctx->pinned, res, sizeof(CheckedResult)));
   CheckedResult r;
   memcpy(&r, ctx->pinned, sizeof r);
   if (r.fail_block < 0) {
@@ -573,8 +571,7 @@ ah_status run_checked(ah_context* ctx, const ah_array_view* v, bool has_valid, v
   hipLaunchKernelGGL((locate_kernel<W, SIGNED, IS_PROD>), dim3(1), dim3(1), 0, ctx->stream, f.base, f.skip, v->length,
                      has_valid ? bv : BitView{nullptr, 0}, vb, ve, rg, r.acc, operands);
   AH_HIP(ctx, hipGetLastError());
-  AH_HIP(ctx, hipMemcpyAsync(ctx->pinned, operands, 2 * sizeof(i128), hipMemcpyDeviceToHost, ctx->stream));
-  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  AH_HIP(ctx, ah_d2h_wait(ctx, ctx->pinned, operands, 2 * sizeof(i128)));
   i128 ops[2];
   memcpy(ops, ctx->pinned, sizeof ops);
   char a[48], b[48];

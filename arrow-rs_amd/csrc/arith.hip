@@ -41,16 +41,37 @@ const char* op_sym(int op) {  // Display for Op (numeric.rs:203-213)
   }
 }
 
+// NaN bit patterns as the reference's host produces them.  The reference runs on x86-64 (SSE2), and its
+// float kernels compare and sort NaNs by their BITS (total_cmp / to_bits equality,
+// arrow-array/src/arithmetic.rs:400-410), so the sign and payload of a NaN result are observable:
+//   * an operation that GENERATES a NaN (inf - inf, 0 * inf, 0 / 0, inf / inf, x % 0, inf % y) yields the x86
+//     "QNaN floating-point indefinite" 0xFFF8000000000000 / 0xFFC00000 — CDNA4 alone would give 0x7FF8... /
+//     0x7FC0..., and `lt(add(inf, -inf), 0.0)` would flip;
+//   * a NaN operand is PROPAGATED: the result is that operand with the quiet bit set, the left one first
+//     (SSE rule: "first source operand if it is a NaN, else the second").
+template <typename T> __device__ __forceinline__ T x86_default_nan();
+template <> __device__ __forceinline__ double x86_default_nan<double>() { return __longlong_as_double((long long)0xFFF8000000000000ull); }
+template <> __device__ __forceinline__ float x86_default_nan<float>() { return __uint_as_float(0xFFC00000u); }
+__device__ __forceinline__ double quieted(double x) { return __longlong_as_double(__double_as_longlong(x) | 0x0008000000000000ll); }
+__device__ __forceinline__ float quieted(float x) { return __uint_as_float(__float_as_uint(x) | 0x00400000u); }
+
 // element semantics: ArrowNativeTypeOp (arrow-array/src/arithmetic.rs:147-430)
 template <typename T, int OP>
 __device__ __forceinline__ bool apply(T l, T r, T* out) {  // returns false on error
   if constexpr (std::is_floating_point<T>::value) {
-    if constexpr (OP == OP_ADD || OP == OP_ADD_W) *out = l + r;
-    else if constexpr (OP == OP_SUB || OP == OP_SUB_W) *out = l - r;
-    else if constexpr (OP == OP_MUL || OP == OP_MUL_W) *out = l * r;
-    else if constexpr (OP == OP_DIV) *out = l / r;
-    else if constexpr (OP == OP_REM) *out = fmod(l, r);
-    else *out = -l;
+    T o;
+    if constexpr (OP == OP_ADD || OP == OP_ADD_W) o = l + r;
+    else if constexpr (OP == OP_SUB || OP == OP_SUB_W) o = l - r;
+    else if constexpr (OP == OP_MUL || OP == OP_MUL_W) o = l * r;
+    else if constexpr (OP == OP_DIV) o = l / r;
+    else if constexpr (OP == OP_REM) o = fmod(l, r);
+    else o = -l;  // neg: a sign flip, also of a NaN (xorps on the reference's host)
+    if constexpr (!op_is_unary(OP)) {
+      if (l != l) o = quieted(l);
+      else if (r != r) o = quieted(r);
+      else if (o != o) o = x86_default_nan<T>();
+    }
+    *out = o;
     return true;
   } else {
     using U = typename std::make_unsigned<T>::type;
@@ -246,7 +267,7 @@ ah_status read_elem_text(ah_context* ctx, ah_type t, const void* base, int64_t i
   int w = ah_type_width(t);
   uint64_t raw = 0;
   AH_HIP(ctx, hipMemcpyAsync(&raw, (const char*)base + idx * w, w, hipMemcpyDeviceToHost, ctx->stream));
-  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  AH_HIP(ctx, ah_stream_wait(ctx));
   *is_zero = raw == 0;
   switch (t) {
     case AH_INT8: snprintf(buf, n, "%d", (int)(int8_t)raw); break;
@@ -384,9 +405,9 @@ extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_a
   }
   hipError_t e = hipGetLastError();
   if (st == AH_OK && e == hipSuccess && checked)
-    e = hipMemcpyAsync(ctx->pinned, first_err, 8, hipMemcpyDeviceToHost, ctx->stream);
+    e = ah_d2h(ctx, ctx->pinned, first_err, 8);
   // checked ops report device-side errors, so they stay synchronous even in deferred mode
-  if (e == hipSuccess) e = checked ? hipStreamSynchronize(ctx->stream) : ah_end_of_call_sync(ctx);
+  if (e == hipSuccess) e = checked ? ah_stream_wait(ctx) : ah_end_of_call_sync(ctx);
   ah_pool_free(ctx, first_err);
   if (st != AH_OK || e != hipSuccess) {
     free_out_bufs(ctx, ov, vbytes, ob, bbytes);
@@ -484,8 +505,8 @@ static ah_status arith_unary(ah_context* ctx, const ah_array_view* v, int op, ah
   ah_status st = dispatch_type(ctx, t, op, a, aligned);
   hipError_t e = hipGetLastError();
   if (st == AH_OK && e == hipSuccess && checked)
-    e = hipMemcpyAsync(ctx->pinned, first_err, 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = checked ? hipStreamSynchronize(ctx->stream) : ah_end_of_call_sync(ctx);
+    e = ah_d2h(ctx, ctx->pinned, first_err, 8);
+  if (e == hipSuccess) e = checked ? ah_stream_wait(ctx) : ah_end_of_call_sync(ctx);
   ah_pool_free(ctx, first_err);
   if (st != AH_OK || e != hipSuccess) {
     free_out_bufs(ctx, ov, vbytes, ob, bbytes);

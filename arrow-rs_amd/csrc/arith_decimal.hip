@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) dec_kernel(DecArgs a) {
 ah_status fetch_i128(ah_context* ctx, const void* base, int64_t idx, i128* out) {
   uint64_t raw[2] = {0, 0};
   AH_HIP(ctx, hipMemcpyAsync(raw, (const char*)base + idx * 16, 16, hipMemcpyDeviceToHost, ctx->stream));
-  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  AH_HIP(ctx, ah_stream_wait(ctx));
   *out = (i128)(((u128)raw[1] << 64) | raw[0]);
   return AH_OK;
 }
@@ -152,7 +152,7 @@ ah_status ah_decimal_arith(ah_context* ctx, ah_arith_op op, const char* op_sym, 
   if (all_null) {
     hipMemsetAsync(ov, 0, vbytes, ctx->stream);
     hipMemsetAsync(ob, 0, bbytes, ctx->stream);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = ah_stream_wait(ctx);
     if (e != hipSuccess) return release(), ah_fail(ctx, AH_HIP_ERROR, "decimal arithmetic: %s", hipGetErrorString(e));
     set_bits = 0;
   } else {
@@ -181,8 +181,7 @@ ah_status ah_decimal_arith(ah_context* ctx, ah_arith_op op, const char* op_sym, 
       dec_kernel<<<grid, 256, 0, ctx->stream>>>(a);
     }
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, first_err, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // a checked op: synchronous also in deferred mode
+    if (e == hipSuccess) e = ah_d2h_wait(ctx, ctx->pinned, first_err, 8);
     ah_pool_free(ctx, first_err);
     if (e != hipSuccess) return release(), ah_fail(ctx, AH_HIP_ERROR, "decimal arithmetic kernel failed: %s", hipGetErrorString(e));
     if (ctx->pinned[0] != ~0ull) {
@@ -342,8 +341,7 @@ ah_status ah_decimal_cast(ah_context* ctx, const ah_array_view* values, const ah
   }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && want_valid) dcast_sum_kernel<<<1, 256, 0, ctx->stream>>>(a.block_valid, grid, aux + 1);
-  if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, aux, 16, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_d2h_wait(ctx, ctx->pinned, aux, 16);
   ah_pool_free(ctx, aux);
   if (e != hipSuccess) return release(), ah_fail(ctx, AH_HIP_ERROR, "decimal cast kernel failed: %s", hipGetErrorString(e));
   if (!a.fail_is_null && ctx->pinned[0] != ~0ull) {
@@ -484,8 +482,7 @@ ah_status ah_int_to_decimal_cast(ah_context* ctx, const ah_array_view* values, c
 #undef AH_ICAST
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && want_valid) dcast_sum_kernel<<<1, 256, 0, ctx->stream>>>(aux + 2, grid, aux + 1);
-  if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, aux, 16, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_d2h_wait(ctx, ctx->pinned, aux, 16);
   ah_pool_free(ctx, aux);
   if (e != hipSuccess) return release(), ah_fail(ctx, AH_HIP_ERROR, "integer -> decimal cast kernel failed: %s", hipGetErrorString(e));
   if (!fin && ctx->pinned[0] != ~0ull) {
@@ -493,7 +490,7 @@ ah_status ah_int_to_decimal_cast(ah_context* ctx, const ah_array_view* values, c
     release();
     uint64_t raw = 0;
     AH_HIP(ctx, hipMemcpyAsync(&raw, (const char*)values->values + pos * w, w, hipMemcpyDeviceToHost, ctx->stream));
-    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AH_HIP(ctx, ah_stream_wait(ctx));
     i128 x;
     if (sg) x = w == 1 ? (i128)(int8_t)raw : w == 2 ? (i128)(int16_t)raw : w == 4 ? (i128)(int32_t)raw : (i128)(int64_t)raw;
     else x = (i128)(u128)raw;

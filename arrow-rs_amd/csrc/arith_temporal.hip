@@ -83,7 +83,7 @@ ah_status date32_diff(ah_context* ctx, const ah_array_view* l, int32_t l_s, cons
   AH_TRY(ah_pool_alloc(ctx, 8, &k));
   const int64_t seconds_in_day = 86400;
   hipError_t e = hipMemcpyAsync(k, &seconds_in_day, 8, hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the host constant must outlive the copy
+  if (e == hipSuccess) e = ah_stream_wait(ctx);  // the host constant must outlive the copy
   if (e != hipSuccess) {
     ah_pool_free(ctx, k);
     return ah_fail(ctx, AH_HIP_ERROR, "date32 difference: %s", hipGetErrorString(e));

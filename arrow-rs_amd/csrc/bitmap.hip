@@ -114,8 +114,7 @@ ah_status ah_bitmap_op(ah_context* ctx, int op, BitView a, BitView b, BitView c,
   bitmap_op_kernel<<<grid, 256, 0, ctx->stream>>>(op, a, b, c, d, len, out_words, part);
   if (set_bits) {
     bm_sum_kernel<<<1, 1024, 0, ctx->stream>>>(part, grid, part + grid);
-    hipError_t e = hipMemcpyAsync(ctx->pinned + 8, part + grid, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = ah_d2h_wait(ctx, ctx->pinned + 8, part + grid, 8);
     ah_pool_free(ctx, part);
     AH_HIP(ctx, e);
     *set_bits = (int64_t)ctx->pinned[8];
@@ -139,8 +138,7 @@ extern "C" ah_status ah_bitmap_set_bits(ah_context* ctx, uint8_t* dst, int64_t d
                                                  make_bitview(src, src_bit_offset), len, part);
   if (set_bits) {
     bm_sum_kernel<<<1, 1024, 0, ctx->stream>>>(part, grid, part + grid);
-    hipError_t e = hipMemcpyAsync(ctx->pinned + 8, part + grid, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = ah_d2h_wait(ctx, ctx->pinned + 8, part + grid, 8);
     ah_pool_free(ctx, part);
     AH_HIP(ctx, e);
     *set_bits = (int64_t)ctx->pinned[8];

@@ -62,11 +62,12 @@ struct CastArgs {
   BitView in_valid;  // words == nullptr: all valid
   int64_t len;
   unsigned long long* out_valid;    // nullptr: none
-  unsigned long long* block_valid;  // per-block valid counts (when out_valid)
-  unsigned long long* first_err;    // unsafe mode
+  unsigned long long* slots;        // 64 zero-state counters of valid output rows (ctx->scratch)
+  unsigned long long* first_err;    // all-ones-state position word (unsafe mode)
   int safe;
 };
 
+// ---- general kernel: lane-per-row, any alignment (sliced inputs, 1/2-byte types)
 template <typename I, typename O>
 __global__ void __launch_bounds__(256) cast_kernel(CastArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -120,38 +121,178 @@ __global__ void __launch_bounds__(256) cast_kernel(CastArgs a) {
     __shared__ unsigned long long s[4];
     if (lane == 0) s[wave] = nvalid;
     __syncthreads();
-    if (threadIdx.x == 0) a.block_valid[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (threadIdx.x == 0) {
+      unsigned long long c = s[0] + s[1] + s[2] + s[3];
+      if (c) atomicAdd(&a.slots[blockIdx.x & 63], c);
+    }
   }
 }
 
-__global__ void __launch_bounds__(1024) cast_sum_kernel(const unsigned long long* in, int64_t n,
-                                                        unsigned long long* out) {
-  unsigned long long acc = 0;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) acc += in[i];
-  acc = wave_reduce_add64(acc);
-  __shared__ unsigned long long s[16];
-  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
-  __syncthreads();
+// ---- streaming kernel: V consecutive rows per lane so that the wider side moves 16 bytes per lane per access
+// (8 -> 8 bytes: both sides), short-lived workgroups with 4 x 16-byte loads in flight per lane — the shape that
+// reaches 5.6 TB/s on a read+write stream on MI355X, against 4.7 TB/s for 8-byte accesses from a persistent
+// grid.  A group of 64*V rows is V validity words: per element slot e the wave ballots "valid and converted",
+// and the scalar unit bit-interleaves the V ballots into the V output words (as cmp.hip does).
+template <int V> __device__ __forceinline__ uint64_t cast_spread(uint64_t x);
+template <> __device__ __forceinline__ uint64_t cast_spread<1>(uint64_t x) { return x; }
+template <> __device__ __forceinline__ uint64_t cast_spread<2>(uint64_t x) {  // 32 bits -> even bit positions
+  x &= 0xFFFFFFFFull;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+template <> __device__ __forceinline__ uint64_t cast_spread<4>(uint64_t x) {  // 16 bits -> every 4th position
+  x &= 0xFFFFull;
+  x = (x | (x << 24)) & 0x000000FF000000FFull;
+  x = (x | (x << 12)) & 0x000F000F000F000Full;
+  x = (x | (x << 6)) & 0x0303030303030303ull;
+  x = (x | (x << 3)) & 0x1111111111111111ull;
+  return x;
+}
+
+template <typename T, int V> struct alignas(sizeof(T) * V) CastVec { T e[V]; };
+constexpr int CAST_G = 4;  // groups in flight per wave
+
+template <typename I, typename O, int V>
+__global__ void __launch_bounds__(256) cast_stream_kernel(CastArgs a) {
+  using VI = CastVec<I, V>;
+  using VO = CastVec<O, V>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const I* ip = (const I*)a.in;
+  O* op = (O*)a.out;
+  const int64_t ngroups = (a.len + 64 * V - 1) / (64 * V);
+  const int64_t nwords = (a.len + 63) >> 6;
+  const int64_t g0 = ((int64_t)blockIdx.x * 4 + wave) * CAST_G;
+  unsigned long long nvalid = 0, err = ~0ull;
+  VI iv[CAST_G];
+  uint32_t vb[CAST_G];
+#pragma unroll
+  for (int gi = 0; gi < CAST_G; ++gi) {  // every load of the wave's groups goes out first
+    const int64_t i = ((g0 + gi) * 64 + lane) * V;
+    vb[gi] = 0;
+    if (i + V <= a.len) {
+      iv[gi] = *(const VI*)(ip + i);
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) iv[gi].e[e] = (i + e < a.len) ? ip[i + e] : I{};
+    }
+    if (i < a.len) vb[gi] = (uint32_t)(bv_fetch64(a.in_valid, i & ~63ll, a.len) >> (i & 63));
+  }
+#pragma unroll
+  for (int gi = 0; gi < CAST_G; ++gi) {
+    const int64_t g = g0 + gi;
+    if (g >= ngroups) break;
+    const int64_t i = (g * 64 + lane) * V;
+    VO ov;
+    uint64_t ballots[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const bool valid = (vb[gi] >> e) & 1u;
+      O o = O{};
+      bool ok = true;
+      if (valid) ok = num_cast<I, O>(iv[gi].e[e], &o);
+      if (!ok) {
+        o = O{};
+        if (!a.safe && i + e < a.len) {
+          unsigned long long pos = (unsigned long long)(i + e);
+          err = pos < err ? pos : err;
+        }
+      }
+      ov.e[e] = o;
+      ballots[e] = __ballot(valid && (ok || !a.safe) && (i + e < a.len));
+    }
+    if (i + V <= a.len) {
+      *(VO*)(op + i) = ov;
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e)
+        if (i + e < a.len) op[i + e] = ov.e[e];
+    }
+    if (a.out_valid) {
+      uint64_t mine = 0;
+#pragma unroll
+      for (int k = 0; k < V; ++k) {  // word k of the group covers lanes [k*64/V, (k+1)*64/V)
+        uint64_t w = 0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) w |= cast_spread<V>(ballots[e] >> (k * (64 / V))) << e;
+        if (lane == k) mine = w;
+      }
+      const int64_t wi = g * V + lane;
+      if (lane < V && wi < nwords) {
+        a.out_valid[wi] = mine;
+        nvalid += __popcll(mine);
+      }
+    }
+  }
+  if (!a.safe) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long other = __shfl_xor(err, o, 64);
+      err = other < err ? other : err;
+    }
+    if (lane == 0 && err != ~0ull) atomicMin(a.first_err, err);
+  }
+  if (a.out_valid) {
+    nvalid = wave_reduce_add64(nvalid);
+    __shared__ unsigned long long s[4];
+    if (lane == 0) s[wave] = nvalid;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long c = s[0] + s[1] + s[2] + s[3];
+      if (c) atomicAdd(&a.slots[blockIdx.x & 63], c);
+    }
+  }
+}
+
+// after the cast: mail[0] = first failing position (~0: none), mail[1] = valid output rows; both scratch
+// areas go back to their rest state and the mailbox is posted (mail == nullptr in deferred mode: clean only)
+__global__ void __launch_bounds__(64) cast_finish_kernel(unsigned long long* slots, unsigned long long* first_err,
+                                                         uint64_t* mail, uint64_t seq) {
+  unsigned long long v = slots[threadIdx.x];
+  slots[threadIdx.x] = 0;
+  v = wave_reduce_add64(v);
   if (threadIdx.x == 0) {
-    unsigned long long t = 0;
-    for (int i = 0; i < 16; i++) t += s[i];
-    *out = t;
+    const unsigned long long e = *first_err;
+    *first_err = ~0ull;
+    if (mail) {
+      __hip_atomic_store(mail, (uint64_t)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(mail + 1, (uint64_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      ah_mail_post(mail, seq);
+    }
+  }
+}
+
+template <typename I, typename O>
+void launch_cast(ah_context* ctx, const CastArgs& a) {
+  constexpr int WMAX = sizeof(I) > sizeof(O) ? sizeof(I) : sizeof(O);
+  constexpr int V = WMAX >= 4 ? 16 / WMAX : 4;
+  const bool aligned = (((uintptr_t)a.in) % (sizeof(I) * V) == 0) && (((uintptr_t)a.out) % (sizeof(O) * V) == 0);
+  if (aligned) {
+    const int64_t ngroups = ah_ceil_div(a.len, 64 * (int64_t)V);
+    const int64_t grid = std::max<int64_t>(1, ah_ceil_div(ngroups, 4 * CAST_G));
+    cast_stream_kernel<I, O, V><<<(unsigned)grid, 256, 0, ctx->stream>>>(a);
+  } else {
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(a.len, 1024), 256 * 16));
+    cast_kernel<I, O><<<grid, 256, 0, ctx->stream>>>(a);
   }
 }
 
 template <typename I>
-ah_status launch_from(ah_context* ctx, ah_type to, const CastArgs& a, int grid) {
+ah_status launch_from(ah_context* ctx, ah_type to, const CastArgs& a) {
   switch (to) {
-    case AH_INT8: cast_kernel<I, int8_t><<<grid, 256, 0, ctx->stream>>>(a); break;
-    case AH_INT16: cast_kernel<I, int16_t><<<grid, 256, 0, ctx->stream>>>(a); break;
-    case AH_INT32: cast_kernel<I, int32_t><<<grid, 256, 0, ctx->stream>>>(a); break;
-    case AH_INT64: cast_kernel<I, int64_t><<<grid, 256, 0, ctx->stream>>>(a); break;
-    case AH_UINT8: cast_kernel<I, uint8_t><<<grid, 256, 0, ctx->stream>>>(a); break;
-    case AH_UINT16: cast_kernel<I, uint16_t><<<grid, 256, 0, ctx->stream>>>(a); break;
-    case AH_UINT32: cast_kernel<I, uint32_t><<<grid, 256, 0, ctx->stream>>>(a); break;
-    case AH_UINT64: cast_kernel<I, uint64_t><<<grid, 256, 0, ctx->stream>>>(a); break;
-    case AH_FLOAT32: cast_kernel<I, float><<<grid, 256, 0, ctx->stream>>>(a); break;
-    case AH_FLOAT64: cast_kernel<I, double><<<grid, 256, 0, ctx->stream>>>(a); break;
+    case AH_INT8: launch_cast<I, int8_t>(ctx, a); break;
+    case AH_INT16: launch_cast<I, int16_t>(ctx, a); break;
+    case AH_INT32: launch_cast<I, int32_t>(ctx, a); break;
+    case AH_INT64: launch_cast<I, int64_t>(ctx, a); break;
+    case AH_UINT8: launch_cast<I, uint8_t>(ctx, a); break;
+    case AH_UINT16: launch_cast<I, uint16_t>(ctx, a); break;
+    case AH_UINT32: launch_cast<I, uint32_t>(ctx, a); break;
+    case AH_UINT64: launch_cast<I, uint64_t>(ctx, a); break;
+    case AH_FLOAT32: launch_cast<I, float>(ctx, a); break;
+    case AH_FLOAT64: launch_cast<I, double>(ctx, a); break;
     default: return ah_fail(ctx, AH_CAST_ERROR, "unsupported cast target");
   }
   return AH_OK;
@@ -191,7 +332,7 @@ ah_status elem_debug_text(ah_context* ctx, ah_type t, const void* base, int64_t 
   int w = ah_type_width(t);
   uint64_t raw = 0;
   AH_HIP(ctx, hipMemcpyAsync(&raw, (const char*)base + idx * w, w, hipMemcpyDeviceToHost, ctx->stream));
-  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  AH_HIP(ctx, ah_stream_wait(ctx));
   char buf[40];
   switch (t) {
     case AH_INT8: snprintf(buf, sizeof buf, "%d", (int)(int8_t)raw); break;
@@ -283,18 +424,13 @@ extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_ty
   }
   void* ov = nullptr;
   void* ob = nullptr;
-  unsigned long long* aux = nullptr;
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(len, 1024), 256 * 16));
   AH_TRY(ah_out_alloc(ctx, vbytes, &ov));
   ah_status st = AH_OK;
   if (want_valid) st = ah_out_alloc(ctx, bbytes, &ob);
-  if (st == AH_OK) st = ah_pool_alloc(ctx, (size_t)(grid + 4) * 8, (void**)&aux);
   if (st != AH_OK) {
     ah_out_free(ctx, ov, vbytes);
-    ah_out_free(ctx, ob, bbytes);
     return st;
   }
-  hipMemsetAsync(aux, 0xFF, 8, ctx->stream);
   CastArgs a{};
   a.in = values->values;
   a.out = ov;
@@ -302,22 +438,22 @@ extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_ty
                                 : BitView{nullptr, 0};
   a.len = len;
   a.out_valid = (unsigned long long*)ob;
-  a.block_valid = aux + 2;
-  a.first_err = aux;
+  a.slots = ctx->scratch;                       // zero between calls
+  a.first_err = ctx->scratch + AH_SCRATCH_ONES;  // all-ones between calls
   a.safe = safe ? 1 : 0;
   {
     ah_prof_scope ps(ctx, "cast_numeric");
     switch (from) {
-      case AH_INT8: st = launch_from<int8_t>(ctx, to_type, a, grid); break;
-      case AH_INT16: st = launch_from<int16_t>(ctx, to_type, a, grid); break;
-      case AH_INT32: st = launch_from<int32_t>(ctx, to_type, a, grid); break;
-      case AH_INT64: st = launch_from<int64_t>(ctx, to_type, a, grid); break;
-      case AH_UINT8: st = launch_from<uint8_t>(ctx, to_type, a, grid); break;
-      case AH_UINT16: st = launch_from<uint16_t>(ctx, to_type, a, grid); break;
-      case AH_UINT32: st = launch_from<uint32_t>(ctx, to_type, a, grid); break;
-      case AH_UINT64: st = launch_from<uint64_t>(ctx, to_type, a, grid); break;
-      case AH_FLOAT32: st = launch_from<float>(ctx, to_type, a, grid); break;
-      default: st = launch_from<double>(ctx, to_type, a, grid); break;
+      case AH_INT8: st = launch_from<int8_t>(ctx, to_type, a); break;
+      case AH_INT16: st = launch_from<int16_t>(ctx, to_type, a); break;
+      case AH_INT32: st = launch_from<int32_t>(ctx, to_type, a); break;
+      case AH_INT64: st = launch_from<int64_t>(ctx, to_type, a); break;
+      case AH_UINT8: st = launch_from<uint8_t>(ctx, to_type, a); break;
+      case AH_UINT16: st = launch_from<uint16_t>(ctx, to_type, a); break;
+      case AH_UINT32: st = launch_from<uint32_t>(ctx, to_type, a); break;
+      case AH_UINT64: st = launch_from<uint64_t>(ctx, to_type, a); break;
+      case AH_FLOAT32: st = launch_from<float>(ctx, to_type, a); break;
+      default: st = launch_from<double>(ctx, to_type, a); break;
     }
   }
   hipError_t e = hipGetLastError();
@@ -325,7 +461,7 @@ extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_ty
     // safe mode cannot fail, so in deferred mode it returns here with the null count unknown;
     // unsafe mode reports the first failing value and stays synchronous
     if (safe && ctx->deferred) {
-      ah_pool_free(ctx, aux);
+      cast_finish_kernel<<<1, 64, 0, ctx->stream>>>(a.slots, a.first_err, nullptr, 0);
       out->values = ov;
       out->values_bytes = (int64_t)vbytes;
       out->validity = (uint8_t*)ob;
@@ -333,11 +469,11 @@ extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_ty
       out->null_count = -1;
       return AH_OK;
     }
-    if (want_valid) cast_sum_kernel<<<1, 1024, 0, ctx->stream>>>(a.block_valid, grid, aux + 1);
-    e = hipMemcpyAsync(ctx->pinned, aux, 16, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    const uint64_t seq = ah_mail_next(ctx);
+    cast_finish_kernel<<<1, 64, 0, ctx->stream>>>(a.slots, a.first_err, ctx->pinned_dev, seq);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
   }
-  ah_pool_free(ctx, aux);
   if (st != AH_OK || e != hipSuccess) {
     ah_out_free(ctx, ov, vbytes);
     ah_out_free(ctx, ob, bbytes);

@@ -61,8 +61,7 @@ ah_status with_slots(ah_context* ctx, F&& launch, int64_t* valid) {
     launch((unsigned long long*)slots);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, slots, 64 * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_d2h_wait(ctx, ctx->pinned, slots, 64 * 8);
   ah_pool_free(ctx, slots);
   if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in Boolean cast", hipGetErrorString(e));
   *valid = 0;

@@ -269,8 +269,8 @@ ah_status ah_cast_parse(ah_context* ctx, const ah_array_view* values, ah_type to
     st = large ? launch_by_type<int64_t>(ctx, to_type, a, grid) : launch_by_type<int32_t>(ctx, to_type, a, grid);
   }
   hipError_t e = hipGetLastError();
-  if (st == AH_OK && e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, ctr, 66 * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (st == AH_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (st == AH_OK && e == hipSuccess) e = ah_d2h(ctx, ctx->pinned, ctr, 66 * 8);
+  if (st == AH_OK && e == hipSuccess) e = ah_stream_wait(ctx);
   if (st == AH_OK && e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in string -> numeric cast", hipGetErrorString(e));
   if (st != AH_OK) {
     cleanup(true);
@@ -286,7 +286,7 @@ ah_status ah_cast_parse(ah_context* ctx, const ah_array_view* values, ah_type to
     uint8_t raw[16];
     int64_t o0 = 0, o1 = 0;
     e = hipMemcpyAsync(raw, (const uint8_t*)values->offsets + first_err * ow, 2 * ow, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ah_stream_wait(ctx);
     if (e == hipSuccess) {
       if (large) {
         memcpy(&o0, raw, 8);
@@ -301,7 +301,7 @@ ah_status ah_cast_parse(ah_context* ctx, const ah_array_view* values, ah_type to
     std::string text((size_t)(o1 - o0), '\0');
     if (e == hipSuccess && !text.empty()) {
       e = hipMemcpyAsync(&text[0], (const uint8_t*)values->values + o0, text.size(), hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess) e = ah_stream_wait(ctx);
     }
     cleanup(true);
     if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s reading the failing row", hipGetErrorString(e));
@@ -318,7 +318,7 @@ ah_status ah_cast_parse(ah_context* ctx, const ah_array_view* values, ah_type to
       else parse_slow_kernel<int32_t, float><<<sgrid, 64, 0, ctx->stream>>>((const int32_t*)a.offs, a.data, len, a.slow_bits, (uint32_t*)ov);
     }
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ah_stream_wait(ctx);
     if (e != hipSuccess) {
       cleanup(true);
       return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in the exact float parse", hipGetErrorString(e));

@@ -143,7 +143,7 @@ ah_status source_value_text(ah_context* ctx, ah_type t, const void* base, int64_
   int w = ah_type_width(t);
   uint64_t raw = 0;
   AH_HIP(ctx, hipMemcpyAsync(&raw, (const char*)base + idx * w, w, hipMemcpyDeviceToHost, ctx->stream));
-  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  AH_HIP(ctx, ah_stream_wait(ctx));
   *out = std::to_string(t == AH_INT32 ? (long long)(int32_t)raw : (long long)(int64_t)raw);
   return AH_OK;
 }
@@ -236,8 +236,7 @@ ah_status run_kernel_step(ah_context* ctx, const ah_array_view* values, const St
       return AH_OK;
     }
     if (want_valid) tcast_sum_kernel<<<1, 1024, 0, ctx->stream>>>(a.block_valid, grid, aux + 1);
-    e = hipMemcpyAsync(ctx->pinned, aux, 16, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    e = ah_d2h_wait(ctx, ctx->pinned, aux, 16);
   }
   ah_pool_free(ctx, aux);
   if (e != hipSuccess) {

@@ -130,7 +130,7 @@ ah_status host_copy(ah_context* ctx, const void* dev, size_t bytes, size_t pad_t
   memset(static_cast<char*>(h) + bytes, 0, cap - bytes);
   if (bytes) {
     hipError_t e = hipMemcpyAsync(h, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ah_stream_wait(ctx);
     if (e != hipSuccess) {
       free(h);
       return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in C Data export", hipGetErrorString(e));
@@ -274,7 +274,7 @@ extern "C" ah_status ah_import_c_data(ah_context* ctx, const struct ArrowArray* 
       out->offsets_bytes = (int64_t)ob;
       if (st != AH_OK) return fail(st);
       if (first) {  // the staging vector dies at the end of this scope
-        hipError_t e = hipStreamSynchronize(ctx->stream);
+        hipError_t e = ah_stream_wait(ctx);
         if (e != hipSuccess)
           return fail(ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in C Data import", hipGetErrorString(e)));
       }
@@ -301,7 +301,7 @@ extern "C" ah_status ah_import_c_data(ah_context* ctx, const struct ArrowArray* 
       if (st != AH_OK) return fail(st);
     }
   }
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = ah_stream_wait(ctx);
   if (e != hipSuccess) return fail(ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in C Data import", hipGetErrorString(e)));
 
   if (!out->validity) {
@@ -433,7 +433,7 @@ ah_status aligned_bits(ah_context* ctx, const void* bits, int64_t bit_offset, in
   AH_TRY(ah_pool_alloc(ctx, ah_bitmap_bytes(len), &tmp));
   ah_status st = ah_bitmap_op(ctx, BM_COPY, make_bitview(bits, bit_offset), BitView{nullptr, 0}, BitView{nullptr, 0}, len,
                               (unsigned long long*)tmp, nullptr);
-  if (st == AH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "bitmap re-alignment failed");
+  if (st == AH_OK && ah_stream_wait(ctx) != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "bitmap re-alignment failed");
   if (st != AH_OK) {
     ah_pool_free(ctx, tmp);
     return st;

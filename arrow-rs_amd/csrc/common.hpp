@@ -44,8 +44,19 @@ struct ah_context {
     void* user;
   };
   std::unordered_map<void*, hook_entry> hook_live;  // outputs handed out by the host allocator hook, with THEIR free
-  // pinned host read-back slots
-  uint64_t* pinned = nullptr;  // 256 x u64
+  // pinned host read-back slots: 255 x u64 of payload + the mailbox sequence word [255].  Device kernels write
+  // the payload and then the sequence word (system-scope release); the host spins on the word instead of
+  // entering hipStreamSynchronize, whose interrupt-driven wake-up costs 0.03-0.8 ms per wait depending on the box
+  // (2.4 ms of the 7.7 ms driver-timed step).
+  uint64_t* pinned = nullptr;      // host address, 256 x u64
+  uint64_t* pinned_dev = nullptr;  // the same memory as the device sees it
+  uint64_t mail_seq = 0;           // last sequence number handed to a kernel
+  int wait_mode = 0;               // 0 = spin on the mailbox (default), 1 = hipStreamSynchronize (AH_WAIT=block)
+  // persistent self-cleaning device scratch (AH_SCRATCH_WORDS u64): [0,64) zero between calls (valid-row
+  // counters), [64,72) all-ones between calls (first-failing-position words); the finish kernels that read
+  // them back also restore them, so no per-call hipMemsetAsync
+  unsigned long long* scratch = nullptr;
+  std::vector<hipEvent_t> event_pool;  // recycled profiling events
   // deferred mode (ah_context_set_deferred): infallible fixed-shape kernels skip the end-of-call sync
   bool deferred = false;
   // profiling
@@ -70,13 +81,29 @@ ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...);
     if (_s != AH_OK) return _s; \
   } while (0)
 
+constexpr int AH_MAIL_FLAG = 255;     // index of the sequence word in ctx->pinned
+constexpr int AH_SCRATCH_WORDS = 72;   // 64 zero-state counters + 8 ones-state position words
+constexpr int AH_SCRATCH_ONES = 64;
+
+// enqueue a device -> pinned-slot copy (a one-wave kernel, stream-ordered like hipMemcpyAsync); `pinned_dst` must
+// point into ctx->pinned and `bytes` is a multiple of 8
+hipError_t ah_d2h(ah_context* ctx, void* pinned_dst, const void* dev_src, size_t bytes);
+// wait until everything enqueued on the context's stream so far has finished (a flag kernel + a host spin)
+hipError_t ah_stream_wait(ah_context* ctx);
+// both in one launch; `reset`: after reading, the device words are overwritten with `reset_value`
+hipError_t ah_d2h_wait(ah_context* ctx, void* pinned_dst, const void* dev_src, size_t bytes, bool reset = false,
+                       uint64_t reset_value = 0);
+// for kernels that post the mailbox themselves (ah_mail_post): reserve the next sequence number, wait for it
+static inline uint64_t ah_mail_next(ah_context* ctx) { return ++ctx->mail_seq; }
+hipError_t ah_mail_wait(ah_context* ctx, uint64_t seq);
+
 // Deferred mode plumbing.  A call that can run deferred hands AH_COUNT(ctx, &n) to the helpers that
 // would read a popcount back (nullptr = no read-back), ends with ah_end_of_call_sync() and reports
 // ah_nulls(): len - set_bits, or -1 when nothing was read back.  Scratch blocks go back to the
 // context's pool right after the enqueue: the pool is per context = per stream, so reuse is stream-ordered.
 #define AH_COUNT(ctx, ptr) ((ctx)->deferred ? nullptr : (ptr))
 static inline hipError_t ah_end_of_call_sync(ah_context* ctx) {
-  return ctx->deferred ? hipSuccess : hipStreamSynchronize(ctx->stream);
+  return ctx->deferred ? hipSuccess : ah_stream_wait(ctx);
 }
 static inline int64_t ah_nulls(const ah_context* ctx, int64_t len, int64_t set_bits) {
   return ctx->deferred ? -1 : len - set_bits;
@@ -96,10 +123,20 @@ struct ah_prof_scope {
   const char* name;
   ah_prof_scope(ah_context* c, const char* n) : ctx(c), name(n) {
     if (ctx->profiling) {
-      hipEventCreate(&a);
-      hipEventCreate(&b);
+      a = take_event();
+      b = take_event();
       hipEventRecord(a, ctx->stream);
     }
+  }
+  hipEvent_t take_event() {
+    hipEvent_t e = nullptr;
+    if (!ctx->event_pool.empty()) {
+      e = ctx->event_pool.back();
+      ctx->event_pool.pop_back();
+    } else {
+      hipEventCreate(&e);
+    }
+    return e;
   }
   ~ah_prof_scope() {
     if (ctx->profiling) {
@@ -203,6 +240,13 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
   return v;
 }
 
+
+// Mailbox post: ONE thread calls this after the payload stores it (or its wave) made to `mail` (= ctx->pinned_dev).
+// The fence orders the payload before the sequence word at system scope; the host polls the word.
+__device__ __forceinline__ void ah_mail_post(uint64_t* mail, uint64_t seq) {
+  __threadfence_system();
+  __hip_atomic_store(mail + AH_MAIL_FLAG, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // ---- shared bitmap machinery (bitmap.hip)
 enum ah_bitmap_opcode {

@@ -36,11 +36,10 @@ ah_status concat_strings(ah_context* ctx, int32_t n, const ah_array_view* pieces
       const ah_array_view& p = pieces[i0 + j];
       ctx->pinned[2 * j] = ctx->pinned[2 * j + 1] = 0;
       if (p.length == 0) continue;
-      AH_HIP(ctx, hipMemcpyAsync(ctx->pinned + 2 * j, p.offsets, ow, hipMemcpyDeviceToHost, ctx->stream));
-      AH_HIP(ctx, hipMemcpyAsync(ctx->pinned + 2 * j + 1, (const char*)p.offsets + p.length * ow, ow,
-                                 hipMemcpyDeviceToHost, ctx->stream));
+      AH_HIP(ctx, ah_d2h(ctx, ctx->pinned + 2 * j, p.offsets, ow));
+      AH_HIP(ctx, ah_d2h(ctx, ctx->pinned + 2 * j + 1, (const char*)p.offsets + p.length * ow, ow));
     }
-    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AH_HIP(ctx, ah_stream_wait(ctx));
     for (int j = 0; j < cnt; ++j) {
       first[i0 + j] = ow == 4 ? (int64_t)(int32_t)ctx->pinned[2 * j] : (int64_t)ctx->pinned[2 * j];
       last[i0 + j] = ow == 4 ? (int64_t)(int32_t)ctx->pinned[2 * j + 1] : (int64_t)ctx->pinned[2 * j + 1];
@@ -92,7 +91,7 @@ ah_status concat_strings(ah_context* ctx, int32_t n, const ah_array_view* pieces
     pos += p.length;
     base += last[i] - first[i];
   }
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = ah_stream_wait(ctx);
   if (st == AH_OK && e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "concat failed: %s", hipGetErrorString(e));
   if (st != AH_OK) return cleanup(st);
   out->offsets = oo;
@@ -188,7 +187,7 @@ extern "C" ah_status ah_concat(ah_context* ctx, int32_t n, const ah_array_view* 
     }
     pos += p->length;
   }
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = ah_stream_wait(ctx);
   if (st == AH_OK && e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "concat failed: %s", hipGetErrorString(e));
   if (st != AH_OK) {
     ah_out_free(ctx, ov, vbytes);
@@ -229,7 +228,7 @@ extern "C" ah_status ah_copy_rows_into(ah_context* ctx, const ah_array_view* src
   AH_TRY(ah_bitmap_set_bits(ctx, dst_validity, dst_row_offset, src->validity,
                             src->validity ? src->validity_bit_offset + offset : 0, len,
                             src->validity ? &set : nullptr));
-  if (!src->validity) AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!src->validity) AH_HIP(ctx, ah_stream_wait(ctx));
   if (appended_nulls) *appended_nulls = len - set;
   return AH_OK;
 }

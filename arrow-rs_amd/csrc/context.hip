@@ -4,6 +4,8 @@
 // and `BooleanBuffer::count_set_bits` (arrow-buffer/src/buffer/boolean.rs).
 #include "common.hpp"
 
+#include <ctime>
+
 ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...) {
   char buf[1024];
   va_list ap;
@@ -151,6 +153,95 @@ void ah_out_free(ah_context* ctx, void* p, size_t bytes) {
   ah_pool_free(ctx, p);
 }
 
+// ---------------------------------------------------------------- mailbox
+// One wave: copy `nwords` device words into the pinned slots, optionally restore the device words to
+// `reset_value`, then (seq != 0) publish the sequence word.  nwords == 0 is the pure "stream reached here" flag.
+__global__ void __launch_bounds__(64) mail_kernel(const unsigned long long* src, int nwords, uint64_t* dst,
+                                                  uint64_t* mail, uint64_t seq, int reset,
+                                                  unsigned long long reset_value) {
+  for (int i = threadIdx.x; i < nwords; i += 64) {
+    unsigned long long v = src[i];
+    __hip_atomic_store(dst + i, (uint64_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (reset) ((unsigned long long*)src)[i] = reset_value;
+  }
+  if (seq) {
+    __threadfence_system();  // every lane's payload stores, before lane 0's sequence store
+    if (threadIdx.x == 0) __hip_atomic_store(mail + AH_MAIL_FLAG, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
+
+hipError_t ah_mail_wait(ah_context* ctx, uint64_t seq) {
+  volatile uint64_t* flag = ctx->pinned + AH_MAIL_FLAG;
+  if (ctx->wait_mode == 1) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) < seq) e = hipErrorUnknown;
+    return e;
+  }
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (uint64_t spins = 1;; ++spins) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq) return hipSuccess;
+    cpu_relax();
+    if ((spins & 4095) == 0) {
+      timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+      if (us > 20000.0) {  // a long kernel, or a fault that will never post: ask the runtime
+        hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq ? hipSuccess : hipErrorUnknown;
+        if (q != hipErrorNotReady) return q;
+        if (us > 500000.0) {  // half a second of spinning: sleep in the runtime instead
+          hipError_t e = hipStreamSynchronize(ctx->stream);
+          if (e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) < seq) e = hipErrorUnknown;
+          return e;
+        }
+      }
+    }
+  }
+}
+
+static inline bool in_pinned(const ah_context* ctx, const void* p, size_t bytes) {
+  const char* b = (const char*)ctx->pinned;
+  return (const char*)p >= b && (const char*)p + bytes <= b + AH_MAIL_FLAG * 8;
+}
+
+hipError_t ah_d2h(ah_context* ctx, void* pinned_dst, const void* dev_src, size_t bytes) {
+  if (!in_pinned(ctx, pinned_dst, bytes) || (bytes & 7) || ((uintptr_t)dev_src & 7))
+    return hipMemcpyAsync(pinned_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  uint64_t* d = ctx->pinned_dev + ((uint64_t*)pinned_dst - ctx->pinned);
+  mail_kernel<<<1, 64, 0, ctx->stream>>>((const unsigned long long*)dev_src, (int)(bytes >> 3), d, ctx->pinned_dev, 0, 0, 0);
+  return hipGetLastError();
+}
+
+hipError_t ah_stream_wait(ah_context* ctx) {
+  if (ctx->wait_mode == 1) return hipStreamSynchronize(ctx->stream);
+  const uint64_t seq = ah_mail_next(ctx);
+  mail_kernel<<<1, 64, 0, ctx->stream>>>(nullptr, 0, ctx->pinned_dev, ctx->pinned_dev, seq, 0, 0);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ah_mail_wait(ctx, seq) : e;
+}
+
+hipError_t ah_d2h_wait(ah_context* ctx, void* pinned_dst, const void* dev_src, size_t bytes, bool reset,
+                       uint64_t reset_value) {
+  if (!in_pinned(ctx, pinned_dst, bytes) || (bytes & 7) || ((uintptr_t)dev_src & 7)) {
+    hipError_t e = hipMemcpyAsync(pinned_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && reset) e = hipMemsetAsync((void*)dev_src, (int)(reset_value & 0xFF), bytes, ctx->stream);
+    return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+  }
+  const uint64_t seq = ah_mail_next(ctx);
+  uint64_t* d = ctx->pinned_dev + ((uint64_t*)pinned_dst - ctx->pinned);
+  mail_kernel<<<1, 64, 0, ctx->stream>>>((const unsigned long long*)dev_src, (int)(bytes >> 3), d, ctx->pinned_dev, seq,
+                                         reset ? 1 : 0, reset_value);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ah_mail_wait(ctx, seq) : e;
+}
+
 // ---------------------------------------------------------------- context
 extern "C" ah_status ah_context_create(int device, ah_context** out) {
   if (!out) return AH_INVALID_ARGUMENT;
@@ -167,7 +258,24 @@ extern "C" ah_status ah_context_create(int device, ah_context** out) {
     return AH_HIP_ERROR;
   }
   c->stream = c->own_stream;
-  if (hipHostMalloc((void**)&c->pinned, 256 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+  // mapped + coherent: kernels store results straight into these slots and the host polls them
+  if (hipHostMalloc((void**)&c->pinned, 256 * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    hipStreamDestroy(c->own_stream);
+    delete c;
+    return AH_HIP_ERROR;
+  }
+  memset(c->pinned, 0, 256 * sizeof(uint64_t));
+  void* dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, c->pinned, 0) != hipSuccess || !dp) dp = c->pinned;  // unified addressing
+  c->pinned_dev = (uint64_t*)dp;
+  const char* wm = getenv("AH_WAIT");
+  c->wait_mode = (wm && strcmp(wm, "block") == 0) ? 1 : 0;
+  uint64_t init[AH_SCRATCH_WORDS];
+  for (int i = 0; i < AH_SCRATCH_WORDS; ++i) init[i] = i < AH_SCRATCH_ONES ? 0ull : ~0ull;
+  if (hipMalloc((void**)&c->scratch, sizeof init) != hipSuccess ||
+      hipMemcpy(c->scratch, init, sizeof init, hipMemcpyHostToDevice) != hipSuccess) {
+    if (c->scratch) hipFree(c->scratch);
+    hipHostFree(c->pinned);
     hipStreamDestroy(c->own_stream);
     delete c;
     return AH_HIP_ERROR;
@@ -183,6 +291,8 @@ extern "C" void ah_context_destroy(ah_context* ctx) {
   ah_profile_reset(ctx);
   ah_pool_trim(ctx);
   for (auto& kv : ctx->pool_live) hipFree(kv.first);
+  for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
+  if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -194,7 +304,11 @@ extern "C" void ah_context_set_allocator(ah_context* ctx, ah_alloc_fn a, ah_free
   ctx->user = user;
 }
 extern "C" void ah_context_set_stream(ah_context* ctx, void* s) {
-  ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+  hipStream_t next = s ? (hipStream_t)s : ctx->own_stream;
+  // pooled scratch and released outputs are reused in STREAM order; when the stream really changes, work still
+  // running on the old one could otherwise overlap a block's next owner: drain the old stream first
+  if (next != ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  ctx->stream = next;
 }
 extern "C" void* ah_context_stream(ah_context* ctx) { return (void*)ctx->stream; }
 extern "C" void ah_context_set_deferred(ah_context* ctx, int32_t on) {
@@ -276,8 +390,8 @@ static void prof_drain(ah_context* ctx, ah_prof_entry& e) {
       e.total_ms += ms;
       e.launches += 1;
     }
-    hipEventDestroy(pr.first);
-    hipEventDestroy(pr.second);
+    ctx->event_pool.push_back(pr.first);
+    ctx->event_pool.push_back(pr.second);
   }
   e.pending.clear();
 }
@@ -344,8 +458,7 @@ extern "C" ah_status ah_count_set_bits(ah_context* ctx, const uint8_t* bits, int
   BitView bv = make_bitview(bits, bit_offset);
   popcount_partial_kernel<<<grid, 256, 0, ctx->stream>>>(bv, len, part);
   sum_u64_kernel<<<1, 1024, 0, ctx->stream>>>(part, grid, part + grid);
-  hipError_t e = hipMemcpyAsync(ctx->pinned, part + grid, 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = ah_d2h_wait(ctx, ctx->pinned, part + grid, 8);
   ah_pool_free(ctx, part);
   AH_HIP(ctx, e);
   *count = (int64_t)ctx->pinned[0];

@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(1024) filter_count_kernel(BitView mask, BitVie
 __global__ void __launch_bounds__(1024) filter_group_scan_kernel(const uint32_t* group_total,
                                                                  int64_t ngroups,
                                                                  unsigned long long* group_prefix,
-                                                                 unsigned long long* total_out) {
+                                                                 unsigned long long* total_out, uint64_t* mail,
+                                                                 uint64_t seq) {
   __shared__ unsigned long long s_wave[16];
   __shared__ unsigned long long s_carry;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -108,7 +109,25 @@ __global__ void __launch_bounds__(1024) filter_group_scan_kernel(const uint32_t*
     if (t == 1023) s_carry = wbase + incl;
     __syncthreads();
   }
-  if (t == 0) *total_out = s_carry;
+  if (t == 0) {
+    *total_out = s_carry;
+    if (mail) {  // K goes straight to the host's pinned slot: the only number the host waits for
+      __hip_atomic_store(mail, (uint64_t)s_carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      ah_mail_post(mail, seq);
+    }
+  }
+}
+
+// after the scatter: fold the VALID_SLOTS counters into one number for the host, leave them zero for the next
+// call (ctx->scratch is self-cleaning: no per-call memset), publish.  mail == nullptr (deferred): clean only.
+__global__ void __launch_bounds__(64) filter_finish_kernel(unsigned long long* slots, uint64_t* mail, uint64_t seq) {
+  unsigned long long v = slots[threadIdx.x];
+  slots[threadIdx.x] = 0;
+  v = wave_reduce_add64(v);
+  if (threadIdx.x == 0 && mail) {
+    __hip_atomic_store(mail, (uint64_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    ah_mail_post(mail, seq);
+  }
 }
 
 // ------------------------------------------------------------------ K3
@@ -408,15 +427,16 @@ extern "C" ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_v
   uint32_t* group_total = (uint32_t*)(base + b_chunk);
   p->group_prefix = (unsigned long long*)(base + b_chunk + b_gt);
   unsigned long long* total = (unsigned long long*)(base + b_chunk + b_gt + b_gp);
+  const uint64_t seq = ah_mail_next(ctx);
   {
     ah_prof_scope ps(ctx, "filter_count");
     filter_count_kernel<<<(unsigned)ngroups, 1024, 0, ctx->stream>>>(p->mask, p->mask_valid, p->len,
                                                                     p->chunk_prefix, group_total);
     filter_group_scan_kernel<<<1, 1024, 0, ctx->stream>>>(group_total, ngroups, p->group_prefix,
-                                                          total);
+                                                          total, ctx->pinned_dev, seq);
   }
-  hipError_t e = hipMemcpyAsync(ctx->pinned, total, 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
   if (e != hipSuccess) {
     ah_pool_free(ctx, p->block);
     delete p;
@@ -442,14 +462,8 @@ static ah_status compact_bits(ah_context* ctx, const ah_filter_predicate* p, Bit
   size_t bytes = ah_bitmap_bytes(p->count);
   void* ob = nullptr;
   AH_TRY(ah_out_alloc(ctx, bytes, &ob));
-  unsigned long long* slots = nullptr;
-  ah_status st = ah_pool_alloc(ctx, VALID_SLOTS * 8, (void**)&slots);
-  if (st != AH_OK) {
-    ah_out_free(ctx, ob, bytes);
-    return st;
-  }
+  unsigned long long* slots = ctx->scratch;  // zero between calls (filter_finish_kernel restores it)
   hipMemsetAsync(ob, 0, bytes, ctx->stream);
-  hipMemsetAsync(slots, 0, VALID_SLOTS * 8, ctx->stream);
   ScatterArgs a{};
   a.values = nullptr;
   a.mask = p->mask;
@@ -463,22 +477,21 @@ static ah_status compact_bits(ah_context* ctx, const ah_filter_predicate* p, Bit
   a.valid_slots = slots;
   launch_scatter<true>(ctx, 0, a, false);
   if (defer) {  // no read-back: the caller reports the count as unknown
-    ah_pool_free(ctx, slots);
+    filter_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, nullptr, 0);
     *set_bits = -1;
     *out_bits = (uint8_t*)ob;
     *out_bytes = bytes;
     return AH_OK;
   }
-  hipError_t e = hipMemcpyAsync(ctx->pinned, slots, VALID_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  ah_pool_free(ctx, slots);
+  const uint64_t seq = ah_mail_next(ctx);
+  filter_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, ctx->pinned_dev, seq);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
   if (e != hipSuccess) {
     ah_out_free(ctx, ob, bytes);
     return ah_fail(ctx, AH_HIP_ERROR, "filter_bits failed: %s", hipGetErrorString(e));
   }
-  int64_t setb = 0;
-  for (int i = 0; i < VALID_SLOTS; ++i) setb += (int64_t)ctx->pinned[i];
-  *set_bits = setb;
+  *set_bits = (int64_t)ctx->pinned[0];
   *out_bits = (uint8_t*)ob;
   *out_bytes = bytes;
   return AH_OK;
@@ -511,7 +524,7 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
     void* offs = nullptr;
     AH_TRY(ah_out_alloc(ctx, ow, &offs));
     hipMemsetAsync(offs, 0, ow, ctx->stream);
-    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AH_HIP(ctx, ah_stream_wait(ctx));
     out->offsets = offs;
     out->offsets_bytes = (int64_t)ow;
     return AH_OK;
@@ -649,14 +662,12 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
   if (has_valid) {
     bbytes = ah_bitmap_bytes(K);
     ah_status st = ah_out_alloc(ctx, bbytes, &ob);
-    if (st == AH_OK) st = ah_pool_alloc(ctx, VALID_SLOTS * 8, (void**)&slots);
     if (st != AH_OK) {
       ah_out_free(ctx, ov, vbytes);
-      ah_out_free(ctx, ob, bbytes);
       return st;
     }
+    slots = ctx->scratch;  // zero between calls (filter_finish_kernel restores it)
     hipMemsetAsync(ob, 0, bbytes, ctx->stream);
-    hipMemsetAsync(slots, 0, VALID_SLOTS * 8, ctx->stream);
   }
   ScatterArgs a{};
   a.values = values->values;
@@ -675,11 +686,17 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
     if (has_valid) launch_scatter<true>(ctx, width, a, skip);
     else launch_scatter<false>(ctx, width, a, skip);
   }
+  // ONE host wait for the whole scatter: the finish kernel folds the valid-row counters, restores them to
+  // zero and posts the mailbox (no D2H copy engine, no hipStreamSynchronize)
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess && has_valid && !defer)
-    e = hipMemcpyAsync(ctx->pinned, slots, VALID_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess && !defer) e = hipStreamSynchronize(ctx->stream);
-  ah_pool_free(ctx, slots);
+  if (e == hipSuccess && has_valid) {
+    const uint64_t seq = defer ? 0 : ah_mail_next(ctx);
+    filter_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, defer ? nullptr : ctx->pinned_dev, seq);
+    e = hipGetLastError();
+    if (e == hipSuccess && !defer) e = ah_mail_wait(ctx, seq);
+  } else if (e == hipSuccess && !defer) {
+    e = ah_stream_wait(ctx);
+  }
   if (e != hipSuccess) {
     ah_out_free(ctx, ov, vbytes);
     ah_out_free(ctx, ob, bbytes);
@@ -693,9 +710,7 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
     out->validity_bytes = (int64_t)bbytes;
     out->null_count = -1;
   } else if (has_valid) {
-    int64_t validc = 0;
-    for (int i = 0; i < VALID_SLOTS; ++i) validc += (int64_t)ctx->pinned[i];
-    int64_t nulls = K - validc;
+    int64_t nulls = K - (int64_t)ctx->pinned[0];
     if (nulls == 0) {  // filter_nulls :523-525 -> None
       ah_out_free(ctx, ob, bbytes);
     } else {
@@ -733,11 +748,7 @@ extern "C" ah_status ah_filter_predicate_apply_into(ah_context* ctx, const ah_fi
   int64_t in_nulls = 0;
   AH_TRY(ah_resolve_null_count(ctx, values, &in_nulls));
   const bool has_valid = values->validity && in_nulls > 0;
-  unsigned long long* slots = nullptr;
-  if (has_valid) {
-    AH_TRY(ah_pool_alloc(ctx, VALID_SLOTS * 8, (void**)&slots));
-    hipMemsetAsync(slots, 0, VALID_SLOTS * 8, ctx->stream);
-  }
+  unsigned long long* slots = has_valid ? ctx->scratch : nullptr;  // zero between calls
   ScatterArgs a{};
   a.values = values->values;
   a.mask = p->mask;
@@ -760,17 +771,17 @@ extern "C" ah_status ah_filter_predicate_apply_into(ah_context* ctx, const ah_fi
   ah_status st = AH_OK;
   if (e == hipSuccess && !has_valid)  // source without nulls: the appended rows are all valid
     st = ah_bitmap_set_bits(ctx, dst_validity, dst_row_offset, nullptr, 0, K, nullptr);
-  if (e == hipSuccess && has_valid)
-    e = hipMemcpyAsync(ctx->pinned, slots, VALID_SLOTS * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  ah_pool_free(ctx, slots);
+  if (e == hipSuccess && has_valid) {
+    const uint64_t seq = ah_mail_next(ctx);
+    filter_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, ctx->pinned_dev, seq);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
+  } else if (e == hipSuccess) {
+    e = ah_stream_wait(ctx);
+  }
   if (st != AH_OK) return st;
   if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "fused filter copy failed: %s", hipGetErrorString(e));
-  if (has_valid && appended_nulls) {
-    int64_t validc = 0;
-    for (int i = 0; i < VALID_SLOTS; ++i) validc += (int64_t)ctx->pinned[i];
-    *appended_nulls = K - validc;
-  }
+  if (has_valid && appended_nulls) *appended_nulls = K - (int64_t)ctx->pinned[0];
   return AH_OK;
 }
 

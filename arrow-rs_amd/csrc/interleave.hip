@@ -133,8 +133,7 @@ extern "C" ah_status ah_interleave(ah_context* ctx, int32_t n_arrays, const ah_a
 #undef AH_IL
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, slots, 65 * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_d2h_wait(ctx, ctx->pinned, slots, 65 * 8);
   if (e != hipSuccess) return cleanup(ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in interleave", hipGetErrorString(e)));
   if (ctx->pinned[64] != ~0ull) {  // slice indexing panics in the reference (`arrays[a].value(r)`)
     const int64_t pos = (int64_t)ctx->pinned[64];

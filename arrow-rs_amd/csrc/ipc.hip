@@ -583,9 +583,8 @@ extern "C" ah_status ah_ipc_encode_batch(ah_context* ctx, int32_t n_cols, const 
     if (is_str) {
       const int ow = t == AH_UTF8 ? 4 : 8;
       if (n > 0) {
-        AH_HIP(ctx, hipMemcpyAsync(ctx->pinned, a.offsets, ow, hipMemcpyDeviceToHost, ctx->stream));
-        AH_HIP(ctx, hipMemcpyAsync(ctx->pinned + 1, (const char*)a.offsets + n * ow, ow, hipMemcpyDeviceToHost, ctx->stream));
-        AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        AH_HIP(ctx, ah_d2h(ctx, ctx->pinned, a.offsets, ow));
+        AH_HIP(ctx, ah_d2h_wait(ctx, ctx->pinned + 1, (const char*)a.offsets + n * ow, ow));
         k.first = ow == 4 ? (int64_t)(int32_t)ctx->pinned[0] : (int64_t)ctx->pinned[0];
         k.last = ow == 4 ? (int64_t)(int32_t)ctx->pinned[1] : (int64_t)ctx->pinned[1];
       }
@@ -677,7 +676,7 @@ extern "C" ah_status ah_ipc_encode_batch(ah_context* ctx, int32_t n_cols, const 
     }
   }
   {
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = ah_stream_wait(ctx);
     if (e != hipSuccess) return hip_fail(e);
   }
 
@@ -795,7 +794,7 @@ extern "C" ah_status ah_ipc_decode_batch(ah_context* ctx, const uint8_t* msg, in
       if (st != AH_OK) return fail(st);
     }
   }
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = ah_stream_wait(ctx);
   if (e != hipSuccess) return fail(ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in IPC decode", hipGetErrorString(e)));
   if (!v.ok) return fail(ah_fail(ctx, AH_PARSE_ERROR, "Unable to get root as message: truncated flatbuffer"));
   *num_rows = rows;

@@ -198,7 +198,7 @@ extern "C" ah_status ah_string_like(ah_context* ctx, ah_like_op op, const ah_arr
     }
     hipMemsetAsync(vals, 0, bytes, ctx->stream);
     hipMemsetAsync(nb, 0, bytes, ctx->stream);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = ah_stream_wait(ctx);
     if (e != hipSuccess) {
       ah_out_free(ctx, vals, bytes);
       ah_out_free(ctx, nb, bytes);
@@ -217,7 +217,7 @@ extern "C" ah_status ah_string_like(ah_context* ctx, ah_like_op op, const ah_arr
   {
     uint8_t raw[16];
     hipError_t e = hipMemcpyAsync(raw, pattern->offsets, 2 * ow, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ah_stream_wait(ctx);
     if (e != hipSuccess) {
       ah_out_free(ctx, vals, bytes);
       return ah_fail(ctx, AH_HIP_ERROR, "reading the pattern failed: %s", hipGetErrorString(e));
@@ -234,7 +234,7 @@ extern "C" ah_status ah_string_like(ah_context* ctx, ah_like_op op, const ah_arr
   std::string pat((size_t)(po[1] - po[0]), '\0');
   if (!pat.empty()) {
     hipError_t e = hipMemcpyAsync(&pat[0], (const uint8_t*)pattern->values + po[0], pat.size(), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ah_stream_wait(ctx);
     if (e != hipSuccess) {
       ah_out_free(ctx, vals, bytes);
       return ah_fail(ctx, AH_HIP_ERROR, "reading the pattern failed: %s", hipGetErrorString(e));
@@ -274,7 +274,7 @@ extern "C" ah_status ah_string_like(ah_context* ctx, ah_like_op op, const ah_arr
     st = ah_bitmap_op(ctx, BM_COPY, make_bitview(values->validity, values->validity_bit_offset), BitView{nullptr, 0},
                       BitView{nullptr, 0}, len, nb, &set);
   hipError_t e = hipGetLastError();
-  if (st == AH_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // prog (host vector) must outlive the H2D copy
+  if (st == AH_OK && e == hipSuccess) e = ah_stream_wait(ctx);  // prog (host vector) must outlive the H2D copy
   ah_pool_free(ctx, dprog);
   if (st != AH_OK || e != hipSuccess) {
     ah_out_free(ctx, vals, bytes);
@@ -334,7 +334,7 @@ extern "C" ah_status ah_string_length(ah_context* ctx, const ah_array_view* valu
     st = ah_bitmap_op(ctx, BM_COPY, make_bitview(values->validity, values->validity_bit_offset), BitView{nullptr, 0},
                       BitView{nullptr, 0}, len, nb, &set);
   hipError_t e = hipGetLastError();
-  if (st == AH_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (st == AH_OK && e == hipSuccess) e = ah_stream_wait(ctx);
   if (st != AH_OK || e != hipSuccess) {
     ah_out_free(ctx, ov, vbytes);
     ah_out_free(ctx, nb, bbytes);

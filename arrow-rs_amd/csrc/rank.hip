@@ -143,13 +143,13 @@ extern "C" ah_status ah_rank(ah_context* ctx, const ah_array_view* v, int32_t de
     rank_fill_kernel<<<grid_for(m), 256, 0, ctx->stream>>>(pp + valid_start, m, (const uint32_t*)ends.out.values, n_ends,
                                                          (uint32_t)valid_start, (uint32_t*)ranks);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the temporaries are released at the end of this scope
+    if (e == hipSuccess) e = ah_stream_wait(ctx);  // the temporaries are released at the end of this scope
     if (e != hipSuccess) return fail_free(ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in rank", hipGetErrorString(e)));
   }
   if (nulls > 0) {
     rank_const_kernel<<<grid_for(nulls), 256, 0, ctx->stream>>>(pp + null_start, nulls, null_rank, (uint32_t*)ranks);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ah_stream_wait(ctx);
     if (e != hipSuccess) return fail_free(ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in rank", hipGetErrorString(e)));
   }
   out->length = n;

@@ -239,8 +239,7 @@ ah_status build_prefix(ah_context* ctx, BitView m, int64_t len, Prefix* p) {
   hipLaunchKernelGGL(sel_count_kernel, dim3(p->nblocks), dim3(SEL_BLOCK), 0, ctx->stream, m, len, nwords, p->counts);
   hipLaunchKernelGGL(sel_scan_kernel, dim3(1), dim3(SEL_BLOCK), 0, ctx->stream, p->counts, p->nblocks, p->prefix);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, p->prefix + p->nblocks, 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_d2h_wait(ctx, ctx->pinned, p->prefix + p->nblocks, 8);
   if (e != hipSuccess) {
     ah_pool_free(ctx, mem);
     p->counts = nullptr;
@@ -311,7 +310,7 @@ extern "C" ah_status ah_selection_and_then(ah_context* ctx, const ah_array_view*
   const int64_t nwords = ah_ceil_div(len, 64);
   if (other_true == 0) {  // `BooleanBuffer::new_unset(mask.len())` (:401-403)
     hipError_t e = hipMemsetAsync(out->values, 0, (size_t)out->values_bytes, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = ah_stream_wait(ctx);
     return done(e == hipSuccess ? AH_OK : ah_fail(ctx, AH_HIP_ERROR, "HIP error %s", hipGetErrorString(e)));
   }
   {
@@ -320,7 +319,7 @@ extern "C" ah_status ah_selection_and_then(ah_context* ctx, const ah_array_view*
                        other->length, p.prefix, (unsigned long long*)out->values);
   }
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_stream_wait(ctx);
   return done(e == hipSuccess ? AH_OK : ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in selection and_then", hipGetErrorString(e)));
 }
 
@@ -342,7 +341,7 @@ extern "C" ah_status ah_selection_combine(ah_context* ctx, int32_t op, const ah_
                      make_bitview(shorter->values, shorter->values_bit_offset), shorter->length, op, nwords,
                      (unsigned long long*)out->values);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_stream_wait(ctx);
   if (e != hipSuccess) {
     ah_array_release(ctx, out);
     return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in selection combine", hipGetErrorString(e));
@@ -379,7 +378,7 @@ extern "C" ah_status ah_selection_boundaries(ah_context* ctx, const ah_array_vie
                            (const unsigned long long*)edges, nwords, p.prefix, (int64_t*)idx);
       }
       hipError_t e = hipGetLastError();
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e == hipSuccess) e = ah_stream_wait(ctx);
       if (e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in selection boundaries", hipGetErrorString(e));
     }
   }
@@ -401,7 +400,7 @@ extern "C" ah_status ah_selection_from_boundaries(ah_context* ctx, const ah_arra
   hipLaunchKernelGGL(sel_from_bounds_kernel, dim3((unsigned)ah_ceil_div(nwords, SEL_BLOCK)), dim3(SEL_BLOCK), 0, ctx->stream,
                      (const int64_t*)bounds->values, bounds->length, total_rows, nwords, (unsigned long long*)out->values);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_stream_wait(ctx);
   if (e != hipSuccess) {
     ah_array_release(ctx, out);
     return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in selection from_boundaries", hipGetErrorString(e));
@@ -430,8 +429,7 @@ extern "C" ah_status ah_selection_find_nth_set_bit(ah_context* ctx, const ah_arr
   hipLaunchKernelGGL(sel_find_nth_kernel, dim3(1), dim3(1), 0, ctx->stream, m, len, ah_ceil_div(len, 64), p.prefix, p.nblocks,
                      start, (unsigned long long)n, dpos);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, dpos, 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_d2h_wait(ctx, ctx->pinned, dpos, 8);
   ah_pool_free(ctx, p.counts);
   if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in find_nth_set_bit", hipGetErrorString(e));
   *pos = (int64_t)ctx->pinned[0];

@@ -359,7 +359,7 @@ ah_status radix_sort_pairs(ah_context* ctx, Scratch& sc, KT** keys, uint32_t** i
                      dim3(RS_BLOCK), 0, ctx->stream, *keys, m, census);
   std::vector<unsigned long long> host((size_t)PASSES * 256);
   AH_HIP(ctx, hipMemcpyAsync(host.data(), census, PASSES * 256 * 8, hipMemcpyDeviceToHost, ctx->stream));
-  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  AH_HIP(ctx, ah_stream_wait(ctx));
   KT* kin = *keys;
   uint32_t* iin = *idx;
   for (int p = 0; p < PASSES; ++p) {
@@ -502,7 +502,7 @@ extern "C" ah_status ah_sort_to_indices(ah_context* ctx, const ah_array_view* v,
   const int64_t a = std::min(lim, n_first), b = lim - a;
   if (a > 0) e = hipMemcpyAsync(o, first, (size_t)a * 4, hipMemcpyDeviceToDevice, ctx->stream);
   if (e == hipSuccess && b > 0) e = hipMemcpyAsync(o + a, second, (size_t)b * 4, hipMemcpyDeviceToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_stream_wait(ctx);
   if (e != hipSuccess) {
     ah_out_free(ctx, res, (size_t)lim * 4);
     return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in sort_to_indices", hipGetErrorString(e));
@@ -544,7 +544,7 @@ ah_status sort_rows_by_column(ah_context* ctx, const ah_array_view* v, bool desc
     else hipLaunchKernelGGL(string_max_len_kernel<int32_t>, rgrid, dim3(256), 0, ctx->stream, (const int32_t*)v->offsets, n, dmax);
     unsigned long long max_len = 0;
     AH_HIP(ctx, hipMemcpyAsync(&max_len, dmax, 8, hipMemcpyDeviceToHost, ctx->stream));
-    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AH_HIP(ctx, ah_stream_wait(ctx));
     uint64_t* keys = nullptr;
     AH_TRY(sc.get((size_t)n * 8, (void**)&keys));
     const uint8_t* data = (const uint8_t*)v->values;
@@ -630,7 +630,7 @@ static ah_status lexsort_chain(ah_context* ctx, int32_t n_cols, const ah_array_v
   void* res = nullptr;
   AH_TRY(ah_out_alloc(ctx, (size_t)lim * 4, &res));
   hipError_t e = hipMemcpyAsync(res, idx, (size_t)lim * 4, hipMemcpyDeviceToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_stream_wait(ctx);
   if (e != hipSuccess) {
     ah_out_free(ctx, res, (size_t)lim * 4);
     return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in lexsort_to_indices", hipGetErrorString(e));

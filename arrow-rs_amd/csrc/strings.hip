@@ -226,8 +226,7 @@ ah_status ranges_to_strings_t(ah_context* ctx, const uint8_t* src, const OFF* st
     int g = (int)std::min<int64_t>(ah_ceil_div(k + 1, 256), 4096);
     range_scan_add_kernel<OFF><<<g, 256, 0, ctx->stream>>>((OFF*)offs, k, block_base, total);
   }
-  hipError_t e = hipMemcpyAsync(ctx->pinned, total, 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = ah_d2h_wait(ctx, ctx->pinned, total, 8);
   ah_pool_free(ctx, scratch);
   if (e != hipSuccess) {
     ah_out_free(ctx, offs, ob);
@@ -252,7 +251,7 @@ ah_status ranges_to_strings_t(ah_context* ctx, const uint8_t* src, const OFF* st
                                                                                    (uint8_t*)data);
   }
   e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_stream_wait(ctx);
   if (e != hipSuccess) {
     ah_out_free(ctx, offs, ob);
     ah_out_free(ctx, data, (size_t)total_bytes);
@@ -320,7 +319,7 @@ ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_a
     void* offs = nullptr;
     AH_TRY(ah_out_alloc(ctx, ow, &offs));
     hipMemsetAsync(offs, 0, ow, ctx->stream);
-    AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AH_HIP(ctx, ah_stream_wait(ctx));
     out->offsets = offs;
     out->offsets_bytes = (int64_t)ow;
     return AH_OK;
@@ -361,8 +360,7 @@ ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_a
                                              (int32_t*)starts, (int32_t*)ends, counters);
   }
   if (st == AH_OK) {
-    hipError_t e = hipMemcpyAsync(ctx->pinned + 16, counters, 16, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = ah_d2h_wait(ctx, ctx->pinned + 16, counters, 16);
     if (e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "take ranges failed: %s", hipGetErrorString(e));
   }
   ah_pool_free(ctx, counters);

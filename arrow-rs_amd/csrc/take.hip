@@ -166,10 +166,15 @@ __global__ void __launch_bounds__(256) check_bounds_kernel(const IDX* idx, BitVi
   if ((threadIdx.x & 63) == 0 && bad != ~0ull) atomicMin(first_bad, bad);
 }
 
-__global__ void __launch_bounds__(1024) sum_u64_kernel2(const unsigned long long* in, int64_t n,
-                                                        unsigned long long* out) {
+// After the gather: mail[0] = first out-of-bounds position (~0 = none), mail[1] = valid output rows; the
+// position word goes back to ~0 for the next call (ctx->scratch is self-cleaning) and the mailbox is posted —
+// the host's ONE wait of the call.  `in` == nullptr: no validity was produced.
+__global__ void __launch_bounds__(1024) take_finish_kernel(const unsigned long long* in, int64_t n,
+                                                           unsigned long long* first_oob, uint64_t* mail,
+                                                           uint64_t seq) {
   unsigned long long acc = 0;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) acc += in[i];
+  if (in)
+    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += in[i];
   acc = wave_reduce_add64(acc);
   __shared__ unsigned long long s[16];
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
@@ -177,7 +182,11 @@ __global__ void __launch_bounds__(1024) sum_u64_kernel2(const unsigned long long
   if (threadIdx.x == 0) {
     unsigned long long tot = 0;
     for (int i = 0; i < 16; i++) tot += s[i];
-    *out = tot;
+    const unsigned long long oob = *first_oob;
+    *first_oob = ~0ull;
+    __hip_atomic_store(mail, (uint64_t)oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(mail + 1, (uint64_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    ah_mail_post(mail, seq);
   }
 }
 
@@ -232,7 +241,7 @@ ah_status read_index(ah_context* ctx, const ah_array_view* ind, int64_t pos, int
   uint64_t raw = 0;
   AH_HIP(ctx, hipMemcpyAsync(&raw, (const char*)ind->values + pos * w, w, hipMemcpyDeviceToHost,
                              ctx->stream));
-  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  AH_HIP(ctx, ah_stream_wait(ctx));
   switch (ind->type) {
     case AH_INT8: *sval = (int8_t)raw; *uval = (uint32_t)(int32_t)(int8_t)raw; break;
     case AH_INT16: *sval = (int16_t)raw; *uval = (uint32_t)(int32_t)(int16_t)raw; break;
@@ -267,11 +276,13 @@ extern "C" ah_status ah_take(ah_context* ctx, const ah_array_view* values,
   BitView ivalid = indices->validity ? make_bitview(indices->validity, indices->validity_bit_offset)
                                      : BitView{nullptr, 0};
 
-  unsigned long long* flags = nullptr;  // [0] first_oob / first_bad
+  unsigned long long* flags = nullptr;  // per-block valid-row counts
   const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(n, 1024), 256 * 16));
   AH_TRY(ah_pool_alloc(ctx, (size_t)(grid + 4) * 8, (void**)&flags));
-  unsigned long long* block_valid = flags + 2;
-  unsigned long long* total_valid = flags + 2 + grid;
+  unsigned long long* block_valid = flags;
+  // first out-of-bounds / first bad position: a persistent word that is all-ones between calls (the kernels
+  // that read it back restore it), so no per-call memset
+  unsigned long long* first_pos = ctx->scratch + AH_SCRATCH_ONES;
 
   // TakeOptions::check_bounds (take.rs:97-99, 167-209)
   if (check_bounds && n > 0) {
@@ -283,20 +294,18 @@ extern "C" ah_status ah_take(ah_context* ctx, const ah_array_view* values,
       representable = (uint64_t)values->length <= maxv;
     }
     if (representable) {
-      hipMemsetAsync(flags, 0xFF, 8, ctx->stream);
       int g = (int)std::min<int64_t>(ah_ceil_div(n, 256), 4096);
       switch (indices->type) {
-        case AH_INT8: launch_cb<int8_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
-        case AH_UINT8: launch_cb<uint8_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
-        case AH_INT16: launch_cb<int16_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
-        case AH_UINT16: launch_cb<uint16_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
-        case AH_INT32: launch_cb<int32_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
-        case AH_UINT32: launch_cb<uint32_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
-        case AH_INT64: launch_cb<int64_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
-        default: launch_cb<uint64_t>(ctx, indices, ivalid, values->length, flags, g, idx_nulls == 0); break;
+        case AH_INT8: launch_cb<int8_t>(ctx, indices, ivalid, values->length, first_pos, g, idx_nulls == 0); break;
+        case AH_UINT8: launch_cb<uint8_t>(ctx, indices, ivalid, values->length, first_pos, g, idx_nulls == 0); break;
+        case AH_INT16: launch_cb<int16_t>(ctx, indices, ivalid, values->length, first_pos, g, idx_nulls == 0); break;
+        case AH_UINT16: launch_cb<uint16_t>(ctx, indices, ivalid, values->length, first_pos, g, idx_nulls == 0); break;
+        case AH_INT32: launch_cb<int32_t>(ctx, indices, ivalid, values->length, first_pos, g, idx_nulls == 0); break;
+        case AH_UINT32: launch_cb<uint32_t>(ctx, indices, ivalid, values->length, first_pos, g, idx_nulls == 0); break;
+        case AH_INT64: launch_cb<int64_t>(ctx, indices, ivalid, values->length, first_pos, g, idx_nulls == 0); break;
+        default: launch_cb<uint64_t>(ctx, indices, ivalid, values->length, first_pos, g, idx_nulls == 0); break;
       }
-      hipError_t e = hipMemcpyAsync(ctx->pinned, flags, 8, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      hipError_t e = ah_d2h_wait(ctx, ctx->pinned, first_pos, 8, true, ~0ull);
       if (e != hipSuccess) {
         ah_pool_free(ctx, flags);
         return ah_fail(ctx, AH_HIP_ERROR, "check_bounds failed: %s", hipGetErrorString(e));
@@ -351,8 +360,6 @@ extern "C" ah_status ah_take(ah_context* ctx, const ah_array_view* values,
     ah_pool_free(ctx, flags);
     return st;
   }
-  hipMemsetAsync(flags, 0xFF, 8, ctx->stream);
-
   TakeArgs a{};
   a.values = values->values;
   a.vbits = width == 0 ? make_bitview(values->values, values->values_bit_offset) : BitView{nullptr, 0};
@@ -365,18 +372,18 @@ extern "C" ah_status ah_take(ah_context* ctx, const ah_array_view* values,
   a.out_values = ov;
   a.out_valid = (unsigned long long*)ob;
   a.block_valid = block_valid;
-  a.first_oob = flags;
+  a.first_oob = first_pos;
   {
     ah_prof_scope ps(ctx, "take_gather");
     st = launch_take(ctx, width, indices->type, a, out_valid, grid);
   }
   hipError_t e = hipSuccess;
   if (st == AH_OK) {
-    if (out_valid) sum_u64_kernel2<<<1, 1024, 0, ctx->stream>>>(block_valid, grid, total_valid);
-    e = hipMemcpyAsync(ctx->pinned, flags, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && out_valid)
-      e = hipMemcpyAsync(ctx->pinned + 1, total_valid, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    const uint64_t seq = ah_mail_next(ctx);
+    take_finish_kernel<<<1, 1024, 0, ctx->stream>>>(out_valid ? block_valid : nullptr, grid, first_pos,
+                                                    ctx->pinned_dev, seq);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
   }
   ah_pool_free(ctx, flags);
   if (st != AH_OK || e != hipSuccess) {

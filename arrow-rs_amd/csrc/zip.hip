@@ -158,8 +158,7 @@ extern "C" ah_status ah_zip(ah_context* ctx, const ah_array_view* mask, const ah
     }
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(ctx->pinned, slots, 64 * 8, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = ah_d2h_wait(ctx, ctx->pinned, slots, 64 * 8);
   if (e != hipSuccess) return cleanup(ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in zip", hipGetErrorString(e)));
   int64_t valid = 0;
   for (int i = 0; i < 64; ++i) valid += (int64_t)ctx->pinned[i];

@@ -567,6 +567,8 @@ def main():
                                         egress_GBps=round(ex["bytes_to_each_peer"] * ex["peers"] / secs / 1e9, 2),
                                         ingress_GBps=round(ex["bytes_received"] / secs / 1e9, 2))
         line["kernel_avg_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
+        # what the step spends outside its profiled kernels (host waits, launches, small helper kernels)
+        line["host_gap_ms"] = round(ms_step - sum(v[0] for v in prof.values()) / max(args.steps, 1), 4)
         if local_elapsed:
             line["local_value"] = round(n * world * args.steps / local_elapsed / 1e6, 1)
             line["local_ms_per_step"] = round(local_elapsed / args.steps * 1e3, 4)
