@@ -25,6 +25,7 @@ AH_PARSE_ERROR = 11
 AH_PANIC = 100
 AH_HIP_ERROR = 101
 AH_OUT_OF_MEMORY = 102
+AH_COMM_ERROR = 103
 
 # physical types
 AH_BOOL, AH_INT8, AH_INT16, AH_INT32, AH_INT64 = 1, 2, 3, 4, 5
@@ -81,6 +82,12 @@ class ArrayOut(C.Structure):
 class Scalar(C.Structure):
     """ah_scalar / orc_scalar (identical layout)."""
     _fields_ = [("type", C.c_int32), ("is_valid", C.c_int32), ("bytes", C.c_uint8 * 32)]
+
+
+class ExchangeStats(C.Structure):
+    """ah_exchange_stats"""
+    _fields_ = [("peers", C.c_int32), ("bytes_to_each_peer", C.c_int64), ("bytes_received", C.c_int64),
+                ("counts_ms", C.c_double), ("total_ms", C.c_double)]
 
 
 class IpcField(C.Structure):
@@ -173,6 +180,17 @@ SIGNATURES = {
     "ah_can_cast_data_types": (C.c_int32, [C.POINTER(DataTypeDesc), C.POINTER(DataTypeDesc)]),
     "ah_concat": (C.c_int32, [_P, C.c_int32, _VIEW, _OUT]),
     "ah_bitmap_set_bits": (C.c_int32, [_P, _P, C.c_int64, _P, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
+    "ah_comm_unique_id": (C.c_int32, [_P, C.c_char_p]),
+    "ah_comm_create": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_char_p, C.POINTER(_P)]),
+    "ah_comm_destroy": (None, [_P, _P]),
+    "ah_comm_rank": (C.c_int32, [_P]),
+    "ah_comm_world": (C.c_int32, [_P]),
+    "ah_comm_barrier": (C.c_int32, [_P, _P]),
+    "ah_comm_allreduce_max_f64": (C.c_int32, [_P, _P, C.POINTER(C.c_double), C.c_int32]),
+    "ah_all_gatherv": (C.c_int32, [_P, _P, _VIEW, _OUT, C.POINTER(ExchangeStats)]),
+    "ah_all_gather_columns": (C.c_int32, [_P, _P, C.c_int32, _VIEW, _OUT, C.POINTER(ExchangeStats)]),
+    "ah_bitmap_concat": (C.c_int32, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P,
+                                     C.POINTER(C.c_int64)]),
     "ah_count_set_bits": (C.c_int32, [_P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),
     "ah_profile_enable": (None, [_P, C.c_int32]),
     "ah_profile_reset": (None, [_P]),

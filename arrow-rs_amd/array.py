@@ -256,6 +256,15 @@ def Decimal128(precision, scale):
                     (L.AH_DT_DECIMAL128, 0, None, precision, scale))
 
 
+_DEC256 = np.dtype([("w0", "<u8"), ("w1", "<u8"), ("w2", "<u8"), ("w3", "<i8")])
+
+
+def Decimal256(precision, scale):
+    """``DataType::Decimal256``: i256 natives (arrow-buffer/src/bigint/mod.rs), little-endian 4 x u64.  A 32-byte
+    fixed-width value for the width-generic selection kernels (filter_native / take_native, filter.rs:731-770)."""
+    return DataType(f"Decimal256({precision}, {scale})", L.AH_FIXED32, _DEC256)
+
+
 _PHYSICAL_DEFAULT = {
     L.AH_BOOL: Boolean, L.AH_INT8: Int8, L.AH_INT16: Int16, L.AH_INT32: Int32, L.AH_INT64: Int64,
     L.AH_UINT8: UInt8, L.AH_UINT16: UInt16, L.AH_UINT32: UInt32, L.AH_UINT64: UInt64,
@@ -592,7 +601,7 @@ class Array:
 
     def slice(self, offset, length):
         """``Array::slice`` (zero-copy).  Panics like the reference when out of range."""
-        if offset + length > self.length:
+        if offset < 0 or length < 0 or offset + length > self.length:  # usize arguments in the reference: never negative
             raise Panic("the length + offset of the sliced PrimitiveArray cannot exceed the existing length")
         w = self.data_type.width
         offs = self.offsets

@@ -590,6 +590,7 @@ template <int W> ah_status run_checked_w(ah_context* ctx, bool is_signed, bool p
 }  // namespace
 
 extern "C" ah_status ah_aggregate(ah_context* ctx, ah_agg_op op, const ah_array_view* v, ah_scalar* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !v || !out) return AH_INVALID_ARGUMENT;
   memset(out, 0, sizeof *out);
   out->type = v->type;

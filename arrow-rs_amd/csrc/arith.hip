@@ -289,6 +289,7 @@ void free_out_bufs(ah_context* ctx, void* ov, size_t vbytes, void* ob, size_t bb
 extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_array_view* lhs,
                                      int32_t l_s, const ah_array_view* rhs, int32_t r_s,
                                      ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !lhs || !rhs || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -439,6 +440,7 @@ static ah_status arith_unary(ah_context* ctx, const ah_array_view* v, int op, ah
 
 extern "C" ah_status ah_arith_neg(ah_context* ctx, const ah_array_view* v, int32_t wrapping,
                                   ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !v || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -453,6 +455,7 @@ extern "C" ah_status ah_arith_neg(ah_context* ctx, const ah_array_view* v, int32
 
 // bitwise_not (arrow-arith/src/bitwise.rs:113-120): `unary`, nulls cloned
 extern "C" ah_status ah_bitwise_not(ah_context* ctx, const ah_array_view* v, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !v || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

@@ -103,6 +103,7 @@ ah_status date32_diff(ah_context* ctx, const ah_array_view* l, int32_t l_s, cons
 extern "C" ah_status ah_arith_with_types(ah_context* ctx, ah_arith_op op, const ah_array_view* lhs, int32_t l_s,
                                          const ah_data_type* lt, const ah_array_view* rhs, int32_t r_s,
                                          const ah_data_type* rt, ah_array_out* out, ah_data_type* out_type) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !lhs || !rhs || !lt || !rt || !out || !out_type) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

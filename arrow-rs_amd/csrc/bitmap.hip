@@ -125,6 +125,7 @@ ah_status ah_bitmap_op(ah_context* ctx, int op, BitView a, BitView b, BitView c,
 extern "C" ah_status ah_bitmap_set_bits(ah_context* ctx, uint8_t* dst, int64_t dst_bit_offset,
                                         const uint8_t* src, int64_t src_bit_offset, int64_t len,
                                         int64_t* set_bits) {
+  ah_ctx_guard _guard(ctx);
   if (set_bits) *set_bits = 0;
   if (len <= 0) return AH_OK;
   if (((uintptr_t)dst & 7) != 0)

@@ -10,6 +10,7 @@
 
 extern "C" ah_status ah_boolean_binary(ah_context* ctx, ah_boolean_op op, const ah_array_view* l,
                                        const ah_array_view* r, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !l || !r || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -76,6 +77,7 @@ extern "C" ah_status ah_boolean_binary(ah_context* ctx, ah_boolean_op op, const 
 
 extern "C" ah_status ah_boolean_unary(ah_context* ctx, ah_boolean_op op, const ah_array_view* v,
                                       ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !v || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -132,6 +134,7 @@ extern "C" ah_status ah_boolean_unary(ah_context* ctx, ah_boolean_op op, const a
 // validity = left_validity & !(right_values & right_validity), always present.
 extern "C" ah_status ah_nullif(ah_context* ctx, const ah_array_view* left, const ah_array_view* right,
                                ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !left || !right || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

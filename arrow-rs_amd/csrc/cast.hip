@@ -370,6 +370,7 @@ extern "C" int32_t ah_can_cast_types(ah_type from, ah_type to) {
 
 extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_type to_type,
                              int32_t safe, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !values || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

@@ -291,6 +291,7 @@ extern "C" int32_t ah_can_cast_data_types(const ah_data_type* from, const ah_dat
 
 extern "C" ah_status ah_cast_with_types(ah_context* ctx, const ah_array_view* values, const ah_data_type* from,
                                         const ah_data_type* to, int32_t safe, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !values || !from || !to || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

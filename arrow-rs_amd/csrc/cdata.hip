@@ -157,6 +157,7 @@ ah_status host_copy_bits(ah_context* ctx, const uint8_t* dev, int64_t bit_offset
 }  // namespace
 
 extern "C" ah_status ah_type_from_format(ah_context* ctx, const char* format, ah_type* out) {
+  ah_ctx_guard _guard(ctx);
   if (!out) return AH_INVALID_ARGUMENT;  // ctx may be NULL: status only, no message
   return type_from_format(ctx, format, out);
 }
@@ -178,6 +179,7 @@ extern "C" const char* ah_format_of_type(ah_type t) {  // arrow-schema/src/ffi.r
 
 extern "C" ah_status ah_import_c_data(ah_context* ctx, const struct ArrowArray* array,
                                       const struct ArrowSchema* schema, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !array || !schema || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -319,6 +321,7 @@ extern "C" ah_status ah_import_c_data(ah_context* ctx, const struct ArrowArray* 
 
 extern "C" ah_status ah_export_c_data(ah_context* ctx, const ah_array_view* v, const char* format,
                                       struct ArrowArray* oa, struct ArrowSchema* os) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !v || !oa || !os) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   const ah_type t = v->type;
@@ -447,6 +450,7 @@ ah_status aligned_bits(ah_context* ctx, const void* bits, int64_t bit_offset, in
 
 extern "C" ah_status ah_export_c_device_data(ah_context* ctx, const ah_array_view* v, ah_array_out* owned,
                                              const char* format, struct ArrowDeviceArray* od, struct ArrowSchema* os) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !v || !od || !os) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   const ah_type t = v->type;
@@ -521,6 +525,7 @@ extern "C" ah_status ah_export_c_device_data(ah_context* ctx, const ah_array_vie
 
 extern "C" ah_status ah_import_c_device_data(ah_context* ctx, const struct ArrowDeviceArray* d, const struct ArrowSchema* schema,
                                              ah_array_view* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !d || !schema || !out) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   memset(out, 0, sizeof *out);

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void compare_bytes_kernel(const O* lo, const u
 
 extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_view* lhs, int32_t l_s,
                                 const ah_array_view* rhs, int32_t r_s, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !lhs || !rhs || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

@@ -27,6 +27,11 @@ struct ah_prof_entry {
 };
 
 struct ah_context {
+  // Entry points lock the context for the duration of the call (recursive: they call each other), so ONE context
+  // may be shared by many host threads — the reference's kernels are re-entrant over Send + Sync arrays
+  // (arrow-array/src/array/mod.rs:100) and a Rust wrapper can be `Send + Sync` without a mutex of its own.  Calls on
+  // one context serialise (they share its stream and read-back slots); threads that want overlap use one context each.
+  std::recursive_mutex mu;
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -62,6 +67,13 @@ struct ah_context {
   // profiling
   bool profiling = false;
   std::map<std::string, ah_prof_entry> prof;
+};
+
+struct ah_ctx_guard {
+  std::unique_lock<std::recursive_mutex> lk;
+  explicit ah_ctx_guard(ah_context* c) {
+    if (c) lk = std::unique_lock<std::recursive_mutex>(c->mu);
+  }
 };
 
 ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...);

@@ -110,6 +110,7 @@ ah_status concat_strings(ah_context* ctx, int32_t n, const ah_array_view* pieces
 
 extern "C" ah_status ah_concat(ah_context* ctx, int32_t n, const ah_array_view* pieces,
                                ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !out || (n > 0 && !pieces)) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -209,6 +210,7 @@ extern "C" ah_status ah_concat(ah_context* ctx, int32_t n, const ah_array_view* 
 extern "C" ah_status ah_copy_rows_into(ah_context* ctx, const ah_array_view* src, int64_t offset, int64_t len,
                                        void* dst_values, uint8_t* dst_validity, int64_t dst_row_offset,
                                        int64_t* appended_nulls) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !src || !dst_values || !dst_validity) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   if (appended_nulls) *appended_nulls = 0;
@@ -238,6 +240,7 @@ extern "C" ah_status ah_copy_rows_into(ah_context* ctx, const ah_array_view* src
 // concat(slice(k, len - k), nulls(k)) for a left shift.  Built exactly that way: the null piece is a zeroed
 // scratch array, the data piece a sub-view, and ah_concat does the copies and the bit-shifted validity merge.
 extern "C" ah_status ah_shift(ah_context* ctx, const ah_array_view* values, int64_t offset, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !values || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

@@ -92,6 +92,7 @@ void ah_pool_free(ah_context* ctx, void* p) {
 }
 
 extern "C" void ah_pool_trim(ah_context* ctx) {
+  ah_ctx_guard _guard(ctx);
   hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->pool_free)
     for (void* p : kv.second) hipFree(p);
@@ -299,28 +300,34 @@ extern "C" void ah_context_destroy(ah_context* ctx) {
 }
 
 extern "C" void ah_context_set_allocator(ah_context* ctx, ah_alloc_fn a, ah_free_fn f, void* user) {
+  ah_ctx_guard _guard(ctx);
   ctx->alloc = a;
   ctx->free_ = f;
   ctx->user = user;
 }
 extern "C" void ah_context_set_stream(ah_context* ctx, void* s) {
+  ah_ctx_guard _guard(ctx);
   hipStream_t next = s ? (hipStream_t)s : ctx->own_stream;
   // pooled scratch and released outputs are reused in STREAM order; when the stream really changes, work still
   // running on the old one could otherwise overlap a block's next owner: drain the old stream first
   if (next != ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->stream = next;
 }
-extern "C" void* ah_context_stream(ah_context* ctx) { return (void*)ctx->stream; }
+extern "C" void* ah_context_stream(ah_context* ctx) {
+  ah_ctx_guard _guard(ctx); return (void*)ctx->stream; }
 extern "C" void ah_context_set_deferred(ah_context* ctx, int32_t on) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx) return;
   if (ctx->deferred && !on) hipStreamSynchronize(ctx->stream);  // leaving deferred mode: everything enqueued is done
   ctx->deferred = on != 0;
 }
 extern "C" int32_t ah_context_deferred(const ah_context* ctx) { return ctx && ctx->deferred; }
-extern "C" const char* ah_last_error(ah_context* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+extern "C" const char* ah_last_error(ah_context* ctx) {
+  ah_ctx_guard _guard(ctx); return ctx ? ctx->err.c_str() : "no context"; }
 extern "C" const char* ah_version(void) { return "arrow_hip 0.1.0 (gfx950)"; }
 
 extern "C" void ah_array_release(ah_context* ctx, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!out) return;
   if (!(out->flags & AH_OUT_BORROWED)) {
     if (!(out->flags & AH_OUT_BORROWED_VALUES)) {
@@ -333,39 +340,47 @@ extern "C" void ah_array_release(ah_context* ctx, ah_array_out* out) {
 }
 
 extern "C" ah_status ah_device_alloc(ah_context* ctx, size_t bytes, void** out) {
+  ah_ctx_guard _guard(ctx);
   hipSetDevice(ctx->device);
   return ah_pool_alloc(ctx, bytes ? bytes : 8, out);
 }
-extern "C" void ah_device_free(ah_context* ctx, void* p) { ah_pool_free(ctx, p); }
+extern "C" void ah_device_free(ah_context* ctx, void* p) {
+  ah_ctx_guard _guard(ctx); ah_pool_free(ctx, p); }
 extern "C" ah_status ah_memcpy_htod(ah_context* ctx, void* dst, const void* src, size_t bytes) {
+  ah_ctx_guard _guard(ctx);
   if (!bytes) return AH_OK;
   AH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AH_OK;
 }
 extern "C" ah_status ah_memcpy_dtod(ah_context* ctx, void* dst, const void* src, size_t bytes) {
+  ah_ctx_guard _guard(ctx);
   if (!bytes) return AH_OK;
   AH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AH_OK;
 }
 extern "C" ah_status ah_memcpy_dtoh(ah_context* ctx, void* dst, const void* src, size_t bytes) {
+  ah_ctx_guard _guard(ctx);
   if (!bytes) return AH_OK;
   AH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AH_OK;
 }
 extern "C" ah_status ah_memset(ah_context* ctx, void* dst, int value, size_t bytes) {
+  ah_ctx_guard _guard(ctx);
   if (!bytes) return AH_OK;
   AH_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
   return AH_OK;
 }
 extern "C" ah_status ah_synchronize(ah_context* ctx) {
+  ah_ctx_guard _guard(ctx);
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AH_OK;
 }
 
 extern "C" ah_status ah_array_resolve(ah_context* ctx, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !out) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -381,7 +396,8 @@ extern "C" ah_status ah_array_resolve(ah_context* ctx, ah_array_out* out) {
 }
 
 // -------------------------------------------------------------- profiling
-extern "C" void ah_profile_enable(ah_context* ctx, int32_t on) { ctx->profiling = on != 0; }
+extern "C" void ah_profile_enable(ah_context* ctx, int32_t on) {
+  ah_ctx_guard _guard(ctx); ctx->profiling = on != 0; }
 static void prof_drain(ah_context* ctx, ah_prof_entry& e) {
   for (auto& pr : e.pending) {
     hipEventSynchronize(pr.second);
@@ -396,11 +412,13 @@ static void prof_drain(ah_context* ctx, ah_prof_entry& e) {
   e.pending.clear();
 }
 extern "C" void ah_profile_reset(ah_context* ctx) {
+  ah_ctx_guard _guard(ctx);
   for (auto& kv : ctx->prof) prof_drain(ctx, kv.second);
   ctx->prof.clear();
 }
 extern "C" ah_status ah_profile_get(ah_context* ctx, const char* kernel, double* total_ms,
                                     int64_t* launches) {
+  ah_ctx_guard _guard(ctx);
   auto it = ctx->prof.find(kernel);
   if (it == ctx->prof.end()) {
     if (total_ms) *total_ms = 0;
@@ -446,6 +464,7 @@ __global__ void __launch_bounds__(1024) sum_u64_kernel(const unsigned long long*
 
 extern "C" ah_status ah_count_set_bits(ah_context* ctx, const uint8_t* bits, int64_t bit_offset,
                                        int64_t len, int64_t* count) {
+  ah_ctx_guard _guard(ctx);
   if (len <= 0 || !bits) {
     *count = bits ? 0 : (len > 0 ? len : 0);
     return AH_OK;

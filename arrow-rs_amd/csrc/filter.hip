@@ -393,6 +393,7 @@ struct ah_filter_predicate {
 
 extern "C" ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_view* predicate,
                                                ah_filter_predicate** out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !predicate || !out) return AH_INVALID_ARGUMENT;
   *out = nullptr;
   if (predicate->type != AH_BOOL)
@@ -450,6 +451,7 @@ extern "C" ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_v
 extern "C" int64_t ah_filter_predicate_count(const ah_filter_predicate* p) { return p ? p->count : 0; }
 
 extern "C" void ah_filter_predicate_free(ah_context* ctx, ah_filter_predicate* p) {
+  ah_ctx_guard _guard(ctx);
   if (!p) return;
   ah_pool_free(ctx, p->block);
   delete p;
@@ -499,6 +501,7 @@ static ah_status compact_bits(ah_context* ctx, const ah_filter_predicate* p, Bit
 
 extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_predicate* p,
                                                const ah_array_view* values, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !p || !values || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -730,6 +733,7 @@ extern "C" ah_status ah_filter_predicate_apply_into(ah_context* ctx, const ah_fi
                                                     const ah_array_view* values, void* dst_values,
                                                     uint8_t* dst_validity, int64_t dst_row_offset,
                                                     int64_t* appended_nulls) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !p || !values || !dst_values || !dst_validity) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   if (appended_nulls) *appended_nulls = 0;
@@ -787,6 +791,7 @@ extern "C" ah_status ah_filter_predicate_apply_into(ah_context* ctx, const ah_fi
 
 extern "C" ah_status ah_filter(ah_context* ctx, const ah_array_view* values,
                                const ah_array_view* predicate, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !values || !predicate || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   if (predicate->type == AH_BOOL && predicate->length > values->length)
@@ -804,6 +809,7 @@ extern "C" ah_status ah_filter_record_batch(ah_context* ctx, int32_t n_columns,
                                             const ah_array_view* columns,
                                             const ah_array_view* predicate, ah_array_out* outs,
                                             int64_t* out_rows) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !predicate || (n_columns > 0 && (!columns || !outs))) return AH_INVALID_ARGUMENT;
   ah_filter_predicate* p = nullptr;
   AH_TRY(ah_filter_predicate_build(ctx, predicate, &p));

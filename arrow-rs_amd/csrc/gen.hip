@@ -79,6 +79,7 @@ int gen_grid(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(ah_
 
 extern "C" ah_status ah_gen_uniform_i64(ah_context* ctx, int64_t* dst, int64_t n, uint64_t seed,
                                         int64_t lo, int64_t hi, int64_t row0) {
+  ah_ctx_guard _guard(ctx);
   if (n <= 0) return AH_OK;
   hipSetDevice(ctx->device);
   uint64_t range = (uint64_t)hi - (uint64_t)lo + 1;  // 0 = full 64-bit range
@@ -88,6 +89,7 @@ extern "C" ah_status ah_gen_uniform_i64(ah_context* ctx, int64_t* dst, int64_t n
 }
 extern "C" ah_status ah_gen_uniform_i32(ah_context* ctx, int32_t* dst, int64_t n, uint64_t seed,
                                         int64_t row0) {
+  ah_ctx_guard _guard(ctx);
   if (n <= 0) return AH_OK;
   hipSetDevice(ctx->device);
   gen_i32_kernel<<<gen_grid(n), 256, 0, ctx->stream>>>(dst, n, seed, row0);
@@ -96,6 +98,7 @@ extern "C" ah_status ah_gen_uniform_i32(ah_context* ctx, int32_t* dst, int64_t n
 }
 extern "C" ah_status ah_gen_uniform_u32(ah_context* ctx, uint32_t* dst, int64_t n, uint64_t seed,
                                         uint32_t bound, int64_t row0) {
+  ah_ctx_guard _guard(ctx);
   if (n <= 0) return AH_OK;
   hipSetDevice(ctx->device);
   gen_u32_kernel<<<gen_grid(n), 256, 0, ctx->stream>>>(dst, n, seed, bound, row0);
@@ -104,6 +107,7 @@ extern "C" ah_status ah_gen_uniform_u32(ah_context* ctx, uint32_t* dst, int64_t 
 }
 extern "C" ah_status ah_gen_uniform_f64(ah_context* ctx, double* dst, int64_t n, uint64_t seed,
                                         double lo, double hi, int64_t row0) {
+  ah_ctx_guard _guard(ctx);
   if (n <= 0) return AH_OK;
   hipSetDevice(ctx->device);
   gen_f64_kernel<<<gen_grid(n), 256, 0, ctx->stream>>>(dst, n, seed, lo, hi - lo, row0);
@@ -112,6 +116,7 @@ extern "C" ah_status ah_gen_uniform_f64(ah_context* ctx, double* dst, int64_t n,
 }
 extern "C" ah_status ah_gen_bernoulli_bits(ah_context* ctx, uint8_t* dst, int64_t n, uint64_t seed,
                                            double p_true, int64_t row0) {
+  ah_ctx_guard _guard(ctx);
   if (n <= 0) return AH_OK;
   hipSetDevice(ctx->device);
   double p = p_true < 0 ? 0 : (p_true > 1 ? 1 : p_true);
@@ -123,6 +128,7 @@ extern "C" ah_status ah_gen_bernoulli_bits(ah_context* ctx, uint8_t* dst, int64_
 }
 extern "C" ah_status ah_zero_null_slots(ah_context* ctx, void* values, int32_t byte_width,
                                         const uint8_t* validity, int64_t n) {
+  ah_ctx_guard _guard(ctx);
   if (n <= 0 || !validity) return AH_OK;
   hipSetDevice(ctx->device);
   const unsigned long long* v = (const unsigned long long*)validity;
@@ -139,6 +145,7 @@ extern "C" ah_status ah_zero_null_slots(ah_context* ctx, void* values, int32_t b
 }
 
 extern "C" ah_status ah_gen_iota_u32(ah_context* ctx, uint32_t* dst, int64_t n, uint32_t start) {
+  ah_ctx_guard _guard(ctx);
   if (n <= 0) return AH_OK;
   hipSetDevice(ctx->device);
   gen_iota_u32_kernel<<<gen_grid(n), 256, 0, ctx->stream>>>(dst, n, start);

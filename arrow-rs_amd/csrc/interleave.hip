@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void interleave_kernel(const Src* __restrict__
 
 extern "C" ah_status ah_interleave(ah_context* ctx, int32_t n_arrays, const ah_array_view* arrays,
                                    const ah_array_view* array_index, const ah_array_view* row_index, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !out || !array_index || !row_index || (n_arrays > 0 && !arrays)) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

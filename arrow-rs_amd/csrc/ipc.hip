@@ -136,7 +136,7 @@ struct FbView {
   bool ok = true;
   template <typename T> T rd(size_t at) {
     T v{};
-    if (at + sizeof(T) > n) {
+    if (at > n || n - at < sizeof(T)) {  // overflow-safe: `at` comes from untrusted offsets
       ok = false;
       return v;
     }
@@ -169,7 +169,7 @@ struct FbView {
   std::string str(size_t s) {
     if (!s) return std::string();
     const uint32_t len = rd<uint32_t>(s);
-    if (s + 4 + len > n) {
+    if (s > n || n - s < 4 || n - s - 4 < len) {
       ok = false;
       return std::string();
     }
@@ -405,6 +405,7 @@ static ah_status build_schema_table(ah_context* ctx, FbBuilder& b, int32_t n_fie
 
 extern "C" ah_status ah_ipc_schema_message(ah_context* ctx, int32_t n_fields, const ah_ipc_field* fields,
                                            int32_t alignment, uint8_t** out, int64_t* out_len) {
+  ah_ctx_guard _guard(ctx);
   if (!out || !out_len || (n_fields > 0 && !fields)) return AH_INVALID_ARGUMENT;  // ctx may be NULL (host only)
   if (alignment != 8 && alignment != 16 && alignment != 32 && alignment != 64)
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "Alignment should be 8, 16, 32, or 64.");  // writer.rs:92
@@ -424,6 +425,10 @@ static ah_status read_schema_table(ah_context* ctx, FbView& v, size_t schema, in
   if (v.scalar<int16_t>(schema, 0, 0) != 0) return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "big-endian IPC streams");
   const size_t fvec = v.indirect(schema, 1);
   const uint32_t n = v.vec_len(fvec);
+  // every field costs at least a 4-byte vector slot: an announced count the message cannot hold is a corrupt
+  // (or hostile) length, not an allocation request
+  if (fvec > v.n || (size_t)n > (v.n - fvec) / 4)
+    return ah_fail(ctx, AH_PARSE_ERROR, "Unable to get root as message: truncated flatbuffer");
   std::vector<std::string> names(n), fmts(n);
   std::vector<int> nullable(n);
   for (uint32_t i = 0; i < n; ++i) {
@@ -456,6 +461,7 @@ static ah_status read_schema_table(ah_context* ctx, FbView& v, size_t schema, in
 
 extern "C" ah_status ah_ipc_decode_schema(ah_context* ctx, const uint8_t* msg, int64_t len, int32_t* n_fields,
                                           ah_ipc_field** fields) {
+  ah_ctx_guard _guard(ctx);
   if (!n_fields || !fields) return AH_INVALID_ARGUMENT;  // ctx may be NULL (host only)
   FbView v{};
   AH_TRY(unframe(ctx, msg, len, &v));
@@ -472,6 +478,7 @@ static_assert(sizeof(ah_ipc_block) == 24, "File.fbs struct Block is 24 bytes");
 
 extern "C" ah_status ah_ipc_file_footer(ah_context* ctx, int32_t n_fields, const ah_ipc_field* fields, int32_t n_blocks,
                                         const ah_ipc_block* blocks, uint8_t** out, int64_t* out_len) {
+  ah_ctx_guard _guard(ctx);
   if (!out || !out_len || (n_fields > 0 && !fields) || (n_blocks > 0 && !blocks)) return AH_INVALID_ARGUMENT;
   // FileWriter::finish (writer.rs:1724-1768): dictionaries and recordBatches vectors first, then the schema
   FbBuilder b;
@@ -507,6 +514,7 @@ extern "C" ah_status ah_ipc_file_footer(ah_context* ctx, int32_t n_fields, const
 extern "C" ah_status ah_ipc_decode_footer(ah_context* ctx, const uint8_t* tail, int64_t tail_len, int64_t* footer_len,
                                           int32_t* n_fields, ah_ipc_field** fields, int32_t* n_blocks,
                                           ah_ipc_block** blocks) {
+  ah_ctx_guard _guard(ctx);
   if (!tail || !footer_len) return AH_INVALID_ARGUMENT;
   // read_footer_length (reader.rs:944-956): the last 10 bytes are [i32 footer length]["ARROW1"]
   if (tail_len < 10 || memcmp(tail + tail_len - 6, ARROW_MAGIC, 6) != 0)
@@ -547,6 +555,7 @@ extern "C" ah_status ah_ipc_decode_footer(ah_context* ctx, const uint8_t* tail, 
 extern "C" ah_status ah_ipc_encode_batch(ah_context* ctx, int32_t n_cols, const ah_array_view* cols, int64_t num_rows,
                                          int32_t alignment, uint8_t** out_meta, int64_t* out_meta_len,
                                          void** out_body, int64_t* out_body_len) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !out_meta || !out_meta_len || !out_body || !out_body_len || (n_cols > 0 && !cols))
     return AH_INVALID_ARGUMENT;
   if (alignment != 8 && alignment != 16 && alignment != 32 && alignment != 64)
@@ -702,9 +711,28 @@ extern "C" ah_status ah_ipc_encode_batch(ah_context* ctx, int32_t n_cols, const 
   return AH_OK;
 }
 
+// first slot i in [0, len] whose offset is negative, above the data length, or above its successor
+template <typename OFF>
+__global__ void __launch_bounds__(256) ipc_check_offsets_kernel(const OFF* offs, int64_t len, int64_t data_len,
+                                                                unsigned long long* first_bad) {
+  unsigned long long bad = ~0ull;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= len; i += (int64_t)gridDim.x * 256) {
+    const int64_t o = (int64_t)offs[i];
+    const bool b = o < 0 || o > data_len || (i < len && (int64_t)offs[i + 1] < o);
+    if (b && (unsigned long long)i < bad) bad = (unsigned long long)i;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long other = __shfl_xor(bad, o, 64);
+    bad = other < bad ? other : bad;
+  }
+  if ((threadIdx.x & 63) == 0 && bad != ~0ull) atomicMin(first_bad, bad);
+}
+
 extern "C" ah_status ah_ipc_decode_batch(ah_context* ctx, const uint8_t* msg, int64_t msg_len, const void* body,
                                          int64_t body_len, int32_t n_fields, const ah_ipc_field* fields,
                                          ah_array_out* out_cols, int64_t* num_rows) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !out_cols || !num_rows || (n_fields > 0 && !fields)) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   for (int i = 0; i < n_fields; ++i) ah_out_init(&out_cols[i]);
@@ -748,11 +776,26 @@ extern "C" ah_status ah_ipc_decode_batch(ah_context* ctx, const uint8_t* msg, in
         return fail(ah_fail(ctx, AH_IPC_ERROR, "buffer %u of field %d lies outside the message body", i, c));
     }
     if (len != rows) return fail(ah_fail(ctx, AH_IPC_ERROR, "field %d has %lld rows, the batch %lld", c, (long long)len, (long long)rows));
+    // FieldNode sanity the reference gets from ArrayData validation (arrow-data/src/data.rs:730-790): without it a
+    // corrupt stream yields zero-copy columns whose later kernels read out of bounds in HBM
+    if (len < 0 || nulls < 0 || nulls > len)
+      return fail(ah_fail(ctx, AH_IPC_ERROR, "field %d announces %lld rows with %lld nulls", c, (long long)len, (long long)nulls));
     const int w = is_str ? (t == AH_UTF8 ? 4 : 8) : ah_type_width(t);
-    // minimum sizes, so a kernel can never be pointed past the body
-    const int64_t need1 = is_str ? (len + 1) * w : (t == AH_BOOL ? (len + 7) / 8 : len * w);
-    if ((nulls > 0 && s[0].length < (len + 7) / 8) || (len > 0 && s[1].length < need1))
+    // minimum sizes, so a kernel can never be pointed past the body; 128-bit so (len + 1) * w cannot wrap
+    const __int128 need1 = is_str ? ((__int128)len + 1) * w : (t == AH_BOOL ? ((__int128)len + 7) / 8 : (__int128)len * w);
+    if ((nulls > 0 && (__int128)s[0].length < ((__int128)len + 7) / 8) || (len > 0 && (__int128)s[1].length < need1))
       return fail(ah_fail(ctx, AH_IPC_ERROR, "buffer of field %d is shorter than its %lld rows need", c, (long long)len));
+    if (is_str && len > 0) {  // offsets must stay inside the data buffer: first >= 0, non-decreasing, last <= data length
+      unsigned long long* bad = ctx->scratch + AH_SCRATCH_ONES + 1;  // all-ones between calls
+      const int g = (int)std::min<int64_t>((len + 255) / 256, 2048);
+      if (w == 4) ipc_check_offsets_kernel<int32_t><<<g, 256, 0, ctx->stream>>>((const int32_t*)(B + s[1].offset), len, s[2].length, bad);
+      else ipc_check_offsets_kernel<int64_t><<<g, 256, 0, ctx->stream>>>((const int64_t*)(B + s[1].offset), len, s[2].length, bad);
+      hipError_t ce = ah_d2h_wait(ctx, ctx->pinned, bad, 8, true, ~0ull);
+      if (ce != hipSuccess) return fail(ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in IPC decode", hipGetErrorString(ce)));
+      if (ctx->pinned[0] != ~0ull)
+        return fail(ah_fail(ctx, AH_IPC_ERROR, "offsets of field %d are not monotonic inside its %lld data bytes (at slot %llu)",
+                            c, (long long)s[2].length, (unsigned long long)ctx->pinned[0]));
+    }
     ah_array_out& o = out_cols[c];
     o.type = t;
     o.length = len;
@@ -804,6 +847,7 @@ extern "C" ah_status ah_ipc_decode_batch(ah_context* ctx, const uint8_t* msg, in
 // header type and body length of a framed message: what a stream reader needs before it fetches the body
 extern "C" ah_status ah_ipc_message_info(ah_context* ctx, const uint8_t* msg, int64_t len, int32_t* header_type,
                                          int64_t* body_len) {
+  ah_ctx_guard _guard(ctx);
   if (!header_type || !body_len) return AH_INVALID_ARGUMENT;  // ctx may be NULL (host only)
   FbView v{};
   AH_TRY(unframe(ctx, msg, len, &v));

@@ -163,6 +163,7 @@ const char* op_name(int op) {
 
 extern "C" ah_status ah_string_like(ah_context* ctx, ah_like_op op, const ah_array_view* values,
                                     const ah_array_view* pattern, int32_t pattern_is_scalar, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !values || !pattern || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(256) void length_kernel(const O* offs, int64_t len,
 }  // namespace
 
 extern "C" ah_status ah_string_length(ah_context* ctx, const ah_array_view* values, int32_t bits, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !values || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

@@ -61,6 +61,7 @@ ah_array_view view_of(const ah_array_out& o) {
 }  // namespace
 
 extern "C" ah_status ah_rank(ah_context* ctx, const ah_array_view* v, int32_t descending, int32_t nulls_first, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !v || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

@@ -274,6 +274,7 @@ ah_status alloc_mask_out(ah_context* ctx, int64_t len, ah_array_out* out) {
 
 extern "C" ah_status ah_selection_and_then(ah_context* ctx, const ah_array_view* mask, const ah_array_view* other,
                                            ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !mask || !other || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -325,6 +326,7 @@ extern "C" ah_status ah_selection_and_then(ah_context* ctx, const ah_array_view*
 
 extern "C" ah_status ah_selection_combine(ah_context* ctx, int32_t op, const ah_array_view* l, const ah_array_view* r,
                                           ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !l || !r || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -350,6 +352,7 @@ extern "C" ah_status ah_selection_combine(ah_context* ctx, int32_t op, const ah_
 }
 
 extern "C" ah_status ah_selection_boundaries(ah_context* ctx, const ah_array_view* mask, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !mask || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -390,6 +393,7 @@ extern "C" ah_status ah_selection_boundaries(ah_context* ctx, const ah_array_vie
 
 extern "C" ah_status ah_selection_from_boundaries(ah_context* ctx, const ah_array_view* bounds, int64_t total_rows,
                                                   ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !bounds || !out || total_rows < 0) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -410,6 +414,7 @@ extern "C" ah_status ah_selection_from_boundaries(ah_context* ctx, const ah_arra
 
 extern "C" ah_status ah_selection_find_nth_set_bit(ah_context* ctx, const ah_array_view* mask, int64_t start, int64_t n,
                                                    int64_t* pos) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !mask || !pos || start < 0 || n < 0) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   AH_TRY(check_mask(ctx, mask));

@@ -387,6 +387,7 @@ static ah_status lexsort_chain(ah_context* ctx, int32_t n_cols, const ah_array_v
 
 extern "C" ah_status ah_sort_to_indices(ah_context* ctx, const ah_array_view* v, int32_t descending, int32_t nulls_first,
                                         int64_t limit, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !v || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);
@@ -603,6 +604,7 @@ ah_status sort_rows_by_column(ah_context* ctx, const ah_array_view* v, bool desc
 extern "C" ah_status ah_lexsort_to_indices(ah_context* ctx, int32_t n_cols, const ah_array_view* cols,
                                            const int32_t* descending, const int32_t* nulls_first, int64_t limit,
                                            ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !out || (n_cols > 0 && (!cols || !descending || !nulls_first))) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

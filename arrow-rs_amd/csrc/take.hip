@@ -257,6 +257,7 @@ ah_status read_index(ah_context* ctx, const ah_array_view* ind, int64_t pos, int
 extern "C" ah_status ah_take(ah_context* ctx, const ah_array_view* values,
                              const ah_array_view* indices, int32_t check_bounds,
                              ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !values || !indices || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void zip_bool_kernel(ZipArgs a) {
 
 extern "C" ah_status ah_zip(ah_context* ctx, const ah_array_view* mask, const ah_array_view* truthy, int32_t t_scalar,
                             const ah_array_view* falsy, int32_t f_scalar, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
   if (!ctx || !mask || !truthy || !falsy || !out) return AH_INVALID_ARGUMENT;
   ah_out_init(out);
   hipSetDevice(ctx->device);

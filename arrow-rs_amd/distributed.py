@@ -193,3 +193,73 @@ class Communicator:
                                               if any_valid else 0)
         self.last_exchange = {"peers": self.world - 1, "bytes_to_each_peer": int(sent), "bytes_received": int(recv)}
         return Array(ctx, dt, total, _RawMem(out_vals.ptr, total * w, out_vals), 0, vmem, 0, nulls)
+
+
+class CApiCommunicator:
+    """The exchange step through the C ABI (``ah_comm_*`` / ``ah_all_gatherv``, csrc/comm.hip): libarrow_hip.so binds
+    RCCL itself, so a Rust (or any FFI) host reassembles shards with the same calls and torch is nowhere in the data
+    path.  The only thing a host must provide is a way to ship rank 0's 128-byte unique id to the other ranks:
+    ``share_id(payload_or_None) -> payload`` (bench.py uses a gloo broadcast; an engine would use its control plane)."""
+
+    def __init__(self, ctx, rank, world, share_id=None, use_rccl=True):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        lib = ctx.lib
+        raw = None
+        if use_rccl or world > 1:
+            buf = C.create_string_buffer(128)
+            if self.rank == 0:
+                ctx.check(lib.ah_comm_unique_id(ctx.handle, buf))
+            raw = bytes(buf.raw)
+            if world > 1:
+                if share_id is None:
+                    raise ValueError("a multi-rank communicator needs share_id to distribute rank 0's unique id")
+                raw = bytes(share_id(raw if self.rank == 0 else None))
+        h = C.c_void_p()
+        ctx.check(lib.ah_comm_create(ctx.handle, self.rank, self.world, raw, C.byref(h)))
+        self._h = h
+        import weakref
+        self._fin = weakref.finalize(self, lib.ah_comm_destroy, ctx.handle, h)
+        self.timings, self.last_exchange = None, None
+
+    def barrier(self):
+        self.ctx.check(self.ctx.lib.ah_comm_barrier(self.ctx.handle, self._h))
+
+    def allreduce_max(self, values):
+        arr = (C.c_double * len(values))(*[float(v) for v in values])
+        self.ctx.check(self.ctx.lib.ah_comm_allreduce_max_f64(self.ctx.handle, self._h, arr, len(values)))
+        return list(arr)
+
+    def _note(self, st):
+        self.timings = {"counts": round(st.counts_ms, 3), "total": round(st.total_ms, 3)}
+        self.last_exchange = {"peers": st.peers, "bytes_to_each_peer": int(st.bytes_to_each_peer),
+                              "bytes_received": int(st.bytes_received)}
+
+    def all_gatherv(self, array):
+        """concat of every rank's ``array`` in rank order, on every rank (== arrow_select::concat of the shards)."""
+        ctx = self.ctx
+        out, st, v = L.ArrayOut(), L.ExchangeStats(), array.view()
+        ctx.check(ctx.lib.ah_all_gatherv(ctx.handle, self._h, C.byref(v), C.byref(out), C.byref(st)))
+        self._note(st)
+        return Array._from_out(ctx, out, array.data_type)
+
+    def all_gather_record_batch(self, batch):
+        """concat_batches of every rank's RecordBatch shard (one count exchange + one grouped exchange for all columns)."""
+        from .array import RecordBatch
+        ctx, n = self.ctx, batch.num_columns()
+        views = (L.ArrayView * n)()
+        for i, c in enumerate(batch.columns):
+            views[i] = c.view()
+        outs = (L.ArrayOut * n)()
+        st = L.ExchangeStats()
+        ctx.check(ctx.lib.ah_all_gather_columns(ctx.handle, self._h, n, views, outs, C.byref(st)))
+        self._note(st)
+        cols = []
+        for i, c in enumerate(batch.columns):
+            o = L.ArrayOut()
+            C.memmove(C.byref(o), C.byref(outs[i]), C.sizeof(L.ArrayOut))
+            cols.append(Array._from_out(ctx, o, c.data_type))
+        return RecordBatch(batch.names, cols, num_rows=cols[0].length if cols else 0)
+
+    def all_gather_batches(self, batch, alignment=64):
+        """Interface twin of ``Communicator.all_gather_batches``: here the result is already concatenated."""
+        return [self.all_gather_record_batch(batch)]

@@ -33,7 +33,7 @@ _NP_OF_PHYSICAL = {
     L.AH_BOOL: np.bool_, L.AH_INT8: np.int8, L.AH_INT16: np.int16, L.AH_INT32: np.int32, L.AH_INT64: np.int64,
     L.AH_UINT8: np.uint8, L.AH_UINT16: np.uint16, L.AH_UINT32: np.uint32, L.AH_UINT64: np.uint64,
     L.AH_FLOAT16: np.float16, L.AH_FLOAT32: np.float32, L.AH_FLOAT64: np.float64,
-    L.AH_FIXED16: A._DEC128, L.AH_FIXED32: np.dtype([("w0", "<u8"), ("w1", "<u8"), ("w2", "<u8"), ("w3", "<i8")]),
+    L.AH_FIXED16: A._DEC128, L.AH_FIXED32: A._DEC256,
     L.AH_UTF8: None, L.AH_LARGE_UTF8: None,
 }
 
@@ -56,8 +56,19 @@ def data_type_from_format(ctx, fmt):
     phys = C.c_int32(0)
     ctx.check(ctx.lib.ah_type_from_format(ctx.handle, fmt.encode(), C.byref(phys)))
     if fmt.startswith("d:"):
-        parts = fmt[2:].split(",")
+        # Decimal (arrow-schema/src/ffi.rs:600-636): "d:p,s" / "d:p,s,128" is the typed Decimal128 the arithmetic and
+        # cast kernels understand (it carries the (AH_DT_DECIMAL128, precision, scale) descriptor); 256 bits is the
+        # 32-byte native the selection kernels move verbatim
+        parts = [x.strip() for x in fmt[2:].split(",")]
         bits = parts[2] if len(parts) > 2 else "128"
+        if bits == "128":
+            dt = A.Decimal128(int(parts[0]), int(parts[1]))
+            dt.format = fmt
+            return dt
+        if bits == "256":
+            dt = A.Decimal256(int(parts[0]), int(parts[1]))
+            dt.format = fmt
+            return dt
         name = f"Decimal{bits}({parts[0]}, {parts[1]})"
     else:
         name = f"ffi<{fmt}>"
@@ -71,6 +82,9 @@ def format_of(data_type):
     if fmt is None and data_type.name.startswith("Decimal128("):
         p, s = data_type.name[len("Decimal128("):-1].split(",")
         fmt = f"d:{p.strip()},{s.strip()}"
+    if fmt is None and data_type.name.startswith("Decimal256("):
+        p, s = data_type.name[len("Decimal256("):-1].split(",")
+        fmt = f"d:{p.strip()},{s.strip()},256"
     return fmt  # None: the library's default for the physical type
 
 

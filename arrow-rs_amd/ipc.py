@@ -180,6 +180,8 @@ class StreamReader:
         n = int.from_bytes(size, "little", signed=True)
         if n == 0:
             return None  # end-of-stream marker
+        if n < 0:  # `read(-1)` would swallow the rest of the stream; the reference reports an invalid metadata length
+            raise A.IpcError(f"Invalid metadata length: {n}")
         meta = self.src.read(n)
         if len(meta) < n:
             raise A.IpcError("Unexpected end of stream inside a message")

@@ -12,42 +12,45 @@ Bernoulli(0.1) predicate, 1e8 uniform UInt32 take indices
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+The ONE JSON line of the default single-GPU run also carries, under "configs", a few timed steps of
+every other single-GPU configuration of BASELINE.json (configs[2]: add_wrapping and lt on 1e9
+Float64 rows; configs[3]: Int64->Float64 and Float64->LargeUtf8 on 2^29 rows), each with its own
+roofline object, so that every quoted roofline fraction is driver-run (--no-configs skips them).
+"roofline.traffic" is measured in the same invocation: bench.py re-runs two steps of the workload
+under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, corrections per
+MI355X_MICROARCH.md §HBM; --pmc-traffic off skips it, and without rocprofv3 it is null).
+
 Multi-GPU (weak scaling): every rank owns one 1e9-row shard of an N x 1e9-row column
 (row-range sharding), filters/takes locally, then the filtered shard results are
 reassembled on every rank with an all-gatherv over RCCL (north_star).  ``value`` includes the
 reassembly; ``local_value`` is the same run's rate without it.
 
-Other workloads (for the per-kernel roofline table in DESIGN.md): --workload arith|cmp|cast|cast_string.
+Other workloads: --workload arith|cmp|cast|cast_string|coalesce|string_filter_take|aggregate|sort|record_batch.
 """
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable copy
-
-
-def pmc_traffic(kernel, args):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_traffic.json,
-    produced by tools/collect_profiles.sh + tools/profile_summary.py: FETCH_SIZE and WRITE_SIZE in
-    separate passes, FETCH doubled for wide coalesced reads as MI355X_MICROARCH.md prescribes).
-    Only valid for the exact default workload the counters were collected on; else null."""
-    if not (args.workload == "filter_take" and args.rows == 1_000_000_000 and args.selectivity == 0.1
-            and args.valid == 0.9):
-        return None
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if not files:
-        return None
-    try:
-        return json.load(open(files[-1]))["hbm_bytes_per_launch"].get(kernel)
-    except Exception:
-        return None
+# Every L2 miss is a 128-byte line fill (TCC_EA0_RDREQ_128B, profiles/r02_take_ablation.md), so the achievable
+# 6.3 TB/s is ~49 G line fills per second whatever the access pattern; a random gather spends one fill per 8-byte
+# value and one per validity byte.
+REQUEST_CEILING_G = 6300.0 / 128.0
+ALL_WORKLOADS = ["filter_take", "arith", "cmp", "cast", "cast_string", "coalesce", "string_filter_take", "aggregate",
+                 "sort", "record_batch"]
+EXTRA_CONFIGS = ["arith", "cmp", "cast", "cast_string"]  # BASELINE configs[2] and [3], timed inside the default run
 
 
 def parse():
@@ -58,15 +61,21 @@ def parse():
     p.add_argument("--rows", type=int, default=1_000_000_000, help="rows per GPU")
     p.add_argument("--selectivity", type=float, default=0.1)
     p.add_argument("--valid", type=float, default=0.9)
-    p.add_argument("--workload", default="filter_take",
-                   choices=["filter_take", "arith", "cmp", "cast", "cast_string", "coalesce", "string_filter_take", "aggregate", "sort", "record_batch"])
+    p.add_argument("--workload", default="filter_take", choices=ALL_WORKLOADS)
     p.add_argument("--batch-rows", type=int, default=1 << 24, help="coalesce workload: rows per pushed batch")
     p.add_argument("--reassemble", default="auto", choices=["auto", "none", "allgatherv"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
+    p.add_argument("--no-configs", action="store_true", help="skip the configs[2]/[3] lines of the default run")
+    p.add_argument("--config-steps", type=int, default=5)
+    p.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"])
+    p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the run rocprofv3 wraps
+    p.add_argument("--transport", default="capi", choices=["capi", "torch"],
+                   help="exchange step: ah_comm_* (libarrow_hip.so drives RCCL itself) or torch.distributed")
     return p.parse_args()
 
 
+# ------------------------------------------------------------------------------------------ inputs
 def mk_array(A, ctx, dt, n, vals, valid=None, nulls=0):
     R = A.array._RawMem
     return A.Array(ctx, dt, n, R(vals.ptr, vals.nbytes, vals), 0,
@@ -99,14 +108,53 @@ def gen_f64_column(A, ctx, n, seed, p_valid, row0):
     return mk_array(A, ctx, A.Float64, n, vals, valid, n - count_bits(ctx, valid, n))
 
 
+def gen_cast_source(A, K, ctx, n, p_valid, row0):
+    """Int64 uniform in [-1e6, 1e6] with 1 % of the rows full-range (so the >= 2^53 rounding of
+    Int64 -> Float64 and the exponent forms of Float64 -> Utf8 are on the timed path), validity p_valid, null slots 0.
+    Built from the plain counter-based generators so the oracle side can rebuild any chunk: rows where
+    Bernoulli(seed 79, 0.01) is set take the full-range stream (seed 78), the others the bounded one (seed 42)."""
+    base = gen_i64_column(A, ctx, n, 42, p_valid, row0, -10**6, 10**6)
+    fv = ctx.alloc(n * 8)
+    ctx.check(ctx.lib.ah_gen_uniform_i64(ctx.handle, fv.ptr, n, 78, -2**63, 2**63 - 1, row0))
+    ctx.check(ctx.lib.ah_zero_null_slots(ctx.handle, fv.ptr, 8, base.validity.ptr, n))
+    full = A.Array(ctx, A.Int64, n, A.array._RawMem(fv.ptr, fv.nbytes, fv), 0, base.validity, 0, base.null_count())
+    pick = gen_predicate(A, ctx, n, 79, 0.01, row0)
+    return K.zip(pick, full, base)
+
+
 def gen_predicate(A, ctx, n, seed, p_true, row0):
     bits = ctx.alloc(((n + 63) // 64) * 8)
     ctx.check(ctx.lib.ah_gen_bernoulli_bits(ctx.handle, bits.ptr, n, seed, p_true, row0))
     return mk_array(A, ctx, A.Boolean, n, bits)
 
 
+# ------------------------------------------------------------------------------------ CPU baseline
+def _host_threads_for(bytes_per_thread):
+    """All host cores, unless the memory this container may use cannot hold one shard per core."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    avail = None
+    try:
+        for l in open("/proc/meminfo"):
+            if l.startswith("MemAvailable:"):
+                avail = int(l.split()[1]) * 1024
+        for f in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            if os.path.exists(f):
+                t = open(f).read().strip()
+                if t.isdigit():
+                    avail = min(avail or int(t), int(t))
+    except Exception:
+        pass
+    if avail:
+        cores = max(1, min(cores, int(avail * 0.5 // bytes_per_thread)))
+    return cores
+
+
 def cpu_baseline_filter_take(args):
-    """The oracle (a scalar port of the reference's algorithm) timed on ONE host core over a
+    """The oracle (a scalar port of the reference's algorithm) timed on the GPU box's host cores over a
     bounded sample of the same workload.  Reported baseline, never the thing shipped."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -148,35 +196,57 @@ def cpu_baseline_filter_take(args):
            "sample": f"{reps} x (filter + take) on {n} Int64 rows, {int(n * args.selectivity)} u32 indices, "
                      f"same generators/densities; oracle/liboracle.so single thread; "
                      f"host has {os.cpu_count()} cores"}
-    # secondary: the same port row-sharded over host threads (how an engine would parallelise the
-    # single-threaded reference kernels); ctypes releases the GIL during the calls
+    del hvh, hmh, hih, hv, hm, hi, vals, valid, mask, idx
+    # secondary: the same port row-sharded over EVERY host core (how an engine parallelises the single-threaded
+    # reference kernels), 2^24 rows = 128 MiB of values per thread so that the shards stream from DRAM rather
+    # than sit in the last-level cache.  Each thread builds its own shard with the
+    # same counter-based generators (row0 = its offset in one global column); ctypes drops the GIL in every call.
     try:
         import threading
-        T = max(1, min(os.cpu_count() or 1, 64))
-        per = (n // T) // 64 * 64
-        if T > 1 and per > 0:
-            shards = []
-            for k in range(T):
-                sv = orc.HostArray(A.Int64, vals[k * per:(k + 1) * per], valid[k * per:(k + 1) * per])
-                sm = orc.HostArray(A.Boolean, mask[k * per:(k + 1) * per])
-                si = orc.HostArray(A.UInt32, (idx[k * (len(idx) // T):(k + 1) * (len(idx) // T)] % per).astype(np.uint32))
-                shards.append((orc._Held(sv), orc._Held(sm), orc._Held(si)))
+        per = 1 << 24
+        T = _host_threads_for(per * 14)
+        nidx = int(per * args.selectivity)
+        shards = [None] * T
 
-            def work(sh):
-                for _ in range(3):
-                    o = orc.Out()
-                    oracle.lib.orc_filter(C.byref(sh[0].view), C.byref(sh[1].view), C.byref(o))
-                    oracle.lib.orc_release(C.byref(o))
-                    o = orc.Out()
-                    oracle.lib.orc_take(C.byref(sh[0].view), C.byref(sh[2].view), 0, C.byref(o))
-                    oracle.lib.orc_release(C.byref(o))
-            ths = [threading.Thread(target=work, args=(sh,)) for sh in shards]
-            t0 = time.perf_counter()
-            [th.start() for th in ths]
-            [th.join() for th in ths]
-            dt = time.perf_counter() - t0
-            res["all_cores"] = {"value": round(per * T * 3 / dt / 1e6, 1), "unit": "Mrows/s", "cores": T,
-                                "sample": f"3 x (filter + take), {T} threads x {per} rows"}
+        def build(k):
+            v = oracle.gen_i64(per, 42, -2**63, 2**63 - 1, k * per)
+            vb = np.zeros(per // 8, dtype=np.uint8)
+            mb = np.zeros(per // 8, dtype=np.uint8)
+            oracle.lib.orc_gen_bernoulli_bits(vb.ctypes.data, per, 43, args.valid, k * per)
+            oracle.lib.orc_gen_bernoulli_bits(mb.ctypes.data, per, 44, args.selectivity, k * per)
+            ix = oracle.gen_u32(nidx, 45 + k, per)
+            vv, mv, iv = orc.View(), orc.View(), orc.View()
+            vv.type, vv.length, vv.null_count, vv.values, vv.validity = A._lib.AH_INT64, per, -1, v.ctypes.data, vb.ctypes.data
+            mv.type, mv.length, mv.null_count, mv.values = A._lib.AH_BOOL, per, 0, mb.ctypes.data
+            iv.type, iv.length, iv.null_count, iv.values = A._lib.AH_UINT32, nidx, 0, ix.ctypes.data
+            shards[k] = (vv, mv, iv, (v, vb, mb, ix))
+
+        ths = [threading.Thread(target=build, args=(k,)) for k in range(T)]
+        [th.start() for th in ths]
+        [th.join() for th in ths]
+        REPS = 4
+        go = threading.Event()
+
+        def work(sh):
+            go.wait()
+            for _ in range(REPS):
+                o = orc.Out()
+                oracle.lib.orc_filter(C.byref(sh[0]), C.byref(sh[1]), C.byref(o))
+                oracle.lib.orc_release(C.byref(o))
+                o = orc.Out()
+                oracle.lib.orc_take(C.byref(sh[0]), C.byref(sh[2]), 0, C.byref(o))
+                oracle.lib.orc_release(C.byref(o))
+        ths = [threading.Thread(target=work, args=(sh,)) for sh in shards]
+        [th.start() for th in ths]
+        time.sleep(0.05)
+        t0 = time.perf_counter()
+        go.set()
+        [th.join() for th in ths]
+        dt = time.perf_counter() - t0
+        res["all_cores"] = {"value": round(per * T * REPS / dt / 1e6, 1), "unit": "Mrows/s", "cores": T,
+                            "sample": f"{REPS} x (filter + take), {T} threads x {per} rows (128 MiB of values per thread, "
+                                      f"{per * T * 8 / 2**30:.0f} GiB in all: DRAM-resident), {nidx} u32 indices per thread"}
+        del shards
     except Exception as ex:
         res["all_cores"] = {"error": repr(ex)}
     # independent sanity line: Arrow C++ through pyarrow on the same sample.  A different
@@ -184,6 +254,10 @@ def cpu_baseline_filter_take(args):
     try:
         import pyarrow as pa
         import pyarrow.compute as pc
+        vals = oracle.gen_i64(n, 42, -2**63, 2**63 - 1)
+        valid = oracle.gen_bits(n, 43, args.valid)
+        mask = oracle.gen_bits(n, 44, args.selectivity)
+        idx = oracle.gen_u32(max(1, int(n * args.selectivity)), 45, n)
         pv = pa.array(vals, mask=~valid)
         pm = pa.array(mask)
         pi = pa.array(idx)
@@ -203,6 +277,294 @@ def cpu_baseline_filter_take(args):
     return res
 
 
+# ------------------------------------------------------------------------------- in-run PMC traffic
+# kernel-name patterns of the kernels a workload's roofline objects talk about, and how FETCH_SIZE is corrected.
+# This rocprofv3 computes FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but on gfx950 the L2's read requests are 128-byte line
+# fills (MI355X_MICROARCH.md §HBM: double it).  That holds for the wide streaming kernels AND — calibrated in
+# profiles/r02_take_ablation.md with TCC_EA0_RDREQ_128B — for the random gather: 1.03e8 (value) + 1.00e8 (validity
+# byte) requests per 1e8 indices, every one a 128-byte request.  So FETCH_SIZE is doubled for every kernel here.
+# WRITE_SIZE is calibrated 1:1 (gen_i64 writes 8.0e9 B and reports 7 812 500 KB).
+PMC_KERNELS = {
+    "filter_take": {"take_gather": (r"take_kernel<", 2.0), "filter_scatter": (r"filter_scatter_kernel<8", 2.0),
+                    "filter_count": (r"filter_count_kernel", 2.0)},
+    "arith": {"arith_binary": (r"arith_kernel<", 2.0)},
+    "cmp": {"compare": (r"compare_kernel<", 2.0)},
+    "cast": {"cast_numeric": (r"cast_(stream_)?kernel<", 2.0)},
+    "cast_string": {"cast_string_len": (r"string_len_kernel<", 2.0), "cast_string_write": (r"string_write_kernel<", 2.0)},
+}
+
+
+def pmc_traffic_inrun(args, wl):
+    """HBM bytes per launch of the workload's kernels, measured NOW: two extra runs of two steps each under
+    rocprofv3 (FETCH_SIZE and WRITE_SIZE in separate passes, never combined with other tracing)."""
+    if args.pmc_traffic == "off" or wl not in PMC_KERNELS or shutil.which("rocprofv3") is None:
+        return None
+    pats = PMC_KERNELS[wl]
+    got = {k: {} for k in pats}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ah_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", wl, "--steps", "2", "--warmup", "1",
+               "--rows", str(args.rows), "--selectivity", str(args.selectivity), "--valid", str(args.valid)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=300, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name", counter) != counter:
+                        continue
+                    for k, (pat, _) in pats.items():
+                        if re.search(pat, r["Kernel_Name"]):
+                            got[k].setdefault(counter, []).append(float(r["Counter_Value"]))
+        except Exception as ex:  # noqa: BLE001 - a profiler hiccup must never cost the bench line
+            return {"error": repr(ex)[:200]}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for k, (pat, fetch_scale) in pats.items():
+        f, w = got[k].get("FETCH_SIZE"), got[k].get("WRITE_SIZE")
+        if f and w:
+            out[k] = int(sum(f) / len(f) * 1024 * fetch_scale + sum(w) / len(w) * 1024)
+    return out or None
+
+
+# --------------------------------------------------------------------------------------- workloads
+class Env:
+    pass
+
+
+def build_workload(env, wl):
+    """-> dict(step, kernels, dominant, state, n, ...) for one workload; inputs are generated in HBM here."""
+    A, K, ctx, args = env.A, env.K, env.ctx, env.args
+    n, row0, rank = args.rows, env.rank * args.rows, env.rank
+    st = {}
+    W = {"state": st, "n": n}
+    if wl == "filter_take":
+        col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
+        pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
+        nidx = max(1, int(n * args.selectivity))
+        ib = ctx.alloc(nidx * 4)
+        ctx.check(ctx.lib.ah_gen_uniform_u32(ctx.handle, ib.ptr, nidx, 45 + rank, n if n < 2**32 else 0, 0))
+        idx = mk_array(A, ctx, A.UInt32, nidx, ib)
+        W["idx"], W["col"], W["pred"] = idx, col, pred
+        # the take is independent of the filter output, so at N>1 it runs on a SECOND context (own HIP
+        # stream, own thread; ctypes drops the GIL) while the filtered shard is being all-gathered over
+        # RCCL: collective and compute overlap on separate streams
+        ctx2 = A.Context(env.local_rank) if env.comm is not None else None
+
+        def rebind(a, c):
+            return A.Array(c, a.data_type, a.length, a.values, a.values_bit_offset, a.validity,
+                           a.validity_bit_offset, a.null_count(), a.offsets)
+
+        col_b, idx_b = (rebind(col, ctx2), rebind(idx, ctx2)) if ctx2 is not None else (None, None)
+
+        def step(with_reassembly):
+            f = K.filter(col, pred)
+            if with_reassembly and not st.get("reassemble_error"):
+                import threading
+                box = {}
+
+                def side():
+                    try:
+                        box["t"] = K.take(col_b, idx_b)
+                    except Exception as ex:  # noqa: BLE001
+                        box["err"] = ex
+                th = threading.Thread(target=side)
+                th.start()
+                try:
+                    g = env.comm.all_gatherv(f)
+                    st["gk"] = g.length
+                except Exception as ex:  # keep the run alive: report local-only numbers + the error
+                    st["reassemble_error"] = repr(ex)[:300]
+                th.join()
+                if "err" in box:
+                    raise box["err"]
+                t = box["t"]
+            else:
+                t = K.take(col, idx)
+            st["k"], st["fn"], st["tn"] = f.length, f.null_count(), t.null_count()
+            return f, t
+
+        W.update(step=step, kernels=["filter_count", "filter_scatter", "take_gather"], dominant="filter_scatter")
+    elif wl == "coalesce":
+        # SURVEY §8f row 1: BatchCoalescer::push_batch_with_filter over a stream of batches —
+        # the filter scatters straight into the in-progress output batch (no intermediate array)
+        col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
+        col2 = gen_f64_column(A, ctx, n, 52, args.valid, row0)
+        pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
+        br = min(args.batch_rows, n)
+        nb = n // br
+        target = max(1, int(br * args.selectivity * 4))
+        batches = [(A.RecordBatch(["a", "b"], [col.slice(i * br, br), col2.slice(i * br, br)]), pred.slice(i * br, br))
+                   for i in range(nb)]
+
+        def step(_r):
+            co = K.BatchCoalescer.new(["a", "b"], [A.Int64, A.Float64], target, ctx)
+            out_rows = 0
+            for rb, f in batches:
+                co.push_batch_with_filter(rb, f)
+                while co.has_completed_batch():
+                    out_rows += co.next_completed_batch().num_rows()
+            co.finish_buffered_batch()
+            while co.has_completed_batch():
+                out_rows += co.next_completed_batch().num_rows()
+            st["out_rows"] = out_rows
+            return out_rows
+
+        W.update(step=step, kernels=["filter_count", "filter_scatter", "copy_rows"], dominant="filter_scatter")
+    elif wl == "string_filter_take":
+        # SURVEY §8f row 3: LargeUtf8 column (the config-4 cast output) through filter and take
+        n = min(n, 1 << 27) if args.rows == 1_000_000_000 else n
+        src = gen_i64_column(A, ctx, n, 42, args.valid, row0, -10**6, 10**6)
+        scol = K.cast(K.cast(src, A.Float64), A.LargeUtf8)
+        pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
+        nidx = max(1, int(n * args.selectivity))
+        ib = ctx.alloc(nidx * 4)
+        ctx.check(ctx.lib.ah_gen_uniform_u32(ctx.handle, ib.ptr, nidx, 45, n, 0))
+        idx = mk_array(A, ctx, A.UInt32, nidx, ib)
+        W["idx"] = idx
+
+        def step(_r):
+            f = K.filter(scol, pred)
+            t = K.take(scol, idx)
+            st["fbytes"], st["tbytes"], st["k"] = f.values.nbytes, t.values.nbytes, f.length
+            return f, t
+
+        W.update(step=step, dominant="string_gather_bytes",
+                 kernels=["filter_count", "filter_scatter", "string_ranges_scan", "string_gather_bytes",
+                          "string_take_ranges", "take_gather"])
+    elif wl == "aggregate":
+        # SURVEY §8f row 4: sum + min + max of the Int64 column (three streaming reads per step)
+        col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
+        G = K.aggregate
+        W.update(step=lambda _r: (G.sum(col), G.min(col), G.max(col)), kernels=["aggregate"], dominant="aggregate")
+    elif wl == "record_batch":
+        # BASELINE configs[4] shape: RecordBatch {Int64, Float64, each with validity} + one mask per shard;
+        # filter_record_batch (one count pass, two scatters), then at N>1 ONE exchange of both columns
+        cola = gen_i64_column(A, ctx, n, 42, args.valid, row0)
+        colb = gen_f64_column(A, ctx, n, 52, args.valid, row0)
+        pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
+        rb = A.RecordBatch(["a", "b"], [cola, colb], n)
+
+        def step(with_reassembly):
+            f = K.filter_record_batch(rb, pred)
+            st["k"] = f.num_rows()
+            if with_reassembly:
+                parts = env.comm.all_gather_batches(f)
+                st["gk"] = sum(p.num_rows() for p in parts)
+            return f
+
+        W.update(step=step, kernels=["filter_count", "filter_scatter"], dominant="filter_scatter")
+    elif wl == "sort":
+        # the producer of take's indices: sort_to_indices of the full-range Int64 column (8 radix passes)
+        n = min(n, 1 << 29) if args.rows == 1_000_000_000 else n
+        col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
+        W["col"] = col
+        W.update(step=lambda _r: K.sort_to_indices(col), kernels=["sort_radix_pass"], dominant="sort_radix_pass")
+    elif wl in ("arith", "cmp"):
+        a = gen_f64_column(A, ctx, n, 52, args.valid, row0)
+        b = gen_f64_column(A, ctx, n, 62, args.valid, row0)
+        fn = K.add_wrapping if wl == "arith" else K.lt
+        k = "arith_binary" if wl == "arith" else "compare"
+        W.update(step=lambda _r: fn(a, b), kernels=[k], dominant=k)
+    else:
+        n = min(n, 1 << 29) if args.rows == 1_000_000_000 else n
+        src = gen_cast_source(A, K, ctx, n, args.valid, row0)
+        if wl == "cast":
+            W.update(step=lambda _r: K.cast(src, A.Float64), kernels=["cast_numeric"])
+        else:
+            f64 = K.cast(src, A.Float64)
+            W.update(step=lambda _r: K.cast(f64, A.LargeUtf8), kernels=["cast_string_len", "cast_string_write"])
+        W["dominant"] = W["kernels"][-1]
+    W["n"] = n
+    return W
+
+
+def describe(env, wl, W, prof, out, steps):
+    """-> (kernel the roofline object is about, its avg ms, its launches, algorithmic bytes per launch, workload text,
+    metric, dtype) — SURVEY §8d: every input buffer read once in full + every output buffer written once."""
+    args, n, st = env.args, W["n"], W["state"]
+    dominant = W["dominant"]
+    dom_ms, dom_n = prof[dominant]
+    dom_avg = dom_ms / max(dom_n, 1)
+    if wl == "filter_take":
+        k = st["k"]
+        alg = n * 8 + 2 * ((n + 7) // 8) + k * 8 + (((k + 7) // 8) if st["fn"] > 0 else 0)
+        text = (f"configs[1]: filter()+take() on {n}-row Int64 per GPU, {args.valid:.0%} valid, "
+                f"{args.selectivity:.0%} selectivity, {W['idx'].length} uniform UInt32 take indices")
+        return dominant, dom_avg, dom_n, alg, text, "filter_take_Mrows_per_s", "int64"
+    per_row = {"arith": 24.375, "cmp": 16.5, "cast": 16.25}.get(wl)
+    kernels = W["kernels"]
+    if wl == "string_filter_take":
+        k, idx = st["k"], W["idx"]
+        # filter: offsets + validity + mask in, K+1 offsets + bytes out; take: idx + ranges in, offsets + bytes out
+        alg = (n + 1) * 8 + 2 * ((n + 7) // 8) + (k + 1) * 8 + 2 * st["fbytes"] + idx.length * (4 + 16 + 8) + 2 * st["tbytes"]
+        dom_avg, dom_n = sum(prof[kk][0] for kk in kernels) / max(steps, 1), steps
+    elif wl == "coalesce":
+        k = st["out_rows"]
+        # two columns share one predicate: 2 x (values + validity) + mask in, 2 x (K values + K bits) out
+        alg = 2 * (n * 8 + (n + 7) // 8) + (n + 7) // 8 + 2 * (k * 8 + (k + 7) // 8)
+        dom_avg, dom_n = sum(prof[kk][0] for kk in kernels) / max(steps, 1), steps  # all launches of one step
+    elif wl == "record_batch":
+        k = st["k"]  # per scatter launch: one column + its validity + the mask in, K values + K bits out
+        alg = n * 8 + 2 * ((n + 7) // 8) + k * 8 + (k + 7) // 8
+    elif wl == "sort":
+        alg = (n - W["col"].null_count()) * 32  # per radix pass: keys read twice, (key, index) pairs written once
+    elif wl == "aggregate":
+        alg = n * 8 + (n + 7) // 8  # per launch: values + validity in, 8 bytes out
+    elif per_row is None:  # cast_string: input + validity in, offsets + bytes + validity out; both passes of one cast
+        alg = n * 8 + (n + 7) // 8 + (n + 1) * 8 + out.values.nbytes + (n + 7) // 8
+        dom_avg = sum(prof[k][0] for k in kernels) / max(prof[kernels[0]][1], 1)
+        dominant = "cast_string_len+cast_string_write"
+    else:
+        alg = int(per_row * n)
+    text = {"arith": "configs[2]: add_wrapping Float64+Float64 with NullBuffers",
+            "cmp": "configs[2]: lt Float64<Float64 with NullBuffers",
+            "cast": "configs[3]: cast Int64->Float64 (values in [-1e6, 1e6], 1 % full-range)",
+            "cast_string": "configs[3]: cast Float64->LargeUtf8 (integer-valued doubles in [-1e6, 1e6], 1 % full-range; parity beyond the reference's five literals is pinned to "
+                           "the oracle's restated ryu, unpinned by the reference itself)",
+            "record_batch": "configs[4] shape: filter_record_batch on {Int64, Float64} with NullBuffers",
+            "sort": "arrow_ord sort_to_indices of a full-range Int64 column with NullBuffer (stable LSD radix)",
+            "aggregate": "SURVEY 8f-4: sum + min + max of an Int64 column with NullBuffer",
+            "string_filter_take": "SURVEY 8f-3: filter + take on a LargeUtf8 column (cast output)",
+            "coalesce": f"SURVEY 8f-1: BatchCoalescer.push_batch_with_filter, Int64+Float64, "
+                        f"{args.batch_rows}-row batches"}[wl] + f", {n} rows per GPU"
+    dtype = "int64" if wl in ("aggregate", "sort") else "int64+f64" if wl == "record_batch" else "f64"
+    return dominant, dom_avg, dom_n, alg, text, f"{wl}_Mrows_per_s", dtype
+
+
+def roofline_obj(kernel, alg, avg_ms, launches, traffic=None):
+    ach = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    r = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg,
+         "avg_launch_ms": round(avg_ms, 4), "launches": launches}
+    if traffic and avg_ms > 0:
+        # what the memory system moved for this kernel (PMC bytes per launch / measured launch time)
+        r["traffic_GBps"] = round(traffic / (avg_ms * 1e-3) / 1e9, 1)
+        r["traffic_frac"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+    return r
+
+
+def run_timed(env, W, steps, warmup, reassemble):
+    ctx = env.ctx
+    step = W["step"]
+    out = None
+    for _ in range(warmup):
+        out = step(reassemble)
+    ctx.profile(True)
+    ctx.profile_reset()
+    env.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step(reassemble)
+    env.sync_all()
+    elapsed = time.perf_counter() - t0
+    prof = {k: ctx.profile_get(k) for k in W["kernels"]}
+    ctx.profile(False)
+    return elapsed, prof, out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -217,7 +579,10 @@ def main():
         args.gpus = world
     dist = None
     torch = None
-    use_dist = world > 1 or args.reassemble == "allgatherv"  # single-rank smoke of the RCCL branch
+    use_dist = world > 1 or args.reassemble == "allgatherv"  # single-rank smoke of the exchange branch
+    transport = args.transport
+    if backend != "nccl":
+        transport = "torch"  # the gloo test hook moves device tensors through torch
     if use_dist:
         import torch
         import torch.distributed as dist
@@ -225,205 +590,77 @@ def main():
         if world == 1 and "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)  # gloo / RCCL print banners on the C stdout: keep stdout for the ONE JSON line
+        try:
+            if transport == "capi":
+                # rendezvous only: a CPU (gloo) group ships rank 0's RCCL unique id; the data path never sees torch
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            elif backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
 
     import arrow_rs_amd as A
     from arrow_rs_amd import compute as K
     ctx = A.Context(local_rank)
     A.set_default_context(ctx)
-    n = args.rows
-    row0 = rank * n  # this rank's row range of the global column
-    reassemble = (world > 1 and args.reassemble == "auto") or args.reassemble == "allgatherv"
-    comm = None
+    env = Env()
+    env.A, env.K, env.ctx, env.args, env.rank, env.local_rank, env.world = A, K, ctx, args, rank, local_rank, world
+    env.comm = None
+    transport_note = None
     if use_dist:
         from arrow_rs_amd import distributed as D
-        comm = D.Communicator(ctx, dist)
+        if transport == "capi":
+            def share_id(payload):
+                box = [payload]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            err = None
+            try:
+                env.comm = D.CApiCommunicator(ctx, rank, world, share_id)
+            except Exception as ex:  # noqa: BLE001 - keep the run alive on the torch transport, say so in the line
+                err = repr(ex)[:200]
+            flags = [None] * world
+            dist.all_gather_object(flags, err)
+            if any(flags):  # every rank switches together
+                transport, transport_note = "torch", "capi transport failed: " + str(next(f for f in flags if f))
+                env.comm = None
+        if env.comm is None:
+            g = dist.new_group(backend="nccl") if (dist.get_backend() != "nccl" and backend == "nccl") else None
+            env.comm = D.Communicator(ctx, dist, group=g)
+            env.torch_group = g
+    reassemble = (world > 1 and args.reassemble == "auto") or args.reassemble == "allgatherv"
 
     def sync_all():
         ctx.synchronize()
         if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+            if transport == "capi":
+                env.comm.barrier()
+            else:
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+    env.sync_all = sync_all
 
     wl = args.workload
-    extra = {}
-    if wl == "filter_take":
-        col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
-        pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
-        nidx = max(1, int(n * args.selectivity))
-        ib = ctx.alloc(nidx * 4)
-        ctx.check(ctx.lib.ah_gen_uniform_u32(ctx.handle, ib.ptr, nidx, 45 + rank, n if n < 2**32 else 0, 0))
-        idx = mk_array(A, ctx, A.UInt32, nidx, ib)
-        # variant (ii) of SURVEY §8d 2b: sorted indices = positions selected by the predicate
-        # (what a filter->indices->take pipeline feeds take); timed outside the step, reported as extra
-        iota = ctx.alloc(n * 4)
-        ctx.check(ctx.lib.ah_gen_iota_u32(ctx.handle, iota.ptr, n, 0)) if n < 2**32 else None
-        sorted_idx = K.filter(mk_array(A, ctx, A.UInt32, n, iota), pred) if n < 2**32 else None
-        del iota
-        state = {}
-        # the take is independent of the filter output, so at N>1 it runs on a SECOND context (own HIP
-        # stream, own thread; ctypes drops the GIL) while the filtered shard is being all-gathered over
-        # RCCL on torch's stream: collective and compute overlap on separate streams
-        ctx2 = A.Context(local_rank) if use_dist else None
-
-        def rebind(a, c):
-            return A.Array(c, a.data_type, a.length, a.values, a.values_bit_offset, a.validity,
-                           a.validity_bit_offset, a.null_count(), a.offsets)
-
-        col_b, idx_b = (rebind(col, ctx2), rebind(idx, ctx2)) if use_dist else (None, None)
-
-        def step(with_reassembly):
-            f = K.filter(col, pred)
-            if with_reassembly and not state.get("reassemble_error"):
-                import threading
-                box = {}
-
-                def side():
-                    try:
-                        box["t"] = K.take(col_b, idx_b)
-                    except Exception as ex:  # noqa: BLE001
-                        box["err"] = ex
-                th = threading.Thread(target=side)
-                th.start()
-                try:
-                    g = comm.all_gatherv(f)
-                    state["gk"] = g.length
-                except Exception as ex:  # keep the run alive: report local-only numbers + the error
-                    state["reassemble_error"] = repr(ex)[:300]
-                th.join()
-                if "err" in box:
-                    raise box["err"]
-                t = box["t"]
-            else:
-                t = K.take(col, idx)
-            state["k"], state["fn"], state["tn"] = f.length, f.null_count(), t.null_count()
-            return f, t
-
-        kernels = ["filter_count", "filter_scatter", "take_gather"]
-        dominant = "filter_scatter"
-    elif wl == "coalesce":
-        # BatchCoalescer::push_batch_with_filter over a stream of batches —
-        # the filter scatters straight into the in-progress output batch (no intermediate array)
-        col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
-        col2 = gen_f64_column(A, ctx, n, 52, args.valid, row0)
-        pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
-        br = min(args.batch_rows, n)
-        nb = n // br
-        target = max(1, int(br * args.selectivity * 4))
-        batches = [(A.RecordBatch(["a", "b"], [col.slice(i * br, br), col2.slice(i * br, br)]), pred.slice(i * br, br))
-                   for i in range(nb)]
-        state = {}
-
-        def step(_r):
-            co = K.BatchCoalescer.new(["a", "b"], [A.Int64, A.Float64], target, ctx)
-            out_rows = 0
-            for rb, f in batches:
-                co.push_batch_with_filter(rb, f)
-                while co.has_completed_batch():
-                    out_rows += co.next_completed_batch().num_rows()
-            co.finish_buffered_batch()
-            while co.has_completed_batch():
-                out_rows += co.next_completed_batch().num_rows()
-            state["out_rows"] = out_rows
-            return out_rows
-
-        kernels = ["filter_count", "filter_scatter", "copy_rows"]
-        dominant = "filter_scatter"
-    elif wl == "string_filter_take":
-        # LargeUtf8 column (the config-4 cast output) through filter and take
-        n = min(n, 1 << 27) if args.rows == 1_000_000_000 else n
-        src = gen_i64_column(A, ctx, n, 42, args.valid, row0, -10**6, 10**6)
-        scol = K.cast(K.cast(src, A.Float64), A.LargeUtf8)
-        pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
-        nidx = max(1, int(n * args.selectivity))
-        ib = ctx.alloc(nidx * 4)
-        ctx.check(ctx.lib.ah_gen_uniform_u32(ctx.handle, ib.ptr, nidx, 45, n, 0))
-        idx = mk_array(A, ctx, A.UInt32, nidx, ib)
-        state = {}
-
-        def step(_r):
-            f = K.filter(scol, pred)
-            t = K.take(scol, idx)
-            state["fbytes"], state["tbytes"], state["k"] = f.values.nbytes, t.values.nbytes, f.length
-            return f, t
-
-        kernels = ["filter_count", "filter_scatter", "string_ranges_scan", "string_gather_bytes", "string_take_ranges",
-                   "take_gather"]
-        dominant = "string_gather_bytes"
-    elif wl == "aggregate":
-        # sum + min + max of the Int64 column (three streaming reads per step)
-        col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
-        G = K.aggregate
-        step = lambda _r: (G.sum(col), G.min(col), G.max(col))
-        kernels = ["aggregate"]
-        dominant = "aggregate"
-    elif wl == "record_batch":
-        # BASELINE configs[4] shape: RecordBatch {Int64, Float64, each with validity} + one mask per shard;
-        # filter_record_batch (one count pass, two scatters), then at N>1 ONE IPC-framed exchange of both columns
-        cola = gen_i64_column(A, ctx, n, 42, args.valid, row0)
-        colb = gen_f64_column(A, ctx, n, 52, args.valid, row0)
-        pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
-        rb = A.RecordBatch(["a", "b"], [cola, colb], n)
-        state = {}
-
-        def step(with_reassembly):
-            f = K.filter_record_batch(rb, pred)
-            state["k"] = f.num_rows()
-            if with_reassembly:
-                parts = comm.all_gather_batches(f)
-                state["gk"] = sum(p.num_rows() for p in parts)
-            return f
-
-        kernels = ["filter_count", "filter_scatter"]
-        dominant = "filter_scatter"
-    elif wl == "sort":
-        # the producer of take's indices: sort_to_indices of the full-range Int64 column (8 radix passes)
-        n = min(n, 1 << 29) if args.rows == 1_000_000_000 else n
-        col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
-        step = lambda _r: K.sort_to_indices(col)
-        kernels = ["sort_radix_pass"]
-        dominant = "sort_radix_pass"
-    elif wl in ("arith", "cmp"):
-        a = gen_f64_column(A, ctx, n, 52, args.valid, row0)
-        b = gen_f64_column(A, ctx, n, 62, args.valid, row0)
-        fn = K.add_wrapping if wl == "arith" else K.lt
-        step = lambda _r: fn(a, b)
-        kernels = ["arith_binary" if wl == "arith" else "compare"]
-        dominant = kernels[0]
-    else:
-        n = min(n, 1 << 29) if args.rows == 1_000_000_000 else n
-        src = gen_i64_column(A, ctx, n, 42, args.valid, row0, -10**6, 10**6)
-        if wl == "cast":
-            step = lambda _r: K.cast(src, A.Float64)
-            kernels = ["cast_numeric"]
-        else:
-            f64 = K.cast(src, A.Float64)
-            step = lambda _r: K.cast(f64, A.LargeUtf8)
-            kernels = ["cast_string_len", "cast_string_write"]
-        dominant = kernels[-1]
-
-    for _ in range(args.warmup):
-        step(reassemble)
-    ctx.profile(True)
-    ctx.profile_reset()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(reassemble)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    prof = {k: ctx.profile_get(k) for k in kernels}
-    ctx.profile(False)
+    W = build_workload(env, wl)
+    n = W["n"]
+    if args.pmc_child:  # the profiled re-run: just the steps, no reporting
+        run_timed(env, W, args.steps, args.warmup, False)
+        return
+    elapsed, prof, out = run_timed(env, W, args.steps, args.warmup, reassemble)
+    comm = env.comm
     if wl == "filter_take" and reassemble and prof["take_gather"][1] == 0:
         # the take ran on the side context during the timed loop: time it alone for the kernel table
         ctx.profile(True)
         ctx.profile_reset()
         for _ in range(3):
-            K.take(col, idx)
+            K.take(W["col"], W["idx"])
         prof["take_gather"] = ctx.profile_get("take_gather")
         ctx.profile(False)
 
@@ -432,130 +669,93 @@ def main():
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step(False)
+            W["step"](False)
         sync_all()
         local_elapsed = time.perf_counter() - t0
 
-    if use_dist:
-        tt = torch.tensor([elapsed, local_elapsed or 0.0], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, local_elapsed = float(tt[0]), (float(tt[1]) if reassemble else None)
+    if use_dist:  # MAX over ranks
+        if transport == "capi":
+            mx = env.comm.allreduce_max([elapsed, local_elapsed or 0.0])
+        else:
+            tt = torch.tensor([elapsed, local_elapsed or 0.0], dtype=torch.float64,
+                              device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            mx = [float(tt[0]), float(tt[1])]
+        elapsed, local_elapsed = mx[0], (mx[1] if reassemble else None)
 
-    sorted_ms = None
-    if wl == "filter_take" and sorted_idx is not None:
-        ctx.profile(True)
-        ctx.profile_reset()
-        for _ in range(3):
-            ts = K.take(col, sorted_idx)
-        sorted_ms = ctx.profile_get("take_gather")
-        sorted_ms = sorted_ms[0] / max(sorted_ms[1], 1)
-        ctx.profile(False)
+    extra = {}
+    if wl == "filter_take" and n < 2**32:
+        # SURVEY §8d 2b variants, timed outside the step: (ii) sorted indices = the positions the predicate selects
+        # (what a filter->indices->take pipeline feeds take); (iii) the same random indices with 10 % null indices
+        col, idx, pred = W["col"], W["idx"], W["pred"]
+        iota = ctx.alloc(n * 4)
+        ctx.check(ctx.lib.ah_gen_iota_u32(ctx.handle, iota.ptr, n, 0))
+        sorted_idx = K.filter(mk_array(A, ctx, A.UInt32, n, iota), pred)
+        del iota
+        ivalid = ctx.alloc(((idx.length + 63) // 64) * 8)
+        ctx.check(ctx.lib.ah_gen_bernoulli_bits(ctx.handle, ivalid.ptr, idx.length, 47, 0.9, 0))
+        R = A.array._RawMem
+        null_idx = A.Array(ctx, A.UInt32, idx.length, idx.values, 0, R(ivalid.ptr, ivalid.nbytes, ivalid), 0,
+                           idx.length - count_bits(ctx, ivalid, idx.length))
+        for name, ix in (("take_sorted_indices_ms", sorted_idx), ("take_null_indices_ms", null_idx)):
+            K.take(col, ix)
+            ctx.profile(True)
+            ctx.profile_reset()
+            for _ in range(3):
+                K.take(col, ix)
+            ms, cnt = ctx.profile_get("take_gather")
+            extra[name] = round(ms / max(cnt, 1), 4)
+            ctx.profile(False)
+        del sorted_idx, null_idx
 
+    line = None
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = n * world * args.steps / elapsed / 1e6
-        dom_ms, dom_n = prof[dominant]
-        dom_avg_ms = dom_ms / max(dom_n, 1)
+        kern, avg_ms, launches, alg, workload, metric, dtype = describe(env, wl, W, prof, out, args.steps)
+        traffic = pmc_traffic_inrun(args, wl) if world == 1 else None
+        tr = traffic if isinstance(traffic, dict) and "error" not in traffic else {}
+        rf = roofline_obj(kern, alg, avg_ms, launches, tr.get(kern))
         if wl == "filter_take":
-            k = state["k"]
-            has_valid_out = state["fn"] > 0
-            # values + validity + mask read once, K values (+ K bits) written once
-            alg_bytes = n * 8 + 2 * ((n + 7) // 8) + k * 8 + (((k + 7) // 8) if has_valid_out else 0)
+            idx, st = W["idx"], W["state"]
             take_bytes = idx.length * (4 + 8 + 8) + 2 * ((idx.length + 7) // 8)
-            step_alg = alg_bytes + take_bytes
             tk_ms, tk_n = prof["take_gather"]
             tk_avg = tk_ms / max(tk_n, 1)
-            # random 8-byte gathers pull one 128-byte L2 line each (rocprofv3 FETCH_SIZE, profiles/):
-            # line traffic is the physical bound of this kernel, algorithmic bytes are 8/128 of it
-            take_line_bytes = idx.length * 128 + idx.length * 4 + idx.length * 8
-            rf_filter = {"bound": "hbm", "kernel": "filter_scatter", "achieved": round(alg_bytes / (dom_avg_ms * 1e-3) / 1e9, 1),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(alg_bytes / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "traffic": pmc_traffic("filter_scatter", args), "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom_n}
-            extra = {
-                "roofline_filter_scatter": rf_filter,
-                "take_line_traffic_GBps_model": round(take_line_bytes / (tk_avg * 1e-3) / 1e9, 1) if tk_n else None,
-                "take_sorted_indices_ms": round(sorted_ms, 4) if sorted_ms else None,
-                "filter_selected_rows": k, "filter_null_count": state["fn"],
-                "take_indices": idx.length,
-                "filter_scatter_ms": round(dom_avg_ms, 4),
-                "filter_count_ms": round(prof["filter_count"][0] / max(prof["filter_count"][1], 1), 4),
-                "take_gather_ms": round(tk_ms / max(tk_n, 1), 4),
-                "take_algorithmic_GBps": round(take_bytes / (tk_ms / max(tk_n, 1) * 1e-3) / 1e9, 1) if tk_n else None,
-                "step_algorithmic_GBps": round(step_alg / (ms_step * 1e-3) / 1e9, 1),
-            }
-            workload = (f"configs[1]: filter()+take() on {n}-row Int64 per GPU, {args.valid:.0%} valid, "
-                        f"{args.selectivity:.0%} selectivity, {idx.length} uniform UInt32 take indices")
-            metric = "filter_take_Mrows_per_s"
-            dtype = "int64"
-        else:
-            per_row = {"arith": 24.375, "cmp": 16.5, "cast": 16.25}.get(wl)
-            if wl == "string_filter_take":
-                k = state["k"]
-                # filter: offsets + validity + mask in, K+1 offsets + bytes out; take: idx + ranges in, offsets + bytes out
-                alg_bytes = (n + 1) * 8 + 2 * ((n + 7) // 8) + (k + 1) * 8 + 2 * state["fbytes"] + \
-                    idx.length * (4 + 16 + 8) + 2 * state["tbytes"]
-                dom_avg_ms = sum(prof[kk][0] for kk in kernels) / max(args.steps, 1)
-                dom_n = args.steps
-            elif wl == "coalesce":
-                k = state["out_rows"]
-                # two columns share one predicate: 2 x (values + validity) + mask in, 2 x (K values + K bits) out
-                alg_bytes = 2 * (n * 8 + (n + 7) // 8) + (n + 7) // 8 + 2 * (k * 8 + (k + 7) // 8)
-                dom_avg_ms = sum(prof[kk][0] for kk in kernels) / max(args.steps, 1)  # all launches of one step
-                dom_n = args.steps
-            elif wl == "record_batch":
-                k = state["k"]  # per scatter launch: one column + its validity + the mask in, K values + K bits out
-                alg_bytes = n * 8 + 2 * ((n + 7) // 8) + k * 8 + (k + 7) // 8
-            elif wl == "sort":
-                m_valid = n - col.null_count()
-                alg_bytes = m_valid * 32  # per radix pass: keys read twice, (key, index) pairs written once
-            elif wl == "aggregate":
-                alg_bytes = n * 8 + (n + 7) // 8  # per launch: values + validity in, 8 bytes out
-            elif per_row is None:  # cast_string: input + offsets + bytes + validity
-                o = out
-                alg_bytes = n * 8 + (n + 7) // 8 + (n + 1) * 8 + o.values.nbytes + (n + 7) // 8
-                dom_ms_all = sum(prof[k][0] for k in kernels) / max(prof[kernels[0]][1], 1)
-                dom_avg_ms = dom_ms_all
-            else:
-                alg_bytes = int(per_row * n)
-            workload = {"arith": "configs[2]: add_wrapping Float64+Float64 with NullBuffers",
-                        "cmp": "configs[2]: lt Float64<Float64 with NullBuffers",
-                        "cast": "configs[3]: cast Int64->Float64",
-                        "cast_string": "configs[3]: cast Float64->LargeUtf8",
-                        "record_batch": "configs[4] shape: filter_record_batch on {Int64, Float64} with NullBuffers"
-                                        + (" + IPC-framed all_gather_batches" if reassemble else ""),
-                        "sort": "arrow_ord sort_to_indices of a full-range Int64 column with NullBuffer (stable LSD radix)",
-                        "aggregate": "SURVEY 8f-4: sum + min + max of an Int64 column with NullBuffer",
-                        "string_filter_take": "SURVEY 8f-3: filter + take on a LargeUtf8 column (cast output)",
-                        "coalesce": f"SURVEY 8f-1: BatchCoalescer.push_batch_with_filter, Int64+Float64, "
-                                    f"{args.batch_rows}-row batches"}[wl] + f", {n} rows per GPU"
-            metric = f"{wl}_Mrows_per_s"
-            dtype = "int64" if wl in ("aggregate", "sort") else "int64+f64" if wl == "record_batch" else "f64"
-        if wl == "filter_take" and tk_avg > dom_avg_ms:
-            # the time-dominant kernel of the step is the random gather: report IT as `roofline`
-            dominant, dom_avg_ms, dom_n, alg_bytes = "take_gather", tk_avg, tk_n, take_bytes
-        achieved = alg_bytes / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
+            rf["note"] = ("frac is in ALGORITHMIC bytes (SURVEY §8d); the kernel skips 128-byte lines that hold no selected "
+                          "row, so its PMC traffic is below the algorithmic figure")
+            extra.update({
+                "roofline_filter_scatter": rf,
+                "filter_selected_rows": st["k"], "filter_null_count": st["fn"], "take_indices": idx.length,
+                "step_algorithmic_GBps": round((alg + take_bytes) / (ms_step * 1e-3) / 1e9, 1),
+            })
+            if tk_avg > avg_ms:
+                # the time-dominant kernel of the step is the random gather: report IT as `roofline`.  Its binding
+                # resource is the fabric's request rate, not bytes: one request per value + one per validity byte.
+                rf = roofline_obj("take_gather", take_bytes, tk_avg, tk_n, tr.get("take_gather"))
+                reqs = idx.length * (2 if st["tn"] > 0 else 1)
+                rf["requests"] = {"per_launch": reqs, "achieved_G_per_s": round(reqs / (tk_avg * 1e-3) / 1e9, 1),
+                                  "ceiling_G_per_s": round(REQUEST_CEILING_G, 1),
+                                  "frac": round(reqs / (tk_avg * 1e-3) / 1e9 / REQUEST_CEILING_G, 3),
+                                  "what": "128-byte L2 line fills (TCC_EA0_RDREQ_128B): 1 per gathered value + 1 per validity "
+                                          "byte; ceiling = the achievable 6.3 TB/s / 128 B; profiles/r02_take_ablation.md"}
         line = {
             "metric": metric, "value": round(value, 1), "unit": "Mrows/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
             "config": {"workload": workload, "rows_per_gpu": n, "parallelism": f"row-sharded x{world}",
-                       "reassemble": ("allgatherv" if reassemble else "none")},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": pmc_traffic(dominant, args), "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms": round(dom_avg_ms, 4), "launches": dom_n},
+                       "reassemble": ("allgatherv" if reassemble else "none"),
+                       "transport": (("ah_comm (RCCL bound by libarrow_hip.so)" if transport == "capi" else "torch.distributed")
+                                     if use_dist else "none")},
+            "roofline": rf,
         }
-        tr = line["roofline"]["traffic"]
-        if tr and dom_avg_ms > 0:
-            # what the memory system actually moved for this kernel (PMC bytes per launch / measured launch time): for the
-            # random gather this is the physically binding number — one 128-byte line per 8-byte value
-            line["roofline"]["traffic_GBps"] = round(tr / (dom_avg_ms * 1e-3) / 1e9, 1)
-            line["roofline"]["traffic_frac"] = round(tr / (dom_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-        if wl == "filter_take" and state.get("reassemble_error"):
-            line["config"]["reassemble"] = "failed: " + state["reassemble_error"]
+        if isinstance(traffic, dict):
+            line["pmc_traffic_bytes_per_launch"] = traffic
+            line["pmc_traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two steps re-run inside this invocation"
+        if transport_note:
+            line["config"]["transport_note"] = transport_note
+        if wl == "filter_take" and W["state"].get("reassemble_error"):
+            line["config"]["reassemble"] = "failed: " + W["state"]["reassemble_error"]
         if comm is not None and getattr(comm, "timings", None):
             line["reassemble_last_ms"] = comm.timings
             ex = getattr(comm, "last_exchange", None)
@@ -573,6 +773,30 @@ def main():
             line["local_value"] = round(n * world * args.steps / local_elapsed / 1e6, 1)
             line["local_ms_per_step"] = round(local_elapsed / args.steps * 1e3, 4)
         line.update(extra)
+
+    # the other single-GPU configurations of BASELINE.json, a few steps each, inside the same line
+    if wl == "filter_take" and world == 1 and not args.no_configs and args.rows == 1_000_000_000:
+        W = out = None
+        configs = {}
+        for w2 in EXTRA_CONFIGS:
+            try:
+                ctx.lib.ah_pool_trim(ctx.handle)
+                W2 = build_workload(env, w2)
+                el2, prof2, out2 = run_timed(env, W2, args.config_steps, 2, False)
+                kern, avg_ms, launches, alg, workload, metric, dtype = describe(env, w2, W2, prof2, out2, args.config_steps)
+                ms2 = el2 / args.config_steps * 1e3
+                configs[w2] = {"workload": workload, "rows": W2["n"], "steps": args.config_steps,
+                               "ms": round(ms2, 4), "value": round(W2["n"] / (ms2 * 1e-3) / 1e6, 1), "unit": "Mrows/s",
+                               "dtype": dtype, "roofline": roofline_obj(kern, alg, avg_ms, launches),
+                               "kernel_avg_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof2.items()},
+                               "host_gap_ms": round(ms2 - sum(v[0] for v in prof2.values()) / args.config_steps, 4)}
+                W2 = out2 = None
+            except Exception as ex:  # noqa: BLE001 - never lose the headline to a secondary config
+                configs[w2] = {"error": repr(ex)[:300]}
+        ctx.lib.ah_pool_trim(ctx.handle)
+        line["configs"] = configs
+
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1 and wl == "filter_take":
             try:
                 cb = cpu_baseline_filter_take(args)

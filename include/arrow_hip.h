@@ -58,7 +58,8 @@ enum {
   AH_PARSE_ERROR = 11,        /* ArrowError::ParseError */
   AH_PANIC = 100,             /* the reference would panic!(); message = panic text */
   AH_HIP_ERROR = 101,         /* runtime failure (no reference analogue) */
-  AH_OUT_OF_MEMORY = 102
+  AH_OUT_OF_MEMORY = 102,
+  AH_COMM_ERROR = 103         /* RCCL failure in the multi-GPU exchange (no reference analogue) */
 };
 
 /* ----------------------------------------------------------------- types */
@@ -388,6 +389,50 @@ AH_API ah_status ah_shift(ah_context* ctx, const ah_array_view* values, int64_t 
 AH_API ah_status ah_bitmap_set_bits(ah_context* ctx, uint8_t* dst, int64_t dst_bit_offset,
                                     const uint8_t* src, int64_t src_bit_offset, int64_t len,
                                     int64_t* set_bits);
+
+/* ---------------------------------------------------- multi-GPU exchange (RCCL over xGMI) */
+/* The reference has no parallelism; the north star shards a RecordBatch by contiguous row range over the GPUs of a
+ * node (RecordBatch::slice semantics, arrow-array/src/record_batch.rs:681), one process per GPU, and reassembles the
+ * per-shard kernel results as their in-order concatenation — arrow_select::concat (arrow-select/src/concat.rs:334-343,
+ * :495) across ranks, validity merged like bit_mask::set_bits (arrow-buffer/src/util/bit_mask.rs:33).
+ *
+ *   rank 0:      ah_comm_unique_id(ctx, id)            -> ship the 128 bytes to every rank by any means
+ *   every rank:  ah_comm_create(ctx, rank, world, id)   (ncclCommInitRank; RCCL is dlopen'ed on first use)
+ *                ah_all_gatherv / ah_all_gather_columns on results of ah_filter & co.
+ *
+ * One ncclAllGather of the per-rank counts (the call's one host wait before the exchange), ONE grouped
+ * ncclSend/ncclRecv that lands every peer's values at their final offset, one bitmap-merge kernel per column with
+ * nulls; RCCL's asynchronous error state is checked after the collective (AH_COMM_ERROR).  Fixed-width types only.
+ * `id == NULL` with world == 1 makes a communicator that never touches RCCL (copies only). */
+#define AH_COMM_ID_BYTES 128
+typedef struct ah_comm ah_comm;
+typedef struct ah_exchange_stats {
+  int32_t peers;              /* world - 1 */
+  int64_t bytes_to_each_peer; /* values + packed validity this rank pushed to EACH peer (one xGMI link each) */
+  int64_t bytes_received;     /* from all peers together */
+  double counts_ms;           /* host time until the counts were known */
+  double total_ms;            /* host time of the whole call */
+} ah_exchange_stats;
+AH_API ah_status ah_comm_unique_id(ah_context* ctx, uint8_t* id /* AH_COMM_ID_BYTES */);
+AH_API ah_status ah_comm_create(ah_context* ctx, int32_t rank, int32_t world, const uint8_t* id, ah_comm** out);
+AH_API void ah_comm_destroy(ah_context* ctx, ah_comm* comm);
+AH_API int32_t ah_comm_rank(const ah_comm* comm);
+AH_API int32_t ah_comm_world(const ah_comm* comm);
+/* stream-ordered barrier over all ranks / element-wise max of up to 32 doubles (bench timing: MAX over ranks) */
+AH_API ah_status ah_comm_barrier(ah_context* ctx, ah_comm* comm);
+AH_API ah_status ah_comm_allreduce_max_f64(ah_context* ctx, ah_comm* comm, double* values, int32_t n);
+/* out = concat(rank 0's array, rank 1's array, ...) on every rank; `stats` may be NULL */
+AH_API ah_status ah_all_gatherv(ah_context* ctx, ah_comm* comm, const ah_array_view* local, ah_array_out* out,
+                                ah_exchange_stats* stats);
+/* the same for the n_columns (<= 16) columns of a RecordBatch shard: one count exchange and one grouped exchange
+ * for all of them (== concat_batches of the shard results, concat.rs:607) */
+AH_API ah_status ah_all_gather_columns(ah_context* ctx, ah_comm* comm, int32_t n_columns, const ah_array_view* columns,
+                                       ah_array_out* outs, ah_exchange_stats* stats);
+/* The merge primitive on its own: dst (8-byte aligned, ceil(total / 64) words, written in full) = the concatenation of
+ * `n` bit-packed pieces (pieces[i], bit_offsets[i], lens[i]); pieces[i] == NULL reads as all ones; bit_offsets may
+ * be NULL (all zero).  bitmap concat of arrow-select/src/concat.rs:300-330 / bit_mask.rs:33 in ONE launch. */
+AH_API ah_status ah_bitmap_concat(ah_context* ctx, int32_t n, const uint8_t* const* pieces, const int64_t* bit_offsets,
+                                  const int64_t* lens, uint8_t* dst, int64_t* total_rows);
 
 /* ------------------------------------------------------------- aggregate */
 /* arrow_arith::aggregate (arrow-arith/src/aggregate.rs): `sum` :943, `sum_checked` :897,

@@ -1,0 +1,65 @@
+"""The exchange step behind the C ABI (csrc/comm.hip): ``ah_comm_*``, ``ah_all_gatherv``,
+``ah_all_gather_columns`` and the one-launch bitmap merge ``ah_bitmap_concat``.
+
+A gpurun box has ONE GPU and RCCL refuses two ranks on one device, so what runs here is: the real RCCL path at
+world 1 (dlopen, ncclCommInitRank, the count all-gather, the grouped exchange with no peers, the async-error query),
+and the merge kernel — the only non-trivial device logic of the N > 1 path — against numpy on many-piece inputs with
+bit offsets and "all ones" pieces.  The N > 1 control flow is the same code with peers in the loop; its gloo twin
+(``Communicator``) is covered at world 2 / 3 in test_distributed_cpu.py and test_gpu_parity.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import arrow_rs_amd as A
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_world1_through_the_c_abi():
+    """The RCCL half runs in its own process (tests/comm_gpu_worker.py): libarrow_hip.so dlopens RCCL, and a process
+    that later imports torch would hold two RCCL copies (ROCm's and torch's bundled one), which abort at exit."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "comm_gpu_worker.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "COMM_WORKER_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bitmap_concat_one_launch(ctx, seed):
+    """ah_bitmap_concat == the in-order concatenation of bit-packed pieces: what reassembles the validity of R shards
+    whose lengths are known only after the filter (arrow-select/src/concat.rs:300-330, bit_mask.rs:33)."""
+    rng = np.random.default_rng(seed)
+    npieces = int(rng.integers(1, 9)) if seed else 8
+    lens = [int(rng.choice([0, 1, 63, 64, 65, 1000, 4097, int(rng.integers(1, 200_000))])) for _ in range(npieces)]
+    offs = [int(rng.integers(0, 64)) if rng.random() < 0.6 else 0 for _ in range(npieces)]
+    bufs, ptrs, expect = [], (C.c_void_p * npieces)(), []
+    for i, (ln, off) in enumerate(zip(lens, offs)):
+        if ln and rng.random() < 0.2:  # a shard without a null buffer: NULL piece = all ones
+            ptrs[i] = None
+            expect.append(np.ones(ln, dtype=bool))
+            offs[i] = 0
+            continue
+        bits = rng.random(ln) < rng.random()
+        packed = A.pack_bits(bits, off)
+        buf = A.DeviceBuffer.from_numpy(ctx, np.concatenate([packed, np.zeros(8, dtype=np.uint8)]))
+        bufs.append(buf)
+        ptrs[i] = buf.ptr
+        expect.append(bits)
+    total = sum(lens)
+    dst = ctx.alloc(((total + 63) // 64) * 8 + 8)
+    ctx.check(ctx.lib.ah_memset(ctx.handle, dst.ptr, 0xAA, dst.nbytes))  # the kernel must write every word itself
+    got_total = C.c_int64()
+    ctx.check(ctx.lib.ah_bitmap_concat(ctx.handle, npieces, ptrs, (C.c_int64 * npieces)(*offs), (C.c_int64 * npieces)(*lens),
+                                       dst.ptr, C.byref(got_total)))
+    assert got_total.value == total
+    want = np.concatenate(expect) if expect else np.zeros(0, dtype=bool)
+    raw = dst.to_numpy()
+    got = A.unpack_bits(raw, 0, total)
+    assert np.array_equal(got, want)
+    if total:
+        words = raw[:((total + 63) // 64) * 8].view(np.uint64)
+        assert int(words[-1]) >> ((total - 1) % 64 + 1) == 0 or total % 64 == 0, "padding bits of the last word are zero"
+    assert np.all(raw[((total + 63) // 64) * 8:] == 0xAA), "nothing is written past the last word"

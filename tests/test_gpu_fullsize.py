@@ -1,0 +1,321 @@
+"""Full-coverage parity at the BASELINE.json sizes.
+
+Every row of the device result is compared with the oracle, not a window of it: the inputs are produced by the
+same counter-based generators on both sides (`ah_gen_*` in HBM, `orc_gen_*` on the host, row-number keyed, so any
+chunk of the global column can be regenerated independently), the oracle runs chunk by chunk on the host cores
+(its kernels are chunk-concatenable: filter is order preserving, the element-wise kernels are row independent
+when chunks start on 64-row boundaries), and each chunk's output is compared with the matching slice of the device
+output — raw bytes, validity bits and null counts.
+
+  configs[1]  filter + take on 1e9 Int64 rows, 10 % nulls, 10 % selectivity, 1e8 u32 indices (+ 10 %-null indices)
+  configs[2]  add_wrapping and lt on 1e9 Float64 rows with NullBuffers (NaN / inf / -0 / denormal rows patched in)
+  configs[3]  Int64 -> Float64 -> LargeUtf8 on 2^29 rows (the > 2^31-byte i64 offsets included)
+
+TEST INFRASTRUCTURE: uses the oracle.  Needs ~40 GB of host memory and a GPU with ~40 GB free."""
+import concurrent.futures as cf
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import arrow_rs_amd as A
+from arrow_rs_amd import _lib as L
+from arrow_rs_amd import compute as K
+from arrow_rs_amd.array import _copy_dtoh
+
+import bench as B
+import orc
+
+pytestmark = pytest.mark.gpu
+
+CH = 1 << 24  # rows per oracle chunk (a multiple of 64: bitmaps split on word boundaries)
+NT = max(4, min(64, (os.cpu_count() or 8) - 2))
+
+
+def _view(type_id, length, values=None, validity=None, null_count=-1):
+    v = orc.View()
+    v.type, v.length, v.null_count = type_id, length, null_count
+    if values is not None:
+        v.values = values.ctypes.data
+    if validity is not None:
+        v.validity = validity.ctypes.data
+    return v
+
+
+def _bits(oracle, rows, seed, p, row0):
+    b = np.zeros(((rows + 63) // 64) * 8, dtype=np.uint8)
+    oracle.lib.orc_gen_bernoulli_bits(b.ctypes.data, rows, seed, p, row0)
+    return b
+
+
+def _unpack(bits, n):
+    return np.unpackbits(bits, bitorder="little", count=n).view(np.bool_)
+
+
+def _out_bytes(ptr, nbytes):
+    if not ptr or nbytes <= 0:
+        return np.empty(0, dtype=np.uint8)
+    return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=np.uint8).copy()
+
+
+def _valid_of(out, rows):
+    return _unpack(_out_bytes(out.validity, (rows + 7) // 8), rows) if out.validity else np.ones(rows, dtype=bool)
+
+
+def _chunks(n):
+    return [(c0, min(CH, n - c0)) for c0 in range(0, n, CH)]
+
+
+def _dev_bytes(ctx, buf, byte_off, nbytes):
+    return _copy_dtoh(ctx, buf.ptr + byte_off, nbytes)
+
+
+def _gen_i64_chunk(oracle, c0, rows, seed, p_valid, lo=-2**63, hi=2**63 - 1):
+    v = np.empty(rows, dtype=np.int64)
+    oracle.lib.orc_gen_uniform_i64(v.ctypes.data, rows, seed, lo, hi, c0)
+    vb = _bits(oracle, rows, seed + 1, p_valid, c0)
+    np.multiply(v, _unpack(vb, rows), out=v)  # ah_zero_null_slots (a ufunc: runs without the GIL)
+    return v, vb
+
+
+def _gen_f64_chunk(oracle, c0, rows, seed, p_valid):
+    v = np.empty(rows, dtype=np.float64)
+    oracle.lib.orc_gen_uniform_f64(v.ctypes.data, rows, seed, -1e6, 1e6, c0)
+    vb = _bits(oracle, rows, seed + 1, p_valid, c0)
+    iv = v.view(np.int64)
+    np.multiply(iv, _unpack(vb, rows), out=iv)  # null slots -> +0.0 bits, like ah_zero_null_slots
+    return v, vb
+
+
+# ------------------------------------------------------------------------------------------- configs[1]
+def test_config1_filter_take_every_row(ctx, oracle):
+    n = 1_000_000_000
+    col = B.gen_i64_column(A, ctx, n, 42, 0.9, 0)
+    pred = B.gen_predicate(A, ctx, n, 44, 0.1, 0)
+    f = K.filter(col, pred)
+    K_dev = f.length
+    assert abs(K_dev / n - 0.1) < 1e-3 and f.validity is not None
+
+    # host copy of the whole column (8 GB + bitmap): the take oracle needs random access to it
+    host_vals = np.empty(n, dtype=np.int64)
+    host_valid = np.zeros(n // 8, dtype=np.uint8)
+
+    def filt(job):
+        c0, rows = job
+        v, vb = _gen_i64_chunk(oracle, c0, rows, 42, 0.9)
+        host_vals[c0:c0 + rows] = v
+        host_valid[c0 // 8:(c0 + rows) // 8] = vb[:rows // 8]
+        mb = _bits(oracle, rows, 44, 0.1, c0)
+        out = orc.Out()
+        st = oracle.lib.orc_filter(C.byref(_view(L.AH_INT64, rows, v, vb)), C.byref(_view(L.AH_BOOL, rows, mb, None, 0)),
+                                   C.byref(out))
+        assert st == 0
+        k = out.length
+        vals = _out_bytes(out.values, k * 8).view(np.int64)
+        valid = _valid_of(out, k)
+        nulls = out.null_count
+        oracle.lib.orc_release(C.byref(out))
+        return k, vals, valid, nulls
+
+    with cf.ThreadPoolExecutor(NT) as ex:
+        parts = list(ex.map(filt, _chunks(n)))
+    assert sum(p[0] for p in parts) == K_dev, "selected row count"
+    assert sum(p[3] for p in parts) == f.null_count(), "filter null_count"
+    dvals = _dev_bytes(ctx, f.values, 0, K_dev * 8).view(np.int64)
+    dvalid = _unpack(_dev_bytes(ctx, f.validity, 0, (K_dev + 7) // 8), K_dev)
+    off = 0
+    for k, vals, valid, _ in parts:
+        assert np.array_equal(dvals[off:off + k], vals), f"filter values differ in output rows [{off}, {off + k})"
+        assert np.array_equal(dvalid[off:off + k], valid), f"filter validity differs in output rows [{off}, {off + k})"
+        off += k
+    del dvals, dvalid, parts, f
+
+    # take: all 1e8 indices, no index nulls, then the 10 %-null-index variant (take.rs:432-457 first arm)
+    m = n // 10
+    ib = ctx.alloc(m * 4)
+    ctx.check(ctx.lib.ah_gen_uniform_u32(ctx.handle, ib.ptr, m, 45, n, 0))
+    idx = B.mk_array(A, ctx, A.UInt32, m, ib)
+    hidx = np.empty(m, dtype=np.uint32)
+    oracle.lib.orc_gen_uniform_u32(hidx.ctypes.data, m, 45, n, 0)
+    ivb_dev = ctx.alloc(((m + 63) // 64) * 8)
+    ctx.check(ctx.lib.ah_gen_bernoulli_bits(ctx.handle, ivb_dev.ptr, m, 47, 0.9, 0))
+    hivb = _bits(oracle, m, 47, 0.9, 0)
+    R = A.array._RawMem
+    idx_nulls = A.Array(ctx, A.UInt32, m, idx.values, 0, R(ivb_dev.ptr, ivb_dev.nbytes, ivb_dev), 0,
+                        m - int(_unpack(hivb, m).sum()))
+    full = _view(L.AH_INT64, n, host_vals, host_valid)
+    for name, darr, with_nulls in (("take", idx, False), ("take with 10 % null indices", idx_nulls, True)):
+        t = K.take(col, darr)
+        tv = _dev_bytes(ctx, t.values, 0, m * 8).view(np.int64)
+        tb = _unpack(_dev_bytes(ctx, t.validity, 0, (m + 7) // 8), m)
+
+        def take(job):
+            c0, rows = job
+            iv = _view(L.AH_UINT32, rows, hidx[c0:c0 + rows], hivb[c0 // 8:] if with_nulls else None, -1 if with_nulls else 0)
+            out = orc.Out()
+            st = oracle.lib.orc_take(C.byref(full), C.byref(iv), 0, C.byref(out))
+            assert st == 0
+            ok = np.array_equal(_out_bytes(out.values, rows * 8).view(np.int64), tv[c0:c0 + rows])
+            ok = ok and np.array_equal(_valid_of(out, rows), tb[c0:c0 + rows])
+            nulls = out.null_count
+            oracle.lib.orc_release(C.byref(out))
+            return ok, nulls
+
+        with cf.ThreadPoolExecutor(NT) as ex:
+            res = list(ex.map(take, [(c0, min(1 << 22, m - c0)) for c0 in range(0, m, 1 << 22)]))
+        assert all(r[0] for r in res), f"{name}: device rows differ from the oracle"
+        assert sum(r[1] for r in res) == t.null_count(), f"{name}: null_count"
+
+
+# ------------------------------------------------------------------------------------------- configs[2]
+_SPECIALS = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
+                      -1.7976931348623157e308, 1.0, -1.0], dtype=np.float64)
+
+
+def _patch_specials(a, b):
+    """rows [0, 4096) of chunk 0: every pair of special operands (NaN payloads of both signs included)"""
+    k = len(_SPECIALS)
+    sa = np.tile(np.repeat(_SPECIALS, k), 4096 // (k * k) + 1)[:4096].copy()
+    sb = np.tile(np.tile(_SPECIALS, k), 4096 // (k * k) + 1)[:4096].copy()
+    sa.view(np.uint64)[5::97] = 0xFFF8000000000123  # negative quiet NaN with a payload
+    sb.view(np.uint64)[7::89] = 0x7FF0000000000456  # positive signalling NaN with a payload
+    a[:4096], b[:4096] = sa, sb
+    return sa, sb
+
+
+def test_config2_add_wrapping_and_lt_every_row(ctx, oracle):
+    n = 1_000_000_000
+    a = B.gen_f64_column(A, ctx, n, 52, 0.9, 0)
+    b = B.gen_f64_column(A, ctx, n, 62, 0.9, 0)
+    sa, sb = _patch_specials(np.zeros(4096), np.zeros(4096))
+    ctx.check(ctx.lib.ah_memcpy_htod(ctx.handle, a.values.ptr, sa.ctypes.data, sa.nbytes))
+    ctx.check(ctx.lib.ah_memcpy_htod(ctx.handle, b.values.ptr, sb.ctypes.data, sb.nbytes))
+    s = K.add_wrapping(a, b)
+    l = K.lt(a, b)
+    assert s.length == n and l.length == n
+
+    def work(job):
+        c0, rows, sv, sbits, lv, lbits = job
+        va, vab = _gen_f64_chunk(oracle, c0, rows, 52, 0.9)
+        vb, vbb = _gen_f64_chunk(oracle, c0, rows, 62, 0.9)
+        if c0 == 0:
+            _patch_specials(va, vb)  # patched AFTER the null-slot zeroing on both sides
+        av, bv = _view(L.AH_FLOAT64, rows, va, vab), _view(L.AH_FLOAT64, rows, vb, vbb)
+        out = orc.Out()
+        assert oracle.lib.orc_arith(1, C.byref(av), 0, C.byref(bv), 0, C.byref(out)) == 0
+        ev = _out_bytes(out.values, rows * 8).view(np.uint64)
+        eb = _out_bytes(out.validity, rows // 8)
+        nulls = out.null_count
+        oracle.lib.orc_release(C.byref(out))
+        both_nan = np.isnan(va) & np.isnan(vb)  # operand order of a commutative SSE op is the compiler's choice
+        ok_add = np.array_equal(ev[~both_nan], sv.view(np.uint64)[~both_nan]) and np.all(np.isnan(sv[both_nan]))
+        ok_add = ok_add and np.array_equal(eb, sbits)
+        out = orc.Out()
+        assert oracle.lib.orc_compare(2, C.byref(av), 0, C.byref(bv), 0, C.byref(out)) == 0
+        ok_lt = np.array_equal(_out_bytes(out.values, rows // 8), lv) and np.array_equal(_out_bytes(out.validity, rows // 8), lbits)
+        lnulls = out.null_count
+        oracle.lib.orc_release(C.byref(out))
+        return ok_add, ok_lt, nulls, lnulls
+
+    def jobs():
+        for c0, rows in _chunks(n):
+            assert rows % 64 == 0
+            yield (c0, rows, _dev_bytes(ctx, s.values, c0 * 8, rows * 8).view(np.float64),
+                   _dev_bytes(ctx, s.validity, c0 // 8, rows // 8), _dev_bytes(ctx, l.values, c0 // 8, rows // 8),
+                   _dev_bytes(ctx, l.validity, c0 // 8, rows // 8))
+
+    res = []
+    with cf.ThreadPoolExecutor(NT) as ex:
+        pending = []
+        for job in jobs():  # device -> host copies stay on this thread (one context = one thread)
+            pending.append(ex.submit(work, job))
+            if len(pending) >= NT:
+                res.append(pending.pop(0).result())
+        res += [p.result() for p in pending]
+    assert all(r[0] for r in res), "add_wrapping differs from the oracle"
+    assert all(r[1] for r in res), "lt differs from the oracle"
+    assert sum(r[2] for r in res) == s.null_count() and sum(r[3] for r in res) == l.null_count()
+
+
+# ------------------------------------------------------------------------------------------- configs[3]
+def test_config3_cast_chain_every_row(ctx, oracle):
+    n = 1 << 29
+    # bench.py's config-4 source: [-1e6, 1e6] with 1 % full-range rows (>= 2^53 rounding, exponent forms)
+    src = B.gen_cast_source(A, K, ctx, n, 0.9, 0)
+    f64 = K.cast(src, A.Float64)
+    txt = K.cast(f64, A.LargeUtf8)
+    assert txt.length == n and txt.null_count() == src.null_count() == f64.null_count()
+    total = int(_dev_bytes(ctx, txt.offsets, n * 8, 8).view(np.int64)[0])
+    assert total > 2**31, "the chain must cross the i32 offset limit (that is why it is LargeUtf8)"
+
+    def work(job):
+        c0, rows, dv, dbits, doffs, dtext = job
+        v, vb = _gen_i64_chunk(oracle, c0, rows, 42, 0.9, -10**6, 10**6)
+        full = np.empty(rows, dtype=np.int64)
+        oracle.lib.orc_gen_uniform_i64(full.ctypes.data, rows, 78, -2**63, 2**63 - 1, c0)
+        pick = _unpack(_bits(oracle, rows, 79, 0.01, c0), rows)
+        np.copyto(v, full, where=pick & _unpack(vb, rows))  # null slots stay 0
+        o1 = orc.Out()
+        assert oracle.lib.orc_cast(C.byref(_view(L.AH_INT64, rows, v, vb)), L.AH_FLOAT64, 1, C.byref(o1)) == 0
+        ok1 = np.array_equal(_out_bytes(o1.values, rows * 8).view(np.uint64), dv.view(np.uint64))
+        ok1 = ok1 and np.array_equal(_out_bytes(o1.validity, rows // 8), dbits)
+        fv = orc.View()
+        fv.type, fv.length, fv.null_count, fv.values, fv.validity = L.AH_FLOAT64, rows, o1.null_count, o1.values, o1.validity
+        o2 = orc.Out()
+        assert oracle.lib.orc_cast(C.byref(fv), L.AH_LARGE_UTF8, 1, C.byref(o2)) == 0
+        eoffs = _out_bytes(o2.offsets, (rows + 1) * 8).view(np.int64)
+        ok2 = np.array_equal(eoffs, doffs - doffs[0])
+        ok2 = ok2 and np.array_equal(_out_bytes(o2.values, int(eoffs[-1])), dtext)
+        oracle.lib.orc_release(C.byref(o1))
+        oracle.lib.orc_release(C.byref(o2))
+        return ok1, ok2
+
+    def jobs():
+        for c0, rows in _chunks(n):
+            doffs = _dev_bytes(ctx, txt.offsets, c0 * 8, (rows + 1) * 8).view(np.int64)
+            yield (c0, rows, _dev_bytes(ctx, f64.values, c0 * 8, rows * 8).view(np.float64),
+                   _dev_bytes(ctx, f64.validity, c0 // 8, rows // 8), doffs,
+                   _dev_bytes(ctx, txt.values, int(doffs[0]), int(doffs[-1] - doffs[0])))
+
+    res = []
+    with cf.ThreadPoolExecutor(NT) as ex:
+        pending = []
+        for job in jobs():
+            pending.append(ex.submit(work, job))
+            if len(pending) >= NT:
+                res.append(pending.pop(0).result())
+        res += [p.result() for p in pending]
+    assert all(r[0] for r in res), "Int64 -> Float64 differs from the oracle"
+    assert all(r[1] for r in res), "Float64 -> LargeUtf8 differs from the oracle"
+    tb = _dev_bytes(ctx, txt.validity, 0, n // 8)
+    assert np.array_equal(tb, _dev_bytes(ctx, f64.validity, 0, n // 8)), "string validity = input validity"
+
+
+# ---------------------------------------------------------------------- 32-byte natives (i256) through filter / take
+@pytest.mark.parametrize("n", [1, 63, 1000, 1025, 40_000, 1_000_003])
+def test_filter_take_32_byte_natives(ctx, oracle, n):
+    """filter_native / take_native are width generic and include i256 (filter.rs:731-770, take.rs:432-457):
+    the W = 32 instantiations against the oracle — validity, slices, index nulls and every index width class."""
+    rng = np.random.default_rng(n)
+    dt = A.Decimal256(50, 3)
+    vals = np.zeros(n, dtype=dt.np_dtype)
+    for w in ("w0", "w1", "w2", "w3"):
+        vals[w] = rng.integers(0, 2**63, n, dtype=np.int64).astype(vals[w].dtype)
+    for valid in (None, rng.random(n) < 0.85):
+        h = orc.HostArray(dt, vals, valid)
+        d = h.to_device(ctx)
+        for sel in (0.0, 0.07, 0.5, 0.93, 1.0):
+            m = orc.HostArray(A.Boolean, rng.random(n) < sel, (rng.random(n) < 0.9) if sel == 0.5 else None)
+            got = K.filter(d, m.to_device(ctx))
+            orc.assert_logical_eq(orc.HostArray.from_device(got), oracle.filter(h, m), f"W=32 filter n={n} sel={sel}")
+        for it, npd in ((A.UInt32, np.uint32), (A.Int64, np.int64), (A.UInt8, np.uint8)):
+            hi = min(n, np.iinfo(npd).max)
+            k = max(1, n // 3)
+            idx = orc.HostArray(it, rng.integers(0, hi, k).astype(npd), (rng.random(k) < 0.8) if it is A.Int64 else None)
+            got = K.take(d, idx.to_device(ctx))
+            orc.assert_logical_eq(orc.HostArray.from_device(got), oracle.take(h, idx), f"W=32 take n={n} {it}")
+        if n > 70:  # a real zero-copy slice at an odd row: 32-byte elements are still 16-byte aligned
+            sl, hs = d.slice(3, n - 7), h.slice(3, n - 7)
+            m = orc.HostArray(A.Boolean, rng.random(n - 7) < 0.3)
+            orc.assert_logical_eq(orc.HostArray.from_device(K.filter(sl, m.to_device(ctx))), oracle.filter(hs, m), "W=32 sliced")

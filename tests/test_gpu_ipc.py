@@ -217,3 +217,74 @@ def test_ipc_file_format_both_directions(ctx, alignment):
     with pytest.raises(A.ParseError) as ei:
         ipc.FileReader(data[:-3] + b"XYZ", ctx)
     assert ei.value.message == "Arrow file does not contain correct footer"
+
+
+def _one_batch_stream(tbl):
+    sink = io.BytesIO()
+    with pa.ipc.new_stream(sink, tbl.schema) as w:
+        w.write_batch(tbl.to_batches()[0])
+    return bytearray(sink.getvalue())
+
+
+def test_corrupt_stream_metadata_is_refused(ctx):
+    """FieldNode / offsets sanity the reference gets from ArrayData validation
+    (arrow-data/src/data.rs:730-790).  A hostile or damaged stream must end in IpcError, never in zero-copy columns
+    whose later kernels read outside the message body."""
+    n = 1000
+    tbl = pa.table({"s": pa.array([("v" * (i % 13)) for i in range(n)]),
+                    "i": pa.array(np.arange(n, dtype=np.int64), mask=(np.arange(n) % 5 == 0))})
+    good = _one_batch_stream(tbl)
+    assert sum(b.num_rows() for b in ipc.StreamReader(bytes(good), ctx)) == n
+
+    def expect_refusal(stream, what):
+        with pytest.raises((A.IpcError, A.ParseError)) as ei:
+            list(ipc.StreamReader(bytes(stream), ctx))
+        assert str(ei.value), what
+
+    # FieldNode {length, null_count} of column "i": (1000, 200) as two little-endian i64
+    node = np.array([n, 200], dtype="<i8").tobytes()
+    at = bytes(good).find(node)
+    assert at > 0
+    for bad_nulls in (-1, n + 1, 2**62):
+        s = bytearray(good)
+        s[at + 8:at + 16] = np.array([bad_nulls], dtype="<i8").tobytes()
+        expect_refusal(s, f"null_count {bad_nulls}")
+    s = bytearray(good)
+    s[at:at + 8] = np.array([-5], dtype="<i8").tobytes()
+    expect_refusal(s, "negative length")
+    s = bytearray(good)
+    s[at:at + 8] = np.array([2**61], dtype="<i8").tobytes()  # (len + 1) * w would wrap in 64 bits
+    expect_refusal(s, "overflowing length")
+    # string offsets: the i32 run 0, 0, 1, 3, 6, ... sits in the body; break monotonicity / point past the data buffer
+    offs = np.cumsum([0] + [i % 13 for i in range(n)]).astype("<i4").tobytes()
+    at = bytes(good).find(offs)
+    assert at > 0
+    for slot, val in ((n, 2**30), (500, -7), (10, 2**20)):
+        s = bytearray(good)
+        s[at + 4 * slot:at + 4 * slot + 4] = np.array([val], dtype="<i4").tobytes()
+        expect_refusal(s, f"offset slot {slot} = {val}")
+    # a message length that is negative is an error, not "read the rest of the stream"
+    s = bytearray(good)
+    s[4:8] = np.array([-1], dtype="<i4").tobytes()
+    with pytest.raises(A.IpcError):
+        ipc.StreamReader(bytes(s), ctx)
+
+
+def test_decimal_columns_keep_their_logical_type_through_ffi(ctx):
+    """a 'd:p,s' column arriving through the C Data Interface / IPC must be the typed
+    Decimal128 (descriptor with precision and scale), so arithmetic and casts on it take the decimal path."""
+    vals = [decimal.Decimal(v).scaleb(-2) for v in (12345, -250, 99999, 1)]
+    col = pa.array(vals + [None], type=pa.decimal128(12, 2))
+    d = ffi.from_pyarrow(col, ctx)
+    assert d.data_type == A.Decimal128(12, 2) and d.data_type.logical is not None
+    assert d.data_type.descriptor().precision == 12 and d.data_type.descriptor().scale == 2
+    s = K.add(d, d)
+    assert s.data_type == A.Decimal128(13, 2)
+    back = ffi.to_pyarrow(s)
+    assert back.to_pylist() == [v * 2 for v in vals] + [None]
+    native = A.Array.from_pylist([12345, -250, 99999, 1, None], A.Decimal128(12, 2), ctx) if hasattr(A.Array, "from_pylist") else None
+    if native is not None:
+        assert ffi.to_pyarrow(K.add(native, d)).to_pylist() == [v * 2 for v in vals] + [None]
+    wide = ffi.from_pyarrow(pa.array([decimal.Decimal(7), None], type=pa.decimal256(40, 0)), ctx)
+    assert wide.data_type == A.Decimal256(40, 0) and wide.data_type.width == 32
+    assert ffi.to_pyarrow(K.filter(wide, ffi.from_pyarrow(pa.array([True, True]), ctx))).to_pylist() == [decimal.Decimal(7), None]

@@ -1163,29 +1163,6 @@ def test_bitmap_ops_large_offsets(ctx, oracle):
     check_exact(K.take(da, idx.to_device(ctx)), oracle.take(ha, idx), "take sliced")
 
 
-def test_full_size_bench_workload_windows(ctx):
-    """BASELINE.json configs[1] at its FULL size (1e9 Int64 rows, 10 % nulls, 10 % selectivity, 1e8
-    random take indices) — the oracle cannot hold 1e9 rows, so parity goes through order
-    preservation: the oracle's filter of the first / last 4 Mi input rows must equal the head / tail
-    of the device output, and 1 Mi take rows are re-derived from the counter-based generators."""
-    import types
-    import bench as B
-    import fullsize
-    n = 1_000_000_000
-    args = types.SimpleNamespace(valid=0.9, selectivity=0.1)
-    col = B.gen_i64_column(A, ctx, n, 42, 0.9, 0)
-    pred = B.gen_predicate(A, ctx, n, 44, 0.1, 0)
-    m = n // 10
-    ib = ctx.alloc(m * 4)
-    ctx.check(ctx.lib.ah_gen_uniform_u32(ctx.handle, ib.ptr, m, 45, n, 0))
-    idx = B.mk_array(A, ctx, A.UInt32, m, ib)
-    f = K.filter(col, pred)
-    t = K.take(col, idx)
-    assert abs(f.length / n - 0.1) < 1e-3 and t.length == m
-    res = fullsize.verify_filter_take(A, ctx, args, n, 0, f, t, idx)
-    assert res["filter_head_rows_checked"] > 400_000 and res["take_rows_checked"] == 1 << 20
-
-
 @pytest.mark.parametrize("world", [2, 3])
 def test_communicator_two_ranks_one_gpu(ctx, world):
     """N>1 on the device path: `world` processes share GPU 0 over gloo (device tensors); sharded
