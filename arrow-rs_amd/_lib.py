@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libarrow_hip.so")
+LIB_PATH = os.environ.get("AH_LIB_PATH") or os.path.join(_HERE, "lib", "libarrow_hip.so")  # AH_LIB_PATH: ablation builds
 
 # status codes (include/arrow_hip.h)
 AH_OK = 0
@@ -164,6 +164,9 @@ SIGNATURES = {
     "ah_filter_record_batch": (C.c_int32, [_P, C.c_int32, _VIEW, _VIEW, _OUT, C.POINTER(C.c_int64)]),
     "ah_filter_predicate_apply_into": (C.c_int32, [_P, _P, _VIEW, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "ah_copy_rows_into": (C.c_int32, [_P, _VIEW, C.c_int64, C.c_int64, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "ah_filter_predicate_apply_into_acc": (C.c_int32, [_P, _P, _VIEW, _P, _P, C.c_int64, _P]),
+    "ah_copy_rows_into_acc": (C.c_int32, [_P, _VIEW, C.c_int64, C.c_int64, _P, _P, C.c_int64, _P]),
+    "ah_read_words": (C.c_int32, [_P, _P, C.c_int32, C.POINTER(C.c_uint64), C.c_int32]),
     "ah_take": (C.c_int32, [_P, _VIEW, _VIEW, C.c_int32, _OUT]),
     "ah_arith_binary": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
     "ah_arith_with_types": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, C.POINTER(DataTypeDesc), _VIEW, C.c_int32,

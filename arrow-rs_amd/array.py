@@ -485,6 +485,16 @@ class Array:
             return cls.from_strings([x if x is not None else "" for x in items], valid, data_type, ctx)
         if data_type.physical == L.AH_BOOL:
             vals = np.array([bool(x) if x is not None else False for x in items], dtype=bool)
+        elif data_type.physical in (L.AH_FIXED16, L.AH_FIXED32):  # i128 / i256: two's complement, little-endian u64 limbs
+            vals = np.zeros(len(items), dtype=data_type.np_dtype)
+            names = data_type.np_dtype.names
+            for i, x in enumerate(items):
+                x = 0 if x is None else int(x)
+                for k, nm in enumerate(names):
+                    limb = (x >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+                    if k == len(names) - 1 and limb >= 1 << 63:  # the top limb is stored signed
+                        limb -= 1 << 64
+                    vals[nm][i] = limb
         else:
             vals = np.array([x if x is not None else 0 for x in items], dtype=data_type.np_dtype)
         return cls.from_numpy(vals, valid, data_type, ctx)

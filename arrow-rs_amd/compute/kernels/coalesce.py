@@ -25,13 +25,16 @@ from .take import take_record_batch
 class _InProgress:
     """InProgressPrimitiveArray (coalesce/primitive.rs:28-52): values + NullBufferBuilder."""
 
-    def __init__(self, ctx, data_type, batch_size):
+    def __init__(self, ctx, data_type, batch_size, nulls_acc_ptr=None):
         if not data_type.is_primitive() or data_type.width <= 0:
             raise NotYetImplemented(f"BatchCoalescer column type {data_type}")
         self.ctx, self.data_type, self.batch_size = ctx, data_type, batch_size
         self.values = None
         self.validity = None
         self.nulls = 0
+        # device word that accumulates the appended null rows: the per-batch calls never wait on the GPU; the
+        # coalescer reads all its columns' words in ONE wait when a batch is finished (ah_read_words)
+        self.acc = nulls_acc_ptr
 
     def ensure_capacity(self):  # allocate on first write (primitive.rs:57-61)
         if self.values is None:
@@ -41,16 +44,24 @@ class _InProgress:
 
     def copy_rows(self, source, offset, length, at):
         self.ensure_capacity()
-        n = C.c_int64()
         v = source.view()
+        if self.acc is not None:
+            self.ctx.check(self.ctx.lib.ah_copy_rows_into_acc(self.ctx.handle, C.byref(v), offset, length,
+                                                              self.values.ptr, self.validity.ptr, at, self.acc))
+            return
+        n = C.c_int64()
         self.ctx.check(self.ctx.lib.ah_copy_rows_into(self.ctx.handle, C.byref(v), offset, length,
                                                       self.values.ptr, self.validity.ptr, at, C.byref(n)))
         self.nulls += n.value
 
     def copy_rows_by_filter_from(self, source, predicate, at):
         self.ensure_capacity()
-        n = C.c_int64()
         v = source.view()
+        if self.acc is not None:
+            self.ctx.check(self.ctx.lib.ah_filter_predicate_apply_into_acc(
+                self.ctx.handle, predicate._h, C.byref(v), self.values.ptr, self.validity.ptr, at, self.acc))
+            return
+        n = C.c_int64()
         self.ctx.check(self.ctx.lib.ah_filter_predicate_apply_into(
             self.ctx.handle, predicate._h, C.byref(v), self.values.ptr, self.validity.ptr, at, C.byref(n)))
         self.nulls += n.value
@@ -88,9 +99,9 @@ class _InProgressGeneric:
         return arr
 
 
-def _in_progress(ctx, data_type, batch_size):  # `create_in_progress_array` (coalesce.rs:673-700)
+def _in_progress(ctx, data_type, batch_size, acc=None):  # `create_in_progress_array` (coalesce.rs:673-700)
     if data_type.is_primitive() and data_type.width > 0 and data_type.physical not in (L.AH_UTF8_VIEW, L.AH_BINARY_VIEW):
-        return _InProgress(ctx, data_type, batch_size)
+        return _InProgress(ctx, data_type, batch_size, acc)
     return _InProgressGeneric(ctx, data_type, batch_size)
 
 
@@ -103,7 +114,14 @@ class BatchCoalescer:
         self.names = list(names)
         self.data_types = list(data_types)
         self.target_batch_size = int(target_batch_size)
-        self.in_progress = [_in_progress(self.ctx, dt, self.target_batch_size) for dt in self.data_types]
+        # one device word per column for the appended-null counts (zeroed once; ah_read_words resets them)
+        ncols = max(len(self.data_types), 1)
+        self._acc = DeviceBuffer(self.ctx, ncols * 8) if ncols <= 200 else None
+        if self._acc is not None:
+            self.ctx.check(self.ctx.lib.ah_memset(self.ctx.handle, self._acc.ptr, 0, self._acc.nbytes))
+        self.in_progress = [_in_progress(self.ctx, dt, self.target_batch_size,
+                                         None if self._acc is None else self._acc.ptr + 8 * i)
+                            for i, dt in enumerate(self.data_types)]
         self.buffered_rows = 0
         self.completed = deque()
         self.biggest_coalesce_batch_size = None
@@ -199,6 +217,13 @@ class BatchCoalescer:
     def finish_buffered_batch(self):
         if self.buffered_rows == 0:
             return
+        if self._acc is not None:  # the ONE wait of this output batch: every column's appended-null count
+            n = len(self.in_progress)
+            host = (C.c_uint64 * n)()
+            self.ctx.check(self.ctx.lib.ah_read_words(self.ctx.handle, self._acc.ptr, n, host, 1))
+            for ip, v in zip(self.in_progress, host):
+                if isinstance(ip, _InProgress):
+                    ip.nulls += int(v)
         cols = [ip.finish(self.buffered_rows) for ip in self.in_progress]
         self.completed.append(RecordBatch(self.names, cols, num_rows=self.buffered_rows))
         self.buffered_rows = 0

@@ -122,6 +122,43 @@ ah_status ah_bitmap_op(ah_context* ctx, int op, BitView a, BitView b, BitView c,
   return AH_OK;
 }
 
+// sum of `n` partial counts -> *acc += base - sum (atomic): the no-wait tail of the *_acc entry points
+__global__ void __launch_bounds__(1024) bm_acc_kernel(const unsigned long long* in, int64_t n, unsigned long long base,
+                                                      unsigned long long* acc) {
+  unsigned long long a = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) a += in[i];
+  a = wave_reduce_add64(a);
+  __shared__ unsigned long long s[16];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int i = 0; i < 16; i++) t += s[i];
+    if (base != t) atomicAdd(acc, base - t);
+  }
+}
+
+// ah_bitmap_set_bits without the read-back: *nulls_acc (device) += len - popcount(copied bits); nothing waits
+ah_status ah_bitmap_set_bits_acc(ah_context* ctx, uint8_t* dst, int64_t dst_bit_offset, const uint8_t* src,
+                                 int64_t src_bit_offset, int64_t len, unsigned long long* nulls_acc) {
+  if (len <= 0) return AH_OK;
+  if (((uintptr_t)dst & 7) != 0) return ah_fail(ctx, AH_INVALID_ARGUMENT, "bitmap destination must be 8-byte aligned");
+  int64_t first = dst_bit_offset >> 6, last = (dst_bit_offset + len - 1) >> 6;
+  int grid = (int)std::min<int64_t>(4096, ah_ceil_div(last - first + 1, 256));
+  unsigned long long* part = nullptr;
+  const bool count = src != nullptr && nulls_acc != nullptr;  // a source without a null buffer appends no nulls
+  if (count) AH_TRY(ah_pool_alloc(ctx, (size_t)(grid + 1) * 8, (void**)&part));
+  set_bits_kernel<<<grid, 256, 0, ctx->stream>>>((unsigned long long*)dst, dst_bit_offset, make_bitview(src, src_bit_offset),
+                                                 len, part);
+  if (count) {
+    bm_acc_kernel<<<1, 1024, 0, ctx->stream>>>(part, grid, (unsigned long long)len, nulls_acc);
+    ah_pool_free(ctx, part);  // stream-ordered reuse
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "set_bits failed: %s", hipGetErrorString(e));
+  return AH_OK;
+}
+
 extern "C" ah_status ah_bitmap_set_bits(ah_context* ctx, uint8_t* dst, int64_t dst_bit_offset,
                                         const uint8_t* src, int64_t src_bit_offset, int64_t len,
                                         int64_t* set_bits) {

@@ -177,6 +177,10 @@ ah_status ah_ranges_to_strings(ah_context* ctx, bool large, const uint8_t* src, 
 ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_array_view* indices,
                         ah_array_out* out);
 
+// bitmap.hip: ah_bitmap_set_bits without a read-back — *nulls_acc (device) += len - popcount(copied bits)
+ah_status ah_bitmap_set_bits_acc(ah_context* ctx, uint8_t* dst, int64_t dst_bit_offset, const uint8_t* src,
+                                 int64_t src_bit_offset, int64_t len, unsigned long long* nulls_acc);
+
 // count valid bits of a view's validity (or trust view->null_count >= 0)
 ah_status ah_resolve_null_count(ah_context* ctx, const ah_array_view* v, int64_t* nulls);
 

@@ -235,6 +235,39 @@ extern "C" ah_status ah_copy_rows_into(ah_context* ctx, const ah_array_view* src
   return AH_OK;
 }
 
+// copy_rows without a host wait: *nulls_acc (device) += the number of null rows appended
+extern "C" ah_status ah_copy_rows_into_acc(ah_context* ctx, const ah_array_view* src, int64_t offset, int64_t len,
+                                           void* dst_values, uint8_t* dst_validity, int64_t dst_row_offset,
+                                           uint64_t* nulls_acc) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !src || !dst_values || !dst_validity || !nulls_acc) return AH_INVALID_ARGUMENT;
+  hipSetDevice(ctx->device);
+  const int w = ah_type_width(src->type);
+  if (w <= 0)
+    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "copy_rows not supported for type %s", ah_type_name(src->type));
+  if (offset < 0 || len < 0 || offset + len > src->length)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "copy_rows range [%lld, %lld) exceeds source length %lld",
+                   (long long)offset, (long long)(offset + len), (long long)src->length);
+  if (len == 0) return AH_OK;
+  ah_prof_scope ps(ctx, "copy_rows");
+  AH_HIP(ctx, hipMemcpyAsync((char*)dst_values + (size_t)dst_row_offset * w,
+                             (const char*)src->values + (size_t)offset * w, (size_t)len * w,
+                             hipMemcpyDeviceToDevice, ctx->stream));
+  return ah_bitmap_set_bits_acc(ctx, dst_validity, dst_row_offset, src->validity,
+                                src->validity ? src->validity_bit_offset + offset : 0, len, (unsigned long long*)nulls_acc);
+}
+
+// `n` (<= 200) device words -> host in ONE wait, optionally resetting them to zero: the read side of the *_acc calls
+extern "C" ah_status ah_read_words(ah_context* ctx, uint64_t* dev_words, int32_t n, uint64_t* host_out, int32_t reset) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || n < 0 || n > 200 || (n > 0 && (!dev_words || !host_out))) return AH_INVALID_ARGUMENT;
+  if (n == 0) return AH_OK;
+  hipSetDevice(ctx->device);
+  AH_HIP(ctx, ah_d2h_wait(ctx, ctx->pinned + 16, dev_words, (size_t)n * 8, reset != 0, 0));
+  memcpy(host_out, ctx->pinned + 16, (size_t)n * 8);
+  return AH_OK;
+}
+
 // arrow_select::window::shift (arrow-select/src/window.rs:56-80): offset 0 is a clone (zero copy), |offset| >= len
 // (or i64::MIN) is new_null_array(len), otherwise concat(nulls(k), slice(0, len - k)) for a right shift or
 // concat(slice(k, len - k), nulls(k)) for a left shift.  Built exactly that way: the null piece is a zeroed

@@ -118,6 +118,15 @@ __global__ void __launch_bounds__(1024) filter_group_scan_kernel(const uint32_t*
   }
 }
 
+// the no-wait tail of ah_filter_predicate_apply_into_acc: *acc += K - (valid rows), counters back to zero
+__global__ void __launch_bounds__(64) filter_finish_acc_kernel(unsigned long long* slots, unsigned long long k,
+                                                               unsigned long long* acc) {
+  unsigned long long v = slots[threadIdx.x];
+  slots[threadIdx.x] = 0;
+  v = wave_reduce_add64(v);
+  if (threadIdx.x == 0 && acc && k != v) atomicAdd(acc, k - v);
+}
+
 // after the scatter: fold the VALID_SLOTS counters into one number for the host, leave them zero for the next
 // call (ctx->scratch is self-cleaning: no per-call memset), publish.  mail == nullptr (deferred): clean only.
 __global__ void __launch_bounds__(64) filter_finish_kernel(unsigned long long* slots, uint64_t* mail, uint64_t seq) {
@@ -729,11 +738,9 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
 // filter scatters straight into an in-progress builder at row `dst_row_offset` — no intermediate
 // array (BatchCoalescer::push_batch_with_filter, arrow-select/src/coalesce.rs:229).  The bitmap
 // words are merged with atomicOr, so any destination bit offset works.
-extern "C" ah_status ah_filter_predicate_apply_into(ah_context* ctx, const ah_filter_predicate* p,
-                                                    const ah_array_view* values, void* dst_values,
-                                                    uint8_t* dst_validity, int64_t dst_row_offset,
-                                                    int64_t* appended_nulls) {
-  ah_ctx_guard _guard(ctx);
+static ah_status apply_into_impl(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* values,
+                                 void* dst_values, uint8_t* dst_validity, int64_t dst_row_offset,
+                                 int64_t* appended_nulls, unsigned long long* nulls_acc, bool no_wait) {
   if (!ctx || !p || !values || !dst_values || !dst_validity) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   if (appended_nulls) *appended_nulls = 0;
@@ -750,7 +757,8 @@ extern "C" ah_status ah_filter_predicate_apply_into(ah_context* ctx, const ah_fi
   const int64_t K = p->count;
   if (p->len == 0 || K == 0) return AH_OK;
   int64_t in_nulls = 0;
-  AH_TRY(ah_resolve_null_count(ctx, values, &in_nulls));
+  if (no_wait && values->null_count < 0) in_nulls = values->validity ? 1 : 0;  // unknown: treat as nullable, no count
+  else AH_TRY(ah_resolve_null_count(ctx, values, &in_nulls));
   const bool has_valid = values->validity && in_nulls > 0;
   unsigned long long* slots = has_valid ? ctx->scratch : nullptr;  // zero between calls
   ScatterArgs a{};
@@ -775,6 +783,15 @@ extern "C" ah_status ah_filter_predicate_apply_into(ah_context* ctx, const ah_fi
   ah_status st = AH_OK;
   if (e == hipSuccess && !has_valid)  // source without nulls: the appended rows are all valid
     st = ah_bitmap_set_bits(ctx, dst_validity, dst_row_offset, nullptr, 0, K, nullptr);
+  if (no_wait) {  // the null count accumulates on the device; the caller reads it when the batch is finished
+    if (e == hipSuccess && has_valid) {
+      filter_finish_acc_kernel<<<1, 64, 0, ctx->stream>>>(slots, (unsigned long long)K, nulls_acc);
+      e = hipGetLastError();
+    }
+    if (st != AH_OK) return st;
+    if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "fused filter copy failed: %s", hipGetErrorString(e));
+    return AH_OK;
+  }
   if (e == hipSuccess && has_valid) {
     const uint64_t seq = ah_mail_next(ctx);
     filter_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, ctx->pinned_dev, seq);
@@ -787,6 +804,25 @@ extern "C" ah_status ah_filter_predicate_apply_into(ah_context* ctx, const ah_fi
   if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "fused filter copy failed: %s", hipGetErrorString(e));
   if (has_valid && appended_nulls) *appended_nulls = K - (int64_t)ctx->pinned[0];
   return AH_OK;
+}
+
+extern "C" ah_status ah_filter_predicate_apply_into(ah_context* ctx, const ah_filter_predicate* p,
+                                                    const ah_array_view* values, void* dst_values,
+                                                    uint8_t* dst_validity, int64_t dst_row_offset,
+                                                    int64_t* appended_nulls) {
+  ah_ctx_guard _guard(ctx);
+  return apply_into_impl(ctx, p, values, dst_values, dst_validity, dst_row_offset, appended_nulls, nullptr, false);
+}
+
+// The same without a host wait (BatchCoalescer's hot loop, arrow-select/src/coalesce.rs:229): the number of NULL rows
+// appended is added to the device word *nulls_acc, read once when the in-progress batch is finished (ah_read_words).
+extern "C" ah_status ah_filter_predicate_apply_into_acc(ah_context* ctx, const ah_filter_predicate* p,
+                                                        const ah_array_view* values, void* dst_values,
+                                                        uint8_t* dst_validity, int64_t dst_row_offset,
+                                                        uint64_t* nulls_acc) {
+  ah_ctx_guard _guard(ctx);
+  if (!nulls_acc) return AH_INVALID_ARGUMENT;
+  return apply_into_impl(ctx, p, values, dst_values, dst_validity, dst_row_offset, nullptr, (unsigned long long*)nulls_acc, true);
 }
 
 extern "C" ah_status ah_filter(ah_context* ctx, const ah_array_view* values,

@@ -470,7 +470,10 @@ def build_workload(env, wl):
         W.update(step=lambda _r: fn(a, b), kernels=[k], dominant=k)
     else:
         n = min(n, 1 << 29) if args.rows == 1_000_000_000 else n
-        src = gen_cast_source(A, K, ctx, n, args.valid, row0)
+        if os.environ.get("AH_BENCH_CAST_PURE") == "1":  # ablation: no full-range rows (round 1's input)
+            src = gen_i64_column(A, ctx, n, 42, args.valid, row0, -10**6, 10**6)
+        else:
+            src = gen_cast_source(A, K, ctx, n, args.valid, row0)
         if wl == "cast":
             W.update(step=lambda _r: K.cast(src, A.Float64), kernels=["cast_numeric"])
         else:

@@ -234,6 +234,16 @@ AH_API ah_status ah_filter_predicate_apply_into(ah_context* ctx, const ah_filter
 AH_API ah_status ah_copy_rows_into(ah_context* ctx, const ah_array_view* src, int64_t offset, int64_t len,
                                    void* dst_values, uint8_t* dst_validity, int64_t dst_row_offset,
                                    int64_t* appended_nulls);
+/* The no-wait forms of the two calls above, for BatchCoalescer's per-batch loop: nothing is read back; the number of
+ * NULL rows appended is added to the device word *nulls_acc (8-byte aligned device memory owned by the caller, one per
+ * in-progress column).  ah_read_words fetches up to 200 such words in ONE host wait (optionally zeroing them) when the
+ * in-progress batch is finished — NullBufferBuilder only needs the count then (coalesce/primitive.rs:94-106). */
+AH_API ah_status ah_filter_predicate_apply_into_acc(ah_context* ctx, const ah_filter_predicate* p,
+                                                    const ah_array_view* values, void* dst_values, uint8_t* dst_validity,
+                                                    int64_t dst_row_offset, uint64_t* nulls_acc);
+AH_API ah_status ah_copy_rows_into_acc(ah_context* ctx, const ah_array_view* src, int64_t offset, int64_t len,
+                                       void* dst_values, uint8_t* dst_validity, int64_t dst_row_offset, uint64_t* nulls_acc);
+AH_API ah_status ah_read_words(ah_context* ctx, uint64_t* dev_words, int32_t n, uint64_t* host_out, int32_t reset);
 
 /* ------------------------------------------------------------------ take */
 /* arrow_select::take::take (arrow-select/src/take.rs:89).  indices.type is any

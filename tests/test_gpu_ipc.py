@@ -282,9 +282,8 @@ def test_decimal_columns_keep_their_logical_type_through_ffi(ctx):
     assert s.data_type == A.Decimal128(13, 2)
     back = ffi.to_pyarrow(s)
     assert back.to_pylist() == [v * 2 for v in vals] + [None]
-    native = A.Array.from_pylist([12345, -250, 99999, 1, None], A.Decimal128(12, 2), ctx) if hasattr(A.Array, "from_pylist") else None
-    if native is not None:
-        assert ffi.to_pyarrow(K.add(native, d)).to_pylist() == [v * 2 for v in vals] + [None]
+    native = A.Array.from_pylist([12345, -250, 99999, 1, None], A.Decimal128(12, 2), ctx)  # a natively typed operand
+    assert ffi.to_pyarrow(K.add(native, d)).to_pylist() == [v * 2 for v in vals] + [None]
     wide = ffi.from_pyarrow(pa.array([decimal.Decimal(7), None], type=pa.decimal256(40, 0)), ctx)
     assert wide.data_type == A.Decimal256(40, 0) and wide.data_type.width == 32
     assert ffi.to_pyarrow(K.filter(wide, ffi.from_pyarrow(pa.array([True, True]), ctx))).to_pylist() == [decimal.Decimal(7), None]
