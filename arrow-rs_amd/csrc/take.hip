@@ -57,8 +57,13 @@ struct TakeArgs {
   unsigned long long* first_oob;    // atomicMin of first out-of-bounds position
 };
 
+#ifdef AH_TAKE_SGPR_CAP
+#define AH_TAKE_SGPR __attribute__((amdgpu_num_sgpr(AH_TAKE_SGPR_CAP)))
+#else
+#define AH_TAKE_SGPR
+#endif
 template <int W, typename IDX, bool OUT_VALID, int KU>
-__global__ void __launch_bounds__(256) take_kernel(TakeArgs a) {
+__global__ void __launch_bounds__(256) AH_TAKE_SGPR take_kernel(TakeArgs a) {
   using ET = typename Elem<W == 0 ? 1 : W>::type;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const IDX* idx = (const IDX*)a.indices;
