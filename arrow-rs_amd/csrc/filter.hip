@@ -180,6 +180,8 @@ __host__ __device__ constexpr int stage_cap(int width) {
 // `vvalid` stream; no value loads.
 // SKIP: predicate each 16-byte load on "any of its rows selected" so cache lines
 // with no selected row are never fetched (pays below ~30% selectivity).
+// 86 VGPRs = 5 workgroups per CU.  Forcing 6 or 8 through __launch_bounds__(256, w) spills the tile's values to scratch and
+// is slower (measured r02: 1.48 ms -> 1.85 ms at w = 6, 3.28 ms at w = 8): the registers ARE the tile.
 template <int W, int V, bool HAS_VALID, bool SKIP>
 __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(ScatterArgs a) {
   constexpr int WE = W == 0 ? 1 : W;

@@ -6,12 +6,13 @@
 //
 // MI355X design: one gather kernel.  A wave owns 256 consecutive output rows as
 // 4 x 64; index loads and value stores are fully coalesced, the 4 gathers per
-// lane are independent.  Measured on MI355X (profiles/): uniformly random 8-byte
-// gathers fill one 128-byte L2 line each (FETCH_SIZE 12.9 GB per 1e8 indices) and
-// the validity-bit gather is a second random line fill served by the Infinity
-// Cache at ~7 TB/s, so the kernel is bound by line-fill traffic: 8 gathers in
-// flight per lane, non-temporal value loads and splitting value/bit gathers into
-// two kernels were all measured and none helps.
+// lane are independent.  Calibrated on MI355X (profiles/r02_take_ablation.md): every
+// random 8-byte gather is ONE 128-byte L2 line fill (TCC_EA0_RDREQ_128B = 1.03e8 per
+// 1e8 indices) and the validity-bit gather a second one (1.00e8, partly served by the
+// Infinity Cache): 26.6 GB moved per launch = 6.8 TB/s, 0.85 of the HBM peak.  The
+// kernel is bound by line-fill bandwidth: 8 gathers in flight per lane, sc0 / sc1 /
+// nt load policies, more resident waves, splitting value / bit gathers, and a
+// radix-partitioned gather + un-permute were all measured and none helps.
 // The output validity word for each group of 64 rows is one __ballot of
 // (index-valid & values-valid[idx]) — the reference's collect_bool
 // (arrow-buffer/src/buffer/mutable.rs:761-791) for free.  Out-of-bounds rows are
@@ -57,13 +58,10 @@ struct TakeArgs {
   unsigned long long* first_oob;    // atomicMin of first out-of-bounds position
 };
 
-#ifdef AH_TAKE_SGPR_CAP
-#define AH_TAKE_SGPR __attribute__((amdgpu_num_sgpr(AH_TAKE_SGPR_CAP)))
-#else
-#define AH_TAKE_SGPR
-#endif
+// 105 SGPRs = 6 workgroups per CU; capping them at 80 (8 per CU) changes nothing (3.95 vs 3.98 ms, r02): the
+// gather is bound by 128-byte line fills (header), not by the number of waves in flight.
 template <int W, typename IDX, bool OUT_VALID, int KU>
-__global__ void __launch_bounds__(256) AH_TAKE_SGPR take_kernel(TakeArgs a) {
+__global__ void __launch_bounds__(256) take_kernel(TakeArgs a) {
   using ET = typename Elem<W == 0 ? 1 : W>::type;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const IDX* idx = (const IDX*)a.indices;
