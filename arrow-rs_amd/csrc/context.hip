@@ -148,6 +148,9 @@ void ah_out_free(ah_context* ctx, void* p, size_t bytes) {
   if (hk != ctx->hook_live.end()) {
     const ah_context::hook_entry e = hk->second;  // freed by the allocator that made it, even if the hook changed since
     ctx->hook_live.erase(hk);
+    // the host's free is not stream-ordered: in deferred mode kernels that still use the buffer may be in flight
+    // (synchronous calls finished theirs before returning), so drain the stream before handing the memory back
+    if (ctx->deferred) (void)ah_stream_wait(ctx);
     if (e.free_) e.free_(e.user, p, bytes);
     return;
   }
