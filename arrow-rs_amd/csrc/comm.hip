@@ -48,9 +48,12 @@ RcclApi* rccl() {
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // AH_RCCL_LIBRARY: an explicit library path (a site's own RCCL build; tests/cpp/fake_rccl.cpp in the test suite)
+    const char* names[] = {getenv("AH_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
+                           "/opt/rocm/lib/librccl.so"};
     for (const char* n : names) {
-      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (!n || !n[0]) continue;
+      api.handle = dlopen(n, RTLD_NOW | (n == names[0] ? RTLD_LOCAL : RTLD_GLOBAL));
       if (api.handle) break;
     }
     if (!api.handle) {

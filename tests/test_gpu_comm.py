@@ -27,6 +27,22 @@ def test_rccl_world1_through_the_c_abi():
     assert out.returncode == 0 and "COMM_WORKER_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_exchange_code_at_world_n_over_a_fake_transport(world, tmp_path):
+    """The product's exchange path (comm.hip) at N > 1 on one GPU: ranks are threads, RCCL's entry points are served by
+    tests/cpp/fake_rccl.cpp (send / recv = matched device-to-device copies).  See tests/comm_ranks_worker.py."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = str(tmp_path / "libfake_rccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Wno-unused-value",
+                           "-o", lib, os.path.join(here, "cpp", "fake_rccl.cpp")])
+    out = subprocess.run([sys.executable, os.path.join(here, "comm_ranks_worker.py"), str(world)], capture_output=True, text=True,
+                         timeout=900, env=dict(os.environ, AH_RCCL_LIBRARY=lib))
+    assert out.returncode == 0 and f"COMM_RANKS_OK {world}" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_bitmap_concat_one_launch(ctx, seed):
     """ah_bitmap_concat == the in-order concatenation of bit-packed pieces: what reassembles the validity of R shards
