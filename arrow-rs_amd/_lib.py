@@ -167,6 +167,15 @@ SIGNATURES = {
     "ah_filter_predicate_apply_into_acc": (C.c_int32, [_P, _P, _VIEW, _P, _P, C.c_int64, _P]),
     "ah_copy_rows_into_acc": (C.c_int32, [_P, _VIEW, C.c_int64, C.c_int64, _P, _P, C.c_int64, _P]),
     "ah_read_words": (C.c_int32, [_P, _P, C.c_int32, C.POINTER(C.c_uint64), C.c_int32]),
+    "ah_coalescer_create": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_int32), C.c_int64, C.POINTER(_P)]),
+    "ah_coalescer_destroy": (None, [_P, _P]),
+    "ah_coalescer_set_biggest_coalesce_batch_size": (None, [_P, C.c_int64]),
+    "ah_coalescer_buffered_rows": (C.c_int64, [_P]),
+    "ah_coalescer_completed_count": (C.c_int32, [_P]),
+    "ah_coalescer_push_batch": (C.c_int32, [_P, _P, _VIEW, C.c_int64, C.c_uint64, C.POINTER(C.c_int32)]),
+    "ah_coalescer_push_batch_with_filter": (C.c_int32, [_P, _P, _VIEW, C.c_int64, _VIEW, C.c_uint64, C.POINTER(C.c_int32)]),
+    "ah_coalescer_finish_buffered_batch": (C.c_int32, [_P, _P]),
+    "ah_coalescer_next_completed_batch": (C.c_int32, [_P, _P, _OUT, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),
     "ah_take": (C.c_int32, [_P, _VIEW, _VIEW, C.c_int32, _OUT]),
     "ah_arith_binary": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
     "ah_arith_with_types": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, C.POINTER(DataTypeDesc), _VIEW, C.c_int32,

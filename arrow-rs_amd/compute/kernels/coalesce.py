@@ -3,8 +3,10 @@
 filter-into-builder path, every other supported layout (Boolean, Utf8, LargeUtf8) through the reference's
 generic buffer-and-concat implementation (coalesce/generic.rs).
 
-The host state machine (exact-size output batches, in input order, optional large-batch bypass)
-is restated here; the data movement happens in HBM:
+The host state machine (exact-size output batches, in input order, optional large-batch bypass) is NATIVE for
+fixed-width columns — ``ah_coalescer_*`` (csrc/coalesce.hip): one C call per pushed batch, no wait except the
+predicate's count, one wait per finished batch.  Schemas with Boolean / string columns keep the Python restatement
+below (their in-progress arrays buffer and concat, coalesce/generic.rs); the data movement happens in HBM either way:
   * ``copy_rows``                 -> ``ah_copy_rows_into`` (D2D copy + funnel-shift bitmap merge)
   * ``copy_rows_by_filter_from``  -> ``ah_filter_predicate_apply_into``: the filter scatters
     straight into the in-progress buffers (no intermediate filtered array, no second copy).
@@ -114,6 +116,18 @@ class BatchCoalescer:
         self.names = list(names)
         self.data_types = list(data_types)
         self.target_batch_size = int(target_batch_size)
+        self.biggest_coalesce_batch_size = None
+        self._native = None
+        if self.data_types and all(dt.is_primitive() and dt.width > 0 and dt.physical not in (L.AH_UTF8_VIEW, L.AH_BINARY_VIEW)
+                                   for dt in self.data_types) and len(self.data_types) <= 200:
+            lib, h = self.ctx.lib, C.c_void_p()
+            types = (C.c_int32 * len(self.data_types))(*[dt.physical for dt in self.data_types])
+            self.ctx.check(lib.ah_coalescer_create(self.ctx.handle, len(self.data_types), types, self.target_batch_size, C.byref(h)))
+            self._native = h
+            self._tagged, self._next_tag = {}, 1
+            import weakref
+            self._fin = weakref.finalize(self, lib.ah_coalescer_destroy, self.ctx.handle, h)
+            return
         # one device word per column for the appended-null counts (zeroed once; ah_read_words resets them)
         ncols = max(len(self.data_types), 1)
         self._acc = DeviceBuffer(self.ctx, ncols * 8) if ncols <= 200 else None
@@ -124,30 +138,69 @@ class BatchCoalescer:
                             for i, dt in enumerate(self.data_types)]
         self.buffered_rows = 0
         self.completed = deque()
-        self.biggest_coalesce_batch_size = None
 
     @classmethod
     def new(cls, names, data_types, target_batch_size, ctx=None):
         return cls(names, data_types, target_batch_size, ctx)
 
     def with_biggest_coalesce_batch_size(self, limit):
-        self.biggest_coalesce_batch_size = limit
+        self.set_biggest_coalesce_batch_size(limit)
         return self
 
     def set_biggest_coalesce_batch_size(self, limit):
         self.biggest_coalesce_batch_size = limit
+        if self._native is not None:
+            self.ctx.lib.ah_coalescer_set_biggest_coalesce_batch_size(self._native, -1 if limit is None else int(limit))
 
     def get_buffered_rows(self):
+        if self._native is not None:
+            return self.ctx.lib.ah_coalescer_buffered_rows(self._native)
         return self.buffered_rows
 
     def is_empty(self):
-        return self.buffered_rows == 0 and not self.completed
+        return self.get_buffered_rows() == 0 and not self.has_completed_batch()
 
     def has_completed_batch(self):
+        if self._native is not None:
+            return self.ctx.lib.ah_coalescer_completed_count(self._native) > 0
         return bool(self.completed)
 
     def next_completed_batch(self):
-        return self.completed.popleft() if self.completed else None
+        if self._native is None:
+            return self.completed.popleft() if self.completed else None
+        n = len(self.data_types)
+        outs = (L.ArrayOut * n)()
+        rows, tag = C.c_int64(), C.c_uint64()
+        self.ctx.check(self.ctx.lib.ah_coalescer_next_completed_batch(self.ctx.handle, self._native, outs, C.byref(rows), C.byref(tag)))
+        if rows.value < 0:
+            return None
+        if tag.value:  # the caller's own batch, passed through untouched (large-batch bypass)
+            return self._tagged.pop(tag.value)
+        cols = []
+        for i, dt in enumerate(self.data_types):
+            o = L.ArrayOut()
+            C.memmove(C.byref(o), C.byref(outs[i]), C.sizeof(L.ArrayOut))
+            cols.append(Array._from_out(self.ctx, o, dt))
+        return RecordBatch(self.names, cols, num_rows=rows.value)
+
+    def _views(self, batch):
+        if batch.num_columns() != len(self.data_types):
+            raise InvalidArgumentError(
+                f"Batch has {batch.num_columns()} columns but BatchCoalescer expects {len(self.data_types)}")
+        views = (L.ArrayView * len(self.data_types))()
+        for i, c in enumerate(batch.columns):
+            views[i] = c.view()
+        return views
+
+    def _native_push(self, fn, batch, *args):
+        """one C call per pushed batch; a bypassed batch (large-batch cases 1 / 2) is kept alive under its tag until it
+        comes back from next_completed_batch"""
+        tag = self._next_tag
+        self._next_tag += 1
+        bypassed = C.c_int32()
+        self.ctx.check(fn(self.ctx.handle, self._native, *args, tag, C.byref(bypassed)))
+        if bypassed.value:
+            self._tagged[tag] = batch
 
     # ---- coalesce.rs:229
     def push_batch_with_filter(self, batch, filter):
@@ -157,6 +210,9 @@ class BatchCoalescer:
         if filter_len > rows:
             raise InvalidArgumentError(
                 f"Filter predicate of length {filter_len} is larger than target array of length {rows}")
+        if self._native is not None:
+            views, fv = self._views(batch), filter.view()
+            return self._native_push(self.ctx.lib.ah_coalescer_push_batch_with_filter, batch, views, rows, C.byref(fv))
         predicate = FilterBuilder.new(filter).optimize().build()  # one count pass for all columns
         selected = predicate.count()
         if selected == 0:
@@ -185,6 +241,8 @@ class BatchCoalescer:
         batch_size = batch.num_rows()
         if batch_size == 0:
             return
+        if self._native is not None:
+            return self._native_push(self.ctx.lib.ah_coalescer_push_batch, batch, self._views(batch), batch_size)
         limit = self.biggest_coalesce_batch_size
         if limit is not None and batch_size > limit:
             if self.buffered_rows == 0:          # case 1: bypass
@@ -215,6 +273,8 @@ class BatchCoalescer:
 
     # ---- coalesce.rs:536
     def finish_buffered_batch(self):
+        if self._native is not None:
+            return self.ctx.check(self.ctx.lib.ah_coalescer_finish_buffered_batch(self.ctx.handle, self._native))
         if self.buffered_rows == 0:
             return
         if self._acc is not None:  # the ONE wait of this output batch: every column's appended-null count

@@ -245,6 +245,32 @@ AH_API ah_status ah_copy_rows_into_acc(ah_context* ctx, const ah_array_view* src
                                        void* dst_values, uint8_t* dst_validity, int64_t dst_row_offset, uint64_t* nulls_acc);
 AH_API ah_status ah_read_words(ah_context* ctx, uint64_t* dev_words, int32_t n, uint64_t* host_out, int32_t reset);
 
+/* BatchCoalescer (arrow-select/src/coalesce.rs:148-700) as a native object: the reference's state machine — exact-size
+ * output batches in input order, `biggest_coalesce_batch_size` bypass cases 1-3 (:296-420), push_batch_with_filter (:229),
+ * finish_buffered_batch (:536), next_completed_batch (:566) — over fixed-width columns (InProgressPrimitiveArray,
+ * coalesce/primitive.rs).  Filtered pushes scatter straight into the in-progress batch; no push waits for the GPU
+ * except for the predicate's count; one wait per finished batch.  `tag` (any non-zero value naming the caller's batch)
+ * comes back from ah_coalescer_next_completed_batch when that very batch was passed through untouched (large-batch
+ * bypass; the push sets *bypassed = 1 so the caller knows to keep that batch alive): its outs are AH_OUT_BORROWED views of the
+ * caller's buffers.  Other column types: AH_NOT_YET_IMPLEMENTED
+ * (the host falls back to buffer-and-concat, coalesce/generic.rs). */
+typedef struct ah_coalescer ah_coalescer;
+AH_API ah_status ah_coalescer_create(ah_context* ctx, int32_t n_columns, const ah_type* types, int64_t target_batch_size,
+                                     ah_coalescer** out);
+AH_API void ah_coalescer_destroy(ah_context* ctx, ah_coalescer* co);
+AH_API void ah_coalescer_set_biggest_coalesce_batch_size(ah_coalescer* co, int64_t limit /* < 0: none */);
+AH_API int64_t ah_coalescer_buffered_rows(const ah_coalescer* co);
+AH_API int32_t ah_coalescer_completed_count(const ah_coalescer* co);
+AH_API ah_status ah_coalescer_push_batch(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns, int64_t num_rows,
+                                         uint64_t tag, int32_t* bypassed /* nullable */);
+AH_API ah_status ah_coalescer_push_batch_with_filter(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns,
+                                                     int64_t num_rows, const ah_array_view* filter, uint64_t tag,
+                                                     int32_t* bypassed /* nullable */);
+AH_API ah_status ah_coalescer_finish_buffered_batch(ah_context* ctx, ah_coalescer* co);
+/* *num_rows = -1 when no batch is ready; outs[n_columns] are released with ah_array_release */
+AH_API ah_status ah_coalescer_next_completed_batch(ah_context* ctx, ah_coalescer* co, ah_array_out* outs, int64_t* num_rows,
+                                                   uint64_t* tag);
+
 /* ------------------------------------------------------------------ take */
 /* arrow_select::take::take (arrow-select/src/take.rs:89).  indices.type is any
  * of the 8 integer types; i32/i64 are reinterpreted as u32/u64, 8/16-bit are
