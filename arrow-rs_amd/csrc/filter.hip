@@ -81,6 +81,36 @@ __global__ void __launch_bounds__(1024) filter_count_kernel(BitView mask, BitVie
   if (t == 1023) group_total[blockIdx.x] = wbase + (uint32_t)incl;
 }
 
+// K1 for small predicates (<= 64 Mi rows: BatchCoalescer / DataFusion-sized batches).  The kernel above gives one
+// 1024-thread block per 1 Mi rows — 16 blocks on 256 CUs for a 2^24-row batch (21 us).  Here a block is ONE wave that
+// owns 64 chunks (65 536 rows), so the same batch spreads over 256 blocks; the group granule becomes 64 chunks
+// (`group_shift` 6 instead of 10) and the scatter reads its prefix with that shift.
+__global__ void __launch_bounds__(64) filter_count_small_kernel(BitView mask, BitView mask_valid, int64_t len,
+                                                               uint32_t* chunk_prefix, uint32_t* group_total) {
+  __shared__ uint32_t s_cnt[64];
+  const int lane = threadIdx.x;
+  const int64_t chunk_base = (int64_t)blockIdx.x * 64;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int64_t chunk4 = chunk_base + it * 4;  // 4 chunks = 64 words per step, coalesced
+    const int64_t s = (chunk4 * 16 + lane) << 6;
+    uint64_t m = bv_fetch64(mask, s, len);
+    if (mask_valid.words) m &= bv_fetch64(mask_valid, s, len);
+    int c = __popcll(m);
+    c += __shfl_xor(c, 1, 64);
+    c += __shfl_xor(c, 2, 64);
+    c += __shfl_xor(c, 4, 64);
+    c += __shfl_xor(c, 8, 64);
+    if ((lane & 15) == 0) s_cnt[it * 4 + (lane >> 4)] = (uint32_t)c;
+  }
+  __syncthreads();
+  const int v = (int)s_cnt[lane];
+  const int incl = wave_scan_incl(v);
+  const int64_t nchunks = (len + CHUNK_ROWS - 1) / CHUNK_ROWS;
+  if (chunk_base + lane < nchunks) chunk_prefix[chunk_base + lane] = (uint32_t)(incl - v);
+  if (lane == 63) group_total[blockIdx.x] = (uint32_t)incl;
+}
+
 // ------------------------------------------------------------------ K2
 __global__ void __launch_bounds__(1024) filter_group_scan_kernel(const uint32_t* group_total,
                                                                  int64_t ngroups,
@@ -164,6 +194,7 @@ struct ScatterArgs {
   void* out_values;
   unsigned long long* out_valid;   // zero-initialised u64 words
   unsigned long long* valid_slots; // VALID_SLOTS zero-initialised counters (valid selected rows)
+  int group_shift;                 // log2(chunks per count group): 10 (filter_count_kernel) or 6 (the small-mask one)
   int xcd_remap;                   // 1: tiles that share output lines stay on one XCD
   int64_t out_base;                // rows already present in the destination (fused filter-into-builder)
   int64_t ntiles;
@@ -260,7 +291,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
   }
 
   const int64_t chunk0 = row0 / CHUNK_ROWS;
-  const int64_t ob = a.out_base + (int64_t)a.group_prefix[chunk0 / GROUP_CHUNKS] + a.chunk_prefix[chunk0];
+  const int64_t ob = a.out_base + (int64_t)a.group_prefix[chunk0 >> a.group_shift] + a.chunk_prefix[chunk0];
   int vc = 0;
 
   for (int p0 = 0; p0 < total; p0 += CAP) {
@@ -399,6 +430,7 @@ struct ah_filter_predicate {
   int64_t count = 0;
   uint32_t* chunk_prefix = nullptr;
   unsigned long long* group_prefix = nullptr;
+  int group_shift = 10;
   void* block = nullptr;  // single pool allocation backing the tables
 };
 
@@ -425,7 +457,9 @@ extern "C" ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_v
     return AH_OK;
   }
   int64_t nchunks = ah_ceil_div(p->len, CHUNK_ROWS);
-  int64_t ngroups = ah_ceil_div(nchunks, GROUP_CHUNKS);
+  const bool small = nchunks <= 65536;  // <= 64 Mi rows: one-wave count blocks, 64-chunk groups
+  p->group_shift = small ? 6 : 10;
+  int64_t ngroups = ah_ceil_div(nchunks, small ? 64 : GROUP_CHUNKS);
   size_t b_chunk = ((size_t)nchunks * 4 + 255) & ~(size_t)255;
   size_t b_gt = ((size_t)ngroups * 4 + 255) & ~(size_t)255;
   size_t b_gp = ((size_t)ngroups * 8 + 255) & ~(size_t)255;
@@ -442,8 +476,12 @@ extern "C" ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_v
   const uint64_t seq = ah_mail_next(ctx);
   {
     ah_prof_scope ps(ctx, "filter_count");
-    filter_count_kernel<<<(unsigned)ngroups, 1024, 0, ctx->stream>>>(p->mask, p->mask_valid, p->len,
-                                                                    p->chunk_prefix, group_total);
+    if (small)
+      filter_count_small_kernel<<<(unsigned)ngroups, 64, 0, ctx->stream>>>(p->mask, p->mask_valid, p->len, p->chunk_prefix,
+                                                                          group_total);
+    else
+      filter_count_kernel<<<(unsigned)ngroups, 1024, 0, ctx->stream>>>(p->mask, p->mask_valid, p->len,
+                                                                      p->chunk_prefix, group_total);
     filter_group_scan_kernel<<<1, 1024, 0, ctx->stream>>>(group_total, ngroups, p->group_prefix,
                                                           total, ctx->pinned_dev, seq);
   }
@@ -485,6 +523,7 @@ static ah_status compact_bits(ah_context* ctx, const ah_filter_predicate* p, Bit
   a.len = p->len;
   a.chunk_prefix = p->chunk_prefix;
   a.group_prefix = p->group_prefix;
+  a.group_shift = p->group_shift;
   a.out_values = nullptr;
   a.out_valid = (unsigned long long*)ob;
   a.valid_slots = slots;
@@ -691,6 +730,7 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
   a.len = p->len;
   a.chunk_prefix = p->chunk_prefix;
   a.group_prefix = p->group_prefix;
+  a.group_shift = p->group_shift;
   a.out_values = ov;
   a.out_valid = (unsigned long long*)ob;
   a.valid_slots = slots;
@@ -771,6 +811,7 @@ static ah_status apply_into_impl(ah_context* ctx, const ah_filter_predicate* p, 
   a.len = p->len;
   a.chunk_prefix = p->chunk_prefix;
   a.group_prefix = p->group_prefix;
+  a.group_shift = p->group_shift;
   a.out_values = dst_values;
   a.out_valid = (unsigned long long*)dst_validity;
   a.valid_slots = slots;
