@@ -16,6 +16,8 @@
 //! | [`shift`] | `arrow_select::window::shift` (arrow-select/src/window.rs:56) |
 //! | [`rank`] | `arrow_ord::rank::rank` (arrow-ord/src/rank.rs:58) |
 //! | [`DeviceArray::from_host`], [`DeviceArray::to_host`] | `arrow::ffi::{to_ffi, from_ffi}` (arrow-array/src/ffi.rs:231-254) |
+//! | [`BatchCoalescer`] | `arrow_select::coalesce::BatchCoalescer` (arrow-select/src/coalesce.rs:148) |
+//! | [`Comm`] | — (no parallelism in the reference): `concat` / `concat_batches` (concat.rs:495,:607) of row shards across GPUs |
 use std::ffi::CStr;
 use std::mem::MaybeUninit;
 use std::ptr;
@@ -28,13 +30,16 @@ use arrow::error::ArrowError;
 use arrow::ffi::{from_ffi, to_ffi, FFI_ArrowArray, FFI_ArrowSchema};
 use arrow_hip_sys as sys;
 
-/// One HIP stream + pooled HBM allocator on one GPU; use one per calling thread.
+/// One HIP stream + pooled HBM allocator on one GPU.
 pub struct Context {
     raw: *mut sys::ah_context,
 }
 
-// the library serialises nothing: a context is used by one thread at a time
+// every entry point of libarrow_hip.so locks its context for the duration of the call (a recursive mutex inside
+// `ah_context`), so one `Context` may be shared by threads: calls on it serialise.  Threads that
+// want their kernels to overlap create one context each.
 unsafe impl Send for Context {}
+unsafe impl Sync for Context {}
 
 impl Context {
     pub fn new(device: i32) -> Result<Arc<Self>, ArrowError> {
@@ -454,4 +459,164 @@ pub fn rank(values: &Arc<DeviceArray>, options: Option<SortOptions>) -> Result<A
     let v = values.view();
     values.ctx.check(unsafe { sys::ah_rank(values.ctx.raw, &v, o.descending as i32, o.nulls_first as i32, out.as_mut_ptr()) })?;
     Ok(wrap(values, unsafe { out.assume_init() }, DataType::UInt32, &[]))
+}
+
+
+// ------------------------------------------------------------------------------------------- BatchCoalescer
+/// `arrow_select::coalesce::BatchCoalescer` (coalesce.rs:148) over fixed-width device columns: the state machine
+/// is native (`ah_coalescer_*`); filtered pushes scatter straight into the in-progress batch and never wait for
+/// the GPU except for the predicate's count.
+pub struct BatchCoalescer {
+    ctx: Arc<Context>,
+    raw: *mut sys::ah_coalescer,
+    types: Vec<DataType>,
+    /// input batches that were passed through untouched (large-batch bypass), by tag, until they are popped
+    bypassed: std::collections::HashMap<u64, Vec<Arc<DeviceArray>>>,
+    next_tag: u64,
+}
+
+impl BatchCoalescer {
+    /// `BatchCoalescer::new(schema, target_batch_size)` (coalesce.rs:167)
+    pub fn new(ctx: &Arc<Context>, types: &[DataType], target_batch_size: usize) -> Result<Self, ArrowError> {
+        let phys: Vec<sys::ah_type> = types.iter().map(|t| physical(ctx, t)).collect::<Result<_, _>>()?;
+        let mut raw = ptr::null_mut();
+        ctx.check(unsafe {
+            sys::ah_coalescer_create(ctx.raw, phys.len() as i32, phys.as_ptr(), target_batch_size as i64, &mut raw)
+        })?;
+        Ok(Self { ctx: ctx.clone(), raw, types: types.to_vec(), bypassed: Default::default(), next_tag: 1 })
+    }
+
+    /// `with_biggest_coalesce_batch_size` (coalesce.rs:196)
+    pub fn with_biggest_coalesce_batch_size(self, limit: Option<usize>) -> Self {
+        unsafe { sys::ah_coalescer_set_biggest_coalesce_batch_size(self.raw, limit.map_or(-1, |l| l as i64)) };
+        self
+    }
+
+    fn push(&mut self, columns: &[Arc<DeviceArray>], filter: Option<&Arc<DeviceArray>>) -> Result<(), ArrowError> {
+        let views: Vec<sys::ah_array_view> = columns.iter().map(|c| c.view()).collect();
+        let rows = columns.first().map_or(0, |c| c.len()) as i64;
+        let (tag, mut bypass) = (self.next_tag, 0i32);
+        self.next_tag += 1;
+        let st = match filter {
+            None => unsafe { sys::ah_coalescer_push_batch(self.ctx.raw, self.raw, views.as_ptr(), rows, tag, &mut bypass) },
+            Some(f) => {
+                let fv = f.view();
+                unsafe {
+                    sys::ah_coalescer_push_batch_with_filter(self.ctx.raw, self.raw, views.as_ptr(), rows, &fv, tag, &mut bypass)
+                }
+            }
+        };
+        self.ctx.check(st)?;
+        if bypass != 0 {
+            self.bypassed.insert(tag, columns.to_vec());
+        }
+        Ok(())
+    }
+
+    /// `push_batch` (coalesce.rs:296)
+    pub fn push_batch(&mut self, columns: &[Arc<DeviceArray>]) -> Result<(), ArrowError> {
+        self.push(columns, None)
+    }
+
+    /// `push_batch_with_filter` (coalesce.rs:229)
+    pub fn push_batch_with_filter(&mut self, columns: &[Arc<DeviceArray>], filter: &Arc<DeviceArray>) -> Result<(), ArrowError> {
+        self.push(columns, Some(filter))
+    }
+
+    /// `finish_buffered_batch` (coalesce.rs:536)
+    pub fn finish_buffered_batch(&mut self) -> Result<(), ArrowError> {
+        self.ctx.check(unsafe { sys::ah_coalescer_finish_buffered_batch(self.ctx.raw, self.raw) })
+    }
+
+    pub fn has_completed_batch(&self) -> bool {
+        unsafe { sys::ah_coalescer_completed_count(self.raw) > 0 }
+    }
+
+    pub fn get_buffered_rows(&self) -> usize {
+        unsafe { sys::ah_coalescer_buffered_rows(self.raw) as usize }
+    }
+
+    /// `next_completed_batch` (coalesce.rs:566): the columns of the next exact-size batch
+    pub fn next_completed_batch(&mut self) -> Result<Option<Vec<Arc<DeviceArray>>>, ArrowError> {
+        let n = self.types.len();
+        let mut outs: Vec<sys::ah_array_out> = (0..n).map(|_| unsafe { std::mem::zeroed() }).collect();
+        let (mut rows, mut tag) = (0i64, 0u64);
+        self.ctx.check(unsafe {
+            sys::ah_coalescer_next_completed_batch(self.ctx.raw, self.raw, outs.as_mut_ptr(), &mut rows, &mut tag)
+        })?;
+        if rows < 0 {
+            return Ok(None);
+        }
+        if tag != 0 {
+            return Ok(self.bypassed.remove(&tag)); // the caller's own batch, untouched
+        }
+        Ok(Some(
+            outs.into_iter()
+                .zip(self.types.iter())
+                .map(|(out, dt)| Arc::new(DeviceArray { ctx: self.ctx.clone(), out, data_type: dt.clone(), _keep: vec![] }))
+                .collect(),
+        ))
+    }
+}
+
+impl Drop for BatchCoalescer {
+    fn drop(&mut self) {
+        unsafe { sys::ah_coalescer_destroy(self.ctx.raw, self.raw) }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- multi-GPU exchange
+/// One rank of the row-sharded exchange (one process per GPU).  libarrow_hip.so binds RCCL itself; the host only
+/// ships rank 0's id to the other ranks (its control plane, a file, MPI ...).  INTEGRATION.md §2d.
+pub struct Comm {
+    ctx: Arc<Context>,
+    raw: *mut sys::ah_comm,
+}
+
+impl Comm {
+    /// rank 0: the 128 bytes every rank passes to [`Comm::new`]
+    pub fn unique_id(ctx: &Context) -> Result<[u8; sys::AH_COMM_ID_BYTES], ArrowError> {
+        let mut id = [0u8; sys::AH_COMM_ID_BYTES];
+        ctx.check(unsafe { sys::ah_comm_unique_id(ctx.raw, id.as_mut_ptr()) })?;
+        Ok(id)
+    }
+
+    /// collective over all ranks (`ncclCommInitRank`)
+    pub fn new(ctx: &Arc<Context>, rank: i32, world: i32, id: &[u8; sys::AH_COMM_ID_BYTES]) -> Result<Self, ArrowError> {
+        let mut raw = ptr::null_mut();
+        ctx.check(unsafe { sys::ah_comm_create(ctx.raw, rank, world, id.as_ptr(), &mut raw) })?;
+        Ok(Self { ctx: ctx.clone(), raw })
+    }
+
+    /// `concat(rank 0's array, rank 1's array, ...)` on every rank (arrow-select/src/concat.rs:495 across ranks)
+    pub fn all_gatherv(&self, local: &Arc<DeviceArray>) -> Result<Arc<DeviceArray>, ArrowError> {
+        let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+        let v = local.view();
+        self.ctx.check(unsafe { sys::ah_all_gatherv(self.ctx.raw, self.raw, &v, out.as_mut_ptr(), ptr::null_mut()) })?;
+        Ok(Arc::new(DeviceArray { ctx: self.ctx.clone(), out: unsafe { out.assume_init() }, data_type: local.data_type.clone(), _keep: vec![] }))
+    }
+
+    /// the columns of a RecordBatch shard in ONE count exchange + ONE grouped send / recv (`concat_batches`, concat.rs:607)
+    pub fn all_gather_columns(&self, shard: &[Arc<DeviceArray>]) -> Result<Vec<Arc<DeviceArray>>, ArrowError> {
+        let views: Vec<sys::ah_array_view> = shard.iter().map(|c| c.view()).collect();
+        let mut outs: Vec<sys::ah_array_out> = (0..shard.len()).map(|_| unsafe { std::mem::zeroed() }).collect();
+        self.ctx.check(unsafe {
+            sys::ah_all_gather_columns(self.ctx.raw, self.raw, views.len() as i32, views.as_ptr(), outs.as_mut_ptr(), ptr::null_mut())
+        })?;
+        Ok(outs
+            .into_iter()
+            .zip(shard.iter())
+            .map(|(out, c)| Arc::new(DeviceArray { ctx: self.ctx.clone(), out, data_type: c.data_type.clone(), _keep: vec![] }))
+            .collect())
+    }
+
+    pub fn barrier(&self) -> Result<(), ArrowError> {
+        self.ctx.check(unsafe { sys::ah_comm_barrier(self.ctx.raw, self.raw) })
+    }
+}
+
+impl Drop for Comm {
+    fn drop(&mut self) {
+        unsafe { sys::ah_comm_destroy(self.ctx.raw, self.raw) }
+    }
 }
