@@ -20,7 +20,9 @@
 //                                         arrow-cast/src/cast/mod.rs:347,:790,:95
 //   arrow_hip::compute::concat            arrow-select/src/concat.rs:495
 #pragma once
+#include <array>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <optional>
 #include <stdexcept>
@@ -65,7 +67,8 @@ class Panic : public std::runtime_error {
   using std::runtime_error::runtime_error;
 };
 
-// One HIP stream + pooled HBM allocator; one per calling thread.
+// One HIP stream + pooled HBM allocator.  Entry points lock their context for the duration of a call, so a Context may
+// be shared by threads (calls serialise); threads that want overlap use one each.
 class Context {
  public:
   explicit Context(int device = 0) {
@@ -497,6 +500,102 @@ inline int64_t find_nth_set_bit(const ArrayRef& mask, int64_t start, int64_t n) 
   return pos;
 }
 }  // namespace selection
+
+// BatchCoalescer (arrow-select/src/coalesce.rs:148): exact-size output batches from a stream of (filtered) input
+// batches.  The state machine is the native ah_coalescer object; fixed-width columns.
+class BatchCoalescer {
+ public:
+  BatchCoalescer(std::shared_ptr<Context> ctx, const std::vector<ah_type>& types, int64_t target_batch_size)
+      : ctx_(std::move(ctx)), n_(types.size()) {
+    ctx_->check(ah_coalescer_create(ctx_->handle(), (int32_t)types.size(), types.data(), target_batch_size, &h_));
+  }
+  ~BatchCoalescer() { ah_coalescer_destroy(ctx_->handle(), h_); }
+  BatchCoalescer(const BatchCoalescer&) = delete;
+  BatchCoalescer& operator=(const BatchCoalescer&) = delete;
+  BatchCoalescer& with_biggest_coalesce_batch_size(std::optional<int64_t> limit) {  // coalesce.rs:196
+    ah_coalescer_set_biggest_coalesce_batch_size(h_, limit ? *limit : -1);
+    return *this;
+  }
+  void push_batch(const RecordBatch& b) { push(b, nullptr); }                                       // :296
+  void push_batch_with_filter(const RecordBatch& b, const ArrayRef& filter) { push(b, &filter); }   // :229
+  void finish_buffered_batch() { ctx_->check(ah_coalescer_finish_buffered_batch(ctx_->handle(), h_)); }  // :536
+  bool has_completed_batch() const { return ah_coalescer_completed_count(h_) > 0; }
+  int64_t get_buffered_rows() const { return ah_coalescer_buffered_rows(h_); }
+  bool is_empty() const { return get_buffered_rows() == 0 && !has_completed_batch(); }
+  std::optional<RecordBatch> next_completed_batch() {  // :566
+    std::vector<ah_array_out> outs(n_);
+    int64_t rows = -1;
+    uint64_t tag = 0;
+    ctx_->check(ah_coalescer_next_completed_batch(ctx_->handle(), h_, outs.data(), &rows, &tag));
+    if (rows < 0) return std::nullopt;
+    if (tag) {  // the caller's own batch, passed through untouched (large-batch bypass)
+      RecordBatch b = std::move(bypassed_.at(tag));
+      bypassed_.erase(tag);
+      return b;
+    }
+    RecordBatch b;
+    b.num_rows = rows;
+    for (size_t i = 0; i < n_; ++i) b.columns.push_back(std::make_shared<Array>(ctx_, outs[i]));
+    return b;
+  }
+
+ private:
+  void push(const RecordBatch& b, const ArrayRef* filter) {
+    std::vector<ah_array_view> views;
+    for (auto& c : b.columns) views.push_back(c->view());
+    const uint64_t tag = next_tag_++;
+    int32_t bypass = 0;
+    if (filter)
+      ctx_->check(ah_coalescer_push_batch_with_filter(ctx_->handle(), h_, views.data(), b.num_rows, &(*filter)->view(), tag, &bypass));
+    else
+      ctx_->check(ah_coalescer_push_batch(ctx_->handle(), h_, views.data(), b.num_rows, tag, &bypass));
+    if (bypass) bypassed_.emplace(tag, b);
+  }
+  std::shared_ptr<Context> ctx_;
+  ah_coalescer* h_ = nullptr;
+  size_t n_;
+  uint64_t next_tag_ = 1;
+  std::map<uint64_t, RecordBatch> bypassed_;
+};
+
+// The multi-GPU exchange: one process per GPU, one Communicator per process (ah_comm_*; libarrow_hip.so binds RCCL).
+// Rank 0 creates the id, the host ships its 128 bytes to every rank, every rank constructs a Communicator with it.
+class Communicator {
+ public:
+  static std::array<uint8_t, AH_COMM_ID_BYTES> unique_id(const std::shared_ptr<Context>& ctx) {
+    std::array<uint8_t, AH_COMM_ID_BYTES> id{};
+    ctx->check(ah_comm_unique_id(ctx->handle(), id.data()));
+    return id;
+  }
+  Communicator(std::shared_ptr<Context> ctx, int rank, int world, const uint8_t* id) : ctx_(std::move(ctx)) {
+    ctx_->check(ah_comm_create(ctx_->handle(), rank, world, id, &h_));
+  }
+  ~Communicator() { ah_comm_destroy(ctx_->handle(), h_); }
+  Communicator(const Communicator&) = delete;
+  Communicator& operator=(const Communicator&) = delete;
+  // concat(rank 0's array, rank 1's array, ...) on every rank (arrow-select/src/concat.rs:495 across ranks)
+  ArrayRef all_gatherv(const ArrayRef& local, ah_exchange_stats* stats = nullptr) {
+    ah_array_out out;
+    ctx_->check(ah_all_gatherv(ctx_->handle(), h_, &local->view(), &out, stats));
+    return std::make_shared<Array>(ctx_, out);
+  }
+  // concat_batches (concat.rs:607) of every rank's shard: one count exchange + one grouped send / recv for all columns
+  RecordBatch all_gather_record_batch(const RecordBatch& shard, ah_exchange_stats* stats = nullptr) {
+    std::vector<ah_array_view> views;
+    for (auto& c : shard.columns) views.push_back(c->view());
+    std::vector<ah_array_out> outs(views.size());
+    ctx_->check(ah_all_gather_columns(ctx_->handle(), h_, (int32_t)views.size(), views.data(), outs.data(), stats));
+    RecordBatch b;
+    for (auto& o : outs) b.columns.push_back(std::make_shared<Array>(ctx_, o));
+    b.num_rows = b.columns.empty() ? 0 : b.columns[0]->len();
+    return b;
+  }
+  void barrier() { ctx_->check(ah_comm_barrier(ctx_->handle(), h_)); }
+
+ private:
+  std::shared_ptr<Context> ctx_;
+  ah_comm* h_ = nullptr;
+};
 
 // Arrow C Data Interface (arrow-array/src/ffi.rs:231-254).  `from_ffi` copies a host-resident
 // producer array into HBM (the producer keeps ownership of its structs); `to_ffi` fills structs

@@ -135,6 +135,41 @@ int main() {
     auto back = compute::cast(ts, compute::timestamp(AH_SECOND, 20700), compute::date32());
     assert((download<int32_t>(back) == std::vector<int32_t>{18628, 18993}));
   }
+  // BatchCoalescer doc examples (coalesce.rs:79-107 push_batch, :218-228 with a filter) through the native object
+  {
+    BatchCoalescer co(ctx, {AH_INT32}, 4);
+    RecordBatch b1{{upload<int32_t>(ctx, AH_INT32, {1, 2, 3}, nullptr, keep)}, 3};
+    RecordBatch b2{{upload<int32_t>(ctx, AH_INT32, {4, 5}, nullptr, keep)}, 2};
+    co.push_batch(b1);
+    assert(!co.next_completed_batch().has_value());
+    co.push_batch(b2);
+    auto done = co.next_completed_batch();
+    assert(done && done->num_rows == 4 && (download<int32_t>(done->columns[0]) == std::vector<int32_t>{1, 2, 3, 4}));
+    co.finish_buffered_batch();
+    done = co.next_completed_batch();
+    assert(done && (download<int32_t>(done->columns[0]) == std::vector<int32_t>{5}) && co.is_empty());
+
+    BatchCoalescer cf(ctx, {AH_INT32}, 1000);
+    auto keep3 = upload_bool(ctx, {true, false, true}, keep);
+    cf.push_batch_with_filter(RecordBatch{{upload<int32_t>(ctx, AH_INT32, {1, 2, 3}, nullptr, keep)}, 3}, keep3);
+    cf.push_batch_with_filter(RecordBatch{{upload<int32_t>(ctx, AH_INT32, {4, 5, 6}, nullptr, keep)}, 3}, keep3);
+    cf.finish_buffered_batch();
+    done = cf.next_completed_batch();
+    assert(done && (download<int32_t>(done->columns[0]) == std::vector<int32_t>{1, 3, 4, 6}) && !done->columns[0]->has_nulls_buffer());
+    // large-batch bypass: the caller's own batch comes back untouched (coalesce.rs:330-345, case 1)
+    BatchCoalescer cb(ctx, {AH_INT32}, 4);
+    cb.with_biggest_coalesce_batch_size(2);
+    cb.push_batch(b1);
+    done = cb.next_completed_batch();
+    assert(done && done->columns[0].get() == b1.columns[0].get());
+  }
+  // the exchange step at world 1 without RCCL (id == nullptr): concat of one shard
+  {
+    Communicator comm(ctx, 0, 1, nullptr);
+    auto g = comm.all_gatherv(c);
+    assert(g->len() == 2 && (download<int32_t>(g) == std::vector<int32_t>{5, 8}));
+    comm.barrier();
+  }
   std::puts("CPP_HOST_MIRROR_OK");
   // C Data Interface round trip (arrow-array/src/ffi.rs:231-254): host producer -> HBM -> filter -> host
   {
