@@ -174,6 +174,9 @@ SIGNATURES = {
     "ah_coalescer_completed_count": (C.c_int32, [_P]),
     "ah_coalescer_push_batch": (C.c_int32, [_P, _P, _VIEW, C.c_int64, C.c_uint64, C.POINTER(C.c_int32)]),
     "ah_coalescer_push_batch_with_filter": (C.c_int32, [_P, _P, _VIEW, C.c_int64, _VIEW, C.c_uint64, C.POINTER(C.c_int32)]),
+    "ah_coalescer_push_batches_with_filters": (C.c_int32, [_P, _P, C.c_int32, _VIEW, C.POINTER(C.c_int64), _VIEW,
+                                                           C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
+    "ah_filter_predicates_build": (C.c_int32, [_P, C.c_int32, _VIEW, C.POINTER(_P)]),
     "ah_coalescer_finish_buffered_batch": (C.c_int32, [_P, _P]),
     "ah_coalescer_next_completed_batch": (C.c_int32, [_P, _P, _OUT, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),
     "ah_take": (C.c_int32, [_P, _VIEW, _VIEW, C.c_int32, _OUT]),

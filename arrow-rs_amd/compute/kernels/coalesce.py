@@ -232,6 +232,38 @@ class BatchCoalescer:
         if self.buffered_rows >= self.target_batch_size:
             self.finish_buffered_batch()
 
+    def push_batches_with_filters(self, pairs):
+        """``push_batch_with_filter`` for a list of (batch, filter) pairs — the same output batches in the same order, but
+        with ONE host wait for all the predicate counts (``ah_coalescer_push_batches_with_filters``): for a caller that
+        has several batches queued.  Non-native schemas fall back to one push per pair."""
+        pairs = list(pairs)
+        if self._native is None or not pairs:
+            for b, f in pairs:
+                self.push_batch_with_filter(b, f)
+            return
+        n, nc = len(pairs), len(self.data_types)
+        views = (L.ArrayView * (n * nc))()
+        fviews = (L.ArrayView * n)()
+        rows = (C.c_int64 * n)()
+        tags = (C.c_uint64 * n)()
+        bypassed = (C.c_int32 * n)()
+        for i, (b, f) in enumerate(pairs):
+            if f.data_type != Boolean:
+                raise InvalidArgumentError(f"filter predicate must be Boolean, got {f.data_type}")
+            if b.num_columns() != nc:
+                raise InvalidArgumentError(f"Batch has {b.num_columns()} columns but BatchCoalescer expects {nc}")
+            for k, c in enumerate(b.columns):
+                views[i * nc + k] = c.view()
+            fviews[i] = f.view()
+            rows[i] = b.num_rows()
+            tags[i] = self._next_tag
+            self._next_tag += 1
+        self.ctx.check(self.ctx.lib.ah_coalescer_push_batches_with_filters(self.ctx.handle, self._native, n, views, rows, fviews,
+                                                                           tags, bypassed))
+        for i, (b, _f) in enumerate(pairs):
+            if bypassed[i]:
+                self._tagged[tags[i]] = b
+
     # ---- coalesce.rs:257
     def push_batch_with_indices(self, batch, indices):
         return self.push_batch(take_record_batch(batch, indices))

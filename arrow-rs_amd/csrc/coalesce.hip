@@ -19,6 +19,7 @@
 
 extern "C" ah_status ah_filter_predicate_apply_into_acc(ah_context*, const ah_filter_predicate*, const ah_array_view*, void*,
                                                         uint8_t*, int64_t, uint64_t*);
+extern "C" ah_status ah_filter_predicates_build(ah_context*, int32_t, const ah_array_view*, ah_filter_predicate**);
 
 namespace {
 
@@ -241,6 +242,74 @@ extern "C" ah_status ah_coalescer_push_batch(ah_context* ctx, ah_coalescer* co, 
   return push_batch_impl(ctx, co, columns, num_rows, tag, bypassed);
 }
 
+namespace {
+
+ah_status check_filter(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns, int64_t num_rows, const ah_array_view* filter) {
+  if (filter->type != AH_BOOL)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "filter predicate must be Boolean, got %s", ah_type_name(filter->type));
+  if (filter->length > num_rows)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "Filter predicate of length %lld is larger than target array of length %lld",
+                   (long long)filter->length, (long long)num_rows);
+  return check_columns(ctx, co, columns, num_rows);
+}
+
+// push_batch_with_filter (coalesce.rs:229) once the predicate's count is known
+ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns, int64_t num_rows,
+                             const ah_array_view* filter, ah_filter_predicate* p, uint64_t tag, int32_t* bypassed) {
+  const int64_t selected = ah_filter_predicate_count(p);
+  ah_status st = AH_OK;
+  if (selected == 0) return AH_OK;  // nothing to append
+  if (selected == num_rows && filter->length == num_rows) return push_batch_impl(ctx, co, columns, num_rows, tag, bypassed);
+  const bool exceeds = co->limit >= 0 && selected > co->limit;
+  const bool does_not_fit = selected > co->target - co->buffered;
+  if (exceeds || does_not_fit) {  // materialise the filtered batch, then split it across output batches
+    std::vector<ah_array_out> outs((size_t)co->ncols);
+    std::vector<ah_array_view> views((size_t)co->ncols);
+    for (auto& o : outs) ah_out_init(&o);
+    for (int i = 0; i < co->ncols && st == AH_OK; ++i) st = ah_filter_predicate_apply(ctx, p, &columns[i], &outs[i]);
+    if (st == AH_OK) {
+      for (int i = 0; i < co->ncols; ++i) {
+        ah_array_view& v = views[i];
+        memset(&v, 0, sizeof v);
+        v.type = outs[i].type;
+        v.length = outs[i].length;
+        v.null_count = outs[i].validity ? outs[i].null_count : 0;
+        v.values = outs[i].values;
+        v.values_bit_offset = outs[i].values_bit_offset;
+        v.validity = outs[i].validity;
+        v.validity_bit_offset = outs[i].validity_bit_offset;
+      }
+      // a filtered batch that is itself bypassed would hand out buffers this call owns: emit it as an OWNED batch
+      if (co->limit >= 0 && selected > co->limit && (co->buffered == 0 || co->buffered > co->limit)) {
+        if (co->buffered > co->limit) st = finish_buffered(ctx, co);
+        if (st == AH_OK) {
+          CoBatch b;
+          b.rows = selected;
+          b.cols = outs;  // ownership moves to the completed queue
+          for (auto& o : outs) ah_out_init(&o);
+          co->completed.push_back(std::move(b));
+        }
+      } else {
+        st = push_batch_impl(ctx, co, views.data(), selected, 0, nullptr);
+        if (st == AH_OK) st = ah_stream_wait(ctx) == hipSuccess ? AH_OK : ah_fail(ctx, AH_HIP_ERROR, "coalescer copy failed");
+      }
+    }
+    for (auto& o : outs) ah_array_release(ctx, &o);  // the copies out of them have finished (wait above)
+    return st;
+  }
+  st = ensure_capacity(ctx, co);
+  for (int i = 0; i < co->ncols && st == AH_OK; ++i)
+    st = ah_filter_predicate_apply_into_acc(ctx, p, &columns[i], co->cols[i].values, co->cols[i].validity, co->buffered,
+                                            co->acc + i);
+  if (st == AH_OK) {
+    co->buffered += selected;
+    if (co->buffered >= co->target) st = finish_buffered(ctx, co);
+  }
+  return st;
+}
+
+}  // namespace
+
 // push_batch_with_filter (coalesce.rs:229)
 extern "C" ah_status ah_coalescer_push_batch_with_filter(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns,
                                                          int64_t num_rows, const ah_array_view* filter, uint64_t tag,
@@ -249,68 +318,42 @@ extern "C" ah_status ah_coalescer_push_batch_with_filter(ah_context* ctx, ah_coa
   if (bypassed) *bypassed = 0;
   if (!ctx || !co || !columns || !filter || num_rows < 0) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
-  if (filter->type != AH_BOOL)
-    return ah_fail(ctx, AH_INVALID_ARGUMENT, "filter predicate must be Boolean, got %s", ah_type_name(filter->type));
-  if (filter->length > num_rows)
-    return ah_fail(ctx, AH_INVALID_ARGUMENT, "Filter predicate of length %lld is larger than target array of length %lld",
-                   (long long)filter->length, (long long)num_rows);
-  AH_TRY(check_columns(ctx, co, columns, num_rows));
+  AH_TRY(check_filter(ctx, co, columns, num_rows, filter));
   ah_filter_predicate* p = nullptr;
   AH_TRY(ah_filter_predicate_build(ctx, filter, &p));  // one count pass for all columns: the push's one host wait
-  const int64_t selected = ah_filter_predicate_count(p);
-  ah_status st = AH_OK;
-  if (selected == 0) {
-    // nothing to append
-  } else if (selected == num_rows && filter->length == num_rows) {
-    st = push_batch_impl(ctx, co, columns, num_rows, tag, bypassed);
-  } else {
-    const bool exceeds = co->limit >= 0 && selected > co->limit;
-    const bool does_not_fit = selected > co->target - co->buffered;
-    if (exceeds || does_not_fit) {  // materialise the filtered batch, then split it across output batches
-      std::vector<ah_array_out> outs((size_t)co->ncols);
-      std::vector<ah_array_view> views((size_t)co->ncols);
-      for (auto& o : outs) ah_out_init(&o);
-      for (int i = 0; i < co->ncols && st == AH_OK; ++i) st = ah_filter_predicate_apply(ctx, p, &columns[i], &outs[i]);
-      if (st == AH_OK) {
-        for (int i = 0; i < co->ncols; ++i) {
-          ah_array_view& v = views[i];
-          memset(&v, 0, sizeof v);
-          v.type = outs[i].type;
-          v.length = outs[i].length;
-          v.null_count = outs[i].validity ? outs[i].null_count : 0;
-          v.values = outs[i].values;
-          v.values_bit_offset = outs[i].values_bit_offset;
-          v.validity = outs[i].validity;
-          v.validity_bit_offset = outs[i].validity_bit_offset;
-        }
-        // a filtered batch that is itself bypassed would hand out buffers this call owns: emit it as an OWNED batch
-        if (co->limit >= 0 && selected > co->limit && (co->buffered == 0 || co->buffered > co->limit)) {
-          if (co->buffered > co->limit) st = finish_buffered(ctx, co);
-          if (st == AH_OK) {
-            CoBatch b;
-            b.rows = selected;
-            b.cols = outs;  // ownership moves to the completed queue
-            for (auto& o : outs) ah_out_init(&o);
-            co->completed.push_back(std::move(b));
-          }
-        } else {
-          st = push_batch_impl(ctx, co, views.data(), selected, 0, nullptr);
-          if (st == AH_OK) st = ah_stream_wait(ctx) == hipSuccess ? AH_OK : ah_fail(ctx, AH_HIP_ERROR, "coalescer copy failed");
-        }
-      }
-      for (auto& o : outs) ah_array_release(ctx, &o);  // the copies out of them have finished (wait above)
-    } else {
-      st = ensure_capacity(ctx, co);
-      for (int i = 0; i < co->ncols && st == AH_OK; ++i)
-        st = ah_filter_predicate_apply_into_acc(ctx, p, &columns[i], co->cols[i].values, co->cols[i].validity, co->buffered,
-                                                co->acc + i);
-      if (st == AH_OK) {
-        co->buffered += selected;
-        if (co->buffered >= co->target) st = finish_buffered(ctx, co);
-      }
-    }
-  }
+  ah_status st = push_filtered_impl(ctx, co, columns, num_rows, filter, p, tag, bypassed);
   ah_filter_predicate_free(ctx, p);
+  return st;
+}
+
+// `n` filtered pushes in one call, for a host that has several batches queued: the n count passes are enqueued
+// back to back and read with ONE wait (ah_filter_predicates_build), then every batch is appended exactly as n calls
+// of ah_coalescer_push_batch_with_filter would — the same output batches in the same order — without the GPU idling
+// for a count round trip between batches.  columns: n x n_columns views, batch-major.
+extern "C" ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_coalescer* co, int32_t n,
+                                                            const ah_array_view* columns, const int64_t* num_rows,
+                                                            const ah_array_view* filters, const uint64_t* tags,
+                                                            int32_t* bypassed) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !co || n < 0 || (n > 0 && (!columns || !num_rows || !filters))) return AH_INVALID_ARGUMENT;
+  hipSetDevice(ctx->device);
+  for (int i = 0; i < n; ++i) {
+    if (bypassed) bypassed[i] = 0;
+    if (num_rows[i] < 0) return AH_INVALID_ARGUMENT;
+    AH_TRY(check_filter(ctx, co, columns + (size_t)i * co->ncols, num_rows[i], &filters[i]));
+  }
+  ah_status st = AH_OK;
+  for (int base = 0; base < n && st == AH_OK; base += 128) {
+    const int m = std::min(128, n - base);
+    std::vector<ah_filter_predicate*> preds((size_t)m, nullptr);
+    st = ah_filter_predicates_build(ctx, m, filters + base, preds.data());
+    for (int j = 0; j < m && st == AH_OK; ++j) {
+      const int i = base + j;
+      st = push_filtered_impl(ctx, co, columns + (size_t)i * co->ncols, num_rows[i], &filters[i], preds[j], tags ? tags[i] : 0,
+                              bypassed ? &bypassed[i] : nullptr);
+    }
+    for (auto* p : preds) ah_filter_predicate_free(ctx, p);
+  }
   return st;
 }
 

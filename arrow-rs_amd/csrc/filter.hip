@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(1024) filter_group_scan_kernel(const uint32_t*
     *total_out = s_carry;
     if (mail) {  // K goes straight to the host's pinned slot: the only number the host waits for
       __hip_atomic_store(mail, (uint64_t)s_carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      ah_mail_post(mail, seq);
+      if (seq) ah_mail_post(mail, seq);  // seq == 0: one of several counts, a later kernel posts for all of them
     }
   }
 }
@@ -434,11 +434,12 @@ struct ah_filter_predicate {
   void* block = nullptr;  // single pool allocation backing the tables
 };
 
-extern "C" ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_view* predicate,
-                                               ah_filter_predicate** out) {
-  ah_ctx_guard _guard(ctx);
-  if (!ctx || !predicate || !out) return AH_INVALID_ARGUMENT;
+// The count pass of a predicate, enqueued only: K lands in pinned slot `slot` (and, with seq != 0, the mailbox is
+// posted).  `*enqueued` = false when there was nothing to launch (empty predicate: count 0).
+static ah_status predicate_enqueue(ah_context* ctx, const ah_array_view* predicate, int slot, uint64_t seq,
+                                   ah_filter_predicate** out, bool* enqueued) {
   *out = nullptr;
+  *enqueued = false;
   if (predicate->type != AH_BOOL)
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "filter predicate must be Boolean, got %s",
                    ah_type_name(predicate->type));
@@ -456,6 +457,7 @@ extern "C" ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_v
     *out = p;
     return AH_OK;
   }
+  *enqueued = true;
   int64_t nchunks = ah_ceil_div(p->len, CHUNK_ROWS);
   const bool small = nchunks <= 65536;  // <= 64 Mi rows: one-wave count blocks, 64-chunk groups
   p->group_shift = small ? 6 : 10;
@@ -473,7 +475,6 @@ extern "C" ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_v
   uint32_t* group_total = (uint32_t*)(base + b_chunk);
   p->group_prefix = (unsigned long long*)(base + b_chunk + b_gt);
   unsigned long long* total = (unsigned long long*)(base + b_chunk + b_gt + b_gp);
-  const uint64_t seq = ah_mail_next(ctx);
   {
     ah_prof_scope ps(ctx, "filter_count");
     if (small)
@@ -483,17 +484,67 @@ extern "C" ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_v
       filter_count_kernel<<<(unsigned)ngroups, 1024, 0, ctx->stream>>>(p->mask, p->mask_valid, p->len,
                                                                       p->chunk_prefix, group_total);
     filter_group_scan_kernel<<<1, 1024, 0, ctx->stream>>>(group_total, ngroups, p->group_prefix,
-                                                          total, ctx->pinned_dev, seq);
+                                                          total, ctx->pinned_dev + slot, seq);
   }
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
   if (e != hipSuccess) {
     ah_pool_free(ctx, p->block);
     delete p;
     return ah_fail(ctx, AH_HIP_ERROR, "filter count failed: %s", hipGetErrorString(e));
   }
-  p->count = (int64_t)ctx->pinned[0];
   *out = p;
+  return AH_OK;
+}
+
+extern "C" ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_view* predicate,
+                                               ah_filter_predicate** out) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !predicate || !out) return AH_INVALID_ARGUMENT;
+  const uint64_t seq = ah_mail_next(ctx);
+  bool enqueued = false;
+  ah_filter_predicate* p = nullptr;
+  *out = nullptr;
+  AH_TRY(predicate_enqueue(ctx, predicate, 0, seq, &p, &enqueued));
+  if (enqueued) {
+    hipError_t e = ah_mail_wait(ctx, seq);
+    if (e != hipSuccess) {
+      ah_pool_free(ctx, p->block);
+      delete p;
+      return ah_fail(ctx, AH_HIP_ERROR, "filter count failed: %s", hipGetErrorString(e));
+    }
+    p->count = (int64_t)ctx->pinned[0];
+  }
+  *out = p;
+  return AH_OK;
+}
+
+// Counts of `n` (<= 128) predicates with ONE host wait: every count pass is enqueued, the last mailbox kernel posts for
+// all of them (BatchCoalescer's multi-batch push; a host that has several batches queued hides the count round trip).
+extern "C" ah_status ah_filter_predicates_build(ah_context* ctx, int32_t n, const ah_array_view* predicates,
+                                                ah_filter_predicate** outs) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || n < 0 || n > 128 || (n > 0 && (!predicates || !outs))) return AH_INVALID_ARGUMENT;
+  for (int i = 0; i < n; ++i) outs[i] = nullptr;
+  std::vector<char> launched((size_t)std::max(n, 1), 0);
+  ah_status st = AH_OK;
+  for (int i = 0; i < n && st == AH_OK; ++i) {
+    bool enq = false;
+    st = predicate_enqueue(ctx, &predicates[i], 16 + i, 0, &outs[i], &enq);
+    launched[i] = enq ? 1 : 0;
+  }
+  if (st == AH_OK) {
+    hipError_t e = ah_stream_wait(ctx);  // one flag kernel behind all the count passes
+    if (e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "filter count failed: %s", hipGetErrorString(e));
+  }
+  if (st != AH_OK) {
+    for (int i = 0; i < n; ++i) {
+      ah_filter_predicate_free(ctx, outs[i]);
+      outs[i] = nullptr;
+    }
+    return st;
+  }
+  for (int i = 0; i < n; ++i)
+    if (launched[i]) outs[i]->count = (int64_t)ctx->pinned[16 + i];
   return AH_OK;
 }
 

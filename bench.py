@@ -399,11 +399,16 @@ def build_workload(env, wl):
         batches = [(A.RecordBatch(["a", "b"], [col.slice(i * br, br), col2.slice(i * br, br)]), pred.slice(i * br, br))
                    for i in range(nb)]
 
+        group = max(1, int(os.environ.get("AH_COALESCE_GROUP", "1")))  # > 1: the multi-batch push (several batches queued)
+
         def step(_r):
             co = K.BatchCoalescer.new(["a", "b"], [A.Int64, A.Float64], target, ctx)
             out_rows = 0
-            for rb, f in batches:
-                co.push_batch_with_filter(rb, f)
+            for i in range(0, len(batches), group):
+                if group == 1:
+                    co.push_batch_with_filter(*batches[i])
+                else:
+                    co.push_batches_with_filters(batches[i:i + group])
                 while co.has_completed_batch():
                     out_rows += co.next_completed_batch().num_rows()
             co.finish_buffered_batch()
@@ -532,7 +537,9 @@ def describe(env, wl, W, prof, out, steps):
             "aggregate": "SURVEY 8f-4: sum + min + max of an Int64 column with NullBuffer",
             "string_filter_take": "SURVEY 8f-3: filter + take on a LargeUtf8 column (cast output)",
             "coalesce": f"SURVEY 8f-1: BatchCoalescer.push_batch_with_filter, Int64+Float64, "
-                        f"{args.batch_rows}-row batches"}[wl] + f", {n} rows per GPU"
+                        f"{args.batch_rows}-row batches"
+                        + (f", pushed {os.environ['AH_COALESCE_GROUP']} at a time (ah_coalescer_push_batches_with_filters)"
+                           if int(os.environ.get("AH_COALESCE_GROUP", "1")) > 1 else "")}[wl] + f", {n} rows per GPU"
     dtype = "int64" if wl in ("aggregate", "sort") else "int64+f64" if wl == "record_batch" else "f64"
     return dominant, dom_avg, dom_n, alg, text, f"{wl}_Mrows_per_s", dtype
 
@@ -658,6 +665,16 @@ def main():
         return
     elapsed, prof, out = run_timed(env, W, args.steps, args.warmup, reassemble)
     comm = env.comm
+    # the same loop without the per-kernel HIP events: what the measurement itself costs (nothing for three big
+    # kernels per step, ~20 % for the coalescer's 500 small launches per step)
+    no_events_ms = None
+    if world == 1:
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = W["step"](reassemble)
+        sync_all()
+        no_events_ms = (time.perf_counter() - t0) / args.steps * 1e3
     if wl == "filter_take" and reassemble and prof["take_gather"][1] == 0:
         # the take ran on the side context during the timed loop: time it alone for the kernel table
         ctx.profile(True)
@@ -772,6 +789,8 @@ def main():
         line["kernel_avg_ms"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
         # what the step spends outside its profiled kernels (host waits, launches, small helper kernels)
         line["host_gap_ms"] = round(ms_step - sum(v[0] for v in prof.values()) / max(args.steps, 1), 4)
+        if no_events_ms is not None:
+            line["ms_per_step_without_kernel_events"] = round(no_events_ms, 4)
         if local_elapsed:
             line["local_value"] = round(n * world * args.steps / local_elapsed / 1e6, 1)
             line["local_ms_per_step"] = round(local_elapsed / args.steps * 1e3, 4)

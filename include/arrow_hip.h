@@ -211,6 +211,9 @@ AH_API ah_status ah_filter(ah_context* ctx, const ah_array_view* values,
 typedef struct ah_filter_predicate ah_filter_predicate;
 AH_API ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_view* predicate,
                                            ah_filter_predicate** out);
+/* the counts of n (<= 128) predicates with ONE host wait (every count pass is enqueued first) */
+AH_API ah_status ah_filter_predicates_build(ah_context* ctx, int32_t n, const ah_array_view* predicates,
+                                            ah_filter_predicate** outs);
 AH_API int64_t ah_filter_predicate_count(const ah_filter_predicate* p); /* FilterPredicate::count :481 */
 AH_API ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_predicate* p,
                                            const ah_array_view* values, ah_array_out* out);
@@ -266,6 +269,13 @@ AH_API ah_status ah_coalescer_push_batch(ah_context* ctx, ah_coalescer* co, cons
 AH_API ah_status ah_coalescer_push_batch_with_filter(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns,
                                                      int64_t num_rows, const ah_array_view* filter, uint64_t tag,
                                                      int32_t* bypassed /* nullable */);
+/* n filtered pushes in ONE call (columns: n x n_columns views, batch-major): identical output to n calls of
+ * ah_coalescer_push_batch_with_filter, but the n predicate counts are read with a single host wait, so the GPU never
+ * idles for a count round trip between batches — for hosts that have several batches queued. */
+AH_API ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_coalescer* co, int32_t n,
+                                                        const ah_array_view* columns, const int64_t* num_rows,
+                                                        const ah_array_view* filters, const uint64_t* tags /* nullable */,
+                                                        int32_t* bypassed /* n entries, nullable */);
 AH_API ah_status ah_coalescer_finish_buffered_batch(ah_context* ctx, ah_coalescer* co);
 /* *num_rows = -1 when no batch is ready; outs[n_columns] are released with ah_array_release */
 AH_API ah_status ah_coalescer_next_completed_batch(ah_context* ctx, ah_coalescer* co, ah_array_out* outs, int64_t* num_rows,

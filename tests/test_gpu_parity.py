@@ -915,6 +915,37 @@ def test_batch_coalescer_fuzz(ctx, oracle, limit):
         assert co.is_empty()
 
 
+def test_batch_coalescer_grouped_pushes_equal_single_pushes(ctx, oracle):
+    """ah_coalescer_push_batches_with_filters (n filtered pushes, one wait for the n counts) must produce exactly the
+    output batches of n single pushes — compared with the model of coalesce.rs, bypass limit included."""
+    from coalesce_model import ModelCoalescer
+    rng = np.random.default_rng(4242)
+    dts = [A.Int64, A.Float64]
+    for trial, limit in enumerate([None, 300, None, 64]):
+        target = int(rng.choice([50, 512, 4096]))
+        co = K.BatchCoalescer.new(["a", "b"], dts, target, ctx).with_biggest_coalesce_batch_size(limit)
+        model = ModelCoalescer(oracle, dts, target)
+        model.limit = limit
+        pending = []
+        for step in range(40):
+            n = int(rng.integers(0, 3 * target + 5))
+            cols = [HostArray(dt, _rand_values(rng, dt, n), (rng.random(n) < 0.85) if k == 0 else None) for k, dt in enumerate(dts)]
+            flen = n - int(rng.integers(0, min(n, 3) + 1))
+            f = HostArray(A.Boolean, rng.random(flen) < float(rng.choice([0.0, 0.05, 0.4, 1.0])),
+                          (rng.random(flen) < 0.9) if step % 3 == 0 else None)
+            pending.append((A.RecordBatch(["a", "b"], [c.to_device(ctx) for c in cols]), f.to_device(ctx)))
+            model.push_with_filter(cols, f)
+            if len(pending) >= int(rng.integers(1, 8)) or step == 39:
+                co.push_batches_with_filters(pending)
+                pending = []
+                assert co.get_buffered_rows() == model.buffered, f"trial {trial} step {step}"
+                _check_batches(co, model, f"grouped trial {trial} step {step}")
+        co.finish_buffered_batch()
+        model.finish()
+        _check_batches(co, model, f"grouped trial {trial} final")
+        assert co.is_empty()
+
+
 def test_batch_coalescer_generic_columns(ctx, oracle):
     """Boolean / Utf8 / LargeUtf8 columns go through GenericInProgressArray (coalesce/generic.rs): buffered
     slices and filtered arrays, `concat` on finish — next to a primitive column on the fused path; same batch
