@@ -154,7 +154,10 @@ template <> __device__ __forceinline__ uint64_t cast_spread<4>(uint64_t x) {  //
 }
 
 template <typename T, int V> struct alignas(sizeof(T) * V) CastVec { T e[V]; };
-constexpr int CAST_G = 4;  // groups in flight per wave
+#ifndef AH_CAST_G
+#define AH_CAST_G 4
+#endif
+constexpr int CAST_G = AH_CAST_G;  // groups in flight per wave
 
 template <typename I, typename O, int V>
 __global__ void __launch_bounds__(256) cast_stream_kernel(CastArgs a) {

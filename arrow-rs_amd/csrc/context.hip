@@ -6,6 +6,16 @@
 
 #include <ctime>
 
+// The message of a failing call is kept per THREAD as well as per context: with one context shared by threads,
+// `ah_last_error` right after a failing call must not return another thread's later failure.
+namespace {
+struct TlsError {
+  const ah_context* ctx = nullptr;
+  std::string msg;
+};
+thread_local TlsError tls_error;
+}  // namespace
+
 ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...) {
   char buf[1024];
   va_list ap;
@@ -13,6 +23,8 @@ ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...) {
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
   if (ctx) ctx->err = buf;
+  tls_error.ctx = ctx;
+  tls_error.msg = buf;
   return st;
 }
 
@@ -326,7 +338,11 @@ extern "C" void ah_context_set_deferred(ah_context* ctx, int32_t on) {
 }
 extern "C" int32_t ah_context_deferred(const ah_context* ctx) { return ctx && ctx->deferred; }
 extern "C" const char* ah_last_error(ah_context* ctx) {
-  ah_ctx_guard _guard(ctx); return ctx ? ctx->err.c_str() : "no context"; }
+  if (!ctx) return "no context";
+  if (tls_error.ctx == ctx) return tls_error.msg.c_str();  // this thread's own last failure on this context
+  ah_ctx_guard _guard(ctx);
+  return ctx->err.c_str();
+}
 extern "C" const char* ah_version(void) { return "arrow_hip 0.1.0 (gfx950)"; }
 
 extern "C" void ah_array_release(ah_context* ctx, ah_array_out* out) {

@@ -1116,6 +1116,42 @@ def test_user_stream_and_two_contexts_in_threads(ctx, oracle):
     assert not errs, errs
 
 
+def test_one_context_shared_by_many_threads(ctx, oracle):
+    """Every entry point locks its context (include/arrow_hip.h): six threads hammering ONE
+    context — the pool, the read-back mailbox, the self-cleaning scratch and the error string are all per context —
+    must give the oracle's answers, including the error texts of calls that fail."""
+    import threading
+    rng = np.random.default_rng(31)
+    n = 200_000
+    h = HostArray(A.Int64, rng.integers(-2**40, 2**40, n), rng.random(n) < 0.9)
+    m = HostArray(A.Boolean, rng.random(n) < 0.3)
+    idx = HostArray(A.UInt32, rng.integers(0, n, n // 7).astype(np.uint32))
+    bad = HostArray(A.UInt32, np.array([1, n + 5], dtype=np.uint32))
+    dv, dm, di, db = h.to_device(ctx), m.to_device(ctx), idx.to_device(ctx), bad.to_device(ctx)
+    exp_f, exp_t = oracle.filter(h, m), oracle.take(h, idx)
+    exp_c, exp_a = oracle.cast(h, A.Float64), oracle.arith(1, h, h)
+    errs = []
+
+    def work(k):
+        try:
+            for it in range(15):
+                check(K.filter(dv, dm), exp_f, f"thread {k} filter")
+                check(K.take(dv, di), exp_t, f"thread {k} take")
+                check_exact(K.cast(dv, A.Float64), exp_c, f"thread {k} cast")
+                check_exact(K.add_wrapping(dv, dv), exp_a, f"thread {k} add")
+                if (it + k) % 5 == 0:
+                    with pytest.raises(A.Panic) as ei:
+                        K.take(dv, db)
+                    assert str(ei.value) == f"index out of bounds: the len is {n} but the index is {n + 5}"
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(repr(ex)[:300])
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+
+
 def test_bench_json_contract(ctx):
     """bench.py prints ONE JSON line with the contract keys (small --rows so it runs in seconds)."""
     import json
