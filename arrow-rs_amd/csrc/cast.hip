@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) cast_stream_kernel(CastArgs a) {
   O* op = (O*)a.out;
   const int64_t ngroups = (a.len + 64 * V - 1) / (64 * V);
   const int64_t nwords = (a.len + 63) >> 6;
-  const int64_t g0 = ((int64_t)blockIdx.x * 4 + wave) * CAST_G;
+  const int64_t g0 = ((int64_t)blockIdx.x * 4 + ah_uniform(wave)) * CAST_G;
   unsigned long long nvalid = 0, err = ~0ull;
   VI iv[CAST_G];
   uint32_t vb[CAST_G];
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) cast_stream_kernel(CastArgs a) {
 #pragma unroll
       for (int e = 0; e < V; ++e) iv[gi].e[e] = (i + e < a.len) ? ip[i + e] : I{};
     }
-    if (i < a.len) vb[gi] = (uint32_t)(bv_fetch64(a.in_valid, i & ~63ll, a.len) >> (i & 63));
+    vb[gi] = bv_lane_bits<V>(a.in_valid, (g0 + gi) * 64 * V, lane, a.len);  // scalar loads: see common.hpp
   }
 #pragma unroll
   for (int gi = 0; gi < CAST_G; ++gi) {

@@ -234,6 +234,40 @@ __device__ __forceinline__ uint64_t bv_fetch64(const BitView& v, int64_t s, int6
   return lo;
 }
 
+// A wave-uniform value the compiler can see is uniform (scalar register): addresses built from it become scalar
+// loads (s_load, counted by lgkmcnt), which do not make the vector loads already in flight wait.
+__device__ __forceinline__ int ah_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ int64_t ah_uniform64(int64_t x) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)x >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// Validity bits of the V consecutive rows a lane owns — rows base + lane * V .. + V - 1 — when `base` is
+// wave-uniform (made so with ah_uniform) and a multiple of 64: the V words of the wave's 64 * V rows come through
+// the scalar unit and each lane picks its own.  A per-lane bv_fetch64 made hipcc put `s_waitcnt vmcnt(0)` right
+// behind the fetch, i.e. one full memory round trip per group with nothing else in flight.
+template <int V>
+__device__ __forceinline__ uint32_t bv_lane_bits(const BitView& v, int64_t base, int lane, int64_t len) {
+  uint64_t mine = 0;
+  if (v.words && (v.off & 63) == 0 && base + 64 * V <= len) {  // whole words: one wide scalar load
+    const uint64_t* w = v.words + ((v.off + base) >> 6);
+    uint64_t ww[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) ww[j] = w[j];
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+      if (((lane * V) >> 6) == j) mine = ww[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const uint64_t w = bv_fetch64(v, base + 64 * j, len);
+      if (((lane * V) >> 6) == j) mine = w;
+    }
+  }
+  return (uint32_t)(mine >> ((lane * V) & 63)) & ((1u << V) - 1u);
+}
+
 __device__ __forceinline__ int bv_get(const BitView& v, int64_t i) {
   if (!v.words) return 1;
   int64_t pos = v.off + i;
