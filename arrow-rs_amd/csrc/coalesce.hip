@@ -20,6 +20,9 @@
 extern "C" ah_status ah_filter_predicate_apply_into_acc(ah_context*, const ah_filter_predicate*, const ah_array_view*, void*,
                                                         uint8_t*, int64_t, uint64_t*);
 extern "C" ah_status ah_filter_predicates_build(ah_context*, int32_t, const ah_array_view*, ah_filter_predicate**);
+// filter.hip: the columns of one batch through one scatter launch (AH_NOT_YET_IMPLEMENTED: shapes differ, nothing done)
+ah_status ah_filter_apply_into_acc_cols(ah_context*, const ah_filter_predicate*, int, const ah_array_view*, void* const*,
+                                        uint8_t* const*, int64_t, unsigned long long*, unsigned long long*, int64_t, int64_t);
 
 namespace {
 
@@ -197,8 +200,10 @@ extern "C" ah_status ah_coalescer_create(ah_context* ctx, int32_t n_columns, con
     co->cols[i].type = types[i];
     co->cols[i].width = w;
   }
-  ah_status st = ah_pool_alloc(ctx, (size_t)n_columns * 8, (void**)&co->acc);
-  if (st == AH_OK && hipMemsetAsync(co->acc, 0, (size_t)n_columns * 8, ctx->stream) != hipSuccess)
+  // acc: one appended-null counter per column, then 64 zero-state valid-row counters per column (fused scatter)
+  const size_t acc_bytes = (size_t)n_columns * 8 * (1 + 64);
+  ah_status st = ah_pool_alloc(ctx, acc_bytes, (void**)&co->acc);
+  if (st == AH_OK && hipMemsetAsync(co->acc, 0, acc_bytes, ctx->stream) != hipSuccess)
     st = ah_fail(ctx, AH_HIP_ERROR, "coalescer counter reset failed");
   if (st != AH_OK) {
     delete co;
@@ -261,7 +266,31 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
   if (selected == 0) return AH_OK;  // nothing to append
   if (selected == num_rows && filter->length == num_rows) return push_batch_impl(ctx, co, columns, num_rows, tag, bypassed);
   const bool exceeds = co->limit >= 0 && selected > co->limit;
-  const bool does_not_fit = selected > co->target - co->buffered;
+  bool does_not_fit = selected > co->target - co->buffered;
+  if (!exceeds && co->ncols <= 8) {
+    // Same-shape nullable columns: ONE scatter launch per output batch the filtered rows land in — positions
+    // [done, done + take) of the filtered stream go straight into the in-progress batch, also when the batch straddles
+    // two (or more) output batches.  No intermediate filtered array, no host wait besides finish_buffered's.
+    void* dv[8];
+    uint8_t* db[8];
+    int64_t done = 0;
+    while (done < selected && st == AH_OK) {
+      st = ensure_capacity(ctx, co);
+      if (st != AH_OK) break;
+      for (int i = 0; i < co->ncols; ++i) dv[i] = co->cols[i].values, db[i] = co->cols[i].validity;
+      const int64_t take = std::min(co->target - co->buffered, selected - done);
+      const ah_status fs = ah_filter_apply_into_acc_cols(ctx, p, co->ncols, columns, dv, db, co->buffered,
+                                                         (unsigned long long*)co->acc,
+                                                         (unsigned long long*)(co->acc + co->ncols), done, done + take);
+      if (fs == AH_NOT_YET_IMPLEMENTED && done == 0) break;  // shapes differ: the per-column paths below
+      if (fs != AH_OK) return fs == AH_NOT_YET_IMPLEMENTED ? ah_fail(ctx, AH_INVALID_ARGUMENT, "coalescer: column shapes changed") : fs;
+      co->buffered += take;
+      done += take;
+      if (co->buffered >= co->target) st = finish_buffered(ctx, co);
+    }
+    if (st != AH_OK || done == selected) return st;
+    does_not_fit = selected > co->target - co->buffered;
+  }
   if (exceeds || does_not_fit) {  // materialise the filtered batch, then split it across output batches
     std::vector<ah_array_out> outs((size_t)co->ncols);
     std::vector<ah_array_view> views((size_t)co->ncols);

@@ -234,6 +234,32 @@ __device__ __forceinline__ uint64_t bv_fetch64(const BitView& v, int64_t s, int6
   return lo;
 }
 
+// bv_fetch64 split in two so that SEVERAL bitmaps' words can be in flight together: bv_issue only issues loads (both
+// candidate words, no branch, no use of the data), bv_finish assembles the 64 bits.  With bv_fetch64 itself hipcc
+// waits (s_waitcnt vmcnt(0)) inside each call: mask, mask validity and value validity cost three serialized memory
+// round trips per workgroup.
+struct BvRaw {
+  uint64_t lo, hi;
+  int sh;
+  bool has_hi;
+};
+__device__ __forceinline__ BvRaw bv_issue(const BitView& v, int64_t s, int64_t len) {  // needs v.words and s < len
+  BvRaw r;
+  const int64_t pos = v.off + s, w = pos >> 6, last_word = (v.off + len - 1) >> 6;
+  r.sh = (int)(pos & 63);
+  r.has_hi = r.sh != 0 && w + 1 <= last_word;
+  r.lo = v.words[w];
+  r.hi = v.words[w + 1 <= last_word ? w + 1 : last_word];
+  return r;
+}
+__device__ __forceinline__ uint64_t bv_finish(const BvRaw& r, int64_t s, int64_t len) {
+  uint64_t x = r.lo >> r.sh;
+  if (r.has_hi) x |= r.hi << (64 - r.sh);
+  const int64_t rem = len - s;
+  if (rem < 64) x &= (1ull << rem) - 1;
+  return x;
+}
+
 // A wave-uniform value the compiler can see is uniform (scalar register): addresses built from it become scalar
 // loads (s_load, counted by lgkmcnt), which do not make the vector loads already in flight wait.
 __device__ __forceinline__ int ah_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }

@@ -55,18 +55,38 @@ __global__ void __launch_bounds__(1024) filter_count_kernel(BitView mask, BitVie
   __shared__ uint32_t s_wave[16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t chunk_base = (int64_t)blockIdx.x * GROUP_CHUNKS;
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    int64_t chunk4 = chunk_base + wave * 64 + it * 4;  // 4 chunks = 64 words per wave step
-    int64_t s = (chunk4 * 16 + lane) << 6;
-    uint64_t m = bv_fetch64(mask, s, len);
-    if (mask_valid.words) m &= bv_fetch64(mask_valid, s, len);
-    int c = __popcll(m);
-    c += __shfl_xor(c, 1, 64);
-    c += __shfl_xor(c, 2, 64);
-    c += __shfl_xor(c, 4, 64);
-    c += __shfl_xor(c, 8, 64);
-    if ((lane & 15) == 0) s_cnt[wave * 64 + it * 4 + (lane >> 4)] = (uint32_t)c;
+  // four steps' words (mask and its validity) are requested before the first one is counted: bv_fetch64 in the loop
+  // waits for each word in turn (16 serialized round trips per wave)
+  const bool has_mv = mask_valid.words != nullptr;
+  for (int it0 = 0; it0 < 16; it0 += 4) {
+    BvRaw rm[4], rv[4] = {};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t s = ((chunk_base + wave * 64 + (it0 + j) * 4) * 16 + lane) << 6;  // 4 chunks = 64 words per wave step
+      rm[j] = bv_issue(mask, s < len ? s : 0, len);
+    }
+    if (has_mv) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t s = ((chunk_base + wave * 64 + (it0 + j) * 4) * 16 + lane) << 6;
+        rv[j] = bv_issue(mask_valid, s < len ? s : 0, len);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int it = it0 + j;
+      const int64_t s = ((chunk_base + wave * 64 + it * 4) * 16 + lane) << 6;
+      const int64_t sc = s < len ? s : 0;
+      uint64_t m = bv_finish(rm[j], sc, len);
+      if (has_mv) m &= bv_finish(rv[j], sc, len);
+      if (s >= len) m = 0;
+      int c = __popcll(m);
+      c += __shfl_xor(c, 1, 64);
+      c += __shfl_xor(c, 2, 64);
+      c += __shfl_xor(c, 4, 64);
+      c += __shfl_xor(c, 8, 64);
+      if ((lane & 15) == 0) s_cnt[wave * 64 + it * 4 + (lane >> 4)] = (uint32_t)c;
+    }
   }
   __syncthreads();
   int v = (int)s_cnt[t];
@@ -90,12 +110,31 @@ __global__ void __launch_bounds__(64) filter_count_small_kernel(BitView mask, Bi
   __shared__ uint32_t s_cnt[64];
   const int lane = threadIdx.x;
   const int64_t chunk_base = (int64_t)blockIdx.x * 64;
-#pragma unroll 4
+  // every word of the wave's 64 chunks is requested before the first one is counted (bv_fetch64 in the loop made
+  // this 16 serialized memory round trips per wave: 17-20 us for a 2 MiB mask, 6.5 us now).  Folding K2 into this
+  // kernel ("last wave done" ticket) was measured and dropped: the agent-scope release / acquire fences it needs
+  // write back and invalidate L2 on a multi-XCD part, 16.7 us against 6.5 + 3.9 us for the two launches.
+  const bool has_mv = mask_valid.words != nullptr;
+  BvRaw rm[16], rv[16] = {};
+#pragma unroll
   for (int it = 0; it < 16; ++it) {
-    const int64_t chunk4 = chunk_base + it * 4;  // 4 chunks = 64 words per step, coalesced
-    const int64_t s = (chunk4 * 16 + lane) << 6;
-    uint64_t m = bv_fetch64(mask, s, len);
-    if (mask_valid.words) m &= bv_fetch64(mask_valid, s, len);
+    const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;  // 4 chunks = 64 words per step, coalesced
+    rm[it] = bv_issue(mask, s < len ? s : 0, len);
+  }
+  if (has_mv) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
+      rv[it] = bv_issue(mask_valid, s < len ? s : 0, len);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
+    const int64_t sc = s < len ? s : 0;
+    uint64_t m = bv_finish(rm[it], sc, len);
+    if (has_mv) m &= bv_finish(rv[it], sc, len);
+    if (s >= len) m = 0;
     int c = __popcll(m);
     c += __shfl_xor(c, 1, 64);
     c += __shfl_xor(c, 2, 64);
@@ -157,6 +196,16 @@ __global__ void __launch_bounds__(64) filter_finish_acc_kernel(unsigned long lon
   if (threadIdx.x == 0 && acc && k != v) atomicAdd(acc, k - v);
 }
 
+// the same for the columns of one fused launch: block c folds column c's counters
+__global__ void __launch_bounds__(64) filter_finish_acc_cols_kernel(unsigned long long* slots, unsigned long long k,
+                                                                    unsigned long long* acc) {
+  unsigned long long* my = slots + (size_t)blockIdx.x * 64;
+  unsigned long long v = my[threadIdx.x];
+  my[threadIdx.x] = 0;
+  v = wave_reduce_add64(v);
+  if (threadIdx.x == 0 && k != v) atomicAdd(acc + blockIdx.x, k - v);
+}
+
 // after the scatter: fold the VALID_SLOTS counters into one number for the host, leave them zero for the next
 // call (ctx->scratch is self-cleaning: no per-call memset), publish.  mail == nullptr (deferred): clean only.
 __global__ void __launch_bounds__(64) filter_finish_kernel(unsigned long long* slots, uint64_t* mail, uint64_t seq) {
@@ -198,7 +247,20 @@ struct ScatterArgs {
   int xcd_remap;                   // 1: tiles that share output lines stay on one XCD
   int64_t out_base;                // rows already present in the destination (fused filter-into-builder)
   int64_t ntiles;
+  // window of the filtered stream this launch writes: positions [win_lo, win_hi) land at out_base + (pos - win_lo);
+  // win_hi == 0: everything.  BatchCoalescer splits a batch that straddles two output batches into two launches.
+  int64_t win_lo, win_hi;
+  // further columns of the SAME width / validity shape filtered by the same launch (blockIdx.y = column): a record
+  // batch's columns share the predicate, its prefix tables and the destination row offset
+  struct Col {
+    const void* values;
+    BitView vvalid;
+    void* out_values;
+    unsigned long long* out_valid;
+    unsigned long long* valid_slots;
+  } more[7];
 };
+constexpr int SCATTER_MAX_COLS = 8;
 
 constexpr int VALID_SLOTS = 64;
 
@@ -234,6 +296,20 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
   __shared__ uint8_t s_flag[HAS_VALID ? CAP : 1];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // this workgroup's column (uniform: scalar selects)
+  const void* c_values = a.values;
+  BitView c_vvalid = a.vvalid;
+  void* c_out_values = a.out_values;
+  unsigned long long* c_out_valid = a.out_valid;
+  unsigned long long* c_valid_slots = a.valid_slots;
+  if (blockIdx.y) {
+    const ScatterArgs::Col& c = a.more[blockIdx.y - 1];
+    c_values = c.values;
+    c_vvalid = c.vvalid;
+    c_out_values = c.out_values;
+    c_out_valid = c.out_valid;
+    c_valid_slots = c.valid_slots;
+  }
   // XCD-aware tile mapping: workgroup b lands on XCD b % 8 (observed dispatch order,
   // used for speed only), so XCD x walks the contiguous tile range [x*per, (x+1)*per):
   // neighbouring tiles, which share output cache lines and boundary bitmap words,
@@ -249,7 +325,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
   // 1. value loads (16 B per lane per load on the aligned path) go out first
   Vec<WE, V> regs[L];
   if constexpr (W != 0 && !SKIP) {
-    const ET* vp = (const ET*)a.values;
+    const ET* vp = (const ET*)c_values;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       int64_t r = row0 + (int64_t)(l * SCATTER_THREADS + t) * V;
@@ -260,11 +336,19 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
   // 2. wave 0 builds the word table: mask, validity, exclusive popcount prefix
   if (wave == 0) {
     uint64_t m = 0, v = 0;
-    if (lane < NW) {
-      int64_t s = row0 + ((int64_t)lane << 6);
-      m = bv_fetch64(a.mask, s, a.len);
-      if (a.mask_valid.words) m &= bv_fetch64(a.mask_valid, s, a.len);
-      if constexpr (HAS_VALID) v = bv_fetch64(a.vvalid, s, a.len);
+    const int64_t s = row0 + ((int64_t)lane << 6);
+    if (lane < NW && s < a.len) {
+      // all three bitmaps' words are requested before the first one is used: one memory round trip, not three
+      const bool has_mv = a.mask_valid.words != nullptr;
+      const bool has_vv = HAS_VALID && c_vvalid.words != nullptr;
+      // (an absent bitmap re-reads the mask's words — same lines, no branch between the loads — and is ignored)
+      const BvRaw rm = bv_issue(a.mask, s, a.len);
+      const BvRaw rmv = bv_issue(has_mv ? a.mask_valid : a.mask, s, a.len);
+      const BvRaw rvv = bv_issue(has_vv ? c_vvalid : a.mask, s, a.len);
+      m = bv_finish(rm, s, a.len);
+      const uint64_t mv = bv_finish(rmv, s, a.len), vv = bv_finish(rvv, s, a.len);
+      if (has_mv) m &= mv;
+      if constexpr (HAS_VALID) v = has_vv ? vv : bv_fetch64(c_vvalid, s, a.len);
     }
     int c = __popcll(m);
     int incl = wave_scan_incl(c);
@@ -279,9 +363,19 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
 
   const int total = (int)s_total;
   if (total == 0) return;
+  const int64_t chunk0 = row0 / CHUNK_ROWS;
+  const int64_t rel = (int64_t)a.group_prefix[chunk0 >> a.group_shift] + a.chunk_prefix[chunk0];  // tile's first output position
+  int lo_t = 0, hi_t = total;  // the tile's positions inside the launch's window
+  if (a.win_hi != 0) {
+    const int64_t lo = a.win_lo - rel, hi = a.win_hi - rel;
+    lo_t = lo < 0 ? 0 : (lo > total ? total : (int)lo);
+    hi_t = hi < 0 ? 0 : (hi > total ? total : (int)hi);
+    if (lo_t >= hi_t) return;
+  }
+  const int64_t ob = a.out_base + rel - a.win_lo;
 
   if constexpr (W != 0 && SKIP) {
-    const ET* vp = (const ET*)a.values;
+    const ET* vp = (const ET*)c_values;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       int r0 = (l * SCATTER_THREADS + t) * V;
@@ -290,12 +384,11 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
     }
   }
 
-  const int64_t chunk0 = row0 / CHUNK_ROWS;
-  const int64_t ob = a.out_base + (int64_t)a.group_prefix[chunk0 >> a.group_shift] + a.chunk_prefix[chunk0];
   int vc = 0;
 
-  for (int p0 = 0; p0 < total; p0 += CAP) {
+  for (int p0 = lo_t; p0 < hi_t; p0 += CAP) {
     const int phase = (int)((ob + p0) & (EPV - 1));
+    const int cnt = (hi_t - p0) < CAP ? (hi_t - p0) : CAP;
     // 3. compact the selected rows whose output position falls in [p0, p0+CAP) into LDS
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -311,7 +404,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
         for (int e = 0; e < V; ++e) {
           if ((bits >> e) & 1u) {
             uint32_t pos = base + (uint32_t)__popc(bits & ((1u << e) - 1u));
-            if (pos < (uint32_t)CAP) {  // unsigned: also rejects positions before p0
+            if (pos < (uint32_t)cnt) {  // unsigned: also rejects positions before p0
               if constexpr (W != 0) s_vals[pos + phase] = regs[l].u.e[e];
               if constexpr (HAS_VALID) s_flag[pos] = (uint8_t)((vb >> e) & 1u);
             }
@@ -322,10 +415,9 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
     __syncthreads();
 
     // 4. coalesced write-out of this chunk
-    const int cnt = (total - p0) < CAP ? (total - p0) : CAP;
     const int64_t cb = ob + p0;
     if constexpr (W != 0) {
-      ET* op = (ET*)a.out_values + cb;
+      ET* op = (ET*)c_out_values + cb;
       if constexpr (EPV > 1) {
         // 16-byte stores: LDS slot = output position + phase, so LDS vectors and global
         // vectors share their 16-byte alignment; ragged head/tail go element-wise
@@ -358,25 +450,25 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
           // EVERY word goes through atomicOr (buffer pre-zeroed): tiles share their boundary
           // words, and mixing plain stores with L2 atomics on one cache line costs 0.5 ms
           // per 1e9 rows on MI355X (measured), while atomics alone are free.
-          if (word) atomicOr(&a.out_valid[wi], (unsigned long long)word);
+          if (word) atomicOr(&c_out_valid[wi], (unsigned long long)word);
           vc += __popcll(word);
         }
       }
     }
-    if (p0 + CAP < total) __syncthreads();  // LDS is reused by the next chunk
+    if (p0 + CAP < hi_t) __syncthreads();  // LDS is reused by the next chunk
   }
   if constexpr (HAS_VALID) {
     if (lane == 0) s_vc[wave] = (uint32_t)vc;
     __syncthreads();
     if (t == 0) {
       uint32_t c = s_vc[0] + s_vc[1] + s_vc[2] + s_vc[3];
-      if (c) atomicAdd(&a.valid_slots[tile & (VALID_SLOTS - 1)], (unsigned long long)c);
+      if (c) atomicAdd(&c_valid_slots[tile & (VALID_SLOTS - 1)], (unsigned long long)c);
     }
   }
 }
 
 template <int W, bool HV>
-void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, bool skip) {
+void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, bool skip, int ncols = 1) {
   constexpr int WE = W == 0 ? 1 : W;
   constexpr int T = tile_rows(WE);
   int64_t ntiles = ah_ceil_div(a_in.len, T);
@@ -384,7 +476,7 @@ void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, 
   a.ntiles = ntiles;
   static const char* xr = getenv("AH_FILTER_XCD");
   a.xcd_remap = (xr && xr[0] == '0') ? 0 : 1;
-  dim3 grid((unsigned)(a.xcd_remap ? 8 * ((ntiles + 7) / 8) : ntiles)), block(SCATTER_THREADS);
+  dim3 grid((unsigned)(a.xcd_remap ? 8 * ((ntiles + 7) / 8) : ntiles), (unsigned)ncols), block(SCATTER_THREADS);
   constexpr int VV = (W == 0) ? 16 : (W >= 16 ? 1 : 16 / W);
   if constexpr (W == 0) {
     filter_scatter_kernel<W, VV, HV, false><<<grid, block, 0, ctx->stream>>>(a);
@@ -397,16 +489,17 @@ void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, 
 }
 
 template <bool HV>
-ah_status launch_scatter(ah_context* ctx, int width, const ScatterArgs& a, bool skip) {
+ah_status launch_scatter(ah_context* ctx, int width, const ScatterArgs& a, bool skip, int ncols = 1) {
   bool aligned16 = (((uintptr_t)a.values) & 15) == 0;
+  for (int c = 1; c < ncols; ++c) aligned16 = aligned16 && (((uintptr_t)a.more[c - 1].values) & 15) == 0;
   switch (width) {
-    case 0: launch_scatter_w<0, HV>(ctx, a, true, false); break;
-    case 1: launch_scatter_w<1, HV>(ctx, a, aligned16, skip); break;
-    case 2: launch_scatter_w<2, HV>(ctx, a, aligned16, skip); break;
-    case 4: launch_scatter_w<4, HV>(ctx, a, aligned16, skip); break;
-    case 8: launch_scatter_w<8, HV>(ctx, a, aligned16, skip); break;
-    case 16: launch_scatter_w<16, HV>(ctx, a, aligned16, skip); break;
-    case 32: launch_scatter_w<32, HV>(ctx, a, aligned16, skip); break;
+    case 0: launch_scatter_w<0, HV>(ctx, a, true, false, ncols); break;
+    case 1: launch_scatter_w<1, HV>(ctx, a, aligned16, skip, ncols); break;
+    case 2: launch_scatter_w<2, HV>(ctx, a, aligned16, skip, ncols); break;
+    case 4: launch_scatter_w<4, HV>(ctx, a, aligned16, skip, ncols); break;
+    case 8: launch_scatter_w<8, HV>(ctx, a, aligned16, skip, ncols); break;
+    case 16: launch_scatter_w<16, HV>(ctx, a, aligned16, skip, ncols); break;
+    case 32: launch_scatter_w<32, HV>(ctx, a, aligned16, skip, ncols); break;
     default: return ah_fail(ctx, AH_INVALID_ARGUMENT, "unsupported value width %d", width);
   }
   return AH_OK;
@@ -477,12 +570,13 @@ static ah_status predicate_enqueue(ah_context* ctx, const ah_array_view* predica
   unsigned long long* total = (unsigned long long*)(base + b_chunk + b_gt + b_gp);
   {
     ah_prof_scope ps(ctx, "filter_count");
-    if (small)
+    if (small) {
       filter_count_small_kernel<<<(unsigned)ngroups, 64, 0, ctx->stream>>>(p->mask, p->mask_valid, p->len, p->chunk_prefix,
                                                                           group_total);
-    else
+    } else {
       filter_count_kernel<<<(unsigned)ngroups, 1024, 0, ctx->stream>>>(p->mask, p->mask_valid, p->len,
                                                                       p->chunk_prefix, group_total);
+    }
     filter_group_scan_kernel<<<1, 1024, 0, ctx->stream>>>(group_total, ngroups, p->group_prefix,
                                                           total, ctx->pinned_dev + slot, seq);
   }
@@ -897,6 +991,57 @@ static ah_status apply_into_impl(ah_context* ctx, const ah_filter_predicate* p, 
   if (st != AH_OK) return st;
   if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "fused filter copy failed: %s", hipGetErrorString(e));
   if (has_valid && appended_nulls) *appended_nulls = K - (int64_t)ctx->pinned[0];
+  return AH_OK;
+}
+
+// Several columns of one batch through ONE scatter launch (BatchCoalescer's filtered push): the columns must share
+// the value width and all carry validity; returns AH_NOT_YET_IMPLEMENTED (nothing enqueued) when they do not, and the
+// caller goes column by column.  Only positions [win_lo, win_hi) of the filtered batch are appended (at
+// dst_row_offset onwards): a batch that straddles two output batches is two launches, no intermediate array.  `slots`: ncols x 64 zeroed words the
+// kernels leave zero; nulls_acc: ncols device words.
+ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predicate* p, int ncols, const ah_array_view* values,
+                                        void* const* dst_values, uint8_t* const* dst_validity, int64_t dst_row_offset,
+                                        unsigned long long* nulls_acc, unsigned long long* slots, int64_t win_lo,
+                                        int64_t win_hi) {
+  if (ncols < 1 || ncols > SCATTER_MAX_COLS) return AH_NOT_YET_IMPLEMENTED;
+  const int width = ah_type_width(values[0].type);
+  if (width <= 0) return AH_NOT_YET_IMPLEMENTED;
+  for (int c = 0; c < ncols; ++c) {
+    if (ah_type_width(values[c].type) != width || !values[c].validity || values[c].null_count == 0) return AH_NOT_YET_IMPLEMENTED;
+    if (p->len > values[c].length || ((uintptr_t)dst_validity[c] & 7) != 0) return AH_NOT_YET_IMPLEMENTED;
+  }
+  if (win_hi > p->count) win_hi = p->count;
+  const int64_t K = win_hi - win_lo;  // rows this launch appends: positions [win_lo, win_hi) of the filtered batch
+  if (p->len == 0 || K <= 0) return AH_OK;
+  ScatterArgs a{};
+  a.mask = p->mask;
+  a.mask_valid = p->mask_valid;
+  a.len = p->len;
+  a.chunk_prefix = p->chunk_prefix;
+  a.group_prefix = p->group_prefix;
+  a.group_shift = p->group_shift;
+  a.out_base = dst_row_offset;
+  if (!(win_lo == 0 && win_hi == p->count)) a.win_lo = win_lo, a.win_hi = win_hi;
+  a.values = values[0].values;
+  a.vvalid = make_bitview(values[0].validity, values[0].validity_bit_offset);
+  a.out_values = dst_values[0];
+  a.out_valid = (unsigned long long*)dst_validity[0];
+  a.valid_slots = slots;
+  for (int c = 1; c < ncols; ++c) {
+    ScatterArgs::Col& m = a.more[c - 1];
+    m.values = values[c].values;
+    m.vvalid = make_bitview(values[c].validity, values[c].validity_bit_offset);
+    m.out_values = dst_values[c];
+    m.out_valid = (unsigned long long*)dst_validity[c];
+    m.valid_slots = slots + (size_t)c * 64;
+  }
+  {
+    ah_prof_scope ps(ctx, "filter_scatter");
+    launch_scatter<true>(ctx, width, a, use_skip(p->count, p->len), ncols);
+  }
+  filter_finish_acc_cols_kernel<<<(unsigned)ncols, 64, 0, ctx->stream>>>(slots, (unsigned long long)K, nulls_acc);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "fused filter copy failed: %s", hipGetErrorString(e));
   return AH_OK;
 }
 

@@ -294,17 +294,30 @@ PMC_KERNELS = {
 }
 
 
+# workloads whose roofline object covers ALL launches of one step: every dispatch whose name matches is summed and
+# divided by the steps the child ran (setup kernels — generators, the casts that build the input — do not match)
+PMC_STEP_KERNELS = {
+    "string_filter_take": r"filter_(scatter|count|count_small|group_scan|finish)\w*_kernel|range_scan_\w+_kernel|"
+                          r"gather_bytes_kernel|take_ranges_kernel",
+    "coalesce": r"filter_(scatter|count|count_small|group_scan|finish|finish_acc)\w*_kernel|copy_rows\w*_kernel|bm_acc_kernel",
+}
+PMC_CHILD_STEPS, PMC_CHILD_WARMUP = 2, 1
+
+
 def pmc_traffic_inrun(args, wl):
     """HBM bytes per launch of the workload's kernels, measured NOW: two extra runs of two steps each under
     rocprofv3 (FETCH_SIZE and WRITE_SIZE in separate passes, never combined with other tracing)."""
-    if args.pmc_traffic == "off" or wl not in PMC_KERNELS or shutil.which("rocprofv3") is None:
+    if args.pmc_traffic == "off" or (wl not in PMC_KERNELS and wl not in PMC_STEP_KERNELS) or shutil.which("rocprofv3") is None:
         return None
-    pats = PMC_KERNELS[wl]
+    pats = PMC_KERNELS.get(wl, {})
+    step_pat = PMC_STEP_KERNELS.get(wl)
     got = {k: {} for k in pats}
+    step_sum = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ah_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-               sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", wl, "--steps", "2", "--warmup", "1",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", wl, "--steps", str(PMC_CHILD_STEPS),
+               "--warmup", str(PMC_CHILD_WARMUP),
                "--rows", str(args.rows), "--selectivity", str(args.selectivity), "--valid", str(args.valid)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
@@ -317,6 +330,8 @@ def pmc_traffic_inrun(args, wl):
                     for k, (pat, _) in pats.items():
                         if re.search(pat, r["Kernel_Name"]):
                             got[k].setdefault(counter, []).append(float(r["Counter_Value"]))
+                    if step_pat and re.search(step_pat, r["Kernel_Name"]):
+                        step_sum[counter] = step_sum.get(counter, 0.0) + float(r["Counter_Value"])
         except Exception as ex:  # noqa: BLE001 - a profiler hiccup must never cost the bench line
             return {"error": repr(ex)[:200]}
         finally:
@@ -326,6 +341,9 @@ def pmc_traffic_inrun(args, wl):
         f, w = got[k].get("FETCH_SIZE"), got[k].get("WRITE_SIZE")
         if f and w:
             out[k] = int(sum(f) / len(f) * 1024 * fetch_scale + sum(w) / len(w) * 1024)
+    if step_pat and "FETCH_SIZE" in step_sum and "WRITE_SIZE" in step_sum:
+        child_steps = PMC_CHILD_STEPS + PMC_CHILD_WARMUP
+        out["step_total"] = int((step_sum["FETCH_SIZE"] * 2.0 + step_sum["WRITE_SIZE"]) * 1024 / child_steps)
     return out or None
 
 
@@ -735,7 +753,11 @@ def main():
         kern, avg_ms, launches, alg, workload, metric, dtype = describe(env, wl, W, prof, out, args.steps)
         traffic = pmc_traffic_inrun(args, wl) if world == 1 else None
         tr = traffic if isinstance(traffic, dict) and "error" not in traffic else {}
-        rf = roofline_obj(kern, alg, avg_ms, launches, tr.get(kern))
+        rf = roofline_obj(kern, alg, avg_ms, launches, tr.get("step_total") if wl in PMC_STEP_KERNELS else tr.get(kern))
+        if wl in PMC_STEP_KERNELS:
+            rf["note"] = ("all launches of one step; traffic = PMC bytes of those launches per step.  Random row access moves one "
+                          "128-byte line per offsets pair / validity bit / short value, so traffic_frac, not frac, says how "
+                          "close to the memory system's limit the step runs")
         if wl == "filter_take":
             idx, st = W["idx"], W["state"]
             take_bytes = idx.length * (4 + 8 + 8) + 2 * ((idx.length + 7) // 8)

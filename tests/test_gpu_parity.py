@@ -915,6 +915,44 @@ def test_batch_coalescer_fuzz(ctx, oracle, limit):
         assert co.is_empty()
 
 
+@pytest.mark.parametrize("dts", [(A.Int64, A.Float64), (A.Int32, A.Float32, A.UInt32), (A.Int16,),
+                                 (A.Int64, A.Float64, A.UInt64, A.Int64, A.Float64, A.UInt64, A.Int64, A.Float64)])
+def test_batch_coalescer_same_shape_columns_one_launch(ctx, oracle, dts):
+    """All columns nullable and of one width: ONE scatter launch per output batch a filtered push lands in
+    (ah_filter_apply_into_acc_cols), windows of the filtered stream when the push straddles output batches — also
+    several of them (target far below the selected rows).  Same batches as the model of coalesce.rs:229."""
+    from coalesce_model import ModelCoalescer
+    rng = np.random.default_rng(99 + len(dts))
+    names = [f"c{k}" for k in range(len(dts))]
+    for trial, limit in enumerate([None, None, 5000, None]):
+        target = int(rng.choice([13, 64, 1000, 4096, 20000]))
+        co = K.BatchCoalescer.new(names, list(dts), target, ctx).with_biggest_coalesce_batch_size(limit)
+        model = ModelCoalescer(oracle, list(dts), target)
+        model.limit = limit
+        for step in range(20):
+            n = int(rng.integers(0, 6 * target + 9)) if step % 4 else int(rng.integers(4096, 70000))
+            cols = [HostArray(dt, _rand_values(rng, dt, n), rng.random(n) < float(rng.choice([0.5, 0.9]))) for dt in dts]
+            sel = float(rng.choice([0.02, 0.3, 0.97]))
+            flen = n - int(rng.integers(0, min(n, 3) + 1))
+            f = HostArray(A.Boolean, rng.random(flen) < sel, (rng.random(flen) < 0.9) if step % 2 else None)
+            off = int(rng.integers(0, 70)) if n > 200 else 0  # sliced inputs: bit offsets in mask and validity
+            dcols = [c.to_device(ctx) for c in cols]
+            df = f.to_device(ctx)
+            if off and flen > off:
+                dcols = [c.slice(off, n - off) for c in dcols]
+                df = df.slice(off, flen - off)
+                cols = [c.slice(off, n - off) for c in cols]
+                f = f.slice(off, flen - off)
+            co.push_batch_with_filter(A.RecordBatch(names, dcols), df)
+            model.push_with_filter(cols, f)
+            assert co.get_buffered_rows() == model.buffered, f"trial {trial} step {step}"
+            _check_batches(co, model, f"same-shape trial {trial} step {step}")
+        co.finish_buffered_batch()
+        model.finish()
+        _check_batches(co, model, f"same-shape trial {trial} final")
+        assert co.is_empty()
+
+
 def test_batch_coalescer_grouped_pushes_equal_single_pushes(ctx, oracle):
     """ah_coalescer_push_batches_with_filters (n filtered pushes, one wait for the n counts) must produce exactly the
     output batches of n single pushes — compared with the model of coalesce.rs, bypass limit included."""
