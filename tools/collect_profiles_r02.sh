@@ -10,9 +10,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- pyt
 for wl in arith cmp cast cast_string; do
   python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_$wl.json 2> $O/bench_$wl.err
 done
-for wl in coalesce record_batch string_filter_take aggregate; do
+for wl in coalesce string_filter_take; do  # roofline over ALL launches of a step, PMC traffic summed per step
+  python bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_$wl.json 2> $O/bench_$wl.err
+done
+for wl in record_batch aggregate; do
   python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $O/bench_$wl.json 2> $O/bench_$wl.err
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cast_string -o bench -- python bench.py --workload cast_string --steps 5 --warmup 2 --no-cpu-baseline --pmc-traffic off > $O/bench_cs_trace.json 2> $O/trace_cs.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_coalesce -o bench -- python bench.py --workload coalesce --steps 5 --warmup 2 --no-cpu-baseline --pmc-traffic off > $O/bench_co_trace.json 2> $O/trace_co.log
 python bench.py --reassemble allgatherv --steps 5 --warmup 2 --no-cpu-baseline --no-configs --pmc-traffic off > $O/bench_exchange_world1.json 2> $O/bench_exchange_world1.err
 AH_WAIT=block python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs --pmc-traffic off > $O/bench_wait_block.json 2> $O/bench_wait_block.err
 ls $O

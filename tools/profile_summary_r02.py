@@ -79,8 +79,8 @@ if os.path.exists(p):
                "launches of the extra measurement, 1.5 ms.)\n")
 
 out.append("## Per-workload lines with in-run PMC traffic\n")
-out.append("| workload | ms per call | roofline kernel | frac | PMC traffic per launch (GB) | host_gap_ms |")
-out.append("|---|---|---|---|---|---|")
+out.append("| workload | ms per call (without per-kernel events) | roofline kernel | frac | traffic_frac | PMC traffic per launch / step (GB) | host_gap_ms |")
+out.append("|---|---|---|---|---|---|---|")
 traffic = {}
 for wl in ["arith", "cmp", "cast", "cast_string", "coalesce", "record_batch", "string_filter_take", "aggregate"]:
     d2 = line_of(f"bench_{wl}.json")
@@ -88,10 +88,26 @@ for wl in ["arith", "cmp", "cast", "cast_string", "coalesce", "record_batch", "s
         continue
     tr = d2.get("pmc_traffic_bytes_per_launch")
     traffic[wl] = tr
-    out.append(f"| {wl} | {d2['ms_per_step']} | {d2['roofline']['kernel']} | {d2['roofline']['frac']} | "
+    out.append(f"| {wl} | {d2['ms_per_step']} ({d2.get('ms_per_step_without_kernel_events', '—')}) | {d2['roofline']['kernel']} | "
+               f"{d2['roofline']['frac']} | {d2['roofline'].get('traffic_frac', '—')} | "
                f"{ {k: round(v / 1e9, 2) for k, v in tr.items()} if isinstance(tr, dict) else '—'} | {d2.get('host_gap_ms')} |")
     shutil.copy(os.path.join(src, f"bench_{wl}.json"), os.path.join(dst, f"r02_bench_{wl}.json"))
 out.append("")
+
+for tag, title in (("trace_cast_string", "cast_string (configs[3], Float64 -> LargeUtf8, 2^29 rows)"),
+                   ("trace_coalesce", "coalesce (BatchCoalescer, 60 pushes of 2^24 rows per step)")):
+    p2 = os.path.join(src, tag, "bench_kernel_stats.csv")
+    if os.path.exists(p2):
+        shutil.copy(p2, os.path.join(dst, f"r02_{tag}_kernel_stats.csv"))
+        out.append(f"## rocprofv3 --kernel-trace --stats: {title}; times in µs\n")
+        out.append("| kernel | calls | avg µs | min µs | % |")
+        out.append("|---|---|---|---|---|")
+        for r in csv.DictReader(open(p2)):
+            if float(r["Percentage"]) < 0.5:
+                continue
+            out.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
+                       f"{float(r['Percentage']):.2f} |")
+        out.append("")
 
 ex = line_of("bench_exchange_world1.json")
 if ex:
