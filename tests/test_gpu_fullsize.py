@@ -168,6 +168,65 @@ def test_config1_filter_take_every_row(ctx, oracle):
         assert sum(r[1] for r in res) == t.null_count(), f"{name}: null_count"
 
 
+# ------------------------------------------------------------------------------ BatchCoalescer at the bench's size
+def test_coalescer_filtered_pushes_every_row(ctx, oracle):
+    """SURVEY 8f-1 at bench.py's `coalesce` size: 1e9 rows of {Int64, Float64} pushed as 2^24-row batches with a 10 %
+    filter (coalesce.rs:229); every output batch — size, values, validity, null count — is compared with the oracle's
+    filter of the same rows cut into `target`-row batches.  Covers the one-launch-for-all-columns scatter and its
+    output windows (pushes that straddle output batches) at large destination offsets."""
+    n, br = 1_000_000_000, 1 << 24
+    a = B.gen_i64_column(A, ctx, n, 42, 0.9, 0)
+    b = B.gen_f64_column(A, ctx, n, 52, 0.9, 0)
+    pred = B.gen_predicate(A, ctx, n, 44, 0.1, 0)
+    target = int(br * 0.1 * 4)
+    co = K.BatchCoalescer.new(["a", "b"], [A.Int64, A.Float64], target, ctx)
+    got = []
+    for i in range(0, n, br):
+        rows = min(br, n - i)
+        co.push_batch_with_filter(A.RecordBatch(["a", "b"], [a.slice(i, rows), b.slice(i, rows)]), pred.slice(i, rows))
+        while co.has_completed_batch():
+            got.append(co.next_completed_batch())
+    co.finish_buffered_batch()
+    while co.has_completed_batch():
+        got.append(co.next_completed_batch())
+
+    def filt(job):
+        c0, rows = job
+        mb = _bits(oracle, rows, 44, 0.1, c0)
+        res = []
+        for gen, seed, tid, dt in ((_gen_i64_chunk, 42, L.AH_INT64, np.int64), (_gen_f64_chunk, 52, L.AH_FLOAT64, np.float64)):
+            v, vb = gen(oracle, c0, rows, seed, 0.9)
+            out = orc.Out()
+            assert oracle.lib.orc_filter(C.byref(_view(tid, rows, v, vb)), C.byref(_view(L.AH_BOOL, rows, mb, None, 0)), C.byref(out)) == 0
+            k = out.length
+            res.append((_out_bytes(out.values, k * 8).view(np.uint64), _valid_of(out, k)))
+            oracle.lib.orc_release(C.byref(out))
+        return res
+
+    with cf.ThreadPoolExecutor(NT) as ex:
+        parts = list(ex.map(filt, _chunks(n)))
+    total = sum(len(p[0][0]) for p in parts)
+    assert sum(g.num_rows() for g in got) == total
+    assert all(g.num_rows() == target for g in got[:-1]) and 0 < got[-1].num_rows() <= target
+    for c in range(2):
+        ev = np.concatenate([p[c][0] for p in parts])
+        eb = np.concatenate([p[c][1] for p in parts])
+        off = 0
+        for bi, g in enumerate(got):
+            k, col = g.num_rows(), g.columns[c]
+            assert col.length == k
+            dv = _dev_bytes(ctx, col.values, 0, k * 8).view(np.uint64)
+            assert np.array_equal(dv, ev[off:off + k]), f"column {c}, output batch {bi}: values"
+            exp_valid = eb[off:off + k]
+            if col.validity is None:
+                assert exp_valid.all(), f"column {c}, output batch {bi}: null buffer missing"
+            else:
+                assert np.array_equal(_unpack(_dev_bytes(ctx, col.validity, 0, (k + 7) // 8), k), exp_valid), \
+                    f"column {c}, output batch {bi}: validity"
+            assert col.null_count() == int(k - exp_valid.sum()), f"column {c}, output batch {bi}: null_count"
+            off += k
+
+
 # ------------------------------------------------------------------------------------------- configs[2]
 _SPECIALS = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
                       -1.7976931348623157e308, 1.0, -1.0], dtype=np.float64)
