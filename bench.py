@@ -321,7 +321,7 @@ def pmc_traffic_inrun(args, wl):
                "--rows", str(args.rows), "--selectivity", str(args.selectivity), "--valid", str(args.valid)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, timeout=300, check=True)
+                           stderr=subprocess.DEVNULL, timeout=150, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             for f in files:
                 for r in csv.DictReader(open(f)):
