@@ -613,6 +613,35 @@ def test_cast_f64_to_utf8_vs_oracle(ctx, oracle):
     check(K.cast(d, A.Utf8), oracle.cast(h.slice(3, 20001), A.Utf8), "sliced")
 
 
+@pytest.mark.parametrize("src", [A.Float64, A.Float32])
+def test_cast_to_utf8_sparse_and_dense_tiles(ctx, oracle, src):
+    """The side queue's tile decision: a 512-row tile with fewer than 16 shortest-digit (Ryu) rows hands them to the
+    dense side passes (tile record of at most 15 {row, length} entries), one with 16 or more keeps them in-kernel.
+    Tiles with 0..20 such rows, next to each other inside one 2048-row length-pass workgroup, with nulls, sliced."""
+    rng = np.random.default_rng(5150)
+    tiles, T = 84, 512
+    n = tiles * T + 77  # ragged last tile
+    vals = rng.integers(-10**6, 10**6, n).astype(np.float64)
+    for j in range(tiles):
+        g = j % 21
+        rows = j * T + rng.choice(T, g, replace=False)
+        kind = rng.integers(0, 4, g)
+        gen = np.where(kind == 0, rng.integers(2**53, 2**62, g).astype(np.float64) * rng.choice([-1.0, 1.0], g),
+                       np.where(kind == 1, rng.normal(size=g) * 1e-7,
+                                np.where(kind == 2, rng.normal(size=g) * 1e300 if src is A.Float64 else rng.normal(size=g) * 1e30,
+                                         rng.normal(size=g) * 123.456)))
+        vals[rows] = gen
+    vals = vals.astype(src.np_dtype)
+    h = HostArray(src, vals, rng.random(n) < 0.9)
+    d = h.to_device(ctx)
+    for to in (A.Utf8, A.LargeUtf8):
+        check(K.cast(d, to), oracle.cast(h, to), f"{src}->{to}")
+        for off in (5, 64, 511):
+            check(K.cast(d.slice(off, n - off - 3), to), oracle.cast(h.slice(off, n - off - 3), to), f"{src}->{to} sliced at {off}")
+    allvalid = HostArray(src, vals)
+    check(K.cast(allvalid.to_device(ctx), A.LargeUtf8), oracle.cast(allvalid, A.LargeUtf8), "no nulls")
+
+
 def test_cast_f32_and_ints_to_utf8(ctx, oracle):
     rng = np.random.default_rng(78)
     f32 = np.concatenate([rng.integers(0, 2**32, 40000, dtype=np.uint64).astype(np.uint32).view(np.float32),
