@@ -267,7 +267,9 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
   if (selected == num_rows && filter->length == num_rows) return push_batch_impl(ctx, co, columns, num_rows, tag, bypassed);
   const bool exceeds = co->limit >= 0 && selected > co->limit;
   bool does_not_fit = selected > co->target - co->buffered;
-  if (!exceeds && co->ncols <= 8) {
+  // (every window is a launch over the whole input batch: a push that would fill more than three output batches
+  // goes through the materialised path below instead — one filter, then copies)
+  if (!exceeds && co->ncols <= 8 && selected <= (co->target - co->buffered) + 2 * co->target) {
     // Same-shape nullable columns: ONE scatter launch per output batch the filtered rows land in — positions
     // [done, done + take) of the filtered stream go straight into the in-progress batch, also when the batch straddles
     // two (or more) output batches.  No intermediate filtered array, no host wait besides finish_buffered's.
