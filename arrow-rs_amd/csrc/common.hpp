@@ -57,7 +57,7 @@ struct ah_context {
   uint64_t* pinned_dev = nullptr;  // the same memory as the device sees it
   uint64_t mail_seq = 0;           // last sequence number handed to a kernel
   int wait_mode = 0;               // 0 = spin on the mailbox (default), 1 = hipStreamSynchronize (AH_WAIT=block)
-  // persistent self-cleaning device scratch (AH_SCRATCH_WORDS u64): [0,64) zero between calls (valid-row
+  // persistent self-cleaning device scratch (AH_SCRATCH_WORDS u64): [0,512) zero between calls (valid-row
   // counters), [64,72) all-ones between calls (first-failing-position words); the finish kernels that read
   // them back also restore them, so no per-call hipMemsetAsync
   unsigned long long* scratch = nullptr;
@@ -94,8 +94,8 @@ ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...);
   } while (0)
 
 constexpr int AH_MAIL_FLAG = 255;     // index of the sequence word in ctx->pinned
-constexpr int AH_SCRATCH_WORDS = 72;   // 64 zero-state counters + 8 ones-state position words
-constexpr int AH_SCRATCH_ONES = 64;
+constexpr int AH_SCRATCH_WORDS = 520;  // 8 x 64 zero-state counters (one set per column of a fused launch) + 8 ones-state position words
+constexpr int AH_SCRATCH_ONES = 512;
 
 // enqueue a device -> pinned-slot copy (a one-wave kernel, stream-ordered like hipMemcpyAsync); `pinned_dst` must
 // point into ctx->pinned and `bytes` is a multiple of 8

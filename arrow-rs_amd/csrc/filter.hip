@@ -206,6 +206,25 @@ __global__ void __launch_bounds__(64) filter_finish_acc_cols_kernel(unsigned lon
   if (threadIdx.x == 0 && k != v) atomicAdd(acc + blockIdx.x, k - v);
 }
 
+// the output bitmaps of a fused multi-column scatter, zeroed by one launch (blockIdx.y = column)
+struct ZeroCols { unsigned long long* p[8]; };
+__global__ void __launch_bounds__(256) zero_words_cols_kernel(ZeroCols z, int64_t words) {
+  unsigned long long* p = z.p[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256) p[i] = 0;
+}
+
+// one wait for a fused multi-column scatter: column c's valid-row count lands in mail[c], counters back to zero
+__global__ void __launch_bounds__(64) filter_finish_cols_kernel(unsigned long long* slots, int ncols, uint64_t* mail,
+                                                                uint64_t seq) {
+  for (int c = 0; c < ncols; ++c) {
+    unsigned long long v = slots[c * 64 + threadIdx.x];
+    slots[c * 64 + threadIdx.x] = 0;
+    v = wave_reduce_add64(v);
+    if (threadIdx.x == 0) __hip_atomic_store(mail + c, (uint64_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (threadIdx.x == 0) ah_mail_post(mail, seq);
+}
+
 // after the scatter: fold the VALID_SLOTS counters into one number for the host, leave them zero for the next
 // call (ctx->scratch is self-cleaning: no per-call memset), publish.  mail == nullptr (deferred): clean only.
 __global__ void __launch_bounds__(64) filter_finish_kernel(unsigned long long* slots, uint64_t* mail, uint64_t seq) {
@@ -1080,6 +1099,93 @@ extern "C" ah_status ah_filter(ah_context* ctx, const ah_array_view* values,
   return st;
 }
 
+// filter_record_batch's primitive columns of one width and validity shape through ONE scatter launch and ONE host
+// wait (`cols`: indices into columns / outs, 2..8 of them).  The per-column path costs a launch pair and a wait per
+// column, which is what a query engine's 8 Ki-row batches of many columns pay for.
+static ah_status filter_columns_fused(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* columns,
+                                      ah_array_out* outs, const int* cols, int ncols, int width, bool has_valid) {
+  const int64_t K = p->count;
+  const size_t vbytes = (size_t)K * width, bbytes = has_valid ? ah_bitmap_bytes(K) : 0;
+  void* ov[SCATTER_MAX_COLS] = {};
+  void* ob[SCATTER_MAX_COLS] = {};
+  ah_status st = AH_OK;
+  for (int i = 0; i < ncols && st == AH_OK; ++i) {
+    st = ah_out_alloc(ctx, vbytes, &ov[i]);
+    if (st == AH_OK && has_valid) st = ah_out_alloc(ctx, bbytes, &ob[i]);
+  }
+  if (st == AH_OK && has_valid) {
+    ZeroCols z{};
+    for (int i = 0; i < ncols; ++i) z.p[i] = (unsigned long long*)ob[i];
+    const int64_t words = (int64_t)(bbytes / 8);  // ah_bitmap_bytes: whole 64-bit words
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(words, 256), 2048));
+    zero_words_cols_kernel<<<dim3(gx, (unsigned)ncols), 256, 0, ctx->stream>>>(z, words);
+  }
+  hipError_t e = hipSuccess;
+  if (st == AH_OK) {
+    ScatterArgs a{};
+    a.mask = p->mask;
+    a.mask_valid = p->mask_valid;
+    a.len = p->len;
+    a.chunk_prefix = p->chunk_prefix;
+    a.group_prefix = p->group_prefix;
+    a.group_shift = p->group_shift;
+    for (int i = 0; i < ncols; ++i) {
+      const ah_array_view& v = columns[cols[i]];
+      const BitView vv = has_valid ? make_bitview(v.validity, v.validity_bit_offset) : BitView{nullptr, 0};
+      if (i == 0) {
+        a.values = v.values, a.vvalid = vv, a.out_values = ov[0], a.out_valid = (unsigned long long*)ob[0];
+        a.valid_slots = has_valid ? ctx->scratch : nullptr;
+      } else {
+        ScatterArgs::Col& m = a.more[i - 1];
+        m.values = v.values, m.vvalid = vv, m.out_values = ov[i], m.out_valid = (unsigned long long*)ob[i];
+        m.valid_slots = has_valid ? ctx->scratch + (size_t)i * 64 : nullptr;
+      }
+    }
+    {
+      ah_prof_scope ps(ctx, "filter_scatter");
+      if (has_valid) st = launch_scatter<true>(ctx, width, a, use_skip(K, p->len), ncols);
+      else st = launch_scatter<false>(ctx, width, a, use_skip(K, p->len), ncols);
+    }
+    e = hipGetLastError();
+    if (st == AH_OK && e == hipSuccess) {
+      if (has_valid) {
+        const uint64_t seq = ah_mail_next(ctx);
+        filter_finish_cols_kernel<<<1, 64, 0, ctx->stream>>>(ctx->scratch, ncols, ctx->pinned_dev, seq);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
+      } else {
+        e = ah_stream_wait(ctx);
+      }
+    }
+    if (st == AH_OK && e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "filter scatter failed: %s", hipGetErrorString(e));
+  }
+  if (st != AH_OK) {
+    for (int i = 0; i < ncols; ++i) {
+      ah_out_free(ctx, ov[i], vbytes);
+      ah_out_free(ctx, ob[i], bbytes);
+    }
+    return st;
+  }
+  for (int i = 0; i < ncols; ++i) {
+    ah_array_out* out = &outs[cols[i]];
+    out->type = columns[cols[i]].type;
+    out->length = K;
+    out->values = ov[i];
+    out->values_bytes = (int64_t)vbytes;
+    if (has_valid) {
+      const int64_t nulls = K - (int64_t)ctx->pinned[i];
+      if (nulls == 0) {  // filter_nulls :523-525 -> None
+        ah_out_free(ctx, ob[i], bbytes);
+      } else {
+        out->validity = (uint8_t*)ob[i];
+        out->validity_bytes = (int64_t)bbytes;
+        out->null_count = nulls;
+      }
+    }
+  }
+  return AH_OK;
+}
+
 extern "C" ah_status ah_filter_record_batch(ah_context* ctx, int32_t n_columns,
                                             const ah_array_view* columns,
                                             const ah_array_view* predicate, ah_array_out* outs,
@@ -1090,8 +1196,33 @@ extern "C" ah_status ah_filter_record_batch(ah_context* ctx, int32_t n_columns,
   AH_TRY(ah_filter_predicate_build(ctx, predicate, &p));
   ah_status st = AH_OK;
   for (int32_t c = 0; c < n_columns; ++c) ah_out_init(&outs[c]);
+  // same-shape primitive columns go out together; everything else (and the None / All strategies, deferred mode,
+  // error cases) column by column
+  std::vector<char> done((size_t)std::max(n_columns, 1), 0);
+  if (!ctx->deferred && p->len > 0 && p->count > 0 && p->count < p->len) {
+    std::vector<int> width((size_t)n_columns, 0);
+    std::vector<char> hv((size_t)n_columns, 0);
+    for (int32_t c = 0; c < n_columns && st == AH_OK; ++c) {
+      const ah_array_view& v = columns[c];
+      const bool prim = v.type != AH_BOOL && v.type != AH_UTF8 && v.type != AH_LARGE_UTF8 && ah_type_width(v.type) > 0;
+      if (!prim || p->len > v.length) continue;
+      int64_t in_nulls = 0;
+      st = ah_resolve_null_count(ctx, &v, &in_nulls);
+      width[c] = ah_type_width(v.type);
+      hv[c] = v.validity && in_nulls > 0;
+    }
+    for (int32_t c = 0; c < n_columns && st == AH_OK; ++c) {
+      if (done[c] || width[c] == 0) continue;
+      int group[SCATTER_MAX_COLS], g = 0;
+      for (int32_t d = c; d < n_columns && g < SCATTER_MAX_COLS; ++d)
+        if (!done[d] && width[d] == width[c] && hv[d] == hv[c]) group[g++] = d;
+      if (g < 2) continue;
+      st = filter_columns_fused(ctx, p, columns, outs, group, g, width[c], hv[c] != 0);
+      for (int i = 0; i < g; ++i) done[group[i]] = 1;
+    }
+  }
   for (int32_t c = 0; c < n_columns && st == AH_OK; ++c)
-    st = ah_filter_predicate_apply(ctx, p, &columns[c], &outs[c]);
+    if (!done[c]) st = ah_filter_predicate_apply(ctx, p, &columns[c], &outs[c]);
   if (st != AH_OK)
     for (int32_t c = 0; c < n_columns; ++c) ah_array_release(ctx, &outs[c]);
   if (out_rows) *out_rows = p->count;  // RecordBatch row_count = predicate.count (filter.rs:476)

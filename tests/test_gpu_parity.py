@@ -235,6 +235,35 @@ def test_filter_predicate_reuse_and_record_batch(ctx, oracle):
         check(c, e)
 
 
+@pytest.mark.parametrize("n", [1, 777, 8192, 100003])
+def test_filter_record_batch_many_columns_one_launch(ctx, oracle, n):
+    """filter_record_batch (filter.rs:201-221 applied per column, :476 row count): primitive columns of one width and
+    validity shape leave through ONE scatter launch and one host wait (groups of up to 8), everything else column by
+    column; each output column — values, null-buffer presence, null count — must equal the oracle's filter()."""
+    rng = np.random.default_rng(31 + n)
+    nulls = lambda p: rng.random(n) < p
+    spec = [(A.Int64, nulls(0.9)), (A.Float64, nulls(0.8)), (A.Int64, None), (A.UInt64, nulls(0.5)), (A.Int32, nulls(0.9)),
+            (A.Float32, nulls(0.9)), (A.Int32, None), (A.UInt32, None), (A.Boolean, nulls(0.9)), (A.Utf8, nulls(0.9)),
+            (A.Int16, nulls(0.7)), (A.UInt16, nulls(0.7)), (A.Int8, None)] + [(A.Int64, nulls(0.95)) for _ in range(9)]
+    cols = []
+    for dt, v in spec:
+        if dt is A.Utf8:
+            cols.append(HostArray.from_pylist([None if (v is not None and not v[i]) else f"s{i % 97}" * (i % 4) for i in range(n)], A.Utf8))
+        elif dt is A.Boolean:
+            cols.append(HostArray(A.Boolean, rng.random(n) < 0.5, v))
+        else:
+            cols.append(HostArray(dt, _rand_values(rng, dt, n), v))
+    names = [f"c{i}" for i in range(len(cols))]
+    for sel, mask_nulls in ((0.1, True), (0.6, False), (1.0, False), (0.0, False)):
+        mask = HostArray(A.Boolean, rng.random(n) < sel, (rng.random(n) < 0.95) if mask_nulls else None)
+        out = K.filter_record_batch(A.RecordBatch(names, [c.to_device(ctx) for c in cols]), mask.to_device(ctx))
+        exp = [oracle.filter(c, mask) for c in cols]
+        assert out.num_rows() == len(exp[0]), f"selectivity {sel}"
+        for i, (c, e) in enumerate(zip(out.columns, exp)):
+            check(c, e, f"column {i} ({spec[i][0]}) at selectivity {sel}")
+            assert_same_nulls_presence(host(c), e, f"column {i} at selectivity {sel}")
+
+
 # --------------------------------------------------------------- fuzz: take
 @pytest.mark.parametrize("idt", [A.UInt8, A.Int8, A.UInt16, A.Int16, A.UInt32, A.Int32, A.UInt64, A.Int64], ids=str)
 def test_fuzz_take(ctx, oracle, idt):
