@@ -22,7 +22,12 @@ extern "C" ah_status ah_filter_predicate_apply_into_acc(ah_context*, const ah_fi
 extern "C" ah_status ah_filter_predicates_build(ah_context*, int32_t, const ah_array_view*, ah_filter_predicate**);
 // filter.hip: the columns of one batch through one scatter launch (AH_NOT_YET_IMPLEMENTED: shapes differ, nothing done)
 ah_status ah_filter_apply_into_acc_cols(ah_context*, const ah_filter_predicate*, int, const ah_array_view*, void* const*,
-                                        uint8_t* const*, int64_t, unsigned long long*, unsigned long long*, int64_t, int64_t);
+                                        uint8_t* const*, int64_t, unsigned long long*, unsigned long long*, int64_t, int64_t,
+                                        int, double);
+// filter.hip: ah_filter_predicate_build in two halves (enqueue the count pass / wait for K)
+ah_status ah_filter_predicate_begin(ah_context*, const ah_array_view*, ah_filter_predicate**, uint64_t*, bool*);
+ah_status ah_filter_predicate_end(ah_context*, ah_filter_predicate*, uint64_t, bool);
+extern "C" void ah_filter_predicate_free(ah_context*, ah_filter_predicate*);
 
 namespace {
 
@@ -50,6 +55,7 @@ struct ah_coalescer {
   int64_t buffered = 0;
   std::deque<CoBatch> completed;
   uint64_t* acc = nullptr;  // device: appended-null count per column of the in-progress batch
+  double selectivity = 0.1;  // of the last filtered push: picks the speculative scatter's load-predication mode
 };
 
 namespace {
@@ -145,10 +151,11 @@ ah_status bypass(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns
   return AH_OK;
 }
 
+// `offset0`: rows [0, offset0) of `columns` are already in the coalescer (a speculative scatter put them there)
 ah_status push_batch_impl(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns, int64_t num_rows, uint64_t tag,
-                          int32_t* bypassed) {
-  if (num_rows == 0) return AH_OK;
-  if (co->limit >= 0 && num_rows > co->limit) {
+                          int32_t* bypassed, int64_t offset0 = 0) {
+  if (num_rows - offset0 <= 0) return AH_OK;
+  if (offset0 == 0 && co->limit >= 0 && num_rows > co->limit) {
     if (co->buffered == 0) {  // case 1
       if (bypassed) *bypassed = 1;
       return bypass(ctx, co, columns, num_rows, tag);
@@ -159,7 +166,7 @@ ah_status push_batch_impl(ah_context* ctx, ah_coalescer* co, const ah_array_view
       return bypass(ctx, co, columns, num_rows, tag);
     }
   }
-  int64_t remaining_rows = num_rows, offset = 0;
+  int64_t remaining_rows = num_rows - offset0, offset = offset0;
   while (remaining_rows > co->target - co->buffered) {
     const int64_t room = co->target - co->buffered;
     AH_TRY(copy_rows_all(ctx, co, columns, offset, room));
@@ -259,23 +266,25 @@ ah_status check_filter(ah_context* ctx, ah_coalescer* co, const ah_array_view* c
 }
 
 // push_batch_with_filter (coalesce.rs:229) once the predicate's count is known
+// `done0`: positions [0, done0) of the filtered stream are already appended (speculative scatter; only without a
+// bypass limit)
 ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns, int64_t num_rows,
-                             const ah_array_view* filter, ah_filter_predicate* p, uint64_t tag, int32_t* bypassed) {
+                             const ah_array_view* filter, ah_filter_predicate* p, uint64_t tag, int32_t* bypassed,
+                             int64_t done0 = 0) {
   const int64_t selected = ah_filter_predicate_count(p);
   ah_status st = AH_OK;
-  if (selected == 0) return AH_OK;  // nothing to append
-  if (selected == num_rows && filter->length == num_rows) return push_batch_impl(ctx, co, columns, num_rows, tag, bypassed);
+  if (selected == 0 || done0 >= selected) return AH_OK;  // nothing (more) to append
+  if (done0 == 0 && selected == num_rows && filter->length == num_rows) return push_batch_impl(ctx, co, columns, num_rows, tag, bypassed);
   const bool exceeds = co->limit >= 0 && selected > co->limit;
-  bool does_not_fit = selected > co->target - co->buffered;
+  int64_t done = done0;
   // (every window is a launch over the whole input batch: a push that would fill more than three output batches
   // goes through the materialised path below instead — one filter, then copies)
-  if (!exceeds && co->ncols <= 8 && selected <= (co->target - co->buffered) + 2 * co->target) {
+  if (!exceeds && co->ncols <= 8 && selected - done <= (co->target - co->buffered) + 2 * co->target) {
     // Same-shape nullable columns: ONE scatter launch per output batch the filtered rows land in — positions
     // [done, done + take) of the filtered stream go straight into the in-progress batch, also when the batch straddles
     // two (or more) output batches.  No intermediate filtered array, no host wait besides finish_buffered's.
     void* dv[8];
     uint8_t* db[8];
-    int64_t done = 0;
     while (done < selected && st == AH_OK) {
       st = ensure_capacity(ctx, co);
       if (st != AH_OK) break;
@@ -283,7 +292,7 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
       const int64_t take = std::min(co->target - co->buffered, selected - done);
       const ah_status fs = ah_filter_apply_into_acc_cols(ctx, p, co->ncols, columns, dv, db, co->buffered,
                                                          (unsigned long long*)co->acc,
-                                                         (unsigned long long*)(co->acc + co->ncols), done, done + take);
+                                                         (unsigned long long*)(co->acc + co->ncols), done, done + take, 0, 0.0);
       if (fs == AH_NOT_YET_IMPLEMENTED && done == 0) break;  // shapes differ: the per-column paths below
       if (fs != AH_OK) return fs == AH_NOT_YET_IMPLEMENTED ? ah_fail(ctx, AH_INVALID_ARGUMENT, "coalescer: column shapes changed") : fs;
       co->buffered += take;
@@ -291,9 +300,9 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
       if (co->buffered >= co->target) st = finish_buffered(ctx, co);
     }
     if (st != AH_OK || done == selected) return st;
-    does_not_fit = selected > co->target - co->buffered;
   }
-  if (exceeds || does_not_fit) {  // materialise the filtered batch, then split it across output batches
+  const bool does_not_fit = selected - done > co->target - co->buffered;
+  if (exceeds || does_not_fit || done > 0) {  // materialise the filtered batch, then split it across output batches
     std::vector<ah_array_out> outs((size_t)co->ncols);
     std::vector<ah_array_view> views((size_t)co->ncols);
     for (auto& o : outs) ah_out_init(&o);
@@ -321,7 +330,7 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
           co->completed.push_back(std::move(b));
         }
       } else {
-        st = push_batch_impl(ctx, co, views.data(), selected, 0, nullptr);
+        st = push_batch_impl(ctx, co, views.data(), selected, 0, nullptr, done);
         if (st == AH_OK) st = ah_stream_wait(ctx) == hipSuccess ? AH_OK : ah_fail(ctx, AH_HIP_ERROR, "coalescer copy failed");
       }
     }
@@ -351,8 +360,41 @@ extern "C" ah_status ah_coalescer_push_batch_with_filter(ah_context* ctx, ah_coa
   hipSetDevice(ctx->device);
   AH_TRY(check_filter(ctx, co, columns, num_rows, filter));
   ah_filter_predicate* p = nullptr;
-  AH_TRY(ah_filter_predicate_build(ctx, filter, &p));  // one count pass for all columns: the push's one host wait
-  ah_status st = push_filtered_impl(ctx, co, columns, num_rows, filter, p, tag, bypassed);
+  // One count pass for all columns; its K is the push's one host wait.  Without a bypass limit the rows that fit the
+  // in-progress batch do not depend on K, so their scatter is enqueued BEFORE the wait (it clips itself to the rows
+  // that exist): the GPU works through the count's round trip to the host instead of idling (~15 us per push).
+  uint64_t seq = 0;
+  bool enqueued = false;
+  AH_TRY(ah_filter_predicate_begin(ctx, filter, &p, &seq, &enqueued));
+  ah_status st = AH_OK;
+  int64_t room = 0;
+  bool speculated = false;
+  if (enqueued && co->limit < 0 && co->ncols <= 8) {
+    st = ensure_capacity(ctx, co);
+    if (st == AH_OK) {
+      void* dv[8];
+      uint8_t* db[8];
+      for (int i = 0; i < co->ncols; ++i) dv[i] = co->cols[i].values, db[i] = co->cols[i].validity;
+      room = co->target - co->buffered;
+      const ah_status fs = ah_filter_apply_into_acc_cols(ctx, p, co->ncols, columns, dv, db, co->buffered,
+                                                         (unsigned long long*)co->acc,
+                                                         (unsigned long long*)(co->acc + co->ncols), 0, room, 1, co->selectivity);
+      if (fs == AH_OK) speculated = true;
+      else if (fs != AH_NOT_YET_IMPLEMENTED) st = fs;
+    }
+  }
+  if (st == AH_OK) st = ah_filter_predicate_end(ctx, p, seq, enqueued);
+  if (st == AH_OK) {
+    const int64_t selected = ah_filter_predicate_count(p);
+    if (filter->length > 0) co->selectivity = (double)selected / (double)filter->length;
+    int64_t done0 = 0;
+    if (speculated) {
+      done0 = std::min(selected, room);
+      co->buffered += done0;
+      if (co->buffered >= co->target) st = finish_buffered(ctx, co);
+    }
+    if (st == AH_OK) st = push_filtered_impl(ctx, co, columns, num_rows, filter, p, tag, bypassed, done0);
+  }
   ah_filter_predicate_free(ctx, p);
   return st;
 }

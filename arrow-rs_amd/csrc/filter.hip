@@ -213,6 +213,19 @@ __global__ void __launch_bounds__(256) zero_words_cols_kernel(ZeroCols z, int64_
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256) p[i] = 0;
 }
 
+// the speculative launch's tail: K is still on its way to the host, so the window's row count comes from the device
+__global__ void __launch_bounds__(64) filter_finish_acc_cols_dev_kernel(unsigned long long* slots, const unsigned long long* total,
+                                                                        unsigned long long win_lo, unsigned long long win_hi,
+                                                                        unsigned long long* acc) {
+  unsigned long long* my = slots + (size_t)blockIdx.x * 64;
+  unsigned long long v = my[threadIdx.x];
+  my[threadIdx.x] = 0;
+  v = wave_reduce_add64(v);
+  const unsigned long long hi = *total < win_hi ? *total : win_hi;
+  const unsigned long long k = hi > win_lo ? hi - win_lo : 0;
+  if (threadIdx.x == 0 && k != v) atomicAdd(acc + blockIdx.x, k - v);
+}
+
 // one wait for a fused multi-column scatter: column c's valid-row count lands in mail[c], counters back to zero
 __global__ void __launch_bounds__(64) filter_finish_cols_kernel(unsigned long long* slots, int ncols, uint64_t* mail,
                                                                 uint64_t seq) {
@@ -544,6 +557,7 @@ struct ah_filter_predicate {
   unsigned long long* group_prefix = nullptr;
   int group_shift = 10;
   void* block = nullptr;  // single pool allocation backing the tables
+  unsigned long long* total_dev = nullptr;  // K on the device (kernels that run before the host has read it)
 };
 
 // The count pass of a predicate, enqueued only: K lands in pinned slot `slot` (and, with seq != 0, the mailbox is
@@ -587,6 +601,7 @@ static ah_status predicate_enqueue(ah_context* ctx, const ah_array_view* predica
   uint32_t* group_total = (uint32_t*)(base + b_chunk);
   p->group_prefix = (unsigned long long*)(base + b_chunk + b_gt);
   unsigned long long* total = (unsigned long long*)(base + b_chunk + b_gt + b_gp);
+  p->total_dev = total;
   {
     ah_prof_scope ps(ctx, "filter_count");
     if (small) {
@@ -628,6 +643,21 @@ extern "C" ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_v
     p->count = (int64_t)ctx->pinned[0];
   }
   *out = p;
+  return AH_OK;
+}
+
+// The two halves of ah_filter_predicate_build for a caller that has device work to enqueue between them
+// (BatchCoalescer's speculative scatter): begin enqueues the count pass, end waits for K.
+ah_status ah_filter_predicate_begin(ah_context* ctx, const ah_array_view* predicate, ah_filter_predicate** out, uint64_t* seq,
+                                    bool* enqueued) {
+  *seq = ah_mail_next(ctx);
+  return predicate_enqueue(ctx, predicate, 0, *seq, out, enqueued);
+}
+ah_status ah_filter_predicate_end(ah_context* ctx, ah_filter_predicate* p, uint64_t seq, bool enqueued) {
+  if (!enqueued) return AH_OK;
+  hipError_t e = ah_mail_wait(ctx, seq);
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "filter count failed: %s", hipGetErrorString(e));
+  p->count = (int64_t)ctx->pinned[0];
   return AH_OK;
 }
 
@@ -1021,7 +1051,7 @@ static ah_status apply_into_impl(ah_context* ctx, const ah_filter_predicate* p, 
 ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predicate* p, int ncols, const ah_array_view* values,
                                         void* const* dst_values, uint8_t* const* dst_validity, int64_t dst_row_offset,
                                         unsigned long long* nulls_acc, unsigned long long* slots, int64_t win_lo,
-                                        int64_t win_hi) {
+                                        int64_t win_hi, int speculative, double selectivity_hint) {
   if (ncols < 1 || ncols > SCATTER_MAX_COLS) return AH_NOT_YET_IMPLEMENTED;
   const int width = ah_type_width(values[0].type);
   if (width <= 0) return AH_NOT_YET_IMPLEMENTED;
@@ -1029,8 +1059,10 @@ ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predica
     if (ah_type_width(values[c].type) != width || !values[c].validity || values[c].null_count == 0) return AH_NOT_YET_IMPLEMENTED;
     if (p->len > values[c].length || ((uintptr_t)dst_validity[c] & 7) != 0) return AH_NOT_YET_IMPLEMENTED;
   }
-  if (win_hi > p->count) win_hi = p->count;
-  const int64_t K = win_hi - win_lo;  // rows this launch appends: positions [win_lo, win_hi) of the filtered batch
+  // speculative: the count pass is enqueued but K has not reached the host; the launch clips itself to the rows
+  // that exist (a tile outside the window or without selected rows exits) and the tail kernel reads K on the device
+  if (!speculative && win_hi > p->count) win_hi = p->count;
+  const int64_t K = win_hi - win_lo;  // rows this launch appends (at most, when speculative): positions [win_lo, win_hi)
   if (p->len == 0 || K <= 0) return AH_OK;
   ScatterArgs a{};
   a.mask = p->mask;
@@ -1040,7 +1072,7 @@ ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predica
   a.group_prefix = p->group_prefix;
   a.group_shift = p->group_shift;
   a.out_base = dst_row_offset;
-  if (!(win_lo == 0 && win_hi == p->count)) a.win_lo = win_lo, a.win_hi = win_hi;
+  if (speculative || !(win_lo == 0 && win_hi == p->count)) a.win_lo = win_lo, a.win_hi = win_hi;
   a.values = values[0].values;
   a.vvalid = make_bitview(values[0].validity, values[0].validity_bit_offset);
   a.out_values = dst_values[0];
@@ -1056,9 +1088,14 @@ ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predica
   }
   {
     ah_prof_scope ps(ctx, "filter_scatter");
-    launch_scatter<true>(ctx, width, a, use_skip(p->count, p->len), ncols);
+    const bool skip = speculative ? use_skip((int64_t)(selectivity_hint * (double)p->len), p->len) : use_skip(p->count, p->len);
+    launch_scatter<true>(ctx, width, a, skip, ncols);
   }
-  filter_finish_acc_cols_kernel<<<(unsigned)ncols, 64, 0, ctx->stream>>>(slots, (unsigned long long)K, nulls_acc);
+  if (speculative)
+    filter_finish_acc_cols_dev_kernel<<<(unsigned)ncols, 64, 0, ctx->stream>>>(slots, p->total_dev, (unsigned long long)win_lo,
+                                                                               (unsigned long long)win_hi, nulls_acc);
+  else
+    filter_finish_acc_cols_kernel<<<(unsigned)ncols, 64, 0, ctx->stream>>>(slots, (unsigned long long)K, nulls_acc);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "fused filter copy failed: %s", hipGetErrorString(e));
   return AH_OK;

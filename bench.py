@@ -12,7 +12,7 @@ Bernoulli(0.1) predicate, 1e8 uniform UInt32 take indices
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-The ONE JSON line of the default single-GPU run also carries, under "configs", a few timed steps of
+The ONE JSON line of the default single-GPU run also carries, under "configs" (and "next_rows": SURVEY 8f), a few timed steps of
 every other single-GPU configuration of BASELINE.json (configs[2]: add_wrapping and lt on 1e9
 Float64 rows; configs[3]: Int64->Float64 and Float64->LargeUtf8 on 2^29 rows), each with its own
 roofline object, so that every quoted roofline fraction is driver-run (--no-configs skips them).
@@ -51,6 +51,7 @@ REQUEST_CEILING_G = 6300.0 / 128.0
 ALL_WORKLOADS = ["filter_take", "arith", "cmp", "cast", "cast_string", "coalesce", "string_filter_take", "aggregate",
                  "sort", "record_batch"]
 EXTRA_CONFIGS = ["arith", "cmp", "cast", "cast_string"]  # BASELINE configs[2] and [3], timed inside the default run
+NEXT_ROWS = ["coalesce", "record_batch", "string_filter_take"]  # SURVEY 8f rows 1 / 3 and configs[4]'s per-GPU shape, ditto
 
 
 def parse():
@@ -464,7 +465,7 @@ def build_workload(env, wl):
         W.update(step=lambda _r: (G.sum(col), G.min(col), G.max(col)), kernels=["aggregate"], dominant="aggregate")
     elif wl == "record_batch":
         # BASELINE configs[4] shape: RecordBatch {Int64, Float64, each with validity} + one mask per shard;
-        # filter_record_batch (one count pass, two scatters), then at N>1 ONE exchange of both columns
+        # filter_record_batch (one count pass, one two-column scatter launch), then at N>1 ONE exchange of both columns
         cola = gen_i64_column(A, ctx, n, 42, args.valid, row0)
         colb = gen_f64_column(A, ctx, n, 52, args.valid, row0)
         pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
@@ -533,8 +534,8 @@ def describe(env, wl, W, prof, out, steps):
         alg = 2 * (n * 8 + (n + 7) // 8) + (n + 7) // 8 + 2 * (k * 8 + (k + 7) // 8)
         dom_avg, dom_n = sum(prof[kk][0] for kk in kernels) / max(steps, 1), steps  # all launches of one step
     elif wl == "record_batch":
-        k = st["k"]  # per scatter launch: one column + its validity + the mask in, K values + K bits out
-        alg = n * 8 + 2 * ((n + 7) // 8) + k * 8 + (k + 7) // 8
+        k = st["k"]  # ONE scatter launch for both columns: 2 x (values + validity) + the mask in, 2 x (K values + K bits) out
+        alg = 2 * (n * 8 + (n + 7) // 8) + (n + 7) // 8 + 2 * (k * 8 + (k + 7) // 8)
     elif wl == "sort":
         alg = (n - W["col"].null_count()) * 32  # per radix pass: keys read twice, (key, index) pairs written once
     elif wl == "aggregate":
@@ -821,24 +822,35 @@ def main():
     # the other single-GPU configurations of BASELINE.json, a few steps each, inside the same line
     if wl == "filter_take" and world == 1 and not args.no_configs and args.rows == 1_000_000_000:
         W = out = None
-        configs = {}
-        for w2 in EXTRA_CONFIGS:
+        configs, next_rows = {}, {}
+        for w2 in EXTRA_CONFIGS + NEXT_ROWS:
+            dest = configs if w2 in EXTRA_CONFIGS else next_rows
             try:
                 ctx.lib.ah_pool_trim(ctx.handle)
                 W2 = build_workload(env, w2)
                 el2, prof2, out2 = run_timed(env, W2, args.config_steps, 2, False)
                 kern, avg_ms, launches, alg, workload, metric, dtype = describe(env, w2, W2, prof2, out2, args.config_steps)
                 ms2 = el2 / args.config_steps * 1e3
-                configs[w2] = {"workload": workload, "rows": W2["n"], "steps": args.config_steps,
-                               "ms": round(ms2, 4), "value": round(W2["n"] / (ms2 * 1e-3) / 1e6, 1), "unit": "Mrows/s",
-                               "dtype": dtype, "roofline": roofline_obj(kern, alg, avg_ms, launches),
-                               "kernel_avg_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof2.items()},
-                               "host_gap_ms": round(ms2 - sum(v[0] for v in prof2.values()) / args.config_steps, 4)}
+                dest[w2] = {"workload": workload, "rows": W2["n"], "steps": args.config_steps,
+                            "ms": round(ms2, 4), "value": round(W2["n"] / (ms2 * 1e-3) / 1e6, 1), "unit": "Mrows/s",
+                            "dtype": dtype, "roofline": roofline_obj(kern, alg, avg_ms, launches),
+                            "kernel_avg_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof2.items()},
+                            "host_gap_ms": round(ms2 - sum(v[0] for v in prof2.values()) / args.config_steps, 4)}
+                if w2 == "coalesce":  # ~430 small launches per step: the per-kernel HIP events themselves cost ~1 ms
+                    env.sync_all()
+                    t0 = time.perf_counter()
+                    for _ in range(args.config_steps):
+                        W2["step"](False)
+                    env.sync_all()
+                    ms3 = (time.perf_counter() - t0) / args.config_steps * 1e3
+                    dest[w2]["ms_without_kernel_events"] = round(ms3, 4)
+                    dest[w2]["frac_without_kernel_events"] = round(alg / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
                 W2 = out2 = None
             except Exception as ex:  # noqa: BLE001 - never lose the headline to a secondary config
-                configs[w2] = {"error": repr(ex)[:300]}
+                dest[w2] = {"error": repr(ex)[:300]}
         ctx.lib.ah_pool_trim(ctx.handle)
         line["configs"] = configs
+        line["next_rows"] = next_rows
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and wl == "filter_take":
