@@ -48,10 +48,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); ~6.
 # 6.3 TB/s is ~49 G line fills per second whatever the access pattern; a random gather spends one fill per 8-byte
 # value and one per validity byte.
 REQUEST_CEILING_G = 6300.0 / 128.0
-ALL_WORKLOADS = ["filter_take", "arith", "cmp", "cast", "cast_string", "coalesce", "string_filter_take", "aggregate",
+ALL_WORKLOADS = ["filter_take", "arith", "cmp", "cast", "cast_string", "coalesce", "string_filter_take", "predicate_filter", "aggregate",
                  "sort", "record_batch"]
 EXTRA_CONFIGS = ["arith", "cmp", "cast", "cast_string"]  # BASELINE configs[2] and [3], timed inside the default run
-NEXT_ROWS = ["coalesce", "record_batch", "string_filter_take"]  # SURVEY 8f rows 1 / 3 and configs[4]'s per-GPU shape, ditto
+NEXT_ROWS = ["coalesce", "record_batch", "string_filter_take", "predicate_filter"]  # SURVEY 8f rows 1 / 3 and configs[4]'s per-GPU shape, ditto
 
 
 def parse():
@@ -301,6 +301,7 @@ PMC_STEP_KERNELS = {
     "string_filter_take": r"filter_(scatter|count|count_small|group_scan|finish)\w*_kernel|range_scan_\w+_kernel|"
                           r"gather_bytes_kernel|take_ranges_kernel",
     "coalesce": r"filter_(scatter|count|count_small|group_scan|finish|finish_acc)\w*_kernel|copy_rows\w*_kernel|bm_acc_kernel",
+    "predicate_filter": r"compare_kernel|bitmap_op_kernel|filter_(scatter|count|count_small|group_scan|finish)\w*_kernel|popcount_partial_kernel",
 }
 PMC_CHILD_STEPS, PMC_CHILD_WARMUP = 2, 1
 
@@ -458,6 +459,21 @@ def build_workload(env, wl):
         W.update(step=step, dominant="string_gather_bytes",
                  kernels=["filter_count", "filter_scatter", "string_ranges_scan", "string_gather_bytes",
                           "string_take_ranges", "take_gather"])
+    elif wl == "predicate_filter":
+        # the predicate is BUILT on the device and consumed by filter without leaving it —
+        # WHERE a < 0 AND b >= 0: lt(a, scalar), gt_eq(b, scalar), and_kleene, filter(a, mask with nulls)
+        col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
+        colb = gen_f64_column(A, ctx, n, 52, args.valid, row0)
+        s0 = A.Scalar.new(0, A.Int64, ctx)
+        s1 = A.Scalar.new(0.0, A.Float64, ctx)
+
+        def step(_r):
+            m = K.and_kleene(K.lt(col, s0), K.gt_eq(colb, s1))
+            f = K.filter(col, m)
+            st["k"], st["fn"] = f.length, f.null_count()
+            return f
+
+        W.update(step=step, kernels=["compare", "boolean", "filter_count", "filter_scatter"], dominant="filter_scatter")
     elif wl == "aggregate":
         # sum + min + max of the Int64 column (three streaming reads per step)
         col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
@@ -533,6 +549,13 @@ def describe(env, wl, W, prof, out, steps):
         # two columns share one predicate: 2 x (values + validity) + mask in, 2 x (K values + K bits) out
         alg = 2 * (n * 8 + (n + 7) // 8) + (n + 7) // 8 + 2 * (k * 8 + (k + 7) // 8)
         dom_avg, dom_n = sum(prof[kk][0] for kk in kernels) / max(steps, 1), steps  # all launches of one step
+    elif wl == "predicate_filter":
+        k = st["k"]
+        wb = (n + 7) // 8
+        # two scalar compares (values + validity in, bits + validity out), and_kleene (4 bitmaps in, 2 out),
+        # filter (values + validity + mask + mask validity in, K values + K bits out)
+        alg = 2 * (n * 8 + wb + 2 * wb) + 6 * wb + (n * 8 + 3 * wb + k * 8 + (k + 7) // 8)
+        dom_avg, dom_n = sum(prof[kk][0] for kk in kernels) / max(steps, 1), steps  # all launches of one step
     elif wl == "record_batch":
         k = st["k"]  # ONE scatter launch for both columns: 2 x (values + validity) + the mask in, 2 x (K values + K bits) out
         alg = 2 * (n * 8 + (n + 7) // 8) + (n + 7) // 8 + 2 * (k * 8 + (k + 7) // 8)
@@ -555,6 +578,7 @@ def describe(env, wl, W, prof, out, steps):
             "sort": "arrow_ord sort_to_indices of a full-range Int64 column with NullBuffer (stable LSD radix)",
             "aggregate": "SURVEY 8f-4: sum + min + max of an Int64 column with NullBuffer",
             "string_filter_take": "SURVEY 8f-3: filter + take on a LargeUtf8 column (cast output)",
+            "predicate_filter": "SURVEY 8f-2: filter(a, and_kleene(lt(a, 0), gt_eq(b, 0.0))) on Int64 a, Float64 b with NullBuffers",
             "coalesce": f"SURVEY 8f-1: BatchCoalescer.push_batch_with_filter, Int64+Float64, "
                         f"{args.batch_rows}-row batches"
                         + (f", pushed {os.environ['AH_COALESCE_GROUP']} at a time (ah_coalescer_push_batches_with_filters)"
