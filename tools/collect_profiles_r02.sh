@@ -10,7 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- pyt
 for wl in arith cmp cast cast_string; do
   python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_$wl.json 2> $O/bench_$wl.err
 done
-for wl in coalesce string_filter_take; do  # roofline over ALL launches of a step, PMC traffic summed per step
+for wl in coalesce string_filter_take predicate_filter; do  # roofline over ALL launches of a step, PMC traffic summed per step
   python bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_$wl.json 2> $O/bench_$wl.err
 done
 for wl in record_batch aggregate; do

@@ -40,7 +40,7 @@ d = line_of("bench_default.json")
 if d:
     shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, "r02_bench_default.json"))
     rf, fs = d["roofline"], d.get("roofline_filter_scatter", {})
-    out.append("## The default line: `python bench.py --steps 20 --warmup 5` (configs[1] + configs[2] + configs[3])\n")
+    out.append("## The default line: `python bench.py --steps 20 --warmup 5` (configs[1] + configs[2] + configs[3] + the SURVEY 8f rows)\n")
     out.append(f"value **{d['value']} Mrows/s**, {d['ms_per_step']} ms per step, host_gap_ms {d['host_gap_ms']} "
                f"(step time minus its profiled kernels), kernels {d['kernel_avg_ms']}.\n")
     out.append("| kernel / config | avg ms | algorithmic GB per launch | GB/s | frac of 8 TB/s | PMC traffic GB per launch | traffic frac |")
@@ -57,6 +57,11 @@ if d:
     for k, v in d.get("configs", {}).items():
         if "roofline" in v:
             row(f"{v['roofline']['kernel']} ({k}: {v['rows']} rows, {v['ms']} ms per call)", v["roofline"])
+    for k, v in d.get("next_rows", {}).items():
+        if "roofline" in v:
+            extra_ms = f", {v['ms_without_kernel_events']} ms without per-kernel events" if "ms_without_kernel_events" in v else ""
+            row(f"{v['roofline']['kernel']} (next_rows.{k}: {v['rows']} rows, {v['ms']} ms per step{extra_ms}; all launches of a step)"
+                if k != "record_batch" else f"{v['roofline']['kernel']} (next_rows.{k}: {v['rows']} rows, {v['ms']} ms per call)", v["roofline"])
     if "requests" in rf:
         out.append(f"\ntake_gather in line fills: {rf['requests']}\n")
     out.append(f"take variants: sorted indices {d.get('take_sorted_indices_ms')} ms, 10 % null indices {d.get('take_null_indices_ms')} ms.\n")
@@ -82,7 +87,7 @@ out.append("## Per-workload lines with in-run PMC traffic\n")
 out.append("| workload | ms per call (without per-kernel events) | roofline kernel | frac | traffic_frac | PMC traffic per launch / step (GB) | host_gap_ms |")
 out.append("|---|---|---|---|---|---|---|")
 traffic = {}
-for wl in ["arith", "cmp", "cast", "cast_string", "coalesce", "record_batch", "string_filter_take", "aggregate"]:
+for wl in ["arith", "cmp", "cast", "cast_string", "coalesce", "record_batch", "string_filter_take", "predicate_filter", "aggregate"]:
     d2 = line_of(f"bench_{wl}.json")
     if not d2:
         continue
