@@ -56,6 +56,7 @@ struct ah_coalescer {
   std::deque<CoBatch> completed;
   uint64_t* acc = nullptr;  // device: appended-null count per column of the in-progress batch
   double selectivity = 0.1;  // of the last filtered push: picks the speculative scatter's load-predication mode
+  bool failed = false;       // a device error hit after rows had been enqueued into the in-progress batch
 };
 
 namespace {
@@ -114,6 +115,7 @@ ah_status copy_rows_all(ah_context* ctx, ah_coalescer* co, const ah_array_view* 
 }
 
 ah_status check_columns(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns, int64_t num_rows) {
+  if (co->failed) return ah_fail(ctx, AH_INVALID_ARGUMENT, "BatchCoalescer: unusable after an earlier device error");
   for (int i = 0; i < co->ncols; ++i) {
     if (columns[i].type != co->cols[i].type)
       return ah_fail(ctx, AH_INVALID_ARGUMENT, "column %d has type %s, the coalescer expects %s", i,
@@ -395,6 +397,9 @@ extern "C" ah_status ah_coalescer_push_batch_with_filter(ah_context* ctx, ah_coa
     }
     if (st == AH_OK) st = push_filtered_impl(ctx, co, columns, num_rows, filter, p, tag, bypassed, done0);
   }
+  // the speculative scatter may have written rows (and validity bits) past `buffered_rows` that the bookkeeping
+  // never accounted for: the in-progress batch cannot be trusted any more
+  if (st != AH_OK && speculated) co->failed = true;
   ah_filter_predicate_free(ctx, p);
   return st;
 }
