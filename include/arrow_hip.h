@@ -256,7 +256,11 @@ AH_API ah_status ah_read_words(ah_context* ctx, uint64_t* dev_words, int32_t n, 
  * comes back from ah_coalescer_next_completed_batch when that very batch was passed through untouched (large-batch
  * bypass; the push sets *bypassed = 1 so the caller knows to keep that batch alive): its outs are AH_OUT_BORROWED views of the
  * caller's buffers.  Other column types: AH_NOT_YET_IMPLEMENTED
- * (the host falls back to buffer-and-concat, coalesce/generic.rs). */
+ * (the host falls back to buffer-and-concat, coalesce/generic.rs).
+ * Input lifetime: a push returns while its copies / scatters may still be running on the context's stream.  Buffers
+ * that came from this context's allocator may be released at once (releases are stream-ordered); buffers the host
+ * allocated itself must stay alive until the stream has passed them (the next finished batch's wait, or
+ * ah_context_synchronize). */
 typedef struct ah_coalescer ah_coalescer;
 AH_API ah_status ah_coalescer_create(ah_context* ctx, int32_t n_columns, const ah_type* types, int64_t target_batch_size,
                                      ah_coalescer** out);
