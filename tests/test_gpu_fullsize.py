@@ -27,7 +27,18 @@ from arrow_rs_amd.array import _copy_dtoh
 import bench as B
 import orc
 
-pytestmark = pytest.mark.gpu
+def _host_memory_ok():
+    """The oracle side holds the 8 GB column, its filtered parts and per-chunk scratch on the host (~25 GB at the peak):
+    on a box that cannot hold that, skipping beats an out-of-memory kill of the whole test run."""
+    try:
+        import psutil
+        return psutil.virtual_memory().available >= 48 * 2**30
+    except Exception:  # noqa: BLE001 - no psutil: assume the pool's standard box
+        return True
+
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not _host_memory_ok(), reason="full-size parity needs ~48 GB of free host memory")]
 
 CH = 1 << 24  # rows per oracle chunk (a multiple of 64: bitmaps split on word boundaries)
 NT = max(4, min(64, (os.cpu_count() or 8) - 2))
