@@ -368,11 +368,15 @@ extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_a
     return AH_OK;
   }
   int64_t set_bits = len;
+  // The validity union (+ its popcount read-back) is one host wait.  Checked ops need the union BEFORE the value
+  // kernel (it only evaluates valid slots); unchecked ops do not, so their value kernel is enqueued first and the
+  // union's read-back is the call's ONE wait (it used to be two, with the GPU idle between them).
+  const bool union_first = checked;
   if (want_valid) {
     ah_status st = ah_out_alloc(ctx, bbytes, &ob);
-    if (st == AH_OK)
+    if (st == AH_OK && union_first)
       st = ah_bitmap_op(ctx, (va.words && vb.words) ? BM_AND : BM_COPY, va.words ? va : vb, vb,
-                        BitView{nullptr, 0}, len, (unsigned long long*)ob, checked ? &set_bits : AH_COUNT(ctx, &set_bits));
+                        BitView{nullptr, 0}, len, (unsigned long long*)ob, &set_bits);
     if (st != AH_OK) {
       free_out_bufs(ctx, ov, vbytes, ob, bbytes);
       return st;
@@ -405,10 +409,17 @@ extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_a
     st = dispatch_type(ctx, t, op, a, aligned);
   }
   hipError_t e = hipGetLastError();
+  bool waited = false;
+  if (st == AH_OK && e == hipSuccess && want_valid && !union_first) {
+    int64_t* cnt = AH_COUNT(ctx, &set_bits);
+    st = ah_bitmap_op(ctx, (va.words && vb.words) ? BM_AND : BM_COPY, va.words ? va : vb, vb, BitView{nullptr, 0}, len,
+                      (unsigned long long*)ob, cnt);
+    waited = st == AH_OK && cnt != nullptr;  // the popcount read-back waited for the whole stream
+  }
   if (st == AH_OK && e == hipSuccess && checked)
     e = ah_d2h(ctx, ctx->pinned, first_err, 8);
   // checked ops report device-side errors, so they stay synchronous even in deferred mode
-  if (e == hipSuccess) e = checked ? ah_stream_wait(ctx) : ah_end_of_call_sync(ctx);
+  if (e == hipSuccess && !waited) e = checked ? ah_stream_wait(ctx) : ah_end_of_call_sync(ctx);
   ah_pool_free(ctx, first_err);
   if (st != AH_OK || e != hipSuccess) {
     free_out_bufs(ctx, ov, vbytes, ob, bbytes);

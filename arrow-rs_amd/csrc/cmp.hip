@@ -370,7 +370,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
   const BitView none{nullptr, 0};
   int64_t set_bits = len;
   bool count_known = !ctx->deferred;  // deferred: only the all-null results know their count
-  bool has_nb = false;
+  bool has_nb = false, waited = false;
   ah_status st = AH_OK;
 
   if (lnul && rnul && l_s == r_s) {
@@ -387,6 +387,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
       st = run_values(vals);
       if (st == AH_OK) st = ah_out_alloc(ctx, bytes, (void**)&nb);
       if (st == AH_OK) st = ah_bitmap_op(ctx, BM_AND, lv, rv, none, len, nb, AH_COUNT(ctx, &set_bits));
+      waited = st == AH_OK && !ctx->deferred;  // the popcount read-back waited for the stream: it ends the call
       has_nb = true;
     }
   } else if (lnul && rnul) {
@@ -434,6 +435,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
       st = run_values(vals);
       if (st == AH_OK) st = ah_out_alloc(ctx, bytes, (void**)&nb);
       if (st == AH_OK) st = ah_bitmap_op(ctx, BM_COPY, nv, none, none, len, nb, AH_COUNT(ctx, &set_bits));
+      waited = st == AH_OK && !ctx->deferred;
       has_nb = true;
     }
   } else {
@@ -442,7 +444,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
   (void)need_values;
   if (st != AH_OK) return fail_free(st);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = ah_end_of_call_sync(ctx);
+  if (e == hipSuccess && !waited) e = ah_end_of_call_sync(ctx);
   if (e != hipSuccess) {
     fail_free(AH_HIP_ERROR);
     return ah_fail(ctx, AH_HIP_ERROR, "compare kernel failed: %s", hipGetErrorString(e));
