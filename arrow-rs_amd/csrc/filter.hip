@@ -256,8 +256,10 @@ template <> struct Elem<1> { using type = uint8_t; };
 template <> struct Elem<2> { using type = uint16_t; };
 template <> struct Elem<4> { using type = uint32_t; };
 template <> struct Elem<8> { using type = uint64_t; };
-struct alignas(16) E16 { uint32_t x, y, z, w; };
-struct alignas(16) E32 { E16 a, b; };
+// 16- and 32-byte natives as clang vector types: first-class values the optimizer keeps in registers (as structs of
+// four dwords the per-thread arrays of them stayed in scratch: 144 bytes per thread in the Decimal128 / i256 variants)
+typedef uint32_t E16 __attribute__((ext_vector_type(4)));
+typedef uint32_t E32 __attribute__((ext_vector_type(8), aligned(16)));  // i256 buffers are only 16-byte aligned
 template <> struct Elem<16> { using type = E16; };
 template <> struct Elem<32> { using type = E32; };
 
