@@ -79,6 +79,12 @@ class ArrayOut(C.Structure):
     ]
 
 
+class FilterTerm(C.Structure):
+    """ah_filter_term"""
+    _fields_ = [("op", C.c_int32), ("lhs", C.POINTER(ArrayView)), ("lhs_is_scalar", C.c_int32), ("rhs", C.POINTER(ArrayView)),
+                ("rhs_is_scalar", C.c_int32)]
+
+
 class Scalar(C.Structure):
     """ah_scalar / orc_scalar (identical layout)."""
     _fields_ = [("type", C.c_int32), ("is_valid", C.c_int32), ("bytes", C.c_uint8 * 32)]
@@ -137,6 +143,7 @@ _P = C.c_void_p
 _VIEW = C.POINTER(ArrayView)
 _OUT = C.POINTER(ArrayOut)
 SIGNATURES = {
+    "ah_device_count": (C.c_int32, []),
     "ah_context_create": (C.c_int32, [C.c_int, C.POINTER(_P)]),
     "ah_context_destroy": (None, [_P]),
     "ah_context_set_allocator": (None, [_P, ALLOC_FN, FREE_FN, _P]),
@@ -158,6 +165,7 @@ SIGNATURES = {
     "ah_pool_trim": (None, [_P]),
     "ah_filter": (C.c_int32, [_P, _VIEW, _VIEW, _OUT]),
     "ah_filter_predicate_build": (C.c_int32, [_P, _VIEW, C.POINTER(_P)]),
+    "ah_filter_predicate_build_expr": (C.c_int32, [_P, C.c_int32, C.POINTER(FilterTerm), C.POINTER(C.c_int32), C.POINTER(_P)]),
     "ah_filter_predicate_count": (C.c_int64, [_P]),
     "ah_filter_predicate_apply": (C.c_int32, [_P, _P, _VIEW, _OUT]),
     "ah_filter_predicate_free": (None, [_P, _P]),
@@ -204,6 +212,8 @@ SIGNATURES = {
     "ah_comm_allreduce_max_f64": (C.c_int32, [_P, _P, C.POINTER(C.c_double), C.c_int32]),
     "ah_all_gatherv": (C.c_int32, [_P, _P, _VIEW, _OUT, C.POINTER(ExchangeStats)]),
     "ah_all_gather_columns": (C.c_int32, [_P, _P, C.c_int32, _VIEW, _OUT, C.POINTER(ExchangeStats)]),
+    "ah_all_gather_columns_begin": (C.c_int32, [_P, _P, C.c_int32, _VIEW, C.POINTER(_P)]),
+    "ah_all_gather_columns_end": (C.c_int32, [_P, _P, _P, _OUT, C.POINTER(ExchangeStats)]),
     "ah_bitmap_concat": (C.c_int32, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P,
                                      C.POINTER(C.c_int64)]),
     "ah_count_set_bits": (C.c_int32, [_P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]),

@@ -9,6 +9,10 @@ from ... import _lib as L
 from ...array import Array, Boolean, RecordBatch, InvalidArgumentError
 
 
+_CMP_OPS = {"eq": 0, "neq": 1, "lt": 2, "lt_eq": 3, "gt": 4, "gt_eq": 5}
+_JOIN_OPS = {"and": 0, "or": 1, "and_kleene": 3, "or_kleene": 4}
+
+
 def _check_predicate(predicate):
     if predicate.data_type != Boolean:
         raise InvalidArgumentError(f"filter predicate must be Boolean, got {predicate.data_type}")
@@ -80,7 +84,42 @@ class FilterBuilder:
     def is_optimize_beneficial(data_type):
         return False  # only Struct / sparse Union in the reference (filter.rs:304-314)
 
+    @classmethod
+    def from_terms(cls, terms, joins=()):
+        """The lazy predicate (``ah_filter_predicate_build_expr``): ``terms`` = [(op, lhs, rhs), ...] with ``op`` one of
+        "eq" "neq" "lt" "lt_eq" "gt" "gt_eq" and lhs / rhs Datums (Array or Scalar); ``joins`` = "and" | "or" |
+        "and_kleene" | "or_kleene" between consecutive terms, folded left to right.  Result-identical to
+        ``FilterBuilder::new(&and_kleene(&lt(..)?, &gt_eq(..)?)?)`` (cmp.rs:113-164, boolean.rs:60-300, filter.rs:256-273)
+        with the comparisons evaluated inside the filter's count pass instead of being materialised."""
+        self = cls.__new__(cls)
+        self._predicate = None
+        self._terms = [(_CMP_OPS[op] if isinstance(op, str) else int(op), lhs, rhs) for op, lhs, rhs in terms]
+        self._joins = [_JOIN_OPS[j] if isinstance(j, str) else int(j) for j in joins]
+        if len(self._joins) != max(len(self._terms) - 1, 0):
+            raise InvalidArgumentError("a filter expression of n terms takes n - 1 joins")
+        return self
+
+    def _build_expr(self):
+        n = len(self._terms)
+        arr = (L.FilterTerm * max(n, 1))()
+        keep = []
+        ctx = None
+        for i, (op, lhs, rhs) in enumerate(self._terms):
+            l, l_s = lhs.get()
+            r, r_s = rhs.get()
+            ctx = ctx or l.ctx
+            lv, rv = l.view(), r.view()
+            keep += [l, r, lv, rv]
+            arr[i].op, arr[i].lhs, arr[i].lhs_is_scalar = op, C.pointer(lv), int(l_s)
+            arr[i].rhs, arr[i].rhs_is_scalar = C.pointer(rv), int(r_s)
+        joins = (C.c_int32 * max(len(self._joins), 1))(*self._joins)
+        h = C.c_void_p()
+        ctx.check(ctx.lib.ah_filter_predicate_build_expr(ctx.handle, n, arr, joins, C.byref(h)))
+        return FilterPredicate(ctx, h, None)  # the operand buffers are only read during the call
+
     def build(self):
+        if self._predicate is None:
+            return self._build_expr()
         ctx = self._predicate.ctx
         h = C.c_void_p()
         pv = self._predicate.view()

@@ -64,6 +64,11 @@ struct ah_context {
   std::vector<hipEvent_t> event_pool;  // recycled profiling events
   // deferred mode (ah_context_set_deferred): infallible fixed-shape kernels skip the end-of-call sync
   bool deferred = false;
+  // "unwaited work in flight": set by every entry point that returns while its kernels may still be reading the
+  // caller's buffers (the *_acc forms, the coalescer's pushes, ah_all_gather_columns_begin); cleared by any successful
+  // host wait on the stream.  ah_out_free drains the stream before a HOST-allocator free while it is set (the host's
+  // free is not stream-ordered).
+  bool inflight = false;
   // profiling
   bool profiling = false;
   std::map<std::string, ah_prof_entry> prof;
@@ -322,6 +327,43 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
 __device__ __forceinline__ void ah_mail_post(uint64_t* mail, uint64_t seq) {
   __threadfence_system();
   __hip_atomic_store(mail + AH_MAIL_FLAG, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Once-read / once-written streams: `ah_ld_stream` / `ah_st_stream` are plain vector accesses, or
+// the non-temporal forms (`global_load ... nt` / `global_store ... nt`) when the library is built with -DAH_NT_LOADS=1 /
+// -DAH_NT_STORES=1.  The A/B over the four streaming kernels is profiles/r03_nt_ablation.md; the default build keeps what won.
+#ifndef AH_NT_LOADS
+#define AH_NT_LOADS 0
+#endif
+#ifndef AH_NT_STORES
+#define AH_NT_STORES 0
+#endif
+template <int BYTES> struct ah_raw_vec;
+template <> struct ah_raw_vec<1> { typedef uint8_t type; };
+template <> struct ah_raw_vec<2> { typedef uint16_t type; };
+template <> struct ah_raw_vec<4> { typedef uint32_t type; };
+template <> struct ah_raw_vec<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct ah_raw_vec<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <typename VT> __device__ __forceinline__ VT ah_ld_stream(const VT* p) {
+  if constexpr (AH_NT_LOADS && (sizeof(VT) == 1 || sizeof(VT) == 2 || sizeof(VT) == 4 || sizeof(VT) == 8 || sizeof(VT) == 16)) {
+    using R = typename ah_raw_vec<sizeof(VT)>::type;
+    const R x = __builtin_nontemporal_load((const R*)p);
+    VT r;
+    __builtin_memcpy(&r, &x, sizeof(VT));
+    return r;
+  } else {
+    return *p;
+  }
+}
+template <typename VT> __device__ __forceinline__ void ah_st_stream(VT* p, const VT& v) {
+  if constexpr (AH_NT_STORES && (sizeof(VT) == 1 || sizeof(VT) == 2 || sizeof(VT) == 4 || sizeof(VT) == 8 || sizeof(VT) == 16)) {
+    using R = typename ah_raw_vec<sizeof(VT)>::type;
+    R x;
+    __builtin_memcpy(&x, &v, sizeof(VT));
+    __builtin_nontemporal_store(x, (R*)p);
+  } else {
+    *p = v;
+  }
 }
 
 // ---- shared bitmap machinery (bitmap.hip)

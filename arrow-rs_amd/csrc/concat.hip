@@ -249,6 +249,7 @@ extern "C" ah_status ah_copy_rows_into_acc(ah_context* ctx, const ah_array_view*
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "copy_rows range [%lld, %lld) exceeds source length %lld",
                    (long long)offset, (long long)(offset + len), (long long)src->length);
   if (len == 0) return AH_OK;
+  ctx->inflight = true;
   ah_prof_scope ps(ctx, "copy_rows");
   AH_HIP(ctx, hipMemcpyAsync((char*)dst_values + (size_t)dst_row_offset * w,
                              (const char*)src->values + (size_t)offset * w, (size_t)len * w,

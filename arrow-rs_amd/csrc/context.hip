@@ -160,9 +160,9 @@ void ah_out_free(ah_context* ctx, void* p, size_t bytes) {
   if (hk != ctx->hook_live.end()) {
     const ah_context::hook_entry e = hk->second;  // freed by the allocator that made it, even if the hook changed since
     ctx->hook_live.erase(hk);
-    // the host's free is not stream-ordered: in deferred mode kernels that still use the buffer may be in flight
-    // (synchronous calls finished theirs before returning), so drain the stream before handing the memory back
-    if (ctx->deferred) (void)ah_stream_wait(ctx);
+    // the host's free is not stream-ordered: in deferred mode, or after a no-wait call (ctx->inflight), kernels that
+    // still use the buffer may be in flight, so drain the stream before handing the memory back
+    if (ctx->deferred || ctx->inflight) (void)ah_stream_wait(ctx);
     if (e.free_) e.free_(e.user, p, bytes);
     return;
   }
@@ -197,12 +197,16 @@ hipError_t ah_mail_wait(ah_context* ctx, uint64_t seq) {
   if (ctx->wait_mode == 1) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) < seq) e = hipErrorUnknown;
+    if (e == hipSuccess) ctx->inflight = false;
     return e;
   }
   timespec t0;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   for (uint64_t spins = 1;; ++spins) {
-    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq) return hipSuccess;
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq) {
+      ctx->inflight = false;  // the stream has passed everything enqueued before the posting kernel
+      return hipSuccess;
+    }
     cpu_relax();
     if ((spins & 4095) == 0) {
       timespec t1;
@@ -210,7 +214,10 @@ hipError_t ah_mail_wait(ah_context* ctx, uint64_t seq) {
       const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
       if (us > 20000.0) {  // a long kernel, or a fault that will never post: ask the runtime
         hipError_t q = hipStreamQuery(ctx->stream);
-        if (q == hipSuccess) return __atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq ? hipSuccess : hipErrorUnknown;
+        if (q == hipSuccess) {
+          ctx->inflight = false;
+          return __atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq ? hipSuccess : hipErrorUnknown;
+        }
         if (q != hipErrorNotReady) return q;
         if (us > 500000.0) {  // half a second of spinning: sleep in the runtime instead
           hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -236,7 +243,11 @@ hipError_t ah_d2h(ah_context* ctx, void* pinned_dst, const void* dev_src, size_t
 }
 
 hipError_t ah_stream_wait(ah_context* ctx) {
-  if (ctx->wait_mode == 1) return hipStreamSynchronize(ctx->stream);
+  if (ctx->wait_mode == 1) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) ctx->inflight = false;
+    return e;
+  }
   const uint64_t seq = ah_mail_next(ctx);
   mail_kernel<<<1, 64, 0, ctx->stream>>>(nullptr, 0, ctx->pinned_dev, ctx->pinned_dev, seq, 0, 0);
   hipError_t e = hipGetLastError();
@@ -259,6 +270,11 @@ hipError_t ah_d2h_wait(ah_context* ctx, void* pinned_dst, const void* dev_src, s
 }
 
 // ---------------------------------------------------------------- context
+extern "C" int32_t ah_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0;
+}
+
 extern "C" ah_status ah_context_create(int device, ah_context** out) {
   if (!out) return AH_INVALID_ARGUMENT;
   *out = nullptr;
@@ -395,6 +411,7 @@ extern "C" ah_status ah_memset(ah_context* ctx, void* dst, int value, size_t byt
 extern "C" ah_status ah_synchronize(ah_context* ctx) {
   ah_ctx_guard _guard(ctx);
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->inflight = false;
   return AH_OK;
 }
 

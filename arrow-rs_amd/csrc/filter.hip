@@ -36,6 +36,7 @@
 //                            per tile) -> null_count without a reduce pass.
 // Values are read at most once; the mask twice (1.4% of the bytes at Int64).
 #include "common.hpp"
+#include "filter_internal.hpp"
 
 namespace {
 
@@ -363,7 +364,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       int64_t r = row0 + (int64_t)(l * SCATTER_THREADS + t) * V;
-      if (r < a.len) regs[l] = *(const Vec<WE, V>*)(vp + r);
+      if (r < a.len) regs[l] = ah_ld_stream((const Vec<WE, V>*)(vp + r));
     }
   }
 
@@ -414,7 +415,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
     for (int l = 0; l < L; ++l) {
       int r0 = (l * SCATTER_THREADS + t) * V;
       uint32_t bits = (uint32_t)(s_m[r0 >> 6] >> (r0 & 63)) & VMASK;
-      if (bits) regs[l] = *(const Vec<WE, V>*)(vp + row0 + r0);
+      if (bits) regs[l] = ah_ld_stream((const Vec<WE, V>*)(vp + row0 + r0));
     }
   }
 
@@ -460,7 +461,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
         ET* gbase = op - phase;                               // 16-byte aligned
         if (vfirst < vlast) {
           for (int j = vfirst + t; j < vlast; j += SCATTER_THREADS)
-            *(Vec<WE, EPV>*)(gbase + j * EPV) = *(const Vec<WE, EPV>*)(s_vals + j * EPV);
+            ah_st_stream((Vec<WE, EPV>*)(gbase + j * EPV), *(const Vec<WE, EPV>*)(s_vals + j * EPV));
           if (t < vfirst * EPV - first) gbase[first + t] = s_vals[first + t];
           if (t < last - vlast * EPV) gbase[vlast * EPV + t] = s_vals[vlast * EPV + t];
         } else {
@@ -549,18 +550,13 @@ bool use_skip(int64_t count, int64_t len) {
 
 }  // namespace
 
-// FilterPredicate (filter.rs:442-449): predicate bits (borrowed), count and the
-// device-resident prefix tables that replace IterationStrategy::Indices.
-struct ah_filter_predicate {
-  BitView mask, mask_valid;
-  int64_t len = 0;
-  int64_t count = 0;
-  uint32_t* chunk_prefix = nullptr;
-  unsigned long long* group_prefix = nullptr;
-  int group_shift = 10;
-  void* block = nullptr;  // single pool allocation backing the tables
-  unsigned long long* total_dev = nullptr;  // K on the device (kernels that run before the host has read it)
-};
+// (struct ah_filter_predicate: filter_internal.hpp)
+
+// K2 for filter_expr.hip's own count pass
+void ah_filter_launch_group_scan(ah_context* ctx, const uint32_t* group_total, int64_t ngroups, unsigned long long* group_prefix,
+                                 unsigned long long* total, int slot, uint64_t seq) {
+  filter_group_scan_kernel<<<1, 1024, 0, ctx->stream>>>(group_total, ngroups, group_prefix, total, ctx->pinned_dev + slot, seq);
+}
 
 // The count pass of a predicate, enqueued only: K lands in pinned slot `slot` (and, with seq != 0, the mailbox is
 // posted).  `*enqueued` = false when there was nothing to launch (empty predicate: count 0).
@@ -1023,6 +1019,7 @@ static ah_status apply_into_impl(ah_context* ctx, const ah_filter_predicate* p, 
   if (e == hipSuccess && !has_valid)  // source without nulls: the appended rows are all valid
     st = ah_bitmap_set_bits(ctx, dst_validity, dst_row_offset, nullptr, 0, K, nullptr);
   if (no_wait) {  // the null count accumulates on the device; the caller reads it when the batch is finished
+    ctx->inflight = true;
     if (e == hipSuccess && has_valid) {
       filter_finish_acc_kernel<<<1, 64, 0, ctx->stream>>>(slots, (unsigned long long)K, nulls_acc);
       e = hipGetLastError();
@@ -1088,6 +1085,7 @@ ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predica
     m.out_valid = (unsigned long long*)dst_validity[c];
     m.valid_slots = slots + (size_t)c * 64;
   }
+  ctx->inflight = true;
   {
     ah_prof_scope ps(ctx, "filter_scatter");
     const bool skip = speculative ? use_skip((int64_t)(selectivity_hint * (double)p->len), p->len) : use_skip(p->count, p->len);

@@ -1,0 +1,448 @@
+// filter_expr.hip — the lazily evaluated predicate: compare -> (Kleene) and / or -> filter with the comparison
+// evaluated INSIDE the filter's count pass.
+//
+// Reference call shape (what an engine writes for `WHERE a < 0 AND b >= 0.0`):
+//     let m = and_kleene(&lt(&a, &zero)?, &gt_eq(&b, &zero_f)?)?;      arrow-ord/src/cmp.rs:113,164 -> compare_op :220-382
+//     filter(&a, &m)                                                    arrow-arith/src/boolean.rs:60-300; filter.rs:201
+// i.e. two compare passes that write bitmaps (collect_bool, cmp.rs:580-611), one bitmap pass, and the filter's own
+// count pass that reads them back (FilterBuilder::new, filter.rs:256-273: `prep_null_mask_filter` = values AND
+// validity, then true_count).  Five launches and ~27.5 GB for 1e9 rows here.
+//
+// MI355X design: the predicate is handed over as TERMS (op, lhs, rhs | scalar) joined left to right.  ONE kernel
+// streams the operand columns with 16-byte loads (two rows per lane), turns every comparison into wave ballots —
+// the ballot IS the predicate word (north_star: "__ballot(pred)") — folds the terms' (value, validity) word pairs on
+// the scalar unit with exactly the reference's bit formulas (so nulls propagate identically, including the Kleene
+// cases), ANDs value and validity (filter.rs:167-171: a null predicate row selects nothing), stores the 1-bit-per-row
+// selection words and the per-1024-row-chunk prefix counts.  From there on it is an ordinary ah_filter_predicate: the
+// scatter kernels read the selection words like any materialised mask (0.125 B per row).  Per row the predicate
+// side costs the operand bytes once and one bit, instead of operand bytes + 2 x (2 bits written + 2 bits read back)
+// + 4 bits read + 2 written + 2 read.
+//
+// Operand types: the integer types and Float32 / Float64 (IEEE totalOrder, equality = bit equality,
+// arrow-array/src/arithmetic.rs:400-410).  Ops: eq, neq, lt, lt_eq, gt, gt_eq.  Joins: and, or, and_kleene, or_kleene.
+#include "common.hpp"
+#include "filter_internal.hpp"
+
+namespace {
+
+constexpr int EXPR_MAX_TERMS = 4;
+constexpr int GROUP_CHUNKS_E = 64;  // chunks per workgroup = per count group (group_shift 6)
+constexpr int HALF_STEPS = 4;       // wave steps (128 rows each) whose loads are in flight together
+
+struct ExprTerm {
+  const void* l;
+  const void* r;
+  BitView lv, rv;  // validity; words == nullptr: all valid
+  int width;       // 1, 2, 4, 8
+  int kind;        // 0 signed, 1 unsigned, 2 float
+  int op;          // AH_EQ .. AH_GT_EQ
+  int l_scalar, r_scalar;
+  int l_vec, r_vec;  // operand pointer is aligned for a 2-element vector load
+};
+struct ExprArgs {
+  ExprTerm t[EXPR_MAX_TERMS];
+  int nterms;
+  int join[EXPR_MAX_TERMS - 1];
+  int64_t len;
+  unsigned long long* mask_out;
+  uint32_t* chunk_prefix;
+  uint32_t* group_total;
+};
+
+__device__ __forceinline__ uint64_t spread2(uint64_t x) {  // bit p of the low 32 -> bit 2p
+  x &= 0xFFFFFFFFull;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+
+// raw little-endian element -> a signed 64-bit key whose signed order is the type's order (floats: totalOrder)
+template <int W> __device__ __forceinline__ int64_t to_key(uint64_t raw, int kind) {
+  if constexpr (W == 8) {
+    if (kind == 1) return (int64_t)(raw ^ 0x8000000000000000ull);
+    const int64_t b = (int64_t)raw;
+    return kind == 2 ? (b ^ (int64_t)((uint64_t)(b >> 63) >> 1)) : b;
+  } else if constexpr (W == 4) {
+    if (kind == 1) return (int64_t)(uint32_t)raw;
+    const int32_t b = (int32_t)(uint32_t)raw;
+    return kind == 2 ? (int64_t)(b ^ (int32_t)((uint32_t)(b >> 31) >> 1)) : (int64_t)b;
+  } else if constexpr (W == 2) {
+    return kind == 1 ? (int64_t)(uint16_t)raw : (int64_t)(int16_t)(uint16_t)raw;
+  } else {
+    return kind == 1 ? (int64_t)(uint8_t)raw : (int64_t)(int8_t)(uint8_t)raw;
+  }
+}
+
+template <int W> struct RawT;
+template <> struct RawT<1> { using type = uint8_t; };
+template <> struct RawT<2> { using type = uint16_t; };
+template <> struct RawT<4> { using type = uint32_t; };
+template <> struct RawT<8> { using type = uint64_t; };
+template <int W> struct alignas(2 * W) Pair { typename RawT<W>::type e[2]; };
+
+// the two rows a lane owns (row, row + 1; row even): raw elements.  Rows at or past `len` re-read an in-range
+// element (their bits are masked off later): no branch between the loads of a step.
+template <int W> __device__ __forceinline__ void load_pair(const void* base, int64_t row, int64_t len, bool scalar, bool vec,
+                                                           uint64_t& x0, uint64_t& x1) {
+  using R = typename RawT<W>::type;
+  const R* p = (const R*)base;
+  if (scalar) {
+    x0 = x1 = (uint64_t)p[0];
+    return;
+  }
+  if (vec) {  // len >= 2 (host): the last aligned pair is always in range
+    const int64_t rc = row + 1 < len ? row : ((len - 2) & ~1ll);
+    const Pair<W> v = *(const Pair<W>*)(p + rc);
+    x0 = (uint64_t)v.e[0];
+    x1 = (uint64_t)v.e[1];
+  } else {
+    const int64_t r0 = row < len ? row : len - 1, r1 = row + 1 < len ? row + 1 : len - 1;
+    x0 = (uint64_t)p[r0];
+    x1 = (uint64_t)p[r1];
+  }
+}
+__device__ __forceinline__ void load_pair_w(int width, const void* base, int64_t row, int64_t len, bool scalar, bool vec,
+                                            uint64_t& x0, uint64_t& x1) {
+  switch (width) {  // wave-uniform
+    case 8: load_pair<8>(base, row, len, scalar, vec, x0, x1); break;
+    case 4: load_pair<4>(base, row, len, scalar, vec, x0, x1); break;
+    case 2: load_pair<2>(base, row, len, scalar, vec, x0, x1); break;
+    default: load_pair<1>(base, row, len, scalar, vec, x0, x1); break;
+  }
+}
+__device__ __forceinline__ int64_t key_w(int width, uint64_t raw, int kind) {
+  switch (width) {
+    case 8: return to_key<8>(raw, kind);
+    case 4: return to_key<4>(raw, kind);
+    case 2: return to_key<2>(raw, kind);
+    default: return to_key<1>(raw, kind);
+  }
+}
+
+
+
+// branch-free comparison: op as three wave-uniform masks over (lt, eq, gt)
+struct OpMask { bool lt, eq, gt; };
+__device__ __forceinline__ OpMask op_mask(int op) {
+  OpMask m;
+  m.lt = op == AH_LT || op == AH_LT_EQ || op == AH_NEQ;
+  m.eq = op == AH_EQ || op == AH_LT_EQ || op == AH_GT_EQ;
+  m.gt = op == AH_GT || op == AH_GT_EQ || op == AH_NEQ;
+  return m;
+}
+__device__ __forceinline__ bool cmp_masked(const OpMask& m, int64_t a, int64_t b) {
+  const int lt = a < b, eq = a == b;  // bitwise on purpose: `&&` / `||` become branches around the ballots
+  return ((lt & (int)m.lt) | (eq & (int)m.eq) | (((lt | eq) ^ 1) & (int)m.gt)) != 0;
+}
+// branch-free key of the fast path (FW = 8 or 4): kind is wave-uniform, selected with v_cndmask
+template <int W> __device__ __forceinline__ int64_t fast_key(uint64_t raw, int kind) {
+  if constexpr (W == 8) {
+    const int64_t b = (int64_t)raw;
+    const int64_t f = b ^ (int64_t)((uint64_t)(b >> 63) >> 1);
+    const int64_t u = (int64_t)(raw ^ 0x8000000000000000ull);
+    return kind == 2 ? f : (kind == 1 ? u : b);
+  } else {
+    const int32_t b = (int32_t)(uint32_t)raw;
+    const int64_t f = (int64_t)(b ^ (int32_t)((uint32_t)(b >> 31) >> 1));
+    const int64_t u = (int64_t)(uint32_t)raw;
+    return kind == 2 ? f : (kind == 1 ? u : (int64_t)b);
+  }
+}
+
+// (the first version of this kernel fetched validity words per step with inlined bv_fetch64's: 16 K instructions, past
+// the instruction cache, 3.6 TB/s.  Validity is now read once per chunk, 16 words at a time in lanes 0..15.)
+__device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// One workgroup = 64 chunks (65 536 rows); in iteration `it` wave w owns chunk it * 4 + w: 8 wave steps of 128 rows,
+// lane l of a step owning rows 2l and 2l + 1 (one 16-byte load per 8-byte operand).  Per step and term: 2 ballots ->
+// 2 value words (bit-interleaved on the scalar unit); the terms' validity words are folded once per chunk, 16 words at
+// a time in lanes 0..15.
+// FW != 0: the fast instantiation — every term compares FW-byte operands, every array operand pointer is aligned for a
+// two-element vector load, and (RS) every right-hand side is a scalar: the loads of four steps are unconditional vector
+// loads issued back to back and the comparison is branch-free.  FW == 0: any mix of widths / alignments / scalar sides,
+// dispatched per term at run time (correct, not tuned).
+template <int NT, int FW, bool RS>
+__global__ void __launch_bounds__(256) filter_expr_count_kernel(ExprArgs a) {
+  constexpr int HS = FW ? HALF_STEPS : 1;  // steps whose loads are in flight together
+  constexpr int NH = 8 / HS;
+  __shared__ uint32_t s_cnt[GROUP_CHUNKS_E];
+  __shared__ uint64_t s_val[4][NT][16];  // per wave: the value words of the chunk's terms
+  const int t = threadIdx.x, lane = t & 63, wave = ah_uniform(t >> 6);
+  const int64_t chunk_base = (int64_t)blockIdx.x * GROUP_CHUNKS_E;
+  const int64_t nchunks = (a.len + AH_FILTER_CHUNK_ROWS - 1) / AH_FILTER_CHUNK_ROWS;
+  OpMask om[NT];
+  int64_t rkey[NT];  // RS: the scalar right-hand sides, once
+  uint64_t lsw[NT], rsw[NT];  // validity of scalar operands as a word, once (a load here waits for nothing else)
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    om[k] = op_mask(a.t[k].op);
+    rkey[k] = 0;
+    lsw[k] = (a.t[k].l_scalar && a.t[k].lv.words && !bv_get(a.t[k].lv, 0)) ? 0ull : ~0ull;
+    rsw[k] = (a.t[k].r_scalar && a.t[k].rv.words && !bv_get(a.t[k].rv, 0)) ? 0ull : ~0ull;
+    lsw[k] = (uint64_t)ah_uniform64((int64_t)lsw[k]);
+    rsw[k] = (uint64_t)ah_uniform64((int64_t)rsw[k]);
+    if constexpr (FW != 0 && RS) {
+      uint64_t x0, x1;
+      load_pair<(FW ? FW : 8)>(a.t[k].r, 0, 1, true, false, x0, x1);
+      rkey[k] = fast_key<(FW ? FW : 8)>(x0, a.t[k].kind);
+    }
+  }
+  for (int it = 0; it < GROUP_CHUNKS_E / 4; ++it) {
+    const int64_t chunk = chunk_base + it * 4 + wave;
+    if (chunk >= nchunks) {  // wave-uniform
+      if (lane == 0) s_cnt[it * 4 + wave] = 0;
+      continue;
+    }
+    const int64_t row0 = ah_uniform64(chunk * AH_FILTER_CHUNK_ROWS);
+    // 1. the chunk's validity words, term by term: lane j < 16 holds word j.  Only ISSUED here (no use of the data): the
+    //    value loads below go out behind them without a wait in between.
+    const int64_t vs = row0 + ((int64_t)lane << 6), vsc = vs < a.len ? vs : 0;
+    BvRaw rl[NT] = {}, rr[NT] = {};
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      if (a.t[k].lv.words && !a.t[k].l_scalar && lane < 16) rl[k] = bv_issue(a.t[k].lv, vsc, a.len);
+      if (a.t[k].rv.words && !a.t[k].r_scalar && lane < 16) rr[k] = bv_issue(a.t[k].rv, vsc, a.len);
+    }
+    // 2. the value words: ballots of the comparisons, four steps' loads in flight at a time
+#pragma unroll 1
+    for (int half = 0; half < NH; ++half) {
+      uint64_t lx[NT][HS][2], rx[NT][HS][2];
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        const ExprTerm& tm = a.t[k];
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+          const int64_t row = row0 + (half * HS + s) * 128 + 2 * lane;
+          if constexpr (FW != 0) {
+            load_pair<(FW ? FW : 8)>(tm.l, row, a.len, false, true, lx[k][s][0], lx[k][s][1]);
+            if constexpr (!RS) load_pair<(FW ? FW : 8)>(tm.r, row, a.len, false, true, rx[k][s][0], rx[k][s][1]);
+            else rx[k][s][0] = rx[k][s][1] = 0;
+          } else {
+            load_pair_w(tm.width, tm.l, row, a.len, tm.l_scalar != 0, tm.l_vec != 0, lx[k][s][0], lx[k][s][1]);
+            load_pair_w(tm.width, tm.r, row, a.len, tm.r_scalar != 0, tm.r_vec != 0, rx[k][s][0], rx[k][s][1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < HS; ++s) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+          const ExprTerm& tm = a.t[k];
+          bool c0, c1;
+          if constexpr (FW != 0) {
+            const int64_t r0 = RS ? rkey[k] : fast_key<(FW ? FW : 8)>(rx[k][s][0], tm.kind);
+            const int64_t r1 = RS ? rkey[k] : fast_key<(FW ? FW : 8)>(rx[k][s][1], tm.kind);
+            c0 = cmp_masked(om[k], fast_key<(FW ? FW : 8)>(lx[k][s][0], tm.kind), r0);
+            c1 = cmp_masked(om[k], fast_key<(FW ? FW : 8)>(lx[k][s][1], tm.kind), r1);
+          } else {
+            c0 = cmp_masked(om[k], key_w(tm.width, lx[k][s][0], tm.kind), key_w(tm.width, rx[k][s][0], tm.kind));
+            c1 = cmp_masked(om[k], key_w(tm.width, lx[k][s][1], tm.kind), key_w(tm.width, rx[k][s][1], tm.kind));
+          }
+          const uint64_t b0 = __ballot(c0), b1 = __ballot(c1);  // bit l = row 2l (b0) / 2l + 1 (b1)
+          const uint64_t tv0 = spread2(b0) | (spread2(b1) << 1);
+          const uint64_t tv1 = spread2(b0 >> 32) | (spread2(b1 >> 32) << 1);
+          if (lane == 0) {
+            s_val[wave][k][(half * HS + s) * 2] = tv0;
+            s_val[wave][k][(half * HS + s) * 2 + 1] = tv1;
+          }
+        }
+      }
+    }
+    // 3. fold the terms, 16 words at a time (lane j < 16 = word j).  Bit formulas of arrow-arith/src/boolean.rs.
+    //    (same-wave LDS traffic: the writes above are ordered before these reads by the wave's own program order)
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    uint64_t v = 0, nn = 0;
+    if (lane < 16) {
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        const uint64_t lw = a.t[k].l_scalar ? lsw[k] : (a.t[k].lv.words ? bv_finish(rl[k], vsc, a.len) : ~0ull);
+        const uint64_t rw = a.t[k].r_scalar ? rsw[k] : (a.t[k].rv.words ? bv_finish(rr[k], vsc, a.len) : ~0ull);
+        const uint64_t tv = s_val[wave][k][lane], tk = lw & rw;
+        if (k == 0) {
+          v = tv, nn = tk;
+        } else {
+          const int j = a.join[k - 1];  // uniform
+          if (j == AH_BOOL_AND) {  // :279 binary_boolean_kernel: values a & b, nulls = union of the null sets
+            v &= tv, nn &= tk;
+          } else if (j == AH_BOOL_OR) {  // :300
+            v |= tv, nn &= tk;
+          } else if (j == AH_BOOL_AND_KLEENE) {  // :60-150: valid where both are, or where either side is a valid false
+            const uint64_t m = (nn & tk) | (nn & ~v) | (tk & ~tv);
+            v &= tv, nn = m;
+          } else {  // AH_BOOL_OR_KLEENE :152-241: valid where both are, or where either side is a valid true
+            const uint64_t m = (nn & tk) | (nn & v) | (tk & tv);
+            v |= tv, nn = m;
+          }
+        }
+      }
+    }
+    // prep_null_mask_filter (filter.rs:167-171): selected = value AND valid; rows past len are not rows
+    uint64_t sel = v & nn;
+    const int64_t rem = a.len - (row0 + ((int64_t)lane << 6));
+    if (rem < 64) sel = rem <= 0 ? 0 : (sel & ((1ull << rem) - 1));
+    if (lane >= 16) sel = 0;
+    if (lane < 16) a.mask_out[chunk * 16 + lane] = sel;  // one 128-byte store per chunk
+    int c = __popcll(sel);
+    c += __shfl_xor(c, 1, 64);
+    c += __shfl_xor(c, 2, 64);
+    c += __shfl_xor(c, 4, 64);
+    c += __shfl_xor(c, 8, 64);
+    if (lane == 0) s_cnt[it * 4 + wave] = (uint32_t)c;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int v = (int)s_cnt[lane];
+    const int incl = wave_scan_incl(v);
+    if (chunk_base + lane < nchunks) a.chunk_prefix[chunk_base + lane] = (uint32_t)(incl - v);
+    if (lane == 63) a.group_total[blockIdx.x] = (uint32_t)incl;
+  }
+}
+
+template <int NT>
+void launch_expr_count(ah_context* ctx, const ExprArgs& a, int64_t ngroups, int fw, bool rs) {
+  const dim3 g((unsigned)ngroups), b(256);
+  if (fw == 8 && rs) filter_expr_count_kernel<NT, 8, true><<<g, b, 0, ctx->stream>>>(a);
+  else if (fw == 8) filter_expr_count_kernel<NT, 8, false><<<g, b, 0, ctx->stream>>>(a);
+  else if (fw == 4 && rs) filter_expr_count_kernel<NT, 4, true><<<g, b, 0, ctx->stream>>>(a);
+  else if (fw == 4) filter_expr_count_kernel<NT, 4, false><<<g, b, 0, ctx->stream>>>(a);
+  else filter_expr_count_kernel<NT, 0, false><<<g, b, 0, ctx->stream>>>(a);
+}
+
+const char* cmp_sym_e(int op) {
+  switch (op) {
+    case AH_EQ: return "==";
+    case AH_NEQ: return "!=";
+    case AH_LT: return "<";
+    case AH_LT_EQ: return "<=";
+    case AH_GT: return ">";
+    default: return ">=";
+  }
+}
+
+}  // namespace
+
+extern "C" ah_status ah_filter_predicate_build_expr(ah_context* ctx, int32_t n_terms, const ah_filter_term* terms,
+                                                    const ah_boolean_op* joins, ah_filter_predicate** out) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !out || !terms || (n_terms > 1 && !joins)) return AH_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (n_terms < 1 || n_terms > EXPR_MAX_TERMS)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "a filter expression takes 1..%d comparison terms, got %d", EXPR_MAX_TERMS, n_terms);
+  hipSetDevice(ctx->device);
+  ExprArgs a{};
+  a.nterms = n_terms;
+  int64_t len = -1;
+  for (int k = 0; k < n_terms; ++k) {
+    const ah_filter_term& tm = terms[k];
+    if (!tm.lhs || !tm.rhs) return AH_INVALID_ARGUMENT;
+    const bool ls = tm.lhs_is_scalar != 0, rs = tm.rhs_is_scalar != 0;
+    if (tm.op < AH_EQ || tm.op > AH_GT_EQ)
+      return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "filter expression: comparison op %d (eq, neq, lt, lt_eq, gt, gt_eq only)", tm.op);
+    // compare_op (cmp.rs:228-264)
+    if (tm.lhs->length != tm.rhs->length && !ls && !rs)
+      return ah_fail(ctx, AH_INVALID_ARGUMENT, "Cannot compare arrays of different lengths, got %lld vs %lld",
+                     (long long)tm.lhs->length, (long long)tm.rhs->length);
+    if (tm.lhs->type != tm.rhs->type)
+      return ah_fail(ctx, AH_INVALID_ARGUMENT, "Invalid comparison operation: %s %s %s", ah_type_name(tm.lhs->type),
+                     cmp_sym_e(tm.op), ah_type_name(tm.rhs->type));
+    const ah_type ty = tm.lhs->type;
+    if (!(ah_type_is_integer(ty) || ah_type_is_float(ty)))
+      return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "filter expression: comparison of %s operands (integers and Float32 / Float64 only)",
+                     ah_type_name(ty));
+    if ((ls && tm.lhs->length < 1) || (rs && tm.rhs->length < 1))
+      return ah_fail(ctx, AH_INVALID_ARGUMENT, "scalar datum must have length 1");
+    if (ls && rs) return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "filter expression: a term needs at least one array operand");
+    const int64_t tl = ls ? tm.rhs->length : tm.lhs->length;
+    if (len < 0) len = tl;
+    // binary_boolean_kernel (boolean.rs:262-266)
+    if (tl != len) return ah_fail(ctx, AH_COMPUTE_ERROR, "Cannot perform bitwise operation on arrays of different length");
+    if (k > 0) {
+      const int j = joins[k - 1];
+      if (j != AH_BOOL_AND && j != AH_BOOL_OR && j != AH_BOOL_AND_KLEENE && j != AH_BOOL_OR_KLEENE)
+        return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "filter expression: join op %d (and, or, and_kleene, or_kleene only)", j);
+      a.join[k - 1] = j;
+    }
+    ExprTerm& e = a.t[k];
+    e.l = tm.lhs->values, e.r = tm.rhs->values;
+    e.width = ah_type_width(ty);
+    e.kind = ah_type_is_float(ty) ? 2 : (ah_type_is_signed(ty) ? 0 : 1);
+    e.op = tm.op;
+    e.l_scalar = ls, e.r_scalar = rs;
+    auto valid_of = [](const ah_array_view* v) {
+      return (v->validity && v->null_count != 0) ? make_bitview(v->validity, v->validity_bit_offset) : BitView{nullptr, 0};
+    };
+    e.lv = valid_of(tm.lhs), e.rv = valid_of(tm.rhs);
+    e.l_vec = !ls && tl >= 2 && ((uintptr_t)e.l % (2 * e.width)) == 0;
+    e.r_vec = !rs && tl >= 2 && ((uintptr_t)e.r % (2 * e.width)) == 0;
+  }
+  auto* p = new ah_filter_predicate();
+  p->len = len;
+  p->mask_valid = BitView{nullptr, 0};
+  p->group_shift = 6;
+  if (len <= 0) {
+    p->len = 0;
+    *out = p;
+    return AH_OK;
+  }
+  const int64_t nchunks = ah_ceil_div(len, AH_FILTER_CHUNK_ROWS), ngroups = ah_ceil_div(nchunks, GROUP_CHUNKS_E);
+  const size_t b_mask = (size_t)nchunks * 16 * 8;
+  const size_t b_chunk = ((size_t)nchunks * 4 + 255) & ~(size_t)255;
+  const size_t b_gt = ((size_t)ngroups * 4 + 255) & ~(size_t)255;
+  const size_t b_gp = ((size_t)ngroups * 8 + 255) & ~(size_t)255;
+  ah_status st = ah_pool_alloc(ctx, b_mask + b_chunk + b_gt + b_gp + 256, &p->block);
+  if (st != AH_OK) {
+    delete p;
+    return st;
+  }
+  char* base = (char*)p->block;
+  a.mask_out = (unsigned long long*)base;
+  p->mask = BitView{(const uint64_t*)base, 0};
+  p->chunk_prefix = (uint32_t*)(base + b_mask);
+  uint32_t* group_total = (uint32_t*)(base + b_mask + b_chunk);
+  p->group_prefix = (unsigned long long*)(base + b_mask + b_chunk + b_gt);
+  p->total_dev = (unsigned long long*)(base + b_mask + b_chunk + b_gt + b_gp);
+  a.len = len;
+  a.chunk_prefix = p->chunk_prefix;
+  a.group_total = group_total;
+  const uint64_t seq = ah_mail_next(ctx);
+  {
+    ah_prof_scope ps(ctx, "filter_expr_count");
+    // the fast instantiations: one operand width (8 or 4), every array operand vector-aligned, left sides arrays, right
+    // sides all scalars (RS) or all arrays
+    int fw = a.t[0].width;
+    bool all_rs = true, all_ra = true;
+    for (int k = 0; k < n_terms; ++k) {
+      const ExprTerm& e = a.t[k];
+      if (e.width != fw || e.l_scalar || !e.l_vec || (!e.r_scalar && !e.r_vec)) fw = 0;
+      all_rs = all_rs && e.r_scalar;
+      all_ra = all_ra && !e.r_scalar;
+    }
+    if ((fw != 8 && fw != 4) || !(all_rs || all_ra)) fw = 0;
+    static const char* force = getenv("AH_FILTER_EXPR_GENERIC");  // tests: run the generic instantiation on any input
+    if (force && force[0] == '1') fw = 0;
+    switch (n_terms) {
+      case 1: launch_expr_count<1>(ctx, a, ngroups, fw, all_rs); break;
+      case 2: launch_expr_count<2>(ctx, a, ngroups, fw, all_rs); break;
+      case 3: launch_expr_count<3>(ctx, a, ngroups, fw, all_rs); break;
+      default: launch_expr_count<4>(ctx, a, ngroups, fw, all_rs); break;
+    }
+  }
+  ah_filter_launch_group_scan(ctx, group_total, ngroups, p->group_prefix, p->total_dev, 0, seq);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
+  if (e != hipSuccess) {
+    ah_pool_free(ctx, p->block);
+    delete p;
+    return ah_fail(ctx, AH_HIP_ERROR, "filter expression count failed: %s", hipGetErrorString(e));
+  }
+  p->count = (int64_t)ctx->pinned[0];
+  *out = p;
+  return AH_OK;
+}

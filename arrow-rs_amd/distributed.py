@@ -242,24 +242,49 @@ class CApiCommunicator:
         self._note(st)
         return Array._from_out(ctx, out, array.data_type)
 
-    def all_gather_record_batch(self, batch):
-        """concat_batches of every rank's RecordBatch shard (one count exchange + one grouped exchange for all columns)."""
-        from .array import RecordBatch
+    def all_gather_record_batch_begin(self, batch):
+        """Start the exchange of ``batch``'s columns (``ah_all_gather_columns_begin``: count exchange, outputs allocated,
+        grouped send / recv and merge kernels enqueued) and return a handle whose ``end()`` yields the concatenated
+        RecordBatch.  Between the two the host is free to drive OTHER contexts (streams): that is how a C host overlaps
+        a take with the reassembly."""
         ctx, n = self.ctx, batch.num_columns()
         views = (L.ArrayView * n)()
         for i, c in enumerate(batch.columns):
             views[i] = c.view()
+        h = C.c_void_p()
+        ctx.check(ctx.lib.ah_all_gather_columns_begin(ctx.handle, self._h, n, views, C.byref(h)))
+        return _PendingExchange(self, batch, views, h)
+
+    def all_gather_record_batch(self, batch):
+        """concat_batches of every rank's RecordBatch shard (one count exchange + one grouped exchange for all columns)."""
+        return self.all_gather_record_batch_begin(batch).end()
+
+    def all_gather_batches(self, batch, alignment=64):
+        """Interface twin of ``Communicator.all_gather_batches``: here the result is already concatenated."""
+        return [self.all_gather_record_batch(batch)]
+
+
+class _PendingExchange:
+    """An exchange between ``ah_all_gather_columns_begin`` and ``_end``; keeps the input batch alive."""
+
+    def __init__(self, comm, batch, views, handle):
+        self.comm, self.batch, self.views, self.handle = comm, batch, views, handle
+
+    def end(self):
+        from .array import RecordBatch
+        comm, batch = self.comm, self.batch
+        ctx, n = comm.ctx, batch.num_columns()
+        if self.handle is None:
+            raise RuntimeError("exchange already ended")
         outs = (L.ArrayOut * n)()
         st = L.ExchangeStats()
-        ctx.check(ctx.lib.ah_all_gather_columns(ctx.handle, self._h, n, views, outs, C.byref(st)))
-        self._note(st)
+        h, self.handle = self.handle, None
+        ctx.check(ctx.lib.ah_all_gather_columns_end(ctx.handle, comm._h, h, outs, C.byref(st)))
+        comm._note(st)
         cols = []
         for i, c in enumerate(batch.columns):
             o = L.ArrayOut()
             C.memmove(C.byref(o), C.byref(outs[i]), C.sizeof(L.ArrayOut))
             cols.append(Array._from_out(ctx, o, c.data_type))
+        self.batch = self.views = None
         return RecordBatch(batch.names, cols, num_rows=cols[0].length if cols else 0)
-
-    def all_gather_batches(self, batch, alignment=64):
-        """Interface twin of ``Communicator.all_gather_batches``: here the result is already concatenated."""
-        return [self.all_gather_record_batch(batch)]

@@ -44,14 +44,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable copy
-# Every L2 miss is a 128-byte line fill (TCC_EA0_RDREQ_128B, profiles/r02_take_ablation.md), so the achievable
-# 6.3 TB/s is ~49 G line fills per second whatever the access pattern; a random gather spends one fill per 8-byte
-# value and one per validity byte.
-REQUEST_CEILING_G = 6300.0 / 128.0
-ALL_WORKLOADS = ["filter_take", "arith", "cmp", "cast", "cast_string", "coalesce", "string_filter_take", "predicate_filter", "aggregate",
-                 "sort", "record_batch"]
-EXTRA_CONFIGS = ["arith", "cmp", "cast", "cast_string"]  # BASELINE configs[2] and [3], timed inside the default run
-NEXT_ROWS = ["coalesce", "record_batch", "string_filter_take", "predicate_filter"]  # SURVEY 8f rows 1 / 3 and configs[4]'s per-GPU shape, ditto
+# Every L2 miss is a 128-byte line fill (TCC_EA0_RDREQ_128B, profiles/r02_take_ablation.md); a random gather spends one
+# fill per 8-byte value and one per validity bit.  The MEASURED maximum for exactly that mix is the `value_bit` probe of
+# tools/gather_probe2.hip (the same accesses with nothing else in the kernel): 201.6 M fills in 3.819 ms = 52.8 G/s
+# (the bitmap half is served by the Infinity Cache, which is why this is above 6.3 TB/s / 128 B = 49 G/s).
+PROBE_MAX_FILLS_G = 52.8
+ALL_WORKLOADS = ["filter_take", "arith", "cmp", "cast", "cast_string", "cast_string_utf8", "coalesce", "string_filter_take", "string_filter",
+                 "string_take", "predicate_filter", "predicate_filter_fused", "aggregate", "sort", "record_batch"]
+EXTRA_CONFIGS = ["arith", "cmp", "cast", "cast_string", "cast_string_utf8"]  # BASELINE configs[2] and [3], timed inside the default run
+# SURVEY 8f rows 1 / 2 / 3 and configs[4]'s per-GPU shape, ditto
+NEXT_ROWS = ["coalesce", "record_batch", "string_filter", "string_take", "predicate_filter", "predicate_filter_fused"]
 
 
 def parse():
@@ -154,6 +156,134 @@ def _host_threads_for(bytes_per_thread):
     return cores
 
 
+def _granted_cores():
+    """(core ids this process may run on, clipped by the cgroup CPU quota; what limited it)."""
+    try:
+        ids = sorted(os.sched_getaffinity(0))
+    except Exception:
+        ids = list(range(os.cpu_count() or 1))
+    why = f"affinity mask: {len(ids)} cores"
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(f).read().split()
+            if f.endswith("cpu.max"):
+                quota, period = t[0], int(t[1])
+            else:
+                quota, period = t[0], int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(int(quota) / period))
+                if q < len(ids):
+                    ids, why = ids[:q], f"cgroup cpu quota: {q} cores of {len(ids)} in the affinity mask"
+            break
+        except Exception:
+            continue
+    return ids, why
+
+
+def cpu_worker_main(argv):
+    """`bench.py --cpu-worker <k> <core> <rows> <reps> <sel> <valid>`: one pinned process of the all-core baseline.
+    Raw ctypes on oracle/liboracle.so (no HIP runtime in 256 processes).  Prints READY, waits for a line on stdin,
+    runs, prints its elapsed seconds."""
+    import numpy as np
+    k, core, per, reps, sel, valid = int(argv[0]), int(argv[1]), int(argv[2]), int(argv[3]), float(argv[4]), float(argv[5])
+    try:
+        os.sched_setaffinity(0, {core})
+    except Exception:
+        pass
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+
+    class View(C.Structure):
+        _fields_ = [("type", C.c_int32), ("length", C.c_int64), ("null_count", C.c_int64), ("values", C.c_void_p),
+                    ("values_bit_offset", C.c_int64), ("validity", C.c_void_p), ("validity_bit_offset", C.c_int64),
+                    ("offsets", C.c_void_p)]
+
+    class Out(C.Structure):
+        _fields_ = [("type", C.c_int32), ("length", C.c_int64), ("null_count", C.c_int64), ("values", C.c_void_p),
+                    ("values_bytes", C.c_int64), ("values_bit_offset", C.c_int64), ("validity", C.c_void_p),
+                    ("validity_bytes", C.c_int64), ("validity_bit_offset", C.c_int64), ("offsets", C.c_void_p),
+                    ("offsets_bytes", C.c_int64), ("flags", C.c_int32)]
+    lib.orc_gen_uniform_i64.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, C.c_int64]
+    lib.orc_gen_uniform_u32.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_int64]
+    lib.orc_gen_bernoulli_bits.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int64]
+    nidx = int(per * sel)
+    v = np.empty(per, dtype=np.int64)
+    vb = np.zeros(per // 8 + 8, dtype=np.uint8)
+    mb = np.zeros(per // 8 + 8, dtype=np.uint8)
+    ix = np.empty(nidx, dtype=np.uint32)
+    lib.orc_gen_uniform_i64(v.ctypes.data, per, 42, -2**63, 2**63 - 1, k * per)
+    lib.orc_gen_bernoulli_bits(vb.ctypes.data, per, 43, valid, k * per)
+    lib.orc_gen_bernoulli_bits(mb.ctypes.data, per, 44, sel, k * per)
+    lib.orc_gen_uniform_u32(ix.ctypes.data, nidx, 45 + k, per, 0)
+    AH_BOOL, AH_INT64, AH_UINT32 = 1, 5, 8
+    vv, mv, iv = View(), View(), View()
+    vv.type, vv.length, vv.null_count, vv.values, vv.validity = AH_INT64, per, -1, v.ctypes.data, vb.ctypes.data
+    mv.type, mv.length, mv.null_count, mv.values = AH_BOOL, per, 0, mb.ctypes.data
+    iv.type, iv.length, iv.null_count, iv.values = AH_UINT32, nidx, 0, ix.ctypes.data
+
+    def once():
+        o = Out()
+        lib.orc_filter(C.byref(vv), C.byref(mv), C.byref(o))
+        lib.orc_release(C.byref(o))
+        o = Out()
+        lib.orc_take(C.byref(vv), C.byref(iv), 0, C.byref(o))
+        lib.orc_release(C.byref(o))
+    once()  # heap warmed: the outputs of the timed calls reuse these chunks
+    print("READY", flush=True)
+    sys.stdin.readline()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    print(f"DONE {time.perf_counter() - t0:.6f}", flush=True)
+
+
+def cpu_baseline_all_cores(args, one_core_mrows):
+    per, reps = 1 << 24, 8
+    ids, why = _granted_cores()
+    T = min(len(ids), _host_threads_for(per * 14))
+    if T < len(ids):
+        why += f"; host memory holds {T} shards of {per} rows"
+    env = dict(os.environ, MALLOC_MMAP_THRESHOLD_=str(1 << 30), MALLOC_TRIM_THRESHOLD_=str(1 << 34), MALLOC_TOP_PAD_=str(64 << 20),
+               OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(k), str(ids[k]), str(per), str(reps),
+                               str(args.selectivity), str(args.valid)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, text=True, env=env) for k in range(T)]
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != "READY":
+                raise RuntimeError("a CPU baseline worker did not start")
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        each = [float(p.stdout.readline().split()[1]) for p in procs]
+        wall = time.perf_counter() - t0
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
+    nidx = int(per * args.selectivity)
+    mrows = per * T * reps / wall / 1e6
+    # bytes the port moves per (filter + take): values + 2 bitmaps in, K values + bits out; idx + gathered values in, values + bits out
+    k_sel = int(per * args.selectivity)
+    alg = per * 8 + 2 * (per // 8) + k_sel * 8 + k_sel // 8 + nidx * (4 + 8 + 8) + 2 * (nidx // 8)
+    out = {"value": round(mrows, 1), "unit": "Mrows/s", "cores": T, "processes": T, "granted": why,
+           "speedup_over_one_core": round(mrows / one_core_mrows, 1) if one_core_mrows else None,
+           "algorithmic_GBps": round(alg * T * reps / wall / 1e9, 1),
+           "slowest_worker_s": round(max(each), 3), "fastest_worker_s": round(min(each), 3), "wall_s": round(wall, 3),
+           "sample": f"{reps} x (filter + take), {T} pinned processes x {per} rows (128 MiB of values each, "
+                     f"{per * T * 8 / 2**30:.0f} GiB in all: DRAM-resident), {nidx} u32 indices per process, outputs reused from the heap"}
+    if one_core_mrows and mrows < 20 * one_core_mrows:
+        out["limit"] = (f"{T} processes reach {mrows / one_core_mrows:.1f}x one core: the port is DRAM-bound "
+                        f"({out['algorithmic_GBps']} GB/s algorithmic, random 8-byte gathers fetch whole lines on top), not core-bound")
+    return out
+
+
 def cpu_baseline_filter_take(args):
     """The oracle (a scalar port of the reference's algorithm) timed on the GPU box's host cores over a
     bounded sample of the same workload.  Reported baseline, never the thing shipped."""
@@ -198,57 +328,13 @@ def cpu_baseline_filter_take(args):
                      f"same generators/densities; oracle/liboracle.so single thread; "
                      f"host has {os.cpu_count()} cores"}
     del hvh, hmh, hih, hv, hm, hi, vals, valid, mask, idx
-    # secondary: the same port row-sharded over EVERY host core (how an engine parallelises the single-threaded
-    # reference kernels), 2^24 rows = 128 MiB of values per thread so that the shards stream from DRAM rather
-    # than sit in the last-level cache.  Each thread builds its own shard with the
-    # same counter-based generators (row0 = its offset in one global column); ctypes drops the GIL in every call.
+    # secondary: the same port row-sharded over EVERY host core this container is granted (how an engine parallelises
+    # the single-threaded reference kernels): ONE PROCESS per core, pinned, 2^24 rows = 128 MiB of values each so the
+    # shards stream from DRAM, glibc told to keep the 13 MB outputs on its heap instead of mmap/munmap-ing them per call
+    # (256 threads of one process fought over the address-space lock and reported 4x one core).
     try:
-        import threading
-        per = 1 << 24
-        T = _host_threads_for(per * 14)
-        nidx = int(per * args.selectivity)
-        shards = [None] * T
-
-        def build(k):
-            v = oracle.gen_i64(per, 42, -2**63, 2**63 - 1, k * per)
-            vb = np.zeros(per // 8, dtype=np.uint8)
-            mb = np.zeros(per // 8, dtype=np.uint8)
-            oracle.lib.orc_gen_bernoulli_bits(vb.ctypes.data, per, 43, args.valid, k * per)
-            oracle.lib.orc_gen_bernoulli_bits(mb.ctypes.data, per, 44, args.selectivity, k * per)
-            ix = oracle.gen_u32(nidx, 45 + k, per)
-            vv, mv, iv = orc.View(), orc.View(), orc.View()
-            vv.type, vv.length, vv.null_count, vv.values, vv.validity = A._lib.AH_INT64, per, -1, v.ctypes.data, vb.ctypes.data
-            mv.type, mv.length, mv.null_count, mv.values = A._lib.AH_BOOL, per, 0, mb.ctypes.data
-            iv.type, iv.length, iv.null_count, iv.values = A._lib.AH_UINT32, nidx, 0, ix.ctypes.data
-            shards[k] = (vv, mv, iv, (v, vb, mb, ix))
-
-        ths = [threading.Thread(target=build, args=(k,)) for k in range(T)]
-        [th.start() for th in ths]
-        [th.join() for th in ths]
-        REPS = 4
-        go = threading.Event()
-
-        def work(sh):
-            go.wait()
-            for _ in range(REPS):
-                o = orc.Out()
-                oracle.lib.orc_filter(C.byref(sh[0]), C.byref(sh[1]), C.byref(o))
-                oracle.lib.orc_release(C.byref(o))
-                o = orc.Out()
-                oracle.lib.orc_take(C.byref(sh[0]), C.byref(sh[2]), 0, C.byref(o))
-                oracle.lib.orc_release(C.byref(o))
-        ths = [threading.Thread(target=work, args=(sh,)) for sh in shards]
-        [th.start() for th in ths]
-        time.sleep(0.05)
-        t0 = time.perf_counter()
-        go.set()
-        [th.join() for th in ths]
-        dt = time.perf_counter() - t0
-        res["all_cores"] = {"value": round(per * T * REPS / dt / 1e6, 1), "unit": "Mrows/s", "cores": T,
-                            "sample": f"{REPS} x (filter + take), {T} threads x {per} rows (128 MiB of values per thread, "
-                                      f"{per * T * 8 / 2**30:.0f} GiB in all: DRAM-resident), {nidx} u32 indices per thread"}
-        del shards
-    except Exception as ex:
+        res["all_cores"] = cpu_baseline_all_cores(args, mrows)
+    except Exception as ex:  # noqa: BLE001
         res["all_cores"] = {"error": repr(ex)}
     # independent sanity line: Arrow C++ through pyarrow on the same sample.  A different
     # implementation (filter/take semantics coincide) — NOT the reference and not the baseline.
@@ -298,9 +384,13 @@ PMC_KERNELS = {
 # workloads whose roofline object covers ALL launches of one step: every dispatch whose name matches is summed and
 # divided by the steps the child ran (setup kernels — generators, the casts that build the input — do not match)
 PMC_STEP_KERNELS = {
+    "string_filter": r"filter_(scatter|count|count_small|group_scan|finish)\w*_kernel|range_scan_\w+_kernel|"
+                     r"gather_bytes_kernel|string_filter_\w+_kernel",
+    "string_take": r"range_scan_\w+_kernel|gather_bytes_kernel|take_ranges_kernel",
     "string_filter_take": r"filter_(scatter|count|count_small|group_scan|finish)\w*_kernel|range_scan_\w+_kernel|"
                           r"gather_bytes_kernel|take_ranges_kernel",
     "coalesce": r"filter_(scatter|count|count_small|group_scan|finish|finish_acc)\w*_kernel|copy_rows\w*_kernel|bm_acc_kernel",
+    "predicate_filter_fused": r"filter_expr_count_kernel|filter_(scatter|group_scan|finish)\w*_kernel",
     "predicate_filter": r"compare_kernel|bitmap_op_kernel|filter_(scatter|count|count_small|group_scan|finish)\w*_kernel|popcount_partial_kernel",
 }
 PMC_CHILD_STEPS, PMC_CHILD_WARMUP = 2, 1
@@ -381,7 +471,13 @@ def build_workload(env, wl):
 
         def step(with_reassembly):
             f = K.filter(col, pred)
-            if with_reassembly and not st.get("reassemble_error"):
+            if with_reassembly and hasattr(env.comm, "all_gather_record_batch_begin"):
+                # the C-host form: start the exchange on this context's stream (ah_all_gather_columns_begin), run the
+                # take on the second context = second stream while RCCL moves the shards, come back for the result
+                pending = env.comm.all_gather_record_batch_begin(A.RecordBatch(["f"], [f], f.length))
+                t = K.take(col_b, idx_b)
+                st["gk"] = pending.end().num_rows()
+            elif with_reassembly and not st.get("reassemble_error"):
                 import threading
                 box = {}
 
@@ -438,8 +534,10 @@ def build_workload(env, wl):
             return out_rows
 
         W.update(step=step, kernels=["filter_count", "filter_scatter", "copy_rows"], dominant="filter_scatter")
-    elif wl == "string_filter_take":
-        # LargeUtf8 column (the config-4 cast output) through filter and take
+    elif wl in ("string_filter_take", "string_filter", "string_take"):
+        # LargeUtf8 column (the config-4 cast output) through filter and take — as two rows, because
+        # the two halves are different machines: the filter is order-preserving (contiguous selected runs stream), the
+        # take is a random row gather (bound by line fills)
         n = min(n, 1 << 27) if args.rows == 1_000_000_000 else n
         src = gen_i64_column(A, ctx, n, 42, args.valid, row0, -10**6, 10**6)
         scol = K.cast(K.cast(src, A.Float64), A.LargeUtf8)
@@ -450,15 +548,18 @@ def build_workload(env, wl):
         idx = mk_array(A, ctx, A.UInt32, nidx, ib)
         W["idx"] = idx
 
+        do_f, do_t = wl != "string_take", wl != "string_filter"
+
         def step(_r):
-            f = K.filter(scol, pred)
-            t = K.take(scol, idx)
-            st["fbytes"], st["tbytes"], st["k"] = f.values.nbytes, t.values.nbytes, f.length
+            f = K.filter(scol, pred) if do_f else None
+            t = K.take(scol, idx) if do_t else None
+            st["fbytes"], st["tbytes"] = (f.values.nbytes if do_f else 0), (t.values.nbytes if do_t else 0)
+            st["k"] = f.length if do_f else 0
             return f, t
 
         W.update(step=step, dominant="string_gather_bytes",
-                 kernels=["filter_count", "filter_scatter", "string_ranges_scan", "string_gather_bytes",
-                          "string_take_ranges", "take_gather"])
+                 kernels=(["filter_count", "filter_scatter", "string_filter_copy"] if do_f else []) +
+                         ["string_ranges_scan", "string_gather_bytes"] + (["string_take_ranges", "take_gather"] if do_t else []))
     elif wl == "predicate_filter":
         # the predicate is BUILT on the device and consumed by filter without leaving it —
         # WHERE a < 0 AND b >= 0: lt(a, scalar), gt_eq(b, scalar), and_kleene, filter(a, mask with nulls)
@@ -474,6 +575,21 @@ def build_workload(env, wl):
             return f
 
         W.update(step=step, kernels=["compare", "boolean", "filter_count", "filter_scatter"], dominant="filter_scatter")
+    elif wl == "predicate_filter_fused":
+        # the same WHERE a < 0 AND b >= 0 handed over as TERMS (ah_filter_predicate_build_expr): the comparisons become
+        # ballots inside the filter's count pass; nothing but the 1-bit-per-row selection is materialised
+        col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
+        colb = gen_f64_column(A, ctx, n, 52, args.valid, row0)
+        s0 = A.Scalar.new(0, A.Int64, ctx)
+        s1 = A.Scalar.new(0.0, A.Float64, ctx)
+
+        def step(_r):
+            p_ = K.FilterBuilder.from_terms([("lt", col, s0), ("gt_eq", colb, s1)], ["and_kleene"]).build()
+            f = p_.filter(col)
+            st["k"], st["fn"] = f.length, f.null_count()
+            return f
+
+        W.update(step=step, kernels=["filter_expr_count", "filter_scatter"], dominant="filter_scatter")
     elif wl == "aggregate":
         # sum + min + max of the Int64 column (three streaming reads per step)
         col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
@@ -516,6 +632,18 @@ def build_workload(env, wl):
             src = gen_cast_source(A, K, ctx, n, args.valid, row0)
         if wl == "cast":
             W.update(step=lambda _r: K.cast(src, A.Float64), kernels=["cast_numeric"])
+        elif wl == "cast_string_utf8":
+            # SURVEY 8d cfg 4: "Utf8 in 64 Mi-row batches to show i32 behaviour" — the same 2^29 rows, 8 casts per step
+            f64 = K.cast(src, A.Float64)
+            br = min(n, 1 << 26)
+            parts = [f64.slice(i * br, min(br, n - i * br)) for i in range((n + br - 1) // br)]
+
+            def step(_r):
+                outs = [K.cast(p_, A.Utf8) for p_ in parts]
+                st["out_bytes"] = sum(o.values.nbytes for o in outs)
+                st["batches"] = len(outs)
+                return outs[-1]
+            W.update(step=step, kernels=["cast_string_len", "cast_string_write"])
         else:
             f64 = K.cast(src, A.Float64)
             W.update(step=lambda _r: K.cast(f64, A.LargeUtf8), kernels=["cast_string_len", "cast_string_write"])
@@ -539,16 +667,23 @@ def describe(env, wl, W, prof, out, steps):
         return dominant, dom_avg, dom_n, alg, text, "filter_take_Mrows_per_s", "int64"
     per_row = {"arith": 24.375, "cmp": 16.5, "cast": 16.25}.get(wl)
     kernels = W["kernels"]
-    if wl == "string_filter_take":
+    if wl in ("string_filter_take", "string_filter", "string_take"):
         k, idx = st["k"], W["idx"]
-        # filter: offsets + validity + mask in, K+1 offsets + bytes out; take: idx + ranges in, offsets + bytes out
-        alg = (n + 1) * 8 + 2 * ((n + 7) // 8) + (k + 1) * 8 + 2 * st["fbytes"] + idx.length * (4 + 16 + 8) + 2 * st["tbytes"]
+        # filter: offsets + validity + mask in, K+1 offsets + K validity bits + bytes out (selected bytes read once, written once);
+        # take: idx + one offsets pair and one validity bit per index in, offsets + bits + bytes out
+        alg = 0
+        if wl != "string_take":
+            alg += (n + 1) * 8 + 2 * ((n + 7) // 8) + (k + 1) * 8 + (k + 7) // 8 + 2 * st["fbytes"]
+        if wl != "string_filter":
+            alg += idx.length * (4 + 16 + 8) + 2 * ((idx.length + 7) // 8) + 2 * st["tbytes"]
         dom_avg, dom_n = sum(prof[kk][0] for kk in kernels) / max(steps, 1), steps
+        dominant = f"{wl}_step"
     elif wl == "coalesce":
         k = st["out_rows"]
         # two columns share one predicate: 2 x (values + validity) + mask in, 2 x (K values + K bits) out
         alg = 2 * (n * 8 + (n + 7) // 8) + (n + 7) // 8 + 2 * (k * 8 + (k + 7) // 8)
         dom_avg, dom_n = sum(prof[kk][0] for kk in kernels) / max(steps, 1), steps  # all launches of one step
+        dominant = "coalesce_step"
     elif wl == "predicate_filter":
         k = st["k"]
         wb = (n + 7) // 8
@@ -556,6 +691,15 @@ def describe(env, wl, W, prof, out, steps):
         # filter (values + validity + mask + mask validity in, K values + K bits out)
         alg = 2 * (n * 8 + wb + 2 * wb) + 6 * wb + (n * 8 + 3 * wb + k * 8 + (k + 7) // 8)
         dom_avg, dom_n = sum(prof[kk][0] for kk in kernels) / max(steps, 1), steps  # all launches of one step
+        dominant = "predicate_filter_step"
+    elif wl == "predicate_filter_fused":
+        k = st["k"]
+        wb = (n + 7) // 8
+        # count pass: a, b values + their validity in, selection bits out; scatter: a + its validity + selection bits in,
+        # K values + K bits out
+        alg = (2 * n * 8 + 2 * wb + wb) + (n * 8 + 2 * wb + k * 8 + (k + 7) // 8)
+        dom_avg, dom_n = sum(prof[kk][0] for kk in kernels) / max(steps, 1), steps
+        dominant = "predicate_filter_fused_step"
     elif wl == "record_batch":
         k = st["k"]  # ONE scatter launch for both columns: 2 x (values + validity) + the mask in, 2 x (K values + K bits) out
         alg = 2 * (n * 8 + (n + 7) // 8) + (n + 7) // 8 + 2 * (k * 8 + (k + 7) // 8)
@@ -563,6 +707,10 @@ def describe(env, wl, W, prof, out, steps):
         alg = (n - W["col"].null_count()) * 32  # per radix pass: keys read twice, (key, index) pairs written once
     elif wl == "aggregate":
         alg = n * 8 + (n + 7) // 8  # per launch: values + validity in, 8 bytes out
+    elif wl == "cast_string_utf8":  # all batches of one step: i32 offsets
+        alg = n * 8 + (n + 7) // 8 + (n + st["batches"]) * 4 + st["out_bytes"] + (n + 7) // 8
+        dom_avg, dom_n = sum(prof[k][0] for k in kernels) / max(steps, 1), steps
+        dominant = "cast_string_utf8_step"
     elif per_row is None:  # cast_string: input + validity in, offsets + bytes + validity out; both passes of one cast
         alg = n * 8 + (n + 7) // 8 + (n + 1) * 8 + out.values.nbytes + (n + 7) // 8
         dom_avg = sum(prof[k][0] for k in kernels) / max(prof[kernels[0]][1], 1)
@@ -578,6 +726,10 @@ def describe(env, wl, W, prof, out, steps):
             "sort": "arrow_ord sort_to_indices of a full-range Int64 column with NullBuffer (stable LSD radix)",
             "aggregate": "SURVEY 8f-4: sum + min + max of an Int64 column with NullBuffer",
             "string_filter_take": "SURVEY 8f-3: filter + take on a LargeUtf8 column (cast output)",
+            "string_filter": "SURVEY 8f-3: filter on a LargeUtf8 column (cast output): order-preserving, selected runs stream",
+            "string_take": "SURVEY 8f-3: take with uniform random UInt32 indices on a LargeUtf8 column (cast output): one row gather per index",
+            "cast_string_utf8": "configs[3]: cast Float64->Utf8 (i32 offsets) in 64 Mi-row batches of the same column",
+            "predicate_filter_fused": "SURVEY 8f-2: the same WHERE a < 0 AND b >= 0 as ONE lazy predicate (ah_filter_expr): compares evaluated inside the count and scatter kernels",
             "predicate_filter": "SURVEY 8f-2: filter(a, and_kleene(lt(a, 0), gt_eq(b, 0.0))) on Int64 a, Float64 b with NullBuffers",
             "coalesce": f"SURVEY 8f-1: BatchCoalescer.push_batch_with_filter, Int64+Float64, "
                         f"{args.batch_rows}-row batches"
@@ -618,8 +770,61 @@ def run_timed(env, W, steps, warmup, reassemble):
     return elapsed, prof, out
 
 
+def _free_port():
+    import socket
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: spawn N ranks HERE (one per visible GPU, rendezvous on
+    127.0.0.1), relay rank 0's ONE JSON line.  Fewer than N GPUs visible: say so in the line and exit non-zero —
+    a 1-GPU number is never reported as n_gpus N."""
+    import arrow_rs_amd as A
+    visible = int(A._lib.load().ah_device_count())
+    shared = os.environ.get("AH_BENCH_SHARED_GPU") == "1"
+    if visible < args.gpus and not shared:
+        print(json.dumps({"metric": "filter_take_Mrows_per_s", "value": None, "unit": "Mrows/s", "n_gpus": visible,
+                          "requested_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                          "error": f"--gpus {args.gpus} requested but only {visible} GPU(s) are visible to this process "
+                                   "(hipGetDeviceCount); refusing to report a multi-GPU number from fewer devices"}), flush=True)
+        return 3
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(args.gpus), AH_BENCH_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if shared:
+            env.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = procs[0].communicate()[0].decode()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            rc = rc or p.wait(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = rc or 4
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    for l in out0.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return rc if rc else (0 if lines else 5)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker_main(sys.argv[2:])
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # test hooks (tests/test_gpu_parity.py::test_bench_two_ranks_one_gpu): every rank on GPU 0 and a transport
@@ -769,8 +974,22 @@ def main():
             ms, cnt = ctx.profile_get("take_gather")
             extra[name] = round(ms / max(cnt, 1), 4)
             ctx.profile(False)
+            if name == "take_sorted_indices_ms":
+                # what filter -> indices -> take feeds the kernel; same algorithmic bytes per index
+                tb = ix.length * (4 + 8 + 8) + 2 * ((ix.length + 7) // 8)
+                extra["roofline_take_sorted"] = roofline_obj("take_gather (sorted indices = positions of the predicate)", tb,
+                                                             ms / max(cnt, 1), cnt)
         del sorted_idx, null_idx
 
+    # ranks the transport really initialised (ah_comm_world / the process group), never the --gpus argument
+    n_ranks = (int(getattr(env.comm, "world", world)) if env.comm is not None else 1) if use_dist else 1
+    if n_ranks != world:
+        raise SystemExit(f"bench.py: launcher says {world} ranks but the transport initialised {n_ranks}")
+    devices = {local_rank}
+    if use_dist:
+        got = [None] * world
+        dist.all_gather_object(got, (local_rank, os.environ.get("AH_BENCH_SHARED_GPU") == "1"))
+        devices = {d for d, _ in got}
     line = None
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -801,16 +1020,18 @@ def main():
                 rf = roofline_obj("take_gather", take_bytes, tk_avg, tk_n, tr.get("take_gather"))
                 reqs = idx.length * (2 if st["tn"] > 0 else 1)
                 rf["requests"] = {"per_launch": reqs, "achieved_G_per_s": round(reqs / (tk_avg * 1e-3) / 1e9, 1),
-                                  "ceiling_G_per_s": round(REQUEST_CEILING_G, 1),
-                                  "frac": round(reqs / (tk_avg * 1e-3) / 1e9 / REQUEST_CEILING_G, 3),
+                                  "probe_max_G_per_s": PROBE_MAX_FILLS_G,
+                                  "frac_of_probe_max": round(reqs / (tk_avg * 1e-3) / 1e9 / PROBE_MAX_FILLS_G, 3),
                                   "what": "128-byte L2 line fills (TCC_EA0_RDREQ_128B): 1 per gathered value + 1 per validity "
-                                          "byte; ceiling = the achievable 6.3 TB/s / 128 B; profiles/r02_take_ablation.md"}
+                                          "bit; probe_max = the measured fill rate of the bare value+bit gather probe "
+                                          "(profiles/r02_take_ablation.md, value_bit: 201.6 M fills / 3.819 ms), not a derived ceiling"}
         line = {
-            "metric": metric, "value": round(value, 1), "unit": "Mrows/s", "n_gpus": world,
+            "metric": metric, "value": round(value, 1), "unit": "Mrows/s", "n_gpus": n_ranks,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
             "config": {"workload": workload, "rows_per_gpu": n, "parallelism": f"row-sharded x{world}",
+                       "distinct_devices": len(devices),
                        "reassemble": ("allgatherv" if reassemble else "none"),
                        "transport": (("ah_comm (RCCL bound by libarrow_hip.so)" if transport == "capi" else "torch.distributed")
                                      if use_dist else "none")},
@@ -875,6 +1096,48 @@ def main():
         ctx.lib.ah_pool_trim(ctx.handle)
         line["configs"] = configs
         line["next_rows"] = next_rows
+
+    if wl == "filter_take" and world > 1 and not args.no_configs:
+        # BASELINE configs[4]: {Int64, Float64, bitmaps} per shard through filter_record_batch, then ONE exchange of both
+        # columns (ah_all_gather_columns) — every rank runs it, rank 0 reports
+        W = out = None
+        try:
+            ctx.lib.ah_pool_trim(ctx.handle)
+            W2 = build_workload(env, "record_batch")
+            el2, prof2, out2 = run_timed(env, W2, args.config_steps, 2, True)
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(args.config_steps):
+                W2["step"](False)
+            sync_all()
+            loc2 = time.perf_counter() - t0
+            if transport == "capi":
+                el2, loc2 = env.comm.allreduce_max([el2, loc2])
+            else:
+                tt = torch.tensor([el2, loc2], dtype=torch.float64, device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el2, loc2 = float(tt[0]), float(tt[1])
+            if rank == 0:
+                kern, avg_ms, launches, alg, workload, metric, dtype = describe(env, "record_batch", W2, prof2, out2, args.config_steps)
+                ms2 = el2 / args.config_steps * 1e3
+                rb = {"workload": workload.replace("configs[4] shape", "configs[4]") + f", all-gatherv of both columns over {world} ranks",
+                      "rows_per_gpu": W2["n"], "steps": args.config_steps, "ms": round(ms2, 4),
+                      "value": round(W2["n"] * world / (ms2 * 1e-3) / 1e6, 1), "unit": "Mrows/s", "dtype": dtype,
+                      "local_ms": round(loc2 / args.config_steps * 1e3, 4),
+                      "local_value": round(W2["n"] * world * args.config_steps / loc2 / 1e6, 1),
+                      "roofline": roofline_obj(kern, alg, avg_ms, launches), "gathered_rows": W2["state"].get("gk")}
+                ex, tm = getattr(env.comm, "last_exchange", None), getattr(env.comm, "timings", None)
+                if ex and tm and tm.get("total") and ex["peers"]:
+                    secs = tm["total"] * 1e-3
+                    rb["exchange"] = dict(ex, total_ms=tm["total"], counts_ms=tm.get("counts"),
+                                          per_link_GBps=round(ex["bytes_to_each_peer"] / secs / 1e9, 2),
+                                          egress_GBps=round(ex["bytes_to_each_peer"] * ex["peers"] / secs / 1e9, 2),
+                                          ingress_GBps=round(ex["bytes_received"] / secs / 1e9, 2))
+                line.setdefault("configs", {})["record_batch_allgather"] = rb
+            W2 = out2 = None
+        except Exception as exc:  # noqa: BLE001 - never lose the headline to a secondary config
+            if rank == 0:
+                line.setdefault("configs", {})["record_batch_allgather"] = {"error": repr(exc)[:300]}
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and wl == "filter_take":

@@ -157,6 +157,8 @@ typedef struct ah_context ah_context;
 typedef void* (*ah_alloc_fn)(void* user, size_t bytes); /* returns device ptr, 256B aligned */
 typedef void (*ah_free_fn)(void* user, void* ptr, size_t bytes);
 
+/* GPUs visible to this process (hipGetDeviceCount); 0 when there is none or the runtime cannot start. */
+AH_API int32_t ah_device_count(void);
 AH_API ah_status ah_context_create(int device, ah_context** out);
 AH_API void ah_context_destroy(ah_context* ctx);
 /* Route OUTPUT allocations through the host's allocator (the hook a Rust host
@@ -214,6 +216,26 @@ AH_API ah_status ah_filter_predicate_build(ah_context* ctx, const ah_array_view*
 /* the counts of n (<= 128) predicates with ONE host wait (every count pass is enqueued first) */
 AH_API ah_status ah_filter_predicates_build(ah_context* ctx, int32_t n, const ah_array_view* predicates,
                                             ah_filter_predicate** outs);
+/* The LAZY form of FilterBuilder for predicates an engine computes on the fly — `filter(a, and_kleene(lt(a, x),
+ * gt_eq(b, y)))` (arrow-ord/src/cmp.rs:113-164 compare_op :220-382; arrow-arith/src/boolean.rs:60-300;
+ * filter.rs:201,256-273): instead of materialising every comparison and the boolean kernel's result, hand over the
+ * TERMS.  term_0 join_0 term_1 join_1 ... is folded left to right; each term is a comparison (AH_EQ .. AH_GT_EQ) of
+ * two Datums of one integer or Float32 / Float64 type, at least one of them an array; joins are AH_BOOL_AND, AH_BOOL_OR,
+ * AH_BOOL_AND_KLEENE or AH_BOOL_OR_KLEENE.  The comparisons are evaluated inside the filter's count pass (__ballot
+ * words, null propagation with the reference's bit formulas, null predicate rows select nothing) and the resulting
+ * predicate is used like any other: ah_filter_predicate_count / _apply / _apply_into / the coalescer.  Result-identical
+ * to the materialised chain; errors carry compare_op's / binary_boolean_kernel's texts.  The operand buffers are only
+ * read during this call. */
+typedef struct ah_filter_term {
+  int32_t op; /* ah_cmp_op: AH_EQ .. AH_GT_EQ */
+  const ah_array_view* lhs;
+  int32_t lhs_is_scalar;
+  const ah_array_view* rhs;
+  int32_t rhs_is_scalar;
+} ah_filter_term;
+AH_API ah_status ah_filter_predicate_build_expr(ah_context* ctx, int32_t n_terms, const ah_filter_term* terms,
+                                                const int32_t* joins /* n_terms - 1 ah_boolean_op values */,
+                                                ah_filter_predicate** out);
 AH_API int64_t ah_filter_predicate_count(const ah_filter_predicate* p); /* FilterPredicate::count :481 */
 AH_API ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_predicate* p,
                                            const ah_array_view* values, ah_array_out* out);
@@ -258,9 +280,10 @@ AH_API ah_status ah_read_words(ah_context* ctx, uint64_t* dev_words, int32_t n, 
  * caller's buffers.  Other column types: AH_NOT_YET_IMPLEMENTED
  * (the host falls back to buffer-and-concat, coalesce/generic.rs).
  * Input lifetime: a push returns while its copies / scatters may still be running on the context's stream.  Buffers
- * that came from this context's allocator may be released at once (releases are stream-ordered); buffers the host
- * allocated itself must stay alive until the stream has passed them (the next finished batch's wait, or
- * ah_context_synchronize). */
+ * that came from this context's allocator — the built-in pool, or the ah_context_set_allocator hook — may be released
+ * at once (pool releases are stream-ordered; before a hook free the library drains the stream while no-wait work is in
+ * flight); buffers the host allocated itself must stay alive until the stream has passed them (the next finished
+ * batch's wait, or ah_synchronize). */
 typedef struct ah_coalescer ah_coalescer;
 AH_API ah_status ah_coalescer_create(ah_context* ctx, int32_t n_columns, const ah_type* types, int64_t target_batch_size,
                                      ah_coalescer** out);
@@ -451,8 +474,18 @@ AH_API ah_status ah_bitmap_set_bits(ah_context* ctx, uint8_t* dst, int64_t dst_b
  *                ah_all_gatherv / ah_all_gather_columns on results of ah_filter & co.
  *
  * One ncclAllGather of the per-rank counts (the call's one host wait before the exchange), ONE grouped
- * ncclSend/ncclRecv that lands every peer's values at their final offset, one bitmap-merge kernel per column with
- * nulls; RCCL's asynchronous error state is checked after the collective (AH_COMM_ERROR).  Fixed-width types only.
+ * ncclSend/ncclRecv that lands every peer's values (and string bytes) at their final offset, ONE kernel that merges
+ * every staged bitmap (validity of every column, Boolean value bits: concat_boolean, concat.rs:345) and one
+ * offset-rebase kernel per Utf8 / LargeUtf8 column (concat_bytes, concat.rs:355; a Utf8 total past i32::MAX bytes is
+ * AH_OFFSET_OVERFLOW_ERROR on every rank, before anything moves).  Column types: fixed-width, AH_BOOL, AH_UTF8,
+ * AH_LARGE_UTF8 (views are refused like ah_concat refuses them).  RCCL's asynchronous error state is checked after
+ * the collective (AH_COMM_ERROR).
+ * Failing together: the count payload carries a per-rank status word and every column's type, so a rank whose
+ * arguments are bad still takes part in the count exchange and EVERY rank returns an error (its own, or
+ * AH_COMM_ERROR "rank r failed before the exchange" / AH_INVALID_ARGUMENT for a schema mismatch) instead of
+ * leaving peers blocked.  A rank that fails between the count exchange and the grouped exchange (out of memory)
+ * aborts the communicator (ncclCommAbort): its peers see an asynchronous RCCL error, and every later call on that
+ * communicator is AH_COMM_ERROR.
  * `id == NULL` with world == 1 makes a communicator that never touches RCCL (copies only). */
 #define AH_COMM_ID_BYTES 128
 typedef struct ah_comm ah_comm;
@@ -478,6 +511,18 @@ AH_API ah_status ah_all_gatherv(ah_context* ctx, ah_comm* comm, const ah_array_v
  * for all of them (== concat_batches of the shard results, concat.rs:607) */
 AH_API ah_status ah_all_gather_columns(ah_context* ctx, ah_comm* comm, int32_t n_columns, const ah_array_view* columns,
                                        ah_array_out* outs, ah_exchange_stats* stats);
+/* The two halves of ah_all_gather_columns for a host that has other work to overlap with the exchange (a `take` on a
+ * second context = a second stream, bench.py's filter_take at N > 1).  _begin does the count exchange (one host wait:
+ * output sizes depend on it), allocates the outputs, enqueues the grouped exchange and the merge kernels on the
+ * context's stream and returns; _end waits for the stream, checks RCCL's asynchronous error state and hands over
+ * the outputs (n_columns of them) and the statistics.  The `columns` buffers must stay alive until _end; every _begin
+ * must be followed by exactly one _end on the same context and communicator (on failure _begin leaves *handle NULL
+ * and nothing to end); exchanges of one communicator do not nest. */
+typedef struct ah_exchange ah_exchange;
+AH_API ah_status ah_all_gather_columns_begin(ah_context* ctx, ah_comm* comm, int32_t n_columns, const ah_array_view* columns,
+                                             ah_exchange** handle);
+AH_API ah_status ah_all_gather_columns_end(ah_context* ctx, ah_comm* comm, ah_exchange* handle, ah_array_out* outs,
+                                           ah_exchange_stats* stats);
 /* The merge primitive on its own: dst (8-byte aligned, ceil(total / 64) words, written in full) = the concatenation of
  * `n` bit-packed pieces (pieces[i], bit_offsets[i], lens[i]); pieces[i] == NULL reads as all ones; bit_offsets may
  * be NULL (all zero).  bitmap concat of arrow-select/src/concat.rs:300-330 / bit_mask.rs:33 in ONE launch. */

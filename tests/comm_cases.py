@@ -1,0 +1,136 @@
+"""Shared cases of the exchange tests (fake transport at world 2 / 3 / 8 on one GPU, real RCCL at world 1 / 2 / 8):
+every rank runs the SAME code on its shard; the expectation is the oracle on the un-sharded input.
+TEST INFRASTRUCTURE (uses the oracle)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import arrow_rs_amd as A  # noqa: E402
+from arrow_rs_amd import compute as K  # noqa: E402
+from arrow_rs_amd import distributed as D  # noqa: E402
+import orc  # noqa: E402
+from orc import HostArray, assert_logical_eq  # noqa: E402
+
+N = 1_000_003
+
+
+def _strings(rng, n, maxlen=12):
+    lens = rng.integers(0, maxlen, n)
+    pool = rng.integers(97, 123, int(lens.sum()) + 1).astype(np.uint8).tobytes().decode()
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    return [pool[offs[i]:offs[i + 1]] for i in range(n)]
+
+
+def build_cases(world, n=N):
+    """(values HostArray, mask HostArray) pairs; identical on every rank (seeded by world only)."""
+    rng = np.random.default_rng(100 + world)
+    cases = []
+    for dt, vals in ((A.Int64, rng.integers(-2**62, 2**62, n)), (A.Float64, rng.standard_normal(n)),
+                     (A.Int16, rng.integers(-2**15, 2**15 - 1, n).astype(np.int16))):
+        for valid in (rng.random(n) < 0.9, None):
+            cases.append((HostArray(dt, np.asarray(vals, dtype=dt.np_dtype), valid), HostArray(A.Boolean, rng.random(n) < 0.13)))
+    # only SOME shards carry nulls (the others contribute all-ones pieces)
+    v = rng.random(n) < 0.999
+    v[n // world:] = True
+    cases.append((HostArray(A.Int64, rng.integers(0, 9, n), v), HostArray(A.Boolean, rng.random(n) < 0.5)))
+    # rank 0 selects nothing
+    m = rng.random(n) < 0.2
+    m[:D.shard_range(n, 0, world)[1]] = False
+    cases.append((HostArray(A.Int32, rng.integers(0, 9, n).astype(np.int32), rng.random(n) < 0.7), HostArray(A.Boolean, m)))
+    # Boolean values (concat_boolean, concat.rs:345): bit pieces through the merge kernel, with and without nulls
+    cases.append((HostArray(A.Boolean, rng.random(n) < 0.4, rng.random(n) < 0.8), HostArray(A.Boolean, rng.random(n) < 0.37)))
+    cases.append((HostArray(A.Boolean, rng.random(n) < 0.6), HostArray(A.Boolean, m)))
+    # Utf8 / LargeUtf8 (concat_bytes, concat.rs:355): bytes gatherv + offset rebase
+    ns = 200_003
+    sv = _strings(rng, ns)
+    cases.append((HostArray(A.Utf8, sv, rng.random(ns) < 0.85), HostArray(A.Boolean, rng.random(ns) < 0.3)))
+    cases.append((HostArray(A.LargeUtf8, sv), HostArray(A.Boolean, rng.random(ns) < 0.6)))
+    ms = rng.random(ns) < 0.5
+    ms[D.shard_range(ns, world - 1, world)[0]:] = False  # the LAST rank contributes an empty string shard
+    cases.append((HostArray(A.Utf8, sv, rng.random(ns) < 0.5), HostArray(A.Boolean, ms)))
+    return cases
+
+
+def run_rank(ctx, comm, oracle, r, world, n=N, heavy=True):
+    """Everything one rank checks.  Raises on the first mismatch."""
+    cases = build_cases(world, n)
+    for ci, (h, mask) in enumerate(cases):
+        s, e = D.shard_range(len(h), r, world)
+        hs, ms = h.slice(s, e - s), mask.slice(s, e - s)
+        f = K.filter(hs.to_device(ctx), ms.to_device(ctx))
+        g = comm.all_gatherv(f)
+        exp = oracle.filter(h, mask)
+        assert_logical_eq(HostArray.from_device(g), exp, f"rank {r} case {ci} ({h.data_type})")
+        assert g.null_count() == exp.null_count, f"rank {r} case {ci} null_count"
+        assert (g.validity is None) == (exp.null_count == 0), f"rank {r} case {ci} null buffer presence"
+        assert comm.last_exchange["peers"] == world - 1
+    # un-filtered sliced shards: validity / value bit offsets and string offsets that do not start at 0
+    for ci in (0, 8, 10):
+        h = cases[ci][0]
+        s, e = D.shard_range(len(h), r, world, align=1)
+        d = h.to_device(ctx).slice(s, e - s)
+        g = comm.all_gatherv(d)
+        assert_logical_eq(HostArray.from_device(g), h, f"rank {r} sliced shard of case {ci}")
+    # record-batch form: ONE count exchange + ONE group for columns of four kinds, through begin / end
+    nrb = len(cases[11][0])
+    ha, hb, hc, ma = (cases[0][0].slice(0, nrb), cases[2][0].slice(0, nrb), cases[8][0].slice(0, nrb), cases[0][1].slice(0, nrb))
+    hd = HostArray(A.LargeUtf8, cases[11][0].values, np.random.default_rng(8).random(nrb) < 0.9)
+    s, e = D.shard_range(nrb, r, world)
+    names = ["a", "b", "c", "d"]
+    rb = A.RecordBatch(names, [x.slice(s, e - s).to_device(ctx) for x in (ha, hb, hc, hd)], e - s)
+    fb = K.filter_record_batch(rb, ma.slice(s, e - s).to_device(ctx))
+    pending = comm.all_gather_record_batch_begin(fb)
+    side = K.take(rb.columns[0], HostArray(A.UInt32, np.arange(0, e - s, 7, dtype=np.uint32)).to_device(ctx)) if e > s else None
+    out = pending.end()
+    for i, hx in enumerate((ha, hb, hc, hd)):
+        assert_logical_eq(HostArray.from_device(out.columns[i]), oracle.filter(hx, ma), f"rank {r} batch col {names[i]}")
+    if side is not None:
+        assert_logical_eq(HostArray.from_device(side), HostArray(ha.data_type, np.ascontiguousarray(ha.values[s:e:7]), None if ha.valid is None else np.ascontiguousarray(ha.valid[s:e:7])),
+                          f"rank {r} take between begin and end")
+    comm.barrier()
+    assert comm.allreduce_max([float(r), -float(r)]) == [float(world - 1), 0.0]
+    # failing together: a schema mismatch (rank 0 passes Int32, everyone else Int64) is an error on EVERY rank, at once
+    bad = HostArray(A.Int32 if r == 0 else A.Int64, np.arange(10, dtype=np.int32 if r == 0 else np.int64)).to_device(ctx)
+    if world > 1:
+        try:
+            comm.all_gatherv(bad)
+            raise AssertionError(f"rank {r}: schema mismatch must fail")
+        except A.InvalidArgumentError as ex:
+            assert "rank 0" in str(ex) or "on rank" in str(ex), str(ex)
+        # a rank whose OWN arguments are bad (a view column on rank 1 only) still takes part: peers get AH_COMM_ERROR
+        ok = HostArray(A.Int64, np.arange(5, dtype=np.int64)).to_device(ctx)
+        try:
+            if r == 1:
+                v = ok.view()
+                v.type = A._lib.AH_UTF8_VIEW
+                out_, st_ = A._lib.ArrayOut(), A._lib.ExchangeStats()
+                ctx.check(ctx.lib.ah_all_gatherv(ctx.handle, comm._h, C.byref(v), C.byref(out_), C.byref(st_)))
+            else:
+                comm.all_gatherv(ok)
+            raise AssertionError(f"rank {r}: a failing peer must fail everyone")
+        except (A.ArrowError, A.array.HipError) as ex:  # AH_COMM_ERROR has no ArrowError variant
+            assert ("Utf8View" in str(ex)) if r == 1 else ("rank 1 failed" in str(ex)), str(ex)
+        # the communicator is still usable afterwards
+        g = comm.all_gatherv(ok)
+        assert g.length == 5 * world
+    if heavy and world == 2:
+        # Utf8 whose concatenation passes i32::MAX bytes: OffsetOverflowError on every rank, nothing moves
+        # (GenericByteBuilder::append_array, generic_bytes_builder.rs:186)
+        rows, each = 1200, 1 << 20
+        data = ctx.alloc(rows * each)
+        offs = A.DeviceBuffer.from_numpy(ctx, (np.arange(rows + 1, dtype=np.int64) * each).astype(np.int32))
+        R_ = A.array._RawMem
+        big = A.Array(ctx, A.Utf8, rows, R_(data.ptr, data.nbytes, data), 0, None, 0, 0, R_(offs.ptr, offs.nbytes, offs))
+        try:
+            comm.all_gatherv(big)
+            raise AssertionError("i32 offsets past 2 GiB must fail")
+        except A.OffsetOverflowError as ex:
+            assert str(rows * each * 2) in str(ex), str(ex)
+        del big, data, offs
+        comm.barrier()

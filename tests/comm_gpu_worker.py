@@ -54,15 +54,30 @@ def test_rccl_world1_record_batch():
     assert_logical_eq(HostArray.from_device(out.columns[0]), a, "col a")
     assert_logical_eq(HostArray.from_device(out.columns[1]), b, "col b")
     assert out.columns[1].validity is None
+    # Boolean values and strings go through the same call (concat_boolean / concat_bytes)
+    hb = HostArray(A.Boolean, rng.random(1000) < 0.5, rng.random(1000) < 0.9)
+    assert_logical_eq(HostArray.from_device(comm.all_gatherv(hb.to_device(ctx).slice(3, 900))), hb.slice(3, 900), "bool")
+    hs = HostArray(A.Utf8, [f"s{i % 97}" * (i % 5) for i in range(1000)], rng.random(1000) < 0.9)
+    assert_logical_eq(HostArray.from_device(comm.all_gatherv(hs.to_device(ctx).slice(5, 800))), hs.slice(5, 800), "utf8")
     try:
-        comm.all_gatherv(HostArray(A.Boolean, rng.random(10) < 0.5).to_device(ctx))
-        raise AssertionError("Boolean all-gather must be refused")
+        import ctypes as C
+        v = a.to_device(ctx).view()
+        v.type = A._lib.AH_UTF8_VIEW
+        o_, s_ = A._lib.ArrayOut(), A._lib.ExchangeStats()
+        ctx.check(ctx.lib.ah_all_gatherv(ctx.handle, comm._h, C.byref(v), C.byref(o_), C.byref(s_)))
+        raise AssertionError("view columns must be refused")
     except A.ArrowError:
         pass
 
 
+def test_rccl_world1_shared_cases():
+    """the N-rank case list at world 1 over real RCCL (tests/comm_cases.py)"""
+    import comm_cases as cc
+    cc.run_rank(ctx, comm, oracle, 0, 1, heavy=False)
+
 
 test_rccl_world1_all_gatherv_is_concat_of_one()
 test_rccl_world1_record_batch()
+test_rccl_world1_shared_cases()
 del comm
 print("COMM_WORKER_OK")

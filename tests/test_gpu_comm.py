@@ -30,7 +30,8 @@ def test_rccl_world1_through_the_c_abi():
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_exchange_code_at_world_n_over_a_fake_transport(world, tmp_path):
     """The product's exchange path (comm.hip) at N > 1 on one GPU: ranks are threads, RCCL's entry points are served by
-    tests/cpp/fake_rccl.cpp (send / recv = matched device-to-device copies).  See tests/comm_ranks_worker.py."""
+    tests/cpp/fake_rccl.cpp (send / recv = matched device-to-device copies).  Fixed-width, Boolean, Utf8 and LargeUtf8
+    columns, begin / end, failing together.  See tests/comm_ranks_worker.py and tests/comm_cases.py."""
     import os
     import subprocess
     import sys
@@ -39,8 +40,40 @@ def test_exchange_code_at_world_n_over_a_fake_transport(world, tmp_path):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Wno-unused-value",
                            "-o", lib, os.path.join(here, "cpp", "fake_rccl.cpp")])
     out = subprocess.run([sys.executable, os.path.join(here, "comm_ranks_worker.py"), str(world)], capture_output=True, text=True,
-                         timeout=900, env=dict(os.environ, AH_RCCL_LIBRARY=lib))
+                         timeout=1200, env=dict(os.environ, AH_RCCL_LIBRARY=lib))
     assert out.returncode == 0 and f"COMM_RANKS_OK {world}" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def _gpu_count():
+    import arrow_rs_amd as A_
+    return int(A_._lib.load().ah_device_count())
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_exchange_over_real_rccl_one_process_per_gpu(world, tmp_path):
+    """comm.hip over REAL RCCL / xGMI: `world` processes, rank r on GPU r, the unique id shipped through a file, every
+    rank comparing the reassembled result with the oracle's un-sharded filter (tests/comm_rccl_worker.py).  Arms itself
+    on a box with >= `world` GPUs; a gpurun box has one, where the N > 1 control flow is covered by the fake transport
+    above and real RCCL by the world-1 test."""
+    if _gpu_count() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {_gpu_count()}")
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "comm_rccl_worker.py"), str(r), str(world), str(tmp_path)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=1500)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"COMM_RCCL_RANK_OK {r}/{world}" in o, f"rank {r}:\n{o[-3000:]}"
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -308,6 +308,63 @@ def test_config2_add_wrapping_and_lt_every_row(ctx, oracle):
     assert sum(r[2] for r in res) == s.null_count() and sum(r[3] for r in res) == l.null_count()
 
 
+# ------------------------------------------------------------------------- the lazy predicate, 1e9 rows
+def test_lazy_predicate_filter_every_row(ctx, oracle):
+    """`filter(a, and_kleene(lt(a, 0), gt_eq(b, 0.0)))` with the comparisons evaluated inside the filter's count pass
+    (ah_filter_predicate_build_expr) at 1e9 rows: every output row against the oracle's MATERIALISED chain
+    (orc_compare x 2 -> orc_boolean_binary(and_kleene) -> orc_filter), null operands on both sides, NaN / inf / -0
+    rows patched into b."""
+    n = 1_000_000_000
+    a = B.gen_i64_column(A, ctx, n, 42, 0.9, 0)
+    b = B.gen_f64_column(A, ctx, n, 52, 0.9, 0)
+    sa, sb = _patch_specials(np.zeros(4096), np.zeros(4096))
+    ctx.check(ctx.lib.ah_memcpy_htod(ctx.handle, b.values.ptr, sb.ctypes.data, sb.nbytes))
+    s0, s1 = A.Scalar.new(0, A.Int64, ctx), A.Scalar.new(0.0, A.Float64, ctx)
+    pred = K.FilterBuilder.from_terms([("lt", a, s0), ("gt_eq", b, s1)], ["and_kleene"]).build()
+    f = pred.filter(a)
+    K_dev = f.length
+    assert K_dev == pred.count() and 0.15 < K_dev / n < 0.25
+    z0, z1 = np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.float64)
+
+    def work(job):
+        c0, rows = job
+        va, vab = _gen_i64_chunk(oracle, c0, rows, 42, 0.9)
+        vb, vbb = _gen_f64_chunk(oracle, c0, rows, 52, 0.9)
+        if c0 == 0:
+            _patch_specials(np.zeros(4096), vb)
+        av, bv = _view(L.AH_INT64, rows, va, vab), _view(L.AH_FLOAT64, rows, vb, vbb)
+        m1, m2, m = orc.Out(), orc.Out(), orc.Out()
+        assert oracle.lib.orc_compare(2, C.byref(av), 0, C.byref(_view(L.AH_INT64, 1, z0, None, 0)), 1, C.byref(m1)) == 0
+        assert oracle.lib.orc_compare(5, C.byref(bv), 0, C.byref(_view(L.AH_FLOAT64, 1, z1, None, 0)), 1, C.byref(m2)) == 0
+
+        def as_view(o):
+            v = orc.View()
+            v.type, v.length, v.null_count, v.values, v.validity = L.AH_BOOL, o.length, o.null_count, o.values, o.validity
+            return v
+        assert oracle.lib.orc_boolean_binary(3, C.byref(as_view(m1)), C.byref(as_view(m2)), C.byref(m)) == 0
+        out = orc.Out()
+        assert oracle.lib.orc_filter(C.byref(av), C.byref(as_view(m)), C.byref(out)) == 0
+        k = out.length
+        vals = _out_bytes(out.values, k * 8).view(np.int64)
+        valid = _valid_of(out, k)
+        nulls = out.null_count
+        for o in (m1, m2, m, out):
+            oracle.lib.orc_release(C.byref(o))
+        return k, vals, valid, nulls
+
+    with cf.ThreadPoolExecutor(NT) as ex:
+        parts = list(ex.map(work, _chunks(n)))
+    assert sum(p_[0] for p_ in parts) == K_dev, "selected row count"
+    assert sum(p_[3] for p_ in parts) == f.null_count(), "null_count"
+    dvals = _dev_bytes(ctx, f.values, 0, K_dev * 8).view(np.int64)
+    dvalid = _unpack(_dev_bytes(ctx, f.validity, 0, (K_dev + 7) // 8), K_dev) if f.validity is not None else np.ones(K_dev, dtype=bool)
+    off = 0
+    for k, vals, valid, _ in parts:
+        assert np.array_equal(dvalid[off:off + k], valid), f"validity differs in output rows [{off}, {off + k})"
+        assert np.array_equal(dvals[off:off + k][valid], vals[valid]), f"values differ in output rows [{off}, {off + k})"
+        off += k
+
+
 # ------------------------------------------------------------------------------------------- configs[3]
 def test_config3_cast_chain_every_row(ctx, oracle):
     n = 1 << 29
