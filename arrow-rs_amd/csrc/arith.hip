@@ -147,8 +147,8 @@ __global__ void __launch_bounds__(256) arith_kernel(ArithArgs a) {
       if (vi < nvec) {
         int64_t i = vi * V;
         if (i + V <= a.len) {
-          if (!a.l_scalar) lv[u] = ah_ld_stream((const VT*)(lp + i));
-          if (!op_is_unary(OP) && !a.r_scalar) rv[u] = ah_ld_stream((const VT*)(rp + i));
+          if (!a.l_scalar) lv[u] = ah_ld_stream<ah_nt_l(false)>((const VT*)(lp + i));
+          if (!op_is_unary(OP) && !a.r_scalar) rv[u] = ah_ld_stream<ah_nt_l(false)>((const VT*)(rp + i));
         } else {
 #pragma unroll
           for (int e = 0; e < V; ++e) {
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) arith_kernel(ArithArgs a) {
         }
         ov.e[e] = o;
       }
-      if (i + V <= a.len) ah_st_stream((VT*)(op + i), ov);
+      if (i + V <= a.len) ah_st_stream<ah_nt_s(false)>((VT*)(op + i), ov);
       else
         for (int e = 0; e < V; ++e) if (i + e < a.len) op[i + e] = ov.e[e];
     }

@@ -12,7 +12,7 @@ namespace {
 
 __global__ void __launch_bounds__(256) bitmap_op_kernel(int op, BitView a, BitView b, BitView c, BitView d,
                                                         int64_t len, unsigned long long* out,
-                                                        unsigned long long* partials) {
+                                                        unsigned long long* ticket, uint64_t* mail, uint64_t seq) {
   int64_t nwords = (len + 63) >> 6;
   unsigned long long acc = 0;
   for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * 256) {
@@ -53,12 +53,12 @@ __global__ void __launch_bounds__(256) bitmap_op_kernel(int op, BitView a, BitVi
     out[w] = r;
     acc += __popcll(r);
   }
-  if (partials) {
+  if (ticket) {  // counted: the last block to arrive posts the popcount to the host (pinned slot 8)
     acc = wave_reduce_add64(acc);
     __shared__ unsigned long long sm[4];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+    if (threadIdx.x == 0) ah_ticket_post(ticket, sm[0] + sm[1] + sm[2] + sm[3], gridDim.x, mail, 8, seq);
   }
 }
 
@@ -77,10 +77,12 @@ __global__ void __launch_bounds__(1024) bm_sum_kernel(const unsigned long long* 
   }
 }
 
-// dst |= src bits placed at dst_off (dst range pre-zeroed); one thread per dst word
+// dst |= src bits placed at dst_off (dst range pre-zeroed); one thread per dst word.  partials: per-block counts for
+// the no-wait accumulate form; ticket: the counted form (last block posts the popcount to pinned slot 8)
 __global__ void __launch_bounds__(256) set_bits_kernel(unsigned long long* dst, int64_t dst_off,
                                                        BitView src, int64_t len,
-                                                       unsigned long long* partials) {
+                                                       unsigned long long* partials, unsigned long long* ticket = nullptr,
+                                                       uint64_t* mail = nullptr, uint64_t seq = 0) {
   int64_t first = dst_off >> 6, last = (dst_off + len - 1) >> 6;
   unsigned long long acc = 0;
   for (int64_t w = first + (int64_t)blockIdx.x * 256 + threadIdx.x; w <= last;
@@ -90,12 +92,16 @@ __global__ void __launch_bounds__(256) set_bits_kernel(unsigned long long* dst, 
     if (v) dst[w] |= v;
     acc += __popcll(v);
   }
-  if (partials) {
+  if (partials || ticket) {
     acc = wave_reduce_add64(acc);
     __shared__ unsigned long long sm[4];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+    if (threadIdx.x == 0) {
+      const unsigned long long tot = sm[0] + sm[1] + sm[2] + sm[3];
+      if (partials) partials[blockIdx.x] = tot;
+      else ah_ticket_post(ticket, tot, gridDim.x, mail, 8, seq);
+    }
   }
 }
 
@@ -109,16 +115,17 @@ ah_status ah_bitmap_op(ah_context* ctx, int op, BitView a, BitView b, BitView c,
   }
   int64_t nwords = (len + 63) >> 6;
   int grid = (int)std::min<int64_t>(4096, ah_ceil_div(nwords, 256));
-  unsigned long long* part = nullptr;
-  if (set_bits) AH_TRY(ah_pool_alloc(ctx, (size_t)(grid + 1) * 8, (void**)&part));
-  bitmap_op_kernel<<<grid, 256, 0, ctx->stream>>>(op, a, b, c, d, len, out_words, part);
-  if (set_bits) {
-    bm_sum_kernel<<<1, 1024, 0, ctx->stream>>>(part, grid, part + grid);
-    hipError_t e = ah_d2h_wait(ctx, ctx->pinned + 8, part + grid, 8);
-    ah_pool_free(ctx, part);
-    AH_HIP(ctx, e);
-    *set_bits = (int64_t)ctx->pinned[8];
+  if (!set_bits) {
+    bitmap_op_kernel<<<grid, 256, 0, ctx->stream>>>(op, a, b, c, d, len, out_words, nullptr, nullptr, 0);
+    return AH_OK;
   }
+  // counted: ONE launch — the kernel's last block posts the popcount (and with it "the stream got here") to the host
+  const uint64_t seq = ah_mail_next(ctx);
+  bitmap_op_kernel<<<grid, 256, 0, ctx->stream>>>(op, a, b, c, d, len, out_words, ctx->scratch + AH_TICKET_COUNT, ctx->pinned_dev, seq);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
+  AH_HIP(ctx, e);
+  *set_bits = (int64_t)ctx->pinned[8];
   return AH_OK;
 }
 
@@ -170,16 +177,16 @@ extern "C" ah_status ah_bitmap_set_bits(ah_context* ctx, uint8_t* dst, int64_t d
   hipSetDevice(ctx->device);
   int64_t first = dst_bit_offset >> 6, last = (dst_bit_offset + len - 1) >> 6;
   int grid = (int)std::min<int64_t>(4096, ah_ceil_div(last - first + 1, 256));
-  unsigned long long* part = nullptr;
-  if (set_bits) AH_TRY(ah_pool_alloc(ctx, (size_t)(grid + 1) * 8, (void**)&part));
-  set_bits_kernel<<<grid, 256, 0, ctx->stream>>>((unsigned long long*)dst, dst_bit_offset,
-                                                 make_bitview(src, src_bit_offset), len, part);
-  if (set_bits) {
-    bm_sum_kernel<<<1, 1024, 0, ctx->stream>>>(part, grid, part + grid);
-    hipError_t e = ah_d2h_wait(ctx, ctx->pinned + 8, part + grid, 8);
-    ah_pool_free(ctx, part);
-    AH_HIP(ctx, e);
-    *set_bits = (int64_t)ctx->pinned[8];
+  if (!set_bits) {
+    set_bits_kernel<<<grid, 256, 0, ctx->stream>>>((unsigned long long*)dst, dst_bit_offset, make_bitview(src, src_bit_offset), len, nullptr);
+    return AH_OK;
   }
+  const uint64_t seq = ah_mail_next(ctx);
+  set_bits_kernel<<<grid, 256, 0, ctx->stream>>>((unsigned long long*)dst, dst_bit_offset, make_bitview(src, src_bit_offset), len, nullptr,
+                                                 ctx->scratch + AH_TICKET_COUNT, ctx->pinned_dev, seq);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
+  AH_HIP(ctx, e);
+  *set_bits = (int64_t)ctx->pinned[8];
   return AH_OK;
 }

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) cast_stream_kernel(CastArgs a) {
     const int64_t i = ((g0 + gi) * 64 + lane) * V;
     vb[gi] = 0;
     if (i + V <= a.len) {
-      iv[gi] = ah_ld_stream((const VI*)(ip + i));
+      iv[gi] = ah_ld_stream<ah_nt_l(true)>((const VI*)(ip + i));
     } else {
 #pragma unroll
       for (int e = 0; e < V; ++e) iv[gi].e[e] = (i + e < a.len) ? ip[i + e] : I{};
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) cast_stream_kernel(CastArgs a) {
       ballots[e] = __ballot(valid && (ok || !a.safe) && (i + e < a.len));
     }
     if (i + V <= a.len) {
-      ah_st_stream((VO*)(op + i), ov);
+      ah_st_stream<ah_nt_s(true)>((VO*)(op + i), ov);
     } else {
 #pragma unroll
       for (int e = 0; e < V; ++e)

@@ -91,8 +91,8 @@ __global__ void __launch_bounds__(256) compare_kernel(CmpArgs a) {
     for (int gi = 0; gi < CMP_G; ++gi) {  // all loads of the wave's CMP_G groups go out first
       int64_t i = ((g0 + gi) * 64 + lane) * V;
       if (i + V <= a.len) {
-        if (!a.l_scalar) lv[gi] = ah_ld_stream((const VT*)(lp + i));
-        if (!a.r_scalar) rv[gi] = ah_ld_stream((const VT*)(rp + i));
+        if (!a.l_scalar) lv[gi] = ah_ld_stream<ah_nt_l(false)>((const VT*)(lp + i));
+        if (!a.r_scalar) rv[gi] = ah_ld_stream<ah_nt_l(false)>((const VT*)(rp + i));
       } else {
 #pragma unroll
         for (int e = 0; e < V; ++e) {

@@ -22,8 +22,12 @@ extern "C" ah_status ah_filter_predicate_apply_into_acc(ah_context*, const ah_fi
 extern "C" ah_status ah_filter_predicates_build(ah_context*, int32_t, const ah_array_view*, ah_filter_predicate**);
 // filter.hip: the columns of one batch through one scatter launch (AH_NOT_YET_IMPLEMENTED: shapes differ, nothing done)
 ah_status ah_filter_apply_into_acc_cols(ah_context*, const ah_filter_predicate*, int, const ah_array_view*, void* const*,
-                                        uint8_t* const*, int64_t, unsigned long long*, unsigned long long*, int64_t, int64_t,
-                                        int, double);
+                                        uint8_t* const*, int64_t, unsigned long long*, int64_t, int64_t, int, double);
+// filter.hip: up to 8 (batch, window) segments through one scatter launch
+ah_status ah_filter_apply_multi(ah_context*, int, const ah_filter_predicate* const*, const ah_array_view* const*, const int64_t*,
+                                const int64_t*, const int64_t*, int, void* const*, uint8_t* const*, unsigned long long*);
+// filter.hip: ncols x 64 NULL-row counters -> host (summed per column), counters back to zero; one launch, one wait
+ah_status ah_coalesce_read_nulls(ah_context*, unsigned long long*, int, uint64_t*);
 // filter.hip: ah_filter_predicate_build in two halves (enqueue the count pass / wait for K)
 ah_status ah_filter_predicate_begin(ah_context*, const ah_array_view*, ah_filter_predicate**, uint64_t*, bool*);
 ah_status ah_filter_predicate_end(ah_context*, ah_filter_predicate*, uint64_t, bool);
@@ -54,7 +58,8 @@ struct ah_coalescer {
   std::vector<CoColumn> cols;
   int64_t buffered = 0;
   std::deque<CoBatch> completed;
-  uint64_t* acc = nullptr;  // device: appended-null count per column of the in-progress batch
+  uint64_t* acc = nullptr;  // device: 64 appended-null counters per column of the in-progress batch (scatter tiles spread
+                            // their atomics over them; copies add to the first); summed once per finished batch
   double selectivity = 0.1;  // of the last filtered push: picks the speculative scatter's load-predication mode
   bool failed = false;       // a device error hit after rows had been enqueued into the in-progress batch
 };
@@ -68,9 +73,16 @@ ah_status ensure_capacity(ah_context* ctx, ah_coalescer* co) {  // allocate on f
     c.bbytes = ah_bitmap_bytes(co->target);
     AH_TRY(ah_out_alloc(ctx, c.vbytes, &c.values));
     void* b = nullptr;
-    AH_TRY(ah_out_alloc(ctx, c.bbytes, &b));
+    ah_status st = ah_out_alloc(ctx, c.bbytes, &b);
+    if (st == AH_OK && hipMemsetAsync(b, 0, c.bbytes, ctx->stream) != hipSuccess)
+      st = ah_fail(ctx, AH_HIP_ERROR, "coalescer bitmap reset failed");
+    if (st != AH_OK) {  // never leave a column with values but no validity: the next call would skip it
+      ah_out_free(ctx, b, c.bbytes);
+      ah_out_free(ctx, c.values, c.vbytes);
+      c.values = nullptr;
+      return st;
+    }
     c.validity = (uint8_t*)b;
-    AH_HIP(ctx, hipMemsetAsync(c.validity, 0, c.bbytes, ctx->stream));
   }
   return AH_OK;
 }
@@ -79,7 +91,7 @@ ah_status finish_buffered(ah_context* ctx, ah_coalescer* co) {  // coalesce.rs:5
   if (co->buffered == 0) return AH_OK;
   std::vector<uint64_t> nulls((size_t)co->ncols, 0);
   // the ONE wait of this output batch; it also means every scatter / copy into it has finished
-  AH_TRY(ah_read_words(ctx, co->acc, co->ncols, nulls.data(), 1));
+  AH_TRY(ah_coalesce_read_nulls(ctx, (unsigned long long*)co->acc, co->ncols, nulls.data()));
   CoBatch b;
   b.rows = co->buffered;
   b.cols.resize((size_t)co->ncols);
@@ -108,9 +120,16 @@ ah_status finish_buffered(ah_context* ctx, ah_coalescer* co) {  // coalesce.rs:5
 
 ah_status copy_rows_all(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns, int64_t offset, int64_t len) {
   AH_TRY(ensure_capacity(ctx, co));
-  for (int i = 0; i < co->ncols; ++i)
-    AH_TRY(ah_copy_rows_into_acc(ctx, &columns[i], offset, len, co->cols[i].values, co->cols[i].validity, co->buffered,
-                                 co->acc + i));
+  for (int i = 0; i < co->ncols; ++i) {
+    const ah_status st = ah_copy_rows_into_acc(ctx, &columns[i], offset, len, co->cols[i].values, co->cols[i].validity,
+                                               co->buffered, co->acc + (size_t)i * 64);
+    if (st != AH_OK) {
+      // earlier columns already have these rows (and their null counters bumped) while `buffered` has not advanced: a
+      // retried push would double-count — the in-progress batch cannot be trusted any more
+      if (i > 0) co->failed = true;
+      return st;
+    }
+  }
   return AH_OK;
 }
 
@@ -209,8 +228,8 @@ extern "C" ah_status ah_coalescer_create(ah_context* ctx, int32_t n_columns, con
     co->cols[i].type = types[i];
     co->cols[i].width = w;
   }
-  // acc: one appended-null counter per column, then 64 zero-state valid-row counters per column (fused scatter)
-  const size_t acc_bytes = (size_t)n_columns * 8 * (1 + 64);
+  // acc: 64 appended-null counters per column
+  const size_t acc_bytes = (size_t)n_columns * 8 * 64;
   ah_status st = ah_pool_alloc(ctx, acc_bytes, (void**)&co->acc);
   if (st == AH_OK && hipMemsetAsync(co->acc, 0, acc_bytes, ctx->stream) != hipSuccess)
     st = ah_fail(ctx, AH_HIP_ERROR, "coalescer counter reset failed");
@@ -293,8 +312,7 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
       for (int i = 0; i < co->ncols; ++i) dv[i] = co->cols[i].values, db[i] = co->cols[i].validity;
       const int64_t take = std::min(co->target - co->buffered, selected - done);
       const ah_status fs = ah_filter_apply_into_acc_cols(ctx, p, co->ncols, columns, dv, db, co->buffered,
-                                                         (unsigned long long*)co->acc,
-                                                         (unsigned long long*)(co->acc + co->ncols), done, done + take, 0, 0.0);
+                                                         (unsigned long long*)co->acc, done, done + take, 0, 0.0);
       if (fs == AH_NOT_YET_IMPLEMENTED && done == 0) break;  // shapes differ: the per-column paths below
       if (fs != AH_OK) return fs == AH_NOT_YET_IMPLEMENTED ? ah_fail(ctx, AH_INVALID_ARGUMENT, "coalescer: column shapes changed") : fs;
       co->buffered += take;
@@ -340,9 +358,11 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
     return st;
   }
   st = ensure_capacity(ctx, co);
-  for (int i = 0; i < co->ncols && st == AH_OK; ++i)
+  for (int i = 0; i < co->ncols && st == AH_OK; ++i) {
     st = ah_filter_predicate_apply_into_acc(ctx, p, &columns[i], co->cols[i].values, co->cols[i].validity, co->buffered,
-                                            co->acc + i);
+                                            co->acc + (size_t)i * 64);
+    if (st != AH_OK && i > 0) co->failed = true;  // some columns have the rows, `buffered` does not
+  }
   if (st == AH_OK) {
     co->buffered += selected;
     if (co->buffered >= co->target) st = finish_buffered(ctx, co);
@@ -379,8 +399,7 @@ extern "C" ah_status ah_coalescer_push_batch_with_filter(ah_context* ctx, ah_coa
       for (int i = 0; i < co->ncols; ++i) dv[i] = co->cols[i].values, db[i] = co->cols[i].validity;
       room = co->target - co->buffered;
       const ah_status fs = ah_filter_apply_into_acc_cols(ctx, p, co->ncols, columns, dv, db, co->buffered,
-                                                         (unsigned long long*)co->acc,
-                                                         (unsigned long long*)(co->acc + co->ncols), 0, room, 1, co->selectivity);
+                                                         (unsigned long long*)co->acc, 0, room, 1, co->selectivity);
       if (fs == AH_OK) speculated = true;
       else if (fs != AH_NOT_YET_IMPLEMENTED) st = fs;
     }
@@ -420,15 +439,76 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_
     if (num_rows[i] < 0) return AH_INVALID_ARGUMENT;
     AH_TRY(check_filter(ctx, co, columns + (size_t)i * co->ncols, num_rows[i], &filters[i]));
   }
+  // Grouped scatter: when there is no bypass limit and every column of every batch has the same shape (one width,
+  // all nullable), the batches that land in one output window leave through ONE launch (up to 8 per launch) — 2^24-row
+  // batches pay the ramp and tail of a launch once per window instead of once per batch.  Same output batches, same order.
+  bool fusable = co->limit < 0 && co->ncols <= 8 && n > 1;
+  for (int i = 0; i < n && fusable; ++i)
+    for (int k = 0; k < co->ncols; ++k) {
+      const ah_array_view& v = columns[(size_t)i * co->ncols + k];
+      if (co->cols[k].width != co->cols[0].width || !v.validity || v.null_count == 0 || filters[i].length > v.length) fusable = false;
+    }
   ah_status st = AH_OK;
   for (int base = 0; base < n && st == AH_OK; base += 128) {
     const int m = std::min(128, n - base);
     std::vector<ah_filter_predicate*> preds((size_t)m, nullptr);
     st = ah_filter_predicates_build(ctx, m, filters + base, preds.data());
-    for (int j = 0; j < m && st == AH_OK; ++j) {
-      const int i = base + j;
-      st = push_filtered_impl(ctx, co, columns + (size_t)i * co->ncols, num_rows[i], &filters[i], preds[j], tags ? tags[i] : 0,
-                              bypassed ? &bypassed[i] : nullptr);
+    if (st == AH_OK && fusable) {
+      const ah_filter_predicate* seg_p[8];
+      const ah_array_view* seg_c[8];
+      int64_t seg_lo[8], seg_hi[8], seg_base[8];
+      int nseg = 0;
+      int64_t virt = co->buffered;  // rows of the in-progress batch once the pending segments have run
+      bool enq = false;
+      auto flush = [&]() -> ah_status {
+        if (nseg == 0) return AH_OK;
+        void* dv[8];
+        uint8_t* db[8];
+        for (int k = 0; k < co->ncols; ++k) dv[k] = co->cols[k].values, db[k] = co->cols[k].validity;
+        const ah_status fs = ah_filter_apply_multi(ctx, nseg, seg_p, seg_c, seg_lo, seg_hi, seg_base, co->ncols, dv, db,
+                                                   (unsigned long long*)co->acc);
+        nseg = 0;
+        if (fs == AH_OK) enq = true;
+        co->buffered = virt;
+        return fs;
+      };
+      for (int j = 0; j < m && st == AH_OK; ++j) {
+        const int i = base + j;
+        const ah_array_view* cols_i = columns + (size_t)i * co->ncols;
+        const int64_t selected = ah_filter_predicate_count(preds[j]);
+        if (selected == 0) continue;
+        if (selected == num_rows[i] && filters[i].length == num_rows[i]) {  // every row: plain copies (coalesce.rs:229 -> push_batch)
+          st = flush();
+          if (st == AH_OK) st = push_batch_impl(ctx, co, cols_i, num_rows[i], tags ? tags[i] : 0, bypassed ? &bypassed[i] : nullptr);
+          virt = co->buffered;
+          continue;
+        }
+        int64_t done = 0;
+        while (done < selected && st == AH_OK) {
+          if (nseg == 0) st = ensure_capacity(ctx, co);
+          if (st != AH_OK) break;
+          const int64_t take = std::min(co->target - virt, selected - done);
+          seg_p[nseg] = preds[j], seg_c[nseg] = cols_i, seg_lo[nseg] = done, seg_hi[nseg] = done + take, seg_base[nseg] = virt;
+          ++nseg;
+          virt += take;
+          done += take;
+          if (virt >= co->target) {  // the window is full: run its segments, hand the batch over
+            st = flush();
+            if (st == AH_OK) st = finish_buffered(ctx, co);
+            virt = co->buffered;
+          } else if (nseg == 8) {
+            st = flush();
+          }
+        }
+      }
+      if (st == AH_OK) st = flush();
+      if (st != AH_OK && enq) co->failed = true;  // rows were enqueued that the bookkeeping may not cover
+    } else {
+      for (int j = 0; j < m && st == AH_OK; ++j) {
+        const int i = base + j;
+        st = push_filtered_impl(ctx, co, columns + (size_t)i * co->ncols, num_rows[i], &filters[i], preds[j], tags ? tags[i] : 0,
+                                bypassed ? &bypassed[i] : nullptr);
+      }
     }
     for (auto* p : preds) ah_filter_predicate_free(ctx, p);
   }

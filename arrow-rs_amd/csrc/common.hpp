@@ -99,8 +99,9 @@ ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...);
   } while (0)
 
 constexpr int AH_MAIL_FLAG = 255;     // index of the sequence word in ctx->pinned
-constexpr int AH_SCRATCH_WORDS = 520;  // 8 x 64 zero-state counters (one set per column of a fused launch) + 8 ones-state position words
-constexpr int AH_SCRATCH_ONES = 512;
+constexpr int AH_SCRATCH_WORDS = 560;  // 8 x 64 zero-state counters (one set per column of a fused launch) + 8 ones-state position words + 40 zero-state ticket words
+constexpr int AH_SCRATCH_ONES = 512;     // [512, 520): all ones between calls
+constexpr int AH_SCRATCH_TICKETS = 520;  // [520, 560): zero between calls (filter_small.hip's completion tickets)
 
 // enqueue a device -> pinned-slot copy (a one-wave kernel, stream-ordered like hipMemcpyAsync); `pinned_dst` must
 // point into ctx->pinned and `bytes` is a multiple of 8
@@ -329,23 +330,28 @@ __device__ __forceinline__ void ah_mail_post(uint64_t* mail, uint64_t seq) {
   __hip_atomic_store(mail + AH_MAIL_FLAG, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// Once-read / once-written streams: `ah_ld_stream` / `ah_st_stream` are plain vector accesses, or
-// the non-temporal forms (`global_load ... nt` / `global_store ... nt`) when the library is built with -DAH_NT_LOADS=1 /
-// -DAH_NT_STORES=1.  The A/B over the four streaming kernels is profiles/r03_nt_ablation.md; the default build keeps what won.
+// Once-read / once-written streams: `ah_ld_stream<NT>` / `ah_st_stream<NT>` are plain vector
+// accesses (NT = false) or the non-temporal forms (`global_load ... nt` / `global_store ... nt`).  Which kernel uses
+// which was settled by an A/B on MI355X (profiles/r03_nt_ablation.md: -DAH_NT_LOADS=1 / -DAH_NT_STORES=1 builds of all
+// four streaming kernels): the numeric cast gains 7 % with both, the filter scatter 3-4 % with nt stores, arithmetic and
+// compare gain nothing (and lose 1-5 % with nt stores alone).  The per-kernel defaults below are that outcome; the -D
+// overrides remain for re-running the ablation.
 #ifndef AH_NT_LOADS
-#define AH_NT_LOADS 0
+#define AH_NT_LOADS -1  // -1: per-kernel default; 0 / 1: force for every streaming kernel
 #endif
 #ifndef AH_NT_STORES
-#define AH_NT_STORES 0
+#define AH_NT_STORES -1
 #endif
+constexpr bool ah_nt_l(bool kernel_default) { return AH_NT_LOADS < 0 ? kernel_default : AH_NT_LOADS != 0; }
+constexpr bool ah_nt_s(bool kernel_default) { return AH_NT_STORES < 0 ? kernel_default : AH_NT_STORES != 0; }
 template <int BYTES> struct ah_raw_vec;
 template <> struct ah_raw_vec<1> { typedef uint8_t type; };
 template <> struct ah_raw_vec<2> { typedef uint16_t type; };
 template <> struct ah_raw_vec<4> { typedef uint32_t type; };
 template <> struct ah_raw_vec<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
 template <> struct ah_raw_vec<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
-template <typename VT> __device__ __forceinline__ VT ah_ld_stream(const VT* p) {
-  if constexpr (AH_NT_LOADS && (sizeof(VT) == 1 || sizeof(VT) == 2 || sizeof(VT) == 4 || sizeof(VT) == 8 || sizeof(VT) == 16)) {
+template <bool NT, typename VT> __device__ __forceinline__ VT ah_ld_stream(const VT* p) {
+  if constexpr (NT && (sizeof(VT) == 1 || sizeof(VT) == 2 || sizeof(VT) == 4 || sizeof(VT) == 8 || sizeof(VT) == 16)) {
     using R = typename ah_raw_vec<sizeof(VT)>::type;
     const R x = __builtin_nontemporal_load((const R*)p);
     VT r;
@@ -355,8 +361,8 @@ template <typename VT> __device__ __forceinline__ VT ah_ld_stream(const VT* p) {
     return *p;
   }
 }
-template <typename VT> __device__ __forceinline__ void ah_st_stream(VT* p, const VT& v) {
-  if constexpr (AH_NT_STORES && (sizeof(VT) == 1 || sizeof(VT) == 2 || sizeof(VT) == 4 || sizeof(VT) == 8 || sizeof(VT) == 16)) {
+template <bool NT, typename VT> __device__ __forceinline__ void ah_st_stream(VT* p, const VT& v) {
+  if constexpr (NT && (sizeof(VT) == 1 || sizeof(VT) == 2 || sizeof(VT) == 4 || sizeof(VT) == 8 || sizeof(VT) == 16)) {
     using R = typename ah_raw_vec<sizeof(VT)>::type;
     R x;
     __builtin_memcpy(&x, &v, sizeof(VT));
@@ -365,6 +371,22 @@ template <typename VT> __device__ __forceinline__ void ah_st_stream(VT* p, const
     *p = v;
   }
 }
+
+// Completion ticket of a counting kernel: ONE thread per block hands in the block's partial count; the block that
+// arrives last stores the grand total into the host's pinned slot and posts the mailbox sequence word — the count
+// read-back needs no partials buffer, no sum kernel and no copy kernel (three launches fewer per call, which is what a
+// 10^4-row batch pays for).  `ticket` is a zero-between-calls word of ctx->scratch: {arrivals : 16 | count : 48}.
+__device__ __forceinline__ void ah_ticket_post(unsigned long long* ticket, unsigned long long count, unsigned nblocks,
+                                               uint64_t* mail, int slot, uint64_t seq) {
+  const unsigned long long mine = 1ull | (count << 16);
+  const unsigned long long old = atomicAdd(ticket, mine);
+  if ((unsigned)(old & 0xFFFFull) == nblocks - 1) {
+    *ticket = 0;  // self-cleaning: every other block has arrived
+    __hip_atomic_store(mail + slot, (uint64_t)((old + mine) >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    ah_mail_post(mail, seq);
+  }
+}
+constexpr int AH_TICKET_COUNT = AH_SCRATCH_TICKETS + 32;  // the word bitmap.hip / context.hip's counting kernels use
 
 // ---- shared bitmap machinery (bitmap.hip)
 enum ah_bitmap_opcode {

@@ -44,9 +44,7 @@ constexpr int CHUNK_ROWS = 1024;            // count-pass granule (16 mask words
 constexpr int GROUP_CHUNKS = 1024;          // chunks per count block
 constexpr int SCATTER_THREADS = 256;
 
-__host__ __device__ constexpr int tile_rows(int width) {
-  return width <= 8 ? 4096 : (width == 16 ? 2048 : 1024);
-}
+// (tile_rows: filter_internal.hpp)
 
 // ------------------------------------------------------------------ K1
 __global__ void __launch_bounds__(1024) filter_count_kernel(BitView mask, BitView mask_valid,
@@ -106,6 +104,10 @@ __global__ void __launch_bounds__(1024) filter_count_kernel(BitView mask, BitVie
 // 1024-thread block per 1 Mi rows — 16 blocks on 256 CUs for a 2^24-row batch (21 us).  Here a block is ONE wave that
 // owns 64 chunks (65 536 rows), so the same batch spreads over 256 blocks; the group granule becomes 64 chunks
 // (`group_shift` 6 instead of 10) and the scatter reads its prefix with that shift.
+// (Folding K2 in was tried twice and dropped: with release / acquire fences in round 2 — 16.7 us against 6.5 + 3.9 us for
+// the two launches — and in round 3 fence-free, every block adding {1 arrival, its count} to one 64-bit ticket whose last
+// arriver posts K, the scatter summing the group totals itself: the count went from 6.4 to 11.8 us (256 same-address
+// atomics + the system-scope post) and every scatter tile paid an extra dependent L2 round trip, 49 -> 54 us per launch.)
 __global__ void __launch_bounds__(64) filter_count_small_kernel(BitView mask, BitView mask_valid, int64_t len,
                                                                uint32_t* chunk_prefix, uint32_t* group_total) {
   __shared__ uint32_t s_cnt[64];
@@ -252,22 +254,7 @@ __global__ void __launch_bounds__(64) filter_finish_kernel(unsigned long long* s
 }
 
 // ------------------------------------------------------------------ K3
-template <int W> struct Elem;
-template <> struct Elem<1> { using type = uint8_t; };
-template <> struct Elem<2> { using type = uint16_t; };
-template <> struct Elem<4> { using type = uint32_t; };
-template <> struct Elem<8> { using type = uint64_t; };
-// 16- and 32-byte natives as clang vector types: first-class values the optimizer keeps in registers (as structs of
-// four dwords the per-thread arrays of them stayed in scratch: 144 bytes per thread in the Decimal128 / i256 variants)
-typedef uint32_t E16 __attribute__((ext_vector_type(4)));
-typedef uint32_t E32 __attribute__((ext_vector_type(8), aligned(16)));  // i256 buffers are only 16-byte aligned
-template <> struct Elem<16> { using type = E16; };
-template <> struct Elem<32> { using type = E32; };
-
-template <int W, int V> struct alignas((W * V >= 16) ? 16 : W * V) Vec {
-  using T = typename Elem<W>::type;
-  union { T e[V]; } u;
-};
+// (Elem / Vec: filter_internal.hpp)
 
 struct ScatterArgs {
   const void* values;
@@ -275,6 +262,7 @@ struct ScatterArgs {
   int64_t len;  // predicate length
   const uint32_t* chunk_prefix;
   const unsigned long long* group_prefix;
+  int nulls_mode;  // 1: the slots accumulate NULL rows appended (window rows - valid rows) instead of valid rows
   void* out_values;
   unsigned long long* out_valid;   // zero-initialised u64 words
   unsigned long long* valid_slots; // VALID_SLOTS zero-initialised counters (valid selected rows)
@@ -299,10 +287,7 @@ constexpr int SCATTER_MAX_COLS = 8;
 
 constexpr int VALID_SLOTS = 64;
 
-// staging capacity in elements: 16 KiB of LDS per workgroup => 8 workgroups / CU
-__host__ __device__ constexpr int stage_cap(int width) {
-  return width <= 8 ? 2048 : (width == 16 ? 1024 : 512);
-}
+// (stage_cap: filter_internal.hpp)
 
 // WIDTH == 0: bit-only variant (Boolean values / validity-only): compacts the
 // `vvalid` stream; no value loads.
@@ -310,8 +295,12 @@ __host__ __device__ constexpr int stage_cap(int width) {
 // with no selected row are never fetched (pays below ~30% selectivity).
 // 86 VGPRs = 5 workgroups per CU.  Forcing 6 or 8 through __launch_bounds__(256, w) spills the tile's values to scratch and
 // is slower (measured r02: 1.48 ms -> 1.85 ms at w = 6, 3.28 ms at w = 8): the registers ARE the tile.
+// One tile of one column: the body shared by the single-batch kernel and the multi-batch kernel (BatchCoalescer's
+// grouped push: several input batches scattered into one output window by ONE launch).
 template <int W, int V, bool HAS_VALID, bool SKIP>
-__global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(ScatterArgs a) {
+__device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile, const void* c_values, BitView c_vvalid,
+                                             void* c_out_values, unsigned long long* c_out_valid,
+                                             unsigned long long* c_valid_slots) {
   constexpr int WE = W == 0 ? 1 : W;
   constexpr int T = tile_rows(WE);
   constexpr int CAP = stage_cap(WE);
@@ -331,30 +320,6 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
   __shared__ uint8_t s_flag[HAS_VALID ? CAP : 1];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // this workgroup's column (uniform: scalar selects)
-  const void* c_values = a.values;
-  BitView c_vvalid = a.vvalid;
-  void* c_out_values = a.out_values;
-  unsigned long long* c_out_valid = a.out_valid;
-  unsigned long long* c_valid_slots = a.valid_slots;
-  if (blockIdx.y) {
-    const ScatterArgs::Col& c = a.more[blockIdx.y - 1];
-    c_values = c.values;
-    c_vvalid = c.vvalid;
-    c_out_values = c.out_values;
-    c_out_valid = c.out_valid;
-    c_valid_slots = c.valid_slots;
-  }
-  // XCD-aware tile mapping: workgroup b lands on XCD b % 8 (observed dispatch order,
-  // used for speed only), so XCD x walks the contiguous tile range [x*per, (x+1)*per):
-  // neighbouring tiles, which share output cache lines and boundary bitmap words,
-  // meet in ONE L2 instead of ping-ponging dirty lines between XCDs.
-  int64_t tile = blockIdx.x;
-  if (a.xcd_remap) {
-    const int64_t per = (a.ntiles + 7) >> 3;
-    tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile >= a.ntiles || (int64_t)(blockIdx.x >> 3) >= per) return;
-  }
   const int64_t row0 = tile * T;
 
   // 1. value loads (16 B per lane per load on the aligned path) go out first
@@ -364,7 +329,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       int64_t r = row0 + (int64_t)(l * SCATTER_THREADS + t) * V;
-      if (r < a.len) regs[l] = ah_ld_stream((const Vec<WE, V>*)(vp + r));
+      if (r < a.len) regs[l] = ah_ld_stream<ah_nt_l(false)>((const Vec<WE, V>*)(vp + r));
     }
   }
 
@@ -415,7 +380,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
     for (int l = 0; l < L; ++l) {
       int r0 = (l * SCATTER_THREADS + t) * V;
       uint32_t bits = (uint32_t)(s_m[r0 >> 6] >> (r0 & 63)) & VMASK;
-      if (bits) regs[l] = ah_ld_stream((const Vec<WE, V>*)(vp + row0 + r0));
+      if (bits) regs[l] = ah_ld_stream<ah_nt_l(false)>((const Vec<WE, V>*)(vp + row0 + r0));
     }
   }
 
@@ -461,7 +426,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
         ET* gbase = op - phase;                               // 16-byte aligned
         if (vfirst < vlast) {
           for (int j = vfirst + t; j < vlast; j += SCATTER_THREADS)
-            ah_st_stream((Vec<WE, EPV>*)(gbase + j * EPV), *(const Vec<WE, EPV>*)(s_vals + j * EPV));
+            ah_st_stream<ah_nt_s(true)>((Vec<WE, EPV>*)(gbase + j * EPV), *(const Vec<WE, EPV>*)(s_vals + j * EPV));
           if (t < vfirst * EPV - first) gbase[first + t] = s_vals[first + t];
           if (t < last - vlast * EPV) gbase[vlast * EPV + t] = s_vals[vlast * EPV + t];
         } else {
@@ -497,9 +462,94 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
     __syncthreads();
     if (t == 0) {
       uint32_t c = s_vc[0] + s_vc[1] + s_vc[2] + s_vc[3];
+      if (a.nulls_mode) c = (uint32_t)(hi_t - lo_t) - c;  // NULL rows this tile appended
       if (c) atomicAdd(&c_valid_slots[tile & (VALID_SLOTS - 1)], (unsigned long long)c);
     }
   }
+}
+
+// XCD-aware tile mapping: workgroup b lands on XCD b % 8 (observed dispatch order, used for speed only), so XCD x
+// walks the contiguous tile range [x*per, (x+1)*per): neighbouring tiles, which share output cache lines and boundary
+// bitmap words, meet in ONE L2 instead of ping-ponging dirty lines between XCDs.  -1: this workgroup has no tile.
+__device__ __forceinline__ int64_t scatter_tile_of_block(int xcd_remap, int64_t ntiles) {
+  if (!xcd_remap) return blockIdx.x;
+  const int64_t per = (ntiles + 7) >> 3;
+  const int64_t tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  return (tile >= ntiles || (int64_t)(blockIdx.x >> 3) >= per) ? -1 : tile;
+}
+
+template <int W, int V, bool HAS_VALID, bool SKIP>
+__global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(ScatterArgs a) {
+  // this workgroup's column (uniform: scalar selects)
+  const void* c_values = a.values;
+  BitView c_vvalid = a.vvalid;
+  void* c_out_values = a.out_values;
+  unsigned long long* c_out_valid = a.out_valid;
+  unsigned long long* c_valid_slots = a.valid_slots;
+  if (blockIdx.y) {
+    const ScatterArgs::Col& c = a.more[blockIdx.y - 1];
+    c_values = c.values;
+    c_vvalid = c.vvalid;
+    c_out_values = c.out_values;
+    c_out_valid = c.out_valid;
+    c_valid_slots = c.valid_slots;
+  }
+  const int64_t tile = scatter_tile_of_block(a.xcd_remap, a.ntiles);
+  if (tile < 0) return;
+  scatter_tile<W, V, HAS_VALID, SKIP>(a, tile, c_values, c_vvalid, c_out_values, c_out_valid, c_valid_slots);
+}
+
+// ---- several input batches, one launch (BatchCoalescer::push_batches_with_filters): the tiles of up to 8 batches form
+// one tile space; every batch brings its own predicate tables, source columns and window of its filtered stream, all
+// of them append to the SAME in-progress output columns (batch b's rows at out_base[b] onwards).
+constexpr int MULTI_MAX_SEGS = 8;
+struct MultiSeg {
+  BitView mask, mask_valid;
+  int64_t len;
+  const uint32_t* chunk_prefix;
+  const unsigned long long* group_prefix;
+  int group_shift;
+  int64_t out_base, win_lo, win_hi;
+  int64_t tile0;  // first tile of this batch in the launch's tile space
+  struct Src {
+    const void* values;
+    BitView vvalid;
+  } col[SCATTER_MAX_COLS];
+};
+struct MultiArgs {
+  int nsegs, xcd_remap;
+  int64_t ntiles;  // of all segments together
+  struct Dst {
+    void* out_values;
+    unsigned long long* out_valid;
+    unsigned long long* null_slots;
+  } dst[SCATTER_MAX_COLS];
+  MultiSeg seg[MULTI_MAX_SEGS];
+};
+
+template <int W, int V, bool SKIP>
+__global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_multi_kernel(MultiArgs m) {
+  const int64_t gtile = scatter_tile_of_block(m.xcd_remap, m.ntiles);
+  if (gtile < 0) return;
+  int sidx = 0;
+#pragma unroll
+  for (int i = 1; i < MULTI_MAX_SEGS; ++i)
+    if (i < m.nsegs && gtile >= m.seg[i].tile0) sidx = i;
+  const MultiSeg& sg = m.seg[sidx];
+  ScatterArgs a{};
+  a.mask = sg.mask;
+  a.mask_valid = sg.mask_valid;
+  a.len = sg.len;
+  a.chunk_prefix = sg.chunk_prefix;
+  a.group_prefix = sg.group_prefix;
+  a.group_shift = sg.group_shift;
+  a.out_base = sg.out_base;
+  a.win_lo = sg.win_lo;
+  a.win_hi = sg.win_hi;
+  a.nulls_mode = 1;
+  const MultiSeg::Src& src = sg.col[blockIdx.y];
+  const MultiArgs::Dst& d = m.dst[blockIdx.y];
+  scatter_tile<W, V, true, SKIP>(a, gtile - sg.tile0, src.values, src.vvalid, d.out_values, d.out_valid, d.null_slots);
 }
 
 template <int W, bool HV>
@@ -1045,12 +1095,13 @@ static ah_status apply_into_impl(ah_context* ctx, const ah_filter_predicate* p, 
 // Several columns of one batch through ONE scatter launch (BatchCoalescer's filtered push): the columns must share
 // the value width and all carry validity; returns AH_NOT_YET_IMPLEMENTED (nothing enqueued) when they do not, and the
 // caller goes column by column.  Only positions [win_lo, win_hi) of the filtered batch are appended (at
-// dst_row_offset onwards): a batch that straddles two output batches is two launches, no intermediate array.  `slots`: ncols x 64 zeroed words the
-// kernels leave zero; nulls_acc: ncols device words.
+// dst_row_offset onwards): a batch that straddles two output batches is two launches, no intermediate array.
+// `null_slots`: ncols x 64 device words that ACCUMULATE the NULL rows appended (each tile adds its own window rows -
+// valid rows): no tail kernel, nothing to read back per push — the coalescer sums them once per finished batch.
 ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predicate* p, int ncols, const ah_array_view* values,
                                         void* const* dst_values, uint8_t* const* dst_validity, int64_t dst_row_offset,
-                                        unsigned long long* nulls_acc, unsigned long long* slots, int64_t win_lo,
-                                        int64_t win_hi, int speculative, double selectivity_hint) {
+                                        unsigned long long* null_slots, int64_t win_lo, int64_t win_hi, int speculative,
+                                        double selectivity_hint) {
   if (ncols < 1 || ncols > SCATTER_MAX_COLS) return AH_NOT_YET_IMPLEMENTED;
   const int width = ah_type_width(values[0].type);
   if (width <= 0) return AH_NOT_YET_IMPLEMENTED;
@@ -1059,7 +1110,7 @@ ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predica
     if (p->len > values[c].length || ((uintptr_t)dst_validity[c] & 7) != 0) return AH_NOT_YET_IMPLEMENTED;
   }
   // speculative: the count pass is enqueued but K has not reached the host; the launch clips itself to the rows
-  // that exist (a tile outside the window or without selected rows exits) and the tail kernel reads K on the device
+  // that exist (a tile outside the window or without selected rows exits)
   if (!speculative && win_hi > p->count) win_hi = p->count;
   const int64_t K = win_hi - win_lo;  // rows this launch appends (at most, when speculative): positions [win_lo, win_hi)
   if (p->len == 0 || K <= 0) return AH_OK;
@@ -1071,19 +1122,21 @@ ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predica
   a.group_prefix = p->group_prefix;
   a.group_shift = p->group_shift;
   a.out_base = dst_row_offset;
-  if (speculative || !(win_lo == 0 && win_hi == p->count)) a.win_lo = win_lo, a.win_hi = win_hi;
+  a.nulls_mode = 1;
+  // (always windowed here: nulls_mode needs each tile's clipped row count, which the window arithmetic provides)
+  a.win_lo = win_lo, a.win_hi = win_hi;
   a.values = values[0].values;
   a.vvalid = make_bitview(values[0].validity, values[0].validity_bit_offset);
   a.out_values = dst_values[0];
   a.out_valid = (unsigned long long*)dst_validity[0];
-  a.valid_slots = slots;
+  a.valid_slots = null_slots;
   for (int c = 1; c < ncols; ++c) {
     ScatterArgs::Col& m = a.more[c - 1];
     m.values = values[c].values;
     m.vvalid = make_bitview(values[c].validity, values[c].validity_bit_offset);
     m.out_values = dst_values[c];
     m.out_valid = (unsigned long long*)dst_validity[c];
-    m.valid_slots = slots + (size_t)c * 64;
+    m.valid_slots = null_slots + (size_t)c * 64;
   }
   ctx->inflight = true;
   {
@@ -1091,13 +1144,101 @@ ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predica
     const bool skip = speculative ? use_skip((int64_t)(selectivity_hint * (double)p->len), p->len) : use_skip(p->count, p->len);
     launch_scatter<true>(ctx, width, a, skip, ncols);
   }
-  if (speculative)
-    filter_finish_acc_cols_dev_kernel<<<(unsigned)ncols, 64, 0, ctx->stream>>>(slots, p->total_dev, (unsigned long long)win_lo,
-                                                                               (unsigned long long)win_hi, nulls_acc);
-  else
-    filter_finish_acc_cols_kernel<<<(unsigned)ncols, 64, 0, ctx->stream>>>(slots, (unsigned long long)K, nulls_acc);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "fused filter copy failed: %s", hipGetErrorString(e));
+  return AH_OK;
+}
+
+// Up to 8 (batch, window) segments through ONE launch, all appending to the same in-progress columns (the grouped
+// push of BatchCoalescer).  Preconditions (the caller checks them like ah_filter_apply_into_acc_cols does): every
+// column of every batch has the same width and carries validity; dst_validity 8-byte aligned.
+ah_status ah_filter_apply_multi(ah_context* ctx, int nsegs, const ah_filter_predicate* const* preds,
+                                const ah_array_view* const* columns, const int64_t* win_lo, const int64_t* win_hi,
+                                const int64_t* out_base, int ncols, void* const* dst_values, uint8_t* const* dst_validity,
+                                unsigned long long* null_slots) {
+  if (nsegs < 1 || nsegs > MULTI_MAX_SEGS || ncols < 1 || ncols > SCATTER_MAX_COLS) return AH_INVALID_ARGUMENT;
+  const int width = ah_type_width(columns[0][0].type);
+  MultiArgs m{};
+  m.nsegs = nsegs;
+  static const char* xr = getenv("AH_FILTER_XCD");
+  m.xcd_remap = (xr && xr[0] == '0') ? 0 : 1;
+  const int T = tile_rows(width);
+  int64_t tiles = 0, rows = 0, selected = 0;
+  bool aligned16 = true;
+  for (int i = 0; i < nsegs; ++i) {
+    const ah_filter_predicate* p = preds[i];
+    MultiSeg& sg = m.seg[i];
+    sg.mask = p->mask;
+    sg.mask_valid = p->mask_valid;
+    sg.len = p->len;
+    sg.chunk_prefix = p->chunk_prefix;
+    sg.group_prefix = p->group_prefix;
+    sg.group_shift = p->group_shift;
+    sg.out_base = out_base[i];
+    sg.win_lo = win_lo[i];
+    sg.win_hi = win_hi[i];
+    sg.tile0 = tiles;
+    tiles += ah_ceil_div(p->len, T);
+    rows += p->len;
+    selected += p->count;
+    for (int c = 0; c < ncols; ++c) {
+      sg.col[c].values = columns[i][c].values;
+      sg.col[c].vvalid = make_bitview(columns[i][c].validity, columns[i][c].validity_bit_offset);
+      aligned16 = aligned16 && (((uintptr_t)columns[i][c].values) & 15) == 0;
+    }
+  }
+  m.ntiles = tiles;
+  for (int c = 0; c < ncols; ++c) {
+    m.dst[c].out_values = dst_values[c];
+    m.dst[c].out_valid = (unsigned long long*)dst_validity[c];
+    m.dst[c].null_slots = null_slots + (size_t)c * 64;
+  }
+  if (tiles == 0) return AH_OK;
+  ctx->inflight = true;
+  const bool skip = use_skip(selected, rows);
+  const dim3 grid((unsigned)(m.xcd_remap ? 8 * ((tiles + 7) / 8) : tiles), (unsigned)ncols), block(SCATTER_THREADS);
+  {
+    ah_prof_scope ps(ctx, "filter_scatter");
+#define AH_MULTI(W, V)                                                                                  \
+  do {                                                                                                  \
+    if (skip) filter_scatter_multi_kernel<W, V, true><<<grid, block, 0, ctx->stream>>>(m);             \
+    else filter_scatter_multi_kernel<W, V, false><<<grid, block, 0, ctx->stream>>>(m);                 \
+  } while (0)
+    switch (width) {
+      case 1: if (aligned16) AH_MULTI(1, 16); else AH_MULTI(1, 1); break;
+      case 2: if (aligned16) AH_MULTI(2, 8); else AH_MULTI(2, 1); break;
+      case 4: if (aligned16) AH_MULTI(4, 4); else AH_MULTI(4, 1); break;
+      case 8: if (aligned16) AH_MULTI(8, 2); else AH_MULTI(8, 1); break;
+      case 16: AH_MULTI(16, 1); break;
+      case 32: AH_MULTI(32, 1); break;
+      default: return ah_fail(ctx, AH_INVALID_ARGUMENT, "unsupported value width %d", width);
+    }
+#undef AH_MULTI
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "fused filter copy failed: %s", hipGetErrorString(e));
+  return AH_OK;
+}
+
+// the per-column NULL-row counters of a BatchCoalescer (ncols x 64 slots) -> host, slots back to zero: ONE launch,
+// ONE wait per finished output batch (NullBufferBuilder only needs the count then, coalesce/primitive.rs:94-106)
+__global__ void __launch_bounds__(64) coalesce_finish_kernel(unsigned long long* slots, int ncols, uint64_t* mail, uint64_t seq) {
+  for (int c = 0; c < ncols; ++c) {
+    unsigned long long v = slots[(size_t)c * 64 + threadIdx.x];
+    slots[(size_t)c * 64 + threadIdx.x] = 0;
+    v = wave_reduce_add64(v);
+    if (threadIdx.x == 0) __hip_atomic_store(mail + c, (uint64_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (threadIdx.x == 0) ah_mail_post(mail, seq);
+}
+ah_status ah_coalesce_read_nulls(ah_context* ctx, unsigned long long* slots, int ncols, uint64_t* host_out) {
+  if (ncols < 1 || ncols > 200) return AH_INVALID_ARGUMENT;
+  const uint64_t seq = ah_mail_next(ctx);
+  coalesce_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, ncols, ctx->pinned_dev, seq);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "coalescer finish failed: %s", hipGetErrorString(e));
+  for (int c = 0; c < ncols; ++c) host_out[c] = ctx->pinned[c];
   return AH_OK;
 }
 
@@ -1120,6 +1261,12 @@ extern "C" ah_status ah_filter_predicate_apply_into_acc(ah_context* ctx, const a
   return apply_into_impl(ctx, p, values, dst_values, dst_validity, dst_row_offset, nullptr, (unsigned long long*)nulls_acc, true);
 }
 
+// AH_FILTER_SMALL=0 keeps small inputs on the general two-pass path (tests run both; read per call: a getenv is ~0.1 us)
+static bool small_path_enabled() {
+  const char* e = getenv("AH_FILTER_SMALL");
+  return !(e && e[0] == '0');
+}
+
 extern "C" ah_status ah_filter(ah_context* ctx, const ah_array_view* values,
                                const ah_array_view* predicate, ah_array_out* out) {
   ah_ctx_guard _guard(ctx);
@@ -1129,6 +1276,10 @@ extern "C" ah_status ah_filter(ah_context* ctx, const ah_array_view* values,
     return ah_fail(ctx, AH_INVALID_ARGUMENT,
                    "Filter predicate of length %lld is larger than target array of length %lld",
                    (long long)predicate->length, (long long)values->length);
+  if (small_path_enabled()) {  // query-engine-sized batches: one launch, one wait (filter_small.hip)
+    const ah_status ss = ah_filter_small(ctx, 1, values, predicate, out, nullptr);
+    if (ss != AH_NOT_YET_IMPLEMENTED) return ss;
+  }
   ah_filter_predicate* p = nullptr;
   AH_TRY(ah_filter_predicate_build(ctx, predicate, &p));
   ah_status st = ah_filter_predicate_apply(ctx, p, values, out);
@@ -1165,7 +1316,7 @@ static ah_status filter_columns_fused(ah_context* ctx, const ah_filter_predicate
     a.len = p->len;
     a.chunk_prefix = p->chunk_prefix;
     a.group_prefix = p->group_prefix;
-    a.group_shift = p->group_shift;
+      a.group_shift = p->group_shift;
     for (int i = 0; i < ncols; ++i) {
       const ah_array_view& v = columns[cols[i]];
       const BitView vv = has_valid ? make_bitview(v.validity, v.validity_bit_offset) : BitView{nullptr, 0};
@@ -1229,10 +1380,18 @@ extern "C" ah_status ah_filter_record_batch(ah_context* ctx, int32_t n_columns,
                                             int64_t* out_rows) {
   ah_ctx_guard _guard(ctx);
   if (!ctx || !predicate || (n_columns > 0 && (!columns || !outs))) return AH_INVALID_ARGUMENT;
+  for (int32_t c = 0; c < n_columns; ++c) ah_out_init(&outs[c]);
+  if (n_columns > 0 && small_path_enabled()) {  // all columns in one launch per shape, one wait for the whole batch
+    const ah_status ss = ah_filter_small(ctx, n_columns, columns, predicate, outs, out_rows);
+    if (ss != AH_NOT_YET_IMPLEMENTED) {
+      if (ss != AH_OK)
+        for (int32_t c = 0; c < n_columns; ++c) ah_out_init(&outs[c]);
+      return ss;
+    }
+  }
   ah_filter_predicate* p = nullptr;
   AH_TRY(ah_filter_predicate_build(ctx, predicate, &p));
   ah_status st = AH_OK;
-  for (int32_t c = 0; c < n_columns; ++c) ah_out_init(&outs[c]);
   // same-shape primitive columns go out together; everything else (and the None / All strategies, deferred mode,
   // error cases) column by column
   std::vector<char> done((size_t)std::max(n_columns, 1), 0);

@@ -93,11 +93,12 @@ template <int W> __device__ __forceinline__ void load_pair(const void* base, int
     x0 = x1 = (uint64_t)p[0];
     return;
   }
-  if (vec) {  // len >= 2 (host): the last aligned pair is always in range
-    const int64_t rc = row + 1 < len ? row : ((len - 2) & ~1ll);
-    const Pair<W> v = *(const Pair<W>*)(p + rc);
+  if (vec && row + 1 < len) {
+    const Pair<W> v = *(const Pair<W>*)(p + row);
     x0 = (uint64_t)v.e[0];
     x1 = (uint64_t)v.e[1];
+  } else if (vec) {  // the pair straddles the end: row is the last row of an odd-length column, or past the end
+    x0 = x1 = (uint64_t)p[row < len ? row : len - 1];
   } else {
     const int64_t r0 = row < len ? row : len - 1, r1 = row + 1 < len ? row + 1 : len - 1;
     x0 = (uint64_t)p[r0];

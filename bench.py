@@ -515,7 +515,11 @@ def build_workload(env, wl):
         batches = [(A.RecordBatch(["a", "b"], [col.slice(i * br, br), col2.slice(i * br, br)]), pred.slice(i * br, br))
                    for i in range(nb)]
 
-        group = max(1, int(os.environ.get("AH_COALESCE_GROUP", "1")))  # > 1: the multi-batch push (several batches queued)
+        # how many batches the engine hands over per call: 1 = push_batch_with_filter per batch; > 1 = the grouped push
+        # (ah_coalescer_push_batches_with_filters: one count read-back for the group, the batches of one output window
+        # scattered by one launch).  The default run reports the grouped form (8) and, beside it, the single-push time.
+        group = max(1, int(os.environ.get("AH_COALESCE_GROUP", "8")))
+        W["group"] = group
 
         def step(_r):
             co = K.BatchCoalescer.new(["a", "b"], [A.Int64, A.Float64], target, ctx)
@@ -733,8 +737,8 @@ def describe(env, wl, W, prof, out, steps):
             "predicate_filter": "SURVEY 8f-2: filter(a, and_kleene(lt(a, 0), gt_eq(b, 0.0))) on Int64 a, Float64 b with NullBuffers",
             "coalesce": f"SURVEY 8f-1: BatchCoalescer.push_batch_with_filter, Int64+Float64, "
                         f"{args.batch_rows}-row batches"
-                        + (f", pushed {os.environ['AH_COALESCE_GROUP']} at a time (ah_coalescer_push_batches_with_filters)"
-                           if int(os.environ.get("AH_COALESCE_GROUP", "1")) > 1 else "")}[wl] + f", {n} rows per GPU"
+                        + (f", pushed {W.get('group', 1)} at a time (ah_coalescer_push_batches_with_filters)"
+                           if W.get("group", 1) > 1 else ", one push_batch_with_filter per batch")}[wl] + f", {n} rows per GPU"
     dtype = "int64" if wl in ("aggregate", "sort") else "int64+f64" if wl == "record_batch" else "f64"
     return dominant, dom_avg, dom_n, alg, text, f"{wl}_Mrows_per_s", dtype
 
@@ -1081,7 +1085,25 @@ def main():
                             "dtype": dtype, "roofline": roofline_obj(kern, alg, avg_ms, launches),
                             "kernel_avg_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof2.items()},
                             "host_gap_ms": round(ms2 - sum(v[0] for v in prof2.values()) / args.config_steps, 4)}
-                if w2 == "coalesce":  # ~430 small launches per step: the per-kernel HIP events themselves cost ~1 ms
+                if w2 == "coalesce":  # the single-push form of the same step, beside the grouped one
+                    try:
+                        os.environ["AH_COALESCE_GROUP"] = "1"
+                        W3 = build_workload(env, "coalesce")
+                        for _ in range(2):
+                            W3["step"](False)
+                        env.sync_all()
+                        t0 = time.perf_counter()
+                        for _ in range(args.config_steps):
+                            W3["step"](False)
+                        env.sync_all()
+                        ms1 = (time.perf_counter() - t0) / args.config_steps * 1e3
+                        dest[w2]["single_push"] = {"ms_without_kernel_events": round(ms1, 4),
+                                                   "frac_without_kernel_events": round(alg / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                                   "what": "the same batches through one ah_coalescer_push_batch_with_filter call each"}
+                        W3 = None
+                    finally:
+                        os.environ.pop("AH_COALESCE_GROUP", None)
+                if w2 == "coalesce":  # many small launches per step: the per-kernel HIP events themselves cost time
                     env.sync_all()
                     t0 = time.perf_counter()
                     for _ in range(args.config_steps):

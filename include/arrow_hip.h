@@ -112,7 +112,9 @@ typedef struct ah_array_out {
   int64_t length;
   int64_t null_count;
   void* values;            /* primitives: values; AH_BOOL: bit-packed; UTF8: bytes */
-  int64_t values_bytes;
+  int64_t values_bytes;    /* size of the ALLOCATION behind `values` (what the allocator hook's free receives); the array
+                              uses the first length * width bytes of it — filter of a small batch allocates for the
+                              worst case (every row selected) so that it need not wait for the count first */
   int64_t values_bit_offset;   /* AH_BOOL only; 0 unless AH_OUT_BORROWED */
   uint8_t* validity;       /* NULL when the result carries no null buffer */
   int64_t validity_bytes;
@@ -205,6 +207,10 @@ AH_API void ah_pool_trim(ah_context* ctx); /* hipFree everything cached in the p
  * filter.rs:537-541.  values may be any primitive type or AH_BOOL. */
 AH_API ah_status ah_filter(ah_context* ctx, const ah_array_view* values,
                            const ah_array_view* predicate, ah_array_out* out);
+/* Predicates of at most 2^20 rows over fixed-width columns (ah_filter and ah_filter_record_batch alike) take a
+ * one-launch path: count, prefix and scatter in a single kernel, every column of a record batch in that launch, one host
+ * wait for K and all null counts (query-engine batch sizes are latency, not bandwidth: arrow/benches/filter_kernels.rs:
+ * 39-45 runs 512 .. 65 536 rows).  Same results as the general two-pass path; environment AH_FILTER_SMALL=0 disables it. */
 
 /* FilterBuilder::new(..).optimize().build() (filter.rs:256-324): count once,
  * keep per-tile offsets on device, apply to many columns.  The handle BORROWS the

@@ -13,7 +13,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import comm_cases as cc  # noqa: E402
 from comm_cases import A, D, orc, ROOT  # noqa: E402
 
+import faulthandler  # noqa: E402
+
 world = int(sys.argv[1])
+# a rank stuck in a collective would otherwise sit there until the caller's timeout: dump every thread's stack and leave
+faulthandler.dump_traceback_later(int(os.environ.get("AH_COMM_WATCHDOG_S", "420")), exit=True)
 oracle = orc.load(os.path.join(ROOT, "oracle", "liboracle.so"))
 box, lock, bar = {}, threading.Lock(), threading.Barrier(world)
 errors = []
@@ -33,12 +37,9 @@ def rank_main(r):
         cc.run_rank(ctx, comm, oracle, r, world, heavy=(world == 2))
     except BaseException as ex:  # noqa: BLE001
         import traceback
-        with lock:
-            errors.append(f"rank {r}: {ex!r}\n{traceback.format_exc()}")
-        try:
-            bar.abort()
-        except Exception:
-            pass
+        # the other ranks are (or soon will be) blocked inside a collective waiting for this one: report and leave NOW
+        print(f"FAILED rank {r}: {ex!r}\n{traceback.format_exc()}", flush=True)
+        os._exit(1)
 
 
 ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]

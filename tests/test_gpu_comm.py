@@ -40,7 +40,7 @@ def test_exchange_code_at_world_n_over_a_fake_transport(world, tmp_path):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Wno-unused-value",
                            "-o", lib, os.path.join(here, "cpp", "fake_rccl.cpp")])
     out = subprocess.run([sys.executable, os.path.join(here, "comm_ranks_worker.py"), str(world)], capture_output=True, text=True,
-                         timeout=1200, env=dict(os.environ, AH_RCCL_LIBRARY=lib))
+                         timeout=600, env=dict(os.environ, AH_RCCL_LIBRARY=lib))
     assert out.returncode == 0 and f"COMM_RANKS_OK {world}" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 

@@ -1042,6 +1042,39 @@ def test_batch_coalescer_grouped_pushes_equal_single_pushes(ctx, oracle):
         assert co.is_empty()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_batch_coalescer_grouped_pushes_one_launch_per_window(ctx, oracle, seed):
+    """Same-width, all-nullable columns and no bypass limit: the grouped push scatters the batches that land in one
+    output window with ONE multi-batch launch (csrc/filter.hip filter_scatter_multi_kernel: up to 8 (batch, window)
+    segments, windows that straddle output batches, more than 8 batches per window, an all-selected batch in between
+    that takes the copy path).  The output batches must be exactly those of the coalesce.rs model."""
+    from coalesce_model import ModelCoalescer
+    rng = np.random.default_rng(5150 + seed)
+    dts = [[A.Int64, A.Float64], [A.Int32, A.Float32, A.UInt32], [A.Int64], [A.Int16, A.Int16]][seed % 4]
+    names = [f"c{i}" for i in range(len(dts))]
+    target = [3000, 200, 70_000, 1000, 5, 40_000][seed]
+    co = K.BatchCoalescer.new(names, dts, target, ctx)
+    model = ModelCoalescer(oracle, dts, target)
+    pending = []
+    for step in range(60):
+        n = int(rng.integers(1, [2000, 5000, 20_000][seed % 3]))
+        cols = [HostArray(dt, _rand_values(rng, dt, n), rng.random(n) < 0.85) for dt in dts]
+        flen = n - int(rng.integers(0, min(n, 3) + 1))
+        psel = float(rng.choice([0.0, 0.02, 0.3, 0.9, 1.0]))
+        f = HostArray(A.Boolean, rng.random(flen) < psel, (rng.random(flen) < 0.9) if step % 4 == 0 else None)
+        pending.append((A.RecordBatch(names, [c.to_device(ctx) for c in cols]), f.to_device(ctx)))
+        model.push_with_filter(cols, f)
+        if len(pending) >= int(rng.integers(2, 20)) or step == 59:
+            co.push_batches_with_filters(pending)
+            pending = []
+            assert co.get_buffered_rows() == model.buffered, f"seed {seed} step {step}"
+            _check_batches(co, model, f"multi seed {seed} step {step}")
+    co.finish_buffered_batch()
+    model.finish()
+    _check_batches(co, model, f"multi seed {seed} final")
+    assert co.is_empty()
+
+
 def test_batch_coalescer_generic_columns(ctx, oracle):
     """Boolean / Utf8 / LargeUtf8 columns go through GenericInProgressArray (coalesce/generic.rs): buffered
     slices and filtered arrays, `concat` on finish — next to a primitive column on the fused path; same batch
