@@ -166,6 +166,8 @@ SIGNATURES = {
     "ah_filter": (C.c_int32, [_P, _VIEW, _VIEW, _OUT]),
     "ah_filter_predicate_build": (C.c_int32, [_P, _VIEW, C.POINTER(_P)]),
     "ah_filter_predicate_build_expr": (C.c_int32, [_P, C.c_int32, C.POINTER(FilterTerm), C.POINTER(C.c_int32), C.POINTER(_P)]),
+    "ah_filter_expr": (C.c_int32, [_P, C.c_int32, C.POINTER(FilterTerm), C.POINTER(C.c_int32), _VIEW, _OUT]),
+    "ah_array_shrink_to_fit": (C.c_int32, [_P, _OUT]),
     "ah_filter_predicate_count": (C.c_int64, [_P]),
     "ah_filter_predicate_apply": (C.c_int32, [_P, _P, _VIEW, _OUT]),
     "ah_filter_predicate_free": (None, [_P, _P]),
@@ -184,6 +186,7 @@ SIGNATURES = {
     "ah_coalescer_push_batch_with_filter": (C.c_int32, [_P, _P, _VIEW, C.c_int64, _VIEW, C.c_uint64, C.POINTER(C.c_int32)]),
     "ah_coalescer_push_batches_with_filters": (C.c_int32, [_P, _P, C.c_int32, _VIEW, C.POINTER(C.c_int64), _VIEW,
                                                            C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
+    "ah_coalescer_push_batch_with_indices": (C.c_int32, [_P, _P, _VIEW, C.c_int64, _VIEW]),
     "ah_filter_predicates_build": (C.c_int32, [_P, C.c_int32, _VIEW, C.POINTER(_P)]),
     "ah_coalescer_finish_buffered_batch": (C.c_int32, [_P, _P]),
     "ah_coalescer_next_completed_batch": (C.c_int32, [_P, _P, _OUT, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),

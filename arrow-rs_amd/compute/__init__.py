@@ -1,7 +1,7 @@
 """arrow::compute (arrow/src/compute/mod.rs:22-40): kernels flattened."""
 from . import kernels  # noqa: F401
 from .kernels.filter import (filter, filter_record_batch, prep_null_mask_filter, FilterBuilder,  # noqa: F401
-                             FilterPredicate)
+                             FilterPredicate, filter_expr)
 from .kernels.take import take, take_arrays, take_record_batch, TakeOptions  # noqa: F401
 from .kernels.numeric import (add, add_wrapping, sub, sub_wrapping, mul, mul_wrapping, div, rem,  # noqa: F401
                               neg, neg_wrapping)

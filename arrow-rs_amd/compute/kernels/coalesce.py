@@ -3,10 +3,10 @@
 filter-into-builder path, every other supported layout (Boolean, Utf8, LargeUtf8) through the reference's
 generic buffer-and-concat implementation (coalesce/generic.rs).
 
-The host state machine (exact-size output batches, in input order, optional large-batch bypass) is NATIVE for
-fixed-width columns — ``ah_coalescer_*`` (csrc/coalesce.hip): one C call per pushed batch, no wait except the
-predicate's count, one wait per finished batch.  Schemas with Boolean / string columns keep the Python restatement
-below (their in-progress arrays buffer and concat, coalesce/generic.rs); the data movement happens in HBM either way:
+The host state machine (exact-size output batches, in input order, optional large-batch bypass) is NATIVE —
+``ah_coalescer_*`` (csrc/coalesce.hip): one C call per pushed batch, no wait except the predicate's count, one wait per
+finished batch; Boolean / Utf8 / LargeUtf8 columns are the native GenericInProgressArray there (pieces + concat).  Only
+schemas with view columns keep the Python restatement below; the data movement happens in HBM either way:
   * ``copy_rows``                 -> ``ah_copy_rows_into`` (D2D copy + funnel-shift bitmap merge)
   * ``copy_rows_by_filter_from``  -> ``ah_filter_predicate_apply_into``: the filter scatters
     straight into the in-progress buffers (no intermediate filtered array, no second copy).
@@ -118,8 +118,11 @@ class BatchCoalescer:
         self.target_batch_size = int(target_batch_size)
         self.biggest_coalesce_batch_size = None
         self._native = None
-        if self.data_types and all(dt.is_primitive() and dt.width > 0 and dt.physical not in (L.AH_UTF8_VIEW, L.AH_BINARY_VIEW)
-                                   for dt in self.data_types) and len(self.data_types) <= 200:
+        def native_ok(dt):  # fixed-width (InProgressPrimitiveArray) or Boolean / Utf8 / LargeUtf8 (GenericInProgressArray)
+            if dt.physical in (L.AH_BOOL, L.AH_UTF8, L.AH_LARGE_UTF8):
+                return True
+            return dt.is_primitive() and dt.width > 0 and dt.physical not in (L.AH_UTF8_VIEW, L.AH_BINARY_VIEW)
+        if self.data_types and all(native_ok(dt) for dt in self.data_types) and len(self.data_types) <= 200:
             lib, h = self.ctx.lib, C.c_void_p()
             types = (C.c_int32 * len(self.data_types))(*[dt.physical for dt in self.data_types])
             self.ctx.check(lib.ah_coalescer_create(self.ctx.handle, len(self.data_types), types, self.target_batch_size, C.byref(h)))
@@ -164,6 +167,12 @@ class BatchCoalescer:
         if self._native is not None:
             return self.ctx.lib.ah_coalescer_completed_count(self._native) > 0
         return bool(self.completed)
+
+    def completed_count(self):
+        """number of finished batches waiting in the queue"""
+        if self._native is not None:
+            return int(self.ctx.lib.ah_coalescer_completed_count(self._native))
+        return len(self.completed)
 
     def next_completed_batch(self):
         if self._native is None:
@@ -266,6 +275,10 @@ class BatchCoalescer:
 
     # ---- coalesce.rs:257
     def push_batch_with_indices(self, batch, indices):
+        if self._native is not None:
+            views, iv = self._views(batch), indices.view()
+            return self.ctx.check(self.ctx.lib.ah_coalescer_push_batch_with_indices(self.ctx.handle, self._native, views,
+                                                                                   batch.num_rows(), C.byref(iv)))
         return self.push_batch(take_record_batch(batch, indices))
 
     # ---- coalesce.rs:296-525

@@ -127,6 +127,35 @@ class FilterBuilder:
         return FilterPredicate(ctx, h, self._predicate)
 
 
+def _term_array(terms, joins):
+    ops = [(_CMP_OPS[op] if isinstance(op, str) else int(op), lhs, rhs) for op, lhs, rhs in terms]
+    js = [_JOIN_OPS[j] if isinstance(j, str) else int(j) for j in joins]
+    if len(js) != max(len(ops) - 1, 0):
+        raise InvalidArgumentError("a filter expression of n terms takes n - 1 joins")
+    arr = (L.FilterTerm * max(len(ops), 1))()
+    keep, ctx = [], None
+    for i, (op, lhs, rhs) in enumerate(ops):
+        l, l_s = lhs.get()
+        r, r_s = rhs.get()
+        ctx = ctx or l.ctx
+        lv, rv = l.view(), r.view()
+        keep += [l, r, lv, rv]
+        arr[i].op, arr[i].lhs, arr[i].lhs_is_scalar = op, C.pointer(lv), int(l_s)
+        arr[i].rhs, arr[i].rhs_is_scalar = C.pointer(rv), int(r_s)
+    return ctx, len(ops), arr, (C.c_int32 * max(len(js), 1))(*js), keep
+
+
+def filter_expr(values, terms, joins=()):
+    """``filter(values, <terms joined by joins>)`` in one call (``ah_filter_expr``): what an engine writes as
+    ``filter(&a, &and_kleene(&lt(&a, &x)?, &gt_eq(&b, &y)?)?)`` (cmp.rs:113-164, boolean.rs:60-300, filter.rs:201) with
+    nothing materialised — above 2^20 rows of 8-byte columns a single kernel that reads every operand once."""
+    ctx, n, arr, js, _keep = _term_array(terms, joins)
+    out = L.ArrayOut()
+    vv = values.view()
+    ctx.check(ctx.lib.ah_filter_expr(ctx.handle, n, arr, js, C.byref(vv), C.byref(out)))
+    return Array._from_out(ctx, out, values.data_type, keepalive=(values,))
+
+
 def filter_record_batch(record_batch, predicate):
     """``pub fn filter_record_batch(record_batch: &RecordBatch, predicate: &BooleanArray)``
     (filter.rs:225): one predicate pass, then one scatter per column."""

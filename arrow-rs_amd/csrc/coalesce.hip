@@ -10,11 +10,15 @@
 // `buffered_rows` (no intermediate filtered array), and no per-push call waits for the GPU — appended-null counts
 // accumulate in one device word per column and are read in ONE wait when an output batch is finished; the only
 // wait of a filtered push is the predicate's count, which the "fits / does not fit" decision needs.
-// Fixed-width columns only (the reference's InProgressPrimitiveArray); Boolean / string columns go through the
-// mirror's generic buffer-and-concat path (coalesce/generic.rs) as before.
+// Fixed-width columns are InProgressPrimitiveArray (coalesce/primitive.rs): values scattered / copied straight into the
+// in-progress buffers.  Boolean, Utf8 and LargeUtf8 columns are GenericInProgressArray (coalesce/generic.rs:32-108): the
+// in-progress batch keeps a list of pieces — filtered results are ADOPTED (and shared between two output batches when
+// they straddle a boundary, like the reference's Arc'ed slices), unfiltered rows are copied out of the caller's
+// borrowed buffers — and `concat`s them when the batch is finished.  View types: AH_NOT_YET_IMPLEMENTED.
 #include "common.hpp"
 
 #include <deque>
+#include <memory>
 #include <vector>
 
 extern "C" ah_status ah_filter_predicate_apply_into_acc(ah_context*, const ah_filter_predicate*, const ah_array_view*, void*,
@@ -26,27 +30,81 @@ ah_status ah_filter_apply_into_acc_cols(ah_context*, const ah_filter_predicate*,
 // filter.hip: up to 8 (batch, window) segments through one scatter launch
 ah_status ah_filter_apply_multi(ah_context*, int, const ah_filter_predicate* const*, const ah_array_view* const*, const int64_t*,
                                 const int64_t*, const int64_t*, int, void* const*, uint8_t* const*, unsigned long long*);
-// filter.hip: ncols x 64 NULL-row counters -> host (summed per column), counters back to zero; one launch, one wait
-ah_status ah_coalesce_read_nulls(ah_context*, unsigned long long*, int, uint64_t*);
+// filter.hip: ncols x 64 NULL-row counters -> pinned words (summed per column), counters back to zero; one launch, no
+// wait: *seq is posted to the context mailbox behind it
+ah_status ah_coalesce_post_nulls(ah_context*, unsigned long long*, int, uint64_t*, uint64_t*);
+ah_status ah_coalesce_wait(ah_context*, uint64_t);
 // filter.hip: ah_filter_predicate_build in two halves (enqueue the count pass / wait for K)
 ah_status ah_filter_predicate_begin(ah_context*, const ah_array_view*, ah_filter_predicate**, uint64_t*, bool*);
 ah_status ah_filter_predicate_end(ah_context*, ah_filter_predicate*, uint64_t, bool);
 extern "C" void ah_filter_predicate_free(ah_context*, ah_filter_predicate*);
 
+extern "C" ah_status ah_take(ah_context*, const ah_array_view*, const ah_array_view*, int32_t, ah_array_out*);
+
 namespace {
+
+// an owned array shared by the pieces cut out of it
+struct GenOwner {
+  ah_context* ctx;
+  ah_array_out out;
+  GenOwner(ah_context* c, const ah_array_out& o) : ctx(c), out(o) {}
+  GenOwner(const GenOwner&) = delete;
+  ~GenOwner() { ah_array_release(ctx, &out); }
+};
+struct GenPiece {
+  std::shared_ptr<GenOwner> owner;
+  int64_t offset, len;
+};
 
 struct CoColumn {
   ah_type type = AH_INT64;
   int width = 8;
+  bool generic = false;  // Boolean / Utf8 / LargeUtf8: pieces + concat
   void* values = nullptr;
   uint8_t* validity = nullptr;
   size_t vbytes = 0, bbytes = 0;
+  std::vector<GenPiece> pieces;
 };
+
+// rows [offset, offset + len) of an array as a view (Array::slice for the three generic layouts and the primitives)
+ah_array_view slice_view(ah_type t, const void* values, int64_t values_bit_offset, const uint8_t* validity,
+                         int64_t validity_bit_offset, const void* offsets, int64_t whole_len, int64_t whole_nulls, int64_t offset,
+                         int64_t len) {
+  ah_array_view v{};
+  v.type = t;
+  v.length = len;
+  const int w = ah_type_width(t);
+  if (t == AH_UTF8 || t == AH_LARGE_UTF8) {
+    v.values = values;
+    v.offsets = offsets ? (const char*)offsets + (size_t)offset * (t == AH_UTF8 ? 4 : 8) : nullptr;
+  } else if (t == AH_BOOL) {
+    v.values = values;
+    v.values_bit_offset = values_bit_offset + offset;
+  } else {
+    v.values = values ? (const char*)values + (size_t)offset * w : nullptr;
+  }
+  if (validity) {
+    v.validity = validity;
+    v.validity_bit_offset = validity_bit_offset + offset;
+    v.null_count = (offset == 0 && len == whole_len) ? whole_nulls : -1;
+  }
+  return v;
+}
+ah_array_view piece_view(const GenPiece& p) {
+  const ah_array_out& o = p.owner->out;
+  return slice_view(o.type, o.values, o.values_bit_offset, o.validity, o.validity_bit_offset, o.offsets, o.length,
+                    o.validity ? o.null_count : 0, p.offset, p.len);
+}
 
 struct CoBatch {
   std::vector<ah_array_out> cols;
   int64_t rows = 0;
   uint64_t tag = 0;  // != 0: a bypassed input batch (borrowed buffers), the caller's tag for it
+  // a finished batch whose null counts are still on their way: they land in pinned words [ring, ring + ncols) once the
+  // mailbox has passed `seq`; resolved (validity kept or dropped) when the batch is fetched
+  bool pending = false;
+  uint64_t seq = 0;
+  int ring = 0;
 };
 
 }  // namespace
@@ -60,6 +118,9 @@ struct ah_coalescer {
   std::deque<CoBatch> completed;
   uint64_t* acc = nullptr;  // device: 64 appended-null counters per column of the in-progress batch (scatter tiles spread
                             // their atomics over them; copies add to the first); summed once per finished batch
+  uint64_t* pin = nullptr;      // own pinned words for the finished batches' null counts (host view / device view)
+  uint64_t* pin_dev = nullptr;
+  int ring_next = 0, ring_slots = 0;  // ring of ncols-word groups in `pin`
   double selectivity = 0.1;  // of the last filtered push: picks the speculative scatter's load-predication mode
   bool failed = false;       // a device error hit after rows had been enqueued into the in-progress batch
 };
@@ -68,7 +129,7 @@ namespace {
 
 ah_status ensure_capacity(ah_context* ctx, ah_coalescer* co) {  // allocate on first write (primitive.rs:57-61)
   for (auto& c : co->cols) {
-    if (c.values) continue;
+    if (c.values || c.generic) continue;
     c.vbytes = std::max<size_t>((size_t)co->target * c.width, 8);
     c.bbytes = ah_bitmap_bytes(co->target);
     AH_TRY(ah_out_alloc(ctx, c.vbytes, &c.values));
@@ -87,29 +148,75 @@ ah_status ensure_capacity(ah_context* ctx, ah_coalescer* co) {  // allocate on f
   return AH_OK;
 }
 
+// fills in what the null counts decide: NullBufferBuilder::finish keeps a buffer only if a null was ever appended
+void resolve_batch(ah_context* ctx, ah_coalescer* co, CoBatch& b, const uint64_t* nulls) {
+  for (int i = 0; i < co->ncols; ++i) {
+    if (co->cols[i].generic) continue;
+    ah_array_out& o = b.cols[i];
+    if (nulls[i] > 0) {
+      o.null_count = (int64_t)nulls[i];
+    } else {
+      ah_out_free(ctx, o.validity, (size_t)o.validity_bytes);
+      o.validity = nullptr;
+      o.validity_bytes = 0;
+    }
+  }
+  b.pending = false;
+}
+ah_status resolve_pending(ah_context* ctx, ah_coalescer* co, CoBatch& b) {
+  if (!b.pending) return AH_OK;
+  AH_TRY(ah_coalesce_wait(ctx, b.seq));
+  resolve_batch(ctx, co, b, co->pin + (size_t)b.ring * co->ncols);
+  return AH_OK;
+}
+
 ah_status finish_buffered(ah_context* ctx, ah_coalescer* co) {  // coalesce.rs:536
   if (co->buffered == 0) return AH_OK;
-  std::vector<uint64_t> nulls((size_t)co->ncols, 0);
-  // the ONE wait of this output batch; it also means every scatter / copy into it has finished
-  AH_TRY(ah_coalesce_read_nulls(ctx, (unsigned long long*)co->acc, co->ncols, nulls.data()));
+  // NO wait: one kernel folds the null counters into this batch's pinned ring slot and posts the mailbox; the host
+  // looks at them when the batch is fetched.  (A wait here kept the host from enqueueing the next pushes: ~15 us of
+  // idle GPU per output batch.)  The ring slot must be free: the batch that used it last has been resolved.
+  const int ring = co->ring_next;
+  for (auto& old : co->completed)
+    if (old.pending && old.ring == ring) AH_TRY(resolve_pending(ctx, co, old));
+  co->ring_next = (co->ring_next + 1) % co->ring_slots;
+  uint64_t seq = 0;
+  AH_TRY(ah_coalesce_post_nulls(ctx, (unsigned long long*)co->acc, co->ncols, co->pin_dev + (size_t)ring * co->ncols, &seq));
   CoBatch b;
   b.rows = co->buffered;
+  b.pending = true;
+  b.seq = seq;
+  b.ring = ring;
   b.cols.resize((size_t)co->ncols);
   for (int i = 0; i < co->ncols; ++i) {
     CoColumn& c = co->cols[i];
     ah_array_out& o = b.cols[i];
     ah_out_init(&o);
+    if (c.generic) {  // GenericInProgressArray::finish (generic.rs:90-108): concat of the buffered pieces
+      ah_status gs = AH_OK;
+      if (c.pieces.size() == 1 && c.pieces[0].owner.use_count() == 1 && c.pieces[0].offset == 0 &&
+          c.pieces[0].len == c.pieces[0].owner->out.length) {
+        o = c.pieces[0].owner->out;  // the one piece IS the batch: hand its buffers over
+        ah_out_init(&c.pieces[0].owner->out);
+      } else {
+        std::vector<ah_array_view> views;
+        for (auto& p : c.pieces) views.push_back(piece_view(p));
+        gs = ah_concat(ctx, (int32_t)views.size(), views.data(), &o);
+      }
+      c.pieces.clear();
+      if (gs != AH_OK) {
+        for (int k = 0; k < i; ++k) ah_array_release(ctx, &b.cols[k]);
+        co->failed = true;
+        return gs;
+      }
+      continue;
+    }
     o.type = c.type;
     o.length = co->buffered;
     o.values = c.values;
     o.values_bytes = (int64_t)c.vbytes;
-    if (nulls[i] > 0) {  // NullBufferBuilder::finish: a buffer only if a null was ever appended
-      o.validity = c.validity;
-      o.validity_bytes = (int64_t)c.bbytes;
-      o.null_count = (int64_t)nulls[i];
-    } else {
-      ah_out_free(ctx, c.validity, c.bbytes);
-    }
+    o.validity = c.validity;  // kept or dropped when the null count is known (resolve_batch)
+    o.validity_bytes = (int64_t)c.bbytes;
+    o.null_count = -1;
     c.values = nullptr;
     c.validity = nullptr;
   }
@@ -118,9 +225,30 @@ ah_status finish_buffered(ah_context* ctx, ah_coalescer* co) {  // coalesce.rs:5
   return AH_OK;
 }
 
-ah_status copy_rows_all(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns, int64_t offset, int64_t len) {
+// `owners` (optional, per column): the array behind columns[i] is owned by the coalescer (a filtered or taken
+// result): generic columns then reference it instead of copying the rows out
+ah_status copy_rows_all(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns, int64_t offset, int64_t len,
+                        const std::shared_ptr<GenOwner>* owners = nullptr) {
   AH_TRY(ensure_capacity(ctx, co));
   for (int i = 0; i < co->ncols; ++i) {
+    if (co->cols[i].generic) {
+      if (owners && owners[i]) {
+        co->cols[i].pieces.push_back(GenPiece{owners[i], offset, len});
+        continue;
+      }
+      // the caller's buffers are only borrowed for this call (the reference keeps an Arc'ed slice): copy the rows out
+      const ah_array_view& s = columns[i];
+      const ah_array_view sl = slice_view(s.type, s.values, s.values_bit_offset, s.validity, s.validity_bit_offset, s.offsets,
+                                          s.length, s.null_count, offset, len);
+      ah_array_out piece;
+      const ah_status gs = ah_concat(ctx, 1, &sl, &piece);
+      if (gs != AH_OK) {
+        if (i > 0) co->failed = true;
+        return gs;
+      }
+      co->cols[i].pieces.push_back(GenPiece{std::make_shared<GenOwner>(ctx, piece), 0, len});
+      continue;
+    }
     const ah_status st = ah_copy_rows_into_acc(ctx, &columns[i], offset, len, co->cols[i].values, co->cols[i].validity,
                                                co->buffered, co->acc + (size_t)i * 64);
     if (st != AH_OK) {
@@ -158,7 +286,9 @@ ah_status bypass(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns
     o.type = columns[i].type;
     o.length = num_rows;
     o.values = const_cast<void*>(columns[i].values);
-    o.values_bytes = num_rows * co->cols[i].width;
+    o.values_bytes = co->cols[i].width > 0 ? num_rows * co->cols[i].width : 0;
+    o.values_bit_offset = columns[i].values_bit_offset;
+    o.offsets = const_cast<void*>(columns[i].offsets);
     o.flags = AH_OUT_BORROWED;
     if (columns[i].validity) {
       int64_t nulls = 0;
@@ -174,7 +304,7 @@ ah_status bypass(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns
 
 // `offset0`: rows [0, offset0) of `columns` are already in the coalescer (a speculative scatter put them there)
 ah_status push_batch_impl(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns, int64_t num_rows, uint64_t tag,
-                          int32_t* bypassed, int64_t offset0 = 0) {
+                          int32_t* bypassed, int64_t offset0 = 0, const std::shared_ptr<GenOwner>* owners = nullptr) {
   if (num_rows - offset0 <= 0) return AH_OK;
   if (offset0 == 0 && co->limit >= 0 && num_rows > co->limit) {
     if (co->buffered == 0) {  // case 1
@@ -190,13 +320,13 @@ ah_status push_batch_impl(ah_context* ctx, ah_coalescer* co, const ah_array_view
   int64_t remaining_rows = num_rows - offset0, offset = offset0;
   while (remaining_rows > co->target - co->buffered) {
     const int64_t room = co->target - co->buffered;
-    AH_TRY(copy_rows_all(ctx, co, columns, offset, room));
+    AH_TRY(copy_rows_all(ctx, co, columns, offset, room, owners));
     co->buffered += room;
     offset += room;
     remaining_rows -= room;
     AH_TRY(finish_buffered(ctx, co));
   }
-  if (remaining_rows > 0) AH_TRY(copy_rows_all(ctx, co, columns, offset, remaining_rows));
+  if (remaining_rows > 0) AH_TRY(copy_rows_all(ctx, co, columns, offset, remaining_rows, owners));
   co->buffered += remaining_rows;
   if (co->buffered >= co->target) AH_TRY(finish_buffered(ctx, co));
   return AH_OK;
@@ -220,20 +350,32 @@ extern "C" ah_status ah_coalescer_create(ah_context* ctx, int32_t n_columns, con
   co->cols.resize((size_t)n_columns);
   for (int i = 0; i < n_columns; ++i) {
     const int w = ah_type_width(types[i]);
-    if (w <= 0 || types[i] == AH_UTF8_VIEW || types[i] == AH_BINARY_VIEW) {
+    const bool generic = types[i] == AH_BOOL || types[i] == AH_UTF8 || types[i] == AH_LARGE_UTF8;
+    if ((w <= 0 && !generic) || types[i] == AH_UTF8_VIEW || types[i] == AH_BINARY_VIEW) {
       delete co;
-      return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "native BatchCoalescer column type %s (fixed-width types only)",
-                     ah_type_name(types[i]));
+      return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "BatchCoalescer column type %s", ah_type_name(types[i]));
     }
     co->cols[i].type = types[i];
     co->cols[i].width = w;
+    co->cols[i].generic = generic;
   }
   // acc: 64 appended-null counters per column
   const size_t acc_bytes = (size_t)n_columns * 8 * 64;
   ah_status st = ah_pool_alloc(ctx, acc_bytes, (void**)&co->acc);
   if (st == AH_OK && hipMemsetAsync(co->acc, 0, acc_bytes, ctx->stream) != hipSuccess)
     st = ah_fail(ctx, AH_HIP_ERROR, "coalescer counter reset failed");
+  if (st == AH_OK) {
+    co->ring_slots = std::max(4, 512 / n_columns);
+    if (hipHostMalloc((void**)&co->pin, (size_t)co->ring_slots * n_columns * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+      st = ah_fail(ctx, AH_OUT_OF_MEMORY, "coalescer pinned words");
+    else {
+      void* dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, co->pin, 0) != hipSuccess || !dp) dp = co->pin;
+      co->pin_dev = (uint64_t*)dp;
+    }
+  }
   if (st != AH_OK) {
+    ah_pool_free(ctx, co->acc);
     delete co;
     return st;
   }
@@ -249,9 +391,11 @@ extern "C" void ah_coalescer_destroy(ah_context* ctx, ah_coalescer* co) {
     for (auto& c : co->cols) {
       ah_out_free(ctx, c.values, c.vbytes);
       ah_out_free(ctx, c.validity, c.bbytes);
+      c.pieces.clear();  // releases the owned arrays while the context is alive
     }
-    for (auto& b : co->completed) release_batch(ctx, b);
+    for (auto& b : co->completed) release_batch(ctx, b);  // (the wait above passed every pending batch's kernel)
     ah_pool_free(ctx, co->acc);
+    if (co->pin) hipHostFree(co->pin);
   }
   delete co;
 }
@@ -350,7 +494,14 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
           co->completed.push_back(std::move(b));
         }
       } else {
-        st = push_batch_impl(ctx, co, views.data(), selected, 0, nullptr, done);
+        // generic columns adopt their filtered array (shared between the output batches it straddles)
+        std::vector<std::shared_ptr<GenOwner>> owners((size_t)co->ncols);
+        for (int i = 0; i < co->ncols; ++i)
+          if (co->cols[i].generic) {
+            owners[i] = std::make_shared<GenOwner>(ctx, outs[i]);
+            ah_out_init(&outs[i]);
+          }
+        st = push_batch_impl(ctx, co, views.data(), selected, 0, nullptr, done, owners.data());
         if (st == AH_OK) st = ah_stream_wait(ctx) == hipSuccess ? AH_OK : ah_fail(ctx, AH_HIP_ERROR, "coalescer copy failed");
       }
     }
@@ -359,8 +510,21 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
   }
   st = ensure_capacity(ctx, co);
   for (int i = 0; i < co->ncols && st == AH_OK; ++i) {
-    st = ah_filter_predicate_apply_into_acc(ctx, p, &columns[i], co->cols[i].values, co->cols[i].validity, co->buffered,
-                                            co->acc + (size_t)i * 64);
+    if (co->cols[i].generic) {  // copy_rows_by_filter_from of GenericInProgressArray (generic.rs:81-88): keep the filtered array
+      ah_array_out piece;
+      st = ah_filter_predicate_apply(ctx, p, &columns[i], &piece);
+      if (st == AH_OK) {
+        if (piece.flags & AH_OUT_BORROWED) {  // (cannot happen here: selected < rows) never keep borrowed buffers
+          ah_array_release(ctx, &piece);
+          st = ah_fail(ctx, AH_INVALID_ARGUMENT, "coalescer: unexpected borrowed filter result");
+        } else {
+          co->cols[i].pieces.push_back(GenPiece{std::make_shared<GenOwner>(ctx, piece), 0, selected});
+        }
+      }
+    } else {
+      st = ah_filter_predicate_apply_into_acc(ctx, p, &columns[i], co->cols[i].values, co->cols[i].validity, co->buffered,
+                                              co->acc + (size_t)i * 64);
+    }
     if (st != AH_OK && i > 0) co->failed = true;  // some columns have the rows, `buffered` does not
   }
   if (st == AH_OK) {
@@ -515,6 +679,54 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_
   return st;
 }
 
+// push_batch_with_indices (coalesce.rs:289-297): `take_record_batch(&batch, indices)` then push_batch of the result.
+// The taken columns are owned here: generic columns adopt them, fixed-width ones are copied into the in-progress
+// buffers (the reference materialises and copies as well — its own "todo: optimize").
+extern "C" ah_status ah_coalescer_push_batch_with_indices(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns,
+                                                          int64_t num_rows, const ah_array_view* indices) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !co || !columns || !indices || num_rows < 0) return AH_INVALID_ARGUMENT;
+  hipSetDevice(ctx->device);
+  AH_TRY(check_columns(ctx, co, columns, num_rows));
+  std::vector<ah_array_out> outs((size_t)co->ncols);
+  for (auto& o : outs) ah_out_init(&o);
+  ah_status st = AH_OK;
+  for (int i = 0; i < co->ncols && st == AH_OK; ++i) st = ah_take(ctx, &columns[i], indices, 0, &outs[i]);
+  const int64_t rows = indices->length;
+  if (st == AH_OK && rows > 0) {
+    if (co->limit >= 0 && rows > co->limit && (co->buffered == 0 || co->buffered > co->limit)) {
+      // large-batch cases 1 / 2 on a batch this call owns: it leaves as an OWNED completed batch
+      if (co->buffered > co->limit) st = finish_buffered(ctx, co);
+      if (st == AH_OK) {
+        CoBatch b;
+        b.rows = rows;
+        b.cols = outs;
+        for (auto& o : outs) ah_out_init(&o);
+        co->completed.push_back(std::move(b));
+      }
+    } else {
+      std::vector<ah_array_view> views((size_t)co->ncols);
+      std::vector<std::shared_ptr<GenOwner>> owners((size_t)co->ncols);
+      for (int i = 0; i < co->ncols; ++i) {
+        const ah_array_out& o = outs[i];
+        views[i] = slice_view(o.type, o.values, o.values_bit_offset, o.validity, o.validity_bit_offset, o.offsets, o.length,
+                              o.validity ? o.null_count : 0, 0, o.length);
+        if (co->cols[i].generic) {
+          owners[i] = std::make_shared<GenOwner>(ctx, outs[i]);
+          ah_out_init(&outs[i]);
+        }
+      }
+      // (bypass cannot trigger again inside: limit < 0, or rows <= limit, or case 3 = coalesce normally)
+      const int64_t saved_limit = co->limit;
+      co->limit = -1;
+      st = push_batch_impl(ctx, co, views.data(), rows, 0, nullptr, 0, owners.data());
+      co->limit = saved_limit;
+    }
+  }
+  for (auto& o : outs) ah_array_release(ctx, &o);  // fixed-width copies are stream-ordered behind the pool's reuse
+  return st;
+}
+
 extern "C" ah_status ah_coalescer_finish_buffered_batch(ah_context* ctx, ah_coalescer* co) {
   ah_ctx_guard _guard(ctx);
   if (!ctx || !co) return AH_INVALID_ARGUMENT;
@@ -534,6 +746,7 @@ extern "C" ah_status ah_coalescer_next_completed_batch(ah_context* ctx, ah_coale
     return AH_OK;
   }
   CoBatch& b = co->completed.front();
+  AH_TRY(resolve_pending(ctx, co, b));
   for (int i = 0; i < co->ncols; ++i) outs[i] = b.cols[i];
   *num_rows = b.rows;
   if (tag) *tag = b.tag;

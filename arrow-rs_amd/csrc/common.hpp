@@ -182,6 +182,10 @@ ah_status ah_ranges_to_strings(ah_context* ctx, bool large, const uint8_t* src, 
                                const void* ends, int64_t k, bool overflow_is_error, ah_array_out* out);
 ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_array_view* indices,
                         ah_array_out* out);
+struct ah_filter_predicate;
+// strings.hip: [start, end) of the rows the predicate selects, one pass over the offsets
+ah_status ah_string_filter_ranges(ah_context* ctx, const ah_filter_predicate* p, bool large, const void* offsets, void* starts,
+                                  void* ends);
 
 // bitmap.hip: ah_bitmap_set_bits without a read-back — *nulls_acc (device) += len - popcount(copied bits)
 ah_status ah_bitmap_set_bits_acc(ah_context* ctx, uint8_t* dst, int64_t dst_bit_offset, const uint8_t* src,

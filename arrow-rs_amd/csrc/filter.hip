@@ -153,6 +153,82 @@ __global__ void __launch_bounds__(64) filter_count_small_kernel(BitView mask, Bi
   if (lane == 63) group_total[blockIdx.x] = (uint32_t)incl;
 }
 
+// K1 for up to 8 small predicates in ONE launch (blockIdx.y = predicate): the grouped push of BatchCoalescer counted 60
+// batches per 1e9 rows with 120 launches of ~6 us each — 0.7 ms of a 4 ms step.
+struct CountMulti {
+  struct One {
+    BitView mask, mask_valid;
+    int64_t len;
+    uint32_t* chunk_prefix;
+    uint32_t* group_total;
+    unsigned long long* group_prefix;
+    unsigned long long* total;
+    int64_t ngroups;
+  } p[8];
+};
+__global__ void __launch_bounds__(64) filter_count_small_multi_kernel(CountMulti m) {
+  const CountMulti::One& o = m.p[blockIdx.y];
+  if ((int64_t)blockIdx.x >= o.ngroups) return;
+  __shared__ uint32_t s_cnt[64];
+  const int lane = threadIdx.x;
+  const int64_t chunk_base = (int64_t)blockIdx.x * 64, len = o.len;
+  const bool has_mv = o.mask_valid.words != nullptr;
+  BvRaw rm[16], rv[16] = {};
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
+    rm[it] = bv_issue(o.mask, s < len ? s : 0, len);
+  }
+  if (has_mv) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
+      rv[it] = bv_issue(o.mask_valid, s < len ? s : 0, len);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
+    const int64_t sc = s < len ? s : 0;
+    uint64_t mk = bv_finish(rm[it], sc, len);
+    if (has_mv) mk &= bv_finish(rv[it], sc, len);
+    if (s >= len) mk = 0;
+    int c = __popcll(mk);
+    c += __shfl_xor(c, 1, 64);
+    c += __shfl_xor(c, 2, 64);
+    c += __shfl_xor(c, 4, 64);
+    c += __shfl_xor(c, 8, 64);
+    if ((lane & 15) == 0) s_cnt[it * 4 + (lane >> 4)] = (uint32_t)c;
+  }
+  __syncthreads();
+  const int v = (int)s_cnt[lane];
+  const int incl = wave_scan_incl(v);
+  const int64_t nchunks = (len + CHUNK_ROWS - 1) / CHUNK_ROWS;
+  if (chunk_base + lane < nchunks) o.chunk_prefix[chunk_base + lane] = (uint32_t)(incl - v);
+  if (lane == 63) o.group_total[blockIdx.x] = (uint32_t)incl;
+}
+// K2 of the same: block b scans predicate b's group totals (<= 1024 of them) and sends its K to pinned slot slot0 + b
+__global__ void __launch_bounds__(1024) filter_group_scan_multi_kernel(CountMulti m, uint64_t* mail, int slot0) {
+  const CountMulti::One& o = m.p[blockIdx.x];
+  __shared__ unsigned long long s_wave[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned long long v = t < o.ngroups ? o.group_total[t] : 0ull, incl = v;
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    unsigned long long u = __shfl_up(incl, k, 64);
+    if (lane >= k) incl += u;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned long long wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += s_wave[w];
+  if (t < o.ngroups) o.group_prefix[t] = wbase + incl - v;
+  if (t == 1023) {
+    *o.total = wbase + incl;
+    __hip_atomic_store(mail + slot0 + blockIdx.x, (uint64_t)(wbase + incl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ------------------------------------------------------------------ K2
 __global__ void __launch_bounds__(1024) filter_group_scan_kernel(const uint32_t* group_total,
                                                                  int64_t ngroups,
@@ -718,11 +794,55 @@ extern "C" ah_status ah_filter_predicates_build(ah_context* ctx, int32_t n, cons
   for (int i = 0; i < n; ++i) outs[i] = nullptr;
   std::vector<char> launched((size_t)std::max(n, 1), 0);
   ah_status st = AH_OK;
+  // small predicates (<= 1 Mi rows... up to 64 Mi: <= 1024 count groups) are counted eight per launch
+  CountMulti cm{};
+  int ncm = 0, cm_first = 0;
+  int64_t cm_groups = 0;
+  auto flush_multi = [&]() {
+    if (ncm == 0) return;
+    ah_prof_scope ps(ctx, "filter_count");
+    filter_count_small_multi_kernel<<<dim3((unsigned)cm_groups, (unsigned)ncm), 64, 0, ctx->stream>>>(cm);
+    filter_group_scan_multi_kernel<<<(unsigned)ncm, 1024, 0, ctx->stream>>>(cm, ctx->pinned_dev, 16 + cm_first);
+    ncm = 0;
+    cm_groups = 0;
+  };
   for (int i = 0; i < n && st == AH_OK; ++i) {
-    bool enq = false;
-    st = predicate_enqueue(ctx, &predicates[i], 16 + i, 0, &outs[i], &enq);
-    launched[i] = enq ? 1 : 0;
+    const ah_array_view* pv = &predicates[i];
+    const int64_t nchunks = pv->type == AH_BOOL && pv->length > 0 ? ah_ceil_div(pv->length, CHUNK_ROWS) : 0;
+    if (nchunks == 0 || nchunks > 65536) {  // empty / wrong type (error below) / large: the single-predicate path
+      flush_multi();
+      bool enq = false;
+      st = predicate_enqueue(ctx, pv, 16 + i, 0, &outs[i], &enq);
+      launched[i] = enq ? 1 : 0;
+      continue;
+    }
+    auto* p = new ah_filter_predicate();
+    p->len = pv->length;
+    p->mask = make_bitview(pv->values, pv->values_bit_offset);
+    p->mask_valid = (pv->validity && pv->null_count != 0) ? make_bitview(pv->validity, pv->validity_bit_offset) : BitView{nullptr, 0};
+    p->group_shift = 6;
+    const int64_t ngroups = ah_ceil_div(nchunks, 64);
+    const size_t b_chunk = ((size_t)nchunks * 4 + 255) & ~(size_t)255, b_gt = ((size_t)ngroups * 4 + 255) & ~(size_t)255,
+                 b_gp = ((size_t)ngroups * 8 + 255) & ~(size_t)255;
+    st = ah_pool_alloc(ctx, b_chunk + b_gt + b_gp + 256, &p->block);
+    if (st != AH_OK) {
+      delete p;
+      break;
+    }
+    char* base = (char*)p->block;
+    p->chunk_prefix = (uint32_t*)base;
+    p->group_prefix = (unsigned long long*)(base + b_chunk + b_gt);
+    p->total_dev = (unsigned long long*)(base + b_chunk + b_gt + b_gp);
+    outs[i] = p;
+    launched[i] = 1;
+    if (ncm == 0) cm_first = i;
+    CountMulti::One& o = cm.p[ncm++];
+    o.mask = p->mask, o.mask_valid = p->mask_valid, o.len = p->len, o.chunk_prefix = p->chunk_prefix;
+    o.group_total = (uint32_t*)(base + b_chunk), o.group_prefix = p->group_prefix, o.total = p->total_dev, o.ngroups = ngroups;
+    cm_groups = std::max(cm_groups, ngroups);
+    if (ncm == 8) flush_multi();
   }
+  if (st == AH_OK) flush_multi();
   if (st == AH_OK) {
     hipError_t e = ah_stream_wait(ctx);  // one flag kernel behind all the count passes
     if (e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "filter count failed: %s", hipGetErrorString(e));
@@ -863,36 +983,21 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
 
   if (is_string) {  // filter_bytes (filter.rs:890-928): ranges of the selected rows -> new offsets + bytes
     const bool large = values->type == AH_LARGE_UTF8;
-    // Two primitive scatters over offsets[0..n) and offsets[1..n+1) give the selected rows' [start, end).
-    // The first one also carries the column's validity, so the null buffer is compacted by the same pass
-    // (filter_nulls :512-532) instead of a third walk over the predicate.  Both run deferred: the only
-    // host round trip of the string path is the byte total inside ah_ranges_to_strings.
-    ah_array_view ov{};
-    ov.type = large ? AH_INT64 : AH_INT32;
-    ov.length = values->length;
-    ov.values = values->offsets;
-    if (has_valid) {
-      ov.validity = values->validity;
-      ov.validity_bit_offset = values->validity_bit_offset;
-      ov.null_count = in_nulls;
-    }
-    ah_array_out s_out{}, e_out{};
-    const bool was_deferred = ctx->deferred;
-    ctx->deferred = true;
-    ah_status st = ah_filter_predicate_apply(ctx, p, &ov, &s_out);
-    ov.values = (const char*)values->offsets + (large ? 8 : 4);
-    ov.validity = nullptr;
-    ov.null_count = 0;
-    if (st == AH_OK) st = ah_filter_predicate_apply(ctx, p, &ov, &e_out);
-    ctx->deferred = was_deferred;
-    if (st == AH_OK)
-      st = ah_ranges_to_strings(ctx, large, (const uint8_t*)values->values, s_out.values, e_out.values, K, false, out);
-    uint8_t* nb = s_out.validity;  // ownership moves to `out`
-    const size_t nbytes = (size_t)s_out.validity_bytes;
-    s_out.validity = nullptr;
-    s_out.validity_bytes = 0;
-    ah_array_release(ctx, &s_out);
-    ah_array_release(ctx, &e_out);
+    const size_t ow = large ? 8 : 4;
+    // ONE pass over the offsets writes the selected rows' [start, end) pairs (strings.hip); the column's validity is
+    // compacted by the bit-only scatter (filter_nulls :512-532).  Nothing waits here: the only host round trips of the
+    // string path are the byte total inside ah_ranges_to_strings and the null count.
+    char* tmp = nullptr;
+    AH_TRY(ah_pool_alloc(ctx, 2 * (((size_t)K * ow + 15) & ~(size_t)15) + 16, (void**)&tmp));
+    void* starts = tmp;
+    void* ends = tmp + (((size_t)K * ow + 15) & ~(size_t)15);
+    ah_status st = ah_string_filter_ranges(ctx, p, large, values->offsets, starts, ends);
+    uint8_t* nb = nullptr;
+    size_t nbytes = 0;
+    int64_t nset = -1;
+    if (st == AH_OK && has_valid) st = compact_bits(ctx, p, vvalid, &nb, &nbytes, &nset, /*defer=*/true);
+    if (st == AH_OK) st = ah_ranges_to_strings(ctx, large, (const uint8_t*)values->values, starts, ends, K, false, out);
+    ah_pool_free(ctx, tmp);
     if (st != AH_OK) {
       ah_out_free(ctx, nb, nbytes);
       ah_out_init(out);
@@ -901,18 +1006,18 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
     out->type = values->type;
     out->length = K;
     if (nb) {
-      int64_t nset = 0;  // ah_ranges_to_strings synchronised the stream: the bitmap is complete
-      st = ah_count_set_bits(ctx, nb, 0, K, &nset);
+      int64_t cnt = 0;  // ah_ranges_to_strings synchronised the stream: the bitmap is complete
+      st = ah_count_set_bits(ctx, nb, 0, K, &cnt);
       if (st != AH_OK) {
         ah_out_free(ctx, nb, nbytes);
         ah_array_release(ctx, out);
         return st;
       }
-      if (K - nset == 0) ah_out_free(ctx, nb, nbytes);  // filter_nulls :523-525 -> None
+      if (K - cnt == 0) ah_out_free(ctx, nb, nbytes);  // filter_nulls :523-525 -> None
       else {
         out->validity = nb;
         out->validity_bytes = (int64_t)nbytes;
-        out->null_count = K - nset;
+        out->null_count = K - cnt;
       }
     }
     return AH_OK;
@@ -1220,25 +1325,32 @@ ah_status ah_filter_apply_multi(ah_context* ctx, int nsegs, const ah_filter_pred
   return AH_OK;
 }
 
-// the per-column NULL-row counters of a BatchCoalescer (ncols x 64 slots) -> host, slots back to zero: ONE launch,
-// ONE wait per finished output batch (NullBufferBuilder only needs the count then, coalesce/primitive.rs:94-106)
-__global__ void __launch_bounds__(64) coalesce_finish_kernel(unsigned long long* slots, int ncols, uint64_t* mail, uint64_t seq) {
+// the per-column NULL-row counters of a BatchCoalescer (ncols x 64 slots) -> the coalescer's own pinned words `dst`
+// (device view of host memory), counters back to zero, then the context mailbox is posted with `seq`: ONE launch per
+// finished output batch and NO wait — the host reads the counts when the batch is fetched (ah_mail_wait(seq), long
+// passed by then).  NullBufferBuilder only needs the count at finish (coalesce/primitive.rs:94-106).
+__global__ void __launch_bounds__(64) coalesce_finish_kernel(unsigned long long* slots, int ncols, uint64_t* dst, uint64_t* mail,
+                                                             uint64_t seq) {
   for (int c = 0; c < ncols; ++c) {
     unsigned long long v = slots[(size_t)c * 64 + threadIdx.x];
     slots[(size_t)c * 64 + threadIdx.x] = 0;
     v = wave_reduce_add64(v);
-    if (threadIdx.x == 0) __hip_atomic_store(mail + c, (uint64_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(dst + c, (uint64_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (threadIdx.x == 0) ah_mail_post(mail, seq);
 }
-ah_status ah_coalesce_read_nulls(ah_context* ctx, unsigned long long* slots, int ncols, uint64_t* host_out) {
+ah_status ah_coalesce_post_nulls(ah_context* ctx, unsigned long long* slots, int ncols, uint64_t* pinned_dst_dev, uint64_t* seq_out) {
   if (ncols < 1 || ncols > 200) return AH_INVALID_ARGUMENT;
   const uint64_t seq = ah_mail_next(ctx);
-  coalesce_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, ncols, ctx->pinned_dev, seq);
+  coalesce_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, ncols, pinned_dst_dev, ctx->pinned_dev, seq);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
   if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "coalescer finish failed: %s", hipGetErrorString(e));
-  for (int c = 0; c < ncols; ++c) host_out[c] = ctx->pinned[c];
+  *seq_out = seq;
+  return AH_OK;
+}
+ah_status ah_coalesce_wait(ah_context* ctx, uint64_t seq) {
+  hipError_t e = ah_mail_wait(ctx, seq);
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "coalescer finish failed: %s", hipGetErrorString(e));
   return AH_OK;
 }
 

@@ -329,15 +329,14 @@ const char* cmp_sym_e(int op) {
 
 }  // namespace
 
-extern "C" ah_status ah_filter_predicate_build_expr(ah_context* ctx, int32_t n_terms, const ah_filter_term* terms,
-                                                    const ah_boolean_op* joins, ah_filter_predicate** out) {
-  ah_ctx_guard _guard(ctx);
-  if (!ctx || !out || !terms || (n_terms > 1 && !joins)) return AH_INVALID_ARGUMENT;
-  *out = nullptr;
+// the terms of a filter expression, validated with compare_op's / binary_boolean_kernel's texts
+static ah_status parse_terms(ah_context* ctx, int32_t n_terms, const ah_filter_term* terms, const ah_boolean_op* joins, ExprArgs* pa,
+                             int64_t* plen) {
+  if (!terms || (n_terms > 1 && !joins)) return AH_INVALID_ARGUMENT;
   if (n_terms < 1 || n_terms > EXPR_MAX_TERMS)
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "a filter expression takes 1..%d comparison terms, got %d", EXPR_MAX_TERMS, n_terms);
-  hipSetDevice(ctx->device);
-  ExprArgs a{};
+  ExprArgs& a = *pa;
+  a = ExprArgs{};
   a.nterms = n_terms;
   int64_t len = -1;
   for (int k = 0; k < n_terms; ++k) {
@@ -383,6 +382,19 @@ extern "C" ah_status ah_filter_predicate_build_expr(ah_context* ctx, int32_t n_t
     e.l_vec = !ls && tl >= 2 && ((uintptr_t)e.l % (2 * e.width)) == 0;
     e.r_vec = !rs && tl >= 2 && ((uintptr_t)e.r % (2 * e.width)) == 0;
   }
+  *plen = len;
+  return AH_OK;
+}
+
+extern "C" ah_status ah_filter_predicate_build_expr(ah_context* ctx, int32_t n_terms, const ah_filter_term* terms,
+                                                    const ah_boolean_op* joins, ah_filter_predicate** out) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !out) return AH_INVALID_ARGUMENT;
+  *out = nullptr;
+  hipSetDevice(ctx->device);
+  ExprArgs a{};
+  int64_t len = -1;
+  AH_TRY(parse_terms(ctx, n_terms, terms, joins, &a, &len));
   auto* p = new ah_filter_predicate();
   p->len = len;
   p->mask_valid = BitView{nullptr, 0};
@@ -445,5 +457,63 @@ extern "C" ah_status ah_filter_predicate_build_expr(ah_context* ctx, int32_t n_t
   }
   p->count = (int64_t)ctx->pinned[0];
   *out = p;
+  return AH_OK;
+}
+
+// `filter(values, <expression>)` in one call: the lazy predicate, then the ordinary scatter.
+// (A SINGLE-PASS form — evaluate, decoupled look-back over ticket-ordered tiles with 8-byte state granules, compact, every
+// operand read once, 18.2 GB instead of 26.7 GB per 1e9 rows — was built, was bit-exact at 1e9 rows, and lost: 6.7 ms
+// against 4.6 ms for these two passes, 5.6 ms even with the look-back ablated.  Holding two tiles' values in registers
+// across the ticket, the aggregates and the look-back leaves 3 workgroups per CU working in phases that each expose a full
+// memory latency, where the two streaming kernels run at 5.8-5.9 TB/s.  It also needed the output allocated for the worst
+// case (8 GB here).  Numbers: profiles/r03_single_pass_lookback.md; nothing of it is in the tree.)
+extern "C" ah_status ah_filter_expr(ah_context* ctx, int32_t n_terms, const ah_filter_term* terms, const ah_boolean_op* joins,
+                                    const ah_array_view* values, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !values || !out) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  ah_filter_predicate* p = nullptr;
+  AH_TRY(ah_filter_predicate_build_expr(ctx, n_terms, terms, joins, &p));
+  const ah_status st = ah_filter_predicate_apply(ctx, p, values, out);
+  ah_filter_predicate_free(ctx, p);
+  return st;
+}
+
+// Buffer::shrink_to_fit for a result whose buffers were allocated for the worst case (the one-launch filter of small
+// batches, filter_small.hip): values / validity are copied into exact-size allocations.  Fixed-width
+// results only; a result that already fits, or borrows its buffers, is left as it is.
+extern "C" ah_status ah_array_shrink_to_fit(ah_context* ctx, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !out) return AH_INVALID_ARGUMENT;
+  const int w = ah_type_width(out->type);
+  if (w <= 0 || out->type == AH_BOOL || (out->flags & (AH_OUT_BORROWED | AH_OUT_BORROWED_VALUES)) || !out->values) return AH_OK;
+  hipSetDevice(ctx->device);
+  const size_t need = (size_t)out->length * w, bneed = ah_bitmap_bytes(out->length);
+  void *nv = nullptr, *nb = nullptr;
+  const bool sv = (size_t)out->values_bytes > need + (1u << 20);
+  const bool sb = out->validity && (size_t)out->validity_bytes > bneed + (1u << 20);
+  if (!sv && !sb) return AH_OK;
+  ah_status st = AH_OK;
+  if (sv) st = ah_out_alloc(ctx, need, &nv);
+  if (st == AH_OK && sb) st = ah_out_alloc(ctx, bneed, &nb);
+  hipError_t e = hipSuccess;
+  if (st == AH_OK && sv) e = hipMemcpyAsync(nv, out->values, need, hipMemcpyDeviceToDevice, ctx->stream);
+  if (st == AH_OK && e == hipSuccess && sb) e = hipMemcpyAsync(nb, out->validity, bneed, hipMemcpyDeviceToDevice, ctx->stream);
+  if (st == AH_OK && e == hipSuccess) e = ah_stream_wait(ctx);
+  if (st != AH_OK || e != hipSuccess) {
+    ah_out_free(ctx, nv, need);
+    ah_out_free(ctx, nb, bneed);
+    return st != AH_OK ? st : ah_fail(ctx, AH_HIP_ERROR, "shrink_to_fit failed: %s", hipGetErrorString(e));
+  }
+  if (sv) {
+    ah_out_free(ctx, out->values, (size_t)out->values_bytes);
+    out->values = nv;
+    out->values_bytes = (int64_t)need;
+  }
+  if (sb) {
+    ah_out_free(ctx, out->validity, (size_t)out->validity_bytes);
+    out->validity = (uint8_t*)nb;
+    out->validity_bytes = (int64_t)bneed;
+  }
   return AH_OK;
 }

@@ -15,10 +15,77 @@
 //      tail (rows <= 64 B); longer rows are copied cooperatively by the workgroup.  (The first
 //      version walked output bytes with a binary search per byte: 0.32 ms per 120 MB.)
 #include "common.hpp"
+#include "filter_internal.hpp"
 
 #include <type_traits>
 
 namespace {
+
+// filter_bytes' first half in ONE pass over the offsets (it used to be two runs of the primitive scatter kernel, over
+// offsets[0..n) and offsets[1..n+1): 2 x 8 bytes per row read, the second run through an unaligned pointer): every
+// thread owns 16 consecutive rows = a quarter of one predicate word, loads its 17 offsets, and writes the
+// [start, end) pair of each selected row at the row's rank (tile base from the predicate's prefix tables + popcounts).
+template <typename OFF, bool VEC>
+__global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* offsets, BitView mask, BitView mask_valid,
+                                                                   int64_t len, const uint32_t* chunk_prefix,
+                                                                   const unsigned long long* group_prefix, int group_shift,
+                                                                   OFF* starts, OFF* ends) {
+  constexpr int T = 4096, NW = 64, R = 16;
+  __shared__ uint64_t s_m[NW];
+  __shared__ uint32_t s_base[NW];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * T;
+  const int64_t r0 = row0 + (int64_t)t * R;
+  // the thread's offsets go out first
+  OFF o[R + 1];
+  if (r0 + R <= len) {
+    if constexpr (VEC) {
+      constexpr int PV = 16 / sizeof(OFF);  // offsets per 16-byte load
+      struct alignas(16) V16 { OFF e[PV]; };
+#pragma unroll
+      for (int k = 0; k < R / PV; ++k) {
+        const V16 v = *(const V16*)(offsets + r0 + k * PV);
+#pragma unroll
+        for (int e = 0; e < PV; ++e) o[k * PV + e] = v.e[e];
+      }
+      o[R] = offsets[r0 + R];
+    } else {
+#pragma unroll
+      for (int e = 0; e <= R; ++e) o[e] = offsets[r0 + e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e <= R; ++e) o[e] = r0 + e <= len ? offsets[r0 + e] : (OFF)0;
+  }
+  if (wave == 0) {
+    uint64_t m = 0;
+    const int64_t s = row0 + ((int64_t)lane << 6);
+    if (s < len) {
+      m = bv_fetch64(mask, s, len);
+      if (mask_valid.words) m &= bv_fetch64(mask_valid, s, len);
+    }
+    const int c = __popcll(m);
+    const int incl = wave_scan_incl(c);
+    s_m[lane] = m;
+    s_base[lane] = (uint32_t)(incl - c);
+  }
+  __syncthreads();
+  const int sh = (t * R) & 63;
+  const uint64_t word = s_m[(t * R) >> 6];
+  uint32_t bits = (uint32_t)(word >> sh) & 0xFFFFu;
+  if (!bits) return;
+  const int64_t chunk0 = row0 / AH_FILTER_CHUNK_ROWS;
+  int64_t pos = (int64_t)group_prefix[chunk0 >> group_shift] + chunk_prefix[chunk0] + s_base[(t * R) >> 6] +
+                __popcll(word & ((1ull << sh) - 1ull));
+#pragma unroll
+  for (int e = 0; e < R; ++e) {
+    if ((bits >> e) & 1u) {
+      starts[pos] = o[e];
+      ends[pos] = o[e + 1];
+      ++pos;
+    }
+  }
+}
 
 template <typename OFF>
 __global__ void __launch_bounds__(1024) range_scan_local_kernel(const OFF* starts, const OFF* ends, int64_t k,
@@ -288,6 +355,30 @@ ah_status launch_take_ranges(ah_context* ctx, const ah_array_view* values, const
 }
 
 }  // namespace
+
+// the [start, end) byte ranges of the rows `p` selects (K of each, device arrays of the offset type, caller-allocated)
+ah_status ah_string_filter_ranges(ah_context* ctx, const ah_filter_predicate* p, bool large, const void* offsets, void* starts,
+                                  void* ends) {
+  if (p->len <= 0 || p->count <= 0) return AH_OK;
+  const unsigned grid = (unsigned)ah_ceil_div(p->len, 4096);
+  const bool vec = (((uintptr_t)offsets) & 15) == 0;
+  ah_prof_scope ps(ctx, "string_filter_ranges");
+#define AH_SFR(OFF, VEC)                                                                                                      \
+  string_filter_ranges_kernel<OFF, VEC><<<grid, 256, 0, ctx->stream>>>((const OFF*)offsets, p->mask, p->mask_valid, p->len,   \
+                                                                        p->chunk_prefix, p->group_prefix, p->group_shift,      \
+                                                                        (OFF*)starts, (OFF*)ends)
+  if (large) {
+    if (vec) AH_SFR(int64_t, true);
+    else AH_SFR(int64_t, false);
+  } else {
+    if (vec) AH_SFR(int32_t, true);
+    else AH_SFR(int32_t, false);
+  }
+#undef AH_SFR
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "string filter ranges failed: %s", hipGetErrorString(e));
+  return AH_OK;
+}
 
 // ranges [starts[i], ends[i]) of `src` (device arrays of the offset type) -> offsets + bytes
 ah_status ah_ranges_to_strings(ah_context* ctx, bool large, const uint8_t* src, const void* starts,

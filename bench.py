@@ -390,7 +390,7 @@ PMC_STEP_KERNELS = {
     "string_filter_take": r"filter_(scatter|count|count_small|group_scan|finish)\w*_kernel|range_scan_\w+_kernel|"
                           r"gather_bytes_kernel|take_ranges_kernel",
     "coalesce": r"filter_(scatter|count|count_small|group_scan|finish|finish_acc)\w*_kernel|copy_rows\w*_kernel|bm_acc_kernel",
-    "predicate_filter_fused": r"filter_expr_count_kernel|filter_(scatter|group_scan|finish)\w*_kernel",
+    "predicate_filter_fused": r"filter_expr_\w+_kernel|filter_(scatter|group_scan|finish)\w*_kernel",
     "predicate_filter": r"compare_kernel|bitmap_op_kernel|filter_(scatter|count|count_small|group_scan|finish)\w*_kernel|popcount_partial_kernel",
 }
 PMC_CHILD_STEPS, PMC_CHILD_WARMUP = 2, 1
@@ -525,11 +525,15 @@ def build_workload(env, wl):
             co = K.BatchCoalescer.new(["a", "b"], [A.Int64, A.Float64], target, ctx)
             out_rows = 0
             for i in range(0, len(batches), group):
+                # batches finished by EARLIER pushes are handed downstream after this push has been enqueued: fetching a
+                # batch waits for its scatters, and a push's own count read-back has already waited for everything the
+                # earlier pushes enqueued — so the fetch costs nothing and the GPU has this push's work queued meanwhile
+                ready = co.completed_count()
                 if group == 1:
                     co.push_batch_with_filter(*batches[i])
                 else:
                     co.push_batches_with_filters(batches[i:i + group])
-                while co.has_completed_batch():
+                for _ in range(ready):
                     out_rows += co.next_completed_batch().num_rows()
             co.finish_buffered_batch()
             while co.has_completed_batch():
@@ -562,7 +566,7 @@ def build_workload(env, wl):
             return f, t
 
         W.update(step=step, dominant="string_gather_bytes",
-                 kernels=(["filter_count", "filter_scatter", "string_filter_copy"] if do_f else []) +
+                 kernels=(["filter_count", "filter_scatter", "string_filter_ranges"] if do_f else []) +
                          ["string_ranges_scan", "string_gather_bytes"] + (["string_take_ranges", "take_gather"] if do_t else []))
     elif wl == "predicate_filter":
         # the predicate is BUILT on the device and consumed by filter without leaving it —
@@ -588,8 +592,7 @@ def build_workload(env, wl):
         s1 = A.Scalar.new(0.0, A.Float64, ctx)
 
         def step(_r):
-            p_ = K.FilterBuilder.from_terms([("lt", col, s0), ("gt_eq", colb, s1)], ["and_kleene"]).build()
-            f = p_.filter(col)
+            f = K.filter_expr(col, [("lt", col, s0), ("gt_eq", colb, s1)], ["and_kleene"])
             st["k"], st["fn"] = f.length, f.null_count()
             return f
 
@@ -733,7 +736,7 @@ def describe(env, wl, W, prof, out, steps):
             "string_filter": "SURVEY 8f-3: filter on a LargeUtf8 column (cast output): order-preserving, selected runs stream",
             "string_take": "SURVEY 8f-3: take with uniform random UInt32 indices on a LargeUtf8 column (cast output): one row gather per index",
             "cast_string_utf8": "configs[3]: cast Float64->Utf8 (i32 offsets) in 64 Mi-row batches of the same column",
-            "predicate_filter_fused": "SURVEY 8f-2: the same WHERE a < 0 AND b >= 0 as ONE lazy predicate (ah_filter_expr): compares evaluated inside the count and scatter kernels",
+            "predicate_filter_fused": "SURVEY 8f-2: the same WHERE a < 0 AND b >= 0 handed over as terms (ah_filter_expr): the comparisons are ballots inside the filter's count pass, only the 1-bit-per-row selection is materialised",
             "predicate_filter": "SURVEY 8f-2: filter(a, and_kleene(lt(a, 0), gt_eq(b, 0.0))) on Int64 a, Float64 b with NullBuffers",
             "coalesce": f"SURVEY 8f-1: BatchCoalescer.push_batch_with_filter, Int64+Float64, "
                         f"{args.batch_rows}-row batches"

@@ -242,6 +242,12 @@ typedef struct ah_filter_term {
 AH_API ah_status ah_filter_predicate_build_expr(ah_context* ctx, int32_t n_terms, const ah_filter_term* terms,
                                                 const int32_t* joins /* n_terms - 1 ah_boolean_op values */,
                                                 ah_filter_predicate** out);
+/* `filter(values, <the expression>)` in one call: ah_filter_predicate_build_expr + ah_filter_predicate_apply. */
+AH_API ah_status ah_filter_expr(ah_context* ctx, int32_t n_terms, const ah_filter_term* terms, const int32_t* joins,
+                                const ah_array_view* values, ah_array_out* out);
+/* Buffer::shrink_to_fit for fixed-width results whose buffers were allocated for the worst case (filters of small
+ * batches): values / validity are copied into exact-size allocations; a result that fits or borrows is left alone. */
+AH_API ah_status ah_array_shrink_to_fit(ah_context* ctx, ah_array_out* out);
 AH_API int64_t ah_filter_predicate_count(const ah_filter_predicate* p); /* FilterPredicate::count :481 */
 AH_API ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_predicate* p,
                                            const ah_array_view* values, ah_array_out* out);
@@ -278,18 +284,20 @@ AH_API ah_status ah_read_words(ah_context* ctx, uint64_t* dev_words, int32_t n, 
 
 /* BatchCoalescer (arrow-select/src/coalesce.rs:148-700) as a native object: the reference's state machine — exact-size
  * output batches in input order, `biggest_coalesce_batch_size` bypass cases 1-3 (:296-420), push_batch_with_filter (:229),
- * finish_buffered_batch (:536), next_completed_batch (:566) — over fixed-width columns (InProgressPrimitiveArray,
- * coalesce/primitive.rs).  Filtered pushes scatter straight into the in-progress batch; no push waits for the GPU
- * except for the predicate's count; one wait per finished batch.  `tag` (any non-zero value naming the caller's batch)
+ * finish_buffered_batch (:536), next_completed_batch (:566).  Fixed-width columns are InProgressPrimitiveArray
+ * (coalesce/primitive.rs): filtered pushes scatter straight into the in-progress batch; no push waits for the GPU
+ * except for the predicate's count; one wait per finished batch.  AH_BOOL, AH_UTF8 and AH_LARGE_UTF8 columns are
+ * GenericInProgressArray (coalesce/generic.rs): filtered pieces are kept and concatenated when the batch is finished.  `tag` (any non-zero value naming the caller's batch)
  * comes back from ah_coalescer_next_completed_batch when that very batch was passed through untouched (large-batch
  * bypass; the push sets *bypassed = 1 so the caller knows to keep that batch alive): its outs are AH_OUT_BORROWED views of the
- * caller's buffers.  Other column types: AH_NOT_YET_IMPLEMENTED
- * (the host falls back to buffer-and-concat, coalesce/generic.rs).
+ * caller's buffers.  View column types: AH_NOT_YET_IMPLEMENTED.
  * Input lifetime: a push returns while its copies / scatters may still be running on the context's stream.  Buffers
  * that came from this context's allocator — the built-in pool, or the ah_context_set_allocator hook — may be released
  * at once (pool releases are stream-ordered; before a hook free the library drains the stream while no-wait work is in
- * flight); buffers the host allocated itself must stay alive until the stream has passed them (the next finished
- * batch's wait, or ah_synchronize). */
+ * flight); buffers the host allocated itself must stay alive until the stream has passed them (the fetch of a batch
+ * finished after the push — ah_coalescer_next_completed_batch waits for that batch's work — or ah_synchronize).
+ * Finishing a batch does not wait either: its null counts travel to pinned host words behind the last scatter and are
+ * looked at when the batch is fetched. */
 typedef struct ah_coalescer ah_coalescer;
 AH_API ah_status ah_coalescer_create(ah_context* ctx, int32_t n_columns, const ah_type* types, int64_t target_batch_size,
                                      ah_coalescer** out);
@@ -309,6 +317,10 @@ AH_API ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_coal
                                                         const ah_array_view* columns, const int64_t* num_rows,
                                                         const ah_array_view* filters, const uint64_t* tags /* nullable */,
                                                         int32_t* bypassed /* n entries, nullable */);
+/* push_batch_with_indices (coalesce.rs:289): take_record_batch(batch, indices), then push_batch of the result; indices
+ * as for ah_take (unchecked: an out-of-range index is the reference's panic, AH_PANIC). */
+AH_API ah_status ah_coalescer_push_batch_with_indices(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns,
+                                                      int64_t num_rows, const ah_array_view* indices);
 AH_API ah_status ah_coalescer_finish_buffered_batch(ah_context* ctx, ah_coalescer* co);
 /* *num_rows = -1 when no batch is ready; outs[n_columns] are released with ah_array_release */
 AH_API ah_status ah_coalescer_next_completed_batch(ah_context* ctx, ah_coalescer* co, ah_array_out* outs, int64_t* num_rows,

@@ -151,3 +151,90 @@ def test_lazy_predicate_error_texts(ctx):
     e = HostArray(A.Int64, np.zeros(0, dtype=np.int64)).to_device(ctx)
     p = K.FilterBuilder.from_terms([("lt", e, e)]).build()
     assert p.count() == 0 and p.filter(e).length == 0
+
+
+# ---------------------------------------------------------------------------------- the one-call form (ah_filter_expr)
+def _dev_terms(ctx, terms):
+    out = []
+    for op, l, ls, r, rs in terms:
+        dl, dr = l.to_device(ctx), r.to_device(ctx)
+        out.append((op, A.Scalar(dl) if ls else dl, A.Scalar(dr) if rs else dr))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_filter_expr_millions_of_rows_equals_materialised_chain(ctx, oracle, seed):
+    """ah_filter_expr beyond the small-batch sizes (1 - 5 M rows of 8-byte columns, several count groups): against
+    oracle.filter(values, fold(oracle.compare ...)): count, values, validity, null-buffer presence.  Shapes: 1-4 terms,
+    scalar or array right sides, values column that is / is not an operand, nulls everywhere, selectivity from nothing to
+    everything, odd lengths."""
+    rng = np.random.default_rng(8800 + seed)
+    n = [1_048_577, 1_200_001, 2_500_003, 4_194_304 + 4097, 3_000_017, 1_300_000, 5_000_011][seed % 7]
+    dts = [A.Int64, A.Float64, A.UInt64]
+    nterms = 1 + seed % 4
+    scalar_rhs = seed % 2 == 0
+    vals = _column(rng, [A.Int64, A.Float64][seed % 2], n, [0.9, None, 0.5][seed % 3])
+    terms, joins = [], []
+    for k in range(nterms):
+        dt = dts[(seed + k) % 3]
+        l = vals if (k == 0 and seed % 3 != 2 and dt == vals.data_type) else _column(rng, dt, n, [None, 0.8][k % 2])
+        if l is vals:
+            dt = vals.data_type
+        if scalar_rhs:
+            r, rs = _scalar(rng, dt, null=(seed == 6 and k == 1)), True
+        else:
+            r, rs = _column(rng, dt, n, [None, 0.9][(k + seed) % 2]), False
+        op = ["lt", "gt_eq", "neq", "eq", "lt_eq", "gt"][(seed + k) % 6]
+        terms.append((op, l, False, r, rs))
+        if k:
+            joins.append(["and_kleene", "or", "and", "or_kleene"][(seed + k) % 4])
+    if seed == 4:  # nothing selected / everything selected
+        terms, joins = [("lt", vals, False, HostArray(vals.data_type, np.array([np.iinfo(np.int64).min])), True)], []
+    if seed == 5:
+        vals = HostArray(A.Float64, np.abs(vals.values), None)
+        terms, joins = [("gt_eq", vals, False, HostArray(A.Float64, np.array([-1.0])), True)], []
+    mask = _oracle_mask(oracle, terms, joins)
+    exp = oracle.filter(vals, mask)
+    dvals = vals.to_device(ctx)
+    dterms = []
+    for op, l, ls, r, rs in terms:
+        dl = dvals if l is vals else l.to_device(ctx)
+        dr = r.to_device(ctx)
+        dterms.append((op, dl, A.Scalar(dr) if rs else dr))
+    got = K.filter_expr(dvals, dterms, joins)
+    g = HostArray.from_device(got)
+    assert_logical_eq(g, exp, f"filter_expr seed {seed} n {n} {[t_[0] for t_ in terms]} {joins}")
+    assert_same_nulls_presence(g, exp, f"filter_expr seed {seed}")
+    # and through the predicate object
+    pred = K.FilterBuilder.from_terms(dterms, joins).build()
+    assert pred.count() == len(exp)
+    assert_logical_eq(HostArray.from_device(pred.filter(dvals)), exp, f"two pass seed {seed}")
+
+
+def test_filter_expr_other_widths_and_sizes(ctx, oracle):
+    rng = np.random.default_rng(1)
+    for n, dt in ((1000, A.Int64), (70_000, A.Int32), (2_000_000, A.Int32), (2_000_001, A.Int16)):
+        a, b = _column(rng, dt, n, 0.9), _column(rng, dt, n, None)
+        s = _scalar(rng, dt)
+        da, db = a.to_device(ctx), b.to_device(ctx)
+        got = K.filter_expr(da, [("lt", da, db), ("gt", db, A.Scalar(s.to_device(ctx)))], ["or"])
+        mask = oracle.boolean_binary(JOINS["or"], oracle.compare(OPS["lt"], a, b), oracle.compare(OPS["gt"], b, s, r_scalar=True))
+        assert_logical_eq(HostArray.from_device(got), oracle.filter(a, mask), f"n {n} {dt}")
+
+
+def test_shrink_to_fit_after_a_small_batch_filter(ctx, oracle):
+    """the one-launch filter allocates for the worst case; ah_array_shrink_to_fit copies into an exact-size buffer"""
+    import ctypes as C
+    rng = np.random.default_rng(2)
+    n = 1_000_003
+    a = HostArray(A.Int64, rng.integers(-100, 100, n), rng.random(n) < 0.9)
+    m = HostArray(A.Boolean, rng.random(n) < 0.05)
+    da, dm = a.to_device(ctx), m.to_device(ctx)
+    out = A._lib.ArrayOut()
+    vv, mv = da.view(), dm.view()
+    ctx.check(ctx.lib.ah_filter(ctx.handle, C.byref(vv), C.byref(mv), C.byref(out)))
+    assert out.values_bytes == n * 8 and out.length < n // 10  # worst-case capacity
+    ctx.check(ctx.lib.ah_array_shrink_to_fit(ctx.handle, C.byref(out)))
+    assert out.values_bytes == out.length * 8 and out.validity_bytes == ((out.length + 63) // 64) * 8
+    got = A.Array._from_out(ctx, out, A.Int64)
+    assert_logical_eq(HostArray.from_device(got), oracle.filter(a, m), "shrunk")

@@ -321,9 +321,16 @@ def test_lazy_predicate_filter_every_row(ctx, oracle):
     ctx.check(ctx.lib.ah_memcpy_htod(ctx.handle, b.values.ptr, sb.ctypes.data, sb.nbytes))
     s0, s1 = A.Scalar.new(0, A.Int64, ctx), A.Scalar.new(0.0, A.Float64, ctx)
     pred = K.FilterBuilder.from_terms([("lt", a, s0), ("gt_eq", b, s1)], ["and_kleene"]).build()
-    f = pred.filter(a)
+    f2 = pred.filter(a)  # through the predicate object
+    f = K.filter_expr(a, [("lt", a, s0), ("gt_eq", b, s1)], ["and_kleene"])  # the one-call form
     K_dev = f.length
-    assert K_dev == pred.count() and 0.15 < K_dev / n < 0.25
+    assert K_dev == pred.count() == f2.length and 0.15 < K_dev / n < 0.25
+    assert f.null_count() == f2.null_count()
+    assert (f.validity is None) == (f2.validity is None)  # (`a < 0` is null where a is: every selected a is valid)
+    for off in range(0, K_dev, 1 << 26):  # the two forms against each other, byte for byte (and below against the oracle)
+        m = min(1 << 26, K_dev - off)
+        assert np.array_equal(_dev_bytes(ctx, f.values, off * 8, m * 8), _dev_bytes(ctx, f2.values, off * 8, m * 8))
+    del f2, pred
     z0, z1 = np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.float64)
 
     def work(job):
