@@ -12,7 +12,7 @@ namespace {
 
 __global__ void __launch_bounds__(256) bitmap_op_kernel(int op, BitView a, BitView b, BitView c, BitView d,
                                                         int64_t len, unsigned long long* out,
-                                                        unsigned long long* ticket, uint64_t* mail, uint64_t seq) {
+                                                        unsigned long long* total) {
   int64_t nwords = (len + 63) >> 6;
   unsigned long long acc = 0;
   for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * 256) {
@@ -53,12 +53,12 @@ __global__ void __launch_bounds__(256) bitmap_op_kernel(int op, BitView a, BitVi
     out[w] = r;
     acc += __popcll(r);
   }
-  if (ticket) {  // counted: the last block to arrive posts the popcount to the host (pinned slot 8)
+  if (total) {  // counted: the popcount accumulates in a scratch word (see ah_count_add)
     acc = wave_reduce_add64(acc);
     __shared__ unsigned long long sm[4];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) ah_ticket_post(ticket, sm[0] + sm[1] + sm[2] + sm[3], gridDim.x, mail, 8, seq);
+    if (threadIdx.x == 0) ah_count_add(total, sm[0] + sm[1] + sm[2] + sm[3]);
   }
 }
 
@@ -78,11 +78,10 @@ __global__ void __launch_bounds__(1024) bm_sum_kernel(const unsigned long long* 
 }
 
 // dst |= src bits placed at dst_off (dst range pre-zeroed); one thread per dst word.  partials: per-block counts for
-// the no-wait accumulate form; ticket: the counted form (last block posts the popcount to pinned slot 8)
+// the no-wait accumulate form; total: the counted form (popcount accumulated in a scratch word)
 __global__ void __launch_bounds__(256) set_bits_kernel(unsigned long long* dst, int64_t dst_off,
                                                        BitView src, int64_t len,
-                                                       unsigned long long* partials, unsigned long long* ticket = nullptr,
-                                                       uint64_t* mail = nullptr, uint64_t seq = 0) {
+                                                       unsigned long long* partials, unsigned long long* total = nullptr) {
   int64_t first = dst_off >> 6, last = (dst_off + len - 1) >> 6;
   unsigned long long acc = 0;
   for (int64_t w = first + (int64_t)blockIdx.x * 256 + threadIdx.x; w <= last;
@@ -92,7 +91,7 @@ __global__ void __launch_bounds__(256) set_bits_kernel(unsigned long long* dst, 
     if (v) dst[w] |= v;
     acc += __popcll(v);
   }
-  if (partials || ticket) {
+  if (partials || total) {
     acc = wave_reduce_add64(acc);
     __shared__ unsigned long long sm[4];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
@@ -100,7 +99,7 @@ __global__ void __launch_bounds__(256) set_bits_kernel(unsigned long long* dst, 
     if (threadIdx.x == 0) {
       const unsigned long long tot = sm[0] + sm[1] + sm[2] + sm[3];
       if (partials) partials[blockIdx.x] = tot;
-      else ah_ticket_post(ticket, tot, gridDim.x, mail, 8, seq);
+      else ah_count_add(total, tot);
     }
   }
 }
@@ -116,15 +115,12 @@ ah_status ah_bitmap_op(ah_context* ctx, int op, BitView a, BitView b, BitView c,
   int64_t nwords = (len + 63) >> 6;
   int grid = (int)std::min<int64_t>(4096, ah_ceil_div(nwords, 256));
   if (!set_bits) {
-    bitmap_op_kernel<<<grid, 256, 0, ctx->stream>>>(op, a, b, c, d, len, out_words, nullptr, nullptr, 0);
+    bitmap_op_kernel<<<grid, 256, 0, ctx->stream>>>(op, a, b, c, d, len, out_words, nullptr);
     return AH_OK;
   }
-  // counted: ONE launch — the kernel's last block posts the popcount (and with it "the stream got here") to the host
-  const uint64_t seq = ah_mail_next(ctx);
-  bitmap_op_kernel<<<grid, 256, 0, ctx->stream>>>(op, a, b, c, d, len, out_words, ctx->scratch + AH_TICKET_COUNT, ctx->pinned_dev, seq);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
-  AH_HIP(ctx, e);
+  // counted: the kernel accumulates the popcount in a scratch word; one small kernel copies it to the host, zeroes it, posts
+  bitmap_op_kernel<<<grid, 256, 0, ctx->stream>>>(op, a, b, c, d, len, out_words, ctx->scratch + AH_TICKET_COUNT);
+  AH_HIP(ctx, ah_d2h_wait(ctx, ctx->pinned + 8, ctx->scratch + AH_TICKET_COUNT, 8, /*reset=*/true));
   *set_bits = (int64_t)ctx->pinned[8];
   return AH_OK;
 }
@@ -181,12 +177,9 @@ extern "C" ah_status ah_bitmap_set_bits(ah_context* ctx, uint8_t* dst, int64_t d
     set_bits_kernel<<<grid, 256, 0, ctx->stream>>>((unsigned long long*)dst, dst_bit_offset, make_bitview(src, src_bit_offset), len, nullptr);
     return AH_OK;
   }
-  const uint64_t seq = ah_mail_next(ctx);
   set_bits_kernel<<<grid, 256, 0, ctx->stream>>>((unsigned long long*)dst, dst_bit_offset, make_bitview(src, src_bit_offset), len, nullptr,
-                                                 ctx->scratch + AH_TICKET_COUNT, ctx->pinned_dev, seq);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
-  AH_HIP(ctx, e);
+                                                 ctx->scratch + AH_TICKET_COUNT);
+  AH_HIP(ctx, ah_d2h_wait(ctx, ctx->pinned + 8, ctx->scratch + AH_TICKET_COUNT, 8, /*reset=*/true));
   *set_bits = (int64_t)ctx->pinned[8];
   return AH_OK;
 }

@@ -183,9 +183,8 @@ ah_status ah_ranges_to_strings(ah_context* ctx, bool large, const uint8_t* src, 
 ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_array_view* indices,
                         ah_array_out* out);
 struct ah_filter_predicate;
-// strings.hip: [start, end) of the rows the predicate selects, one pass over the offsets
-ah_status ah_string_filter_ranges(ah_context* ctx, const ah_filter_predicate* p, bool large, const void* offsets, void* starts,
-                                  void* ends);
+// strings.hip: filter_bytes — offsets + data of the rows the predicate selects (three launches, one host wait for the byte total)
+ah_status ah_string_filter_bytes(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* values, ah_array_out* out);
 
 // bitmap.hip: ah_bitmap_set_bits without a read-back — *nulls_acc (device) += len - popcount(copied bits)
 ah_status ah_bitmap_set_bits_acc(ah_context* ctx, uint8_t* dst, int64_t dst_bit_offset, const uint8_t* src,
@@ -376,19 +375,16 @@ template <bool NT, typename VT> __device__ __forceinline__ void ah_st_stream(VT*
   }
 }
 
-// Completion ticket of a counting kernel: ONE thread per block hands in the block's partial count; the block that
-// arrives last stores the grand total into the host's pinned slot and posts the mailbox sequence word — the count
-// read-back needs no partials buffer, no sum kernel and no copy kernel (three launches fewer per call, which is what a
-// 10^4-row batch pays for).  `ticket` is a zero-between-calls word of ctx->scratch: {arrivals : 16 | count : 48}.
-__device__ __forceinline__ void ah_ticket_post(unsigned long long* ticket, unsigned long long count, unsigned nblocks,
-                                               uint64_t* mail, int slot, uint64_t seq) {
-  const unsigned long long mine = 1ull | (count << 16);
-  const unsigned long long old = atomicAdd(ticket, mine);
-  if ((unsigned)(old & 0xFFFFull) == nblocks - 1) {
-    *ticket = 0;  // self-cleaning: every other block has arrived
-    __hip_atomic_store(mail + slot, (uint64_t)((old + mine) >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    ah_mail_post(mail, seq);
-  }
+// A counting kernel adds its per-block partials into a zero-between-calls word of ctx->scratch (one atomicAdd per block,
+// none for an empty partial); ONE small kernel behind it (`ah_d2h_wait(..., reset = true)`: copy the word(s) into the pinned
+// slots, zero them, post the mailbox) is the call's read-back.  Two launches per counted bitmap op where round 2 had four
+// (partials buffer, one-block sum, copy kernel).  Posting from INSIDE the counting kernel (last block to arrive) was
+// tried: it saves the second launch (filter 14.8 us at 10^4 rows), but the host then returns while the kernel that wrote
+// the OUTPUT is still retiring — its end-of-kernel release is what makes the output visible to other streams and copy
+// engines, and waiting for the runtime to report the kernel complete (hipStreamQuery) costs 13 us.  A separate posting
+// kernel starts only after the producing kernel has ended, so "synchronous at return" holds for any consumer.
+__device__ __forceinline__ void ah_count_add(unsigned long long* word, unsigned long long count) {
+  if (count) atomicAdd(word, count);
 }
 constexpr int AH_TICKET_COUNT = AH_SCRATCH_TICKETS + 32;  // the word bitmap.hip / context.hip's counting kernels use
 

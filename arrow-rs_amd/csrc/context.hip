@@ -469,8 +469,7 @@ extern "C" ah_status ah_profile_get(ah_context* ctx, const char* kernel, double*
 
 // ----------------------------------------------------------- popcount kernel
 // One u64 partial per block, then a single-block finish: no same-address atomics.
-__global__ void __launch_bounds__(256) popcount_partial_kernel(BitView bits, int64_t len, unsigned long long* ticket,
-                                                               uint64_t* mail, uint64_t seq) {
+__global__ void __launch_bounds__(256) popcount_partial_kernel(BitView bits, int64_t len, unsigned long long* total) {
   int64_t nwords = (len + 63) >> 6;
   unsigned long long acc = 0;
   for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords;
@@ -480,7 +479,7 @@ __global__ void __launch_bounds__(256) popcount_partial_kernel(BitView bits, int
   __shared__ unsigned long long s[4];
   if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) ah_ticket_post(ticket, s[0] + s[1] + s[2] + s[3], gridDim.x, mail, 0, seq);  // last block posts the total
+  if (threadIdx.x == 0) ah_count_add(total, s[0] + s[1] + s[2] + s[3]);
 }
 
 __global__ void __launch_bounds__(1024) sum_u64_kernel(const unsigned long long* in, int64_t n,
@@ -509,11 +508,8 @@ extern "C" ah_status ah_count_set_bits(ah_context* ctx, const uint8_t* bits, int
   int64_t nwords = (len + 63) >> 6;
   int grid = (int)std::min<int64_t>(2048, ah_ceil_div(nwords, 256));
   BitView bv = make_bitview(bits, bit_offset);
-  const uint64_t seq = ah_mail_next(ctx);  // one launch: the kernel's last block posts the total
-  popcount_partial_kernel<<<grid, 256, 0, ctx->stream>>>(bv, len, ctx->scratch + AH_TICKET_COUNT, ctx->pinned_dev, seq);
-  hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
-  AH_HIP(ctx, e);
+  popcount_partial_kernel<<<grid, 256, 0, ctx->stream>>>(bv, len, ctx->scratch + AH_TICKET_COUNT);
+  AH_HIP(ctx, ah_d2h_wait(ctx, ctx->pinned, ctx->scratch + AH_TICKET_COUNT, 8, /*reset=*/true));
   *count = (int64_t)ctx->pinned[0];
   return AH_OK;
 }

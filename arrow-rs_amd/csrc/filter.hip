@@ -982,22 +982,14 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
                              : BitView{nullptr, 0};
 
   if (is_string) {  // filter_bytes (filter.rs:890-928): ranges of the selected rows -> new offsets + bytes
-    const bool large = values->type == AH_LARGE_UTF8;
-    const size_t ow = large ? 8 : 4;
-    // ONE pass over the offsets writes the selected rows' [start, end) pairs (strings.hip); the column's validity is
-    // compacted by the bit-only scatter (filter_nulls :512-532).  Nothing waits here: the only host round trips of the
-    // string path are the byte total inside ah_ranges_to_strings and the null count.
-    char* tmp = nullptr;
-    AH_TRY(ah_pool_alloc(ctx, 2 * (((size_t)K * ow + 15) & ~(size_t)15) + 16, (void**)&tmp));
-    void* starts = tmp;
-    void* ends = tmp + (((size_t)K * ow + 15) & ~(size_t)15);
-    ah_status st = ah_string_filter_ranges(ctx, p, large, values->offsets, starts, ends);
+    // strings.hip: ranges (one pass over the offsets) -> tile-byte scan -> gather; the column's validity is compacted by
+    // the bit-only scatter (filter_nulls :512-532), enqueued first so that it runs during the byte-total round trip
     uint8_t* nb = nullptr;
     size_t nbytes = 0;
     int64_t nset = -1;
-    if (st == AH_OK && has_valid) st = compact_bits(ctx, p, vvalid, &nb, &nbytes, &nset, /*defer=*/true);
-    if (st == AH_OK) st = ah_ranges_to_strings(ctx, large, (const uint8_t*)values->values, starts, ends, K, false, out);
-    ah_pool_free(ctx, tmp);
+    ah_status st = AH_OK;
+    if (has_valid) st = compact_bits(ctx, p, vvalid, &nb, &nbytes, &nset, /*defer=*/true);
+    if (st == AH_OK) st = ah_string_filter_bytes(ctx, p, values, out);
     if (st != AH_OK) {
       ah_out_free(ctx, nb, nbytes);
       ah_out_init(out);

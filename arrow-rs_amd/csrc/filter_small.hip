@@ -13,9 +13,11 @@
 //   * output validity words are written exactly once, by the tile that owns the word's FIRST bit: the owner of a
 //     tile's last (partial) word gathers the missing bits forward from the rows that follow the tile — no atomics, so
 //     no bitmap memset launch either;
-//   * completion: one 64-bit atomicAdd per tile on its column's ticket carries {arrivals, valid rows, selected rows};
-//     the last arriver of a column stores K and the valid-row count into the host's pinned mailbox, the last column
-//     posts the sequence word the host spins on.  Tickets live in the context's self-cleaning scratch.
+//   * completion: one 64-bit atomicAdd per tile on its column's counter word carries {valid rows, selected rows}; ONE
+//     small kernel behind the launch(es) copies the counters into the host's pinned mailbox, zeroes them and posts the
+//     sequence word the host spins on.  (Posting from inside the filter kernel — last tile to arrive — was 2 us faster
+//     and was dropped: the host would return while the kernel that wrote the output is still retiring; a separate
+//     kernel starts only after it has ended, end-of-kernel release included.)  So: two launches, one wait.
 //
 // Results are identical to the general path (same IterationStrategy special cases: K == 0 -> empty, K == len -> the
 // zero-copy slice, filter.rs:545-546; null buffer dropped when the result has no nulls, :523-525).
@@ -38,10 +40,7 @@ struct SmallArgs {
   int64_t len;      // predicate length
   int ntiles;
   int col0;         // index of this launch's first column among all columns of the call (ticket / mail slot)
-  int ncols_total;  // columns of the whole call (all launches)
-  unsigned long long* tickets;  // [AH_SMALL_TICKETS]: one per column, then the call's
-  uint64_t* mail;
-  uint64_t seq;
+  unsigned long long* tickets;  // one zero-between-calls counter word per column: {valid rows : 32 | selected rows : 32}
   SmallCol c[8];
 };
 
@@ -256,28 +255,14 @@ __global__ void __launch_bounds__(SMALL_THREADS) filter_small_kernel(SmallArgs a
     }
   }
 
-  // 5. completion ticket: {arrivals : 12 | valid rows : 21 | selected rows : 21}
+  // 5. this tile's {valid rows, selected rows} into the column's counter word
   if constexpr (HAS_VALID) {
     if (lane == 0) s_vc[wave] = (uint32_t)vc;
   }
   __syncthreads();
-  if (t == 0) {
-    unsigned long long valid = HAS_VALID ? (unsigned long long)(s_vc[0] + s_vc[1] + s_vc[2] + s_vc[3]) : (unsigned long long)total;
-    const unsigned long long mine = 1ull | (valid << 12) | ((unsigned long long)total << 33);
-    const int col = a.col0 + (int)blockIdx.y;
-    const unsigned long long old = atomicAdd(&a.tickets[col], mine);
-    if ((int)(old & 0xFFFull) == a.ntiles - 1) {  // this column is complete
-      const unsigned long long all = old + mine;
-      a.tickets[col] = 0;  // self-cleaning: nobody else touches the word until the next call
-      __hip_atomic_store(a.mail + 1 + col, (uint64_t)((all >> 12) & 0x1FFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (col == 0) __hip_atomic_store(a.mail, (uint64_t)(all >> 33), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __threadfence_system();  // the slots, before this column is counted as done
-      const unsigned long long done = atomicAdd(&a.tickets[SMALL_MAX_COLS], 1ull);
-      if ((int)done == a.ncols_total - 1) {
-        a.tickets[SMALL_MAX_COLS] = 0;
-        ah_mail_post(a.mail, a.seq);  // fence + the sequence word the host spins on
-      }
-    }
+  if (t == 0 && total > 0) {
+    const unsigned long long valid = HAS_VALID ? (unsigned long long)(s_vc[0] + s_vc[1] + s_vc[2] + s_vc[3]) : (unsigned long long)total;
+    atomicAdd(&a.tickets[a.col0 + (int)blockIdx.y], (valid << 32) | (unsigned long long)total);
   }
 }
 
@@ -339,16 +324,12 @@ ah_status ah_filter_small(ah_context* ctx, int ncols, const ah_array_view* colum
     free_all();
     return st;
   }
-  const uint64_t seq = ah_mail_next(ctx);
   SmallArgs base{};
   base.mask = make_bitview(predicate->values, predicate->values_bit_offset);
   base.mask_valid = (predicate->validity && predicate->null_count != 0) ? make_bitview(predicate->validity, predicate->validity_bit_offset)
                                                                          : BitView{nullptr, 0};
   base.len = len;
-  base.ncols_total = ncols;
   base.tickets = ctx->scratch + AH_SCRATCH_TICKETS;
-  base.mail = ctx->pinned_dev;
-  base.seq = seq;
   // one launch per (width, nullable) shape, up to 8 columns each; tickets and mail slots are indexed by the column's
   // position in launch order, so remember where each input column went
   std::vector<int> slot((size_t)ncols, -1);
@@ -380,23 +361,24 @@ ah_status ah_filter_small(ah_context* ctx, int ncols, const ah_array_view* colum
     }
   }
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
+  // the call's one wait: the counter words -> pinned slots [0, ncols), counters back to zero, mailbox posted
+  if (e == hipSuccess) e = ah_d2h_wait(ctx, ctx->pinned, ctx->scratch + AH_SCRATCH_TICKETS, (size_t)ncols * 8, /*reset=*/true);
   if (e != hipSuccess) {
-    // a launch failed part-way: the tickets may be half counted
+    // a launch failed part-way: the counters may be half counted
     hipStreamSynchronize(ctx->stream);
     hipMemsetAsync(ctx->scratch + AH_SCRATCH_TICKETS, 0, (SMALL_MAX_COLS + 1) * 8, ctx->stream);
     hipStreamSynchronize(ctx->stream);
     free_all();
     return ah_fail(ctx, AH_HIP_ERROR, "filter failed: %s", hipGetErrorString(e));
   }
-  const int64_t K = (int64_t)ctx->pinned[0];
+  const int64_t K = (int64_t)(ctx->pinned[slot[0]] & 0xFFFFFFFFull);  // the same for every column
   if (out_rows) *out_rows = K;
   for (int c = 0; c < ncols; ++c) {
     ah_array_out* out = &outs[c];
     ah_out_init(out);
     out->type = columns[c].type;
     const ah_array_view& v = columns[c];
-    const int64_t valid = (int64_t)ctx->pinned[1 + slot[c]];
+    const int64_t valid = (int64_t)(ctx->pinned[slot[c]] >> 32);
     // IterationStrategy::default_strategy (filter.rs:346-364) special cases, as the general path
     if (K == 0) {  // None -> new_empty_array(data_type) :545
       ah_out_free(ctx, ov[c], vbytes[c]);

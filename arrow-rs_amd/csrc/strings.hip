@@ -21,18 +21,31 @@
 
 namespace {
 
-// filter_bytes' first half in ONE pass over the offsets (it used to be two runs of the primitive scatter kernel, over
-// offsets[0..n) and offsets[1..n+1): 2 x 8 bytes per row read, the second run through an unaligned pointer): every
-// thread owns 16 consecutive rows = a quarter of one predicate word, loads its 17 offsets, and writes the
-// [start, end) pair of each selected row at the row's rank (tile base from the predicate's prefix tables + popcounts).
+// ---- filter_bytes (filter.rs:790-928) as three launches: ranges -> tile-byte scan -> gather
+//
+// F1 string_filter_ranges_kernel: ONE pass over the offsets (it used to be two runs of the primitive scatter kernel,
+//    over offsets[0..n) and offsets[1..n+1), then a three-kernel scan over the K selected rows).  A tile is 4096 rows;
+//    every thread owns 16 consecutive rows = a quarter of one predicate word and loads its 17 offsets with 16-byte loads.
+//    A block scan over (selected rows, selected bytes) per thread gives every selected row its rank in the tile and its
+//    byte offset INSIDE the tile's output; (start, local offset) pairs are compacted through a 32 KiB LDS stage and leave
+//    as coalesced stores at the tile's first output row (known from the predicate's prefix tables).  The tile's byte
+//    total goes to tile_bytes[tile].
+// F2 string_tile_scan_kernel: exclusive scan of the <= n / 4096 tile totals (one workgroup) -> tile_base, grand total
+//    (the one number the host waits for: it sizes the data buffer).
+// F3 string_filter_gather_kernel: one workgroup per tile again: new offset = tile_base + local offset, bytes copied row by
+//    row (unaligned 8-byte chunks with an overlapping tail; rows > 64 B cooperatively).
 template <typename OFF, bool VEC>
 __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* offsets, BitView mask, BitView mask_valid,
                                                                    int64_t len, const uint32_t* chunk_prefix,
                                                                    const unsigned long long* group_prefix, int group_shift,
-                                                                   OFF* starts, OFF* ends) {
-  constexpr int T = 4096, NW = 64, R = 16;
+                                                                   OFF* starts, OFF* loffs, unsigned long long* tile_bytes) {
+  constexpr int T = 4096, NW = 64, R = 16, CAP = 2048;
   __shared__ uint64_t s_m[NW];
   __shared__ uint32_t s_base[NW];
+  __shared__ uint32_t s_total;
+  __shared__ unsigned long long s_wbytes[4];
+  __shared__ OFF s_start[CAP];
+  __shared__ OFF s_loff[CAP];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * T;
   const int64_t r0 = row0 + (int64_t)t * R;
@@ -68,25 +81,84 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
     const int incl = wave_scan_incl(c);
     s_m[lane] = m;
     s_base[lane] = (uint32_t)(incl - c);
+    if (lane == 63) s_total = (uint32_t)incl;
   }
   __syncthreads();
   const int sh = (t * R) & 63;
   const uint64_t word = s_m[(t * R) >> 6];
-  uint32_t bits = (uint32_t)(word >> sh) & 0xFFFFu;
-  if (!bits) return;
-  const int64_t chunk0 = row0 / AH_FILTER_CHUNK_ROWS;
-  int64_t pos = (int64_t)group_prefix[chunk0 >> group_shift] + chunk_prefix[chunk0] + s_base[(t * R) >> 6] +
-                __popcll(word & ((1ull << sh) - 1ull));
+  const uint32_t bits = (uint32_t)(word >> sh) & 0xFFFFu;
+  // bytes this thread's selected rows contribute, and their exclusive prefix over the workgroup (thread order = row order)
+  unsigned long long mine = 0;
 #pragma unroll
-  for (int e = 0; e < R; ++e) {
-    if ((bits >> e) & 1u) {
-      starts[pos] = o[e];
-      ends[pos] = o[e + 1];
-      ++pos;
+  for (int e = 0; e < R; ++e)
+    if ((bits >> e) & 1u) mine += (unsigned long long)(o[e + 1] - o[e]);
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    const unsigned long long u = __shfl_up(incl, k, 64);
+    if (lane >= k) incl += u;
+  }
+  if (lane == 63) s_wbytes[wave] = incl;
+  __syncthreads();
+  unsigned long long byte_off = incl - mine;
+  for (int w = 0; w < wave; ++w) byte_off += s_wbytes[w];
+  const int total = (int)s_total;
+  if (t == 0) tile_bytes[blockIdx.x] = s_wbytes[0] + s_wbytes[1] + s_wbytes[2] + s_wbytes[3];
+  if (total == 0) return;
+  const int64_t chunk0 = row0 / AH_FILTER_CHUNK_ROWS;
+  const int64_t P = (int64_t)group_prefix[chunk0 >> group_shift] + chunk_prefix[chunk0];  // the tile's first output row
+  const int rank0 = (int)(s_base[(t * R) >> 6] + __popcll(word & ((1ull << sh) - 1ull)));
+  for (int p0 = 0; p0 < total; p0 += CAP) {  // tiles with more than CAP selected rows take a second round
+    const int cnt = (total - p0) < CAP ? (total - p0) : CAP;
+    if (p0) __syncthreads();
+    int pos = rank0 - p0;
+    unsigned long long bo = byte_off;
+#pragma unroll
+    for (int e = 0; e < R; ++e) {
+      if ((bits >> e) & 1u) {
+        if ((unsigned)pos < (unsigned)cnt) {
+          s_start[pos] = o[e];
+          s_loff[pos] = (OFF)bo;
+        }
+        bo += (unsigned long long)(o[e + 1] - o[e]);
+        ++pos;
+      }
+    }
+    __syncthreads();
+    for (int q = t; q < cnt; q += 256) {
+      starts[P + p0 + q] = s_start[q];
+      loffs[P + p0 + q] = s_loff[q];
     }
   }
 }
 
+// exclusive scan of the tile byte totals (one workgroup); *total_out = grand total
+__global__ void __launch_bounds__(1024) string_tile_scan_kernel(const unsigned long long* tile_bytes, int64_t ntiles,
+                                                                unsigned long long* tile_base, unsigned long long* total_out) {
+  __shared__ unsigned long long s_wave[16];
+  __shared__ unsigned long long s_carry;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < ntiles; b0 += 1024) {
+    const unsigned long long v = (b0 + t < ntiles) ? tile_bytes[b0 + t] : 0ull;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+      const unsigned long long u = __shfl_up(incl, k, 64);
+      if (lane >= k) incl += u;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long wbase = s_carry;
+    for (int w = 0; w < wave; ++w) wbase += s_wave[w];
+    if (b0 + t < ntiles) tile_base[b0 + t] = wbase + incl - v;
+    __syncthreads();
+    if (t == 1023) s_carry = wbase + incl;
+    __syncthreads();
+  }
+  if (t == 0) *total_out = s_carry;
+}
 template <typename OFF>
 __global__ void __launch_bounds__(1024) range_scan_local_kernel(const OFF* starts, const OFF* ends, int64_t k,
                                                                 OFF* dst_off, unsigned long long* block_total) {
@@ -198,6 +270,63 @@ __global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t* src, c
     const unsigned long long whole = rl & ~7ull;
     for (unsigned long long o = (unsigned long long)t * 8; o < whole; o += 2048) copy8(dst + rd + o, src + rs + o);
     if ((unsigned long long)t < rl - whole) dst[rd + whole + t] = src[rs + whole + t];
+  }
+}
+
+// F3: the tile's selected rows [P, P + C): new offsets and bytes.  Same copy scheme as gather_bytes_kernel.
+template <typename OFF>
+__global__ void __launch_bounds__(256) string_filter_gather_kernel(const uint8_t* src, const OFF* starts, const OFF* loffs,
+                                                                   const unsigned long long* tile_bytes,
+                                                                   const unsigned long long* tile_base, int64_t len, int64_t K,
+                                                                   const uint32_t* chunk_prefix, const unsigned long long* group_prefix,
+                                                                   int group_shift, OFF* dst_off, uint8_t* dst) {
+  __shared__ int s_long[256];
+  __shared__ int s_nlong;
+  const int t = threadIdx.x;
+  const int64_t ntiles = (len + 4095) / 4096, tile = blockIdx.x;
+  auto first_row = [&](int64_t tl) -> int64_t {
+    if (tl >= ntiles) return K;
+    const int64_t c0 = tl * 4096 / AH_FILTER_CHUNK_ROWS;
+    return (int64_t)group_prefix[c0 >> group_shift] + chunk_prefix[c0];
+  };
+  const int64_t P = first_row(tile);
+  const int C = (int)(first_row(tile + 1) - P);
+  const unsigned long long base = tile_base[tile], tbytes = tile_bytes[tile];
+  if (tile == ntiles - 1 && t == 0) dst_off[K] = (OFF)(base + tbytes);
+  for (int j0 = 0; j0 < C; j0 += 256) {
+    const int j = j0 + t;
+    if (t == 0) s_nlong = 0;
+    __syncthreads();
+    if (j < C) {
+      const unsigned long long s0 = (unsigned long long)starts[P + j], lo = (unsigned long long)loffs[P + j];
+      const unsigned long long hi = j + 1 < C ? (unsigned long long)loffs[P + j + 1] : tbytes;
+      const unsigned long long n = hi - lo, d0 = base + lo;
+      dst_off[P + j] = (OFF)d0;
+      const uint8_t* sp = src + s0;
+      uint8_t* dp = dst + d0;
+      if (n > 64) {
+        s_long[atomicAdd(&s_nlong, 1)] = j;
+      } else if (n >= 8) {
+        for (unsigned o = 0; o + 8 <= (unsigned)n; o += 8) copy8(dp + o, sp + o);
+        if (n & 7) copy8(dp + n - 8, sp + n - 8);
+      } else if (n >= 4) {
+        copy4(dp, sp);
+        copy4(dp + n - 4, sp + n - 4);
+      } else {
+        for (unsigned o = 0; o < (unsigned)n; ++o) dp[o] = sp[o];
+      }
+    }
+    __syncthreads();
+    const int nlong = s_nlong;
+    for (int q = 0; q < nlong; ++q) {
+      const int r = s_long[q];
+      const unsigned long long rs = (unsigned long long)starts[P + r], lo = (unsigned long long)loffs[P + r];
+      const unsigned long long hi = r + 1 < C ? (unsigned long long)loffs[P + r + 1] : tbytes;
+      const unsigned long long rl = hi - lo, rd = base + lo, whole = rl & ~7ull;
+      for (unsigned long long o = (unsigned long long)t * 8; o < whole; o += 2048) copy8(dst + rd + o, src + rs + o);
+      if ((unsigned long long)t < rl - whole) dst[rd + whole + t] = src[rs + whole + t];
+    }
+    __syncthreads();
   }
 }
 
@@ -356,28 +485,70 @@ ah_status launch_take_ranges(ah_context* ctx, const ah_array_view* values, const
 
 }  // namespace
 
-// the [start, end) byte ranges of the rows `p` selects (K of each, device arrays of the offset type, caller-allocated)
-ah_status ah_string_filter_ranges(ah_context* ctx, const ah_filter_predicate* p, bool large, const void* offsets, void* starts,
-                                  void* ends) {
-  if (p->len <= 0 || p->count <= 0) return AH_OK;
-  const unsigned grid = (unsigned)ah_ceil_div(p->len, 4096);
+// filter_bytes (filter.rs:790-928) for the rows `p` selects: offsets + data of the result (validity is the caller's).
+template <typename OFF>
+static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* values, ah_array_out* out) {
+  const int64_t K = p->count, len = p->len, ntiles = ah_ceil_div(len, 4096);
+  const OFF* offsets = (const OFF*)values->offsets;
+  const size_t ob = (size_t)(K + 1) * sizeof(OFF), kb = (((size_t)K * sizeof(OFF)) + 15) & ~(size_t)15;
+  char* tmp = nullptr;  // starts | local offsets | tile bytes | tile bases | total
+  AH_TRY(ah_pool_alloc(ctx, 2 * kb + (size_t)(2 * ntiles + 2) * 8, (void**)&tmp));
+  OFF* starts = (OFF*)tmp;
+  OFF* loffs = (OFF*)(tmp + kb);
+  unsigned long long* tile_bytes = (unsigned long long*)(tmp + 2 * kb);
+  unsigned long long* tile_base = tile_bytes + ntiles;
+  unsigned long long* total = tile_base + ntiles;
   const bool vec = (((uintptr_t)offsets) & 15) == 0;
-  ah_prof_scope ps(ctx, "string_filter_ranges");
-#define AH_SFR(OFF, VEC)                                                                                                      \
-  string_filter_ranges_kernel<OFF, VEC><<<grid, 256, 0, ctx->stream>>>((const OFF*)offsets, p->mask, p->mask_valid, p->len,   \
-                                                                        p->chunk_prefix, p->group_prefix, p->group_shift,      \
-                                                                        (OFF*)starts, (OFF*)ends)
-  if (large) {
-    if (vec) AH_SFR(int64_t, true);
-    else AH_SFR(int64_t, false);
-  } else {
-    if (vec) AH_SFR(int32_t, true);
-    else AH_SFR(int32_t, false);
+  {
+    ah_prof_scope ps(ctx, "string_filter_ranges");
+    if (vec)
+      string_filter_ranges_kernel<OFF, true><<<(unsigned)ntiles, 256, 0, ctx->stream>>>(offsets, p->mask, p->mask_valid, len, p->chunk_prefix,
+                                                                                        p->group_prefix, p->group_shift, starts, loffs, tile_bytes);
+    else
+      string_filter_ranges_kernel<OFF, false><<<(unsigned)ntiles, 256, 0, ctx->stream>>>(offsets, p->mask, p->mask_valid, len, p->chunk_prefix,
+                                                                                         p->group_prefix, p->group_shift, starts, loffs, tile_bytes);
+    string_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(tile_bytes, ntiles, tile_base, total);
   }
-#undef AH_SFR
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "string filter ranges failed: %s", hipGetErrorString(e));
+  hipError_t e = ah_d2h_wait(ctx, ctx->pinned, total, 8);
+  if (e != hipSuccess) {
+    ah_pool_free(ctx, tmp);
+    return ah_fail(ctx, AH_HIP_ERROR, "string filter ranges failed: %s", hipGetErrorString(e));
+  }
+  const uint64_t total_bytes = ctx->pinned[0];
+  if (sizeof(OFF) == 4 && total_bytes > (uint64_t)INT32_MAX) {
+    ah_pool_free(ctx, tmp);
+    return ah_fail(ctx, AH_PANIC, "illegal offset range");  // filter.rs:838
+  }
+  void *offs = nullptr, *data = nullptr;
+  ah_status st = ah_out_alloc(ctx, ob, &offs);
+  if (st == AH_OK) st = ah_out_alloc(ctx, (size_t)total_bytes, &data);
+  if (st != AH_OK) {
+    ah_out_free(ctx, offs, ob);
+    ah_pool_free(ctx, tmp);
+    return st;
+  }
+  {
+    ah_prof_scope ps(ctx, "string_gather_bytes");
+    string_filter_gather_kernel<OFF><<<(unsigned)ntiles, 256, 0, ctx->stream>>>((const uint8_t*)values->values, starts, loffs, tile_bytes,
+                                                                                tile_base, len, K, p->chunk_prefix, p->group_prefix,
+                                                                                p->group_shift, (OFF*)offs, (uint8_t*)data);
+  }
+  e = hipGetLastError();
+  if (e == hipSuccess) e = ah_stream_wait(ctx);
+  ah_pool_free(ctx, tmp);
+  if (e != hipSuccess) {
+    ah_out_free(ctx, offs, ob);
+    ah_out_free(ctx, data, (size_t)total_bytes);
+    return ah_fail(ctx, AH_HIP_ERROR, "string gather failed: %s", hipGetErrorString(e));
+  }
+  out->offsets = offs;
+  out->offsets_bytes = (int64_t)ob;
+  out->values = data;
+  out->values_bytes = (int64_t)total_bytes;
   return AH_OK;
+}
+ah_status ah_string_filter_bytes(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* values, ah_array_out* out) {
+  return values->type == AH_LARGE_UTF8 ? filter_bytes_t<int64_t>(ctx, p, values, out) : filter_bytes_t<int32_t>(ctx, p, values, out);
 }
 
 // ranges [starts[i], ends[i]) of `src` (device arrays of the offset type) -> offsets + bytes

@@ -279,8 +279,14 @@ def cpu_baseline_all_cores(args, one_core_mrows):
            "sample": f"{reps} x (filter + take), {T} pinned processes x {per} rows (128 MiB of values each, "
                      f"{per * T * 8 / 2**30:.0f} GiB in all: DRAM-resident), {nidx} u32 indices per process, outputs reused from the heap"}
     if one_core_mrows and mrows < 20 * one_core_mrows:
-        out["limit"] = (f"{T} processes reach {mrows / one_core_mrows:.1f}x one core: the port is DRAM-bound "
-                        f"({out['algorithmic_GBps']} GB/s algorithmic, random 8-byte gathers fetch whole lines on top), not core-bound")
+        ratio = mrows / one_core_mrows
+        if T < 20:
+            out["limit"] = (f"{T} cores are all this container is granted ({why}): {ratio:.1f}x one core = {100 * ratio / T:.0f} % per-core "
+                            f"efficiency ({out['algorithmic_GBps']} GB/s algorithmic; the random 8-byte gathers of take fetch whole "
+                            "lines on top); 20x one core is out of reach by construction")
+        else:
+            out["limit"] = (f"{T} processes reach {ratio:.1f}x one core: the port is DRAM-bound ({out['algorithmic_GBps']} GB/s "
+                            "algorithmic, random 8-byte gathers fetch whole lines on top), not core-bound")
     return out
 
 
@@ -362,6 +368,55 @@ def cpu_baseline_filter_take(args):
     except Exception as ex:
         res["arrow_cpp_sanity"] = {"error": repr(ex)}
     return res
+
+
+def crossover_rows(env):
+    """Smallest batch size (rows) at which one synchronous C-ABI `ah_filter` call (Int64, 10 % nulls, 10 % selectivity,
+    inputs resident in HBM) is faster than the 1-core oracle on the same rows: below it a batch is better left on the
+    CPU (SURVEY section 7 'batch-size mismatch').  -> dict(rows, gpu_us, cpu_us per probed size)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import arrow_rs_amd as A
+    from arrow_rs_amd import _lib as L
+    import orc
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so):
+        return None
+    oracle = orc.load(so)
+    ctx, lib, h = env.ctx, env.ctx.lib, env.ctx.handle
+    probes, cross = {}, None
+    for n in (4096, 8192, 16384, 32768, 65536, 131072, 262144, 1048576):
+        col = gen_i64_column(A, ctx, n, 42, 0.9, 0)
+        pred = gen_predicate(A, ctx, n, 44, 0.1, 0)
+        vc, vp = col.view(), pred.view()
+
+        def call():
+            out = L.ArrayOut()
+            assert lib.ah_filter(h, C.byref(vc), C.byref(vp), C.byref(out)) == 0
+            lib.ah_array_release(h, C.byref(out))
+        for _ in range(5):
+            call()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            call()
+        ctx.synchronize()
+        gpu_us = (time.perf_counter() - t0) / 200 * 1e6
+        vals = oracle.gen_i64(n, 42, -2**63, 2**63 - 1)
+        hv = orc._Held(orc.HostArray(A.Int64, vals, oracle.gen_bits(n, 43, 0.9)))
+        hm = orc._Held(orc.HostArray(A.Boolean, oracle.gen_bits(n, 44, 0.1)))
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 0.05:
+            o = orc.Out()
+            oracle.lib.orc_filter(C.byref(hv.view), C.byref(hm.view), C.byref(o))
+            oracle.lib.orc_release(C.byref(o))
+            k += 1
+        cpu_us = (time.perf_counter() - t0) / k * 1e6
+        probes[str(n)] = {"gpu_us": round(gpu_us, 1), "cpu_1core_us": round(cpu_us, 1)}
+        if cross is None and gpu_us < cpu_us:
+            cross = n
+    return {"rows": cross, "probes": probes,
+            "what": "first probed size at which one synchronous C-ABI ah_filter call (Int64, 10 % nulls, 10 % selected) beats the "
+                    "1-core oracle on the same rows"}
 
 
 # ------------------------------------------------------------------------------- in-run PMC traffic
@@ -1166,6 +1221,10 @@ def main():
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and wl == "filter_take":
+            try:
+                line["crossover_rows"] = crossover_rows(env)
+            except Exception as ex:  # noqa: BLE001
+                line["crossover_rows"] = {"error": repr(ex)[:200]}
             try:
                 cb = cpu_baseline_filter_take(args)
                 if cb:

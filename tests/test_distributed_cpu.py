@@ -97,3 +97,21 @@ def test_sharded_filter_allgatherv_gloo(oracle, world):
         outs.append(o)
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o[-2000:]
+
+
+def test_bench_refuses_to_report_n_gpus_from_fewer_devices():
+    """`python bench.py --gpus N` without a launcher spawns its own ranks — and when fewer than N GPUs are visible (none, on
+    this box) it prints ONE line that says so (value null, n_gpus = what is visible) and exits non-zero: a 1-GPU number is
+    never reported as an N-GPU one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "AH_BENCH_SHARED_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode != 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["requested_gpus"] == 2 and d["n_gpus"] < 2 and "visible" in d["error"]

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """filter_record_batch latency at query-engine batch sizes: N nullable Int64 columns x rows, 10 % selectivity.
-fused = ah_filter_record_batch (same-shape columns in one scatter launch, one wait); per_column = one
-predicate + ah_filter_predicate_apply per column (what ah_filter_record_batch did before)."""
+mirror = K.filter_record_batch through the Python mirror (view structs, result objects, finalizers); C ABI = the same
+ah_filter_record_batch call on prebuilt views + ah_array_release per column (what a Rust / C++ host pays); per-column =
+one predicate + ah_filter_predicate_apply per column (the general two-pass path, AH_FILTER_SMALL has no say there)."""
+import ctypes as C
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -12,8 +14,9 @@ from orc import HostArray
 
 ctx = A.Context(0)
 rng = np.random.default_rng(1)
-print("| rows | columns | fused us | per-column us |")
-print("|---|---|---|---|")
+from arrow_rs_amd import _lib as L
+print("| rows | columns | mirror us | C ABI us | per-column us |")
+print("|---|---|---|---|---|")
 for rows in (8192, 65536, 1 << 20):
     for ncol in (2, 8, 16):
         cols = [HostArray(A.Int64, rng.integers(-2**62, 2**62, rows), rng.random(rows) < 0.9).to_device(ctx) for _ in range(ncol)]
@@ -24,12 +27,21 @@ for rows in (8192, 65536, 1 << 20):
         def percol():
             p = K.FilterBuilder.new(mask).build()
             return [p.filter(c) for c in cols]
+        views = (L.ArrayView * ncol)(*[c.view() for c in cols])
+        mv = mask.view()
+        outs = (L.ArrayOut * ncol)()
+        nrows = C.c_int64()
+        def cabi():
+            st = ctx.lib.ah_filter_record_batch(ctx.handle, ncol, views, C.byref(mv), outs, C.byref(nrows))
+            assert st == 0
+            for i in range(ncol):
+                ctx.lib.ah_array_release(ctx.handle, C.byref(outs[i]))
         res = []
-        for fn in (fused, percol):
+        for fn in (fused, cabi, percol):
             for _ in range(20): fn()
             ctx.synchronize()
             t0 = time.perf_counter()
             for _ in range(200): fn()
             ctx.synchronize()
             res.append((time.perf_counter() - t0) / 200 * 1e6)
-        print(f"| {rows} | {ncol} | {res[0]:.0f} | {res[1]:.0f} |")
+        print(f"| {rows} | {ncol} | {res[0]:.0f} | {res[1]:.0f} | {res[2]:.0f} |")
