@@ -69,6 +69,12 @@ struct CmpArgs {
   int base;  // B_EQ / B_LT on (l, r) as given (caller already swapped)
   int neg;
   unsigned long long* out;
+  // small calls (<= 2048 blocks) whose result validity is `va [& vb]`: the kernel also writes those words and accumulates
+  // their popcount (arith.hip does the same): compare + read-back kernel instead of compare + bitmap kernel + read-back
+  int post;
+  BitView va, vb;
+  unsigned long long* vout;
+  unsigned long long* total;
 };
 
 constexpr int CMP_G = 4;  // 64*V-row groups per wave: 2*CMP_G 16-byte loads in flight per lane
@@ -128,6 +134,20 @@ __global__ void __launch_bounds__(256) compare_kernel(CmpArgs a) {
       int64_t wi = g * V + lane;
       if (lane < V && wi < nwords) a.out[wi] = mine;
     }
+  }
+  if (a.post) {  // uniform
+    unsigned long long acc = 0;
+    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * 256) {
+      uint64_t r = bv_fetch64(a.va, w << 6, a.len);
+      if (a.vb.words) r &= bv_fetch64(a.vb, w << 6, a.len);
+      a.vout[w] = r;
+      acc += __popcll(r);
+    }
+    acc = wave_reduce_add64(acc);
+    __shared__ unsigned long long sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ah_count_add(a.total, sm[0] + sm[1] + sm[2] + sm[3]);
   }
 }
 
@@ -300,6 +320,10 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
   const bool scalar_null = (lnul && l_s && !(rnul && r_s)) || (rnul && r_s && !(lnul && l_s));
   const bool need_values = !scalar_null || (lnul && rnul && l_s == r_s);
 
+  // fused validity for small primitive calls: set by the two arms below that would otherwise launch a counted bitmap op
+  BitView f_va{nullptr, 0}, f_vb{nullptr, 0};
+  unsigned long long* f_vout = nullptr;
+  bool fused_done = false;
   auto run_values = [&](unsigned long long* dst) -> ah_status {
     // apply (cmp.rs:480-488)
     int base, neg;
@@ -349,6 +373,16 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
     bool aligned = true;
     if (!Ls) aligned = aligned && (((uintptr_t)a.l & 15) == 0);
     if (!Rs) aligned = aligned && (((uintptr_t)a.r & 15) == 0);
+    if (f_vout && !ctx->deferred) {
+      const int w8 = ah_type_width(t);
+      const int vv = aligned ? (w8 >= 4 ? 16 / w8 : 4) : 1;
+      if (ah_ceil_div(ah_ceil_div(len, 64 * (int64_t)vv), 4 * CMP_G) <= 2048) {
+        a.post = 1;
+        a.va = f_va, a.vb = f_vb, a.vout = f_vout;
+        a.total = ctx->scratch + AH_TICKET_COUNT;
+        fused_done = true;
+      }
+    }
     switch (t) {
       case AH_INT8: launch_cmp_t<int8_t>(ctx, a, aligned); break;
       case AH_INT16: launch_cmp_t<int16_t>(ctx, a, aligned); break;
@@ -384,9 +418,18 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
         st = ah_bitmap_op(ctx, op == AH_DISTINCT ? BM_DISTINCT_BOTH : BM_NOT_DISTINCT_BOTH, lv, rv, tv, len,
                           vals, nullptr);
     } else {
-      st = run_values(vals);
-      if (st == AH_OK) st = ah_out_alloc(ctx, bytes, (void**)&nb);
-      if (st == AH_OK) st = ah_bitmap_op(ctx, BM_AND, lv, rv, none, len, nb, AH_COUNT(ctx, &set_bits));
+      st = ah_out_alloc(ctx, bytes, (void**)&nb);
+      if (st == AH_OK) {
+        f_va = lv, f_vb = rv, f_vout = nb;
+        st = run_values(vals);
+      }
+      if (st == AH_OK && fused_done) {
+        hipError_t fe = ah_d2h_wait(ctx, ctx->pinned + 8, ctx->scratch + AH_TICKET_COUNT, 8, /*reset=*/true);
+        if (fe != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "compare kernel failed: %s", hipGetErrorString(fe));
+        set_bits = (int64_t)ctx->pinned[8];
+      } else if (st == AH_OK) {
+        st = ah_bitmap_op(ctx, BM_AND, lv, rv, none, len, nb, AH_COUNT(ctx, &set_bits));
+      }
       waited = st == AH_OK && !ctx->deferred;  // the popcount read-back waited for the stream: it ends the call
       has_nb = true;
     }
@@ -432,9 +475,18 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
       if (st == AH_OK)
         st = ah_bitmap_op(ctx, op == AH_DISTINCT ? BM_ORNOT : BM_AND, nv, tv, none, len, vals, nullptr);
     } else {
-      st = run_values(vals);
-      if (st == AH_OK) st = ah_out_alloc(ctx, bytes, (void**)&nb);
-      if (st == AH_OK) st = ah_bitmap_op(ctx, BM_COPY, nv, none, none, len, nb, AH_COUNT(ctx, &set_bits));
+      st = ah_out_alloc(ctx, bytes, (void**)&nb);
+      if (st == AH_OK) {
+        f_va = nv, f_vb = none, f_vout = nb;
+        st = run_values(vals);
+      }
+      if (st == AH_OK && fused_done) {
+        hipError_t fe = ah_d2h_wait(ctx, ctx->pinned + 8, ctx->scratch + AH_TICKET_COUNT, 8, /*reset=*/true);
+        if (fe != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "compare kernel failed: %s", hipGetErrorString(fe));
+        set_bits = (int64_t)ctx->pinned[8];
+      } else if (st == AH_OK) {
+        st = ah_bitmap_op(ctx, BM_COPY, nv, none, none, len, nb, AH_COUNT(ctx, &set_bits));
+      }
       waited = st == AH_OK && !ctx->deferred;
       has_nb = true;
     }

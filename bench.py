@@ -1177,7 +1177,7 @@ def main():
         line["configs"] = configs
         line["next_rows"] = next_rows
 
-    if wl == "filter_take" and world > 1 and not args.no_configs:
+    if wl == "filter_take" and (world > 1 or args.reassemble == "allgatherv") and use_dist and not args.no_configs:
         # BASELINE configs[4]: {Int64, Float64, bitmaps} per shard through filter_record_batch, then ONE exchange of both
         # columns (ah_all_gather_columns) — every rank runs it, rank 0 reports
         W = out = None
