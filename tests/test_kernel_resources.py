@@ -65,7 +65,9 @@ def _find(kernels, *parts):
 
 def test_no_hot_kernel_spills(kernels):
     for parts in (("filter_scatter_kernel",), ("take_kernel",), ("arith_kernel",), ("compare_kernel",), ("cast_stream_kernel",),
-                  ("string_len_kernel",), ("string_write_kernel",), ("filter_count",)):
+                  ("string_len_kernel",), ("string_write_kernel",), ("filter_count",), ("filter_small_kernel",),
+                  ("filter_scatter_multi_kernel",), ("filter_expr_count_kernel",), ("string_filter_ranges_kernel",),
+                  ("string_filter_gather_kernel",)):
         for r in _find(kernels, *parts):
             assert r["scratch"] == 0, f"{parts}: {r['scratch']} bytes of scratch (register spill)"
 
@@ -81,3 +83,18 @@ def test_string_passes_keep_eight_workgroups_per_cu(kernels):
         assert r["sgpr"] <= 80 and r["lds"] <= 20480 and r["vgpr"] <= 64, r
     for r in _find(kernels, "string_len_kernelIdE"):
         assert r["sgpr"] <= 80 and r["lds"] <= 20480 and r["vgpr"] <= 64, r
+
+
+def test_round3_kernels_keep_their_occupancy(kernels):
+    # the lazy predicate's fast instantiation (2 terms, 8-byte operands, scalar right sides): 6 waves per SIMD
+    for r in _find(kernels, "filter_expr_count_kernelILi2ELi8ELb1E"):
+        assert r["vgpr"] <= 84, r
+    # the multi-batch scatter shares filter_scatter's body: same budget
+    for r in _find(kernels, "filter_scatter_multi_kernelILi8ELi2ELb1E"):
+        assert r["vgpr"] <= 96 and r["lds"] <= 32768, r
+    # the one-launch filter of small batches, Int64 with validity: a latency-bound kernel (<= 256 tiles); 4 waves per SIMD
+    for r in _find(kernels, "filter_small_kernelILi8ELi2ELb1E"):
+        assert r["vgpr"] <= 128 and r["lds"] <= 32768, r
+    # string filter ranges: a 32 KiB stage -> 4-5 workgroups per CU
+    for r in _find(kernels, "string_filter_ranges_kernelIlLb1E"):
+        assert r["lds"] <= 36864, r
