@@ -445,8 +445,7 @@ extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_a
   hipError_t e = hipGetLastError();
   bool waited = false;
   if (fused_post && st == AH_OK && e == hipSuccess) {
-    e = ah_d2h_wait(ctx, ctx->pinned + 8, ctx->scratch + AH_TICKET_COUNT, 8, /*reset=*/true);
-    set_bits = (int64_t)ctx->pinned[8];
+    e = ah_count_read(ctx, &set_bits);
     waited = true;
   } else if (st == AH_OK && e == hipSuccess && want_valid && !union_first) {
     int64_t* cnt = AH_COUNT(ctx, &set_bits);

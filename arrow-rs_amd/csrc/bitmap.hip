@@ -120,8 +120,7 @@ ah_status ah_bitmap_op(ah_context* ctx, int op, BitView a, BitView b, BitView c,
   }
   // counted: the kernel accumulates the popcount in a scratch word; one small kernel copies it to the host, zeroes it, posts
   bitmap_op_kernel<<<grid, 256, 0, ctx->stream>>>(op, a, b, c, d, len, out_words, ctx->scratch + AH_TICKET_COUNT);
-  AH_HIP(ctx, ah_d2h_wait(ctx, ctx->pinned + 8, ctx->scratch + AH_TICKET_COUNT, 8, /*reset=*/true));
-  *set_bits = (int64_t)ctx->pinned[8];
+  AH_HIP(ctx, ah_count_read(ctx, set_bits));
   return AH_OK;
 }
 
@@ -179,7 +178,6 @@ extern "C" ah_status ah_bitmap_set_bits(ah_context* ctx, uint8_t* dst, int64_t d
   }
   set_bits_kernel<<<grid, 256, 0, ctx->stream>>>((unsigned long long*)dst, dst_bit_offset, make_bitview(src, src_bit_offset), len, nullptr,
                                                  ctx->scratch + AH_TICKET_COUNT);
-  AH_HIP(ctx, ah_d2h_wait(ctx, ctx->pinned + 8, ctx->scratch + AH_TICKET_COUNT, 8, /*reset=*/true));
-  *set_bits = (int64_t)ctx->pinned[8];
+  AH_HIP(ctx, ah_count_read(ctx, set_bits));
   return AH_OK;
 }

@@ -424,9 +424,8 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
         st = run_values(vals);
       }
       if (st == AH_OK && fused_done) {
-        hipError_t fe = ah_d2h_wait(ctx, ctx->pinned + 8, ctx->scratch + AH_TICKET_COUNT, 8, /*reset=*/true);
+        hipError_t fe = ah_count_read(ctx, &set_bits);
         if (fe != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "compare kernel failed: %s", hipGetErrorString(fe));
-        set_bits = (int64_t)ctx->pinned[8];
       } else if (st == AH_OK) {
         st = ah_bitmap_op(ctx, BM_AND, lv, rv, none, len, nb, AH_COUNT(ctx, &set_bits));
       }
@@ -481,9 +480,8 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
         st = run_values(vals);
       }
       if (st == AH_OK && fused_done) {
-        hipError_t fe = ah_d2h_wait(ctx, ctx->pinned + 8, ctx->scratch + AH_TICKET_COUNT, 8, /*reset=*/true);
+        hipError_t fe = ah_count_read(ctx, &set_bits);
         if (fe != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "compare kernel failed: %s", hipGetErrorString(fe));
-        set_bits = (int64_t)ctx->pinned[8];
       } else if (st == AH_OK) {
         st = ah_bitmap_op(ctx, BM_COPY, nv, none, none, len, nb, AH_COUNT(ctx, &set_bits));
       }

@@ -99,7 +99,7 @@ ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...);
   } while (0)
 
 constexpr int AH_MAIL_FLAG = 255;     // index of the sequence word in ctx->pinned
-constexpr int AH_SCRATCH_WORDS = 560;  // 8 x 64 zero-state counters (one set per column of a fused launch) + 8 ones-state position words + 40 zero-state ticket words
+constexpr int AH_SCRATCH_WORDS = 640;  // 8 x 64 zero-state counters (one set per column of a fused launch) + 8 ones-state position words + 40 + 64 zero-state counter words
 constexpr int AH_SCRATCH_ONES = 512;     // [512, 520): all ones between calls
 constexpr int AH_SCRATCH_TICKETS = 520;  // [520, 560): zero between calls (filter_small.hip's completion tickets)
 
@@ -182,10 +182,6 @@ ah_status ah_ranges_to_strings(ah_context* ctx, bool large, const uint8_t* src, 
                                const void* ends, int64_t k, bool overflow_is_error, ah_array_out* out);
 ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_array_view* indices,
                         ah_array_out* out);
-struct ah_filter_predicate;
-// strings.hip: filter_bytes — offsets + data of the rows the predicate selects (three launches, one host wait for the byte total)
-ah_status ah_string_filter_bytes(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* values, ah_array_out* out);
-
 // bitmap.hip: ah_bitmap_set_bits without a read-back — *nulls_acc (device) += len - popcount(copied bits)
 ah_status ah_bitmap_set_bits_acc(ah_context* ctx, uint8_t* dst, int64_t dst_bit_offset, const uint8_t* src,
                                  int64_t src_bit_offset, int64_t len, unsigned long long* nulls_acc);
@@ -383,10 +379,20 @@ template <bool NT, typename VT> __device__ __forceinline__ void ah_st_stream(VT*
 // the OUTPUT is still retiring — its end-of-kernel release is what makes the output visible to other streams and copy
 // engines, and waiting for the runtime to report the kernel complete (hipStreamQuery) costs 13 us.  A separate posting
 // kernel starts only after the producing kernel has ended, so "synchronous at return" holds for any consumer.
-__device__ __forceinline__ void ah_count_add(unsigned long long* word, unsigned long long count) {
-  if (count) atomicAdd(word, count);
+// (64 counters, picked by block index: 4096 blocks finishing together on ONE word serialize at ~12 ns per atomic — 50 us)
+__device__ __forceinline__ void ah_count_add(unsigned long long* words, unsigned long long count) {
+  if (count) atomicAdd(words + (blockIdx.x & 63), count);
 }
-constexpr int AH_TICKET_COUNT = AH_SCRATCH_TICKETS + 32;  // the word bitmap.hip / context.hip's counting kernels use
+constexpr int AH_TICKET_COUNT = AH_SCRATCH_TICKETS + 40;  // [560, 624): the 64 counter words of the counting kernels
+// the read-back of ah_count_add: 64 counters -> pinned slots, counters zeroed, mailbox posted, host sum
+hipError_t ah_count_read(ah_context* ctx, int64_t* total);
+
+struct ah_filter_predicate;
+// strings.hip: filter_bytes + filter_nulls of a Utf8 / LargeUtf8 column — offsets, data and (vvalid.words != nullptr) the
+// compacted validity of the rows the predicate selects: ranges (one pass over the offsets) -> tile scan -> gather, one host
+// wait for {byte total, valid rows} in between
+ah_status ah_string_filter_bytes(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* values, BitView vvalid,
+                                 ah_array_out* out);
 
 // ---- shared bitmap machinery (bitmap.hip)
 enum ah_bitmap_opcode {

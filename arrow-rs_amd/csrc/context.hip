@@ -254,6 +254,15 @@ hipError_t ah_stream_wait(ah_context* ctx) {
   return e == hipSuccess ? ah_mail_wait(ctx, seq) : e;
 }
 
+hipError_t ah_count_read(ah_context* ctx, int64_t* total) {
+  hipError_t e = ah_d2h_wait(ctx, ctx->pinned + 64, ctx->scratch + AH_TICKET_COUNT, 64 * 8, /*reset=*/true);
+  if (e != hipSuccess) return e;
+  uint64_t t = 0;
+  for (int i = 0; i < 64; ++i) t += ctx->pinned[64 + i];
+  *total = (int64_t)t;
+  return hipSuccess;
+}
+
 hipError_t ah_d2h_wait(ah_context* ctx, void* pinned_dst, const void* dev_src, size_t bytes, bool reset,
                        uint64_t reset_value) {
   if (!in_pinned(ctx, pinned_dst, bytes) || (bytes & 7) || ((uintptr_t)dev_src & 7)) {
@@ -509,8 +518,7 @@ extern "C" ah_status ah_count_set_bits(ah_context* ctx, const uint8_t* bits, int
   int grid = (int)std::min<int64_t>(2048, ah_ceil_div(nwords, 256));
   BitView bv = make_bitview(bits, bit_offset);
   popcount_partial_kernel<<<grid, 256, 0, ctx->stream>>>(bv, len, ctx->scratch + AH_TICKET_COUNT);
-  AH_HIP(ctx, ah_d2h_wait(ctx, ctx->pinned, ctx->scratch + AH_TICKET_COUNT, 8, /*reset=*/true));
-  *count = (int64_t)ctx->pinned[0];
+  AH_HIP(ctx, ah_count_read(ctx, count));
   return AH_OK;
 }
 

@@ -981,37 +981,14 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
   BitView vvalid = has_valid ? make_bitview(values->validity, values->validity_bit_offset)
                              : BitView{nullptr, 0};
 
-  if (is_string) {  // filter_bytes (filter.rs:890-928): ranges of the selected rows -> new offsets + bytes
-    // strings.hip: ranges (one pass over the offsets) -> tile-byte scan -> gather; the column's validity is compacted by
-    // the bit-only scatter (filter_nulls :512-532), enqueued first so that it runs during the byte-total round trip
-    uint8_t* nb = nullptr;
-    size_t nbytes = 0;
-    int64_t nset = -1;
-    ah_status st = AH_OK;
-    if (has_valid) st = compact_bits(ctx, p, vvalid, &nb, &nbytes, &nset, /*defer=*/true);
-    if (st == AH_OK) st = ah_string_filter_bytes(ctx, p, values, out);
+  if (is_string) {  // filter_bytes (filter.rs:890-928) + filter_nulls: strings.hip — ranges, tile scan, gather
+    const ah_status st = ah_string_filter_bytes(ctx, p, values, vvalid, out);
     if (st != AH_OK) {
-      ah_out_free(ctx, nb, nbytes);
       ah_out_init(out);
       return st;
     }
     out->type = values->type;
     out->length = K;
-    if (nb) {
-      int64_t cnt = 0;  // ah_ranges_to_strings synchronised the stream: the bitmap is complete
-      st = ah_count_set_bits(ctx, nb, 0, K, &cnt);
-      if (st != AH_OK) {
-        ah_out_free(ctx, nb, nbytes);
-        ah_array_release(ctx, out);
-        return st;
-      }
-      if (K - cnt == 0) ah_out_free(ctx, nb, nbytes);  // filter_nulls :523-525 -> None
-      else {
-        out->validity = nb;
-        out->validity_bytes = (int64_t)nbytes;
-        out->null_count = K - cnt;
-      }
-    }
     return AH_OK;
   }
 

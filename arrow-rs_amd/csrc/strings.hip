@@ -34,18 +34,27 @@ namespace {
 //    (the one number the host waits for: it sizes the data buffer).
 // F3 string_filter_gather_kernel: one workgroup per tile again: new offset = tile_base + local offset, bytes copied row by
 //    row (unaligned 8-byte chunks with an overlapping tail; rows > 64 B cooperatively).
-template <typename OFF, bool VEC>
+//    With HAS_VALID the same pass compacts the column's validity (filter_nulls, filter.rs:512-532): the selected rows'
+//    validity flags ride through the stage, are re-packed with __ballot aligned to the output's 64-bit words and merged
+//    with atomicOr (pre-zeroed bitmap), the valid rows are counted into *valid_count (it was a separate bit-only scatter
+//    over the predicate, 107 us at 2^27 rows, plus a popcount launch and a host wait).
+template <typename OFF, bool VEC, bool HAS_VALID>
 __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* offsets, BitView mask, BitView mask_valid,
                                                                    int64_t len, const uint32_t* chunk_prefix,
                                                                    const unsigned long long* group_prefix, int group_shift,
-                                                                   OFF* starts, OFF* loffs, unsigned long long* tile_bytes) {
+                                                                   OFF* starts, OFF* loffs, unsigned long long* tile_bytes,
+                                                                   BitView vvalid, unsigned long long* out_valid,
+                                                                   unsigned long long* valid_count) {
   constexpr int T = 4096, NW = 64, R = 16, CAP = 2048;
   __shared__ uint64_t s_m[NW];
+  __shared__ uint64_t s_v[HAS_VALID ? NW : 1];
   __shared__ uint32_t s_base[NW];
   __shared__ uint32_t s_total;
   __shared__ unsigned long long s_wbytes[4];
   __shared__ OFF s_start[CAP];
   __shared__ OFF s_loff[CAP];
+  __shared__ uint8_t s_flag[HAS_VALID ? CAP : 1];
+  __shared__ uint32_t s_vc[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * T;
   const int64_t r0 = row0 + (int64_t)t * R;
@@ -71,15 +80,17 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
     for (int e = 0; e <= R; ++e) o[e] = r0 + e <= len ? offsets[r0 + e] : (OFF)0;
   }
   if (wave == 0) {
-    uint64_t m = 0;
+    uint64_t m = 0, vv = 0;
     const int64_t s = row0 + ((int64_t)lane << 6);
     if (s < len) {
       m = bv_fetch64(mask, s, len);
       if (mask_valid.words) m &= bv_fetch64(mask_valid, s, len);
+      if constexpr (HAS_VALID) vv = bv_fetch64(vvalid, s, len);
     }
     const int c = __popcll(m);
     const int incl = wave_scan_incl(c);
     s_m[lane] = m;
+    if constexpr (HAS_VALID) s_v[lane] = vv;
     s_base[lane] = (uint32_t)(incl - c);
     if (lane == 63) s_total = (uint32_t)incl;
   }
@@ -87,6 +98,8 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
   const int sh = (t * R) & 63;
   const uint64_t word = s_m[(t * R) >> 6];
   const uint32_t bits = (uint32_t)(word >> sh) & 0xFFFFu;
+  uint32_t vbits = 0;
+  if constexpr (HAS_VALID) vbits = (uint32_t)(s_v[(t * R) >> 6] >> sh) & 0xFFFFu;
   // bytes this thread's selected rows contribute, and their exclusive prefix over the workgroup (thread order = row order)
   unsigned long long mine = 0;
 #pragma unroll
@@ -108,6 +121,7 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
   const int64_t chunk0 = row0 / AH_FILTER_CHUNK_ROWS;
   const int64_t P = (int64_t)group_prefix[chunk0 >> group_shift] + chunk_prefix[chunk0];  // the tile's first output row
   const int rank0 = (int)(s_base[(t * R) >> 6] + __popcll(word & ((1ull << sh) - 1ull)));
+  int vc = 0;
   for (int p0 = 0; p0 < total; p0 += CAP) {  // tiles with more than CAP selected rows take a second round
     const int cnt = (total - p0) < CAP ? (total - p0) : CAP;
     if (p0) __syncthreads();
@@ -119,6 +133,7 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
         if ((unsigned)pos < (unsigned)cnt) {
           s_start[pos] = o[e];
           s_loff[pos] = (OFF)bo;
+          if constexpr (HAS_VALID) s_flag[pos] = (uint8_t)((vbits >> e) & 1u);
         }
         bo += (unsigned long long)(o[e + 1] - o[e]);
         ++pos;
@@ -129,36 +144,60 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
       starts[P + p0 + q] = s_start[q];
       loffs[P + p0 + q] = s_loff[q];
     }
+    if constexpr (HAS_VALID) {  // validity words of output rows [P + p0, + cnt): ballots aligned to the global words
+      const int64_t cb = P + p0, g0 = cb & ~63ll;
+      const int lead = (int)(cb - g0), span64 = (lead + cnt + 63) & ~63;
+      for (int q = t; q < span64; q += 256) {
+        const int j = q - lead;
+        const int f = (j >= 0 && j < cnt) ? (int)s_flag[j] : 0;
+        const uint64_t w = __ballot(f);
+        if (lane == 0) {
+          if (w) atomicOr(&out_valid[(g0 + q) >> 6], (unsigned long long)w);
+          vc += __popcll(w);
+        }
+      }
+    }
+  }
+  if constexpr (HAS_VALID) {
+    if (lane == 0) s_vc[wave] = (uint32_t)vc;
+    __syncthreads();
+    // 64 counters, one add per tile (32 Ki same-address atomics cost 0.2 ms: ~12 ns each, serialized); the tile scan folds them
+    if (t == 0) ah_count_add(valid_count, (unsigned long long)(s_vc[0] + s_vc[1] + s_vc[2] + s_vc[3]));
   }
 }
 
-// exclusive scan of the tile byte totals (one workgroup); *total_out = grand total
+// exclusive scan of the tile byte totals (one workgroup: every thread owns a contiguous run of ceil(n / 1024) tiles, one
+// block scan over the run totals — the first version walked 1024 tiles per step, 53 us for 32 Ki tiles); *total_out = grand total
 __global__ void __launch_bounds__(1024) string_tile_scan_kernel(const unsigned long long* tile_bytes, int64_t ntiles,
-                                                                unsigned long long* tile_base, unsigned long long* total_out) {
+                                                                unsigned long long* tile_base, unsigned long long* total_out,
+                                                                const unsigned long long* valid_slots) {
   __shared__ unsigned long long s_wave[16];
-  __shared__ unsigned long long s_carry;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t == 0) s_carry = 0;
-  __syncthreads();
-  for (int64_t b0 = 0; b0 < ntiles; b0 += 1024) {
-    const unsigned long long v = (b0 + t < ntiles) ? tile_bytes[b0 + t] : 0ull;
-    unsigned long long incl = v;
-#pragma unroll
-    for (int k = 1; k < 64; k <<= 1) {
-      const unsigned long long u = __shfl_up(incl, k, 64);
-      if (lane >= k) incl += u;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    unsigned long long wbase = s_carry;
-    for (int w = 0; w < wave; ++w) wbase += s_wave[w];
-    if (b0 + t < ntiles) tile_base[b0 + t] = wbase + incl - v;
-    __syncthreads();
-    if (t == 1023) s_carry = wbase + incl;
-    __syncthreads();
+  if (wave == 15 && valid_slots) {  // total_out[1] = valid rows = the 64 counters of the ranges kernel
+    const unsigned long long v = wave_reduce_add64(valid_slots[lane]);
+    if (lane == 0) total_out[1] = v;
   }
-  if (t == 0) *total_out = s_carry;
+  const int64_t per = (ntiles + 1023) / 1024, b0 = (int64_t)t * per, b1 = b0 + per < ntiles ? b0 + per : ntiles;
+  unsigned long long mine = 0;
+  for (int64_t i = b0; i < b1; ++i) mine += tile_bytes[i];
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    const unsigned long long u = __shfl_up(incl, k, 64);
+    if (lane >= k) incl += u;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned long long run = incl - mine;
+  for (int w = 0; w < wave; ++w) run += s_wave[w];
+  for (int64_t i = b0; i < b1; ++i) {
+    const unsigned long long v = tile_bytes[i];
+    tile_base[i] = run;
+    run += v;
+  }
+  if (t == 1023) *total_out = run;
 }
+
 template <typename OFF>
 __global__ void __launch_bounds__(1024) range_scan_local_kernel(const OFF* starts, const OFF* ends, int64_t k,
                                                                 OFF* dst_off, unsigned long long* block_total) {
@@ -485,38 +524,58 @@ ah_status launch_take_ranges(ah_context* ctx, const ah_array_view* values, const
 
 }  // namespace
 
-// filter_bytes (filter.rs:790-928) for the rows `p` selects: offsets + data of the result (validity is the caller's).
+// filter_bytes (filter.rs:790-928) + filter_nulls (:512-532) for the rows `p` selects: offsets, data and — when `vvalid` has
+// words — the compacted validity of the result (dropped again when it has no nulls, :523-525).
 template <typename OFF>
-static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* values, ah_array_out* out) {
+static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* values, BitView vvalid,
+                                ah_array_out* out) {
   const int64_t K = p->count, len = p->len, ntiles = ah_ceil_div(len, 4096);
   const OFF* offsets = (const OFF*)values->offsets;
-  const size_t ob = (size_t)(K + 1) * sizeof(OFF), kb = (((size_t)K * sizeof(OFF)) + 15) & ~(size_t)15;
-  char* tmp = nullptr;  // starts | local offsets | tile bytes | tile bases | total
-  AH_TRY(ah_pool_alloc(ctx, 2 * kb + (size_t)(2 * ntiles + 2) * 8, (void**)&tmp));
+  const bool hv = vvalid.words != nullptr;
+  const size_t ob = (size_t)(K + 1) * sizeof(OFF), kb = (((size_t)K * sizeof(OFF)) + 15) & ~(size_t)15, nbytes = hv ? ah_bitmap_bytes(K) : 0;
+  char* tmp = nullptr;  // starts | local offsets | tile bytes | tile bases | {total bytes, valid rows} | 64 valid-row counters
+  AH_TRY(ah_pool_alloc(ctx, 2 * kb + (size_t)(2 * ntiles + 2 + 64) * 8, (void**)&tmp));
+  void* nb = nullptr;
+  if (hv) {
+    const ah_status as = ah_out_alloc(ctx, nbytes, &nb);
+    if (as != AH_OK) {
+      ah_pool_free(ctx, tmp);
+      return as;
+    }
+    hipMemsetAsync(nb, 0, nbytes, ctx->stream);
+  }
   OFF* starts = (OFF*)tmp;
   OFF* loffs = (OFF*)(tmp + kb);
   unsigned long long* tile_bytes = (unsigned long long*)(tmp + 2 * kb);
   unsigned long long* tile_base = tile_bytes + ntiles;
-  unsigned long long* total = tile_base + ntiles;
+  unsigned long long* total = tile_base + ntiles;  // [0] byte total, [1] valid rows (both written by the tile scan)
+  unsigned long long* vslots = total + 2;
+  if (hv) hipMemsetAsync(vslots, 0, 64 * 8, ctx->stream);
   const bool vec = (((uintptr_t)offsets) & 15) == 0;
   {
     ah_prof_scope ps(ctx, "string_filter_ranges");
-    if (vec)
-      string_filter_ranges_kernel<OFF, true><<<(unsigned)ntiles, 256, 0, ctx->stream>>>(offsets, p->mask, p->mask_valid, len, p->chunk_prefix,
-                                                                                        p->group_prefix, p->group_shift, starts, loffs, tile_bytes);
-    else
-      string_filter_ranges_kernel<OFF, false><<<(unsigned)ntiles, 256, 0, ctx->stream>>>(offsets, p->mask, p->mask_valid, len, p->chunk_prefix,
-                                                                                         p->group_prefix, p->group_shift, starts, loffs, tile_bytes);
-    string_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(tile_bytes, ntiles, tile_base, total);
+#define AH_SFR(VEC, HV)                                                                                                          \
+  string_filter_ranges_kernel<OFF, VEC, HV><<<(unsigned)ntiles, 256, 0, ctx->stream>>>(                                          \
+      offsets, p->mask, p->mask_valid, len, p->chunk_prefix, p->group_prefix, p->group_shift, starts, loffs, tile_bytes, vvalid, \
+      (unsigned long long*)nb, vslots)
+    if (vec && hv) AH_SFR(true, true);
+    else if (vec) AH_SFR(true, false);
+    else if (hv) AH_SFR(false, true);
+    else AH_SFR(false, false);
+#undef AH_SFR
+    string_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(tile_bytes, ntiles, tile_base, total, hv ? vslots : nullptr);
   }
-  hipError_t e = ah_d2h_wait(ctx, ctx->pinned, total, 8);
+  hipError_t e = ah_d2h_wait(ctx, ctx->pinned, total, 16);  // the one wait before the gather: byte total + valid rows
   if (e != hipSuccess) {
     ah_pool_free(ctx, tmp);
+    ah_out_free(ctx, nb, nbytes);
     return ah_fail(ctx, AH_HIP_ERROR, "string filter ranges failed: %s", hipGetErrorString(e));
   }
   const uint64_t total_bytes = ctx->pinned[0];
+  const int64_t nulls = hv ? K - (int64_t)ctx->pinned[1] : 0;
   if (sizeof(OFF) == 4 && total_bytes > (uint64_t)INT32_MAX) {
     ah_pool_free(ctx, tmp);
+    ah_out_free(ctx, nb, nbytes);
     return ah_fail(ctx, AH_PANIC, "illegal offset range");  // filter.rs:838
   }
   void *offs = nullptr, *data = nullptr;
@@ -524,6 +583,7 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
   if (st == AH_OK) st = ah_out_alloc(ctx, (size_t)total_bytes, &data);
   if (st != AH_OK) {
     ah_out_free(ctx, offs, ob);
+    ah_out_free(ctx, nb, nbytes);
     ah_pool_free(ctx, tmp);
     return st;
   }
@@ -539,16 +599,26 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
   if (e != hipSuccess) {
     ah_out_free(ctx, offs, ob);
     ah_out_free(ctx, data, (size_t)total_bytes);
+    ah_out_free(ctx, nb, nbytes);
     return ah_fail(ctx, AH_HIP_ERROR, "string gather failed: %s", hipGetErrorString(e));
   }
   out->offsets = offs;
   out->offsets_bytes = (int64_t)ob;
   out->values = data;
   out->values_bytes = (int64_t)total_bytes;
+  if (hv && nulls > 0) {
+    out->validity = (uint8_t*)nb;
+    out->validity_bytes = (int64_t)nbytes;
+    out->null_count = nulls;
+  } else {
+    ah_out_free(ctx, nb, nbytes);  // filter_nulls :523-525 -> None
+  }
   return AH_OK;
 }
-ah_status ah_string_filter_bytes(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* values, ah_array_out* out) {
-  return values->type == AH_LARGE_UTF8 ? filter_bytes_t<int64_t>(ctx, p, values, out) : filter_bytes_t<int32_t>(ctx, p, values, out);
+ah_status ah_string_filter_bytes(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* values, BitView vvalid,
+                                 ah_array_out* out) {
+  return values->type == AH_LARGE_UTF8 ? filter_bytes_t<int64_t>(ctx, p, values, vvalid, out)
+                                       : filter_bytes_t<int32_t>(ctx, p, values, vvalid, out);
 }
 
 // ranges [starts[i], ends[i]) of `src` (device arrays of the offset type) -> offsets + bytes
