@@ -148,7 +148,7 @@ def _term_array(terms, joins):
 def filter_expr(values, terms, joins=()):
     """``filter(values, <terms joined by joins>)`` in one call (``ah_filter_expr``): what an engine writes as
     ``filter(&a, &and_kleene(&lt(&a, &x)?, &gt_eq(&b, &y)?)?)`` (cmp.rs:113-164, boolean.rs:60-300, filter.rs:201) with
-    nothing materialised — above 2^20 rows of 8-byte columns a single kernel that reads every operand once."""
+    nothing materialised: the comparisons run inside the filter's count pass, the scatter reads the packed result."""
     ctx, n, arr, js, _keep = _term_array(terms, joins)
     out = L.ArrayOut()
     vv = values.view()

@@ -466,7 +466,10 @@ extern "C" ah_status ah_filter_predicate_build_expr(ah_context* ctx, int32_t n_t
 // against 4.6 ms for these two passes, 5.6 ms even with the look-back ablated.  Holding two tiles' values in registers
 // across the ticket, the aggregates and the look-back leaves 3 workgroups per CU working in phases that each expose a full
 // memory latency, where the two streaming kernels run at 5.8-5.9 TB/s.  It also needed the output allocated for the worst
-// case (8 GB here).  Numbers: profiles/r03_single_pass_lookback.md; nothing of it is in the tree.)
+// case (8 GB here).  A stash form — the count pass also leaves each chunk's selected values compacted in a slot, the
+// second pass copies slots instead of re-reading the column: 21.8 GB — was built too and lost as well (5.2 ms against 5.0 on
+// the same box: ranking + compacting inside the count pass costs more than the re-read saves).  Numbers for both:
+// profiles/r03_single_pass_lookback.md; nothing of either is in the tree.)
 extern "C" ah_status ah_filter_expr(ah_context* ctx, int32_t n_terms, const ah_filter_term* terms, const ah_boolean_op* joins,
                                     const ah_array_view* values, ah_array_out* out) {
   ah_ctx_guard _guard(ctx);

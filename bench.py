@@ -651,7 +651,7 @@ def build_workload(env, wl):
             st["k"], st["fn"] = f.length, f.null_count()
             return f
 
-        W.update(step=step, kernels=["filter_expr_count", "filter_scatter"], dominant="filter_scatter")
+        W.update(step=step, kernels=["filter_expr_count", "filter_scatter"], dominant="filter_expr_count")
     elif wl == "aggregate":
         # sum + min + max of the Int64 column (three streaming reads per step)
         col = gen_i64_column(A, ctx, n, 42, args.valid, row0)
@@ -757,9 +757,10 @@ def describe(env, wl, W, prof, out, steps):
     elif wl == "predicate_filter_fused":
         k = st["k"]
         wb = (n + 7) // 8
-        # count pass: a, b values + their validity in, selection bits out; scatter: a + its validity + selection bits in,
-        # K values + K bits out
-        alg = (2 * n * 8 + 2 * wb + wb) + (n * 8 + 2 * wb + k * 8 + (k + 7) // 8)
+        # every input once (a, b values + their validity), every output once (K values + K bits).  The
+        # selection words and the second pass's re-read of `a` are the implementation's own traffic (r03's first
+        # collection counted the two-pass plan's 26.3 GB here, which flattered the fraction: 0.68 instead of 0.47).
+        alg = 2 * n * 8 + 2 * wb + k * 8 + (k + 7) // 8
         dom_avg, dom_n = sum(prof[kk][0] for kk in kernels) / max(steps, 1), steps
         dominant = "predicate_filter_fused_step"
     elif wl == "record_batch":

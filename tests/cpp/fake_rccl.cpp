@@ -112,8 +112,11 @@ void run_ops(std::vector<std::pair<FakeComm*, PendingOp>>& ops) {
       w->box[key].pop_front();
     }
     const size_t n = m->bytes < e.second.bytes ? m->bytes : e.second.bytes;
+    // on the RECEIVER'S stream and waited for: a plain hipMemcpy of device memory may return before the copy has run,
+    // and it runs on the null stream, which the contexts' non-blocking streams do not order against — the receiver's
+    // merge / rebase kernels could then read the piece before it had landed (seen once at world 8: a stale offset)
+    if (n) hipMemcpyAsync(e.second.ptr, m->src, n, hipMemcpyDeviceToDevice, e.second.stream);
     hipStreamSynchronize(e.second.stream);
-    if (n) hipMemcpy(e.second.ptr, m->src, n, hipMemcpyDeviceToDevice);
     {
       std::lock_guard<std::mutex> lk(w->mu);
       m->consumed = true;
@@ -209,7 +212,10 @@ __attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void* se
   {
     // deposit + wait for everyone (see collective_exchange: the last arriver publishes the snapshot)
     std::vector<char> mine(bytes);
-    if (bytes) hipMemcpy(mine.data(), send, bytes, hipMemcpyDeviceToHost);
+    if (bytes) {
+      hipMemcpyAsync(mine.data(), send, bytes, hipMemcpyDeviceToHost, stream);
+      hipStreamSynchronize(stream);
+    }
     std::unique_lock<std::mutex> lk(w->mu);
     const int gen = w->coll_gen;
     if (w->coll_host.size() != (size_t)w->size) w->coll_host.assign(w->size, {});
@@ -226,7 +232,8 @@ __attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void* se
     all = fake_snapshots()[w];
   }
   for (int r = 0; r < w->size; ++r)
-    if (bytes) hipMemcpy((char*)recv + (size_t)r * bytes, all[r].data(), bytes, hipMemcpyHostToDevice);
+    if (bytes) hipMemcpyAsync((char*)recv + (size_t)r * bytes, all[r].data(), bytes, hipMemcpyHostToDevice, stream);
+  hipStreamSynchronize(stream);  // `all` is pageable: the copies have left it; and the stream's next kernel sees them
   // nobody may start the next collective (and overwrite the snapshot) before everyone has read this one
   {
     std::unique_lock<std::mutex> lk(w->mu);
@@ -251,13 +258,15 @@ __attribute__((visibility("default"))) ncclResult_t ncclAllReduce(const void* se
   if (hipMalloc(&scratch, count * 8 * (size_t)w->size) != hipSuccess) return 1;
   ncclResult_t r = ncclAllGather(send, scratch, count, t, comm, stream);
   std::vector<double> all(count * (size_t)w->size), out(count);
-  hipMemcpy(all.data(), scratch, all.size() * 8, hipMemcpyDeviceToHost);
+  hipMemcpyAsync(all.data(), scratch, all.size() * 8, hipMemcpyDeviceToHost, stream);
+  hipStreamSynchronize(stream);
   for (size_t i = 0; i < count; ++i) {
     double m = all[i];
     for (int k = 1; k < w->size; ++k) m = all[(size_t)k * count + i] > m ? all[(size_t)k * count + i] : m;
     out[i] = m;
   }
-  hipMemcpy(recv, out.data(), count * 8, hipMemcpyHostToDevice);
+  hipMemcpyAsync(recv, out.data(), count * 8, hipMemcpyHostToDevice, stream);
+  hipStreamSynchronize(stream);
   hipFree(scratch);
   return r;
 }

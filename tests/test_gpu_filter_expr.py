@@ -222,6 +222,72 @@ def test_filter_expr_other_widths_and_sizes(ctx, oracle):
         assert_logical_eq(HostArray.from_device(got), oracle.filter(a, mask), f"n {n} {dt}")
 
 
+# ------------------------------------------------------- ah_filter_expr around the chunk / tile / group boundaries
+def _boundary_case(rng, seed):
+    """values column = the array operand of one term; selectivity from nothing to everything, dense stretches"""
+    n = [1, 2, 63, 1023, 1024, 1025, 4095, 4097, 8191, 65_536 + 1, 70_001, 262_147, 1_000_003][seed % 13]
+    dt = [A.Int64, A.Float64, A.Int32, A.UInt64, A.Float32, A.UInt32][seed % 6]
+    p_valid = [0.9, None, 0.5, 0.999][seed % 4]
+    npdt = dt.np_dtype
+    if np.issubdtype(npdt, np.floating):
+        v = rng.standard_normal(n).astype(npdt)
+        if n > 10:
+            v[rng.integers(0, n, max(1, n // 40))] = np.nan
+    elif np.issubdtype(npdt, np.signedinteger):
+        v = rng.integers(-1000, 1000, n).astype(npdt)
+    else:
+        v = rng.integers(0, 2000, n).astype(npdt)
+    vals = HostArray(dt, v, None if p_valid is None else rng.random(n) < p_valid)
+    # threshold chosen for a target selectivity; clustered variant: a stretch of the column selects everything
+    sel = [0.02, 0.2, 0.45, 0.7, 0.0, 1.0, 0.3][seed % 7]
+    finite = v[np.isfinite(v.astype(np.float64))] if n else v
+    thr = np.quantile(finite.astype(np.float64), sel) if len(finite) else 0
+    thr_h = HostArray(dt, np.array([thr]).astype(npdt))
+    terms = [("lt", vals, False, thr_h, True)]
+    joins = []
+    if seed % 3 != 0:
+        other = _column(rng, dt, n, [None, 0.8][seed % 2])
+        if seed % 2:
+            terms.append(("gt_eq", other, False, _scalar(rng, dt), True))
+        else:  # array right sides everywhere (the RS = false instantiation)
+            terms = [("lt", vals, False, HostArray(dt, np.full(n, thr).astype(npdt)), False),
+                     ("neq", other, False, _column(rng, dt, n, None), False)]
+        joins.append(["and_kleene", "or_kleene", "and", "or"][seed % 4])
+        if seed % 5 == 0:  # the values column as the SECOND term's operand
+            terms.reverse()
+    if seed % 11 == 7 and n > 5000:  # one dense stretch: a few chunks overflow their slots, the rest are sparse
+        v2 = v.copy()
+        v2[2048:2048 + 3000] = (thr - 1) if not np.issubdtype(npdt, np.unsignedinteger) else 0
+        vals2 = HostArray(dt, v2, vals.valid)
+        terms = [(op, vals2 if l is vals else l, ls, r, rs) for op, l, ls, r, rs in terms]
+        vals = vals2
+    return vals, terms, joins
+
+
+@pytest.mark.parametrize("seed", range(52))
+def test_filter_expr_boundary_sizes_fuzz(ctx, oracle, seed):
+    """ah_filter_expr where the filtered column is an operand of the expression: against the oracle's materialised chain —
+    every size class around the chunk (1024) / tile (4096) / count-group (65 536) boundaries and the small-batch limit,
+    8- and 4-byte types, with and without nulls, scalar and array right sides, the column as first or second term, a dense
+    stretch inside a sparse selection, nothing / everything selected.  (Written for a variant of the count pass that
+    stashed the selected values — profiles/r03_single_pass_lookback.md — and kept for the shapes.)"""
+    rng = np.random.default_rng(9900 + seed)
+    vals, terms, joins = _boundary_case(rng, seed)
+    mask = _oracle_mask(oracle, terms, joins)
+    exp = oracle.filter(vals, mask)
+    dvals = vals.to_device(ctx)
+    dterms = []
+    for op, l, ls, r, rs in terms:
+        dl = dvals if l is vals else l.to_device(ctx)
+        dr = r.to_device(ctx)
+        dterms.append((op, dl, A.Scalar(dr) if rs else dr))
+    got = K.filter_expr(dvals, dterms, joins)
+    g = HostArray.from_device(got)
+    assert_logical_eq(g, exp, f"seed {seed} n {len(vals)} {vals.data_type} {[t_[0] for t_ in terms]} {joins}")
+    assert_same_nulls_presence(g, exp, f"seed {seed}")
+    assert got.null_count() == exp.null_count
+
+
 def test_shrink_to_fit_after_a_small_batch_filter(ctx, oracle):
     """the one-launch filter allocates for the worst case; ah_array_shrink_to_fit copies into an exact-size buffer"""
     import ctypes as C
