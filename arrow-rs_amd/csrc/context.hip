@@ -3,6 +3,7 @@
 // Rust's global allocator + `MutableBuffer` (arrow-buffer/src/buffer/mutable.rs)
 // and `BooleanBuffer::count_set_bits` (arrow-buffer/src/buffer/boolean.rs).
 #include "common.hpp"
+#include <sched.h>
 
 #include <ctime>
 
@@ -219,6 +220,7 @@ hipError_t ah_mail_wait(ah_context* ctx, uint64_t seq) {
           return __atomic_load_n(flag, __ATOMIC_ACQUIRE) >= seq ? hipSuccess : hipErrorUnknown;
         }
         if (q != hipErrorNotReady) return q;
+        sched_yield();  // a kernel of tens of milliseconds: let threads queued on this context's host side run
         if (us > 500000.0) {  // half a second of spinning: sleep in the runtime instead
           hipError_t e = hipStreamSynchronize(ctx->stream);
           if (e == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) < seq) e = hipErrorUnknown;

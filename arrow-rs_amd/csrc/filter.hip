@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(1024) filter_group_scan_multi_kernel(CountMult
 __global__ void __launch_bounds__(1024) filter_group_scan_kernel(const uint32_t* group_total,
                                                                  int64_t ngroups,
                                                                  unsigned long long* group_prefix,
-                                                                 unsigned long long* total_out, uint64_t* mail,
+                                                                 unsigned long long* total_out, uint64_t* mail, int slot,
                                                                  uint64_t seq) {
   __shared__ unsigned long long s_wave[16];
   __shared__ unsigned long long s_carry;
@@ -259,9 +259,10 @@ __global__ void __launch_bounds__(1024) filter_group_scan_kernel(const uint32_t*
   }
   if (t == 0) {
     *total_out = s_carry;
-    if (mail) {  // K goes straight to the host's pinned slot: the only number the host waits for
-      __hip_atomic_store(mail, (uint64_t)s_carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (seq) ah_mail_post(mail, seq);  // seq == 0: one of several counts, a later kernel posts for all of them
+    if (mail) {  // K goes straight to the host's pinned slot `slot`: the only number the host waits for
+      __hip_atomic_store(mail + slot, (uint64_t)s_carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (seq) ah_mail_post(mail, seq);  // on the mailbox BASE (the sequence word is mail[AH_MAIL_FLAG]); seq == 0: one of
+                                         // several counts, a later kernel posts for all of them
     }
   }
 }
@@ -681,7 +682,7 @@ bool use_skip(int64_t count, int64_t len) {
 // K2 for filter_expr.hip's own count pass
 void ah_filter_launch_group_scan(ah_context* ctx, const uint32_t* group_total, int64_t ngroups, unsigned long long* group_prefix,
                                  unsigned long long* total, int slot, uint64_t seq) {
-  filter_group_scan_kernel<<<1, 1024, 0, ctx->stream>>>(group_total, ngroups, group_prefix, total, ctx->pinned_dev + slot, seq);
+  filter_group_scan_kernel<<<1, 1024, 0, ctx->stream>>>(group_total, ngroups, group_prefix, total, ctx->pinned_dev, slot, seq);
 }
 
 // The count pass of a predicate, enqueued only: K lands in pinned slot `slot` (and, with seq != 0, the mailbox is
@@ -736,7 +737,7 @@ static ah_status predicate_enqueue(ah_context* ctx, const ah_array_view* predica
                                                                       p->chunk_prefix, group_total);
     }
     filter_group_scan_kernel<<<1, 1024, 0, ctx->stream>>>(group_total, ngroups, p->group_prefix,
-                                                          total, ctx->pinned_dev + slot, seq);
+                                                          total, ctx->pinned_dev, slot, seq);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -19,6 +19,10 @@
 
 #include <type_traits>
 
+#ifndef AH_SFR_CAP
+#define AH_SFR_CAP 1024  // selected rows staged per round of the ranges kernel: 18 KiB of LDS, 7 workgroups per CU (2048: 36 KiB, 4 per CU, 0.343 ms against 0.309 per 2^27 rows)
+#endif
+
 namespace {
 
 // ---- filter_bytes (filter.rs:790-928) as three launches: ranges -> tile-byte scan -> gather
@@ -27,7 +31,7 @@ namespace {
 //    over offsets[0..n) and offsets[1..n+1), then a three-kernel scan over the K selected rows).  A tile is 4096 rows;
 //    every thread owns 16 consecutive rows = a quarter of one predicate word and loads its 17 offsets with 16-byte loads.
 //    A block scan over (selected rows, selected bytes) per thread gives every selected row its rank in the tile and its
-//    byte offset INSIDE the tile's output; (start, local offset) pairs are compacted through a 32 KiB LDS stage and leave
+//    byte offset INSIDE the tile's output; (start, local offset) pairs are compacted through a 16 KiB LDS stage (1024 rows per round) and leave
 //    as coalesced stores at the tile's first output row (known from the predicate's prefix tables).  The tile's byte
 //    total goes to tile_bytes[tile].
 // F2 string_tile_scan_kernel: exclusive scan of the <= n / 4096 tile totals (one workgroup) -> tile_base, grand total
@@ -45,7 +49,7 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
                                                                    OFF* starts, OFF* loffs, unsigned long long* tile_bytes,
                                                                    BitView vvalid, unsigned long long* out_valid,
                                                                    unsigned long long* valid_count) {
-  constexpr int T = 4096, NW = 64, R = 16, CAP = 2048;
+  constexpr int T = 4096, NW = 64, R = 16, CAP = AH_SFR_CAP;
   __shared__ uint64_t s_m[NW];
   __shared__ uint64_t s_v[HAS_VALID ? NW : 1];
   __shared__ uint32_t s_base[NW];
