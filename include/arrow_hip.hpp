@@ -9,6 +9,9 @@
 //   arrow_hip::compute::filter            arrow-select/src/filter.rs:201
 //   arrow_hip::compute::filter_record_batch                        :225
 //   arrow_hip::compute::FilterBuilder / FilterPredicate            :248-533
+//   arrow_hip::compute::Term / filter_expr / FilterBuilder::from_terms
+//                                         the lazy form of filter(v, and_kleene(lt(..), gt_eq(..))): cmp.rs:113-164,
+//                                         arrow-arith/src/boolean.rs:60-300, filter.rs:201 (ah_filter_expr)
 //   arrow_hip::compute::take / TakeOptions arrow-select/src/take.rs:89, :388
 //   arrow_hip::compute::{add,add_wrapping,sub,...,rem,neg,neg_wrapping}
 //                                         arrow-arith/src/numeric.rs:36-186
@@ -95,6 +98,8 @@ class Context {
   ah_context* h_ = nullptr;
 };
 
+inline int device_count() { return (int)ah_device_count(); }  // GPUs visible to this process (hipGetDeviceCount)
+
 // An array whose buffers live in HBM (PrimitiveArray<T> / BooleanArray / StringArray).
 // Owns an ah_array_out, or borrows a caller-described view.
 class Array {
@@ -136,6 +141,15 @@ class Array {
   const ah_array_view& view() const { return view_; }
   const void* offsets() const { return out_.offsets; }
   const std::shared_ptr<Context>& context() const { return ctx_; }
+  // Buffer::shrink_to_fit (arrow-buffer/src/buffer/immutable.rs:215): results of small-batch filters are allocated for the
+  // worst case (K is not known at allocation time); copies them into exact-size buffers.  Owned fixed-width results only.
+  void shrink_to_fit() {
+    if (!owned_) return;
+    ctx_->check(ah_array_shrink_to_fit(ctx_->handle(), &out_));
+    view_.values = out_.values;
+    view_.validity = out_.validity;
+  }
+  int64_t values_capacity_bytes() const { return out_.values_bytes; }
   // copy `bytes` of the values buffer to the host (debug / tests)
   void values_to_host(void* dst, size_t bytes) const {
     ctx_->check(ah_memcpy_dtoh(ctx_->handle(), dst, view_.values, bytes));
@@ -201,12 +215,56 @@ class FilterPredicate {  // filter.rs:442-533
   ah_filter_predicate* p_;
 };
 
+// One comparison of a filter expression: `op(lhs, rhs)` with Datum operands (cmp.rs:79-202).
+struct Term {
+  ah_cmp_op op;
+  Datum lhs, rhs;
+};
+namespace detail {
+// the C form of an expression; the views point into the Arrays the terms hold
+struct TermArrays {
+  std::vector<ah_filter_term> terms;
+  std::vector<int32_t> joins;
+  std::vector<ArrayRef> keep;
+  std::shared_ptr<Context> ctx;
+  TermArrays(const std::vector<Term>& ts, const std::vector<ah_boolean_op>& js) {
+    if (ts.empty()) throw ArrowError(AH_INVALID_ARGUMENT, "a filter expression needs at least one term");
+    if (js.size() + 1 != ts.size()) throw ArrowError(AH_INVALID_ARGUMENT, "a filter expression of n terms takes n - 1 joins");
+    ctx = ts[0].lhs.array->context();
+    for (auto& t : ts) {
+      ah_filter_term c{};
+      c.op = (int32_t)t.op;
+      c.lhs = &t.lhs.array->view(), c.lhs_is_scalar = t.lhs.is_scalar ? 1 : 0;
+      c.rhs = &t.rhs.array->view(), c.rhs_is_scalar = t.rhs.is_scalar ? 1 : 0;
+      terms.push_back(c);
+      keep.push_back(t.lhs.array);
+      keep.push_back(t.rhs.array);
+    }
+    for (auto j : js) joins.push_back((int32_t)j);
+  }
+};
+}  // namespace detail
+
 class FilterBuilder {  // filter.rs:248-324
  public:
   explicit FilterBuilder(ArrayRef predicate) : predicate_(std::move(predicate)) {}
+  // The lazy predicate: what `FilterBuilder::new(&and_kleene(&lt(a, x)?, &gt_eq(b, y)?)?)` selects, with the comparisons
+  // evaluated inside the filter's count pass instead of being materialised (ah_filter_predicate_build_expr).  Terms are
+  // folded left to right by `joins` (AH_BOOL_AND / _OR / _AND_KLEENE / _OR_KLEENE).
+  static FilterBuilder from_terms(std::vector<Term> terms, std::vector<ah_boolean_op> joins) {
+    FilterBuilder b{ArrayRef()};
+    b.terms_ = std::move(terms);
+    b.joins_ = std::move(joins);
+    return b;
+  }
   FilterBuilder& optimize() { return *this; }  // device predicates always carry prefix tables
   std::unique_ptr<FilterPredicate> build() {
     ah_filter_predicate* p = nullptr;
+    if (!predicate_) {
+      detail::TermArrays t(terms_, joins_);
+      t.ctx->check(ah_filter_predicate_build_expr(t.ctx->handle(), (int32_t)t.terms.size(), t.terms.data(), t.joins.data(), &p));
+      return std::make_unique<FilterPredicate>(terms_[0].lhs.array, p);  // (the predicate owns its selection words)
+    }
     predicate_->context()->check(
         ah_filter_predicate_build(predicate_->context()->handle(), &predicate_->view(), &p));
     return std::make_unique<FilterPredicate>(predicate_, p);
@@ -214,10 +272,31 @@ class FilterBuilder {  // filter.rs:248-324
 
  private:
   ArrayRef predicate_;
+  std::vector<Term> terms_;
+  std::vector<ah_boolean_op> joins_;
 };
 
+// `filter(values, <terms folded by joins>)` in one call (ah_filter_expr)
+inline ArrayRef filter_expr(const ArrayRef& values, const std::vector<Term>& terms, const std::vector<ah_boolean_op>& joins) {
+  detail::TermArrays t(terms, joins);
+  ah_array_out out;
+  t.ctx->check(ah_filter_expr(t.ctx->handle(), (int32_t)t.terms.size(), t.terms.data(), t.joins.data(), &values->view(), &out));
+  return wrap(values, out, {values});
+}
+
+// filter_record_batch (filter.rs:225): ONE count pass and ONE scatter launch per group of same-shaped columns
+// (ah_filter_record_batch); batches of at most 2^20 rows take the one-launch path
 inline RecordBatch filter_record_batch(const RecordBatch& rb, const ArrayRef& predicate) {
-  return FilterBuilder(predicate).optimize().build()->filter_record_batch(rb);
+  auto& ctx = predicate->context();
+  std::vector<ah_array_view> views;
+  for (auto& c : rb.columns) views.push_back(c->view());
+  std::vector<ah_array_out> outs(views.size());
+  int64_t rows = 0;
+  ctx->check(ah_filter_record_batch(ctx->handle(), (int32_t)views.size(), views.data(), &predicate->view(), outs.data(), &rows));
+  RecordBatch o;
+  o.num_rows = rows;
+  for (size_t i = 0; i < outs.size(); ++i) o.columns.push_back(wrap(rb.columns[i], outs[i], {rb.columns[i]}));
+  return o;
 }
 
 // ---- take (arrow-select/src/take.rs)
@@ -502,7 +581,7 @@ inline int64_t find_nth_set_bit(const ArrayRef& mask, int64_t start, int64_t n) 
 }  // namespace selection
 
 // BatchCoalescer (arrow-select/src/coalesce.rs:148): exact-size output batches from a stream of (filtered) input
-// batches.  The state machine is the native ah_coalescer object; fixed-width columns.
+// batches.  The state machine is the native ah_coalescer object; primitive, Boolean and Utf8 / LargeUtf8 columns.
 class BatchCoalescer {
  public:
   BatchCoalescer(std::shared_ptr<Context> ctx, const std::vector<ah_type>& types, int64_t target_batch_size)
@@ -518,7 +597,31 @@ class BatchCoalescer {
   }
   void push_batch(const RecordBatch& b) { push(b, nullptr); }                                       // :296
   void push_batch_with_filter(const RecordBatch& b, const ArrayRef& filter) { push(b, &filter); }   // :229
-  void finish_buffered_batch() { ctx_->check(ah_coalescer_finish_buffered_batch(ctx_->handle(), h_)); }  // :536
+  // take_record_batch(batch, indices) into the in-progress batch (:289)
+  void push_batch_with_indices(const RecordBatch& b, const ArrayRef& indices) {
+    std::vector<ah_array_view> views;
+    for (auto& c : b.columns) views.push_back(c->view());
+    ctx_->check(ah_coalescer_push_batch_with_indices(ctx_->handle(), h_, views.data(), b.num_rows, &indices->view()));
+  }
+  // several filtered pushes handed over together: the same output as one push_batch_with_filter each, but ONE count
+  // read-back for the group and the batches of one output window scattered by one launch (for hosts with batches queued)
+  void push_batches_with_filters(const std::vector<std::pair<RecordBatch, ArrayRef>>& batches) {
+    std::vector<ah_array_view> views, filters;
+    std::vector<int64_t> rows;
+    std::vector<uint64_t> tags;
+    for (auto& bf : batches) {
+      for (auto& c : bf.first.columns) views.push_back(c->view());
+      filters.push_back(bf.second->view());
+      rows.push_back(bf.first.num_rows);
+      tags.push_back(next_tag_++);
+    }
+    std::vector<int32_t> bypass(batches.size(), 0);
+    ctx_->check(ah_coalescer_push_batches_with_filters(ctx_->handle(), h_, (int32_t)batches.size(), views.data(), rows.data(),
+                                                       filters.data(), tags.data(), bypass.data()));
+    for (size_t i = 0; i < batches.size(); ++i)
+      if (bypass[i]) bypassed_.emplace(tags[i], batches[i].first);
+  }
+  void finish_buffered_batch() { ctx_->check(ah_coalescer_finish_buffered_batch(ctx_->handle(), h_)); }  // :547; does not wait
   bool has_completed_batch() const { return ah_coalescer_completed_count(h_) > 0; }
   int64_t get_buffered_rows() const { return ah_coalescer_buffered_rows(h_); }
   bool is_empty() const { return get_buffered_rows() == 0 && !has_completed_batch(); }
@@ -590,7 +693,48 @@ class Communicator {
     b.num_rows = b.columns.empty() ? 0 : b.columns[0]->len();
     return b;
   }
+  // The same exchange split in two: `begin` enqueues the count exchange, the sends / receives and the merges and returns;
+  // independent work (a take on another context, the next filter) runs meanwhile; `end()` waits and hands the batch over.
+  // The shard's buffers must stay alive until end() (the handle holds them).
+  class Pending {
+   public:
+    Pending(Communicator* c, ah_exchange* x, RecordBatch shard) : c_(c), x_(x), shard_(std::move(shard)) {}
+    Pending(Pending&& o) noexcept : c_(o.c_), x_(o.x_), shard_(std::move(o.shard_)) { o.x_ = nullptr; }
+    Pending(const Pending&) = delete;
+    ~Pending() {  // abandoned: finish it anyway (peers are in the collective) and drop the result
+      if (!x_) return;
+      std::vector<ah_array_out> outs(shard_.columns.size());
+      if (ah_all_gather_columns_end(c_->ctx_->handle(), c_->h_, x_, outs.data(), nullptr) == AH_OK)
+        for (auto& o : outs) ah_array_release(c_->ctx_->handle(), &o);
+    }
+    RecordBatch end(ah_exchange_stats* stats = nullptr) {
+      std::vector<ah_array_out> outs(shard_.columns.size());
+      ah_exchange* x = x_;
+      x_ = nullptr;
+      c_->ctx_->check(ah_all_gather_columns_end(c_->ctx_->handle(), c_->h_, x, outs.data(), stats));
+      RecordBatch b;
+      for (auto& o : outs) b.columns.push_back(std::make_shared<Array>(c_->ctx_, o));
+      b.num_rows = b.columns.empty() ? 0 : b.columns[0]->len();
+      return b;
+    }
+
+   private:
+    Communicator* c_;
+    ah_exchange* x_;
+    RecordBatch shard_;
+  };
+  Pending all_gather_record_batch_begin(const RecordBatch& shard) {
+    std::vector<ah_array_view> views;
+    for (auto& c : shard.columns) views.push_back(c->view());
+    ah_exchange* x = nullptr;
+    ctx_->check(ah_all_gather_columns_begin(ctx_->handle(), h_, (int32_t)views.size(), views.data(), &x));
+    return Pending(this, x, shard);
+  }
   void barrier() { ctx_->check(ah_comm_barrier(ctx_->handle(), h_)); }
+  // element-wise MAX over ranks (the bench's "slowest rank" clock), in place
+  void allreduce_max(std::vector<double>& values) {
+    ctx_->check(ah_comm_allreduce_max_f64(ctx_->handle(), h_, values.data(), (int32_t)values.size()));
+  }
 
  private:
   std::shared_ptr<Context> ctx_;

@@ -169,6 +169,69 @@ int main() {
     auto g = comm.all_gatherv(c);
     assert(g->len() == 2 && (download<int32_t>(g) == std::vector<int32_t>{5, 8}));
     comm.barrier();
+    // begin / end: the batch comes back from end(); work enqueued in between (a take) is independent of it
+    std::vector<bool> sv{true, false, true};
+    RecordBatch shard{{upload<int64_t>(ctx, AH_INT64, {7, 8, 9}, &sv, keep), upload<double>(ctx, AH_FLOAT64, {0.5, 1.5, 2.5}, nullptr, keep)}, 3};
+    auto pending = comm.all_gather_record_batch_begin(shard);
+    auto side = compute::take(v8, idx);
+    auto gathered = pending.end();
+    assert(gathered.num_rows == 3 && gathered.columns[0]->null_count() == 1 && !gathered.columns[1]->has_nulls_buffer());
+    assert((download<double>(gathered.columns[1]) == std::vector<double>{0.5, 1.5, 2.5}) && side->len() == 5);
+    { auto dropped = comm.all_gather_record_batch_begin(shard); }  // an abandoned handle completes in its destructor
+    std::vector<double> mx{3.0, -1.0};
+    comm.allreduce_max(mx);
+    assert(mx[0] == 3.0 && mx[1] == -1.0 && device_count() >= 1);
+  }
+  // the lazy predicate: WHERE a < 3 AND b >= 0.0 as terms == the materialised chain (cmp.rs:113,164; boolean.rs:60; filter.rs:201)
+  {
+    std::vector<bool> av{true, true, false, true, true, true};
+    std::vector<bool> bv{true, false, true, true, true, true};
+    auto ea = upload<int64_t>(ctx, AH_INT64, {1, 2, 0, 5, -4, 2}, &av, keep);
+    auto eb = upload<double>(ctx, AH_FLOAT64, {0.0, 9.0, 1.0, 2.0, -0.0, -1.0}, &bv, keep);
+    auto three = upload<int64_t>(ctx, AH_INT64, {3}, nullptr, keep);
+    auto zero = upload<double>(ctx, AH_FLOAT64, {0.0}, nullptr, keep);
+    std::vector<compute::Term> terms{{AH_LT, ea, Scalar(three)}, {AH_GT_EQ, eb, Scalar(zero)}};
+    auto lazy = compute::filter_expr(ea, terms, {AH_BOOL_AND_KLEENE});
+    auto mask = compute::and_kleene(compute::lt(ea, Scalar(three)), compute::gt_eq(eb, Scalar(zero)));
+    auto chain = compute::filter(ea, mask);
+    // row 0: 1 < 3, 0.0 >= 0.0 -> kept; row 1: b null -> null & true = null -> dropped; row 2: a null; row 3: 5 < 3 false;
+    // row 4: -4 < 3, -0.0 >= 0.0 is FALSE under totalOrder (-0.0 < 0.0, arithmetic.rs:400-410) -> dropped; row 5: -1.0 -> dropped
+    assert(lazy->len() == 1 && chain->len() == 1 && download<int64_t>(lazy)[0] == 1 && download<int64_t>(chain)[0] == 1);
+    auto pred = compute::FilterBuilder::from_terms(terms, {AH_BOOL_AND_KLEENE}).optimize().build();
+    assert(pred->count() == 1 && (download<double>(pred->filter(eb)) == std::vector<double>{0.0}));
+    bool bad = false;
+    try {
+      compute::filter_expr(ea, {{AH_LT, ea, Scalar(zero)}}, {});
+    } catch (const ArrowError& e) {
+      bad = std::string(e.what()) == "Invalid argument error: Invalid comparison operation: Int64 < Float64";
+    }
+    assert(bad);
+  }
+  // filter_record_batch through ONE fused call; a small-batch result is allocated for the worst case until shrunk
+  {
+    std::vector<int64_t> big(4096);
+    std::vector<bool> keepm(4096);
+    for (int i = 0; i < 4096; ++i) big[i] = i, keepm[i] = i % 64 == 3;
+    RecordBatch rb{{upload<int64_t>(ctx, AH_INT64, big, nullptr, keep), upload<int64_t>(ctx, AH_INT64, big, nullptr, keep)}, 4096};
+    auto fb = compute::filter_record_batch(rb, upload_bool(ctx, keepm, keep));
+    assert(fb.num_rows == 64 && fb.columns.size() == 2 && download<int64_t>(fb.columns[1])[1] == 67);
+    // (below 1 MiB of slack shrink_to_fit leaves the buffers alone: still the same values afterwards)
+    fb.columns[0]->shrink_to_fit();
+    assert(download<int64_t>(fb.columns[0])[63] == 63 * 64 + 3);
+  }
+  // BatchCoalescer: push_batch_with_indices (coalesce.rs:289) and the grouped filtered push
+  {
+    BatchCoalescer ci(ctx, {AH_INT32}, 5);
+    RecordBatch src{{upload<int32_t>(ctx, AH_INT32, {10, 11, 12, 13}, nullptr, keep)}, 4};
+    ci.push_batch_with_indices(src, upload<uint32_t>(ctx, AH_UINT32, {3, 3, 0}, nullptr, keep));
+    auto f1 = upload_bool(ctx, {true, false, false, true}, keep);
+    auto f2 = upload_bool(ctx, {false, true, true, false}, keep);
+    ci.push_batches_with_filters({{src, f1}, {src, f2}});
+    auto done = ci.next_completed_batch();
+    assert(done && (download<int32_t>(done->columns[0]) == std::vector<int32_t>{13, 13, 10, 10, 13}));
+    ci.finish_buffered_batch();
+    done = ci.next_completed_batch();
+    assert(done && (download<int32_t>(done->columns[0]) == std::vector<int32_t>{11, 12}) && ci.is_empty());
   }
   std::puts("CPP_HOST_MIRROR_OK");
   // C Data Interface round trip (arrow-array/src/ffi.rs:231-254): host producer -> HBM -> filter -> host
