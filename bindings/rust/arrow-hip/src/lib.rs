@@ -243,6 +243,53 @@ impl Drop for FilterPredicate {
     }
 }
 
+/// One comparison of a filter expression: `op(lhs, rhs)` (`sys::AH_EQ` .. `sys::AH_GT_EQ`; cmp.rs:79-202).
+pub struct Term<'a> {
+    pub op: i32,
+    pub lhs: Datum<'a>,
+    pub rhs: Datum<'a>,
+}
+
+fn with_terms<R>(terms: &[Term], joins: &[i32],
+                 f: impl FnOnce(&Arc<Context>, i32, *const sys::ah_filter_term, *const i32) -> Result<R, ArrowError>) -> Result<R, ArrowError> {
+    if terms.is_empty() || joins.len() + 1 != terms.len() {
+        return Err(ArrowError::InvalidArgumentError("a filter expression of n terms takes n - 1 joins".into()));
+    }
+    // the views must outlive the call: collect them first, then point the C terms at them
+    let views: Vec<(sys::ah_array_view, i32, sys::ah_array_view, i32)> = terms.iter().map(|t| {
+        let ((l, ls), (r, rs)) = (t.lhs.get(), t.rhs.get());
+        (l.view(), ls, r.view(), rs)
+    }).collect();
+    let raw: Vec<sys::ah_filter_term> = terms.iter().zip(&views).map(|(t, v)| sys::ah_filter_term {
+        op: t.op, lhs: &v.0, lhs_is_scalar: v.1, rhs: &v.2, rhs_is_scalar: v.3,
+    }).collect();
+    let ctx = &terms[0].lhs.get().0.ctx;
+    f(ctx, raw.len() as i32, raw.as_ptr(), joins.as_ptr())
+}
+
+/// `filter(values, &and_kleene(&lt(a, x)?, &gt_eq(b, y)?)?)` with nothing materialised (cmp.rs:113-164,
+/// arrow-arith/src/boolean.rs:60-300, filter.rs:201): the comparisons run inside the filter's count pass.
+/// `joins` are `sys::AH_BOOL_AND` / `_OR` / `_AND_KLEENE` / `_OR_KLEENE`, folded left to right.
+pub fn filter_expr(values: &Arc<DeviceArray>, terms: &[Term], joins: &[i32]) -> Result<Arc<DeviceArray>, ArrowError> {
+    with_terms(terms, joins, |ctx, n, t, j| {
+        let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
+        let v = values.view();
+        ctx.check(unsafe { sys::ah_filter_expr(ctx.raw, n, t, j, &v, out.as_mut_ptr()) })?;
+        Ok(wrap(values, unsafe { out.assume_init() }, values.data_type.clone(), &[values]))
+    })
+}
+
+impl FilterPredicate {
+    /// the lazy form of `FilterBuilder::new(&<expression>)`: an ordinary predicate (count / filter) built from terms
+    pub fn from_terms(terms: &[Term], joins: &[i32]) -> Result<Self, ArrowError> {
+        with_terms(terms, joins, |ctx, n, t, j| {
+            let mut raw = ptr::null_mut();
+            ctx.check(unsafe { sys::ah_filter_predicate_build_expr(ctx.raw, n, t, j, &mut raw) })?;
+            Ok(Self { ctx: ctx.clone(), raw, _mask: terms[0].lhs.get().0.clone() })  // (the predicate owns its selection words)
+        })
+    }
+}
+
 /// `TakeOptions { check_bounds }` (take.rs:388)
 #[derive(Default, Clone, Copy)]
 pub struct TakeOptions {
@@ -523,7 +570,15 @@ impl BatchCoalescer {
         self.push(columns, Some(filter))
     }
 
-    /// `finish_buffered_batch` (coalesce.rs:536)
+    /// `push_batch_with_indices` (coalesce.rs:289): `take_record_batch(batch, indices)` into the in-progress batch
+    pub fn push_batch_with_indices(&mut self, columns: &[Arc<DeviceArray>], indices: &Arc<DeviceArray>) -> Result<(), ArrowError> {
+        let views: Vec<sys::ah_array_view> = columns.iter().map(|c| c.view()).collect();
+        let rows = columns.first().map_or(0, |c| c.len()) as i64;
+        let iv = indices.view();
+        self.ctx.check(unsafe { sys::ah_coalescer_push_batch_with_indices(self.ctx.raw, self.raw, views.as_ptr(), rows, &iv) })
+    }
+
+    /// `finish_buffered_batch` (coalesce.rs:547); does not wait: null counts are looked at when the batch is fetched
     pub fn finish_buffered_batch(&mut self) -> Result<(), ArrowError> {
         self.ctx.check(unsafe { sys::ah_coalescer_finish_buffered_batch(self.ctx.raw, self.raw) })
     }
