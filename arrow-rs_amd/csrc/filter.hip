@@ -535,12 +535,14 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
     if (p0 + CAP < hi_t) __syncthreads();  // LDS is reused by the next chunk
   }
   if constexpr (HAS_VALID) {
-    if (lane == 0) s_vc[wave] = (uint32_t)vc;
-    __syncthreads();
-    if (t == 0) {
-      uint32_t c = s_vc[0] + s_vc[1] + s_vc[2] + s_vc[3];
-      if (a.nulls_mode) c = (uint32_t)(hi_t - lo_t) - c;  // NULL rows this tile appended
-      if (c) atomicAdd(&c_valid_slots[tile & (VALID_SLOTS - 1)], (unsigned long long)c);
+    if (c_valid_slots) {  // (null: a plain result's valid rows are counted from its output bitmap afterwards)
+      if (lane == 0) s_vc[wave] = (uint32_t)vc;
+      __syncthreads();
+      if (t == 0) {
+        uint32_t c = s_vc[0] + s_vc[1] + s_vc[2] + s_vc[3];
+        if (a.nulls_mode) c = (uint32_t)(hi_t - lo_t) - c;  // NULL rows this tile appended
+        if (c) atomicAdd(&c_valid_slots[tile & (VALID_SLOTS - 1)], (unsigned long long)c);
+      }
     }
   }
 }
@@ -574,6 +576,148 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
   const int64_t tile = scatter_tile_of_block(a.xcd_remap, a.ntiles);
   if (tile < 0) return;
   scatter_tile<W, V, HAS_VALID, SKIP>(a, tile, c_values, c_vvalid, c_out_values, c_out_valid, c_valid_slots);
+}
+
+// ---- sparse selections (at most two selected rows per predicate word on average: K * 32 <= len).  The tiled kernel above
+// is then bound by its own per-tile latency chain, not by bytes: 244 K tiles of a 1e9-row column, each a workgroup that
+// loads its words, synchronises, loads a handful of values, synchronises, stores — five workgroups per CU, 0.45-0.75 ms
+// at 0.1 % selected where the bytes (the two bitmaps + ~1e6 lines) are worth ~0.1 ms.  Here a tile belongs to ONE WAVE
+// (lane l = predicate word l, no LDS, no barrier): the wave scans its 64 popcounts, every lane walks the set bits of its
+// own word — up to four value loads in flight — and stores each selected value straight to its output row; validity
+// bits are merged with atomicOr (one per valid selected row: few by construction).  32 tiles in flight per CU
+// instead of 5.  Same results, window / destination-offset / NULL-counting modes included.
+template <int W, bool HAS_VALID>
+__global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_sparse_kernel(ScatterArgs a) {
+  using ET = typename Elem<W>::type;
+  constexpr int T = 4096;
+  const void* c_values = a.values;
+  BitView c_vvalid = a.vvalid;
+  void* c_out_values = a.out_values;
+  unsigned long long* c_out_valid = a.out_valid;
+  unsigned long long* c_valid_slots = a.valid_slots;
+  if (blockIdx.y) {
+    const ScatterArgs::Col& c = a.more[blockIdx.y - 1];
+    c_values = c.values;
+    c_vvalid = c.vvalid;
+    c_out_values = c.out_values;
+    c_out_valid = c.out_valid;
+    c_valid_slots = c.valid_slots;
+  }
+  const int lane = threadIdx.x & 63, wave = ah_uniform((int)(threadIdx.x >> 6));
+  const int64_t nwg = (a.ntiles + 3) >> 2;
+  const int64_t wg = scatter_tile_of_block(a.xcd_remap, nwg);
+  if (wg < 0) return;
+  const int64_t tile = wg * 4 + wave;
+  if (tile >= a.ntiles) return;
+  const int64_t row0 = tile * T, s = row0 + ((int64_t)lane << 6);
+  uint64_t m = 0, v = 0;
+  if (s < a.len) {  // the three bitmaps' words are requested together (one round trip), as in scatter_tile
+    const bool has_mv = a.mask_valid.words != nullptr;
+    const bool has_vv = HAS_VALID && c_vvalid.words != nullptr;
+    const BvRaw rm = bv_issue(a.mask, s, a.len);
+    const BvRaw rmv = bv_issue(has_mv ? a.mask_valid : a.mask, s, a.len);
+    const BvRaw rvv = bv_issue(has_vv ? c_vvalid : a.mask, s, a.len);
+    m = bv_finish(rm, s, a.len);
+    const uint64_t mv = bv_finish(rmv, s, a.len), vv = bv_finish(rvv, s, a.len);
+    if (has_mv) m &= mv;
+    if constexpr (HAS_VALID) v = has_vv ? vv : ~0ull;
+  }
+  const int c = __popcll(m);
+  const int incl = wave_scan_incl(c);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  if (total == 0) return;
+  const int64_t chunk0 = row0 / CHUNK_ROWS;
+  int64_t pos = (int64_t)a.group_prefix[chunk0 >> a.group_shift] + a.chunk_prefix[chunk0] + (incl - c);  // in the filtered stream
+  const ET* vp = (const ET*)c_values + s;
+  ET* op = (ET*)c_out_values;
+  int cnt = 0;  // valid rows written (nulls_mode: NULL rows written)
+  // validity: the wave's rows occupy consecutive output positions, i.e. at most 65 output words; their bits are
+  // collected in LDS (ds_or, wave-private: no barrier) and leave as ONE global atomicOr per word (one per ROW cost
+  // 0.64 ms per 10^6 rows: the output bitmap of a sparse selection is a few hundred cache lines, every atomic lands there)
+  __shared__ unsigned long long s_w[HAS_VALID ? SCATTER_THREADS / 64 : 1][HAS_VALID ? 66 : 1];
+  const int64_t first = (int64_t)a.group_prefix[chunk0 >> a.group_shift] + a.chunk_prefix[chunk0];  // == pos of lane 0's first row
+  int64_t lo = first, hi = first + total;  // this wave's positions, clipped to the launch's window
+  if (a.win_hi != 0) {
+    lo = lo < a.win_lo ? a.win_lo : lo;
+    hi = hi > a.win_hi ? a.win_hi : hi;
+  }
+  if (lo >= hi) return;
+  const int64_t wb = (a.out_base + lo - a.win_lo) >> 6;                       // first output word this wave touches
+  const int nw = (int)(((a.out_base + hi - 1 - a.win_lo) >> 6) - wb) + 1;   // <= 65
+  if constexpr (HAS_VALID) {
+    s_w[wave][lane] = 0;
+    if (lane < 2) s_w[wave][64 + lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+  }
+  while (m) {  // up to four rows per round: their loads go out together
+    int b[4], nb = 0;
+    ET x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      b[k] = 0;
+      if (m) {
+        b[k] = __builtin_ctzll(m);
+        m &= m - 1;
+        nb = k + 1;
+        x[k] = vp[b[k]];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < nb) {
+        const int64_t p = pos + k;
+        if (p >= lo && p < hi) {
+          const int64_t dst = a.out_base + p - a.win_lo;
+          op[dst] = x[k];
+          if constexpr (HAS_VALID) {
+            const int vb = (int)((v >> b[k]) & 1ull);
+            if (vb) atomicOr(&s_w[wave][(int)((dst >> 6) - wb)], 1ull << (dst & 63));
+            cnt += a.nulls_mode ? 1 - vb : vb;
+          }
+        }
+      }
+    }
+    pos += nb;
+  }
+  if constexpr (HAS_VALID) {
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < nw; j += 64) {
+      const unsigned long long w = s_w[wave][j];
+      if (w) atomicOr(&c_out_valid[wb + j], w);
+    }
+    if (c_valid_slots) {  // (null: the caller counts the output bitmap afterwards — scatter_valid_count_kernel)
+      const int sum = (int)wave_reduce_add64((unsigned long long)cnt);
+      if (lane == 0 && sum) atomicAdd(&c_valid_slots[tile & (VALID_SLOTS - 1)], (unsigned long long)sum);
+    }
+  }
+}
+
+// Valid rows of a sparse result, counted from its (small) output bitmap: one atomic per BLOCK into the column's 64
+// counters.  A per-tile atomic inside the scatter — 244 K of them on 64 addresses for a 1e9-row column — serialises at
+// ~150 ns per same-address atomic across the XCDs: 0.55 ms, which a 1.3 ms dense scatter hides and a 0.1 ms sparse
+// one does not.
+__global__ void __launch_bounds__(256) scatter_valid_count_kernel(ScatterArgs a, int64_t out_rows) {
+  const unsigned long long* bits = a.out_valid;
+  unsigned long long* slots = a.valid_slots;
+  if (blockIdx.y) {
+    bits = a.more[blockIdx.y - 1].out_valid;
+    slots = a.more[blockIdx.y - 1].valid_slots;
+  }
+  const int64_t nwords = (out_rows + 63) >> 6;
+  unsigned long long acc = 0;
+  for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * 256) {
+    unsigned long long x = bits[w];
+    if (w == nwords - 1 && (out_rows & 63)) x &= (1ull << (out_rows & 63)) - 1ull;
+    acc += (unsigned long long)__popcll(x);
+  }
+  acc = wave_reduce_add64(acc);
+  __shared__ unsigned long long s_acc[4];
+  if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = s_acc[0] + s_acc[1] + s_acc[2] + s_acc[3];
+    if (t) atomicAdd(&slots[blockIdx.x & (VALID_SLOTS - 1)], t);
+  }
 }
 
 // ---- several input batches, one launch (BatchCoalescer::push_batches_with_filters): the tiles of up to 8 batches form
@@ -630,7 +774,8 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_multi_kernel(M
 }
 
 template <int W, bool HV>
-void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, bool skip, int ncols = 1) {
+void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, bool skip, int ncols = 1, bool sparse = false,
+                      int64_t out_rows = 0) {
   constexpr int WE = W == 0 ? 1 : W;
   constexpr int T = tile_rows(WE);
   int64_t ntiles = ah_ceil_div(a_in.len, T);
@@ -638,33 +783,71 @@ void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, 
   a.ntiles = ntiles;
   static const char* xr = getenv("AH_FILTER_XCD");
   a.xcd_remap = (xr && xr[0] == '0') ? 0 : 1;
+  // Plain results (whole filtered stream, destination row 0, VALID-row counting, K known): the valid rows are counted
+  // from the output bitmap AFTER the scatter (scatter_valid_count_kernel: K / 8 bytes, one atomic per block) instead of one
+  // atomic per tile on the column's 64 counters — 244 K same-address atomics per 1e9 rows serialise across the XCDs at
+  // ~150 ns each (0.55 ms), which shows as soon as the scatter itself is faster than that (3 % selected: 1.02 -> 0.72 ms).
+  // (up to ~12 % selected; a denser scatter runs long enough to hide its counter atomics, and counting a 125 MB bitmap
+  // afterwards would only add to it)
+  const bool count_after = HV && out_rows > 0 && out_rows * 8 <= a_in.len && !a.nulls_mode && a.out_base == 0 && a.win_hi == 0;
+  auto launch_count = [&]() {
+    const int64_t nwords = (out_rows + 63) >> 6;
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, ah_ceil_div(nwords, 256 * 4)));
+    scatter_valid_count_kernel<<<dim3(gx, (unsigned)ncols), 256, 0, ctx->stream>>>(a, out_rows);
+  };
+  ScatterArgs b = a;  // the scatter's copy: no counters when they are filled afterwards
+  if (count_after) {
+    b.valid_slots = nullptr;
+    for (int c = 1; c < ncols; ++c) b.more[c - 1].valid_slots = nullptr;
+  }
+  if constexpr (W != 0) {
+    // the sparse form serves plain results; the windowed / NULL-counting launches of the coalescer keep the tiled kernel
+    if (sparse && (!HV || count_after)) {
+      b.ntiles = ah_ceil_div(a_in.len, 4096);  // one 4096-row tile per wave, four per workgroup
+      const int64_t nwg = (b.ntiles + 3) >> 2;
+      dim3 g((unsigned)(a.xcd_remap ? 8 * ((nwg + 7) / 8) : nwg), (unsigned)ncols);
+      filter_scatter_sparse_kernel<W, HV><<<g, SCATTER_THREADS, 0, ctx->stream>>>(b);
+      if (count_after) launch_count();
+      return;
+    }
+  }
   dim3 grid((unsigned)(a.xcd_remap ? 8 * ((ntiles + 7) / 8) : ntiles), (unsigned)ncols), block(SCATTER_THREADS);
   constexpr int VV = (W == 0) ? 16 : (W >= 16 ? 1 : 16 / W);
   if constexpr (W == 0) {
-    filter_scatter_kernel<W, VV, HV, false><<<grid, block, 0, ctx->stream>>>(a);
+    filter_scatter_kernel<W, VV, HV, false><<<grid, block, 0, ctx->stream>>>(b);
   } else if (aligned16 || VV == 1) {
-    if (skip) filter_scatter_kernel<W, VV, HV, true><<<grid, block, 0, ctx->stream>>>(a);
-    else filter_scatter_kernel<W, VV, HV, false><<<grid, block, 0, ctx->stream>>>(a);
+    if (skip) filter_scatter_kernel<W, VV, HV, true><<<grid, block, 0, ctx->stream>>>(b);
+    else filter_scatter_kernel<W, VV, HV, false><<<grid, block, 0, ctx->stream>>>(b);
   } else {
-    filter_scatter_kernel<W, 1, HV, false><<<grid, block, 0, ctx->stream>>>(a);
+    filter_scatter_kernel<W, 1, HV, false><<<grid, block, 0, ctx->stream>>>(b);
   }
+  if (count_after) launch_count();
 }
 
 template <bool HV>
-ah_status launch_scatter(ah_context* ctx, int width, const ScatterArgs& a, bool skip, int ncols = 1) {
+ah_status launch_scatter(ah_context* ctx, int width, const ScatterArgs& a, bool skip, int ncols = 1, bool sparse = false,
+                         int64_t out_rows = 0) {
   bool aligned16 = (((uintptr_t)a.values) & 15) == 0;
   for (int c = 1; c < ncols; ++c) aligned16 = aligned16 && (((uintptr_t)a.more[c - 1].values) & 15) == 0;
   switch (width) {
     case 0: launch_scatter_w<0, HV>(ctx, a, true, false, ncols); break;
-    case 1: launch_scatter_w<1, HV>(ctx, a, aligned16, skip, ncols); break;
-    case 2: launch_scatter_w<2, HV>(ctx, a, aligned16, skip, ncols); break;
-    case 4: launch_scatter_w<4, HV>(ctx, a, aligned16, skip, ncols); break;
-    case 8: launch_scatter_w<8, HV>(ctx, a, aligned16, skip, ncols); break;
-    case 16: launch_scatter_w<16, HV>(ctx, a, aligned16, skip, ncols); break;
-    case 32: launch_scatter_w<32, HV>(ctx, a, aligned16, skip, ncols); break;
+    case 1: launch_scatter_w<1, HV>(ctx, a, aligned16, skip, ncols, sparse, out_rows); break;
+    case 2: launch_scatter_w<2, HV>(ctx, a, aligned16, skip, ncols, sparse, out_rows); break;
+    case 4: launch_scatter_w<4, HV>(ctx, a, aligned16, skip, ncols, sparse, out_rows); break;
+    case 8: launch_scatter_w<8, HV>(ctx, a, aligned16, skip, ncols, sparse, out_rows); break;
+    case 16: launch_scatter_w<16, HV>(ctx, a, aligned16, skip, ncols, sparse, out_rows); break;
+    case 32: launch_scatter_w<32, HV>(ctx, a, aligned16, skip, ncols, sparse, out_rows); break;
     default: return ah_fail(ctx, AH_INVALID_ARGUMENT, "unsupported value width %d", width);
   }
   return AH_OK;
+}
+
+// at most two selected rows per predicate word on average: the wave-per-tile kernel (AH_FILTER_SPARSE=0 / 1 force)
+bool use_sparse(int64_t count, int64_t len) {
+  const char* env = getenv("AH_FILTER_SPARSE");  // read per call: tests and the A/B flip it
+  if (env && env[0] == '0') return false;
+  if (env && env[0] == '1') return true;
+  return count * 32 <= len;  // crossover measured between 3 % and 10 % selected (profiles/r03_selectivity_sweep.md)
 }
 
 // load predication pays when most 128-byte lines hold no selected row; tunable for experiments
@@ -1054,8 +1237,8 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
   const bool skip = use_skip(K, p->len);
   {
     ah_prof_scope ps(ctx, "filter_scatter");
-    if (has_valid) launch_scatter<true>(ctx, width, a, skip);
-    else launch_scatter<false>(ctx, width, a, skip);
+    if (has_valid) launch_scatter<true>(ctx, width, a, skip, 1, use_sparse(K, p->len), K);
+    else launch_scatter<false>(ctx, width, a, skip, 1, use_sparse(K, p->len), K);
   }
   // ONE host wait for the whole scatter: the finish kernel folds the valid-row counters, restores them to
   // zero and posts the mailbox (no D2H copy engine, no hipStreamSynchronize)
@@ -1136,8 +1319,8 @@ static ah_status apply_into_impl(ah_context* ctx, const ah_filter_predicate* p, 
   const bool skip = use_skip(K, p->len);
   {
     ah_prof_scope ps(ctx, "filter_scatter");
-    if (has_valid) launch_scatter<true>(ctx, width, a, skip);
-    else launch_scatter<false>(ctx, width, a, skip);
+    if (has_valid) launch_scatter<true>(ctx, width, a, skip, 1, use_sparse(K, p->len), K);
+    else launch_scatter<false>(ctx, width, a, skip, 1, use_sparse(K, p->len), K);
   }
   hipError_t e = hipGetLastError();
   ah_status st = AH_OK;
@@ -1217,7 +1400,7 @@ ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predica
   {
     ah_prof_scope ps(ctx, "filter_scatter");
     const bool skip = speculative ? use_skip((int64_t)(selectivity_hint * (double)p->len), p->len) : use_skip(p->count, p->len);
-    launch_scatter<true>(ctx, width, a, skip, ncols);
+    launch_scatter<true>(ctx, width, a, skip, ncols);  // (windowed, NULL-counting: the tiled kernel)
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "fused filter copy failed: %s", hipGetErrorString(e));
@@ -1413,8 +1596,8 @@ static ah_status filter_columns_fused(ah_context* ctx, const ah_filter_predicate
     }
     {
       ah_prof_scope ps(ctx, "filter_scatter");
-      if (has_valid) st = launch_scatter<true>(ctx, width, a, use_skip(K, p->len), ncols);
-      else st = launch_scatter<false>(ctx, width, a, use_skip(K, p->len), ncols);
+      if (has_valid) st = launch_scatter<true>(ctx, width, a, use_skip(K, p->len), ncols, use_sparse(K, p->len), K);
+      else st = launch_scatter<false>(ctx, width, a, use_skip(K, p->len), ncols, use_sparse(K, p->len), K);
     }
     e = hipGetLastError();
     if (st == AH_OK && e == hipSuccess) {

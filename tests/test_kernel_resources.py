@@ -95,6 +95,9 @@ def test_round3_kernels_keep_their_occupancy(kernels):
     # the one-launch filter of small batches, Int64 with validity: a latency-bound kernel (<= 256 tiles); 4 waves per SIMD
     for r in _find(kernels, "filter_small_kernelILi8ELi2ELb1E"):
         assert r["vgpr"] <= 128 and r["lds"] <= 32768, r
+    # the wave-per-tile scatter for sparse selections lives on occupancy: 8 waves per SIMD, no scratch, <= 3 KiB of LDS
+    for r in _find(kernels, "filter_scatter_sparse_kernelILi8ELb1E"):
+        assert r["vgpr"] <= 64 and r["lds"] <= 3072 and r["scratch"] == 0, r
     # string filter ranges: a 16 KiB stage (1024 selected rows per round) -> 7 workgroups per CU (registers)
     for r in _find(kernels, "string_filter_ranges_kernelIlLb1E"):
         assert r["lds"] <= 20480 and r["vgpr"] <= 72, r
