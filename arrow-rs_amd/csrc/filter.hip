@@ -587,28 +587,11 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
 // bits are merged with atomicOr (one per valid selected row: few by construction).  32 tiles in flight per CU
 // instead of 5.  Same results, window / destination-offset / NULL-counting modes included.
 template <int W, bool HAS_VALID>
-__global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_sparse_kernel(ScatterArgs a) {
+__device__ __forceinline__ void sparse_tile(const ScatterArgs& a, int64_t tile, int lane, int wave, const void* c_values,
+                                            BitView c_vvalid, void* c_out_values, unsigned long long* c_out_valid,
+                                            unsigned long long* c_valid_slots) {
   using ET = typename Elem<W>::type;
   constexpr int T = 4096;
-  const void* c_values = a.values;
-  BitView c_vvalid = a.vvalid;
-  void* c_out_values = a.out_values;
-  unsigned long long* c_out_valid = a.out_valid;
-  unsigned long long* c_valid_slots = a.valid_slots;
-  if (blockIdx.y) {
-    const ScatterArgs::Col& c = a.more[blockIdx.y - 1];
-    c_values = c.values;
-    c_vvalid = c.vvalid;
-    c_out_values = c.out_values;
-    c_out_valid = c.out_valid;
-    c_valid_slots = c.valid_slots;
-  }
-  const int lane = threadIdx.x & 63, wave = ah_uniform((int)(threadIdx.x >> 6));
-  const int64_t nwg = (a.ntiles + 3) >> 2;
-  const int64_t wg = scatter_tile_of_block(a.xcd_remap, nwg);
-  if (wg < 0) return;
-  const int64_t tile = wg * 4 + wave;
-  if (tile >= a.ntiles) return;
   const int64_t row0 = tile * T, s = row0 + ((int64_t)lane << 6);
   uint64_t m = 0, v = 0;
   if (s < a.len) {  // the three bitmaps' words are requested together (one round trip), as in scatter_tile
@@ -692,6 +675,30 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_sparse_kernel(
   }
 }
 
+template <int W, bool HAS_VALID>
+__global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_sparse_kernel(ScatterArgs a) {
+  const void* c_values = a.values;
+  BitView c_vvalid = a.vvalid;
+  void* c_out_values = a.out_values;
+  unsigned long long* c_out_valid = a.out_valid;
+  unsigned long long* c_valid_slots = a.valid_slots;
+  if (blockIdx.y) {
+    const ScatterArgs::Col& c = a.more[blockIdx.y - 1];
+    c_values = c.values;
+    c_vvalid = c.vvalid;
+    c_out_values = c.out_values;
+    c_out_valid = c.out_valid;
+    c_valid_slots = c.valid_slots;
+  }
+  const int lane = threadIdx.x & 63, wave = ah_uniform((int)(threadIdx.x >> 6));
+  const int64_t nwg = (a.ntiles + 3) >> 2;
+  const int64_t wg = scatter_tile_of_block(a.xcd_remap, nwg);
+  if (wg < 0) return;
+  const int64_t tile = wg * 4 + wave;
+  if (tile >= a.ntiles) return;
+  sparse_tile<W, HAS_VALID>(a, tile, lane, wave, c_values, c_vvalid, c_out_values, c_out_valid, c_valid_slots);
+}
+
 // Valid rows of a sparse result, counted from its (small) output bitmap: one atomic per BLOCK into the column's 64
 // counters.  A per-tile atomic inside the scatter — 244 K of them on 64 addresses for a 1e9-row column — serialises at
 // ~150 ns per same-address atomic across the XCDs: 0.55 ms, which a 1.3 ms dense scatter hides and a 0.1 ms sparse
@@ -771,6 +778,65 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_multi_kernel(M
   const MultiSeg::Src& src = sg.col[blockIdx.y];
   const MultiArgs::Dst& d = m.dst[blockIdx.y];
   scatter_tile<W, V, true, SKIP>(a, gtile - sg.tile0, src.values, src.vvalid, d.out_values, d.out_valid, d.null_slots);
+}
+
+// the multi-batch launch for sparse selections: the tile space of all segments, one 4096-row tile per wave (W <= 8: the
+// tiled kernels' tile is 4096 rows too, so MultiSeg::tile0 means the same), no counters: the caller counts afterwards
+template <int W>
+__global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_multi_sparse_kernel(MultiArgs m) {
+  static_assert(tile_rows(W) == 4096, "tile0 is counted in 4096-row tiles");
+  const int lane = threadIdx.x & 63, wave = ah_uniform((int)(threadIdx.x >> 6));
+  const int64_t nwg = (m.ntiles + 3) >> 2;
+  const int64_t wg = scatter_tile_of_block(m.xcd_remap, nwg);
+  if (wg < 0) return;
+  const int64_t gtile = wg * 4 + wave;
+  if (gtile >= m.ntiles) return;
+  int sidx = 0;
+#pragma unroll
+  for (int i = 1; i < MULTI_MAX_SEGS; ++i)
+    if (i < m.nsegs && gtile >= m.seg[i].tile0) sidx = i;
+  const MultiSeg& sg = m.seg[sidx];
+  ScatterArgs a{};
+  a.mask = sg.mask;
+  a.mask_valid = sg.mask_valid;
+  a.len = sg.len;
+  a.chunk_prefix = sg.chunk_prefix;
+  a.group_prefix = sg.group_prefix;
+  a.group_shift = sg.group_shift;
+  a.out_base = sg.out_base;
+  a.win_lo = sg.win_lo;
+  a.win_hi = sg.win_hi;
+  a.nulls_mode = 1;
+  const MultiSeg::Src& src = sg.col[blockIdx.y];
+  const MultiArgs::Dst& d = m.dst[blockIdx.y];
+  sparse_tile<W, true>(a, gtile - sg.tile0, lane, wave, src.values, src.vvalid, d.out_values, d.out_valid, nullptr);
+}
+
+// NULL rows among destination rows [bit_lo, bit_lo + nbits) of up to 8 columns (blockIdx.y), added to each column's
+// counters: what the sparse multi-batch launch appended, counted from the in-progress bitmaps afterwards
+struct RangeCount {
+  const unsigned long long* bits[SCATTER_MAX_COLS];
+  unsigned long long* slots[SCATTER_MAX_COLS];
+  int64_t bit_lo, nbits;
+};
+__global__ void __launch_bounds__(256) range_null_count_kernel(RangeCount r) {
+  const unsigned long long* bits = r.bits[blockIdx.y];
+  const int64_t w0 = r.bit_lo >> 6, w1 = (r.bit_lo + r.nbits - 1) >> 6;
+  unsigned long long nulls = 0;
+  for (int64_t w = w0 + (int64_t)blockIdx.x * 256 + threadIdx.x; w <= w1; w += (int64_t)gridDim.x * 256) {
+    unsigned long long in = ~0ull;  // the bits of word w inside the range
+    if (w == w0) in &= ~0ull << (r.bit_lo & 63);
+    if (w == w1 && ((r.bit_lo + r.nbits) & 63)) in &= (1ull << ((r.bit_lo + r.nbits) & 63)) - 1ull;
+    nulls += (unsigned long long)__popcll(in & ~bits[w]);
+  }
+  nulls = wave_reduce_add64(nulls);
+  __shared__ unsigned long long s_acc[4];
+  if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = nulls;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = s_acc[0] + s_acc[1] + s_acc[2] + s_acc[3];
+    if (t) atomicAdd(&r.slots[blockIdx.y][blockIdx.x & (VALID_SLOTS - 1)], t);
+  }
 }
 
 template <int W, bool HV>
@@ -1350,6 +1416,29 @@ static ah_status apply_into_impl(ah_context* ctx, const ah_filter_predicate* p, 
   return AH_OK;
 }
 
+// The coalescer's scatters for sparse selections (W <= 8): m.ntiles counted in 4096-row tiles; the launch appends
+// `appended` rows at destination row `dest0` of every column; their NULL rows are counted behind it into m.dst[c].null_slots.
+static ah_status launch_multi_sparse(ah_context* ctx, const MultiArgs& m, int width, int ncols, int64_t dest0, int64_t appended) {
+  const int64_t nwg = (m.ntiles + 3) >> 2;
+  const dim3 grid((unsigned)(m.xcd_remap ? 8 * ((nwg + 7) / 8) : nwg), (unsigned)ncols);
+  switch (width) {
+    case 1: filter_scatter_multi_sparse_kernel<1><<<grid, SCATTER_THREADS, 0, ctx->stream>>>(m); break;
+    case 2: filter_scatter_multi_sparse_kernel<2><<<grid, SCATTER_THREADS, 0, ctx->stream>>>(m); break;
+    case 4: filter_scatter_multi_sparse_kernel<4><<<grid, SCATTER_THREADS, 0, ctx->stream>>>(m); break;
+    case 8: filter_scatter_multi_sparse_kernel<8><<<grid, SCATTER_THREADS, 0, ctx->stream>>>(m); break;
+    default: return ah_fail(ctx, AH_INVALID_ARGUMENT, "unsupported value width %d", width);
+  }
+  if (appended > 0) {
+    RangeCount r{};
+    for (int c = 0; c < ncols; ++c) r.bits[c] = m.dst[c].out_valid, r.slots[c] = m.dst[c].null_slots;
+    r.bit_lo = dest0, r.nbits = appended;
+    const int64_t nwords = ((dest0 + appended - 1) >> 6) - (dest0 >> 6) + 1;
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, ah_ceil_div(nwords, 256 * 4)));
+    range_null_count_kernel<<<dim3(gx, (unsigned)ncols), 256, 0, ctx->stream>>>(r);
+  }
+  return AH_OK;
+}
+
 // Several columns of one batch through ONE scatter launch (BatchCoalescer's filtered push): the columns must share
 // the value width and all carry validity; returns AH_NOT_YET_IMPLEMENTED (nothing enqueued) when they do not, and the
 // caller goes column by column.  Only positions [win_lo, win_hi) of the filtered batch are appended (at
@@ -1372,6 +1461,33 @@ ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predica
   if (!speculative && win_hi > p->count) win_hi = p->count;
   const int64_t K = win_hi - win_lo;  // rows this launch appends (at most, when speculative): positions [win_lo, win_hi)
   if (p->len == 0 || K <= 0) return AH_OK;
+  if (!speculative && width <= 8 && use_sparse(p->count, p->len)) {  // a sparse selection: a tile per wave, NULLs counted after
+    MultiArgs m{};
+    m.nsegs = 1;
+    static const char* xr = getenv("AH_FILTER_XCD");
+    m.xcd_remap = (xr && xr[0] == '0') ? 0 : 1;
+    MultiSeg& sg = m.seg[0];
+    sg.mask = p->mask, sg.mask_valid = p->mask_valid, sg.len = p->len;
+    sg.chunk_prefix = p->chunk_prefix, sg.group_prefix = p->group_prefix, sg.group_shift = p->group_shift;
+    sg.out_base = dst_row_offset, sg.win_lo = win_lo, sg.win_hi = win_hi, sg.tile0 = 0;
+    m.ntiles = ah_ceil_div(p->len, 4096);
+    for (int c = 0; c < ncols; ++c) {
+      sg.col[c].values = values[c].values;
+      sg.col[c].vvalid = make_bitview(values[c].validity, values[c].validity_bit_offset);
+      m.dst[c].out_values = dst_values[c];
+      m.dst[c].out_valid = (unsigned long long*)dst_validity[c];
+      m.dst[c].null_slots = null_slots + (size_t)c * 64;
+    }
+    ctx->inflight = true;
+    ah_status st;
+    {
+      ah_prof_scope ps(ctx, "filter_scatter");
+      st = launch_multi_sparse(ctx, m, width, ncols, dst_row_offset, K);
+    }
+    const hipError_t e = hipGetLastError();
+    if (st == AH_OK && e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "fused filter copy failed: %s", hipGetErrorString(e));
+    return st;
+  }
   ScatterArgs a{};
   a.mask = p->mask;
   a.mask_valid = p->mask_valid;
@@ -1453,6 +1569,22 @@ ah_status ah_filter_apply_multi(ah_context* ctx, int nsegs, const ah_filter_pred
   }
   if (tiles == 0) return AH_OK;
   ctx->inflight = true;
+  if (width <= 8 && use_sparse(selected, rows)) {  // (tile_rows(width <= 8) == 4096: `tiles` / tile0 already are in wave tiles)
+    // rows this launch appends: consecutive destination rows from the first segment's out_base on
+    int64_t appended = 0;
+    for (int i = 0; i < nsegs; ++i) {
+      const int64_t hi = (win_hi[i] != 0 && win_hi[i] < preds[i]->count) ? win_hi[i] : preds[i]->count;
+      if (hi > win_lo[i]) appended += hi - win_lo[i];
+    }
+    ah_status st;
+    {
+      ah_prof_scope ps(ctx, "filter_scatter");
+      st = launch_multi_sparse(ctx, m, width, ncols, out_base[0], appended);
+    }
+    const hipError_t e = hipGetLastError();
+    if (st == AH_OK && e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "fused filter copy failed: %s", hipGetErrorString(e));
+    return st;
+  }
   const bool skip = use_skip(selected, rows);
   const dim3 grid((unsigned)(m.xcd_remap ? 8 * ((tiles + 7) / 8) : tiles), (unsigned)ncols), block(SCATTER_THREADS);
   {

@@ -88,7 +88,8 @@ def test_sparse_scatter_record_batch_and_coalescer(ctx, oracle, seed):
     rng = np.random.default_rng(9800 + seed)
     n = [1_200_003, 2_000_000][seed % 2]
     dts = [A.Int64, A.Float64, A.Int64, A.Int32][:2 + seed % 3]
-    cols = [_values(rng, dt, n, [0.9, None, 0.5][i % 3]) for i, dt in enumerate(dts)]
+    pv = [0.9, None, 0.5] if seed % 2 else [0.9, 0.7, 0.5]  # (all-nullable batches take the coalescer's fused launches)
+    cols = [_values(rng, dt, n, pv[i % 3]) for i, dt in enumerate(dts)]
     mask = HostArray(A.Boolean, rng.random(n) < [0.002, 0.01, 0.0005][seed % 3], (rng.random(n) < 0.97) if seed % 2 else None)
     rb = A.RecordBatch([f"c{i}" for i in range(len(cols))], [c.to_device(ctx) for c in cols], n)
     dm = mask.to_device(ctx)
@@ -103,22 +104,28 @@ def test_sparse_scatter_record_batch_and_coalescer(ctx, oracle, seed):
             # coalescer: target smaller than K so that pushes straddle output batches (windows), two pushes
             k = len(exps[0])
             target = max(1, k // 3 + 1)
-            co = K.BatchCoalescer.new([f"c{i}" for i in range(len(cols))], dts, target, ctx)
-            co.push_batch_with_filter(rb, dm)
-            co.push_batch_with_filter(rb, dm)
-            co.finish_buffered_batch()
-            got = [[] for _ in cols]
-            while co.has_completed_batch():
-                b = co.next_completed_batch()
-                for i in range(len(cols)):
-                    got[i].append(HostArray.from_device(b.columns[i]))
-            for i, e in enumerate(exps):
-                vals = np.concatenate([g.values for g in got[i]])
-                valid = np.concatenate([g.valid if g.valid is not None else np.ones(len(g), dtype=bool) for g in got[i]])
-                e_valid = e.valid if e.valid is not None else np.ones(len(e), dtype=bool)
-                assert len(vals) == 2 * k
-                assert np.array_equal(valid, np.concatenate([e_valid, e_valid])), f"coalescer validity sparse={force} column {i}"
-                ev = np.concatenate([e.values, e.values])
-                assert np.array_equal(vals[valid], ev[valid]), f"coalescer values sparse={force} column {i}"
-                for g in got[i]:  # null-buffer presence per output batch == has nulls (coalesce/primitive.rs finish)
-                    assert (g.valid is None) == (g.null_count == 0)
+            names = [f"c{i}" for i in range(len(cols))]
+            for grouped in (False, True):  # single pushes (ah_filter_apply_into_acc_cols) / one grouped push (ah_filter_apply_multi)
+                co = K.BatchCoalescer.new(names, dts, target, ctx)
+                if grouped:
+                    co.push_batches_with_filters([(rb, dm), (rb, dm)])
+                else:
+                    co.push_batch_with_filter(rb, dm)
+                    co.push_batch_with_filter(rb, dm)
+                co.finish_buffered_batch()
+                got = [[] for _ in cols]
+                while co.has_completed_batch():
+                    b = co.next_completed_batch()
+                    for i in range(len(cols)):
+                        got[i].append(HostArray.from_device(b.columns[i]))
+                label = f"coalescer sparse={force} grouped={grouped}"
+                for i, e in enumerate(exps):
+                    vals = np.concatenate([g.values for g in got[i]])
+                    valid = np.concatenate([g.valid if g.valid is not None else np.ones(len(g), dtype=bool) for g in got[i]])
+                    e_valid = e.valid if e.valid is not None else np.ones(len(e), dtype=bool)
+                    assert len(vals) == 2 * k, label
+                    assert np.array_equal(valid, np.concatenate([e_valid, e_valid])), f"{label} validity column {i}"
+                    ev = np.concatenate([e.values, e.values])
+                    assert np.array_equal(vals[valid], ev[valid]), f"{label} values column {i}"
+                    for g in got[i]:  # null-buffer presence per output batch == has nulls (coalesce/primitive.rs finish)
+                        assert (g.valid is None) == (g.null_count == 0), f"{label} null buffer presence column {i}"
