@@ -210,7 +210,9 @@ AH_API ah_status ah_filter(ah_context* ctx, const ah_array_view* values,
 /* Predicates of at most 2^20 rows over fixed-width columns (ah_filter and ah_filter_record_batch alike) take a
  * one-launch path: count, prefix and scatter in a single kernel, every column of a record batch in that launch, one host
  * wait for K and all null counts (query-engine batch sizes are latency, not bandwidth: arrow/benches/filter_kernels.rs:
- * 39-45 runs 512 .. 65 536 rows).  Same results as the general two-pass path; environment AH_FILTER_SMALL=0 disables it. */
+ * 39-45 runs 512 .. 65 536 rows).  Same results as the general two-pass path; environment AH_FILTER_SMALL=0 disables it.
+ * Larger predicates that select at most 1 row in 32 (the reference bench's "kept 1/1024" shapes) scatter through a
+ * tile-per-wave kernel instead of the LDS-staged one (AH_FILTER_SPARSE=0 / 1 forces either); again the same results. */
 
 /* FilterBuilder::new(..).optimize().build() (filter.rs:256-324): count once,
  * keep per-tile offsets on device, apply to many columns.  The handle BORROWS the
