@@ -1043,6 +1043,26 @@ def main():
                 extra["roofline_take_sorted"] = roofline_obj("take_gather (sorted indices = positions of the predicate)", tb,
                                                              ms / max(cnt, 1), cnt)
         del sorted_idx, null_idx
+        # the selectivity axis of the reference's own bench (arrow/benches/filter_kernels.rs: kept 1/1024 ... 1023/1024):
+        # the same column through filter at other densities, scatter kernel time per call.  Sparse selections take the
+        # tile-per-wave kernel; the full sweep is profiles/r03_selectivity_sweep.md
+        if args.rows == 1_000_000_000 and not args.no_configs:
+            by_sel = {}
+            for i, sel in enumerate((0.001, 0.01, 0.5)):
+                try:
+                    pr = gen_predicate(A, ctx, n, 61 + i, sel, row0=0 if world == 1 else rank * n)
+                    K.filter(col, pr)
+                    ctx.profile(True)
+                    ctx.profile_reset()
+                    for _ in range(3):
+                        f = K.filter(col, pr)
+                    ms, cnt = ctx.profile_get("filter_scatter")
+                    ctx.profile(False)
+                    by_sel[str(sel)] = {"filter_scatter_ms": round(ms / max(cnt, 1), 4), "selected_rows": f.length}
+                    del pr, f
+                except Exception as ex:  # noqa: BLE001 - a side measurement never costs the headline
+                    by_sel[str(sel)] = {"error": repr(ex)[:200]}
+            extra["filter_by_selectivity"] = by_sel
 
     # ranks the transport really initialised (ah_comm_world / the process group), never the --gpus argument
     n_ranks = (int(getattr(env.comm, "world", world)) if env.comm is not None else 1) if use_dist else 1

@@ -68,6 +68,8 @@ if d:
         out.append(f"take with sorted indices (positions of the predicate): {d['roofline_take_sorted']}\n")
     if d.get("crossover_rows"):
         out.append(f"crossover_rows: {d['crossover_rows']}\n")
+    if d.get("filter_by_selectivity"):
+        out.append(f"filter_scatter at other selectivities of the same column (the sparse path below 3 %): {d['filter_by_selectivity']}\n")
     out.append(f"take variants: sorted indices {d.get('take_sorted_indices_ms')} ms, 10 % null indices {d.get('take_null_indices_ms')} ms.\n")
     cb = d.get("cpu_baseline", {})
     out.append(f"cpu_baseline (oracle = scalar port of the reference, same box): {cb.get('value')} Mrows/s on 1 core; all cores: "
