@@ -170,6 +170,102 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
   }
 }
 
+// F1 for sparse selections (K * 32 <= len; the reference bench's "filter context string low selectivity (kept 1/1024)"):
+// the tiled kernel above reads ALL offsets — 1 GB per 2^27 rows, 0.31 ms at any selectivity — and is a per-tile chain of
+// four barriers.  Here a 4096-row tile belongs to ONE WAVE (lane l = predicate word l), only the offsets of selected rows
+// are loaded, the (start, local offset) pairs go straight to their output rows, validity bits are collected in a
+// wave-private LDS strip and leave as one atomicOr per output word; valid rows are counted from the output bitmap
+// afterwards (bitmap_count_to_slots_kernel) — per-tile counter atomics serialise across the XCDs.
+template <typename OFF, bool HAS_VALID>
+__global__ void __launch_bounds__(256) string_filter_ranges_sparse_kernel(const OFF* offsets, BitView mask, BitView mask_valid, int64_t len,
+                                                                          const uint32_t* chunk_prefix,
+                                                                          const unsigned long long* group_prefix, int group_shift,
+                                                                          OFF* starts, OFF* loffs, unsigned long long* tile_bytes,
+                                                                          BitView vvalid, unsigned long long* out_valid,
+                                                                          int64_t ntiles) {
+  __shared__ unsigned long long s_w[HAS_VALID ? 4 : 1][HAS_VALID ? 66 : 1];
+  const int lane = threadIdx.x & 63, wave = ah_uniform((int)(threadIdx.x >> 6));
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  if (tile >= ntiles) return;
+  const int64_t row0 = tile * 4096, s = row0 + ((int64_t)lane << 6);
+  uint64_t m = 0, v = 0;
+  if (s < len) {
+    m = bv_fetch64(mask, s, len);
+    if (mask_valid.words) m &= bv_fetch64(mask_valid, s, len);
+    if constexpr (HAS_VALID) v = bv_fetch64(vvalid, s, len);
+  }
+  const int c = __popcll(m);
+  const int incl = wave_scan_incl(c);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  if (total == 0) {
+    if (lane == 0) tile_bytes[tile] = 0;
+    return;
+  }
+  const OFF* op = offsets + s;
+  unsigned long long mine = 0;  // bytes of this lane's selected rows
+  for (uint64_t mm = m; mm; mm &= mm - 1) {
+    const int b = __builtin_ctzll(mm);
+    mine += (unsigned long long)(op[b + 1] - op[b]);
+  }
+  unsigned long long bincl = mine;
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    const unsigned long long u = __shfl_up(bincl, k, 64);
+    if (lane >= k) bincl += u;
+  }
+  const unsigned long long tbytes = __shfl(bincl, 63, 64);
+  if (lane == 0) tile_bytes[tile] = tbytes;
+  const int64_t chunk0 = row0 / AH_FILTER_CHUNK_ROWS;
+  const int64_t P = (int64_t)group_prefix[chunk0 >> group_shift] + chunk_prefix[chunk0];  // the tile's first output row
+  const int64_t wb = P >> 6;
+  if constexpr (HAS_VALID) {
+    s_w[wave][lane] = 0;
+    if (lane < 2) s_w[wave][64 + lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+  }
+  int64_t pos = P + (incl - c);
+  unsigned long long bo = bincl - mine;  // byte offset of this lane's first selected row inside the tile's output
+  for (uint64_t mm = m; mm; mm &= mm - 1) {
+    const int b = __builtin_ctzll(mm);
+    const OFF o0 = op[b], o1 = op[b + 1];
+    starts[pos] = o0;
+    loffs[pos] = (OFF)bo;
+    bo += (unsigned long long)(o1 - o0);
+    if constexpr (HAS_VALID) {
+      if ((v >> b) & 1ull) atomicOr(&s_w[wave][(int)((pos >> 6) - wb)], 1ull << (pos & 63));
+    }
+    ++pos;
+  }
+  if constexpr (HAS_VALID) {
+    __builtin_amdgcn_wave_barrier();
+    const int nw = (int)(((P + total - 1) >> 6) - wb) + 1;  // <= 65
+    for (int j = lane; j < nw; j += 64) {
+      const unsigned long long w = s_w[wave][j];
+      if (w) atomicOr(&out_valid[wb + j], w);
+    }
+  }
+}
+
+// set bits among the first `nbits` bits of `bits`, added block by block to slots[0..64)
+__global__ void __launch_bounds__(256) bitmap_count_to_slots_kernel(const unsigned long long* bits, int64_t nbits,
+                                                                    unsigned long long* slots) {
+  const int64_t nwords = (nbits + 63) >> 6;
+  unsigned long long acc = 0;
+  for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * 256) {
+    unsigned long long x = bits[w];
+    if (w == nwords - 1 && (nbits & 63)) x &= (1ull << (nbits & 63)) - 1ull;
+    acc += (unsigned long long)__popcll(x);
+  }
+  acc = wave_reduce_add64(acc);
+  __shared__ unsigned long long s_acc[4];
+  if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = s_acc[0] + s_acc[1] + s_acc[2] + s_acc[3];
+    if (t) atomicAdd(&slots[blockIdx.x & 63], t);
+  }
+}
+
 // exclusive scan of the tile byte totals (one workgroup: every thread owns a contiguous run of ceil(n / 1024) tiles, one
 // block scan over the run totals — the first version walked 1024 tiles per step, 53 us for 32 Ki tiles); *total_out = grand total
 __global__ void __launch_bounds__(1024) string_tile_scan_kernel(const unsigned long long* tile_bytes, int64_t ntiles,
@@ -556,7 +652,27 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
   unsigned long long* vslots = total + 2;
   if (hv) hipMemsetAsync(vslots, 0, 64 * 8, ctx->stream);
   const bool vec = (((uintptr_t)offsets) & 15) == 0;
-  {
+  bool sparse = K * 32 <= len;  // as for the primitive scatter (filter.hip: use_sparse); AH_FILTER_SPARSE=0 / 1 forces
+  if (const char* env = getenv("AH_FILTER_SPARSE")) {
+    if (env[0] == '0') sparse = false;
+    if (env[0] == '1') sparse = true;
+  }
+  if (sparse) {
+    ah_prof_scope ps(ctx, "string_filter_ranges");
+    const unsigned grid = (unsigned)ah_ceil_div(ntiles, 4);
+    if (hv) {
+      string_filter_ranges_sparse_kernel<OFF, true><<<grid, 256, 0, ctx->stream>>>(offsets, p->mask, p->mask_valid, len, p->chunk_prefix,
+                                                                                  p->group_prefix, p->group_shift, starts, loffs,
+                                                                                  tile_bytes, vvalid, (unsigned long long*)nb, ntiles);
+      const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, ah_ceil_div((K + 63) >> 6, 256 * 4)));
+      bitmap_count_to_slots_kernel<<<gx, 256, 0, ctx->stream>>>((const unsigned long long*)nb, K, vslots);
+    } else {
+      string_filter_ranges_sparse_kernel<OFF, false><<<grid, 256, 0, ctx->stream>>>(offsets, p->mask, p->mask_valid, len, p->chunk_prefix,
+                                                                                   p->group_prefix, p->group_shift, starts, loffs,
+                                                                                   tile_bytes, vvalid, nullptr, ntiles);
+    }
+    string_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(tile_bytes, ntiles, tile_base, total, hv ? vslots : nullptr);
+  } else {
     ah_prof_scope ps(ctx, "string_filter_ranges");
 #define AH_SFR(VEC, HV)                                                                                                          \
   string_filter_ranges_kernel<OFF, VEC, HV><<<(unsigned)ntiles, 256, 0, ctx->stream>>>(                                          \

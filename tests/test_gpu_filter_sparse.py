@@ -129,3 +129,37 @@ def test_sparse_scatter_record_batch_and_coalescer(ctx, oracle, seed):
                     assert np.array_equal(vals[valid], ev[valid]), f"{label} values column {i}"
                     for g in got[i]:  # null-buffer presence per output batch == has nulls (coalesce/primitive.rs finish)
                         assert (g.valid is None) == (g.null_count == 0), f"{label} null buffer presence column {i}"
+
+
+def _strings(rng, n, maxlen=14):
+    lens = rng.integers(0, maxlen, n)
+    pool = rng.integers(97, 123, int(lens.sum()) + 1).astype(np.uint8).tobytes().decode()
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    return [pool[offs[i]:offs[i + 1]] for i in range(n)]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_sparse_string_filter_against_tiled_and_oracle(ctx, oracle, seed):
+    """filter_bytes through string_filter_ranges_sparse_kernel (only the offsets of selected rows are read; validity bits
+    through the wave's LDS strip, valid rows counted from the output bitmap afterwards) and through the tiled ranges
+    kernel, both against the oracle (filter.rs:790-928, :512-532): Utf8 / LargeUtf8, nulls or none, a null-carrying
+    predicate, one row ... every row, lengths around the 4096-row tile, a sliced column (offsets not starting at 0)"""
+    rng = np.random.default_rng(9900 + seed)
+    n = [1, 4095, 4097, 50_003, 200_001][seed % 5]
+    dt = [A.Utf8, A.LargeUtf8][seed % 2]
+    sv = _strings(rng, n + 7)
+    full = HostArray(dt, sv, (rng.random(n + 7) < 0.85) if seed % 3 else None)
+    off = [0, 3, 7][seed % 3]
+    h = full.slice(off, n)
+    kind = ["0.001", "0.02", "one", "0.3", "none", "all", "runs"][seed % 7]
+    mask = HostArray(A.Boolean, _mask(rng, n, kind), (rng.random(n) < 0.9) if seed % 4 == 0 else None)
+    exp = oracle.filter(h, mask)
+    d = full.to_device(ctx).slice(off, n)
+    dm = mask.to_device(ctx)
+    for force in ("1", "0"):
+        with _force(force):
+            got = K.filter(d, dm)
+            g = HostArray.from_device(got)
+        assert_logical_eq(g, exp, f"string sparse={force} seed {seed} n {n} {dt} mask {kind}")
+        assert_same_nulls_presence(g, exp, f"string sparse={force} seed {seed}")
+        assert got.null_count() == exp.null_count
