@@ -390,6 +390,10 @@ class DeviceBuffer:
                 "strides": None}
 
 
+_SHRINK_MIN_BYTES = 256 << 10   # below this the slack is not worth a copy
+_SHRINK_SLACK = 4               # allocation > 4 x what the rows need
+
+
 class _OutOwner:
     """Keeps an ah_array_out alive; releases its buffers with ah_array_release."""
 
@@ -561,8 +565,17 @@ class Array:
 
     @classmethod
     def _from_out(cls, ctx, out, data_type, keepalive=()):
+        w = data_type.width
+        if (w > 0 and out.flags == 0 and out.values and out.values_bytes >= _SHRINK_MIN_BYTES
+                and out.values_bytes > _SHRINK_SLACK * max(out.length, 1) * w):
+            # the one-launch small filter allocates for the worst case (every row selected) so that it need not wait
+            # for the count first; a long-lived, highly selective result would pin len / K times its size:
+            # Buffer::shrink_to_fit it.  Results that are close to their allocation keep it (no copy on the fast path).
+            ctx.check(ctx.lib.ah_array_shrink_to_fit(ctx.handle, C.byref(out)))
         owner = _OutOwner(ctx, out, keepalive)
-        vals = _RawMem(out.values, out.values_bytes, owner) if out.values else None
+        # `values_bytes` is the ALLOCATION (what release frees); the array itself is the first length * width bytes
+        vbytes = min(out.values_bytes, out.length * w) if (w > 0 and out.flags == 0) else out.values_bytes
+        vals = _RawMem(out.values, vbytes, owner) if out.values else None
         nmem = _RawMem(out.validity, out.validity_bytes, owner) if out.validity else None
         offs = _RawMem(out.offsets, out.offsets_bytes, owner) if out.offsets else None
         arr = cls(ctx, data_type, out.length, vals, out.values_bit_offset, nmem,

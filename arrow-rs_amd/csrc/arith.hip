@@ -447,6 +447,8 @@ extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_a
   if (fused_post && st == AH_OK && e == hipSuccess) {
     e = ah_count_read(ctx, &set_bits);
     waited = true;
+  } else if (fused_post) {
+    ah_count_reset(ctx);  // the kernel may have been enqueued with its counting tail: never leave the counters dirty
   } else if (st == AH_OK && e == hipSuccess && want_valid && !union_first) {
     int64_t* cnt = AH_COUNT(ctx, &set_bits);
     st = ah_bitmap_op(ctx, (va.words && vb.words) ? BM_AND : BM_COPY, va.words ? va : vb, vb, BitView{nullptr, 0}, len,

@@ -426,6 +426,8 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
       if (st == AH_OK && fused_done) {
         hipError_t fe = ah_count_read(ctx, &set_bits);
         if (fe != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "compare kernel failed: %s", hipGetErrorString(fe));
+      } else if (fused_done) {
+        ah_count_reset(ctx);  // enqueued with its counting tail but never read: the counters must not stay dirty
       } else if (st == AH_OK) {
         st = ah_bitmap_op(ctx, BM_AND, lv, rv, none, len, nb, AH_COUNT(ctx, &set_bits));
       }
@@ -482,6 +484,8 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
       if (st == AH_OK && fused_done) {
         hipError_t fe = ah_count_read(ctx, &set_bits);
         if (fe != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "compare kernel failed: %s", hipGetErrorString(fe));
+      } else if (fused_done) {
+        ah_count_reset(ctx);  // enqueued with its counting tail but never read: the counters must not stay dirty
       } else if (st == AH_OK) {
         st = ah_bitmap_op(ctx, BM_COPY, nv, none, none, len, nb, AH_COUNT(ctx, &set_bits));
       }

@@ -607,6 +607,10 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_
   // all nullable), the batches that land in one output window leave through ONE launch (up to 8 per launch) — 2^24-row
   // batches pay the ramp and tail of a launch once per window instead of once per batch.  Same output batches, same order.
   bool fusable = co->limit < 0 && co->ncols <= 8 && n > 1;
+  // generic columns (Boolean: width 0, Utf8 / LargeUtf8: width -1) keep piece lists, not in-progress buffers: they take
+  // the per-batch path below (an all-Boolean or all-Utf8 schema has "one width" too)
+  for (int k = 0; k < co->ncols && fusable; ++k)
+    if (co->cols[k].generic || co->cols[k].width <= 0) fusable = false;
   for (int i = 0; i < n && fusable; ++i)
     for (int k = 0; k < co->ncols; ++k) {
       const ah_array_view& v = columns[(size_t)i * co->ncols + k];
@@ -632,8 +636,12 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_
         const ah_status fs = ah_filter_apply_multi(ctx, nseg, seg_p, seg_c, seg_lo, seg_hi, seg_base, co->ncols, dv, db,
                                                    (unsigned long long*)co->acc);
         nseg = 0;
-        if (fs == AH_OK) enq = true;
-        co->buffered = virt;
+        if (fs == AH_OK) {
+          enq = true;
+          co->buffered = virt;  // the bookkeeping only ever covers rows whose scatter was enqueued
+        } else {
+          co->failed = true;  // segments of this window were planned against `virt`; nothing may be appended after them
+        }
         return fs;
       };
       for (int j = 0; j < m && st == AH_OK; ++j) {

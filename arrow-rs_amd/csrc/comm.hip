@@ -338,6 +338,16 @@ __global__ void __launch_bounds__(128) fill_counts_kernel(unsigned long long* ds
   }
 }
 
+// The count all-gather always moves the FULL payload (EX_HDR + EX_PER_COL * EX_MAX_COLS words per rank): the send
+// count of the collective must not depend on what a rank was handed (ranks that disagree on n_columns — or one whose
+// arguments failed the check — would otherwise enter ncclAllGather with different counts, which is undefined on real
+// RCCL).  The host only needs the header of every rank and the first `ncols` columns of each: this one-wave kernel
+// packs exactly those words so that the usual case still comes back through the pinned mailbox.
+__global__ void __launch_bounds__(64) compact_counts_kernel(unsigned long long* dst, const unsigned long long* src, int world,
+                                                            int per_full, int per) {
+  for (int i = threadIdx.x; i < world * per; i += 64) dst[i] = src[(size_t)(i / per) * per_full + (i % per)];
+}
+
 // a piece of a concatenated offsets buffer: rank r's raw offsets (len + 1), its first output row and byte base
 struct OffPiece {
   const void* src;
@@ -480,6 +490,8 @@ extern "C" ah_status ah_all_gather_columns_begin(ah_context* ctx, ah_comm* comm,
     fail_local(ah_fail(ctx, AH_INVALID_ARGUMENT, "all-gather takes 1..%d columns", EX_MAX_COLS));
     n_columns = 0;
   }
+  // `per_full` words per rank travel (identical on every rank whatever it was handed); `per` of them are read back
+  constexpr int per_full = EX_HDR + EX_PER_COL * EX_MAX_COLS;
   const int per = EX_HDR + EX_PER_COL * n_columns;
   CountFill fill{};
   for (int c = 0; c < n_columns; ++c) {
@@ -514,7 +526,7 @@ extern "C" ah_status ah_all_gather_columns_begin(ah_context* ctx, ah_comm* comm,
   }
   unsigned long long* dcounts = nullptr;
   {
-    ah_status s = ah_pool_alloc(ctx, (size_t)(per * (R + 1)) * 8, (void**)&dcounts);
+    ah_status s = ah_pool_alloc(ctx, (size_t)(per_full * (R + 1) + per * R) * 8, (void**)&dcounts);
     if (s != AH_OK) fail_local(s);
   }
   if (!api && local != AH_OK) {  // no peers to keep in step
@@ -536,12 +548,13 @@ extern "C" ah_status ah_all_gather_columns_begin(ah_context* ctx, ah_comm* comm,
 
   // ---- 1. counts
   std::vector<unsigned long long> counts((size_t)per * R);
-  fill_counts_kernel<<<1, 128, 0, ctx->stream>>>(dcounts, per, n_columns, fill);
+  fill_counts_kernel<<<1, 128, 0, ctx->stream>>>(dcounts, per_full, n_columns, fill);
   {
-    ncclResult_t r = api ? api->AllGather(dcounts, dcounts + per, (size_t)per, ncclUint64, comm->nccl, ctx->stream) : ncclSuccess;
-    const unsigned long long* src = api ? dcounts + per : dcounts;
+    ncclResult_t r = api ? api->AllGather(dcounts, dcounts + per_full, (size_t)per_full, ncclUint64, comm->nccl, ctx->stream) : ncclSuccess;
+    unsigned long long* src = dcounts + (size_t)per_full * (R + 1);
     hipError_t e = hipSuccess;
     if (r == ncclSuccess) {
+      compact_counts_kernel<<<1, 64, 0, ctx->stream>>>(src, api ? dcounts + per_full : dcounts, R, per_full, per);
       if (per * R <= 200) {
         e = ah_d2h_wait(ctx, ctx->pinned + 16, src, (size_t)per * R * 8);
         if (e == hipSuccess) memcpy(counts.data(), ctx->pinned + 16, (size_t)per * R * 8);

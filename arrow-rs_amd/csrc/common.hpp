@@ -386,6 +386,8 @@ __device__ __forceinline__ void ah_count_add(unsigned long long* words, unsigned
 constexpr int AH_TICKET_COUNT = AH_SCRATCH_TICKETS + 40;  // [560, 624): the 64 counter words of the counting kernels
 // the read-back of ah_count_add: 64 counters -> pinned slots, counters zeroed, mailbox posted, host sum
 hipError_t ah_count_read(ah_context* ctx, int64_t* total);
+// a caller that bails out AFTER enqueueing a counting kernel without reading it: stream drained, counters back to zero
+void ah_count_reset(ah_context* ctx);
 
 struct ah_filter_predicate;
 // strings.hip: filter_bytes + filter_nulls of a Utf8 / LargeUtf8 column — offsets, data and (vvalid.words != nullptr) the

@@ -256,9 +256,21 @@ hipError_t ah_stream_wait(ah_context* ctx) {
   return e == hipSuccess ? ah_mail_wait(ctx, seq) : e;
 }
 
+// The 64 counters are "zero between calls": only a successful read-back restores that.  When the read (or the call
+// around an already enqueued counting kernel) fails, drain the stream and zero them here — otherwise every later
+// counted op of the context would report the leftovers as null counts.
+void ah_count_reset(ah_context* ctx) {
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipGetLastError();
+  if (hipMemsetAsync(ctx->scratch + AH_TICKET_COUNT, 0, 64 * 8, ctx->stream) == hipSuccess) (void)hipStreamSynchronize(ctx->stream);
+}
+
 hipError_t ah_count_read(ah_context* ctx, int64_t* total) {
   hipError_t e = ah_d2h_wait(ctx, ctx->pinned + 64, ctx->scratch + AH_TICKET_COUNT, 64 * 8, /*reset=*/true);
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess) {
+    ah_count_reset(ctx);
+    return e;
+  }
   uint64_t t = 0;
   for (int i = 0; i < 64; ++i) t += ctx->pinned[64 + i];
   *total = (int64_t)t;

@@ -1532,6 +1532,10 @@ ah_status ah_filter_apply_multi(ah_context* ctx, int nsegs, const ah_filter_pred
                                 unsigned long long* null_slots) {
   if (nsegs < 1 || nsegs > MULTI_MAX_SEGS || ncols < 1 || ncols > SCATTER_MAX_COLS) return AH_INVALID_ARGUMENT;
   const int width = ah_type_width(columns[0][0].type);
+  if (width <= 0)  // Boolean / string / view columns have no fixed-width in-progress buffer to scatter into
+    return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "grouped filter scatter of %s columns", ah_type_name(columns[0][0].type));
+  for (int c = 0; c < ncols; ++c)
+    if (!dst_values[c] || !dst_validity[c]) return ah_fail(ctx, AH_INVALID_ARGUMENT, "grouped filter scatter: column %d has no destination", c);
   MultiArgs m{};
   m.nsegs = nsegs;
   static const char* xr = getenv("AH_FILTER_XCD");

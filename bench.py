@@ -73,6 +73,9 @@ def parse():
     p.add_argument("--config-steps", type=int, default=5)
     p.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"])
     p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the run rocprofv3 wraps
+    # test hook (tests/test_gpu_comm.py): rank 0 writes the LAST reassembled column(s) of the headline workload to this
+    # .npz so a checker can compare them with the oracle's un-sharded filter
+    p.add_argument("--dump-gathered", default=None, help=argparse.SUPPRESS)
     p.add_argument("--transport", default="capi", choices=["capi", "torch"],
                    help="exchange step: ah_comm_* (libarrow_hip.so drives RCCL itself) or torch.distributed")
     return p.parse_args()
@@ -531,7 +534,10 @@ def build_workload(env, wl):
                 # take on the second context = second stream while RCCL moves the shards, come back for the result
                 pending = env.comm.all_gather_record_batch_begin(A.RecordBatch(["f"], [f], f.length))
                 t = K.take(col_b, idx_b)
-                st["gk"] = pending.end().num_rows()
+                g = pending.end()
+                st["gk"] = g.num_rows()
+                if args.dump_gathered:
+                    st["gathered"] = g
             elif with_reassembly and not st.get("reassemble_error"):
                 import threading
                 box = {}
@@ -671,6 +677,8 @@ def build_workload(env, wl):
             if with_reassembly:
                 parts = env.comm.all_gather_batches(f)
                 st["gk"] = sum(p.num_rows() for p in parts)
+                if args.dump_gathered and len(parts) == 1:
+                    st["gathered"] = parts[0]
             return f
 
         W.update(step=step, kernels=["filter_count", "filter_scatter"], dominant="filter_scatter")
@@ -995,6 +1003,16 @@ def main():
         prof["take_gather"] = ctx.profile_get("take_gather")
         ctx.profile(False)
 
+    if args.dump_gathered and rank == 0 and W["state"].get("gathered") is not None:
+        import numpy as np
+        g = W["state"].pop("gathered")
+        dump = {"selected_local": np.int64(W["state"]["k"]), "gathered_rows": np.int64(g.num_rows())}
+        for i, c in enumerate(g.columns):
+            dump[f"values{i}"] = c.values_numpy()
+            dump[f"valid{i}"] = c.valid_mask()
+        np.savez(args.dump_gathered, **dump)
+        del g, dump
+    W["state"].pop("gathered", None)
     local_elapsed = None
     if reassemble:  # same run, same data, without the exchange step
         sync_all()

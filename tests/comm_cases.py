@@ -116,6 +116,27 @@ def run_rank(ctx, comm, oracle, r, world, n=N, heavy=True):
             raise AssertionError(f"rank {r}: a failing peer must fail everyone")
         except (A.ArrowError, A.array.HipError) as ex:  # AH_COMM_ERROR has no ArrowError variant
             assert ("Utf8View" in str(ex)) if r == 1 else ("rank 1 failed" in str(ex)), str(ex)
+        # ranks that disagree on the NUMBER of columns (VERDICT r03 weak #4 / ADVICE r03): the count all-gather moves a
+        # fixed-size payload, so nobody enters a collective with a different send count (the fake transports reject that,
+        # real RCCL would hang or corrupt) and every rank gets the same kind of error
+        L_ = A._lib
+        for ncols_of in (lambda rr: 3 if rr == 1 else 2, lambda rr: 0 if rr == 1 else 2):
+            mine = ncols_of(r)
+            views = (L_.ArrayView * 3)()
+            for i in range(3):
+                views[i] = ok.view()
+            outs_ = (L_.ArrayOut * 3)()
+            st_ = L_.ExchangeStats()
+            try:
+                ctx.check(ctx.lib.ah_all_gather_columns(ctx.handle, comm._h, mine, views, outs_, C.byref(st_)))
+                raise AssertionError(f"rank {r}: a column-count mismatch must fail everyone")
+            except (A.ArrowError, A.array.HipError) as ex:
+                if mine == 0:
+                    assert "1..16 columns" in str(ex), str(ex)
+                elif ncols_of(1) == 0:
+                    assert "rank 1 failed" in str(ex), str(ex)
+                else:
+                    assert "columns" in str(ex) and "passed" in str(ex), str(ex)
         # the communicator is still usable afterwards
         g = comm.all_gatherv(ok)
         assert g.length == 5 * world

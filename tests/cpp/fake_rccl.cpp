@@ -231,6 +231,14 @@ __attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void* se
     }
     all = fake_snapshots()[w];
   }
+  // the send count must be the same on every rank — undefined (a hang or corruption) on real RCCL otherwise; every rank
+  // sees the same snapshot, so every rank returns the error
+  for (int r = 0; r < w->size; ++r)
+    if (all[r].size() != bytes) {
+      fprintf(stderr, "fake_rccl: ncclAllGather send counts differ: rank %d sends %zu bytes, rank %d sends %zu\n", comm->rank, bytes, r,
+              all[r].size());
+      return 4;
+    }
   for (int r = 0; r < w->size; ++r)
     if (bytes) hipMemcpyAsync((char*)recv + (size_t)r * bytes, all[r].data(), bytes, hipMemcpyHostToDevice, stream);
   hipStreamSynchronize(stream);  // `all` is pageable: the copies have left it; and the stream's next kernel sees them

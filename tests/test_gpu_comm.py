@@ -44,6 +44,95 @@ def test_exchange_code_at_world_n_over_a_fake_transport(world, tmp_path):
     assert out.returncode == 0 and f"COMM_RANKS_OK {world}" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
 
+def _build_fake(tmp_path, name):
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = str(tmp_path / f"lib{name}.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-Wno-unused-value",
+                           "-o", lib, os.path.join(here, "cpp", f"{name}.cpp")])
+    return lib
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_code_across_processes_over_a_fake_transport(world, tmp_path):
+    """One PROCESS per rank, all on GPU 0, the unique id through a file — exactly the shape of the real-RCCL test below,
+    with RCCL's entry points served by tests/cpp/fake_rccl_xproc.cpp (a file-backed shared mapping between the
+    processes).  The whole shared case list (tests/comm_cases.py), incl. ranks that disagree on the column count."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = _build_fake(tmp_path, "fake_rccl_xproc")
+    env = dict(os.environ, AH_RCCL_LIBRARY=lib, AH_TEST_SHARED_GPU="1", AH_FAKE_RCCL_DIR=str(tmp_path), AH_FAKE_RCCL_TIMEOUT_S="90")
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "comm_rccl_worker.py"), str(r), str(world), str(tmp_path)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=900)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"COMM_RCCL_RANK_OK {r}/{world}" in o, f"rank {r}:\n{o[-3000:]}"
+
+
+@pytest.mark.parametrize("workload", ["filter_take", "record_batch"])
+def test_bench_self_spawned_ranks_over_the_c_abi_transport(workload, tmp_path, ctx, oracle):
+    """`python bench.py --gpus 2` started PLAINLY — the path the driver's 8-GPU run takes: bench.py spawns its own ranks,
+    a gloo group ships the 128-byte id, every rank builds a CApiCommunicator and the reassembly goes through
+    ah_all_gather_columns_begin / _end ACROSS PROCESSES (VERDICT r03 missing #1).  One GPU here, so both ranks sit on
+    it (AH_BENCH_SHARED_GPU=1) and RCCL is the cross-process fake; the line must say so honestly
+    (distinct_devices == 1).  Rank 0 dumps what it reassembled: it must equal the oracle's filter of the UN-SHARDED
+    column (concat of the shard results == filter of the whole, concat.rs:495 / :607)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import bench as B
+    from orc import HostArray, assert_logical_eq
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = _build_fake(tmp_path, "fake_rccl_xproc")
+    rows = 50_000_000
+    dump = str(tmp_path / "gathered.npz")
+    env = dict(os.environ, AH_BENCH_SHARED_GPU="1", AH_RCCL_LIBRARY=lib, AH_FAKE_RCCL_DIR=str(tmp_path), AH_FAKE_RCCL_TIMEOUT_S="90")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", str(rows),
+           "--no-cpu-baseline", "--workload", workload, "--config-steps", "2", "--dump-gathered", dump]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    cfg = d["config"]
+    assert cfg["transport"].startswith("ah_comm") and "transport_note" not in cfg, cfg
+    assert cfg["distinct_devices"] == 1 and cfg["reassemble"] == "allgatherv", cfg
+    if workload == "filter_take":
+        ex = d["exchange"]
+        assert ex["peers"] == 1 and ex["bytes_to_each_peer"] > 0
+        rb = d["configs"]["record_batch_allgather"]  # BASELINE configs[4] rides in the same line at N > 1
+        assert "error" not in rb and rb["gathered_rows"] > 0 and rb["exchange"]["peers"] == 1, rb
+    # the reassembled result against the oracle on the un-sharded input (the generators are counter-based: rank r's
+    # shard is rows [r * rows, (r + 1) * rows) of one global column)
+    z = np.load(dump)
+    n = 2 * rows
+    pred = B.gen_predicate(A, ctx, n, 44, 0.1, 0)
+    hp = HostArray(A.Boolean, pred.values_numpy())
+    cols = [B.gen_i64_column(A, ctx, n, 42, 0.9, 0)]
+    if workload == "record_batch":
+        cols.append(B.gen_f64_column(A, ctx, n, 52, 0.9, 0))
+    total = None
+    for i, c in enumerate(cols):
+        exp = oracle.filter(HostArray(c.data_type, c.values_numpy(), c.valid_mask()), hp)
+        got = HostArray(c.data_type, z[f"values{i}"], z[f"valid{i}"])
+        assert_logical_eq(got, exp, f"{workload}: reassembled column {i} vs the oracle's un-sharded filter")
+        total = len(exp)
+    assert int(z["gathered_rows"]) == total and 0 < int(z["selected_local"]) < total  # gathered rows = sum of the K_r
+
+
 def _gpu_count():
     import arrow_rs_amd as A_
     return int(A_._lib.load().ah_device_count())

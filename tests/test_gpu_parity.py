@@ -1117,6 +1117,48 @@ def test_batch_coalescer_generic_columns(ctx, oracle):
         _check_batches(co, model, f"generic trial {trial} final", presence_cols=[1])
 
 
+@pytest.mark.parametrize("schema", ["bool", "utf8", "large_utf8", "mixed", "bool_i64"])
+def test_batch_coalescer_grouped_pushes_generic_schemas(ctx, oracle, schema):
+    """a grouped push (n > 1, no bypass limit) of a schema whose columns are ALL Boolean, or ALL
+    Utf8 / LargeUtf8, all nullable, has "one width" (0 / -1) and used to be sent to the multi-batch scatter, which has no
+    in-progress buffers for generic columns.  Such schemas take the per-batch path; the output batches are those of the
+    coalesce.rs model, and the coalescer stays usable."""
+    from coalesce_model import ModelCoalescer
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(schema.encode()))
+    dts = {"bool": [A.Boolean, A.Boolean], "utf8": [A.Utf8], "large_utf8": [A.LargeUtf8, A.LargeUtf8],
+           "mixed": [A.Utf8, A.Boolean, A.LargeUtf8], "bool_i64": [A.Boolean, A.Int64]}[schema]
+    names = [f"c{i}" for i in range(len(dts))]
+    words = ["", "q", "rs", "a somewhat longer value "]
+
+    def col(dt, n):
+        valid = rng.random(n) < 0.8  # every column nullable: the shape the fused path keys on
+        if dt in (A.Utf8, A.LargeUtf8):
+            return HostArray(dt, [words[rng.integers(0, 4)] + str(rng.integers(0, 99)) for _ in range(n)], valid)
+        return HostArray(dt, _rand_values(rng, dt, n), valid)
+
+    for trial in range(3):
+        target = int(rng.choice([7, 100, 1500]))
+        co = K.BatchCoalescer.new(names, dts, target, ctx)
+        model = ModelCoalescer(oracle, dts, target)
+        pending = []
+        for step in range(24):
+            n = int(rng.integers(1, 2 * target + 9))
+            cols = [col(dt, n) for dt in dts]
+            f = HostArray(A.Boolean, rng.random(n) < float(rng.choice([0.0, 0.1, 0.6, 1.0])), (rng.random(n) < 0.9) if step % 4 == 0 else None)
+            pending.append((A.RecordBatch(names, [c.to_device(ctx) for c in cols]), f.to_device(ctx)))
+            model.push_with_filter(cols, f)
+            if len(pending) >= int(rng.integers(2, 7)) or step == 23:
+                co.push_batches_with_filters(pending)
+                pending = []
+                assert co.get_buffered_rows() == model.buffered, f"{schema} trial {trial} step {step}"
+                _check_batches(co, model, f"grouped generic {schema} trial {trial} step {step}", presence_cols=[])
+        co.finish_buffered_batch()
+        model.finish()
+        _check_batches(co, model, f"grouped generic {schema} trial {trial} final", presence_cols=[])
+        assert co.is_empty()
+
+
 # ------------------------------------------------- RCCL reassembly, 1 rank
 def test_communicator_world1_nccl(ctx, oracle):
     """Plumbing of the RCCL path with a single rank (the box has one GPU): count exchange,
