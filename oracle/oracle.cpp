@@ -1854,6 +1854,13 @@ int32_t orc_filter(const orc_view* values, const orc_view* predicate, orc_out* o
   return filter_impl(values, predicate, out);
 }
 
+// IterationStrategy::default_strategy (filter.rs:346-364) for this predicate: 0 None, 1 All, 2 SlicesIterator, 3 IndexIterator
+int32_t orc_filter_strategy(const orc_view* predicate) {
+  Predicate p;
+  build_predicate(predicate, &p);
+  return (int32_t)p.strategy;
+}
+
 int32_t orc_take(const orc_view* values, const orc_view* indices, int32_t cb, orc_out* out) {
   out_init(out);
   if (type_width(values->type) < 0 && values->type != ORC_UTF8 && values->type != ORC_LARGE_UTF8)

@@ -79,6 +79,8 @@ int64_t orc_set_indices(const uint8_t* bits, int64_t bit_offset, int64_t len, in
                         int64_t cap);
 
 int32_t orc_filter(const orc_view* values, const orc_view* predicate, orc_out* out);
+/* IterationStrategy::default_strategy (filter.rs:346-364): 0 None, 1 All, 2 SlicesIterator, 3 IndexIterator */
+int32_t orc_filter_strategy(const orc_view* predicate);
 int32_t orc_take(const orc_view* values, const orc_view* indices, int32_t check_bounds, orc_out* out);
 int32_t orc_arith(int32_t op, const orc_view* lhs, int32_t lhs_scalar, const orc_view* rhs,
                   int32_t rhs_scalar, orc_out* out);

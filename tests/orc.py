@@ -245,6 +245,12 @@ class Oracle:
             self._raise(st)
         return self._collect(out, values.data_type)
 
+    def filter_strategy(self, predicate):
+        """IterationStrategy::default_strategy (filter.rs:346-364) the reference would pick: "None" | "All" | "Slices" | "Indices"."""
+        hp = _Held(predicate)
+        self.lib.orc_filter_strategy.argtypes = [C.POINTER(View)]
+        return ["None", "All", "Slices", "Indices"][self.lib.orc_filter_strategy(C.byref(hp.view))]
+
     def take(self, values, indices, check_bounds=False, bit_offset=0, elem_offset=0):
         hv, hi = _Held(values, bit_offset, elem_offset), _Held(indices, bit_offset)
         out = Out()

