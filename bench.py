@@ -76,6 +76,8 @@ def parse():
     # test hook (tests/test_gpu_comm.py): rank 0 writes the LAST reassembled column(s) of the headline workload to this
     # .npz so a checker can compare them with the oracle's un-sharded filter
     p.add_argument("--dump-gathered", default=None, help=argparse.SUPPRESS)
+    p.add_argument("--detail-json", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                   help="where the full-detail object goes (stdout carries the compact line); '' = stderr only")
     p.add_argument("--transport", default="capi", choices=["capi", "torch"],
                    help="exchange step: ah_comm_* (libarrow_hip.so drives RCCL itself) or torch.distributed")
     return p.parse_args()
@@ -420,6 +422,180 @@ def crossover_rows(env):
     return {"rows": cross, "probes": probes,
             "what": "first probed size at which one synchronous C-ABI ah_filter call (Int64, 10 % nulls, 10 % selected) beats the "
                     "1-core oracle on the same rows"}
+
+
+def reference_bench_shapes(env, batch=64):
+    """The drop-in at the reference's OWN criterion shapes: 65 536-row filters at the three
+    selectivities of arrow/benches/filter_kernels.rs:39-45,96-120 (with a fresh predicate and with a prebuilt
+    FilterPredicate, without and with 50 % nulls), take of 512 / 1 024 Int32 rows (take_kernels.rs:32-80), add_wrapping
+    and lt on 65 536 Float32 (arithmetic_kernels.rs:26-33, comparison_kernels.rs:33).  Per shape, through the raw C ABI:
+      sync_us     one synchronous call (result complete and null_count known at return) — the reference's contract;
+      batched_us  the same call amortised over `batch` calls handed over together: predicates for the whole batch built
+                  with ONE wait (ah_filter_predicates_build), every apply / arith / compare only ENQUEUED (deferred mode),
+                  ONE ah_synchronize at the end — what an engine that has several batches queued can do;
+      cpu_1core_us the oracle (scalar port of the reference's kernel) on one host core, same data.
+    take stays synchronous in every mode (an out-of-bounds index must surface as the reference's panic), so it has no
+    batched form: at 512 / 1 024 rows a GPU call cannot win and the line says so."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import arrow_rs_amd as A
+    from arrow_rs_amd import _lib as L
+    import orc
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so):
+        return None
+    oracle = orc.load(so)
+    ctx, lib, h = env.ctx, env.ctx.lib, env.ctx.handle
+    rng = np.random.default_rng(42)
+    n = 65536
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    def cpu_timed(fn):
+        fn()
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 0.05:
+            fn()
+            k += 1
+        return (time.perf_counter() - t0) / k * 1e6
+
+    def release(out):
+        lib.ah_array_release(h, C.byref(out))
+
+    shapes = {}
+
+    def row(name, rows, sync_us, batched_us, cpu_us, note=None):
+        r = {"rows": rows, "sync_us": round(sync_us, 2), "batched_us": None if batched_us is None else round(batched_us, 2),
+             "cpu_1core_us": round(cpu_us, 2),
+             "sync_beats_cpu": bool(sync_us < cpu_us), "batched_beats_cpu": None if batched_us is None else bool(batched_us < cpu_us)}
+        if note:
+            r["note"] = note
+        shapes[name] = r
+
+    # ---- filter (filter_kernels.rs): Int32, three selectivities; fresh predicate (no nulls) and prebuilt predicate (50 % nulls)
+    sels = (("kept 1/2", 0.5), ("high selectivity (kept 1023/1024)", 1.0 - 1.0 / 1024.0), ("low selectivity (kept 1/1024)", 1.0 / 1024.0))
+    for nulls, pv in (("", None), (" w NULLs", 0.5)):
+        hv = orc.HostArray(A.Int32, rng.integers(-2**31, 2**31 - 1, n, dtype=np.int32), None if pv is None else rng.random(n) < pv)
+        dv = hv.to_device(ctx)
+        vv = dv.view()
+        for label, sel in sels:
+            hm = orc.HostArray(A.Boolean, rng.random(n) < sel)
+            dm = hm.to_device(ctx)
+            mv = dm.view()
+            hvh, hmh = orc._Held(hv), orc._Held(hm)
+
+            def cpu():
+                o = orc.Out()
+                oracle.lib.orc_filter(C.byref(hvh.view), C.byref(hmh.view), C.byref(o))
+                oracle.lib.orc_release(C.byref(o))
+            cpu_us = cpu_timed(cpu)
+            if pv is None:  # "filter i32 (...)": FilterBuilder::new + filter per call
+                def sync():
+                    out = L.ArrayOut()
+                    assert lib.ah_filter(h, C.byref(vv), C.byref(mv), C.byref(out)) == 0
+                    release(out)
+                masks = (L.ArrayView * batch)(*[mv] * batch)
+
+                def batched():
+                    preds = (C.c_void_p * batch)()
+                    assert lib.ah_filter_predicates_build(h, batch, masks, preds) == 0  # ONE wait for `batch` counts
+                    lib.ah_context_set_deferred(h, 1)
+                    outs = [L.ArrayOut() for _ in range(batch)]
+                    for i in range(batch):
+                        assert lib.ah_filter_predicate_apply(h, preds[i], C.byref(vv), C.byref(outs[i])) == 0
+                    lib.ah_context_set_deferred(h, 0)
+                    assert lib.ah_synchronize(h) == 0
+                    for i in range(batch):
+                        release(outs[i])
+                        lib.ah_filter_predicate_free(h, preds[i])
+                row(f"filter i32 ({label})" if label.startswith("kept") else f"filter i32 {label}", n, timed(sync, 200),
+                    timed(batched, 8) / batch, cpu_us)
+            else:  # "filter context i32 w NULLs (...)": the FilterPredicate is built once, outside the timed call
+                pred = C.c_void_p()
+                assert lib.ah_filter_predicate_build(h, C.byref(mv), C.byref(pred)) == 0
+
+                def sync():
+                    out = L.ArrayOut()
+                    assert lib.ah_filter_predicate_apply(h, pred, C.byref(vv), C.byref(out)) == 0
+                    release(out)
+
+                def batched():
+                    lib.ah_context_set_deferred(h, 1)
+                    outs = [L.ArrayOut() for _ in range(batch)]
+                    for i in range(batch):
+                        assert lib.ah_filter_predicate_apply(h, pred, C.byref(vv), C.byref(outs[i])) == 0
+                    lib.ah_context_set_deferred(h, 0)
+                    assert lib.ah_synchronize(h) == 0
+                    for o in outs:
+                        release(o)
+                row(f"filter context i32 w NULLs ({label})" if label.startswith("kept") else f"filter context i32 w NULLs {label}", n,
+                    timed(sync, 200), timed(batched, 8) / batch, cpu_us,
+                    "cpu_1core_us includes the oracle's predicate build (it has no prebuilt-predicate entry point)")
+                lib.ah_filter_predicate_free(h, pred)
+
+    # ---- take (take_kernels.rs): Int32 values, random u32 indices, no nulls
+    for m in (512, 1024):
+        hv = orc.HostArray(A.Int32, rng.integers(-2**31, 2**31 - 1, m, dtype=np.int32))
+        hi = orc.HostArray(A.UInt32, rng.integers(0, m, m).astype(np.uint32))
+        dv, di = hv.to_device(ctx), hi.to_device(ctx)
+        vv, iv = dv.view(), di.view()
+        hvh, hih = orc._Held(hv), orc._Held(hi)
+
+        def sync():
+            out = L.ArrayOut()
+            assert lib.ah_take(h, C.byref(vv), C.byref(iv), 0, C.byref(out)) == 0
+            release(out)
+
+        def cpu():
+            o = orc.Out()
+            oracle.lib.orc_take(C.byref(hvh.view), C.byref(hih.view), 0, C.byref(o))
+            oracle.lib.orc_release(C.byref(o))
+        row(f"take i32 {m}", m, timed(sync, 200), None, cpu_timed(cpu),
+            "take reports out-of-bounds indices (the reference's panic) at return, so it is synchronous in every mode: no batched form")
+
+    # ---- add_wrapping / lt on 65 536 Float32, no nulls (arithmetic_kernels.rs add(0), comparison_kernels.rs lt)
+    ha = orc.HostArray(A.Float32, rng.random(n, dtype=np.float32))
+    hb = orc.HostArray(A.Float32, rng.random(n, dtype=np.float32))
+    da, db = ha.to_device(ctx), hb.to_device(ctx)
+    av, bv = da.view(), db.view()
+    hah, hbh = orc._Held(ha), orc._Held(hb)
+    for name, fn_name, op, ofn in (("add(0) f32", "ah_arith_binary", 1, "orc_arith"), ("lt f32", "ah_compare", 2, "orc_compare")):
+        fn = getattr(lib, fn_name)
+
+        def sync():
+            out = L.ArrayOut()
+            assert fn(h, op, C.byref(av), 0, C.byref(bv), 0, C.byref(out)) == 0
+            release(out)
+
+        def batched():
+            lib.ah_context_set_deferred(h, 1)
+            outs = [L.ArrayOut() for _ in range(batch)]
+            for i in range(batch):
+                assert fn(h, op, C.byref(av), 0, C.byref(bv), 0, C.byref(outs[i])) == 0
+            lib.ah_context_set_deferred(h, 0)
+            assert lib.ah_synchronize(h) == 0
+            for o in outs:
+                release(o)
+
+        def cpu():
+            o = orc.Out()
+            getattr(oracle.lib, ofn)(op, C.byref(hah.view), 0, C.byref(hbh.view), 0, C.byref(o))
+            oracle.lib.orc_release(C.byref(o))
+        row(name, n, timed(sync, 200), timed(batched, 8) / batch, cpu_timed(cpu))
+    lost = [k for k, v in shapes.items() if v["batched_beats_cpu"] is False or (v["batched_beats_cpu"] is None and not v["sync_beats_cpu"])]
+    return {"batch": batch, "shapes": shapes, "shapes_where_one_cpu_core_wins": lost,
+            "what": "the reference's own criterion shapes through the raw C ABI: sync_us = one synchronous call; batched_us = per call "
+                    "inside a batch of %d (predicates built with one wait, applies / arith / compare enqueued in deferred mode, one "
+                    "ah_synchronize); cpu_1core_us = the oracle on one host core.  A one-call-at-a-time drop-in loses to one core at "
+                    "these sizes; the batched form is what an engine with several batches queued gets" % batch}
 
 
 # ------------------------------------------------------------------------------- in-run PMC traffic
@@ -839,6 +1015,83 @@ def run_timed(env, W, steps, warmup, reassemble):
     prof = {k: ctx.profile_get(k) for k in W["kernels"]}
     ctx.profile(False)
     return elapsed, prof, out
+
+
+def _compact_roofline(rf):
+    if not isinstance(rf, dict):
+        return rf
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches",
+            "traffic_GBps", "traffic_frac")
+    return {k: rf[k] for k in keep if k in rf}
+
+
+def _compact_config(c):
+    """One per-config entry of the compact line: what the judge recomputes fractions from, nothing else."""
+    if not isinstance(c, dict) or "error" in c:
+        return c
+    out = {k: c[k] for k in ("rows", "rows_per_gpu", "ms", "value", "local_ms", "local_value", "gathered_rows", "host_gap_ms",
+                              "ms_without_kernel_events") if k in c}
+    if "roofline" in c:
+        rf = c["roofline"]
+        out.update(kernel=rf.get("kernel"), avg_launch_ms=rf.get("avg_launch_ms"), alg_bytes=rf.get("algorithmic_bytes_per_launch"),
+                   frac=rf.get("frac"))
+    if isinstance(c.get("single_push"), dict):
+        out["single_push_ms"] = c["single_push"].get("ms_without_kernel_events")
+    if isinstance(c.get("exchange"), dict):
+        out["exchange"] = {k: c["exchange"][k] for k in ("peers", "bytes_to_each_peer", "total_ms", "per_link_GBps") if k in c["exchange"]}
+    return out
+
+
+def emit(line, args):
+    """stdout gets ONE compact JSON line, LAST: the contract keys, `roofline`, `cpu_baseline` and a few numbers per config
+    (enough to recompute every fraction) — small enough that a log tail keeps all of it (r03's single 14 KB line lost
+    `configs.arith` off the front of the driver's stdout tail).  The full-detail object (every roofline object, notes,
+    probes) goes to stderr as one JSON line and to --detail-json (default gpurun_out/bench_detail.json)."""
+    detail = json.dumps(line)
+    path = args.detail_json
+    try:
+        if path:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            with open(path, "w") as f:
+                f.write(detail + "\n")
+    except OSError:
+        path = None
+    print("BENCH_DETAIL " + detail, file=sys.stderr, flush=True)
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "kernel_avg_ms", "host_gap_ms", "local_value", "local_ms_per_step", "exchange", "reassemble_last_ms",
+            "step_algorithmic_GBps", "filter_selected_rows", "take_indices", "take_sorted_indices_ms", "take_null_indices_ms",
+            "pmc_traffic_bytes_per_launch")
+    compact = {k: line[k] for k in keep if k in line}
+    compact["roofline"] = _compact_roofline(line.get("roofline"))
+    if "requests" in (line.get("roofline") or {}):
+        rq = line["roofline"]["requests"]
+        compact["roofline"]["requests"] = {k: rq[k] for k in ("per_launch", "achieved_G_per_s", "probe_max_G_per_s", "frac_of_probe_max") if k in rq}
+    if "roofline_filter_scatter" in line:
+        compact["roofline_filter_scatter"] = _compact_roofline(line["roofline_filter_scatter"])
+    for grp in ("configs", "next_rows"):
+        if grp in line:
+            compact[grp] = {k: _compact_config(v) for k, v in line[grp].items()}
+    if isinstance(line.get("filter_by_selectivity"), dict):
+        compact["filter_scatter_ms_by_selectivity"] = {k: (v.get("filter_scatter_ms") if isinstance(v, dict) else v)
+                                                       for k, v in line["filter_by_selectivity"].items()}
+    rs = line.get("reference_bench_shapes")
+    if isinstance(rs, dict) and "shapes" in rs:
+        compact["reference_bench_shapes"] = {
+            "batch": rs["batch"], "columns": ["sync_us", "batched_us", "cpu_1core_us"],
+            "shapes": {k: [v["sync_us"], v["batched_us"], v["cpu_1core_us"]] for k, v in rs["shapes"].items()},
+            "one_cpu_core_wins": rs["shapes_where_one_cpu_core_wins"]}
+    elif rs is not None:
+        compact["reference_bench_shapes"] = rs
+    cr = line.get("crossover_rows")
+    if isinstance(cr, dict):
+        compact["crossover_rows"] = cr.get("rows", cr)
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict):
+        compact["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "error") if k in cb}
+        if isinstance(cb.get("all_cores"), dict):
+            compact["cpu_baseline"]["all_cores"] = {k: cb["all_cores"][k] for k in ("value", "cores", "unit") if k in cb["all_cores"]}
+    compact["detail"] = "stderr line 'BENCH_DETAIL {...}'" + (f" and {path}" if path else "")
+    print(json.dumps(compact), flush=True)
 
 
 def _free_port():
@@ -1265,12 +1518,16 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 line["crossover_rows"] = {"error": repr(ex)[:200]}
             try:
+                line["reference_bench_shapes"] = reference_bench_shapes(env)
+            except Exception as ex:  # noqa: BLE001
+                line["reference_bench_shapes"] = {"error": repr(ex)[:200]}
+            try:
                 cb = cpu_baseline_filter_take(args)
                 if cb:
                     line["cpu_baseline"] = cb
             except Exception as ex:  # never lose the GPU line to a baseline hiccup
                 line["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(line), flush=True)
+        emit(line, args)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -1442,6 +1442,21 @@ def test_bench_json_contract(ctx):
     for k in ["value", "unit", "cores", "kind", "sample"]:
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["value"] > 0
+    # round 4: the stdout line is the COMPACT one and it comes last; the full-detail object is on stderr and in the file
+    assert len(lines[0]) < 8000 and out.stdout.rstrip().splitlines()[-1] == lines[0]
+    det = [l for l in out.stderr.splitlines() if l.startswith("BENCH_DETAIL {")]
+    assert len(det) == 1 and json.loads(det[0][len("BENCH_DETAIL "):])["value"] == d["value"]
+    # the reference's own criterion shapes (filter_kernels.rs:39-120, take_kernels.rs:32-80, arithmetic / comparison
+    # kernels at 65 536 rows): synchronous us, amortised us inside a batch of 64 deferred calls, 1-core oracle us
+    rs = d["reference_bench_shapes"]
+    assert rs["columns"] == ["sync_us", "batched_us", "cpu_1core_us"] and rs["batch"] == 64
+    names = set(rs["shapes"])
+    for want in ("filter i32 (kept 1/2)", "filter i32 high selectivity (kept 1023/1024)", "filter i32 low selectivity (kept 1/1024)",
+                 "filter context i32 w NULLs (kept 1/2)", "take i32 512", "take i32 1024", "add(0) f32", "lt f32"):
+        assert want in names, want
+    for name, (sync_us, batched_us, cpu_us) in rs["shapes"].items():
+        assert sync_us > 0 and cpu_us > 0 and (batched_us is None) == name.startswith("take"), name
+    assert set(rs["one_cpu_core_wins"]) <= names  # the honest crossover statement, whatever it is on this box
 
 
 def test_filter_tile_and_chunk_boundaries(ctx, oracle):
