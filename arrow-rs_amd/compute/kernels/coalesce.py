@@ -273,6 +273,44 @@ class BatchCoalescer:
             if bypassed[i]:
                 self._tagged[tags[i]] = b
 
+    def push_batches_with_filters_begin(self, pairs):
+        """First half of ``push_batches_with_filters`` (``ah_coalescer_push_batches_with_filters_begin``): the count passes
+        of up to 64 (batch, filter) pairs are ENQUEUED and the call returns; ``.end()`` of the returned handle waits for
+        the counts and appends the batches.  An engine that already holds the next group calls ``begin`` for it BEFORE
+        ``end`` of the current one, so the GPU never idles for a count round trip:
+
+            pending = co.push_batches_with_filters_begin(groups[0])
+            for g in groups[1:]:
+                nxt = co.push_batches_with_filters_begin(g)
+                pending.end()
+                pending = nxt
+            pending.end()
+
+        Same output batches, same order as the one-call form.  Non-native schemas: everything happens in ``end()``."""
+        pairs = list(pairs)
+        if self._native is None or not pairs or len(pairs) > 64:
+            return _PendingPush(self, pairs, None, None, None)
+        n, nc = len(pairs), len(self.data_types)
+        views = (L.ArrayView * (n * nc))()
+        fviews = (L.ArrayView * n)()
+        rows = (C.c_int64 * n)()
+        tags = (C.c_uint64 * n)()
+        for i, (b, f) in enumerate(pairs):
+            if f.data_type != Boolean:
+                raise InvalidArgumentError(f"filter predicate must be Boolean, got {f.data_type}")
+            if b.num_columns() != nc:
+                raise InvalidArgumentError(f"Batch has {b.num_columns()} columns but BatchCoalescer expects {nc}")
+            for k, c in enumerate(b.columns):
+                views[i * nc + k] = c.view()
+            fviews[i] = f.view()
+            rows[i] = b.num_rows()
+            tags[i] = self._next_tag
+            self._next_tag += 1
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.ah_coalescer_push_batches_with_filters_begin(self.ctx.handle, self._native, n, views, rows, fviews,
+                                                                                 tags, C.byref(h)))
+        return _PendingPush(self, pairs, h, tags, (views, fviews, rows))
+
     # ---- coalesce.rs:257
     def push_batch_with_indices(self, batch, indices):
         if self._native is not None:
@@ -332,3 +370,26 @@ class BatchCoalescer:
         cols = [ip.finish(self.buffered_rows) for ip in self.in_progress]
         self.completed.append(RecordBatch(self.names, cols, num_rows=self.buffered_rows))
         self.buffered_rows = 0
+
+
+class _PendingPush:
+    """A grouped push between ``push_batches_with_filters_begin`` and ``end``; keeps the input batches alive."""
+
+    def __init__(self, co, pairs, handle, tags, keep):
+        self.co, self.pairs, self.handle, self.tags, self._keep = co, pairs, handle, tags, keep
+
+    def end(self):
+        co, pairs = self.co, self.pairs
+        if pairs is None:
+            raise RuntimeError("push already ended")
+        self.pairs = None
+        if self.handle is None:  # not native (or more than 64 pairs): the one-call form
+            return co.push_batches_with_filters(pairs)
+        n = len(pairs)
+        bypassed = (C.c_int32 * n)()
+        h, self.handle = self.handle, None
+        co.ctx.check(co.ctx.lib.ah_coalescer_push_batches_with_filters_end(co.ctx.handle, co._native, h, bypassed))
+        for i, (b, _f) in enumerate(pairs):
+            if bypassed[i]:
+                co._tagged[self.tags[i]] = b
+        self._keep = None

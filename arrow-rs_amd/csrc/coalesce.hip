@@ -38,6 +38,9 @@ ah_status ah_coalesce_wait(ah_context*, uint64_t);
 ah_status ah_filter_predicate_begin(ah_context*, const ah_array_view*, ah_filter_predicate**, uint64_t*, bool*);
 ah_status ah_filter_predicate_end(ah_context*, ah_filter_predicate*, uint64_t, bool);
 extern "C" void ah_filter_predicate_free(ah_context*, ah_filter_predicate*);
+// filter.hip: the counts of up to 64 predicates into the CALLER's pinned words, posted / waited separately
+ah_status ah_filter_predicates_begin(ah_context*, int32_t, const ah_array_view*, ah_filter_predicate**, uint64_t*, uint64_t*);
+ah_status ah_filter_predicates_end(ah_context*, int32_t, ah_filter_predicate**, const uint64_t*, uint64_t);
 
 extern "C" ah_status ah_take(ah_context*, const ah_array_view*, const ah_array_view*, int32_t, ah_array_out*);
 
@@ -121,6 +124,10 @@ struct ah_coalescer {
   uint64_t* pin = nullptr;      // own pinned words for the finished batches' null counts (host view / device view)
   uint64_t* pin_dev = nullptr;
   int ring_next = 0, ring_slots = 0;  // ring of ncols-word groups in `pin`
+  // two groups of 64 pinned count words for pushes whose counts are in flight (push_batches_with_filters_begin / _end)
+  uint64_t* cnt_pin = nullptr;
+  uint64_t* cnt_pin_dev = nullptr;
+  bool cnt_busy[2] = {false, false};
   double selectivity = 0.1;  // of the last filtered push: picks the speculative scatter's load-predication mode
   bool failed = false;       // a device error hit after rows had been enqueued into the in-progress batch
 };
@@ -366,12 +373,15 @@ extern "C" ah_status ah_coalescer_create(ah_context* ctx, int32_t n_columns, con
     st = ah_fail(ctx, AH_HIP_ERROR, "coalescer counter reset failed");
   if (st == AH_OK) {
     co->ring_slots = std::max(4, 512 / n_columns);
-    if (hipHostMalloc((void**)&co->pin, (size_t)co->ring_slots * n_columns * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+    const size_t ring_words = (size_t)co->ring_slots * n_columns;
+    if (hipHostMalloc((void**)&co->pin, (ring_words + 128) * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
       st = ah_fail(ctx, AH_OUT_OF_MEMORY, "coalescer pinned words");
     else {
       void* dp = nullptr;
       if (hipHostGetDevicePointer(&dp, co->pin, 0) != hipSuccess || !dp) dp = co->pin;
       co->pin_dev = (uint64_t*)dp;
+      co->cnt_pin = co->pin + ring_words;  // 2 x 64 count words behind the null-count ring
+      co->cnt_pin_dev = co->pin_dev + ring_words;
     }
   }
   if (st != AH_OK) {
@@ -587,6 +597,13 @@ extern "C" ah_status ah_coalescer_push_batch_with_filter(ah_context* ctx, ah_coa
   return st;
 }
 
+namespace {
+bool group_fusable(const ah_coalescer* co, int n, const ah_array_view* columns, const ah_array_view* filters);
+ah_status append_group(ah_context* ctx, ah_coalescer* co, int m, const ah_array_view* columns, const int64_t* num_rows,
+                       const ah_array_view* filters, const uint64_t* tags, int32_t* bypassed, ah_filter_predicate* const* preds,
+                       bool fusable);
+}  // namespace
+
 // `n` filtered pushes in one call, for a host that has several batches queued: the n count passes are enqueued
 // back to back and read with ONE wait (ah_filter_predicates_build), then every batch is appended exactly as n calls
 // of ah_coalescer_push_batch_with_filter would — the same output batches in the same order — without the GPU idling
@@ -606,9 +623,27 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_
   // Grouped scatter: when there is no bypass limit and every column of every batch has the same shape (one width,
   // all nullable), the batches that land in one output window leave through ONE launch (up to 8 per launch) — 2^24-row
   // batches pay the ramp and tail of a launch once per window instead of once per batch.  Same output batches, same order.
+  const bool fusable = group_fusable(co, n, columns, filters);
+  ah_status st = AH_OK;
+  for (int base = 0; base < n && st == AH_OK; base += 128) {
+    const int m = std::min(128, n - base);
+    std::vector<ah_filter_predicate*> preds((size_t)m, nullptr);
+    st = ah_filter_predicates_build(ctx, m, filters + base, preds.data());
+    if (st == AH_OK)
+      st = append_group(ctx, co, m, columns + (size_t)base * co->ncols, num_rows + base, filters + base, tags ? tags + base : nullptr,
+                        bypassed ? bypassed + base : nullptr, preds.data(), fusable);
+    for (auto* p : preds) ah_filter_predicate_free(ctx, p);
+  }
+  return st;
+}
+
+namespace {
+
+// the grouped scatter is possible when there is no bypass limit and every column of every batch has the same shape
+bool group_fusable(const ah_coalescer* co, int n, const ah_array_view* columns, const ah_array_view* filters) {
   bool fusable = co->limit < 0 && co->ncols <= 8 && n > 1;
   // generic columns (Boolean: width 0, Utf8 / LargeUtf8: width -1) keep piece lists, not in-progress buffers: they take
-  // the per-batch path below (an all-Boolean or all-Utf8 schema has "one width" too)
+  // the per-batch path (an all-Boolean or all-Utf8 schema has "one width" too)
   for (int k = 0; k < co->ncols && fusable; ++k)
     if (co->cols[k].generic || co->cols[k].width <= 0) fusable = false;
   for (int i = 0; i < n && fusable; ++i)
@@ -616,11 +651,16 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_
       const ah_array_view& v = columns[(size_t)i * co->ncols + k];
       if (co->cols[k].width != co->cols[0].width || !v.validity || v.null_count == 0 || filters[i].length > v.length) fusable = false;
     }
+  return fusable;
+}
+
+// `m` batches whose predicates (with their counts) are built: appended exactly as m calls of push_batch_with_filter would
+ah_status append_group(ah_context* ctx, ah_coalescer* co, int m, const ah_array_view* columns, const int64_t* num_rows,
+                       const ah_array_view* filters, const uint64_t* tags, int32_t* bypassed, ah_filter_predicate* const* preds,
+                       bool fusable) {
   ah_status st = AH_OK;
-  for (int base = 0; base < n && st == AH_OK; base += 128) {
-    const int m = std::min(128, n - base);
-    std::vector<ah_filter_predicate*> preds((size_t)m, nullptr);
-    st = ah_filter_predicates_build(ctx, m, filters + base, preds.data());
+  const int base = 0;
+  {
     if (st == AH_OK && fusable) {
       const ah_filter_predicate* seg_p[8];
       const ah_array_view* seg_c[8];
@@ -682,8 +722,88 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_
                                 bypassed ? &bypassed[i] : nullptr);
       }
     }
-    for (auto* p : preds) ah_filter_predicate_free(ctx, p);
   }
+  return st;
+}
+
+}  // namespace
+
+// The same push in two halves, for a host that has the NEXT group of batches in hand while this one is appended
+// (every grouped push ended in a count wait with the GPU idle behind it — 0.6-0.7 ms per 1e9 rows).
+//   _begin  checks the arguments, enqueues the count passes of the n (<= 64) predicates and returns at once; the counts
+//           travel to pinned words the coalescer owns (two groups may be in flight)
+//   _end    waits for those counts (long there if the host called _begin of the next group first: the GPU meanwhile
+//           runs the previous group's scatters) and appends the batches exactly as the one-call form does.
+// Between the two the caller keeps the batches' device buffers alive; the view structs themselves are copied.
+// Calls on one coalescer must be ended in the order they were begun.  An engine loop:
+//     h1 = begin(group 1); for g in 2..: { h2 = begin(group g); end(h1); h1 = h2; }  end(h1);
+struct ah_coalescer_push {
+  int n = 0, slot = -1;
+  bool counted = false;  // the predicates were built synchronously in _begin (shapes the multi-count pass does not take)
+  uint64_t seq = 0;
+  std::vector<ah_array_view> columns, filters;
+  std::vector<int64_t> num_rows;
+  std::vector<uint64_t> tags;
+  std::vector<ah_filter_predicate*> preds;
+};
+
+extern "C" ah_status ah_coalescer_push_batches_with_filters_begin(ah_context* ctx, ah_coalescer* co, int32_t n,
+                                                                  const ah_array_view* columns, const int64_t* num_rows,
+                                                                  const ah_array_view* filters, const uint64_t* tags,
+                                                                  ah_coalescer_push** handle) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !co || !handle || n < 0 || n > 64 || (n > 0 && (!columns || !num_rows || !filters))) return AH_INVALID_ARGUMENT;
+  *handle = nullptr;
+  hipSetDevice(ctx->device);
+  for (int i = 0; i < n; ++i) {
+    if (num_rows[i] < 0) return AH_INVALID_ARGUMENT;
+    AH_TRY(check_filter(ctx, co, columns + (size_t)i * co->ncols, num_rows[i], &filters[i]));
+  }
+  auto* h = new ah_coalescer_push();
+  h->n = n;
+  h->columns.assign(columns, columns + (size_t)n * co->ncols);
+  h->filters.assign(filters, filters + n);
+  h->num_rows.assign(num_rows, num_rows + n);
+  if (tags) h->tags.assign(tags, tags + n);
+  h->preds.assign((size_t)n, nullptr);
+  ah_status st = AH_OK;
+  if (n > 0) {
+    const int slot = !co->cnt_busy[0] ? 0 : (!co->cnt_busy[1] ? 1 : -1);
+    st = slot < 0 ? AH_NOT_YET_IMPLEMENTED
+                  : ah_filter_predicates_begin(ctx, n, h->filters.data(), h->preds.data(), co->cnt_pin_dev + 64 * slot, &h->seq);
+    if (st == AH_OK) {
+      h->slot = slot;
+      co->cnt_busy[slot] = true;
+    } else if (st == AH_NOT_YET_IMPLEMENTED) {  // both slots in flight, or a predicate the multi-count pass does not take
+      st = ah_filter_predicates_build(ctx, n, h->filters.data(), h->preds.data());
+      h->counted = st == AH_OK;
+    }
+  }
+  if (st != AH_OK) {
+    delete h;
+    return st;
+  }
+  *handle = h;
+  return AH_OK;
+}
+
+extern "C" ah_status ah_coalescer_push_batches_with_filters_end(ah_context* ctx, ah_coalescer* co, ah_coalescer_push* h,
+                                                                int32_t* bypassed) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !co || !h) return AH_INVALID_ARGUMENT;
+  hipSetDevice(ctx->device);
+  ah_status st = AH_OK;
+  for (int i = 0; i < h->n && bypassed; ++i) bypassed[i] = 0;
+  if (h->slot >= 0) {
+    st = ah_filter_predicates_end(ctx, h->n, h->preds.data(), co->cnt_pin + 64 * h->slot, h->seq);
+    co->cnt_busy[h->slot] = false;
+  }
+  if (st == AH_OK && co->failed) st = ah_fail(ctx, AH_INVALID_ARGUMENT, "BatchCoalescer: unusable after an earlier device error");
+  if (st == AH_OK && h->n > 0)
+    st = append_group(ctx, co, h->n, h->columns.data(), h->num_rows.data(), h->filters.data(), h->tags.empty() ? nullptr : h->tags.data(),
+                      bypassed, h->preds.data(), group_fusable(co, h->n, h->columns.data(), h->filters.data()));
+  for (auto* p : h->preds) ah_filter_predicate_free(ctx, p);
+  delete h;
   return st;
 }
 

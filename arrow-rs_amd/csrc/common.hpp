@@ -114,6 +114,7 @@ hipError_t ah_d2h_wait(ah_context* ctx, void* pinned_dst, const void* dev_src, s
 // for kernels that post the mailbox themselves (ah_mail_post): reserve the next sequence number, wait for it
 static inline uint64_t ah_mail_next(ah_context* ctx) { return ++ctx->mail_seq; }
 hipError_t ah_mail_wait(ah_context* ctx, uint64_t seq);
+hipError_t ah_mail_post_async(ah_context* ctx, uint64_t* seq_out);  // post only; pair with ah_mail_wait
 
 // Deferred mode plumbing.  A call that can run deferred hands AH_COUNT(ctx, &n) to the helpers that
 // would read a popcount back (nullptr = no read-back), ends with ah_end_of_call_sync() and reports

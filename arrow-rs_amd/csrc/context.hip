@@ -244,6 +244,15 @@ hipError_t ah_d2h(ah_context* ctx, void* pinned_dst, const void* dev_src, size_t
   return hipGetLastError();
 }
 
+// the first half of ah_stream_wait: post the next mailbox sequence number behind everything enqueued so far and return
+// it; ah_mail_wait(ctx, seq) is the second half.  A caller that keeps enqueueing in between overlaps its own wait.
+hipError_t ah_mail_post_async(ah_context* ctx, uint64_t* seq_out) {
+  const uint64_t seq = ah_mail_next(ctx);
+  mail_kernel<<<1, 64, 0, ctx->stream>>>(nullptr, 0, ctx->pinned_dev, ctx->pinned_dev, seq, 0, 0);
+  *seq_out = seq;
+  return hipGetLastError();
+}
+
 hipError_t ah_stream_wait(ah_context* ctx) {
   if (ctx->wait_mode == 1) {
     hipError_t e = hipStreamSynchronize(ctx->stream);

@@ -1109,6 +1109,84 @@ extern "C" ah_status ah_filter_predicates_build(ah_context* ctx, int32_t n, cons
   return AH_OK;
 }
 
+// ah_filter_predicates_build in two halves, for a caller that wants its OWN count slots so that two groups can be in flight
+// (BatchCoalescer's begin / end pushes): `begin` enqueues the count passes of n (<= 64) predicates whose K's land in
+// pin_dev[0 .. n) (the device view of the caller's pinned words) and posts the mailbox behind them (*seq); `end` waits for
+// that sequence number and fills in the counts from the host view.  Only the multi-count shape (non-empty Boolean
+// predicates of at most 64 Mi rows): anything else -> AH_NOT_YET_IMPLEMENTED with nothing enqueued (use the one-call build).
+ah_status ah_filter_predicates_begin(ah_context* ctx, int32_t n, const ah_array_view* predicates, ah_filter_predicate** outs,
+                                     uint64_t* pin_dev, uint64_t* seq) {
+  if (n < 1 || n > 64) return AH_NOT_YET_IMPLEMENTED;
+  for (int i = 0; i < n; ++i) {
+    outs[i] = nullptr;
+    const ah_array_view* pv = &predicates[i];
+    const int64_t nchunks = pv->type == AH_BOOL && pv->length > 0 ? ah_ceil_div(pv->length, CHUNK_ROWS) : 0;
+    if (nchunks == 0 || nchunks > 65536) return AH_NOT_YET_IMPLEMENTED;
+  }
+  ah_status st = AH_OK;
+  CountMulti cm{};
+  int ncm = 0, cm_first = 0;
+  int64_t cm_groups = 0;
+  auto flush_multi = [&]() {
+    if (ncm == 0) return;
+    ah_prof_scope ps(ctx, "filter_count");
+    filter_count_small_multi_kernel<<<dim3((unsigned)cm_groups, (unsigned)ncm), 64, 0, ctx->stream>>>(cm);
+    filter_group_scan_multi_kernel<<<(unsigned)ncm, 1024, 0, ctx->stream>>>(cm, pin_dev, cm_first);
+    ncm = 0;
+    cm_groups = 0;
+  };
+  for (int i = 0; i < n && st == AH_OK; ++i) {
+    const ah_array_view* pv = &predicates[i];
+    const int64_t nchunks = ah_ceil_div(pv->length, CHUNK_ROWS);
+    auto* p = new ah_filter_predicate();
+    p->len = pv->length;
+    p->mask = make_bitview(pv->values, pv->values_bit_offset);
+    p->mask_valid = (pv->validity && pv->null_count != 0) ? make_bitview(pv->validity, pv->validity_bit_offset) : BitView{nullptr, 0};
+    p->group_shift = 6;
+    const int64_t ngroups = ah_ceil_div(nchunks, 64);
+    const size_t b_chunk = ((size_t)nchunks * 4 + 255) & ~(size_t)255, b_gt = ((size_t)ngroups * 4 + 255) & ~(size_t)255,
+                 b_gp = ((size_t)ngroups * 8 + 255) & ~(size_t)255;
+    st = ah_pool_alloc(ctx, b_chunk + b_gt + b_gp + 256, &p->block);
+    if (st != AH_OK) {
+      delete p;
+      break;
+    }
+    char* base = (char*)p->block;
+    p->chunk_prefix = (uint32_t*)base;
+    p->group_prefix = (unsigned long long*)(base + b_chunk + b_gt);
+    p->total_dev = (unsigned long long*)(base + b_chunk + b_gt + b_gp);
+    outs[i] = p;
+    if (ncm == 0) cm_first = i;
+    CountMulti::One& o = cm.p[ncm++];
+    o.mask = p->mask, o.mask_valid = p->mask_valid, o.len = p->len, o.chunk_prefix = p->chunk_prefix;
+    o.group_total = (uint32_t*)(base + b_chunk), o.group_prefix = p->group_prefix, o.total = p->total_dev, o.ngroups = ngroups;
+    cm_groups = std::max(cm_groups, ngroups);
+    if (ncm == 8) flush_multi();
+  }
+  if (st == AH_OK) {
+    flush_multi();
+    ctx->inflight = true;
+    hipError_t e = ah_mail_post_async(ctx, seq);
+    if (e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "filter count failed: %s", hipGetErrorString(e));
+  }
+  if (st != AH_OK) {
+    (void)ah_stream_wait(ctx);  // count kernels of earlier predicates may be running on the blocks freed below
+    for (int i = 0; i < n; ++i) {
+      ah_filter_predicate_free(ctx, outs[i]);
+      outs[i] = nullptr;
+    }
+  }
+  return st;
+}
+ah_status ah_filter_predicates_end(ah_context* ctx, int32_t n, ah_filter_predicate** outs, const uint64_t* pin_host, uint64_t seq) {
+  const bool later_work = seq != ctx->mail_seq || ctx->inflight;  // enqueued behind the post: still running afterwards
+  hipError_t e = ah_mail_wait(ctx, seq);
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "filter count failed: %s", hipGetErrorString(e));
+  if (later_work && ctx->wait_mode != 1) ctx->inflight = true;  // ah_mail_wait cleared it for the work BEFORE the post only
+  for (int i = 0; i < n; ++i) outs[i]->count = (int64_t)__atomic_load_n(&pin_host[i], __ATOMIC_RELAXED);
+  return AH_OK;
+}
+
 extern "C" int64_t ah_filter_predicate_count(const ah_filter_predicate* p) { return p ? p->count : 0; }
 
 extern "C" void ah_filter_predicate_free(ah_context* ctx, ah_filter_predicate* p) {

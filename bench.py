@@ -756,22 +756,33 @@ def build_workload(env, wl):
         # (ah_coalescer_push_batches_with_filters: one count read-back for the group, the batches of one output window
         # scattered by one launch).  The default run reports the grouped form (8) and, beside it, the single-push time.
         group = max(1, int(os.environ.get("AH_COALESCE_GROUP", "8")))
-        W["group"] = group
+        pipelined = os.environ.get("AH_COALESCE_PIPELINE", "1") != "0"
+        W["group"], W["pipelined"] = group, pipelined
 
         def step(_r):
             co = K.BatchCoalescer.new(["a", "b"], [A.Int64, A.Float64], target, ctx)
             out_rows = 0
+            pending = None
             for i in range(0, len(batches), group):
                 # batches finished by EARLIER pushes are handed downstream after this push has been enqueued: fetching a
                 # batch waits for its scatters, and a push's own count read-back has already waited for everything the
                 # earlier pushes enqueued — so the fetch costs nothing and the GPU has this push's work queued meanwhile
                 ready = co.completed_count()
-                if group == 1:
+                if pipelined:
+                    # the engine holds the NEXT group already: its count passes are enqueued before this group is appended
+                    # (ah_coalescer_push_batches_with_filters_begin / _end), so no count round trip leaves the GPU idle
+                    nxt = co.push_batches_with_filters_begin(batches[i:i + group])
+                    if pending is not None:
+                        pending.end()
+                    pending = nxt
+                elif group == 1:
                     co.push_batch_with_filter(*batches[i])
                 else:
                     co.push_batches_with_filters(batches[i:i + group])
                 for _ in range(ready):
                     out_rows += co.next_completed_batch().num_rows()
+            if pending is not None:
+                pending.end()
             co.finish_buffered_batch()
             while co.has_completed_batch():
                 out_rows += co.next_completed_batch().num_rows()
@@ -980,8 +991,10 @@ def describe(env, wl, W, prof, out, steps):
             "predicate_filter": "SURVEY 8f-2: filter(a, and_kleene(lt(a, 0), gt_eq(b, 0.0))) on Int64 a, Float64 b with NullBuffers",
             "coalesce": f"SURVEY 8f-1: BatchCoalescer.push_batch_with_filter, Int64+Float64, "
                         f"{args.batch_rows}-row batches"
-                        + (f", pushed {W.get('group', 1)} at a time (ah_coalescer_push_batches_with_filters)"
-                           if W.get("group", 1) > 1 else ", one push_batch_with_filter per batch")}[wl] + f", {n} rows per GPU"
+                        + (f", pushed {W.get('group', 1)} at a time (ah_coalescer_push_batches_with_filters"
+                           + ("_begin / _end: the next group's counts are enqueued before this group is appended)" if W.get("pipelined") else ")")
+                           if W.get("group", 1) > 1 else ", one push_batch_with_filter per batch"
+                           + (" (pipelined: begin of batch i + 1 before end of batch i)" if W.get("pipelined") else ""))}[wl] + f", {n} rows per GPU"
     dtype = "int64" if wl in ("aggregate", "sort") else "int64+f64" if wl == "record_batch" else "f64"
     return dominant, dom_avg, dom_n, alg, text, f"{wl}_Mrows_per_s", dtype
 
@@ -1035,8 +1048,9 @@ def _compact_config(c):
         rf = c["roofline"]
         out.update(kernel=rf.get("kernel"), avg_launch_ms=rf.get("avg_launch_ms"), alg_bytes=rf.get("algorithmic_bytes_per_launch"),
                    frac=rf.get("frac"))
-    if isinstance(c.get("single_push"), dict):
-        out["single_push_ms"] = c["single_push"].get("ms_without_kernel_events")
+    for k in ("single_push", "single_push_pipelined", "grouped_not_pipelined"):
+        if isinstance(c.get(k), dict):
+            out[k + "_ms"] = c[k].get("ms_without_kernel_events")
     if isinstance(c.get("exchange"), dict):
         out["exchange"] = {k: c["exchange"][k] for k in ("peers", "bytes_to_each_peer", "total_ms", "per_link_GBps") if k in c["exchange"]}
     return out
@@ -1435,24 +1449,28 @@ def main():
                             "dtype": dtype, "roofline": roofline_obj(kern, alg, avg_ms, launches),
                             "kernel_avg_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof2.items()},
                             "host_gap_ms": round(ms2 - sum(v[0] for v in prof2.values()) / args.config_steps, 4)}
-                if w2 == "coalesce":  # the single-push form of the same step, beside the grouped one
-                    try:
-                        os.environ["AH_COALESCE_GROUP"] = "1"
-                        W3 = build_workload(env, "coalesce")
-                        for _ in range(2):
-                            W3["step"](False)
-                        env.sync_all()
-                        t0 = time.perf_counter()
-                        for _ in range(args.config_steps):
-                            W3["step"](False)
-                        env.sync_all()
-                        ms1 = (time.perf_counter() - t0) / args.config_steps * 1e3
-                        dest[w2]["single_push"] = {"ms_without_kernel_events": round(ms1, 4),
-                                                   "frac_without_kernel_events": round(alg / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                                   "what": "the same batches through one ah_coalescer_push_batch_with_filter call each"}
-                        W3 = None
-                    finally:
-                        os.environ.pop("AH_COALESCE_GROUP", None)
+                if w2 == "coalesce":  # the single-push forms of the same step, beside the grouped one
+                    for key, pipe, what in (("single_push", "0", "the same batches through one synchronous ah_coalescer_push_batch_with_filter call each"),
+                                            ("single_push_pipelined", "1", "one batch per push, begin of batch i + 1 before end of batch i"),
+                                            ("grouped_not_pipelined", None, "8 batches per synchronous ah_coalescer_push_batches_with_filters call (round 3's form)")):
+                        try:
+                            os.environ["AH_COALESCE_GROUP"] = "1" if pipe is not None else "8"
+                            os.environ["AH_COALESCE_PIPELINE"] = pipe or "0"
+                            W3 = build_workload(env, "coalesce")
+                            for _ in range(2):
+                                W3["step"](False)
+                            env.sync_all()
+                            t0 = time.perf_counter()
+                            for _ in range(args.config_steps):
+                                W3["step"](False)
+                            env.sync_all()
+                            ms1 = (time.perf_counter() - t0) / args.config_steps * 1e3
+                            dest[w2][key] = {"ms_without_kernel_events": round(ms1, 4),
+                                             "frac_without_kernel_events": round(alg / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "what": what}
+                            W3 = None
+                        finally:
+                            os.environ.pop("AH_COALESCE_GROUP", None)
+                            os.environ.pop("AH_COALESCE_PIPELINE", None)
                 if w2 == "coalesce":  # many small launches per step: the per-kernel HIP events themselves cost time
                     env.sync_all()
                     t0 = time.perf_counter()

@@ -319,6 +319,20 @@ AH_API ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_coal
                                                         const ah_array_view* columns, const int64_t* num_rows,
                                                         const ah_array_view* filters, const uint64_t* tags /* nullable */,
                                                         int32_t* bypassed /* n entries, nullable */);
+/* The same push in two halves, for a host that already holds the NEXT group of batches while this one is appended:
+ * _begin checks the arguments, ENQUEUES the count passes of the n (<= 64) predicates and returns at once (their counts
+ * travel to pinned words the coalescer owns; two groups may be in flight); _end waits for them and appends the batches
+ * exactly as the one-call form does, then frees the handle.  Calling _begin of group g + 1 before _end of group g keeps
+ * the GPU busy with group g's scatters while group g + 1's counts make their round trip to the host.  The view structs
+ * are copied by _begin; the device buffers behind them must stay alive until _end.  Handles of one coalescer are ended
+ * in the order they were begun. */
+typedef struct ah_coalescer_push ah_coalescer_push;
+AH_API ah_status ah_coalescer_push_batches_with_filters_begin(ah_context* ctx, ah_coalescer* co, int32_t n,
+                                                              const ah_array_view* columns, const int64_t* num_rows,
+                                                              const ah_array_view* filters, const uint64_t* tags /* nullable */,
+                                                              ah_coalescer_push** handle);
+AH_API ah_status ah_coalescer_push_batches_with_filters_end(ah_context* ctx, ah_coalescer* co, ah_coalescer_push* handle,
+                                                            int32_t* bypassed /* n entries, nullable */);
 /* push_batch_with_indices (coalesce.rs:289): take_record_batch(batch, indices), then push_batch of the result; indices
  * as for ah_take (unchecked: an out-of-range index is the reference's panic, AH_PANIC). */
 AH_API ah_status ah_coalescer_push_batch_with_indices(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns,

@@ -200,6 +200,24 @@ def test_coalescer_filtered_pushes_every_row(ctx, oracle):
     co.finish_buffered_batch()
     while co.has_completed_batch():
         got.append(co.next_completed_batch())
+    # round 4: the same stream through the PIPELINED grouped push (begin of group g + 1 before end of group g: the counts
+    # of the next group make their round trip while this group's scatters run) must produce the same output batches
+    co2 = K.BatchCoalescer.new(["a", "b"], [A.Int64, A.Float64], target, ctx)
+    pairs = [(A.RecordBatch(["a", "b"], [a.slice(i, min(br, n - i)), b.slice(i, min(br, n - i))]), pred.slice(i, min(br, n - i)))
+             for i in range(0, n, br)]
+    got2, pending = [], None
+    for g0 in range(0, len(pairs), 8):
+        nxt = co2.push_batches_with_filters_begin(pairs[g0:g0 + 8])
+        if pending is not None:
+            pending.end()
+        pending = nxt
+        while co2.has_completed_batch():
+            got2.append(co2.next_completed_batch())
+    pending.end()
+    co2.finish_buffered_batch()
+    while co2.has_completed_batch():
+        got2.append(co2.next_completed_batch())
+    assert [g.num_rows() for g in got2] == [g.num_rows() for g in got]
 
     def filt(job):
         c0, rows = job
@@ -222,20 +240,21 @@ def test_coalescer_filtered_pushes_every_row(ctx, oracle):
     for c in range(2):
         ev = np.concatenate([p[c][0] for p in parts])
         eb = np.concatenate([p[c][1] for p in parts])
-        off = 0
-        for bi, g in enumerate(got):
-            k, col = g.num_rows(), g.columns[c]
-            assert col.length == k
-            dv = _dev_bytes(ctx, col.values, 0, k * 8).view(np.uint64)
-            assert np.array_equal(dv, ev[off:off + k]), f"column {c}, output batch {bi}: values"
-            exp_valid = eb[off:off + k]
-            if col.validity is None:
-                assert exp_valid.all(), f"column {c}, output batch {bi}: null buffer missing"
-            else:
-                assert np.array_equal(_unpack(_dev_bytes(ctx, col.validity, 0, (k + 7) // 8), k), exp_valid), \
-                    f"column {c}, output batch {bi}: validity"
-            assert col.null_count() == int(k - exp_valid.sum()), f"column {c}, output batch {bi}: null_count"
-            off += k
+        for which, batches in (("single pushes", got), ("pipelined grouped pushes", got2)):
+            off = 0
+            for bi, g in enumerate(batches):
+                k, col = g.num_rows(), g.columns[c]
+                assert col.length == k
+                dv = _dev_bytes(ctx, col.values, 0, k * 8).view(np.uint64)
+                assert np.array_equal(dv, ev[off:off + k]), f"{which}: column {c}, output batch {bi}: values"
+                exp_valid = eb[off:off + k]
+                if col.validity is None:
+                    assert exp_valid.all(), f"{which}: column {c}, output batch {bi}: null buffer missing"
+                else:
+                    assert np.array_equal(_unpack(_dev_bytes(ctx, col.validity, 0, (k + 7) // 8), k), exp_valid), \
+                        f"{which}: column {c}, output batch {bi}: validity"
+                assert col.null_count() == int(k - exp_valid.sum()), f"{which}: column {c}, output batch {bi}: null_count"
+                off += k
 
 
 # ------------------------------------------------------------------------------------------- configs[2]

@@ -1139,6 +1139,58 @@ def test_batch_coalescer_grouped_pushes_equal_single_pushes(ctx, oracle):
         assert co.is_empty()
 
 
+@pytest.mark.parametrize("schema", ["i64_f64", "i32x3", "mixed_generic", "limit"])
+def test_batch_coalescer_pipelined_pushes_equal_the_model(ctx, oracle, schema):
+    """push_batches_with_filters_begin / _end (round 4): the counts of group g + 1 are enqueued BEFORE group g is appended,
+    two groups in flight.  The output batches must be exactly those of the coalesce.rs model fed the same pairs in the
+    same order — fused multi-scatter shapes, generic columns, a bypass limit, groups of one (the pipelined single push),
+    empty predicates and predicates shorter than their batch."""
+    from coalesce_model import ModelCoalescer
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("pipe-" + schema).encode()))
+    dts = {"i64_f64": [A.Int64, A.Float64], "i32x3": [A.Int32, A.Float32, A.UInt32], "mixed_generic": [A.Utf8, A.Int64, A.Boolean],
+           "limit": [A.Int64, A.Float64]}[schema]
+    names = [f"c{i}" for i in range(len(dts))]
+    limit = 300 if schema == "limit" else None
+
+    def col(dt, n):
+        valid = rng.random(n) < 0.85
+        if dt in (A.Utf8, A.LargeUtf8):
+            return HostArray(dt, ["v" * int(rng.integers(0, 5)) + str(rng.integers(0, 999)) for _ in range(n)], valid)
+        return HostArray(dt, _rand_values(rng, dt, n), valid)
+
+    for trial in range(3):
+        target = int(rng.choice([60, 1000, 30_000]))
+        co = K.BatchCoalescer.new(names, dts, target, ctx).with_biggest_coalesce_batch_size(limit)
+        model = ModelCoalescer(oracle, dts, target)
+        model.limit = limit
+        groups, hosts = [], []
+        for _ in range(10):
+            g, hg = [], []
+            for _ in range(int(rng.integers(1, 9))):
+                n = int(rng.integers(1, 4000))
+                cols = [col(dt, n) for dt in dts]
+                flen = n - int(rng.integers(0, min(n, 3) + 1))
+                f = HostArray(A.Boolean, rng.random(flen) < float(rng.choice([0.0, 0.03, 0.4, 1.0])), (rng.random(flen) < 0.9) if rng.random() < 0.3 else None)
+                g.append((A.RecordBatch(names, [c.to_device(ctx) for c in cols]), f.to_device(ctx)))
+                hg.append((cols, f))
+            groups.append(g)
+            hosts.append(hg)
+        pending, pending_host = co.push_batches_with_filters_begin(groups[0]), hosts[0]
+        for gi in range(1, len(groups) + 1):
+            nxt = co.push_batches_with_filters_begin(groups[gi]) if gi < len(groups) else None
+            pending.end()
+            for cols, f in pending_host:
+                model.push_with_filter(cols, f)
+            assert co.get_buffered_rows() == model.buffered, f"{schema} trial {trial} group {gi - 1}"
+            _check_batches(co, model, f"pipelined {schema} trial {trial} group {gi - 1}", presence_cols=[] if schema == "mixed_generic" else None)
+            pending, pending_host = nxt, (hosts[gi] if gi < len(groups) else None)
+        co.finish_buffered_batch()
+        model.finish()
+        _check_batches(co, model, f"pipelined {schema} trial {trial} final", presence_cols=[] if schema == "mixed_generic" else None)
+        assert co.is_empty()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_batch_coalescer_grouped_pushes_one_launch_per_window(ctx, oracle, seed):
     """Same-width, all-nullable columns and no bypass limit: the grouped push scatters the batches that land in one
