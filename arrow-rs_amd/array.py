@@ -416,6 +416,20 @@ class _RawMem:
         self.ptr, self.nbytes, self.owner = ptr, nbytes, owner
 
 
+class _OutBuffer:
+    """A device buffer owned by an ah_array_out (a produced view array's data buffer): ptr / nbytes / to_numpy like
+    DeviceBuffer, alive as long as the owner."""
+
+    def __init__(self, ctx, ptr, nbytes, owner):
+        self.ctx, self.ptr, self.nbytes, self.owner = ctx, int(ptr), int(nbytes), owner
+
+    def to_numpy(self, dtype=np.uint8):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        if out.nbytes:
+            self.ctx.check(self.ctx.lib.ah_memcpy_dtoh(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+
 def pack_bits(bools, bit_offset=0):
     """LSB-first bit packing with a leading bit offset; padded to whole u64 words
     (BooleanBuffer layout, arrow-buffer/src/buffer/boolean.rs:97-104)."""
@@ -582,9 +596,15 @@ class Array:
                   out.validity_bit_offset, out.null_count, offs)
         arr._owner = owner
         if data_type.physical in (L.AH_UTF8_VIEW, L.AH_BINARY_VIEW):
-            # filter_byte_view / take_byte_view: same buffer list on the result (filter.rs:937, take.rs:638)
-            src = next((k for k in keepalive if getattr(k, "data_buffers", None) is not None), None)
-            arr.data_buffers = src.data_buffers if src is not None else []
+            if out.offsets or not keepalive:
+                # a view array PRODUCED here (cast -> Utf8View): its one variadic data buffer travels in the `offsets`
+                # fields of the ah_array_out (a view array has no offsets); no buffer at all when every string is inline
+                arr.offsets = None
+                arr.data_buffers = [_OutBuffer(ctx, out.offsets, out.offsets_bytes, owner)] if out.offsets else []
+            else:
+                # filter_byte_view / take_byte_view: same buffer list on the result (filter.rs:937, take.rs:638)
+                src = next((k for k in keepalive if getattr(k, "data_buffers", None) is not None), None)
+                arr.data_buffers = src.data_buffers if src is not None else []
         return arr
 
     # ---- Arrow C Data Interface / pyarrow (arrow-array/src/ffi.rs:231-254, arrow-pyarrow/src/lib.rs:199-257)

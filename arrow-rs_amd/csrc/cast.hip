@@ -19,6 +19,7 @@
 #include <limits>
 #include <type_traits>
 
+ah_status ah_cast_to_string_view(ah_context* ctx, const ah_array_view* values, ah_array_out* out);  // cast_view.hip
 ah_status ah_cast_to_string(ah_context* ctx, const ah_array_view* values, ah_type to_type,
                             ah_array_out* out);  // cast_string.hip
 ah_status ah_cast_bool(ah_context* ctx, const ah_array_view* values, ah_type to_type, ah_array_out* out);  // cast_bool.hip
@@ -368,6 +369,8 @@ extern "C" int32_t ah_can_cast_types(ah_type from, ah_type to) {
   if ((from == AH_BOOL && is_numeric(to)) || (is_numeric(from) && to == AH_BOOL)) return 1;  // cast/mod.rs:254-255
   if (is_numeric(from) && (to == AH_UTF8 || to == AH_LARGE_UTF8)) return 1;
   if ((from == AH_UTF8 || from == AH_LARGE_UTF8) && is_numeric(to)) return 1;  // cast/mod.rs `(Utf8, _)` parse arms
+  // cast/mod.rs:278 `(Utf8 | LargeUtf8, Utf8View)`, :281 `(_, Utf8View) => from_type.is_primitive()`
+  if (to == AH_UTF8_VIEW && (is_numeric(from) || from == AH_UTF8 || from == AH_LARGE_UTF8)) return 1;
   return 0;
 }
 
@@ -381,6 +384,7 @@ extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_ty
   if (!ah_can_cast_types(from, to_type))
     return ah_fail(ctx, AH_CAST_ERROR, "Casting from %s to %s not supported", ah_type_name(from),
                    ah_type_name(to_type));
+  if (to_type == AH_UTF8_VIEW) return ah_cast_to_string_view(ctx, values, out);  // cast/mod.rs:1546 (numbers), :1302 / :1432 (Utf8 / LargeUtf8)
   if ((from == AH_UTF8 || from == AH_LARGE_UTF8) && is_numeric(to_type)) return ah_cast_parse(ctx, values, to_type, safe, out);
   if (to_type == AH_UTF8 || to_type == AH_LARGE_UTF8) return ah_cast_to_string(ctx, values, to_type, out);
   if ((from == AH_BOOL) != (to_type == AH_BOOL)) return ah_cast_bool(ctx, values, to_type, out);

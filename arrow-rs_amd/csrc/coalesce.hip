@@ -480,7 +480,18 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
     std::vector<ah_array_out> outs((size_t)co->ncols);
     std::vector<ah_array_view> views((size_t)co->ncols);
     for (auto& o : outs) ah_out_init(&o);
-    for (int i = 0; i < co->ncols && st == AH_OK; ++i) st = ah_filter_predicate_apply(ctx, p, &columns[i], &outs[i]);
+    for (int i = 0; i < co->ncols && st == AH_OK; ++i) {
+      st = ah_filter_predicate_apply(ctx, p, &columns[i], &outs[i]);
+      if (st == AH_OK && co->cols[i].generic && (outs[i].flags & AH_OUT_BORROWED)) {
+        // the `All` strategy of a predicate shorter than its batch: a borrowed slice — a generic column would ADOPT it and
+        // keep the caller's buffers past this call.  Copy the rows out instead.
+        ah_array_release(ctx, &outs[i]);
+        const ah_array_view& sv = columns[i];
+        const ah_array_view sl = slice_view(sv.type, sv.values, sv.values_bit_offset, sv.validity, sv.validity_bit_offset, sv.offsets,
+                                            sv.length, sv.null_count, 0, selected);
+        st = ah_concat(ctx, 1, &sl, &outs[i]);
+      }
+    }
     if (st == AH_OK) {
       for (int i = 0; i < co->ncols; ++i) {
         ah_array_view& v = views[i];
@@ -523,14 +534,17 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
     if (co->cols[i].generic) {  // copy_rows_by_filter_from of GenericInProgressArray (generic.rs:81-88): keep the filtered array
       ah_array_out piece;
       st = ah_filter_predicate_apply(ctx, p, &columns[i], &piece);
-      if (st == AH_OK) {
-        if (piece.flags & AH_OUT_BORROWED) {  // (cannot happen here: selected < rows) never keep borrowed buffers
-          ah_array_release(ctx, &piece);
-          st = ah_fail(ctx, AH_INVALID_ARGUMENT, "coalescer: unexpected borrowed filter result");
-        } else {
-          co->cols[i].pieces.push_back(GenPiece{std::make_shared<GenOwner>(ctx, piece), 0, selected});
-        }
+      if (st == AH_OK && (piece.flags & AH_OUT_BORROWED)) {
+        // a predicate SHORTER than its batch that selects every one of its rows takes filter's `All` strategy: the result
+        // is a borrowed slice of the caller's buffers (filter.rs:546), which the coalescer may not keep past this call —
+        // copy those rows out like an unfiltered push does
+        ah_array_release(ctx, &piece);
+        const ah_array_view& sv = columns[i];
+        const ah_array_view sl = slice_view(sv.type, sv.values, sv.values_bit_offset, sv.validity, sv.validity_bit_offset, sv.offsets,
+                                            sv.length, sv.null_count, 0, selected);
+        st = ah_concat(ctx, 1, &sl, &piece);
       }
+      if (st == AH_OK) co->cols[i].pieces.push_back(GenPiece{std::make_shared<GenOwner>(ctx, piece), 0, selected});
     } else {
       st = ah_filter_predicate_apply_into_acc(ctx, p, &columns[i], co->cols[i].values, co->cols[i].validity, co->buffered,
                                               co->acc + (size_t)i * 64);

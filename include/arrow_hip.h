@@ -119,7 +119,10 @@ typedef struct ah_array_out {
   uint8_t* validity;       /* NULL when the result carries no null buffer */
   int64_t validity_bytes;
   int64_t validity_bit_offset; /* 0 unless AH_OUT_BORROWED */
-  void* offsets;           /* AH_UTF8 / AH_LARGE_UTF8 only: length+1 offsets */
+  void* offsets;           /* AH_UTF8 / AH_LARGE_UTF8: length+1 offsets.  AH_UTF8_VIEW PRODUCED by ah_cast: the result's one
+                              variadic data buffer (buffer index 0 of its views: the strings longer than 12 bytes, back
+                              to back), NULL when every string is inline; views that pass through filter / take keep
+                              referring to the caller's buffers and leave this NULL */
   int64_t offsets_bytes;
   int32_t flags;
 } ah_array_out;

@@ -784,6 +784,75 @@ def test_cast_f32_and_ints_to_utf8(ctx, oracle):
         check(K.cast(h.to_device(ctx), A.Utf8), oracle.cast(h, A.Utf8), str(dt))
 
 
+def _check_views(got, exp_strings_host, msg):
+    """A Utf8View result against the oracle's Utf8 strings of the same cast (value_to_string_view and value_to_string
+    share the formatter, cast/string.rs:21 vs :41) + the layout rules of a view array (byte_view.rs): length, <= 12
+    bytes inline and zero padded, longer ones {4-byte prefix, buffer 0, offset} into the one data buffer."""
+    assert got.data_type == A.Utf8View and got.length == len(exp_strings_host)
+    ev = exp_strings_host.valid if exp_strings_host.valid is not None else np.ones(len(exp_strings_host), dtype=bool)
+    assert np.array_equal(got.valid_mask(), ev), f"{msg}: validity"
+    assert (got.validity is None) == (exp_strings_host.null_count == 0), f"{msg}: null buffer presence"
+    vals = got.values_numpy()  # decodes the views through the data buffer
+    for i, (g, e, v) in enumerate(zip(vals, exp_strings_host.values, ev)):
+        if v and g != e:
+            raise AssertionError(f"{msg}: row {i}: got {g!r} expected {e!r}")
+    raw = A.array._copy_dtoh(got.ctx, got.values.ptr, got.length * 16).reshape(-1, 16)
+    lens = raw[:, :4].copy().view(np.uint32).ravel()
+    inline = ev & (lens <= 12)
+    pad = np.arange(12)[None, :] >= lens[:, None]
+    assert not (raw[:, 4:][inline] * pad[inline]).any(), f"{msg}: inline views must be zero padded"
+    assert not raw[~ev].any(), f"{msg}: null rows are all-zero views (append_null)"
+    long_rows = ev & (lens > 12)
+    nb = sum(len(e.encode()) for e, v, ln in zip(exp_strings_host.values, ev, lens) if v and ln > 12)
+    if long_rows.any():
+        assert len(got.data_buffers) == 1 and got.data_buffers[0].nbytes == nb, f"{msg}: one exact-size data buffer"
+        assert not raw[long_rows][:, 8:12].any(), f"{msg}: buffer index 0"
+    else:
+        assert got.data_buffers == [], f"{msg}: no data buffer when every string is inline"
+
+
+def test_cast_to_utf8view(ctx, oracle):
+    """The `-> Utf8View` arms (VERDICT r03 missing #3): numbers (cast/mod.rs:1546 -> value_to_string_view, cast/string.rs:41)
+    and Utf8 / LargeUtf8 (:1302 / :1432).  The reference's own goldens go through THIS arm: test_cast_float_to_utf8view
+    (mod.rs:4857-4876: [1.5, 2.5, None] for Float32 and Float64) and test_cast_int_to_utf8view (:4827-4853:
+    [None, 8, 9, 10] for every integer type)."""
+    for dt in (A.Float32, A.Float64):
+        h = HostArray(dt, np.array([1.5, 2.5, 0.0], dtype=dt.np_dtype), np.array([True, True, False]))
+        assert K.can_cast_types(dt, A.Utf8View)
+        got = K.cast(h.to_device(ctx), A.Utf8View)
+        assert got.to_pylist() == ["1.5", "2.5", None]
+    for dt in (A.Int8, A.Int16, A.Int32, A.Int64, A.UInt8, A.UInt16, A.UInt32, A.UInt64):
+        h = HostArray(dt, np.array([0, 8, 9, 10], dtype=dt.np_dtype), np.array([False, True, True, True]))
+        assert K.cast(h.to_device(ctx), A.Utf8View).to_pylist() == [None, "8", "9", "10"]
+    rng = np.random.default_rng(4857)
+    # Float64 over the whole corpus of the Utf8 tests (exponent forms are > 12 bytes: the out-of-line path), nulls, sliced
+    vals = _f64_corpus(rng, 20000)
+    h = HostArray(A.Float64, vals, rng.random(len(vals)) < 0.9)
+    _check_views(K.cast(h.to_device(ctx), A.Utf8View), oracle.cast(h, A.Utf8), "f64")
+    _check_views(K.cast(h.to_device(ctx).slice(5, 9000), A.Utf8View), oracle.cast(h.slice(5, 9000), A.Utf8), "f64 sliced")
+    nonull = HostArray(A.Float64, vals[:4000])
+    _check_views(K.cast(nonull.to_device(ctx), A.Utf8View), oracle.cast(nonull, A.Utf8), "f64 no nulls")
+    # every string inline: small integers as doubles
+    small = HostArray(A.Float64, rng.integers(-999, 999, 5000).astype(np.float64), rng.random(5000) < 0.8)
+    _check_views(K.cast(small.to_device(ctx), A.Utf8View), oracle.cast(small, A.Utf8), "f64 all inline")
+    f32 = rng.integers(0, 2**32, 20000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    h32 = HostArray(A.Float32, f32, rng.random(len(f32)) < 0.95)
+    _check_views(K.cast(h32.to_device(ctx), A.Utf8View), oracle.cast(h32, A.Utf8), "f32 bit patterns")
+    for dt in (A.Int64, A.UInt64, A.Int8):  # full-range 64-bit integers print 19-20 digits: out of line
+        iv = _rand_values(rng, dt, 7000)
+        hi = HostArray(dt, iv, rng.random(7000) < 0.9)
+        _check_views(K.cast(hi.to_device(ctx), A.Utf8View), oracle.cast(hi, A.Utf8), str(dt))
+    # Utf8 / LargeUtf8 -> Utf8View: empty strings, exactly 12 and 13 bytes, multi-byte UTF-8, null slots that carry bytes
+    words = ["", "a", "twelve bytes", "thirteen byte", "ünïcödé ✓ text that is long", "x" * 40, "1234567890ab", "1234567890abc"]
+    strs = [words[i] for i in rng.integers(0, len(words), 6000)]
+    for dt in (A.Utf8, A.LargeUtf8):
+        hs = HostArray(dt, strs, rng.random(6000) < 0.85)
+        d = A.Array.from_strings(strs, hs.valid, dt, ctx)
+        _check_views(K.cast(d, A.Utf8View), hs, f"{dt} -> Utf8View")
+        _check_views(K.cast(d.slice(7, 3000), A.Utf8View), hs.slice(7, 3000), f"{dt} sliced -> Utf8View")
+    assert K.cast(A.Array.from_strings([], None, A.Utf8, ctx), A.Utf8View).length == 0
+
+
 def test_cast_chain_config4_shape(ctx, oracle):
     """Config 4: Int64 -> Float64 -> Utf8 on the SURVEY §8d distribution (uniform [-1e6,1e6] with
     1% full range), 10% nulls — 2M rows on both sides."""
