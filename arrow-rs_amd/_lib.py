@@ -90,6 +90,13 @@ class Scalar(C.Structure):
     _fields_ = [("type", C.c_int32), ("is_valid", C.c_int32), ("bytes", C.c_uint8 * 32)]
 
 
+class ContextStats(C.Structure):
+    """ah_context_stats_t"""
+    _fields_ = [(n, C.c_int64) for n in ("live_bytes", "high_water_bytes", "cached_bytes", "reserved_high_water_bytes",
+                                         "allocated_bytes_total", "freed_bytes_total", "alloc_calls", "free_calls", "pool_hits",
+                                         "device_malloc_calls")]
+
+
 class ExchangeStats(C.Structure):
     """ah_exchange_stats"""
     _fields_ = [("peers", C.c_int32), ("bytes_to_each_peer", C.c_int64), ("bytes_received", C.c_int64),
@@ -162,6 +169,7 @@ SIGNATURES = {
     "ah_memcpy_dtod": (C.c_int32, [_P, _P, _P, C.c_size_t]),
     "ah_memset": (C.c_int32, [_P, _P, C.c_int, C.c_size_t]),
     "ah_synchronize": (C.c_int32, [_P]),
+    "ah_context_stats": (C.c_int32, [_P, C.POINTER(ContextStats), C.c_int32]),
     "ah_pool_trim": (None, [_P]),
     "ah_filter": (C.c_int32, [_P, _VIEW, _VIEW, _OUT]),
     "ah_filter_predicate_build": (C.c_int32, [_P, _VIEW, C.POINTER(_P)]),

@@ -324,6 +324,13 @@ class Context:
         return _Scope()
 
     # raw buffers
+    def memory_stats(self, reset_peaks=False):
+        """``ah_context_stats``: live / high-water / cached bytes of the pooled device allocator and its call counts — the
+        reference's ``MemoryPool::used`` for HBM (arrow-buffer/src/pool.rs:73-93)."""
+        st = L.ContextStats()
+        self.check(self.lib.ah_context_stats(self.handle, C.byref(st), int(reset_peaks)))
+        return {n: int(getattr(st, n)) for n, _ in st._fields_}
+
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 

@@ -123,6 +123,7 @@ struct ah_coalescer {
                             // their atomics over them; copies add to the first); summed once per finished batch
   uint64_t* pin = nullptr;      // own pinned words for the finished batches' null counts (host view / device view)
   uint64_t* pin_dev = nullptr;
+  size_t pin_bytes = 0;
   int ring_next = 0, ring_slots = 0;  // ring of ncols-word groups in `pin`
   // two groups of 64 pinned count words for pushes whose counts are in flight (push_batches_with_filters_begin / _end)
   uint64_t* cnt_pin = nullptr;
@@ -374,11 +375,11 @@ extern "C" ah_status ah_coalescer_create(ah_context* ctx, int32_t n_columns, con
   if (st == AH_OK) {
     co->ring_slots = std::max(4, 512 / n_columns);
     const size_t ring_words = (size_t)co->ring_slots * n_columns;
-    if (hipHostMalloc((void**)&co->pin, (ring_words + 128) * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
-      st = ah_fail(ctx, AH_OUT_OF_MEMORY, "coalescer pinned words");
-    else {
-      void* dp = nullptr;
-      if (hipHostGetDevicePointer(&dp, co->pin, 0) != hipSuccess || !dp) dp = co->pin;
+    void *hp = nullptr, *dp = nullptr;
+    co->pin_bytes = (ring_words + 128) * 8;
+    st = ah_pinned_alloc(ctx, co->pin_bytes, &hp, &dp);  // from the context's cache: hipHostMalloc is 0.1-0.3 ms
+    if (st == AH_OK) {
+      co->pin = (uint64_t*)hp;
       co->pin_dev = (uint64_t*)dp;
       co->cnt_pin = co->pin + ring_words;  // 2 x 64 count words behind the null-count ring
       co->cnt_pin_dev = co->pin_dev + ring_words;
@@ -405,7 +406,7 @@ extern "C" void ah_coalescer_destroy(ah_context* ctx, ah_coalescer* co) {
     }
     for (auto& b : co->completed) release_batch(ctx, b);  // (the wait above passed every pending batch's kernel)
     ah_pool_free(ctx, co->acc);
-    if (co->pin) hipHostFree(co->pin);
+    ah_pinned_free(ctx, co->pin, co->pin_bytes);
   }
   delete co;
 }

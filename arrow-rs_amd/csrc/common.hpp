@@ -69,6 +69,14 @@ struct ah_context {
   // host wait on the stream.  ah_out_free drains the stream before a HOST-allocator free while it is set (the host's
   // free is not stream-ordered).
   bool inflight = false;
+  // small pinned (host-coherent, device-mapped) blocks handed to objects that own mailboxes of their own (a
+  // BatchCoalescer's null-count ring and count words).  hipHostMalloc costs 0.1-0.3 ms, which showed up as idle GPU at
+  // the start of every coalescer's life (profiles/r04_coalesce_gaps.md): released blocks are kept here and reused.
+  std::vector<std::pair<size_t, void*>> pinned_cache;
+  // memory accounting (ah_context_stats; SURVEY 5 "allocation high-water / bytes moved", the analogue of the reference's
+  // MemoryPool::used / TrackingMemoryPool, arrow-buffer/src/pool.rs:73-93): device bytes held by live pool blocks
+  // (rounded sizes), their high-water mark, cumulative bytes and calls, and what the free lists cache
+  ah_context_stats_t stats{};
   // profiling
   bool profiling = false;
   std::map<std::string, ah_prof_entry> prof;
@@ -82,6 +90,9 @@ struct ah_ctx_guard {
 };
 
 ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...);
+// a pinned, device-mapped host block of at least `bytes` (zeroed); ah_pinned_free returns it to the context's cache
+ah_status ah_pinned_alloc(ah_context* ctx, size_t bytes, void** host, void** dev);
+void ah_pinned_free(ah_context* ctx, void* host, size_t bytes);
 
 #define AH_HIP(ctx, expr)                                                                  \
   do {                                                                                     \

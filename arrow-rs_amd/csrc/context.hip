@@ -73,6 +73,21 @@ static size_t pool_round(size_t bytes) {
   return (bytes + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);
 }
 
+static inline void stats_on_alloc(ah_context* ctx, size_t r, bool from_cache) {
+  ah_context_stats_t& s = ctx->stats;
+  s.live_bytes += (int64_t)r;
+  s.allocated_bytes_total += (int64_t)r;
+  s.alloc_calls += 1;
+  if (from_cache) {
+    s.pool_hits += 1;
+    s.cached_bytes -= (int64_t)r;
+  } else {
+    s.device_malloc_calls += 1;
+  }
+  if (s.live_bytes > s.high_water_bytes) s.high_water_bytes = s.live_bytes;
+  if (s.live_bytes + s.cached_bytes > s.reserved_high_water_bytes) s.reserved_high_water_bytes = s.live_bytes + s.cached_bytes;
+}
+
 ah_status ah_pool_alloc(ah_context* ctx, size_t bytes, void** out) {
   size_t r = pool_round(bytes);
   auto it = ctx->pool_free.find(r);
@@ -80,6 +95,7 @@ ah_status ah_pool_alloc(ah_context* ctx, size_t bytes, void** out) {
     *out = it->second.back();
     it->second.pop_back();
     ctx->pool_live[*out] = r;
+    stats_on_alloc(ctx, r, true);
     return AH_OK;
   }
   void* p = nullptr;
@@ -93,6 +109,7 @@ ah_status ah_pool_alloc(ah_context* ctx, size_t bytes, void** out) {
   }
   ctx->pool_live[p] = r;
   *out = p;
+  stats_on_alloc(ctx, r, false);
   return AH_OK;
 }
 
@@ -101,6 +118,10 @@ void ah_pool_free(ah_context* ctx, void* p) {
   auto it = ctx->pool_live.find(p);
   if (it == ctx->pool_live.end()) return;  // not ours
   ctx->pool_free[it->second].push_back(p);
+  ctx->stats.live_bytes -= (int64_t)it->second;
+  ctx->stats.freed_bytes_total += (int64_t)it->second;
+  ctx->stats.cached_bytes += (int64_t)it->second;
+  ctx->stats.free_calls += 1;
   ctx->pool_live.erase(it);
 }
 
@@ -110,6 +131,45 @@ extern "C" void ah_pool_trim(ah_context* ctx) {
   for (auto& kv : ctx->pool_free)
     for (void* p : kv.second) hipFree(p);
   ctx->pool_free.clear();
+  ctx->stats.cached_bytes = 0;
+}
+
+// MemoryPool::used() and friends for this context (arrow-buffer/src/pool.rs:73-93)
+extern "C" ah_status ah_context_stats(ah_context* ctx, ah_context_stats_t* out, int32_t reset_peaks) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !out) return AH_INVALID_ARGUMENT;
+  *out = ctx->stats;
+  if (reset_peaks) {
+    ctx->stats.high_water_bytes = ctx->stats.live_bytes;
+    ctx->stats.reserved_high_water_bytes = ctx->stats.live_bytes + ctx->stats.cached_bytes;
+  }
+  return AH_OK;
+}
+
+// ------------------------------------------------------------------- pinned blocks
+ah_status ah_pinned_alloc(ah_context* ctx, size_t bytes, void** host, void** dev) {
+  const size_t r = (std::max<size_t>(bytes, 8) + 4095) & ~(size_t)4095;
+  void* h = nullptr;
+  for (size_t i = 0; i < ctx->pinned_cache.size(); ++i)
+    if (ctx->pinned_cache[i].first == r) {
+      h = ctx->pinned_cache[i].second;
+      ctx->pinned_cache.erase(ctx->pinned_cache.begin() + (long)i);
+      break;
+    }
+  if (!h && hipHostMalloc(&h, r, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+    return ah_fail(ctx, AH_OUT_OF_MEMORY, "pinned host block of %zu bytes", r);
+  memset(h, 0, r);
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) d = h;  // unified addressing
+  *host = h;
+  *dev = d;
+  return AH_OK;
+}
+void ah_pinned_free(ah_context* ctx, void* host, size_t bytes) {
+  if (!host) return;
+  const size_t r = (std::max<size_t>(bytes, 8) + 4095) & ~(size_t)4095;
+  if (ctx->pinned_cache.size() < 32) ctx->pinned_cache.emplace_back(r, host);
+  else hipHostFree(host);
 }
 
 // Debug redzones (AH_DEBUG_REDZONE=1): every pooled output buffer gets a 256-byte canary right
@@ -358,6 +418,7 @@ extern "C" void ah_context_destroy(ah_context* ctx) {
   for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->pinned) hipHostFree(ctx->pinned);
+  for (auto& pb : ctx->pinned_cache) hipHostFree(pb.second);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

@@ -1073,7 +1073,7 @@ def emit(line, args):
     print("BENCH_DETAIL " + detail, file=sys.stderr, flush=True)
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
             "data", "config", "kernel_avg_ms", "host_gap_ms", "local_value", "local_ms_per_step", "exchange", "reassemble_last_ms",
-            "step_algorithmic_GBps", "filter_selected_rows", "take_indices", "take_sorted_indices_ms", "take_null_indices_ms",
+            "step_algorithmic_GBps", "hbm_pool", "filter_selected_rows", "take_indices", "take_sorted_indices_ms", "take_null_indices_ms",
             "pmc_traffic_bytes_per_launch")
     compact = {k: line[k] for k in keep if k in line}
     compact["roofline"] = _compact_roofline(line.get("roofline"))
@@ -1431,6 +1431,13 @@ def main():
             line["local_value"] = round(n * world * args.steps / local_elapsed / 1e6, 1)
             line["local_ms_per_step"] = round(local_elapsed / args.steps * 1e3, 4)
         line.update(extra)
+        try:  # the pooled allocator's accounting for this run (ah_context_stats): peak HBM held by results + scratch
+            ms_ = ctx.memory_stats()
+            line["hbm_pool"] = {"high_water_GB": round(ms_["high_water_bytes"] / 1e9, 3), "live_GB": round(ms_["live_bytes"] / 1e9, 3),
+                                "reserved_high_water_GB": round(ms_["reserved_high_water_bytes"] / 1e9, 3),
+                                "alloc_calls": ms_["alloc_calls"], "device_malloc_calls": ms_["device_malloc_calls"]}
+        except Exception:  # noqa: BLE001
+            pass
 
     # the other single-GPU configurations of BASELINE.json, a few steps each, inside the same line
     if wl == "filter_take" and world == 1 and not args.no_configs and args.rows == 1_000_000_000:

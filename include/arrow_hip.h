@@ -189,6 +189,23 @@ AH_API void ah_context_set_deferred(ah_context* ctx, int32_t on);
 AH_API int32_t ah_context_deferred(const ah_context* ctx);
 /* ah_synchronize + count the nulls of a deferred result (null_count < 0) on the device. */
 AH_API ah_status ah_array_resolve(ah_context* ctx, ah_array_out* out);
+/* Memory accounting of a context's built-in pooled allocator — the reference's MemoryPool::used() / TrackingMemoryPool
+ * (arrow-buffer/src/pool.rs:73-93) for device memory: what a host samples to size its batches and what bench.py /
+ * a profiler reads next to HBM traffic.  Sizes are the pool's ROUNDED block sizes (what is really held).  Outputs routed
+ * through a host allocator hook (ah_context_set_allocator) are the host's to account for and do not appear here. */
+typedef struct ah_context_stats_t {
+  int64_t live_bytes;                /* held by blocks handed out and not yet released (results + scratch) */
+  int64_t high_water_bytes;          /* maximum of live_bytes since creation / the last reset */
+  int64_t cached_bytes;              /* released blocks kept on the free lists (ah_pool_trim returns them to HIP) */
+  int64_t reserved_high_water_bytes; /* maximum of live + cached: what the context has had hipMalloc'ed at once */
+  int64_t allocated_bytes_total;     /* cumulative */
+  int64_t freed_bytes_total;
+  int64_t alloc_calls;
+  int64_t free_calls;
+  int64_t pool_hits;                 /* allocations served from the free lists */
+  int64_t device_malloc_calls;       /* allocations that went to hipMalloc */
+} ah_context_stats_t;
+AH_API ah_status ah_context_stats(ah_context* ctx, ah_context_stats_t* out, int32_t reset_peaks);
 AH_API const char* ah_last_error(ah_context* ctx);
 AH_API void ah_array_release(ah_context* ctx, ah_array_out* out);
 AH_API const char* ah_version(void);

@@ -1541,6 +1541,34 @@ def test_one_context_shared_by_many_threads(ctx, oracle):
     assert not errs, errs
 
 
+def test_context_memory_stats(ctx):
+    """ah_context_stats: the pooled allocator's accounting (MemoryPool::used / TrackingMemoryPool for HBM,
+    arrow-buffer/src/pool.rs:73-93).  Live bytes follow results as they are produced and released, the high-water mark
+    keeps the peak until it is reset, cached bytes are what ah_pool_trim hands back to HIP."""
+    import gc
+    gc.collect()
+    n = 3_000_000
+    a = HostArray(A.Int64, np.arange(n, dtype=np.int64)).to_device(ctx)
+    s0 = ctx.memory_stats(reset_peaks=True)
+    r = K.add_wrapping(a, a)  # one 24 MB result (rounded up to whole MiB by the pool)
+    s1 = ctx.memory_stats()
+    assert n * 8 <= s1["live_bytes"] - s0["live_bytes"] <= n * 8 + (2 << 20)
+    assert s1["high_water_bytes"] >= s1["live_bytes"] and s1["alloc_calls"] > s0["alloc_calls"]
+    assert s1["allocated_bytes_total"] - s0["allocated_bytes_total"] >= n * 8
+    del r
+    gc.collect()
+    s2 = ctx.memory_stats()
+    assert s2["live_bytes"] <= s0["live_bytes"] + (1 << 20) and s2["free_calls"] > s1["free_calls"]
+    assert s2["high_water_bytes"] == s1["high_water_bytes"]  # the peak stays
+    assert s2["cached_bytes"] >= n * 8  # the released block sits on a free list
+    r2 = K.add_wrapping(a, a)  # ... and serves the next allocation of that size
+    s3 = ctx.memory_stats(reset_peaks=True)
+    assert s3["pool_hits"] > s2["pool_hits"] and s3["device_malloc_calls"] == s2["device_malloc_calls"]
+    s4 = ctx.memory_stats()
+    assert s4["high_water_bytes"] == s4["live_bytes"]  # reset: the peak restarts from what is live now
+    del r2
+
+
 def test_bench_json_contract(ctx):
     """bench.py prints ONE JSON line with the contract keys (small --rows so it runs in seconds)."""
     import json
