@@ -590,7 +590,10 @@ template <int W, bool HAS_VALID>
 __device__ __forceinline__ void sparse_tile(const ScatterArgs& a, int64_t tile, int lane, int wave, const void* c_values,
                                             BitView c_vvalid, void* c_out_values, unsigned long long* c_out_valid,
                                             unsigned long long* c_valid_slots) {
-  using ET = typename Elem<W>::type;
+  // W == 0: a bit stream alone (Boolean values / a validity bitmap through filter_bits, filter.rs:680-729): the stream
+  // travels as `c_vvalid`, there are no value loads or stores
+  using ET = typename Elem<W == 0 ? 1 : W>::type;
+  static_assert(W != 0 || HAS_VALID, "the bit-only form compacts the HAS_VALID stream");
   constexpr int T = 4096;
   const int64_t row0 = tile * T, s = row0 + ((int64_t)lane << 6);
   uint64_t m = 0, v = 0;
@@ -642,7 +645,7 @@ __device__ __forceinline__ void sparse_tile(const ScatterArgs& a, int64_t tile, 
         b[k] = __builtin_ctzll(m);
         m &= m - 1;
         nb = k + 1;
-        x[k] = vp[b[k]];
+        if constexpr (W != 0) x[k] = vp[b[k]];
       }
     }
 #pragma unroll
@@ -651,7 +654,7 @@ __device__ __forceinline__ void sparse_tile(const ScatterArgs& a, int64_t tile, 
         const int64_t p = pos + k;
         if (p >= lo && p < hi) {
           const int64_t dst = a.out_base + p - a.win_lo;
-          op[dst] = x[k];
+          if constexpr (W != 0) op[dst] = x[k];
           if constexpr (HAS_VALID) {
             const int vb = (int)((v >> b[k]) & 1ull);
             if (vb) atomicOr(&s_w[wave][(int)((dst >> 6) - wb)], 1ull << (dst & 63));
@@ -866,8 +869,9 @@ void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, 
     b.valid_slots = nullptr;
     for (int c = 1; c < ncols; ++c) b.more[c - 1].valid_slots = nullptr;
   }
-  if constexpr (W != 0) {
+  if constexpr (W != 0 || HV) {
     // the sparse form serves plain results; the windowed / NULL-counting launches of the coalescer keep the tiled kernel
+    // (W == 0, round 4: the bit-only stream of filter_boolean / filter_nulls takes it too)
     if (sparse && (!HV || count_after)) {
       b.ntiles = ah_ceil_div(a_in.len, 4096);  // one 4096-row tile per wave, four per workgroup
       const int64_t nwg = (b.ntiles + 3) >> 2;
@@ -896,7 +900,7 @@ ah_status launch_scatter(ah_context* ctx, int width, const ScatterArgs& a, bool 
   bool aligned16 = (((uintptr_t)a.values) & 15) == 0;
   for (int c = 1; c < ncols; ++c) aligned16 = aligned16 && (((uintptr_t)a.more[c - 1].values) & 15) == 0;
   switch (width) {
-    case 0: launch_scatter_w<0, HV>(ctx, a, true, false, ncols); break;
+    case 0: launch_scatter_w<0, HV>(ctx, a, true, false, ncols, sparse, out_rows); break;
     case 1: launch_scatter_w<1, HV>(ctx, a, aligned16, skip, ncols, sparse, out_rows); break;
     case 2: launch_scatter_w<2, HV>(ctx, a, aligned16, skip, ncols, sparse, out_rows); break;
     case 4: launch_scatter_w<4, HV>(ctx, a, aligned16, skip, ncols, sparse, out_rows); break;
@@ -1217,7 +1221,10 @@ static ah_status compact_bits(ah_context* ctx, const ah_filter_predicate* p, Bit
   a.out_values = nullptr;
   a.out_valid = (unsigned long long*)ob;
   a.valid_slots = slots;
-  launch_scatter<true>(ctx, 0, a, false);
+  // a sparse selection (<= 1 selected row in 32): the wave-per-tile kernel, set bits counted from the small output
+  // bitmap afterwards — as for fixed-width values; filter_boolean was the one value kind left on the tiled
+  // kernel at low selectivity
+  launch_scatter<true>(ctx, 0, a, false, 1, use_sparse(p->count, p->len), p->count);
   if (defer) {  // no read-back: the caller reports the count as unknown
     filter_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, nullptr, 0);
     *set_bits = -1;

@@ -59,6 +59,34 @@ def test_sparse_scatter_fuzz_against_tiled_and_oracle(ctx, oracle, seed):
         assert_same_nulls_presence(g, exp, f"sparse={force} seed {seed}")
 
 
+@pytest.mark.parametrize("seed", range(18))
+def test_sparse_filter_boolean_against_tiled_and_oracle(ctx, oracle, seed):
+    """filter_boolean (filter.rs:723-729 -> filter_bits :680-720) and the validity stream of every nullable filter through
+    the BIT-ONLY form of the sparse kernel (round 4; the tiled W == 0 kernel was the only choice before): Boolean values
+    with and without nulls, value / validity / predicate bit offsets, a null-carrying predicate, every density — forced
+    sparse, forced tiled and the heuristic's own choice against the oracle, through the predicate object AND plain filter."""
+    rng = np.random.default_rng(9900 + seed)
+    n = [7, 4095, 4097, 70_003, 262_144 + 65, 1_500_007][seed % 6]
+    pv = [None, 0.9, 0.3][seed % 3]
+    h = HostArray(A.Boolean, rng.random(n) < [0.5, 0.02, 0.98][(seed // 3) % 3], None if pv is None else rng.random(n) < pv)
+    kind = ["0.001", "0.01", "0.0002", "one", "0.1", "runs", "0.9"][seed % 7]
+    mask = HostArray(A.Boolean, _mask(rng, n, kind), (rng.random(n) < 0.9) if seed % 4 == 0 else None)
+    exp = oracle.filter(h, mask)
+    bo = int(rng.integers(0, 64)) if seed % 2 == 0 else 0
+    dv, dm = h.to_device(ctx, bit_offset=bo), mask.to_device(ctx, bit_offset=(bo * 7) % 64)
+    for force in ("1", "0", None):
+        ctxm = _force(force) if force is not None else _force("")
+        with ctxm:
+            if force is None:
+                os.environ.pop("AH_FILTER_SPARSE", None)
+            pred = K.FilterBuilder(dm).optimize().build()
+            g = HostArray.from_device(pred.filter(dv))
+            g2 = HostArray.from_device(K.filter(dv, dm))
+        for label, got in (("predicate", g), ("filter", g2)):
+            assert_logical_eq(got, exp, f"{label} sparse={force} seed {seed} n {n} mask {kind}")
+            assert_same_nulls_presence(got, exp, f"{label} sparse={force} seed {seed}")
+
+
 def test_sparse_kernel_is_what_runs_for_a_sparse_predicate(ctx, oracle):
     """the heuristic: 3 M rows, 0.1 % selected -> the sparse kernel (name in the kernel profile is the scatter's either
     way; the A/B below shows both give the same bytes); 10 % selected -> the tiled kernel.  Sliced (unaligned) values."""
