@@ -920,6 +920,15 @@ bool use_sparse(int64_t count, int64_t len) {
   return count * 32 <= len;  // crossover measured between 3 % and 10 % selected (profiles/r03_selectivity_sweep.md)
 }
 
+// the bit-only stream (filter_boolean, filter_bits): no value traffic, so the wave-per-tile form wins further up —
+// measured on 1e9 Boolean rows with 10 % nulls (profiles/r04_bool_filter_ab.md): 0.43 against 0.85 ms at 10 % selected
+bool use_sparse_bits(int64_t count, int64_t len) {
+  const char* env = getenv("AH_FILTER_SPARSE");
+  if (env && env[0] == '0') return false;
+  if (env && env[0] == '1') return true;
+  return count * 8 <= len;
+}
+
 // load predication pays when most 128-byte lines hold no selected row; tunable for experiments
 bool use_skip(int64_t count, int64_t len) {
   static const char* env = getenv("AH_FILTER_SKIP");  // "0" / "1" force, unset = heuristic
@@ -1224,7 +1233,7 @@ static ah_status compact_bits(ah_context* ctx, const ah_filter_predicate* p, Bit
   // a sparse selection (<= 1 selected row in 32): the wave-per-tile kernel, set bits counted from the small output
   // bitmap afterwards — as for fixed-width values; filter_boolean was the one value kind left on the tiled
   // kernel at low selectivity
-  launch_scatter<true>(ctx, 0, a, false, 1, use_sparse(p->count, p->len), p->count);
+  launch_scatter<true>(ctx, 0, a, false, 1, use_sparse_bits(p->count, p->len), p->count);
   if (defer) {  // no read-back: the caller reports the count as unknown
     filter_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, nullptr, 0);
     *set_bits = -1;

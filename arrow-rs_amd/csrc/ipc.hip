@@ -300,7 +300,12 @@ ah_status format_from_type(ah_context* ctx, FbView& v, uint8_t tt, size_t t, std
       *out = std::string(1, s[sg ? 0 : 1]);
       return AH_OK;
     }
-    case T_FloatingPoint: *out = std::string(1, "efg"[v.scalar<int16_t>(t, 0, 0) % 3]); return AH_OK;
+    case T_FloatingPoint: {
+      const int prec = v.scalar<int16_t>(t, 0, 0);  // Precision: HALF, SINGLE, DOUBLE — anything else is a corrupt message
+      if (prec < 0 || prec > 2) return ah_fail(ctx, AH_IPC_ERROR, "Unexpected precision %d for a FloatingPoint type", prec);
+      *out = std::string(1, "efg"[prec]);
+      return AH_OK;
+    }
     case T_Bool: *out = "b"; return AH_OK;
     case T_Utf8: *out = "u"; return AH_OK;
     case T_LargeUtf8: *out = "U"; return AH_OK;

@@ -283,3 +283,71 @@ def test_device_interface_moves_ownership(ctx):
         C.CFUNCTYPE(None, C.c_void_p)(sch.release)(C.addressof(sch))
     finally:
         ctx.lib.ah_context_set_allocator(ctx.handle, L.ALLOC_FN(0), L.FREE_FN(0), None)
+
+
+def test_import_survives_mutated_structs(ctx):
+    """Round 4: the C Data Interface carries no buffer SIZES (the consumer must trust `length` /
+    `offset`, exactly like arrow-array/src/ffi.rs:470-500), so what can be validated is everything else — and every such
+    violation must come back as a status from the C entry point (AH_C_DATA_INTERFACE / AH_NOT_YET_IMPLEMENTED / ...),
+    never as a crash: format strings (unknown, truncated, garbage bytes), buffer counts, negative length / offset, null
+    buffer pointers, non-monotonic or negative string offsets, a released struct, a dictionary pointer."""
+    L = A._lib
+    rng = np.random.default_rng(99)
+    sources = [pa.array(rng.integers(0, 100, 50), mask=rng.random(50) < 0.2), pa.array([None if i % 4 == 0 else "s" * (i % 7) for i in range(50)]),
+               pa.array(rng.random(50) < 0.5), pa.array(rng.standard_normal(50)), pa.array([b"ab", None, b""] * 10, type=pa.large_binary())]
+    formats = [b"", b"?", b"zz", b"tsq:", b"d:", b"d:abc", b"w:", b"+l", b"+s", b"\xff\xfe", b"t", b"td", b"tt", b"l" * 300, b"tsu", b"d:1", b"w:-4"]
+    seen = {}
+    spare = ffi.FFI_ArrowArray()
+    for it in range(600):
+        arr = sources[it % len(sources)]
+        a, s_ = ffi.FFI_ArrowArray(), ffi.FFI_ArrowSchema()
+        arr._export_to_c(C.addressof(a), C.addressof(s_))
+        rel_a, rel_s, fmt0, bufs0 = a.release, s_.release, s_.format, [a.buffers[i] for i in range(a.n_buffers)]
+        keep = []  # mutated format strings / offsets must outlive the call
+        kind = int(rng.integers(0, 9))
+        if kind == 0:
+            buf = C.create_string_buffer(formats[int(rng.integers(0, len(formats)))])
+            keep.append(buf)
+            s_.format = C.cast(buf, C.c_char_p)
+        elif kind == 1:
+            a.n_buffers = int(rng.integers(-2, 6))
+        elif kind == 2:
+            a.length = -int(rng.integers(1, 100))
+        elif kind == 3:
+            a.offset = -int(rng.integers(1, 100))
+        elif kind == 4 and a.n_buffers >= 2:
+            a.buffers[int(rng.integers(1, a.n_buffers))] = None
+        elif kind == 5 and pa.types.is_string(arr.type):
+            offs = np.frombuffer((C.c_int32 * (len(arr) + 1)).from_address(a.buffers[1]), dtype=np.int32).copy()
+            offs[int(rng.integers(0, len(offs)))] = int(rng.choice([-5, 2**30, -2**31]))
+            offs[-1] = int(rng.choice([offs[-1], -1, 0]))
+            keep.append(offs)
+            a.buffers[1] = offs.ctypes.data
+        elif kind == 6:
+            a.dictionary = C.pointer(spare)
+        elif kind == 7:
+            a.release = None  # "already released"
+        out = L.ArrayOut()
+        st = ctx.lib.ah_import_c_data(ctx.handle, C.byref(a), C.byref(s_), C.byref(out))
+        seen[(kind, st)] = seen.get((kind, st), 0) + 1
+        assert st in (L.AH_OK, L.AH_C_DATA_INTERFACE, L.AH_NOT_YET_IMPLEMENTED, L.AH_INVALID_ARGUMENT, L.AH_CAST_ERROR, L.AH_PARSE_ERROR), (kind, st)
+        if st == L.AH_OK:
+            if kind == 8:
+                assert A.Array._from_out(ctx, out, ffi.data_type_from_format(ctx, fmt0.decode())).to_pyarrow().equals(arr)
+            else:
+                ctx.lib.ah_array_release(ctx.handle, C.byref(out))
+        elif kind in (1, 2, 3, 7):
+            assert st == L.AH_C_DATA_INTERFACE, (kind, st)
+        elif kind == 6:
+            assert st == L.AH_NOT_YET_IMPLEMENTED, (kind, st)
+        # give the producer back exactly what it exported, then release it
+        a.release, s_.release, s_.format, a.dictionary = rel_a, rel_s, fmt0, None
+        a.n_buffers = len(bufs0)
+        for i, b in enumerate(bufs0):
+            a.buffers[i] = b
+        for st_ in (a, s_):
+            C.CFUNCTYPE(None, C.c_void_p)(st_.release)(C.addressof(st_))
+    ok = sum(v for (k, st), v in seen.items() if st == L.AH_OK)
+    refused = sum(v for (k, st), v in seen.items() if st != L.AH_OK)
+    assert ok >= 60 and refused >= 250, seen
+    assert K.filter(A.Array.from_numpy(np.arange(10), ctx=ctx), A.Array.from_numpy(np.arange(10) % 2 == 0, ctx=ctx)).length == 5

@@ -287,3 +287,62 @@ def test_decimal_columns_keep_their_logical_type_through_ffi(ctx):
     wide = ffi.from_pyarrow(pa.array([decimal.Decimal(7), None], type=pa.decimal256(40, 0)), ctx)
     assert wide.data_type == A.Decimal256(40, 0) and wide.data_type.width == 32
     assert ffi.to_pyarrow(K.filter(wide, ffi.from_pyarrow(pa.array([True, True]), ctx))).to_pylist() == [decimal.Decimal(7), None]
+
+
+def test_decode_batch_survives_mutated_metadata(ctx):
+    """Round 4: a byte-mutation fuzz of ``ah_ipc_decode_batch`` — the one IPC decoder that needs a
+    device (its columns are zero-copy views of the body in HBM and string offsets are validated by a kernel).  A real
+    RecordBatch message of {Int64 with nulls, Utf8, Boolean, Float64} is mutated 1 500 times (bit flips, boundary values
+    in 32- / 64-bit words, truncations); every call must return a status.  Whatever is still ACCEPTED must be safe to
+    use: every column is run through a kernel that touches all of its buffers (null count + filter + for strings a
+    gather), with the allocator's red zones on in a child... here: results are only required not to fault the device
+    (a fault would fail every later test of this session)."""
+    rng = np.random.default_rng(1234)
+    n = 4000
+    cols = [A.Array.from_numpy(rng.integers(-2**62, 2**62, n), rng.random(n) < 0.8, ctx=ctx),
+            A.Array.from_strings([("s" * int(k)) + str(i) for i, k in enumerate(rng.integers(0, 9, n))], rng.random(n) < 0.9, A.Utf8, ctx),
+            A.Array.from_numpy(rng.random(n) < 0.5, ctx=ctx),
+            A.Array.from_numpy(rng.standard_normal(n), ctx=ctx)]
+    batch = A.RecordBatch(["i", "s", "b", "f"], cols, n)
+    schema = ipc.Schema.of(batch)
+    meta, body = ipc.encode_batch(batch, 64)
+    good = ipc.decode_batch(meta, body.ptr, body.nbytes, schema, ctx, keepalive=(body,))
+    assert good.num_rows() == n and good.columns[1].to_pylist() == cols[1].to_pylist()
+    boundary = [0, 1, -1, 7, 8, 64, 255, 65535, 2**31 - 1, -2**31, 2**31, 2**40, 2**62, -2**62, n, n + 1, n - 1, body.nbytes, body.nbytes + 1]
+    mask = A.Array.from_numpy(rng.random(n) < 0.3, ctx=ctx)
+    accepted = refused = 0
+    for it in range(1500):
+        m = bytearray(meta)
+        for _ in range(int(rng.integers(1, 4))):
+            kind = int(rng.integers(0, 5))
+            if kind == 0:
+                m[int(rng.integers(0, len(m)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1 and len(m) >= 8:
+                at = int(rng.integers(0, len(m) // 8)) * 8
+                m[at:at + 8] = int(boundary[int(rng.integers(0, len(boundary)))]).to_bytes(8, "little", signed=True)
+            elif kind == 2 and len(m) >= 4:
+                at = int(rng.integers(0, len(m) // 4)) * 4
+                v = int(boundary[int(rng.integers(0, 12))])
+                m[at:at + 4] = (v & 0xFFFFFFFF).to_bytes(4, "little")
+            elif kind == 3:
+                m = m[:int(rng.integers(0, len(m) + 1))]
+            elif len(m):
+                at = int(rng.integers(0, len(m)))
+                m[at:at + 6] = bytes(rng.integers(0, 256, 6, dtype=np.uint8))[:max(0, min(6, len(m) - at))]
+        try:
+            got = ipc.decode_batch(bytes(m), body.ptr, body.nbytes, schema, ctx, keepalive=(body,))
+        except (A.ArrowError, A.array.HipError):
+            refused += 1
+            continue
+        accepted += 1
+        # an accepted message must describe buffers INSIDE the body: use every column
+        for c in got.columns:
+            if c.length == 0:
+                continue
+            c.null_count()
+            if c.length <= mask.length:
+                f = K.filter(c, mask.slice(0, c.length))
+                assert f.length <= c.length
+    assert refused > 300 and accepted > 50, (accepted, refused)
+    # the context still works
+    assert K.filter(cols[0], mask).length == int(np.asarray(mask.values_numpy()).sum())
