@@ -30,6 +30,10 @@ use arrow::error::ArrowError;
 use arrow::ffi::{from_ffi, to_ffi, FFI_ArrowArray, FFI_ArrowSchema};
 use arrow_hip_sys as sys;
 
+/// The drop-in layer: the reference's own signatures (`filter(&dyn Array, &BooleanArray) -> Result<ArrayRef>`, …) over
+/// arrays whose buffers are `Buffer::from_custom_allocation` views of HBM.
+pub mod kernels;
+
 /// One HIP stream + pooled HBM allocator on one GPU.
 pub struct Context {
     raw: *mut sys::ah_context,
@@ -62,12 +66,16 @@ impl Context {
         self.check(unsafe { sys::ah_synchronize(self.raw) })
     }
 
+    pub(crate) fn raw(&self) -> *mut sys::ah_context {
+        self.raw
+    }
+
     fn message(&self) -> String {
         unsafe { CStr::from_ptr(sys::ah_last_error(self.raw)) }.to_string_lossy().into_owned()
     }
 
     /// status -> `ArrowError` with the reference's message text; reference panics stay panics.
-    fn check(&self, st: sys::ah_status) -> Result<(), ArrowError> {
+    pub(crate) fn check(&self, st: sys::ah_status) -> Result<(), ArrowError> {
         match st {
             sys::AH_OK => Ok(()),
             sys::AH_INVALID_ARGUMENT => Err(ArrowError::InvalidArgumentError(self.message())),
@@ -131,7 +139,7 @@ impl DeviceArray {
         Ok(self.out.null_count as usize)
     }
 
-    fn view(&self) -> sys::ah_array_view {
+    pub(crate) fn view(&self) -> sys::ah_array_view {
         sys::ah_array_view {
             type_: self.out.type_,
             length: self.out.length,
@@ -146,6 +154,12 @@ impl DeviceArray {
 
     /// Host array -> HBM through the C Data Interface (`to_ffi`, then `ah_import_c_data` = `from_ffi` on the device).
     pub fn from_host(ctx: &Arc<Context>, array: &dyn Array) -> Result<Arc<Self>, ArrowError> {
+        let out = Self::import(ctx, array)?;
+        Ok(Arc::new(Self { ctx: ctx.clone(), out, data_type: array.data_type().clone(), _keep: vec![] }))
+    }
+
+    /// the raw half of `from_host`: the owned `ah_array_out` (whoever holds it calls `ah_array_release`)
+    pub(crate) fn import(ctx: &Arc<Context>, array: &dyn Array) -> Result<sys::ah_array_out, ArrowError> {
         let (ffi_array, ffi_schema) = to_ffi(&array.to_data())?;
         let mut out = MaybeUninit::<sys::ah_array_out>::zeroed();
         ctx.check(unsafe {
@@ -156,7 +170,27 @@ impl DeviceArray {
                 out.as_mut_ptr(),
             )
         })?;
-        Ok(Arc::new(Self { ctx: ctx.clone(), out: unsafe { out.assume_init() }, data_type: array.data_type().clone(), _keep: vec![] }))
+        Ok(unsafe { out.assume_init() })
+    }
+
+    /// A `DeviceArray` that only BORROWS device buffers described by a view (`AH_OUT_BORROWED`: its release frees
+    /// nothing) — how `kernels::download` exports an `ArrayRef` whose buffers are owned elsewhere.
+    pub(crate) fn borrowing(ctx: &Arc<Context>, v: sys::ah_array_view, data_type: DataType) -> Self {
+        let out = sys::ah_array_out {
+            type_: v.type_,
+            length: v.length,
+            null_count: v.null_count,
+            values: v.values as *mut _,
+            values_bytes: 0,
+            values_bit_offset: v.values_bit_offset,
+            validity: v.validity as *mut _,
+            validity_bytes: 0,
+            validity_bit_offset: v.validity_bit_offset,
+            offsets: v.offsets as *mut _,
+            offsets_bytes: 0,
+            flags: sys::AH_OUT_BORROWED,
+        };
+        Self { ctx: ctx.clone(), out, data_type, _keep: vec![] }
     }
 
     /// HBM -> host array (`ah_export_c_data` fills FFI structs whose release callbacks free the host copies).

@@ -311,3 +311,30 @@ def test_ipc_file_footer_against_pyarrow():
         assert rd.get_batch(i).equals(b)
     st, f2, b2, _ = parse(mine[-(ln.value):])            # and our parser on our own trailer
     assert st == L.AH_OK and f2 == fields and b2 == [(bl[i].offset, bl[i].meta_data_length, bl[i].body_length) for i in range(3)]
+
+
+def test_integration_md_quotes_the_crate():
+    """INTEGRATION.md section 2 shows the drop-in Rust layer by quoting bindings/rust/arrow-hip/src/kernels.rs VERBATIM
+    (the blocks between its `// <<integration:NAME` ... `// integration>>` markers).  Neither compiles here, which is
+    exactly why they must at least agree: this fails when one is edited without the other.  The
+    quoted layer must carry the reference's own signatures."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "arrow-hip", "src", "kernels.rs")).read()
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = dict(re.findall(r"// <<integration:(\w+)\n(.*?)// integration>>", src, flags=re.S))
+    assert set(blocks) >= {"owner", "view", "wrap", "filter", "take", "numeric", "cmp", "cast"}
+    for name, text in blocks.items():
+        assert text.strip() and text in md, f"INTEGRATION.md does not quote block `{name}` of kernels.rs verbatim"
+    # the signatures north_star asks for (arrow-select/src/filter.rs:201, take.rs:89, arrow-arith/src/numeric.rs:41,
+    # arrow-ord/src/cmp.rs:113, arrow-cast/src/cast/mod.rs:347)
+    for sig in ("pub fn filter(values: &dyn Array, predicate: &BooleanArray) -> Result<ArrayRef, ArrowError>",
+                "pub fn take(values: &dyn Array, indices: &dyn Array, options: Option<TakeOptions>) -> Result<ArrayRef, ArrowError>",
+                "pub fn add_wrapping(lhs: &dyn Datum, rhs: &dyn Datum) -> Result<ArrayRef, ArrowError>",
+                "pub fn lt(lhs: &dyn Datum, rhs: &dyn Datum) -> Result<BooleanArray, ArrowError>",
+                "pub fn cast(array: &dyn Array, to_type: &DataType) -> Result<ArrayRef, ArrowError>"):
+        assert sig in src and sig in md, sig
+    assert "Buffer::from_custom_allocation" in blocks["wrap"] and "NullBuffer::new_unchecked" in blocks["wrap"]
+    # every sys:: name the drop-in layer uses exists in the generated declarations
+    committed = open(os.path.join(ROOT, "bindings", "rust", "arrow-hip-sys", "src", "lib.rs")).read()
+    known = set(re.findall(r"pub (?:fn|const|struct|type) (\w+)", committed))
+    used = set(re.findall(r"sys::(\w+)", src))
+    assert used <= known, sorted(used - known)

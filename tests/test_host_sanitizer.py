@@ -18,7 +18,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "arrow-rs_amd", "csrc")
-SAN_LIB = os.path.join(ROOT, "arrow-rs_amd", "lib", "san", "libarrow_hip_san.so")
+SAN_DIR = os.environ.get("AH_SAN_DIR", "/tmp/arrow_hip_san")  # outside the tree: 110 MB of instrumented objects
+SAN_LIB = os.path.join(SAN_DIR, "libarrow_hip_san.so")
 SAN_ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
 
 pytestmark = pytest.mark.skipif(os.environ.get("AH_SKIP_SAN") == "1", reason="AH_SKIP_SAN=1")
@@ -26,7 +27,7 @@ pytestmark = pytest.mark.skipif(os.environ.get("AH_SKIP_SAN") == "1", reason="AH
 
 @pytest.fixture(scope="module")
 def san_lib():
-    subprocess.check_call(["make", "-C", CSRC, "SAN=1", "-j", str(min(16, os.cpu_count() or 4))], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC, "SAN=1", f"SANDIR={SAN_DIR}", "-j", str(min(16, os.cpu_count() or 4))], stdout=subprocess.DEVNULL)
     assert os.path.exists(SAN_LIB)
     return SAN_LIB
 
