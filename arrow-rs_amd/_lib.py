@@ -197,6 +197,8 @@ SIGNATURES = {
     "ah_coalescer_push_batches_with_filters_begin": (C.c_int32, [_P, _P, C.c_int32, _VIEW, C.POINTER(C.c_int64), _VIEW,
                                                                 C.POINTER(C.c_uint64), C.POINTER(_P)]),
     "ah_coalescer_push_batches_with_filters_end": (C.c_int32, [_P, _P, _P, C.POINTER(C.c_int32)]),
+    "ah_coalescer_declare_view_buffers": (C.c_int32, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
+    "ah_coalescer_completed_batch_sources": (C.c_int32, [_P, _P, C.POINTER(C.c_uint64), C.c_int32, C.POINTER(C.c_int32)]),
     "ah_coalescer_push_batch_with_indices": (C.c_int32, [_P, _P, _VIEW, C.c_int64, _VIEW]),
     "ah_filter_predicates_build": (C.c_int32, [_P, C.c_int32, _VIEW, C.POINTER(_P)]),
     "ah_coalescer_finish_buffered_batch": (C.c_int32, [_P, _P]),

@@ -5,8 +5,10 @@ generic buffer-and-concat implementation (coalesce/generic.rs).
 
 The host state machine (exact-size output batches, in input order, optional large-batch bypass) is NATIVE —
 ``ah_coalescer_*`` (csrc/coalesce.hip): one C call per pushed batch, no wait except the predicate's count, one wait per
-finished batch; Boolean / Utf8 / LargeUtf8 columns are the native GenericInProgressArray there (pieces + concat).  Only
-schemas with view columns keep the Python restatement below; the data movement happens in HBM either way:
+finished batch; Boolean / Utf8 / LargeUtf8 columns are the native GenericInProgressArray there (pieces + concat), Utf8View /
+BinaryView columns the native InProgressByteViewArray (views as a 16-byte column; the data-buffer LISTS are kept here, the
+library shifts buffer indices and reports which inputs make up each output batch).  The Python restatement below is only
+the fallback for schemas the native object refuses (> 200 columns); the data movement happens in HBM either way:
   * ``copy_rows``                 -> ``ah_copy_rows_into`` (D2D copy + funnel-shift bitmap merge)
   * ``copy_rows_by_filter_from``  -> ``ah_filter_predicate_apply_into``: the filter scatters
     straight into the in-progress buffers (no intermediate filtered array, no second copy).
@@ -118,16 +120,21 @@ class BatchCoalescer:
         self.target_batch_size = int(target_batch_size)
         self.biggest_coalesce_batch_size = None
         self._native = None
-        def native_ok(dt):  # fixed-width (InProgressPrimitiveArray) or Boolean / Utf8 / LargeUtf8 (GenericInProgressArray)
-            if dt.physical in (L.AH_BOOL, L.AH_UTF8, L.AH_LARGE_UTF8):
+        def native_ok(dt):  # fixed-width (InProgressPrimitiveArray), Boolean / Utf8 / LargeUtf8 (GenericInProgressArray),
+            if dt.physical in (L.AH_BOOL, L.AH_UTF8, L.AH_LARGE_UTF8, L.AH_UTF8_VIEW, L.AH_BINARY_VIEW):  # views (InProgressByteViewArray)
                 return True
-            return dt.is_primitive() and dt.width > 0 and dt.physical not in (L.AH_UTF8_VIEW, L.AH_BINARY_VIEW)
+            return dt.is_primitive() and dt.width > 0
         if self.data_types and all(native_ok(dt) for dt in self.data_types) and len(self.data_types) <= 200:
             lib, h = self.ctx.lib, C.c_void_p()
             types = (C.c_int32 * len(self.data_types))(*[dt.physical for dt in self.data_types])
             self.ctx.check(lib.ah_coalescer_create(self.ctx.handle, len(self.data_types), types, self.target_batch_size, C.byref(h)))
             self._native = h
             self._tagged, self._next_tag = {}, 1
+            # view columns (InProgressByteViewArray, coalesce/byte_view.rs:39): the variadic data buffers stay on this side
+            # of the C ABI.  Every pushed batch is an input with a sequence number (the library counts the same way);
+            # `_inputs[seq]` = its view columns' buffer lists until no completed batch can refer to it any more
+            self._view_cols = [i for i, dt in enumerate(self.data_types) if dt.physical in (L.AH_UTF8_VIEW, L.AH_BINARY_VIEW)]
+            self._seq, self._inputs = 0, {}
             import weakref
             self._fin = weakref.finalize(self, lib.ah_coalescer_destroy, self.ctx.handle, h)
             return
@@ -180,6 +187,7 @@ class BatchCoalescer:
         n = len(self.data_types)
         outs = (L.ArrayOut * n)()
         rows, tag = C.c_int64(), C.c_uint64()
+        self._pending_sources = self._read_sources() if self._view_cols else []
         self.ctx.check(self.ctx.lib.ah_coalescer_next_completed_batch(self.ctx.handle, self._native, outs, C.byref(rows), C.byref(tag)))
         if rows.value < 0:
             return None
@@ -190,7 +198,36 @@ class BatchCoalescer:
             o = L.ArrayOut()
             C.memmove(C.byref(o), C.byref(outs[i]), C.sizeof(L.ArrayOut))
             cols.append(Array._from_out(self.ctx, o, dt))
+        if self._view_cols:
+            for i in self._view_cols:  # the inputs that contributed rows, in order: their buffer lists, concatenated
+                cols[i].data_buffers = [b for sq in self._pending_sources for b in self._inputs[sq][i]]
+            for sq in [k for k in self._inputs if self._pending_sources and k < self._pending_sources[0]]:
+                del self._inputs[sq]  # inputs contribute in push order: nothing older can show up again
         return RecordBatch(self.names, cols, num_rows=rows.value)
+
+    def _read_sources(self):
+        """which inputs make up the FRONT completed batch (``ah_coalescer_completed_batch_sources``)"""
+        n = C.c_int32()
+        self.ctx.check(self.ctx.lib.ah_coalescer_completed_batch_sources(self.ctx.handle, self._native, None, 0, C.byref(n)))
+        seqs = (C.c_uint64 * max(n.value, 1))()
+        self.ctx.check(self.ctx.lib.ah_coalescer_completed_batch_sources(self.ctx.handle, self._native, seqs, n.value, C.byref(n)))
+        return [int(seqs[i]) for i in range(n.value)]
+
+    def _declare_inputs(self, batches):
+        """before the native push of `batches` (view schemas): their data-buffer counts go to the library, their buffer
+        lists stay here under the sequence numbers the library will give them"""
+        if not self._view_cols:
+            return
+        nc = len(self.data_types)
+        counts = (C.c_int32 * (len(batches) * nc))()
+        for b_i, b in enumerate(batches):
+            bufs = {}
+            for i in self._view_cols:
+                bufs[i] = list(b.columns[i].data_buffers or [])
+                counts[b_i * nc + i] = len(bufs[i])
+            self._inputs[self._seq] = bufs
+            self._seq += 1
+        self.ctx.check(self.ctx.lib.ah_coalescer_declare_view_buffers(self.ctx.handle, self._native, len(batches), counts))
 
     def _views(self, batch):
         if batch.num_columns() != len(self.data_types):
@@ -207,6 +244,7 @@ class BatchCoalescer:
         tag = self._next_tag
         self._next_tag += 1
         bypassed = C.c_int32()
+        self._declare_inputs([batch])
         self.ctx.check(fn(self.ctx.handle, self._native, *args, tag, C.byref(bypassed)))
         if bypassed.value:
             self._tagged[tag] = batch
@@ -267,6 +305,7 @@ class BatchCoalescer:
             rows[i] = b.num_rows()
             tags[i] = self._next_tag
             self._next_tag += 1
+        self._declare_inputs([b for b, _f in pairs])
         self.ctx.check(self.ctx.lib.ah_coalescer_push_batches_with_filters(self.ctx.handle, self._native, n, views, rows, fviews,
                                                                            tags, bypassed))
         for i, (b, _f) in enumerate(pairs):
@@ -315,6 +354,7 @@ class BatchCoalescer:
     def push_batch_with_indices(self, batch, indices):
         if self._native is not None:
             views, iv = self._views(batch), indices.view()
+            self._declare_inputs([batch])
             return self.ctx.check(self.ctx.lib.ah_coalescer_push_batch_with_indices(self.ctx.handle, self._native, views,
                                                                                    batch.num_rows(), C.byref(iv)))
         return self.push_batch(take_record_batch(batch, indices))
@@ -388,6 +428,7 @@ class _PendingPush:
         n = len(pairs)
         bypassed = (C.c_int32 * n)()
         h, self.handle = self.handle, None
+        co._declare_inputs([b for b, _f in pairs])  # (the library numbers a group's batches when they are APPENDED: now)
         co.ctx.check(co.ctx.lib.ah_coalescer_push_batches_with_filters_end(co.ctx.handle, co._native, h, bypassed))
         for i, (b, _f) in enumerate(pairs):
             if bypassed[i]:

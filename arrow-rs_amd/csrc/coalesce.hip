@@ -14,7 +14,17 @@
 // in-progress buffers.  Boolean, Utf8 and LargeUtf8 columns are GenericInProgressArray (coalesce/generic.rs:32-108): the
 // in-progress batch keeps a list of pieces — filtered results are ADOPTED (and shared between two output batches when
 // they straddle a boundary, like the reference's Arc'ed slices), unfiltered rows are copied out of the caller's
-// borrowed buffers — and `concat`s them when the batch is finished.  View types: AH_NOT_YET_IMPLEMENTED.
+// borrowed buffers — and `concat`s them when the batch is finished.
+// Utf8View / BinaryView columns (round 4; InProgressByteViewArray, coalesce/byte_view.rs:39-330): the 16-byte views are a
+// fixed-width column like any other; what the reference's builder does on top — append the source's data buffers to the
+// in-progress array and shift every appended view's buffer index by the number of buffers already there
+// (byte_view.rs `append_views_and_update_buffer_index`) — is split between the two sides of the C ABI: the variadic data
+// buffers never enter it (filter / take of views work the same way), so the HOST declares how many buffers each pushed
+// batch carries (ah_coalescer_declare_view_buffers), the library shifts the buffer indices of the rows it appends
+// (rebase_views_kernel) and reports, per completed batch, WHICH inputs contributed rows and in which order
+// (ah_coalescer_completed_batch_sources: the push sequence numbers) — the host concatenates those inputs' buffer lists.
+// The reference additionally copies strings out of sparsely used buffers (its `ideal_buffer_size` GC heuristic); that
+// changes memory footprint, not the logical value, and is not done here.
 #include "common.hpp"
 
 #include <deque>
@@ -63,6 +73,10 @@ struct CoColumn {
   ah_type type = AH_INT64;
   int width = 8;
   bool generic = false;  // Boolean / Utf8 / LargeUtf8: pieces + concat
+  bool is_view = false;  // Utf8View / BinaryView: 16-byte views as a fixed-width column + buffer-index bookkeeping
+  uint32_t view_base = 0;  // data buffers the in-progress batch already references (from earlier contributing inputs)
+  uint32_t cur_base = 0;   // ... as it was when the CURRENT input started contributing: what its views are shifted by
+  int32_t cur_nbuf = 0;    // data buffers of the current input
   void* values = nullptr;
   uint8_t* validity = nullptr;
   size_t vbytes = 0, bbytes = 0;
@@ -101,6 +115,7 @@ ah_array_view piece_view(const GenPiece& p) {
 
 struct CoBatch {
   std::vector<ah_array_out> cols;
+  std::vector<uint64_t> sources;  // push sequence numbers of the inputs that contributed rows, in order (view schemas)
   int64_t rows = 0;
   uint64_t tag = 0;  // != 0: a bypassed input batch (borrowed buffers), the caller's tag for it
   // a finished batch whose null counts are still on their way: they land in pinned words [ring, ring + ncols) once the
@@ -129,11 +144,54 @@ struct ah_coalescer {
   uint64_t* cnt_pin = nullptr;
   uint64_t* cnt_pin_dev = nullptr;
   bool cnt_busy[2] = {false, false};
+  // view schemas: every push is an "input" with a sequence number (0, 1, 2, ... in push order; the host counts the same
+  // way); `declared` holds the per-column data-buffer counts of the inputs about to be pushed
+  bool has_views = false;
+  uint64_t input_seq = 0, cur_seq = 0;
+  std::deque<std::vector<int32_t>> declared;
+  std::vector<uint64_t> sources;  // inputs that have contributed rows to the in-progress batch
   double selectivity = 0.1;  // of the last filtered push: picks the speculative scatter's load-predication mode
   bool failed = false;       // a device error hit after rows had been enqueued into the in-progress batch
 };
 
 namespace {
+
+// views [0, n): buffer_index += base for the views that point into a data buffer (length > 12; byte_view.rs
+// `append_views_and_update_buffer_index`)
+__global__ void __launch_bounds__(256) rebase_views_kernel(uint4* views, int64_t n, uint32_t base) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    uint4 v = views[i];
+    if (v.x > 12u) {
+      v.z += base;
+      views[i] = v;
+    }
+  }
+}
+
+// a push starts: its sequence number, and (view schemas) the data-buffer counts the host declared for it
+ah_status begin_input(ah_context* ctx, ah_coalescer* co) {
+  co->cur_seq = co->input_seq++;
+  if (!co->has_views) return AH_OK;
+  if (co->declared.empty())
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "BatchCoalescer with view columns: call ah_coalescer_declare_view_buffers before each push");
+  const std::vector<int32_t> counts = co->declared.front();
+  co->declared.pop_front();
+  for (int i = 0; i < co->ncols; ++i) co->cols[i].cur_nbuf = co->cols[i].is_view ? counts[(size_t)i] : 0;
+  return AH_OK;
+}
+
+// the current input is about to append rows to the in-progress batch: the first time it does, it becomes a source of
+// that batch and its views are shifted by the buffers the batch already references
+void note_contribution(ah_coalescer* co) {
+  if (!co->has_views) return;
+  if (!co->sources.empty() && co->sources.back() == co->cur_seq) return;
+  co->sources.push_back(co->cur_seq);
+  for (auto& c : co->cols)
+    if (c.is_view) {
+      c.cur_base = c.view_base;
+      c.view_base += (uint32_t)c.cur_nbuf;
+    }
+}
 
 ah_status ensure_capacity(ah_context* ctx, ah_coalescer* co) {  // allocate on first write (primitive.rs:57-61)
   for (auto& c : co->cols) {
@@ -194,6 +252,8 @@ ah_status finish_buffered(ah_context* ctx, ah_coalescer* co) {  // coalesce.rs:5
   b.pending = true;
   b.seq = seq;
   b.ring = ring;
+  b.sources.swap(co->sources);  // (view schemas) the next batch starts with no buffers attached
+  for (auto& c : co->cols) c.view_base = c.cur_base = 0;
   b.cols.resize((size_t)co->ncols);
   for (int i = 0; i < co->ncols; ++i) {
     CoColumn& c = co->cols[i];
@@ -238,6 +298,7 @@ ah_status finish_buffered(ah_context* ctx, ah_coalescer* co) {  // coalesce.rs:5
 ah_status copy_rows_all(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns, int64_t offset, int64_t len,
                         const std::shared_ptr<GenOwner>* owners = nullptr) {
   AH_TRY(ensure_capacity(ctx, co));
+  note_contribution(co);
   for (int i = 0; i < co->ncols; ++i) {
     if (co->cols[i].generic) {
       if (owners && owners[i]) {
@@ -264,6 +325,10 @@ ah_status copy_rows_all(ah_context* ctx, ah_coalescer* co, const ah_array_view* 
       // retried push would double-count — the in-progress batch cannot be trusted any more
       if (i > 0) co->failed = true;
       return st;
+    }
+    if (co->cols[i].is_view && co->cols[i].cur_base > 0 && len > 0) {  // stream-ordered behind the copy
+      const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, ah_ceil_div(len, 256)));
+      rebase_views_kernel<<<g, 256, 0, ctx->stream>>>((uint4*)co->cols[i].values + co->buffered, len, co->cols[i].cur_base);
     }
   }
   return AH_OK;
@@ -306,6 +371,7 @@ ah_status bypass(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns
       o.null_count = nulls;
     }
   }
+  if (co->has_views) b.sources.push_back(co->cur_seq);  // the batch leaves with its own buffers, indices untouched
   co->completed.push_back(std::move(b));
   return AH_OK;
 }
@@ -359,13 +425,15 @@ extern "C" ah_status ah_coalescer_create(ah_context* ctx, int32_t n_columns, con
   for (int i = 0; i < n_columns; ++i) {
     const int w = ah_type_width(types[i]);
     const bool generic = types[i] == AH_BOOL || types[i] == AH_UTF8 || types[i] == AH_LARGE_UTF8;
-    if ((w <= 0 && !generic) || types[i] == AH_UTF8_VIEW || types[i] == AH_BINARY_VIEW) {
+    if (w <= 0 && !generic) {
       delete co;
       return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "BatchCoalescer column type %s", ah_type_name(types[i]));
     }
     co->cols[i].type = types[i];
     co->cols[i].width = w;
     co->cols[i].generic = generic;
+    co->cols[i].is_view = types[i] == AH_UTF8_VIEW || types[i] == AH_BINARY_VIEW;
+    co->has_views = co->has_views || co->cols[i].is_view;
   }
   // acc: 64 appended-null counters per column
   const size_t acc_bytes = (size_t)n_columns * 8 * 64;
@@ -427,6 +495,7 @@ extern "C" ah_status ah_coalescer_push_batch(ah_context* ctx, ah_coalescer* co, 
   if (!ctx || !co || !columns || num_rows < 0) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   AH_TRY(check_columns(ctx, co, columns, num_rows));
+  AH_TRY(begin_input(ctx, co));
   return push_batch_impl(ctx, co, columns, num_rows, tag, bypassed);
 }
 
@@ -455,7 +524,8 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
   int64_t done = done0;
   // (every window is a launch over the whole input batch: a push that would fill more than three output batches
   // goes through the materialised path below instead — one filter, then copies)
-  if (!exceeds && co->ncols <= 8 && selected - done <= (co->target - co->buffered) + 2 * co->target) {
+  // view schemas: always filter first, then copy (the appended views must pass through copy_rows_all's index shift)
+  if (!exceeds && !co->has_views && co->ncols <= 8 && selected - done <= (co->target - co->buffered) + 2 * co->target) {
     // Same-shape nullable columns: ONE scatter launch per output batch the filtered rows land in — positions
     // [done, done + take) of the filtered stream go straight into the in-progress batch, also when the batch straddles
     // two (or more) output batches.  No intermediate filtered array, no host wait besides finish_buffered's.
@@ -477,7 +547,7 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
     if (st != AH_OK || done == selected) return st;
   }
   const bool does_not_fit = selected - done > co->target - co->buffered;
-  if (exceeds || does_not_fit || done > 0) {  // materialise the filtered batch, then split it across output batches
+  if (exceeds || does_not_fit || done > 0 || co->has_views) {  // materialise the filtered batch, then split it across output batches
     std::vector<ah_array_out> outs((size_t)co->ncols);
     std::vector<ah_array_view> views((size_t)co->ncols);
     for (auto& o : outs) ah_out_init(&o);
@@ -513,6 +583,7 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
           b.rows = selected;
           b.cols = outs;  // ownership moves to the completed queue
           for (auto& o : outs) ah_out_init(&o);
+          if (co->has_views) b.sources.push_back(co->cur_seq);
           co->completed.push_back(std::move(b));
         }
       } else {
@@ -570,6 +641,7 @@ extern "C" ah_status ah_coalescer_push_batch_with_filter(ah_context* ctx, ah_coa
   if (!ctx || !co || !columns || !filter || num_rows < 0) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   AH_TRY(check_filter(ctx, co, columns, num_rows, filter));
+  AH_TRY(begin_input(ctx, co));
   ah_filter_predicate* p = nullptr;
   // One count pass for all columns; its K is the push's one host wait.  Without a bypass limit the rows that fit the
   // in-progress batch do not depend on K, so their scatter is enqueued BEFORE the wait (it clips itself to the rows
@@ -580,7 +652,7 @@ extern "C" ah_status ah_coalescer_push_batch_with_filter(ah_context* ctx, ah_coa
   ah_status st = AH_OK;
   int64_t room = 0;
   bool speculated = false;
-  if (enqueued && co->limit < 0 && co->ncols <= 8) {
+  if (enqueued && co->limit < 0 && co->ncols <= 8 && !co->has_views) {
     st = ensure_capacity(ctx, co);
     if (st == AH_OK) {
       void* dv[8];
@@ -656,7 +728,7 @@ namespace {
 
 // the grouped scatter is possible when there is no bypass limit and every column of every batch has the same shape
 bool group_fusable(const ah_coalescer* co, int n, const ah_array_view* columns, const ah_array_view* filters) {
-  bool fusable = co->limit < 0 && co->ncols <= 8 && n > 1;
+  bool fusable = co->limit < 0 && co->ncols <= 8 && n > 1 && !co->has_views;
   // generic columns (Boolean: width 0, Utf8 / LargeUtf8: width -1) keep piece lists, not in-progress buffers: they take
   // the per-batch path (an all-Boolean or all-Utf8 schema has "one width" too)
   for (int k = 0; k < co->ncols && fusable; ++k)
@@ -703,6 +775,7 @@ ah_status append_group(ah_context* ctx, ah_coalescer* co, int m, const ah_array_
         const int i = base + j;
         const ah_array_view* cols_i = columns + (size_t)i * co->ncols;
         const int64_t selected = ah_filter_predicate_count(preds[j]);
+        (void)begin_input(ctx, co);  // (fused path = no view columns: only the sequence number advances)
         if (selected == 0) continue;
         if (selected == num_rows[i] && filters[i].length == num_rows[i]) {  // every row: plain copies (coalesce.rs:229 -> push_batch)
           st = flush();
@@ -733,8 +806,10 @@ ah_status append_group(ah_context* ctx, ah_coalescer* co, int m, const ah_array_
     } else {
       for (int j = 0; j < m && st == AH_OK; ++j) {
         const int i = base + j;
-        st = push_filtered_impl(ctx, co, columns + (size_t)i * co->ncols, num_rows[i], &filters[i], preds[j], tags ? tags[i] : 0,
-                                bypassed ? &bypassed[i] : nullptr);
+        st = begin_input(ctx, co);
+        if (st == AH_OK)
+          st = push_filtered_impl(ctx, co, columns + (size_t)i * co->ncols, num_rows[i], &filters[i], preds[j], tags ? tags[i] : 0,
+                                  bypassed ? &bypassed[i] : nullptr);
       }
     }
   }
@@ -831,6 +906,7 @@ extern "C" ah_status ah_coalescer_push_batch_with_indices(ah_context* ctx, ah_co
   if (!ctx || !co || !columns || !indices || num_rows < 0) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   AH_TRY(check_columns(ctx, co, columns, num_rows));
+  AH_TRY(begin_input(ctx, co));
   std::vector<ah_array_out> outs((size_t)co->ncols);
   for (auto& o : outs) ah_out_init(&o);
   ah_status st = AH_OK;
@@ -845,6 +921,7 @@ extern "C" ah_status ah_coalescer_push_batch_with_indices(ah_context* ctx, ah_co
         b.rows = rows;
         b.cols = outs;
         for (auto& o : outs) ah_out_init(&o);
+        if (co->has_views) b.sources.push_back(co->cur_seq);
         co->completed.push_back(std::move(b));
       }
     } else {
@@ -868,6 +945,36 @@ extern "C" ah_status ah_coalescer_push_batch_with_indices(ah_context* ctx, ah_co
   }
   for (auto& o : outs) ah_array_release(ctx, &o);  // fixed-width copies are stream-ordered behind the pool's reuse
   return st;
+}
+
+// View schemas: the data-buffer counts (n_columns entries per batch; ignored for non-view columns) of the next `n_batches`
+// pushed batches, in push order.  The buffers themselves stay with the host.
+extern "C" ah_status ah_coalescer_declare_view_buffers(ah_context* ctx, ah_coalescer* co, int32_t n_batches, const int32_t* counts) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !co || n_batches < 0 || (n_batches > 0 && !counts)) return AH_INVALID_ARGUMENT;
+  for (int b = 0; b < n_batches; ++b) {
+    std::vector<int32_t> c(counts + (size_t)b * co->ncols, counts + (size_t)(b + 1) * co->ncols);
+    for (int i = 0; i < co->ncols; ++i)
+      if (co->cols[i].is_view && c[(size_t)i] < 0) return ah_fail(ctx, AH_INVALID_ARGUMENT, "negative data buffer count for column %d", i);
+    co->declared.push_back(std::move(c));
+  }
+  return AH_OK;
+}
+
+// The inputs (push sequence numbers: the first push of a coalescer's life is 0, every pushed batch counts — grouped
+// pushes one per batch) whose rows make up the FRONT completed batch, in order: a view column's data buffers are the
+// concatenation of those inputs' buffer lists.  *n = how many there are (may exceed `cap`: call again with more room).
+extern "C" ah_status ah_coalescer_completed_batch_sources(ah_context* ctx, ah_coalescer* co, uint64_t* seqs, int32_t cap, int32_t* n) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !co || !n || cap < 0 || (cap > 0 && !seqs)) return AH_INVALID_ARGUMENT;
+  if (co->completed.empty()) {
+    *n = 0;
+    return AH_OK;
+  }
+  const std::vector<uint64_t>& s = co->completed.front().sources;
+  *n = (int32_t)s.size();
+  for (int32_t i = 0; i < cap && i < (int32_t)s.size(); ++i) seqs[i] = s[(size_t)i];
+  return AH_OK;
 }
 
 extern "C" ah_status ah_coalescer_finish_buffered_batch(ah_context* ctx, ah_coalescer* co) {

@@ -353,6 +353,16 @@ AH_API ah_status ah_coalescer_push_batches_with_filters_begin(ah_context* ctx, a
                                                               ah_coalescer_push** handle);
 AH_API ah_status ah_coalescer_push_batches_with_filters_end(ah_context* ctx, ah_coalescer* co, ah_coalescer_push* handle,
                                                             int32_t* bypassed /* n entries, nullable */);
+/* Utf8View / BinaryView columns (InProgressByteViewArray, coalesce/byte_view.rs:39).  A view column is pushed as its
+ * 16-byte views; the variadic data buffers stay with the host, as for filter / take.  Two calls carry what the
+ * reference's builder does with them: BEFORE pushing, declare how many data buffers each view column of the next
+ * `n_batches` batches has (n_batches x n_columns counts, batch-major; entries of non-view columns are ignored) — the
+ * library shifts the buffer indices of the views it appends by the buffers the in-progress batch already references;
+ * BEFORE fetching a completed batch, ask which inputs contributed rows to it — push sequence numbers, in order (every
+ * pushed batch of the coalescer's life counts: 0, 1, 2, ...; a grouped push counts one per batch) — and attach the
+ * concatenation of those inputs' buffer lists to the fetched view columns. */
+AH_API ah_status ah_coalescer_declare_view_buffers(ah_context* ctx, ah_coalescer* co, int32_t n_batches, const int32_t* counts);
+AH_API ah_status ah_coalescer_completed_batch_sources(ah_context* ctx, ah_coalescer* co, uint64_t* seqs, int32_t cap, int32_t* n);
 /* push_batch_with_indices (coalesce.rs:289): take_record_batch(batch, indices), then push_batch of the result; indices
  * as for ah_take (unchecked: an out-of-range index is the reference's panic, AH_PANIC). */
 AH_API ah_status ah_coalescer_push_batch_with_indices(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns,

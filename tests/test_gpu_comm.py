@@ -79,8 +79,8 @@ def test_exchange_code_across_processes_over_a_fake_transport(world, tmp_path):
         assert p.returncode == 0 and f"COMM_RCCL_RANK_OK {r}/{world}" in o, f"rank {r}:\n{o[-3000:]}"
 
 
-@pytest.mark.parametrize("workload", ["filter_take", "record_batch"])
-def test_bench_self_spawned_ranks_over_the_c_abi_transport(workload, tmp_path, ctx, oracle):
+@pytest.mark.parametrize("workload,launcher", [("filter_take", "self"), ("record_batch", "self"), ("filter_take", "torchrun")])
+def test_bench_self_spawned_ranks_over_the_c_abi_transport(workload, launcher, tmp_path, ctx, oracle):
     """`python bench.py --gpus 2` started PLAINLY — the path the driver's 8-GPU run takes: bench.py spawns its own ranks,
     a gloo group ships the 128-byte id, every rank builds a CApiCommunicator and the reassembly goes through
     ah_all_gather_columns_begin / _end ACROSS PROCESSES (VERDICT r03 missing #1).  One GPU here, so both ranks sit on
@@ -102,6 +102,17 @@ def test_bench_self_spawned_ranks_over_the_c_abi_transport(workload, tmp_path, c
     env.pop("RANK", None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", str(rows),
            "--no-cpu-baseline", "--workload", workload, "--config-steps", "2", "--dump-gathered", dump]
+    if launcher == "torchrun":
+        # EXACTLY the driver's N > 1 command line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+        # 127.0.0.1 --master-port P bench.py --gpus N ...`): the launcher's ranks, gloo rendezvous for the id, ah_comm transport
+        import socket
+        so = socket.socket()
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+        so.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + cmd[1:]
+        env["GLOO_SOCKET_IFNAME"] = "lo"
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-4000:])

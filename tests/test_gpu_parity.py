@@ -1377,6 +1377,85 @@ def test_batch_coalescer_grouped_pushes_generic_schemas(ctx, oracle, schema):
         assert co.is_empty()
 
 
+@pytest.mark.parametrize("dt", [A.Utf8View, A.BinaryView], ids=str)
+def test_batch_coalescer_view_columns(ctx, oracle, dt):
+    """Utf8View / BinaryView columns through the native coalescer (InProgressByteViewArray, coalesce/byte_view.rs:39;
+    VERDICT r03 missing #4): inputs with MANY data buffers each (so buffer indices really are shifted), pushed plain,
+    filtered (single, grouped, pipelined) and by indices, straddling output batches, next to an Int64 column, with and
+    without a bypass limit — every output batch must hold exactly the rows of the coalesce.rs model, as logical values
+    (views are decoded through the buffer list the mirror attaches: a wrong index shift reads the wrong bytes)."""
+    from coalesce_model import ModelCoalescer
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(dt.name.encode()))
+    dts = [dt, A.Int64]
+    names = ["v", "i"]
+
+    def make(n):
+        items = _view_items(rng, n)
+        # the MODEL's column is LargeUtf8 (the CPU oracle has no view layout; the logical values are the same strings)
+        host_v = HostArray(A.LargeUtf8, [x if x is not None else "" for x in items],
+                           np.array([x is not None for x in items]) if any(x is None for x in items) else None)
+        dev_items = items if dt == A.Utf8View else [None if x is None else x.encode() for x in items]
+        dev_v = A.Array.from_string_views(dev_items, dt, ctx=ctx, block_size=int(rng.choice([64, 256, 8192])))
+        host_i = HostArray(A.Int64, rng.integers(-99, 99, n), rng.random(n) < 0.9)
+        return [host_v, host_i], A.RecordBatch(names, [dev_v, host_i.to_device(ctx)], n)
+
+    def same(co, model, tag):
+        while True:
+            b = co.next_completed_batch()
+            if b is None:
+                break
+            assert model.completed, f"{tag}: extra batch"
+            exp = model.completed.popleft()
+            assert b.num_rows() == len(exp[0]), tag
+            got_v = [x.decode() if isinstance(x, bytes) else x for x in b.columns[0].to_pylist()]
+            want_v = [x if (exp[0].valid is None or exp[0].valid[k]) else None for k, x in enumerate(exp[0].values)]
+            assert got_v == want_v, f"{tag}: view column"
+            check(b.columns[1], exp[1], tag)
+        assert not model.completed, f"{tag}: missing batches"
+
+    for trial, limit in enumerate([None, None, 400]):
+        target = int(rng.choice([37, 500, 2000]))
+        co = K.BatchCoalescer.new(names, dts, target, ctx).with_biggest_coalesce_batch_size(limit)
+        model = ModelCoalescer(oracle, [A.LargeUtf8, A.Int64], target)
+        model.limit = limit
+        for step in range(28):
+            n = int(rng.integers(1, 3 * target + 5))
+            hosts, batch = make(n)
+            kind = step % 5
+            if kind == 0:
+                co.push_batch(batch)
+                model.push(hosts)
+            elif kind == 1:
+                f = HostArray(A.Boolean, rng.random(n) < float(rng.choice([0.0, 0.1, 0.6, 1.0])), (rng.random(n) < 0.9) if step % 2 else None)
+                co.push_batch_with_filter(batch, f.to_device(ctx))
+                model.push_with_filter(hosts, f)
+            elif kind == 2:
+                idx = HostArray(A.UInt32, rng.integers(0, n, int(rng.integers(0, 2 * n))).astype(np.uint32))
+                co.push_batch_with_indices(batch, idx.to_device(ctx))
+                model.push_with_indices(hosts, idx)
+            else:  # grouped (3) / pipelined grouped (4): two or three filtered batches in one call
+                pairs, hp = [], []
+                for _ in range(int(rng.integers(2, 4))):
+                    m_ = int(rng.integers(1, 2 * target))
+                    h2, b2 = make(m_)
+                    f = HostArray(A.Boolean, rng.random(m_) < float(rng.choice([0.05, 0.5, 1.0])))
+                    pairs.append((b2, f.to_device(ctx)))
+                    hp.append((h2, f))
+                if kind == 3:
+                    co.push_batches_with_filters(pairs)
+                else:
+                    co.push_batches_with_filters_begin(pairs).end()
+                for h2, f in hp:
+                    model.push_with_filter(h2, f)
+            assert co.get_buffered_rows() == model.buffered, f"{dt} trial {trial} step {step}"
+            same(co, model, f"{dt} trial {trial} step {step} kind {kind}")
+        co.finish_buffered_batch()
+        model.finish()
+        same(co, model, f"{dt} trial {trial} final")
+        assert co.is_empty()
+
+
 # ------------------------------------------------- RCCL reassembly, 1 rank
 def test_communicator_world1_nccl(ctx, oracle):
     """Plumbing of the RCCL path with a single rank (the box has one GPU): count exchange,
