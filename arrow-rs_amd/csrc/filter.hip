@@ -858,7 +858,9 @@ void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, 
   // ~150 ns each (0.55 ms), which shows as soon as the scatter itself is faster than that (3 % selected: 1.02 -> 0.72 ms).
   // (up to ~12 % selected; a denser scatter runs long enough to hide its counter atomics, and counting a 125 MB bitmap
   // afterwards would only add to it)
-  const bool count_after = HV && out_rows > 0 && out_rows * 8 <= a_in.len && !a.nulls_mode && a.out_base == 0 && a.win_hi == 0;
+  const bool plain = !a.nulls_mode && a.out_base == 0 && a.win_hi == 0;
+  const bool no_count = HV && plain && a_in.valid_slots == nullptr && ncols == 1;  // (deferred results: nobody wants the count)
+  const bool count_after = HV && !no_count && out_rows > 0 && out_rows * 8 <= a_in.len && plain;
   auto launch_count = [&]() {
     const int64_t nwords = (out_rows + 63) >> 6;
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, ah_ceil_div(nwords, 256 * 4)));
@@ -872,7 +874,7 @@ void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, 
   if constexpr (W != 0 || HV) {
     // the sparse form serves plain results; the windowed / NULL-counting launches of the coalescer keep the tiled kernel
     // (W == 0, round 4: the bit-only stream of filter_boolean / filter_nulls takes it too)
-    if (sparse && (!HV || count_after)) {
+    if (sparse && (!HV || count_after || no_count)) {
       b.ntiles = ah_ceil_div(a_in.len, 4096);  // one 4096-row tile per wave, four per workgroup
       const int64_t nwg = (b.ntiles + 3) >> 2;
       dim3 g((unsigned)(a.xcd_remap ? 8 * ((nwg + 7) / 8) : nwg), (unsigned)ncols);
@@ -1229,13 +1231,12 @@ static ah_status compact_bits(ah_context* ctx, const ah_filter_predicate* p, Bit
   a.group_shift = p->group_shift;
   a.out_values = nullptr;
   a.out_valid = (unsigned long long*)ob;
-  a.valid_slots = slots;
+  a.valid_slots = defer ? nullptr : slots;  // (deferred: the count is reported as unknown, nothing to fold or restore)
   // a sparse selection (<= 1 selected row in 32): the wave-per-tile kernel, set bits counted from the small output
   // bitmap afterwards — as for fixed-width values; filter_boolean was the one value kind left on the tiled
   // kernel at low selectivity
   launch_scatter<true>(ctx, 0, a, false, 1, use_sparse_bits(p->count, p->len), p->count);
   if (defer) {  // no read-back: the caller reports the count as unknown
-    filter_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, nullptr, 0);
     *set_bits = -1;
     *out_bits = (uint8_t*)ob;
     *out_bytes = bytes;
@@ -1379,7 +1380,9 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
       ah_out_free(ctx, ov, vbytes);
       return st;
     }
-    slots = ctx->scratch;  // zero between calls (filter_finish_kernel restores it)
+    // deferred mode reports null_count = -1 ("unknown"): nothing counts the valid rows, so there are no counters to fold
+    // and restore afterwards — one launch less per call (host launch cost is what bounds a batch of small deferred calls)
+    slots = defer ? nullptr : ctx->scratch;  // zero between calls (filter_finish_kernel restores it)
     hipMemsetAsync(ob, 0, bbytes, ctx->stream);
   }
   ScatterArgs a{};
@@ -1403,11 +1406,11 @@ extern "C" ah_status ah_filter_predicate_apply(ah_context* ctx, const ah_filter_
   // ONE host wait for the whole scatter: the finish kernel folds the valid-row counters, restores them to
   // zero and posts the mailbox (no D2H copy engine, no hipStreamSynchronize)
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess && has_valid) {
-    const uint64_t seq = defer ? 0 : ah_mail_next(ctx);
-    filter_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, defer ? nullptr : ctx->pinned_dev, seq);
+  if (e == hipSuccess && has_valid && !defer) {
+    const uint64_t seq = ah_mail_next(ctx);
+    filter_finish_kernel<<<1, 64, 0, ctx->stream>>>(slots, ctx->pinned_dev, seq);
     e = hipGetLastError();
-    if (e == hipSuccess && !defer) e = ah_mail_wait(ctx, seq);
+    if (e == hipSuccess) e = ah_mail_wait(ctx, seq);
   } else if (e == hipSuccess && !defer) {
     e = ah_stream_wait(ctx);
   }

@@ -1,22 +1,31 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence committed under profiles/ (run on the GPU box via gpurun):
-#   kernel-trace + stats, then FETCH_SIZE and WRITE_SIZE in their own passes (PMC never combined
-#   with sys/runtime tracing).  Usage: bash tools/collect_profiles.sh <round-tag>
-TAG=${1:-r01}
+# Collects one round's rocprofv3 / bench evidence for profiles/ (run on the GPU box via gpurun):
+#   usage: bash tools/collect_profiles.sh <round tag, e.g. r04>      -> gpurun_out/profiles_<tag>/, then
+#          python tools/profile_summary.py <tag> gpurun_out/profiles_<tag>   (in the build container) writes profiles/<tag>_*
+# the default bench line (all single-GPU configs + next rows + reference bench shapes + in-run PMC traffic + crossover + CPU
+# baselines; FULL-DETAIL object via --detail-json, the compact stdout line beside it), a kernel trace of that same command,
+# per-workload lines with in-run PMC traffic, traces of the coalescer / string filter / lazy predicate steps with the
+# GPU-timeline gap analysis, and the world-1 exchange through the C ABI (filter_take and configs[4]).
+# (One parametrised script since round 4; rounds 1-3 had a copy per round — see the git history.)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/profiles_$TAG
-mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/trace.log
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.json 2> $OUT/fetch.log
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o bench -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_write.json 2> $OUT/write.log
-for wl in arith cmp aggregate; do
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$wl -o bench -- python bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/fetch_$wl.log
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$wl -o bench -- python bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/write_$wl.log
+R=${1:-r04}
+O=gpurun_out/profiles_$R
+mkdir -p $O
+timeout 900 python bench.py --steps 20 --warmup 5 --detail-json $O/bench_default.json > $O/bench_default.compact.json 2> $O/bench_default.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --pmc-traffic off --detail-json "" > $O/bench_trace.json 2> $O/trace.log
+for wl in arith cmp cast cast_string; do
+  timeout 300 python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --detail-json $O/bench_$wl.json > /dev/null 2> $O/bench_$wl.err
 done
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/sq -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/sq.log
-for wl in arith cmp cast cast_string coalesce string_filter_take aggregate sort; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o bench -- python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_$wl.json 2> $OUT/trace_$wl.log
+for wl in coalesce string_filter string_take predicate_filter predicate_filter_fused; do  # roofline over ALL launches of a step, PMC traffic summed per step
+  timeout 300 python bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --detail-json $O/bench_$wl.json > /dev/null 2> $O/bench_$wl.err
 done
-python tools/next_rows_time.py > $OUT/next_rows.json 2> $OUT/next_rows.log
-python bench.py --steps 10 --warmup 3 > $OUT/bench_plain.json 2> $OUT/bench_plain.log
-find $OUT -name "*.csv" | head -40
+timeout 300 python bench.py --workload record_batch --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off --detail-json $O/bench_record_batch.json > /dev/null 2> $O/bench_record_batch.err
+for wl in coalesce string_filter predicate_filter_fused; do
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$wl -o bench -- python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --pmc-traffic off --detail-json "" > /dev/null 2> $O/trace_$wl.log
+  python tools/kernel_gaps.py $(find $O/trace_$wl -name "*kernel_trace.csv" | head -1) --tail-ms 18 > $O/gaps_$wl.md 2>/dev/null
+  find $O/trace_$wl -name "*kernel_trace.csv" -delete   # (tens of MB; the stats CSV and the gap table are what is kept)
+done
+find $O/trace -name "*kernel_trace.csv" -delete
+timeout 300 python bench.py --reassemble allgatherv --steps 5 --warmup 2 --no-cpu-baseline --config-steps 3 --pmc-traffic off --detail-json $O/bench_exchange_world1.json > /dev/null 2> $O/bench_exchange_world1.err
+AH_WAIT=block timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-configs --pmc-traffic off --detail-json $O/bench_wait_block.json > /dev/null 2>&1
+ls $O

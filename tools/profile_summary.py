@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Turns a tools/collect_profiles.sh output directory into the markdown + CSV evidence
-committed under profiles/.  usage: profile_summary.py gpurun_out/profiles_r01 r01"""
-import collections
+"""Turns a tools/collect_profiles.sh output directory into the evidence committed under profiles/ (one parametrised tool
+since round 4; the per-round copies of rounds 1-3 are in the git history).
+usage: python tools/profile_summary.py <round tag, e.g. r04> gpurun_out/profiles_<tag>"""
 import csv
 import json
 import os
@@ -9,9 +9,19 @@ import re
 import shutil
 import sys
 
-src, tag = sys.argv[1], sys.argv[2]
+R, src = sys.argv[1], sys.argv[2]
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(dst, exist_ok=True)
+
+
+def line_of(name):
+    p = os.path.join(src, name)
+    if not os.path.exists(p):
+        return None
+    for l in open(p):
+        if l.startswith("{"):
+            return json.loads(l)
+    return None
 
 
 def short(name):
@@ -20,135 +30,138 @@ def short(name):
     return m.group(1) if m else name[:60]
 
 
-def bench_line(path):
-    if not os.path.exists(path):
-        return None
-    for l in open(path):
-        if l.startswith("{"):
-            return json.loads(l)
-    return None
+out = [f"# rocprofv3 / bench evidence, round {R} (one MI355X, ROCm 7.2; builder-side gpurun box)\n",
+       "Produced by `tools/collect_profiles.sh` + `tools/profile_summary.py`.  Kernel times: HIP events recorded by the",
+       "library on its launch stream (`kernel_avg_ms`), cross-checked by the rocprofv3 kernel trace below.  `traffic` = HBM",
+       "bytes per launch from rocprofv3 PMC passes run INSIDE the bench invocation (FETCH_SIZE and WRITE_SIZE in separate",
+       "passes; FETCH_SIZE doubled: this rocprofv3 tallies every 128-byte L2 line fill at 64 bytes — calibrated with",
+       "TCC_EA0_RDREQ_128B in `r02_take_ablation.md`).  `frac` = algorithmic bytes (SURVEY §8d) / kernel time / 8 TB/s.\n"]
 
+d = line_of("bench_default.json")
+if d:
+    shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(dst, f"{R}_bench_default.json"))
+    rf, fs = d["roofline"], d.get("roofline_filter_scatter", {})
+    out.append("## The default line: `python bench.py --steps 20 --warmup 5` (configs[1] + configs[2] + configs[3] + the SURVEY 8f rows)\n")
+    out.append(f"value **{d['value']} Mrows/s**, {d['ms_per_step']} ms per step, host_gap_ms {d['host_gap_ms']} "
+               f"(step time minus its profiled kernels), kernels {d['kernel_avg_ms']}.\n")
+    out.append("| kernel / config | avg ms | algorithmic GB per launch | GB/s | frac of 8 TB/s | PMC traffic GB per launch | traffic frac |")
+    out.append("|---|---|---|---|---|---|---|")
 
-out = [f"# rocprofv3 evidence, round {tag} (MI355X, ROCm 7.2)\n",
-       "Collected by `tools/collect_profiles.sh` (kernel-trace + stats; FETCH_SIZE and WRITE_SIZE each in their own",
-       "PMC pass).  Times in µs.  FETCH_SIZE/WRITE_SIZE are KB as reported; per MI355X_MICROARCH.md §HBM, FETCH_SIZE of a",
-       "wide coalesced stream reads exactly half the bytes (doubled in the `HBM bytes` column for streaming kernels,",
-       "NOT for the random gather whose 128-B line fills are tallied in full); WRITE_SIZE is calibrated",
-       "(gen_i64 writes 8.0e9 B and reports 7 812 500 KB).\n"]
+    def row(name, r):
+        tr = r.get("traffic")
+        out.append(f"| {name} | {r['avg_launch_ms']} | {r['algorithmic_bytes_per_launch'] / 1e9:.3f} | {r['achieved']} | {r['frac']} | "
+                   f"{tr / 1e9:.2f} | {r.get('traffic_frac')} |" if tr else
+                   f"| {name} | {r['avg_launch_ms']} | {r['algorithmic_bytes_per_launch'] / 1e9:.3f} | {r['achieved']} | {r['frac']} | — | — |")
+    if fs:
+        row("filter_scatter (configs[1] filter)", fs)
+    row(f"{rf['kernel']} (configs[1] take, 1e8 random u32 indices)", rf)
+    for k, v in d.get("configs", {}).items():
+        if "roofline" in v:
+            row(f"{v['roofline']['kernel']} ({k}: {v['rows']} rows, {v['ms']} ms per call)", v["roofline"])
+    for k, v in d.get("next_rows", {}).items():
+        if "roofline" in v:
+            extra_ms = f", {v['ms_without_kernel_events']} ms without per-kernel events" if "ms_without_kernel_events" in v else ""
+            row(f"{v['roofline']['kernel']} (next_rows.{k}: {v['rows']} rows, {v['ms']} ms per step{extra_ms}; all launches of a step)"
+                if k != "record_batch" else f"{v['roofline']['kernel']} (next_rows.{k}: {v['rows']} rows, {v['ms']} ms per call)", v["roofline"])
+    if "requests" in rf:
+        out.append(f"\ntake_gather in line fills: {rf['requests']}\n")
+    if d.get("roofline_take_sorted"):
+        out.append(f"take with sorted indices (positions of the predicate): {d['roofline_take_sorted']}\n")
+    if d.get("crossover_rows"):
+        out.append(f"crossover_rows: {d['crossover_rows']}\n")
+    if d.get("filter_by_selectivity"):
+        out.append(f"filter_scatter at other selectivities of the same column (the sparse path below 3 %): {d['filter_by_selectivity']}\n")
+    out.append(f"take variants: sorted indices {d.get('take_sorted_indices_ms')} ms, 10 % null indices {d.get('take_null_indices_ms')} ms.\n")
+    cb = d.get("cpu_baseline", {})
+    out.append(f"cpu_baseline (oracle = scalar port of the reference, same box): {cb.get('value')} Mrows/s on 1 core; all cores: "
+               f"{cb.get('all_cores')}; Arrow C++ sanity: {cb.get('arrow_cpp_sanity')}.\n")
 
-for sub, title in [("trace", "filter + take step (bench.py default)"), ("trace_arith", "add_wrapping f64"),
-                   ("trace_cmp", "lt f64"), ("trace_cast", "cast Int64->Float64"),
-                   ("trace_cast_string", "cast Float64->LargeUtf8"),
-                   ("trace_coalesce", "BatchCoalescer.push_batch_with_filter (2 columns, 2^24-row batches)"),
-                   ("trace_string_filter_take", "filter + take on a LargeUtf8 column (2^27 rows)"),
-                   ("trace_aggregate", "sum + min + max of an Int64 column (1e9 rows, 10 % nulls)"),
-                   ("trace_sort", "sort_to_indices of a full-range Int64 column (2^29 rows, 10 % nulls)")]:
-    p = os.path.join(src, sub, "bench_kernel_stats.csv")
-    if not os.path.exists(p):
-        continue
-    shutil.copy(p, os.path.join(dst, f"{tag}_{sub}_kernel_stats.csv"))
-    out.append(f"## {title}\n")
-    b = bench_line(os.path.join(src, f"bench_{sub.replace('trace_', '') if sub != 'trace' else 'trace'}.json"))
-    if b:
-        out.append(f"bench line under the profiler: value {b['value']} {b['unit']}, {b['ms_per_step']} ms/step, "
-                   f"roofline {json.dumps(b['roofline'])}\n")
+p = os.path.join(src, "trace", "bench_kernel_stats.csv")
+if os.path.exists(p):
+    shutil.copy(p, os.path.join(dst, f"{R}_trace_kernel_stats.csv"))
+    out.append("## rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3` (same workloads; times in µs)\n")
     out.append("| kernel | calls | avg µs | min µs | max µs | % |")
     out.append("|---|---|---|---|---|---|")
     for r in csv.DictReader(open(p)):
-        if float(r["Percentage"]) < 0.05:
+        if float(r["Percentage"]) < 0.04:
             continue
-        out.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
-                   f"{float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
-    out.append("")
+        out.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
+                   f"{float(r['MaxNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+    out.append("\n(`take_kernel`'s average mixes the random-index launches of the step, 3.7–3.9 ms, with the sorted-index "
+               "launches of the extra measurement, 1.5 ms.)\n")
 
-pm = {}
-for sub, cname in [("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")]:
-    p = os.path.join(src, sub, "bench_counter_collection.csv")
-    if not os.path.exists(p):
+out.append("## Per-workload lines with in-run PMC traffic\n")
+out.append("| workload | ms per call (without per-kernel events) | roofline kernel | frac | traffic_frac | PMC traffic per launch / step (GB) | host_gap_ms |")
+out.append("|---|---|---|---|---|---|---|")
+traffic = {}
+for wl in ["arith", "cmp", "cast", "cast_string", "coalesce", "record_batch", "string_filter", "string_take", "predicate_filter",
+           "predicate_filter_fused"]:
+    d2 = line_of(f"bench_{wl}.json")
+    if not d2:
         continue
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(p)):
-        k = short(r["Kernel_Name"])
-        if k.startswith("take_kernel"):  # random-index launches (>2.5 ms) vs the sorted-index extra launches
-            dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-            k += " [random idx]" if dur > 2.5 else " [sorted idx]"
-        agg[k].append(float(r["Counter_Value"]))
-    pm[cname] = {k: (len(v), sum(v) / len(v)) for k, v in agg.items()}
-    with open(os.path.join(dst, f"{tag}_{cname}_per_kernel.csv"), "w") as f:
-        f.write("kernel,dispatches,avg_value_KB\n")
-        for k, (n, a) in sorted(pm[cname].items(), key=lambda kv: -kv[1][1]):
-            f.write(f"\"{k}\",{n},{a:.1f}\n")
-if pm:
-    out.append("## HBM traffic per launch (PMC)\n")
-    out.append("| kernel | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes per launch (corrected) | note |")
-    out.append("|---|---|---|---|---|")
-    traffic = {}
-    for k, key in [("filter_scatter_kernel<8, 2, true, true>", "filter_scatter"),
-                   ("take_kernel<8, unsigned int, true, 4> [random idx]", "take_gather"),
-                   ("take_kernel<8, unsigned int, true, 4> [sorted idx]", "take_gather_sorted"),
-                   ("filter_count_kernel", "filter_count")]:
-        f = pm.get("FETCH_SIZE", {}).get(k, (0, 0))[1]
-        w = pm.get("WRITE_SIZE", {}).get(k, (0, 0))[1]
-        if "random" in k:
-            total = f * 1024 + w * 1024
-            note = "8-byte random gathers: each fills one 128-B line, tallied in full (no x2)"
-        else:
-            total = 2 * f * 1024 + w * 1024
-            note = "wide coalesced reads: FETCH x2 (guide correction)"
-        traffic[key] = round(total)
-        out.append(f"| {k} | {f:.0f} | {w:.0f} | {total/1e9:.2f} GB | {note} |")
+    tr = d2.get("pmc_traffic_bytes_per_launch")
+    traffic[wl] = tr
+    out.append(f"| {wl} | {d2['ms_per_step']} ({d2.get('ms_per_step_without_kernel_events', '—')}) | {d2['roofline']['kernel']} | "
+               f"{d2['roofline']['frac']} | {d2['roofline'].get('traffic_frac', '—')} | "
+               f"{ {k: round(v / 1e9, 2) for k, v in tr.items()} if isinstance(tr, dict) else '—'} | {d2.get('host_gap_ms')} |")
+    shutil.copy(os.path.join(src, f"bench_{wl}.json"), os.path.join(dst, f"{R}_bench_{wl}.json"))
+out.append("")
+
+for tag, title in (("trace_coalesce", "coalesce (BatchCoalescer, 60 batches of 2^24 rows per step, pushed 8 at a time)"),
+                   ("trace_string_filter", "string_filter (LargeUtf8 column, 2^27 rows, 10 % selected)"),
+                   ("trace_predicate_filter_fused", "predicate_filter_fused (ah_filter_expr: WHERE a < 0 AND b >= 0.0, 1e9 rows)")):
+    p2 = os.path.join(src, tag, "bench_kernel_stats.csv")
+    if os.path.exists(p2):
+        shutil.copy(p2, os.path.join(dst, f"{R}_{tag}_kernel_stats.csv"))
+        out.append(f"## rocprofv3 --kernel-trace --stats: {title}; times in µs\n")
+        out.append("| kernel | calls | avg µs | min µs | % |")
+        out.append("|---|---|---|---|---|")
+        for r in csv.DictReader(open(p2)):
+            if float(r["Percentage"]) < 0.5:
+                continue
+            out.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
+                       f"{float(r['Percentage']):.2f} |")
+        out.append("")
+
+for wl, title in (("coalesce", "coalesce"), ("string_filter", "string_filter"), ("predicate_filter_fused", "predicate_filter_fused")):
+    p3 = os.path.join(src, f"gaps_{wl}.md")
+    if os.path.exists(p3) and os.path.getsize(p3):
+        shutil.copy(p3, os.path.join(dst, f"{R}_gaps_{wl}.md"))
+        out.append(f"## GPU timeline of the `{title}` step under rocprofv3 (tools/kernel_gaps.py: idle time between kernels, by the pair around the gap)\n")
+        out.append(open(p3).read())
+if d and isinstance(d.get("reference_bench_shapes"), dict) and "shapes" in d["reference_bench_shapes"]:
+    rs = d["reference_bench_shapes"]
+    out.append("## The reference's own criterion shapes through the raw C ABI (`reference_bench_shapes`; microseconds per call)\n")
+    out.append(rs["what"] + "\n")
+    out.append("| shape | rows | synchronous call | per call in a batch of %d | 1-core oracle | batched beats one core |" % rs["batch"])
+    out.append("|---|---|---|---|---|---|")
+    for k, v in rs["shapes"].items():
+        out.append(f"| {k} | {v['rows']} | {v['sync_us']} | {v['batched_us'] if v['batched_us'] is not None else '— (synchronous by contract)'} | "
+                   f"{v['cpu_1core_us']} | {v['batched_beats_cpu'] if v['batched_beats_cpu'] is not None else v['sync_beats_cpu']} |")
     out.append("")
-    json.dump({"source": f"profiles/{tag}_FETCH_SIZE_per_kernel.csv + {tag}_WRITE_SIZE_per_kernel.csv",
-               "workload": "bench.py default (1e9 Int64 rows, 10% nulls, 10% selectivity, 1e8 random u32 indices)",
-               "hbm_bytes_per_launch": traffic}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
-# streaming kernels of the other workloads: FETCH x2 + WRITE
-extra = []
-for wl, kern in [("arith", "arith_kernel"), ("cmp", "compare_kernel"), ("aggregate", "agg_kernel")]:
-    vals = {}
-    for sub, cname in [(f"fetch_{wl}", "FETCH_SIZE"), (f"write_{wl}", "WRITE_SIZE")]:
-        p = os.path.join(src, sub, "bench_counter_collection.csv")
-        if os.path.exists(p):
-            xs = [float(r["Counter_Value"]) for r in csv.DictReader(open(p)) if kern in r["Kernel_Name"]]
-            if xs:
-                vals[cname] = sum(xs) / len(xs)
-    if "FETCH_SIZE" in vals:
-        vals.setdefault("WRITE_SIZE", 0.0)
-        tot = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
-        extra.append(f"| {kern} ({wl}, 1e9 rows) | {vals['FETCH_SIZE']:.0f} | {vals['WRITE_SIZE']:.0f} | {tot/1e9:.2f} GB | wide coalesced reads: FETCH x2 |")
-if extra:
-    out.append("## HBM traffic of the other streaming kernels (PMC)\n")
-    out.append("| kernel | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes per launch (corrected) | note |")
-    out.append("|---|---|---|---|---|")
-    out += extra
-    out.append("")
-p = os.path.join(src, "sq", "bench_counter_collection.csv")
-if os.path.exists(p):
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(p)):
-        k = short(r["Kernel_Name"])
-        if k.startswith(("filter_scatter", "take_kernel", "filter_count")):
-            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    out.append("## SQ counters, filter + take step (quad-cycles summed over waves)\n")
-    names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
-             "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]
-    out.append("| kernel | " + " | ".join(n.replace("SQ_", "") for n in names) + " |")
-    out.append("|---|" + "---|" * len(names))
-    for k, v in agg.items():
-        out.append(f"| {k} | " + " | ".join(f"{sum(v[n])/max(len(v[n]),1):.3g}" if n in v else "-" for n in names) + " |")
-    out.append("")
-open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(out) + "\n")
-nr = os.path.join(src, "next_rows.json")
-if os.path.exists(nr):
-    for l in open(nr):
-        if l.startswith("{"):
-            d = json.loads(l)
-            with open(os.path.join(dst, f"{tag}_summary.md"), "a") as fsum:
-                fsum.write("\n## SURVEY §8f rows without a bench workload (tools/next_rows_time.py, wall clock of the "
-                           "synchronous C-ABI call, median of 5)\n\n| quantity | value |\n|---|---|\n")
-                for k, v in d.items():
-                    fsum.write(f"| {k} | {v} |\n")
-            shutil.copy(nr, os.path.join(dst, f"{tag}_next_rows.json"))
-for f in ["bench_plain.json"]:
-    if os.path.exists(os.path.join(src, f)):
-        shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
+if d and d.get("hbm_pool"):
+    out.append(f"HBM held by the pooled allocator over the default run (`ah_context_stats`): {d['hbm_pool']}\n")
+
+ex = line_of("bench_exchange_world1.json")
+if ex:
+    out.append("## Exchange step through the C ABI at world 1 (real RCCL: ncclCommInitRank, count all-gather, group, merge)\n")
+    out.append(f"`bench.py --reassemble allgatherv`: transport {ex['config'].get('transport')}, step {ex['ms_per_step']} ms with the "
+               f"reassembly (ah_all_gather_columns_begin -> take on the second context -> _end) vs {ex.get('local_ms_per_step')} ms "
+               f"without; last call {ex.get('reassemble_last_ms')}.  configs[4] (filter_record_batch + ah_all_gather_columns): "
+               f"{ex.get('configs', {}).get('record_batch_allgather')}\n")
+wb = line_of("bench_wait_block.json")
+if wb and d:
+    out.append("## Host waits: mailbox spin (default) vs `AH_WAIT=block` (hipStreamSynchronize), same box\n")
+    out.append(f"spin: {d['ms_per_step']} ms per step, host_gap_ms {d['host_gap_ms']}; block: {wb['ms_per_step']} ms, host_gap_ms "
+               f"{wb['host_gap_ms']}.  (The driver's round-1 box showed 2.39 ms of gap with blocking waits: interrupt wake-up "
+               "latency is a property of the host, the spin path does not depend on it.)\n")
+
+with open(os.path.join(dst, f"{R}_summary.md"), "w") as f:
+    f.write("\n".join(out) + "\n")
+if d and isinstance(d.get("pmc_traffic_bytes_per_launch"), dict):
+    tj = {"source": f"bench.py in-run rocprofv3 PMC passes (profiles/{R}_bench_*.json)", "hbm_bytes_per_launch": dict(d["pmc_traffic_bytes_per_launch"])}
+    for wl, tr in traffic.items():
+        if isinstance(tr, dict):
+            tj["hbm_bytes_per_launch"].update(tr)
+    json.dump(tj, open(os.path.join(dst, f"{R}_traffic.json"), "w"), indent=1)
 print("\n".join(out))
