@@ -508,10 +508,12 @@ def reference_bench_shapes(env, batch=64):
                     preds = (C.c_void_p * batch)()
                     assert lib.ah_filter_predicates_build(h, batch, masks, preds) == 0  # ONE wait for `batch` counts
                     lib.ah_context_set_deferred(h, 1)
-                    outs = [L.ArrayOut() for _ in range(batch)]
-                    for i in range(batch):
-                        assert lib.ah_filter_predicate_apply(h, preds[i], C.byref(vv), C.byref(outs[i])) == 0
-                    lib.ah_context_set_deferred(h, 0)
+                    try:
+                        outs = [L.ArrayOut() for _ in range(batch)]
+                        for i in range(batch):
+                            assert lib.ah_filter_predicate_apply(h, preds[i], C.byref(vv), C.byref(outs[i])) == 0
+                    finally:
+                        lib.ah_context_set_deferred(h, 0)
                     assert lib.ah_synchronize(h) == 0
                     for i in range(batch):
                         release(outs[i])
@@ -529,10 +531,12 @@ def reference_bench_shapes(env, batch=64):
 
                 def batched():
                     lib.ah_context_set_deferred(h, 1)
-                    outs = [L.ArrayOut() for _ in range(batch)]
-                    for i in range(batch):
-                        assert lib.ah_filter_predicate_apply(h, pred, C.byref(vv), C.byref(outs[i])) == 0
-                    lib.ah_context_set_deferred(h, 0)
+                    try:
+                        outs = [L.ArrayOut() for _ in range(batch)]
+                        for i in range(batch):
+                            assert lib.ah_filter_predicate_apply(h, pred, C.byref(vv), C.byref(outs[i])) == 0
+                    finally:
+                        lib.ah_context_set_deferred(h, 0)
                     assert lib.ah_synchronize(h) == 0
                     for o in outs:
                         release(o)
@@ -577,10 +581,12 @@ def reference_bench_shapes(env, batch=64):
 
         def batched():
             lib.ah_context_set_deferred(h, 1)
-            outs = [L.ArrayOut() for _ in range(batch)]
-            for i in range(batch):
-                assert fn(h, op, C.byref(av), 0, C.byref(bv), 0, C.byref(outs[i])) == 0
-            lib.ah_context_set_deferred(h, 0)
+            try:
+                outs = [L.ArrayOut() for _ in range(batch)]
+                for i in range(batch):
+                    assert fn(h, op, C.byref(av), 0, C.byref(bv), 0, C.byref(outs[i])) == 0
+            finally:
+                lib.ah_context_set_deferred(h, 0)
             assert lib.ah_synchronize(h) == 0
             for o in outs:
                 release(o)

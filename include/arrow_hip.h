@@ -345,7 +345,9 @@ AH_API ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_coal
  * exactly as the one-call form does, then frees the handle.  Calling _begin of group g + 1 before _end of group g keeps
  * the GPU busy with group g's scatters while group g + 1's counts make their round trip to the host.  The view structs
  * are copied by _begin; the device buffers behind them must stay alive until _end.  Handles of one coalescer are ended
- * in the order they were begun. */
+ * in the order they were begun, every handle is ended (also after an error elsewhere: _end is what frees it) and none
+ * may be pending when the coalescer is destroyed.  At most two may be in flight with their counts travelling; a third
+ * _begin simply builds its predicates synchronously. */
 typedef struct ah_coalescer_push ah_coalescer_push;
 AH_API ah_status ah_coalescer_push_batches_with_filters_begin(ah_context* ctx, ah_coalescer* co, int32_t n,
                                                               const ah_array_view* columns, const int64_t* num_rows,
