@@ -170,6 +170,11 @@ SIGNATURES = {
     "ah_memset": (C.c_int32, [_P, _P, C.c_int, C.c_size_t]),
     "ah_synchronize": (C.c_int32, [_P]),
     "ah_context_stats": (C.c_int32, [_P, C.POINTER(ContextStats), C.c_int32]),
+    "ah_graph_begin": (C.c_int32, [_P]),
+    "ah_graph_end": (C.c_int32, [_P, C.POINTER(_P)]),
+    "ah_graph_node_count": (C.c_int32, [_P]),
+    "ah_graph_launch": (C.c_int32, [_P, _P]),
+    "ah_graph_destroy": (None, [_P, _P]),
     "ah_pool_trim": (None, [_P]),
     "ah_filter": (C.c_int32, [_P, _VIEW, _VIEW, _OUT]),
     "ah_filter_predicate_build": (C.c_int32, [_P, _VIEW, C.POINTER(_P)]),

@@ -324,6 +324,13 @@ class Context:
         return _Scope()
 
     # raw buffers
+    def graph_capture(self):
+        """``with ctx.graph_capture() as g: ...deferred calls...`` records the calls made inside the block into a hipGraph
+        (``ah_graph_begin`` / ``ah_graph_end``) instead of running them; afterwards ``g.launch()`` replays the whole sequence
+        over the current bytes of the captured inputs, into the outputs the recorded calls returned.  Deferred mode is on
+        inside the block; entry points that must wait on the device fail fast there."""
+        return _GraphCapture(self)
+
     def memory_stats(self, reset_peaks=False):
         """``ah_context_stats``: live / high-water / cached bytes of the pooled device allocator and its call counts — the
         reference's ``MemoryPool::used`` for HBM (arrow-buffer/src/pool.rs:73-93)."""
@@ -347,6 +354,33 @@ class Context:
 
 
 _default_ctx = None
+
+
+class _GraphCapture:
+    def __init__(self, ctx):
+        self.ctx, self._h, self.keep = ctx, None, []
+
+    def __enter__(self):
+        self.ctx.check(self.ctx.lib.ah_graph_begin(self.ctx.handle))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h = C.c_void_p()
+        st = self.ctx.lib.ah_graph_end(self.ctx.handle, C.byref(h))
+        if et is None:
+            self.ctx.check(st)
+            self._h = h
+            self._fin = weakref.finalize(self, self.ctx.lib.ah_graph_destroy, self.ctx.handle, h)
+        elif st == 0:
+            self.ctx.lib.ah_graph_destroy(self.ctx.handle, h)
+        return False
+
+    def node_count(self):
+        return int(self.ctx.lib.ah_graph_node_count(self._h))
+
+    def launch(self):
+        """one replay, enqueued (no wait): ``ctx.synchronize()`` or any synchronous call orders behind it"""
+        self.ctx.check(self.ctx.lib.ah_graph_launch(self.ctx.handle, self._h))
 
 
 def default_context():

@@ -73,6 +73,11 @@ struct ah_context {
   // BatchCoalescer's null-count ring and count words).  hipHostMalloc costs 0.1-0.3 ms, which showed up as idle GPU at
   // the start of every coalescer's life (profiles/r04_coalesce_gaps.md): released blocks are kept here and reused.
   std::vector<std::pair<size_t, void*>> pinned_cache;
+  // hipGraph capture (ah_graph_begin / _end): while `capturing`, every launch of the context's stream is recorded instead
+  // of run; pooled blocks released meanwhile are NOT recycled (a replay writes them again) but parked in `capture_hold`,
+  // which the finished graph takes over; any host wait is refused (the kernels it would wait for are not running)
+  bool capturing = false, capture_was_deferred = false;
+  std::vector<void*> capture_hold;
   // memory accounting (ah_context_stats; SURVEY 5 "allocation high-water / bytes moved", the analogue of the reference's
   // MemoryPool::used / TrackingMemoryPool, arrow-buffer/src/pool.rs:73-93): device bytes held by live pool blocks
   // (rounded sizes), their high-water mark, cumulative bytes and calls, and what the free lists cache

@@ -117,6 +117,10 @@ void ah_pool_free(ah_context* ctx, void* p) {
   if (!p) return;
   auto it = ctx->pool_live.find(p);
   if (it == ctx->pool_live.end()) return;  // not ours
+  if (ctx->capturing) {  // a captured kernel writes this block on every replay: it stays out of circulation with the graph
+    ctx->capture_hold.push_back(p);
+    return;
+  }
   ctx->pool_free[it->second].push_back(p);
   ctx->stats.live_bytes -= (int64_t)it->second;
   ctx->stats.freed_bytes_total += (int64_t)it->second;
@@ -254,6 +258,7 @@ static inline void cpu_relax() {
 }
 
 hipError_t ah_mail_wait(ah_context* ctx, uint64_t seq) {
+  if (ctx->capturing) return hipErrorStreamCaptureUnsupported;  // the posting kernel is being recorded, not run: never spin
   volatile uint64_t* flag = ctx->pinned + AH_MAIL_FLAG;
   if (ctx->wait_mode == 1) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -314,6 +319,7 @@ hipError_t ah_mail_post_async(ah_context* ctx, uint64_t* seq_out) {
 }
 
 hipError_t ah_stream_wait(ah_context* ctx) {
+  if (ctx->capturing) return hipErrorStreamCaptureUnsupported;
   if (ctx->wait_mode == 1) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) ctx->inflight = false;
@@ -442,6 +448,10 @@ extern "C" void* ah_context_stream(ah_context* ctx) {
 extern "C" void ah_context_set_deferred(ah_context* ctx, int32_t on) {
   ah_ctx_guard _guard(ctx);
   if (!ctx) return;
+  if (ctx->capturing) {  // the capture owns the mode until ah_graph_end; remember what to restore
+    ctx->capture_was_deferred = on != 0;
+    return;
+  }
   if (ctx->deferred && !on) hipStreamSynchronize(ctx->stream);  // leaving deferred mode: everything enqueued is done
   ctx->deferred = on != 0;
 }
@@ -501,8 +511,92 @@ extern "C" ah_status ah_memset(ah_context* ctx, void* dst, int value, size_t byt
   AH_HIP(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
   return AH_OK;
 }
+// ------------------------------------------------------------------- hipGraph capture of deferred calls
+// The launch-bound regime (batches of 10^3 .. 10^5 rows: a call is 2-4 us of kernels behind 3-4 us of host launch cost
+// each) as ONE graph launch: between ah_graph_begin and ah_graph_end the deferred entry points (wrapping / float
+// arithmetic, cmp, boolean, safe numeric casts, ah_filter_predicate_apply with a prebuilt predicate) are RECORDED on the
+// context's stream instead of run; ah_graph_launch replays the whole sequence over whatever bytes the captured input
+// pointers hold by then, into the SAME output buffers the captured calls returned.
+struct ah_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  std::vector<void*> held;  // pooled blocks the captured calls released (scratch): parked until the graph dies
+  int nodes = 0;
+};
+
+extern "C" ah_status ah_graph_begin(ah_context* ctx) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx) return AH_INVALID_ARGUMENT;
+  if (ctx->capturing) return ah_fail(ctx, AH_INVALID_ARGUMENT, "a graph capture is already open on this context");
+  hipSetDevice(ctx->device);
+  AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // relaxed: a pool miss may still hipMalloc while recording (it is not part of the graph; the block is then simply owned)
+  AH_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+  ctx->capture_was_deferred = ctx->deferred;
+  ctx->deferred = true;  // only enqueue-only entry points can be recorded; everything else fails fast (no wait is possible)
+  ctx->capturing = true;
+  return AH_OK;
+}
+
+extern "C" ah_status ah_graph_end(ah_context* ctx, ah_graph** out) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !out) return AH_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!ctx->capturing) return ah_fail(ctx, AH_INVALID_ARGUMENT, "no graph capture is open on this context");
+  hipSetDevice(ctx->device);
+  auto* g = new ah_graph();
+  hipError_t e = hipStreamEndCapture(ctx->stream, &g->graph);
+  ctx->capturing = false;
+  ctx->deferred = ctx->capture_was_deferred;
+  g->held.swap(ctx->capture_hold);
+  if (e == hipSuccess && !g->graph) e = hipErrorStreamCaptureInvalidated;
+  if (e == hipSuccess) {
+    size_t n = 0;
+    if (hipGraphGetNodes(g->graph, nullptr, &n) == hipSuccess) g->nodes = (int)n;
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (g->graph) hipGraphDestroy(g->graph);
+    for (void* p : g->held) ah_pool_free(ctx, p);
+    delete g;
+    return ah_fail(ctx, AH_HIP_ERROR, "graph capture failed: %s (an entry point that must wait on the device was called while recording?)",
+                   hipGetErrorString(e));
+  }
+  *out = g;
+  return AH_OK;
+}
+
+extern "C" int32_t ah_graph_node_count(const ah_graph* g) { return g ? g->nodes : 0; }
+
+// one replay, enqueued on the context's stream (no wait: ah_synchronize / the next synchronous call orders behind it)
+extern "C" ah_status ah_graph_launch(ah_context* ctx, ah_graph* g) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !g || !g->exec) return AH_INVALID_ARGUMENT;
+  if (ctx->capturing) return ah_fail(ctx, AH_INVALID_ARGUMENT, "cannot launch a graph while recording one");
+  hipSetDevice(ctx->device);
+  ctx->inflight = true;
+  AH_HIP(ctx, hipGraphLaunch(g->exec, ctx->stream));
+  return AH_OK;
+}
+
+extern "C" void ah_graph_destroy(ah_context* ctx, ah_graph* g) {
+  ah_ctx_guard _guard(ctx);
+  if (!g) return;
+  if (ctx) {
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);  // a replay may still be writing the held blocks
+  }
+  if (g->exec) hipGraphExecDestroy(g->exec);
+  if (g->graph) hipGraphDestroy(g->graph);
+  if (ctx)
+    for (void* p : g->held) ah_pool_free(ctx, p);
+  delete g;
+}
+
 extern "C" ah_status ah_synchronize(ah_context* ctx) {
   ah_ctx_guard _guard(ctx);
+  if (ctx->capturing) return ah_fail(ctx, AH_INVALID_ARGUMENT, "ah_synchronize while a graph is being recorded: end the capture first");
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->inflight = false;
   return AH_OK;

@@ -470,12 +470,42 @@ def reference_bench_shapes(env, batch=64):
     def release(out):
         lib.ah_array_release(h, C.byref(out))
 
+    def graph_timed(record_one, replays=40):
+        """`batch` calls RECORDED into one hipGraph (ah_graph_begin / _end), then replayed: us per call.  None if the
+        capture is refused (a shape whose call must wait on the device)."""
+        outs = [L.ArrayOut() for _ in range(batch)]
+        g = C.c_void_p()
+        if lib.ah_graph_begin(h) != 0:
+            return None
+        ok = all(record_one(outs[i]) == 0 for i in range(batch))
+        st = lib.ah_graph_end(h, C.byref(g))
+        if not ok or st != 0:
+            if st == 0:
+                lib.ah_graph_destroy(h, g)
+            for o in outs:
+                release(o)
+            return None
+        try:
+            for _ in range(3):
+                assert lib.ah_graph_launch(h, g) == 0
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(replays):
+                assert lib.ah_graph_launch(h, g) == 0
+            ctx.synchronize()
+            return (time.perf_counter() - t0) / (replays * batch) * 1e6
+        finally:
+            lib.ah_graph_destroy(h, g)
+            for o in outs:
+                release(o)
+
     shapes = {}
 
-    def row(name, rows, sync_us, batched_us, cpu_us, note=None):
+    def row(name, rows, sync_us, batched_us, cpu_us, note=None, graph_us=None):
+        best = min(x for x in (batched_us, graph_us) if x is not None) if (batched_us is not None or graph_us is not None) else None
         r = {"rows": rows, "sync_us": round(sync_us, 2), "batched_us": None if batched_us is None else round(batched_us, 2),
-             "cpu_1core_us": round(cpu_us, 2),
-             "sync_beats_cpu": bool(sync_us < cpu_us), "batched_beats_cpu": None if batched_us is None else bool(batched_us < cpu_us)}
+             "graph_us": None if graph_us is None else round(graph_us, 2), "cpu_1core_us": round(cpu_us, 2),
+             "sync_beats_cpu": bool(sync_us < cpu_us), "batched_beats_cpu": None if best is None else bool(best < cpu_us)}
         if note:
             r["note"] = note
         shapes[name] = r
@@ -540,9 +570,10 @@ def reference_bench_shapes(env, batch=64):
                     assert lib.ah_synchronize(h) == 0
                     for o in outs:
                         release(o)
+                gus = graph_timed(lambda o: lib.ah_filter_predicate_apply(h, pred, C.byref(vv), C.byref(o)))
                 row(f"filter context i32 w NULLs ({label})" if label.startswith("kept") else f"filter context i32 w NULLs {label}", n,
                     timed(sync, 200), timed(batched, 8) / batch, cpu_us,
-                    "cpu_1core_us includes the oracle's predicate build (it has no prebuilt-predicate entry point)")
+                    "cpu_1core_us includes the oracle's predicate build (it has no prebuilt-predicate entry point)", graph_us=gus)
                 lib.ah_filter_predicate_free(h, pred)
 
     # ---- take (take_kernels.rs): Int32 values, random u32 indices, no nulls
@@ -595,13 +626,16 @@ def reference_bench_shapes(env, batch=64):
             o = orc.Out()
             getattr(oracle.lib, ofn)(op, C.byref(hah.view), 0, C.byref(hbh.view), 0, C.byref(o))
             oracle.lib.orc_release(C.byref(o))
-        row(name, n, timed(sync, 200), timed(batched, 8) / batch, cpu_timed(cpu))
+        gus = graph_timed(lambda o: fn(h, op, C.byref(av), 0, C.byref(bv), 0, C.byref(o)))
+        row(name, n, timed(sync, 200), timed(batched, 8) / batch, cpu_timed(cpu), graph_us=gus)
     lost = [k for k, v in shapes.items() if v["batched_beats_cpu"] is False or (v["batched_beats_cpu"] is None and not v["sync_beats_cpu"])]
     return {"batch": batch, "shapes": shapes, "shapes_where_one_cpu_core_wins": lost,
             "what": "the reference's own criterion shapes through the raw C ABI: sync_us = one synchronous call; batched_us = per call "
                     "inside a batch of %d (predicates built with one wait, applies / arith / compare enqueued in deferred mode, one "
-                    "ah_synchronize); cpu_1core_us = the oracle on one host core.  A one-call-at-a-time drop-in loses to one core at "
-                    "these sizes; the batched form is what an engine with several batches queued gets" % batch}
+                    "ah_synchronize); graph_us = per call when those %d deferred calls are RECORDED once into a hipGraph "
+                    "(ah_graph_begin / _end) and replayed (shapes whose output size is fixed: a prebuilt predicate, add, lt); "
+                    "cpu_1core_us = the oracle on one host core.  A one-call-at-a-time drop-in loses to one core at "
+                    "these sizes; the batched / graph forms are what an engine with several batches queued gets" % (batch, batch)}
 
 
 # ------------------------------------------------------------------------------- in-run PMC traffic
@@ -1097,8 +1131,8 @@ def emit(line, args):
     rs = line.get("reference_bench_shapes")
     if isinstance(rs, dict) and "shapes" in rs:
         compact["reference_bench_shapes"] = {
-            "batch": rs["batch"], "columns": ["sync_us", "batched_us", "cpu_1core_us"],
-            "shapes": {k: [v["sync_us"], v["batched_us"], v["cpu_1core_us"]] for k, v in rs["shapes"].items()},
+            "batch": rs["batch"], "columns": ["sync_us", "batched_us", "graph_us", "cpu_1core_us"],
+            "shapes": {k: [v["sync_us"], v["batched_us"], v.get("graph_us"), v["cpu_1core_us"]] for k, v in rs["shapes"].items()},
             "one_cpu_core_wins": rs["shapes_where_one_cpu_core_wins"]}
     elif rs is not None:
         compact["reference_bench_shapes"] = rs

@@ -187,6 +187,22 @@ AH_API void* ah_context_stream(ah_context* ctx);
  * Every other entry point (data-dependent sizes, device-side errors to report) stays synchronous. */
 AH_API void ah_context_set_deferred(ah_context* ctx, int32_t on);
 AH_API int32_t ah_context_deferred(const ah_context* ctx);
+/* hipGraph capture of deferred calls — the launch-bound regime (query-engine batches of 10^3 .. 10^5 rows: 2-4 us of
+ * kernel behind 3-4 us of host launch cost per kernel) as ONE graph launch.  Between ah_graph_begin and ah_graph_end
+ * the entry points deferred mode covers (see above) are RECORDED on the context's stream, not run: they return their
+ * ah_array_out as usual (null_count = -1) but the buffers are written only when the graph is launched.  ah_graph_launch
+ * enqueues one replay of the whole sequence: it reads whatever bytes the captured INPUT pointers hold at that moment
+ * and rewrites the SAME output buffers the captured calls returned — keep inputs, outputs and (for filters) the
+ * prebuilt ah_filter_predicate alive and unmoved for as long as the graph lives; shapes (lengths, the predicate and
+ * hence K) are frozen at capture.  An entry point that has to wait on the device (data-dependent sizes, checked
+ * arithmetic, take, strings, ah_synchronize) fails fast while recording and invalidates the capture (ah_graph_end then
+ * returns the error).  Scratch released while recording stays reserved until ah_graph_destroy. */
+typedef struct ah_graph ah_graph;
+AH_API ah_status ah_graph_begin(ah_context* ctx);
+AH_API ah_status ah_graph_end(ah_context* ctx, ah_graph** out);
+AH_API int32_t ah_graph_node_count(const ah_graph* g);
+AH_API ah_status ah_graph_launch(ah_context* ctx, ah_graph* g);
+AH_API void ah_graph_destroy(ah_context* ctx, ah_graph* g);
 /* ah_synchronize + count the nulls of a deferred result (null_count < 0) on the device. */
 AH_API ah_status ah_array_resolve(ah_context* ctx, ah_array_out* out);
 /* Memory accounting of a context's built-in pooled allocator — the reference's MemoryPool::used() / TrackingMemoryPool

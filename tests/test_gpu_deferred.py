@@ -290,3 +290,59 @@ def test_deferred_chain_captured_in_a_hip_graph(ctx, oracle):
         graph.replay()
     torch.cuda.synchronize()
     print(f"hipGraph replay of the 3-kernel chain: {(time.perf_counter() - t0) / 500 * 1e6:.1f} us per chain")
+
+
+def test_graph_capture_through_the_c_abi(ctx, oracle):
+    """ah_graph_begin / _end / _launch (round 4): the launch-bound small-batch loop as ONE graph launch WITHOUT torch —
+    deferred calls are recorded on the context's stream (arithmetic chain, compare, a prebuilt FilterPredicate applied to
+    a nullable column), the inputs' bytes are then replaced behind the same device pointers and the graph is replayed:
+    every captured output must equal the oracle on the NEW bytes.  Scratch released while recording stays parked; an
+    entry point that has to wait fails fast and invalidates the capture instead of hanging; the context works afterwards."""
+    rng = np.random.default_rng(23)
+    n = 65536
+    gctx = A.Context(0)
+    ha, hb = _cols(rng, n, A.Int64, 0.9), _cols(rng, n, A.Int64, None)
+    hf = _cols(rng, n, A.Float32, None)
+    hm = HostArray(A.Boolean, rng.random(n) < 0.5)
+    da, db, df, dm = ha.to_device(gctx), hb.to_device(gctx), hf.to_device(gctx), hm.to_device(gctx)
+    pred = K.FilterBuilder(dm).build()  # built OUTSIDE the capture: its count is a host wait
+    with gctx.graph_capture() as g:
+        chain = K.cast(K.add_wrapping(K.mul_wrapping(da, db), da), A.Float64)
+        cmpd = K.lt(df, df)
+        summed = K.add_wrapping(df, df)
+        filt = pred.filter(da)
+        nd = K.distinct(da, db)  # (allocates and releases a scratch bitmap while recording)
+    assert g.node_count() >= 6
+    # new bytes behind the same pointers (validity of `a` stays: shapes are frozen at capture)
+    ha2 = HostArray(A.Int64, rng.integers(-2**40, 2**40, n), ha.valid)
+    hb2 = HostArray(A.Int64, rng.integers(-2**20, 2**20, n))
+    hf2 = _cols(rng, n, A.Float32, None)
+    for d, h in ((da, ha2), (db, hb2), (df, hf2)):
+        gctx.check(gctx.lib.ah_memcpy_htod(gctx.handle, d.values.ptr, np.ascontiguousarray(h.values).ctypes.data, n * h.values.dtype.itemsize))
+    for _ in range(3):
+        g.launch()
+    gctx.synchronize()
+    same(chain, oracle.cast(oracle.arith(1, oracle.arith(5, ha2, hb2), ha2), A.Float64), "graph: arithmetic chain")
+    same(cmpd, oracle.compare(2, hf2, hf2), "graph: lt")
+    same(summed, oracle.arith(1, hf2, hf2), "graph: add f32")
+    same(filt, oracle.filter(ha2, hm), "graph: prebuilt predicate on a nullable column")
+    same(nd, oracle.compare(6, ha2, hb2), "graph: distinct")
+    # other work on the context between replays does not disturb the parked scratch / outputs
+    other = K.add_wrapping(db, db)
+    g.launch()
+    gctx.synchronize()
+    same(other, oracle.arith(1, hb2, hb2), "call between replays")
+    same(chain, oracle.cast(oracle.arith(1, oracle.arith(5, ha2, hb2), ha2), A.Float64), "graph: chain after other work")
+    # an entry point that must wait on the device cannot be recorded: fails fast, the capture is reported invalid
+    with pytest.raises((A.ArrowError, A.array.HipError)):
+        with gctx.graph_capture():
+            K.add(da, db)  # checked arithmetic reads its error word back
+    # ... and the context is still usable
+    same(K.add_wrapping(da, db), oracle.arith(1, ha2, hb2), "after a failed capture")
+    import time
+    gctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        g.launch()
+    gctx.synchronize()
+    print(f"hipGraph replay of 7 recorded calls on 65 536 rows: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per replay")

@@ -1677,13 +1677,15 @@ def test_bench_json_contract(ctx):
     # the reference's own criterion shapes (filter_kernels.rs:39-120, take_kernels.rs:32-80, arithmetic / comparison
     # kernels at 65 536 rows): synchronous us, amortised us inside a batch of 64 deferred calls, 1-core oracle us
     rs = d["reference_bench_shapes"]
-    assert rs["columns"] == ["sync_us", "batched_us", "cpu_1core_us"] and rs["batch"] == 64
+    assert rs["columns"] == ["sync_us", "batched_us", "graph_us", "cpu_1core_us"] and rs["batch"] == 64
     names = set(rs["shapes"])
     for want in ("filter i32 (kept 1/2)", "filter i32 high selectivity (kept 1023/1024)", "filter i32 low selectivity (kept 1/1024)",
                  "filter context i32 w NULLs (kept 1/2)", "take i32 512", "take i32 1024", "add(0) f32", "lt f32"):
         assert want in names, want
-    for name, (sync_us, batched_us, cpu_us) in rs["shapes"].items():
+    for name, (sync_us, batched_us, graph_us, cpu_us) in rs["shapes"].items():
         assert sync_us > 0 and cpu_us > 0 and (batched_us is None) == name.startswith("take"), name
+        if name.startswith(("filter context", "add", "lt")):  # fixed output shape: recordable into a hipGraph
+            assert graph_us is not None and 0 < graph_us < sync_us, (name, graph_us, sync_us)
     assert set(rs["one_cpu_core_wins"]) <= names  # the honest crossover statement, whatever it is on this box
 
 

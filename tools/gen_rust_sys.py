@@ -27,7 +27,7 @@ BASE = {
     "ah_array_out": "ah_array_out", "ah_scalar": "ah_scalar", "ah_data_type": "ah_data_type", "ah_ipc_field": "ah_ipc_field", "ah_ipc_block": "ah_ipc_block",
     "ArrowArray": "ArrowArray", "ArrowSchema": "ArrowSchema", "ArrowDeviceArray": "ArrowDeviceArray",
     "ah_alloc_fn": "ah_alloc_fn", "ah_free_fn": "ah_free_fn",
-    "ah_comm": "ah_comm", "ah_exchange_stats": "ah_exchange_stats", "ah_context_stats_t": "ah_context_stats_t", "ah_coalescer": "ah_coalescer", "ah_coalescer_push": "ah_coalescer_push", "ah_exchange": "ah_exchange", "ah_filter_term": "ah_filter_term",
+    "ah_comm": "ah_comm", "ah_exchange_stats": "ah_exchange_stats", "ah_context_stats_t": "ah_context_stats_t", "ah_coalescer": "ah_coalescer", "ah_coalescer_push": "ah_coalescer_push", "ah_graph": "ah_graph", "ah_exchange": "ah_exchange", "ah_filter_term": "ah_filter_term",
 }
 RUST_KEYWORDS = {"type", "ref", "in", "fn", "move", "match", "loop", "box", "use", "mod", "impl", "self", "where"}
 
@@ -142,6 +142,8 @@ def render(consts, aliases, structs, funcs):
     o.append("/// Opaque: BatchCoalescer state (in-progress buffers + completed queue).")
     o.append("#[repr(C)] pub struct ah_coalescer { _private: [u8; 0] }")
     o.append("#[repr(C)] pub struct ah_coalescer_push { _private: [u8; 0] }")
+    o.append("/// Opaque: a recorded sequence of deferred calls (hipGraph + its executable).")
+    o.append("#[repr(C)] pub struct ah_graph { _private: [u8; 0] }")
     o.append("#[repr(C)] pub struct ah_exchange { _private: [u8; 0] }")
     o.append("pub type ah_alloc_fn = Option<unsafe extern \"C\" fn(user: *mut c_void, bytes: usize) -> *mut c_void>;")
     o.append("pub type ah_free_fn = Option<unsafe extern \"C\" fn(user: *mut c_void, ptr: *mut c_void, bytes: usize)>;")

@@ -133,11 +133,11 @@ if d and isinstance(d.get("reference_bench_shapes"), dict) and "shapes" in d["re
     rs = d["reference_bench_shapes"]
     out.append("## The reference's own criterion shapes through the raw C ABI (`reference_bench_shapes`; microseconds per call)\n")
     out.append(rs["what"] + "\n")
-    out.append("| shape | rows | synchronous call | per call in a batch of %d | 1-core oracle | batched beats one core |" % rs["batch"])
-    out.append("|---|---|---|---|---|---|")
+    out.append("| shape | rows | synchronous call | per call in a batch of %d | per call in a replayed hipGraph of %d | 1-core oracle | batched / graph beats one core |" % (rs["batch"], rs["batch"]))
+    out.append("|---|---|---|---|---|---|---|")
     for k, v in rs["shapes"].items():
         out.append(f"| {k} | {v['rows']} | {v['sync_us']} | {v['batched_us'] if v['batched_us'] is not None else '— (synchronous by contract)'} | "
-                   f"{v['cpu_1core_us']} | {v['batched_beats_cpu'] if v['batched_beats_cpu'] is not None else v['sync_beats_cpu']} |")
+                   f"{v.get('graph_us') if v.get('graph_us') is not None else '—'} | {v['cpu_1core_us']} | {v['batched_beats_cpu'] if v['batched_beats_cpu'] is not None else v['sync_beats_cpu']} |")
     out.append("")
 if d and d.get("hbm_pool"):
     out.append(f"HBM held by the pooled allocator over the default run (`ah_context_stats`): {d['hbm_pool']}\n")
