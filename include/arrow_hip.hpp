@@ -87,6 +87,40 @@ class Context {
   void set_deferred(bool on) { ah_context_set_deferred(h_, on ? 1 : 0); }
   bool deferred() const { return ah_context_deferred(h_) != 0; }
   void synchronize() const { check(ah_synchronize(h_)); }
+  // hipGraph capture of deferred calls (ah_graph_begin / _end): `auto g = ctx.capture([&] { ... deferred kernels ... });`
+  // records the calls the callable makes instead of running them; g->launch() replays them as one graph launch over the
+  // current bytes of the captured inputs, into the outputs the recorded calls returned (keep those alive)
+  class Graph {
+   public:
+    Graph(const Context* c, ah_graph* g) : c_(c), g_(g) {}
+    Graph(const Graph&) = delete;
+    ~Graph() { ah_graph_destroy(c_->h_, g_); }
+    void launch() const { c_->check(ah_graph_launch(c_->h_, g_)); }
+    int node_count() const { return ah_graph_node_count(g_); }
+
+   private:
+    const Context* c_;
+    ah_graph* g_;
+  };
+  template <typename F>
+  std::unique_ptr<Graph> capture(F&& record) const {
+    check(ah_graph_begin(h_));
+    ah_graph* g = nullptr;
+    try {
+      record();
+    } catch (...) {
+      if (ah_graph_end(h_, &g) == AH_OK) ah_graph_destroy(h_, g);
+      throw;
+    }
+    check(ah_graph_end(h_, &g));
+    return std::make_unique<Graph>(this, g);
+  }
+  // MemoryPool::used and friends for the pooled device allocator (ah_context_stats)
+  ah_context_stats_t memory_stats(bool reset_peaks = false) const {
+    ah_context_stats_t st{};
+    check(ah_context_stats(h_, &st, reset_peaks ? 1 : 0));
+    return st;
+  }
   void check(ah_status st) const {
     if (st == AH_OK) return;
     std::string m = ah_last_error(h_);

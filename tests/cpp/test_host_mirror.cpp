@@ -135,6 +135,27 @@ int main() {
     auto back = compute::cast(ts, compute::timestamp(AH_SECOND, 20700), compute::date32());
     assert((download<int32_t>(back) == std::vector<int32_t>{18628, 18993}));
   }
+  // a recorded sequence of deferred calls replayed as one hipGraph launch over NEW input bytes (ah_graph_begin / _end)
+  {
+    auto ga = upload<int64_t>(ctx, AH_INT64, {1, 2, 3, 4}, nullptr, keep);
+    auto gb = upload<int64_t>(ctx, AH_INT64, {10, 20, 30, 40}, nullptr, keep);
+    ArrayRef sum, less;
+    auto g = ctx->capture([&] {
+      sum = compute::add_wrapping(ga, gb);
+      less = compute::lt(ga, gb);
+    });
+    assert(g->node_count() >= 2);
+    const std::vector<int64_t> fresh{100, 5, -7, 1000};
+    ctx->check(ah_memcpy_htod(ctx->handle(), const_cast<void*>(ga->view().values), fresh.data(), fresh.size() * 8));
+    g->launch();
+    ctx->synchronize();
+    assert((download<int64_t>(sum) == std::vector<int64_t>{110, 25, 23, 1040}));
+    uint64_t lw = 0;
+    less->values_to_host(&lw, 8);
+    assert((lw & 0xF) == 0b0110);  // [100 < 10, 5 < 20, -7 < 30, 1000 < 40] = [F, T, T, F]
+    const ah_context_stats_t ms = ctx->memory_stats();
+    assert(ms.live_bytes > 0 && ms.high_water_bytes >= ms.live_bytes && ms.alloc_calls > 0);
+  }
   // BatchCoalescer doc examples (coalesce.rs:79-107 push_batch, :218-228 with a filter) through the native object
   {
     BatchCoalescer co(ctx, {AH_INT32}, 4);
