@@ -131,6 +131,7 @@ void ah_pool_free(ah_context* ctx, void* p) {
 
 extern "C" void ah_pool_trim(ah_context* ctx) {
   ah_ctx_guard _guard(ctx);
+  if (ctx->capturing) return;  // (cached blocks stay cached; a sync would invalidate the capture)
   hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->pool_free)
     for (void* p : kv.second) hipFree(p);
@@ -335,6 +336,7 @@ hipError_t ah_stream_wait(ah_context* ctx) {
 // around an already enqueued counting kernel) fails, drain the stream and zero them here — otherwise every later
 // counted op of the context would report the leftovers as null counts.
 void ah_count_reset(ah_context* ctx) {
+  if (ctx->capturing) return;  // recorded kernels never ran: the counters are clean, and a sync would invalidate the capture
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipGetLastError();
   if (hipMemsetAsync(ctx->scratch + AH_TICKET_COUNT, 0, 64 * 8, ctx->stream) == hipSuccess) (void)hipStreamSynchronize(ctx->stream);
@@ -354,6 +356,7 @@ hipError_t ah_count_read(ah_context* ctx, int64_t* total) {
 
 hipError_t ah_d2h_wait(ah_context* ctx, void* pinned_dst, const void* dev_src, size_t bytes, bool reset,
                        uint64_t reset_value) {
+  if (ctx->capturing) return hipErrorStreamCaptureUnsupported;  // (before ANY HIP call: a sync would invalidate the capture)
   if (!in_pinned(ctx, pinned_dst, bytes) || (bytes & 7) || ((uintptr_t)dev_src & 7)) {
     hipError_t e = hipMemcpyAsync(pinned_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && reset) e = hipMemsetAsync((void*)dev_src, (int)(reset_value & 0xFF), bytes, ctx->stream);
@@ -487,6 +490,7 @@ extern "C" void ah_device_free(ah_context* ctx, void* p) {
 extern "C" ah_status ah_memcpy_htod(ah_context* ctx, void* dst, const void* src, size_t bytes) {
   ah_ctx_guard _guard(ctx);
   if (!bytes) return AH_OK;
+  if (ctx->capturing) return ah_fail(ctx, AH_INVALID_ARGUMENT, "ah_memcpy_htod while a graph is being recorded: it waits for the stream");
   AH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AH_OK;
@@ -494,6 +498,7 @@ extern "C" ah_status ah_memcpy_htod(ah_context* ctx, void* dst, const void* src,
 extern "C" ah_status ah_memcpy_dtod(ah_context* ctx, void* dst, const void* src, size_t bytes) {
   ah_ctx_guard _guard(ctx);
   if (!bytes) return AH_OK;
+  if (ctx->capturing) return ah_fail(ctx, AH_INVALID_ARGUMENT, "ah_memcpy_dtod while a graph is being recorded: it waits for the stream");
   AH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AH_OK;
@@ -501,6 +506,7 @@ extern "C" ah_status ah_memcpy_dtod(ah_context* ctx, void* dst, const void* src,
 extern "C" ah_status ah_memcpy_dtoh(ah_context* ctx, void* dst, const void* src, size_t bytes) {
   ah_ctx_guard _guard(ctx);
   if (!bytes) return AH_OK;
+  if (ctx->capturing) return ah_fail(ctx, AH_INVALID_ARGUMENT, "ah_memcpy_dtoh while a graph is being recorded: it waits for the stream");
   AH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AH_OK;
@@ -549,7 +555,25 @@ extern "C" ah_status ah_graph_end(ah_context* ctx, ah_graph** out) {
   ctx->capturing = false;
   ctx->deferred = ctx->capture_was_deferred;
   g->held.swap(ctx->capture_hold);
+  for (int k = 0; k < 8 && hipGetLastError() != hipSuccess; ++k) {}  // errors raised while recording are sticky per thread
   if (e == hipSuccess && !g->graph) e = hipErrorStreamCaptureInvalidated;
+  if (e != hipSuccess) {
+    // An INVALIDATED capture (some HIP call that is illegal while recording slipped through) can leave the stream
+    // refusing every later launch ("operation failed due to a previous error during capture", seen on ROCm 7.2 even
+    // after hipStreamEndCapture returned).  The context's own stream is replaced; a caller-provided stream is the caller's.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool stuck = hipStreamIsCapturing(ctx->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone ||
+                       (hipStreamQuery(ctx->stream) != hipSuccess && hipStreamQuery(ctx->stream) != hipErrorNotReady);
+    (void)hipGetLastError();
+    if (stuck && ctx->stream == ctx->own_stream) {
+      hipStream_t fresh = nullptr;
+      if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
+        (void)hipStreamDestroy(ctx->own_stream);
+        ctx->own_stream = ctx->stream = fresh;
+      }
+      (void)hipGetLastError();
+    }
+  }
   if (e == hipSuccess) {
     size_t n = 0;
     if (hipGraphGetNodes(g->graph, nullptr, &n) == hipSuccess) g->nodes = (int)n;

@@ -102,6 +102,60 @@ impl Drop for Context {
     }
 }
 
+/// A recorded sequence of deferred calls (`ah_graph_begin` / `_end`): `Context::capture(|| { … })` records the
+/// kernels the closure enqueues instead of running them; [`Graph::launch`] replays them as ONE hipGraph launch over the
+/// current bytes of the captured inputs, into the outputs the recorded calls returned (keep those alive).
+pub struct Graph {
+    ctx: Arc<Context>,
+    raw: *mut sys::ah_graph,
+}
+
+impl Graph {
+    pub fn launch(&self) -> Result<(), ArrowError> {
+        self.ctx.check(unsafe { sys::ah_graph_launch(self.ctx.raw, self.raw) })
+    }
+
+    pub fn node_count(&self) -> usize {
+        unsafe { sys::ah_graph_node_count(self.raw) as usize }
+    }
+}
+
+impl Drop for Graph {
+    fn drop(&mut self) {
+        unsafe { sys::ah_graph_destroy(self.ctx.raw, self.raw) }
+    }
+}
+
+impl Context {
+    /// Record the deferred calls `record` makes on this context (wrapping / float arithmetic, cmp, boolean, safe numeric
+    /// casts, `FilterPredicate::filter` with a prebuilt predicate); a call that must wait on the device fails fast.
+    pub fn capture<R>(self: &Arc<Self>, record: impl FnOnce() -> Result<R, ArrowError>) -> Result<(Graph, R), ArrowError> {
+        self.check(unsafe { sys::ah_graph_begin(self.raw) })?;
+        let recorded = record();
+        let mut raw = ptr::null_mut();
+        let st = unsafe { sys::ah_graph_end(self.raw, &mut raw) };
+        match recorded {
+            Ok(r) => {
+                self.check(st)?;
+                Ok((Graph { ctx: self.clone(), raw }, r))
+            }
+            Err(e) => {
+                if st == sys::AH_OK {
+                    unsafe { sys::ah_graph_destroy(self.raw, raw) };
+                }
+                Err(e)
+            }
+        }
+    }
+
+    /// `MemoryPool::used` and friends for the pooled device allocator (`ah_context_stats`).
+    pub fn memory_stats(&self, reset_peaks: bool) -> Result<sys::ah_context_stats_t, ArrowError> {
+        let mut st = MaybeUninit::<sys::ah_context_stats_t>::zeroed();
+        self.check(unsafe { sys::ah_context_stats(self.raw, st.as_mut_ptr(), reset_peaks as i32) })?;
+        Ok(unsafe { st.assume_init() })
+    }
+}
+
 /// An array whose buffers live in HBM.  Owns an `ah_array_out`; the logical `DataType` travels on the host
 /// exactly as the reference carries `data_type` through filter / take (filter.rs:783-787, take.rs:414).
 pub struct DeviceArray {
