@@ -7,7 +7,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-faulthandler.dump_traceback_later(200, exit=True)  # a hang is the failure mode under test: dump and leave
+faulthandler.dump_traceback_later(int(os.environ.get("AH_WORKER_WATCHDOG_S", "200")), exit=True)  # a hang is the failure mode under test: dump and leave
 
 import arrow_rs_amd as A  # noqa: E402
 from arrow_rs_amd import compute as K  # noqa: E402
