@@ -170,10 +170,10 @@ __global__ void __launch_bounds__(256) rebase_views_kernel(uint4* views, int64_t
 
 // a push starts: its sequence number, and (view schemas) the data-buffer counts the host declared for it
 ah_status begin_input(ah_context* ctx, ah_coalescer* co) {
+  if (co->has_views && co->declared.empty())  // (checked before the sequence number moves: host and library count together)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "BatchCoalescer with view columns: call ah_coalescer_declare_view_buffers before each push");
   co->cur_seq = co->input_seq++;
   if (!co->has_views) return AH_OK;
-  if (co->declared.empty())
-    return ah_fail(ctx, AH_INVALID_ARGUMENT, "BatchCoalescer with view columns: call ah_coalescer_declare_view_buffers before each push");
   const std::vector<int32_t> counts = co->declared.front();
   co->declared.pop_front();
   for (int i = 0; i < co->ncols; ++i) co->cols[i].cur_nbuf = co->cols[i].is_view ? counts[(size_t)i] : 0;

@@ -79,8 +79,9 @@ def test_exchange_code_across_processes_over_a_fake_transport(world, tmp_path):
         assert p.returncode == 0 and f"COMM_RCCL_RANK_OK {r}/{world}" in o, f"rank {r}:\n{o[-3000:]}"
 
 
-@pytest.mark.parametrize("workload,launcher", [("filter_take", "self"), ("record_batch", "self"), ("filter_take", "torchrun")])
-def test_bench_self_spawned_ranks_over_the_c_abi_transport(workload, launcher, tmp_path, ctx, oracle):
+@pytest.mark.parametrize("workload,launcher,world", [("filter_take", "self", 2), ("record_batch", "self", 2), ("filter_take", "torchrun", 2),
+                                                     ("filter_take", "torchrun", 8)])
+def test_bench_self_spawned_ranks_over_the_c_abi_transport(workload, launcher, world, tmp_path, ctx, oracle):
     """`python bench.py --gpus 2` started PLAINLY — the path the driver's 8-GPU run takes: bench.py spawns its own ranks,
     a gloo group ships the 128-byte id, every rank builds a CApiCommunicator and the reassembly goes through
     ah_all_gather_columns_begin / _end ACROSS PROCESSES (VERDICT r03 missing #1).  One GPU here, so both ranks sit on
@@ -95,12 +96,12 @@ def test_bench_self_spawned_ranks_over_the_c_abi_transport(workload, launcher, t
     from orc import HostArray, assert_logical_eq
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = _build_fake(tmp_path, "fake_rccl_xproc")
-    rows = 50_000_000
+    rows = 50_000_000 if world == 2 else 6_000_000  # (world 8: the driver's SCALE command line shape, eight ranks on the one GPU)
     dump = str(tmp_path / "gathered.npz")
     env = dict(os.environ, AH_BENCH_SHARED_GPU="1", AH_RCCL_LIBRARY=lib, AH_FAKE_RCCL_DIR=str(tmp_path), AH_FAKE_RCCL_TIMEOUT_S="90")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", str(rows),
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--rows", str(rows),
            "--no-cpu-baseline", "--workload", workload, "--config-steps", "2", "--dump-gathered", dump]
     if launcher == "torchrun":
         # EXACTLY the driver's N > 1 command line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
@@ -110,26 +111,26 @@ def test_bench_self_spawned_ranks_over_the_c_abi_transport(workload, launcher, t
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
         so.close()
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(port)] + cmd[1:]
         env["GLOO_SOCKET_IFNAME"] = "lo"
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-4000:])
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["n_gpus"] == world and d["value"] > 0 and d["scaling"] == "weak"
     cfg = d["config"]
     assert cfg["transport"].startswith("ah_comm") and "transport_note" not in cfg, cfg
     assert cfg["distinct_devices"] == 1 and cfg["reassemble"] == "allgatherv", cfg
     if workload == "filter_take":
         ex = d["exchange"]
-        assert ex["peers"] == 1 and ex["bytes_to_each_peer"] > 0
+        assert ex["peers"] == world - 1 and ex["bytes_to_each_peer"] > 0
         rb = d["configs"]["record_batch_allgather"]  # BASELINE configs[4] rides in the same line at N > 1
-        assert "error" not in rb and rb["gathered_rows"] > 0 and rb["exchange"]["peers"] == 1, rb
+        assert "error" not in rb and rb["gathered_rows"] > 0 and rb["exchange"]["peers"] == world - 1, rb
     # the reassembled result against the oracle on the un-sharded input (the generators are counter-based: rank r's
     # shard is rows [r * rows, (r + 1) * rows) of one global column)
     z = np.load(dump)
-    n = 2 * rows
+    n = world * rows
     pred = B.gen_predicate(A, ctx, n, 44, 0.1, 0)
     hp = HostArray(A.Boolean, pred.values_numpy())
     cols = [B.gen_i64_column(A, ctx, n, 42, 0.9, 0)]
