@@ -94,7 +94,7 @@ class ContextStats(C.Structure):
     """ah_context_stats_t"""
     _fields_ = [(n, C.c_int64) for n in ("live_bytes", "high_water_bytes", "cached_bytes", "reserved_high_water_bytes",
                                          "allocated_bytes_total", "freed_bytes_total", "alloc_calls", "free_calls", "pool_hits",
-                                         "device_malloc_calls")]
+                                         "device_malloc_calls", "host_to_device_bytes", "device_to_host_bytes")]
 
 
 class ExchangeStats(C.Structure):

@@ -129,6 +129,7 @@ ah_status host_copy(ah_context* ctx, const void* dev, size_t bytes, size_t pad_t
   if (!h) return ah_fail(ctx, AH_OUT_OF_MEMORY, "host allocation of %zu bytes failed", cap);
   memset(static_cast<char*>(h) + bytes, 0, cap - bytes);
   if (bytes) {
+    ctx->stats.device_to_host_bytes += (int64_t)bytes;
     hipError_t e = hipMemcpyAsync(h, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = ah_stream_wait(ctx);
     if (e != hipSuccess) {
@@ -208,6 +209,7 @@ extern "C" ah_status ah_import_c_data(ah_context* ctx, const struct ArrowArray* 
   auto h2d = [&](const void* src, size_t bytes, size_t alloc_bytes, void** dst) -> ah_status {
     AH_TRY(ah_out_alloc(ctx, alloc_bytes, dst));
     if (bytes) {
+      ctx->stats.host_to_device_bytes += (int64_t)bytes;
       hipError_t e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream);
       if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in C Data import", hipGetErrorString(e));
     }
@@ -287,6 +289,7 @@ extern "C" ah_status ah_import_c_data(ah_context* ctx, const struct ArrowArray* 
       out->values_bytes = (int64_t)(db ? db : 8);
       if (st != AH_OK) return fail(st);
       if (db) {
+        ctx->stats.host_to_device_bytes += (int64_t)db;
         hipError_t e = hipMemcpyAsync(dd, hd + first, db, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess)
           return fail(ah_fail(ctx, AH_HIP_ERROR, "HIP error %s in C Data import", hipGetErrorString(e)));

@@ -493,6 +493,7 @@ extern "C" ah_status ah_memcpy_htod(ah_context* ctx, void* dst, const void* src,
   if (ctx->capturing) return ah_fail(ctx, AH_INVALID_ARGUMENT, "ah_memcpy_htod while a graph is being recorded: it waits for the stream");
   AH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stats.host_to_device_bytes += (int64_t)bytes;
   return AH_OK;
 }
 extern "C" ah_status ah_memcpy_dtod(ah_context* ctx, void* dst, const void* src, size_t bytes) {
@@ -509,6 +510,7 @@ extern "C" ah_status ah_memcpy_dtoh(ah_context* ctx, void* dst, const void* src,
   if (ctx->capturing) return ah_fail(ctx, AH_INVALID_ARGUMENT, "ah_memcpy_dtoh while a graph is being recorded: it waits for the stream");
   AH_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stats.device_to_host_bytes += (int64_t)bytes;
   return AH_OK;
 }
 extern "C" ah_status ah_memset(ah_context* ctx, void* dst, int value, size_t bytes) {

@@ -220,6 +220,8 @@ typedef struct ah_context_stats_t {
   int64_t free_calls;
   int64_t pool_hits;                 /* allocations served from the free lists */
   int64_t device_malloc_calls;       /* allocations that went to hipMalloc */
+  int64_t host_to_device_bytes;      /* cumulative payload bytes the host boundary moved over PCIe: ah_memcpy_htod and */
+  int64_t device_to_host_bytes;      /* ah_import_c_data / ah_memcpy_dtoh and ah_export_c_data (kernel traffic stays in HBM) */
 } ah_context_stats_t;
 AH_API ah_status ah_context_stats(ah_context* ctx, ah_context_stats_t* out, int32_t reset_peaks);
 AH_API const char* ah_last_error(ah_context* ctx);

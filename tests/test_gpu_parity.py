@@ -1645,6 +1645,11 @@ def test_context_memory_stats(ctx):
     assert s3["pool_hits"] > s2["pool_hits"] and s3["device_malloc_calls"] == s2["device_malloc_calls"]
     s4 = ctx.memory_stats()
     assert s4["high_water_bytes"] == s4["live_bytes"]  # reset: the peak restarts from what is live now
+    # bytes over the host boundary: the upload of `a` was counted, a download is
+    assert s4["host_to_device_bytes"] >= n * 8
+    before = s4["device_to_host_bytes"]
+    r2.values_numpy()
+    assert ctx.memory_stats()["device_to_host_bytes"] - before == n * 8
     del r2
 
 
