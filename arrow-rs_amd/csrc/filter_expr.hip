@@ -49,16 +49,6 @@ struct ExprArgs {
   uint32_t* group_total;
 };
 
-__device__ __forceinline__ uint64_t spread2(uint64_t x) {  // bit p of the low 32 -> bit 2p
-  x &= 0xFFFFFFFFull;
-  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-  x = (x | (x << 2)) & 0x3333333333333333ull;
-  x = (x | (x << 1)) & 0x5555555555555555ull;
-  return x;
-}
-
 // raw little-endian element -> a signed 64-bit key whose signed order is the type's order (floats: totalOrder)
 template <int W> __device__ __forceinline__ int64_t to_key(uint64_t raw, int kind) {
   if constexpr (W == 8) {
@@ -125,32 +115,59 @@ __device__ __forceinline__ int64_t key_w(int width, uint64_t raw, int kind) {
 
 
 
-// branch-free comparison: op as three wave-uniform masks over (lt, eq, gt)
-struct OpMask { bool lt, eq, gt; };
+// The comparison as BALLOTS: `a < b` and `a == b` compile to one v_cmp each whose result IS the 64-lane mask in a
+// scalar register pair; the op is three wave-uniform 64-bit masks over (lt, eq, gt) applied on the scalar unit.
+// (The first form built 0 / 1 integers per lane with v_cndmask, combined them on the vector unit and compared the
+// result with zero to get the ballot: ~16 vector instructions per value pair instead of 4.)
+struct OpMask { uint64_t lt, eq, gt; };
 __device__ __forceinline__ OpMask op_mask(int op) {
   OpMask m;
-  m.lt = op == AH_LT || op == AH_LT_EQ || op == AH_NEQ;
-  m.eq = op == AH_EQ || op == AH_LT_EQ || op == AH_GT_EQ;
-  m.gt = op == AH_GT || op == AH_GT_EQ || op == AH_NEQ;
+  m.lt = (op == AH_LT || op == AH_LT_EQ || op == AH_NEQ) ? ~0ull : 0ull;
+  m.eq = (op == AH_EQ || op == AH_LT_EQ || op == AH_GT_EQ) ? ~0ull : 0ull;
+  m.gt = (op == AH_GT || op == AH_GT_EQ || op == AH_NEQ) ? ~0ull : 0ull;
   return m;
 }
-__device__ __forceinline__ bool cmp_masked(const OpMask& m, int64_t a, int64_t b) {
-  const int lt = a < b, eq = a == b;  // bitwise on purpose: `&&` / `||` become branches around the ballots
-  return ((lt & (int)m.lt) | (eq & (int)m.eq) | (((lt | eq) ^ 1) & (int)m.gt)) != 0;
+template <typename KT> __device__ __forceinline__ uint64_t cmp_ballot(const OpMask& m, KT a, KT b) {
+  const uint64_t lt = __ballot(a < b), eq = __ballot(a == b);
+  return (lt & m.lt) | (eq & m.eq) | (~(lt | eq) & m.gt);
 }
-// branch-free key of the fast path (FW = 8 or 4): kind is wave-uniform, selected with v_cndmask
-template <int W> __device__ __forceinline__ int64_t fast_key(uint64_t raw, int kind) {
+// branch-free key of the fast path (FW = 8 or 4): the kind as two wave-uniform masks — floats flip the magnitude bits
+// of negative values (totalOrder), unsigned types flip the sign bit — so no select and no branch per value
+template <int W> struct KeyT { using type = int64_t; };
+template <> struct KeyT<4> { using type = int32_t; };
+struct KindMask { uint64_t flt, uns; };
+template <int W> __device__ __forceinline__ KindMask kind_mask(int kind) {
+  KindMask m;
+  if constexpr (W == 8) {
+    m.flt = kind == 2 ? 0x7FFFFFFFFFFFFFFFull : 0ull;
+    m.uns = kind == 1 ? 0x8000000000000000ull : 0ull;
+  } else {
+    m.flt = kind == 2 ? 0x7FFFFFFFull : 0ull;
+    m.uns = kind == 1 ? 0x80000000ull : 0ull;
+  }
+  return m;
+}
+template <int W> __device__ __forceinline__ typename KeyT<W>::type fast_key(uint64_t raw, const KindMask& km) {
   if constexpr (W == 8) {
     const int64_t b = (int64_t)raw;
-    const int64_t f = b ^ (int64_t)((uint64_t)(b >> 63) >> 1);
-    const int64_t u = (int64_t)(raw ^ 0x8000000000000000ull);
-    return kind == 2 ? f : (kind == 1 ? u : b);
+    return b ^ ((b >> 63) & (int64_t)km.flt) ^ (int64_t)km.uns;
   } else {
     const int32_t b = (int32_t)(uint32_t)raw;
-    const int64_t f = (int64_t)(b ^ (int32_t)((uint32_t)(b >> 31) >> 1));
-    const int64_t u = (int64_t)(uint32_t)raw;
-    return kind == 2 ? f : (kind == 1 ? u : (int64_t)b);
+    return b ^ ((b >> 31) & (int32_t)(uint32_t)km.flt) ^ (int32_t)(uint32_t)km.uns;
   }
+}
+// bit p of a 32-bit half word -> bit 2p of a 64-bit word, on the vector unit (lanes 0..15 of the fold do 16 words at once;
+// done per wave step on the scalar unit this was 60 scalar instructions per ballot pair: the CU's one scalar unit was
+// the kernel's limit)
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
+__device__ __forceinline__ uint64_t spread32(uint32_t x) {
+  return (uint64_t)spread16(x & 0xFFFFu) | ((uint64_t)spread16(x >> 16) << 32);
 }
 
 // (the first version of this kernel fetched validity words per step with inlined bv_fetch64's: 16 K instructions, past
@@ -159,6 +176,66 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), l);
   return ((uint64_t)hi << 32) | lo;
+}
+
+// The comparison ballots of one chunk (1024 rows at row0) for every term: 8 wave steps of 128 rows; s_raw[k][step] =
+// (ballot of rows 2l, ballot of rows 2l + 1), interleaved into value words by the fold.
+// FULL: the chunk lies wholly inside the column — unconditional 16-byte loads, HS steps' worth issued back to back.
+template <int NT, int FW, bool RS, bool FULL>
+__device__ __forceinline__ void expr_value_words(const ExprArgs& a, int64_t row0, int lane, const OpMask (&om)[NT],
+                                                 const KindMask (&km)[NT], const int64_t (&rkey)[NT], ulonglong2 (*s_raw)[8]) {
+  constexpr int HS = FW ? HALF_STEPS : 1;  // steps whose loads are in flight together
+  constexpr int NH = 8 / HS;
+  constexpr int W = FW ? FW : 8;
+  using R = typename RawT<W>::type;
+  using KT = typename KeyT<W>::type;
+#pragma unroll 1
+  for (int half = 0; half < NH; ++half) {
+    uint64_t lx[NT][HS][2], rx[NT][HS][2];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+      const ExprTerm& tm = a.t[k];
+#pragma unroll
+      for (int s = 0; s < HS; ++s) {
+        const int64_t row = row0 + (half * HS + s) * 128 + 2 * lane;
+        if constexpr (FW != 0 && FULL) {
+          const Pair<W> lv = *(const Pair<W>*)((const R*)tm.l + row);
+          lx[k][s][0] = (uint64_t)lv.e[0], lx[k][s][1] = (uint64_t)lv.e[1];
+          if constexpr (!RS) {
+            const Pair<W> rv = *(const Pair<W>*)((const R*)tm.r + row);
+            rx[k][s][0] = (uint64_t)rv.e[0], rx[k][s][1] = (uint64_t)rv.e[1];
+          } else {
+            rx[k][s][0] = rx[k][s][1] = 0;
+          }
+        } else if constexpr (FW != 0) {
+          load_pair<W>(tm.l, row, a.len, false, true, lx[k][s][0], lx[k][s][1]);
+          if constexpr (!RS) load_pair<W>(tm.r, row, a.len, false, true, rx[k][s][0], rx[k][s][1]);
+          else rx[k][s][0] = rx[k][s][1] = 0;
+        } else {
+          load_pair_w(tm.width, tm.l, row, a.len, tm.l_scalar != 0, tm.l_vec != 0, lx[k][s][0], lx[k][s][1]);
+          load_pair_w(tm.width, tm.r, row, a.len, tm.r_scalar != 0, tm.r_vec != 0, rx[k][s][0], rx[k][s][1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < HS; ++s) {
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        const ExprTerm& tm = a.t[k];
+        uint64_t b0, b1;  // bit l = row 2l (b0) / 2l + 1 (b1)
+        if constexpr (FW != 0) {
+          const KT r0 = RS ? (KT)rkey[k] : fast_key<W>(rx[k][s][0], km[k]);
+          const KT r1 = RS ? (KT)rkey[k] : fast_key<W>(rx[k][s][1], km[k]);
+          b0 = cmp_ballot<KT>(om[k], fast_key<W>(lx[k][s][0], km[k]), r0);
+          b1 = cmp_ballot<KT>(om[k], fast_key<W>(lx[k][s][1], km[k]), r1);
+        } else {
+          b0 = cmp_ballot<int64_t>(om[k], key_w(tm.width, lx[k][s][0], tm.kind), key_w(tm.width, rx[k][s][0], tm.kind));
+          b1 = cmp_ballot<int64_t>(om[k], key_w(tm.width, lx[k][s][1], tm.kind), key_w(tm.width, rx[k][s][1], tm.kind));
+        }
+        if (lane == 0) s_raw[k][half * HS + s] = make_ulonglong2(b0, b1);
+      }
+    }
+  }
 }
 
 // One workgroup = 64 chunks (65 536 rows); in iteration `it` wave w owns chunk it * 4 + w: 8 wave steps of 128 rows,
@@ -171,19 +248,19 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
 // dispatched per term at run time (correct, not tuned).
 template <int NT, int FW, bool RS>
 __global__ void __launch_bounds__(256) filter_expr_count_kernel(ExprArgs a) {
-  constexpr int HS = FW ? HALF_STEPS : 1;  // steps whose loads are in flight together
-  constexpr int NH = 8 / HS;
   __shared__ uint32_t s_cnt[GROUP_CHUNKS_E];
-  __shared__ uint64_t s_val[4][NT][16];  // per wave: the value words of the chunk's terms
+  __shared__ ulonglong2 s_raw[4][NT][8];  // per wave: the comparison ballots of the chunk's terms, per wave step
   const int t = threadIdx.x, lane = t & 63, wave = ah_uniform(t >> 6);
   const int64_t chunk_base = (int64_t)blockIdx.x * GROUP_CHUNKS_E;
   const int64_t nchunks = (a.len + AH_FILTER_CHUNK_ROWS - 1) / AH_FILTER_CHUNK_ROWS;
   OpMask om[NT];
+  KindMask km[NT];
   int64_t rkey[NT];  // RS: the scalar right-hand sides, once
   uint64_t lsw[NT], rsw[NT];  // validity of scalar operands as a word, once (a load here waits for nothing else)
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     om[k] = op_mask(a.t[k].op);
+    km[k] = kind_mask<(FW ? FW : 8)>(a.t[k].kind);
     rkey[k] = 0;
     lsw[k] = (a.t[k].l_scalar && a.t[k].lv.words && !bv_get(a.t[k].lv, 0)) ? 0ull : ~0ull;
     rsw[k] = (a.t[k].r_scalar && a.t[k].rv.words && !bv_get(a.t[k].rv, 0)) ? 0ull : ~0ull;
@@ -192,7 +269,7 @@ __global__ void __launch_bounds__(256) filter_expr_count_kernel(ExprArgs a) {
     if constexpr (FW != 0 && RS) {
       uint64_t x0, x1;
       load_pair<(FW ? FW : 8)>(a.t[k].r, 0, 1, true, false, x0, x1);
-      rkey[k] = fast_key<(FW ? FW : 8)>(x0, a.t[k].kind);
+      rkey[k] = (int64_t)fast_key<(FW ? FW : 8)>(x0, km[k]);
     }
   }
   for (int it = 0; it < GROUP_CHUNKS_E / 4; ++it) {
@@ -211,51 +288,13 @@ __global__ void __launch_bounds__(256) filter_expr_count_kernel(ExprArgs a) {
       if (a.t[k].lv.words && !a.t[k].l_scalar && lane < 16) rl[k] = bv_issue(a.t[k].lv, vsc, a.len);
       if (a.t[k].rv.words && !a.t[k].r_scalar && lane < 16) rr[k] = bv_issue(a.t[k].rv, vsc, a.len);
     }
-    // 2. the value words: ballots of the comparisons, four steps' loads in flight at a time
-#pragma unroll 1
-    for (int half = 0; half < NH; ++half) {
-      uint64_t lx[NT][HS][2], rx[NT][HS][2];
-#pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        const ExprTerm& tm = a.t[k];
-#pragma unroll
-        for (int s = 0; s < HS; ++s) {
-          const int64_t row = row0 + (half * HS + s) * 128 + 2 * lane;
-          if constexpr (FW != 0) {
-            load_pair<(FW ? FW : 8)>(tm.l, row, a.len, false, true, lx[k][s][0], lx[k][s][1]);
-            if constexpr (!RS) load_pair<(FW ? FW : 8)>(tm.r, row, a.len, false, true, rx[k][s][0], rx[k][s][1]);
-            else rx[k][s][0] = rx[k][s][1] = 0;
-          } else {
-            load_pair_w(tm.width, tm.l, row, a.len, tm.l_scalar != 0, tm.l_vec != 0, lx[k][s][0], lx[k][s][1]);
-            load_pair_w(tm.width, tm.r, row, a.len, tm.r_scalar != 0, tm.r_vec != 0, rx[k][s][0], rx[k][s][1]);
-          }
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < HS; ++s) {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-          const ExprTerm& tm = a.t[k];
-          bool c0, c1;
-          if constexpr (FW != 0) {
-            const int64_t r0 = RS ? rkey[k] : fast_key<(FW ? FW : 8)>(rx[k][s][0], tm.kind);
-            const int64_t r1 = RS ? rkey[k] : fast_key<(FW ? FW : 8)>(rx[k][s][1], tm.kind);
-            c0 = cmp_masked(om[k], fast_key<(FW ? FW : 8)>(lx[k][s][0], tm.kind), r0);
-            c1 = cmp_masked(om[k], fast_key<(FW ? FW : 8)>(lx[k][s][1], tm.kind), r1);
-          } else {
-            c0 = cmp_masked(om[k], key_w(tm.width, lx[k][s][0], tm.kind), key_w(tm.width, rx[k][s][0], tm.kind));
-            c1 = cmp_masked(om[k], key_w(tm.width, lx[k][s][1], tm.kind), key_w(tm.width, rx[k][s][1], tm.kind));
-          }
-          const uint64_t b0 = __ballot(c0), b1 = __ballot(c1);  // bit l = row 2l (b0) / 2l + 1 (b1)
-          const uint64_t tv0 = spread2(b0) | (spread2(b1) << 1);
-          const uint64_t tv1 = spread2(b0 >> 32) | (spread2(b1 >> 32) << 1);
-          if (lane == 0) {
-            s_val[wave][k][(half * HS + s) * 2] = tv0;
-            s_val[wave][k][(half * HS + s) * 2 + 1] = tv1;
-          }
-        }
-      }
-    }
+    // 2. the value words: ballots of the comparisons, four steps' loads in flight at a time.  A chunk that lies wholly
+    //    inside the column (all but the last) loads without a bounds test: the tested form compiles to a divergent
+    //    branch per load with an s_waitcnt vmcnt(0) behind it — ONE load in flight per wave (5.3 TB/s for 1e9 rows).
+    if (FW != 0 && row0 + AH_FILTER_CHUNK_ROWS <= a.len)  // wave-uniform
+      expr_value_words<NT, FW, RS, true>(a, row0, lane, om, km, rkey, s_raw[wave]);
+    else
+      expr_value_words<NT, FW, RS, false>(a, row0, lane, om, km, rkey, s_raw[wave]);
     // 3. fold the terms, 16 words at a time (lane j < 16 = word j).  Bit formulas of arrow-arith/src/boolean.rs.
     //    (same-wave LDS traffic: the writes above are ordered before these reads by the wave's own program order)
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
@@ -265,7 +304,10 @@ __global__ void __launch_bounds__(256) filter_expr_count_kernel(ExprArgs a) {
       for (int k = 0; k < NT; ++k) {
         const uint64_t lw = a.t[k].l_scalar ? lsw[k] : (a.t[k].lv.words ? bv_finish(rl[k], vsc, a.len) : ~0ull);
         const uint64_t rw = a.t[k].r_scalar ? rsw[k] : (a.t[k].rv.words ? bv_finish(rr[k], vsc, a.len) : ~0ull);
-        const uint64_t tv = s_val[wave][k][lane], tk = lw & rw;
+        // word j of the chunk = rows 64j .. 64j + 63 = half (j & 1) of step j >> 1: its two ballot halves, interleaved
+        const ulonglong2 bb = s_raw[wave][k][lane >> 1];
+        const int sh = (lane & 1) * 32;
+        const uint64_t tv = spread32((uint32_t)(bb.x >> sh)) | (spread32((uint32_t)(bb.y >> sh)) << 1), tk = lw & rw;
         if (k == 0) {
           v = tv, nn = tk;
         } else {
