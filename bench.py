@@ -1148,6 +1148,111 @@ def emit(line, args):
     print(json.dumps(compact), flush=True)
 
 
+# ------------------------------------------------------------------------------------------ transport probe (N > 1)
+PROBE_ROWS = 1 << 22  # rows per rank in the probe exchange (Int64 + Float64 with validity: ~68 MB per rank)
+
+
+def probe_child_main(argv):
+    """`python bench.py --probe-transport capi|torch`: ONE exchange of a {Int64, Float64, validity} shard per rank over
+    the transport named, in a process of its own.  The parent rank (below) runs it BEFORE it touches the transport: a
+    transport that hangs or aborts on this node (first contact with real RCCL over xGMI happens on the driver's scaling
+    run) takes this child down, not the benchmark — the parent then switches transports or reports shard-local numbers.
+    Exit 0 + 'PROBE_OK' = the concatenation arrived with the right row count on this rank."""
+    transport = argv[0] if argv else "capi"
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = 0 if os.environ.get("AH_BENCH_SHARED_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("AH_BENCH_BACKEND", "nccl")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import arrow_rs_amd as A
+    from arrow_rs_amd import distributed as D
+    ctx = A.Context(local_rank)
+    A.set_default_context(ctx)
+    n = PROBE_ROWS + 4096 * rank  # ragged on purpose: the counts differ per rank
+    a = gen_i64_column(A, ctx, n, 7, 0.9, rank * PROBE_ROWS)
+    b = gen_f64_column(A, ctx, n, 9, 0.9, rank * PROBE_ROWS)
+    total = sum(PROBE_ROWS + 4096 * r for r in range(world))
+    if transport == "capi":
+        def share_id(payload):
+            box = [payload]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = D.CApiCommunicator(ctx, rank, world, share_id)
+        g = comm.all_gather_record_batch(A.RecordBatch(["a", "b"], [a, b], n))
+        rows, nulls = g.num_rows(), [c.null_count() for c in g.columns]
+        comm.barrier()
+    else:
+        grp = dist.new_group(backend="nccl") if backend == "nccl" else None
+        comm = D.Communicator(ctx, dist, group=grp)
+        ga, gb = comm.all_gatherv(a), comm.all_gatherv(b)
+        rows, nulls = ga.length, [ga.null_count(), gb.null_count()]
+        if gb.length != rows:
+            raise SystemExit(f"probe: columns disagree ({rows} vs {gb.length} rows)")
+        dist.barrier()
+    ctx.synchronize()
+    if rows != total:
+        raise SystemExit(f"probe: {rows} rows arrived, {total} expected")
+    # every rank must see the same NULL counts (the bitmaps travelled and were merged at the right bit offsets)
+    seen = [None] * world
+    dist.all_gather_object(seen, nulls)
+    if any(x != seen[0] for x in seen):
+        raise SystemExit(f"probe: ranks disagree on the gathered NULL counts: {seen}")
+    print("PROBE_OK", flush=True)
+    sys.stdout.flush()
+    os._exit(0)  # no destructors: a transport that tears down badly must not turn a good probe into a bad one
+
+
+def probe_transport(dist, rank, world, transport):
+    """Run the probe child of every rank (collectively) and agree on the verdict.  -> (ok, reason)"""
+    import tempfile
+    box = [_free_port() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    timeout = float(os.environ.get("AH_BENCH_PROBE_TIMEOUT", "150"))
+    # (under torch.distributed.run the ranks rendezvous through the AGENT's store — TORCHELASTIC_USE_AGENT_STORE — which
+    # does not listen on the probe's port: without those variables the child of rank 0 hosts the store itself)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env.update(MASTER_PORT=str(box[0]), AH_BENCH_PROBE_CHILD="1")
+    log = tempfile.NamedTemporaryFile(prefix=f"ah_probe_{transport}_{rank}_", suffix=".log", delete=False)
+    t0 = time.perf_counter()
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--probe-transport", transport], env=env,
+                         stdout=log, stderr=subprocess.STDOUT)
+    why = None
+    try:
+        rc = p.wait(timeout=timeout)
+        if rc != 0:
+            why = f"rank {rank}: probe exited {rc}"
+    except subprocess.TimeoutExpired:
+        p.kill()  # (this exact child)
+        p.wait()
+        why = f"rank {rank}: no answer within {timeout:.0f} s (hung)"
+    log.close()
+    try:
+        text = open(log.name, errors="replace").read()
+        os.unlink(log.name)
+    except OSError:
+        text = ""
+    if why is None and "PROBE_OK" not in text:
+        why = f"rank {rank}: probe ended without PROBE_OK"
+    if why is not None:
+        tail = " | ".join(l.strip() for l in text.strip().splitlines()[-3:])
+        why = (why + (": " + tail if tail else ""))[:300]
+    verdicts = [None] * world
+    dist.all_gather_object(verdicts, why)
+    bad = [v for v in verdicts if v]
+    return (not bad), (bad[0] if bad else f"ok in {time.perf_counter() - t0:.1f} s")
+
+
+class ShardLocalOnly:
+    """What is left when no transport passed the probe: barriers and the MAX over ranks through the CPU process group;
+    no exchange (the line says so).  Never chosen silently: `config.transport_note` carries both probes' verdicts."""
+
+    def __init__(self, dist, world):
+        self.dist, self.world = dist, world
+        self.timings, self.last_exchange = None, None
+
+
 def _free_port():
     import socket
     so = socket.socket()
@@ -1200,6 +1305,8 @@ def spawn_ranks(args):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         return cpu_worker_main(sys.argv[2:])
+    if len(sys.argv) > 1 and sys.argv[1] == "--probe-transport":
+        return probe_child_main(sys.argv[2:])
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
         sys.exit(spawn_ranks(args))
@@ -1241,6 +1348,20 @@ def main():
             os.dup2(keep, 1)
             os.close(keep)
 
+    # N > 1: every transport is tried in a child process first (probe_transport above); one that hangs or aborts costs
+    # that child, and the run goes on with the next transport — or shard-local, saying so — instead of ending there
+    probe_notes, exchange_ok = [], True
+    if (world > 1 and use_dist and transport == "capi" and not args.pmc_child and os.environ.get("AH_BENCH_PROBE", "1") != "0"):
+        ok, why = probe_transport(dist, rank, world, "capi")
+        if not ok:
+            probe_notes.append("ah_comm transport failed its probe (" + why + ")")
+            ok, why = probe_transport(dist, rank, world, "torch")
+            if ok:
+                transport = "torch"
+            else:
+                probe_notes.append("torch.distributed transport failed its probe (" + why + ")")
+                exchange_ok = False
+
     import arrow_rs_amd as A
     from arrow_rs_amd import compute as K
     ctx = A.Context(local_rank)
@@ -1248,8 +1369,11 @@ def main():
     env = Env()
     env.A, env.K, env.ctx, env.args, env.rank, env.local_rank, env.world = A, K, ctx, args, rank, local_rank, world
     env.comm = None
-    transport_note = None
-    if use_dist:
+    transport_note = "; ".join(probe_notes) if probe_notes else None
+    if use_dist and not exchange_ok:
+        env.comm = ShardLocalOnly(dist, world)
+        transport = "torch"  # (barriers and the MAX over ranks go through the CPU process group)
+    elif use_dist:
         from arrow_rs_amd import distributed as D
         if transport == "capi":
             def share_id(payload):
@@ -1264,13 +1388,14 @@ def main():
             flags = [None] * world
             dist.all_gather_object(flags, err)
             if any(flags):  # every rank switches together
-                transport, transport_note = "torch", "capi transport failed: " + str(next(f for f in flags if f))
+                transport = "torch"
+                transport_note = "; ".join(probe_notes + ["capi transport failed: " + str(next(f for f in flags if f))])
                 env.comm = None
         if env.comm is None:
             g = dist.new_group(backend="nccl") if (dist.get_backend() != "nccl" and backend == "nccl") else None
             env.comm = D.Communicator(ctx, dist, group=g)
             env.torch_group = g
-    reassemble = (world > 1 and args.reassemble == "auto") or args.reassemble == "allgatherv"
+    reassemble = exchange_ok and ((world > 1 and args.reassemble == "auto") or args.reassemble == "allgatherv")
 
     def sync_all():
         ctx.synchronize()
@@ -1440,7 +1565,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "rows_per_gpu": n, "parallelism": f"row-sharded x{world}",
                        "distinct_devices": len(devices),
-                       "reassemble": ("allgatherv" if reassemble else "none"),
+                       "reassemble": ("allgatherv" if reassemble else ("none" if exchange_ok else "skipped: no transport passed its probe")),
                        "transport": (("ah_comm (RCCL bound by libarrow_hip.so)" if transport == "capi" else "torch.distributed")
                                      if use_dist else "none")},
             "roofline": rf,
@@ -1534,7 +1659,7 @@ def main():
         line["configs"] = configs
         line["next_rows"] = next_rows
 
-    if wl == "filter_take" and (world > 1 or args.reassemble == "allgatherv") and use_dist and not args.no_configs:
+    if wl == "filter_take" and (world > 1 or args.reassemble == "allgatherv") and use_dist and exchange_ok and not args.no_configs:
         # BASELINE configs[4]: {Int64, Float64, bitmaps} per shard through filter_record_batch, then ONE exchange of both
         # columns (ah_all_gather_columns) — every rank runs it, rank 0 reports
         W = out = None

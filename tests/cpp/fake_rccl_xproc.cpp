@@ -343,6 +343,10 @@ FAKE_API ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t t, int pe
 FAKE_API ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t t, ncclComm_t c, hipStream_t stream) {
   const size_t bytes = count * type_size(t);
   if (!c || bytes > COLL_BYTES - 8) return 4;
+  if (const char* h = getenv("AH_FAKE_RCCL_HANG")) {  // fault injection: a collective that never returns (bench.py's probe must survive it)
+    if (h[0] == '1')
+      for (int i = 0; i < 36000; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+  }
   if (hipStreamSynchronize(stream) != hipSuccess) return 1;
   if (bytes && hipMemcpy(c->shm->coll[c->rank], send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
   // the send count must be the same on every rank (undefined on real RCCL otherwise): the checker checks

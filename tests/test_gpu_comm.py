@@ -98,7 +98,8 @@ def test_bench_self_spawned_ranks_over_the_c_abi_transport(workload, launcher, w
     lib = _build_fake(tmp_path, "fake_rccl_xproc")
     rows = 50_000_000 if world == 2 else 6_000_000  # (world 8: the driver's SCALE command line shape, eight ranks on the one GPU)
     dump = str(tmp_path / "gathered.npz")
-    env = dict(os.environ, AH_BENCH_SHARED_GPU="1", AH_RCCL_LIBRARY=lib, AH_FAKE_RCCL_DIR=str(tmp_path), AH_FAKE_RCCL_TIMEOUT_S="90")
+    env = dict(os.environ, AH_BENCH_SHARED_GPU="1", AH_RCCL_LIBRARY=lib, AH_FAKE_RCCL_DIR=str(tmp_path), AH_FAKE_RCCL_TIMEOUT_S="90",
+               AH_BENCH_PROBE_TIMEOUT="90")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--rows", str(rows),
@@ -120,7 +121,7 @@ def test_bench_self_spawned_ranks_over_the_c_abi_transport(workload, launcher, w
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["value"] > 0 and d["scaling"] == "weak"
     cfg = d["config"]
-    assert cfg["transport"].startswith("ah_comm") and "transport_note" not in cfg, cfg
+    assert cfg["transport"].startswith("ah_comm") and "transport_note" not in cfg, (cfg, cfg.get("transport_note"))
     assert cfg["distinct_devices"] == 1 and cfg["reassemble"] == "allgatherv", cfg
     if workload == "filter_take":
         ex = d["exchange"]
@@ -143,6 +144,38 @@ def test_bench_self_spawned_ranks_over_the_c_abi_transport(workload, launcher, w
         assert_logical_eq(got, exp, f"{workload}: reassembled column {i} vs the oracle's un-sharded filter")
         total = len(exp)
     assert int(z["gathered_rows"]) == total and 0 < int(z["selected_local"]) < total  # gathered rows = sum of the K_r
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_survives_a_transport_that_hangs(tmp_path):
+    """The driver's scaling run is the first contact with real RCCL over xGMI.  bench.py therefore tries every transport
+    in a CHILD process first (one ragged {Int64, Float64, validity} exchange per rank): here the cross-process fake is
+    told to hang in its all-gather (AH_FAKE_RCCL_HANG=1), so the ah_comm probe must be killed at its deadline; the
+    torch.distributed probe then fails fast (RCCL refuses two ranks on one device); and the run must still END with one
+    valid line — shard-local numbers, the exchange marked as skipped and both probes' verdicts in `transport_note`."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = _build_fake(tmp_path, "fake_rccl_xproc")
+    env = dict(os.environ, AH_BENCH_SHARED_GPU="1", AH_RCCL_LIBRARY=lib, AH_FAKE_RCCL_DIR=str(tmp_path), AH_FAKE_RCCL_TIMEOUT_S="60",
+               AH_FAKE_RCCL_HANG="1", AH_BENCH_PROBE_TIMEOUT="25")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "20000000",
+           "--no-cpu-baseline", "--config-steps", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak", d
+    assert cfg["reassemble"].startswith("skipped"), cfg
+    note = cfg["transport_note"]
+    assert "ah_comm transport failed its probe" in note and "hung" in note and "torch.distributed transport failed its probe" in note, note
+    assert "exchange" not in d and "record_batch_allgather" not in d.get("configs", {}), d.keys()
 
 
 def _gpu_count():
