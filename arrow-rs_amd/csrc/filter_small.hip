@@ -93,21 +93,6 @@ __global__ void __launch_bounds__(SMALL_THREADS) filter_small_kernel(SmallArgs a
     }
   }
 
-  // 1b. wave 0: every bit word it will need — predicate, predicate validity, value validity, of this tile AND of the 4096
-  //     rows behind it (step 4 reads those; issued in step 3) — is ISSUED behind the value loads and before anything waits: fetched
-  //     one bv_fetch64 at a time (load, wait, second word, wait) they were up to seven dependent memory round trips on the
-  //     critical path of a kernel that is all latency (13-16 us per synchronous call).
-  BvRaw t_m{}, t_mv{}, t_vv{}, n_m{}, n_mv{}, n_vv{};
-  const bool has_mv = a.mask_valid.words != nullptr;
-  const int64_t ts = row0 + ((int64_t)lane << 6), ns = ts + T;
-  const bool t_in = lane < NW && ts < a.len, n_in = HAS_VALID && ns < a.len;
-  if (wave == 0) {
-    const int64_t tc = t_in ? ts : 0;  // (out-of-range lanes re-read word 0: no branch around a load)
-    t_m = bv_issue(a.mask, tc, a.len);
-    if (has_mv) t_mv = bv_issue(a.mask_valid, tc, a.len);
-    if constexpr (HAS_VALID) t_vv = bv_issue(c.vvalid, tc, a.len);
-  }
-
   // 2. the tile's first output position: popcount of every predicate word before it (L2-resident: every tile of every
   //    column reads the same <= 128 KiB)
   unsigned long long pre = 0;
@@ -118,6 +103,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) filter_small_kernel(SmallArgs a
 #pragma unroll 8
       for (int64_t w = t; w < nprev; w += SMALL_THREADS) pre += __popcll(mw[w]);
     } else {  // bit offsets / predicate nulls: four words' loads in flight at a time (bv_fetch64 would wait for each)
+      const bool has_mv = a.mask_valid.words != nullptr;
       for (int64_t w0 = t; w0 < nprev; w0 += 4 * SMALL_THREADS) {
         BvRaw rm[4], rv[4] = {};
 #pragma unroll
@@ -139,19 +125,13 @@ __global__ void __launch_bounds__(SMALL_THREADS) filter_small_kernel(SmallArgs a
   pre = wave_reduce_add64(pre);
   if (lane == 0) s_pre[wave] = pre;
 
-  // 3. wave 0: the tile's word table (mask, validity, exclusive popcount prefix) from the words issued in step 1b
+  // 3. wave 0: the tile's word table (mask, validity, exclusive popcount prefix)
   if (wave == 0) {
-    if constexpr (HAS_VALID) {  // the rows behind the tile: in flight while the tile's words are scanned (held across step 2
-      const int64_t nc = n_in ? ns : 0;  // as well they cost 40 VGPRs = a workgroup per CU)
-      n_m = bv_issue(a.mask, nc, a.len);
-      if (has_mv) n_mv = bv_issue(a.mask_valid, nc, a.len);
-      n_vv = bv_issue(c.vvalid, nc, a.len);
-    }
     uint64_t m = 0, v = 0;
-    if (t_in) {
-      m = bv_finish(t_m, ts, a.len);
-      if (has_mv) m &= bv_finish(t_mv, ts, a.len);
-      if constexpr (HAS_VALID) v = bv_finish(t_vv, ts, a.len);
+    const int64_t s = row0 + ((int64_t)lane << 6);
+    if (lane < NW && s < a.len) {
+      m = sel_word(a, s);
+      if constexpr (HAS_VALID) v = bv_fetch64(c.vvalid, s, a.len);
     }
     const int cnt = __popcll(m);
     const int incl = wave_scan_incl(cnt);
@@ -179,13 +159,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) filter_small_kernel(SmallArgs a
       for (int64_t base = row0 + T; need > 0 && base < a.len && got < need; base += 4096) {  // wave-uniform loop
         const int64_t s = base + ((int64_t)lane << 6);
         uint64_t m = 0, vv = 0;
-        if (base == row0 + T) {  // the 4096 rows right behind the tile: prefetched in step 3
-          if (n_in) {
-            m = bv_finish(n_m, ns, a.len);
-            if (has_mv) m &= bv_finish(n_mv, ns, a.len);
-            vv = bv_finish(n_vv, ns, a.len);
-          }
-        } else if (s < a.len) {
+        if (s < a.len) {
           m = sel_word(a, s);
           vv = bv_fetch64(c.vvalid, s, a.len);
         }

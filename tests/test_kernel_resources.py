@@ -93,11 +93,9 @@ def test_round3_kernels_keep_their_occupancy(kernels):
     # the multi-batch scatter shares filter_scatter's body: same budget
     for r in _find(kernels, "filter_scatter_multi_kernelILi8ELi2ELb1E"):
         assert r["vgpr"] <= 96 and r["lds"] <= 32768, r
-    # the one-launch filter of small batches, Int64 with validity: a latency-bound kernel (<= 256 tiles per column).  r04:
-    # wave 0 holds the tile's predicate / validity words in flight across the prefix pass (three dependent round trips
-    # less) — 130 VGPRs, 3 workgroups per CU instead of 4, which a launch of <= 256 tiles per column does not notice
+    # the one-launch filter of small batches, Int64 with validity: a latency-bound kernel (<= 256 tiles); 4 waves per SIMD
     for r in _find(kernels, "filter_small_kernelILi8ELi2ELb1E"):
-        assert r["vgpr"] <= 136 and r["lds"] <= 32768, r
+        assert r["vgpr"] <= 128 and r["lds"] <= 32768, r
     # the wave-per-tile scatter for sparse selections lives on occupancy: 8 waves per SIMD, no scratch, <= 3 KiB of LDS
     for r in _find(kernels, "filter_scatter_sparse_kernelILi8ELb1E"):
         assert r["vgpr"] <= 64 and r["lds"] <= 3072 and r["scratch"] == 0, r
