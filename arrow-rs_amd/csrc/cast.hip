@@ -133,26 +133,7 @@ __global__ void __launch_bounds__(256) cast_kernel(CastArgs a) {
 // (8 -> 8 bytes: both sides), short-lived workgroups with 4 x 16-byte loads in flight per lane — the shape that
 // reaches 5.6 TB/s on a read+write stream on MI355X, against 4.7 TB/s for 8-byte accesses from a persistent
 // grid.  A group of 64*V rows is V validity words: per element slot e the wave ballots "valid and converted",
-// and the scalar unit bit-interleaves the V ballots into the V output words (as cmp.hip does).
-template <int V> __device__ __forceinline__ uint64_t cast_spread(uint64_t x);
-template <> __device__ __forceinline__ uint64_t cast_spread<1>(uint64_t x) { return x; }
-template <> __device__ __forceinline__ uint64_t cast_spread<2>(uint64_t x) {  // 32 bits -> even bit positions
-  x &= 0xFFFFFFFFull;
-  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-  x = (x | (x << 2)) & 0x3333333333333333ull;
-  x = (x | (x << 1)) & 0x5555555555555555ull;
-  return x;
-}
-template <> __device__ __forceinline__ uint64_t cast_spread<4>(uint64_t x) {  // 16 bits -> every 4th position
-  x &= 0xFFFFull;
-  x = (x | (x << 24)) & 0x000000FF000000FFull;
-  x = (x | (x << 12)) & 0x000F000F000F000Full;
-  x = (x | (x << 6)) & 0x0303030303030303ull;
-  x = (x | (x << 3)) & 0x1111111111111111ull;
-  return x;
-}
+// and lane k < V bit-interleaves its slices of the V ballots into output word k on the vector unit (as cmp.hip does).
 
 template <typename T, int V> struct alignas(sizeof(T) * V) CastVec { T e[V]; };
 #ifndef AH_CAST_G
@@ -216,14 +197,11 @@ __global__ void __launch_bounds__(256) cast_stream_kernel(CastArgs a) {
         if (i + e < a.len) op[i + e] = ov.e[e];
     }
     if (a.out_valid) {
+      // word k of the group covers lanes [k*64/V, (k+1)*64/V): lane k < V interleaves its slices of the V ballots (vector unit)
+      const int ksh = (lane & (V - 1)) * (64 / V);
       uint64_t mine = 0;
 #pragma unroll
-      for (int k = 0; k < V; ++k) {  // word k of the group covers lanes [k*64/V, (k+1)*64/V)
-        uint64_t w = 0;
-#pragma unroll
-        for (int e = 0; e < V; ++e) w |= cast_spread<V>(ballots[e] >> (k * (64 / V))) << e;
-        if (lane == k) mine = w;
-      }
+      for (int e = 0; e < V; ++e) mine |= vspread<V>(ballots[e] >> ksh) << e;
       const int64_t wi = g * V + lane;
       if (lane < V && wi < nwords) {
         a.out_valid[wi] = mine;

@@ -38,27 +38,10 @@ __device__ __forceinline__ int64_t bits_key(double v) { return __double_as_longl
 __device__ __forceinline__ int32_t bits_key(float v) { return __float_as_int(v); }
 template <typename T> __device__ __forceinline__ T bits_key(T v) { return v; }
 
-// place bit p of x at bit p*V
-template <int V> __device__ __forceinline__ uint64_t spread(uint64_t x);
-template <> __device__ __forceinline__ uint64_t spread<1>(uint64_t x) { return x; }
-template <> __device__ __forceinline__ uint64_t spread<2>(uint64_t x) {  // 32 -> 64
-  x &= 0xFFFFFFFFull;
-  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-  x = (x | (x << 2)) & 0x3333333333333333ull;
-  x = (x | (x << 1)) & 0x5555555555555555ull;
-  return x;
-}
-template <> __device__ __forceinline__ uint64_t spread<4>(uint64_t x) {  // 16 -> 64
-  x &= 0xFFFFull;
-  x = (x | (x << 24)) & 0x000000FF000000FFull;
-  x = (x | (x << 12)) & 0x000F000F000F000Full;
-  x = (x | (x << 6)) & 0x0303030303030303ull;
-  x = (x | (x << 3)) & 0x1111111111111111ull;
-  return x;
-}
-
+// place bit p of the low 64 / V bits of x at bit p * V — on the VECTOR unit, per lane: lane k < V assembles output word k
+// of its wave's group from the V ballots.  (The first form built all V words on the scalar unit, ~15 scalar
+// instructions per spread: one scalar unit serves the four SIMDs of a CU, and a compare against a SCALAR — half the
+// bytes per row of an array-array compare — ran out of scalar issue slots at 4.9 TB/s.)
 template <typename T, int V> struct alignas(sizeof(T) * V) VecT { T e[V]; };
 
 struct CmpArgs {
@@ -91,6 +74,8 @@ __global__ void __launch_bounds__(256) compare_kernel(CmpArgs a) {
   const int64_t wave0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
   const int64_t nwords = (a.len + 63) >> 6;
+  __shared__ uint64_t s_b[4][CMP_G * V];  // per wave: the ballots of its CMP_G groups
+  const int wave = threadIdx.x >> 6;
   for (int64_t g0 = wave0 * CMP_G; g0 < ngroups; g0 += nwaves * CMP_G) {
     VT lv[CMP_G], rv[CMP_G];
 #pragma unroll
@@ -109,30 +94,28 @@ __global__ void __launch_bounds__(256) compare_kernel(CmpArgs a) {
     }
 #pragma unroll
     for (int gi = 0; gi < CMP_G; ++gi) {
-      const int64_t g = g0 + gi;
-      if (g >= ngroups) break;
-      const int64_t i = (g * 64 + lane) * V;
-      uint64_t ballots[V];
+      const int64_t i = ((g0 + gi) * 64 + lane) * V;  // (groups past the end compare nothing: every row test fails)
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         T x = a.l_scalar ? ls : lv[gi].e[e];
         T y = a.r_scalar ? rs : rv[gi].e[e];
         bool res = a.base == B_EQ ? (bits_key(x) == bits_key(y)) : (order_key(x) < order_key(y));
         res = res && (i + e < a.len);
-        ballots[e] = __ballot(res);
+        const uint64_t b = __ballot(res);
+        if (lane == 0) s_b[wave][gi * V + e] = b;
       }
-      // word k of the group covers lanes [k*64/V, (k+1)*64/V)
+    }
+    // The CMP_G * V output words of the wave's groups, one per lane: word j = group j / V, lanes [k * 64 / V, (k + 1) * 64 / V)
+    // with k = j % V — lane j interleaves its 64 / V-bit slices of that group's V ballots.  (Same-wave LDS traffic: the
+    // writes above are ordered before these reads by the wave's own program order.)
+    if (lane < CMP_G * V) {
+      const int gi = lane / V, ksh = (lane % V) * (64 / V);
       uint64_t mine = 0;
 #pragma unroll
-      for (int k = 0; k < V; ++k) {
-        uint64_t w = 0;
-#pragma unroll
-        for (int e = 0; e < V; ++e) w |= spread<V>(ballots[e] >> (k * (64 / V))) << e;
-        if (a.neg) w = ~w;  // collect_bool negates whole words, padding included (cmp.rs:590-592)
-        if (lane == k) mine = w;
-      }
-      int64_t wi = g * V + lane;
-      if (lane < V && wi < nwords) a.out[wi] = mine;
+      for (int e = 0; e < V; ++e) mine |= vspread<V>(s_b[wave][gi * V + e] >> ksh) << e;
+      if (a.neg) mine = ~mine;  // collect_bool negates whole words, padding included (cmp.rs:590-592)
+      const int64_t wi = g0 * V + lane;
+      if (wi < nwords) a.out[wi] = mine;
     }
   }
   if (a.post) {  // uniform

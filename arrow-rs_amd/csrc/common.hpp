@@ -282,6 +282,35 @@ __device__ __forceinline__ uint64_t bv_finish(const BvRaw& r, int64_t s, int64_t
   return x;
 }
 
+// Bit p of the low 64 / V bits of x -> bit p * V, written so that it runs on the VECTOR unit when x depends on the lane
+// (cmp.hip / cast.hip: lane k < V assembles output word k of a 64 * V-row group from the V ballots).  Built on the scalar
+// unit — all V words per wave, ~15 scalar instructions per spread — these interleaves made kernels scalar-issue bound:
+// one scalar unit serves the four SIMDs of a CU.
+__device__ __forceinline__ uint32_t vspread16x2(uint32_t x) {  // 16 bits -> 32, stride 2
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
+__device__ __forceinline__ uint32_t vspread8x4(uint32_t x) {  // 8 bits -> 32, stride 4
+  x = (x | (x << 12)) & 0x000F000Fu;
+  x = (x | (x << 6)) & 0x03030303u;
+  x = (x | (x << 3)) & 0x11111111u;
+  return x;
+}
+template <int V> __device__ __forceinline__ uint64_t vspread(uint64_t x);
+template <> __device__ __forceinline__ uint64_t vspread<1>(uint64_t x) { return x; }
+template <> __device__ __forceinline__ uint64_t vspread<2>(uint64_t x) {  // low 32 -> 64
+  const uint32_t h = (uint32_t)x;
+  return (uint64_t)vspread16x2(h & 0xFFFFu) | ((uint64_t)vspread16x2(h >> 16) << 32);
+}
+template <> __device__ __forceinline__ uint64_t vspread<4>(uint64_t x) {  // low 16 -> 64
+  const uint32_t h = (uint32_t)x;
+  return (uint64_t)vspread8x4(h & 0xFFu) | ((uint64_t)vspread8x4((h >> 8) & 0xFFu) << 32);
+}
+
+
 // A wave-uniform value the compiler can see is uniform (scalar register): addresses built from it become scalar
 // loads (s_load, counted by lgkmcnt), which do not make the vector loads already in flight wait.
 __device__ __forceinline__ int ah_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
