@@ -49,8 +49,8 @@ ah_status ah_filter_predicate_begin(ah_context*, const ah_array_view*, ah_filter
 ah_status ah_filter_predicate_end(ah_context*, ah_filter_predicate*, uint64_t, bool);
 extern "C" void ah_filter_predicate_free(ah_context*, ah_filter_predicate*);
 // filter.hip: the counts of up to 64 predicates into the CALLER's pinned words, posted / waited separately
-ah_status ah_filter_predicates_begin(ah_context*, int32_t, const ah_array_view*, ah_filter_predicate**, uint64_t*, uint64_t*);
-ah_status ah_filter_predicates_end(ah_context*, int32_t, ah_filter_predicate**, const uint64_t*, uint64_t);
+ah_status ah_filter_predicates_begin(ah_context*, int32_t, const ah_array_view*, ah_filter_predicate**, uint64_t*, uint64_t*, uint64_t*);
+ah_status ah_filter_predicates_end(ah_context*, int32_t, ah_filter_predicate**, const uint64_t*, uint64_t, const uint64_t*);
 
 extern "C" ah_status ah_take(ah_context*, const ah_array_view*, const ah_array_view*, int32_t, ah_array_out*);
 
@@ -143,6 +143,8 @@ struct ah_coalescer {
   // two groups of 64 pinned count words for pushes whose counts are in flight (push_batches_with_filters_begin / _end)
   uint64_t* cnt_pin = nullptr;
   uint64_t* cnt_pin_dev = nullptr;
+  uint64_t* quant_pin = nullptr;
+  uint64_t* quant_pin_dev = nullptr;
   bool cnt_busy[2] = {false, false};
   // view schemas: every push is an "input" with a sequence number (0, 1, 2, ... in push order; the host counts the same
   // way); `declared` holds the per-column data-buffer counts of the inputs about to be pushed
@@ -499,13 +501,15 @@ extern "C" ah_status ah_coalescer_create(ah_context* ctx, int32_t n_columns, con
     co->ring_slots = std::max(4, 512 / n_columns);
     const size_t ring_words = (size_t)co->ring_slots * n_columns;
     void *hp = nullptr, *dp = nullptr;
-    co->pin_bytes = (ring_words + 128) * 8;
+    co->pin_bytes = (ring_words + 128 + 2 * 64 * 32) * 8;  // ... + 2 x 64 predicates x 32 quantile words (AH_FILTER_QUANTS)
     st = ah_pinned_alloc(ctx, co->pin_bytes, &hp, &dp);  // from the context's cache: hipHostMalloc is 0.1-0.3 ms
     if (st == AH_OK) {
       co->pin = (uint64_t*)hp;
       co->pin_dev = (uint64_t*)dp;
       co->cnt_pin = co->pin + ring_words;  // 2 x 64 count words behind the null-count ring
       co->cnt_pin_dev = co->pin_dev + ring_words;
+      co->quant_pin = co->cnt_pin + 128;  // the predicates' quantile prefixes (filter_internal.hpp), 64 x 32 words per slot
+      co->quant_pin_dev = co->cnt_pin_dev + 128;
     }
   }
   if (st != AH_OK) {
@@ -915,7 +919,8 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters_begin(ah_context* ct
   if (n > 0) {
     const int slot = !co->cnt_busy[0] ? 0 : (!co->cnt_busy[1] ? 1 : -1);
     st = slot < 0 ? AH_NOT_YET_IMPLEMENTED
-                  : ah_filter_predicates_begin(ctx, n, h->filters.data(), h->preds.data(), co->cnt_pin_dev + 64 * slot, &h->seq);
+                  : ah_filter_predicates_begin(ctx, n, h->filters.data(), h->preds.data(), co->cnt_pin_dev + 64 * slot, &h->seq,
+                                               co->quant_pin_dev + (size_t)64 * 32 * slot);
     if (st == AH_OK) {
       h->slot = slot;
       co->cnt_busy[slot] = true;
@@ -940,7 +945,7 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters_end(ah_context* ctx,
   ah_status st = AH_OK;
   for (int i = 0; i < h->n && bypassed; ++i) bypassed[i] = 0;
   if (h->slot >= 0) {
-    st = ah_filter_predicates_end(ctx, h->n, h->preds.data(), co->cnt_pin + 64 * h->slot, h->seq);
+    st = ah_filter_predicates_end(ctx, h->n, h->preds.data(), co->cnt_pin + 64 * h->slot, h->seq, co->quant_pin + (size_t)64 * 32 * h->slot);
     co->cnt_busy[h->slot] = false;
   }
   if (st == AH_OK && co->failed) st = ah_fail(ctx, AH_INVALID_ARGUMENT, "BatchCoalescer: unusable after an earlier device error");

@@ -164,6 +164,8 @@ struct CountMulti {
     unsigned long long* group_prefix;
     unsigned long long* total;
     int64_t ngroups;
+    uint64_t* quant_pin;  // device view of pinned words (or null): prefix of every quant_step-th group, for the host
+    int64_t quant_step;
   } p[8];
 };
 __global__ void __launch_bounds__(64) filter_count_small_multi_kernel(CountMulti m) {
@@ -222,7 +224,11 @@ __global__ void __launch_bounds__(1024) filter_group_scan_multi_kernel(CountMult
   __syncthreads();
   unsigned long long wbase = 0;
   for (int w = 0; w < wave; ++w) wbase += s_wave[w];
-  if (t < o.ngroups) o.group_prefix[t] = wbase + incl - v;
+  if (t < o.ngroups) {
+    o.group_prefix[t] = wbase + incl - v;
+    if (o.quant_pin && t % o.quant_step == 0)
+      __hip_atomic_store(o.quant_pin + t / o.quant_step, (uint64_t)(wbase + incl - v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (t == 1023) {
     *o.total = wbase + incl;
     __hip_atomic_store(mail + slot0 + blockIdx.x, (uint64_t)(wbase + incl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -741,7 +747,8 @@ struct MultiSeg {
   const unsigned long long* group_prefix;
   int group_shift;
   int64_t out_base, win_lo, win_hi;
-  int64_t tile0;  // first tile of this batch in the launch's tile space
+  int64_t tile0;    // first tile of this batch in the launch's tile space
+  int64_t tile_lo;  // ... which stands for tile `tile_lo` of the batch (tiles before it hold no row of the window)
   struct Src {
     const void* values;
     BitView vvalid;
@@ -780,7 +787,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_multi_kernel(M
   a.nulls_mode = 1;
   const MultiSeg::Src& src = sg.col[blockIdx.y];
   const MultiArgs::Dst& d = m.dst[blockIdx.y];
-  scatter_tile<W, V, true, SKIP>(a, gtile - sg.tile0, src.values, src.vvalid, d.out_values, d.out_valid, d.null_slots);
+  scatter_tile<W, V, true, SKIP>(a, gtile - sg.tile0 + sg.tile_lo, src.values, src.vvalid, d.out_values, d.out_valid, d.null_slots);
 }
 
 // the multi-batch launch for sparse selections: the tile space of all segments, one 4096-row tile per wave (W <= 8: the
@@ -812,7 +819,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_multi_sparse_k
   a.nulls_mode = 1;
   const MultiSeg::Src& src = sg.col[blockIdx.y];
   const MultiArgs::Dst& d = m.dst[blockIdx.y];
-  sparse_tile<W, true>(a, gtile - sg.tile0, lane, wave, src.values, src.vvalid, d.out_values, d.out_valid, nullptr);
+  sparse_tile<W, true>(a, gtile - sg.tile0 + sg.tile_lo, lane, wave, src.values, src.vvalid, d.out_values, d.out_valid, nullptr);
 }
 
 // NULL rows among destination rows [bit_lo, bit_lo + nbits) of up to 8 columns (blockIdx.y), added to each column's
@@ -1129,8 +1136,10 @@ extern "C" ah_status ah_filter_predicates_build(ah_context* ctx, int32_t n, cons
 // pin_dev[0 .. n) (the device view of the caller's pinned words) and posts the mailbox behind them (*seq); `end` waits for
 // that sequence number and fills in the counts from the host view.  Only the multi-count shape (non-empty Boolean
 // predicates of at most 64 Mi rows): anything else -> AH_NOT_YET_IMPLEMENTED with nothing enqueued (use the one-call build).
+// quant_dev / quant_host (optional): n x AH_FILTER_QUANTS pinned words for the predicates' quantile prefixes
+// (ah_filter_predicate::quant).
 ah_status ah_filter_predicates_begin(ah_context* ctx, int32_t n, const ah_array_view* predicates, ah_filter_predicate** outs,
-                                     uint64_t* pin_dev, uint64_t* seq) {
+                                     uint64_t* pin_dev, uint64_t* seq, uint64_t* quant_dev) {
   if (n < 1 || n > 64) return AH_NOT_YET_IMPLEMENTED;
   for (int i = 0; i < n; ++i) {
     outs[i] = nullptr;
@@ -1175,6 +1184,11 @@ ah_status ah_filter_predicates_begin(ah_context* ctx, int32_t n, const ah_array_
     CountMulti::One& o = cm.p[ncm++];
     o.mask = p->mask, o.mask_valid = p->mask_valid, o.len = p->len, o.chunk_prefix = p->chunk_prefix;
     o.group_total = (uint32_t*)(base + b_chunk), o.group_prefix = p->group_prefix, o.total = p->total_dev, o.ngroups = ngroups;
+    if (quant_dev) {
+      p->quant_step = ah_ceil_div(ngroups, (int64_t)AH_FILTER_QUANTS);
+      p->quant_n = (int)ah_ceil_div(ngroups, p->quant_step);
+      o.quant_pin = quant_dev + (size_t)i * AH_FILTER_QUANTS, o.quant_step = p->quant_step;
+    }
     cm_groups = std::max(cm_groups, ngroups);
     if (ncm == 8) flush_multi();
   }
@@ -1193,12 +1207,19 @@ ah_status ah_filter_predicates_begin(ah_context* ctx, int32_t n, const ah_array_
   }
   return st;
 }
-ah_status ah_filter_predicates_end(ah_context* ctx, int32_t n, ah_filter_predicate** outs, const uint64_t* pin_host, uint64_t seq) {
+ah_status ah_filter_predicates_end(ah_context* ctx, int32_t n, ah_filter_predicate** outs, const uint64_t* pin_host, uint64_t seq,
+                                   const uint64_t* quant_host) {
   const bool later_work = seq != ctx->mail_seq || ctx->inflight;  // enqueued behind the post: still running afterwards
   hipError_t e = ah_mail_wait(ctx, seq);
   if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "filter count failed: %s", hipGetErrorString(e));
   if (later_work && ctx->wait_mode != 1) ctx->inflight = true;  // ah_mail_wait cleared it for the work BEFORE the post only
-  for (int i = 0; i < n; ++i) outs[i]->count = (int64_t)__atomic_load_n(&pin_host[i], __ATOMIC_RELAXED);
+  for (int i = 0; i < n; ++i) {
+    ah_filter_predicate* p = outs[i];
+    p->count = (int64_t)__atomic_load_n(&pin_host[i], __ATOMIC_RELAXED);
+    if (!quant_host) p->quant_n = 0;
+    for (int k = 0; k < p->quant_n; ++k) p->quant[k] = __atomic_load_n(&quant_host[(size_t)i * AH_FILTER_QUANTS + k], __ATOMIC_RELAXED);
+    p->quant[p->quant_n] = (uint64_t)p->count;
+  }
   return AH_OK;
 }
 
@@ -1623,6 +1644,27 @@ ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predica
 // Up to 8 (batch, window) segments through ONE launch, all appending to the same in-progress columns (the grouped
 // push of BatchCoalescer).  Preconditions (the caller checks them like ah_filter_apply_into_acc_cols does): every
 // column of every batch has the same width and carries validity; dst_validity 8-byte aligned.
+// Tiles [*t_lo, *t_hi) of predicate p that can hold positions [lo, hi) of its filtered stream (hi == 0: to the end), from
+// the predicate's quantile prefixes; everything when it has none.  A batch cut by an output-batch boundary is two
+// segments: without the bound each walks all of the batch's tiles and exits early from the ones outside its window —
+// 8192 workgroups per cut that only cost dispatch (~25 us per cut, 0.35 ms per 1e9 rows at four batches per output batch).
+static void window_tiles(const ah_filter_predicate* p, int64_t lo, int64_t hi, int T, int64_t* t_lo, int64_t* t_hi) {
+  static const char* off = getenv("AH_FILTER_WINDOW_TILES");  // "0": walk every tile (A/B runs)
+  if (p->quant_n <= 0 || (off && off[0] == '0')) return;
+  if (hi == 0 || hi > p->count) hi = p->count;
+  if (hi <= lo) {  // nothing to append
+    *t_hi = *t_lo;
+    return;
+  }
+  int a = 0, b = p->quant_n - 1;
+  while (a + 1 < p->quant_n && (int64_t)p->quant[a + 1] <= lo) ++a;  // position lo lies in quantile a
+  while (b > a && (int64_t)p->quant[b] >= hi) --b;                    // position hi - 1 lies in quantile b
+  const int64_t rows_per_q = (p->quant_step << p->group_shift) * AH_FILTER_CHUNK_ROWS;  // (a multiple of every tile size)
+  const int64_t ntiles = *t_hi;
+  *t_lo = std::min<int64_t>(ntiles, (int64_t)a * rows_per_q / T);
+  *t_hi = std::min<int64_t>(ntiles, ((int64_t)b + 1) * rows_per_q / T);
+}
+
 ah_status ah_filter_apply_multi(ah_context* ctx, int nsegs, const ah_filter_predicate* const* preds,
                                 const ah_array_view* const* columns, const int64_t* win_lo, const int64_t* win_hi,
                                 const int64_t* out_base, int ncols, void* const* dst_values, uint8_t* const* dst_validity,
@@ -1653,7 +1695,10 @@ ah_status ah_filter_apply_multi(ah_context* ctx, int nsegs, const ah_filter_pred
     sg.win_lo = win_lo[i];
     sg.win_hi = win_hi[i];
     sg.tile0 = tiles;
-    tiles += ah_ceil_div(p->len, T);
+    int64_t t_lo = 0, t_hi = ah_ceil_div(p->len, T);
+    window_tiles(p, win_lo[i], win_hi[i], T, &t_lo, &t_hi);
+    sg.tile_lo = t_lo;
+    tiles += t_hi - t_lo;
     rows += p->len;
     selected += p->count;
     for (int c = 0; c < ncols; ++c) {

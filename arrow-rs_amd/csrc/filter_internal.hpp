@@ -5,6 +5,7 @@
 #ifdef __HIPCC__
 // FilterPredicate (filter.rs:442-449): predicate bits (borrowed, or owned when built from an expression), count and
 // the device-resident prefix tables that replace IterationStrategy::Indices.
+constexpr int AH_FILTER_QUANTS = 32;
 struct ah_filter_predicate {
   BitView mask, mask_valid;
   int64_t len = 0;
@@ -14,6 +15,13 @@ struct ah_filter_predicate {
   int group_shift = 10;
   void* block = nullptr;  // single pool allocation backing the tables (and the mask of an expression predicate)
   unsigned long long* total_dev = nullptr;  // K on the device (kernels that run before the host has read it)
+  // Coarse host-side view of WHERE the selected rows are (predicates counted through ah_filter_predicates_begin with a
+  // quantile area): quant[k] = selected rows in count groups [0, k * quant_step), k = 0 .. quant_n, quant[quant_n] = count.
+  // A caller that appends only positions [lo, hi) of the filtered stream (BatchCoalescer: a batch cut by an output-batch
+  // boundary) bounds the tiles worth launching with it instead of walking — and early-exiting from — every tile.
+  int quant_n = 0;  // 0: not recorded
+  int64_t quant_step = 0;
+  uint64_t quant[AH_FILTER_QUANTS + 1] = {};
 };
 
 constexpr int AH_FILTER_CHUNK_ROWS = 1024;

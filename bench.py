@@ -788,7 +788,8 @@ def build_workload(env, wl):
         pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
         br = min(args.batch_rows, n)
         nb = n // br
-        target = max(1, int(br * args.selectivity * 4))
+        # (AH_COALESCE_TARGET_BATCHES: output batch size in pushed batches' worth of selected rows; experiments only)
+        target = max(1, int(br * args.selectivity * float(os.environ.get("AH_COALESCE_TARGET_BATCHES", "4"))))
         batches = [(A.RecordBatch(["a", "b"], [col.slice(i * br, br), col2.slice(i * br, br)]), pred.slice(i * br, br))
                    for i in range(nb)]
 

@@ -1260,6 +1260,67 @@ def test_batch_coalescer_pipelined_pushes_equal_the_model(ctx, oracle, schema):
         assert co.is_empty()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_batch_coalescer_cut_batches_walk_only_their_tiles(ctx, oracle, seed):
+    """A pushed batch that an output-batch boundary cuts is appended by one scatter segment per output batch; each segment
+    launches only the tiles its window of the filtered stream can lie in, bounded on the host from the predicate's quantile
+    prefixes (csrc/filter.hip window_tiles; recorded by the pipelined pushes).  Batches of 0.2-2.5 M rows (4 ... 39 count
+    groups, so the bounds really cut), targets that cut every batch several times, and selections that are uniform, empty
+    at one end, or packed into a narrow band — a bound one tile short loses rows, and the coalesce.rs model notices."""
+    from coalesce_model import ModelCoalescer
+    rng = np.random.default_rng(9100 + seed)
+    dts = [[A.Int64, A.Float64], [A.Int32, A.Float32, A.UInt32], [A.Int64], [A.Int16, A.Int16]][seed]
+    names = [f"c{i}" for i in range(len(dts))]
+    target = [70_001, 333_333, 20_000, 150_000][seed]
+    co = K.BatchCoalescer.new(names, dts, target, ctx)
+    model = ModelCoalescer(oracle, dts, target)
+
+    def predicate(n):
+        shape = int(rng.integers(0, 5))
+        m = np.zeros(n, dtype=bool)
+        if shape == 0:
+            m = rng.random(n) < float(rng.choice([0.05, 0.3, 0.8]))
+        elif shape == 1:  # nothing selected in the first part
+            cut = int(rng.integers(0, n))
+            m[cut:] = rng.random(n - cut) < 0.5
+        elif shape == 2:  # nothing selected in the last part
+            cut = int(rng.integers(1, n + 1))
+            m[:cut] = rng.random(cut) < 0.5
+        elif shape == 3:  # a narrow dense band
+            a = int(rng.integers(0, n))
+            m[a:min(n, a + int(rng.integers(1, 200_000)))] = True
+        else:  # bands at count-group boundaries (65 536 rows)
+            for g in rng.integers(0, max(1, n // 65536), size=3):
+                lo = int(g) * 65536
+                m[max(0, lo - 3):min(n, lo + 5)] = True
+        return m
+
+    groups, hosts = [], []
+    for _ in range(4):
+        g, hg = [], []
+        for _ in range(int(rng.integers(1, 5))):
+            n = int(rng.integers(200_000, 2_500_000))
+            cols = [HostArray(dt, _rand_values(rng, dt, n), rng.random(n) < 0.85) for dt in dts]
+            f = HostArray(A.Boolean, predicate(n), (rng.random(n) < 0.95) if rng.random() < 0.3 else None)
+            g.append((A.RecordBatch(names, [c.to_device(ctx) for c in cols]), f.to_device(ctx)))
+            hg.append((cols, f))
+        groups.append(g)
+        hosts.append(hg)
+    pending, pending_host = co.push_batches_with_filters_begin(groups[0]), hosts[0]
+    for gi in range(1, len(groups) + 1):
+        nxt = co.push_batches_with_filters_begin(groups[gi]) if gi < len(groups) else None
+        pending.end()
+        for cols, f in pending_host:
+            model.push_with_filter(cols, f)
+        assert co.get_buffered_rows() == model.buffered, f"seed {seed} group {gi - 1}"
+        _check_batches(co, model, f"cut batches seed {seed} group {gi - 1}")
+        pending, pending_host = nxt, (hosts[gi] if gi < len(groups) else None)
+    co.finish_buffered_batch()
+    model.finish()
+    _check_batches(co, model, f"cut batches seed {seed} final")
+    assert co.is_empty()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_batch_coalescer_grouped_pushes_one_launch_per_window(ctx, oracle, seed):
     """Same-width, all-nullable columns and no bypass limit: the grouped push scatters the batches that land in one
