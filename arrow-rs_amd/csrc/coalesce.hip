@@ -771,10 +771,26 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_
   // batches pay the ramp and tail of a launch once per window instead of once per batch.  Same output batches, same order.
   const bool fusable = group_fusable(co, n, columns, filters);
   ah_status st = AH_OK;
-  for (int base = 0; base < n && st == AH_OK; base += 128) {
-    const int m = std::min(128, n - base);
+  for (int base = 0; base < n && st == AH_OK; base += 64) {
+    const int m = std::min(64, n - base);
     std::vector<ah_filter_predicate*> preds((size_t)m, nullptr);
-    st = ah_filter_predicates_build(ctx, m, filters + base, preds.data());
+    // the counts through the coalescer's own pinned words when a slot is free (no pipelined push in flight there): the same
+    // one wait, and the predicates come back with their quantile prefixes, so cut batches launch only the tiles they need
+    const int slot = fusable ? (!co->cnt_busy[0] ? 0 : (!co->cnt_busy[1] ? 1 : -1)) : -1;
+    st = AH_NOT_YET_IMPLEMENTED;
+    if (slot >= 0) {
+      uint64_t seq = 0;
+      st = ah_filter_predicates_begin(ctx, m, filters + base, preds.data(), co->cnt_pin_dev + 64 * slot, &seq,
+                                      co->quant_pin_dev + (size_t)64 * 32 * slot);
+      if (st == AH_OK) {
+        st = ah_filter_predicates_end(ctx, m, preds.data(), co->cnt_pin + 64 * slot, seq, co->quant_pin + (size_t)64 * 32 * slot);
+        if (st != AH_OK) {
+          (void)ah_stream_wait(ctx);  // the count kernels may still be writing the blocks freed below
+          for (auto*& p : preds) ah_filter_predicate_free(ctx, p), p = nullptr;
+        }
+      }
+    }
+    if (st == AH_NOT_YET_IMPLEMENTED) st = ah_filter_predicates_build(ctx, m, filters + base, preds.data());  // (any shape)
     if (st == AH_OK)
       st = append_group(ctx, co, m, columns + (size_t)base * co->ncols, num_rows + base, filters + base, tags ? tags + base : nullptr,
                         bypassed ? bypassed + base : nullptr, preds.data(), fusable);

@@ -1260,8 +1260,9 @@ def test_batch_coalescer_pipelined_pushes_equal_the_model(ctx, oracle, schema):
         assert co.is_empty()
 
 
+@pytest.mark.parametrize("form", ["pipelined", "one_call"])
 @pytest.mark.parametrize("seed", range(4))
-def test_batch_coalescer_cut_batches_walk_only_their_tiles(ctx, oracle, seed):
+def test_batch_coalescer_cut_batches_walk_only_their_tiles(ctx, oracle, seed, form):
     """A pushed batch that an output-batch boundary cuts is appended by one scatter segment per output batch; each segment
     launches only the tiles its window of the filtered stream can lie in, bounded on the host from the predicate's quantile
     prefixes (csrc/filter.hip window_tiles; recorded by the pipelined pushes).  Batches of 0.2-2.5 M rows (4 ... 39 count
@@ -1306,15 +1307,23 @@ def test_batch_coalescer_cut_batches_walk_only_their_tiles(ctx, oracle, seed):
             hg.append((cols, f))
         groups.append(g)
         hosts.append(hg)
-    pending, pending_host = co.push_batches_with_filters_begin(groups[0]), hosts[0]
-    for gi in range(1, len(groups) + 1):
-        nxt = co.push_batches_with_filters_begin(groups[gi]) if gi < len(groups) else None
-        pending.end()
-        for cols, f in pending_host:
-            model.push_with_filter(cols, f)
-        assert co.get_buffered_rows() == model.buffered, f"seed {seed} group {gi - 1}"
-        _check_batches(co, model, f"cut batches seed {seed} group {gi - 1}")
-        pending, pending_host = nxt, (hosts[gi] if gi < len(groups) else None)
+    if form == "one_call":  # ah_coalescer_push_batches_with_filters: the counts through the coalescer's own words as well
+        for gi, g in enumerate(groups):
+            co.push_batches_with_filters(g)
+            for cols, f in hosts[gi]:
+                model.push_with_filter(cols, f)
+            assert co.get_buffered_rows() == model.buffered, f"seed {seed} group {gi}"
+            _check_batches(co, model, f"cut batches (one call) seed {seed} group {gi}")
+    else:
+        pending, pending_host = co.push_batches_with_filters_begin(groups[0]), hosts[0]
+        for gi in range(1, len(groups) + 1):
+            nxt = co.push_batches_with_filters_begin(groups[gi]) if gi < len(groups) else None
+            pending.end()
+            for cols, f in pending_host:
+                model.push_with_filter(cols, f)
+            assert co.get_buffered_rows() == model.buffered, f"seed {seed} group {gi - 1}"
+            _check_batches(co, model, f"cut batches seed {seed} group {gi - 1}")
+            pending, pending_host = nxt, (hosts[gi] if gi < len(groups) else None)
     co.finish_buffered_batch()
     model.finish()
     _check_batches(co, model, f"cut batches seed {seed} final")
