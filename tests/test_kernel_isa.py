@@ -1,0 +1,67 @@
+"""ISA-level regression guards (no GPU: hipcc cross-compiles gfx950 here).  Round 4 found three kernels whose SOURCE looked
+fine and whose machine code was not (profiles/r04_isa_pass.md): a bounds test that the compiler turned into one load in
+flight per wave, and bit-interleaves that ran on the CU's single scalar unit until it was the bottleneck.  These tests pin
+the properties the fixes established, with generous margins — they are about the SHAPE of the code, not instruction counts
+to the unit.  Method: tools/isa_scan.py (the same scan the profile note describes)."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_scan  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.exists(isa_scan.HIPCC) or shutil.which("c++filt") is None, reason="needs hipcc and c++filt")
+
+
+def _kernels(tmp_path_factory, name):
+    out = tmp_path_factory.mktemp("isa")
+    ks = isa_scan.kernels(isa_scan.assemble(os.path.join(ROOT, "arrow-rs_amd", "csrc", name), str(out)))
+    names = list(ks)
+    return {pretty: ks[m] for m, pretty in zip(names, isa_scan.demangle(names))}
+
+
+@pytest.fixture(scope="module")
+def expr_kernels(tmp_path_factory):
+    return _kernels(tmp_path_factory, "filter_expr.hip")
+
+
+@pytest.fixture(scope="module")
+def cmp_kernels(tmp_path_factory):
+    return _kernels(tmp_path_factory, "cmp.hip")
+
+
+def _one(kernels, part):
+    hits = [(n, l) for n, l in kernels.items() if part in n]
+    assert len(hits) == 1, [n for n, _ in hits]
+    return hits[0][1]
+
+
+def test_lazy_predicate_count_pass_keeps_its_loads_in_flight(expr_kernels):
+    lines = _one(expr_kernels, "filter_expr_count_kernel<2, 8, true>")
+    # the eight 16-byte operand loads of four wave steps go out back to back: no wait on the vector memory counter between them
+    run = best = 0
+    for l in lines:
+        if l.startswith("global_load_dwordx4"):
+            run += 1
+            best = max(best, run)
+        elif l.startswith("s_waitcnt") and "vmcnt" in l:
+            run = 0
+    assert best >= 8, f"operand loads are separated by waits (longest run {best})"
+    s = isa_scan.stats(lines)
+    # the interleave of the ballots lives on the vector unit (once per chunk): the scalar unit is shared by four SIMDs.
+    # 1 283 scalar instructions before the round-4 rewrite, ~670 after
+    assert s["salu"] <= 900, s
+    assert s["instructions"] <= 2600, s  # (3 587 before: the whole fast instantiation fits the instruction cache comfortably)
+
+
+@pytest.mark.parametrize("inst", ["compare_kernel<double, 2>", "compare_kernel<long, 2>", "compare_kernel<float, 4>"])
+def test_compare_builds_its_output_words_on_the_vector_unit(cmp_kernels, inst):
+    lines = _one(cmp_kernels, inst)
+    s = isa_scan.stats(lines)
+    # ballots staged in LDS, lanes 0 .. 4V - 1 interleave them: ds traffic present, scalar count far below the per-group
+    # scalar spreads of rounds 1-3 (532 / 564 for the 8-byte kernels, ~1 300 for the 4-byte ones)
+    assert s["lds"] >= 2, s
+    assert s["salu"] <= (450 if "4>" in inst else 350), s
