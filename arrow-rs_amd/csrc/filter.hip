@@ -37,6 +37,7 @@
 // Values are read at most once; the mask twice (1.4% of the bytes at Int64).
 #include "common.hpp"
 #include "filter_internal.hpp"
+#include "window_tiles.hpp"
 
 namespace {
 
@@ -1641,30 +1642,21 @@ ah_status ah_filter_apply_into_acc_cols(ah_context* ctx, const ah_filter_predica
   return AH_OK;
 }
 
-// Up to 8 (batch, window) segments through ONE launch, all appending to the same in-progress columns (the grouped
-// push of BatchCoalescer).  Preconditions (the caller checks them like ah_filter_apply_into_acc_cols does): every
-// column of every batch has the same width and carries validity; dst_validity 8-byte aligned.
 // Tiles [*t_lo, *t_hi) of predicate p that can hold positions [lo, hi) of its filtered stream (hi == 0: to the end), from
-// the predicate's quantile prefixes; everything when it has none.  A batch cut by an output-batch boundary is two
-// segments: without the bound each walks all of the batch's tiles and exits early from the ones outside its window —
-// 8192 workgroups per cut that only cost dispatch (~25 us per cut, 0.35 ms per 1e9 rows at four batches per output batch).
+// the predicate's quantile prefixes; everything when it has none (window_tiles.hpp).  A batch cut by an output-batch
+// boundary is two segments: without the bound each walks all of the batch's tiles and exits early from the ones outside
+// its window — 8192 workgroups per cut that only cost dispatch (~25 us per cut, 0.35 ms per 1e9 rows at four batches per
+// output batch).
 static void window_tiles(const ah_filter_predicate* p, int64_t lo, int64_t hi, int T, int64_t* t_lo, int64_t* t_hi) {
   static const char* off = getenv("AH_FILTER_WINDOW_TILES");  // "0": walk every tile (A/B runs)
   if (p->quant_n <= 0 || (off && off[0] == '0')) return;
-  if (hi == 0 || hi > p->count) hi = p->count;
-  if (hi <= lo) {  // nothing to append
-    *t_hi = *t_lo;
-    return;
-  }
-  int a = 0, b = p->quant_n - 1;
-  while (a + 1 < p->quant_n && (int64_t)p->quant[a + 1] <= lo) ++a;  // position lo lies in quantile a
-  while (b > a && (int64_t)p->quant[b] >= hi) --b;                    // position hi - 1 lies in quantile b
-  const int64_t rows_per_q = (p->quant_step << p->group_shift) * AH_FILTER_CHUNK_ROWS;  // (a multiple of every tile size)
-  const int64_t ntiles = *t_hi;
-  *t_lo = std::min<int64_t>(ntiles, (int64_t)a * rows_per_q / T);
-  *t_hi = std::min<int64_t>(ntiles, ((int64_t)b + 1) * rows_per_q / T);
+  const int64_t rows_per_group = ((int64_t)1 << p->group_shift) * AH_FILTER_CHUNK_ROWS;  // (a multiple of every tile size)
+  ah_window_tiles(p->quant_n, p->quant_step, p->quant, p->count, rows_per_group, lo, hi, T, *t_hi, t_lo, t_hi);
 }
 
+// Up to 8 (batch, window) segments through ONE launch, all appending to the same in-progress columns (the grouped
+// push of BatchCoalescer).  Preconditions (the caller checks them like ah_filter_apply_into_acc_cols does): every
+// column of every batch has the same width and carries validity; dst_validity 8-byte aligned.
 ah_status ah_filter_apply_multi(ah_context* ctx, int nsegs, const ah_filter_predicate* const* preds,
                                 const ah_array_view* const* columns, const int64_t* win_lo, const int64_t* win_hi,
                                 const int64_t* out_base, int ncols, void* const* dst_values, uint8_t* const* dst_validity,

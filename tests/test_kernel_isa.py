@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import isa_scan  # noqa: E402
 
-pytestmark = pytest.mark.skipif(not os.path.exists(isa_scan.HIPCC) or shutil.which("c++filt") is None, reason="needs hipcc and c++filt")
+needs_hipcc = pytest.mark.skipif(not os.path.exists(isa_scan.HIPCC) or shutil.which("c++filt") is None, reason="needs hipcc and c++filt")
 
 
 def _kernels(tmp_path_factory, name):
@@ -39,6 +39,7 @@ def _one(kernels, part):
     return hits[0][1]
 
 
+@needs_hipcc
 def test_lazy_predicate_count_pass_keeps_its_loads_in_flight(expr_kernels):
     lines = _one(expr_kernels, "filter_expr_count_kernel<2, 8, true>")
     # the eight 16-byte operand loads of four wave steps go out back to back: no wait on the vector memory counter between them
@@ -57,6 +58,7 @@ def test_lazy_predicate_count_pass_keeps_its_loads_in_flight(expr_kernels):
     assert s["instructions"] <= 2600, s  # (3 587 before: the whole fast instantiation fits the instruction cache comfortably)
 
 
+@needs_hipcc
 @pytest.mark.parametrize("inst", ["compare_kernel<double, 2>", "compare_kernel<long, 2>", "compare_kernel<float, 4>"])
 def test_compare_builds_its_output_words_on_the_vector_unit(cmp_kernels, inst):
     lines = _one(cmp_kernels, inst)
@@ -65,3 +67,18 @@ def test_compare_builds_its_output_words_on_the_vector_unit(cmp_kernels, inst):
     # scalar spreads of rounds 1-3 (532 / 564 for the 8-byte kernels, ~1 300 for the 4-byte ones)
     assert s["lds"] >= 2, s
     assert s["salu"] <= (450 if "4>" in inst else 350), s
+
+
+def test_window_tile_bound_is_a_superset_on_the_host(tmp_path):
+    """csrc/window_tiles.hpp (the host-side bound that lets a cut batch of BatchCoalescer launch only the tiles its window of
+    the filtered stream can lie in) against brute force: a bound one tile short would lose rows silently on the GPU.
+    tests/cpp/window_tiles_host_test.cpp: 20 000 random selections x 24 windows each, all three tile sizes."""
+    import subprocess
+    exe = str(tmp_path / "window_tiles_host_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "window_tiles_host_test.cpp")],
+                   check=True)
+    for seed in ("1", "2"):
+        r = subprocess.run([exe, "20000", seed], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "WINDOW_TILES_OK" in r.stdout, r.stdout + r.stderr
+        checked, tight = [int(x) for x in r.stdout.split() if x.isdigit()][:2]
+        assert checked == 480000 and tight > checked // 2, r.stdout  # (the bound really cuts in most cases)
