@@ -1176,6 +1176,8 @@ def probe_child_main(argv):
     run) takes this child down, not the benchmark — the parent then switches transports or reports shard-local numbers.
     Exit 0 + 'PROBE_OK' = the concatenation arrived with the right row count on this rank."""
     transport = argv[0] if argv else "capi"
+    if os.environ.get("AH_BENCH_PROBE_TEST_SLEEP"):  # test hook (tests/test_bench_probe_cpu.py): a child that never answers
+        time.sleep(float(os.environ["AH_BENCH_PROBE_TEST_SLEEP"]))
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local_rank = 0 if os.environ.get("AH_BENCH_SHARED_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("AH_BENCH_BACKEND", "nccl")
