@@ -36,10 +36,13 @@ def demangle(names):
 
 
 def kernels(asm_path):
-    """-> {mangled name: [instruction lines]} for every function that ends in s_endpgm"""
+    """-> {mangled name: [instruction lines]} for every kernel (a function whose body contains s_endpgm); the body runs to the
+    function's end label, not to the first s_endpgm (early exits end the program too)"""
     txt = open(asm_path).read()
     out = {}
-    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)s_endpgm", txt, re.S | re.M):
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", txt, re.S | re.M):
+        if "s_endpgm" not in m.group(2):
+            continue
         out[m.group(1)] = [l.strip() for l in m.group(2).splitlines() if l.strip() and not l.strip().startswith((";", "."))]
     return out
 
