@@ -1,5 +1,7 @@
 """Worker of tests/test_bench_probe_cpu.py: one rank of a gloo group that runs bench.probe_transport (the orchestration around
-the per-transport probe child of `bench.py --gpus N`) and prints its verdict as one JSON line."""
+the per-transport probe child of `bench.py --gpus N`) and writes its verdict as JSON into its OWN file
+`$PROBE_VERDICT_DIR/rank<r>.json` (written whole, then renamed into place).  Two ranks printing onto the launcher's one
+stdout pipe interleaved their lines about every other run — a verdict per file cannot.  """
 import json
 import os
 import sys
@@ -16,7 +18,10 @@ def main():
     import bench
     t0 = time.time()
     ok, why = bench.probe_transport(dist, rank, world, sys.argv[1] if len(sys.argv) > 1 else "capi")
-    print("PROBE_VERDICT " + json.dumps({"rank": rank, "ok": ok, "why": why, "seconds": round(time.time() - t0, 1)}), flush=True)
+    out = os.path.join(os.environ["PROBE_VERDICT_DIR"], f"rank{rank}.json")
+    with open(out + ".tmp", "w") as f:
+        json.dump({"rank": rank, "ok": ok, "why": why, "seconds": round(time.time() - t0, 1)}, f)
+    os.replace(out + ".tmp", out)
     dist.barrier()
     dist.destroy_process_group()
 

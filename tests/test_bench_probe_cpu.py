@@ -24,21 +24,22 @@ def _free_port():
     return port
 
 
-def _run(extra_env, timeout):
-    env = dict(os.environ, GLOO_SOCKET_IFNAME="lo", **extra_env)
+def _run(extra_env, timeout, tmp_path):
+    env = dict(os.environ, GLOO_SOCKET_IFNAME="lo", PROBE_VERDICT_DIR=str(tmp_path), **extra_env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "probe_worker.py"), "capi"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
-    verdicts = [json.loads(l.split(" ", 1)[1]) for l in r.stdout.splitlines() if l.startswith("PROBE_VERDICT ")]
+    # one file per rank: the ranks share the launcher's stdout pipe, and verdict lines printed there interleaved
+    verdicts = [json.load(open(os.path.join(tmp_path, f))) for f in sorted(os.listdir(tmp_path)) if f.endswith(".json")]
     assert r.returncode == 0 and len(verdicts) == 2, (r.stdout[-2000:], r.stderr[-3000:])
     return sorted(verdicts, key=lambda v: v["rank"])
 
 
 @pytest.mark.timeout(300)
-def test_probe_child_that_fails_is_reported_by_every_rank():
-    v = _run({"AH_BENCH_PROBE_TIMEOUT": "120"}, 280)
+def test_probe_child_that_fails_is_reported_by_every_rank(tmp_path):
+    v = _run({"AH_BENCH_PROBE_TIMEOUT": "120"}, 280, tmp_path)
     assert [x["ok"] for x in v] == [False, False]
     assert v[0]["why"] == v[1]["why"], v  # the ranks agree on ONE verdict (all-gathered, first failing rank's words)
     assert "probe exited" in v[0]["why"] or "without PROBE_OK" in v[0]["why"], v
@@ -47,8 +48,8 @@ def test_probe_child_that_fails_is_reported_by_every_rank():
 
 
 @pytest.mark.timeout(300)
-def test_probe_child_that_never_answers_is_killed_at_the_deadline():
-    v = _run({"AH_BENCH_PROBE_TIMEOUT": "4", "AH_BENCH_PROBE_TEST_SLEEP": "600"}, 280)
+def test_probe_child_that_never_answers_is_killed_at_the_deadline(tmp_path):
+    v = _run({"AH_BENCH_PROBE_TIMEOUT": "4", "AH_BENCH_PROBE_TEST_SLEEP": "600"}, 280, tmp_path)
     assert [x["ok"] for x in v] == [False, False]
     assert "hung" in v[0]["why"] and "4 s" in v[0]["why"], v
     assert max(x["seconds"] for x in v) < 60, v
