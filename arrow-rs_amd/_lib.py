@@ -245,6 +245,8 @@ SIGNATURES = {
     "ah_gen_uniform_i32": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_int64]),
     "ah_gen_uniform_f64": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_double, C.c_double, C.c_int64]),
     "ah_gen_uniform_u32": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_uint32, C.c_int64]),
+    "ah_gen_uniform_f32": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_float, C.c_float, C.c_int64]),
+    "ah_gen_uniform_small": (C.c_int32, [_P, _P, C.c_int32, C.c_int64, C.c_uint64, C.c_int64]),
     "ah_gen_iota_u32": (C.c_int32, [_P, _P, C.c_int64, C.c_uint32]),
     "ah_gen_bernoulli_bits": (C.c_int32, [_P, _P, C.c_int64, C.c_uint64, C.c_double, C.c_int64]),
     "ah_zero_null_slots": (C.c_int32, [_P, _P, C.c_int32, _P, C.c_int64]),

@@ -357,13 +357,16 @@ __device__ __forceinline__ unsigned long long wave_reduce_add64(unsigned long lo
   return v;
 }
 // inclusive scan across the 64 lanes of a wave
+// Six `v_add_u32_dpp` (row_shr 1 / 2 / 4 / 8 inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3; lanes without a source add 0).  The __shfl_up form this replaces compiled to six
+// ds_bpermute round trips with ~7 vector instructions each (42 + 6 LDS waits in every scatter tile's table build).
 __device__ __forceinline__ int wave_scan_incl(int v) {
-  unsigned lane = __lane_id();
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(v, o, 64);
-    if (lane >= (unsigned)o) v += t;
-  }
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
   return v;
 }
 

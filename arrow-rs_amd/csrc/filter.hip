@@ -381,25 +381,38 @@ constexpr int VALID_SLOTS = 64;
 // is slower (measured r02: 1.48 ms -> 1.85 ms at w = 6, 3.28 ms at w = 8): the registers ARE the tile.
 // One tile of one column: the body shared by the single-batch kernel and the multi-batch kernel (BatchCoalescer's
 // grouped push: several input batches scattered into one output window by ONE launch).
-template <int W, int V, bool HAS_VALID, bool SKIP>
+// S: 4096-row sub-tiles per workgroup (plain single-batch launches of 1-, 2- and 4-byte columns only).  A 4096-row tile of
+// Int8 is 4 KiB of values: eight resident workgroups per CU keep 32 KiB in flight per CU, a quarter of what the latency x
+// bandwidth product needs, and every tile pays the same word-table / barrier / prefix-lookup chain as a 32 KiB Int64 tile
+// (round 5: filter Int8 ran at 0.31 of peak, Int16 at 0.47, Int64 at 0.86).  With S sub-tiles the workgroup owns S * 4096
+// rows: waves 0..S-1 each build one sub-tile's 64-word table, `woff` carries the sub-tile bases.
+template <int W, int V, bool HAS_VALID, bool SKIP, int S = 1>
 __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile, const void* c_values, BitView c_vvalid,
                                              void* c_out_values, unsigned long long* c_out_valid,
                                              unsigned long long* c_valid_slots) {
   constexpr int WE = W == 0 ? 1 : W;
-  constexpr int T = tile_rows(WE);
+  constexpr int T = tile_rows(WE) * S;
   constexpr int CAP = stage_cap(WE);
   constexpr int RPT = T / SCATTER_THREADS;
   constexpr int L = RPT / V;
-  constexpr int NW = T / 64;  // mask words per tile (<= 64)
+  constexpr int NW = T / 64;  // mask words per tile (<= 64 per sub-tile)
+  static_assert(S >= 1 && S <= 4 && (S == 1 || tile_rows(WE) == 4096), "sub-tiles are 4096 rows, one table-building wave each");
   constexpr uint32_t VMASK = (V >= 32) ? 0xFFFFFFFFu : ((1u << V) - 1u);
   using ET = typename Elem<WE>::type;
 
   __shared__ uint64_t s_m[NW];
   __shared__ uint64_t s_v[HAS_VALID ? NW : 1];
   __shared__ uint32_t s_base[NW];
-  __shared__ uint32_t s_total;
+  __shared__ uint32_t s_wsum[S];  // selected rows per sub-tile
   __shared__ uint32_t s_vc[4];
   constexpr int EPV = (W == 0 || W >= 16) ? 1 : 16 / W;  // elements per 16-byte store
+  // STAGED (1- and 2-byte values, S > 1): the tile's values are parked in LDS as loaded (16-byte writes) and the compaction
+  // walks the SET BITS of each thread's 32 / 64 mask bits, reading the selected values back by row.  The per-row form
+  // below visits every row in a lane slot (~14 vector instructions per row whether or not it is selected, because some
+  // lane of the wave selects element e of its vector for every e): at 16 rows per 16-byte load that made filter Int8
+  // VALU-bound at 0.31 of the HBM peak.  Here a wave's trip count is the largest popcount among its lanes.
+  constexpr bool STAGED = (W == 1 || W == 2) && S > 1;
+  __shared__ __attribute__((aligned(16))) ET s_raw[STAGED ? T : 1];
   __shared__ __attribute__((aligned(16))) ET s_vals[W == 0 ? 1 : CAP + EPV];
   __shared__ uint8_t s_flag[HAS_VALID ? CAP : 1];
 
@@ -407,8 +420,22 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
   const int64_t row0 = tile * T;
 
   // 1. value loads (16 B per lane per load on the aligned path) go out first
-  Vec<WE, V> regs[L];
-  if constexpr (W != 0 && !SKIP) {
+  Vec<WE, V> regs[STAGED ? 1 : L];
+  E16 raw[STAGED ? L : 1];  // STAGED: the 16 bytes as ONE value (as a Vec of 16 bytes the compiler unpacked every load into 16
+                            // byte registers behind a vmcnt(0) and re-packed them for the LDS write: ~25 instructions per load)
+  if constexpr (STAGED) {
+    static_assert(!SKIP && V * WE == 16, "the staged form loads whole 16-byte vectors unconditionally");
+    const ET* vp = (const ET*)c_values;
+    // every load is issued, unconditionally: vectors past the end of the column re-read its last vector (their mask bits
+    // are 0).  A load under `if (r < len)` into an array element cost a branch, a vmcnt(0) and a register shuffle per load.
+    const int64_t last_vec = ((a.len - 1) / V) * V;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      int64_t r = row0 + (int64_t)(l * SCATTER_THREADS + t) * V;
+      r = r < last_vec ? r : last_vec;
+      raw[l] = ah_ld_stream<ah_nt_l(false)>((const E16*)(vp + r));
+    }
+  } else if constexpr (W != 0 && !SKIP) {
     const ET* vp = (const ET*)c_values;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -417,14 +444,30 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
     }
   }
 
-  // 2. wave 0 builds the word table: mask, validity, exclusive popcount prefix
-  if (wave == 0) {
+  // 2. wave w < S builds sub-tile w's word table: mask, validity, exclusive popcount prefix
+  if (wave < S) {
     uint64_t m = 0, v = 0;
-    const int64_t s = row0 + ((int64_t)lane << 6);
-    if (lane < NW && s < a.len) {
+    const int wi = wave * 64 + lane;
+    const int64_t s = row0 + ((int64_t)wi << 6);
+    const bool has_mv = a.mask_valid.words != nullptr;
+    const bool has_vv = HAS_VALID && c_vvalid.words != nullptr;
+    // A tile wholly inside the predicate whose bitmaps all start on a word boundary (every unsliced array) reads its words
+    // directly — tile-uniform test, three independent 8-byte loads, no funnel shifts or length masks (~60 of the ~110
+    // vector instructions of a table build; round 5)
+    const bool word_aligned = row0 + T <= a.len &&
+                              ((a.mask.off | (has_mv ? a.mask_valid.off : 0) | (has_vv ? c_vvalid.off : 0)) & 63) == 0;
+    if (word_aligned) {
+      if (wi < NW) {
+        const int64_t wq = s >> 6;
+        const uint64_t* pm = a.mask.words + (a.mask.off >> 6);
+        const uint64_t* pmv = has_mv ? a.mask_valid.words + (a.mask_valid.off >> 6) : pm;  // (absent: the mask's word again, ignored)
+        const uint64_t* pvv = has_vv ? c_vvalid.words + (c_vvalid.off >> 6) : pm;
+        const uint64_t xm = pm[wq], xmv = pmv[wq], xvv = pvv[wq];
+        m = has_mv ? (xm & xmv) : xm;
+        if constexpr (HAS_VALID) v = has_vv ? xvv : ~0ull;
+      }
+    } else if (wi < NW && s < a.len) {
       // all three bitmaps' words are requested before the first one is used: one memory round trip, not three
-      const bool has_mv = a.mask_valid.words != nullptr;
-      const bool has_vv = HAS_VALID && c_vvalid.words != nullptr;
       // (an absent bitmap re-reads the mask's words — same lines, no branch between the loads — and is ignored)
       const BvRaw rm = bv_issue(a.mask, s, a.len);
       const BvRaw rmv = bv_issue(has_mv ? a.mask_valid : a.mask, s, a.len);
@@ -436,17 +479,30 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
     }
     int c = __popcll(m);
     int incl = wave_scan_incl(c);
-    if (lane < NW) {
-      s_m[lane] = m;
-      if constexpr (HAS_VALID) s_v[lane] = v;
-      s_base[lane] = (uint32_t)(incl - c);
+    if (wi < NW) {
+      s_m[wi] = m;
+      if constexpr (HAS_VALID) s_v[wi] = v;
+      s_base[wi] = (uint32_t)(incl - c);
     }
-    if (lane == 63) s_total = (uint32_t)incl;
+    if (lane == 63) s_wsum[wave] = (uint32_t)incl;
+  }
+  if constexpr (STAGED) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int r0 = (l * SCATTER_THREADS + t) * V;
+      *(E16*)(s_raw + r0) = raw[l];
+    }
   }
   __syncthreads();
 
-  const int total = (int)s_total;
+  uint32_t woff[S];  // selected rows of the tile before sub-tile s
+  woff[0] = 0;
+#pragma unroll
+  for (int q = 1; q < S; ++q) woff[q] = woff[q - 1] + s_wsum[q - 1];
+  const int total = (int)(woff[S - 1] + s_wsum[S - 1]);
   if (total == 0) return;
+  // (requesting these two words up front, with the values and the bitmap words, was measured in round 5: the Int64 scatter
+  // went from 1.31 to 1.35-1.37 ms per 1e9 rows on one box, the narrow forms did not move)
   const int64_t chunk0 = row0 / CHUNK_ROWS;
   const int64_t rel = (int64_t)a.group_prefix[chunk0 >> a.group_shift] + a.chunk_prefix[chunk0];  // tile's first output position
   int lo_t = 0, hi_t = total;  // the tile's positions inside the launch's window
@@ -474,6 +530,44 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
     const int phase = (int)((ob + p0) & (EPV - 1));
     const int cnt = (hi_t - p0) < CAP ? (hi_t - p0) : CAP;
     // 3. compact the selected rows whose output position falls in [p0, p0+CAP) into LDS
+    if constexpr (STAGED) {
+      const bool whole = lo_t == 0 && hi_t == total && total <= CAP;
+      constexpr int RS = T / SCATTER_THREADS;  // consecutive rows per thread: half a mask word or a whole one
+      static_assert(RS == 32 || RS == 64, "a thread walks the set bits of 32 or 64 mask bits");
+      const int r0 = t * RS, w = r0 >> 6, sh = r0 & 63;
+      const uint64_t word = s_m[w];
+      uint32_t wsel = woff[0];
+#pragma unroll
+      for (int q = 1; q < S; ++q) wsel = (r0 >> 12) == q ? woff[q] : wsel;
+      uint32_t pos = s_base[w] + wsel + (uint32_t)__popcll(word & ((1ull << sh) - 1ull)) - (uint32_t)p0;
+      uint64_t vword = 0;
+      if constexpr (HAS_VALID) vword = s_v[w];
+#pragma unroll
+      for (int h = 0; h < RS / 32; ++h) {  // 32 bits at a time: the walk's arithmetic stays 32-bit
+        uint32_t b = (uint32_t)(word >> (sh + 32 * h));
+        const uint32_t vb = (uint32_t)(vword >> (sh + 32 * h));
+        const ET* src = s_raw + r0 + 32 * h;
+        if (whole) {  // (tile-uniform) every selected row of the tile is staged by this one pass: no range test in the walk
+          while (b) {
+            const int e = __builtin_ctz(b);
+            b &= b - 1;
+            s_vals[pos + phase] = src[e];
+            if constexpr (HAS_VALID) s_flag[pos] = (uint8_t)((vb >> e) & 1u);
+            ++pos;
+          }
+        } else {
+          while (b) {
+            const int e = __builtin_ctz(b);
+            b &= b - 1;
+            if (pos < (uint32_t)cnt) {  // unsigned: also rejects positions before p0
+              s_vals[pos + phase] = src[e];
+              if constexpr (HAS_VALID) s_flag[pos] = (uint8_t)((vb >> e) & 1u);
+            }
+            ++pos;
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       int r0 = (l * SCATTER_THREADS + t) * V;
@@ -481,7 +575,8 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
       uint64_t word = s_m[w];
       uint32_t bits = (uint32_t)(word >> sh) & VMASK;
       if (bits) {
-        uint32_t base = s_base[w] + (uint32_t)__popcll(word & ((1ull << sh) - 1ull)) - (uint32_t)p0;
+        // (a thread's V rows of step l lie in sub-tile l * 256 * V / 4096: a compile-time index into woff)
+        uint32_t base = s_base[w] + woff[(l * SCATTER_THREADS * V) >> 12] + (uint32_t)__popcll(word & ((1ull << sh) - 1ull)) - (uint32_t)p0;
         uint32_t vb = 0;
         if constexpr (HAS_VALID) vb = (uint32_t)(s_v[w] >> sh);
 #pragma unroll
@@ -495,6 +590,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
           }
         }
       }
+    }
     }
     __syncthreads();
 
@@ -564,7 +660,7 @@ __device__ __forceinline__ int64_t scatter_tile_of_block(int xcd_remap, int64_t 
   return (tile >= ntiles || (int64_t)(blockIdx.x >> 3) >= per) ? -1 : tile;
 }
 
-template <int W, int V, bool HAS_VALID, bool SKIP>
+template <int W, int V, bool HAS_VALID, bool SKIP, int S = 1>
 __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(ScatterArgs a) {
   // this workgroup's column (uniform: scalar selects)
   const void* c_values = a.values;
@@ -582,8 +678,20 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_kernel(Scatter
   }
   const int64_t tile = scatter_tile_of_block(a.xcd_remap, a.ntiles);
   if (tile < 0) return;
-  scatter_tile<W, V, HAS_VALID, SKIP>(a, tile, c_values, c_vvalid, c_out_values, c_out_valid, c_valid_slots);
+  scatter_tile<W, V, HAS_VALID, SKIP, S>(a, tile, c_values, c_vvalid, c_out_values, c_out_valid, c_valid_slots);
 }
+
+// sub-tiles per workgroup of the plain tiled launch, by value width (scatter_tile): 16-32 KiB of values per workgroup
+#ifndef AH_SCATTER_S1
+#define AH_SCATTER_S1 4
+#endif
+#ifndef AH_SCATTER_S2
+#define AH_SCATTER_S2 2
+#endif
+#ifndef AH_SCATTER_S4
+#define AH_SCATTER_S4 1  // (2 measured: no gain at Int32, 1.607 vs 1.598 ms per 2e9 rows)
+#endif
+constexpr int scatter_sub_tiles(int w) { return w == 1 ? AH_SCATTER_S1 : w == 2 ? AH_SCATTER_S2 : w == 4 ? AH_SCATTER_S4 : 1; }
 
 // ---- sparse selections (at most two selected rows per predicate word on average: K * 32 <= len).  The tiled kernel above
 // is then bound by its own per-tile latency chain, not by bytes: 244 K tiles of a 1e9-row column, each a workgroup that
@@ -854,7 +962,10 @@ template <int W, bool HV>
 void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, bool skip, int ncols = 1, bool sparse = false,
                       int64_t out_rows = 0) {
   constexpr int WE = W == 0 ? 1 : W;
-  constexpr int T = tile_rows(WE);
+  constexpr int VV = (W == 0) ? 16 : (W >= 16 ? 1 : 16 / W);
+  constexpr int SS = W == 0 ? 1 : scatter_sub_tiles(W);
+  const int S = (aligned16 || VV == 1) ? SS : 1;  // (the element-wise form for unaligned buffers keeps the 4096-row tile)
+  const int T = tile_rows(WE) * S;
   int64_t ntiles = ah_ceil_div(a_in.len, T);
   ScatterArgs a = a_in;
   a.ntiles = ntiles;
@@ -892,12 +1003,14 @@ void launch_scatter_w(ah_context* ctx, const ScatterArgs& a_in, bool aligned16, 
     }
   }
   dim3 grid((unsigned)(a.xcd_remap ? 8 * ((ntiles + 7) / 8) : ntiles), (unsigned)ncols), block(SCATTER_THREADS);
-  constexpr int VV = (W == 0) ? 16 : (W >= 16 ? 1 : 16 / W);
   if constexpr (W == 0) {
     filter_scatter_kernel<W, VV, HV, false><<<grid, block, 0, ctx->stream>>>(b);
   } else if (aligned16 || VV == 1) {
-    if (skip) filter_scatter_kernel<W, VV, HV, true><<<grid, block, 0, ctx->stream>>>(b);
-    else filter_scatter_kernel<W, VV, HV, false><<<grid, block, 0, ctx->stream>>>(b);
+    // (1- and 2-byte values: a 128-byte line holds 128 / 64 rows, so no line goes unselected before the sparse kernel
+    // takes over at ~3 % — predicating the loads would only serialise them)
+    if constexpr (W <= 2) filter_scatter_kernel<W, VV, HV, false, SS><<<grid, block, 0, ctx->stream>>>(b);
+    else if (skip) filter_scatter_kernel<W, VV, HV, true, SS><<<grid, block, 0, ctx->stream>>>(b);
+    else filter_scatter_kernel<W, VV, HV, false, SS><<<grid, block, 0, ctx->stream>>>(b);
   } else {
     filter_scatter_kernel<W, 1, HV, false><<<grid, block, 0, ctx->stream>>>(b);
   }

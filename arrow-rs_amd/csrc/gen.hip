@@ -45,6 +45,21 @@ __global__ void gen_f64_kernel(double* dst, int64_t n, uint64_t seed, double lo,
     dst[i] = fma(u, span, lo);  // explicit fma: identical on host and device
   }
 }
+__global__ void gen_f32_kernel(float* dst, int64_t n, uint64_t seed, float lo, float span, int64_t row0) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t r = splitmix64(seed, (uint64_t)(row0 + i));
+    float u = (float)(r >> 40) * 0x1.0p-24f;
+    dst[i] = fmaf(u, span, lo);
+  }
+}
+// 1- and 2-byte columns: the low bytes of splitmix64(seed, row) (full-range Int8 / Int16 bit patterns)
+template <typename T>
+__global__ void gen_small_kernel(T* dst, int64_t n, uint64_t seed, int64_t row0) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = (T)splitmix64(seed, (uint64_t)(row0 + i));
+}
 __global__ void gen_bits_kernel(unsigned long long* dst, int64_t n, uint64_t seed,
                                 uint64_t threshold, int64_t row0) {
   int64_t nwords = (n + 63) >> 6;
@@ -111,6 +126,26 @@ extern "C" ah_status ah_gen_uniform_f64(ah_context* ctx, double* dst, int64_t n,
   if (n <= 0) return AH_OK;
   hipSetDevice(ctx->device);
   gen_f64_kernel<<<gen_grid(n), 256, 0, ctx->stream>>>(dst, n, seed, lo, hi - lo, row0);
+  AH_HIP(ctx, hipGetLastError());
+  return AH_OK;
+}
+extern "C" ah_status ah_gen_uniform_f32(ah_context* ctx, float* dst, int64_t n, uint64_t seed,
+                                        float lo, float hi, int64_t row0) {
+  ah_ctx_guard _guard(ctx);
+  if (n <= 0) return AH_OK;
+  hipSetDevice(ctx->device);
+  gen_f32_kernel<<<gen_grid(n), 256, 0, ctx->stream>>>(dst, n, seed, lo, hi - lo, row0);
+  AH_HIP(ctx, hipGetLastError());
+  return AH_OK;
+}
+extern "C" ah_status ah_gen_uniform_small(ah_context* ctx, void* dst, int32_t byte_width, int64_t n,
+                                          uint64_t seed, int64_t row0) {
+  ah_ctx_guard _guard(ctx);
+  if (n <= 0) return AH_OK;
+  hipSetDevice(ctx->device);
+  if (byte_width == 1) gen_small_kernel<uint8_t><<<gen_grid(n), 256, 0, ctx->stream>>>((uint8_t*)dst, n, seed, row0);
+  else if (byte_width == 2) gen_small_kernel<uint16_t><<<gen_grid(n), 256, 0, ctx->stream>>>((uint16_t*)dst, n, seed, row0);
+  else return ah_fail(ctx, AH_INVALID_ARGUMENT, "unsupported byte width %d", byte_width);
   AH_HIP(ctx, hipGetLastError());
   return AH_OK;
 }

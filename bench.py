@@ -70,6 +70,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
     p.add_argument("--no-configs", action="store_true", help="skip the configs[2]/[3] lines of the default run")
+    p.add_argument("--only-narrow", action="store_true", help="print just the configs_narrow block (4-byte and narrower operands)")
     p.add_argument("--config-steps", type=int, default=5)
     p.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"])
     p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the run rocprofv3 wraps
@@ -134,6 +135,118 @@ def gen_predicate(A, ctx, n, seed, p_true, row0):
     bits = ctx.alloc(((n + 63) // 64) * 8)
     ctx.check(ctx.lib.ah_gen_bernoulli_bits(ctx.handle, bits.ptr, n, seed, p_true, row0))
     return mk_array(A, ctx, A.Boolean, n, bits)
+
+
+def gen_column(A, ctx, dt, n, seed, p_valid, row0=0):
+    """A fixed-width column of any primitive width with Bernoulli validity, null slots zeroed (the reference's bench arrays,
+    arrow/src/util/bench_util.rs:45-60): Int32 / Int16 / Int8 full-range bit patterns, Float32 uniform in [-1e6, 1e6)."""
+    lib, h = ctx.lib, ctx.handle
+    width = {A.Int8: 1, A.Int16: 2, A.Int32: 4, A.Float32: 4}[dt]
+    vals = ctx.alloc(n * width)
+    if dt is A.Int32:
+        ctx.check(lib.ah_gen_uniform_i32(h, vals.ptr, n, seed, row0))
+    elif dt is A.Float32:
+        ctx.check(lib.ah_gen_uniform_f32(h, vals.ptr, n, seed, -1e6, 1e6, row0))
+    else:
+        ctx.check(lib.ah_gen_uniform_small(h, vals.ptr, width, n, seed, row0))
+    if p_valid >= 1.0:
+        return mk_array(A, ctx, dt, n, vals)
+    valid = ctx.alloc(((n + 63) // 64) * 8)
+    ctx.check(lib.ah_gen_bernoulli_bits(h, valid.ptr, n, seed + 1, p_valid, row0))
+    ctx.check(lib.ah_zero_null_slots(h, vals.ptr, width, valid.ptr, n))
+    return mk_array(A, ctx, dt, n, vals, valid, n - count_bits(ctx, valid, n))
+
+
+# The reference's own criterion shapes are 4-byte and narrower (arrow/benches/filter_kernels.rs:39-45 i32/u8/f32,
+# arithmetic_kernels.rs:26-33 f32, comparison_kernels.rs:33,83-84 f32/i32, cast_kernels.rs:34-40 i32->f64/i64, take_kernels.rs i32);
+# BASELINE configs[0] is Int32.  Each entry: the same kernels on a narrow operand at a size that moves ~8-25 GB, with the
+# SURVEY 8d accounting (every input buffer once in full, every output buffer once).
+NARROW_CONFIGS = ["filter_i32", "take_i32", "add_wrapping_f32", "lt_f32", "lt_i32_scalar", "cast_i32_f64", "cast_i32_i64",
+                  "filter_i16", "filter_i8"]
+
+
+def build_narrow(env, name):
+    A, K, ctx, args = env.A, env.K, env.ctx, env.args
+    st = {}
+    W = {"state": st}
+    wb = lambda m: (m + 7) // 8  # noqa: E731
+    if name.startswith("filter_"):
+        dt, width, n = {"filter_i32": (A.Int32, 4, 2_000_000_000), "filter_i16": (A.Int16, 2, 4_000_000_000),
+                        "filter_i8": (A.Int8, 1, 4_000_000_000)}[name]
+        col = gen_column(A, ctx, dt, n, 42, args.valid)
+        pred = gen_predicate(A, ctx, n, 44, args.selectivity, 0)
+
+        def step(_r):
+            f = K.filter(col, pred)
+            st["k"], st["fn"] = f.length, f.null_count()
+            return f
+
+        def alg():
+            k = st["k"]
+            return n * width + 2 * wb(n) + k * width + (wb(k) if st["fn"] > 0 else 0)
+        W.update(step=step, kernels=["filter_count", "filter_scatter"], dominant="filter_scatter", alg=alg,
+                 text=f"filter {dt.name}, {n} rows, {args.valid:.0%} valid, {args.selectivity:.0%} selected (filter_kernels.rs:39-45)")
+    elif name == "take_i32":
+        n, nidx = 2_000_000_000, 100_000_000
+        col = gen_column(A, ctx, A.Int32, n, 42, args.valid)
+        ib = ctx.alloc(nidx * 4)
+        ctx.check(ctx.lib.ah_gen_uniform_u32(ctx.handle, ib.ptr, nidx, 45, n, 0))
+        idx = mk_array(A, ctx, A.UInt32, nidx, ib)
+        W.update(step=lambda _r: K.take(col, idx), kernels=["take_gather"], dominant="take_gather",
+                 alg=lambda: nidx * (4 + 4 + 4) + 2 * wb(nidx), rows=nidx,
+                 text=f"take Int32 by {nidx} uniform UInt32 indices from {n} rows, {args.valid:.0%} valid (take_kernels.rs:32-80); "
+                      "a random gather: bound by 128-byte line fills, not bytes")
+    elif name in ("add_wrapping_f32", "lt_f32"):
+        n = 2_000_000_000
+        a = gen_column(A, ctx, A.Float32, n, 52, args.valid)
+        b = gen_column(A, ctx, A.Float32, n, 62, args.valid)
+        if name == "lt_f32":
+            W.update(step=lambda _r: K.lt(a, b), kernels=["compare"], dominant="compare", alg=lambda: 8 * n + 4 * wb(n),
+                     text=f"lt Float32 < Float32, {n} rows, both with NullBuffers (comparison_kernels.rs:33)")
+        else:
+            W.update(step=lambda _r: K.add_wrapping(a, b), kernels=["arith_binary"], dominant="arith_binary", alg=lambda: 12 * n + 3 * wb(n),
+                     text=f"add_wrapping Float32 + Float32, {n} rows, both with NullBuffers (arithmetic_kernels.rs:26-33)")
+    elif name == "lt_i32_scalar":
+        n = 2_000_000_000
+        a = gen_column(A, ctx, A.Int32, n, 42, args.valid)
+        s0 = A.Scalar.new(0, A.Int32, ctx)
+        W.update(step=lambda _r: K.lt(a, s0), kernels=["compare"], dominant="compare", alg=lambda: 4 * n + 3 * wb(n),
+                 text=f"lt Int32 < scalar, {n} rows with NullBuffer (comparison_kernels.rs:83-84)")
+    elif name in ("cast_i32_f64", "cast_i32_i64"):
+        n = 2_000_000_000
+        a = gen_column(A, ctx, A.Int32, n, 42, args.valid)
+        to = A.Float64 if name == "cast_i32_f64" else A.Int64
+        W.update(step=lambda _r: K.cast(a, to), kernels=["cast_numeric"], dominant="cast_numeric", alg=lambda: 12 * n + 2 * wb(n),
+                 text=f"cast Int32 -> {to.name}, {n} rows with NullBuffer (cast_kernels.rs:34-40)")
+    else:
+        raise ValueError(name)
+    W.setdefault("rows", n)
+    W["n"] = n
+    return W
+
+
+def narrow_configs(env):
+    """-> {name: {...}}: a few timed steps of every NARROW_CONFIGS entry, each with alg_bytes / avg_launch_ms / frac."""
+    ctx, args = env.ctx, env.args
+    res = {}
+    only = os.environ.get("AH_NARROW_ONLY")  # A/B runs: a comma-separated subset
+    for name in (NARROW_CONFIGS if not only else [x for x in NARROW_CONFIGS if x in only.split(",")]):
+        try:
+            ctx.lib.ah_pool_trim(ctx.handle)
+            W = build_narrow(env, name)
+            el, prof, out = run_timed(env, W, args.config_steps, 2, False, settle=True)
+            ms = el / args.config_steps * 1e3
+            dom_ms, dom_n = prof[W["dominant"]]
+            rf = roofline_obj(W["dominant"], W["alg"](), dom_ms / max(dom_n, 1), dom_n)
+            res[name] = {"workload": W["text"], "rows": W["n"], "steps": args.config_steps, "ms": round(ms, 4),
+                         "value": round(W["rows"] / (ms * 1e-3) / 1e6, 1), "unit": "Mrows/s", "roofline": rf,
+                         "kernel_avg_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()},
+                         "host_gap_ms": round(ms - sum(v[0] for v in prof.values()) / args.config_steps, 4)}
+            W = out = None
+        except Exception as ex:  # noqa: BLE001 - never lose the headline to a secondary config
+            res[name] = {"error": repr(ex)[:300]}
+    ctx.lib.ah_pool_trim(ctx.handle)
+    return res
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
@@ -1139,7 +1252,7 @@ def emit(line, args):
         compact["roofline"]["requests"] = {k: rq[k] for k in ("per_launch", "achieved_G_per_s", "probe_max_G_per_s", "frac_of_probe_max") if k in rq}
     if "roofline_filter_scatter" in line:
         compact["roofline_filter_scatter"] = _compact_roofline(line["roofline_filter_scatter"])
-    for grp in ("configs", "next_rows"):
+    for grp in ("configs", "next_rows", "configs_narrow"):
         if grp in line:
             compact[grp] = {k: _compact_config(v) for k, v in line[grp].items()}
     if isinstance(line.get("filter_by_selectivity"), dict):
@@ -1428,6 +1541,9 @@ def main():
     env.sync_all = sync_all
 
     wl = args.workload
+    if args.only_narrow:
+        print(json.dumps({"configs_narrow": {k: _compact_config(v) for k, v in narrow_configs(env).items()}}), flush=True)
+        return
     W = build_workload(env, wl)
     n = W["n"]
     if args.pmc_child:  # the profiled re-run: just the steps, no reporting
@@ -1678,6 +1794,7 @@ def main():
         ctx.lib.ah_pool_trim(ctx.handle)
         line["configs"] = configs
         line["next_rows"] = next_rows
+        line["configs_narrow"] = narrow_configs(env)
 
     if wl == "filter_take" and (world > 1 or args.reassemble == "allgatherv") and use_dist and exchange_ok and not args.no_configs:
         # BASELINE configs[4]: {Int64, Float64, bitmaps} per shard through filter_record_batch, then ONE exchange of both

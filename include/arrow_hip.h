@@ -657,6 +657,11 @@ AH_API ah_status ah_gen_uniform_f64(ah_context* ctx, double* dst, int64_t n, uin
                                     double lo, double hi, int64_t row0);
 AH_API ah_status ah_gen_uniform_u32(ah_context* ctx, uint32_t* dst, int64_t n, uint64_t seed,
                                     uint32_t bound, int64_t row0);
+AH_API ah_status ah_gen_uniform_f32(ah_context* ctx, float* dst, int64_t n, uint64_t seed,
+                                    float lo, float hi, int64_t row0);
+/* byte_width 1 or 2: the low bytes of splitmix64(seed, row) (full-range Int8 / Int16 patterns) */
+AH_API ah_status ah_gen_uniform_small(ah_context* ctx, void* dst, int32_t byte_width, int64_t n,
+                                      uint64_t seed, int64_t row0);
 /* dst[i] = start + i (row positions, e.g. to turn a predicate into take indices) */
 AH_API ah_status ah_gen_iota_u32(ah_context* ctx, uint32_t* dst, int64_t n, uint32_t start);
 /* Bernoulli(p_true) bits, LSB-first, written at bit offset 0 of dst

@@ -69,6 +69,40 @@ def test_compare_builds_its_output_words_on_the_vector_unit(cmp_kernels, inst):
     assert s["salu"] <= (450 if "4>" in inst else 350), s
 
 
+@pytest.fixture(scope="module")
+def filter_kernels(tmp_path_factory):
+    return _kernels(tmp_path_factory, "filter.hip")
+
+
+@needs_hipcc
+@pytest.mark.parametrize("inst,loads", [("filter_scatter_kernel<1, 16, true, false, 4>", 4), ("filter_scatter_kernel<2, 8, true, false, 2>", 4)])
+def test_narrow_scatter_parks_whole_vectors_and_walks_set_bits(filter_kernels, inst, loads):
+    """Round 5 (profiles/r05_narrow_filter.md): the 1- and 2-byte scatter was VALU-bound, not HBM-bound — ~14 vector instructions
+    per ROW in the per-element form, every 16-byte load unpacked into byte registers behind a vmcnt(0).  The staged form
+    loads 16-byte values back to back, parks them in LDS with ds_write_b128 and reads the selected rows back one by one."""
+    lines = _one(filter_kernels, inst)
+    run = best = 0
+    for l in lines:
+        if l.startswith("global_load_dwordx4"):
+            run += 1
+            best = max(best, run)
+        elif l.startswith("s_waitcnt") and "vmcnt" in l:
+            run = 0
+    assert best >= loads, f"value loads separated by waits (longest run {best})"
+    assert sum(1 for l in lines if l.startswith("ds_write_b128")) >= loads, "values are parked as whole 16-byte vectors"
+    assert any(l.startswith("ds_read_u8" if "<1," in inst else "ds_read_u16") for l in lines), "selected rows are read back by row"
+    assert any(l.startswith("v_ffbl_b32") for l in lines), "the compaction walks set bits"
+    s = isa_scan.stats(lines)
+    assert s["instructions"] <= 900, s  # (1 130 for the per-element Int8 form)
+
+
+@needs_hipcc
+def test_scatter_table_scan_uses_dpp(filter_kernels):
+    """wave_scan_incl: six v_add_u32_dpp, not six ds_bpermute round trips (common.hpp)."""
+    lines = _one(filter_kernels, "filter_scatter_kernel<8, 2, true, true, 1>")
+    assert sum(1 for l in lines if "_dpp" in l and ("row_shr" in l or "row_bcast" in l)) >= 6
+
+
 def test_window_tile_bound_is_a_superset_on_the_host(tmp_path):
     """csrc/window_tiles.hpp (the host-side bound that lets a cut batch of BatchCoalescer launch only the tiles its window of
     the filtered stream can lie in) against brute force: a bound one tile short would lose rows silently on the GPU.
