@@ -58,7 +58,18 @@ __device__ __forceinline__ float quieted(float x) { return __uint_as_float(__flo
 // element semantics: ArrowNativeTypeOp (arrow-array/src/arithmetic.rs:147-430)
 template <typename T, int OP>
 __device__ __forceinline__ bool apply(T l, T r, T* out) {  // returns false on error
-  if constexpr (std::is_floating_point<T>::value) {
+  if constexpr (std::is_same<T, ah_f16>::value) {
+    // half::f16 (numeric.rs:240 float_op::<Float16Type>): to f32, ONE f32 operation with the same NaN rules, one rounding back;
+    // Neg flips bit 15 of the pattern, NaNs included
+    if constexpr (op_is_unary(OP)) {
+      out->bits = (uint16_t)(l.bits ^ 0x8000u);
+    } else {
+      float o;
+      apply<float, OP>(ah_f16_to_f32(l), ah_f16_to_f32(r), &o);
+      *out = ah_f32_to_f16(o);
+    }
+    return true;
+  } else if constexpr (std::is_floating_point<T>::value) {
     T o;
     if constexpr (OP == OP_ADD || OP == OP_ADD_W) o = l + r;
     else if constexpr (OP == OP_SUB || OP == OP_SUB_W) o = l - r;
@@ -235,7 +246,7 @@ void launch_arith_op(ah_context* ctx, const ArithArgs& a, bool aligned) {
 
 template <typename T>
 void launch_arith(ah_context* ctx, int op, const ArithArgs& a, bool aligned) {
-  constexpr bool F = std::is_floating_point<T>::value;
+  constexpr bool F = ah_is_fp<T>::value;
   switch (op) {
     case OP_ADD: launch_arith_op<T, OP_ADD, !F>(ctx, a, aligned); break;
     case OP_ADD_W: launch_arith_op<T, OP_ADD_W, false>(ctx, a, aligned); break;
@@ -273,6 +284,7 @@ ah_status dispatch_type(ah_context* ctx, ah_type t, int op, const ArithArgs& a, 
     case AH_UINT16: launch_arith<uint16_t>(ctx, op, a, aligned); break;
     case AH_UINT32: launch_arith<uint32_t>(ctx, op, a, aligned); break;
     case AH_UINT64: launch_arith<uint64_t>(ctx, op, a, aligned); break;
+    case AH_FLOAT16: launch_arith<ah_f16>(ctx, op, a, aligned); break;
     case AH_FLOAT32: launch_arith<float>(ctx, op, a, aligned); break;
     case AH_FLOAT64: launch_arith<double>(ctx, op, a, aligned); break;
     default: return ah_fail(ctx, AH_INVALID_ARGUMENT, "unsupported arithmetic type");
@@ -280,8 +292,10 @@ ah_status dispatch_type(ah_context* ctx, ah_type t, int op, const ArithArgs& a, 
   return AH_OK;
 }
 
+bool is_float_type(ah_type t) { return ah_type_is_float(t) || t == AH_FLOAT16; }
+
 bool op_checked_for(ah_type t, int op) {
-  if (ah_type_is_float(t)) return false;
+  if (is_float_type(t)) return false;
   return op == OP_ADD || op == OP_SUB || op == OP_MUL || op == OP_DIV || op == OP_REM || op == OP_NEG;
 }
 
@@ -322,7 +336,7 @@ extern "C" ah_status ah_arith_binary(ah_context* ctx, ah_arith_op op, const ah_a
   if (bitwise) op = OP_BAND + (op - AH_BIT_AND);  // public 8..13 -> internal OP_BAND..OP_BANDNOT
   const ah_type t = lhs->type;
   // arithmetic_op (numeric.rs:225-275): both sides must be the same numeric type; bitwise.rs: integers
-  if (lhs->type != rhs->type || !(ah_type_is_integer(t) || (ah_type_is_float(t) && !bitwise)))
+  if (lhs->type != rhs->type || !(ah_type_is_integer(t) || (is_float_type(t) && !bitwise)))
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "Invalid arithmetic operation: %s %s %s",
                    ah_type_name(lhs->type), op_sym(op), ah_type_name(rhs->type));
   const bool checked = op_checked_for(t, op);
@@ -497,7 +511,7 @@ extern "C" ah_status ah_arith_neg(ah_context* ctx, const ah_array_view* v, int32
   const ah_type t = v->type;
   // neg (numeric.rs:103-178): signed ints (checked) and floats; neg_wrapping
   // (:181-186): every integer and float
-  bool ok = ah_type_is_float(t) || ah_type_is_signed(t) || (wrapping && ah_type_is_integer(t));
+  bool ok = is_float_type(t) || ah_type_is_signed(t) || (wrapping && ah_type_is_integer(t));
   if (!ok)
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "Invalid arithmetic operation: !%s", ah_type_name(t));
   return arith_unary(ctx, v, wrapping ? OP_NEG_W : OP_NEG, out);

@@ -30,7 +30,22 @@ namespace {
 
 template <typename I, typename O>
 __device__ __forceinline__ bool num_cast(I v, O* out) {
-  if constexpr (std::is_floating_point<O>::value) {
+  // Float16 on either side (half 2.7.1 num_traits.rs): `NumCast for f16` = n.to_f32().map(f16::from_f32), `ToPrimitive for f16`
+  // = self.to_f32().to_X() — every conversion goes through f32 (i64 / f64 -> f16 round twice, as the reference does)
+  if constexpr (std::is_same<I, ah_f16>::value && std::is_same<O, ah_f16>::value) {
+    *out = v;
+    return true;
+  } else if constexpr (std::is_same<I, ah_f16>::value) {
+    return num_cast<float, O>(ah_f16_to_f32(v), out);
+  } else if constexpr (std::is_same<O, ah_f16>::value) {
+    float f;
+    num_cast<I, float>(v, &f);
+    *out = ah_f32_to_f16(f);
+    return true;
+  } else if constexpr (std::is_same<I, O>::value) {
+    *out = v;
+    return true;
+  } else if constexpr (std::is_floating_point<O>::value) {
     *out = (O)v;
     return true;
   } else if constexpr (std::is_floating_point<I>::value) {
@@ -273,6 +288,7 @@ ah_status launch_from(ah_context* ctx, ah_type to, const CastArgs& a) {
     case AH_UINT16: launch_cast<I, uint16_t>(ctx, a); break;
     case AH_UINT32: launch_cast<I, uint32_t>(ctx, a); break;
     case AH_UINT64: launch_cast<I, uint64_t>(ctx, a); break;
+    case AH_FLOAT16: launch_cast<I, ah_f16>(ctx, a); break;
     case AH_FLOAT32: launch_cast<I, float>(ctx, a); break;
     case AH_FLOAT64: launch_cast<I, double>(ctx, a); break;
     default: return ah_fail(ctx, AH_CAST_ERROR, "unsupported cast target");
@@ -281,6 +297,7 @@ ah_status launch_from(ah_context* ctx, ah_type to, const CastArgs& a) {
 }
 
 bool is_numeric(ah_type t) { return ah_type_is_integer(t) || ah_type_is_float(t); }
+bool is_numeric16(ah_type t) { return is_numeric(t) || t == AH_FLOAT16; }  // the numeric <-> numeric arms (cast/mod.rs:1578-1697) take Float16 too
 
 // Rust `{:?}` of a float (core::fmt float_to_general_debug): shortest digits,
 // exponential iff |v| >= 1e16 or 0 < |v| < 1e-4.  Host-side, error text only.
@@ -321,6 +338,12 @@ ah_status elem_debug_text(ah_context* ctx, ah_type t, const void* base, int64_t 
     case AH_INT16: snprintf(buf, sizeof buf, "%d", (int)(int16_t)raw); break;
     case AH_INT32: snprintf(buf, sizeof buf, "%d", (int)(int32_t)raw); break;
     case AH_INT64: snprintf(buf, sizeof buf, "%lld", (long long)(int64_t)raw); break;
+    case AH_FLOAT16: {  // Debug for f16 prints its f32 value
+      ah_f16 h;
+      h.bits = (uint16_t)raw;
+      *out = rust_debug_float<float>(ah_f16_to_f32(h));
+      return AH_OK;
+    }
     case AH_FLOAT32: {
       float f;
       memcpy(&f, &raw, 4);
@@ -343,7 +366,7 @@ ah_status elem_debug_text(ah_context* ctx, ah_type t, const void* base, int64_t 
 
 extern "C" int32_t ah_can_cast_types(ah_type from, ah_type to) {
   if (from == to) return ah_type_width(from) >= 0 || from == AH_UTF8 || from == AH_LARGE_UTF8;
-  if (is_numeric(from) && is_numeric(to)) return 1;
+  if (is_numeric16(from) && is_numeric16(to)) return 1;
   if ((from == AH_BOOL && is_numeric(to)) || (is_numeric(from) && to == AH_BOOL)) return 1;  // cast/mod.rs:254-255
   if (is_numeric(from) && (to == AH_UTF8 || to == AH_LARGE_UTF8)) return 1;
   if ((from == AH_UTF8 || from == AH_LARGE_UTF8) && is_numeric(to)) return 1;  // cast/mod.rs `(Utf8, _)` parse arms
@@ -438,6 +461,7 @@ extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_ty
       case AH_UINT16: st = launch_from<uint16_t>(ctx, to_type, a); break;
       case AH_UINT32: st = launch_from<uint32_t>(ctx, to_type, a); break;
       case AH_UINT64: st = launch_from<uint64_t>(ctx, to_type, a); break;
+      case AH_FLOAT16: st = launch_from<ah_f16>(ctx, to_type, a); break;
       case AH_FLOAT32: st = launch_from<float>(ctx, to_type, a); break;
       default: st = launch_from<double>(ctx, to_type, a); break;
     }

@@ -33,6 +33,12 @@ __device__ __forceinline__ int32_t order_key(float v) {
   int32_t b = __float_as_int(v);
   return b ^ (int32_t)((uint32_t)(b >> 31) >> 1);
 }
+// f16::total_cmp / to_bits equality (half 2.7.1): the f32 rule on the 16-bit pattern
+__device__ __forceinline__ int16_t order_key(ah_f16 v) {
+  const int16_t b = (int16_t)v.bits;
+  return (int16_t)(b ^ (int16_t)((uint16_t)(b >> 15) >> 1));
+}
+__device__ __forceinline__ uint16_t bits_key(ah_f16 v) { return v.bits; }
 template <typename T> __device__ __forceinline__ T order_key(T v) { return v; }
 __device__ __forceinline__ int64_t bits_key(double v) { return __double_as_longlong(v); }
 __device__ __forceinline__ int32_t bits_key(float v) { return __float_as_int(v); }
@@ -260,7 +266,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
   const bool is_bytes = t == AH_UTF8 || t == AH_LARGE_UTF8;
   // AH_FIXED16 compares as i128 (Decimal128; the host checks that precision and scale agree, compare_op cmp.rs:243-249).
   // IntervalMonthDayNano shares the layout but orders by (months, days, nanoseconds): its host must not come here.
-  if (!(t == AH_BOOL || ah_type_is_integer(t) || ah_type_is_float(t) || is_bytes || t == AH_FIXED16))
+  if (!(t == AH_BOOL || ah_type_is_integer(t) || ah_type_is_float(t) || t == AH_FLOAT16 || is_bytes || t == AH_FIXED16))
     return ah_fail(ctx, AH_NOT_YET_IMPLEMENTED, "comparison not supported for type %s", ah_type_name(t));
   if ((l_s && lhs->length < 1) || (r_s && rhs->length < 1))
     return ah_fail(ctx, AH_INVALID_ARGUMENT, "scalar datum must have length 1");
@@ -375,6 +381,7 @@ extern "C" ah_status ah_compare(ah_context* ctx, ah_cmp_op op, const ah_array_vi
       case AH_UINT16: launch_cmp_t<uint16_t>(ctx, a, aligned); break;
       case AH_UINT32: launch_cmp_t<uint32_t>(ctx, a, aligned); break;
       case AH_UINT64: launch_cmp_t<uint64_t>(ctx, a, aligned); break;
+      case AH_FLOAT16: launch_cmp_t<ah_f16>(ctx, a, aligned); break;
       case AH_FLOAT32: launch_cmp_t<float>(ctx, a, aligned); break;
       case AH_FIXED16: launch_cmp_t<__int128>(ctx, a, aligned); break;
       default: launch_cmp_t<double>(ctx, a, aligned); break;

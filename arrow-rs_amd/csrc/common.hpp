@@ -14,6 +14,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -356,6 +357,54 @@ __device__ __forceinline__ unsigned long long wave_reduce_add64(unsigned long lo
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// ---------------------------------------------------------------------------------------------------------- Float16
+// `half::f16` as arrow-rs sees it on its x86-64 host (crate `half` 2.7.1, software conversions: arrow-buffer/Cargo.toml:46 takes
+// it with default-features = false): f16 -> f32 exact, a NaN keeps sign and payload (<< 13) and gets the quiet bit; f32 -> f16
+// round-to-nearest-even, a NaN becomes sign | 0x7C00 | 0x0200 | (mantissa >> 13); arithmetic is "to f32, one f32 operation,
+// one rounding back" — never a native half-precision instruction (v_add_f16 would round once where the reference rounds twice).
+// Device: the hardware converts (v_cvt_f32_f16 / v_cvt_f16_f32, round-to-nearest-even, denormals kept) carry the non-NaN
+// values, the NaN rule is applied explicitly; host (error texts only): integer arithmetic.
+struct ah_f16 {
+  uint16_t bits;
+};
+__host__ __device__ __forceinline__ float ah_f16_to_f32(ah_f16 h) {
+  const uint32_t sign = (uint32_t)(h.bits & 0x8000u) << 16, exp = h.bits & 0x7C00u, man = h.bits & 0x03FFu;
+#ifdef __HIP_DEVICE_COMPILE__
+  if (exp == 0x7C00u && man) return __uint_as_float(sign | 0x7FC00000u | (man << 13));
+  _Float16 x;
+  __builtin_memcpy(&x, &h.bits, 2);
+  return (float)x;
+#else
+  uint32_t x;
+  if (exp == 0x7C00u) x = man ? (sign | 0x7FC00000u | (man << 13)) : (sign | 0x7F800000u);
+  else if (exp == 0) {
+    if (man == 0) x = sign;
+    else {
+      int e = 0;
+      uint32_t m = man;
+      while (!(m & 0x0400u)) { m <<= 1; ++e; }
+      x = sign | ((uint32_t)(127 - 15 - e + 1) << 23) | ((m & 0x03FFu) << 13);
+    }
+  } else x = sign | (((exp >> 10) + (127 - 15)) << 23) | (man << 13);
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+#endif
+}
+__device__ __forceinline__ ah_f16 ah_f32_to_f16(float f) {
+  const uint32_t x = __float_as_uint(f);
+  ah_f16 r;
+  if ((x & 0x7FFFFFFFu) > 0x7F800000u) {
+    r.bits = (uint16_t)(((x >> 16) & 0x8000u) | 0x7E00u | ((x & 0x007FFFFFu) >> 13));
+    return r;
+  }
+  const _Float16 h = (_Float16)f;
+  __builtin_memcpy(&r.bits, &h, 2);
+  return r;
+}
+template <typename T> struct ah_is_fp { static constexpr bool value = std::is_floating_point<T>::value; };
+template <> struct ah_is_fp<ah_f16> { static constexpr bool value = true; };
+
 // inclusive scan across the 64 lanes of a wave
 // Six `v_add_u32_dpp` (row_shr 1 / 2 / 4 / 8 inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and
 // row_bcast:31 into rows 2 and 3; lanes without a source add 0).  The __shfl_up form this replaces compiled to six

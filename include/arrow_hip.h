@@ -76,7 +76,9 @@ enum {
   AH_FIXED32 = 13, /* 32-byte natives: i256 / Decimal256 */
   AH_UTF8 = 14,       /* i32 offsets: output of cast; input/output of filter, take */
   AH_LARGE_UTF8 = 15, /* i64 offsets */
-  AH_FLOAT16 = 16,    /* filter/take/concat only (bit copy); min/max aggregates */
+  AH_FLOAT16 = 16,    /* half::f16: filter/take/concat (bit copy), sort, min/max; arithmetic, neg, compare and the numeric
+                       * casts computed as the `half` crate does (to f32, one operation, one rounding back; totalOrder on
+                       * the 16-bit pattern) — numeric.rs:113,240, cast/mod.rs:1578-1697 */
   /* GenericByteViewArray (arrow-array/src/array/byte_view_array.rs): `values` = the 16-byte views.
    * filter / take / nullif copy views unchanged and the host keeps the SAME variadic data-buffer list
    * on the result (filter.rs:931-944 `filter_byte_view`, take.rs:630-640 `take_byte_view`), so the data

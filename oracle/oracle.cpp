@@ -753,6 +753,63 @@ int32_t take_typed(const orc_view* values, const orc_view* indices, int32_t cb, 
   return ORC_OK;
 }
 
+// ------------------------------------------------------------------ Float16
+// `half::f16` (crate `half` 2.7.1 per /root/reference/Cargo.lock; a third-party dependency, not vendored in the reference tree —
+// the conversion routines below restate its published software fallbacks, which are what arrow-rs gets on x86-64: it depends on
+// `half` with default-features = false, arrow-buffer/Cargo.toml:46, so there is no runtime F16C detection).
+//   * f16 -> f32 (`f16_to_f32_fallback`): exact; a NaN keeps its sign and payload (shifted left 13) and gets the quiet bit.
+//   * f32 -> f16 (`f32_to_f16_fallback`): round to nearest even, overflow -> infinity, results below half the smallest
+//     subnormal -> signed zero; a NaN becomes sign | 0x7C00 | 0x0200 | (mantissa >> 13).
+//   * arithmetic (`impl Add/Sub/Mul/Div/Rem for f16`): convert both operands to f32, one f32 operation, convert back — never
+//     a native half-precision instruction.  Neg flips bit 15.  total_cmp works on the 16-bit pattern like f32's.
+//   * num_traits casts (half/src/num_traits.rs): `NumCast for f16` is `n.to_f32().map(f16::from_f32)` (every source type goes
+//     through f32: i64 -> f32 `as`, f64 -> f32 `as`, then one more rounding), `ToPrimitive for f16` is `self.to_f32().to_X()`.
+// Pinned against numpy's float16 (IEEE binary16, the same round-to-nearest-even conversions) in tests/test_oracle_golden.py.
+struct F16 {
+  uint16_t bits;
+};
+inline float f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  const uint32_t exp = h & 0x7C00u, man = h & 0x03FFu;
+  uint32_t x;
+  if (exp == 0x7C00u) x = man ? (sign | 0x7FC00000u | (man << 13)) : (sign | 0x7F800000u);
+  else if (exp == 0) {
+    if (man == 0) x = sign;
+    else {  // subnormal: normalise
+      int e = 0;
+      uint32_t m = man;
+      while (!(m & 0x0400u)) { m <<= 1; ++e; }
+      x = sign | ((uint32_t)(127 - 15 - e + 1) << 23) | ((m & 0x03FFu) << 13);
+    }
+  } else x = sign | (((exp >> 10) + (127 - 15)) << 23) | (man << 13);
+  float f;
+  memcpy(&f, &x, 4);
+  return f;
+}
+inline uint16_t f32_to_f16(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = x & 0x80000000u, exp = x & 0x7F800000u, man = x & 0x007FFFFFu;
+  if (exp == 0x7F800000u) return (uint16_t)((sign >> 16) | 0x7C00u | (man ? 0x0200u : 0u) | (man >> 13));
+  const uint32_t hs = sign >> 16;
+  const int he = (int)(exp >> 23) - 127 + 15;
+  if (he >= 0x1F) return (uint16_t)(hs | 0x7C00u);
+  if (he <= 0) {
+    if (14 - he > 24) return (uint16_t)hs;
+    const uint32_t m = man | 0x00800000u;
+    uint32_t hm = m >> (14 - he);
+    const uint32_t round_bit = 1u << (13 - he);
+    if ((m & round_bit) != 0 && (m & (3 * round_bit - 1)) != 0) hm += 1;
+    return (uint16_t)(hs | hm);
+  }
+  const uint32_t hm = man >> 13, round_bit = 0x00001000u;
+  uint32_t r = hs | ((uint32_t)he << 10) | hm;
+  if ((man & round_bit) != 0 && (man & (3 * round_bit - 1)) != 0) r += 1;
+  return (uint16_t)r;
+}
+template <typename T> struct is_fp : std::is_floating_point<T> {};
+template <> struct is_fp<F16> : std::true_type {};
+
 // -------------------------------------------------------------------- arith
 enum { OP_ADD = 0, OP_ADD_W, OP_SUB, OP_SUB_W, OP_MUL, OP_MUL_W, OP_DIV, OP_REM };
 const char* op_sym(int op) {  // Display for Op (numeric.rs:203-213)
@@ -817,6 +874,11 @@ inline T float_op(int op, T l, T r) {  // arithmetic.rs:308-430, numeric.rs:357-
   }
 }
 
+template <>
+inline F16 float_op<F16>(int op, F16 l, F16 r) {  // to f32, one f32 operation, one rounding back (half 2.7.1 `impl Add for f16` ...)
+  return F16{f32_to_f16(float_op<float>(op, f16_to_f32(l.bits), f16_to_f32(r.bits)))};
+}
+
 bool op_is_checked_int(int op) { return op == OP_ADD || op == OP_SUB || op == OP_MUL || op == OP_DIV || op == OP_REM; }
 
 // NullBuffer::union (arrow-buffer/src/buffer/null.rs:79-88): presence-based
@@ -840,7 +902,7 @@ uint8_t* nulls_clone(const orc_view* a, int64_t len) {
 
 template <typename T>
 int32_t arith_typed(int op, const orc_view* l, bool l_s, const orc_view* r, bool r_s, orc_out* out) {
-  constexpr bool is_float = std::is_floating_point<T>::value;
+  constexpr bool is_float = is_fp<T>::value;
   const bool checked = !is_float && op_is_checked_int(op);
   const T* lv = (const T*)l->values;
   const T* rv = (const T*)r->values;
@@ -960,6 +1022,12 @@ inline int32_t total_key(float x) {
   memcpy(&b, &x, 4);
   return b ^ (int32_t)((uint32_t)(b >> 31) >> 1);
 }
+inline int16_t total_key(F16 x) {  // f16::total_cmp (half 2.7.1): the f32 rule on the 16-bit pattern
+  const int16_t b = (int16_t)x.bits;
+  return (int16_t)(b ^ (int16_t)((uint16_t)(b >> 15) >> 1));
+}
+template <> inline bool is_lt<F16>(F16 a, F16 b) { return total_key(a) < total_key(b); }
+template <> inline bool is_eq<F16>(F16 a, F16 b) { return a.bits == b.bits; }
 template <> inline bool is_lt<double>(double a, double b) { return total_key(a) < total_key(b); }
 template <> inline bool is_lt<float>(float a, float b) { return total_key(a) < total_key(b); }
 template <> inline bool is_eq<double>(double a, double b) { return memcmp(&a, &b, 8) == 0; }
@@ -1117,8 +1185,32 @@ inline bool num_cast(I v, O* out) {
   }
 }
 
+// Float16 on either side (half 2.7.1 num_traits.rs): every conversion goes through f32
+template <typename O>
+inline bool num_cast_from_f16(F16 v, O* out) {
+  if constexpr (std::is_same<O, F16>::value) { *out = v; return true; }
+  else return num_cast<float, O>(f16_to_f32(v.bits), out);
+}
+template <typename I>
+inline bool num_cast_to_f16(I v, F16* out) {
+  float f;
+  num_cast<I, float>(v, &f);  // `as f32`: never fails
+  out->bits = f32_to_f16(f);
+  return true;
+}
+template <typename I, typename O>
+inline bool num_cast_any(I v, O* out) {
+  if constexpr (std::is_same<I, F16>::value) return num_cast_from_f16<O>(v, out);
+  else if constexpr (std::is_same<O, F16>::value) return num_cast_to_f16<I>(v, out);
+  else return num_cast<I, O>(v, out);
+}
+
 template <typename T> std::string dbg_num(T v) {
-  if constexpr (std::is_floating_point<T>::value) {
+  if constexpr (std::is_same<T, F16>::value) {  // Debug for f16 prints the f32 value
+    char b[40];
+    int n = orc_format_f32(f16_to_f32(v.bits), b);
+    return std::string(b, (size_t)n);
+  } else if constexpr (std::is_floating_point<T>::value) {
     char b[40];
     int n = std::is_same<T, float>::value ? orc_format_f32((float)v, b) : orc_format_f64((double)v, b);
     return std::string(b, (size_t)n);  // Rust {:?} of a float == shortest round-trip, "256.0"
@@ -1145,7 +1237,7 @@ int32_t cast_numeric(const orc_view* in, int32_t to_type, bool safe, orc_out* ou
     for (int64_t i = 0; i < len; ++i) {
       if (!get_bit(nb, i)) continue;
       O o;
-      if (num_cast<I, O>(iv[i], &o)) ov[i] = o;
+      if (num_cast_any<I, O>(iv[i], &o)) ov[i] = o;
       else {
         nulls += 1;
         nb[i >> 3] &= (uint8_t)~(1u << (i & 7));
@@ -1161,7 +1253,7 @@ int32_t cast_numeric(const orc_view* in, int32_t to_type, bool safe, orc_out* ou
   for (int64_t i = 0; i < len; ++i) {
     if (nb && !get_bit(nb, i)) continue;
     O o;
-    if (!num_cast<I, O>(iv[i], &o)) {
+    if (!num_cast_any<I, O>(iv[i], &o)) {
       free(nb);
       orc_release(out);
       return fail(ORC_CAST_ERROR, "Can't cast value %s to type %s", dbg_num(iv[i]).c_str(), type_name(to_type));
@@ -1187,6 +1279,7 @@ int32_t cast_from(const orc_view* in, int32_t to, bool safe, orc_out* out) {
     case ORC_UINT16: return cast_numeric<I, uint16_t>(in, to, safe, out);
     case ORC_UINT32: return cast_numeric<I, uint32_t>(in, to, safe, out);
     case ORC_UINT64: return cast_numeric<I, uint64_t>(in, to, safe, out);
+    case ORC_FLOAT16: return cast_numeric<I, F16>(in, to, safe, out);
     case ORC_FLOAT32: return cast_numeric<I, float>(in, to, safe, out);
     case ORC_FLOAT64: return cast_numeric<I, double>(in, to, safe, out);
   }
@@ -1341,7 +1434,8 @@ int32_t neg_typed(const orc_view* v, bool wrapping, orc_out* out) {
   out->values_bytes = len * (int64_t)sizeof(T);
   uint8_t* nb = nulls_clone(v, len);
   for (int64_t i = 0; i < len; ++i) {
-    if constexpr (std::is_floating_point<T>::value) ov[i] = -iv[i];
+    if constexpr (std::is_same<T, F16>::value) ov[i] = F16{(uint16_t)(iv[i].bits ^ 0x8000u)};  // Neg for f16
+    else if constexpr (std::is_floating_point<T>::value) ov[i] = -iv[i];
     else if (wrapping) ov[i] = (T)(0 - (typename std::make_unsigned<T>::type)iv[i]);
     else {
       if (nb && !get_bit(nb, i)) continue;
@@ -1880,7 +1974,7 @@ int32_t orc_take(const orc_view* values, const orc_view* indices, int32_t cb, or
 
 int32_t orc_arith(int32_t op, const orc_view* l, int32_t l_s, const orc_view* r, int32_t r_s, orc_out* out) {
   out_init(out);
-  if (l->type != r->type || !(is_integer(l->type) || l->type == ORC_FLOAT32 || l->type == ORC_FLOAT64))
+  if (l->type != r->type || !(is_integer(l->type) || l->type == ORC_FLOAT16 || l->type == ORC_FLOAT32 || l->type == ORC_FLOAT64))
     return fail(ORC_INVALID_ARGUMENT, "Invalid arithmetic operation: %s %s %s", type_name(l->type),
                 op_sym(op), type_name(r->type));  // numeric.rs:270-272
   switch (l->type) {
@@ -1892,6 +1986,7 @@ int32_t orc_arith(int32_t op, const orc_view* l, int32_t l_s, const orc_view* r,
     case ORC_UINT16: return arith_typed<uint16_t>(op, l, l_s, r, r_s, out);
     case ORC_UINT32: return arith_typed<uint32_t>(op, l, l_s, r, r_s, out);
     case ORC_UINT64: return arith_typed<uint64_t>(op, l, l_s, r, r_s, out);
+    case ORC_FLOAT16: return arith_typed<F16>(op, l, l_s, r, r_s, out);  // numeric.rs:240
     case ORC_FLOAT32: return arith_typed<float>(op, l, l_s, r, r_s, out);
     default: return arith_typed<double>(op, l, l_s, r, r_s, out);
   }
@@ -1904,6 +1999,7 @@ int32_t orc_neg(const orc_view* v, int32_t wrapping, orc_out* out) {
     case ORC_INT16: return neg_typed<int16_t>(v, wrapping, out);
     case ORC_INT32: return neg_typed<int32_t>(v, wrapping, out);
     case ORC_INT64: return neg_typed<int64_t>(v, wrapping, out);
+    case ORC_FLOAT16: return neg_typed<F16>(v, wrapping, out);
     case ORC_FLOAT32: return neg_typed<float>(v, wrapping, out);
     case ORC_FLOAT64: return neg_typed<double>(v, wrapping, out);
     case ORC_UINT8: if (wrapping) return neg_typed<uint8_t>(v, true, out); break;
@@ -1938,6 +2034,7 @@ int32_t orc_compare(int32_t op, const orc_view* l, int32_t l_s, const orc_view* 
       case ORC_UINT16: return cmp_values<uint16_t>(op, l, l_s, r, r_s, len);
       case ORC_UINT32: return cmp_values<uint32_t>(op, l, l_s, r, r_s, len);
       case ORC_UINT64: return cmp_values<uint64_t>(op, l, l_s, r, r_s, len);
+      case ORC_FLOAT16: return cmp_values<F16>(op, l, l_s, r, r_s, len);
       case ORC_FLOAT32: return cmp_values<float>(op, l, l_s, r, r_s, len);
       case ORC_FLOAT64: return cmp_values<double>(op, l, l_s, r, r_s, len);
       case ORC_UTF8: case ORC_LARGE_UTF8: return cmp_values_bytes(op, l, l_s, r, r_s, len);
@@ -1946,7 +2043,7 @@ int32_t orc_compare(int32_t op, const orc_view* l, int32_t l_s, const orc_view* 
     return nullptr;
   };
   const bool is_bytes = l->type == ORC_UTF8 || l->type == ORC_LARGE_UTF8;
-  if ((type_width(l->type) < 0 && !is_bytes) || l->type == ORC_FIXED32 || l->type == ORC_FLOAT16)
+  if ((type_width(l->type) < 0 && !is_bytes) || l->type == ORC_FIXED32)
     return fail(ORC_NOT_YET_IMPLEMENTED, "comparison not supported for type %s", type_name(l->type));
   size_t bytes = bitmap_bytes(len);
   // nulls filtered by null_count > 0 (:345-346)
@@ -2433,6 +2530,7 @@ int32_t orc_cast(const orc_view* in, int32_t to, int32_t safe, orc_out* out) {
     case ORC_UINT16: return cast_from<uint16_t>(in, to, safe, out);
     case ORC_UINT32: return cast_from<uint32_t>(in, to, safe, out);
     case ORC_UINT64: return cast_from<uint64_t>(in, to, safe, out);
+    case ORC_FLOAT16: return cast_from<F16>(in, to, safe, out);
     case ORC_FLOAT32: return cast_from<float>(in, to, safe, out);
     case ORC_FLOAT64: return cast_from<double>(in, to, safe, out);
   }

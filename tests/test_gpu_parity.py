@@ -363,6 +363,80 @@ def test_fuzz_arith(ctx, oracle, dt):
                 check_exact(got, exp, f"{dt} op {op} iter {it}")
 
 
+INT_TYPES = [A.Int8, A.Int16, A.Int32, A.Int64, A.UInt8, A.UInt16, A.UInt32, A.UInt64]
+
+
+def _full_range_ints(rng, dt, n):
+    """Uniform over the whole encoding space of the width, with the edge values planted: MIN, MAX, -1, 0, 1, MIN + 1."""
+    info = np.iinfo(dt.np_dtype)
+    x = rng.integers(info.min, info.max, n, dtype=dt.np_dtype, endpoint=True)
+    edges = [info.min, info.max, 0, 1, info.min + 1, info.max - 1] + ([-1, -2] if info.min < 0 else [])
+    k = rng.random(n) < 0.08
+    x[k] = rng.choice(np.array(edges, dtype=dt.np_dtype), int(k.sum()))
+    return x
+
+
+def _arith_same(oracle, op, ha, hb, da, db, msg, **sc):
+    """One op through the oracle and the device: identical result (raw bytes, null slots included) or identical failure
+    (error class AND text: the first failing valid row's operands are in it)."""
+    try:
+        exp = oracle.arith(op, ha, hb, **sc)
+    except A.ArrowError as ex:
+        with pytest.raises(type(ex)) as ei:
+            ARITH_FN[op](da, db)
+        assert ei.value.message == ex.message, msg
+        return False
+    check_exact(ARITH_FN[op](da, db), exp, msg)
+    return True
+
+
+@pytest.mark.parametrize("dt", INT_TYPES, ids=str)
+def test_fuzz_arith_full_range_integers(ctx, oracle, dt):
+    """the integer ops over FULL-RANGE operands, all eight widths (the 8- and 16-bit kernels run 8-16 rows
+    per lane: where a sign-extension slip would hide).  Wrapping ops must match bit for bit; checked ops fail on the first
+    failing VALID row with the reference's text (`Overflow happened on: a + b`, arithmetic.rs:147-260); `MIN / -1` overflows,
+    `MIN % -1` is 0 (numeric.rs:345-351), a zero divisor under a NULL slot is not an error (try_binary visits valid slots
+    only, arity.rs:285-294).  Arrays, sliced arrays, scalars on either side."""
+    rng = np.random.default_rng(_seed("fullrange-" + dt.name))
+    info = np.iinfo(dt.np_dtype)
+    ok_count = fail_count = 0
+    for it in range(6):
+        n = int(rng.integers(1, 6000))
+        a, b = _full_range_ints(rng, dt, n), _full_range_ints(rng, dt, n)
+        av = (rng.random(n) < 0.85) if it % 2 == 0 else None
+        bv = (rng.random(n) < 0.85) if it % 3 != 1 else None
+        if it == 2:  # every zero divisor sits under a NULL slot: div / rem must succeed unless MIN / -1 shows up
+            bv = (b != 0) & (rng.random(n) < 0.9)
+        if it == 3:  # small second operand: the checked forms mostly succeed at full-range first operands
+            b = rng.integers(0, 2, n).astype(dt.np_dtype)
+        if it == 4 and info.min < 0:  # MIN / -1 and MIN % -1 as the ONLY special rows
+            a = np.where(rng.random(n) < 0.5, info.min, a).astype(dt.np_dtype)
+            b = np.full(n, -1, dtype=dt.np_dtype)
+        ha, hb = HostArray(dt, a, av), HostArray(dt, b, bv)
+        da, db = ha.to_device(ctx), hb.to_device(ctx)
+        off = int(rng.integers(0, min(n, 130)))
+        for op in range(8):
+            r = _arith_same(oracle, op, ha, hb, da, db, f"{dt} full-range op {op} iter {it}")
+            ok_count, fail_count = ok_count + r, fail_count + (not r)
+            _arith_same(oracle, op, ha.slice(off, n - off), hb.slice(off, n - off), da.slice(off, n - off), db.slice(off, n - off),
+                        f"{dt} full-range op {op} iter {it} sliced {off}")
+            for sv in (a[int(rng.integers(0, n))], info.min, info.max, dt.np_dtype(1)) + ((dt.np_dtype(-1),) if info.min < 0 else ()):
+                hs = HostArray(dt, np.array([sv], dtype=dt.np_dtype))
+                ds = A.Scalar(hs.to_device(ctx))
+                _arith_same(oracle, op, ha, hs, da, ds, f"{dt} full-range op {op} iter {it} rscalar {sv}", r_scalar=True)
+                _arith_same(oracle, op, hs, hb, ds, db, f"{dt} full-range op {op} iter {it} lscalar {sv}", l_scalar=True)
+        for wrapping, fn in ((False, K.neg), (True, K.neg_wrapping)):
+            try:
+                exp = oracle.neg(ha, wrapping=wrapping)
+            except A.ArrowError as ex:
+                with pytest.raises(type(ex)) as ei:
+                    fn(da)
+                assert ei.value.message == ex.message, f"{dt} neg wrapping={wrapping}"
+                continue
+            check_exact(fn(da), exp, f"{dt} full-range neg wrapping={wrapping} iter {it}")
+    assert ok_count >= 18 and fail_count >= 6, (ok_count, fail_count)  # the wrapping forms succeeded, the checked forms failed
+
+
 @pytest.mark.parametrize("dt", [A.Float32, A.Float64], ids=str)
 def test_fuzz_arith_float_bit_patterns(ctx, oracle, dt):
     """All eight ops of arrow_arith::numeric on float operands drawn over the WHOLE encoding space (`_float_strata`):
@@ -389,6 +463,115 @@ def test_fuzz_arith_float_bit_patterns(ctx, oracle, dt):
                 check_float(ARITH_FN[op](ds, db), oracle.arith(op, hs, hb, l_scalar=True), f"{dt} bit-pattern op {op} lscalar {sv!r}", full, b)
         check_float(K.neg(da), oracle.neg(ha), f"{dt} bit-pattern neg")
         check_float(K.neg_wrapping(da), oracle.neg(ha, wrapping=True), f"{dt} bit-pattern neg_wrapping")
+
+
+def _f16_strata(rng, n):
+    """Float16 operand pairs over the whole encoding space (the sampler that pins the oracle: tests/test_oracle_golden.py)."""
+    from test_oracle_golden import f16_strata
+    return f16_strata(rng, n)
+
+
+def check_f16(got_dev, exp_host, msg, lhs=None, rhs=None):
+    """Bit equality on the 16-bit patterns, NaNs included, except where BOTH operands are NaN (check_float's rule)."""
+    g = host(got_dev)
+    assert_same_nulls_presence(g, exp_host, msg)
+    gv, ev = np.asarray(g.values).view(np.uint16), np.asarray(exp_host.values).view(np.uint16)
+    m = np.ones(len(gv), dtype=bool)
+    if lhs is not None and rhs is not None:
+        both = np.isnan(np.asarray(lhs)) & np.isnan(np.asarray(rhs))
+        assert np.all(np.isnan(gv[both].view(np.float16)) & np.isnan(ev[both].view(np.float16))), f"{msg} NaN op NaN must be NaN"
+        m = ~both
+    bad = np.nonzero(gv[m] != ev[m])[0]
+    assert len(bad) == 0, f"{msg}: {len(bad)} patterns differ, first {bad[:4]}: got {gv[m][bad[:4]]} want {ev[m][bad[:4]]}"
+    assert got_dev.null_count() == exp_host.null_count, f"{msg} null_count"
+
+
+def test_float16_every_encoding_neg_and_casts(ctx, oracle):
+    """VERDICT r04 missing #3: Float16 through neg / neg_wrapping and the numeric casts on ALL 65 536 encodings (arrays with and
+    without nulls, sliced), both directions, safe and unsafe — bit-exact against the oracle, whose conversions are pinned to
+    numpy float16 on the CPU.  Reference arms: numeric.rs:113 (neg), cast/mod.rs:1578-1697 (`(Int64, Float16)`, `(Float16, Float64)`, ...)."""
+    h = np.arange(1 << 16, dtype=np.uint32).astype(np.uint16).view(np.float16)
+    rng = np.random.default_rng(_seed("f16-casts"))
+    for valid in (None, rng.random(len(h)) < 0.9):
+        hh = HostArray(A.Float16, h, valid)
+        dh = hh.to_device(ctx)
+        check_f16(K.neg(dh), oracle.neg(hh), "f16 neg")
+        check_f16(K.neg_wrapping(dh), oracle.neg(hh, wrapping=True), "f16 neg_wrapping")
+        check_f16(K.neg(dh.slice(77, 4001)), oracle.neg(hh.slice(77, 4001)), "f16 neg sliced")
+        for to in (A.Float32, A.Float64, A.Int8, A.Int16, A.Int32, A.Int64, A.UInt8, A.UInt16, A.UInt32, A.UInt64):
+            check_exact(K.cast(dh, to), oracle.cast(hh, to), f"cast f16 -> {to}")
+            check_exact(K.cast(dh.slice(33, 5000), to), oracle.cast(hh.slice(33, 5000), to), f"cast f16 -> {to} sliced")
+        check_f16(K.cast(dh, A.Float16), oracle.cast(hh, A.Float16), "cast f16 -> f16")
+    # unsafe mode: the first value that does not fit is reported with its Debug text (f16 prints as its f32 value)
+    few = HostArray(A.Float16, np.array([1.5, 300.0, -2.0, np.nan], dtype=np.float16))
+    for to in (A.Int8, A.UInt8, A.Int16):
+        try:
+            exp = oracle.cast(few, to, safe=False)
+        except A.ArrowError as ex:
+            with pytest.raises(type(ex)) as ei:
+                K.cast_with_options(few.to_device(ctx), to, K.CastOptions(safe=False))
+            assert ei.value.message == ex.message
+        else:
+            check_exact(K.cast_with_options(few.to_device(ctx), to, K.CastOptions(safe=False)), exp, f"unsafe cast f16 -> {to}")
+    # -> Float16: every f16 value as f32 / f64, its f32 neighbours and the exact midpoints between adjacent f16 values
+    fin = h[np.isfinite(h)].astype(np.float32)
+    with np.errstate(over="ignore"):
+        nxt = np.nextafter(h[np.isfinite(h)], np.float16(np.inf)).astype(np.float32)
+    mid = ((fin.astype(np.float64) + nxt.astype(np.float64)) / 2).astype(np.float32)
+    nanbits = np.array([0x7FC00000, 0xFFC00000, 0x7F800001, 0xFF800001, 0x7FA00000, 0x7FFFFFFF, 0x7F802000], dtype=np.uint32).view(np.float32)
+    cand = np.concatenate([fin, np.nextafter(fin, np.float32(np.inf)), np.nextafter(fin, np.float32(-np.inf)), mid,
+                           np.nextafter(mid, np.float32(np.inf)), np.nextafter(mid, np.float32(-np.inf)), nanbits,
+                           np.array([65504, 65519.99, 65520, 65536, 1e9, np.inf, -np.inf, 2.0**-24, 2.0**-25, 2.0**-25 * 1.0001, 2.0**-26,
+                                     -2.0**-25, 1e-30, 0.0, -0.0], dtype=np.float32)])
+    with np.errstate(invalid="ignore"):  # (the signalling NaNs among the candidates)
+        cand64 = np.concatenate([cand.astype(np.float64), np.array([1.0 + 2.0**-11 + 2.0**-30, 2049.0000001, 65519.999999])])
+    for src_dt, vals in ((A.Float32, cand), (A.Float64, cand64)):
+        hs = HostArray(src_dt, vals.astype(src_dt.np_dtype), rng.random(len(vals)) < 0.95)
+        check_f16(K.cast(hs.to_device(ctx), A.Float16), oracle.cast(hs, A.Float16), f"cast {src_dt} -> f16")
+    for src_dt in INT_TYPES:
+        info = np.iinfo(src_dt.np_dtype)
+        iv = np.concatenate([rng.integers(max(info.min, -70000), min(info.max, 70000), 4000, endpoint=True),
+                             rng.integers(info.min, info.max, 3000, dtype=src_dt.np_dtype, endpoint=True).astype(object),
+                             np.array([x for x in (2049, 2051, 65519, 65520, -65520, 16777217, info.min, info.max) if info.min <= x <= info.max], dtype=object)])
+        hs = HostArray(src_dt, np.array([int(x) for x in iv], dtype=src_dt.np_dtype), rng.random(len(iv)) < 0.9)
+        check_f16(K.cast(hs.to_device(ctx), A.Float16), oracle.cast(hs, A.Float16), f"cast {src_dt} -> f16")
+
+
+def test_float16_arith_and_compare_bit_patterns(ctx, oracle):
+    """Float16 add / sub / mul / div / rem (and the wrapping aliases) and the eight compares on a stratified sample of encoding
+    PAIRS: computed as `half` does — to f32, one operation, one rounding back; totalOrder / bit equality on the 16-bit pattern
+    (numeric.rs:240, arithmetic.rs:400-430) — arrays, sliced arrays, scalars on either side, bit-exact."""
+    rng = np.random.default_rng(_seed("f16-arith"))
+    for it in range(3):
+        a, b = _f16_strata(rng, int(rng.integers(3000, 40000)))
+        n = len(a)
+        av = (rng.random(n) < 0.9) if it % 2 == 0 else None
+        bv = (rng.random(n) < 0.9) if it == 1 else None
+        ha, hb = HostArray(A.Float16, a, av), HostArray(A.Float16, b, bv)
+        da, db = ha.to_device(ctx), hb.to_device(ctx)
+        off = int(rng.integers(1, 70))
+        scalars = [b[int(i)] for i in rng.integers(0, n, 2)] + [np.float16(0.0), np.float16(np.inf), np.float16(-0.0)]
+        for op in range(8):
+            check_f16(ARITH_FN[op](da, db), oracle.arith(op, ha, hb), f"f16 op {op} iter {it}", a, b)
+            check_f16(ARITH_FN[op](da.slice(off, n - off), db.slice(off, n - off)), oracle.arith(op, ha.slice(off, n - off), hb.slice(off, n - off)),
+                      f"f16 op {op} sliced", a[off:], b[off:])
+            for sv in scalars[:2] if it else scalars:
+                hs = HostArray(A.Float16, np.array([sv], dtype=np.float16))
+                ds = A.Scalar(hs.to_device(ctx))
+                full = np.full(n, sv, dtype=np.float16)
+                check_f16(ARITH_FN[op](da, ds), oracle.arith(op, ha, hs, r_scalar=True), f"f16 op {op} rscalar {sv!r}", a, full)
+                check_f16(ARITH_FN[op](ds, db), oracle.arith(op, hs, hb, l_scalar=True), f"f16 op {op} lscalar {sv!r}", full, b)
+            exp = oracle.compare(op, ha, hb)
+            got = CMP_FN[op](da, db)
+            check(got, exp, f"f16 cmp op {op}")
+            assert_same_nulls_presence(host(got), exp, f"f16 cmp op {op}")
+            check(CMP_FN[op](da.slice(off, n - off), db.slice(off, n - off)),
+                  oracle.compare(op, ha.slice(off, n - off), hb.slice(off, n - off)), f"f16 cmp op {op} sliced")
+            for i in rng.integers(0, n, 2):
+                sc = HostArray(A.Float16, b[int(i):int(i) + 1].copy(), None)
+                dsc = A.Scalar(sc.to_device(ctx))
+                check(CMP_FN[op](da, dsc), oracle.compare(op, ha, sc, r_scalar=True), f"f16 cmp op {op} rscalar")
+                check(CMP_FN[op](dsc, db), oracle.compare(op, sc, hb, l_scalar=True), f"f16 cmp op {op} lscalar")
 
 
 @pytest.mark.parametrize("dt", [A.Float32, A.Float64], ids=str)

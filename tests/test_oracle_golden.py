@@ -627,6 +627,190 @@ def test_oracle_float_compare_is_total_order_on_every_encoding(oracle, dt):
         assert np.array_equal(np.asarray(oracle.compare(op, ha, hb).values, dtype=bool), want), f"{dt} compare op {op}"
 
 
+INT_TYPES = [A.Int8, A.Int16, A.Int32, A.Int64, A.UInt8, A.UInt16, A.UInt32, A.UInt64]
+
+
+@pytest.mark.parametrize("dt", INT_TYPES, ids=str)
+def test_oracle_integer_arith_full_range_vs_bigint_model(oracle, dt):
+    """Pins the CHECKER of test_fuzz_arith_full_range_integers: the oracle's integer ops (ArrowNativeTypeOp for integers,
+    arrow-array/src/arithmetic.rs:147-260; numeric.rs:345-351 for `MIN % -1`) over full-range operands of every width
+    against an independent model in Python's unbounded integers: wrapping = reduce modulo 2^bits; checked = error iff
+    the exact result leaves the type, reporting the FIRST failing valid row with the reference's text; division truncates
+    toward zero, zero divisor = DivideByZero, `MIN / -1` overflows, `MIN % -1` = 0."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("intmodel-" + dt.name).encode()))
+    info = np.iinfo(dt.np_dtype)
+    bits, lo, hi = info.bits, int(info.min), int(info.max)
+    sym = {0: "+", 2: "-", 4: "*", 6: "/", 7: "%"}
+
+    def wrap(v):
+        v &= (1 << bits) - 1
+        return v - (1 << bits) if lo < 0 and v >= (1 << (bits - 1)) else v
+
+    def tdiv(x, y):
+        q = abs(x) // abs(y)
+        return q if (x < 0) == (y < 0) else -q
+
+    for it in range(6):
+        n = int(rng.integers(1, 400))
+        a = rng.integers(lo, hi, n, dtype=dt.np_dtype, endpoint=True)
+        b = rng.integers(lo, hi, n, dtype=dt.np_dtype, endpoint=True)
+        edges = np.array([lo, hi, 0, 1] + ([-1] if lo < 0 else []), dtype=dt.np_dtype)
+        for x in (a, b):
+            k = rng.random(n) < 0.1
+            x[k] = rng.choice(edges, int(k.sum()))
+        if it >= 3:
+            b = rng.integers(1, 3, n).astype(dt.np_dtype)  # the checked forms succeed now and then
+        valid = (rng.random(n) < 0.8) if it % 2 else None
+        ha, hb = HostArray(dt, a, valid), HostArray(dt, b)
+        A_, B_ = [int(v) for v in a], [int(v) for v in b]
+        ok_rows = range(n) if valid is None else [i for i in range(n) if valid[i]]
+        for op in range(8):
+            exact = {0: lambda x, y: x + y, 1: lambda x, y: x + y, 2: lambda x, y: x - y, 3: lambda x, y: x - y,
+                     4: lambda x, y: x * y, 5: lambda x, y: x * y}.get(op)
+            err = None
+            want = [0] * n
+            if op in (1, 3, 5):  # wrapping: every slot (arity::binary applies the op to null slots too)
+                want = [wrap(exact(x, y)) for x, y in zip(A_, B_)]
+            else:
+                for i in ok_rows:
+                    x, y = A_[i], B_[i]
+                    if op in (6, 7) and y == 0:
+                        err = (A.array.DivideByZero, "Divide by zero error")
+                        break
+                    if op == 7:
+                        r = 0 if y == -1 else x - tdiv(x, y) * y
+                    else:
+                        r = tdiv(x, y) if op == 6 else exact(x, y)
+                    if not lo <= r <= hi:
+                        err = (A.array.ArithmeticOverflow, f"Overflow happened on: {x} {sym[op]} {y}")
+                        break
+                    want[i] = r
+            if err:
+                with pytest.raises(err[0]) as ei:
+                    oracle.arith(op, ha, hb)
+                assert ei.value.message == err[1], f"{dt} op {op} iter {it}"
+                continue
+            got = oracle.arith(op, ha, hb)
+            gv = [int(v) for v in np.asarray(got.values)]
+            rows = range(n) if op in (1, 3, 5) else ok_rows
+            assert all(gv[i] == want[i] for i in rows), f"{dt} op {op} iter {it}"
+            if op not in (1, 3, 5) and valid is not None:  # try_binary leaves 0 under null slots (arity.rs:285-294)
+                assert all(gv[i] == 0 for i in range(n) if not valid[i]), f"{dt} op {op} iter {it}: null slots"
+
+
+def f16_strata(rng, n):
+    """Float16 operand pairs over the whole encoding space: uniform bit patterns (every exponent, subnormals, NaN payloads of
+    both signs), plus planted zeros / infinities / the largest and smallest magnitudes / ties for the 11-bit significand."""
+    a = rng.integers(0, 1 << 16, n, dtype=np.uint16)
+    b = rng.integers(0, 1 << 16, n, dtype=np.uint16)
+    special = np.array([0x0000, 0x8000, 0x7C00, 0xFC00, 0x7BFF, 0xFBFF, 0x0001, 0x8001, 0x03FF, 0x0400, 0x3C00, 0xBC00, 0x7E00, 0xFE00,
+                        0x7C01, 0xFDFF, 0x3555, 0x4248], dtype=np.uint16)
+    for x in (a, b):
+        k = rng.random(n) < 0.15
+        x[k] = rng.choice(special, int(k.sum()))
+    k = rng.random(n) < 0.1  # near-equal magnitudes: cancellation, quotients near 1
+    b[k] = a[k] ^ rng.integers(0, 4, int(k.sum())).astype(np.uint16)
+    return a.view(np.float16), b.view(np.float16)
+
+
+def test_oracle_float16_conversions_on_every_encoding(oracle):
+    """The oracle's restated `half` 2.7.1 conversions against numpy's IEEE binary16: all 65 536 encodings through
+    Float16 -> Float32 / Float64 / every integer type and `neg`, and Float32 / Float64 / Int64 -> Float16 on every f16 value,
+    both of its f32 neighbours and the exact midpoints between adjacent f16 values (the ties of round-to-nearest-even)."""
+    h = np.arange(1 << 16, dtype=np.uint32).astype(np.uint16)
+    hv = h.view(np.float16)
+    hh = HostArray(A.Float16, hv)
+    nan = np.isnan(hv)
+    # f16 -> f32 / f64: exact; NaN: payload << 13 with the quiet bit set (f16_to_f32_fallback)
+    for dt, ut in ((A.Float32, np.uint32), (A.Float64, np.uint64)):
+        got = np.asarray(oracle.cast(hh, dt).values)
+        want = hv.astype(dt.np_dtype)
+        assert np.array_equal(got[~nan].view(ut), want[~nan].view(ut)), dt
+        assert np.isnan(got[nan]).all()
+    g32 = np.asarray(oracle.cast(hh, A.Float32).values).view(np.uint32)
+    want_nan = ((h[nan].astype(np.uint32) & 0x8000) << 16) | 0x7FC00000 | ((h[nan].astype(np.uint32) & 0x3FF) << 13)
+    assert np.array_equal(g32[nan], want_nan)
+    # neg: bit 15 flips, NaNs included
+    assert np.array_equal(np.asarray(oracle.neg(hh).values).view(np.uint16), h ^ 0x8000)
+    assert np.array_equal(np.asarray(oracle.neg(hh, wrapping=True).values).view(np.uint16), h ^ 0x8000)
+    # f16 -> integers (safe): via f32; valid iff trunc(v) is representable, NaN / inf -> null
+    f = hv.astype(np.float64)
+    for dt in (A.Int8, A.Int16, A.Int32, A.Int64, A.UInt8, A.UInt16, A.UInt32, A.UInt64):
+        info = np.iinfo(dt.np_dtype)
+        out = oracle.cast(hh, dt)
+        with np.errstate(invalid="ignore"):
+            t = np.trunc(f)
+        ok = np.isfinite(f) & (t >= info.min) & (t <= info.max)
+        assert np.array_equal(np.asarray(out.valid, dtype=bool), ok), dt
+        assert np.array_equal(np.asarray(out.values)[ok], t[ok].astype(dt.np_dtype)), dt
+    # f32 -> f16: every f16 value, its two f32 neighbours, and the midpoint to the next f16 (ties to even)
+    fin = hv[np.isfinite(hv)].astype(np.float32)
+    with np.errstate(over="ignore"):
+        nxt = np.nextafter(hv[np.isfinite(hv)], np.float16(np.inf)).astype(np.float32)
+    mid = ((fin.astype(np.float64) + nxt.astype(np.float64)) / 2).astype(np.float32)  # exact: 12 significant bits
+    cand = np.concatenate([fin, np.nextafter(fin, np.float32(np.inf)), np.nextafter(fin, np.float32(-np.inf)), mid,
+                           np.nextafter(mid, np.float32(np.inf)), np.nextafter(mid, np.float32(-np.inf)),
+                           np.array([65504, 65519.99, 65520, 65536, 1e9, np.inf, -np.inf, 2.0**-24, 2.0**-25, 2.0**-25 * 1.0001, 2.0**-26,
+                                     -2.0**-25, 1e-30, 0.0, -0.0], dtype=np.float32)])
+    with np.errstate(over="ignore"):
+        want = cand.astype(np.float16).view(np.uint16)
+    got = np.asarray(oracle.cast(HostArray(A.Float32, cand), A.Float16).values).view(np.uint16)
+    assert np.array_equal(got, want)
+    # f32 NaNs: sign | 0x7C00 | 0x0200 | (mantissa >> 13)   (f32_to_f16_fallback)
+    nb = np.array([0x7FC00000, 0xFFC00000, 0x7F800001, 0xFF800001, 0x7FA00000, 0x7FFFFFFF, 0x7F802000], dtype=np.uint32)
+    got = np.asarray(oracle.cast(HostArray(A.Float32, nb.view(np.float32)), A.Float16).values).view(np.uint16)
+    assert np.array_equal(got, ((nb >> 16) & 0x8000) | 0x7C00 | 0x0200 | ((nb & 0x7FFFFF) >> 13))
+    # f64 -> f16 and i64 -> f16 go THROUGH f32 (NumCast for f16 = n.to_f32().map(f16::from_f32)): double rounding is observable
+    d = np.concatenate([cand.astype(np.float64), np.array([1.0 + 2.0**-11 + 2.0**-30, 2049.0000001, 65519.999999], dtype=np.float64)])
+    with np.errstate(over="ignore"):
+        want = d.astype(np.float32).astype(np.float16).view(np.uint16)
+    assert np.array_equal(np.asarray(oracle.cast(HostArray(A.Float64, d), A.Float16).values).view(np.uint16), want)
+    assert np.float64(1.0 + 2.0**-11 + 2.0**-30).astype(np.float16) != np.float64(1.0 + 2.0**-11 + 2.0**-30).astype(np.float32).astype(np.float16)
+    rng = np.random.default_rng(16)
+    iv = np.concatenate([rng.integers(-70000, 70000, 4000), rng.integers(-2**63, 2**63 - 1, 2000), np.array([2049, 2051, 65519, 65520, -65520, 16777217])]).astype(np.int64)
+    with np.errstate(over="ignore"):
+        want = iv.astype(np.float32).astype(np.float16).view(np.uint16)
+    assert np.array_equal(np.asarray(oracle.cast(HostArray(A.Int64, iv), A.Float16).values).view(np.uint16), want)
+
+
+def test_oracle_float16_arith_and_compare_vs_numpy(oracle):
+    """Float16 add / sub / mul / div / rem = to f32, ONE f32 operation, round back (half 2.7.1 `impl Add for f16` etc.; numpy's
+    float16 arithmetic is defined the same way), on a stratified sample of encoding pairs: bit-exact wherever the result is
+    not a NaN.  Compare = totalOrder on the 16-bit pattern, equality = bit equality."""
+    rng = np.random.default_rng(1616)
+    a, b = f16_strata(rng, 60000)
+    ha, hb = HostArray(A.Float16, a), HostArray(A.Float16, b)
+    a32, b32 = a.astype(np.float32), b.astype(np.float32)
+    with np.errstate(all="ignore"):
+        ref = {0: a32 + b32, 1: a32 + b32, 2: a32 - b32, 3: a32 - b32, 4: a32 * b32, 5: a32 * b32, 6: a32 / b32, 7: np.fmod(a32, b32)}
+        ref = {k: v.astype(np.float16) for k, v in ref.items()}
+    for op, want in ref.items():
+        got = np.asarray(oracle.arith(op, ha, hb).values)
+        ok = ~np.isnan(want)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), f"f16 op {op}: NaN positions"
+        bad = np.nonzero(got[ok].view(np.uint16) != want[ok].view(np.uint16))[0]
+        assert len(bad) == 0, f"f16 op {op}: {len(bad)} results differ from numpy, first at {bad[:4]}"
+    # generated NaN is the x86 default NaN through f32: 0xFFC00000 -> 0xFE00
+    inf = HostArray(A.Float16, np.array([np.inf], dtype=np.float16))
+    ninf = HostArray(A.Float16, np.array([-np.inf], dtype=np.float16))
+    assert np.asarray(oracle.arith(0, inf, ninf).values).view(np.uint16)[0] == 0xFE00
+
+    def key(x):
+        i = x.view(np.int16).copy()
+        return i ^ ((i >> 15) & 0x7FFF)
+    ka, kb = key(a), key(b)
+    for op, want in ((0, ka == kb), (1, ka != kb), (2, ka < kb), (3, ka <= kb), (4, ka > kb), (5, ka >= kb)):
+        assert np.array_equal(np.asarray(oracle.compare(op, ha, hb).values, dtype=bool), want), f"f16 compare op {op}"
+    # scalar forms and nulls ride the same generic paths as f32 (arith_typed / compare_op)
+    sc = HostArray(A.Float16, b[:1].copy())
+    got = np.asarray(oracle.arith(4, ha, sc, r_scalar=True).values)
+    with np.errstate(all="ignore"):
+        want = (a32 * b32[0]).astype(np.float16)
+    ok = ~np.isnan(want)
+    assert np.array_equal(got[ok].view(np.uint16), want[ok].view(np.uint16))
+
+
 def test_config0_on_the_oracle():
     """BASELINE.json configs[0] on the CPU reference path: filter() on a 2^20-row Int32 PrimitiveArray, 50 % selected,
     no nulls (arrow/benches/filter_kernels.rs:39-45 at BASELINE's size).  default_strategy picks IndexIterator
