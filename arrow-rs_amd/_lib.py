@@ -208,6 +208,10 @@ SIGNATURES = {
     "ah_filter_predicates_build": (C.c_int32, [_P, C.c_int32, _VIEW, C.POINTER(_P)]),
     "ah_coalescer_finish_buffered_batch": (C.c_int32, [_P, _P]),
     "ah_coalescer_next_completed_batch": (C.c_int32, [_P, _P, _OUT, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),
+    "ah_coalescer_next_completed_batches": (C.c_int32, [_P, _P, C.c_int32, _OUT, C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
+                                                        C.POINTER(C.c_int32)]),
+    "ah_arrays_release": (None, [_P, _OUT, C.c_int64]),
+    "ah_coalescer_push_abort": (None, [_P, _P, _P]),
     "ah_take": (C.c_int32, [_P, _VIEW, _VIEW, C.c_int32, _OUT]),
     "ah_arith_binary": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
     "ah_arith_with_types": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, C.POINTER(DataTypeDesc), _VIEW, C.c_int32,

@@ -205,6 +205,41 @@ class BatchCoalescer:
                 del self._inputs[sq]  # inputs contribute in push order: nothing older can show up again
         return RecordBatch(self.names, cols, num_rows=rows.value)
 
+    def next_completed_batches(self, max_batches=1 << 30):
+        """Up to ``max_batches`` finished batches with ONE C call (``ah_coalescer_next_completed_batches``): a grouped push of
+        8192-row batches — the reference's operating point, coalesce.rs:172-173 — completes thousands of output batches
+        at once.  View schemas and bypassed batches keep the one-at-a-time path (their bookkeeping is per batch)."""
+        out = []
+        if self._native is None or self._view_cols or self._tagged:
+            while len(out) < max_batches:
+                b = self.next_completed_batch()
+                if b is None:
+                    break
+                out.append(b)
+            return out
+        nc = len(self.data_types)
+        want = min(max_batches, self.completed_count())
+        if want <= 0:
+            return out
+        outs = (L.ArrayOut * (want * nc))()
+        rows = (C.c_int64 * want)()
+        n = C.c_int32()
+        self.ctx.check(self.ctx.lib.ah_coalescer_next_completed_batches(self.ctx.handle, self._native, want, outs, rows, None, C.byref(n)))
+        for j in range(n.value):
+            cols = []
+            for i, dt in enumerate(self.data_types):
+                o = L.ArrayOut()
+                C.memmove(C.byref(o), C.byref(outs[j * nc + i]), C.sizeof(L.ArrayOut))
+                cols.append(Array._from_out(self.ctx, o, dt))
+            out.append(RecordBatch(self.names, cols, num_rows=rows[j]))
+        return out
+
+    def _slab_schema(self):
+        """the library's slab push takes this schema (csrc/coalesce.hip slab_eligible): any number of batches per call"""
+        return (self._native is not None and self.biggest_coalesce_batch_size is None and not self._view_cols
+                and self.target_batch_size % 64 == 0 and len(self.data_types) <= 8
+                and all(dt.is_primitive() and dt.width in (1, 2, 4, 8) and dt.physical != L.AH_BOOL for dt in self.data_types))
+
     def _read_sources(self):
         """which inputs make up the FRONT completed batch (``ah_coalescer_completed_batch_sources``)"""
         n = C.c_int32()
@@ -327,7 +362,7 @@ class BatchCoalescer:
 
         Same output batches, same order as the one-call form.  Non-native schemas: everything happens in ``end()``."""
         pairs = list(pairs)
-        if self._native is None or not pairs or len(pairs) > 64:
+        if self._native is None or not pairs or (len(pairs) > 64 and not self._slab_schema()):
             return _PendingPush(self, pairs, None, None, None)
         n, nc = len(pairs), len(self.data_types)
         views = (L.ArrayView * (n * nc))()
@@ -417,6 +452,17 @@ class _PendingPush:
 
     def __init__(self, co, pairs, handle, tags, keep):
         self.co, self.pairs, self.handle, self.tags, self._keep = co, pairs, handle, tags, keep
+        self._fin = None
+        if handle is not None:  # a handle that is never ended must not keep its pinned slot and predicates
+            import weakref
+            self._fin = weakref.finalize(self, co.ctx.lib.ah_coalescer_push_abort, co.ctx.handle, co._native, handle)
+
+    def abort(self):
+        """give the push up without appending its batches (``ah_coalescer_push_abort``)"""
+        self.pairs = None
+        if self._fin is not None and self._fin.alive:
+            self._fin()  # calls the abort once
+        self.handle = self._keep = None
 
     def end(self):
         co, pairs = self.co, self.pairs
@@ -428,6 +474,8 @@ class _PendingPush:
         n = len(pairs)
         bypassed = (C.c_int32 * n)()
         h, self.handle = self.handle, None
+        if self._fin is not None:
+            self._fin.detach()  # _end consumes the handle, also when it fails
         co._declare_inputs([b for b, _f in pairs])  # (the library numbers a group's batches when they are APPENDED: now)
         co.ctx.check(co.ctx.lib.ah_coalescer_push_batches_with_filters_end(co.ctx.handle, co._native, h, bypassed))
         for i, (b, _f) in enumerate(pairs):

@@ -26,7 +26,9 @@
 // The reference additionally copies strings out of sparsely used buffers (its `ideal_buffer_size` GC heuristic); that
 // changes memory footprint, not the logical value, and is not done here.
 #include "common.hpp"
+#include "filter_internal.hpp"
 
+#include <algorithm>
 #include <deque>
 #include <memory>
 #include <vector>
@@ -123,6 +125,29 @@ struct CoBatch {
   bool pending = false;
   uint64_t seq = 0;
   int ring = 0;
+  // a batch carved out of a slab push: its null counts are words [slab_index * ncols, ...) of the push's pinned block
+  std::shared_ptr<struct SlabNulls> slab_nulls;
+  int64_t slab_index = 0;
+};
+
+// null counts of the full output batches of one slab push, written by ONE kernel into pinned words the batches share
+struct SlabNulls {
+  ah_context* ctx = nullptr;
+  uint64_t* pin = nullptr;
+  size_t bytes = 0;
+  uint64_t seq = 0;
+  bool arrived = false;
+  ~SlabNulls() {
+    if (pin) ah_pinned_free(ctx, pin, bytes);
+  }
+};
+
+// pinned block of a slab push in flight: [wave prefixes (nwaves + 1 words)][table staging]; grown on demand, two per coalescer
+struct SlabPin {
+  void* host = nullptr;
+  void* dev = nullptr;
+  size_t bytes = 0;
+  bool busy = false;
 };
 
 }  // namespace
@@ -146,6 +171,7 @@ struct ah_coalescer {
   uint64_t* quant_pin = nullptr;
   uint64_t* quant_pin_dev = nullptr;
   bool cnt_busy[2] = {false, false};
+  SlabPin slab_pin[2];
   // view schemas: every push is an "input" with a sequence number (0, 1, 2, ... in push order; the host counts the same
   // way); `declared` holds the per-column data-buffer counts of the inputs about to be pushed
   bool has_views = false;
@@ -181,6 +207,21 @@ ah_status begin_input(ah_context* ctx, ah_coalescer* co) {
   for (int i = 0; i < co->ncols; ++i) co->cols[i].cur_nbuf = co->cols[i].is_view ? counts[(size_t)i] : 0;
   return AH_OK;
 }
+
+// every push consumes exactly `n` sequence numbers and (view schemas) `n` declared buffer-count entries, whether or not it
+// succeeds — the host counts its pushes the same way, so a rejected push cannot leave the two sides out of step
+struct InputGuard {
+  ah_coalescer* co;
+  uint64_t seq0;
+  size_t decl0;
+  int n;
+  InputGuard(ah_coalescer* c, int n_) : co(c), seq0(c->input_seq), decl0(c->declared.size()), n(n_) {}
+  ~InputGuard() {
+    co->input_seq = seq0 + (uint64_t)n;
+    const size_t want = decl0 > (size_t)n ? decl0 - (size_t)n : 0;
+    while (co->declared.size() > want) co->declared.pop_front();
+  }
+};
 
 // the current input is about to append rows to the in-progress batch: the first time it does, it becomes a source of
 // that batch and its views are shifted by the buffers the batch already references
@@ -288,6 +329,18 @@ void resolve_batch(ah_context* ctx, ah_coalescer* co, CoBatch& b, const uint64_t
 }
 ah_status resolve_pending(ah_context* ctx, ah_coalescer* co, CoBatch& b) {
   if (!b.pending) return AH_OK;
+  if (b.slab_nulls) {
+    SlabNulls& sn = *b.slab_nulls;
+    if (!sn.arrived) {
+      AH_TRY(ah_coalesce_wait(ctx, sn.seq));
+      sn.arrived = true;
+    }
+    uint64_t nulls[AH_TBL_MAX_COLS];
+    for (int i = 0; i < co->ncols; ++i) nulls[i] = __atomic_load_n(&sn.pin[(size_t)b.slab_index * co->ncols + i], __ATOMIC_RELAXED);
+    resolve_batch(ctx, co, b, nulls);
+    b.slab_nulls.reset();
+    return AH_OK;
+  }
   AH_TRY(ah_coalesce_wait(ctx, b.seq));
   resolve_batch(ctx, co, b, co->pin + (size_t)b.ring * co->ncols);
   return AH_OK;
@@ -300,7 +353,7 @@ ah_status finish_buffered(ah_context* ctx, ah_coalescer* co) {  // coalesce.rs:5
   // idle GPU per output batch.)  The ring slot must be free: the batch that used it last has been resolved.
   const int ring = co->ring_next;
   for (auto& old : co->completed)
-    if (old.pending && old.ring == ring) AH_TRY(resolve_pending(ctx, co, old));
+    if (old.pending && !old.slab_nulls && old.ring == ring) AH_TRY(resolve_pending(ctx, co, old));
   co->ring_next = (co->ring_next + 1) % co->ring_slots;
   uint64_t seq = 0;
   AH_TRY(ah_coalesce_post_nulls(ctx, (unsigned long long*)co->acc, co->ncols, co->pin_dev + (size_t)ring * co->ncols, &seq));
@@ -534,6 +587,8 @@ extern "C" void ah_coalescer_destroy(ah_context* ctx, ah_coalescer* co) {
     for (auto& b : co->completed) release_batch(ctx, b);  // (the wait above passed every pending batch's kernel)
     ah_pool_free(ctx, co->acc);
     ah_pinned_free(ctx, co->pin, co->pin_bytes);
+    for (auto& sp : co->slab_pin)
+      if (sp.host) ah_pinned_free(ctx, sp.host, sp.bytes);
   }
   delete co;
 }
@@ -553,6 +608,7 @@ extern "C" ah_status ah_coalescer_push_batch(ah_context* ctx, ah_coalescer* co, 
   if (bypassed) *bypassed = 0;
   if (!ctx || !co || !columns || num_rows < 0) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
+  InputGuard input_guard(co, 1);
   AH_TRY(check_columns(ctx, co, columns, num_rows));
   AH_TRY(begin_input(ctx, co));
   return push_batch_impl(ctx, co, columns, num_rows, tag, bypassed);
@@ -699,6 +755,7 @@ extern "C" ah_status ah_coalescer_push_batch_with_filter(ah_context* ctx, ah_coa
   if (bypassed) *bypassed = 0;
   if (!ctx || !co || !columns || !filter || num_rows < 0) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
+  InputGuard input_guard(co, 1);
   AH_TRY(check_filter(ctx, co, columns, num_rows, filter));
   AH_TRY(begin_input(ctx, co));
   ah_filter_predicate* p = nullptr;
@@ -750,6 +807,338 @@ ah_status append_group(ah_context* ctx, ah_coalescer* co, int m, const ah_array_
                        bool fusable);
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------- slab push
+// Round 5: the reference's operating point is 8192-row input batches (coalesce.rs:172-173 "Typical
+// values are 4096 or 8192 rows"; arrow/benches/coalesce_kernels.rs:34) — 122 000 pushes and 12 000 output batches per 1e9
+// rows at 10 % selected.  A grouped push of ANY number of batches is one table upload, one count launch, one scan, and one
+// scatter launch per destination (per value width):
+//   * the rows that top up the in-progress batch go into its buffers (positions [0, room) of the push's filtered stream);
+//   * every further row goes into ONE slab — a single allocation holding ceil(rest / target) output batches back to back,
+//     so output batch j simply IS rows [j * target, (j + 1) * target) of the slab (values and validity bits alike: the target
+//     must be a multiple of 64), handed out as slices that keep the block alive (ah_slab, context.hip); the slab's last,
+//     partial batch becomes the new in-progress batch;
+//   * NULL rows are counted from the output bitmaps behind the scatter: per full slab batch into pinned words the batches
+//     share (read when a batch is fetched), for the top-up and the tail into the in-progress counters.
+// The host waits once per push: for the wave prefixes (positions of every 65 536-row group's first selected row), from
+// which it knows K, how the rows split between top-up and slab, and which tiles each launch needs.
+namespace {
+
+struct SlabPush {
+  int n = 0, slot = -1;
+  int64_t total_rows = 0;
+  ah_tbl_push t{};
+  void* dev_block = nullptr;
+  uint64_t seq = 0;
+  std::vector<int64_t> wave0, tile0;  // per batch (n + 1 entries): first count wave / first 4096-row tile
+  bool aligned16 = true;
+};
+
+bool slab_enabled() {
+  const char* e = getenv("AH_COALESCE_SLAB");  // "0": the round-4 grouped path (A/B runs); read per call
+  return !(e && e[0] == '0');
+}
+
+// the slab path serves: no bypass limit, fixed-width columns of 1 / 2 / 4 / 8 bytes (at most 8), a target that is a multiple
+// of 64, the built-in allocator, a synchronous context
+bool slab_eligible(ah_context* ctx, const ah_coalescer* co, int n, const ah_array_view* columns, const int64_t* num_rows,
+                   const ah_array_view* filters) {
+  if (!slab_enabled() || n < 2 || co->limit >= 0 || co->has_views || co->ncols > AH_TBL_MAX_COLS || (co->target & 63)) return false;
+  if (ctx->alloc || ctx->deferred || ctx->capturing) return false;
+  for (int k = 0; k < co->ncols; ++k) {
+    const int w = co->cols[k].width;
+    if (co->cols[k].generic || !(w == 1 || w == 2 || w == 4 || w == 8)) return false;
+  }
+  for (int i = 0; i < n; ++i) {
+    if (filters[i].length > num_rows[i]) return false;  // (check_filter reports it)
+    if (ah_ceil_div(filters[i].length, 4096) > INT32_MAX) return false;
+  }
+  return true;
+}
+
+ah_status slab_pin_reserve(ah_context* ctx, SlabPin& sp, size_t bytes) {
+  if (sp.bytes >= bytes) return AH_OK;
+  if (sp.host) ah_pinned_free(ctx, sp.host, sp.bytes);
+  sp.host = sp.dev = nullptr;
+  sp.bytes = 0;
+  size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 16);
+  AH_TRY(ah_pinned_alloc(ctx, want, &sp.host, &sp.dev));
+  sp.bytes = want;
+  return AH_OK;
+}
+
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// tables built and uploaded, count + scan enqueued, mailbox posted: nothing waited for
+ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_view* columns, const int64_t* num_rows,
+                     const ah_array_view* filters, SlabPush** out) {
+  *out = nullptr;
+  const int slot = !co->slab_pin[0].busy ? 0 : (!co->slab_pin[1].busy ? 1 : -1);
+  if (slot < 0) return AH_NOT_YET_IMPLEMENTED;  // two pushes already in flight
+  std::unique_ptr<SlabPush> sp(new SlabPush());
+  sp->n = n;
+  sp->slot = slot;
+  sp->wave0.resize((size_t)n + 1);
+  sp->tile0.resize((size_t)n + 1);
+  int64_t nchunks = 0, nwaves = 0, ntiles = 0;
+  std::vector<int64_t> chunk0((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const int64_t len = filters[i].length;
+    chunk0[(size_t)i] = nchunks;
+    sp->wave0[(size_t)i] = nwaves;
+    sp->tile0[(size_t)i] = ntiles;
+    const int64_t c = ah_ceil_div(len, AH_FILTER_CHUNK_ROWS);
+    nchunks += c;
+    nwaves += ah_ceil_div(c, 64);
+    ntiles += ah_ceil_div(len, 4096);
+    sp->total_rows += len;
+  }
+  sp->wave0[(size_t)n] = nwaves;
+  sp->tile0[(size_t)n] = ntiles;
+  if (nwaves == 0) {  // every predicate is empty: nothing to count, nothing to append
+    *out = sp.release();
+    (*out)->slot = -1;
+    return AH_OK;
+  }
+  // pinned block: [nwaves + 1 prefix words][segs][waves][tiles]; device block: [segs][waves][tiles][chunk_prefix][wave_total][wave_prefix]
+  const size_t b_pref = up256(((size_t)nwaves + 1) * 8), b_seg = up256((size_t)n * sizeof(ah_tbl_seg)),
+               b_wav = up256((size_t)nwaves * sizeof(ah_tbl_wave)), b_til = up256((size_t)ntiles * sizeof(ah_tbl_tile));
+  const size_t b_tables = b_seg + b_wav + b_til;
+  const size_t b_cp = up256((size_t)nchunks * 4), b_wt = up256((size_t)nwaves * 4), b_wp = up256(((size_t)nwaves + 1) * 8);
+  SlabPin& pin = co->slab_pin[slot];
+  AH_TRY(slab_pin_reserve(ctx, pin, b_pref + b_tables));
+  AH_TRY(ah_pool_alloc(ctx, b_tables + b_cp + b_wt + b_wp, &sp->dev_block));
+  char* hs = (char*)pin.host + b_pref;
+  auto* segs = (ah_tbl_seg*)hs;
+  auto* waves = (ah_tbl_wave*)(hs + b_seg);
+  auto* tiles = (ah_tbl_tile*)(hs + b_seg + b_wav);
+  int64_t wi = 0, ti = 0;
+  for (int i = 0; i < n; ++i) {
+    const ah_array_view& f = filters[i];
+    ah_tbl_seg& sg = segs[i];
+    memset(&sg, 0, sizeof sg);
+    sg.mask = make_bitview(f.values, f.values_bit_offset);
+    sg.mask_valid = (f.validity && f.null_count != 0) ? make_bitview(f.validity, f.validity_bit_offset) : BitView{nullptr, 0};
+    sg.len = f.length;
+    sg.chunk0 = chunk0[(size_t)i];
+    sg.wave0 = sp->wave0[(size_t)i];
+    for (int k = 0; k < co->ncols; ++k) {
+      const ah_array_view& v = columns[(size_t)i * co->ncols + k];
+      sg.values[k] = v.values;
+      sg.vvalid[k] = (v.validity && v.null_count != 0) ? make_bitview(v.validity, v.validity_bit_offset) : BitView{nullptr, 0};
+      if (((uintptr_t)v.values) & 15) sp->aligned16 = false;
+    }
+    const int64_t nw = sp->wave0[(size_t)i + 1] - sp->wave0[(size_t)i], nt = sp->tile0[(size_t)i + 1] - sp->tile0[(size_t)i];
+    for (int64_t g = 0; g < nw; ++g) waves[wi++] = ah_tbl_wave{i, (int32_t)g};
+    for (int64_t q = 0; q < nt; ++q) tiles[ti++] = ah_tbl_tile{i, (int32_t)q};
+  }
+  char* db = (char*)sp->dev_block;
+  sp->t.segs = (const ah_tbl_seg*)db;
+  sp->t.waves = (const ah_tbl_wave*)(db + b_seg);
+  sp->t.tiles = (const ah_tbl_tile*)(db + b_seg + b_wav);
+  sp->t.nsegs = n, sp->t.nwaves = nwaves, sp->t.ntiles = ntiles;
+  sp->t.chunk_prefix = (uint32_t*)(db + b_tables);
+  sp->t.wave_total = (uint32_t*)(db + b_tables + b_cp);
+  sp->t.wave_prefix = (unsigned long long*)(db + b_tables + b_cp + b_wt);
+  ah_status st = AH_OK;
+  if (hipMemcpyAsync(db, hs, b_tables, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    st = ah_fail(ctx, AH_HIP_ERROR, "coalescer table upload failed");
+  if (st == AH_OK) st = ah_filter_table_count(ctx, sp->t, (uint64_t*)pin.dev);
+  if (st == AH_OK && ah_mail_post_async(ctx, &sp->seq) != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "coalescer count failed");
+  if (st != AH_OK) {
+    (void)ah_stream_wait(ctx);
+    ah_pool_free(ctx, sp->dev_block);
+    return st;
+  }
+  pin.busy = true;
+  *out = sp.release();
+  return AH_OK;
+}
+
+void slab_abort(ah_context* ctx, ah_coalescer* co, SlabPush* sp) {
+  if (!sp) return;
+  if (sp->slot >= 0) {
+    (void)ah_stream_wait(ctx);  // the count kernels may still be writing the tables' block and the pinned words
+    co->slab_pin[sp->slot].busy = false;
+  }
+  ah_pool_free(ctx, sp->dev_block);
+  delete sp;
+}
+
+// waits for the wave prefixes and appends the push's selected rows: the same output batches, in the same order, as n calls
+// of push_batch_with_filter.  Consumes `sp`.
+ah_status slab_end(ah_context* ctx, ah_coalescer* co, SlabPush* sp_raw) {
+  std::unique_ptr<SlabPush> sp(sp_raw);
+  if (sp->slot < 0) return AH_OK;  // nothing was enqueued (every predicate empty)
+  SlabPin& pin = co->slab_pin[sp->slot];
+  const bool later_work = sp->seq != ctx->mail_seq || ctx->inflight;
+  const hipError_t we = ah_mail_wait(ctx, sp->seq);
+  if (later_work && ctx->wait_mode != 1) ctx->inflight = true;
+  pin.busy = false;
+  struct FreeBlock {  // (pool reuse is stream-ordered behind the launches below)
+    ah_context* c;
+    void* b;
+    ~FreeBlock() { ah_pool_free(c, b); }
+  } fb{ctx, sp->dev_block};
+  if (we != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "coalescer count failed: %s", hipGetErrorString(we));
+  if (co->failed) return ah_fail(ctx, AH_INVALID_ARGUMENT, "BatchCoalescer: unusable after an earlier device error");
+  const uint64_t* P = (const uint64_t*)pin.host;  // [nwaves + 1]
+  const int64_t nwaves = sp->t.nwaves, K = (int64_t)__atomic_load_n(&P[nwaves], __ATOMIC_RELAXED);
+  if (sp->total_rows > 0) co->selectivity = (double)K / (double)sp->total_rows;
+  if (K == 0) return AH_OK;
+  const bool sparse = K * 32 <= sp->total_rows, skip = (double)K < 0.12 * (double)sp->total_rows;
+  // tiles of the count waves [w_lo, w_hi): every wave is 16 tiles except a batch's last one
+  auto tile_of_wave = [&](int64_t w) -> int64_t {  // first tile of count wave w (w == nwaves: one past the last tile)
+    if (w >= nwaves) return sp->t.ntiles;
+    const int64_t i = (int64_t)(std::upper_bound(sp->wave0.begin(), sp->wave0.end(), w) - sp->wave0.begin()) - 1;  // its batch
+    return sp->tile0[(size_t)i] + (w - sp->wave0[(size_t)i]) * 16;
+  };
+  auto first_wave_reaching = [&](int64_t pos) -> int64_t {  // smallest w with P[w] >= pos  (P is non-decreasing)
+    int64_t lo = 0, hi = nwaves;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)P[mid] >= pos) hi = mid;
+      else lo = mid + 1;
+    }
+    return lo;
+  };
+  // launch columns grouped by value width
+  int widths[4] = {1, 2, 4, 8};
+  auto scatter_all = [&](void* const* dv, uint8_t* const* db, int64_t tile_lo, int64_t tile_hi, int64_t win_lo, int64_t win_hi,
+                         int64_t out_base) -> ah_status {
+    for (int w : widths) {
+      int idx[AH_TBL_MAX_COLS], m = 0;
+      ah_tbl_dst dst[AH_TBL_MAX_COLS];
+      for (int k = 0; k < co->ncols; ++k)
+        if (co->cols[k].width == w) {
+          idx[m] = k;
+          dst[m].out_values = dv[k];
+          dst[m].out_valid = (unsigned long long*)db[k];
+          ++m;
+        }
+      if (m == 0) continue;
+      AH_TRY(ah_filter_table_scatter(ctx, sp->t, w, m, idx, dst, tile_lo, tile_hi, win_lo, win_hi, out_base, sp->aligned16, sparse, skip));
+    }
+    return AH_OK;
+  };
+  ah_status st = AH_OK;
+  bool enq = false;
+  // 1. top up the in-progress batch
+  int64_t take1 = 0;
+  const bool have_buf = co->cols[0].values != nullptr;
+  if (have_buf && co->buffered < co->target) {
+    take1 = std::min(K, co->target - co->buffered);
+    void* dv[AH_TBL_MAX_COLS];
+    uint8_t* db[AH_TBL_MAX_COLS];
+    const unsigned long long* bits[AH_TBL_MAX_COLS];
+    unsigned long long* slots[AH_TBL_MAX_COLS];
+    for (int k = 0; k < co->ncols; ++k) {
+      dv[k] = co->cols[k].values, db[k] = co->cols[k].validity;
+      bits[k] = (const unsigned long long*)co->cols[k].validity;
+      slots[k] = (unsigned long long*)co->acc + (size_t)k * 64;
+    }
+    const int64_t w_hi = first_wave_reaching(take1);  // waves [0, w_hi) start before position take1
+    st = scatter_all(dv, db, 0, tile_of_wave(w_hi), 0, take1, co->buffered);
+    enq = st == AH_OK;
+    if (st == AH_OK) st = ah_filter_count_nulls_range(ctx, co->ncols, bits, slots, co->buffered, take1);
+    if (st == AH_OK) {
+      co->buffered += take1;
+      if (co->buffered >= co->target) st = finish_buffered(ctx, co);
+    }
+  }
+  // 2. everything else: one slab of whole output batches
+  const int64_t rest = K - take1;
+  if (st == AH_OK && rest > 0) {
+    const int64_t nb = ah_ceil_div(rest, co->target), nfull = rest / co->target, tail = rest % co->target;
+    size_t off = 0, voff[AH_TBL_MAX_COLS], boff[AH_TBL_MAX_COLS];
+    for (int k = 0; k < co->ncols; ++k) {
+      voff[k] = off;
+      off += up256((size_t)nb * co->target * co->cols[k].width);
+    }
+    const size_t bits_begin = off;
+    for (int k = 0; k < co->ncols; ++k) {
+      boff[k] = off;
+      off += up256((size_t)nb * co->target / 8);
+    }
+    ah_slab* slab = nullptr;
+    st = ah_slab_create(ctx, off, &slab);
+    if (st == AH_OK) {
+      char* base = (char*)slab->block;
+      void* dv[AH_TBL_MAX_COLS];
+      uint8_t* db[AH_TBL_MAX_COLS];
+      const unsigned long long* bits[AH_TBL_MAX_COLS];
+      unsigned long long* slots[AH_TBL_MAX_COLS];
+      for (int k = 0; k < co->ncols; ++k) {
+        dv[k] = base + voff[k], db[k] = (uint8_t*)(base + boff[k]);
+        bits[k] = (const unsigned long long*)db[k];
+        slots[k] = (unsigned long long*)co->acc + (size_t)k * 64;
+      }
+      if (hipMemsetAsync(base + bits_begin, 0, off - bits_begin, ctx->stream) != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "coalescer bitmap reset failed");
+      // waves that can hold a position >= take1: from the last wave that starts at or before it
+      int64_t w_lo = first_wave_reaching(take1 + 1);  // first wave starting AFTER take1 ...
+      w_lo = w_lo > 0 ? w_lo - 1 : 0;                  // ... so the one before it holds position take1
+      if (st == AH_OK) st = scatter_all(dv, db, tile_of_wave(w_lo), sp->t.ntiles, take1, K, 0);
+      enq = enq || st == AH_OK;
+      std::shared_ptr<SlabNulls> sn;
+      if (st == AH_OK && nfull > 0) {
+        sn = std::make_shared<SlabNulls>();
+        sn->ctx = ctx;
+        sn->bytes = (size_t)nfull * co->ncols * 8;
+        void *hp = nullptr, *dp = nullptr;
+        st = ah_pinned_alloc(ctx, sn->bytes, &hp, &dp);
+        if (st == AH_OK) {
+          sn->pin = (uint64_t*)hp;
+          st = ah_filter_count_nulls_batches(ctx, co->ncols, bits, co->target, nfull, co->target, (unsigned long long*)dp);
+        }
+        if (st == AH_OK && ah_mail_post_async(ctx, &sn->seq) != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "coalescer null count failed");
+      }
+      if (st == AH_OK && tail > 0) st = ah_filter_count_nulls_range(ctx, co->ncols, bits, slots, nfull * co->target, tail);
+      if (st == AH_OK) {
+        for (int64_t j = 0; j < nfull; ++j) {
+          CoBatch b;
+          b.rows = co->target;
+          b.pending = true;
+          b.ring = -1;
+          b.slab_nulls = sn;
+          b.slab_index = j;
+          b.cols.resize((size_t)co->ncols);
+          for (int k = 0; k < co->ncols; ++k) {
+            ah_array_out& o = b.cols[(size_t)k];
+            ah_out_init(&o);
+            o.type = co->cols[k].type;
+            o.length = co->target;
+            o.values = (char*)dv[k] + (size_t)j * co->target * co->cols[k].width;
+            o.values_bytes = co->target * co->cols[k].width;
+            o.validity = db[k] + (size_t)j * co->target / 8;
+            o.validity_bytes = co->target / 8;
+            o.null_count = -1;
+            ah_slab_slice(ctx, slab, o.values);
+            ah_slab_slice(ctx, slab, o.validity);
+          }
+          co->completed.push_back(std::move(b));
+        }
+        if (tail > 0) {  // the slab's last, partial batch is the new in-progress batch (capacity: a whole target)
+          for (int k = 0; k < co->ncols; ++k) {
+            CoColumn& c = co->cols[k];
+            c.values = (char*)dv[k] + (size_t)nfull * co->target * c.width;
+            c.validity = db[k] + (size_t)nfull * co->target / 8;
+            c.vbytes = (size_t)co->target * c.width;
+            c.bbytes = (size_t)co->target / 8;
+            ah_slab_slice(ctx, slab, c.values);
+            ah_slab_slice(ctx, slab, c.validity);
+          }
+          co->buffered = tail;
+        }
+      }
+      ah_slab_unref(ctx, slab);  // the slices keep the block alive (none were made on failure: it goes back to the pool)
+    }
+  }
+  if (st != AH_OK && enq) co->failed = true;  // rows were enqueued that the bookkeeping may not cover
+  return st;
+}
+
+
+}  // namespace
+
 // `n` filtered pushes in one call, for a host that has several batches queued: the n count passes are enqueued
 // back to back and read with ONE wait (ah_filter_predicates_build), then every batch is appended exactly as n calls
 // of ah_coalescer_push_batch_with_filter would — the same output batches in the same order — without the GPU idling
@@ -761,10 +1150,17 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters(ah_context* ctx, ah_
   ah_ctx_guard _guard(ctx);
   if (!ctx || !co || n < 0 || (n > 0 && (!columns || !num_rows || !filters))) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
+  InputGuard input_guard(co, n);
   for (int i = 0; i < n; ++i) {
     if (bypassed) bypassed[i] = 0;
     if (num_rows[i] < 0) return AH_INVALID_ARGUMENT;
     AH_TRY(check_filter(ctx, co, columns + (size_t)i * co->ncols, num_rows[i], &filters[i]));
+  }
+  if (slab_eligible(ctx, co, n, columns, num_rows, filters)) {  // any number of batches: one count, one scatter per destination
+    SlabPush* sp = nullptr;
+    const ah_status bs = slab_begin(ctx, co, n, columns, num_rows, filters, &sp);
+    if (bs == AH_OK) return slab_end(ctx, co, sp);
+    if (bs != AH_NOT_YET_IMPLEMENTED) return bs;
   }
   // Grouped scatter: when there is no bypass limit and every column of every batch has the same shape (one width,
   // all nullable), the batches that land in one output window leave through ONE launch (up to 8 per launch) — 2^24-row
@@ -903,6 +1299,7 @@ ah_status append_group(ah_context* ctx, ah_coalescer* co, int m, const ah_array_
 // Calls on one coalescer must be ended in the order they were begun.  An engine loop:
 //     h1 = begin(group 1); for g in 2..: { h2 = begin(group g); end(h1); h1 = h2; }  end(h1);
 struct ah_coalescer_push {
+  SlabPush* slab = nullptr;  // the push travels as device tables (slab push): nothing else below is filled
   int n = 0, slot = -1;
   bool counted = false;  // the predicates were built synchronously in _begin (shapes the multi-count pass does not take)
   uint64_t seq = 0;
@@ -917,13 +1314,26 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters_begin(ah_context* ct
                                                                   const ah_array_view* filters, const uint64_t* tags,
                                                                   ah_coalescer_push** handle) {
   ah_ctx_guard _guard(ctx);
-  if (!ctx || !co || !handle || n < 0 || n > 64 || (n > 0 && (!columns || !num_rows || !filters))) return AH_INVALID_ARGUMENT;
+  if (!ctx || !co || !handle || n < 0 || (n > 0 && (!columns || !num_rows || !filters))) return AH_INVALID_ARGUMENT;
   *handle = nullptr;
   hipSetDevice(ctx->device);
   for (int i = 0; i < n; ++i) {
     if (num_rows[i] < 0) return AH_INVALID_ARGUMENT;
     AH_TRY(check_filter(ctx, co, columns + (size_t)i * co->ncols, num_rows[i], &filters[i]));
   }
+  if (slab_eligible(ctx, co, n, columns, num_rows, filters)) {
+    SlabPush* sp = nullptr;
+    const ah_status bs = slab_begin(ctx, co, n, columns, num_rows, filters, &sp);
+    if (bs == AH_OK) {
+      auto* hs = new ah_coalescer_push();
+      hs->n = n;
+      hs->slab = sp;
+      *handle = hs;
+      return AH_OK;
+    }
+    if (bs != AH_NOT_YET_IMPLEMENTED) return bs;
+  }
+  if (n > 64) return ah_fail(ctx, AH_INVALID_ARGUMENT, "a grouped push of more than 64 batches needs the slab path (fixed-width columns, no bypass limit, target a multiple of 64)");
   auto* h = new ah_coalescer_push();
   h->n = n;
   h->columns.assign(columns, columns + (size_t)n * co->ncols);
@@ -959,10 +1369,17 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters_end(ah_context* ctx,
   if (!ctx || !co || !h) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   ah_status st = AH_OK;
+  InputGuard input_guard(co, h->n);
   for (int i = 0; i < h->n && bypassed; ++i) bypassed[i] = 0;
+  if (h->slab) {
+    st = slab_end(ctx, co, h->slab);
+    delete h;
+    return st;
+  }
   if (h->slot >= 0) {
     st = ah_filter_predicates_end(ctx, h->n, h->preds.data(), co->cnt_pin + 64 * h->slot, h->seq, co->quant_pin + (size_t)64 * 32 * h->slot);
     co->cnt_busy[h->slot] = false;
+    if (st != AH_OK) (void)ah_stream_wait(ctx);  // the count kernels may still be writing the blocks freed below
   }
   if (st == AH_OK && co->failed) st = ah_fail(ctx, AH_INVALID_ARGUMENT, "BatchCoalescer: unusable after an earlier device error");
   if (st == AH_OK && h->n > 0)
@@ -973,6 +1390,23 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters_end(ah_context* ctx,
   return st;
 }
 
+// A begun push the host will not end (an error between begin and end): waits for its count kernels, gives its pinned slot
+// and predicate blocks back.  The batches of the group are NOT appended; their sequence numbers are still consumed.
+extern "C" void ah_coalescer_push_abort(ah_context* ctx, ah_coalescer* co, ah_coalescer_push* h) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !co || !h) return;
+  hipSetDevice(ctx->device);
+  InputGuard input_guard(co, h->n);
+  if (h->slab) {
+    slab_abort(ctx, co, h->slab);
+  } else {
+    (void)ah_stream_wait(ctx);
+    if (h->slot >= 0) co->cnt_busy[h->slot] = false;
+    for (auto* p : h->preds) ah_filter_predicate_free(ctx, p);
+  }
+  delete h;
+}
+
 // push_batch_with_indices (coalesce.rs:289-297): `take_record_batch(&batch, indices)` then push_batch of the result.
 // The taken columns are owned here: generic columns adopt them, fixed-width ones are copied into the in-progress
 // buffers (the reference materialises and copies as well — its own "todo: optimize").
@@ -981,6 +1415,7 @@ extern "C" ah_status ah_coalescer_push_batch_with_indices(ah_context* ctx, ah_co
   ah_ctx_guard _guard(ctx);
   if (!ctx || !co || !columns || !indices || num_rows < 0) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
+  InputGuard input_guard(co, 1);
   AH_TRY(check_columns(ctx, co, columns, num_rows));
   AH_TRY(begin_input(ctx, co));
   std::vector<ah_array_out> outs((size_t)co->ncols);
@@ -1078,4 +1513,30 @@ extern "C" ah_status ah_coalescer_next_completed_batch(ah_context* ctx, ah_coale
   if (tag) *tag = b.tag;
   co->completed.pop_front();
   return AH_OK;
+}
+
+// next_completed_batch for up to `max_batches` batches in one call (a slab push completes thousands of 8192-row batches at
+// once): outs receives *n x n_columns results, batch-major; num_rows / tags (optional) one entry per batch.
+extern "C" ah_status ah_coalescer_next_completed_batches(ah_context* ctx, ah_coalescer* co, int32_t max_batches, ah_array_out* outs,
+                                                         int64_t* num_rows, uint64_t* tags, int32_t* n) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !co || !outs || !num_rows || !n || max_batches < 0) return AH_INVALID_ARGUMENT;
+  *n = 0;
+  while (*n < max_batches && !co->completed.empty()) {
+    CoBatch& b = co->completed.front();
+    AH_TRY(resolve_pending(ctx, co, b));
+    for (int i = 0; i < co->ncols; ++i) outs[(size_t)*n * co->ncols + i] = b.cols[i];
+    num_rows[*n] = b.rows;
+    if (tags) tags[*n] = b.tag;
+    co->completed.pop_front();
+    *n += 1;
+  }
+  return AH_OK;
+}
+
+// ah_array_release for `n` results in one call
+extern "C" void ah_arrays_release(ah_context* ctx, ah_array_out* outs, int64_t n) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !outs) return;
+  for (int64_t i = 0; i < n; ++i) ah_array_release(ctx, &outs[i]);
 }

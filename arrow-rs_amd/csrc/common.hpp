@@ -45,6 +45,9 @@ struct ah_context {
   std::map<size_t, std::vector<void*>> pool_free;
   std::unordered_map<void*, size_t> pool_live;  // ptr -> rounded size
   std::unordered_map<void*, size_t> redzones;   // AH_DEBUG_REDZONE: ptr -> requested size
+  // output buffers carved out of ONE pool block (BatchCoalescer's slab push: thousands of 8192-row output batches per
+  // allocation): slice pointer -> its slab; the block goes back to the pool when the last slice (and the creator) let go
+  std::unordered_map<void*, struct ah_slab*> slab_slices;
   struct hook_entry {
     ah_free_fn free_;
     void* user;
@@ -194,6 +197,17 @@ bool ah_type_is_signed(ah_type t);
 bool ah_type_is_float(ah_type t);
 
 void ah_out_init(ah_array_out* out);
+
+// context.hip: a pool block whose slices are handed out as results (released through ah_array_release / ah_out_free like
+// any other output buffer)
+struct ah_slab {
+  void* block = nullptr;
+  size_t bytes = 0;
+  int64_t refs = 0;
+};
+ah_status ah_slab_create(ah_context* ctx, size_t bytes, ah_slab** out);  // refs = 1: the creator's
+void ah_slab_slice(ah_context* ctx, ah_slab* s, void* ptr);              // registers `ptr` (inside the block) as an output buffer
+void ah_slab_unref(ah_context* ctx, ah_slab* s);                         // the creator (or a slice) lets go
 
 // strings.hip: byte ranges -> (offsets, bytes); take for Utf8 / LargeUtf8
 ah_status ah_ranges_to_strings(ah_context* ctx, bool large, const uint8_t* src, const void* starts,

@@ -207,8 +207,34 @@ ah_status ah_out_alloc(ah_context* ctx, size_t bytes, void** out) {
   return ah_pool_alloc(ctx, bytes, out);
 }
 
+ah_status ah_slab_create(ah_context* ctx, size_t bytes, ah_slab** out) {
+  *out = nullptr;
+  void* b = nullptr;
+  AH_TRY(ah_pool_alloc(ctx, bytes ? bytes : 8, &b));
+  auto* s = new ah_slab();
+  s->block = b, s->bytes = bytes, s->refs = 1;
+  *out = s;
+  return AH_OK;
+}
+void ah_slab_unref(ah_context* ctx, ah_slab* s) {
+  if (!s || --s->refs > 0) return;
+  ah_pool_free(ctx, s->block);
+  delete s;
+}
+void ah_slab_slice(ah_context* ctx, ah_slab* s, void* ptr) {
+  ctx->slab_slices[ptr] = s;
+  s->refs += 1;
+}
+
 void ah_out_free(ah_context* ctx, void* p, size_t bytes) {
   if (!p) return;
+  auto sl = ctx->slab_slices.find(p);
+  if (sl != ctx->slab_slices.end()) {  // a slice of a slab: the block outlives it while other slices are out
+    ah_slab* s = sl->second;
+    ctx->slab_slices.erase(sl);
+    ah_slab_unref(ctx, s);
+    return;
+  }
   auto rz = ctx->redzones.find(p);
   if (rz != ctx->redzones.end()) {
     unsigned char tail[RZ];

@@ -931,6 +931,152 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_multi_sparse_k
   sparse_tile<W, true>(a, gtile - sg.tile0 + sg.tile_lo, lane, wave, src.values, src.vvalid, d.out_values, d.out_valid, nullptr);
 }
 
+// ---- batch tables in device memory (filter_internal.hpp: ah_tbl_*).  One wave per 64-chunk group of one batch, as
+// filter_count_small_kernel; where the batch's tables live comes from the wave table instead of the kernel arguments.
+__global__ void __launch_bounds__(64) filter_count_table_kernel(ah_tbl_push t) {
+  const ah_tbl_wave wv = t.waves[blockIdx.x];
+  const ah_tbl_seg& o = t.segs[wv.seg];
+  __shared__ uint32_t s_cnt[64];
+  const int lane = threadIdx.x;
+  const int64_t chunk_base = (int64_t)wv.group * 64, len = o.len;
+  const BitView mask = o.mask, mask_valid = o.mask_valid;
+  const bool has_mv = mask_valid.words != nullptr;
+  BvRaw rm[16], rv[16] = {};
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
+    rm[it] = bv_issue(mask, s < len ? s : 0, len);
+  }
+  if (has_mv) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
+      rv[it] = bv_issue(mask_valid, s < len ? s : 0, len);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
+    const int64_t sc = s < len ? s : 0;
+    uint64_t mk = bv_finish(rm[it], sc, len);
+    if (has_mv) mk &= bv_finish(rv[it], sc, len);
+    if (s >= len) mk = 0;
+    int c = __popcll(mk);
+    c += __shfl_xor(c, 1, 64);
+    c += __shfl_xor(c, 2, 64);
+    c += __shfl_xor(c, 4, 64);
+    c += __shfl_xor(c, 8, 64);
+    if ((lane & 15) == 0) s_cnt[it * 4 + (lane >> 4)] = (uint32_t)c;
+  }
+  __syncthreads();
+  const int v = (int)s_cnt[lane];
+  const int incl = wave_scan_incl(v);
+  const int64_t nchunks = (len + CHUNK_ROWS - 1) / CHUNK_ROWS;
+  if (chunk_base + lane < nchunks) t.chunk_prefix[o.chunk0 + chunk_base + lane] = (uint32_t)(incl - v);
+  if (lane == 63) t.wave_total[blockIdx.x] = (uint32_t)incl;
+}
+// one block: exclusive scan of the wave totals -> wave_prefix[0 .. nwaves] (the last entry is K), in device memory for the
+// scatter and in the host's pinned words (what the host waits for; the mailbox is posted by the kernel behind this one)
+__global__ void __launch_bounds__(1024) filter_scan_table_kernel(ah_tbl_push t, uint64_t* pin) {
+  __shared__ unsigned long long s_wave[16];
+  __shared__ unsigned long long s_carry;
+  const int th = threadIdx.x, lane = th & 63, wave = th >> 6;
+  if (th == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < t.nwaves; base += 1024) {
+    unsigned long long v = (base + th < t.nwaves) ? t.wave_total[base + th] : 0ull, incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      unsigned long long u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long wbase = s_carry;
+    for (int w = 0; w < wave; ++w) wbase += s_wave[w];
+    if (base + th < t.nwaves) t.wave_prefix[base + th] = wbase + incl - v;
+    __syncthreads();
+    if (th == 1023) s_carry = wbase + incl;
+    __syncthreads();
+  }
+  if (th == 0) t.wave_prefix[t.nwaves] = s_carry;
+  __threadfence();
+  __syncthreads();
+  for (int64_t i = th; i <= t.nwaves; i += 1024)
+    __hip_atomic_store(pin + i, (uint64_t)t.wave_prefix[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct TblScatterArgs {
+  ah_tbl_push t;
+  int64_t tile_lo, ntiles;  // this launch walks tiles [tile_lo, tile_lo + ntiles) of the tile table
+  int xcd_remap;
+  int64_t win_lo, win_hi, out_base;
+  int col_index[AH_TBL_MAX_COLS];
+  ah_tbl_dst dst[AH_TBL_MAX_COLS];
+};
+__device__ __forceinline__ ScatterArgs tbl_tile_args(const TblScatterArgs& m, const ah_tbl_seg& sg) {
+  ScatterArgs a{};
+  a.mask = sg.mask;
+  a.mask_valid = sg.mask_valid;
+  a.len = sg.len;
+  a.chunk_prefix = m.t.chunk_prefix + sg.chunk0;
+  a.group_prefix = m.t.wave_prefix + sg.wave0;  // positions in the filtered stream of the WHOLE push
+  a.group_shift = 6;
+  a.out_base = m.out_base;
+  a.win_lo = m.win_lo;
+  a.win_hi = m.win_hi;
+  return a;
+}
+template <int W, int V, bool SKIP>
+__global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_table_kernel(TblScatterArgs m) {
+  const int64_t g = scatter_tile_of_block(m.xcd_remap, m.ntiles);
+  if (g < 0) return;
+  const ah_tbl_tile tt = m.t.tiles[m.tile_lo + g];
+  const ah_tbl_seg& sg = m.t.segs[tt.seg];
+  const ScatterArgs a = tbl_tile_args(m, sg);
+  const int c = m.col_index[blockIdx.y];
+  const ah_tbl_dst d = m.dst[blockIdx.y];
+  scatter_tile<W, V, true, SKIP>(a, tt.tile, sg.values[c], sg.vvalid[c], d.out_values, d.out_valid, nullptr);
+}
+template <int W>
+__global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_table_sparse_kernel(TblScatterArgs m) {
+  static_assert(tile_rows(W) == 4096, "the tile table is in 4096-row tiles");
+  const int lane = threadIdx.x & 63, wave = ah_uniform((int)(threadIdx.x >> 6));
+  const int64_t nwg = (m.ntiles + 3) >> 2;
+  const int64_t wg = scatter_tile_of_block(m.xcd_remap, nwg);
+  if (wg < 0) return;
+  const int64_t g = wg * 4 + wave;
+  if (g >= m.ntiles) return;
+  const ah_tbl_tile tt = m.t.tiles[m.tile_lo + g];
+  const ah_tbl_seg& sg = m.t.segs[tt.seg];
+  ScatterArgs a = tbl_tile_args(m, sg);
+  a.nulls_mode = 1;
+  const int c = m.col_index[blockIdx.y];
+  const ah_tbl_dst d = m.dst[blockIdx.y];
+  sparse_tile<W, true>(a, tt.tile, lane, wave, sg.values[c], sg.vvalid[c], d.out_values, d.out_valid, nullptr);
+}
+
+// zero bits of `nbatches` consecutive `stride`-bit ranges of up to 8 bitmaps (grid: batch x column; one wave each)
+struct NullBatches {
+  const unsigned long long* bits[AH_TBL_MAX_COLS];
+  int ncols;
+  int64_t stride, nbatches, last_rows;
+  unsigned long long* out;
+};
+__global__ void __launch_bounds__(64) count_nulls_batches_kernel(NullBatches nb) {
+  const int64_t j = blockIdx.x;
+  const unsigned long long* bits = nb.bits[blockIdx.y] + j * (nb.stride >> 6);
+  const int64_t rows = j == nb.nbatches - 1 ? nb.last_rows : nb.stride, nwords = (rows + 63) >> 6;
+  unsigned long long nulls = 0;
+  for (int64_t w = threadIdx.x; w < nwords; w += 64) {
+    unsigned long long in = ~0ull;
+    if (w == nwords - 1 && (rows & 63)) in = (1ull << (rows & 63)) - 1ull;
+    nulls += (unsigned long long)__popcll(in & ~bits[w]);
+  }
+  nulls = wave_reduce_add64(nulls);
+  if (threadIdx.x == 0) __hip_atomic_store(nb.out + j * nb.ncols + blockIdx.y, nulls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // NULL rows among destination rows [bit_lo, bit_lo + nbits) of up to 8 columns (blockIdx.y), added to each column's
 // counters: what the sparse multi-batch launch appended, counted from the in-progress bitmaps afterwards
 struct RangeCount {
@@ -1668,6 +1814,90 @@ static ah_status launch_multi_sparse(ah_context* ctx, const MultiArgs& m, int wi
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, ah_ceil_div(nwords, 256 * 4)));
     range_null_count_kernel<<<dim3(gx, (unsigned)ncols), 256, 0, ctx->stream>>>(r);
   }
+  return AH_OK;
+}
+
+// ---- batch tables (filter_internal.hpp)
+ah_status ah_filter_table_count(ah_context* ctx, const ah_tbl_push& t, uint64_t* pin_dev) {
+  if (t.nwaves < 1 || t.nsegs < 1) return AH_INVALID_ARGUMENT;
+  ctx->inflight = true;
+  {
+    ah_prof_scope ps(ctx, "filter_count");
+    filter_count_table_kernel<<<(unsigned)t.nwaves, 64, 0, ctx->stream>>>(t);
+    filter_scan_table_kernel<<<1, 1024, 0, ctx->stream>>>(t, pin_dev);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "filter count failed: %s", hipGetErrorString(e));
+  return AH_OK;
+}
+
+ah_status ah_filter_table_scatter(ah_context* ctx, const ah_tbl_push& t, int width, int ncols, const int* col_index,
+                                  const ah_tbl_dst* dst, int64_t tile_lo, int64_t tile_hi, int64_t win_lo, int64_t win_hi,
+                                  int64_t out_base, bool aligned16, bool sparse, bool skip) {
+  if (ncols < 1 || ncols > AH_TBL_MAX_COLS || tile_hi <= tile_lo || win_hi <= win_lo) return ncols < 1 || ncols > AH_TBL_MAX_COLS ? AH_INVALID_ARGUMENT : AH_OK;
+  TblScatterArgs m{};
+  m.t = t;
+  m.tile_lo = tile_lo;
+  m.ntiles = tile_hi - tile_lo;
+  static const char* xr = getenv("AH_FILTER_XCD");
+  m.xcd_remap = (xr && xr[0] == '0') ? 0 : 1;
+  m.win_lo = win_lo, m.win_hi = win_hi, m.out_base = out_base;
+  for (int c = 0; c < ncols; ++c) m.col_index[c] = col_index[c], m.dst[c] = dst[c];
+  ctx->inflight = true;
+  ah_prof_scope ps(ctx, "filter_scatter");
+  if (sparse) {
+    const int64_t nwg = (m.ntiles + 3) >> 2;
+    const dim3 grid((unsigned)(m.xcd_remap ? 8 * ((nwg + 7) / 8) : nwg), (unsigned)ncols);
+    switch (width) {
+      case 1: filter_scatter_table_sparse_kernel<1><<<grid, SCATTER_THREADS, 0, ctx->stream>>>(m); break;
+      case 2: filter_scatter_table_sparse_kernel<2><<<grid, SCATTER_THREADS, 0, ctx->stream>>>(m); break;
+      case 4: filter_scatter_table_sparse_kernel<4><<<grid, SCATTER_THREADS, 0, ctx->stream>>>(m); break;
+      case 8: filter_scatter_table_sparse_kernel<8><<<grid, SCATTER_THREADS, 0, ctx->stream>>>(m); break;
+      default: return ah_fail(ctx, AH_INVALID_ARGUMENT, "unsupported value width %d", width);
+    }
+  } else {
+    const dim3 grid((unsigned)(m.xcd_remap ? 8 * ((m.ntiles + 7) / 8) : m.ntiles), (unsigned)ncols);
+#define AH_TBL(W, V)                                                                                        \
+  if (!aligned16) filter_scatter_table_kernel<W, 1, false><<<grid, SCATTER_THREADS, 0, ctx->stream>>>(m);   \
+  else if (skip) filter_scatter_table_kernel<W, V, true><<<grid, SCATTER_THREADS, 0, ctx->stream>>>(m);     \
+  else filter_scatter_table_kernel<W, V, false><<<grid, SCATTER_THREADS, 0, ctx->stream>>>(m)
+    switch (width) {
+      case 1: AH_TBL(1, 16); break;
+      case 2: AH_TBL(2, 8); break;
+      case 4: AH_TBL(4, 4); break;
+      case 8: AH_TBL(8, 2); break;
+      default: return ah_fail(ctx, AH_INVALID_ARGUMENT, "unsupported value width %d", width);
+    }
+#undef AH_TBL
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "table scatter failed: %s", hipGetErrorString(e));
+  return AH_OK;
+}
+
+ah_status ah_filter_count_nulls_batches(ah_context* ctx, int ncols, const unsigned long long* const* bits, int64_t stride,
+                                        int64_t nbatches, int64_t last_rows, unsigned long long* out) {
+  if (ncols < 1 || ncols > AH_TBL_MAX_COLS || (stride & 63) || nbatches < 1) return AH_INVALID_ARGUMENT;
+  NullBatches nb{};
+  for (int c = 0; c < ncols; ++c) nb.bits[c] = bits[c];
+  nb.ncols = ncols, nb.stride = stride, nb.nbatches = nbatches, nb.last_rows = last_rows, nb.out = out;
+  count_nulls_batches_kernel<<<dim3((unsigned)nbatches, (unsigned)ncols), 64, 0, ctx->stream>>>(nb);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "null count failed: %s", hipGetErrorString(e));
+  return AH_OK;
+}
+ah_status ah_filter_count_nulls_range(ah_context* ctx, int ncols, const unsigned long long* const* bits, unsigned long long* const* slots,
+                                      int64_t bit_lo, int64_t nbits) {
+  if (ncols < 1 || ncols > SCATTER_MAX_COLS) return AH_INVALID_ARGUMENT;
+  if (nbits <= 0) return AH_OK;
+  RangeCount r{};
+  for (int c = 0; c < ncols; ++c) r.bits[c] = bits[c], r.slots[c] = slots[c];
+  r.bit_lo = bit_lo, r.nbits = nbits;
+  const int64_t nwords = ((bit_lo + nbits - 1) >> 6) - (bit_lo >> 6) + 1;
+  const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, ah_ceil_div(nwords, 256 * 4)));
+  range_null_count_kernel<<<dim3(gx, (unsigned)ncols), 256, 0, ctx->stream>>>(r);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "null count failed: %s", hipGetErrorString(e));
   return AH_OK;
 }
 

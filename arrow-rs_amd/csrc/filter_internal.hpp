@@ -53,6 +53,51 @@ constexpr int64_t AH_FILTER_SMALL_MAX = 1 << 20;
 ah_status ah_filter_small(ah_context* ctx, int ncols, const ah_array_view* columns, const ah_array_view* predicate,
                           ah_array_out* outs, int64_t* out_rows);  // granule of the count pass: 16 mask words
 
+// ---- batch tables in device memory (round 5; BatchCoalescer's slab push at the reference's operating point: thousands of
+// 8192-row input batches per call, coalesce.rs:172-173).  The grouped push of round 4 passed up to 8 (batch, window) segments
+// BY VALUE in the kernel arguments: 1 900 grouped calls and 12 000 output-batch allocations per 1e9 rows at 8192-row batches.
+// Here the host writes one table entry per batch (and per 64-chunk count group, and per 4096-row tile), uploads the tables
+// with one copy, and ONE count launch + ONE scan + ONE scatter launch per destination cover the whole push.
+constexpr int AH_TBL_MAX_COLS = 8;
+struct ah_tbl_seg {   // one input batch
+  BitView mask, mask_valid;   // mask_valid.words == nullptr: the predicate has no nulls
+  int64_t len;                // predicate length (<= the batch's rows)
+  int64_t chunk0;             // this batch's first entry in the push's chunk-prefix array (one per 1024 rows)
+  int64_t wave0;              // ... and in its wave-prefix array (one per 64 chunks = 65 536 rows)
+  const void* values[AH_TBL_MAX_COLS];
+  BitView vvalid[AH_TBL_MAX_COLS];  // words == nullptr: every row valid
+};
+struct ah_tbl_wave { int32_t seg, group; };   // count wave w: 64-chunk group `group` of batch `seg`
+struct ah_tbl_tile { int32_t seg, tile; };    // scatter tile t: 4096-row tile `tile` of batch `seg`
+struct ah_tbl_push {                          // all device pointers
+  const ah_tbl_seg* segs;
+  const ah_tbl_wave* waves;
+  const ah_tbl_tile* tiles;
+  int64_t nsegs, nwaves, ntiles;
+  uint32_t* chunk_prefix;            // selected rows of the wave's 64-chunk group before each chunk
+  uint32_t* wave_total;              // selected rows per count wave
+  unsigned long long* wave_prefix;   // [nwaves + 1]: position of each wave's first selected row in the push's filtered stream
+};
+// count + scan, enqueued only: pin_dev[w] = position of count wave w's first selected row (w = 0 .. nwaves - 1), pin_dev[nwaves] = K
+ah_status ah_filter_table_count(ah_context* ctx, const ah_tbl_push& t, uint64_t* pin_dev);
+struct ah_tbl_dst {
+  void* out_values;
+  unsigned long long* out_valid;  // zero-initialised words
+};
+// positions [win_lo, win_hi) of the push's filtered stream -> destination rows out_base + (pos - win_lo), for `ncols` columns
+// of one value width (launch column y reads table column col_index[y]); tiles [tile_lo, tile_hi) of the tile table
+ah_status ah_filter_table_scatter(ah_context* ctx, const ah_tbl_push& t, int width, int ncols, const int* col_index,
+                                  const ah_tbl_dst* dst, int64_t tile_lo, int64_t tile_hi, int64_t win_lo, int64_t win_hi,
+                                  int64_t out_base, bool aligned16, bool sparse, bool skip);
+// NULL rows (0 bits) of bit ranges, counted after a scatter that kept no counters:
+//   batch form: for j < nbatches, column c < ncols: out[j * ncols + c] = zero bits among bits [j * stride, j * stride + rows_j)
+//   of bits[c] (rows_j = stride except for the last batch: last_rows); `out` may be device-visible pinned memory
+ah_status ah_filter_count_nulls_batches(ah_context* ctx, int ncols, const unsigned long long* const* bits, int64_t stride,
+                                        int64_t nbatches, int64_t last_rows, unsigned long long* out);
+//   range form: slots[c][..] += zero bits among bits [bit_lo, bit_lo + nbits) of bits[c]   (c < ncols <= 8)
+ah_status ah_filter_count_nulls_range(ah_context* ctx, int ncols, const unsigned long long* const* bits, unsigned long long* const* slots,
+                                      int64_t bit_lo, int64_t nbits);
+
 // filter.hip: K2 (scan of the group totals; K lands in pinned slot `slot`, the mailbox is posted with `seq` != 0)
 void ah_filter_launch_group_scan(ah_context* ctx, const uint32_t* group_total, int64_t ngroups, unsigned long long* group_prefix,
                                  unsigned long long* total, int slot, uint64_t seq);

@@ -393,6 +393,16 @@ AH_API ah_status ah_coalescer_finish_buffered_batch(ah_context* ctx, ah_coalesce
 /* *num_rows = -1 when no batch is ready; outs[n_columns] are released with ah_array_release */
 AH_API ah_status ah_coalescer_next_completed_batch(ah_context* ctx, ah_coalescer* co, ah_array_out* outs, int64_t* num_rows,
                                                    uint64_t* tag);
+/* next_completed_batch for up to max_batches batches in one call: outs receives *n x n_columns results (batch-major),
+ * num_rows and (optional) tags one entry per batch.  A grouped push of 8192-row batches (the reference's operating
+ * point, coalesce.rs:172-173) completes thousands of output batches at once. */
+AH_API ah_status ah_coalescer_next_completed_batches(ah_context* ctx, ah_coalescer* co, int32_t max_batches,
+                                                     ah_array_out* outs, int64_t* num_rows, uint64_t* tags, int32_t* n);
+/* ah_array_release for n results in one call */
+AH_API void ah_arrays_release(ah_context* ctx, ah_array_out* outs, int64_t n);
+/* Gives up a push begun with ah_coalescer_push_batches_with_filters_begin (waits for its count kernels, frees its
+ * resources).  Its batches are not appended; their sequence numbers are consumed like those of a failed push. */
+AH_API void ah_coalescer_push_abort(ah_context* ctx, ah_coalescer* co, ah_coalescer_push* handle);
 
 /* ------------------------------------------------------------------ take */
 /* arrow_select::take::take (arrow-select/src/take.rs:89).  indices.type is any

@@ -1546,6 +1546,124 @@ def test_batch_coalescer_grouped_pushes_one_launch_per_window(ctx, oracle, seed)
     assert co.is_empty()
 
 
+def _expected_stream(host_cols, keep, target):
+    """What BatchCoalescer must emit for a stream of filtered pushes (coalesce.rs:229-330): the selected rows of the whole
+    stream, in order, cut into `target`-row batches — an independent numpy statement of the same thing the coalesce.rs model
+    computes push by push.  -> list of batches, each a list of HostArray (validity None iff the batch holds no null)."""
+    sel = [HostArray(c.data_type, np.asarray(c.values)[keep], None if c.valid is None else np.asarray(c.valid)[keep]) for c in host_cols]
+    k = int(keep.sum())
+    out = []
+    for lo in range(0, k, target):
+        n = min(target, k - lo)
+        batch = []
+        for c in sel:
+            piece = c.slice(lo, n)
+            nulls = 0 if piece.valid is None else int((~piece.valid).sum())
+            batch.append(HostArray(piece.data_type, piece.values, piece.valid if nulls else None))
+        out.append(batch)
+    return out
+
+
+def _drain_and_check(co, expected, tag):
+    """every completed batch (bulk fetch) against the head of `expected`; -> batches consumed"""
+    got = co.next_completed_batches()
+    assert len(got) <= len(expected), f"{tag}: device produced {len(got)} batches, expected at most {len(expected)}"
+    for j, b in enumerate(got):
+        exp = expected[j]
+        assert b.num_rows() == len(exp[0]), f"{tag}: batch {j} rows {b.num_rows()} != {len(exp[0])}"
+        for c, e in zip(b.columns, exp):
+            check(c, e, f"{tag} batch {j}")
+            assert_same_nulls_presence(host(c), e, f"{tag} batch {j}")
+    del expected[:len(got)]
+    return len(got)
+
+
+@pytest.mark.parametrize("shape", ["i64_f64_8192x1024", "mixed_widths_ragged", "sparse_0.001", "dense_0.6_no_validity"])
+def test_batch_coalescer_slab_push_reference_operating_point(ctx, shape):
+    """the reference's own operating point — 8192-row input batches, target 8192 (coalesce.rs:172-173,
+    arrow/benches/coalesce_kernels.rs:34) — through the slab push: ANY number of batches per call, one count + one scatter
+    launch per destination, output batches carved from one slab.  1 024 batches in one call, then pipelined groups of 256
+    (begin / end, two in flight), then single pushes and grouped pushes alternating (the slab continues the in-progress batch
+    of the round-4 paths and vice versa).  Every output batch against an independent numpy statement of the stream."""
+    rng = np.random.default_rng(_seed("slab-" + shape))
+    if shape == "i64_f64_8192x1024":
+        dts, target, sizes, p_sel = [A.Int64, A.Float64], 8192, [8192] * 1024, 0.1
+    elif shape == "mixed_widths_ragged":
+        dts, target, p_sel = [A.Int32, A.Int64, A.Int8, A.Float64, A.Int16], 4096, 0.13
+        sizes = [int(x) for x in rng.integers(0, 20000, 400)] + [70000, 1, 0, 131072 + 5]
+    elif shape == "sparse_0.001":
+        dts, target, sizes, p_sel = [A.Int64, A.Float64], 8192, [8192] * 700 + [65536 * 2 + 17] * 3, 0.001
+    else:
+        dts, target, sizes, p_sel = [A.Float64, A.Int64], 1 << 16, [8192] * 300, 0.6
+    total = sum(sizes)
+    names = [f"c{k}" for k in range(len(dts))]
+    with_valid = shape != "dense_0.6_no_validity"
+    hcols = [HostArray(dt, _rand_values(rng, dt, total), (rng.random(total) < 0.9) if (with_valid or k == 1) and k != 2 else None)
+             for k, dt in enumerate(dts)]
+    fbits = rng.random(total) < p_sel
+    fvalid = (rng.random(total) < 0.95) if shape != "sparse_0.001" else None
+    hf = HostArray(A.Boolean, fbits, fvalid)
+    keep = fbits & (fvalid if fvalid is not None else True)
+    dcols = [c.to_device(ctx) for c in hcols]
+    df = hf.to_device(ctx)
+    pairs, off = [], 0
+    for n in sizes:  # zero-copy device slices: ragged sizes give every bit offset
+        pairs.append((A.RecordBatch(names, [c.slice(off, n) for c in dcols], n), df.slice(off, n)))
+        off += n
+    expected_all = _expected_stream(hcols, keep, target)
+
+    # (a) everything in ONE call
+    co = K.BatchCoalescer.new(names, dts, target, ctx)
+    expected = [list(b) for b in expected_all]
+    co.push_batches_with_filters(pairs)
+    assert co.get_buffered_rows() == int(keep.sum()) % target
+    _drain_and_check(co, expected, f"{shape} one call")
+    co.finish_buffered_batch()
+    _drain_and_check(co, expected, f"{shape} one call, tail")
+    assert not expected and co.is_empty()
+
+    # (b) pipelined groups: begin of group g + 1 before end of group g
+    co = K.BatchCoalescer.new(names, dts, target, ctx)
+    expected = [list(b) for b in expected_all]
+    gsz = 256
+    groups = [pairs[i:i + gsz] for i in range(0, len(pairs), gsz)]
+    pending = co.push_batches_with_filters_begin(groups[0])
+    for g in groups[1:]:
+        nxt = co.push_batches_with_filters_begin(g)
+        pending.end()
+        pending = nxt
+        _drain_and_check(co, expected, f"{shape} pipelined")
+    pending.end()
+    co.finish_buffered_batch()
+    _drain_and_check(co, expected, f"{shape} pipelined, tail")
+    assert not expected and co.is_empty()
+
+    # (c) single pushes (round-4 paths: speculative scatter into the in-progress buffers) and grouped pushes alternating,
+    # an aborted group in between (its batches are NOT appended)
+    co = K.BatchCoalescer.new(names, dts, target, ctx)
+    i, step, kept = 0, 0, np.zeros(total, dtype=bool)
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    while i < len(pairs):
+        if step % 3 == 0:
+            co.push_batch_with_filter(*pairs[i])
+            kept[starts[i]:starts[i + 1]] = True
+            i += 1
+        elif step % 7 == 4:
+            h = co.push_batches_with_filters_begin(pairs[i:i + 5])
+            h.abort()
+            i += 5
+        else:
+            m = int(rng.integers(2, 90))
+            co.push_batches_with_filters(pairs[i:i + m])
+            kept[starts[i]:starts[min(i + m, len(pairs))]] = True
+            i += m
+        step += 1
+    co.finish_buffered_batch()
+    expected = _expected_stream(hcols, keep & kept, target)
+    _drain_and_check(co, expected, f"{shape} alternating")
+    assert not expected and co.is_empty()
+
+
 def test_batch_coalescer_generic_columns(ctx, oracle):
     """Boolean / Utf8 / LargeUtf8 columns go through GenericInProgressArray (coalesce/generic.rs): buffered
     slices and filtered arrays, `concat` on finish — next to a primitive column on the fused path; same batch
