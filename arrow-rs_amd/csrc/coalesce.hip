@@ -29,6 +29,7 @@
 #include "filter_internal.hpp"
 
 #include <algorithm>
+#include <ctime>
 #include <deque>
 #include <memory>
 #include <vector>
@@ -57,6 +58,27 @@ ah_status ah_filter_predicates_end(ah_context*, int32_t, ah_filter_predicate**, 
 extern "C" ah_status ah_take(ah_context*, const ah_array_view*, const ah_array_view*, int32_t, ah_array_out*);
 
 namespace {
+
+// AH_COALESCE_TIMING=1: host time of the slab push's phases, printed when a coalescer is destroyed (profiles/r05_coalesce_sweep.md)
+struct SlabTiming {
+  bool on = false;
+  double build = 0, upload_count = 0, wait = 0, append = 0;
+  int64_t pushes = 0, batches = 0;
+};
+SlabTiming& slab_timing() {
+  static SlabTiming t = [] {
+    SlabTiming x;
+    const char* e = getenv("AH_COALESCE_TIMING");
+    x.on = e && e[0] == '1';
+    return x;
+  }();
+  return t;
+}
+double now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
 
 // an owned array shared by the pieces cut out of it
 struct GenOwner {
@@ -128,6 +150,12 @@ struct CoBatch {
   // a batch carved out of a slab push: its null counts are words [slab_index * ncols, ...) of the push's pinned block
   std::shared_ptr<struct SlabNulls> slab_nulls;
   int64_t slab_index = 0;
+  // run_n > 0: this entry stands for run_n consecutive target-row batches of one slab (batch j = rows [j * target, ...) of the
+  // base pointers); they are materialised one by one when fetched — a push at the reference's batch sizes completes thousands
+  int64_t run_n = 0, run_next = 0;
+  ah_slab* run_slab = nullptr;  // one reference held until the run is used up
+  std::vector<void*> run_values;
+  std::vector<uint8_t*> run_valid;
 };
 
 // null counts of the full output batches of one slab push, written by ONE kernel into pinned words the batches share
@@ -159,6 +187,7 @@ struct ah_coalescer {
   std::vector<CoColumn> cols;
   int64_t buffered = 0;
   std::deque<CoBatch> completed;
+  int64_t completed_batches = 0;  // batches the queue stands for (a slab run counts each of its batches)
   uint64_t* acc = nullptr;  // device: 64 appended-null counters per column of the in-progress batch (scatter tiles spread
                             // their atomics over them; copies add to the first); summed once per finished batch
   uint64_t* pin = nullptr;      // own pinned words for the finished batches' null counts (host view / device view)
@@ -398,7 +427,7 @@ ah_status finish_buffered(ah_context* ctx, ah_coalescer* co) {  // coalesce.rs:5
     c.values = nullptr;
     c.validity = nullptr;
   }
-  co->completed.push_back(std::move(b));
+  co->completed.push_back(std::move(b)), co->completed_batches += 1;
   co->buffered = 0;
   return AH_OK;
 }
@@ -482,7 +511,7 @@ ah_status bypass(ah_context* ctx, ah_coalescer* co, const ah_array_view* columns
     }
   }
   if (co->has_views) b.sources.push_back(co->cur_seq);  // the batch leaves with its own buffers, indices untouched
-  co->completed.push_back(std::move(b));
+  co->completed.push_back(std::move(b)), co->completed_batches += 1;
   return AH_OK;
 }
 
@@ -518,6 +547,53 @@ ah_status push_batch_impl(ah_context* ctx, ah_coalescer* co, const ah_array_view
 
 void release_batch(ah_context* ctx, CoBatch& b) {
   for (auto& o : b.cols) ah_array_release(ctx, &o);
+  if (b.run_slab) ah_slab_unref(ctx, b.run_slab), b.run_slab = nullptr;
+}
+
+// the front entry of the completed queue as ONE batch: outs[0 .. ncols), rows, tag; pops the entry (a run: when used up)
+ah_status pop_front_batch(ah_context* ctx, ah_coalescer* co, ah_array_out* outs, int64_t* num_rows, uint64_t* tag) {
+  CoBatch& b = co->completed.front();
+  if (b.run_n > 0) {
+    SlabNulls& sn = *b.slab_nulls;
+    if (!sn.arrived) {
+      AH_TRY(ah_coalesce_wait(ctx, sn.seq));
+      sn.arrived = true;
+    }
+    const int64_t j = b.run_next;
+    for (int k = 0; k < co->ncols; ++k) {
+      ah_array_out& o = outs[k];
+      ah_out_init(&o);
+      const int w = co->cols[k].width;
+      o.type = co->cols[k].type;
+      o.length = co->target;
+      o.values = (char*)b.run_values[(size_t)k] + (size_t)j * co->target * w;
+      o.values_bytes = co->target * w;
+      ah_slab_slice(ctx, b.run_slab, o.values);
+      const uint64_t nulls = __atomic_load_n(&sn.pin[(size_t)j * co->ncols + k], __ATOMIC_RELAXED);
+      if (nulls > 0) {  // NullBufferBuilder::finish keeps a buffer only if a null was ever appended
+        o.validity = b.run_valid[(size_t)k] + (size_t)j * co->target / 8;
+        o.validity_bytes = co->target / 8;
+        o.null_count = (int64_t)nulls;
+        ah_slab_slice(ctx, b.run_slab, o.validity);
+      }
+    }
+    *num_rows = co->target;
+    if (tag) *tag = 0;
+    if (++b.run_next == b.run_n) {
+      ah_slab_unref(ctx, b.run_slab);
+      b.run_slab = nullptr;
+      co->completed.pop_front();
+    }
+    co->completed_batches -= 1;
+    return AH_OK;
+  }
+  AH_TRY(resolve_pending(ctx, co, b));
+  for (int i = 0; i < co->ncols; ++i) outs[i] = b.cols[i];
+  *num_rows = b.rows;
+  if (tag) *tag = b.tag;
+  co->completed.pop_front();
+  co->completed_batches -= 1;
+  return AH_OK;
 }
 
 }  // namespace
@@ -577,6 +653,13 @@ extern "C" ah_status ah_coalescer_create(ah_context* ctx, int32_t n_columns, con
 extern "C" void ah_coalescer_destroy(ah_context* ctx, ah_coalescer* co) {
   ah_ctx_guard _guard(ctx);
   if (!co) return;
+  if (slab_timing().on && slab_timing().pushes) {
+    SlabTiming& t = slab_timing();
+    fprintf(stderr, "arrow_hip: slab pushes %lld (%lld batches): host us — table build %.0f, upload + count enqueue %.0f, count wait %.0f, append %.0f\n",
+            (long long)t.pushes, (long long)t.batches, t.build, t.upload_count, t.wait, t.append);
+    t = SlabTiming{};
+    t.on = true;
+  }
   if (ctx) {
     (void)ah_stream_wait(ctx);  // scatters into the in-progress buffers may still be in flight
     for (auto& c : co->cols) {
@@ -597,7 +680,9 @@ extern "C" void ah_coalescer_set_biggest_coalesce_batch_size(ah_coalescer* co, i
   if (co) co->limit = limit;
 }
 extern "C" int64_t ah_coalescer_buffered_rows(const ah_coalescer* co) { return co ? co->buffered : 0; }
-extern "C" int32_t ah_coalescer_completed_count(const ah_coalescer* co) { return co ? (int32_t)co->completed.size() : 0; }
+extern "C" int32_t ah_coalescer_completed_count(const ah_coalescer* co) {
+  return co ? (int32_t)std::min<int64_t>(co->completed_batches, INT32_MAX) : 0;
+}
 
 // push_batch (coalesce.rs:296): `tag` identifies the caller's batch; *bypassed = 1 tells the caller that this very batch
 // was queued untouched (large-batch bypass): it comes back from ah_coalescer_next_completed_batch with that tag and
@@ -699,7 +784,7 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
           b.cols = outs;  // ownership moves to the completed queue
           for (auto& o : outs) ah_out_init(&o);
           if (co->has_views) b.sources.push_back(co->cur_seq);
-          co->completed.push_back(std::move(b));
+          co->completed.push_back(std::move(b)), co->completed_batches += 1;
         }
       } else {
         // generic columns adopt their filtered array (shared between the output batches it straddles)
@@ -848,10 +933,8 @@ bool slab_eligible(ah_context* ctx, const ah_coalescer* co, int n, const ah_arra
     const int w = co->cols[k].width;
     if (co->cols[k].generic || !(w == 1 || w == 2 || w == 4 || w == 8)) return false;
   }
-  for (int i = 0; i < n; ++i) {
-    if (filters[i].length > num_rows[i]) return false;  // (check_filter reports it)
-    if (ah_ceil_div(filters[i].length, 4096) > INT32_MAX) return false;
-  }
+  for (int i = 0; i < n; ++i)  // (a predicate longer than its batch: check_filter reports it)
+    if (filters[i].length > num_rows[i] || (filters[i].length >> 12) >= INT32_MAX) return false;
   return true;
 }
 
@@ -879,6 +962,8 @@ ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_vi
   sp->slot = slot;
   sp->wave0.resize((size_t)n + 1);
   sp->tile0.resize((size_t)n + 1);
+  SlabTiming& tm = slab_timing();
+  const double t_0 = tm.on ? now_us() : 0;
   int64_t nchunks = 0, nwaves = 0, ntiles = 0;
   std::vector<int64_t> chunk0((size_t)n);
   for (int i = 0; i < n; ++i) {
@@ -886,10 +971,11 @@ ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_vi
     chunk0[(size_t)i] = nchunks;
     sp->wave0[(size_t)i] = nwaves;
     sp->tile0[(size_t)i] = ntiles;
-    const int64_t c = ah_ceil_div(len, AH_FILTER_CHUNK_ROWS);
+    const int64_t c = (len + AH_FILTER_CHUNK_ROWS - 1) >> 10;  // (shifts: this loop runs 122 000 times per 1e9 rows at 8192-row batches)
+    static_assert(AH_FILTER_CHUNK_ROWS == 1024, "chunk shift");
     nchunks += c;
-    nwaves += ah_ceil_div(c, 64);
-    ntiles += ah_ceil_div(len, 4096);
+    nwaves += (c + 63) >> 6;
+    ntiles += (len + 4095) >> 12;
     sp->total_rows += len;
   }
   sp->wave0[(size_t)n] = nwaves;
@@ -901,21 +987,22 @@ ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_vi
   }
   // pinned block: [nwaves + 1 prefix words][segs][waves][tiles]; device block: [segs][waves][tiles][chunk_prefix][wave_total][wave_prefix]
   const size_t b_pref = up256(((size_t)nwaves + 1) * 8), b_seg = up256((size_t)n * sizeof(ah_tbl_seg)),
+               b_col = up256((size_t)n * co->ncols * sizeof(ah_tbl_col)),
                b_wav = up256((size_t)nwaves * sizeof(ah_tbl_wave)), b_til = up256((size_t)ntiles * sizeof(ah_tbl_tile));
-  const size_t b_tables = b_seg + b_wav + b_til;
+  const size_t b_tables = b_seg + b_col + b_wav + b_til;
   const size_t b_cp = up256((size_t)nchunks * 4), b_wt = up256((size_t)nwaves * 4), b_wp = up256(((size_t)nwaves + 1) * 8);
   SlabPin& pin = co->slab_pin[slot];
   AH_TRY(slab_pin_reserve(ctx, pin, b_pref + b_tables));
   AH_TRY(ah_pool_alloc(ctx, b_tables + b_cp + b_wt + b_wp, &sp->dev_block));
   char* hs = (char*)pin.host + b_pref;
   auto* segs = (ah_tbl_seg*)hs;
-  auto* waves = (ah_tbl_wave*)(hs + b_seg);
-  auto* tiles = (ah_tbl_tile*)(hs + b_seg + b_wav);
+  auto* tcols = (ah_tbl_col*)(hs + b_seg);
+  auto* waves = (ah_tbl_wave*)(hs + b_seg + b_col);
+  auto* tiles = (ah_tbl_tile*)(hs + b_seg + b_col + b_wav);
   int64_t wi = 0, ti = 0;
   for (int i = 0; i < n; ++i) {
     const ah_array_view& f = filters[i];
     ah_tbl_seg& sg = segs[i];
-    memset(&sg, 0, sizeof sg);
     sg.mask = make_bitview(f.values, f.values_bit_offset);
     sg.mask_valid = (f.validity && f.null_count != 0) ? make_bitview(f.validity, f.validity_bit_offset) : BitView{nullptr, 0};
     sg.len = f.length;
@@ -923,8 +1010,9 @@ ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_vi
     sg.wave0 = sp->wave0[(size_t)i];
     for (int k = 0; k < co->ncols; ++k) {
       const ah_array_view& v = columns[(size_t)i * co->ncols + k];
-      sg.values[k] = v.values;
-      sg.vvalid[k] = (v.validity && v.null_count != 0) ? make_bitview(v.validity, v.validity_bit_offset) : BitView{nullptr, 0};
+      ah_tbl_col& tc = tcols[(size_t)i * co->ncols + k];
+      tc.values = v.values;
+      tc.vvalid = (v.validity && v.null_count != 0) ? make_bitview(v.validity, v.validity_bit_offset) : BitView{nullptr, 0};
       if (((uintptr_t)v.values) & 15) sp->aligned16 = false;
     }
     const int64_t nw = sp->wave0[(size_t)i + 1] - sp->wave0[(size_t)i], nt = sp->tile0[(size_t)i + 1] - sp->tile0[(size_t)i];
@@ -933,22 +1021,25 @@ ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_vi
   }
   char* db = (char*)sp->dev_block;
   sp->t.segs = (const ah_tbl_seg*)db;
-  sp->t.waves = (const ah_tbl_wave*)(db + b_seg);
-  sp->t.tiles = (const ah_tbl_tile*)(db + b_seg + b_wav);
+  sp->t.cols = (const ah_tbl_col*)(db + b_seg);
+  sp->t.ncols = co->ncols;
+  sp->t.waves = (const ah_tbl_wave*)(db + b_seg + b_col);
+  sp->t.tiles = (const ah_tbl_tile*)(db + b_seg + b_col + b_wav);
   sp->t.nsegs = n, sp->t.nwaves = nwaves, sp->t.ntiles = ntiles;
   sp->t.chunk_prefix = (uint32_t*)(db + b_tables);
   sp->t.wave_total = (uint32_t*)(db + b_tables + b_cp);
   sp->t.wave_prefix = (unsigned long long*)(db + b_tables + b_cp + b_wt);
   ah_status st = AH_OK;
+  const double t_1 = tm.on ? now_us() : 0;
   if (hipMemcpyAsync(db, hs, b_tables, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
     st = ah_fail(ctx, AH_HIP_ERROR, "coalescer table upload failed");
-  if (st == AH_OK) st = ah_filter_table_count(ctx, sp->t, (uint64_t*)pin.dev);
-  if (st == AH_OK && ah_mail_post_async(ctx, &sp->seq) != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "coalescer count failed");
+  if (st == AH_OK) st = ah_filter_table_count(ctx, sp->t, (uint64_t*)pin.dev, &sp->seq);
   if (st != AH_OK) {
     (void)ah_stream_wait(ctx);
     ah_pool_free(ctx, sp->dev_block);
     return st;
   }
+  if (tm.on) tm.build += t_1 - t_0, tm.upload_count += now_us() - t_1, tm.pushes += 1, tm.batches += n;
   pin.busy = true;
   *out = sp.release();
   return AH_OK;
@@ -970,8 +1061,18 @@ ah_status slab_end(ah_context* ctx, ah_coalescer* co, SlabPush* sp_raw) {
   std::unique_ptr<SlabPush> sp(sp_raw);
   if (sp->slot < 0) return AH_OK;  // nothing was enqueued (every predicate empty)
   SlabPin& pin = co->slab_pin[sp->slot];
+  SlabTiming& tm = slab_timing();
+  const double t_0 = tm.on ? now_us() : 0;
+  struct AppendTimer {
+    SlabTiming& t;
+    double t1 = 0;
+    ~AppendTimer() {
+      if (t.on && t1 > 0) t.append += now_us() - t1;
+    }
+  } append_timer{tm};
   const bool later_work = sp->seq != ctx->mail_seq || ctx->inflight;
   const hipError_t we = ah_mail_wait(ctx, sp->seq);
+  if (tm.on) append_timer.t1 = now_us(), tm.wait += append_timer.t1 - t_0;
   if (later_work && ctx->wait_mode != 1) ctx->inflight = true;
   pin.busy = false;
   struct FreeBlock {  // (pool reuse is stream-ordered behind the launches below)
@@ -1087,34 +1188,23 @@ ah_status slab_end(ah_context* ctx, ah_coalescer* co, SlabPush* sp_raw) {
         st = ah_pinned_alloc(ctx, sn->bytes, &hp, &dp);
         if (st == AH_OK) {
           sn->pin = (uint64_t*)hp;
-          st = ah_filter_count_nulls_batches(ctx, co->ncols, bits, co->target, nfull, co->target, (unsigned long long*)dp);
+          st = ah_filter_count_nulls_batches(ctx, co->ncols, bits, co->target, nfull, co->target, (unsigned long long*)dp, &sn->seq);
         }
-        if (st == AH_OK && ah_mail_post_async(ctx, &sn->seq) != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "coalescer null count failed");
       }
       if (st == AH_OK && tail > 0) st = ah_filter_count_nulls_range(ctx, co->ncols, bits, slots, nfull * co->target, tail);
       if (st == AH_OK) {
-        for (int64_t j = 0; j < nfull; ++j) {
+        if (nfull > 0) {  // ONE queue entry for the nfull whole batches: materialised when fetched (pop_front_batch)
           CoBatch b;
           b.rows = co->target;
-          b.pending = true;
+          b.pending = false;
           b.ring = -1;
           b.slab_nulls = sn;
-          b.slab_index = j;
-          b.cols.resize((size_t)co->ncols);
-          for (int k = 0; k < co->ncols; ++k) {
-            ah_array_out& o = b.cols[(size_t)k];
-            ah_out_init(&o);
-            o.type = co->cols[k].type;
-            o.length = co->target;
-            o.values = (char*)dv[k] + (size_t)j * co->target * co->cols[k].width;
-            o.values_bytes = co->target * co->cols[k].width;
-            o.validity = db[k] + (size_t)j * co->target / 8;
-            o.validity_bytes = co->target / 8;
-            o.null_count = -1;
-            ah_slab_slice(ctx, slab, o.values);
-            ah_slab_slice(ctx, slab, o.validity);
-          }
+          b.run_n = nfull;
+          b.run_slab = slab;
+          ah_slab_slice(ctx, slab, nullptr);  // the run's own reference
+          for (int k = 0; k < co->ncols; ++k) b.run_values.push_back(dv[k]), b.run_valid.push_back(db[k]);
           co->completed.push_back(std::move(b));
+          co->completed_batches += nfull;
         }
         if (tail > 0) {  // the slab's last, partial batch is the new in-progress batch (capacity: a whole target)
           for (int k = 0; k < co->ncols; ++k) {
@@ -1433,7 +1523,7 @@ extern "C" ah_status ah_coalescer_push_batch_with_indices(ah_context* ctx, ah_co
         b.cols = outs;
         for (auto& o : outs) ah_out_init(&o);
         if (co->has_views) b.sources.push_back(co->cur_seq);
-        co->completed.push_back(std::move(b));
+        co->completed.push_back(std::move(b)), co->completed_batches += 1;
       }
     } else {
       std::vector<ah_array_view> views((size_t)co->ncols);
@@ -1506,13 +1596,7 @@ extern "C" ah_status ah_coalescer_next_completed_batch(ah_context* ctx, ah_coale
     *num_rows = -1;
     return AH_OK;
   }
-  CoBatch& b = co->completed.front();
-  AH_TRY(resolve_pending(ctx, co, b));
-  for (int i = 0; i < co->ncols; ++i) outs[i] = b.cols[i];
-  *num_rows = b.rows;
-  if (tag) *tag = b.tag;
-  co->completed.pop_front();
-  return AH_OK;
+  return pop_front_batch(ctx, co, outs, num_rows, tag);
 }
 
 // next_completed_batch for up to `max_batches` batches in one call (a slab push completes thousands of 8192-row batches at
@@ -1523,12 +1607,7 @@ extern "C" ah_status ah_coalescer_next_completed_batches(ah_context* ctx, ah_coa
   if (!ctx || !co || !outs || !num_rows || !n || max_batches < 0) return AH_INVALID_ARGUMENT;
   *n = 0;
   while (*n < max_batches && !co->completed.empty()) {
-    CoBatch& b = co->completed.front();
-    AH_TRY(resolve_pending(ctx, co, b));
-    for (int i = 0; i < co->ncols; ++i) outs[(size_t)*n * co->ncols + i] = b.cols[i];
-    num_rows[*n] = b.rows;
-    if (tags) tags[*n] = b.tag;
-    co->completed.pop_front();
+    AH_TRY(pop_front_batch(ctx, co, outs + (size_t)*n * co->ncols, &num_rows[*n], tags ? &tags[*n] : nullptr));
     *n += 1;
   }
   return AH_OK;

@@ -212,28 +212,33 @@ ah_status ah_slab_create(ah_context* ctx, size_t bytes, ah_slab** out) {
   void* b = nullptr;
   AH_TRY(ah_pool_alloc(ctx, bytes ? bytes : 8, &b));
   auto* s = new ah_slab();
-  s->block = b, s->bytes = bytes, s->refs = 1;
+  s->block = b, s->bytes = bytes ? bytes : 8, s->refs = 1;
+  ctx->slabs[(uintptr_t)b] = s;
   *out = s;
   return AH_OK;
 }
 void ah_slab_unref(ah_context* ctx, ah_slab* s) {
   if (!s || --s->refs > 0) return;
+  ctx->slabs.erase((uintptr_t)s->block);
   ah_pool_free(ctx, s->block);
   delete s;
 }
 void ah_slab_slice(ah_context* ctx, ah_slab* s, void* ptr) {
-  ctx->slab_slices[ptr] = s;
+  (void)ctx, (void)ptr;
   s->refs += 1;
 }
 
 void ah_out_free(ah_context* ctx, void* p, size_t bytes) {
   if (!p) return;
-  auto sl = ctx->slab_slices.find(p);
-  if (sl != ctx->slab_slices.end()) {  // a slice of a slab: the block outlives it while other slices are out
-    ah_slab* s = sl->second;
-    ctx->slab_slices.erase(sl);
-    ah_slab_unref(ctx, s);
-    return;
+  if (!ctx->slabs.empty()) {  // a slice of a slab (any pointer inside a live slab's block): the block outlives it while others are out
+    auto it = ctx->slabs.upper_bound((uintptr_t)p);
+    if (it != ctx->slabs.begin()) {
+      --it;
+      if ((uintptr_t)p < it->first + it->second->bytes) {
+        ah_slab_unref(ctx, it->second);
+        return;
+      }
+    }
   }
   auto rz = ctx->redzones.find(p);
   if (rz != ctx->redzones.end()) {

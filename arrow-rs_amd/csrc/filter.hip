@@ -977,7 +977,7 @@ __global__ void __launch_bounds__(64) filter_count_table_kernel(ah_tbl_push t) {
 }
 // one block: exclusive scan of the wave totals -> wave_prefix[0 .. nwaves] (the last entry is K), in device memory for the
 // scatter and in the host's pinned words (what the host waits for; the mailbox is posted by the kernel behind this one)
-__global__ void __launch_bounds__(1024) filter_scan_table_kernel(ah_tbl_push t, uint64_t* pin) {
+__global__ void __launch_bounds__(1024) filter_scan_table_kernel(ah_tbl_push t, uint64_t* pin, uint64_t* mail, uint64_t seq) {
   __shared__ unsigned long long s_wave[16];
   __shared__ unsigned long long s_carry;
   const int th = threadIdx.x, lane = th & 63, wave = th >> 6;
@@ -1004,6 +1004,9 @@ __global__ void __launch_bounds__(1024) filter_scan_table_kernel(ah_tbl_push t, 
   __syncthreads();
   for (int64_t i = th; i <= t.nwaves; i += 1024)
     __hip_atomic_store(pin + i, (uint64_t)t.wave_prefix[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();  // every thread's pinned words before the barrier ...
+  __syncthreads();
+  if (th == 0) ah_mail_post(mail, seq);  // ... and the sequence word after it (a separate posting kernel cost ~10 us per push)
 }
 
 struct TblScatterArgs {
@@ -1034,9 +1037,9 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_table_kernel(T
   const ah_tbl_tile tt = m.t.tiles[m.tile_lo + g];
   const ah_tbl_seg& sg = m.t.segs[tt.seg];
   const ScatterArgs a = tbl_tile_args(m, sg);
-  const int c = m.col_index[blockIdx.y];
+  const ah_tbl_col sc = m.t.cols[(int64_t)tt.seg * m.t.ncols + m.col_index[blockIdx.y]];
   const ah_tbl_dst d = m.dst[blockIdx.y];
-  scatter_tile<W, V, true, SKIP>(a, tt.tile, sg.values[c], sg.vvalid[c], d.out_values, d.out_valid, nullptr);
+  scatter_tile<W, V, true, SKIP>(a, tt.tile, sc.values, sc.vvalid, d.out_values, d.out_valid, nullptr);
 }
 template <int W>
 __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_table_sparse_kernel(TblScatterArgs m) {
@@ -1051,30 +1054,40 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_table_sparse_k
   const ah_tbl_seg& sg = m.t.segs[tt.seg];
   ScatterArgs a = tbl_tile_args(m, sg);
   a.nulls_mode = 1;
-  const int c = m.col_index[blockIdx.y];
+  const ah_tbl_col sc = m.t.cols[(int64_t)tt.seg * m.t.ncols + m.col_index[blockIdx.y]];
   const ah_tbl_dst d = m.dst[blockIdx.y];
-  sparse_tile<W, true>(a, tt.tile, lane, wave, sg.values[c], sg.vvalid[c], d.out_values, d.out_valid, nullptr);
+  sparse_tile<W, true>(a, tt.tile, lane, wave, sc.values, sc.vvalid, d.out_values, d.out_valid, nullptr);
 }
 
 // zero bits of `nbatches` consecutive `stride`-bit ranges of up to 8 bitmaps (grid: batch x column; one wave each)
 struct NullBatches {
   const unsigned long long* bits[AH_TBL_MAX_COLS];
-  int ncols;
+  int ncols, parts;  // `parts` workgroups share one batch's words
   int64_t stride, nbatches, last_rows;
-  unsigned long long* out;
+  unsigned long long* acc;  // device: nbatches x ncols words, zero on entry
 };
-__global__ void __launch_bounds__(64) count_nulls_batches_kernel(NullBatches nb) {
-  const int64_t j = blockIdx.x;
+// (one wave per batch was the first form: a 2^20-row target is 16 K words — 256 dependent iterations per wave, 7 ms per 1e9 rows)
+__global__ void __launch_bounds__(256) count_nulls_batches_kernel(NullBatches nb) {
+  const int64_t j = blockIdx.x / nb.parts;
+  const int part = (int)(blockIdx.x % nb.parts);
   const unsigned long long* bits = nb.bits[blockIdx.y] + j * (nb.stride >> 6);
   const int64_t rows = j == nb.nbatches - 1 ? nb.last_rows : nb.stride, nwords = (rows + 63) >> 6;
   unsigned long long nulls = 0;
-  for (int64_t w = threadIdx.x; w < nwords; w += 64) {
+  for (int64_t w = (int64_t)part * 256 + threadIdx.x; w < nwords; w += (int64_t)nb.parts * 256) {
     unsigned long long in = ~0ull;
     if (w == nwords - 1 && (rows & 63)) in = (1ull << (rows & 63)) - 1ull;
     nulls += (unsigned long long)__popcll(in & ~bits[w]);
   }
   nulls = wave_reduce_add64(nulls);
-  if (threadIdx.x == 0) __hip_atomic_store(nb.out + j * nb.ncols + blockIdx.y, nulls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if ((threadIdx.x & 63) == 0 && nulls) atomicAdd(nb.acc + j * nb.ncols + blockIdx.y, nulls);
+}
+// one block: the counted words to the host's pinned words, then the mailbox post
+__global__ void __launch_bounds__(1024) words_to_pinned_kernel(const unsigned long long* src, int64_t n, unsigned long long* dst, uint64_t* mail,
+                                                               uint64_t seq) {
+  for (int64_t i = threadIdx.x; i < n; i += 1024) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) ah_mail_post(mail, seq);
 }
 
 // NULL rows among destination rows [bit_lo, bit_lo + nbits) of up to 8 columns (blockIdx.y), added to each column's
@@ -1818,13 +1831,15 @@ static ah_status launch_multi_sparse(ah_context* ctx, const MultiArgs& m, int wi
 }
 
 // ---- batch tables (filter_internal.hpp)
-ah_status ah_filter_table_count(ah_context* ctx, const ah_tbl_push& t, uint64_t* pin_dev) {
+ah_status ah_filter_table_count(ah_context* ctx, const ah_tbl_push& t, uint64_t* pin_dev, uint64_t* seq_out) {
   if (t.nwaves < 1 || t.nsegs < 1) return AH_INVALID_ARGUMENT;
   ctx->inflight = true;
+  const uint64_t seq = ah_mail_next(ctx);
+  *seq_out = seq;
   {
     ah_prof_scope ps(ctx, "filter_count");
     filter_count_table_kernel<<<(unsigned)t.nwaves, 64, 0, ctx->stream>>>(t);
-    filter_scan_table_kernel<<<1, 1024, 0, ctx->stream>>>(t, pin_dev);
+    filter_scan_table_kernel<<<1, 1024, 0, ctx->stream>>>(t, pin_dev, ctx->pinned_dev, seq);
   }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "filter count failed: %s", hipGetErrorString(e));
@@ -1876,12 +1891,22 @@ ah_status ah_filter_table_scatter(ah_context* ctx, const ah_tbl_push& t, int wid
 }
 
 ah_status ah_filter_count_nulls_batches(ah_context* ctx, int ncols, const unsigned long long* const* bits, int64_t stride,
-                                        int64_t nbatches, int64_t last_rows, unsigned long long* out) {
+                                        int64_t nbatches, int64_t last_rows, unsigned long long* out, uint64_t* seq_out) {
   if (ncols < 1 || ncols > AH_TBL_MAX_COLS || (stride & 63) || nbatches < 1) return AH_INVALID_ARGUMENT;
   NullBatches nb{};
   for (int c = 0; c < ncols; ++c) nb.bits[c] = bits[c];
-  nb.ncols = ncols, nb.stride = stride, nb.nbatches = nbatches, nb.last_rows = last_rows, nb.out = out;
-  count_nulls_batches_kernel<<<dim3((unsigned)nbatches, (unsigned)ncols), 64, 0, ctx->stream>>>(nb);
+  const int64_t nwords = stride >> 6, n = nbatches * ncols;
+  nb.parts = (int)std::max<int64_t>(1, std::min<int64_t>(64, ah_ceil_div(nwords, 256 * 8)));
+  nb.ncols = ncols, nb.stride = stride, nb.nbatches = nbatches, nb.last_rows = last_rows;
+  void* acc = nullptr;
+  AH_TRY(ah_pool_alloc(ctx, (size_t)n * 8, &acc));
+  nb.acc = (unsigned long long*)acc;
+  hipMemsetAsync(acc, 0, (size_t)n * 8, ctx->stream);
+  count_nulls_batches_kernel<<<dim3((unsigned)(nbatches * nb.parts), (unsigned)ncols), 256, 0, ctx->stream>>>(nb);
+  const uint64_t seq = ah_mail_next(ctx);
+  *seq_out = seq;
+  words_to_pinned_kernel<<<1, 1024, 0, ctx->stream>>>(nb.acc, n, out, ctx->pinned_dev, seq);
+  ah_pool_free(ctx, acc);  // (reuse is stream-ordered behind the two kernels)
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "null count failed: %s", hipGetErrorString(e));
   return AH_OK;

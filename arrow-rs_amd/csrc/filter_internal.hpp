@@ -64,13 +64,17 @@ struct ah_tbl_seg {   // one input batch
   int64_t len;                // predicate length (<= the batch's rows)
   int64_t chunk0;             // this batch's first entry in the push's chunk-prefix array (one per 1024 rows)
   int64_t wave0;              // ... and in its wave-prefix array (one per 64 chunks = 65 536 rows)
-  const void* values[AH_TBL_MAX_COLS];
-  BitView vvalid[AH_TBL_MAX_COLS];  // words == nullptr: every row valid
+};
+struct ah_tbl_col {   // column k of batch i: entry i * ncols + k
+  const void* values;
+  BitView vvalid;             // words == nullptr: every row valid
 };
 struct ah_tbl_wave { int32_t seg, group; };   // count wave w: 64-chunk group `group` of batch `seg`
 struct ah_tbl_tile { int32_t seg, tile; };    // scatter tile t: 4096-row tile `tile` of batch `seg`
 struct ah_tbl_push {                          // all device pointers
   const ah_tbl_seg* segs;
+  const ah_tbl_col* cols;
+  int ncols;
   const ah_tbl_wave* waves;
   const ah_tbl_tile* tiles;
   int64_t nsegs, nwaves, ntiles;
@@ -79,7 +83,8 @@ struct ah_tbl_push {                          // all device pointers
   unsigned long long* wave_prefix;   // [nwaves + 1]: position of each wave's first selected row in the push's filtered stream
 };
 // count + scan, enqueued only: pin_dev[w] = position of count wave w's first selected row (w = 0 .. nwaves - 1), pin_dev[nwaves] = K
-ah_status ah_filter_table_count(ah_context* ctx, const ah_tbl_push& t, uint64_t* pin_dev);
+// ... and *seq = the mailbox sequence number the scan posts behind them (ah_mail_wait)
+ah_status ah_filter_table_count(ah_context* ctx, const ah_tbl_push& t, uint64_t* pin_dev, uint64_t* seq);
 struct ah_tbl_dst {
   void* out_values;
   unsigned long long* out_valid;  // zero-initialised words
@@ -93,7 +98,7 @@ ah_status ah_filter_table_scatter(ah_context* ctx, const ah_tbl_push& t, int wid
 //   batch form: for j < nbatches, column c < ncols: out[j * ncols + c] = zero bits among bits [j * stride, j * stride + rows_j)
 //   of bits[c] (rows_j = stride except for the last batch: last_rows); `out` may be device-visible pinned memory
 ah_status ah_filter_count_nulls_batches(ah_context* ctx, int ncols, const unsigned long long* const* bits, int64_t stride,
-                                        int64_t nbatches, int64_t last_rows, unsigned long long* out);
+                                        int64_t nbatches, int64_t last_rows, unsigned long long* out, uint64_t* seq);
 //   range form: slots[c][..] += zero bits among bits [bit_lo, bit_lo + nbits) of bits[c]   (c < ncols <= 8)
 ah_status ah_filter_count_nulls_range(ah_context* ctx, int ncols, const unsigned long long* const* bits, unsigned long long* const* slots,
                                       int64_t bit_lo, int64_t nbits);

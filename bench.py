@@ -71,6 +71,8 @@ def parse():
     p.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
     p.add_argument("--no-configs", action="store_true", help="skip the configs[2]/[3] lines of the default run")
     p.add_argument("--only-narrow", action="store_true", help="print just the configs_narrow block (4-byte and narrower operands)")
+    p.add_argument("--only-coalesce-sweep", default=None, nargs="?", const="all",
+                   help="print just the coalesce_by_batch_rows block (optionally a comma-separated list of '<batch_rows>x<target>' keys)")
     p.add_argument("--config-steps", type=int, default=5)
     p.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"])
     p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the run rocprofv3 wraps
@@ -247,6 +249,210 @@ def narrow_configs(env):
             res[name] = {"error": repr(ex)[:300]}
     ctx.lib.ah_pool_trim(ctx.handle)
     return res
+
+
+# ------------------------------------------------------------------------------- BatchCoalescer by input batch size
+# the reference's operating point is 8192-row input batches (arrow-select/src/coalesce.rs:172-173 "Typical
+# values are 4096 or 8192 rows"; arrow/benches/coalesce_kernels.rs:34 batch_size = 8192), not the 2^24-row batches of the
+# `coalesce` row.  The stream is the same 1e9 rows {Int64, Float64, both with NullBuffers} + 10 %-selected predicate, handed over
+# as zero-copy slices of `batch_rows` rows; the host side is what an engine in C++ / Rust would do — the batch descriptors
+# (ah_array_view) are prepared ahead, the timed loop is C-ABI calls only: grouped pushes (begin of group g + 1 before end of
+# group g), bulk fetch + bulk release of the completed batches after every push.
+COALESCE_SWEEP_BATCH_ROWS = [8192, 65536, 1 << 20, 1 << 24]
+
+
+def _np_views(n):
+    import numpy as np
+    dt = np.dtype({"names": ["type", "length", "null_count", "values", "values_bit_offset", "validity", "validity_bit_offset", "offsets"],
+                   "formats": ["<i4", "<i8", "<i8", "<u8", "<i8", "<u8", "<i8", "<u8"], "offsets": [0, 8, 16, 24, 32, 40, 48, 56],
+                   "itemsize": 64})
+    return np.zeros(n, dtype=dt)
+
+
+class CoalesceStream:
+    """`n` rows of (col_a, col_b, pred) as n / batch_rows pushes through ah_coalescer_push_batches_with_filters_begin / _end."""
+
+    def __init__(self, env, cols, pred, n, batch_rows, target, group):
+        import numpy as np
+        from arrow_rs_amd import _lib as L
+        self.env, self.lib, self.h = env, env.ctx.lib, env.ctx.handle
+        self.ncols, self.target = len(cols), target
+        nb = n // batch_rows
+        self.nb, self.rows_streamed = nb, nb * batch_rows
+        i = np.arange(nb, dtype=np.int64)
+        cv = _np_views(nb * self.ncols).reshape(nb, self.ncols)
+        for k, c in enumerate(cols):
+            w = c.data_type.width
+            cv["type"][:, k] = c.data_type.physical
+            cv["length"][:, k] = batch_rows
+            cv["null_count"][:, k] = -1
+            cv["values"][:, k] = c.values.ptr + i * batch_rows * w
+            cv["validity"][:, k] = c.validity.ptr
+            cv["validity_bit_offset"][:, k] = i * batch_rows
+        fv = _np_views(nb)
+        fv["type"], fv["length"], fv["null_count"] = L.AH_BOOL, batch_rows, 0
+        fv["values"], fv["values_bit_offset"] = pred.values.ptr, i * batch_rows
+        self._cv, self._fv = np.ascontiguousarray(cv.reshape(-1)), fv
+        self._rows = np.full(nb, batch_rows, dtype=np.int64)
+        self._keep = (cols, pred)
+        VP = C.POINTER(L.ArrayView)
+        self.groups = []
+        for g0 in range(0, nb, group):
+            m = min(group, nb - g0)
+            self.groups.append((m, C.cast(self._cv.ctypes.data + g0 * self.ncols * 64, VP), C.cast(self._rows.ctypes.data + g0 * 8, C.POINTER(C.c_int64)),
+                                C.cast(self._fv.ctypes.data + g0 * 64, VP)))
+        self.types = (C.c_int32 * self.ncols)(*[c.data_type.physical for c in cols])
+        cap = int(group * batch_rows / max(target, 1)) + 8
+        self.cap = cap
+        self.outs = (L.ArrayOut * (cap * self.ncols))()
+        self.out_rows = np.zeros(cap, dtype=np.int64)
+        self.out_rows_p = C.cast(self.out_rows.ctypes.data, C.POINTER(C.c_int64))
+        self.pushes = len(self.groups)
+
+    def run(self):
+        lib, h, ctx = self.lib, self.h, self.env.ctx
+        co = C.c_void_p()
+        ctx.check(lib.ah_coalescer_create(h, self.ncols, self.types, self.target, C.byref(co)))
+        total = batches = 0
+        n = C.c_int32()
+
+        def drain(limit=1 << 30):
+            nonlocal total, batches
+            while limit > 0:
+                ctx.check(lib.ah_coalescer_next_completed_batches(h, co, min(self.cap, limit), self.outs, self.out_rows_p, None, C.byref(n)))
+                if n.value == 0:
+                    return
+                total += int(self.out_rows[:n.value].sum())
+                batches += n.value
+                limit -= n.value
+                lib.ah_arrays_release(h, self.outs, n.value * self.ncols)
+        try:
+            pending = None
+            for m, cv, rows, fv in self.groups:
+                nxt = C.c_void_p()
+                ctx.check(lib.ah_coalescer_push_batches_with_filters_begin(h, co, m, cv, rows, fv, None, C.byref(nxt)))
+                if pending is not None:
+                    # the batches finished by EARLIER pushes go downstream after this push has been enqueued: fetching a batch
+                    # waits for its scatter and null counts, and those of the push just ended have only now been queued
+                    ready = lib.ah_coalescer_completed_count(co)
+                    ctx.check(lib.ah_coalescer_push_batches_with_filters_end(h, co, pending, None))
+                    drain(ready)
+                pending = nxt
+            if pending is not None:
+                ctx.check(lib.ah_coalescer_push_batches_with_filters_end(h, co, pending, None))
+            ctx.check(lib.ah_coalescer_finish_buffered_batch(h, co))
+            drain()
+        finally:
+            lib.ah_coalescer_destroy(h, co)
+        return total, batches
+
+
+def cpu_coalesce_1core(batch_rows, sample_rows, sel, valid):
+    """One CPU core on the same stream shape: the oracle's filter of both columns, batch by batch (the reference's fused
+    `copy_rows_by_filter_from` is a filter into the builder: coalesce/primitive.rs:95-140) -> Mrows/s."""
+    import numpy as np
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+
+    class View(C.Structure):
+        _fields_ = [("type", C.c_int32), ("length", C.c_int64), ("null_count", C.c_int64), ("values", C.c_void_p),
+                    ("values_bit_offset", C.c_int64), ("validity", C.c_void_p), ("validity_bit_offset", C.c_int64),
+                    ("offsets", C.c_void_p)]
+
+    class Out(C.Structure):
+        _fields_ = [("type", C.c_int32), ("length", C.c_int64), ("null_count", C.c_int64), ("values", C.c_void_p),
+                    ("values_bytes", C.c_int64), ("values_bit_offset", C.c_int64), ("validity", C.c_void_p),
+                    ("validity_bytes", C.c_int64), ("validity_bit_offset", C.c_int64), ("offsets", C.c_void_p),
+                    ("offsets_bytes", C.c_int64), ("flags", C.c_int32)]
+    lib.orc_gen_uniform_i64.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, C.c_int64]
+    lib.orc_gen_bernoulli_bits.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int64]
+    per = sample_rows
+    v = np.empty(per, dtype=np.int64)
+    vb = np.zeros(per // 8 + 8, dtype=np.uint8)
+    mb = np.zeros(per // 8 + 8, dtype=np.uint8)
+    lib.orc_gen_uniform_i64(v.ctypes.data, per, 42, -2**63, 2**63 - 1, 0)
+    lib.orc_gen_bernoulli_bits(vb.ctypes.data, per, 43, valid, 0)
+    lib.orc_gen_bernoulli_bits(mb.ctypes.data, per, 44, sel, 0)
+    nb = per // batch_rows
+    views = []
+    for i in range(nb):
+        vv, mv = View(), View()
+        vv.type, vv.length, vv.null_count, vv.values, vv.validity, vv.validity_bit_offset = 5, batch_rows, -1, v.ctypes.data + i * batch_rows * 8, vb.ctypes.data, i * batch_rows
+        mv.type, mv.length, mv.null_count, mv.values, mv.values_bit_offset = 1, batch_rows, 0, mb.ctypes.data, i * batch_rows
+        views.append((vv, mv))
+
+    def once():
+        for vv, mv in views:
+            for _col in range(2):  # two 8-byte columns share the predicate
+                o = Out()
+                lib.orc_filter(C.byref(vv), C.byref(mv), C.byref(o))
+                lib.orc_release(C.byref(o))
+    once()
+    t0 = time.perf_counter()
+    once()
+    dt = time.perf_counter() - t0
+    return nb * batch_rows / dt / 1e6
+
+
+def coalesce_by_batch_rows(env, only=None):
+    """-> {"<batch_rows>x<target>": {...}}: ms per 1e9 rows streamed, Mrows/s, frac (SURVEY 8d bytes of the `coalesce` row), pushes and
+    launches per step, output batches, and the one-core CPU figure for the same input batch size."""
+    A, K, ctx, args = env.A, env.K, env.ctx, env.args
+    n = args.rows
+    ctx.lib.ah_pool_trim(ctx.handle)
+    col = gen_i64_column(A, ctx, n, 42, args.valid, 0)
+    col2 = gen_f64_column(A, ctx, n, 52, args.valid, 0)
+    pred = gen_predicate(A, ctx, n, 44, args.selectivity, 0)
+    res = {}
+    cpu = {}
+    for br in COALESCE_SWEEP_BATCH_ROWS:
+        if br > n:
+            continue
+        rule4 = max(64, int(br * args.selectivity * 4) // 64 * 64)
+        for tname, target in (("8192", 8192), ("2^20", 1 << 20), ("4x", rule4)):
+            key = f"{br}x{tname}"
+            if only and key not in only:
+                continue
+            try:
+                group = max(2, min(4096, (1 << 25) // br)) if br < (1 << 24) else 8
+                stream = CoalesceStream(env, [col, col2], pred, n, br, target, group)
+                stream.run()
+                env.sync_all()
+                times = []
+                for _ in range(5):  # median of five whole streams (an occasional stream pays a pool miss: +2-3 ms)
+                    t0 = time.perf_counter()
+                    out_rows, out_batches = stream.run()
+                    env.sync_all()
+                    times.append((time.perf_counter() - t0) * 1e3)
+                ms = sorted(times)[len(times) // 2]
+                ctx.profile(True)
+                ctx.profile_reset()
+                stream.run()
+                env.sync_all()
+                prof = {k: ctx.profile_get(k) for k in ("filter_count", "filter_scatter", "copy_rows")}
+                ctx.profile(False)
+                rows = stream.rows_streamed
+                alg = 2 * (rows * 8 + (rows + 7) // 8) + (rows + 7) // 8 + 2 * (out_rows * 8 + (out_rows + 7) // 8)
+                res[key] = {"batch_rows": br, "target": target, "rows": rows, "ms": round(ms, 3), "value": round(rows / (ms * 1e-3) / 1e6, 1),
+                            "unit": "Mrows/s", "alg_bytes": alg, "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "pushes": stream.pushes, "batches_per_push": group, "output_batches": out_batches, "output_rows": out_rows,
+                            "kernel_launches": {k: v[1] for k, v in prof.items()},
+                            "kernel_ms": {k: round(v[0], 3) for k, v in prof.items()}, "stream_ms_all": [round(t, 3) for t in times]}
+                stream = None
+            except Exception as ex:  # noqa: BLE001
+                res[key] = {"error": repr(ex)[:300]}
+        if not args.no_cpu_baseline and not only:
+            try:
+                cpu[str(br)] = round(cpu_coalesce_1core(br, min(1 << 25, n), args.selectivity, args.valid), 1)
+            except Exception as ex:  # noqa: BLE001
+                cpu[str(br)] = repr(ex)[:120]
+    ids, _why = _granted_cores()
+    out = {"points": res, "cpu_1core_Mrows_per_s_by_batch_rows": cpu, "cpu_cores_granted": len(ids),
+           "what": "1e9 rows {Int64, Float64, NullBuffers}, 10 % selected, streamed as batch_rows-row pushes into BatchCoalescer(target): ms per "
+                   "whole stream incl. fetching and releasing every output batch; C-ABI calls only in the timed loop (descriptors prepared ahead); "
+                   "cpu = the oracle's filter of both columns batch by batch on one core (x cores_granted = a linear-scaling upper bound)"}
+    col = col2 = pred = None
+    ctx.lib.ah_pool_trim(ctx.handle)
+    return out
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
@@ -1258,6 +1464,16 @@ def emit(line, args):
     if isinstance(line.get("filter_by_selectivity"), dict):
         compact["filter_scatter_ms_by_selectivity"] = {k: (v.get("filter_scatter_ms") if isinstance(v, dict) else v)
                                                        for k, v in line["filter_by_selectivity"].items()}
+    cs = line.get("coalesce_by_batch_rows")
+    if isinstance(cs, dict) and "points" in cs:
+        compact["coalesce_by_batch_rows"] = {
+            "columns": ["ms", "Mrows_per_s", "frac", "pushes", "output_batches", "launches"],
+            "points": {k: ([v.get("ms"), v.get("value"), v.get("frac"), v.get("pushes"), v.get("output_batches"),
+                            sum((v.get("kernel_launches") or {}).values())] if "error" not in v else v) for k, v in cs["points"].items()},
+            "alg_bytes_per_stream": next((v.get("alg_bytes") for v in cs["points"].values() if "alg_bytes" in v), None),
+            "cpu_1core_Mrows_per_s_by_batch_rows": cs.get("cpu_1core_Mrows_per_s_by_batch_rows"), "cpu_cores_granted": cs.get("cpu_cores_granted")}
+    elif cs is not None:
+        compact["coalesce_by_batch_rows"] = cs
     rs = line.get("reference_bench_shapes")
     if isinstance(rs, dict) and "shapes" in rs:
         compact["reference_bench_shapes"] = {
@@ -1544,6 +1760,10 @@ def main():
     if args.only_narrow:
         print(json.dumps({"configs_narrow": {k: _compact_config(v) for k, v in narrow_configs(env).items()}}), flush=True)
         return
+    if args.only_coalesce_sweep:
+        only = None if args.only_coalesce_sweep == "all" else args.only_coalesce_sweep.split(",")
+        print(json.dumps({"coalesce_by_batch_rows": coalesce_by_batch_rows(env, only)}), flush=True)
+        return
     W = build_workload(env, wl)
     n = W["n"]
     if args.pmc_child:  # the profiled re-run: just the steps, no reporting
@@ -1795,6 +2015,10 @@ def main():
         line["configs"] = configs
         line["next_rows"] = next_rows
         line["configs_narrow"] = narrow_configs(env)
+        try:
+            line["coalesce_by_batch_rows"] = coalesce_by_batch_rows(env)
+        except Exception as ex:  # noqa: BLE001
+            line["coalesce_by_batch_rows"] = {"error": repr(ex)[:300]}
 
     if wl == "filter_take" and (world > 1 or args.reassemble == "allgatherv") and use_dist and exchange_ok and not args.no_configs:
         # BASELINE configs[4]: {Int64, Float64, bitmaps} per shard through filter_record_batch, then ONE exchange of both
