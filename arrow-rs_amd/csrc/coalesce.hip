@@ -933,8 +933,16 @@ bool slab_eligible(ah_context* ctx, const ah_coalescer* co, int n, const ah_arra
     const int w = co->cols[k].width;
     if (co->cols[k].generic || !(w == 1 || w == 2 || w == 4 || w == 8)) return false;
   }
-  for (int i = 0; i < n; ++i)  // (a predicate longer than its batch: check_filter reports it)
+  int64_t rows = 0;
+  for (int i = 0; i < n; ++i) {  // (a predicate longer than its batch: check_filter reports it)
     if (filters[i].length > num_rows[i] || (filters[i].length >> 12) >= INT32_MAX) return false;
+    rows += filters[i].length;
+  }
+  // A handful of very large batches keeps the round-4 grouped path: per-batch predicate objects with quantile prefixes and at
+  // most 8 segments per launch — measured at 2^24-row batches, 8 per push: 3.07-3.24 ms per 1e9 rows against 3.27-3.55 here
+  // (profiles/r05_coalesce_sweep.md).  Below ~4 Mi rows per batch, or with more batches than that path groups, the tables win.
+  static const char* force = getenv("AH_COALESCE_SLAB");
+  if (!(force && force[0] == '1') && n <= 8 && rows >= (int64_t)n << 22) return false;
   return true;
 }
 

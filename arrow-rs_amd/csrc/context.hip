@@ -210,15 +210,28 @@ ah_status ah_out_alloc(ah_context* ctx, size_t bytes, void** out) {
 ah_status ah_slab_create(ah_context* ctx, size_t bytes, ah_slab** out) {
   *out = nullptr;
   void* b = nullptr;
-  AH_TRY(ah_pool_alloc(ctx, bytes ? bytes : 8, &b));
+  if (!bytes) bytes = 8;
+  const bool rz = redzone_on();  // AH_DEBUG_REDZONE: a canary behind the slab as behind every other output buffer
+  AH_TRY(ah_pool_alloc(ctx, bytes + (rz ? RZ : 0), &b));
+  if (rz) AH_HIP(ctx, hipMemsetAsync((char*)b + bytes, 0xA5, RZ, ctx->stream));
   auto* s = new ah_slab();
-  s->block = b, s->bytes = bytes ? bytes : 8, s->refs = 1;
+  s->block = b, s->bytes = bytes, s->refs = 1;
   ctx->slabs[(uintptr_t)b] = s;
   *out = s;
   return AH_OK;
 }
 void ah_slab_unref(ah_context* ctx, ah_slab* s) {
   if (!s || --s->refs > 0) return;
+  if (redzone_on()) {
+    unsigned char tail[RZ];
+    hipStreamSynchronize(ctx->stream);
+    if (hipMemcpy(tail, (char*)s->block + s->bytes, RZ, hipMemcpyDeviceToHost) == hipSuccess)
+      for (size_t i = 0; i < RZ; ++i)
+        if (tail[i] != 0xA5) {
+          fprintf(stderr, "arrow_hip: REDZONE CORRUPTED: slab %p of %zu bytes overrun at +%zu\n", s->block, s->bytes, i);
+          abort();
+        }
+  }
   ctx->slabs.erase((uintptr_t)s->block);
   ah_pool_free(ctx, s->block);
   delete s;

@@ -68,7 +68,7 @@ def parse():
     p.add_argument("--batch-rows", type=int, default=1 << 24, help="coalesce workload: rows per pushed batch")
     p.add_argument("--reassemble", default="auto", choices=["auto", "none", "allgatherv"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
+    p.add_argument("--cpu-sample-rows", type=int, default=1 << 27)  # SURVEY 8d / BASELINE.md 2: 2^27-2^28 rows
     p.add_argument("--no-configs", action="store_true", help="skip the configs[2]/[3] lines of the default run")
     p.add_argument("--only-narrow", action="store_true", help="print just the configs_narrow block (4-byte and narrower operands)")
     p.add_argument("--only-coalesce-sweep", default=None, nargs="?", const="all",
@@ -1109,6 +1109,8 @@ def build_workload(env, wl):
         nb = n // br
         # (AH_COALESCE_TARGET_BATCHES: output batch size in pushed batches' worth of selected rows; experiments only)
         target = max(1, int(br * args.selectivity * float(os.environ.get("AH_COALESCE_TARGET_BATCHES", "4"))))
+        if target >= 64 and os.environ.get("AH_COALESCE_TARGET_ANY") != "1":
+            target = target // 64 * 64  # whole validity words per output batch: what the slab push (csrc/coalesce.hip) takes
         batches = [(A.RecordBatch(["a", "b"], [col.slice(i * br, br), col2.slice(i * br, br)]), pred.slice(i * br, br))
                    for i in range(nb)]
 
