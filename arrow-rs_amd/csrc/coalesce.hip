@@ -941,8 +941,11 @@ bool slab_eligible(ah_context* ctx, const ah_coalescer* co, int n, const ah_arra
   // A handful of very large batches keeps the round-4 grouped path: per-batch predicate objects with quantile prefixes and at
   // most 8 segments per launch — measured at 2^24-row batches, 8 per push: 3.07-3.24 ms per 1e9 rows against 3.27-3.55 here
   // (profiles/r05_coalesce_sweep.md).  Below ~4 Mi rows per batch, or with more batches than that path groups, the tables win.
+  // (and only while the push fills a handful of output batches: that path launches once per output window — 12 000 launches and
+  // 147 ms per 1e9 rows at a target of 8192)
   static const char* force = getenv("AH_COALESCE_SLAB");
-  if (!(force && force[0] == '1') && n <= 8 && rows >= (int64_t)n << 22) return false;
+  const double est_out_batches = (double)rows * co->selectivity / (double)co->target;
+  if (!(force && force[0] == '1') && n <= 8 && rows >= (int64_t)n << 22 && est_out_batches <= 4.0) return false;
   return true;
 }
 

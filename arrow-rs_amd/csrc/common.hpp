@@ -50,6 +50,11 @@ struct ah_context {
   // (found by ADDRESS RANGE: a pointer inside a live slab's block is a slice of it — no per-slice bookkeeping: a slab push
   // hands out 30 000 output batches per 1e9 rows at the reference's batch sizes)
   std::map<uintptr_t, struct ah_slab*> slabs;  // block base -> slab
+  // A fault a DEFERRED call found on the device (ah_take's out-of-bounds index: the reference's panic) stays there until the
+  // host next waits for the stream: 4 device words {position (~0 = none), index value, values length, kind}; the first fault
+  // in stream order wins.  ah_synchronize / ah_array_resolve read them when `fault_armed` and raise the error.
+  unsigned long long* fault_dev = nullptr;
+  bool fault_armed = false, capture_fault_armed_before = false;
   struct hook_entry {
     ah_free_fn free_;
     void* user;
@@ -199,6 +204,9 @@ bool ah_type_is_signed(ah_type t);
 bool ah_type_is_float(ah_type t);
 
 void ah_out_init(ah_array_out* out);
+// context.hip: after the stream has been waited for — the fault a deferred call left on the device, if any (AH_PANIC with the
+// reference's text), else AH_OK
+ah_status ah_check_deferred_fault(ah_context* ctx);
 
 // context.hip: a pool block whose slices are handed out as results (released through ah_array_release / ah_out_free like
 // any other output buffer)

@@ -457,6 +457,16 @@ extern "C" ah_status ah_context_create(int device, ah_context** out) {
     delete c;
     return AH_HIP_ERROR;
   }
+  const unsigned long long fault_init[4] = {~0ull, 0, 0, 0};
+  if (hipMalloc((void**)&c->fault_dev, sizeof fault_init) != hipSuccess ||
+      hipMemcpy(c->fault_dev, fault_init, sizeof fault_init, hipMemcpyHostToDevice) != hipSuccess) {
+    if (c->fault_dev) hipFree(c->fault_dev);
+    hipFree(c->scratch);
+    hipHostFree(c->pinned);
+    hipStreamDestroy(c->own_stream);
+    delete c;
+    return AH_HIP_ERROR;
+  }
   *out = c;
   return AH_OK;
 }
@@ -470,6 +480,7 @@ extern "C" void ah_context_destroy(ah_context* ctx) {
   for (auto& kv : ctx->pool_live) hipFree(kv.first);
   for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
   if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->fault_dev) hipFree(ctx->fault_dev);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   for (auto& pb : ctx->pinned_cache) hipHostFree(pb.second);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -574,6 +585,7 @@ struct ah_graph {
   hipGraphExec_t exec = nullptr;
   std::vector<void*> held;  // pooled blocks the captured calls released (scratch): parked until the graph dies
   int nodes = 0;
+  bool arms_fault = false;  // a recorded call (ah_take) can leave a fault on the device: every replay re-arms the host's check
 };
 
 extern "C" ah_status ah_graph_begin(ah_context* ctx) {
@@ -587,6 +599,8 @@ extern "C" ah_status ah_graph_begin(ah_context* ctx) {
   ctx->capture_was_deferred = ctx->deferred;
   ctx->deferred = true;  // only enqueue-only entry points can be recorded; everything else fails fast (no wait is possible)
   ctx->capturing = true;
+  ctx->capture_fault_armed_before = ctx->fault_armed;
+  ctx->fault_armed = false;
   return AH_OK;
 }
 
@@ -599,6 +613,8 @@ extern "C" ah_status ah_graph_end(ah_context* ctx, ah_graph** out) {
   auto* g = new ah_graph();
   hipError_t e = hipStreamEndCapture(ctx->stream, &g->graph);
   ctx->capturing = false;
+  g->arms_fault = ctx->fault_armed;  // (nothing ran while recording: the capture itself leaves no fault)
+  ctx->fault_armed = ctx->capture_fault_armed_before;
   ctx->deferred = ctx->capture_was_deferred;
   g->held.swap(ctx->capture_hold);
   for (int k = 0; k < 8 && hipGetLastError() != hipSuccess; ++k) {}  // errors raised while recording are sticky per thread
@@ -646,6 +662,7 @@ extern "C" ah_status ah_graph_launch(ah_context* ctx, ah_graph* g) {
   if (ctx->capturing) return ah_fail(ctx, AH_INVALID_ARGUMENT, "cannot launch a graph while recording one");
   hipSetDevice(ctx->device);
   ctx->inflight = true;
+  if (g->arms_fault) ctx->fault_armed = true;
   AH_HIP(ctx, hipGraphLaunch(g->exec, ctx->stream));
   return AH_OK;
 }
@@ -664,12 +681,27 @@ extern "C" void ah_graph_destroy(ah_context* ctx, ah_graph* g) {
   delete g;
 }
 
+// The fault slot of deferred calls (common.hpp): read and re-armed after a stream wait.
+ah_status ah_check_deferred_fault(ah_context* ctx) {
+  if (!ctx->fault_armed || !ctx->fault_dev) return AH_OK;
+  ctx->fault_armed = false;
+  unsigned long long w[4];
+  AH_HIP(ctx, hipMemcpy(w, ctx->fault_dev, sizeof w, hipMemcpyDeviceToHost));
+  if (w[0] == ~0ull) return AH_OK;
+  const unsigned long long rearm[4] = {~0ull, 0, 0, 0};
+  AH_HIP(ctx, hipMemcpy(ctx->fault_dev, rearm, sizeof rearm, hipMemcpyHostToDevice));
+  // ah_take's three panics (take.rs:447, :454; arrow-buffer/src/buffer/boolean.rs:495), as the synchronous call words them
+  if (w[3] == 0) return ah_fail(ctx, AH_PANIC, "assertion failed: idx < self.bit_len");
+  if (w[3] == 1) return ah_fail(ctx, AH_PANIC, "Out-of-bounds index %llu", w[1]);
+  return ah_fail(ctx, AH_PANIC, "index out of bounds: the len is %lld but the index is %llu", (long long)w[2], w[1]);
+}
+
 extern "C" ah_status ah_synchronize(ah_context* ctx) {
   ah_ctx_guard _guard(ctx);
   if (ctx->capturing) return ah_fail(ctx, AH_INVALID_ARGUMENT, "ah_synchronize while a graph is being recorded: end the capture first");
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->inflight = false;
-  return AH_OK;
+  return ah_check_deferred_fault(ctx);
 }
 
 extern "C" ah_status ah_array_resolve(ah_context* ctx, ah_array_out* out) {
@@ -677,6 +709,7 @@ extern "C" ah_status ah_array_resolve(ah_context* ctx, ah_array_out* out) {
   if (!ctx || !out) return AH_INVALID_ARGUMENT;
   hipSetDevice(ctx->device);
   AH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  AH_TRY(ah_check_deferred_fault(ctx));
   if (out->null_count >= 0) return AH_OK;
   if (!out->validity) {
     out->null_count = 0;

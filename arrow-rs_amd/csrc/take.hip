@@ -195,6 +195,32 @@ __global__ void __launch_bounds__(1024) take_finish_kernel(const unsigned long l
   }
 }
 
+// Deferred mode (and hipGraph capture): nothing is read back.  If the gather met an out-of-bounds index, the FIRST such fault
+// in stream order is parked in the context's fault slot {position, index value as the reference prints it, values length,
+// kind} — ah_synchronize / ah_array_resolve raise it with the synchronous call's text — and the position word is re-armed
+// for the next call (also on every replay of a captured graph).
+__global__ void __launch_bounds__(64) take_finish_deferred_kernel(unsigned long long* first_oob, const void* indices, int iw, int is_signed,
+                                                                  unsigned long long values_len, unsigned long long kind,
+                                                                  unsigned long long* fault) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long oob = *first_oob;
+  if (oob == ~0ull) return;
+  *first_oob = ~0ull;
+  if (fault[0] != ~0ull) return;  // an earlier call's fault is still waiting for the host
+  unsigned long long raw = 0;
+  const unsigned char* p = (const unsigned char*)indices + oob * (unsigned long long)iw;
+  for (int b = 0; b < iw; ++b) raw |= (unsigned long long)p[b] << (8 * b);
+  unsigned long long uv = raw;  // ToIndices (take.rs:1030-1084): i8 / i16 widen with their sign, then everything is taken as unsigned
+  if (is_signed && iw == 1) uv = (uint32_t)(int32_t)(int8_t)raw;
+  else if (is_signed && iw == 2) uv = (uint32_t)(int32_t)(int16_t)raw;
+  else if (iw == 4) uv = (uint32_t)raw;
+  fault[1] = uv;
+  fault[2] = values_len;
+  fault[3] = kind;
+  __threadfence();
+  fault[0] = oob;
+}
+
 template <int W, typename IDX>
 void launch_take_wi(ah_context* ctx, const TakeArgs& a, bool out_valid, int grid) {
   if (out_valid) take_kernel<W, IDX, true, 4><<<grid, 256, 0, ctx->stream>>>(a);
@@ -277,8 +303,13 @@ extern "C" ah_status ah_take(ah_context* ctx, const ah_array_view* values,
   const int64_t n = indices->length;
   out->type = values->type;
 
+  // Deferred mode: a take of fixed-width values without check_bounds only ENQUEUES — the reference's
+  // out-of-bounds panic is raised by the next ah_synchronize / ah_array_resolve (same text) instead of at return.  It needs
+  // the index null count to be known (it picks the panic's wording) or no index validity at all.
+  const bool defer = ctx->deferred && !check_bounds && !is_string && n > 0 && (!indices->validity || indices->null_count >= 0);
   int64_t idx_nulls = 0;
-  AH_TRY(ah_resolve_null_count(ctx, indices, &idx_nulls));
+  if (defer) idx_nulls = indices->validity ? indices->null_count : 0;
+  else AH_TRY(ah_resolve_null_count(ctx, indices, &idx_nulls));
   BitView ivalid = indices->validity ? make_bitview(indices->validity, indices->validity_bit_offset)
                                      : BitView{nullptr, 0};
 
@@ -345,7 +376,9 @@ extern "C" ah_status ah_take(ah_context* ctx, const ah_array_view* values,
   }
 
   int64_t val_nulls = 0;
-  {
+  if (defer) {
+    val_nulls = values->validity ? (values->null_count != 0 ? 1 : 0) : 0;  // unknown counts as "has nulls": the validity is gathered
+  } else {
     ah_status st = ah_resolve_null_count(ctx, values, &val_nulls);
     if (st != AH_OK) {
       ah_pool_free(ctx, flags);
@@ -384,6 +417,30 @@ extern "C" ah_status ah_take(ah_context* ctx, const ah_array_view* values,
     st = launch_take(ctx, width, indices->type, a, out_valid, grid);
   }
   hipError_t e = hipSuccess;
+  if (st == AH_OK && defer) {
+    const unsigned long long kind = width == 0 ? 0 : (idx_nulls > 0 ? 1 : 2);
+    take_finish_deferred_kernel<<<1, 64, 0, ctx->stream>>>(first_pos, indices->values, ah_type_width(indices->type),
+                                                           ah_type_is_signed(indices->type) ? 1 : 0, (unsigned long long)values->length, kind,
+                                                           ctx->fault_dev);
+    e = hipGetLastError();
+    ah_pool_free(ctx, flags);  // (reuse is stream-ordered; while a graph is recorded the block stays parked with it)
+    if (e != hipSuccess) {
+      ah_out_free(ctx, ov, vbytes);
+      ah_out_free(ctx, ob, bbytes);
+      return ah_fail(ctx, AH_HIP_ERROR, "take failed: %s", hipGetErrorString(e));
+    }
+    ctx->fault_armed = true;
+    ctx->inflight = true;
+    out->length = n;
+    out->values = ov;
+    out->values_bytes = (int64_t)vbytes;
+    if (out_valid) {  // kept even if it turns out all-valid; the count is unknown until ah_array_resolve
+      out->validity = (uint8_t*)ob;
+      out->validity_bytes = (int64_t)bbytes;
+      out->null_count = -1;
+    }
+    return AH_OK;
+  }
   if (st == AH_OK) {
     const uint64_t seq = ah_mail_next(ctx);
     take_finish_kernel<<<1, 1024, 0, ctx->stream>>>(out_valid ? block_valid : nullptr, grid, first_pos,

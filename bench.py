@@ -753,8 +753,7 @@ def reference_bench_shapes(env, batch=64):
                   with ONE wait (ah_filter_predicates_build), every apply / arith / compare only ENQUEUED (deferred mode),
                   ONE ah_synchronize at the end — what an engine that has several batches queued can do;
       cpu_1core_us the oracle (scalar port of the reference's kernel) on one host core, same data.
-    take stays synchronous in every mode (an out-of-bounds index must surface as the reference's panic), so it has no
-    batched form: at 512 / 1 024 rows a GPU call cannot win and the line says so."""
+    take (round 5) has the deferred form too: the out-of-bounds panic is then raised by the next ah_synchronize."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import arrow_rs_amd as A
@@ -912,8 +911,21 @@ def reference_bench_shapes(env, batch=64):
             o = orc.Out()
             oracle.lib.orc_take(C.byref(hvh.view), C.byref(hih.view), 0, C.byref(o))
             oracle.lib.orc_release(C.byref(o))
-        row(f"take i32 {m}", m, timed(sync, 200), None, cpu_timed(cpu),
-            "take reports out-of-bounds indices (the reference's panic) at return, so it is synchronous in every mode: no batched form")
+        def batched():  # deferred mode (round 5): the gathers are only enqueued; an out-of-bounds index would be raised by the synchronize
+            lib.ah_context_set_deferred(h, 1)
+            try:
+                outs = [L.ArrayOut() for _ in range(batch)]
+                for i in range(batch):
+                    assert lib.ah_take(h, C.byref(vv), C.byref(iv), 0, C.byref(outs[i])) == 0
+            finally:
+                lib.ah_context_set_deferred(h, 0)
+            assert lib.ah_synchronize(h) == 0
+            for o in outs:
+                release(o)
+        gus = graph_timed(lambda o: lib.ah_take(h, C.byref(vv), C.byref(iv), 0, C.byref(o)))
+        row(f"take i32 {m}", m, timed(sync, 200), timed(batched, 8) / batch, cpu_timed(cpu),
+            "sync: an out-of-bounds index (the reference's panic) is reported at return; batched / graph: deferred mode, the panic "
+            "is raised by the next ah_synchronize", graph_us=gus)
 
     # ---- add_wrapping / lt on 65 536 Float32, no nulls (arithmetic_kernels.rs add(0), comparison_kernels.rs lt)
     ha = orc.HostArray(A.Float32, rng.random(n, dtype=np.float32))

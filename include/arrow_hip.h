@@ -179,13 +179,17 @@ AH_API void* ah_context_stream(ah_context* ctx);
  * by default: every entry point returns with its result complete and `null_count` known.  With deferred mode
  * on, the entry points whose output SHAPE does not depend on the data and that cannot fail on the device —
  * ah_arith_binary / ah_arith_neg for the wrapping, floating-point and bitwise ops, ah_bitwise_not, ah_compare,
- * ah_boolean_binary / ah_boolean_unary, ah_cast between numeric types in safe mode, and
- * ah_filter_predicate_apply on fixed-width and Boolean values (the row count comes from the predicate) — only
+ * ah_boolean_binary / ah_boolean_unary, ah_cast between numeric types in safe mode,
+ * ah_filter_predicate_apply on fixed-width and Boolean values (the row count comes from the predicate), and ah_take of
+ * fixed-width / Boolean values without check_bounds (indices with a known null count or no validity) — only
  * ENQUEUE their kernels on the context's stream and return at once: no host synchronisation, `null_count = -1`
  * ("unknown", the C Data Interface's convention; every entry point accepts -1 on its inputs) and the validity
  * buffer kept even where the synchronous call would have dropped an all-valid one.  Results may be passed
  * straight to further calls on the same context (stream order).  Before reading them from the host, another
  * stream or another context call ah_synchronize(); ah_array_resolve() does that and fills in null_count.
+ * A deferred ah_take that meets an out-of-bounds index cannot report it at return: the reference's panic (same AH_PANIC
+ * text as the synchronous call, take.rs:447,454) is returned by the NEXT ah_synchronize / ah_array_resolve on the context —
+ * the first such fault in stream order; the take's own output is then garbage at that row, as after a caught panic.
  * Every other entry point (data-dependent sizes, device-side errors to report) stays synchronous. */
 AH_API void ah_context_set_deferred(ah_context* ctx, int32_t on);
 AH_API int32_t ah_context_deferred(const ah_context* ctx);

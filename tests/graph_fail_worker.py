@@ -32,7 +32,7 @@ def works(tag):
 works("before")
 cases = {
     "checked add (reads its error word back)": lambda: K.add(a, b),
-    "take (reports out-of-bounds indices at return)": lambda: K.take(a, idx),
+    "take with check_bounds (reports at return)": lambda: K.take(a, idx, K.TakeOptions(True)),
     "cast to Utf8 (data-dependent size)": lambda: K.cast(b, A.Utf8),
     "a host copy": lambda: a.values_numpy(),
     "synchronize": lambda: ctx.synchronize(),

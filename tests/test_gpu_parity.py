@@ -313,6 +313,65 @@ def test_take_oob_semantics(ctx):
     assert str(ei.value) == "Out-of-bounds index 400"
 
 
+def test_take_deferred_mode_parity_and_late_oob(ctx, oracle):
+    """ah_take in deferred mode only ENQUEUES (no read-back): results are the oracle's (null count
+    resolved lazily), and an out-of-bounds index — the reference's panic (take.rs:447,454) — surfaces at the NEXT
+    ah_synchronize / ah_array_resolve with the synchronous call's exact text, the first fault in stream order, once."""
+    rng = np.random.default_rng(_seed("take-deferred"))
+    v4 = HostArray(A.Int32, np.arange(4, dtype=np.int32)).to_device(ctx)
+    cases = []
+    for it, (vdt, idt) in enumerate([(A.Int64, A.UInt32), (A.Int8, A.Int16), (A.Float64, A.Int64), (A.Boolean, A.UInt8), (A.Int32, A.Int32)]):
+        vlen = int(rng.integers(1, 200 if idt in (A.UInt8,) else 5000))
+        n = int(rng.integers(1, 9000))
+        hv = HostArray(vdt, _rand_values(rng, vdt, vlen), (rng.random(vlen) < 0.8) if it % 2 else None)
+        idx = rng.integers(0, min(vlen, np.iinfo(idt.np_dtype).max), n).astype(idt.np_dtype)
+        ivalid = (rng.random(n) < 0.85) if it % 3 == 0 else None
+        if ivalid is not None:
+            idx = np.where(ivalid, idx, np.iinfo(idt.np_dtype).max).astype(idt.np_dtype)
+        hi = HostArray(idt, idx, ivalid)
+        cases.append((hv, hi, hv.to_device(ctx), hi.to_device(ctx)))
+    with ctx.deferred_mode():
+        outs = [K.take(dv, di) for _hv, _hi, dv, di in cases]  # enqueued back to back, nothing read back
+        chained = K.take(outs[0], cases[0][3].slice(0, min(50, cases[0][3].length)))  # a deferred result as the next call's values
+    for (hv, hi, _dv, _di), got in zip(cases, outs):
+        check(got, oracle.take(hv, hi), f"deferred take {hv.data_type} by {hi.data_type}")
+    check(chained, oracle.take(oracle.take(cases[0][0], cases[0][1]), cases[0][1].slice(0, min(50, len(cases[0][1])))), "deferred take of a deferred take")
+    # out-of-bounds: nothing at return, the panic at the next synchronisation — the three wordings
+    for mk, text in ((lambda: HostArray(A.Int32, np.array([1, -1], dtype=np.int32)), "index out of bounds: the len is 4 but the index is 4294967295"),
+                     (lambda: HostArray(A.UInt32, np.array([1, 400, 2], dtype=np.uint32), np.array([True, True, False])), "Out-of-bounds index 400"),
+                     (lambda: HostArray(A.Int16, np.array([2, 3, -5, 9], dtype=np.int16)), "index out of bounds: the len is 4 but the index is 4294967291")):
+        ctx.set_deferred(True)
+        try:
+            bad = K.take(v4, mk().to_device(ctx))      # returns: only enqueued
+            good = K.take(v4, HostArray(A.UInt32, np.array([3, 0], dtype=np.uint32)).to_device(ctx))
+            also_bad = K.take(v4, HostArray(A.UInt32, np.array([77], dtype=np.uint32)).to_device(ctx))  # a later fault: the first one wins
+            with pytest.raises(A.Panic) as ei:
+                ctx.synchronize()
+            assert str(ei.value) == text
+            ctx.synchronize()  # raised once; the slot is re-armed
+            assert host(good).to_pylist() == [3, 0]
+            del bad, also_bad
+        finally:
+            ctx.set_deferred(False)
+    with ctx.deferred_mode():  # Boolean values: BooleanBuffer::value's assertion
+        hb = HostArray(A.Boolean, np.array([True, False, True]))
+        K.take(hb.to_device(ctx), HostArray(A.UInt32, np.array([0, 5], dtype=np.uint32)).to_device(ctx))
+        with pytest.raises(A.Panic) as ei:
+            ctx.synchronize()
+        assert str(ei.value) == "assertion failed: idx < self.bit_len"
+    # check_bounds and string values stay synchronous in deferred mode (errors at return)
+    with ctx.deferred_mode():
+        with pytest.raises(A.array.ComputeError):
+            K.take(v4, HostArray(A.Int32, np.array([1, 9], dtype=np.int32)).to_device(ctx), K.TakeOptions(True))
+    # a recorded take: every replay re-arms the check
+    ok_idx = HostArray(A.UInt32, np.array([3, 1, 1, 0], dtype=np.uint32)).to_device(ctx)
+    with ctx.graph_capture() as g:
+        t = K.take(v4, ok_idx)
+    g.launch()
+    ctx.synchronize()
+    assert host(t).to_pylist() == [3, 1, 1, 0]
+
+
 # -------------------------------------------------------------- fuzz: arith
 @pytest.mark.parametrize("dt", [A.Int8, A.Int16, A.Int32, A.Int64, A.UInt8, A.UInt16, A.UInt32, A.UInt64,
                                 A.Float32, A.Float64], ids=str)
