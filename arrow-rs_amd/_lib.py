@@ -219,6 +219,8 @@ SIGNATURES = {
     "ah_bitwise_not": (C.c_int32, [_P, _VIEW, _OUT]),
     "ah_arith_neg": (C.c_int32, [_P, _VIEW, C.c_int32, _OUT]),
     "ah_compare": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, _VIEW, C.c_int32, _OUT]),
+    "ah_compare_with_types": (C.c_int32, [_P, C.c_int32, _VIEW, C.c_int32, C.POINTER(DataTypeDesc), _VIEW, C.c_int32,
+                                          C.POINTER(DataTypeDesc), _OUT]),
     "ah_boolean_binary": (C.c_int32, [_P, C.c_int32, _VIEW, _VIEW, _OUT]),
     "ah_boolean_unary": (C.c_int32, [_P, C.c_int32, _VIEW, _OUT]),
     "ah_nullif": (C.c_int32, [_P, _VIEW, _VIEW, _OUT]),

@@ -621,13 +621,14 @@ class Array:
     @classmethod
     def _from_out(cls, ctx, out, data_type, keepalive=()):
         w = data_type.width
+        owner = _OutOwner(ctx, out, keepalive)  # first: if anything below raises, the buffers are still released
         if (w > 0 and out.flags == 0 and out.values and out.values_bytes >= _SHRINK_MIN_BYTES
-                and out.values_bytes > _SHRINK_SLACK * max(out.length, 1) * w):
+                and out.values_bytes > _SHRINK_SLACK * max(out.length, 1) * w and not ctx.deferred):
             # the one-launch small filter allocates for the worst case (every row selected) so that it need not wait
             # for the count first; a long-lived, highly selective result would pin len / K times its size:
             # Buffer::shrink_to_fit it.  Results that are close to their allocation keep it (no copy on the fast path).
+            # Not in deferred mode / while a graph is recorded: the shrink waits for the stream and copies.
             ctx.check(ctx.lib.ah_array_shrink_to_fit(ctx.handle, C.byref(out)))
-        owner = _OutOwner(ctx, out, keepalive)
         # `values_bytes` is the ALLOCATION (what release frees); the array itself is the first length * width bytes
         vbytes = min(out.values_bytes, out.length * w) if (w > 0 and out.flags == 0) else out.values_bytes
         vals = _RawMem(out.values, vbytes, owner) if out.values else None

@@ -3,7 +3,7 @@ Floats compare in IEEE totalOrder; equality is bitwise (arrow-array/src/arithmet
 import ctypes as C
 
 from ... import _lib as L
-from ...array import Array, Boolean, InvalidArgumentError
+from ...array import Array, Boolean
 
 EQ, NEQ, LT, LT_EQ, GT, GT_EQ, DISTINCT, NOT_DISTINCT = range(8)
 
@@ -14,10 +14,13 @@ def _compare(op, lhs, rhs):
     ctx = l.ctx
     out = L.ArrayOut()
     lv, rv = l.view(), r.view()
-    if l.data_type.physical == L.AH_FIXED16 and l.data_type != r.data_type:
-        # compare_op (cmp.rs:243-249): the logical types must agree — Decimal128(12, 3) vs Decimal128(12, 1) is refused
-        sym = ["==", "!=", "<", "<=", ">", ">=", "IS DISTINCT FROM", "IS NOT DISTINCT FROM"][op]
-        raise InvalidArgumentError(f"Invalid comparison operation: {l.data_type} {sym} {r.data_type}")
+    if l.data_type.logical is not None or r.data_type.logical is not None:
+        # compare_op's rule that the LOGICAL types agree (cmp.rs:243-264: Decimal128(12, 3) vs Decimal128(12, 1) is refused)
+        # lives behind the C ABI (ah_compare_with_types), not here: a Rust host gets it from the same place
+        lt, rt = l.data_type.descriptor(), r.data_type.descriptor()
+        ctx.check(ctx.lib.ah_compare_with_types(ctx.handle, op, C.byref(lv), int(l_s), C.byref(lt), C.byref(rv), int(r_s),
+                                                C.byref(rt), C.byref(out)))
+        return Array._from_out(ctx, out, Boolean)
     ctx.check(ctx.lib.ah_compare(ctx.handle, op, C.byref(lv), int(l_s), C.byref(rv), int(r_s),
                                  C.byref(out)))
     return Array._from_out(ctx, out, Boolean)

@@ -156,3 +156,25 @@ extern "C" ah_status ah_arith_with_types(ah_context* ctx, ah_arith_op op, const 
     return interval_nyi();
   return ah_fail(ctx, AH_INVALID_ARGUMENT, "Invalid arithmetic operation: %s %s %s", ls.c_str(), op_text(op), rs.c_str());
 }
+
+// compare_op's type rule behind the C ABI (arrow-ord/src/cmp.rs:243-264): the LOGICAL types of the two sides must be equal —
+// Decimal128(12, 3) vs Decimal128(12, 1), Timestamp(Second) vs Timestamp(Millisecond), Date32 vs Int32 are refused with the
+// reference's text — then the values compare as their physical type (ah_compare).  Round 4 kept this check in the Python
+// mirror (compute/kernels/cmp.py), where a Rust host would have had to re-implement it.
+extern "C" ah_status ah_compare_with_types(ah_context* ctx, ah_cmp_op op, const ah_array_view* lhs, int32_t lhs_is_scalar,
+                                           const ah_data_type* lhs_type, const ah_array_view* rhs, int32_t rhs_is_scalar,
+                                           const ah_data_type* rhs_type, ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !lhs || !rhs || !lhs_type || !rhs_type || !out) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  if (op < AH_EQ || op > AH_NOT_DISTINCT) return ah_fail(ctx, AH_INVALID_ARGUMENT, "unknown comparison op %d", op);
+  const ah_data_type &l = *lhs_type, &r = *rhs_type;
+  const bool same = l.id == r.id && l.unit == r.unit && (l.has_tz != 0) == (r.has_tz != 0) &&
+                    (!l.has_tz || l.tz_offset_seconds == r.tz_offset_seconds) && l.precision == r.precision && l.scale == r.scale;
+  if (!same) {
+    static const char* sym[] = {"==", "!=", "<", "<=", ">", ">=", "IS DISTINCT FROM", "IS NOT DISTINCT FROM"};  // Display for Op (cmp.rs:55-68)
+    return ah_fail(ctx, AH_INVALID_ARGUMENT, "Invalid comparison operation: %s %s %s", arith_type_text(l).c_str(), sym[op - AH_EQ],
+                   arith_type_text(r).c_str());
+  }
+  return ah_compare(ctx, op, lhs, lhs_is_scalar, rhs, rhs_is_scalar, out);
+}

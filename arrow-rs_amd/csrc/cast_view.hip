@@ -40,9 +40,12 @@ __device__ __forceinline__ int block_sum(int v, int* s_wave) {
 // pass 1: bytes of the long (> 12) strings of valid rows, per block of VB rows
 template <typename OFF>
 __global__ void __launch_bounds__(VT) view_long_bytes_kernel(const OFF* offs, BitView valid, int64_t len, uint32_t* block_bytes) {
-  __shared__ int s_wave[VT / 64];
+  __shared__ unsigned long long s_tot[VT / 64];
   const int64_t r0 = (int64_t)blockIdx.x * VB + (int64_t)threadIdx.x * VR;
-  int mine = 0;
+  // 64-bit sums, SATURATED into the u32 block total: a LargeUtf8 source with more than 2-4 GiB of long strings inside one
+  // block's 1024 rows wrapped here BEFORE the caller's `long_bytes > INT32_MAX` test, which could then pass on a wrapped
+  // total; a saturated block keeps the grand total above the limit
+  unsigned long long mine = 0;
   OFF o[VR + 1];
 #pragma unroll
   for (int k = 0; k <= VR; ++k) o[k] = r0 + k <= len ? offs[r0 + k] : OFF(0);
@@ -50,10 +53,16 @@ __global__ void __launch_bounds__(VT) view_long_bytes_kernel(const OFF* offs, Bi
   for (int k = 0; k < VR; ++k)
     if (r0 + k < len) {
       const int64_t l = (int64_t)o[k + 1] - (int64_t)o[k];
-      if (l > INLINE_MAX && bv_get(valid, r0 + k)) mine += (int)l;
+      if (l > INLINE_MAX && bv_get(valid, r0 + k)) mine += (unsigned long long)l;
     }
-  const int tot = block_sum(mine, s_wave);
-  if (threadIdx.x == 0) block_bytes[blockIdx.x] = (uint32_t)tot;
+  mine = wave_reduce_add64(mine);
+  if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long tot = 0;
+    for (int w = 0; w < VT / 64; ++w) tot += s_tot[w];
+    block_bytes[blockIdx.x] = tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot;
+  }
 }
 
 // exclusive scan of the block totals (u32 -> u64), one workgroup: every thread owns a contiguous slice
@@ -88,7 +97,9 @@ __global__ void __launch_bounds__(1024) view_scan_kernel(const uint32_t* block_b
 
 // the first 12 bytes at `p` (which may have any alignment) as three dwords; bytes at index >= l are zero
 __device__ __forceinline__ void load12(const uint8_t* data, int64_t base, int l, int64_t data_bytes, uint32_t d[3]) {
-  if (base + 16 <= data_bytes) {  // four aligned dwords cover bytes [a, a + 12] whatever a & 3 is
+  // four aligned dwords cover bytes [a, a + 12] whatever a & 3 is — the first of them starts up to 3 bytes BEFORE a, so the
+  // fast path needs a 4-aligned buffer start or base >= 3 (an unaligned / sliced values buffer read before its start: ADVICE r04)
+  if (base + 16 <= data_bytes && ((((uintptr_t)data) & 3) == 0 || base >= 3)) {
     const uintptr_t a = (uintptr_t)(data + base);
     const uint32_t* p = (const uint32_t*)(a & ~(uintptr_t)3);
     const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];

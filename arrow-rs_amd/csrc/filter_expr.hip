@@ -246,8 +246,13 @@ __device__ __forceinline__ void expr_value_words(const ExprArgs& a, int64_t row0
 // two-element vector load, and (RS) every right-hand side is a scalar: the loads of four steps are unconditional vector
 // loads issued back to back and the comparison is branch-free.  FW == 0: any mix of widths / alignments / scalar sides,
 // dispatched per term at run time (correct, not tuned).
+#ifdef AH_EXPR_WAVES  // ablation builds: force the occupancy of the count pass (profiles/r05_expr_occupancy.md)
+#define AH_EXPR_ATTR __attribute__((amdgpu_waves_per_eu(AH_EXPR_WAVES, 8)))
+#else
+#define AH_EXPR_ATTR
+#endif
 template <int NT, int FW, bool RS>
-__global__ void __launch_bounds__(256) filter_expr_count_kernel(ExprArgs a) {
+__global__ void __launch_bounds__(256) AH_EXPR_ATTR filter_expr_count_kernel(ExprArgs a) {
   __shared__ uint32_t s_cnt[GROUP_CHUNKS_E];
   __shared__ ulonglong2 s_raw[4][NT][8];  // per wave: the comparison ballots of the chunk's terms, per wave step
   const int t = threadIdx.x, lane = t & 63, wave = ah_uniform(t >> 6);

@@ -1168,9 +1168,11 @@ def build_workload(env, wl):
         # LargeUtf8 column (the config-4 cast output) through filter and take — as two rows, because
         # the two halves are different machines: the filter is order-preserving (contiguous selected runs stream), the
         # take is a random row gather (bound by line fills)
-        n = min(n, 1 << 27) if args.rows == 1_000_000_000 else n
+        n = min(n, 1 << 29) if args.rows == 1_000_000_000 else n  # (2^29 rows: the size of the cast that produces the column, configs[3])
         src = gen_i64_column(A, ctx, n, 42, args.valid, row0, -10**6, 10**6)
         scol = K.cast(K.cast(src, A.Float64), A.LargeUtf8)
+        st["text_bytes"] = scol.values.nbytes
+        src = None
         pred = gen_predicate(A, ctx, n, 44, args.selectivity, row0)
         nidx = max(1, int(n * args.selectivity))
         ib = ctx.alloc(nidx * 4)
@@ -1309,6 +1311,10 @@ def describe(env, wl, W, prof, out, steps):
             alg += idx.length * (4 + 16 + 8) + 2 * ((idx.length + 7) // 8) + 2 * st["tbytes"]
         dom_avg, dom_n = sum(prof[kk][0] for kk in kernels) / max(steps, 1), steps
         dominant = f"{wl}_step"
+        if wl == "string_filter":
+            # SURVEY 8d prices "every input buffer read once in full": the WHOLE text buffer, not only the selected rows' bytes
+            # (whose 128-byte lines the kernel has to fetch almost all of anyway: ~14 rows per line, 10 % selected)
+            W["alg_survey_rule"] = alg - st["fbytes"] + st["text_bytes"]
     elif wl == "coalesce":
         k = st["out_rows"]
         # two columns share one predicate: 2 x (values + validity) + mask in, 2 x (K values + K bits) out
@@ -1438,6 +1444,8 @@ def _compact_config(c):
         rf = c["roofline"]
         out.update(kernel=rf.get("kernel"), avg_launch_ms=rf.get("avg_launch_ms"), alg_bytes=rf.get("algorithmic_bytes_per_launch"),
                    frac=rf.get("frac"))
+        if "frac_survey_rule" in rf:
+            out.update(alg_bytes_survey_rule=rf.get("algorithmic_bytes_survey_rule"), frac_survey_rule=rf.get("frac_survey_rule"))
     for k in ("single_push", "single_push_pipelined", "grouped_not_pipelined"):
         if isinstance(c.get(k), dict):
             out[k + "_ms"] = c[k].get("ms_without_kernel_events")
@@ -1991,6 +1999,13 @@ def main():
                             "kernel_avg_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof2.items()},
                             "host_gap_ms": round(ms2 - sum(v[0] for v in prof2.values()) / args.config_steps, 4),
                             "settle_ms": W2.get("settle_ms")}  # the untimed steps before the timed ones (run_timed)
+                if w2 == "string_filter" and W2.get("alg_survey_rule"):
+                    a2 = W2["alg_survey_rule"]
+                    dest[w2]["roofline"]["frac_selected_bytes_only"] = dest[w2]["roofline"]["frac"]
+                    dest[w2]["roofline"]["algorithmic_bytes_survey_rule"] = a2
+                    dest[w2]["roofline"]["frac_survey_rule"] = round(a2 / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                    dest[w2]["roofline"]["note"] = ("frac prices the selected rows' bytes only (read once, written once); frac_survey_rule prices the "
+                                                    "whole text buffer as an input read once in full (SURVEY 8d)")
                 if w2 == "coalesce":  # the single-push forms of the same step, beside the grouped one
                     for key, pipe, what in (("single_push", "0", "the same batches through one synchronous ah_coalescer_push_batch_with_filter call each"),
                                             ("single_push_pipelined", "1", "one batch per push, begin of batch i + 1 before end of batch i"),

@@ -251,7 +251,16 @@ numeric_fn! {
 fn compare_op(op: i32, lhs: &dyn Datum, rhs: &dyn Datum) -> Result<BooleanArray, ArrowError> {
     let ctx = current_context()?;
     let (l, r) = (operand(&ctx, lhs)?, operand(&ctx, rhs)?);
-    let out = call(&ctx, |c, o| unsafe { sys::ah_compare(c, op, &l.view, l.is_scalar, &r.view, r.is_scalar, o) })?;
+    // compare_op's rule that the LOGICAL types agree (cmp.rs:243-264: Decimal128(12, 3) vs Decimal128(12, 1) is refused) is the
+    // library's (ah_compare_with_types): this layer only says which logical types it holds
+    let (lt, rt) = (crate::logical(lhs.get().0.data_type())?, crate::logical(rhs.get().0.data_type())?);
+    let out = if lt.is_none() && rt.is_none() {
+        call(&ctx, |c, o| unsafe { sys::ah_compare(c, op, &l.view, l.is_scalar, &r.view, r.is_scalar, o) })?
+    } else {
+        let plain = |id| sys::ah_data_type { id, unit: 0, has_tz: 0, tz_offset_seconds: 0, precision: 0, scale: 0 };
+        let (lt, rt) = (lt.unwrap_or(plain(l.view.type_)), rt.unwrap_or(plain(r.view.type_)));
+        call(&ctx, |c, o| unsafe { sys::ah_compare_with_types(c, op, &l.view, l.is_scalar, &lt, &r.view, r.is_scalar, &rt, o) })?
+    };
     Ok(BooleanArray::from(wrap(ctx, out, DataType::Boolean, &[])?.to_data()))
 }
 

@@ -474,6 +474,12 @@ AH_API ah_status ah_compare(ah_context* ctx, ah_cmp_op op,
                             const ah_array_view* lhs, int32_t lhs_is_scalar,
                             const ah_array_view* rhs, int32_t rhs_is_scalar,
                             ah_array_out* out);
+/* ah_compare with compare_op's LOGICAL-type rule (cmp.rs:243-264): the two sides' DataTypes must be equal (Decimal128
+ * precision and scale, time units, zones included), else AH_INVALID_ARGUMENT "Invalid comparison operation: {l} {op} {r}";
+ * the values then compare as their physical type. */
+AH_API ah_status ah_compare_with_types(ah_context* ctx, ah_cmp_op op, const ah_array_view* lhs, int32_t lhs_is_scalar,
+                                       const ah_data_type* lhs_type, const ah_array_view* rhs, int32_t rhs_is_scalar,
+                                       const ah_data_type* rhs_type, ah_array_out* out);
 
 /* --------------------------------------------------------------- boolean */
 typedef int32_t ah_boolean_op;

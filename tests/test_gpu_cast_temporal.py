@@ -365,6 +365,13 @@ def test_decimal_compare_matches_the_oracle(ctx, oracle):
     with pytest.raises(A.array.InvalidArgumentError) as ei:
         K.lt(dl, HostArray.from_pylist(rv, A.Decimal128(38, 2)).to_device(ctx))
     assert ei.value.message == "Invalid comparison operation: Decimal128(38, 4) < Decimal128(38, 2)"
+    # the rule lives behind the C ABI (ah_compare_with_types, round 5): any two different LOGICAL types over one physical type
+    ts_s = HostArray(A.Timestamp(A.SECOND), np.arange(5, dtype=np.int64)).to_device(ctx)
+    ts_ms = HostArray(A.Timestamp(A.MILLISECOND), np.arange(5, dtype=np.int64)).to_device(ctx)
+    with pytest.raises(A.array.InvalidArgumentError) as ei:
+        K.gt_eq(ts_s, ts_ms)
+    assert ei.value.message.startswith("Invalid comparison operation: Timestamp(") and " >= Timestamp(" in ei.value.message
+    assert host(K.eq(ts_s, ts_s)).to_pylist() == [True] * 5  # equal logical types compare as their physical type
 
 
 def test_decimal_to_decimal_cast_matches_the_oracle(ctx, oracle):
