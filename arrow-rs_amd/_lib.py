@@ -225,6 +225,7 @@ SIGNATURES = {
     "ah_boolean_unary": (C.c_int32, [_P, C.c_int32, _VIEW, _OUT]),
     "ah_nullif": (C.c_int32, [_P, _VIEW, _VIEW, _OUT]),
     "ah_cast": (C.c_int32, [_P, _VIEW, C.c_int32, C.c_int32, _OUT]),
+    "ah_cast_chain": (C.c_int32, [_P, _VIEW, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _OUT]),
     "ah_can_cast_types": (C.c_int32, [C.c_int32, C.c_int32]),
     "ah_cast_with_types": (C.c_int32, [_P, _VIEW, C.POINTER(DataTypeDesc), C.POINTER(DataTypeDesc), C.c_int32, _OUT]),
     "ah_can_cast_data_types": (C.c_int32, [C.POINTER(DataTypeDesc), C.POINTER(DataTypeDesc)]),

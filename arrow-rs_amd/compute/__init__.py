@@ -6,7 +6,7 @@ from .kernels.take import take, take_arrays, take_record_batch, TakeOptions  # n
 from .kernels.numeric import (add, add_wrapping, sub, sub_wrapping, mul, mul_wrapping, div, rem,  # noqa: F401
                               neg, neg_wrapping)
 from .kernels.cmp import eq, neq, lt, lt_eq, gt, gt_eq, distinct, not_distinct  # noqa: F401
-from .kernels.cast import cast, cast_with_options, can_cast_types, CastOptions  # noqa: F401
+from .kernels.cast import cast, cast_with_options, cast_chain, can_cast_types, CastOptions  # noqa: F401
 from .kernels.concat import concat, concat_batches  # noqa: F401
 from .kernels.boolean import (and_, or_, and_not, and_kleene, or_kleene, not_, is_null, is_not_null, nullif)  # noqa: F401
 from .kernels.coalesce import BatchCoalescer  # noqa: F401

@@ -41,3 +41,21 @@ def cast_with_options(array, to_type, cast_options):
 def cast(array, to_type):
     """cast/mod.rs:347 — ``cast_with_options(array, to_type, &CastOptions::default())``"""
     return cast_with_options(array, to_type, CastOptions())
+
+
+def cast_chain(array, to_types, cast_options=None):
+    """``cast(cast(array, to_types[0]), to_types[1]) ...`` as ONE call (``ah_cast_chain``): byte-identical results; the
+    library decides what to materialise in between — Int64 -> Float64 -> Utf8 / LargeUtf8 (BASELINE configs[3]) never builds
+    the Float64 array.  Plain (non-logical) types only; anything else: chain ``cast`` yourself."""
+    opts = cast_options or CastOptions()
+    if array.data_type.logical is not None or any(t.logical is not None for t in to_types):
+        out = array
+        for t in to_types:
+            out = cast_with_options(out, t, opts)
+        return out
+    ctx = array.ctx
+    out = L.ArrayOut()
+    v = array.view()
+    types = (C.c_int32 * len(to_types))(*[t.physical for t in to_types])
+    ctx.check(ctx.lib.ah_cast_chain(ctx.handle, C.byref(v), len(to_types), types, int(opts.safe), C.byref(out)))
+    return Array._from_out(ctx, out, to_types[-1])

@@ -25,6 +25,7 @@ ah_status ah_cast_to_string(ah_context* ctx, const ah_array_view* values, ah_typ
 ah_status ah_cast_bool(ah_context* ctx, const ah_array_view* values, ah_type to_type, ah_array_out* out);  // cast_bool.hip
 ah_status ah_cast_parse(ah_context* ctx, const ah_array_view* values, ah_type to_type, int32_t safe,
                         ah_array_out* out);  // cast_parse.hip
+ah_status ah_cast_i64_via_f64_to_string(ah_context* ctx, const ah_array_view* values, ah_type to_type, ah_array_out* out);  // cast_string.hip
 
 namespace {
 
@@ -505,5 +506,50 @@ extern "C" ah_status ah_cast(ah_context* ctx, const ah_array_view* values, ah_ty
     out->validity_bytes = (int64_t)bbytes;
     out->null_count = len - (int64_t)ctx->pinned[1];
   }
+  return AH_OK;
+}
+
+// A chain of casts as ONE call: cast(cast(values, types[0]), types[1]) ... — what BASELINE configs[3] runs (Int64 -> Float64 ->
+// Utf8; arrow-cast/src/cast/mod.rs:1664 then :1549-1553 / cast/string.rs:21-39).  The cast analogue of ah_filter_expr: the caller
+// says what it wants, the library decides what to materialise.  Int64 -> Float64 -> Utf8 / LargeUtf8 formats straight from the
+// Int64 column (`v as f64` in registers): the Float64 intermediate — 4.3 GB written by X1 and read twice by X2 at 2^29 rows — is
+// never built.  Every other chain runs its steps in sequence, releasing each intermediate as soon as the next step has it.
+// Byte-exact against the step-by-step result (tests/test_gpu_parity.py::test_cast_chain_*, the 2^29-row test).
+extern "C" ah_status ah_cast_chain(ah_context* ctx, const ah_array_view* values, int32_t n_types, const ah_type* types, int32_t safe,
+                                   ah_array_out* out) {
+  ah_ctx_guard _guard(ctx);
+  if (!ctx || !values || !out || n_types < 1 || !types) return AH_INVALID_ARGUMENT;
+  ah_out_init(out);
+  hipSetDevice(ctx->device);
+  ah_type from = values->type;
+  for (int i = 0; i < n_types; ++i) {  // the whole chain is validated before anything runs
+    if (!ah_can_cast_types(from, types[i]))
+      return ah_fail(ctx, AH_CAST_ERROR, "Casting from %s to %s not supported", ah_type_name(from), ah_type_name(types[i]));
+    from = types[i];
+  }
+  static const char* fuse_env = getenv("AH_CAST_CHAIN_FUSE");  // "0": always step by step (A/B runs)
+  if (n_types == 2 && values->type == AH_INT64 && types[0] == AH_FLOAT64 && (types[1] == AH_UTF8 || types[1] == AH_LARGE_UTF8) &&
+      !(fuse_env && fuse_env[0] == '0'))
+    return ah_cast_i64_via_f64_to_string(ctx, values, types[1], out);  // (Int64 -> Float64 cannot fail or null anything: safe is moot)
+  ah_array_out cur;
+  ah_out_init(&cur);
+  ah_array_view v = *values;
+  for (int i = 0; i < n_types; ++i) {
+    ah_array_out next;
+    const ah_status st = ah_cast(ctx, &v, types[i], safe, &next);
+    if (i > 0) ah_array_release(ctx, &cur);  // (the pool reuses it in stream order, behind the step that read it)
+    if (st != AH_OK) return st;
+    cur = next;
+    memset(&v, 0, sizeof v);
+    v.type = cur.type;
+    v.length = cur.length;
+    v.null_count = cur.validity ? cur.null_count : 0;
+    v.values = cur.values;
+    v.values_bit_offset = cur.values_bit_offset;
+    v.validity = cur.validity;
+    v.validity_bit_offset = cur.validity_bit_offset;
+    v.offsets = cur.offsets;
+  }
+  *out = cur;
   return AH_OK;
 }

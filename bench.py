@@ -49,9 +49,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md); ~6.
 # tools/gather_probe2.hip (the same accesses with nothing else in the kernel): 201.6 M fills in 3.819 ms = 52.8 G/s
 # (the bitmap half is served by the Infinity Cache, which is why this is above 6.3 TB/s / 128 B = 49 G/s).
 PROBE_MAX_FILLS_G = 52.8
-ALL_WORKLOADS = ["filter_take", "arith", "cmp", "cast", "cast_string", "cast_string_utf8", "coalesce", "string_filter_take", "string_filter",
+ALL_WORKLOADS = ["filter_take", "arith", "cmp", "cast", "cast_string", "cast_string_utf8", "cast_chain", "coalesce", "string_filter_take", "string_filter",
                  "string_take", "predicate_filter", "predicate_filter_fused", "aggregate", "sort", "record_batch"]
-EXTRA_CONFIGS = ["arith", "cmp", "cast", "cast_string", "cast_string_utf8"]  # BASELINE configs[2] and [3], timed inside the default run
+EXTRA_CONFIGS = ["arith", "cmp", "cast", "cast_string", "cast_string_utf8", "cast_chain"]  # BASELINE configs[2] and [3], timed inside the default run
 # SURVEY 8f rows 1 / 2 / 3 and configs[4]'s per-GPU shape, ditto
 NEXT_ROWS = ["coalesce", "record_batch", "string_filter", "string_take", "predicate_filter", "predicate_filter_fused"]
 
@@ -1265,6 +1265,9 @@ def build_workload(env, wl):
             src = gen_cast_source(A, K, ctx, n, args.valid, row0)
         if wl == "cast":
             W.update(step=lambda _r: K.cast(src, A.Float64), kernels=["cast_numeric"])
+        elif wl == "cast_chain":
+            # configs[3] as ONE call (ah_cast_chain): text straight from the Int64 column, the Float64 array is never built
+            W.update(step=lambda _r: K.cast_chain(src, [A.Float64, A.LargeUtf8]), kernels=["cast_string_len", "cast_string_write"])
         elif wl == "cast_string_utf8":
             # SURVEY 8d cfg 4: "Utf8 in 64 Mi-row batches to show i32 behaviour" — the same 2^29 rows, 8 casts per step
             f64 = K.cast(src, A.Float64)
@@ -1349,7 +1352,7 @@ def describe(env, wl, W, prof, out, steps):
         alg = n * 8 + (n + 7) // 8 + (n + st["batches"]) * 4 + st["out_bytes"] + (n + 7) // 8
         dom_avg, dom_n = sum(prof[k][0] for k in kernels) / max(steps, 1), steps
         dominant = "cast_string_utf8_step"
-    elif per_row is None:  # cast_string: input + validity in, offsets + bytes + validity out; both passes of one cast
+    elif per_row is None:  # cast_string / cast_chain: input + validity in, offsets + bytes + validity out; both passes of one cast
         alg = n * 8 + (n + 7) // 8 + (n + 1) * 8 + out.values.nbytes + (n + 7) // 8
         dom_avg = sum(prof[k][0] for k in kernels) / max(prof[kernels[0]][1], 1)
         dominant = "cast_string_len+cast_string_write"
@@ -1367,6 +1370,8 @@ def describe(env, wl, W, prof, out, steps):
             "string_filter": "SURVEY 8f-3: filter on a LargeUtf8 column (cast output): order-preserving, selected runs stream",
             "string_take": "SURVEY 8f-3: take with uniform random UInt32 indices on a LargeUtf8 column (cast output): one row gather per index",
             "cast_string_utf8": "configs[3]: cast Float64->Utf8 (i32 offsets) in 64 Mi-row batches of the same column",
+            "cast_chain": "configs[3] as ONE call: ah_cast_chain(Int64 -> Float64 -> LargeUtf8), text formatted straight from the Int64 column (no Float64 "
+                          "array); compare with configs.cast.ms + configs.cast_string.ms for the two separate calls",
             "predicate_filter_fused": "SURVEY 8f-2: the same WHERE a < 0 AND b >= 0 handed over as terms (ah_filter_expr): the comparisons are ballots inside the filter's count pass, only the 1-bit-per-row selection is materialised",
             "predicate_filter": "SURVEY 8f-2: filter(a, and_kleene(lt(a, 0), gt_eq(b, 0.0))) on Int64 a, Float64 b with NullBuffers",
             "coalesce": f"SURVEY 8f-1: BatchCoalescer.push_batch_with_filter, Int64+Float64, "

@@ -551,6 +551,11 @@ AH_API int32_t ah_can_cast_types(ah_type from, ah_type to); /* cast/mod.rs:115 s
  * negative scale, then the precision test.  The other decimal casts are AH_NOT_YET_IMPLEMENTED. */
 AH_API ah_status ah_cast_with_types(ah_context* ctx, const ah_array_view* values, const ah_data_type* from,
                                     const ah_data_type* to, int32_t safe, ah_array_out* out);
+/* cast(cast(values, types[0]), types[1]) ... as ONE call (BASELINE configs[3]: Int64 -> Float64 -> Utf8).  Results are
+ * byte-identical to the step-by-step casts; what is materialised in between is the library's business:
+ * Int64 -> Float64 -> Utf8 / LargeUtf8 formats straight from the Int64 column, never building the Float64 array. */
+AH_API ah_status ah_cast_chain(ah_context* ctx, const ah_array_view* values, int32_t n_types, const ah_type* types,
+                               int32_t safe, ah_array_out* out);
 AH_API int32_t ah_can_cast_data_types(const ah_data_type* from, const ah_data_type* to); /* cast/mod.rs:115 */
 
 /* ---------------------------------------------------------------- concat */

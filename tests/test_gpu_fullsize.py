@@ -443,6 +443,19 @@ def test_config3_cast_chain_every_row(ctx, oracle):
     assert all(r[1] for r in res), "Float64 -> LargeUtf8 differs from the oracle"
     tb = _dev_bytes(ctx, txt.validity, 0, n // 8)
     assert np.array_equal(tb, _dev_bytes(ctx, f64.validity, 0, n // 8)), "string validity = input validity"
+    # round 5: the same chain as ONE call (ah_cast_chain: text straight from the Int64 column, no Float64 array) — every
+    # offset, every byte and the validity identical to the step-by-step result checked against the oracle above
+    del f64
+    chain = K.cast_chain(src, [A.Float64, A.LargeUtf8])
+    assert chain.length == n and chain.null_count() == txt.null_count()
+    step = 1 << 26  # offsets and text compared in slabs the host can hold
+    for r0 in range(0, n, step):
+        oa = _dev_bytes(ctx, chain.offsets, r0 * 8, (step + 1) * 8).view(np.int64)
+        ob = _dev_bytes(ctx, txt.offsets, r0 * 8, (step + 1) * 8).view(np.int64)
+        assert np.array_equal(oa, ob), f"chain offsets differ in rows [{r0}, {r0 + step})"
+        assert np.array_equal(_dev_bytes(ctx, chain.values, int(oa[0]), int(oa[-1] - oa[0])),
+                              _dev_bytes(ctx, txt.values, int(ob[0]), int(ob[-1] - ob[0]))), f"chain text differs in rows [{r0}, {r0 + step})"
+    assert np.array_equal(_dev_bytes(ctx, chain.validity, 0, n // 8), tb), "chain validity"
 
 
 # ---------------------------------------------------------------------- 32-byte natives (i256) through filter / take

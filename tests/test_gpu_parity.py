@@ -524,6 +524,34 @@ def test_fuzz_arith_float_bit_patterns(ctx, oracle, dt):
         check_float(K.neg_wrapping(da), oracle.neg(ha, wrapping=True), f"{dt} bit-pattern neg_wrapping")
 
 
+def test_cast_chain_is_the_step_by_step_casts(ctx, oracle):
+    """ah_cast_chain (round 5): cast(cast(x, t0), t1) ... as one call — byte-exact against the oracle's
+    step-by-step casts.  Int64 -> Float64 -> Utf8 / LargeUtf8 takes the fused path (text straight from the Int64 column,
+    `v as f64` in registers: values >= 2^53 round, exponent forms appear); other chains run step by step inside the library.
+    Reference arms: cast/mod.rs:1664 (Int64 -> Float64), :1549-1553 + cast/string.rs:21-39 (Float64 -> Utf8)."""
+    rng = np.random.default_rng(_seed("cast-chain"))
+    for it in range(4):
+        n = int(rng.integers(1, 70000))
+        v = rng.integers(-10**6, 10**6, n).astype(np.int64)
+        k = rng.random(n) < 0.05
+        v[k] = rng.integers(-2**63, 2**63 - 1, int(k.sum()), dtype=np.int64)  # full range: rounding above 2^53, "1e16"-style output
+        edge = np.array([0, 1, -1, 2**53, 2**53 + 1, -(2**53) - 1, 2**63 - 1, -2**63, 10**15, 10**16, 10**17, 999999999999999999], dtype=np.int64)
+        v[:min(n, len(edge))] = edge[:min(n, len(edge))]
+        h = HostArray(A.Int64, v, (rng.random(n) < 0.9) if it % 2 == 0 else None)
+        d = h.to_device(ctx)
+        for to in (A.LargeUtf8, A.Utf8):
+            exp = oracle.cast(oracle.cast(h, A.Float64), to)
+            check_exact(K.cast_chain(d, [A.Float64, to]), exp, f"chain Int64 -> Float64 -> {to} iter {it}")
+            check_exact(K.cast_chain(d.slice(7, n - 7), [A.Float64, to]) if n > 7 else K.cast_chain(d, [A.Float64, to]),
+                        oracle.cast(oracle.cast(h.slice(7, n - 7), A.Float64), to) if n > 7 else exp, f"chain sliced -> {to}")
+        # unfused chains: same answer as the separate calls
+        check_exact(K.cast_chain(d, [A.Float64, A.Float32, A.Int32]), oracle.cast(oracle.cast(oracle.cast(h, A.Float64), A.Float32), A.Int32), "three numeric steps")
+        check_exact(K.cast_chain(d, [A.Int32, A.LargeUtf8]), oracle.cast(oracle.cast(h, A.Int32), A.LargeUtf8), "Int64 -> Int32 -> LargeUtf8")
+        check_exact(K.cast_chain(d, [A.Float64]), oracle.cast(h, A.Float64), "one step")
+    with pytest.raises(A.array.CastError):
+        K.cast_chain(d, [A.Float64, A.Utf8, A.Utf8View, A.Boolean])
+
+
 def _f16_strata(rng, n):
     """Float16 operand pairs over the whole encoding space (the sampler that pins the oracle: tests/test_oracle_golden.py)."""
     from test_oracle_golden import f16_strata
