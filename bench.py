@@ -413,7 +413,10 @@ def coalesce_by_batch_rows(env, only=None):
             if only and key not in only:
                 continue
             try:
-                group = max(2, min(4096, (1 << 25) // br)) if br < (1 << 24) else 8
+                # batches per grouped push: ~2^27 rows' worth (at most 16 384 batches) — a push pays ~30 us of fixed GPU latency
+                # (table upload, count, scan, read-back), 2^25-row pushes spent 0.9 of 5.5 ms per 1e9 rows on it at 8192-row batches
+                gr = int(os.environ.get("AH_SWEEP_PUSH_ROWS", str(1 << 27)))
+                group = max(2, min(16384, gr // br)) if br < (1 << 24) else 8
                 stream = CoalesceStream(env, [col, col2], pred, n, br, target, group)
                 stream.run()
                 env.sync_all()

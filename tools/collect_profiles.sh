@@ -8,12 +8,12 @@
 # GPU-timeline gap analysis, and the world-1 exchange through the C ABI (filter_take and configs[4]).
 # (One parametrised script since round 4; rounds 1-3 had a copy per round — see the git history.)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/profiles_$R
 mkdir -p $O
 timeout 900 python bench.py --steps 20 --warmup 5 --detail-json $O/bench_default.json > $O/bench_default.compact.json 2> $O/bench_default.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --pmc-traffic off --detail-json "" > $O/bench_trace.json 2> $O/trace.log
-for wl in arith cmp cast cast_string; do
+for wl in arith cmp cast cast_string cast_chain; do
   timeout 300 python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --detail-json $O/bench_$wl.json > /dev/null 2> $O/bench_$wl.err
 done
 for wl in coalesce string_filter string_take predicate_filter predicate_filter_fused; do  # roofline over ALL launches of a step, PMC traffic summed per step

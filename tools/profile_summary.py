@@ -63,6 +63,27 @@ if d:
             extra_ms = f", {v['ms_without_kernel_events']} ms without per-kernel events" if "ms_without_kernel_events" in v else ""
             row(f"{v['roofline']['kernel']} (next_rows.{k}: {v['rows']} rows, {v['ms']} ms per step{extra_ms}; all launches of a step)"
                 if k != "record_batch" else f"{v['roofline']['kernel']} (next_rows.{k}: {v['rows']} rows, {v['ms']} ms per call)", v["roofline"])
+    for k, v in d.get("configs_narrow", {}).items():  # round 5: 4-byte and narrower operands
+        if "roofline" in v:
+            row(f"{v['roofline']['kernel']} (configs_narrow.{k}: {v['rows']} rows, {v['ms']} ms per call)", v["roofline"])
+    sf = d.get("next_rows", {}).get("string_filter", {}).get("roofline", {})
+    if "frac_survey_rule" in sf:
+        out.append(f"\nstring_filter both ways: selected rows' bytes only {sf['algorithmic_bytes_per_launch'] / 1e9:.3f} GB -> frac {sf['frac']}; "
+                   f"whole text buffer as an input (SURVEY 8d) {sf['algorithmic_bytes_survey_rule'] / 1e9:.3f} GB -> frac {sf['frac_survey_rule']}.\n")
+    cs = d.get("coalesce_by_batch_rows", {})
+    if cs.get("points"):
+        out.append("\n### BatchCoalescer by input batch size (`coalesce_by_batch_rows`; the reference's operating point is 8192-row batches)\n")
+        out.append(cs.get("what", "") + "\n")
+        out.append("| batch rows x target | ms per 1e9 rows | Mrows/s | frac | pushes | output batches | launches (count / scatter) | kernel ms (count + scatter) |")
+        out.append("|---|---|---|---|---|---|---|---|")
+        for k, v in cs["points"].items():
+            if "error" in v:
+                out.append(f"| {k} | error: {v['error']} |")
+                continue
+            kl, km = v.get("kernel_launches", {}), v.get("kernel_ms", {})
+            out.append(f"| {k} (target {v['target']}) | {v['ms']} | {v['value']} | {v['frac']} | {v['pushes']} | {v['output_batches']} | "
+                       f"{kl.get('filter_count')} / {kl.get('filter_scatter')} | {km.get('filter_count')} + {km.get('filter_scatter')} |")
+        out.append(f"\none CPU core (oracle filter of both columns, batch by batch): {cs.get('cpu_1core_Mrows_per_s_by_batch_rows')} Mrows/s; cores granted: {cs.get('cpu_cores_granted')}\n")
     if "requests" in rf:
         out.append(f"\ntake_gather in line fills: {rf['requests']}\n")
     if d.get("roofline_take_sorted"):
@@ -94,7 +115,7 @@ out.append("## Per-workload lines with in-run PMC traffic\n")
 out.append("| workload | ms per call (without per-kernel events) | roofline kernel | frac | traffic_frac | PMC traffic per launch / step (GB) | host_gap_ms |")
 out.append("|---|---|---|---|---|---|---|")
 traffic = {}
-for wl in ["arith", "cmp", "cast", "cast_string", "coalesce", "record_batch", "string_filter", "string_take", "predicate_filter",
+for wl in ["arith", "cmp", "cast", "cast_string", "cast_chain", "coalesce", "record_batch", "string_filter", "string_take", "predicate_filter",
            "predicate_filter_fused"]:
     d2 = line_of(f"bench_{wl}.json")
     if not d2:
