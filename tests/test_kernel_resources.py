@@ -81,7 +81,7 @@ def test_filter_scatter_keeps_five_workgroups_per_cu(kernels):
 def test_string_passes_keep_eight_workgroups_per_cu(kernels):
     for r in _find(kernels, "string_write_kernelId"):
         assert r["sgpr"] <= 80 and r["lds"] <= 20480 and r["vgpr"] <= 64, r
-    for r in _find(kernels, "string_len_kernelIdE"):
+    for r in _find(kernels, "string_len_kernelId"):
         assert r["sgpr"] <= 80 and r["lds"] <= 20480 and r["vgpr"] <= 64, r
 
 
