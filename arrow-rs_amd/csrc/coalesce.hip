@@ -914,7 +914,7 @@ struct SlabPush {
   ah_tbl_push t{};
   void* dev_block = nullptr;
   uint64_t seq = 0;
-  std::vector<int64_t> wave0, tile0;  // per batch (n + 1 entries): first count wave / first 4096-row tile
+  std::vector<int64_t> chunk0, tile0;  // per batch (n + 1 entries): first 1024-row chunk of the push's numbering / first 4096-row tile
   bool aligned16 = true;
 };
 
@@ -971,36 +971,33 @@ ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_vi
   std::unique_ptr<SlabPush> sp(new SlabPush());
   sp->n = n;
   sp->slot = slot;
-  sp->wave0.resize((size_t)n + 1);
+  sp->chunk0.resize((size_t)n + 1);
   sp->tile0.resize((size_t)n + 1);
   SlabTiming& tm = slab_timing();
   const double t_0 = tm.on ? now_us() : 0;
-  int64_t nchunks = 0, nwaves = 0, ntiles = 0;
-  std::vector<int64_t> chunk0((size_t)n);
+  int64_t nchunks = 0, ntiles = 0;
   for (int i = 0; i < n; ++i) {
     const int64_t len = filters[i].length;
-    chunk0[(size_t)i] = nchunks;
-    sp->wave0[(size_t)i] = nwaves;
+    sp->chunk0[(size_t)i] = nchunks;
     sp->tile0[(size_t)i] = ntiles;
-    const int64_t c = (len + AH_FILTER_CHUNK_ROWS - 1) >> 10;  // (shifts: this loop runs 122 000 times per 1e9 rows at 8192-row batches)
     static_assert(AH_FILTER_CHUNK_ROWS == 1024, "chunk shift");
-    nchunks += c;
-    nwaves += (c + 63) >> 6;
+    nchunks += (len + AH_FILTER_CHUNK_ROWS - 1) >> 10;  // (shifts: this loop runs 122 000 times per 1e9 rows at 8192-row batches)
     ntiles += (len + 4095) >> 12;
     sp->total_rows += len;
   }
-  sp->wave0[(size_t)n] = nwaves;
+  sp->chunk0[(size_t)n] = nchunks;
   sp->tile0[(size_t)n] = ntiles;
+  const int64_t nwaves = (nchunks + 63) >> 6;  // a count wave owns 64 consecutive chunks of the push, across batches
   if (nwaves == 0) {  // every predicate is empty: nothing to count, nothing to append
     *out = sp.release();
     (*out)->slot = -1;
     return AH_OK;
   }
-  // pinned block: [nwaves + 1 prefix words][segs][waves][tiles]; device block: [segs][waves][tiles][chunk_prefix][wave_total][wave_prefix]
+  // pinned block: [nwaves + 1 prefix words][segs][cols][chunk_seg][tiles]; device block: the same tables, then chunk_prefix, wave_total, wave_prefix
   const size_t b_pref = up256(((size_t)nwaves + 1) * 8), b_seg = up256((size_t)n * sizeof(ah_tbl_seg)),
                b_col = up256((size_t)n * co->ncols * sizeof(ah_tbl_col)),
-               b_wav = up256((size_t)nwaves * sizeof(ah_tbl_wave)), b_til = up256((size_t)ntiles * sizeof(ah_tbl_tile));
-  const size_t b_tables = b_seg + b_col + b_wav + b_til;
+               b_cs = up256((size_t)nchunks * 4), b_til = up256((size_t)ntiles * sizeof(ah_tbl_tile));
+  const size_t b_tables = b_seg + b_col + b_cs + b_til;
   const size_t b_cp = up256((size_t)nchunks * 4), b_wt = up256((size_t)nwaves * 4), b_wp = up256(((size_t)nwaves + 1) * 8);
   SlabPin& pin = co->slab_pin[slot];
   AH_TRY(slab_pin_reserve(ctx, pin, b_pref + b_tables));
@@ -1008,17 +1005,16 @@ ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_vi
   char* hs = (char*)pin.host + b_pref;
   auto* segs = (ah_tbl_seg*)hs;
   auto* tcols = (ah_tbl_col*)(hs + b_seg);
-  auto* waves = (ah_tbl_wave*)(hs + b_seg + b_col);
-  auto* tiles = (ah_tbl_tile*)(hs + b_seg + b_col + b_wav);
-  int64_t wi = 0, ti = 0;
+  auto* chunk_seg = (int32_t*)(hs + b_seg + b_col);
+  auto* tiles = (ah_tbl_tile*)(hs + b_seg + b_col + b_cs);
+  int64_t ti = 0;
   for (int i = 0; i < n; ++i) {
     const ah_array_view& f = filters[i];
     ah_tbl_seg& sg = segs[i];
     sg.mask = make_bitview(f.values, f.values_bit_offset);
     sg.mask_valid = (f.validity && f.null_count != 0) ? make_bitview(f.validity, f.validity_bit_offset) : BitView{nullptr, 0};
     sg.len = f.length;
-    sg.chunk0 = chunk0[(size_t)i];
-    sg.wave0 = sp->wave0[(size_t)i];
+    sg.chunk0 = sp->chunk0[(size_t)i];
     for (int k = 0; k < co->ncols; ++k) {
       const ah_array_view& v = columns[(size_t)i * co->ncols + k];
       ah_tbl_col& tc = tcols[(size_t)i * co->ncols + k];
@@ -1026,17 +1022,17 @@ ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_vi
       tc.vvalid = (v.validity && v.null_count != 0) ? make_bitview(v.validity, v.validity_bit_offset) : BitView{nullptr, 0};
       if (((uintptr_t)v.values) & 15) sp->aligned16 = false;
     }
-    const int64_t nw = sp->wave0[(size_t)i + 1] - sp->wave0[(size_t)i], nt = sp->tile0[(size_t)i + 1] - sp->tile0[(size_t)i];
-    for (int64_t g = 0; g < nw; ++g) waves[wi++] = ah_tbl_wave{i, (int32_t)g};
+    for (int64_t c = sp->chunk0[(size_t)i]; c < sp->chunk0[(size_t)i + 1]; ++c) chunk_seg[c] = i;
+    const int64_t nt = sp->tile0[(size_t)i + 1] - sp->tile0[(size_t)i];
     for (int64_t q = 0; q < nt; ++q) tiles[ti++] = ah_tbl_tile{i, (int32_t)q};
   }
   char* db = (char*)sp->dev_block;
   sp->t.segs = (const ah_tbl_seg*)db;
   sp->t.cols = (const ah_tbl_col*)(db + b_seg);
   sp->t.ncols = co->ncols;
-  sp->t.waves = (const ah_tbl_wave*)(db + b_seg + b_col);
-  sp->t.tiles = (const ah_tbl_tile*)(db + b_seg + b_col + b_wav);
-  sp->t.nsegs = n, sp->t.nwaves = nwaves, sp->t.ntiles = ntiles;
+  sp->t.chunk_seg = (const int32_t*)(db + b_seg + b_col);
+  sp->t.tiles = (const ah_tbl_tile*)(db + b_seg + b_col + b_cs);
+  sp->t.nsegs = n, sp->t.nchunks = nchunks, sp->t.nwaves = nwaves, sp->t.ntiles = ntiles;
   sp->t.chunk_prefix = (uint32_t*)(db + b_tables);
   sp->t.wave_total = (uint32_t*)(db + b_tables + b_cp);
   sp->t.wave_prefix = (unsigned long long*)(db + b_tables + b_cp + b_wt);
@@ -1098,11 +1094,17 @@ ah_status slab_end(ah_context* ctx, ah_coalescer* co, SlabPush* sp_raw) {
   if (sp->total_rows > 0) co->selectivity = (double)K / (double)sp->total_rows;
   if (K == 0) return AH_OK;
   const bool sparse = K * 32 <= sp->total_rows, skip = (double)K < 0.12 * (double)sp->total_rows;
-  // tiles of the count waves [w_lo, w_hi): every wave is 16 tiles except a batch's last one
-  auto tile_of_wave = [&](int64_t w) -> int64_t {  // first tile of count wave w (w == nwaves: one past the last tile)
-    if (w >= nwaves) return sp->t.ntiles;
-    const int64_t i = (int64_t)(std::upper_bound(sp->wave0.begin(), sp->wave0.end(), w) - sp->wave0.begin()) - 1;  // its batch
-    return sp->tile0[(size_t)i] + (w - sp->wave0[(size_t)i]) * 16;
+  // the tile that holds global chunk gc (a batch's tiles are 4 chunks each from ITS first chunk: a tile can straddle two waves)
+  auto tile_with_chunk = [&](int64_t gc) -> int64_t {
+    const int64_t i = (int64_t)(std::upper_bound(sp->chunk0.begin(), sp->chunk0.end(), gc) - sp->chunk0.begin()) - 1;  // its batch
+    return sp->tile0[(size_t)i] + ((gc - sp->chunk0[(size_t)i]) >> 2);
+  };
+  auto tiles_before_wave = [&](int64_t w) -> int64_t {  // one past the last tile with a chunk of waves [0, w)
+    if (w <= 0) return 0;
+    return tile_with_chunk(std::min(w * 64, sp->t.nchunks) - 1) + 1;
+  };
+  auto first_tile_of_wave = [&](int64_t w) -> int64_t {  // the first tile with a chunk of wave w (w == nwaves: one past the last)
+    return w >= nwaves ? sp->t.ntiles : tile_with_chunk(w * 64);
   };
   auto first_wave_reaching = [&](int64_t pos) -> int64_t {  // smallest w with P[w] >= pos  (P is non-decreasing)
     int64_t lo = 0, hi = nwaves;
@@ -1149,7 +1151,7 @@ ah_status slab_end(ah_context* ctx, ah_coalescer* co, SlabPush* sp_raw) {
       slots[k] = (unsigned long long*)co->acc + (size_t)k * 64;
     }
     const int64_t w_hi = first_wave_reaching(take1);  // waves [0, w_hi) start before position take1
-    st = scatter_all(dv, db, 0, tile_of_wave(w_hi), 0, take1, co->buffered);
+    st = scatter_all(dv, db, 0, tiles_before_wave(w_hi), 0, take1, co->buffered);
     enq = st == AH_OK;
     if (st == AH_OK) st = ah_filter_count_nulls_range(ctx, co->ncols, bits, slots, co->buffered, take1);
     if (st == AH_OK) {
@@ -1188,7 +1190,7 @@ ah_status slab_end(ah_context* ctx, ah_coalescer* co, SlabPush* sp_raw) {
       // waves that can hold a position >= take1: from the last wave that starts at or before it
       int64_t w_lo = first_wave_reaching(take1 + 1);  // first wave starting AFTER take1 ...
       w_lo = w_lo > 0 ? w_lo - 1 : 0;                  // ... so the one before it holds position take1
-      if (st == AH_OK) st = scatter_all(dv, db, tile_of_wave(w_lo), sp->t.ntiles, take1, K, 0);
+      if (st == AH_OK) st = scatter_all(dv, db, first_tile_of_wave(w_lo), sp->t.ntiles, take1, K, 0);
       enq = enq || st == AH_OK;
       std::shared_ptr<SlabNulls> sn;
       if (st == AH_OK && nfull > 0) {

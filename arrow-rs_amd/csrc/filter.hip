@@ -351,6 +351,8 @@ struct ScatterArgs {
   unsigned long long* out_valid;   // zero-initialised u64 words
   unsigned long long* valid_slots; // VALID_SLOTS zero-initialised counters (valid selected rows)
   int group_shift;                 // log2(chunks per count group): 10 (filter_count_kernel) or 6 (the small-mask one)
+  int64_t chunk_base;              // batch tables (ah_tbl_*): the predicate's first chunk in the PUSH's chunk numbering — the prefix
+                                   // arrays are indexed by global chunk there (a count wave spans batches); 0 everywhere else
   int xcd_remap;                   // 1: tiles that share output lines stay on one XCD
   int64_t out_base;                // rows already present in the destination (fused filter-into-builder)
   int64_t ntiles;
@@ -503,7 +505,7 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
   if (total == 0) return;
   // (requesting these two words up front, with the values and the bitmap words, was measured in round 5: the Int64 scatter
   // went from 1.31 to 1.35-1.37 ms per 1e9 rows on one box, the narrow forms did not move)
-  const int64_t chunk0 = row0 / CHUNK_ROWS;
+  const int64_t chunk0 = a.chunk_base + row0 / CHUNK_ROWS;
   const int64_t rel = (int64_t)a.group_prefix[chunk0 >> a.group_shift] + a.chunk_prefix[chunk0];  // tile's first output position
   int lo_t = 0, hi_t = total;  // the tile's positions inside the launch's window
   if (a.win_hi != 0) {
@@ -727,7 +729,7 @@ __device__ __forceinline__ void sparse_tile(const ScatterArgs& a, int64_t tile, 
   const int incl = wave_scan_incl(c);
   const int total = __builtin_amdgcn_readlane(incl, 63);
   if (total == 0) return;
-  const int64_t chunk0 = row0 / CHUNK_ROWS;
+  const int64_t chunk0 = a.chunk_base + row0 / CHUNK_ROWS;
   int64_t pos = (int64_t)a.group_prefix[chunk0 >> a.group_shift] + a.chunk_prefix[chunk0] + (incl - c);  // in the filtered stream
   const ET* vp = (const ET*)c_values + s;
   ET* op = (ET*)c_out_values;
@@ -931,48 +933,95 @@ __global__ void __launch_bounds__(SCATTER_THREADS) filter_scatter_multi_sparse_k
   sparse_tile<W, true>(a, gtile - sg.tile0 + sg.tile_lo, lane, wave, src.values, src.vvalid, d.out_values, d.out_valid, nullptr);
 }
 
-// ---- batch tables in device memory (filter_internal.hpp: ah_tbl_*).  One wave per 64-chunk group of one batch, as
-// filter_count_small_kernel; where the batch's tables live comes from the wave table instead of the kernel arguments.
+// ---- batch tables in device memory (filter_internal.hpp: ah_tbl_*).  A count wave owns 64 consecutive chunks of the PUSH —
+// across batch boundaries: an 8192-row batch is 8 chunks, and one wave per batch (the first form) left seven eighths of every
+// wave idle (0.75 ms per 1e9 rows of 8192-row batches against 0.22 ms at 65 536-row batches).  chunk_seg[c] names chunk c's
+// batch; lanes 16g .. 16g + 15 of step `it` read the 16 mask words of chunk 64 w + 4 it + g.  Two halves of eight steps:
+// each half's loads are all requested before the first is used.
 __global__ void __launch_bounds__(64) filter_count_table_kernel(ah_tbl_push t) {
-  const ah_tbl_wave wv = t.waves[blockIdx.x];
-  const ah_tbl_seg& o = t.segs[wv.seg];
   __shared__ uint32_t s_cnt[64];
   const int lane = threadIdx.x;
-  const int64_t chunk_base = (int64_t)wv.group * 64, len = o.len;
-  const BitView mask = o.mask, mask_valid = o.mask_valid;
-  const bool has_mv = mask_valid.words != nullptr;
-  BvRaw rm[16], rv[16] = {};
-#pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
-    rm[it] = bv_issue(mask, s < len ? s : 0, len);
-  }
-  if (has_mv) {
+  const int64_t c0 = (int64_t)blockIdx.x * 64;
+  const int64_t c_last = c0 + 63 < t.nchunks ? c0 + 63 : t.nchunks - 1;
+  const int seg_first = ah_uniform(t.chunk_seg[c0]), seg_last = ah_uniform(t.chunk_seg[c_last]);
+  if (seg_first == seg_last) {
+    // the whole wave lies in ONE batch (every wave of a batch of >= 64 chunks but its first and last): the batch's tables are
+    // wave-uniform and all 16 steps' words are requested together, as filter_count_small_kernel does — the per-lane table
+    // walk below costs three dependent round trips per half (0.35 against 0.22 ms per 1e9 rows at 65 536-row batches)
+    const ah_tbl_seg& o = t.segs[seg_first];
+    const int64_t chunk_base = c0 - o.chunk0, len = o.len;
+    const BitView mask = o.mask, mask_valid = o.mask_valid;
+    const bool has_mv = mask_valid.words != nullptr;
+    BvRaw rm[16], rv[16] = {};
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
       const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
-      rv[it] = bv_issue(mask_valid, s < len ? s : 0, len);
+      rm[it] = bv_issue(mask, s < len ? s : 0, len);
+    }
+    if (has_mv) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
+        rv[it] = bv_issue(mask_valid, s < len ? s : 0, len);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
+      const int64_t sc = s < len ? s : 0;
+      uint64_t mk = bv_finish(rm[it], sc, len);
+      if (has_mv) mk &= bv_finish(rv[it], sc, len);
+      if (s >= len) mk = 0;
+      int c = __popcll(mk);
+      c += __shfl_xor(c, 1, 64);
+      c += __shfl_xor(c, 2, 64);
+      c += __shfl_xor(c, 4, 64);
+      c += __shfl_xor(c, 8, 64);
+      if ((lane & 15) == 0) s_cnt[it * 4 + (lane >> 4)] = (uint32_t)c;
+    }
+  } else {
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    BvRaw rm[8], rv[8];
+    int64_t ss[8], ln[8];
+    bool mv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int it = half * 8 + k;
+      const int64_t c = c0 + it * 4 + (lane >> 4);
+      const bool live = c < t.nchunks;
+      const ah_tbl_seg& o = t.segs[live ? t.chunk_seg[c] : 0];
+      const int64_t s = live ? (((c - o.chunk0) * 16 + (lane & 15)) << 6) : 0;
+      const int64_t len = o.len;
+      const bool in = live && s < len;
+      mv[k] = o.mask_valid.words != nullptr;
+      ss[k] = in ? s : -1;
+      ln[k] = len;
+      rm[k] = bv_issue(o.mask, in ? s : 0, len);
+      rv[k] = bv_issue(mv[k] ? o.mask_valid : o.mask, in ? s : 0, len);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int it = half * 8 + k;
+      uint64_t mk = 0;
+      if (ss[k] >= 0) {
+        mk = bv_finish(rm[k], ss[k], ln[k]);
+        const uint64_t v = bv_finish(rv[k], ss[k], ln[k]);
+        if (mv[k]) mk &= v;
+      }
+      int c = __popcll(mk);
+      c += __shfl_xor(c, 1, 64);
+      c += __shfl_xor(c, 2, 64);
+      c += __shfl_xor(c, 4, 64);
+      c += __shfl_xor(c, 8, 64);
+      if ((lane & 15) == 0) s_cnt[it * 4 + (lane >> 4)] = (uint32_t)c;
     }
   }
-#pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int64_t s = ((chunk_base + it * 4) * 16 + lane) << 6;
-    const int64_t sc = s < len ? s : 0;
-    uint64_t mk = bv_finish(rm[it], sc, len);
-    if (has_mv) mk &= bv_finish(rv[it], sc, len);
-    if (s >= len) mk = 0;
-    int c = __popcll(mk);
-    c += __shfl_xor(c, 1, 64);
-    c += __shfl_xor(c, 2, 64);
-    c += __shfl_xor(c, 4, 64);
-    c += __shfl_xor(c, 8, 64);
-    if ((lane & 15) == 0) s_cnt[it * 4 + (lane >> 4)] = (uint32_t)c;
   }
   __syncthreads();
   const int v = (int)s_cnt[lane];
   const int incl = wave_scan_incl(v);
-  const int64_t nchunks = (len + CHUNK_ROWS - 1) / CHUNK_ROWS;
-  if (chunk_base + lane < nchunks) t.chunk_prefix[o.chunk0 + chunk_base + lane] = (uint32_t)(incl - v);
+  if (c0 + lane < t.nchunks) t.chunk_prefix[c0 + lane] = (uint32_t)(incl - v);
   if (lane == 63) t.wave_total[blockIdx.x] = (uint32_t)incl;
 }
 // one block: exclusive scan of the wave totals -> wave_prefix[0 .. nwaves] (the last entry is K), in device memory for the
@@ -1022,9 +1071,10 @@ __device__ __forceinline__ ScatterArgs tbl_tile_args(const TblScatterArgs& m, co
   a.mask = sg.mask;
   a.mask_valid = sg.mask_valid;
   a.len = sg.len;
-  a.chunk_prefix = m.t.chunk_prefix + sg.chunk0;
-  a.group_prefix = m.t.wave_prefix + sg.wave0;  // positions in the filtered stream of the WHOLE push
+  a.chunk_prefix = m.t.chunk_prefix;  // indexed by the push's global chunk number: chunk_base + the tile's chunk
+  a.group_prefix = m.t.wave_prefix;   // positions in the filtered stream of the WHOLE push, one per 64 global chunks
   a.group_shift = 6;
+  a.chunk_base = sg.chunk0;
   a.out_base = m.out_base;
   a.win_lo = m.win_lo;
   a.win_hi = m.win_hi;

@@ -56,29 +56,27 @@ ah_status ah_filter_small(ah_context* ctx, int ncols, const ah_array_view* colum
 // ---- batch tables in device memory (round 5; BatchCoalescer's slab push at the reference's operating point: thousands of
 // 8192-row input batches per call, coalesce.rs:172-173).  The grouped push of round 4 passed up to 8 (batch, window) segments
 // BY VALUE in the kernel arguments: 1 900 grouped calls and 12 000 output-batch allocations per 1e9 rows at 8192-row batches.
-// Here the host writes one table entry per batch (and per 64-chunk count group, and per 4096-row tile), uploads the tables
+// Here the host writes one table entry per batch (and per 1024-row chunk, and per 4096-row tile), uploads the tables
 // with one copy, and ONE count launch + ONE scan + ONE scatter launch per destination cover the whole push.
 constexpr int AH_TBL_MAX_COLS = 8;
 struct ah_tbl_seg {   // one input batch
   BitView mask, mask_valid;   // mask_valid.words == nullptr: the predicate has no nulls
   int64_t len;                // predicate length (<= the batch's rows)
-  int64_t chunk0;             // this batch's first entry in the push's chunk-prefix array (one per 1024 rows)
-  int64_t wave0;              // ... and in its wave-prefix array (one per 64 chunks = 65 536 rows)
+  int64_t chunk0;             // this batch's first chunk (1024 rows) in the push's global chunk numbering
 };
 struct ah_tbl_col {   // column k of batch i: entry i * ncols + k
   const void* values;
   BitView vvalid;             // words == nullptr: every row valid
 };
-struct ah_tbl_wave { int32_t seg, group; };   // count wave w: 64-chunk group `group` of batch `seg`
 struct ah_tbl_tile { int32_t seg, tile; };    // scatter tile t: 4096-row tile `tile` of batch `seg`
 struct ah_tbl_push {                          // all device pointers
   const ah_tbl_seg* segs;
   const ah_tbl_col* cols;
   int ncols;
-  const ah_tbl_wave* waves;
+  const int32_t* chunk_seg;          // [nchunks]: the batch of each global chunk
   const ah_tbl_tile* tiles;
-  int64_t nsegs, nwaves, ntiles;
-  uint32_t* chunk_prefix;            // selected rows of the wave's 64-chunk group before each chunk
+  int64_t nsegs, nchunks, nwaves, ntiles;  // nwaves = ceil(nchunks / 64): a count wave owns 64 consecutive global chunks
+  uint32_t* chunk_prefix;            // [nchunks]: selected rows of the chunk's wave before the chunk
   uint32_t* wave_total;              // selected rows per count wave
   unsigned long long* wave_prefix;   // [nwaves + 1]: position of each wave's first selected row in the push's filtered stream
 };
