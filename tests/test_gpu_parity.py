@@ -2146,10 +2146,20 @@ def test_bench_json_contract(ctx):
                  "filter context i32 w NULLs (kept 1/2)", "take i32 512", "take i32 1024", "add(0) f32", "lt f32"):
         assert want in names, want
     for name, (sync_us, batched_us, graph_us, cpu_us) in rs["shapes"].items():
-        assert sync_us > 0 and cpu_us > 0 and (batched_us is None) == name.startswith("take"), name
-        if name.startswith(("filter context", "add", "lt")):  # fixed output shape: recordable into a hipGraph
+        assert sync_us > 0 and cpu_us > 0 and batched_us is not None and batched_us > 0, name  # (round 5: take has the deferred form too)
+        if name.startswith(("filter context", "add", "lt", "take")):  # fixed output shape: recordable into a hipGraph
             assert graph_us is not None and 0 < graph_us < sync_us, (name, graph_us, sync_us)
     assert set(rs["one_cpu_core_wins"]) <= names  # the honest crossover statement, whatever it is on this box
+    # round 5: 4-byte and narrower operands, and the coalescer at the reference's batch sizes, in the same line
+    if "configs_narrow" in d:
+        for k in ("filter_i32", "take_i32", "add_wrapping_f32", "lt_f32", "lt_i32_scalar", "cast_i32_f64", "cast_i32_i64", "filter_i16", "filter_i8"):
+            c = d["configs_narrow"][k]
+            assert "error" not in c and c["avg_launch_ms"] > 0 and abs(c["frac"] - c["alg_bytes"] / (c["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0) < 2e-3, (k, c)
+    if "coalesce_by_batch_rows" in d:
+        pts = d["coalesce_by_batch_rows"]["points"]
+        for k in ("8192x8192", "65536x2^20", "16777216x2^20"):
+            ms, mrows, frac, pushes, out_batches, launches = pts[k]
+            assert ms > 0 and out_batches > 0 and launches < 400, (k, pts[k])
 
 
 def test_filter_tile_and_chunk_boundaries(ctx, oracle):
