@@ -330,12 +330,14 @@ def test_take_deferred_mode_parity_and_late_oob(ctx, oracle):
             idx = np.where(ivalid, idx, np.iinfo(idt.np_dtype).max).astype(idt.np_dtype)
         hi = HostArray(idt, idx, ivalid)
         cases.append((hv, hi, hv.to_device(ctx), hi.to_device(ctx)))
+    n0 = len(cases[0][1])
+    hi2 = HostArray(A.UInt32, rng.integers(0, n0, 50).astype(np.uint32))  # into the FIRST take's result (n0 rows)
     with ctx.deferred_mode():
         outs = [K.take(dv, di) for _hv, _hi, dv, di in cases]  # enqueued back to back, nothing read back
-        chained = K.take(outs[0], cases[0][3].slice(0, min(50, cases[0][3].length)))  # a deferred result as the next call's values
+        chained = K.take(outs[0], hi2.to_device(ctx))  # a deferred result as the next call's values
     for (hv, hi, _dv, _di), got in zip(cases, outs):
         check(got, oracle.take(hv, hi), f"deferred take {hv.data_type} by {hi.data_type}")
-    check(chained, oracle.take(oracle.take(cases[0][0], cases[0][1]), cases[0][1].slice(0, min(50, len(cases[0][1])))), "deferred take of a deferred take")
+    check(chained, oracle.take(oracle.take(cases[0][0], cases[0][1]), hi2), "deferred take of a deferred take")
     # out-of-bounds: nothing at return, the panic at the next synchronisation — the three wordings
     for mk, text in ((lambda: HostArray(A.Int32, np.array([1, -1], dtype=np.int32)), "index out of bounds: the len is 4 but the index is 4294967295"),
                      (lambda: HostArray(A.UInt32, np.array([1, 400, 2], dtype=np.uint32), np.array([True, True, False])), "Out-of-bounds index 400"),
