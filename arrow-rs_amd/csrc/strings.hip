@@ -34,7 +34,7 @@ namespace {
 //    byte offset INSIDE the tile's output; (start, local offset) pairs are compacted through a 16 KiB LDS stage (1024 rows per round) and leave
 //    as coalesced stores at the tile's first output row (known from the predicate's prefix tables).  The tile's byte
 //    total goes to tile_bytes[tile].
-// F2 string_tile_scan_kernel: exclusive scan of the <= n / 4096 tile totals (one workgroup) -> tile_base, grand total
+// F2 string_tile_scan_kernel: exclusive scan of the <= n / 4096 tile totals (one launch, <= 256 chained workgroups) -> tile_base, grand total
 //    (the one number the host waits for: it sizes the data buffer).
 // F3 string_filter_gather_kernel: one workgroup per tile again: new offset = tile_base + local offset, bytes copied row by
 //    row (unaligned 8-byte chunks with an overlapping tail; rows > 64 B cooperatively).
@@ -266,36 +266,92 @@ __global__ void __launch_bounds__(256) bitmap_count_to_slots_kernel(const unsign
   }
 }
 
-// exclusive scan of the tile byte totals (one workgroup: every thread owns a contiguous run of ceil(n / 1024) tiles, one
-// block scan over the run totals — the first version walked 1024 tiles per step, 53 us for 32 Ki tiles); *total_out = grand total
-__global__ void __launch_bounds__(1024) string_tile_scan_kernel(const unsigned long long* tile_bytes, int64_t ntiles,
-                                                                unsigned long long* tile_base, unsigned long long* total_out,
-                                                                const unsigned long long* valid_slots) {
-  __shared__ unsigned long long s_wave[16];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (wave == 15 && valid_slots) {  // total_out[1] = valid rows = the 64 counters of the ranges kernel
-    const unsigned long long v = wave_reduce_add64(valid_slots[lane]);
-    if (lane == 0) total_out[1] = v;
-  }
-  const int64_t per = (ntiles + 1023) / 1024, b0 = (int64_t)t * per, b1 = b0 + per < ntiles ? b0 + per : ntiles;
-  unsigned long long mine = 0;
-  for (int64_t i = b0; i < b1; ++i) mine += tile_bytes[i];
-  unsigned long long incl = mine;
+// exclusive scan of the tile byte totals; *total_out = grand total.  Round 5: ONE launch of up to 256 workgroups chained through
+// `slots` (zeroed by the caller): workgroup b sums its contiguous segment of tiles with coalesced loads, publishes
+// FLAG | sum, collects the published sums of workgroups [0, b) — they were dispatched before it, so the wait cannot deadlock —
+// and writes its segment's bases.  (It was one workgroup whose threads each walked a contiguous run: 128 dependent, uncoalesced
+// steps per thread at 2^29 rows = 229 us of the 2.15 ms step; 53 us at 2^27 rows.)
+constexpr int AH_TILE_SCAN_MAX_BLOCKS = 256;
+constexpr unsigned long long AH_TILE_SCAN_FLAG = 1ull << 63;
+
+__device__ __forceinline__ unsigned long long block_scan_incl_1024(unsigned long long v, unsigned long long* s_wave, int lane,
+                                                                    int wave, unsigned long long* block_total) {
+  unsigned long long incl = v;
 #pragma unroll
   for (int k = 1; k < 64; k <<= 1) {
     const unsigned long long u = __shfl_up(incl, k, 64);
     if (lane >= k) incl += u;
   }
+  __syncthreads();  // (s_wave of the previous round has been read)
   if (lane == 63) s_wave[wave] = incl;
   __syncthreads();
-  unsigned long long run = incl - mine;
-  for (int w = 0; w < wave; ++w) run += s_wave[w];
-  for (int64_t i = b0; i < b1; ++i) {
-    const unsigned long long v = tile_bytes[i];
-    tile_base[i] = run;
-    run += v;
+  unsigned long long base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const unsigned long long x = s_wave[w];
+    if (w < wave) base += x;
+    tot += x;
   }
-  if (t == 1023) *total_out = run;
+  *block_total = tot;
+  return base + incl;
+}
+
+__global__ void __launch_bounds__(1024) string_tile_scan_kernel(const unsigned long long* tile_bytes, int64_t ntiles, int64_t seg,
+                                                                unsigned long long* tile_base, unsigned long long* total_out,
+                                                                const unsigned long long* valid_slots,
+                                                                unsigned long long* slots) {
+  __shared__ unsigned long long s_wave[16];
+  __shared__ unsigned long long s_base;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
+  const bool last = b == (int)gridDim.x - 1;
+  if (last && wave == 15 && valid_slots) {  // total_out[1] = valid rows = the 64 counters of the ranges kernel
+    const unsigned long long v = wave_reduce_add64(valid_slots[lane]);
+    if (lane == 0) total_out[1] = v;
+  }
+  const int64_t i0 = (int64_t)b * seg, i1 = i0 + seg < ntiles ? i0 + seg : ntiles;
+  // 1. the segment's total
+  unsigned long long mine = 0;
+  for (int64_t i = i0 + t; i < i1; i += 1024) mine += tile_bytes[i];
+  unsigned long long seg_total = 0;
+  (void)block_scan_incl_1024(mine, s_wave, lane, wave, &seg_total);
+  if (t == 0) __hip_atomic_store(slots + b, AH_TILE_SCAN_FLAG | seg_total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // 2. the totals of the segments in front (wave 0: 64 of them per round)
+  if (wave == 0) {
+    unsigned long long acc = 0;
+    for (int j = lane; j < b; j += 64) {
+      unsigned long long x;
+      do {
+        x = __hip_atomic_load(slots + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(x & AH_TILE_SCAN_FLAG)) __builtin_amdgcn_s_sleep(1);
+      } while (!(x & AH_TILE_SCAN_FLAG));
+      acc += x & ~AH_TILE_SCAN_FLAG;
+    }
+    acc = wave_reduce_add64(acc);
+    if (lane == 0) s_base = acc;
+  }
+  __syncthreads();
+  unsigned long long run = s_base;
+  // 3. the segment's bases, 1024 tiles per round
+  for (int64_t c0 = i0; c0 < i1; c0 += 1024) {
+    const int64_t i = c0 + t;
+    const unsigned long long v = i < i1 ? tile_bytes[i] : 0ull;
+    unsigned long long tot = 0;
+    const unsigned long long incl = block_scan_incl_1024(v, s_wave, lane, wave, &tot);
+    if (i < i1) tile_base[i] = run + incl - v;
+    run += tot;
+  }
+  if (last && t == 0) *total_out = run;
+}
+
+// the launch: segments of whole 1024-tile rounds, at most AH_TILE_SCAN_MAX_BLOCKS of them
+static void launch_string_tile_scan(ah_context* ctx, const unsigned long long* tile_bytes, int64_t ntiles,
+                                    unsigned long long* tile_base, unsigned long long* total,
+                                    const unsigned long long* valid_slots, unsigned long long* slots) {
+  const int64_t rounds = std::max<int64_t>(1, ah_ceil_div(ntiles, 1024));
+  const int64_t per = ah_ceil_div(rounds, AH_TILE_SCAN_MAX_BLOCKS);  // rounds per workgroup
+  const int64_t seg = per * 1024;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, ah_ceil_div(ntiles, seg));
+  string_tile_scan_kernel<<<grid, 1024, 0, ctx->stream>>>(tile_bytes, ntiles, seg, tile_base, total, valid_slots, slots);
 }
 
 template <typename OFF>
@@ -317,34 +373,6 @@ __global__ void __launch_bounds__(1024) range_scan_local_kernel(const OFF* start
   for (int w = 0; w < wave; ++w) base += s_wave[w];
   if (i < k) dst_off[i] = (OFF)(base + incl - v);  // block-local; the block base is added by range_scan_add
   if (t == 1023) block_total[blockIdx.x] = base + incl;
-}
-
-__global__ void __launch_bounds__(1024) range_scan_blocks_kernel(const unsigned long long* block_total,
-                                                                 int64_t nblocks, unsigned long long* block_base,
-                                                                 unsigned long long* total_out) {
-  __shared__ unsigned long long s_wave[16];
-  __shared__ unsigned long long s_carry;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (t == 0) s_carry = 0;
-  __syncthreads();
-  for (int64_t b0 = 0; b0 < nblocks; b0 += 1024) {
-    unsigned long long v = (b0 + t < nblocks) ? block_total[b0 + t] : 0ull;
-    unsigned long long incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      unsigned long long u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
-    }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    unsigned long long wbase = s_carry;
-    for (int w = 0; w < wave; ++w) wbase += s_wave[w];
-    if (b0 + t < nblocks) block_base[b0 + t] = wbase + incl - v;
-    __syncthreads();
-    if (t == 1023) s_carry = wbase + incl;
-    __syncthreads();
-  }
-  if (t == 0) *total_out = s_carry;
 }
 
 template <typename OFF>
@@ -546,7 +574,7 @@ ah_status ranges_to_strings_t(ah_context* ctx, const uint8_t* src, const OFF* st
   AH_TRY(ah_out_alloc(ctx, ob, &offs));
   const int64_t nblocks = ah_ceil_div(std::max<int64_t>(k, 1), 1024);
   unsigned long long* scratch = nullptr;
-  ah_status st = ah_pool_alloc(ctx, (size_t)(2 * nblocks + 2) * 8, (void**)&scratch);
+  ah_status st = ah_pool_alloc(ctx, (size_t)(2 * nblocks + 2 + AH_TILE_SCAN_MAX_BLOCKS) * 8, (void**)&scratch);
   if (st != AH_OK) {
     ah_out_free(ctx, offs, ob);
     return st;
@@ -554,10 +582,14 @@ ah_status ranges_to_strings_t(ah_context* ctx, const uint8_t* src, const OFF* st
   unsigned long long* block_total = scratch;
   unsigned long long* block_base = scratch + nblocks;
   unsigned long long* total = scratch + 2 * nblocks;
+  unsigned long long* scan_slots = total + 2;
   {
     ah_prof_scope ps(ctx, "string_ranges_scan");
+    hipMemsetAsync(scan_slots, 0, (size_t)AH_TILE_SCAN_MAX_BLOCKS * 8, ctx->stream);
     range_scan_local_kernel<OFF><<<(unsigned)nblocks, 1024, 0, ctx->stream>>>(starts, ends, k, (OFF*)offs, block_total);
-    range_scan_blocks_kernel<<<1, 1024, 0, ctx->stream>>>(block_total, nblocks, block_base, total);
+    // the 1024-range block totals -> block bases: the chained scan of the string filter (52 Ki totals at 5.4e7 ranges; it was
+    // one workgroup walking them 1024 at a time)
+    launch_string_tile_scan(ctx, block_total, nblocks, block_base, total, nullptr, scan_slots);
     int g = (int)std::min<int64_t>(ah_ceil_div(k + 1, 256), 4096);
     range_scan_add_kernel<OFF><<<g, 256, 0, ctx->stream>>>((OFF*)offs, k, block_base, total);
   }
@@ -633,8 +665,8 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
   const OFF* offsets = (const OFF*)values->offsets;
   const bool hv = vvalid.words != nullptr;
   const size_t ob = (size_t)(K + 1) * sizeof(OFF), kb = (((size_t)K * sizeof(OFF)) + 15) & ~(size_t)15, nbytes = hv ? ah_bitmap_bytes(K) : 0;
-  char* tmp = nullptr;  // starts | local offsets | tile bytes | tile bases | {total bytes, valid rows} | 64 valid-row counters
-  AH_TRY(ah_pool_alloc(ctx, 2 * kb + (size_t)(2 * ntiles + 2 + 64) * 8, (void**)&tmp));
+  char* tmp = nullptr;  // starts | local offsets | tile bytes | tile bases | {total bytes, valid rows} | 64 valid-row counters | tile-scan slots
+  AH_TRY(ah_pool_alloc(ctx, 2 * kb + (size_t)(2 * ntiles + 2 + 64 + AH_TILE_SCAN_MAX_BLOCKS) * 8, (void**)&tmp));
   void* nb = nullptr;
   if (hv) {
     const ah_status as = ah_out_alloc(ctx, nbytes, &nb);
@@ -650,7 +682,8 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
   unsigned long long* tile_base = tile_bytes + ntiles;
   unsigned long long* total = tile_base + ntiles;  // [0] byte total, [1] valid rows (both written by the tile scan)
   unsigned long long* vslots = total + 2;
-  if (hv) hipMemsetAsync(vslots, 0, 64 * 8, ctx->stream);
+  unsigned long long* scan_slots = vslots + 64;
+  hipMemsetAsync(hv ? vslots : scan_slots, 0, (size_t)((hv ? 64 : 0) + AH_TILE_SCAN_MAX_BLOCKS) * 8, ctx->stream);
   const bool vec = (((uintptr_t)offsets) & 15) == 0;
   bool sparse = K * 32 <= len;  // as for the primitive scatter (filter.hip: use_sparse); AH_FILTER_SPARSE=0 / 1 forces
   if (const char* env = getenv("AH_FILTER_SPARSE")) {
@@ -671,7 +704,7 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
                                                                                    p->group_prefix, p->group_shift, starts, loffs,
                                                                                    tile_bytes, vvalid, nullptr, ntiles);
     }
-    string_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(tile_bytes, ntiles, tile_base, total, hv ? vslots : nullptr);
+    launch_string_tile_scan(ctx, tile_bytes, ntiles, tile_base, total, hv ? vslots : nullptr, scan_slots);
   } else {
     ah_prof_scope ps(ctx, "string_filter_ranges");
 #define AH_SFR(VEC, HV)                                                                                                          \
@@ -683,7 +716,7 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
     else if (hv) AH_SFR(false, true);
     else AH_SFR(false, false);
 #undef AH_SFR
-    string_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(tile_bytes, ntiles, tile_base, total, hv ? vslots : nullptr);
+    launch_string_tile_scan(ctx, tile_bytes, ntiles, tile_base, total, hv ? vslots : nullptr, scan_slots);
   }
   hipError_t e = ah_d2h_wait(ctx, ctx->pinned, total, 16);  // the one wait before the gather: byte total + valid rows
   if (e != hipSuccess) {
