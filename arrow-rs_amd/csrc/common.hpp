@@ -219,9 +219,7 @@ ah_status ah_slab_create(ah_context* ctx, size_t bytes, ah_slab** out);  // refs
 void ah_slab_slice(ah_context* ctx, ah_slab* s, void* ptr);              // `ptr` (inside the block) leaves as an output buffer: one more reference
 void ah_slab_unref(ah_context* ctx, ah_slab* s);                         // the creator (or a slice) lets go
 
-// strings.hip: byte ranges -> (offsets, bytes); take for Utf8 / LargeUtf8
-ah_status ah_ranges_to_strings(ah_context* ctx, bool large, const uint8_t* src, const void* starts,
-                               const void* ends, int64_t k, bool overflow_is_error, ah_array_out* out);
+// strings.hip: take for Utf8 / LargeUtf8
 ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_array_view* indices,
                         ah_array_out* out);
 // bitmap.hip: ah_bitmap_set_bits without a read-back — *nulls_acc (device) += len - popcount(copied bits)

@@ -5,15 +5,17 @@
 // take_bytes (arrow-select/src/take.rs:499-627: output nulls get zero-length slots; i32 offsets
 // past i32::MAX => ArrowError::OffsetOverflowError(capacity)).
 //
-// MI355X design: both become "ranges -> strings":
-//   1. the selected rows' [start, end) byte ranges are produced by the EXISTING kernels —
-//      filter: the primitive scatter kernel run on offsets[0..n) and offsets[1..n+1);
-//      take:   take_ranges_kernel (index -> range, zero length under an output null);
-//   2. range_scan: lengths -> exclusive scan -> new offsets (1024-row blocks, u64 block totals,
-//      single-block scan of the totals, add-back) — the grand total sizes the byte buffer;
-//   3. gather_bytes_kernel: one output row per thread, unaligned 8-byte chunks with an overlapping
-//      tail (rows <= 64 B); longer rows are copied cooperatively by the workgroup.  (The first
-//      version walked output bytes with a binary search per byte: 0.32 ms per 120 MB.)
+// MI355X design: both are "ranges -> scan of block totals -> gather", three launches and one wait before the gather
+// (the byte total sizes the data buffer):
+//   filter: string_filter_ranges_kernel / string_tile_scan_kernel / string_filter_gather_kernel (F1-F3 below);
+//   take:   T1 take_ranges_kernel: index -> source start (zero length under an output null), the output validity word, and —
+//              a workgroup round being 1024 consecutive output rows — the rows' byte offsets INSIDE the round plus the
+//              round's byte total (rounds 1-4 wrote [start, end) pairs and ran a three-kernel scan over them: 0.47 ms of
+//              the 4.1 ms step at 5.4e7 indices);
+//           T2 string_tile_scan_kernel over the round totals -> round bases, grand total;
+//           T3 take_gather_rows_kernel: final offset = round base + local offset (written out), one output row per thread,
+//              unaligned 8-byte chunks with an overlapping tail (rows <= 64 B); longer rows are copied cooperatively by
+//              the workgroup.  (The first version walked output bytes with a binary search per byte: 0.32 ms per 120 MB.)
 #include "common.hpp"
 #include "filter_internal.hpp"
 
@@ -354,37 +356,6 @@ static void launch_string_tile_scan(ah_context* ctx, const unsigned long long* t
   string_tile_scan_kernel<<<grid, 1024, 0, ctx->stream>>>(tile_bytes, ntiles, seg, tile_base, total, valid_slots, slots);
 }
 
-template <typename OFF>
-__global__ void __launch_bounds__(1024) range_scan_local_kernel(const OFF* starts, const OFF* ends, int64_t k,
-                                                                OFF* dst_off, unsigned long long* block_total) {
-  __shared__ unsigned long long s_wave[16];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 1024 + t;
-  unsigned long long v = i < k ? (unsigned long long)(ends[i] - starts[i]) : 0ull;
-  unsigned long long incl = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    unsigned long long u = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += u;
-  }
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  unsigned long long base = 0;
-  for (int w = 0; w < wave; ++w) base += s_wave[w];
-  if (i < k) dst_off[i] = (OFF)(base + incl - v);  // block-local; the block base is added by range_scan_add
-  if (t == 1023) block_total[blockIdx.x] = base + incl;
-}
-
-template <typename OFF>
-__global__ void __launch_bounds__(256) range_scan_add_kernel(OFF* dst_off, int64_t k,
-                                                             const unsigned long long* block_base,
-                                                             const unsigned long long* total) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i <= k; i += (int64_t)gridDim.x * 256) {
-    if (i < k) dst_off[i] = (OFF)((unsigned long long)dst_off[i] + block_base[i >> 10]);
-    else dst_off[k] = (OFF)*total;
-  }
-}
-
 __device__ __forceinline__ void copy8(uint8_t* d, const uint8_t* s) {  // unaligned 8-byte move
   unsigned long long v;
   __builtin_memcpy(&v, s, 8);
@@ -396,28 +367,41 @@ __device__ __forceinline__ void copy4(uint8_t* d, const uint8_t* s) {
   __builtin_memcpy(d, &v, 4);
 }
 
-// One output row per thread: rows up to 64 bytes are moved with unaligned 8-byte chunks (the last
+// T3.  One output row per thread: rows up to 64 bytes are moved with unaligned 8-byte chunks (the last
 // chunk overlaps backwards instead of a byte tail — gfx950 global accesses need no alignment);
 // consecutive lanes write consecutive regions, so a wave's stores still cover one contiguous span.
 // Longer rows are queued in LDS and copied by the whole workgroup, 8 bytes per thread per step.
+// Row j's bytes go to round_base[j / 1024] + loc[j]; that sum is also the row's new offset.
 template <typename OFF>
-__global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t* src, const OFF* starts,
-                                                           const OFF* dst_off, int64_t k, uint8_t* dst) {
-  __shared__ int s_long[256];
+__global__ void __launch_bounds__(256) take_gather_rows_kernel(const uint8_t* src, const OFF* starts, const OFF* loc,
+                                                               const unsigned long long* round_base,
+                                                               const unsigned long long* total, int64_t k, OFF* dst_off,
+                                                               uint8_t* dst) {
+  __shared__ unsigned long long s_rs[256], s_rd[256], s_rl[256];
   __shared__ int s_nlong;
   const int t = threadIdx.x;
   const int64_t j = (int64_t)blockIdx.x * 256 + t;
   if (t == 0) s_nlong = 0;
   __syncthreads();
-  unsigned long long s0 = 0, d0 = 0, len = 0;
   if (j < k) {
-    s0 = (unsigned long long)starts[j];
-    d0 = (unsigned long long)dst_off[j];
-    len = (unsigned long long)dst_off[j + 1] - d0;
+    const int64_t r = j >> 10;
+    const unsigned long long rb = round_base[r];
+    const unsigned long long s0 = (unsigned long long)starts[j];
+    // (a local offset is kept in the offset type: it wraps for i32 offsets only when the total overflows, which is an error
+    //  before this kernel runs)
+    const unsigned long long d0 = rb + (unsigned long long)(typename std::make_unsigned<OFF>::type)loc[j];
+    unsigned long long d1;
+    if (j + 1 == k) d1 = *total;
+    else if (((j + 1) & 1023) == 0) d1 = round_base[r + 1];
+    else d1 = rb + (unsigned long long)(typename std::make_unsigned<OFF>::type)loc[j + 1];
+    const unsigned long long len = d1 - d0;
+    dst_off[j] = (OFF)d0;
+    if (j + 1 == k) dst_off[k] = (OFF)d1;
     const uint8_t* sp = src + s0;
     uint8_t* dp = dst + d0;
     if (len > 64) {
-      s_long[atomicAdd(&s_nlong, 1)] = t;
+      const int q = atomicAdd(&s_nlong, 1);
+      s_rs[q] = s0, s_rd[q] = d0, s_rl[q] = len;
     } else if (len >= 8) {
       for (unsigned o = 0; o + 8 <= (unsigned)len; o += 8) copy8(dp + o, sp + o);
       if (len & 7) copy8(dp + len - 8, sp + len - 8);
@@ -431,9 +415,7 @@ __global__ void __launch_bounds__(256) gather_bytes_kernel(const uint8_t* src, c
   __syncthreads();
   const int nlong = s_nlong;
   for (int q = 0; q < nlong; ++q) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + s_long[q];
-    const unsigned long long rs = (unsigned long long)starts[r], rd = (unsigned long long)dst_off[r];
-    const unsigned long long rl = (unsigned long long)dst_off[r + 1] - rd;
+    const unsigned long long rs = s_rs[q], rd = s_rd[q], rl = s_rl[q];
     const unsigned long long whole = rl & ~7ull;
     for (unsigned long long o = (unsigned long long)t * 8; o < whole; o += 2048) copy8(dst + rd + o, src + rs + o);
     if ((unsigned long long)t < rl - whole) dst[rd + whole + t] = src[rs + whole + t];
@@ -497,19 +479,34 @@ __global__ void __launch_bounds__(256) string_filter_gather_kernel(const uint8_t
   }
 }
 
-// indices -> source ranges (take_bytes, take.rs:499-627) and, in the same pass, the output validity
+__device__ __forceinline__ unsigned long long wave_scan_incl64(unsigned long long v, int lane) {
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    const unsigned long long u = __shfl_up(v, k, 64);
+    if (lane >= k) v += u;
+  }
+  return v;
+}
+
+// T1.  indices -> source starts (take_bytes, take.rs:499-627) and, in the same pass, the output validity
 // (take_nulls, take.rs:418-430: index validity AND values.validity[index]) as one ballot word per wave.
-// Output nulls produce empty ranges (take.rs:553-577); a valid out-of-bounds index is reported through
+// Output nulls produce empty rows (take.rs:553-577); a valid out-of-bounds index is reported through
 // first_oob.  counters[0] = first OOB position, counters[1] = number of valid output slots.
+// A workgroup round is 1024 consecutive output rows (wave w: rows [256 w, 256 w + 256), four gathers in flight per lane):
+// the rows' lengths are scanned inside the round — loc[i] = bytes of the round's rows in front of row i — and
+// round_total[round] gets the round's bytes, so what is left of the offsets scan is one pass over n / 1024 totals.
 template <typename OFF, typename IDX>
 __global__ void __launch_bounds__(256) take_ranges_kernel(const OFF* offsets, int64_t nvalues, const IDX* idx,
                                                           int64_t n, BitView ivalid, BitView vvalid,
-                                                          unsigned long long* out_valid, OFF* starts, OFF* ends,
+                                                          unsigned long long* out_valid, OFF* starts, OFF* loc,
+                                                          unsigned long long* round_total,
                                                           unsigned long long* counters) {
   constexpr int KU = 4;  // independent gathers in flight per lane: the offsets pair and the validity bit of 4 rows
+  __shared__ unsigned long long s_wtot[2][4];
   unsigned long long oob = ~0ull, nvalid = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t base = (int64_t)blockIdx.x * (256 * KU); base < n; base += (int64_t)gridDim.x * (256 * KU)) {
+  int par = 0;
+  for (int64_t base = (int64_t)blockIdx.x * (256 * KU); base < n; base += (int64_t)gridDim.x * (256 * KU), par ^= 1) {
     const int64_t wbase = base + wave * (64 * KU);
     uint64_t ix[KU];
     bool live[KU], inb[KU];
@@ -539,20 +536,39 @@ __global__ void __launch_bounds__(256) take_ranges_kernel(const OFF* offsets, in
         vb[k] = bv_get(vvalid, (int64_t)ix[k]);
       }
     }
+    unsigned long long pre[KU], wrun = 0;  // bytes of this wave's rows in front of row k * 64 + lane; the wave's bytes
 #pragma unroll
     for (int k = 0; k < KU; ++k) {
       const int64_t i = wbase + k * 64 + lane;
       if (live[k] && !inb[k] && (unsigned long long)i < oob) oob = (unsigned long long)i;
-      if (i < n) {
-        starts[i] = vb[k] ? s[k] : (OFF)0;
-        ends[i] = vb[k] ? e[k] : (OFF)0;
-      }
+      const unsigned long long len = vb[k] ? (unsigned long long)(e[k] - s[k]) : 0ull;
+      const unsigned long long incl = wave_scan_incl64(len, lane);
+      pre[k] = wrun + incl - len;
+      wrun += __shfl(incl, 63, 64);
       const unsigned long long w = __ballot(vb[k]);
       if (lane == 0 && wbase + k * 64 < n) {
         if (out_valid) out_valid[(wbase + k * 64) >> 6] = w;
         nvalid += __popcll(w);
       }
     }
+    if (lane == 0) s_wtot[par][wave] = wrun;
+    __syncthreads();  // (every thread of the workgroup runs the same rounds; s_wtot alternates, so one barrier per round)
+    unsigned long long wfront = 0, rtot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned long long x = s_wtot[par][w];
+      if (w < wave) wfront += x;
+      rtot += x;
+    }
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+      const int64_t i = wbase + k * 64 + lane;
+      if (i < n) {
+        starts[i] = vb[k] ? s[k] : (OFF)0;
+        loc[i] = (OFF)(wfront + pre[k]);
+      }
+    }
+    if (threadIdx.x == 0) round_total[base >> 10] = rtot;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -566,79 +582,13 @@ __global__ void __launch_bounds__(256) take_ranges_kernel(const OFF* offsets, in
 }
 
 template <typename OFF>
-ah_status ranges_to_strings_t(ah_context* ctx, const uint8_t* src, const OFF* starts, const OFF* ends, int64_t k,
-                              bool overflow_is_error, void** out_offsets, size_t* offsets_bytes,
-                              void** out_data, size_t* data_bytes) {
-  const size_t ob = (size_t)(k + 1) * sizeof(OFF);
-  void* offs = nullptr;
-  AH_TRY(ah_out_alloc(ctx, ob, &offs));
-  const int64_t nblocks = ah_ceil_div(std::max<int64_t>(k, 1), 1024);
-  unsigned long long* scratch = nullptr;
-  ah_status st = ah_pool_alloc(ctx, (size_t)(2 * nblocks + 2 + AH_TILE_SCAN_MAX_BLOCKS) * 8, (void**)&scratch);
-  if (st != AH_OK) {
-    ah_out_free(ctx, offs, ob);
-    return st;
-  }
-  unsigned long long* block_total = scratch;
-  unsigned long long* block_base = scratch + nblocks;
-  unsigned long long* total = scratch + 2 * nblocks;
-  unsigned long long* scan_slots = total + 2;
-  {
-    ah_prof_scope ps(ctx, "string_ranges_scan");
-    hipMemsetAsync(scan_slots, 0, (size_t)AH_TILE_SCAN_MAX_BLOCKS * 8, ctx->stream);
-    range_scan_local_kernel<OFF><<<(unsigned)nblocks, 1024, 0, ctx->stream>>>(starts, ends, k, (OFF*)offs, block_total);
-    // the 1024-range block totals -> block bases: the chained scan of the string filter (52 Ki totals at 5.4e7 ranges; it was
-    // one workgroup walking them 1024 at a time)
-    launch_string_tile_scan(ctx, block_total, nblocks, block_base, total, nullptr, scan_slots);
-    int g = (int)std::min<int64_t>(ah_ceil_div(k + 1, 256), 4096);
-    range_scan_add_kernel<OFF><<<g, 256, 0, ctx->stream>>>((OFF*)offs, k, block_base, total);
-  }
-  hipError_t e = ah_d2h_wait(ctx, ctx->pinned, total, 8);
-  ah_pool_free(ctx, scratch);
-  if (e != hipSuccess) {
-    ah_out_free(ctx, offs, ob);
-    return ah_fail(ctx, AH_HIP_ERROR, "string offset scan failed: %s", hipGetErrorString(e));
-  }
-  const uint64_t total_bytes = ctx->pinned[0];
-  if (sizeof(OFF) == 4 && total_bytes > (uint64_t)INT32_MAX) {
-    ah_out_free(ctx, offs, ob);
-    // take_bytes: T::Offset::from_usize(capacity).ok_or_else(OffsetOverflowError(capacity)) (take.rs:521)
-    if (overflow_is_error) return ah_fail(ctx, AH_OFFSET_OVERFLOW_ERROR, "%llu", (unsigned long long)total_bytes);
-    return ah_fail(ctx, AH_PANIC, "illegal offset range");  // filter.rs:838
-  }
-  void* data = nullptr;
-  st = ah_out_alloc(ctx, (size_t)total_bytes, &data);
-  if (st != AH_OK) {
-    ah_out_free(ctx, offs, ob);
-    return st;
-  }
-  if (total_bytes) {
-    ah_prof_scope ps(ctx, "string_gather_bytes");
-    gather_bytes_kernel<OFF><<<(unsigned)ah_ceil_div(k, 256), 256, 0, ctx->stream>>>(src, starts, (const OFF*)offs, k,
-                                                                                   (uint8_t*)data);
-  }
-  e = hipGetLastError();
-  if (e == hipSuccess) e = ah_stream_wait(ctx);
-  if (e != hipSuccess) {
-    ah_out_free(ctx, offs, ob);
-    ah_out_free(ctx, data, (size_t)total_bytes);
-    return ah_fail(ctx, AH_HIP_ERROR, "string gather failed: %s", hipGetErrorString(e));
-  }
-  *out_offsets = offs;
-  *offsets_bytes = ob;
-  *out_data = data;
-  *data_bytes = (size_t)total_bytes;
-  return AH_OK;
-}
-
-template <typename OFF>
 ah_status launch_take_ranges(ah_context* ctx, const ah_array_view* values, const ah_array_view* indices,
-                             BitView ivalid, BitView vvalid, unsigned long long* out_valid, OFF* starts, OFF* ends,
-                             unsigned long long* counters) {
+                             BitView ivalid, BitView vvalid, unsigned long long* out_valid, OFF* starts, OFF* loc,
+                             unsigned long long* round_total, unsigned long long* counters) {
   const int64_t n = indices->length;
   int g = (int)std::max<int64_t>(1, std::min<int64_t>(ah_ceil_div(n, 1024), 8192));
   const OFF* off = (const OFF*)values->offsets;
-#define AH_TR(IDX) take_ranges_kernel<OFF, IDX><<<g, 256, 0, ctx->stream>>>(off, values->length, (const IDX*)indices->values, n, ivalid, vvalid, out_valid, starts, ends, counters)
+#define AH_TR(IDX) take_ranges_kernel<OFF, IDX><<<g, 256, 0, ctx->stream>>>(off, values->length, (const IDX*)indices->values, n, ivalid, vvalid, out_valid, starts, loc, round_total, counters)
   switch (indices->type) {
     case AH_INT8: AH_TR(int8_t); break;
     case AH_UINT8: AH_TR(uint8_t); break;
@@ -774,25 +724,6 @@ ah_status ah_string_filter_bytes(ah_context* ctx, const ah_filter_predicate* p, 
                                        : filter_bytes_t<int32_t>(ctx, p, values, vvalid, out);
 }
 
-// ranges [starts[i], ends[i]) of `src` (device arrays of the offset type) -> offsets + bytes
-ah_status ah_ranges_to_strings(ah_context* ctx, bool large, const uint8_t* src, const void* starts,
-                               const void* ends, int64_t k, bool overflow_is_error, ah_array_out* out) {
-  void* offs = nullptr;
-  void* data = nullptr;
-  size_t ob = 0, db = 0;
-  if (large)
-    AH_TRY(ranges_to_strings_t<int64_t>(ctx, src, (const int64_t*)starts, (const int64_t*)ends, k, overflow_is_error,
-                                        &offs, &ob, &data, &db));
-  else
-    AH_TRY(ranges_to_strings_t<int32_t>(ctx, src, (const int32_t*)starts, (const int32_t*)ends, k, overflow_is_error,
-                                        &offs, &ob, &data, &db));
-  out->offsets = offs;
-  out->offsets_bytes = (int64_t)ob;
-  out->values = data;
-  out->values_bytes = (int64_t)db;
-  return AH_OK;
-}
-
 // take_bytes (arrow-select/src/take.rs:499-627)
 ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_array_view* indices,
                         ah_array_out* out) {
@@ -825,31 +756,40 @@ ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_a
     vbytes = ah_bitmap_bytes(n);
     AH_TRY(ah_out_alloc(ctx, vbytes, (void**)&out_valid));
   }
+  // tmp: starts | local offsets | round totals | round bases | {first OOB, valid rows, byte total, -} | tile-scan slots
+  const int64_t nrounds = ah_ceil_div(n, 1024);
+  const size_t col = ((size_t)n * ow + 7) & ~(size_t)7;
   char* tmp = nullptr;
-  ah_status st = ah_pool_alloc(ctx, 2 * (size_t)n * ow + 16, (void**)&tmp);
+  ah_status st = ah_pool_alloc(ctx, 2 * col + (size_t)(2 * nrounds + 4 + AH_TILE_SCAN_MAX_BLOCKS) * 8, (void**)&tmp);
   if (st != AH_OK) {
     ah_out_free(ctx, out_valid, vbytes);
     return st;
   }
   void* starts = tmp;
-  void* ends = tmp + (((size_t)n * ow + 7) & ~(size_t)7);
-  unsigned long long* counters = nullptr;
-  st = ah_pool_alloc(ctx, 16, (void**)&counters);
-  if (st == AH_OK) {
-    hipMemsetAsync(counters, 0xFF, 8, ctx->stream);
-    hipMemsetAsync(counters + 1, 0, 8, ctx->stream);
+  void* loc = tmp + col;
+  unsigned long long* round_total = (unsigned long long*)(tmp + 2 * col);
+  unsigned long long* round_base = round_total + nrounds;
+  unsigned long long* counters = round_base + nrounds;
+  unsigned long long* scan_slots = counters + 4;
+  hipMemsetAsync(counters, 0xFF, 8, ctx->stream);
+  hipMemsetAsync(counters + 1, 0, (size_t)(3 + AH_TILE_SCAN_MAX_BLOCKS) * 8, ctx->stream);
+  {
     ah_prof_scope ps(ctx, "string_take_ranges");
     st = large ? launch_take_ranges<int64_t>(ctx, values, indices, ivalid, vvalid, (unsigned long long*)out_valid,
-                                             (int64_t*)starts, (int64_t*)ends, counters)
+                                             (int64_t*)starts, (int64_t*)loc, round_total, counters)
                : launch_take_ranges<int32_t>(ctx, values, indices, ivalid, vvalid, (unsigned long long*)out_valid,
-                                             (int32_t*)starts, (int32_t*)ends, counters);
+                                             (int32_t*)starts, (int32_t*)loc, round_total, counters);
   }
   if (st == AH_OK) {
-    hipError_t e = ah_d2h_wait(ctx, ctx->pinned + 16, counters, 16);
+    ah_prof_scope ps(ctx, "string_ranges_scan");
+    launch_string_tile_scan(ctx, round_total, nrounds, round_base, counters + 2, nullptr, scan_slots);
+  }
+  if (st == AH_OK) {  // the one wait before the gather: first OOB position, valid rows, byte total
+    hipError_t e = ah_d2h_wait(ctx, ctx->pinned + 16, counters, 24);
     if (e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "take ranges failed: %s", hipGetErrorString(e));
   }
-  ah_pool_free(ctx, counters);
   const int64_t out_nulls = st == AH_OK ? n - (int64_t)ctx->pinned[17] : 0;
+  const uint64_t total_bytes = st == AH_OK ? ctx->pinned[18] : 0;
   if (st == AH_OK && ctx->pinned[16] != ~0ull) {
     if (values_nullable) {
       // take_nulls runs first in the reference: take_bits -> BooleanBuffer::value asserts (boolean.rs:495)
@@ -872,12 +812,37 @@ ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_a
                    (long long)values->length + 1, (unsigned long long)bad);
     }
   }
-  if (st == AH_OK) st = ah_ranges_to_strings(ctx, large, (const uint8_t*)values->values, starts, ends, n, true, out);
+  // take_bytes: T::Offset::from_usize(capacity).ok_or_else(OffsetOverflowError(capacity)) (take.rs:521)
+  if (st == AH_OK && !large && total_bytes > (uint64_t)INT32_MAX)
+    st = ah_fail(ctx, AH_OFFSET_OVERFLOW_ERROR, "%llu", (unsigned long long)total_bytes);
+  const size_t ob = (size_t)(n + 1) * ow;
+  void *offs = nullptr, *data = nullptr;
+  if (st == AH_OK) st = ah_out_alloc(ctx, ob, &offs);
+  if (st == AH_OK) st = ah_out_alloc(ctx, (size_t)total_bytes, &data);
+  if (st == AH_OK) {
+    ah_prof_scope ps(ctx, "string_gather_bytes");
+    const unsigned grid = (unsigned)ah_ceil_div(n, 256);
+    if (large)
+      take_gather_rows_kernel<int64_t><<<grid, 256, 0, ctx->stream>>>((const uint8_t*)values->values, (const int64_t*)starts, (const int64_t*)loc,
+                                                                     round_base, counters + 2, n, (int64_t*)offs, (uint8_t*)data);
+    else
+      take_gather_rows_kernel<int32_t><<<grid, 256, 0, ctx->stream>>>((const uint8_t*)values->values, (const int32_t*)starts, (const int32_t*)loc,
+                                                                     round_base, counters + 2, n, (int32_t*)offs, (uint8_t*)data);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = ah_stream_wait(ctx);
+    if (e != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "string gather failed: %s", hipGetErrorString(e));
+  }
   ah_pool_free(ctx, tmp);
   if (st != AH_OK) {
+    ah_out_free(ctx, offs, ob);
+    ah_out_free(ctx, data, (size_t)total_bytes);
     ah_out_free(ctx, out_valid, vbytes);
     return st;
   }
+  out->offsets = offs;
+  out->offsets_bytes = (int64_t)ob;
+  out->values = data;
+  out->values_bytes = (int64_t)total_bytes;
   out->length = n;
   if (out_valid && (out_nulls > 0 || !values_nullable)) {  // take_nulls drops an all-valid result; index nulls are cloned
     out->validity = out_valid;
