@@ -17,6 +17,7 @@
 // (+ one scan launch), then the views and the long strings' bytes.  The result's data buffer travels in the
 // ah_array_out's `offsets` / `offsets_bytes` fields (a view array has no offsets; see include/arrow_hip.h).
 #include "common.hpp"
+#include "scan_chain.hpp"
 
 ah_status ah_cast_to_string(ah_context* ctx, const ah_array_view* values, ah_type to_type, ah_array_out* out);
 
@@ -62,36 +63,6 @@ __global__ void __launch_bounds__(VT) view_long_bytes_kernel(const OFF* offs, Bi
     unsigned long long tot = 0;
     for (int w = 0; w < VT / 64; ++w) tot += s_tot[w];
     block_bytes[blockIdx.x] = tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot;
-  }
-}
-
-// exclusive scan of the block totals (u32 -> u64), one workgroup: every thread owns a contiguous slice
-// total[0] = bytes of all long strings, total[1] = the last offset (the extent of the source text the views may read)
-__global__ void __launch_bounds__(1024) view_scan_kernel(const uint32_t* block_bytes, int64_t nblocks, unsigned long long* prefix,
-                                                         unsigned long long* total, const void* last_off, int wide) {
-  __shared__ unsigned long long s_wave[16];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int64_t per = (nblocks + 1023) / 1024, b0 = (int64_t)t * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
-  unsigned long long mine = 0;
-  for (int64_t b = b0; b < b1; ++b) mine += block_bytes[b];
-  unsigned long long incl = mine;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned long long u = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += u;
-  }
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  unsigned long long base = 0;
-  for (int w = 0; w < wave; ++w) base += s_wave[w];
-  unsigned long long run = base + incl - mine;
-  for (int64_t b = b0; b < b1; ++b) {
-    prefix[b] = run;
-    run += block_bytes[b];
-  }
-  if (t == 1023) {
-    total[0] = base + incl;
-    total[1] = wide ? (unsigned long long)*(const long long*)last_off : (unsigned long long)(long long)*(const int*)last_off;
   }
 }
 
@@ -175,14 +146,21 @@ ah_status build_views(ah_context* ctx, const OFF* offs, const uint8_t* data, Bit
   const int64_t nblocks = ah_ceil_div(len, (int64_t)VB);
   const size_t b_bytes = ((size_t)nblocks * 4 + 255) & ~(size_t)255, b_pre = ((size_t)nblocks * 8 + 255) & ~(size_t)255;
   char* scratch = nullptr;
-  AH_TRY(ah_pool_alloc(ctx, b_bytes + b_pre + 256, (void**)&scratch));
+  AH_TRY(ah_pool_alloc(ctx, b_bytes + b_pre + 256 + (size_t)AH_SCAN_CHAIN_MAX_BLOCKS * 8, (void**)&scratch));
   uint32_t* block_bytes = (uint32_t*)scratch;
   unsigned long long* prefix = (unsigned long long*)(scratch + b_bytes);
   unsigned long long* total = (unsigned long long*)(scratch + b_bytes + b_pre);  // two words
+  unsigned long long* scan_slots = (unsigned long long*)(scratch + b_bytes + b_pre + 256);
   {
     ah_prof_scope ps(ctx, "cast_view_len");
     view_long_bytes_kernel<OFF><<<(unsigned)nblocks, VT, 0, ctx->stream>>>(offs, valid, len, block_bytes);
-    view_scan_kernel<<<1, 1024, 0, ctx->stream>>>(block_bytes, nblocks, prefix, total, offs + len, sizeof(OFF) == 8 ? 1 : 0);
+    // block totals (u32) -> block bases, total[0] = bytes of all long strings, total[1] = the last offset (the extent of the
+    // source text the views may read): one launch of chained workgroups (scan_chain.hpp)
+    hipMemsetAsync(scan_slots, 0, (size_t)AH_SCAN_CHAIN_MAX_BLOCKS * 8, ctx->stream);
+    ScanChainExtra extra;
+    extra.last_off = offs + len;
+    extra.last_wide = sizeof(OFF) == 8 ? 1 : 0;
+    ah_launch_chained_scan<uint32_t>(ctx, block_bytes, nblocks, prefix, total, extra, scan_slots);
   }
   hipError_t e = ah_d2h_wait(ctx, ctx->pinned, total, 16);  // both words in the call's one wait before the allocation
   if (e != hipSuccess) {

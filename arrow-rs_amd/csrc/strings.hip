@@ -7,17 +7,18 @@
 //
 // MI355X design: both are "ranges -> scan of block totals -> gather", three launches and one wait before the gather
 // (the byte total sizes the data buffer):
-//   filter: string_filter_ranges_kernel / string_tile_scan_kernel / string_filter_gather_kernel (F1-F3 below);
+//   filter: string_filter_ranges_kernel / chained_scan_kernel / string_filter_gather_kernel (F1-F3 below);
 //   take:   T1 take_ranges_kernel: index -> source start (zero length under an output null), the output validity word, and —
 //              a workgroup round being 1024 consecutive output rows — the rows' byte offsets INSIDE the round plus the
 //              round's byte total (rounds 1-4 wrote [start, end) pairs and ran a three-kernel scan over them: 0.47 ms of
 //              the 4.1 ms step at 5.4e7 indices);
-//           T2 string_tile_scan_kernel over the round totals -> round bases, grand total;
+//           T2 chained_scan_kernel (scan_chain.hpp) over the round totals -> round bases, grand total;
 //           T3 take_gather_rows_kernel: final offset = round base + local offset (written out), one output row per thread,
 //              unaligned 8-byte chunks with an overlapping tail (rows <= 64 B); longer rows are copied cooperatively by
 //              the workgroup.  (The first version walked output bytes with a binary search per byte: 0.32 ms per 120 MB.)
 #include "common.hpp"
 #include "filter_internal.hpp"
+#include "scan_chain.hpp"
 
 #include <type_traits>
 
@@ -36,7 +37,7 @@ namespace {
 //    byte offset INSIDE the tile's output; (start, local offset) pairs are compacted through a 16 KiB LDS stage (1024 rows per round) and leave
 //    as coalesced stores at the tile's first output row (known from the predicate's prefix tables).  The tile's byte
 //    total goes to tile_bytes[tile].
-// F2 string_tile_scan_kernel: exclusive scan of the <= n / 4096 tile totals (one launch, <= 256 chained workgroups) -> tile_base, grand total
+// F2 chained_scan_kernel (scan_chain.hpp): exclusive scan of the <= n / 4096 tile totals (one launch, <= 256 chained workgroups) -> tile_base, grand total
 //    (the one number the host waits for: it sizes the data buffer).
 // F3 string_filter_gather_kernel: one workgroup per tile again: new offset = tile_base + local offset, bytes copied row by
 //    row (unaligned 8-byte chunks with an overlapping tail; rows > 64 B cooperatively).
@@ -268,92 +269,13 @@ __global__ void __launch_bounds__(256) bitmap_count_to_slots_kernel(const unsign
   }
 }
 
-// exclusive scan of the tile byte totals; *total_out = grand total.  Round 5: ONE launch of up to 256 workgroups chained through
-// `slots` (zeroed by the caller): workgroup b sums its contiguous segment of tiles with coalesced loads, publishes
-// FLAG | sum, collects the published sums of workgroups [0, b) — they were dispatched before it, so the wait cannot deadlock —
-// and writes its segment's bases.  (It was one workgroup whose threads each walked a contiguous run: 128 dependent, uncoalesced
-// steps per thread at 2^29 rows = 229 us of the 2.15 ms step; 53 us at 2^27 rows.)
-constexpr int AH_TILE_SCAN_MAX_BLOCKS = 256;
-constexpr unsigned long long AH_TILE_SCAN_FLAG = 1ull << 63;
-
-__device__ __forceinline__ unsigned long long block_scan_incl_1024(unsigned long long v, unsigned long long* s_wave, int lane,
-                                                                    int wave, unsigned long long* block_total) {
-  unsigned long long incl = v;
-#pragma unroll
-  for (int k = 1; k < 64; k <<= 1) {
-    const unsigned long long u = __shfl_up(incl, k, 64);
-    if (lane >= k) incl += u;
-  }
-  __syncthreads();  // (s_wave of the previous round has been read)
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  unsigned long long base = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < 16; ++w) {
-    const unsigned long long x = s_wave[w];
-    if (w < wave) base += x;
-    tot += x;
-  }
-  *block_total = tot;
-  return base + incl;
-}
-
-__global__ void __launch_bounds__(1024) string_tile_scan_kernel(const unsigned long long* tile_bytes, int64_t ntiles, int64_t seg,
-                                                                unsigned long long* tile_base, unsigned long long* total_out,
-                                                                const unsigned long long* valid_slots,
-                                                                unsigned long long* slots) {
-  __shared__ unsigned long long s_wave[16];
-  __shared__ unsigned long long s_base;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
-  const bool last = b == (int)gridDim.x - 1;
-  if (last && wave == 15 && valid_slots) {  // total_out[1] = valid rows = the 64 counters of the ranges kernel
-    const unsigned long long v = wave_reduce_add64(valid_slots[lane]);
-    if (lane == 0) total_out[1] = v;
-  }
-  const int64_t i0 = (int64_t)b * seg, i1 = i0 + seg < ntiles ? i0 + seg : ntiles;
-  // 1. the segment's total
-  unsigned long long mine = 0;
-  for (int64_t i = i0 + t; i < i1; i += 1024) mine += tile_bytes[i];
-  unsigned long long seg_total = 0;
-  (void)block_scan_incl_1024(mine, s_wave, lane, wave, &seg_total);
-  if (t == 0) __hip_atomic_store(slots + b, AH_TILE_SCAN_FLAG | seg_total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  // 2. the totals of the segments in front (wave 0: 64 of them per round)
-  if (wave == 0) {
-    unsigned long long acc = 0;
-    for (int j = lane; j < b; j += 64) {
-      unsigned long long x;
-      do {
-        x = __hip_atomic_load(slots + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        if (!(x & AH_TILE_SCAN_FLAG)) __builtin_amdgcn_s_sleep(1);
-      } while (!(x & AH_TILE_SCAN_FLAG));
-      acc += x & ~AH_TILE_SCAN_FLAG;
-    }
-    acc = wave_reduce_add64(acc);
-    if (lane == 0) s_base = acc;
-  }
-  __syncthreads();
-  unsigned long long run = s_base;
-  // 3. the segment's bases, 1024 tiles per round
-  for (int64_t c0 = i0; c0 < i1; c0 += 1024) {
-    const int64_t i = c0 + t;
-    const unsigned long long v = i < i1 ? tile_bytes[i] : 0ull;
-    unsigned long long tot = 0;
-    const unsigned long long incl = block_scan_incl_1024(v, s_wave, lane, wave, &tot);
-    if (i < i1) tile_base[i] = run + incl - v;
-    run += tot;
-  }
-  if (last && t == 0) *total_out = run;
-}
-
-// the launch: segments of whole 1024-tile rounds, at most AH_TILE_SCAN_MAX_BLOCKS of them
+// F2 / T2: exclusive scan of the tile (round) byte totals, grand total -> total[0]; with `valid_slots`, total[1] = valid rows
 static void launch_string_tile_scan(ah_context* ctx, const unsigned long long* tile_bytes, int64_t ntiles,
                                     unsigned long long* tile_base, unsigned long long* total,
                                     const unsigned long long* valid_slots, unsigned long long* slots) {
-  const int64_t rounds = std::max<int64_t>(1, ah_ceil_div(ntiles, 1024));
-  const int64_t per = ah_ceil_div(rounds, AH_TILE_SCAN_MAX_BLOCKS);  // rounds per workgroup
-  const int64_t seg = per * 1024;
-  const unsigned grid = (unsigned)std::max<int64_t>(1, ah_ceil_div(ntiles, seg));
-  string_tile_scan_kernel<<<grid, 1024, 0, ctx->stream>>>(tile_bytes, ntiles, seg, tile_base, total, valid_slots, slots);
+  ScanChainExtra extra;
+  extra.valid_slots = valid_slots;
+  ah_launch_chained_scan<unsigned long long>(ctx, tile_bytes, ntiles, tile_base, total, extra, slots);
 }
 
 __device__ __forceinline__ void copy8(uint8_t* d, const uint8_t* s) {  // unaligned 8-byte move
@@ -616,7 +538,7 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
   const bool hv = vvalid.words != nullptr;
   const size_t ob = (size_t)(K + 1) * sizeof(OFF), kb = (((size_t)K * sizeof(OFF)) + 15) & ~(size_t)15, nbytes = hv ? ah_bitmap_bytes(K) : 0;
   char* tmp = nullptr;  // starts | local offsets | tile bytes | tile bases | {total bytes, valid rows} | 64 valid-row counters | tile-scan slots
-  AH_TRY(ah_pool_alloc(ctx, 2 * kb + (size_t)(2 * ntiles + 2 + 64 + AH_TILE_SCAN_MAX_BLOCKS) * 8, (void**)&tmp));
+  AH_TRY(ah_pool_alloc(ctx, 2 * kb + (size_t)(2 * ntiles + 2 + 64 + AH_SCAN_CHAIN_MAX_BLOCKS) * 8, (void**)&tmp));
   void* nb = nullptr;
   if (hv) {
     const ah_status as = ah_out_alloc(ctx, nbytes, &nb);
@@ -633,7 +555,7 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
   unsigned long long* total = tile_base + ntiles;  // [0] byte total, [1] valid rows (both written by the tile scan)
   unsigned long long* vslots = total + 2;
   unsigned long long* scan_slots = vslots + 64;
-  hipMemsetAsync(hv ? vslots : scan_slots, 0, (size_t)((hv ? 64 : 0) + AH_TILE_SCAN_MAX_BLOCKS) * 8, ctx->stream);
+  hipMemsetAsync(hv ? vslots : scan_slots, 0, (size_t)((hv ? 64 : 0) + AH_SCAN_CHAIN_MAX_BLOCKS) * 8, ctx->stream);
   const bool vec = (((uintptr_t)offsets) & 15) == 0;
   bool sparse = K * 32 <= len;  // as for the primitive scatter (filter.hip: use_sparse); AH_FILTER_SPARSE=0 / 1 forces
   if (const char* env = getenv("AH_FILTER_SPARSE")) {
@@ -760,7 +682,7 @@ ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_a
   const int64_t nrounds = ah_ceil_div(n, 1024);
   const size_t col = ((size_t)n * ow + 7) & ~(size_t)7;
   char* tmp = nullptr;
-  ah_status st = ah_pool_alloc(ctx, 2 * col + (size_t)(2 * nrounds + 4 + AH_TILE_SCAN_MAX_BLOCKS) * 8, (void**)&tmp);
+  ah_status st = ah_pool_alloc(ctx, 2 * col + (size_t)(2 * nrounds + 4 + AH_SCAN_CHAIN_MAX_BLOCKS) * 8, (void**)&tmp);
   if (st != AH_OK) {
     ah_out_free(ctx, out_valid, vbytes);
     return st;
@@ -772,7 +694,7 @@ ah_status ah_take_bytes(ah_context* ctx, const ah_array_view* values, const ah_a
   unsigned long long* counters = round_base + nrounds;
   unsigned long long* scan_slots = counters + 4;
   hipMemsetAsync(counters, 0xFF, 8, ctx->stream);
-  hipMemsetAsync(counters + 1, 0, (size_t)(3 + AH_TILE_SCAN_MAX_BLOCKS) * 8, ctx->stream);
+  hipMemsetAsync(counters + 1, 0, (size_t)(3 + AH_SCAN_CHAIN_MAX_BLOCKS) * 8, ctx->stream);
   {
     ah_prof_scope ps(ctx, "string_take_ranges");
     st = large ? launch_take_ranges<int64_t>(ctx, values, indices, ivalid, vvalid, (unsigned long long*)out_valid,

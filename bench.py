@@ -993,10 +993,10 @@ PMC_KERNELS = {
 # divided by the steps the child ran (setup kernels — generators, the casts that build the input — do not match)
 PMC_STEP_KERNELS = {
     "string_filter": r"filter_(scatter|count|count_small|group_scan|finish)\w*_kernel|"
-                     r"string_filter_\w+_kernel|string_tile_scan_kernel",
-    "string_take": r"string_tile_scan_kernel|take_gather_rows_kernel|take_ranges_kernel",
+                     r"string_filter_\w+_kernel|chained_scan_kernel",
+    "string_take": r"chained_scan_kernel|take_gather_rows_kernel|take_ranges_kernel",
     "string_filter_take": r"filter_(scatter|count|count_small|group_scan|finish)\w*_kernel|string_filter_\w+_kernel|"
-                          r"string_tile_scan_kernel|take_gather_rows_kernel|take_ranges_kernel",
+                          r"chained_scan_kernel|take_gather_rows_kernel|take_ranges_kernel",
     "coalesce": r"filter_(scatter|count|count_small|group_scan|finish|finish_acc)\w*_kernel|copy_rows\w*_kernel|bm_acc_kernel|coalesce_finish_kernel",
     "predicate_filter_fused": r"filter_expr_\w+_kernel|filter_(scatter|group_scan|finish)\w*_kernel",
     "predicate_filter": r"compare_kernel|bitmap_op_kernel|filter_(scatter|count|count_small|group_scan|finish)\w*_kernel|popcount_partial_kernel",

@@ -863,6 +863,64 @@ def test_fuzz_string_filter_take(ctx, oracle):
     check(got, oracle.take(oracle.filter(oracle.cast(f, A.Utf8), m), i), "cast->filter->take")
 
 
+def _string_buffers(arr):
+    """(offsets as int64, data bytes) of a device Utf8 / LargeUtf8 array, through plain copies."""
+    ow = np.int64 if arr.data_type == A.LargeUtf8 else np.int32
+    offs = A.array._copy_dtoh(arr.ctx, arr.offsets.ptr, (arr.length + 1) * np.dtype(ow).itemsize).view(ow).astype(np.int64)
+    data = A.array._copy_dtoh(arr.ctx, arr.values.ptr, int(offs[-1])) if offs[-1] else np.zeros(0, np.uint8)
+    return offs, data
+
+
+def test_string_kernels_past_one_scan_workgroup(ctx):
+    """The block totals of the string kernels are scanned by ONE launch of chained workgroups (scan_chain.hpp), 1024 totals
+    per round: every other string test fits one workgroup.  6 Mi rows = 1 536 filter tiles, 3 Mi indices = 3 072 take rounds,
+    6 144+ view blocks -> several chained workgroups.  Checked against results that never touch that scan: filter / take
+    commute with the cast (numbers are filtered / taken first, then printed), and the out-of-line offsets of the views must
+    be the running sum of the long strings' lengths."""
+    n = 6 << 20
+    rng = np.random.default_rng(2909)
+    vals = np.round(rng.normal(size=n) * 1e9, 3)  # "-1234567890.123": out-of-line in a view
+    vals[rng.random(n) < 0.3] = 7.0  # short strings: inline views between the out-of-line ones
+    valid = rng.random(n) < 0.9
+    for dt in (A.LargeUtf8, A.Utf8):
+        x = HostArray(A.Float64, vals, valid).to_device(ctx)
+        sx = K.cast(x, dt)
+        m = HostArray(A.Boolean, rng.random(n) < 0.1).to_device(ctx)
+        got, exp = K.filter(sx, m), K.cast(K.filter(x, m), dt)
+        assert got.length == exp.length and got.null_count() == exp.null_count()
+        go, gd = _string_buffers(got)
+        eo, ed = _string_buffers(exp)
+        assert np.array_equal(go, eo), f"{dt} filter offsets"
+        # (a null slot keeps its bytes through filter_bytes; the cast wrote none, so the data compare is exact too)
+        assert np.array_equal(gd, ed), f"{dt} filter data"
+        k = 3 << 20
+        idx = rng.integers(0, n, k).astype(np.uint32)
+        ivalid = rng.random(k) < 0.95
+        hi = HostArray(A.UInt32, idx, ivalid).to_device(ctx)
+        got, exp = K.take(sx, hi), K.cast(K.take(x, hi), dt)
+        assert got.length == exp.length == k and got.null_count() == exp.null_count()
+        go, gd = _string_buffers(got)
+        eo, ed = _string_buffers(exp)
+        assert np.array_equal(go, eo), f"{dt} take offsets"
+        assert np.array_equal(gd, ed), f"{dt} take data"
+        assert np.array_equal(got.valid_mask(), exp.valid_mask())
+        # -> Utf8View: the long strings' offsets are the exclusive running sum of their lengths, their bytes the source's
+        v = K.cast(sx, A.Utf8View)
+        so, sd = _string_buffers(sx)
+        raw = A.array._copy_dtoh(ctx, v.values.ptr, n * 16).reshape(-1, 16)
+        lens = raw[:, 0:4].copy().view(np.uint32).ravel().astype(np.int64)
+        assert np.array_equal(lens[valid], (so[1:] - so[:-1])[valid]) and not raw[~valid].any()
+        long_rows = valid & (lens > 12)
+        ll = lens[long_rows]
+        want_off = np.cumsum(ll) - ll
+        got_off = raw[:, 12:16].copy().view(np.uint32).ravel().astype(np.int64)[long_rows]
+        assert np.array_equal(got_off, want_off), f"{dt} view offsets"
+        assert len(v.data_buffers) == 1 and v.data_buffers[0].nbytes == int(ll.sum())
+        buf = v.data_buffers[0].to_numpy()
+        src = np.repeat(so[:-1][long_rows] - want_off, ll) + np.arange(int(ll.sum()))
+        assert np.array_equal(buf, sd[src]), f"{dt} view data"
+
+
 def test_string_take_offset_overflow(ctx):
     """take_bytes: i32 offsets past i32::MAX -> ArrowError::OffsetOverflowError(capacity) (take.rs:521)."""
     big = "x" * (1 << 20)
