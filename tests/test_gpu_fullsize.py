@@ -458,6 +458,35 @@ def test_config3_cast_chain_every_row(ctx, oracle):
     assert np.array_equal(_dev_bytes(ctx, chain.validity, 0, n // 8), tb), "chain validity"
 
 
+def test_string_filter_take_every_row_commutes_with_cast(ctx):
+    """String filter / take at the bench's scale (2^28 rows = 65 536 filter tiles, 2^26 indices = 65 536 take rounds: 64
+    chained scan workgroups each, scan_chain.hpp).  filter / take of the printed column must equal the printed filter / take
+    of the numbers — the right-hand sides never run a string scan — compared row by row ON THE DEVICE (not_distinct) plus
+    the byte totals; the numeric filter / take and the cast are the paths the other full-size tests pin to the oracle."""
+    n = 1 << 28
+    src = B.gen_cast_source(A, K, ctx, n, 0.9, 0)
+    txt = K.cast(src, A.LargeUtf8)
+
+    def same_rows(a, b, what):
+        assert a.length == b.length and a.null_count() == b.null_count(), what
+        k = a.length
+        ta = int(_dev_bytes(ctx, a.offsets, k * 8, 8).view(np.int64)[0]) - int(_dev_bytes(ctx, a.offsets, 0, 8).view(np.int64)[0])
+        tb = int(_dev_bytes(ctx, b.offsets, k * 8, 8).view(np.int64)[0]) - int(_dev_bytes(ctx, b.offsets, 0, 8).view(np.int64)[0])
+        assert ta == tb, f"{what}: {ta} bytes against {tb}"
+        same = K.not_distinct(a, b)
+        cnt = C.c_int64()
+        ctx.check(ctx.lib.ah_count_set_bits(ctx.handle, same.values.ptr, 0, k, C.byref(cnt)))
+        assert cnt.value == k, f"{what}: {k - cnt.value} rows differ"
+
+    mask = B.gen_predicate(A, ctx, n, 91, 0.1, 0)
+    same_rows(K.filter(txt, mask), K.cast(K.filter(src, mask), A.LargeUtf8), "filter")
+    k = 1 << 26
+    ib = ctx.alloc(k * 4)
+    ctx.check(ctx.lib.ah_gen_uniform_u32(ctx.handle, ib.ptr, k, 92, n, 0))
+    idx = B.mk_array(A, ctx, A.UInt32, k, ib)
+    same_rows(K.take(txt, idx), K.cast(K.take(src, idx), A.LargeUtf8), "take")
+
+
 # ---------------------------------------------------------------------- 32-byte natives (i256) through filter / take
 @pytest.mark.parametrize("n", [1, 63, 1000, 1025, 40_000, 1_000_003])
 def test_filter_take_32_byte_natives(ctx, oracle, n):
