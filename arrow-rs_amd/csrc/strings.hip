@@ -45,21 +45,28 @@ namespace {
 //    validity flags ride through the stage, are re-packed with __ballot aligned to the output's 64-bit words and merged
 //    with atomicOr (pre-zeroed bitmap), the valid rows are counted into *valid_count (it was a separate bit-only scatter
 //    over the predicate, 107 us at 2^27 rows, plus a popcount launch and a host wait).
-template <typename OFF, bool VEC, bool HAS_VALID>
+// PT = the pairs' element type.  OFF: (absolute start, local offset).  uint32_t with 64-bit offsets ("narrow pairs", round 5):
+// (start - the tile's first offset, local offset) — half the bytes of the pairs' round trip through HBM (0.86 of ~10.7 GB per
+// 2^29 rows at 10 % selected); a tile whose 4096 rows span >= 4 GiB of text cannot be encoded and raises *wide_needed (the host
+// then reruns the call with PT = OFF).
+template <typename OFF, typename PT, bool VEC, bool HAS_VALID>
 __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* offsets, BitView mask, BitView mask_valid,
                                                                    int64_t len, const uint32_t* chunk_prefix,
                                                                    const unsigned long long* group_prefix, int group_shift,
-                                                                   OFF* starts, OFF* loffs, unsigned long long* tile_bytes,
+                                                                   PT* starts, PT* loffs, unsigned long long* tile_bytes,
                                                                    BitView vvalid, unsigned long long* out_valid,
-                                                                   unsigned long long* valid_count) {
+                                                                   unsigned long long* valid_count,
+                                                                   unsigned long long* wide_needed) {
   constexpr int T = 4096, NW = 64, R = 16, CAP = AH_SFR_CAP;
+  constexpr bool NARROW = sizeof(PT) < sizeof(OFF);
+  __shared__ OFF s_tile_first;
   __shared__ uint64_t s_m[NW];
   __shared__ uint64_t s_v[HAS_VALID ? NW : 1];
   __shared__ uint32_t s_base[NW];
   __shared__ uint32_t s_total;
   __shared__ unsigned long long s_wbytes[4];
-  __shared__ OFF s_start[CAP];
-  __shared__ OFF s_loff[CAP];
+  __shared__ PT s_start[CAP];
+  __shared__ PT s_loff[CAP];
   __shared__ uint8_t s_flag[HAS_VALID ? CAP : 1];
   __shared__ uint32_t s_vc[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -67,6 +74,7 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
   const int64_t r0 = row0 + (int64_t)t * R;
   // the thread's offsets go out first
   OFF o[R + 1];
+  OFF olast;  // the thread's last offset inside the array
   if (r0 + R <= len) {
     if constexpr (VEC) {
       constexpr int PV = 16 / sizeof(OFF);  // offsets per 16-byte load
@@ -82,10 +90,16 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
 #pragma unroll
       for (int e = 0; e <= R; ++e) o[e] = offsets[r0 + e];
     }
+    olast = o[R];
   } else {
+    olast = 0;
 #pragma unroll
-    for (int e = 0; e <= R; ++e) o[e] = r0 + e <= len ? offsets[r0 + e] : (OFF)0;
+    for (int e = 0; e <= R; ++e) {
+      o[e] = r0 + e <= len ? offsets[r0 + e] : (OFF)0;
+      if (r0 + e <= len) olast = o[e];
+    }
   }
+  if (NARROW && t == 0) s_tile_first = o[0];
   if (wave == 0) {
     uint64_t m = 0, vv = 0;
     const int64_t s = row0 + ((int64_t)lane << 6);
@@ -112,6 +126,14 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
 #pragma unroll
   for (int e = 0; e < R; ++e)
     if ((bits >> e) & 1u) mine += (unsigned long long)(o[e + 1] - o[e]);
+  OFF tile_first = 0;
+  if constexpr (NARROW) {
+    tile_first = s_tile_first;
+    // a thread with selected rows whose LAST offset lies 4 GiB or more behind the tile's first one: a start or a local offset
+    // may not fit (local offset <= start - tile_first: the selected bytes in front of a row are part of the span in front of
+    // it).  Conservative — the thread's last row need not be a selected one — and one compare per thread.
+    if (bits && ((unsigned long long)(olast - tile_first) >> 32)) atomicOr(wide_needed, 1ull);
+  }
   unsigned long long incl = mine;
 #pragma unroll
   for (int k = 1; k < 64; k <<= 1) {
@@ -138,8 +160,8 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
     for (int e = 0; e < R; ++e) {
       if ((bits >> e) & 1u) {
         if ((unsigned)pos < (unsigned)cnt) {
-          s_start[pos] = o[e];
-          s_loff[pos] = (OFF)bo;
+          s_start[pos] = (PT)(o[e] - tile_first);
+          s_loff[pos] = (PT)bo;
           if constexpr (HAS_VALID) s_flag[pos] = (uint8_t)((vbits >> e) & 1u);
         }
         bo += (unsigned long long)(o[e + 1] - o[e]);
@@ -345,9 +367,10 @@ __global__ void __launch_bounds__(256) take_gather_rows_kernel(const uint8_t* sr
 }
 
 // F3: the tile's selected rows [P, P + C): new offsets and bytes.  Same copy scheme as gather_bytes_kernel.
-template <typename OFF>
-__global__ void __launch_bounds__(256) string_filter_gather_kernel(const uint8_t* src, const OFF* starts, const OFF* loffs,
-                                                                   const unsigned long long* tile_bytes,
+// With narrow pairs (PT = uint32_t under 64-bit offsets) a start is relative to the tile's first offset, read here once.
+template <typename OFF, typename PT>
+__global__ void __launch_bounds__(256) string_filter_gather_kernel(const uint8_t* src, const OFF* offsets, const PT* starts,
+                                                                   const PT* loffs, const unsigned long long* tile_bytes,
                                                                    const unsigned long long* tile_base, int64_t len, int64_t K,
                                                                    const uint32_t* chunk_prefix, const unsigned long long* group_prefix,
                                                                    int group_shift, OFF* dst_off, uint8_t* dst) {
@@ -355,6 +378,8 @@ __global__ void __launch_bounds__(256) string_filter_gather_kernel(const uint8_t
   __shared__ int s_nlong;
   const int t = threadIdx.x;
   const int64_t ntiles = (len + 4095) / 4096, tile = blockIdx.x;
+  using UPT = typename std::make_unsigned<PT>::type;
+  const unsigned long long tile_first = sizeof(PT) < sizeof(OFF) ? (unsigned long long)offsets[tile * 4096] : 0ull;
   auto first_row = [&](int64_t tl) -> int64_t {
     if (tl >= ntiles) return K;
     const int64_t c0 = tl * 4096 / AH_FILTER_CHUNK_ROWS;
@@ -369,8 +394,8 @@ __global__ void __launch_bounds__(256) string_filter_gather_kernel(const uint8_t
     if (t == 0) s_nlong = 0;
     __syncthreads();
     if (j < C) {
-      const unsigned long long s0 = (unsigned long long)starts[P + j], lo = (unsigned long long)loffs[P + j];
-      const unsigned long long hi = j + 1 < C ? (unsigned long long)loffs[P + j + 1] : tbytes;
+      const unsigned long long s0 = tile_first + (unsigned long long)(UPT)starts[P + j], lo = (unsigned long long)(UPT)loffs[P + j];
+      const unsigned long long hi = j + 1 < C ? (unsigned long long)(UPT)loffs[P + j + 1] : tbytes;
       const unsigned long long n = hi - lo, d0 = base + lo;
       dst_off[P + j] = (OFF)d0;
       const uint8_t* sp = src + s0;
@@ -391,8 +416,8 @@ __global__ void __launch_bounds__(256) string_filter_gather_kernel(const uint8_t
     const int nlong = s_nlong;
     for (int q = 0; q < nlong; ++q) {
       const int r = s_long[q];
-      const unsigned long long rs = (unsigned long long)starts[P + r], lo = (unsigned long long)loffs[P + r];
-      const unsigned long long hi = r + 1 < C ? (unsigned long long)loffs[P + r + 1] : tbytes;
+      const unsigned long long rs = tile_first + (unsigned long long)(UPT)starts[P + r], lo = (unsigned long long)(UPT)loffs[P + r];
+      const unsigned long long hi = r + 1 < C ? (unsigned long long)(UPT)loffs[P + r + 1] : tbytes;
       const unsigned long long rl = hi - lo, rd = base + lo, whole = rl & ~7ull;
       for (unsigned long long o = (unsigned long long)t * 8; o < whole; o += 2048) copy8(dst + rd + o, src + rs + o);
       if ((unsigned long long)t < rl - whole) dst[rd + whole + t] = src[rs + whole + t];
@@ -530,15 +555,17 @@ ah_status launch_take_ranges(ah_context* ctx, const ah_array_view* values, const
 
 // filter_bytes (filter.rs:790-928) + filter_nulls (:512-532) for the rows `p` selects: offsets, data and — when `vvalid` has
 // words — the compacted validity of the result (dropped again when it has no nulls, :523-525).
-template <typename OFF>
+template <typename OFF, typename PT>
 static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* values, BitView vvalid,
-                                ah_array_out* out) {
+                                bool sparse, ah_array_out* out, bool* wide_needed) {
+  constexpr bool NARROW = sizeof(PT) < sizeof(OFF);
   const int64_t K = p->count, len = p->len, ntiles = ah_ceil_div(len, 4096);
   const OFF* offsets = (const OFF*)values->offsets;
   const bool hv = vvalid.words != nullptr;
-  const size_t ob = (size_t)(K + 1) * sizeof(OFF), kb = (((size_t)K * sizeof(OFF)) + 15) & ~(size_t)15, nbytes = hv ? ah_bitmap_bytes(K) : 0;
-  char* tmp = nullptr;  // starts | local offsets | tile bytes | tile bases | {total bytes, valid rows} | 64 valid-row counters | tile-scan slots
-  AH_TRY(ah_pool_alloc(ctx, 2 * kb + (size_t)(2 * ntiles + 2 + 64 + AH_SCAN_CHAIN_MAX_BLOCKS) * 8, (void**)&tmp));
+  const size_t ob = (size_t)(K + 1) * sizeof(OFF), kb = (((size_t)K * sizeof(PT)) + 15) & ~(size_t)15, nbytes = hv ? ah_bitmap_bytes(K) : 0;
+  // starts | local offsets | tile bytes | tile bases | {total bytes, valid rows} | {pairs too narrow, -} | 64 valid-row counters | tile-scan slots
+  char* tmp = nullptr;
+  AH_TRY(ah_pool_alloc(ctx, 2 * kb + (size_t)(2 * ntiles + 4 + 64 + AH_SCAN_CHAIN_MAX_BLOCKS) * 8, (void**)&tmp));
   void* nb = nullptr;
   if (hv) {
     const ah_status as = ah_out_alloc(ctx, nbytes, &nb);
@@ -548,49 +575,46 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
     }
     hipMemsetAsync(nb, 0, nbytes, ctx->stream);
   }
-  OFF* starts = (OFF*)tmp;
-  OFF* loffs = (OFF*)(tmp + kb);
+  PT* starts = (PT*)tmp;
+  PT* loffs = (PT*)(tmp + kb);
   unsigned long long* tile_bytes = (unsigned long long*)(tmp + 2 * kb);
   unsigned long long* tile_base = tile_bytes + ntiles;
-  unsigned long long* total = tile_base + ntiles;  // [0] byte total, [1] valid rows (both written by the tile scan)
-  unsigned long long* vslots = total + 2;
+  unsigned long long* total = tile_base + ntiles;  // [0] byte total, [1] valid rows (both written by the tile scan), [2] pairs too narrow
+  unsigned long long* vslots = total + 4;
   unsigned long long* scan_slots = vslots + 64;
-  hipMemsetAsync(hv ? vslots : scan_slots, 0, (size_t)((hv ? 64 : 0) + AH_SCAN_CHAIN_MAX_BLOCKS) * 8, ctx->stream);
+  hipMemsetAsync(total + 2, 0, (size_t)(2 + 64 + AH_SCAN_CHAIN_MAX_BLOCKS) * 8, ctx->stream);
   const bool vec = (((uintptr_t)offsets) & 15) == 0;
-  bool sparse = K * 32 <= len;  // as for the primitive scatter (filter.hip: use_sparse); AH_FILTER_SPARSE=0 / 1 forces
-  if (const char* env = getenv("AH_FILTER_SPARSE")) {
-    if (env[0] == '0') sparse = false;
-    if (env[0] == '1') sparse = true;
-  }
+  {  // ranges + tile scan: one profiled span
+  ah_prof_scope ps(ctx, "string_filter_ranges");
   if (sparse) {
-    ah_prof_scope ps(ctx, "string_filter_ranges");
-    const unsigned grid = (unsigned)ah_ceil_div(ntiles, 4);
-    if (hv) {
-      string_filter_ranges_sparse_kernel<OFF, true><<<grid, 256, 0, ctx->stream>>>(offsets, p->mask, p->mask_valid, len, p->chunk_prefix,
-                                                                                  p->group_prefix, p->group_shift, starts, loffs,
-                                                                                  tile_bytes, vvalid, (unsigned long long*)nb, ntiles);
-      const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, ah_ceil_div((K + 63) >> 6, 256 * 4)));
-      bitmap_count_to_slots_kernel<<<gx, 256, 0, ctx->stream>>>((const unsigned long long*)nb, K, vslots);
-    } else {
-      string_filter_ranges_sparse_kernel<OFF, false><<<grid, 256, 0, ctx->stream>>>(offsets, p->mask, p->mask_valid, len, p->chunk_prefix,
-                                                                                   p->group_prefix, p->group_shift, starts, loffs,
-                                                                                   tile_bytes, vvalid, nullptr, ntiles);
+    if constexpr (!NARROW) {
+      const unsigned grid = (unsigned)ah_ceil_div(ntiles, 4);
+      if (hv) {
+        string_filter_ranges_sparse_kernel<OFF, true><<<grid, 256, 0, ctx->stream>>>(offsets, p->mask, p->mask_valid, len, p->chunk_prefix,
+                                                                                    p->group_prefix, p->group_shift, starts, loffs,
+                                                                                    tile_bytes, vvalid, (unsigned long long*)nb, ntiles);
+        const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, ah_ceil_div((K + 63) >> 6, 256 * 4)));
+        bitmap_count_to_slots_kernel<<<gx, 256, 0, ctx->stream>>>((const unsigned long long*)nb, K, vslots);
+      } else {
+        string_filter_ranges_sparse_kernel<OFF, false><<<grid, 256, 0, ctx->stream>>>(offsets, p->mask, p->mask_valid, len, p->chunk_prefix,
+                                                                                     p->group_prefix, p->group_shift, starts, loffs,
+                                                                                     tile_bytes, vvalid, nullptr, ntiles);
+      }
     }
-    launch_string_tile_scan(ctx, tile_bytes, ntiles, tile_base, total, hv ? vslots : nullptr, scan_slots);
   } else {
-    ah_prof_scope ps(ctx, "string_filter_ranges");
 #define AH_SFR(VEC, HV)                                                                                                          \
-  string_filter_ranges_kernel<OFF, VEC, HV><<<(unsigned)ntiles, 256, 0, ctx->stream>>>(                                          \
+  string_filter_ranges_kernel<OFF, PT, VEC, HV><<<(unsigned)ntiles, 256, 0, ctx->stream>>>(                                      \
       offsets, p->mask, p->mask_valid, len, p->chunk_prefix, p->group_prefix, p->group_shift, starts, loffs, tile_bytes, vvalid, \
-      (unsigned long long*)nb, vslots)
+      (unsigned long long*)nb, vslots, total + 2)
     if (vec && hv) AH_SFR(true, true);
     else if (vec) AH_SFR(true, false);
     else if (hv) AH_SFR(false, true);
     else AH_SFR(false, false);
 #undef AH_SFR
-    launch_string_tile_scan(ctx, tile_bytes, ntiles, tile_base, total, hv ? vslots : nullptr, scan_slots);
   }
-  hipError_t e = ah_d2h_wait(ctx, ctx->pinned, total, 16);  // the one wait before the gather: byte total + valid rows
+  launch_string_tile_scan(ctx, tile_bytes, ntiles, tile_base, total, hv ? vslots : nullptr, scan_slots);
+  }
+  hipError_t e = ah_d2h_wait(ctx, ctx->pinned, total, 24);  // the one wait before the gather: byte total, valid rows, pair overflow
   if (e != hipSuccess) {
     ah_pool_free(ctx, tmp);
     ah_out_free(ctx, nb, nbytes);
@@ -598,6 +622,12 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
   }
   const uint64_t total_bytes = ctx->pinned[0];
   const int64_t nulls = hv ? K - (int64_t)ctx->pinned[1] : 0;
+  if (NARROW && ctx->pinned[2]) {  // a tile spans >= 4 GiB of text: the caller reruns with full-width pairs
+    ah_pool_free(ctx, tmp);
+    ah_out_free(ctx, nb, nbytes);
+    *wide_needed = true;
+    return AH_OK;
+  }
   if (sizeof(OFF) == 4 && total_bytes > (uint64_t)INT32_MAX) {
     ah_pool_free(ctx, tmp);
     ah_out_free(ctx, nb, nbytes);
@@ -614,9 +644,9 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
   }
   {
     ah_prof_scope ps(ctx, "string_gather_bytes");
-    string_filter_gather_kernel<OFF><<<(unsigned)ntiles, 256, 0, ctx->stream>>>((const uint8_t*)values->values, starts, loffs, tile_bytes,
-                                                                                tile_base, len, K, p->chunk_prefix, p->group_prefix,
-                                                                                p->group_shift, (OFF*)offs, (uint8_t*)data);
+    string_filter_gather_kernel<OFF, PT><<<(unsigned)ntiles, 256, 0, ctx->stream>>>((const uint8_t*)values->values, offsets, starts, loffs,
+                                                                                    tile_bytes, tile_base, len, K, p->chunk_prefix,
+                                                                                    p->group_prefix, p->group_shift, (OFF*)offs, (uint8_t*)data);
   }
   e = hipGetLastError();
   if (e == hipSuccess) e = ah_stream_wait(ctx);
@@ -642,8 +672,20 @@ static ah_status filter_bytes_t(ah_context* ctx, const ah_filter_predicate* p, c
 }
 ah_status ah_string_filter_bytes(ah_context* ctx, const ah_filter_predicate* p, const ah_array_view* values, BitView vvalid,
                                  ah_array_out* out) {
-  return values->type == AH_LARGE_UTF8 ? filter_bytes_t<int64_t>(ctx, p, values, vvalid, out)
-                                       : filter_bytes_t<int32_t>(ctx, p, values, vvalid, out);
+  bool sparse = p->count * 32 <= p->len;  // as for the primitive scatter (filter.hip: use_sparse); AH_FILTER_SPARSE=0 / 1 forces
+  if (const char* env = getenv("AH_FILTER_SPARSE")) {
+    if (env[0] == '0') sparse = false;
+    if (env[0] == '1') sparse = true;
+  }
+  bool wide = false;
+  if (values->type != AH_LARGE_UTF8) return filter_bytes_t<int32_t, int32_t>(ctx, p, values, vvalid, sparse, out, &wide);
+  // 64-bit offsets: 4-byte (tile-relative start, local offset) pairs unless a tile spans >= 4 GiB (AH_STRING_PAIRS=wide: A/B runs)
+  const char* pe = getenv("AH_STRING_PAIRS");
+  if (!sparse && !(pe && pe[0] == 'w')) {
+    AH_TRY((filter_bytes_t<int64_t, uint32_t>(ctx, p, values, vvalid, false, out, &wide)));
+    if (!wide) return AH_OK;
+  }
+  return filter_bytes_t<int64_t, int64_t>(ctx, p, values, vvalid, sparse, out, &wide);
 }
 
 // take_bytes (arrow-select/src/take.rs:499-627)

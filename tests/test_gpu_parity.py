@@ -921,6 +921,29 @@ def test_string_kernels_past_one_scan_workgroup(ctx):
         assert np.array_equal(buf, sd[src]), f"{dt} view data"
 
 
+def test_string_filter_tile_spanning_4gib(ctx):
+    """LargeUtf8 filter stages (tile-relative start, local offset) pairs in 4 bytes each; a 4096-row tile whose selected rows
+    end 4 GiB or more behind the tile's first offset cannot be encoded, the ranges pass says so and the call reruns with
+    8-byte pairs.  64 rows of 80 MiB (5 GiB of text, generated on the device); three selected rows, the last two past 4 GiB."""
+    L, rows = 80 << 20, 64
+    R = A.array._RawMem
+    text = ctx.alloc(rows * L)
+    ctx.check(ctx.lib.ah_gen_uniform_small(ctx.handle, text.ptr, 1, rows * L, 77, 0))
+    offs = A.array.DeviceBuffer.from_numpy(ctx, (np.arange(rows + 1, dtype=np.int64) * L))
+    d = A.Array(ctx, A.LargeUtf8, rows, R(text.ptr, text.nbytes, text), 0, None, 0, 0, R(offs.ptr, offs.nbytes, offs))
+    for picks in ([2, 52, 63], [1, 2]):  # the second selection ends before 4 GiB: the narrow pairs serve it
+        m = np.zeros(rows, dtype=bool)
+        m[picks] = True
+        got = K.filter(d, HostArray(A.Boolean, m).to_device(ctx))
+        assert got.length == len(picks) and got.null_count() == 0
+        go = A.array._copy_dtoh(ctx, got.offsets.ptr, (len(picks) + 1) * 8).view(np.int64)
+        assert np.array_equal(go, np.arange(len(picks) + 1, dtype=np.int64) * L)
+        for j, r in enumerate(picks):
+            a = A.array._copy_dtoh(ctx, got.values.ptr + j * L, L)
+            b = A.array._copy_dtoh(ctx, text.ptr + r * L, L)
+            assert np.array_equal(a, b), f"row {r}"
+
+
 def test_string_take_offset_overflow(ctx):
     """take_bytes: i32 offsets past i32::MAX -> ArrowError::OffsetOverflowError(capacity) (take.rs:521)."""
     big = "x" * (1 << 20)
