@@ -133,6 +133,9 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
     // may not fit (local offset <= start - tile_first: the selected bytes in front of a row are part of the span in front of
     // it).  Conservative — the thread's last row need not be a selected one — and one compare per thread.
     if (bits && ((unsigned long long)(olast - tile_first) >> 32)) atomicOr(wide_needed, 1ull);
+    // from here on the thread's offsets are relative to the tile's first one, in place (lengths are differences: unchanged)
+#pragma unroll
+    for (int e = 0; e <= R; ++e) o[e] -= tile_first;
   }
   unsigned long long incl = mine;
 #pragma unroll
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(256) string_filter_ranges_kernel(const OFF* of
     for (int e = 0; e < R; ++e) {
       if ((bits >> e) & 1u) {
         if ((unsigned)pos < (unsigned)cnt) {
-          s_start[pos] = (PT)(o[e] - tile_first);
+          s_start[pos] = (PT)o[e];  // (narrow pairs: o[] is tile-relative by now)
           s_loff[pos] = (PT)bo;
           if constexpr (HAS_VALID) s_flag[pos] = (uint8_t)((vbits >> e) & 1u);
         }

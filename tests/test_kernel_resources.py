@@ -100,5 +100,7 @@ def test_round3_kernels_keep_their_occupancy(kernels):
     for r in _find(kernels, "filter_scatter_sparse_kernelILi8ELb1E"):
         assert r["vgpr"] <= 64 and r["lds"] <= 3072 and r["scratch"] == 0, r
     # string filter ranges: a 16 KiB stage (1024 selected rows per round) -> 7 workgroups per CU (registers)
-    for r in _find(kernels, "string_filter_ranges_kernelIlLb1E"):
+    # (LargeUtf8: 8-byte pairs "Ill" and the 4-byte pairs "Ilj" that normally run — relative starts computed IN PLACE, or the
+    #  compiler keeps 16 more values live: 86 VGPRs, 5 waves per SIMD)
+    for r in _find(kernels, "string_filter_ranges_kernelIl", "Lb1ELb"):
         assert r["lds"] <= 20480 and r["vgpr"] <= 72, r
