@@ -178,6 +178,17 @@ struct SlabPin {
   bool busy = false;
 };
 
+// device copy of one push's tables.  Uploaded on the CONTEXT's copy stream, so the DMA (2.5 MB per 2^27 rows of 8192-row
+// batches: ~50 us) runs beside the previous push's scatter instead of in front of this push's count.  Three, rotating: a buffer
+// is rewritten only behind `idle`, recorded on the context's stream after the last kernel of the push that read it.
+struct SlabTables {
+  void* dev = nullptr;
+  size_t bytes = 0;
+  hipEvent_t idle = nullptr, uploaded = nullptr;
+  bool owner_live = false;  // a push between _begin and _end / _abort reads it
+  bool used = false;        // `idle` has been recorded at least once
+};
+
 }  // namespace
 
 struct ah_coalescer {
@@ -201,6 +212,8 @@ struct ah_coalescer {
   uint64_t* quant_pin_dev = nullptr;
   bool cnt_busy[2] = {false, false};
   SlabPin slab_pin[2];
+  SlabTables slab_tbl[3];
+  int slab_tbl_next = 0;
   // view schemas: every push is an "input" with a sequence number (0, 1, 2, ... in push order; the host counts the same
   // way); `declared` holds the per-column data-buffer counts of the inputs about to be pushed
   bool has_views = false;
@@ -672,6 +685,12 @@ extern "C" void ah_coalescer_destroy(ah_context* ctx, ah_coalescer* co) {
     ah_pinned_free(ctx, co->pin, co->pin_bytes);
     for (auto& sp : co->slab_pin)
       if (sp.host) ah_pinned_free(ctx, sp.host, sp.bytes);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (auto& tb : co->slab_tbl) {
+      ah_pool_free(ctx, tb.dev);
+      if (tb.idle) (void)hipEventDestroy(tb.idle);
+      if (tb.uploaded) (void)hipEventDestroy(tb.uploaded);
+    }
   }
   delete co;
 }
@@ -909,7 +928,7 @@ ah_status append_group(ah_context* ctx, ah_coalescer* co, int m, const ah_array_
 namespace {
 
 struct SlabPush {
-  int n = 0, slot = -1;
+  int n = 0, slot = -1, tbl = -1;
   int64_t total_rows = 0;
   ah_tbl_push t{};
   void* dev_block = nullptr;
@@ -962,6 +981,41 @@ ah_status slab_pin_reserve(ah_context* ctx, SlabPin& sp, size_t bytes) {
 
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// AH_COALESCE_COPY_STREAM=0: table uploads on the context's stream, in front of the count (A/B runs)
+bool slab_copy_stream_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("AH_COALESCE_COPY_STREAM");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+ah_status slab_tables_reserve(ah_context* ctx, SlabTables& tb, size_t bytes, bool* fresh) {
+  if (!ctx->copy_stream && slab_copy_stream_enabled() &&
+      hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess)
+    return ah_fail(ctx, AH_HIP_ERROR, "copy stream creation failed");
+  if (!tb.idle && (hipEventCreateWithFlags(&tb.idle, hipEventDisableTiming) != hipSuccess ||
+                   hipEventCreateWithFlags(&tb.uploaded, hipEventDisableTiming) != hipSuccess))
+    return ah_fail(ctx, AH_HIP_ERROR, "coalescer event creation failed");
+  if (tb.bytes >= bytes) return AH_OK;
+  ah_pool_free(ctx, tb.dev);  // (its readers ran on the context's stream: pool reuse is ordered behind them)
+  tb.dev = nullptr;
+  tb.bytes = 0;
+  const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 16);
+  AH_TRY(ah_pool_alloc(ctx, want, &tb.dev));
+  tb.bytes = want;
+  *fresh = true;
+  return AH_OK;
+}
+
+// the push that read table buffer `tbl` has enqueued its last kernel (or none): the buffer may be rewritten behind this point
+void slab_tables_release(ah_context* ctx, ah_coalescer* co, int tbl) {
+  if (tbl < 0) return;
+  SlabTables& tb = co->slab_tbl[tbl];
+  if (ctx->copy_stream && hipEventRecord(tb.idle, ctx->stream) == hipSuccess) tb.used = true;
+  tb.owner_live = false;
+}
+
 // tables built and uploaded, count + scan enqueued, mailbox posted: nothing waited for
 ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_view* columns, const int64_t* num_rows,
                      const ah_array_view* filters, SlabPush** out) {
@@ -993,7 +1047,8 @@ ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_vi
     (*out)->slot = -1;
     return AH_OK;
   }
-  // pinned block: [nwaves + 1 prefix words][segs][cols][chunk_seg][tiles]; device block: the same tables, then chunk_prefix, wave_total, wave_prefix
+  // pinned block: [nwaves + 1 prefix words][segs][cols][chunk_seg][tiles]; device: the same tables in one of the coalescer's
+  // three table buffers, and a pool block with chunk_prefix, wave_total, wave_prefix
   const size_t b_pref = up256(((size_t)nwaves + 1) * 8), b_seg = up256((size_t)n * sizeof(ah_tbl_seg)),
                b_col = up256((size_t)n * co->ncols * sizeof(ah_tbl_col)),
                b_cs = up256((size_t)nchunks * 4), b_til = up256((size_t)ntiles * sizeof(ah_tbl_tile));
@@ -1001,7 +1056,14 @@ ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_vi
   const size_t b_cp = up256((size_t)nchunks * 4), b_wt = up256((size_t)nwaves * 4), b_wp = up256(((size_t)nwaves + 1) * 8);
   SlabPin& pin = co->slab_pin[slot];
   AH_TRY(slab_pin_reserve(ctx, pin, b_pref + b_tables));
-  AH_TRY(ah_pool_alloc(ctx, b_tables + b_cp + b_wt + b_wp, &sp->dev_block));
+  int tbl = -1;
+  for (int q = 0; q < 3 && tbl < 0; ++q)
+    if (!co->slab_tbl[(co->slab_tbl_next + q) % 3].owner_live) tbl = (co->slab_tbl_next + q) % 3;
+  if (tbl < 0) return ah_fail(ctx, AH_INVALID_ARGUMENT, "BatchCoalescer: no table buffer free");  // (two pushes in flight at most)
+  SlabTables& tb = co->slab_tbl[tbl];
+  bool fresh = false;
+  AH_TRY(slab_tables_reserve(ctx, tb, b_tables, &fresh));
+  AH_TRY(ah_pool_alloc(ctx, b_cp + b_wt + b_wp, &sp->dev_block));
   char* hs = (char*)pin.host + b_pref;
   auto* segs = (ah_tbl_seg*)hs;
   auto* tcols = (ah_tbl_col*)(hs + b_seg);
@@ -1026,27 +1088,38 @@ ah_status slab_begin(ah_context* ctx, ah_coalescer* co, int n, const ah_array_vi
     const int64_t nt = sp->tile0[(size_t)i + 1] - sp->tile0[(size_t)i];
     for (int64_t q = 0; q < nt; ++q) tiles[ti++] = ah_tbl_tile{i, (int32_t)q};
   }
-  char* db = (char*)sp->dev_block;
+  char *db = (char*)tb.dev, *ws = (char*)sp->dev_block;
   sp->t.segs = (const ah_tbl_seg*)db;
   sp->t.cols = (const ah_tbl_col*)(db + b_seg);
   sp->t.ncols = co->ncols;
   sp->t.chunk_seg = (const int32_t*)(db + b_seg + b_col);
   sp->t.tiles = (const ah_tbl_tile*)(db + b_seg + b_col + b_cs);
   sp->t.nsegs = n, sp->t.nchunks = nchunks, sp->t.nwaves = nwaves, sp->t.ntiles = ntiles;
-  sp->t.chunk_prefix = (uint32_t*)(db + b_tables);
-  sp->t.wave_total = (uint32_t*)(db + b_tables + b_cp);
-  sp->t.wave_prefix = (unsigned long long*)(db + b_tables + b_cp + b_wt);
+  sp->t.chunk_prefix = (uint32_t*)ws;
+  sp->t.wave_total = (uint32_t*)(ws + b_cp);
+  sp->t.wave_prefix = (unsigned long long*)(ws + b_cp + b_wt);
   ah_status st = AH_OK;
   const double t_1 = tm.on ? now_us() : 0;
-  if (hipMemcpyAsync(db, hs, b_tables, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-    st = ah_fail(ctx, AH_HIP_ERROR, "coalescer table upload failed");
+  // the upload: on the copy stream, behind the last kernel that read this buffer; the count waits for it
+  const bool side = ctx->copy_stream != nullptr;
+  hipStream_t cs = side ? ctx->copy_stream : ctx->stream;
+  bool ok = true;
+  if (side && fresh) ok = hipEventRecord(tb.idle, ctx->stream) == hipSuccess;  // the block's previous life ran on the context's stream
+  if (ok && side && (fresh || tb.used)) ok = hipStreamWaitEvent(cs, tb.idle, 0) == hipSuccess;
+  ok = ok && hipMemcpyAsync(db, hs, b_tables, hipMemcpyHostToDevice, cs) == hipSuccess;
+  if (ok && side) ok = hipEventRecord(tb.uploaded, cs) == hipSuccess && hipStreamWaitEvent(ctx->stream, tb.uploaded, 0) == hipSuccess;
+  if (!ok) st = ah_fail(ctx, AH_HIP_ERROR, "coalescer table upload failed");
   if (st == AH_OK) st = ah_filter_table_count(ctx, sp->t, (uint64_t*)pin.dev, &sp->seq);
   if (st != AH_OK) {
+    if (side) (void)hipStreamSynchronize(cs);
     (void)ah_stream_wait(ctx);
     ah_pool_free(ctx, sp->dev_block);
     return st;
   }
   if (tm.on) tm.build += t_1 - t_0, tm.upload_count += now_us() - t_1, tm.pushes += 1, tm.batches += n;
+  tb.owner_live = true;
+  sp->tbl = tbl;
+  co->slab_tbl_next = (tbl + 1) % 3;
   pin.busy = true;
   *out = sp.release();
   return AH_OK;
@@ -1057,6 +1130,7 @@ void slab_abort(ah_context* ctx, ah_coalescer* co, SlabPush* sp) {
   if (sp->slot >= 0) {
     (void)ah_stream_wait(ctx);  // the count kernels may still be writing the tables' block and the pinned words
     co->slab_pin[sp->slot].busy = false;
+    slab_tables_release(ctx, co, sp->tbl);
   }
   ah_pool_free(ctx, sp->dev_block);
   delete sp;
@@ -1082,11 +1156,16 @@ ah_status slab_end(ah_context* ctx, ah_coalescer* co, SlabPush* sp_raw) {
   if (tm.on) append_timer.t1 = now_us(), tm.wait += append_timer.t1 - t_0;
   if (later_work && ctx->wait_mode != 1) ctx->inflight = true;
   pin.busy = false;
-  struct FreeBlock {  // (pool reuse is stream-ordered behind the launches below)
+  struct FreeBlock {  // (pool reuse is stream-ordered behind the launches below; the table buffer's `idle` event likewise)
     ah_context* c;
+    ah_coalescer* co;
     void* b;
-    ~FreeBlock() { ah_pool_free(c, b); }
-  } fb{ctx, sp->dev_block};
+    int tbl;
+    ~FreeBlock() {
+      ah_pool_free(c, b);
+      slab_tables_release(c, co, tbl);
+    }
+  } fb{ctx, co, sp->dev_block, sp->tbl};
   if (we != hipSuccess) return ah_fail(ctx, AH_HIP_ERROR, "coalescer count failed: %s", hipGetErrorString(we));
   if (co->failed) return ah_fail(ctx, AH_INVALID_ARGUMENT, "BatchCoalescer: unusable after an earlier device error");
   const uint64_t* P = (const uint64_t*)pin.host;  // [nwaves + 1]

@@ -36,6 +36,7 @@ struct ah_context {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // created on first use (coalesce.hip: table uploads beside the previous push's scatter); a HIP stream costs milliseconds to create
   std::string err;
   // output allocator hook
   ah_alloc_fn alloc = nullptr;

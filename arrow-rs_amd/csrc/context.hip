@@ -475,6 +475,7 @@ extern "C" void ah_context_destroy(ah_context* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
   ah_profile_reset(ctx);
   ah_pool_trim(ctx);
   for (auto& kv : ctx->pool_live) hipFree(kv.first);
@@ -483,6 +484,7 @@ extern "C" void ah_context_destroy(ah_context* ctx) {
   if (ctx->fault_dev) hipFree(ctx->fault_dev);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   for (auto& pb : ctx->pinned_cache) hipHostFree(pb.second);
+  if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
