@@ -12,6 +12,7 @@ Values, validity and offsets are DEVICE buffers; nothing here touches device
 bytes on the host except the explicit ``to_numpy`` / ``to_pylist`` copies.
 """
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -471,6 +472,11 @@ class _OutBuffer:
         return out
 
 
+# AH_DEBUG_GUARD=1 (csrc/context.hip: every buffer ends against an unmapped page): uploaded bitmaps are then NOT padded to whole
+# words, so a kernel that reads bitmap bytes the producer never promised is caught (tests/test_gpu_guard.py)
+_TIGHT_BITMAPS = os.environ.get("AH_DEBUG_GUARD") == "1" or os.environ.get("AH_TIGHT_BITMAPS") == "1"
+
+
 def pack_bits(bools, bit_offset=0):
     """LSB-first bit packing with a leading bit offset; padded to whole u64 words
     (BooleanBuffer layout, arrow-buffer/src/buffer/boolean.rs:97-104)."""
@@ -478,7 +484,10 @@ def pack_bits(bools, bit_offset=0):
     total = bit_offset + len(bools)
     padded = np.zeros(((total + 63) // 64) * 64, dtype=bool)
     padded[bit_offset:total] = bools
-    return np.packbits(padded, bitorder="little")
+    packed = np.packbits(padded, bitorder="little")
+    if _TIGHT_BITMAPS:  # what Arrow guarantees a consumer: ceil(bits / 8) bytes, nothing behind them
+        packed = packed[:(total + 7) // 8].copy()
+    return packed
 
 
 def unpack_bits(byts, bit_offset, length):

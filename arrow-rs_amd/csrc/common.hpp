@@ -46,6 +46,13 @@ struct ah_context {
   std::map<size_t, std::vector<void*>> pool_free;
   std::unordered_map<void*, size_t> pool_live;  // ptr -> rounded size
   std::unordered_map<void*, size_t> redzones;   // AH_DEBUG_REDZONE: ptr -> requested size
+  // AH_DEBUG_GUARD (context.hip): every pool block is its own mapping, flush against an unmapped granule
+  struct guard_block {
+    void* va;
+    size_t va_bytes, map_bytes;
+    hipMemGenericAllocationHandle_t handle;
+  };
+  std::unordered_map<void*, guard_block> guard_live;  // buffer pointer -> its reservation
   // output buffers carved out of ONE pool block (BatchCoalescer's slab push: thousands of 8192-row output batches per
   // allocation): slice pointer -> its slab; the block goes back to the pool when the last slice (and the creator) let go
   // (found by ADDRESS RANGE: a pointer inside a live slab's block is a slice of it — no per-slice bookkeeping: a slab push
@@ -156,6 +163,7 @@ static inline int64_t ah_nulls(const ah_context* ctx, int64_t len, int64_t set_b
   return ctx->deferred ? -1 : len - set_bits;
 }
 
+bool ah_guard_mode();  // AH_DEBUG_GUARD=1 (context.hip)
 // pooled device memory (internal + default output allocator)
 ah_status ah_pool_alloc(ah_context* ctx, size_t bytes, void** out);
 void ah_pool_free(ah_context* ctx, void* p);

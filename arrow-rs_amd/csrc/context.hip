@@ -88,7 +88,89 @@ static inline void stats_on_alloc(ah_context* ctx, size_t r, bool from_cache) {
   if (s.live_bytes + s.cached_bytes > s.reserved_high_water_bytes) s.reserved_high_water_bytes = s.live_bytes + s.cached_bytes;
 }
 
+// Guard mode (AH_DEBUG_GUARD=1): the over-READ detector the redzone canaries are not (the reference's
+// equivalent is Miri over its `unsafe` gathers, .github/workflows/miri.sh, arrow-select/src/filter.rs:756-761, take.rs:442-454).
+// Every pool block — inputs uploaded through ah_device_alloc, outputs, scratch, slabs — is its own virtual-memory mapping
+// (hipMemAddressReserve + hipMemCreate + hipMemMap) with the buffer's END flush against the end of the mapping and the
+// next granule of the reservation left UNMAPPED: a kernel that touches anything at or past the first aligned unit behind
+// the buffer raises "Memory access fault" on every box, instead of reading whatever the pool's power-of-two rounding or a
+// neighbouring allocation happened to put there.  Nothing is cached or recycled: a released block is unmapped after the
+// device has drained, so a kernel that uses a block after its release faults as well.
+// AH_DEBUG_GUARD_ALIGN (default 16, a power of two >= 8) is the alignment of the buffer's start = the slack the end can
+// have: the widest per-lane access is 16 bytes, and an ALIGNED 16-byte access never crosses a page, so up to 15 bytes of
+// aligned overhang cannot fault on any mapping and are not an error; everything wider is.
+static int guard_align_env() {
+  const char* e = getenv("AH_DEBUG_GUARD_ALIGN");
+  long a = e ? atol(e) : 16;
+  if (a < 8 || (a & (a - 1))) a = 16;
+  return (int)a;
+}
+bool ah_guard_mode() {
+  static const bool on = [] {
+    const char* e = getenv("AH_DEBUG_GUARD");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+static ah_status guard_alloc(ah_context* ctx, size_t bytes, void** out) {
+  static const size_t align = (size_t)guard_align_env();
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = ctx->device;
+  static size_t gran = 0;
+  if (!gran) {
+    size_t g = 0;
+    if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || !g)
+      return ah_fail(ctx, AH_HIP_ERROR, "AH_DEBUG_GUARD=1: hipMemGetAllocationGranularity failed (no virtual memory management on this device?)");
+    gran = g;
+  }
+  const size_t padded = (bytes + align - 1) & ~(align - 1);
+  const size_t map_bytes = (padded + gran - 1) / gran * gran;
+  ah_context::guard_block b{};
+  b.va_bytes = map_bytes + gran;  // the last granule stays unmapped: the guard
+  b.map_bytes = map_bytes;
+  hipError_t e = hipMemAddressReserve(&b.va, b.va_bytes, gran, nullptr, 0);
+  if (e == hipSuccess) {
+    e = hipMemCreate(&b.handle, map_bytes, &prop, 0);
+    if (e == hipSuccess) {
+      e = hipMemMap(b.va, map_bytes, 0, b.handle, 0);
+      if (e == hipSuccess) {
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(b.va, map_bytes, &acc, 1);
+        if (e != hipSuccess) (void)hipMemUnmap(b.va, map_bytes);
+      }
+      if (e != hipSuccess) (void)hipMemRelease(b.handle);
+    }
+    if (e != hipSuccess) (void)hipMemAddressFree(b.va, b.va_bytes);
+  }
+  if (e != hipSuccess)
+    return ah_fail(ctx, e == hipErrorOutOfMemory ? AH_OUT_OF_MEMORY : AH_HIP_ERROR, "AH_DEBUG_GUARD=1: mapping %zu bytes failed: %s", map_bytes,
+                   hipGetErrorString(e));
+  void* p = (char*)b.va + map_bytes - padded;
+  // fresh mappings read as zero (the driver clears VRAM), recycled pool blocks do not: poison the whole mapping so that a kernel
+  // which relies on zeroed scratch or output memory sees garbage here on every box (AH_DEBUG_GUARD_FILL=hex byte, default CD)
+  static const int fill = [] {
+    const char* f = getenv("AH_DEBUG_GUARD_FILL");
+    return f ? (int)strtol(f, nullptr, 16) & 0xFF : 0xCD;
+  }();
+  if (!ctx->capturing && hipMemsetAsync(b.va, fill, map_bytes, ctx->stream) != hipSuccess) (void)hipGetLastError();  // (a recorded memset would poison every replay)
+  ctx->guard_live[p] = b;
+  ctx->pool_live[p] = map_bytes;
+  *out = p;
+  stats_on_alloc(ctx, map_bytes, false);
+  return AH_OK;
+}
+static void guard_unmap(const ah_context::guard_block& b) {
+  (void)hipMemUnmap(b.va, b.map_bytes);
+  (void)hipMemRelease(b.handle);
+  (void)hipMemAddressFree(b.va, b.va_bytes);
+}
+
 ah_status ah_pool_alloc(ah_context* ctx, size_t bytes, void** out) {
+  if (ah_guard_mode()) return guard_alloc(ctx, bytes ? bytes : 1, out);
   size_t r = pool_round(bytes);
   auto it = ctx->pool_free.find(r);
   if (it != ctx->pool_free.end() && !it->second.empty()) {
@@ -119,6 +201,17 @@ void ah_pool_free(ah_context* ctx, void* p) {
   if (it == ctx->pool_live.end()) return;  // not ours
   if (ctx->capturing) {  // a captured kernel writes this block on every replay: it stays out of circulation with the graph
     ctx->capture_hold.push_back(p);
+    return;
+  }
+  auto gb = ctx->guard_live.find(p);
+  if (gb != ctx->guard_live.end()) {  // guard mode: never recycled — unmapped once nothing enqueued can still be using it
+    (void)hipDeviceSynchronize();
+    guard_unmap(gb->second);
+    ctx->guard_live.erase(gb);
+    ctx->stats.live_bytes -= (int64_t)it->second;
+    ctx->stats.freed_bytes_total += (int64_t)it->second;
+    ctx->stats.free_calls += 1;
+    ctx->pool_live.erase(it);
     return;
   }
   ctx->pool_free[it->second].push_back(p);
@@ -478,7 +571,11 @@ extern "C" void ah_context_destroy(ah_context* ctx) {
   if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
   ah_profile_reset(ctx);
   ah_pool_trim(ctx);
-  for (auto& kv : ctx->pool_live) hipFree(kv.first);
+  for (auto& kv : ctx->pool_live) {
+    auto gb = ctx->guard_live.find(kv.first);
+    if (gb != ctx->guard_live.end()) guard_unmap(gb->second);
+    else hipFree(kv.first);
+  }
   for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->fault_dev) hipFree(ctx->fault_dev);

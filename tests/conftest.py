@@ -30,6 +30,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_runtest_logstart(nodeid, location):
+    """The id of the test about to run, straight to fd 2 (unbuffered, no capture): when the GPU faults the HSA runtime
+    aborts the process at once, and the last `[ah-test]` line of the log is then the test that was running."""
+    try:
+        os.write(2, f"\n[ah-test] {nodeid}\n".encode())
+    except OSError:
+        pass
+
+
 def pytest_sessionstart(session):
     """A clean checkout has no built artefacts (*.so is git-ignored): build the HIP library (hipcc cross-compiles
     without a GPU) before collection imports the package.  The product itself never builds or falls back."""
