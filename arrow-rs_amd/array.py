@@ -474,7 +474,7 @@ class _OutBuffer:
 
 # AH_DEBUG_GUARD=1 (csrc/context.hip: every buffer ends against an unmapped page): uploaded bitmaps are then NOT padded to whole
 # words, so a kernel that reads bitmap bytes the producer never promised is caught (tests/test_gpu_guard.py)
-_TIGHT_BITMAPS = os.environ.get("AH_DEBUG_GUARD") == "1" or os.environ.get("AH_TIGHT_BITMAPS") == "1"
+_TIGHT_BITMAPS = os.environ.get("AH_TIGHT_BITMAPS", os.environ.get("AH_DEBUG_GUARD", "0")) == "1"  # AH_TIGHT_BITMAPS=0/1 overrides
 
 
 def pack_bits(bools, bit_offset=0):

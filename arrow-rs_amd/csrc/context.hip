@@ -163,10 +163,14 @@ static ah_status guard_alloc(ah_context* ctx, size_t bytes, void** out) {
   stats_on_alloc(ctx, map_bytes, false);
   return AH_OK;
 }
+// The RESERVATION is never given back: (1) a released buffer's addresses then stay unmapped for the life of the process, so a
+// use-after-release faults however late it comes; (2) on this stack (ROCm 7.2 user space, amdgpu of Linux 6.18) a range that is
+// hipMemAddressFree'd, reserved again and mapped to new memory intermittently serves the OLD translation to one of the engines
+// — tools/probes/vmm_probe.hip shows blocks reading back another block's bytes after 15-120 map / unmap cycles with address
+// reuse and none without (profiles/r06_crash.md).  47 bits of address space outlast any test run.
 static void guard_unmap(const ah_context::guard_block& b) {
   (void)hipMemUnmap(b.va, b.map_bytes);
   (void)hipMemRelease(b.handle);
-  (void)hipMemAddressFree(b.va, b.va_bytes);
 }
 
 ah_status ah_pool_alloc(ah_context* ctx, size_t bytes, void** out) {
