@@ -103,6 +103,14 @@ class _InProgressGeneric:
         return arr
 
 
+def _destroy_native(lib, ctx_handle, handle, pending_fins):
+    for f in list(pending_fins):
+        if f.alive:
+            f()  # ah_coalescer_push_abort, once
+    del pending_fins[:]
+    lib.ah_coalescer_destroy(ctx_handle, handle)
+
+
 def _in_progress(ctx, data_type, batch_size, acc=None):  # `create_in_progress_array` (coalesce.rs:673-700)
     if data_type.is_primitive() and data_type.width > 0 and data_type.physical not in (L.AH_UTF8_VIEW, L.AH_BINARY_VIEW):
         return _InProgress(ctx, data_type, batch_size, acc)
@@ -136,7 +144,10 @@ class BatchCoalescer:
             self._view_cols = [i for i, dt in enumerate(self.data_types) if dt.physical in (L.AH_UTF8_VIEW, L.AH_BINARY_VIEW)]
             self._seq, self._inputs = 0, {}
             import weakref
-            self._fin = weakref.finalize(self, lib.ah_coalescer_destroy, self.ctx.handle, h)
+            # begun pushes that were never ended hold native state INSIDE the coalescer: they are aborted before it is
+            # destroyed, whichever of the two Python objects is collected first
+            self._pending_fins = []
+            self._fin = weakref.finalize(self, _destroy_native, lib, self.ctx.handle, h, self._pending_fins)
             return
         # one device word per column for the appended-null counts (zeroed once; ah_read_words resets them)
         ncols = max(len(self.data_types), 1)
@@ -224,7 +235,8 @@ class BatchCoalescer:
         outs = (L.ArrayOut * (want * nc))()
         rows = (C.c_int64 * want)()
         n = C.c_int32()
-        self.ctx.check(self.ctx.lib.ah_coalescer_next_completed_batches(self.ctx.handle, self._native, want, outs, rows, None, C.byref(n)))
+        st = self.ctx.lib.ah_coalescer_next_completed_batches(self.ctx.handle, self._native, want, outs, rows, None, C.byref(n))
+        # the batches the call popped before it failed are owned HERE now: wrap them first, then raise
         for j in range(n.value):
             cols = []
             for i, dt in enumerate(self.data_types):
@@ -232,6 +244,7 @@ class BatchCoalescer:
                 C.memmove(C.byref(o), C.byref(outs[j * nc + i]), C.sizeof(L.ArrayOut))
                 cols.append(Array._from_out(self.ctx, o, dt))
             out.append(RecordBatch(self.names, cols, num_rows=rows[j]))
+        self.ctx.check(st)
         return out
 
     def _slab_schema(self):
@@ -362,7 +375,7 @@ class BatchCoalescer:
 
         Same output batches, same order as the one-call form.  Non-native schemas: everything happens in ``end()``."""
         pairs = list(pairs)
-        if self._native is None or not pairs or (len(pairs) > 64 and not self._slab_schema()):
+        if self._native is None or not pairs:  # (any number of pairs: the library counts groups of 64 itself when its slab path declines)
             return _PendingPush(self, pairs, None, None, None)
         n, nc = len(pairs), len(self.data_types)
         views = (L.ArrayView * (n * nc))()
@@ -456,6 +469,7 @@ class _PendingPush:
         if handle is not None:  # a handle that is never ended must not keep its pinned slot and predicates
             import weakref
             self._fin = weakref.finalize(self, co.ctx.lib.ah_coalescer_push_abort, co.ctx.handle, co._native, handle)
+            co._pending_fins[:] = [f for f in co._pending_fins if f.alive] + [self._fin]
 
     def abort(self):
         """give the push up without appending its batches (``ah_coalescer_push_abort``)"""

@@ -770,11 +770,16 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
     std::vector<ah_array_out> outs((size_t)co->ncols);
     std::vector<ah_array_view> views((size_t)co->ncols);
     for (auto& o : outs) ah_out_init(&o);
+    // (the filtered batch leaves as an OWNED completed batch — the large-batch cases 1 / 2 below — rather than being copied)
+    const bool leaves_as_is = co->limit >= 0 && selected > co->limit && (co->buffered == 0 || co->buffered > co->limit);
     for (int i = 0; i < co->ncols && st == AH_OK; ++i) {
       st = ah_filter_predicate_apply(ctx, p, &columns[i], &outs[i]);
-      if (st == AH_OK && co->cols[i].generic && (outs[i].flags & AH_OUT_BORROWED)) {
-        // the `All` strategy of a predicate shorter than its batch: a borrowed slice — a generic column would ADOPT it and
-        // keep the caller's buffers past this call.  Copy the rows out instead.
+      if (st == AH_OK && (co->cols[i].generic || leaves_as_is) && (outs[i].flags & AH_OUT_BORROWED)) {
+        // the `All` strategy of a predicate shorter than its batch: a borrowed slice — a generic column would ADOPT it, and a
+        // batch that leaves as it is would carry it into the completed queue: either way the caller's buffers would be used
+        // past this call, and the caller is only told to keep BYPASSED batches alive.  Copy the rows out instead.
+        // (round 6, found by AH_DEBUG_GUARD: the fixed-width columns of such a batch read released memory when fetched —
+        // tests/test_gpu_parity.py::test_batch_coalescer_grouped_pushes_equal_single_pushes, limit 64, predicate 2 rows short)
         ah_array_release(ctx, &outs[i]);
         const ah_array_view& sv = columns[i];
         const ah_array_view sl = slice_view(sv.type, sv.values, sv.values_bit_offset, sv.validity, sv.validity_bit_offset, sv.offsets,
@@ -795,7 +800,7 @@ ah_status push_filtered_impl(ah_context* ctx, ah_coalescer* co, const ah_array_v
         v.validity_bit_offset = outs[i].validity_bit_offset;
       }
       // a filtered batch that is itself bypassed would hand out buffers this call owns: emit it as an OWNED batch
-      if (co->limit >= 0 && selected > co->limit && (co->buffered == 0 || co->buffered > co->limit)) {
+      if (leaves_as_is) {
         if (co->buffered > co->limit) st = finish_buffered(ctx, co);
         if (st == AH_OK) {
           CoBatch b;
@@ -980,6 +985,13 @@ ah_status slab_pin_reserve(ah_context* ctx, SlabPin& sp, size_t bytes) {
 }
 
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// the most output one slab holds (a kept batch pins its slab)
+size_t slab_cap_bytes() {  // (read per push, not cached: the tests shrink it to put many slabs into a small push)
+  const char* e = getenv("AH_COALESCE_SLAB_BYTES");
+  const long long v = e ? atoll(e) : 0;
+  return v > 0 ? (size_t)v : (size_t)64 << 20;
+}
 
 // AH_COALESCE_COPY_STREAM=0: table uploads on the context's stream, in front of the count (A/B runs)
 bool slab_copy_stream_enabled() {
@@ -1238,23 +1250,34 @@ ah_status slab_end(ah_context* ctx, ah_coalescer* co, SlabPush* sp_raw) {
       if (co->buffered >= co->target) st = finish_buffered(ctx, co);
     }
   }
-  // 2. everything else: one slab of whole output batches
+  // 2. everything else: slabs of whole output batches.  A slab stays allocated until its LAST slice is released, so a consumer
+  // that keeps one 8192-row batch of a push would otherwise pin the push's whole output (GBs for a 2^27-row push; the reference
+  // allocates every batch on its own, coalesce.rs:560-600).  Slabs are therefore capped (AH_COALESCE_SLAB_BYTES, default
+  // 64 MiB; at least one batch): a kept batch retains at most one cap's worth, and a slab's scatter is still long enough
+  // (>= 64 MiB of output) that the extra launches do not show (profiles/r06_coalesce_slab_cap.md).
   const int64_t rest = K - take1;
   if (st == AH_OK && rest > 0) {
-    const int64_t nb = ah_ceil_div(rest, co->target), nfull = rest / co->target, tail = rest % co->target;
-    size_t off = 0, voff[AH_TBL_MAX_COLS], boff[AH_TBL_MAX_COLS];
-    for (int k = 0; k < co->ncols; ++k) {
-      voff[k] = off;
-      off += up256((size_t)nb * co->target * co->cols[k].width);
-    }
-    const size_t bits_begin = off;
-    for (int k = 0; k < co->ncols; ++k) {
-      boff[k] = off;
-      off += up256((size_t)nb * co->target / 8);
-    }
-    ah_slab* slab = nullptr;
-    st = ah_slab_create(ctx, off, &slab);
-    if (st == AH_OK) {
+    size_t per_batch = 0;
+    for (int k = 0; k < co->ncols; ++k) per_batch += (size_t)co->target * co->cols[k].width + (size_t)co->target / 8;
+    const int64_t cap_batches = std::max<int64_t>(1, (int64_t)(slab_cap_bytes() / std::max<size_t>(per_batch, 1)));
+    const int64_t nb_total = ah_ceil_div(rest, co->target);
+    for (int64_t b0 = 0; b0 < nb_total && st == AH_OK; b0 += cap_batches) {
+      const int64_t nb = std::min(cap_batches, nb_total - b0);
+      const int64_t lo = take1 + b0 * co->target, hi = std::min(K, lo + nb * co->target);
+      const int64_t nfull = (hi - lo) / co->target, tail = (hi - lo) % co->target;  // (a tail only in the push's last slab)
+      size_t off = 0, voff[AH_TBL_MAX_COLS], boff[AH_TBL_MAX_COLS];
+      for (int k = 0; k < co->ncols; ++k) {
+        voff[k] = off;
+        off += up256((size_t)nb * co->target * co->cols[k].width);
+      }
+      const size_t bits_begin = off;
+      for (int k = 0; k < co->ncols; ++k) {
+        boff[k] = off;
+        off += up256((size_t)nb * co->target / 8);
+      }
+      ah_slab* slab = nullptr;
+      st = ah_slab_create(ctx, off, &slab);
+      if (st != AH_OK) break;
       char* base = (char*)slab->block;
       void* dv[AH_TBL_MAX_COLS];
       uint8_t* db[AH_TBL_MAX_COLS];
@@ -1266,10 +1289,12 @@ ah_status slab_end(ah_context* ctx, ah_coalescer* co, SlabPush* sp_raw) {
         slots[k] = (unsigned long long*)co->acc + (size_t)k * 64;
       }
       if (hipMemsetAsync(base + bits_begin, 0, off - bits_begin, ctx->stream) != hipSuccess) st = ah_fail(ctx, AH_HIP_ERROR, "coalescer bitmap reset failed");
-      // waves that can hold a position >= take1: from the last wave that starts at or before it
-      int64_t w_lo = first_wave_reaching(take1 + 1);  // first wave starting AFTER take1 ...
-      w_lo = w_lo > 0 ? w_lo - 1 : 0;                  // ... so the one before it holds position take1
-      if (st == AH_OK) st = scatter_all(dv, db, first_tile_of_wave(w_lo), sp->t.ntiles, take1, K, 0);
+      // waves that can hold a position in [lo, hi): from the last wave that starts at or before `lo` ...
+      int64_t w_lo = first_wave_reaching(lo + 1);  // first wave starting AFTER lo ...
+      w_lo = w_lo > 0 ? w_lo - 1 : 0;               // ... so the one before it holds position lo
+      // ... to the last wave that starts before `hi`
+      const int64_t tile_hi = hi >= K ? sp->t.ntiles : tiles_before_wave(first_wave_reaching(hi));
+      if (st == AH_OK) st = scatter_all(dv, db, first_tile_of_wave(w_lo), tile_hi, lo, hi, 0);
       enq = enq || st == AH_OK;
       std::shared_ptr<SlabNulls> sn;
       if (st == AH_OK && nfull > 0) {
@@ -1515,7 +1540,6 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters_begin(ah_context* ct
     }
     if (bs != AH_NOT_YET_IMPLEMENTED) return bs;
   }
-  if (n > 64) return ah_fail(ctx, AH_INVALID_ARGUMENT, "a grouped push of more than 64 batches needs the slab path (fixed-width columns, no bypass limit, target a multiple of 64)");
   auto* h = new ah_coalescer_push();
   h->n = n;
   h->columns.assign(columns, columns + (size_t)n * co->ncols);
@@ -1524,7 +1548,19 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters_begin(ah_context* ct
   if (tags) h->tags.assign(tags, tags + n);
   h->preds.assign((size_t)n, nullptr);
   ah_status st = AH_OK;
-  if (n > 0) {
+  if (n > 64) {
+    // More than 64 batches and the slab path declined — for a reason that can be transient or a property of the context
+    // (deferred mode, an allocator hook, a capture, two pushes already in flight, AH_COALESCE_SLAB=0, a generic column;
+    // ADVICE r05): counted here, 64 predicates per count pass and one wait each, and appended by _end exactly as the one-call
+    // form appends them.  (Before round 6 this was an AH_INVALID_ARGUMENT.)
+    for (int base = 0; base < n && st == AH_OK; base += 64)
+      st = ah_filter_predicates_build(ctx, std::min(64, n - base), h->filters.data() + base, h->preds.data() + base);
+    h->counted = st == AH_OK;
+    if (st != AH_OK) {
+      (void)ah_stream_wait(ctx);
+      for (auto*& p : h->preds) ah_filter_predicate_free(ctx, p), p = nullptr;
+    }
+  } else if (n > 0) {
     const int slot = !co->cnt_busy[0] ? 0 : (!co->cnt_busy[1] ? 1 : -1);
     st = slot < 0 ? AH_NOT_YET_IMPLEMENTED
                   : ah_filter_predicates_begin(ctx, n, h->filters.data(), h->preds.data(), co->cnt_pin_dev + 64 * slot, &h->seq,
@@ -1564,9 +1600,13 @@ extern "C" ah_status ah_coalescer_push_batches_with_filters_end(ah_context* ctx,
     if (st != AH_OK) (void)ah_stream_wait(ctx);  // the count kernels may still be writing the blocks freed below
   }
   if (st == AH_OK && co->failed) st = ah_fail(ctx, AH_INVALID_ARGUMENT, "BatchCoalescer: unusable after an earlier device error");
-  if (st == AH_OK && h->n > 0)
-    st = append_group(ctx, co, h->n, h->columns.data(), h->num_rows.data(), h->filters.data(), h->tags.empty() ? nullptr : h->tags.data(),
-                      bypassed, h->preds.data(), group_fusable(co, h->n, h->columns.data(), h->filters.data()));
+  if (st == AH_OK && h->n > 0) {
+    const bool fusable = group_fusable(co, h->n, h->columns.data(), h->filters.data());
+    for (int base = 0; base < h->n && st == AH_OK; base += 64)  // (groups of 64, like the one-call form)
+      st = append_group(ctx, co, std::min(64, h->n - base), h->columns.data() + (size_t)base * co->ncols, h->num_rows.data() + base,
+                        h->filters.data() + base, h->tags.empty() ? nullptr : h->tags.data() + base, bypassed ? bypassed + base : nullptr,
+                        h->preds.data() + base, fusable);
+  }
   for (auto* p : h->preds) ah_filter_predicate_free(ctx, p);
   delete h;
   return st;

@@ -22,6 +22,9 @@ from orc import HostArray, assert_logical_eq
 from test_oracle_golden import BOOL_BIN, BOOL_UN
 
 pytestmark = pytest.mark.gpu
+# AH_DEBUG_GUARD=1 maps every pool block with the virtual-memory API, which a stream capture does not allow: the graph tests
+# are not part of the guard-page run (tests/test_gpu_guard.py)
+GUARD = pytest.mark.skipif(__import__("os").environ.get("AH_DEBUG_GUARD") == "1", reason="guard-page allocator cannot map memory during a capture")
 
 
 def host(arr):
@@ -249,6 +252,7 @@ def test_deferred_small_batches_are_cheaper(ctx):
 
 
 @pytest.mark.skipif(os.environ.get("AH_DEBUG_REDZONE") == "1", reason="the redzone check synchronizes: not capturable")
+@GUARD
 def test_deferred_chain_captured_in_a_hip_graph(ctx, oracle):
     """Deferred calls make no host synchronisation and (with a warm pool) no hipMalloc, so a chain of them can be
     stream-captured into a hipGraph and replayed on new input bytes: the launch-bound small-batch loop as ONE
@@ -294,6 +298,7 @@ def test_deferred_chain_captured_in_a_hip_graph(ctx, oracle):
     print(f"hipGraph replay of the 3-kernel chain: {(time.perf_counter() - t0) / 500 * 1e6:.1f} us per chain")
 
 
+@GUARD
 def test_graph_capture_through_the_c_abi(ctx, oracle):
     """ah_graph_begin / _end / _launch (round 4): the launch-bound small-batch loop as ONE graph launch WITHOUT torch —
     deferred calls are recorded on the context's stream (arithmetic chain, compare, a prebuilt FilterPredicate applied to
@@ -344,6 +349,7 @@ def test_graph_capture_through_the_c_abi(ctx, oracle):
     print(f"hipGraph replay of 7 recorded calls on 65 536 rows: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per replay")
 
 
+@GUARD
 def test_graph_capture_refuses_calls_that_wait():
     """An entry point that has to wait on the device (checked arithmetic reads its error word back; take; strings; a
     host copy) cannot be recorded: it must FAIL FAST — never spin on a mailbox whose posting kernel is only being

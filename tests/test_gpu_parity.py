@@ -1834,6 +1834,133 @@ def test_batch_coalescer_slab_push_reference_operating_point(ctx, shape):
     assert not expected and co.is_empty()
 
 
+def test_batch_coalescer_slab_cap_bounds_retention(ctx):
+    """every output batch of a slab push is a slice of a pool block that lives until its LAST slice is released, so
+    one kept batch used to pin the push's whole output; the reference allocates each batch on its own (coalesce.rs:560-600).
+    Slabs are capped (AH_COALESCE_SLAB_BYTES; here 1 MiB so that a small push spans dozens of slabs, with the in-progress batch
+    topped up first and a tail left over): every batch is still the reference's, and after releasing all batches but one the
+    context holds one slab's worth of output, not the push's."""
+    import gc
+    import os
+    rng = np.random.default_rng(77)
+    dts, target, sizes = [A.Int64, A.Float64], 8192, [8192] * 512
+    total = sum(sizes)
+    hcols = [HostArray(dt, _rand_values(rng, dt, total), rng.random(total) < 0.9) for dt in dts]
+    hf = HostArray(A.Boolean, rng.random(total) < 0.5)
+    keep = np.asarray(hf.values)
+    dcols, df = [c.to_device(ctx) for c in hcols], hf.to_device(ctx)
+    names = ["a", "b"]
+    pairs, off = [], 0
+    for n in sizes:
+        pairs.append((A.RecordBatch(names, [c.slice(off, n) for c in dcols], n), df.slice(off, n)))
+        off += n
+    os.environ["AH_COALESCE_SLAB_BYTES"] = str(1 << 20)
+    try:
+        co = K.BatchCoalescer.new(names, dts, target, ctx)
+        expected = _expected_stream(hcols, keep, target)
+        co.push_batches_with_filters(pairs[:3])   # leaves an in-progress batch behind: the next push tops it up first
+        co.push_batches_with_filters(pairs[3:])
+        got = co.next_completed_batches()
+        co.finish_buffered_batch()
+        got += co.next_completed_batches()
+        assert len(got) == len(expected)
+        for j, (b, exp) in enumerate(zip(got, expected)):
+            for c, e in zip(b.columns, exp):
+                check(c, e, f"capped slabs batch {j}")
+        out_bytes = int(keep.sum()) * 16
+        assert out_bytes > 30 << 20
+        kept = got[len(got) // 2]
+        del got, b, c, co
+        gc.collect()
+        base = ctx.memory_stats()["live_bytes"]
+        del kept
+        gc.collect()
+        held_by_one_batch = base - ctx.memory_stats()["live_bytes"]
+        # one slab: at most the cap (rounded up to whole output batches and the pool's 1 MiB granule), never the whole push
+        assert 0 < held_by_one_batch <= 3 << 20, held_by_one_batch
+    finally:
+        os.environ.pop("AH_COALESCE_SLAB_BYTES", None)
+
+
+def test_batch_coalescer_more_than_64_pairs_when_the_slab_path_declines(ctx):
+    """`push_batches_with_filters_begin` with more than 64 pairs raised whenever the slab path declined for a reason
+    Python could not see (deferred context, two pushes already in flight, AH_COALESCE_SLAB=0).  The library now counts groups of
+    64 itself: 100 pairs in deferred mode, and three begins in flight, give the reference's stream."""
+    rng = np.random.default_rng(78)
+    dts, target, sizes = [A.Int64, A.Int32], 8192, [int(x) for x in rng.integers(100, 9000, 300)]
+    total = sum(sizes)
+    hcols = [HostArray(dt, _rand_values(rng, dt, total), rng.random(total) < 0.9) for dt in dts]
+    hf = HostArray(A.Boolean, rng.random(total) < 0.3, rng.random(total) < 0.95)
+    keep = np.asarray(hf.values) & np.asarray(hf.valid)
+    dcols, df = [c.to_device(ctx) for c in hcols], hf.to_device(ctx)
+    names = ["a", "b"]
+    pairs, off = [], 0
+    for n in sizes:
+        pairs.append((A.RecordBatch(names, [c.slice(off, n) for c in dcols], n), df.slice(off, n)))
+        off += n
+    # (a) a deferred context, 100 pairs per begin
+    co = K.BatchCoalescer.new(names, dts, target, ctx)
+    expected = _expected_stream(hcols, keep, target)
+    with ctx.deferred_mode():
+        for g in range(0, 300, 100):
+            co.push_batches_with_filters_begin(pairs[g:g + 100]).end()
+    ctx.synchronize()
+    _drain_and_check(co, expected, "deferred, 100 pairs")
+    co.finish_buffered_batch()
+    _drain_and_check(co, expected, "deferred, 100 pairs, tail")
+    assert not expected
+    # (b) three begins in flight (the slab path takes two), ended in order
+    co = K.BatchCoalescer.new(names, dts, target, ctx)
+    expected = _expected_stream(hcols, keep, target)
+    h = [co.push_batches_with_filters_begin(pairs[g:g + 100]) for g in range(0, 300, 100)]
+    for x in h:
+        x.end()
+    _drain_and_check(co, expected, "three begins in flight")
+    co.finish_buffered_batch()
+    _drain_and_check(co, expected, "three begins in flight, tail")
+    assert not expected
+    # (c) a begun push that is never ended, collected AFTER its coalescer: aborted by the coalescer's own finalizer
+    import gc
+    co = K.BatchCoalescer.new(names, dts, target, ctx)
+    pend = co.push_batches_with_filters_begin(pairs[:70])
+    pend.co = None  # (the pending push normally keeps its coalescer alive: drop that edge to force the order)
+    del co
+    gc.collect()
+    del pend
+    gc.collect()
+    assert len(K.filter(dcols[0], df)) == int(keep.sum())  # the context is still healthy
+
+
+@pytest.mark.parametrize("grouped", [False, True])
+def test_batch_coalescer_owned_large_batch_does_not_alias_its_input(ctx, grouped):
+    """Round 6, found by the guard-page run: a filtered push whose predicate is SHORTER than its batch and selects every one of
+    its rows takes filter's `All` strategy — a borrowed slice of the caller's buffers (filter.rs:546) — and with a bypass limit
+    below the row count that slice went into the completed queue as if the coalescer owned it (large-batch cases 1 / 2,
+    coalesce.rs:330-360): the caller, told the batch was NOT bypassed, may release its input, and the completed batch then read
+    released memory.  Here the input is released and its pool blocks are recycled with other bytes before the batch is fetched."""
+    import gc
+    rng = np.random.default_rng(79)
+    n, flen = 12199, 12197
+    vals = [rng.integers(-2**62, 2**62, n, dtype=np.int64), rng.normal(size=n)]
+    valid = rng.random(n) < 0.85
+    co = K.BatchCoalescer.new(["a", "b"], [A.Int64, A.Float64], 512, ctx).with_biggest_coalesce_batch_size(64)
+    cols = [HostArray(A.Int64, vals[0], valid).to_device(ctx), HostArray(A.Float64, vals[1]).to_device(ctx)]
+    f = HostArray(A.Boolean, np.ones(flen, dtype=bool)).to_device(ctx)
+    rb = A.RecordBatch(["a", "b"], cols)
+    if grouped:
+        co.push_batches_with_filters([(rb, f)])
+    else:
+        co.push_batch_with_filter(rb, f)
+    del rb, cols, f
+    gc.collect()
+    junk = [HostArray(A.Int64, np.full(n, 0x5A5A5A5A5A5A5A5A, dtype=np.int64), np.zeros(n, dtype=bool)).to_device(ctx) for _ in range(4)]
+    got = co.next_completed_batch()
+    assert got is not None and got.num_rows() == flen
+    check(got.columns[0], HostArray(A.Int64, vals[0][:flen], valid[:flen]), "owned large batch, Int64")
+    check(got.columns[1], HostArray(A.Float64, vals[1][:flen]), "owned large batch, Float64")
+    del junk
+
+
 def test_batch_coalescer_generic_columns(ctx, oracle):
     """Boolean / Utf8 / LargeUtf8 columns go through GenericInProgressArray (coalesce/generic.rs): buffered
     slices and filtered arrays, `concat` on finish — next to a primitive column on the fused path; same batch
@@ -2216,6 +2343,11 @@ def test_bench_json_contract(ctx):
     for k in ["value", "unit", "cores", "kind", "sample"]:
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["value"] > 0
+    # round 6: every per-config fraction of the invocation sits INSIDE `roofline` (the driver's record keeps that object whole)
+    bc = d["roofline"]["by_config"]
+    assert "filter" in bc
+    for k, c in bc.items():
+        assert c["avg_launch_ms"] > 0 and abs(c["frac"] - c["alg_bytes"] / (c["avg_launch_ms"] * 1e-3) / 1e9 / 8000.0) < 2e-3, (k, c)
     # round 4: the stdout line is the COMPACT one and it comes last; the full-detail object is on stderr and in the file
     assert len(lines[0]) < 8000 and out.stdout.rstrip().splitlines()[-1] == lines[0]
     det = [l for l in out.stderr.splitlines() if l.startswith("BENCH_DETAIL {")]
