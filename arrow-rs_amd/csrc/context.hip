@@ -130,7 +130,25 @@ static ah_status guard_alloc(ah_context* ctx, size_t bytes, void** out) {
   ah_context::guard_block b{};
   b.va_bytes = map_bytes + gran;  // the last granule stays unmapped: the guard
   b.map_bytes = map_bytes;
-  hipError_t e = hipMemAddressReserve(&b.va, b.va_bytes, gran, nullptr, 0);
+  // Every reservation asks for the next NEVER-USED address (a process-wide cursor handed to hipMemAddressReserve as its
+  // hint; honoured every time in tools/probes/vmm_probe.hip): see guard_unmap for why no address may come back.
+  static std::mutex hint_mu;
+  static char* hint = (char*)0x200000000000ull;
+  hipError_t e = hipSuccess;
+  {
+    std::lock_guard<std::mutex> lk(hint_mu);
+    for (int attempt = 0; attempt < 8; ++attempt) {
+      e = hipMemAddressReserve(&b.va, b.va_bytes, gran, hint, 0);
+      if (e != hipSuccess) break;
+      if ((char*)b.va >= hint) {
+        hint = (char*)b.va + b.va_bytes;
+        break;
+      }
+      if (attempt == 7) break;  // (an address below the cursor eight times over: take it rather than fail the allocation)
+      (void)hipMemAddressFree(b.va, b.va_bytes);
+      hint += (size_t)1 << 30;
+    }
+  }
   if (e == hipSuccess) {
     e = hipMemCreate(&b.handle, map_bytes, &prop, 0);
     if (e == hipSuccess) {
@@ -163,14 +181,17 @@ static ah_status guard_alloc(ah_context* ctx, size_t bytes, void** out) {
   stats_on_alloc(ctx, map_bytes, false);
   return AH_OK;
 }
-// The RESERVATION is never given back: (1) a released buffer's addresses then stay unmapped for the life of the process, so a
-// use-after-release faults however late it comes; (2) on this stack (ROCm 7.2 user space, amdgpu of Linux 6.18) a range that is
-// hipMemAddressFree'd, reserved again and mapped to new memory intermittently serves the OLD translation to one of the engines
-// — tools/probes/vmm_probe.hip shows blocks reading back another block's bytes after 15-120 map / unmap cycles with address
-// reuse and none without (profiles/r06_crash.md).  47 bits of address space outlast any test run.
+// No ADDRESS is ever used twice (guard_alloc's cursor): (1) a released buffer's addresses then stay unmapped for the life of
+// the process, so a use-after-release faults however late it comes; (2) on this stack (ROCm 7.2 user space, amdgpu of Linux
+// 6.18) a range that is hipMemAddressFree'd, reserved again at the same address and mapped to new memory intermittently serves
+// the OLD translation to one of the engines — tools/probes/vmm_probe.hip shows blocks reading back another block's bytes after
+// 15-120 map / unmap cycles with address reuse and none in 6 000 cycles without (profiles/r06_crash.md).  The reservation
+// itself is given back (a kept one costs two host mappings: a long test process ran into vm.max_map_count); 47 bits of
+// address space outlast any test run.
 static void guard_unmap(const ah_context::guard_block& b) {
   (void)hipMemUnmap(b.va, b.map_bytes);
   (void)hipMemRelease(b.handle);
+  (void)hipMemAddressFree(b.va, b.va_bytes);
 }
 
 ah_status ah_pool_alloc(ah_context* ctx, size_t bytes, void** out) {

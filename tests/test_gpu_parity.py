@@ -2288,6 +2288,7 @@ def test_one_context_shared_by_many_threads(ctx, oracle):
     assert not errs, errs
 
 
+@pytest.mark.skipif(__import__("os").environ.get("AH_DEBUG_GUARD") == "1", reason="the guard-page allocator neither rounds nor caches: the pool accounting asserted here does not apply")
 def test_context_memory_stats(ctx):
     """ah_context_stats: the pooled allocator's accounting (MemoryPool::used / TrackingMemoryPool for HBM,
     arrow-buffer/src/pool.rs:73-93).  Live bytes follow results as they are produced and released, the high-water mark

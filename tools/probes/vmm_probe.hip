@@ -8,12 +8,18 @@
 struct Block { void* va; size_t va_bytes, map_bytes; hipMemGenericAllocationHandle_t h; unsigned char* p; size_t bytes; std::vector<unsigned char> host; };
 static size_t gran;
 static hipMemAllocationProp prop;
+static char* hint = nullptr;  // != nullptr: every reservation asks for the next never-used address (argv[4] = 1)
+static int hint_missed = 0;
 static Block make(size_t bytes, hipStream_t s, bool memset_whole, int fill) {
   Block b{};
   const size_t padded = (bytes + 15) & ~(size_t)15;
   b.map_bytes = (padded + gran - 1) / gran * gran;
   b.va_bytes = b.map_bytes + gran;
-  CK(hipMemAddressReserve(&b.va, b.va_bytes, gran, nullptr, 0));
+  CK(hipMemAddressReserve(&b.va, b.va_bytes, gran, hint, 0));
+  if (hint) {
+    if (b.va != hint) ++hint_missed;
+    if ((char*)b.va + b.va_bytes > hint) hint = (char*)b.va + b.va_bytes;
+  }
   CK(hipMemCreate(&b.h, b.map_bytes, &prop, 0));
   CK(hipMemMap(b.va, b.map_bytes, 0, b.h, 0));
   hipMemAccessDesc acc{};
@@ -46,6 +52,7 @@ int main(int argc, char** argv) {
   CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
   std::vector<Block> live;
   int failing = 0;
+  if (argc > 4 && atoi(argv[4])) hint = (char*)0x200000000000ull;
   const int cycles = argc > 2 ? atoi(argv[2]) : 50;
   for (int i = 0; i < cycles; ++i) {  // the guard allocator's release: drain, unmap, release, free the reservation (VAs get reused)
     Block b = make(1000 + i, s, true, fill);
@@ -62,6 +69,6 @@ int main(int argc, char** argv) {
       if (bad) { printf("after block %zu (%zu B at %p, va %p): block %zu (%zu B at %p) has %zu bad bytes\n", live.size() - 1, bytes, live.back().p, live.back().va, k, live[k].bytes, live[k].p, bad); ++failing; }
     }
   }
-  printf("fill %02X: failing checks %d\n", fill, failing);
+  printf("fill %02X: failing checks %d (hints missed %d, last hint %p)\n", fill, failing, hint_missed, (void*)hint);
   return 0;
 }
