@@ -33,6 +33,8 @@ struct ah_context {
   // (arrow-array/src/array/mod.rs:100) and a Rust wrapper can be `Send + Sync` without a mutex of its own.  Calls on
   // one context serialise (they share its stream and read-back slots); threads that want overlap use one context each.
   std::recursive_mutex mu;
+  const char* last_entry = nullptr;  // the entry point that last took the context (fault reporter)
+  uint64_t entry_calls = 0;
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -106,12 +108,27 @@ struct ah_context {
   std::map<std::string, ah_prof_entry> prof;
 };
 
+// context.hip: the fault reporter's view of "what was the library doing" (see ah_fault_note)
+void ah_fault_enter(ah_context* c, const char* entry_point);
+
 struct ah_ctx_guard {
   std::unique_lock<std::recursive_mutex> lk;
-  explicit ah_ctx_guard(ah_context* c) {
-    if (c) lk = std::unique_lock<std::recursive_mutex>(c->mu);
+  // `fn`: the name of the C-ABI entry point that constructs the guard (every one does, first thing)
+  explicit ah_ctx_guard(ah_context* c, const char* fn = __builtin_FUNCTION()) {
+    if (c) {
+      lk = std::unique_lock<std::recursive_mutex>(c->mu);
+      ah_fault_enter(c, fn);
+    }
   }
 };
+
+// Fault reporter (context.hip): every device / pinned block the library hands out or holds is noted in a fixed lock-free
+// table; when the GPU raises a memory fault the HSA runtime calls the library's system-event handler BEFORE it prints
+// "Memory access fault ..." and aborts, and the handler says which block the address belongs to (or lies just outside of),
+// whether that block is live, cached or released, and which entry point was running.
+enum ah_fault_kind { AH_FK_POOL = 1, AH_FK_PINNED = 2, AH_FK_CONTEXT = 3 };
+enum ah_fault_state { AH_FS_LIVE = 1, AH_FS_CACHED = 2, AH_FS_RELEASED = 3 };
+void ah_fault_note(const void* p, size_t bytes, int kind, int state, const char* what);
 
 ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...);
 // a pinned, device-mapped host block of at least `bytes` (zeroed); ah_pinned_free returns it to the context's cache

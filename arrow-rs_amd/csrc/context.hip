@@ -62,6 +62,139 @@ bool ah_type_is_float(ah_type t) { return t == AH_FLOAT32 || t == AH_FLOAT64; }
 
 void ah_out_init(ah_array_out* out) { memset(out, 0, sizeof *out); }
 
+// ------------------------------------------------------------------- fault reporter
+// GPUTEST_r05: "Memory access fault by GPU node-2 ... on address 0x77e74c552000. Reason: Unknown." twice on one box, nothing
+// else — no test id, no stage, no way to tell whether the address was a buffer of this library, the byte behind one, a block
+// already given back, or nothing of ours at all.  The table below is written with plain atomic stores (no lock: the handler
+// runs on the HSA runtime's event thread while the faulting call may hold the context's mutex spinning on a mailbox) and is
+// only ever READ when a fault has already doomed the process.
+#include <dlfcn.h>
+#include <hsa/hsa_ext_amd.h>
+#include <atomic>
+#include <unistd.h>
+namespace {
+struct FaultSlot {
+  std::atomic<uintptr_t> ptr{0};
+  std::atomic<size_t> bytes{0};
+  std::atomic<int> kind{0}, state{0};
+  std::atomic<const char*> what{nullptr};
+  std::atomic<uint64_t> stamp{0};
+};
+constexpr size_t FAULT_SLOTS = 1 << 16;
+FaultSlot g_fault_slots[FAULT_SLOTS];
+std::atomic<uint64_t> g_fault_stamp{0};
+std::atomic<ah_context*> g_fault_ctx[16];
+std::atomic<bool> g_fault_registered{false};
+
+size_t fault_hash(uintptr_t p) { return (size_t)((p >> 8) * 0x9E3779B97F4A7C15ull >> 48) & (FAULT_SLOTS - 1); }
+
+void fault_line(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  int n = vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (n > (int)sizeof buf - 1) n = (int)sizeof buf - 1;
+  if (n > 0) (void)!write(2, buf, (size_t)n);
+}
+const char* kind_name(int k) { return k == AH_FK_POOL ? "pool block" : k == AH_FK_PINNED ? "pinned host block" : "context block"; }
+const char* state_name(int s) { return s == AH_FS_LIVE ? "LIVE" : s == AH_FS_CACHED ? "released to the pool's free list" : "given back to the driver (unmapped)"; }
+
+hsa_status_t fault_handler(const hsa_amd_event_t* ev, void*) {
+  if (!ev || ev->event_type != HSA_AMD_GPU_MEMORY_FAULT_EVENT) return HSA_STATUS_ERROR;
+  const uintptr_t va = (uintptr_t)ev->memory_fault.virtual_address;
+  const uint32_t why = ev->memory_fault.fault_reason_mask;
+  fault_line("\n[arrow_hip] GPU memory fault at %p, reason mask 0x%x%s%s%s (the runtime aborts the process after this report)\n", (void*)va, why,
+             (why & HSA_AMD_MEMORY_FAULT_PAGE_NOT_PRESENT) ? " page-not-present" : "", (why & HSA_AMD_MEMORY_FAULT_READ_ONLY) ? " read-only" : "",
+             (why & HSA_AMD_MEMORY_FAULT_HOST_ONLY) ? " host-only" : "");
+  for (auto& c : g_fault_ctx) {
+    ah_context* ctx = c.load(std::memory_order_relaxed);
+    if (ctx)
+      fault_line("[arrow_hip]   context %p (device %d): last entry point %s, call #%llu, mailbox sequence %llu\n", (void*)ctx, ctx->device,
+                 ctx->last_entry ? ctx->last_entry : "(none)", (unsigned long long)ctx->entry_calls, (unsigned long long)ctx->mail_seq);
+  }
+  // the block that holds the address, else the nearest block on either side (the hardware reports faults per 4 KiB page: an
+  // address on the first page behind a block's last byte is that block's overrun)
+  const FaultSlot *in = nullptr, *below = nullptr, *above = nullptr;
+  size_t noted = 0;
+  for (const FaultSlot& s : g_fault_slots) {
+    const uintptr_t p = s.ptr.load(std::memory_order_relaxed);
+    if (!p) continue;
+    ++noted;
+    const uintptr_t e = p + s.bytes.load(std::memory_order_relaxed);
+    if (va >= p && va < e) {
+      if (!in || s.stamp.load() > in->stamp.load()) in = &s;
+    } else if (e <= va) {
+      if (!below || e > below->ptr.load() + below->bytes.load()) below = &s;
+    } else if (!above || p < above->ptr.load()) {
+      above = &s;
+    }
+  }
+  auto show = [&](const char* rel, const FaultSlot* s) {
+    if (!s) return;
+    const uintptr_t p = s->ptr.load(), e = p + s->bytes.load();
+    const long long d = va >= e ? (long long)(va - e) : (va < p ? (long long)(p - va) : (long long)(va - p));
+    fault_line("[arrow_hip]   %s: %s %p + %zu bytes, %s, noted by %s (#%llu); the address is %lld bytes %s\n", rel, kind_name(s->kind.load()),
+               (void*)p, s->bytes.load(), state_name(s->state.load()), s->what.load() ? s->what.load() : "?", (unsigned long long)s->stamp.load(), d,
+               va >= e ? "past its end" : (va < p ? "before its start" : "into it"));
+  };
+  if (in) show("INSIDE", in);
+  else fault_line("[arrow_hip]   the address is inside none of the %zu blocks this library has noted\n", noted);
+  show("nearest block below", below);
+  show("nearest block above", above);
+  return HSA_STATUS_ERROR;  // not handled: the runtime prints its own line and aborts, exactly as without this handler
+}
+
+void fault_register(ah_context* ctx) {
+  for (auto& c : g_fault_ctx) {
+    ah_context* expect = nullptr;
+    if (c.compare_exchange_strong(expect, ctx)) break;
+  }
+  bool was = false;
+  if (!g_fault_registered.compare_exchange_strong(was, true)) return;
+  const char* off = getenv("AH_FAULT_REPORT");
+  if (off && off[0] == '0') return;
+  using reg_fn = hsa_status_t (*)(hsa_amd_system_event_callback_t, void*);
+  auto reg = (reg_fn)dlsym(RTLD_DEFAULT, "hsa_amd_register_system_event_handler");
+  if (reg) (void)reg(fault_handler, nullptr);
+}
+void fault_unregister(ah_context* ctx) {
+  for (auto& c : g_fault_ctx) {
+    ah_context* expect = ctx;
+    if (c.compare_exchange_strong(expect, nullptr)) break;
+  }
+}
+}  // namespace
+
+void ah_fault_enter(ah_context* c, const char* entry_point) {
+  c->last_entry = entry_point;
+  c->entry_calls += 1;
+}
+
+void ah_fault_note(const void* p, size_t bytes, int kind, int state, const char* what) {
+  if (!p) return;
+  const uintptr_t u = (uintptr_t)p;
+  size_t h = fault_hash(u);
+  FaultSlot* victim = nullptr;
+  for (int probe = 0; probe < 64; ++probe, h = (h + 1) & (FAULT_SLOTS - 1)) {
+    FaultSlot& s = g_fault_slots[h];
+    const uintptr_t cur = s.ptr.load(std::memory_order_relaxed);
+    if (cur == u || cur == 0) {
+      victim = &s;
+      break;
+    }
+    // a full neighbourhood: the oldest entry that is no longer live makes room
+    if (s.state.load(std::memory_order_relaxed) != AH_FS_LIVE && (!victim || s.stamp.load() < victim->stamp.load())) victim = &s;
+  }
+  if (!victim) return;  // 64 live neighbours: this block goes unrecorded (the report says how many blocks it knows)
+  victim->bytes.store(bytes, std::memory_order_relaxed);
+  victim->kind.store(kind, std::memory_order_relaxed);
+  victim->state.store(state, std::memory_order_relaxed);
+  if (what) victim->what.store(what, std::memory_order_relaxed);
+  victim->stamp.store(++g_fault_stamp, std::memory_order_relaxed);
+  victim->ptr.store(u, std::memory_order_release);
+}
+
 // ------------------------------------------------------------------- pool
 static size_t pool_round(size_t bytes) {
   if (bytes < 256) return 256;
@@ -168,6 +301,7 @@ static ah_status guard_alloc(ah_context* ctx, size_t bytes, void** out) {
     return ah_fail(ctx, e == hipErrorOutOfMemory ? AH_OUT_OF_MEMORY : AH_HIP_ERROR, "AH_DEBUG_GUARD=1: mapping %zu bytes failed: %s", map_bytes,
                    hipGetErrorString(e));
   void* p = (char*)b.va + map_bytes - padded;
+  ah_fault_note(p, bytes, AH_FK_POOL, AH_FS_LIVE, ctx->last_entry);
   // fresh mappings read as zero (the driver clears VRAM), recycled pool blocks do not: poison the whole mapping so that a kernel
   // which relies on zeroed scratch or output memory sees garbage here on every box (AH_DEBUG_GUARD_FILL=hex byte, default CD)
   static const int fill = [] {
@@ -203,6 +337,7 @@ ah_status ah_pool_alloc(ah_context* ctx, size_t bytes, void** out) {
     it->second.pop_back();
     ctx->pool_live[*out] = r;
     stats_on_alloc(ctx, r, true);
+    ah_fault_note(*out, r, AH_FK_POOL, AH_FS_LIVE, ctx->last_entry);
     return AH_OK;
   }
   void* p = nullptr;
@@ -217,6 +352,7 @@ ah_status ah_pool_alloc(ah_context* ctx, size_t bytes, void** out) {
   ctx->pool_live[p] = r;
   *out = p;
   stats_on_alloc(ctx, r, false);
+  ah_fault_note(p, r, AH_FK_POOL, AH_FS_LIVE, ctx->last_entry);
   return AH_OK;
 }
 
@@ -231,7 +367,13 @@ void ah_pool_free(ah_context* ctx, void* p) {
   auto gb = ctx->guard_live.find(p);
   if (gb != ctx->guard_live.end()) {  // guard mode: never recycled — unmapped once nothing enqueued can still be using it
     (void)hipDeviceSynchronize();
+    // Unmapping does not reliably invalidate the translations the GPU has cached (tools/fault_demo.py use_after_release reads a
+    // released block without a fault on this stack): the block is overwritten with 0xDD first, so that a late reader at least
+    // gets bytes no parity check accepts.
+    if (hipMemsetAsync(gb->second.va, 0xDD, gb->second.map_bytes, ctx->stream) == hipSuccess) (void)hipStreamSynchronize(ctx->stream);
+    else (void)hipGetLastError();
     guard_unmap(gb->second);
+    ah_fault_note(p, 0, AH_FK_POOL, AH_FS_RELEASED, nullptr);
     ctx->guard_live.erase(gb);
     ctx->stats.live_bytes -= (int64_t)it->second;
     ctx->stats.freed_bytes_total += (int64_t)it->second;
@@ -240,6 +382,7 @@ void ah_pool_free(ah_context* ctx, void* p) {
     return;
   }
   ctx->pool_free[it->second].push_back(p);
+  ah_fault_note(p, it->second, AH_FK_POOL, AH_FS_CACHED, nullptr);
   ctx->stats.live_bytes -= (int64_t)it->second;
   ctx->stats.freed_bytes_total += (int64_t)it->second;
   ctx->stats.cached_bytes += (int64_t)it->second;
@@ -252,7 +395,10 @@ extern "C" void ah_pool_trim(ah_context* ctx) {
   if (ctx->capturing) return;  // (cached blocks stay cached; a sync would invalidate the capture)
   hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->pool_free)
-    for (void* p : kv.second) hipFree(p);
+    for (void* p : kv.second) {
+      hipFree(p);
+      ah_fault_note(p, kv.first, AH_FK_POOL, AH_FS_RELEASED, nullptr);
+    }
   ctx->pool_free.clear();
   ctx->stats.cached_bytes = 0;
 }
@@ -286,13 +432,19 @@ ah_status ah_pinned_alloc(ah_context* ctx, size_t bytes, void** host, void** dev
   if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) d = h;  // unified addressing
   *host = h;
   *dev = d;
+  ah_fault_note(d, r, AH_FK_PINNED, AH_FS_LIVE, ctx->last_entry);
   return AH_OK;
 }
 void ah_pinned_free(ah_context* ctx, void* host, size_t bytes) {
   if (!host) return;
   const size_t r = (std::max<size_t>(bytes, 8) + 4095) & ~(size_t)4095;
-  if (ctx->pinned_cache.size() < 32) ctx->pinned_cache.emplace_back(r, host);
-  else hipHostFree(host);
+  if (ctx->pinned_cache.size() < 32) {
+    ctx->pinned_cache.emplace_back(r, host);
+    ah_fault_note(host, r, AH_FK_PINNED, AH_FS_CACHED, nullptr);
+  } else {
+    hipHostFree(host);
+    ah_fault_note(host, r, AH_FK_PINNED, AH_FS_RELEASED, nullptr);
+  }
 }
 
 // Debug redzones (AH_DEBUG_REDZONE=1): every pooled output buffer gets a 256-byte canary right
@@ -585,12 +737,17 @@ extern "C" ah_status ah_context_create(int device, ah_context** out) {
     delete c;
     return AH_HIP_ERROR;
   }
+  fault_register(c);
+  ah_fault_note(c->pinned_dev, 256 * sizeof(uint64_t), AH_FK_PINNED, AH_FS_LIVE, "ah_context_create (mailbox)");
+  ah_fault_note(c->scratch, sizeof init, AH_FK_CONTEXT, AH_FS_LIVE, "ah_context_create (counter scratch)");
+  ah_fault_note(c->fault_dev, sizeof fault_init, AH_FK_CONTEXT, AH_FS_LIVE, "ah_context_create (deferred fault words)");
   *out = c;
   return AH_OK;
 }
 
 extern "C" void ah_context_destroy(ah_context* ctx) {
   if (!ctx) return;
+  fault_unregister(ctx);
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
