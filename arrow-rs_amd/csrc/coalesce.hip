@@ -993,11 +993,15 @@ size_t slab_cap_bytes() {  // (read per push, not cached: the tests shrink it to
   return v > 0 ? (size_t)v : (size_t)64 << 20;
 }
 
-// AH_COALESCE_COPY_STREAM=0: table uploads on the context's stream, in front of the count (A/B runs)
+// Table uploads run on the context's own stream, in front of the count.  AH_COALESCE_COPY_STREAM=1 moves them to a second
+// stream beside the previous push's scatter (2-3 % at 8192-row batches, profiles/r05_coalesce_sweep.md): OFF by default since
+// round 6 — it is the one place where a pool block changes stream ownership through hand-placed events, it landed minutes
+// before the round-5 driver run that faulted, and although nothing has tied it to that fault (profiles/r06_crash.md) the gain
+// does not pay for the doubt.
 bool slab_copy_stream_enabled() {
   static const bool on = [] {
     const char* e = getenv("AH_COALESCE_COPY_STREAM");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
   }();
   return on;
 }

@@ -135,14 +135,21 @@ ah_status ah_fail(ah_context* ctx, ah_status st, const char* fmt, ...);
 ah_status ah_pinned_alloc(ah_context* ctx, size_t bytes, void** host, void** dev);
 void ah_pinned_free(ah_context* ctx, void* host, size_t bytes);
 
+// (hipErrorAssert is what the library's own waits return while a deferred ah_take's out-of-bounds fault is outstanding:
+// context.hip fault_peek)
 #define AH_HIP(ctx, expr)                                                                  \
   do {                                                                                     \
     hipError_t _e = (expr);                                                                \
+    if (_e == hipErrorAssert)                                                              \
+      return ah_fail((ctx), AH_PANIC, "%s", AH_DEFERRED_FAULT_TEXT);                       \
     if (_e != hipSuccess)                                                                  \
       return ah_fail((ctx), _e == hipErrorOutOfMemory ? AH_OUT_OF_MEMORY : AH_HIP_ERROR,   \
                      "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__,        \
                      __LINE__, #expr);                                                     \
   } while (0)
+#define AH_DEFERRED_FAULT_TEXT                                                                                           \
+  "a deferred ah_take on this context met an out-of-bounds index: its result, and everything computed from it, is invalid " \
+  "(ah_synchronize reports the index with the reference's panic text)"
 
 #define AH_TRY(expr)            \
   do {                          \

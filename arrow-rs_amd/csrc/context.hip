@@ -572,7 +572,26 @@ static inline void cpu_relax() {
 #endif
 }
 
-hipError_t ah_mail_wait(ah_context* ctx, uint64_t seq) {
+// A DEFERRED ah_take that met an out-of-bounds index has left its fault on the device; until the host calls ah_synchronize /
+// ah_array_resolve (which raise it with the reference's panic text) its output — and whatever was computed from it — is garbage.
+// Every internal host wait therefore peeks at the fault word while a deferred take is outstanding (`fault_armed`): a
+// synchronous call that would otherwise hand such garbage on fails instead (AH_HIP turns hipErrorAssert into AH_PANIC with a
+// message that points at ah_synchronize).  The fault stays on the device and `fault_armed` stays set: ah_synchronize still
+// reports it in full.  (waits used to consume a faulted take's output silently.)
+static hipError_t fault_peek(ah_context* ctx, hipError_t e) {
+  if (e != hipSuccess || !ctx->fault_armed || !ctx->fault_dev || ctx->capturing) return e;
+  unsigned long long w0 = ~0ull;
+  if (hipMemcpy(&w0, ctx->fault_dev, sizeof w0, hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return e;
+  }
+  return w0 == ~0ull ? e : hipErrorAssert;
+}
+
+static hipError_t mail_wait_impl(ah_context* ctx, uint64_t seq);
+hipError_t ah_mail_wait(ah_context* ctx, uint64_t seq) { return fault_peek(ctx, mail_wait_impl(ctx, seq)); }
+
+static hipError_t mail_wait_impl(ah_context* ctx, uint64_t seq) {
   if (ctx->capturing) return hipErrorStreamCaptureUnsupported;  // the posting kernel is being recorded, not run: never spin
   volatile uint64_t* flag = ctx->pinned + AH_MAIL_FLAG;
   if (ctx->wait_mode == 1) {
@@ -638,7 +657,7 @@ hipError_t ah_stream_wait(ah_context* ctx) {
   if (ctx->wait_mode == 1) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) ctx->inflight = false;
-    return e;
+    return fault_peek(ctx, e);
   }
   const uint64_t seq = ah_mail_next(ctx);
   mail_kernel<<<1, 64, 0, ctx->stream>>>(nullptr, 0, ctx->pinned_dev, ctx->pinned_dev, seq, 0, 0);
@@ -674,7 +693,7 @@ hipError_t ah_d2h_wait(ah_context* ctx, void* pinned_dst, const void* dev_src, s
   if (!in_pinned(ctx, pinned_dst, bytes) || (bytes & 7) || ((uintptr_t)dev_src & 7)) {
     hipError_t e = hipMemcpyAsync(pinned_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && reset) e = hipMemsetAsync((void*)dev_src, (int)(reset_value & 0xFF), bytes, ctx->stream);
-    return e == hipSuccess ? hipStreamSynchronize(ctx->stream) : e;
+    return e == hipSuccess ? fault_peek(ctx, hipStreamSynchronize(ctx->stream)) : e;
   }
   const uint64_t seq = ah_mail_next(ctx);
   uint64_t* d = ctx->pinned_dev + ((uint64_t*)pinned_dst - ctx->pinned);

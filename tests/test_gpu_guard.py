@@ -186,3 +186,4 @@ def test_parity_suite_under_guard_pages():
     assert "Memory access fault" not in out, tail
     assert r.returncode == 0, tail
     assert "passed" in r.stdout, tail
+    print("guard-page child run:", [l for l in r.stdout.splitlines() if " passed" in l][-1])

@@ -361,6 +361,22 @@ def test_take_deferred_mode_parity_and_late_oob(ctx, oracle):
         with pytest.raises(A.Panic) as ei:
             ctx.synchronize()
         assert str(ei.value) == "assertion failed: idx < self.bit_len"
+    # round 6: a call that WAITS internally (filter reads its count back) while a deferred take's fault is
+    # outstanding must not hand the garbage on silently: it fails, and ah_synchronize still reports the panic in full
+    ctx.set_deferred(True)
+    try:
+        bad = K.take(v4, HostArray(A.UInt32, np.array([1, 400, 2], dtype=np.uint32)).to_device(ctx))
+        with pytest.raises((A.Panic, A.array.HipError)) as ei:
+            K.filter(bad, HostArray(A.Boolean, np.array([True, False, True])).to_device(ctx))
+        assert "deferred ah_take" in str(ei.value) or "assert" in str(ei.value)
+        with pytest.raises(A.Panic) as ei:
+            ctx.synchronize()
+        assert str(ei.value) == "Out-of-bounds index 400"
+        ctx.synchronize()
+        assert host(K.filter(v4, HostArray(A.Boolean, np.array([True, False, True, True])).to_device(ctx))).to_pylist() == [0, 2, 3]
+        del bad
+    finally:
+        ctx.set_deferred(False)
     # check_bounds and string values stay synchronous in deferred mode (errors at return)
     with ctx.deferred_mode():
         with pytest.raises(A.array.ComputeError):
