@@ -371,7 +371,7 @@ def test_take_deferred_mode_parity_and_late_oob(ctx, oracle):
         assert "deferred ah_take" in str(ei.value) or "assert" in str(ei.value)
         with pytest.raises(A.Panic) as ei:
             ctx.synchronize()
-        assert str(ei.value) == "Out-of-bounds index 400"
+        assert str(ei.value) == "index out of bounds: the len is 4 but the index is 400"
         ctx.synchronize()
         assert host(K.filter(v4, HostArray(A.Boolean, np.array([True, False, True, True])).to_device(ctx))).to_pylist() == [0, 2, 3]
         del bad
