@@ -17,8 +17,8 @@ from arrow_rs_amd import compute as K, distributed as D  # noqa: E402
 import orc  # noqa: E402
 from orc import HostArray  # noqa: E402
 
-rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+rank, world, rdzv = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+dist.init_process_group("gloo", init_method=f"file://{rdzv}", rank=rank, world_size=world)
 torch.cuda.set_device(0)
 oracle = orc.load(os.path.join(ROOT, "oracle", "liboracle.so"))
 ctx = A.Context(0)

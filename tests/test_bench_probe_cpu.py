@@ -28,9 +28,10 @@ def _run(extra_env, timeout, tmp_path):
     env = dict(os.environ, GLOO_SOCKET_IFNAME="lo", PROBE_VERDICT_DIR=str(tmp_path), **extra_env)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "probe_worker.py"), "capi"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    from launch import run_with_port
+    r = run_with_port(lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                                    "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "probe_worker.py"), "capi"],
+                      timeout=timeout, env=env, cwd=ROOT)
     # one file per rank: the ranks share the launcher's stdout pipe, and verdict lines printed there interleaved
     verdicts = [json.load(open(os.path.join(tmp_path, f))) for f in sorted(os.listdir(tmp_path)) if f.endswith(".json")]
     assert r.returncode == 0 and len(verdicts) == 2, (r.stdout[-2000:], r.stderr[-3000:])

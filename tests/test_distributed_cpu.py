@@ -21,7 +21,7 @@ import arrow_rs_amd as A
 from arrow_rs_amd import distributed as D
 import orc
 from orc import HostArray
-dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size={world})
+dist.init_process_group("gloo", init_method="file://{rdzv}", rank=int(sys.argv[1]), world_size={world})
 rank, world = dist.get_rank(), dist.get_world_size()
 oracle = orc.load(os.path.join({root!r}, "oracle", "liboracle.so"))
 n = 100_003
@@ -80,9 +80,9 @@ def test_shard_range_partitions_rows():
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_filter_allgatherv_gloo(oracle, world):
-    port = _free_port()
-    code = WORKER.format(root=ROOT, port=port, world=world)
+def test_sharded_filter_allgatherv_gloo(oracle, world, tmp_path):
+    # (a file store: the "free port" idiom can lose its port to another process between close and listen)
+    code = WORKER.format(root=ROOT, rdzv=os.path.join(str(tmp_path), "rendezvous"), world=world)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", GLOO_SOCKET_IFNAME="lo")
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]

@@ -107,15 +107,13 @@ def test_bench_self_spawned_ranks_over_the_c_abi_transport(workload, launcher, w
     if launcher == "torchrun":
         # EXACTLY the driver's N > 1 command line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
         # 127.0.0.1 --master-port P bench.py --gpus N ...`): the launcher's ranks, gloo rendezvous for the id, ah_comm transport
-        import socket
-        so = socket.socket()
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-        so.close()
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-               "--master-port", str(port)] + cmd[1:]
         env["GLOO_SOCKET_IFNAME"] = "lo"
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        from launch import run_with_port
+        tail = cmd[1:]
+        r = run_with_port(lambda port: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                                        "127.0.0.1", "--master-port", str(port)] + tail, timeout=900, env=env, cwd=root)
+    else:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-4000:])
     d = json.loads(lines[0])
