@@ -416,7 +416,13 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
   constexpr bool STAGED = (W == 1 || W == 2) && S > 1;
   __shared__ __attribute__((aligned(16))) ET s_raw[STAGED ? T : 1];
   __shared__ __attribute__((aligned(16))) ET s_vals[W == 0 ? 1 : CAP + EPV];
-  __shared__ uint8_t s_flag[HAS_VALID ? CAP : 1];
+  __shared__ uint8_t s_flag[HAS_VALID && !STAGED ? CAP : 1];
+  // STAGED: the validity of the staged rows is a BITMAP in LDS laid out like the output words (bit `lead + position`), OR-ed
+  // in by run — a thread's selected rows are consecutive positions, so their validity bits are one shifted register (round 6;
+  // a byte per row written in the walk and read back through a ballot per 64 positions cost a third of the walk's LDS traffic)
+  constexpr int NBITS32 = (CAP + 128) / 32;
+  __shared__ uint32_t s_bits[STAGED && HAS_VALID ? NBITS32 : 1];
+  typedef uint32_t __attribute__((aligned(1))) u32u;  // unaligned LDS dword stores (ds_write_b32 at any byte address on gfx950)
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t row0 = tile * T;
@@ -494,6 +500,9 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
       const int r0 = (l * SCATTER_THREADS + t) * V;
       *(E16*)(s_raw + r0) = raw[l];
     }
+    if constexpr (HAS_VALID)
+      if (t < NBITS32) s_bits[t] = 0;
+    static_assert(NBITS32 <= SCATTER_THREADS, "one thread per bitmap word");
   }
   __syncthreads();
 
@@ -532,8 +541,10 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
     const int phase = (int)((ob + p0) & (EPV - 1));
     const int cnt = (hi_t - p0) < CAP ? (hi_t - p0) : CAP;
     // 3. compact the selected rows whose output position falls in [p0, p0+CAP) into LDS
+    [[maybe_unused]] const int lead = (int)((ob + p0) & 63);  // bit of output position p0 inside its validity word
     if constexpr (STAGED) {
       const bool whole = lo_t == 0 && hi_t == total && total <= CAP;
+      constexpr int PER = 4 / WE;  // values per dword
       constexpr int RS = T / SCATTER_THREADS;  // consecutive rows per thread: half a mask word or a whole one
       static_assert(RS == 32 || RS == 64, "a thread walks the set bits of 32 or 64 mask bits");
       const int r0 = t * RS, w = r0 >> 6, sh = r0 & 63;
@@ -550,12 +561,34 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
         const uint32_t vb = (uint32_t)(vword >> (sh + 32 * h));
         const ET* src = s_raw + r0 + 32 * h;
         if (whole) {  // (tile-uniform) every selected row of the tile is staged by this one pass: no range test in the walk
+          // the run's values leave as whole dwords (PER values each, unaligned LDS stores), its validity bits as one register
+          uint32_t acc = 0, vacc = 0, wp = pos + (uint32_t)phase;
+          int k = 0, nsel = 0;
+          const uint32_t pos_h = pos;
           while (b) {
             const int e = __builtin_ctz(b);
             b &= b - 1;
-            s_vals[pos + phase] = src[e];
-            if constexpr (HAS_VALID) s_flag[pos] = (uint8_t)((vb >> e) & 1u);
-            ++pos;
+            acc |= (uint32_t)src[e] << (k * 8 * WE);
+            if constexpr (HAS_VALID) vacc |= ((vb >> e) & 1u) << nsel;
+            ++nsel;
+            if (++k == PER) {
+              *(u32u*)(s_vals + wp) = acc;
+              wp += PER;
+              acc = 0;
+              k = 0;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < PER - 1; ++j)
+            if (j < k) s_vals[wp + j] = (ET)(acc >> (j * 8 * WE));
+          pos += (uint32_t)nsel;
+          if constexpr (HAS_VALID) {
+            if (vacc) {
+              const uint32_t o = (uint32_t)lead + pos_h, sh2 = o & 31u;
+              atomicOr(&s_bits[o >> 5], vacc << sh2);
+              const uint32_t hi2 = sh2 ? (vacc >> (32u - sh2)) : 0u;
+              if (hi2) atomicOr(&s_bits[(o >> 5) + 1], hi2);
+            }
           }
         } else {
           while (b) {
@@ -563,7 +596,10 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
             b &= b - 1;
             if (pos < (uint32_t)cnt) {  // unsigned: also rejects positions before p0
               s_vals[pos + phase] = src[e];
-              if constexpr (HAS_VALID) s_flag[pos] = (uint8_t)((vb >> e) & 1u);
+              if constexpr (HAS_VALID) {
+                const uint32_t o = (uint32_t)lead + pos;
+                if ((vb >> e) & 1u) atomicOr(&s_bits[o >> 5], 1u << (o & 31u));
+              }
             }
             ++pos;
           }
@@ -618,9 +654,19 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
         for (int j = t; j < cnt; j += SCATTER_THREADS) op[j] = s_vals[j];
       }
     }
-    if constexpr (HAS_VALID) {
+    if constexpr (HAS_VALID && STAGED) {
       const int64_t g0 = cb & ~63ll;
-      const int lead = (int)(cb - g0);
+      const int nw = (lead + cnt + 63) >> 6;  // output words this chunk touches: LDS word pair q IS output word (g0 >> 6) + q
+      if (t < nw) {
+        const uint64_t word = (uint64_t)s_bits[2 * t] | ((uint64_t)s_bits[2 * t + 1] << 32);
+        s_bits[2 * t] = 0;  // (clean for the tile's next chunk)
+        s_bits[2 * t + 1] = 0;
+        if (word) atomicOr(&c_out_valid[(g0 >> 6) + t], (unsigned long long)word);
+        vc += __popcll(word);
+      }
+      static_assert((CAP + 64 + 63) / 64 <= SCATTER_THREADS && 2 * ((CAP + 64 + 63) / 64) <= NBITS32, "one thread per output word");
+    } else if constexpr (HAS_VALID) {
+      const int64_t g0 = cb & ~63ll;
       const int span = lead + cnt;
       const int span64 = (span + 63) & ~63;
       for (int q = t; q < span64; q += SCATTER_THREADS) {
@@ -641,6 +687,10 @@ __device__ __forceinline__ void scatter_tile(const ScatterArgs& a, int64_t tile,
   }
   if constexpr (HAS_VALID) {
     if (c_valid_slots) {  // (null: a plain result's valid rows are counted from its output bitmap afterwards)
+      if constexpr (STAGED) {  // (the staged write-out counts per thread, the ballot form on lane 0 only)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vc += __shfl_xor(vc, o, 64);
+      }
       if (lane == 0) s_vc[wave] = (uint32_t)vc;
       __syncthreads();
       if (t == 0) {
