@@ -1137,6 +1137,45 @@ def test_cast_to_utf8_sparse_and_dense_tiles(ctx, oracle, src):
     check(K.cast(allvalid.to_device(ctx), A.LargeUtf8), oracle.cast(allvalid, A.LargeUtf8), "no nulls")
 
 
+def test_cast_big_integer_doubles_to_utf8(ctx, oracle):
+    """Integer-valued doubles in [2^53, 2^64) — what `Int64 as f64` yields beyond 2^53, the cast chain's general rows — take an
+    exact 64-bit form of Ryu's digit-removal loop instead of the 128-bit multiplication (csrc/cast_string.hip: d2d_big_int).
+    Same digits as Ryu for every class that exercises its rules: random mantissas at every exponent, neighbours of powers
+    of ten (long runs of removable digits, "1e19"), halfway cases (last removed digit 5 with zeros below: round half even),
+    even / odd mantissas (inclusive / exclusive interval ends), exact powers of two (which stay on the general path)."""
+    rng = np.random.default_rng(2653)
+    parts = []
+    for s in range(1, 12):  # value = m2 << s, m2 a 53-bit mantissa
+        m2 = rng.integers(1 << 52, 1 << 53, 30000, dtype=np.uint64)
+        parts.append((m2 << np.uint64(s)).astype(np.float64))
+    for k in range(15, 20):  # around 10^k and 5 * 10^(k-1): doubles next to them, both sides
+        for base in (10 ** k, 5 * 10 ** (k - 1), 25 * 10 ** (k - 2), 125 * 10 ** (k - 3)):
+            if base >= 2 ** 64:
+                continue
+            x = np.float64(base)
+            near = [x]
+            lo = hi = x
+            for _ in range(40):
+                lo, hi = np.nextafter(lo, 0.0), np.nextafter(hi, np.inf)
+                near += [lo, hi]
+            parts.append(np.array([v for v in near if 2.0 ** 53 <= v < 2.0 ** 64], dtype=np.float64))
+    # multiples of 5, 50, 500 … (ties after removing 1, 2, 3 … digits) and of 10^j (trailing zeros of the lower bound)
+    for j in range(1, 6):
+        m = rng.integers((1 << 53) // 10 ** j, (1 << 62) // 10 ** j, 20000, dtype=np.uint64) * np.uint64(10 ** j)
+        parts.append(m.astype(np.float64))
+        parts.append((m + np.uint64(5 * 10 ** (j - 1))).astype(np.float64))
+    parts.append(np.array([2.0 ** e for e in range(53, 64)]))
+    vals = np.concatenate(parts)
+    vals = np.concatenate([vals, -vals[::7]])
+    assert ((np.abs(vals) >= 2.0 ** 53) & (np.abs(vals) < 2.0 ** 64)).all()
+    h = HostArray(A.Float64, vals, rng.random(len(vals)) < 0.97)
+    check(K.cast(h.to_device(ctx), A.LargeUtf8), oracle.cast(h, A.LargeUtf8), "big integer doubles")
+    # the chain's own route: Int64 -> Float64 -> LargeUtf8 in one call
+    iv = np.concatenate([rng.integers(-2**63, 2**63 - 1, 200000, dtype=np.int64), rng.integers(-10**6, 10**6, 50000, dtype=np.int64)])
+    hi = HostArray(A.Int64, iv, rng.random(len(iv)) < 0.9)
+    check(K.cast_chain(hi.to_device(ctx), [A.Float64, A.LargeUtf8]), oracle.cast(oracle.cast(hi, A.Float64), A.LargeUtf8), "chain, full-range Int64")
+
+
 def test_cast_f32_and_ints_to_utf8(ctx, oracle):
     rng = np.random.default_rng(78)
     f32 = np.concatenate([rng.integers(0, 2**32, 40000, dtype=np.uint64).astype(np.uint32).view(np.float32),
