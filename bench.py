@@ -985,8 +985,7 @@ PMC_KERNELS = {
     "arith": {"arith_binary": (r"arith_kernel<", 2.0)},
     "cmp": {"compare": (r"compare_kernel<", 2.0)},
     "cast": {"cast_numeric": (r"cast_(stream_)?kernel<", 2.0)},
-    "cast_string": {"cast_string_len": (r"string_len_kernel<", 2.0), "cast_string_write": (r"string_write_kernel<", 2.0),
-                    "cast_string_onepass": (r"string_onepass_kernel<", 2.0)},
+    "cast_string": {"cast_string_len": (r"string_len_kernel<", 2.0), "cast_string_write": (r"string_write_kernel<", 2.0)},
 }
 
 
@@ -1271,7 +1270,7 @@ def build_workload(env, wl):
             W.update(step=lambda _r: K.cast(src, A.Float64), kernels=["cast_numeric"])
         elif wl == "cast_chain":
             # configs[3] as ONE call (ah_cast_chain): text straight from the Int64 column, the Float64 array is never built
-            W.update(step=lambda _r: K.cast_chain(src, [A.Float64, A.LargeUtf8]), kernels=["cast_string_len", "cast_string_write", "cast_string_onepass"])
+            W.update(step=lambda _r: K.cast_chain(src, [A.Float64, A.LargeUtf8]), kernels=["cast_string_len", "cast_string_write"])
         elif wl == "cast_string_utf8":
             # SURVEY 8d cfg 4: "Utf8 in 64 Mi-row batches to show i32 behaviour" — the same 2^29 rows, 8 casts per step
             f64 = K.cast(src, A.Float64)
@@ -1283,10 +1282,10 @@ def build_workload(env, wl):
                 st["out_bytes"] = sum(o.values.nbytes for o in outs)
                 st["batches"] = len(outs)
                 return outs[-1]
-            W.update(step=step, kernels=["cast_string_len", "cast_string_write", "cast_string_onepass"])
+            W.update(step=step, kernels=["cast_string_len", "cast_string_write"])
         else:
             f64 = K.cast(src, A.Float64)
-            W.update(step=lambda _r: K.cast(f64, A.LargeUtf8), kernels=["cast_string_len", "cast_string_write", "cast_string_onepass"])
+            W.update(step=lambda _r: K.cast(f64, A.LargeUtf8), kernels=["cast_string_len", "cast_string_write"])
         W["dominant"] = W["kernels"][-1]
     W["n"] = n
     return W
@@ -1358,9 +1357,8 @@ def describe(env, wl, W, prof, out, steps):
         dominant = "cast_string_utf8_step"
     elif per_row is None:  # cast_string / cast_chain: input + validity in, offsets + bytes + validity out; both passes of one cast
         alg = n * 8 + (n + 7) // 8 + (n + 1) * 8 + out.values.nbytes + (n + 7) // 8
-        # round 6: one launch (cast_string_onepass) where the library takes the one-pass form, the two passes otherwise
-        dom_avg = sum(prof[k][0] for k in kernels) / max(max(prof[k][1] for k in kernels), 1)
-        dominant = "cast_string_onepass" if prof["cast_string_onepass"][1] else "cast_string_len+cast_string_write"
+        dom_avg = sum(prof[k][0] for k in kernels) / max(prof[kernels[0]][1], 1)
+        dominant = "cast_string_len+cast_string_write"
     else:
         alg = int(per_row * n)
     text = {"arith": "configs[2]: add_wrapping Float64+Float64 with NullBuffers",
