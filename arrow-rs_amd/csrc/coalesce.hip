@@ -990,7 +990,7 @@ size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t slab_cap_bytes() {  // (read per push, not cached: the tests shrink it to put many slabs into a small push)
   const char* e = getenv("AH_COALESCE_SLAB_BYTES");
   const long long v = e ? atoll(e) : 0;
-  return v > 0 ? (size_t)v : (size_t)64 << 20;
+  return v > 0 ? (size_t)v : (size_t)256 << 20;
 }
 
 // Table uploads run on the context's own stream, in front of the count.  AH_COALESCE_COPY_STREAM=1 moves them to a second
@@ -1257,8 +1257,9 @@ ah_status slab_end(ah_context* ctx, ah_coalescer* co, SlabPush* sp_raw) {
   // 2. everything else: slabs of whole output batches.  A slab stays allocated until its LAST slice is released, so a consumer
   // that keeps one 8192-row batch of a push would otherwise pin the push's whole output (GBs for a 2^27-row push; the reference
   // allocates every batch on its own, coalesce.rs:560-600).  Slabs are therefore capped (AH_COALESCE_SLAB_BYTES, default
-  // 64 MiB; at least one batch): a kept batch retains at most one cap's worth, and a slab's scatter is still long enough
-  // (>= 64 MiB of output) that the extra launches do not show (profiles/r06_coalesce_slab_cap.md).
+  // 256 MiB; at least one batch): a kept batch retains at most one cap's worth.  Every slab costs its own scatter launch,
+  // bitmap reset and NULL-count launches (~20 us): at 64 MiB (75 us of scatter per slab) that was 0.3 ms per 1e9 rows of
+  // 8192-row batches, at 256 MiB it is within 2 % of uncapped (profiles/r06_coalesce_slab_cap.md).
   const int64_t rest = K - take1;
   if (st == AH_OK && rest > 0) {
     size_t per_batch = 0;
