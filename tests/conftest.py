@@ -61,6 +61,13 @@ def oracle():
 def ctx():
     """A device context. Only gpu-marked tests may request it: it raises without a GPU."""
     import arrow_rs_amd as A
+    import numpy as np
+    os.write(2, b"\n[ah-test] session: creating the context\n")
     c = A.Context(0)
     A.set_default_context(c)
+    # runtime copies only, before the first kernel of the library runs: a fault between these two lines is the box's, not a kernel's
+    os.write(2, b"[ah-test] session: HIP self test (1 MiB host -> device -> host, runtime copies only)\n")
+    src = (np.arange(1 << 20, dtype=np.uint32) * np.uint32(2654435761) >> np.uint32(24)).astype(np.uint8)
+    assert np.array_equal(A.array.DeviceBuffer.from_numpy(c, src).to_numpy(), src), "HIP self test: the round trip changed bytes"
+    os.write(2, b"[ah-test] session: HIP self test ok\n")
     return c
