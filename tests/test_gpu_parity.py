@@ -2485,6 +2485,7 @@ def test_bitmap_ops_large_offsets(ctx, oracle):
     check_exact(K.take(da, idx.to_device(ctx)), oracle.take(ha, idx), "take sliced")
 
 
+@pytest.mark.skipif(__import__("os").environ.get("AH_DEBUG_GUARD") == "1", reason="the gloo TEST transport hands device pointers to writev(): hipMalloc memory is host-visible on these boxes, a guard mapping (hipMemMap, device access only) is not (EFAULT in gloo's tcp pair)")
 @pytest.mark.parametrize("world", [2, 3])
 def test_communicator_two_ranks_one_gpu(ctx, world):
     """N>1 on the device path: `world` processes share GPU 0 over gloo (device tensors); sharded
