@@ -135,6 +135,21 @@ take_cases.append(dict(name="test_take_bool_nullable_index_nonnull_values", sour
                        values=arr("Boolean", [T, T, F]),
                        indices=dict(type="UInt32", raw=[99, 0, 999, 1, 9999, 2], valid=[F, T, F, T, F, T]),
                        expected=arr("Boolean", [N, T, N, T, N, F])))
+# round 6: the remaining in-scope inline vectors of take.rs (sliced indices over Boolean values, sliced string values, null
+# indices whose slots hold out-of-range numbers over a string column)
+take_cases.append(dict(name="test_take_bool_with_offset", source="arrow-select/src/take.rs:1685-1700",
+                       values=arr("Boolean", [F, N, T, F, N]), indices=arr("UInt32", [3, N, 1, 3, 2, N], [2, 4]),
+                       expected=arr("Boolean", [N, F, T, N])))
+SL7 = ["aaa", "bbb", N, "ccccc", "dd", N, "eeee"]
+take_cases.append(dict(name="test_take_bytes_sliced_values_all_valid", source="arrow-select/src/take.rs:1750-1770",
+                       values=arr("Utf8", SL7, [2, 5]), indices=arr("Int32", [1, 2, 4, 1]),
+                       expected=arr("Utf8", ["ccccc", "dd", "eeee", "ccccc"])))
+take_cases.append(dict(name="test_take_bytes_sliced_values_nullable", source="arrow-select/src/take.rs:1772-1778",
+                       values=arr("Utf8", SL7, [2, 5]), indices=arr("Int32", [1, N, 0, 4, 3]),
+                       expected=arr("Utf8", ["ccccc", N, N, "eeee", N])))
+take_cases.append(dict(name="test_take_bytes_null_indices", source="arrow-select/src/take.rs:2719-2728",
+                       values=arr("Utf8", ["foo", N]), indices=dict(type="Int32", raw=[0, 1, 400, 400], valid=[T, T, F, F]),
+                       expected=arr("Utf8", ["foo", N, N, N])))
 take_cases.append(dict(name="test_take_null_indices", source="arrow-select/src/take.rs:2686-2699",
                        values=arr("Int32", [1, 23, 4, 5]),
                        indices=dict(type="Int32", raw=[1, 2, 400, 400], valid=[T, T, F, F]),
@@ -595,6 +610,69 @@ bool_cases.append(dict(name="test_nullif_int_array_offset", source="arrow-select
 bool_cases.append(dict(name="test_nullif_string", source="arrow-select/src/nullif.rs:192-215", op="nullif",
                        lhs=arr("Utf8", ["hello", N, "world", "a", "b"]), rhs=arr("Boolean", [T, T, F, T, N]),
                        expected=arr("Utf8", [N, N, "world", N, "b"])))
+
+# round 6: the rest of the in-scope inline vectors of boolean.rs / nullif.rs (slices, bit offsets, one-sided null buffers)
+BL = "arrow-arith/src/boolean.rs"
+# :398 / :410 assert and_not(a, b) == and(a, not(b)) on slices: expected = a AND NOT b, row by row
+bool_cases.append(dict(name="test_bool_array_and_not_sliced", source=f"{BL}:398-407", op="and_not",
+                       lhs=arr("Boolean", [T, F, T, F, T, F, T], [2, 3]), rhs=arr("Boolean", [F, T, F, T, F, T, F], [2, 3]),
+                       expected=arr("Boolean", [T, F, T])))
+bool_cases.append(dict(name="test_bool_array_and_not_sliced_different_offsets", source=f"{BL}:410-419", op="and_not",
+                       lhs=arr("Boolean", [F, T, T, F, T, F, T], [1, 4]), rhs=arr("Boolean", [T, F, F, T, F, T, F], [2, 4]),
+                       expected=arr("Boolean", [T, F, F, F])))
+bool_cases.append(dict(name="test_bool_array_or_kleene_right_sided_nulls", source=f"{BL}:555-584", op="or_kleene",
+                       lhs=arr("Boolean", [F, F, F, T, T, T]), rhs=arr("Boolean", [T, F, N, T, F, N]),
+                       expected=arr("Boolean", [T, F, N, T, T, T])))
+bool_cases.append(dict(name="test_bool_array_or_kleene_left_sided_nulls", source=f"{BL}:587-616", op="or_kleene",
+                       lhs=arr("Boolean", [T, F, N, T, F, N]), rhs=arr("Boolean", [F, F, F, T, T, T]),
+                       expected=arr("Boolean", [T, F, N, T, T, T])))
+bool_cases.append(dict(name="test_bool_array_and_nulls", source=f"{BL}:642-678", op="and",
+                       lhs=arr("Boolean", A9), rhs=arr("Boolean", B9), expected=arr("Boolean", [N, N, N, N, F, F, N, F, T])))
+F8 = [F] * 8
+bool_cases.append(dict(name="test_bool_array_and_sliced_same_offset", source=f"{BL}:680-698", op="and",
+                       lhs=arr("Boolean", F8 + [F, F, T, T], [8, 4]), rhs=arr("Boolean", F8 + [F, T, F, T], [8, 4]),
+                       expected=arr("Boolean", [F, F, F, T])))
+bool_cases.append(dict(name="test_bool_array_and_sliced_same_offset_mod8", source=f"{BL}:700-718", op="and",
+                       lhs=arr("Boolean", [F, F, T, T] + F8, [0, 4]), rhs=arr("Boolean", F8 + [F, T, F, T], [8, 4]),
+                       expected=arr("Boolean", [F, F, F, T])))
+bool_cases.append(dict(name="test_bool_array_and_sliced_offset1", source=f"{BL}:720-734", op="and",
+                       lhs=arr("Boolean", F8 + [F, F, T, T], [8, 4]), rhs=arr("Boolean", [F, T, F, T]),
+                       expected=arr("Boolean", [F, F, F, T])))
+bool_cases.append(dict(name="test_bool_array_and_sliced_offset2", source=f"{BL}:736-750", op="and",
+                       lhs=arr("Boolean", [F, F, T, T]), rhs=arr("Boolean", F8 + [F, T, F, T], [8, 4]),
+                       expected=arr("Boolean", [F, F, F, T])))
+bool_cases.append(dict(name="test_bool_array_and_nulls_offset", source=f"{BL}:752-773", op="and",
+                       lhs=arr("Boolean", [N, F, T, N, T], [1, 4]), rhs=arr("Boolean", [N, N, T, F, T, T], [2, 4]),
+                       expected=arr("Boolean", [F, F, N, T])))
+I15 = [1, 2, 3, 4, 5, 6, 7, 8, 7, 6, 5, 4, 3, 2, 1]
+bool_cases.append(dict(name="test_nonnull_array_is_null", source=f"{BL}:775-785", op="is_null",
+                       lhs=arr("Int32", [1, 2, 3, 4]), expected=arr("Boolean", [F, F, F, F]), no_null_buffer=True))
+bool_cases.append(dict(name="test_nonnull_array_with_offset_is_null", source=f"{BL}:787-798", op="is_null",
+                       lhs=arr("Int32", I15, [8, 4]), expected=arr("Boolean", [F, F, F, F]), no_null_buffer=True))
+bool_cases.append(dict(name="test_nonnull_array_is_not_null", source=f"{BL}:800-810", op="is_not_null",
+                       lhs=arr("Int32", [1, 2, 3, 4]), expected=arr("Boolean", [T, T, T, T]), no_null_buffer=True))
+bool_cases.append(dict(name="test_nonnull_array_with_offset_is_not_null", source=f"{BL}:812-823", op="is_not_null",
+                       lhs=arr("Int32", I15, [8, 4]), expected=arr("Boolean", [T, T, T, T]), no_null_buffer=True))
+N8I = [N] * 8 + [1, N, 2, N, 3, 4, N, N]
+bool_cases.append(dict(name="test_nullable_array_with_offset_is_null", source=f"{BL}:846-874", op="is_null",
+                       lhs=arr("Int32", N8I, [8, 4]), expected=arr("Boolean", [F, T, F, T]), no_null_buffer=True))
+bool_cases.append(dict(name="test_nullable_array_with_offset_is_not_null", source=f"{BL}:890-918", op="is_not_null",
+                       lhs=arr("Int32", N8I, [8, 4]), expected=arr("Boolean", [T, F, T, F]), no_null_buffer=True))
+NF = "arrow-select/src/nullif.rs"
+bool_cases.append(dict(name="test_nullif_int_large_left_offset", source=f"{NF}:229-275", op="nullif",
+                       lhs=arr("Int32", [-1] * 16 + [N, 15, 8, 1, 9], [17, 3]), rhs=arr("Boolean", [F, F, F, N, T, F, N], [2, 3]),
+                       expected=arr("Int32", [15, 8, N])))
+bool_cases.append(dict(name="test_nullif_int_large_right_offset", source=f"{NF}:278-324", op="nullif",
+                       lhs=arr("Int32", [N, 15, 8, 1, 9], [1, 3]), rhs=arr("Boolean", [F] * 19 + [N, T, F, N], [18, 3]),
+                       expected=arr("Int32", [15, 8, N])))
+bool_cases.append(dict(name="test_nullif_boolean_offset", source=f"{NF}:327-358", op="nullif",
+                       lhs=arr("Boolean", [N, T, F, T, T], [1, 3]), rhs=arr("Boolean", [F, F, F, N, T, F, N], [2, 3]),
+                       expected=arr("Boolean", [T, F, N])))
+bool_cases.append(dict(name="test_nullif_no_nulls", source=f"{NF}:464-472", op="nullif",
+                       lhs=arr("Int32", [15, 7, 8, 1, 9]), rhs=arr("Boolean", [F, N, T, F, N]),
+                       expected=arr("Int32", [15, 7, N, 1, 9])))
+bool_cases.append(dict(name="nullif_empty", source=f"{NF}:475-480", op="nullif",
+                       lhs=arr("Int32", []), rhs=arr("Boolean", []), expected=arr("Int32", [])))
 
 
 # ---------------------------------------------------------------- aggregate (arrow-arith/src/aggregate.rs tests)

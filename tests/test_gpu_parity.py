@@ -1507,6 +1507,56 @@ def test_batch_coalescer_doc_examples(ctx, oracle):
     assert co.next_completed_batch().columns[0].to_pylist() == [0, 0, 0, 1, 1, 1, 4, 4, 5]
 
 
+@pytest.mark.parametrize("case", __import__("coalesce_reference_cases").SCENARIOS, ids=lambda c: c[0])
+def test_batch_coalescer_reference_scenarios(ctx, case):
+    """Every deterministic scenario of the reference's own BatchCoalescer tests (arrow-select/src/coalesce.rs mod tests,
+    transcribed in tests/coalesce_reference_cases.py): output batch sizes in order, buffered rows after each step, has_completed,
+    the three large-batch bypass rules of set_biggest_coalesce_batch_size, and the output rows = the pushed rows."""
+    from coalesce_reference_cases import run_scenario
+    name, source, target, limit, steps, tail = case
+    co = K.BatchCoalescer.new(["c0"], [A.Int32], target, ctx).with_biggest_coalesce_batch_size(limit)
+
+    class Adapter:
+        def push(self, n):
+            co.push_batch(A.RecordBatch(["c0"], [HostArray(A.Int32, np.arange(n, dtype=np.int32)).to_device(ctx)], n))
+
+        def drain(self):
+            out = []
+            while True:
+                b = co.next_completed_batch()
+                if b is None:
+                    return out
+                vals = host(b.columns[0]).values[:b.num_rows()]
+                out.append([int(x) for x in vals])
+
+        def buffered(self):
+            return co.get_buffered_rows()
+
+        def has_completed(self):
+            return co.has_completed_batch()
+
+        def finish(self):
+            co.finish_buffered_batch()
+
+    run_scenario(Adapter(), steps, tail)
+    assert co.is_empty()
+
+
+def test_batch_coalescer_push_batch_with_indices_reference(ctx):
+    """test_coalasce_push_batch_with_indices (coalesce.rs:2635-2662): 0 .. 2333 pushed plainly, then 2333 .. 23333 REVERSED
+    pushed through the reversing indices: one batch 0 .. 23333."""
+    mid, total = 2333, 23333
+    co = K.BatchCoalescer.new(["c0"], [A.UInt32], total, ctx)
+    co.push_batch(A.RecordBatch(["c0"], [HostArray(A.UInt32, np.arange(mid, dtype=np.uint32)).to_device(ctx)]))
+    b2 = HostArray(A.UInt32, np.arange(mid, total, dtype=np.uint32)[::-1].copy())
+    idx = HostArray(A.UInt64, np.arange(total - mid, dtype=np.uint64)[::-1].copy())
+    co.push_batch_with_indices(A.RecordBatch(["c0"], [b2.to_device(ctx)]), idx.to_device(ctx))
+    co.finish_buffered_batch()
+    out = co.next_completed_batch()
+    assert out.num_rows() == total and np.array_equal(host(out.columns[0]).values, np.arange(total, dtype=np.uint32))
+    assert host(out.columns[0]).valid is None and co.next_completed_batch() is None
+
+
 @pytest.mark.parametrize("limit", [None, 500])
 def test_batch_coalescer_fuzz(ctx, oracle, limit):
     """Random push / push_with_filter / push_with_indices sequences: the device coalescer must
@@ -2524,6 +2574,18 @@ def _view_items(rng, n):
 def test_byte_view_filter_take(ctx, dt):
     """filter_byte_view (filter.rs:931-944) / take_byte_view (take.rs:630-640): views are filtered / gathered as
     16-byte natives, the data-buffer list is shared with the input, nulls follow filter_nulls / take_nulls."""
+    # the reference's own inline vectors first: _test_filter_byte_view (filter.rs:1278-1328, both predicates) and
+    # _test_byte_view (take.rs:1780-1815) — ["hello", "world", null, "large payload over 12 bytes", "lulu"]
+    conv = (lambda x: x) if dt == A.Utf8View else (lambda x: None if x is None else x.encode())
+    ref = [conv(x) for x in ["hello", "world", None, "large payload over 12 bytes", "lulu"]]
+    ra = A.Array.from_string_views(ref, dt, ctx=ctx)
+    f1 = K.filter(ra, A.Array.from_numpy(np.array([True, False, True, True, False]), ctx=ctx))
+    assert f1.to_pylist() == [conv(x) for x in ["hello", None, "large payload over 12 bytes"]] and f1.length == 3
+    f2 = K.filter(ra, A.Array.from_numpy(np.array([True, False, False, False, True]), ctx=ctx))
+    assert f2.to_pylist() == [conv(x) for x in ["hello", "lulu"]] and f2.length == 2
+    ti = A.Array.from_numpy(np.array([3, 0, 1, 3, 4, 2], dtype=np.uint32), np.array([True, False, True, True, True, True]), ctx=ctx)
+    t1 = K.take(ra, ti)
+    assert t1.to_pylist() == [conv(x) for x in ["large payload over 12 bytes", None, "world", "large payload over 12 bytes", "lulu", None]]
     rng = np.random.default_rng(12)
     n = 20_000
     items = _view_items(rng, n)

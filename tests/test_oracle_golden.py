@@ -827,3 +827,39 @@ def test_config0_on_the_oracle():
     assert o.filter_strategy(HostArray(A.Boolean, rng.random(n) < 0.9)) == "Slices"
     assert o.filter_strategy(HostArray(A.Boolean, np.ones(8, dtype=bool))) == "All"
     assert o.filter_strategy(HostArray(A.Boolean, np.zeros(8, dtype=bool))) == "None"
+
+
+@pytest.mark.parametrize("case", __import__("coalesce_reference_cases").SCENARIOS, ids=lambda c: c[0])
+def test_coalescer_model_on_the_reference_scenarios(oracle, case):
+    """tests/coalesce_model.py — the Python restatement of BatchCoalescer the GPU fuzz tests compare the device coalescer with —
+    on every deterministic scenario of the reference's own tests (arrow-select/src/coalesce.rs mod tests: output batch sizes,
+    buffered rows, the large-batch bypass rules): the model is pinned to the reference's numbers, not only to itself."""
+    import numpy as np
+    import arrow_rs_amd as A
+    from coalesce_model import ModelCoalescer
+    from coalesce_reference_cases import run_scenario
+    from orc import HostArray
+    name, source, target, limit, steps, tail = case
+    m = ModelCoalescer(oracle, [A.Int32], target)
+    m.limit = limit
+
+    class Adapter:
+        def push(self, n):
+            m.push([HostArray(A.Int32, np.arange(n, dtype=np.int32))])
+
+        def drain(self):
+            out = []
+            while m.completed:
+                out.append([int(x) for x in m.completed.popleft()[0].values])
+            return out
+
+        def buffered(self):
+            return m.buffered
+
+        def has_completed(self):
+            return bool(m.completed)
+
+        def finish(self):
+            m.finish()
+
+    run_scenario(Adapter(), steps, tail)
