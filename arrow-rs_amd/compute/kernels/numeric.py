@@ -84,5 +84,7 @@ def neg(array):
 
 
 def neg_wrapping(array):
-    """numeric.rs:181"""
-    return _neg(array, True)
+    """numeric.rs:181-186: `downcast_integer! { … => neg_wrapping, _ => neg(array) }` — only the plain integer DataTypes wrap;
+    a Duration / Date / Timestamp column (an integer LAYOUT with a logical type) takes `neg`, which is checked for Duration
+    (`neg_wrapping(DurationSecondArray[i64::MIN])` is the overflow error in the reference's test_neg, numeric.rs:1190-1198)."""
+    return _neg(array, array.data_type.logical is None)

@@ -130,6 +130,37 @@ def test_arith_golden(ctx, case, oracle):
         check_exact(fn(l, r), exp, case["name"])
 
 
+def test_neg_reference_vectors(ctx):
+    """test_neg (arrow-arith/src/numeric.rs:1151-1198), the inline vectors: neg over Int32 / Int64 / the four Duration units /
+    Float32, the overflow texts of i32::MIN / i64::MIN / Duration(i64::MIN), neg_wrapping keeping MIN for the plain integers
+    and — `downcast_integer!` does not match a Duration — raising the same overflow for a Duration column."""
+    src, out = [1, -5, 2, 693, 3929], [-1, 5, -2, -693, -3929]
+    for dt in (A.Int32, A.Int64, A.DurationSecond, A.DurationMillisecond, A.DurationMicrosecond, A.DurationNanosecond):
+        r = K.neg(HostArray(dt, np.array(src, dtype=dt.np_dtype)).to_device(ctx))
+        assert r.data_type == dt and r.to_pylist() == out, dt
+    f = np.array([np.finfo(np.float32).max, np.finfo(np.float32).min, np.inf, 1.3, 0.5], dtype=np.float32)
+    r = K.neg(HostArray(A.Float32, f).to_device(ctx))
+    assert np.array_equal(host(r).values.view(np.uint32), (-f).view(np.uint32))
+    for dt, text in ((A.Int32, "Arithmetic overflow: Overflow happened on: - -2147483648"),
+                     (A.Int64, "Arithmetic overflow: Overflow happened on: - -9223372036854775808"),
+                     (A.DurationSecond, "Arithmetic overflow: Overflow happened on: - -9223372036854775808")):
+        lo = np.iinfo(dt.np_dtype).min
+        with pytest.raises(A.array.ArithmeticOverflow) as ei:
+            K.neg(HostArray(dt, np.array([lo], dtype=dt.np_dtype)).to_device(ctx))
+        assert str(ei.value) == text, str(ei.value)
+    for dt in (A.Int32, A.Int64):
+        lo = np.iinfo(dt.np_dtype).min
+        assert K.neg_wrapping(HostArray(dt, np.array([lo], dtype=dt.np_dtype)).to_device(ctx)).to_pylist() == [lo]
+    with pytest.raises(A.array.ArithmeticOverflow) as ei:
+        K.neg_wrapping(HostArray(A.DurationSecond, np.array([-2**63], dtype=np.int64)).to_device(ctx))
+    assert "Arithmetic overflow: Overflow happened on: - -9223372036854775808" in str(ei.value)
+    # neg of an unsigned column is refused, neg_wrapping wraps it (numeric.rs:101-103, :181)
+    with pytest.raises(A.array.InvalidArgumentError) as ei:
+        K.neg(HostArray(A.UInt8, np.array([1, 2], dtype=np.uint8)).to_device(ctx))
+    assert "Invalid arithmetic operation: !UInt8" in str(ei.value)
+    assert K.neg_wrapping(HostArray(A.UInt8, np.array([1, 2], dtype=np.uint8)).to_device(ctx)).to_pylist() == [255, 254]
+
+
 @pytest.mark.parametrize("case", load_golden("cmp"), ids=lambda c: c["name"])
 def test_cmp_golden(ctx, case):
     fn = CMP_FN[CMP[case["op"]]]

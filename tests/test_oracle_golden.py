@@ -863,3 +863,24 @@ def test_coalescer_model_on_the_reference_scenarios(oracle, case):
             m.finish()
 
     run_scenario(Adapter(), steps, tail)
+
+
+def test_neg_reference_vectors_on_the_oracle(oracle):
+    """test_neg (arrow-arith/src/numeric.rs:1151-1187) on the oracle: the inline vectors, the overflow texts, neg_wrapping at MIN,
+    unsigned refused by neg and wrapped by neg_wrapping (:101-103, :181)."""
+    import arrow_rs_amd as A
+    from orc import HostArray
+    src, out = [1, -5, 2, 693, 3929], [-1, 5, -2, -693, -3929]
+    for dt in (A.Int32, A.Int64):
+        assert oracle.neg(HostArray(dt, np.array(src, dtype=dt.np_dtype))).to_pylist() == out
+        lo = np.iinfo(dt.np_dtype).min
+        with pytest.raises(Exception) as ei:
+            oracle.neg(HostArray(dt, np.array([lo], dtype=dt.np_dtype)))
+        assert f"Arithmetic overflow: Overflow happened on: - {lo}" in str(ei.value)
+        assert oracle.neg(HostArray(dt, np.array([lo], dtype=dt.np_dtype)), wrapping=True).to_pylist() == [lo]
+    f = np.array([np.finfo(np.float32).max, np.finfo(np.float32).min, np.inf, 1.3, 0.5], dtype=np.float32)
+    assert np.array_equal(oracle.neg(HostArray(A.Float32, f)).values.view(np.uint32), (-f).view(np.uint32))
+    with pytest.raises(Exception) as ei:
+        oracle.neg(HostArray(A.UInt8, np.array([1, 2], dtype=np.uint8)))
+    assert "Invalid arithmetic operation: !UInt8" in str(ei.value)
+    assert oracle.neg(HostArray(A.UInt8, np.array([1, 2], dtype=np.uint8)), wrapping=True).to_pylist() == [255, 254]
