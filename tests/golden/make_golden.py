@@ -526,6 +526,11 @@ cast_cases.append(dict(name="test_cast_int32_to_u8_with_error", source="arrow-ca
 cast_cases.append(dict(name="test_cast_i32_to_u8_sliced", source="arrow-cast/src/cast/mod.rs:4728-4739",
                        values=arr("Int32", [-5, 6, -7, 8, 100000000], [2, 3]), to="UInt8",
                        expected=arr("UInt8", [N, 8, N])))
+cast_cases.append(dict(name="test_cast_i32_to_f64", source="arrow-cast/src/cast/mod.rs:4688-4698",
+                       values=arr("Int32", [5, 6, 7, 8, 9]), to="Float64", expected=arr("Float64", [5.0, 6.0, 7.0, 8.0, 9.0])))
+for st in ("Utf8", "LargeUtf8"):
+    cast_cases.append(dict(name=f"test_cast_to_strings_{st}", source="arrow-cast/src/cast/mod.rs:7450-7470",
+                           values=arr("Int32", [1, 2, 3]), to=st, expected=arr(st, ["1", "2", "3"])))
 cast_cases.append(dict(name="test_cast_i32_to_i32", source="arrow-cast/src/cast/mod.rs:4742-4751",
                        values=arr("Int32", [5, 6, 7, 8, 9]), to="Int32", expected=arr("Int32", [5, 6, 7, 8, 9])))
 # test_cast_bool_to_i32 / _to_f64 (:5006, :5046) and test_cast_i32_to_bool-style arms (cast/mod.rs:254-255)
