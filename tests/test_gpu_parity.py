@@ -130,6 +130,18 @@ def test_arith_golden(ctx, case, oracle):
         check_exact(fn(l, r), exp, case["name"])
 
 
+def test_count_set_bits_reference_vectors(ctx):
+    """Buffer::count_set_bits_offset's inline vectors (arrow-buffer/src/buffer/immutable.rs:807-890; tests/count_bits_cases.py)
+    through ah_count_set_bits: byte-offset slices, bit offsets, zero lengths — buffers uploaded at their exact size."""
+    import ctypes as C
+    from count_bits_cases import CASES
+    for data, byte_off, bit_off, nbits, expected in CASES:
+        buf = A.array.DeviceBuffer.from_numpy(ctx, np.array(data, dtype=np.uint8))
+        cnt = C.c_int64(-1)
+        ctx.check(ctx.lib.ah_count_set_bits(ctx.handle, C.c_void_p(buf.ptr + byte_off), bit_off, nbits, C.byref(cnt)))
+        assert cnt.value == expected, (data, byte_off, bit_off, nbits, cnt.value, expected)
+
+
 def test_neg_reference_vectors(ctx):
     """test_neg (arrow-arith/src/numeric.rs:1151-1198), the inline vectors: neg over Int32 / Int64 / the four Duration units /
     Float32, the overflow texts of i32::MIN / i64::MIN / Duration(i64::MIN), neg_wrapping keeping MIN for the plain integers

@@ -884,3 +884,13 @@ def test_neg_reference_vectors_on_the_oracle(oracle):
         oracle.neg(HostArray(A.UInt8, np.array([1, 2], dtype=np.uint8)))
     assert "Invalid arithmetic operation: !UInt8" in str(ei.value)
     assert oracle.neg(HostArray(A.UInt8, np.array([1, 2], dtype=np.uint8)), wrapping=True).to_pylist() == [255, 254]
+
+
+def test_count_set_bits_reference_vectors(oracle):
+    """Buffer::count_set_bits_offset (arrow-buffer/src/buffer/immutable.rs:807-890) on the oracle: tests/count_bits_cases.py."""
+    import ctypes as C
+    from count_bits_cases import CASES
+    for data, byte_off, bit_off, nbits, expected in CASES:
+        buf = np.array(list(data) + [0] * 16, dtype=np.uint8)  # (padding: the oracle reads whole words)
+        got = oracle.lib.orc_count_set_bits(buf.ctypes.data + byte_off, bit_off, nbits)
+        assert got == expected, (data, byte_off, bit_off, nbits, got, expected)
