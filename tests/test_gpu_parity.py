@@ -142,6 +142,28 @@ def test_count_set_bits_reference_vectors(ctx):
         assert cnt.value == expected, (data, byte_off, bit_off, nbits, cnt.value, expected)
 
 
+def test_bitmap_set_bits_reference_vectors(ctx):
+    """bit_mask::set_bits' inline vectors (arrow-buffer/src/util/bit_mask.rs:183-263: aligned, unaligned destination start,
+    unaligned destination end, both unaligned) through ah_bitmap_set_bits — the validity merge of concat and of the multi-GPU
+    reassembly.  The reference returns the NULL count of the copied range; the entry point returns the set bits (= len - nulls)."""
+    import ctypes as C
+    d8 = [0b11100111, 0b10100101, 0b10011001, 0b11011011, 0b11101011, 0b11000011, 0b11100111, 0b10100101]
+    cases = [
+        (10, d8, 8, 0, 64, [0, 0b11100111, 0b10100101, 0b10011001, 0b11011011, 0b11101011, 0b11000011, 0b11100111, 0b10100101, 0], 24),
+        (10, d8, 3, 0, 64, [0b00111000, 0b00101111, 0b11001101, 0b11011100, 0b01011110, 0b00011111, 0b00111110, 0b00101111, 0b00000101, 0], 24),
+        (10, d8, 8, 0, 62, [0, 0b11100111, 0b10100101, 0b10011001, 0b11011011, 0b11101011, 0b11000011, 0b11100111, 0b00100101, 0], 23),
+        (13, d8[:6] * 3, 3, 5, 95, [0b01111000, 0b01101001, 0b11100110, 0b11110110, 0b11111010, 0b11110000, 0b01111001, 0b01101001,
+                                        0b11100110, 0b11110110, 0b11111010, 0b11110000, 0b00000001], 35),
+    ]
+    for nbytes, data, off_w, off_r, n, expected, nulls in cases:
+        dst = A.array.DeviceBuffer.from_numpy(ctx, np.zeros(nbytes, dtype=np.uint8))
+        src = A.array.DeviceBuffer.from_numpy(ctx, np.array(data, dtype=np.uint8))
+        got = C.c_int64(-1)
+        ctx.check(ctx.lib.ah_bitmap_set_bits(ctx.handle, C.c_void_p(dst.ptr), off_w, C.c_void_p(src.ptr), off_r, n, C.byref(got)))
+        assert dst.to_numpy().tolist() == expected, (off_w, off_r, n)
+        assert got.value == n - nulls, (got.value, n - nulls)
+
+
 def test_neg_reference_vectors(ctx):
     """test_neg (arrow-arith/src/numeric.rs:1151-1198), the inline vectors: neg over Int32 / Int64 / the four Duration units /
     Float32, the overflow texts of i32::MIN / i64::MIN / Duration(i64::MIN), neg_wrapping keeping MIN for the plain integers
