@@ -416,6 +416,13 @@ cast_cases.append(dict(name="f64_to_utf8_pinned", source="arrow-cast/src/cast/mo
                        "arrow-cast/src/pretty.rs:865-899; arrow-csv/src/writer.rs:705",
                        values=arr("Float64", [1.5, 2.5, N, 3.2234, 123.564532, -556132.25]), to="Utf8",
                        expected=arr("Utf8", ["1.5", "2.5", N, "3.2234", "123.564532", "-556132.25"])))
+# two more Float64 texts the reference holds, through the same ArrayFormatter (arrow-csv/src/writer.rs builds its cells with it)
+cast_cases.append(dict(name="f64_to_utf8_csv_writer_quote_style", source="arrow-csv/src/writer.rs:1374-1385 (test_write_csv_quote_style: "
+                       "float column 1.1, 2.2, 3.3, 4.4)", values=arr("Float64", [1.1, 2.2, 3.3, 4.4]), to="Utf8",
+                       expected=arr("Utf8", ["1.1", "2.2", "3.3", "4.4"])))
+cast_cases.append(dict(name="f64_to_utf8_csv_writer_doc_example", source="arrow-csv/src/writer.rs:144-163 (module doc test: price "
+                       "1.50, 2.25, 3.00)", values=arr("Float64", [1.50, 2.25, 3.00]), to="LargeUtf8",
+                       expected=arr("LargeUtf8", ["1.5", "2.25", "3.0"])))
 cast_cases.append(dict(name="i64_to_f64_to_utf8_chain", source="arrow-cast/src/cast/mod.rs:8449-8480 values through "
                        "display.rs:711-723 (ryu pretty layout; digits pinned by the Float64 expectations above)",
                        values=arr("Float64", [-9223372036854775808.0, -2147483648.0, 0.0, 127.0, 9223372036854775808.0]),
