@@ -783,6 +783,34 @@ agg("float_inf_and_nans_min", 1484, "min", arr("Float64", mix), "-inf")
 agg("float_inf_and_nans_max", 1484, "max", arr("Float64", mix), "nan")
 
 
+# round 6: min_boolean / max_boolean (:1670-1825), sliced inputs (:1896-1938), wrapping / checked sum at the overflow (:1984-1998)
+def agg_minmax(name, line, values, lo, hi):
+    agg(f"{name}_min", line, "min", values, lo)
+    agg(f"{name}_max", line, "max", values, hi)
+
+
+agg_minmax("test_boolean_min_max_empty", 1670, arr("Boolean", []), None, None)
+agg_minmax("test_boolean_min_max_all_null", 1677, arr("Boolean", [N, N]), None, None)
+agg_minmax("test_boolean_min_max_no_null", 1684, arr("Boolean", [T, F, T]), False, True)
+for k, (v, lo, hi) in enumerate([([T, T, N, F, N], False, True), ([N, T, N, F, N], False, True), ([F, T, N, F, N], False, True),
+                                 ([T, N], True, True), ([F, N], False, False), ([T], True, True), ([F], False, False)]):
+    agg_minmax(f"test_boolean_min_max_{k}", "1691-1719", arr("Boolean", v), lo, hi)
+for k, (v, lo, hi) in enumerate([([F], False, False), ([N, F], False, False), ([N, T], True, True), ([T], True, True)]):
+    agg_minmax(f"test_boolean_min_max_smaller_{k}", "1722-1738", arr("Boolean", v), lo, hi)
+agg_minmax("test_boolean_min_max_64_true_64_false", 1741, arr("Boolean", [T] * 64 + [F] * 64), False, True)
+agg_minmax("test_boolean_min_max_64_true_64_false_nulls", 1741, arr("Boolean", [T] * 31 + [N] + [T] * 32 + [F] + [N] * 63), False, True)
+agg_minmax("test_boolean_min_max_64_false_64_true", 1763, arr("Boolean", [F] * 64 + [T] * 64), False, True)
+agg_minmax("test_boolean_min_max_64_false_64_true_nulls", 1763, arr("Boolean", [F] * 31 + [N] + [F] * 32 + [T] + [N] * 63), False, True)
+agg_minmax("test_boolean_min_max_96_true", 1785, arr("Boolean", [T] * 96), True, True)
+agg_minmax("test_boolean_min_max_96_true_nulls", 1785, arr("Boolean", [T] * 31 + [N] + [T] * 32 + [T] * 31 + [N]), True, True)
+agg_minmax("test_boolean_min_max_96_false", 1806, arr("Boolean", [F] * 96), False, False)
+agg_minmax("test_boolean_min_max_96_false_nulls", 1806, arr("Boolean", [F] * 31 + [N] + [F] * 32 + [F] * 31 + [N]), False, False)
+agg_minmax("test_min_max_sliced_primitive", 1896, arr("Float64", [N, N, N, N, N, 4.0], [4, 2]), 4.0, 4.0)
+agg_minmax("test_min_max_sliced_boolean", 1918, arr("Boolean", [N, N, N, N, N, T], [4, 2]), True, True)
+agg("test_sum_overflow", 1984, "sum", arr("Int32", [2147483647, 1]), -2147483648)
+agg("test_sum_checked_overflow", 1992, "sum_checked", arr("Int32", [2147483647, 1]), None,
+    error="ArithmeticOverflow", message="Overflow happened on: 2147483647 + 1")  # (add_checked's text, arrow-array/src/arithmetic.rs:167-175)
+
 # ---------------------------------------------------------------- concat (arrow-select/src/concat.rs tests)
 concat_cases = [
     dict(name="test_concat_string_arrays", source="arrow-select/src/concat.rs:832-853",
