@@ -21,6 +21,7 @@ SCENARIOS = [
     ("test_single_large_batch_smaller_than_target", f"{S}:846-854", 8192, None, [("push", 4096)], [4096]),
     ("test_single_large_batch_equal_to_target", f"{S}:857-865", 4096, None, [("push", 4096)], [4096]),
     ("test_single_large_batch_equally_divisible_in_target", f"{S}:868-876", 1024, None, [("push", 4096)], [1024] * 4),
+    ("test_coalesce_non_null", f"{S}:1024-1032", 1024, None, [("push", 3000), ("push", 1040)], [1024, 1024, 1024, 968]),
     ("test_biggest_coalesce_batch_size_none_default", f"{S}:2210-2237", 100, None, [("push", 1000)], [100] * 10),
     ("test_biggest_coalesce_batch_size_bypass_large_batch", f"{S}:2240-2260", 100, 500,
      [("push", 1000), ("has_completed", True), ("drain", [1000]), ("has_completed", False), ("buffered", 0)], []),

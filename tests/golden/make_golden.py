@@ -858,6 +858,11 @@ concat_cases = [
     dict(name="string_slices", source="arrow-select/src/concat.rs:1140-1170 (test_string_array_slices recipe)",
          pieces=[arr("Utf8", ["hello", "A", "B", "C"], [1, 3]), arr("Utf8", ["D", "E", N, "F"], [2, 2])],
          expected=arr("Utf8", ["A", "B", "C", N, "F"])),
+    dict(name="test_string_array_with_null_slices", source="arrow-select/src/concat.rs:1328-1340",
+         pieces=[arr("Utf8", ["hello", N, "A", "C"], [1, 3]), arr("Utf8", [N, "world", "D", N], [1, 2])],
+         expected=arr("Utf8", [N, "A", "C", "world", "D"])),
+    dict(name="test_concat_one_element_vec", source="arrow-select/src/concat.rs:717-729",
+         pieces=[arr("Int64", [-1, 2, N])], expected=arr("Int64", [-1, 2, N])),
 ]
 
 # ---------------------------------------------------------------- sort_to_indices (arrow-ord/src/sort.rs tests)

@@ -1607,6 +1607,32 @@ def test_batch_coalescer_reference_scenarios(ctx, case):
     assert co.is_empty()
 
 
+@pytest.mark.parametrize("kind", ["utf8", "uint32_nullable"])
+def test_batch_coalescer_utf8_split_reference(ctx, kind):
+    """test_utf8_split (coalesce.rs:1035-1043) and the nullable uint32_batch its siblings use (:2004-2009): 3000 + 1040 rows,
+    every third one NULL (strings "value{i}"), target 1024 -> 1024, 1024, 1024, 968 rows; the output is the input, row for row."""
+    def batch(n):
+        if kind == "utf8":
+            return HostArray.from_pylist([None if i % 3 == 0 else f"value{i}" for i in range(n)], A.Utf8)
+        return HostArray.from_pylist([None if i % 3 == 0 else i for i in range(n)], A.UInt32)
+    dt = A.Utf8 if kind == "utf8" else A.UInt32
+    co = K.BatchCoalescer.new(["c0"], [dt], 1024, ctx)
+    pushed = []
+    for n in (3000, 1040):
+        h = batch(n)
+        pushed += h.to_pylist()
+        co.push_batch(A.RecordBatch(["c0"], [h.to_device(ctx)], n))
+    co.finish_buffered_batch()
+    sizes, got = [], []
+    while True:
+        b = co.next_completed_batch()
+        if b is None:
+            break
+        sizes.append(b.num_rows())
+        got += host(b.columns[0]).to_pylist()
+    assert sizes == [1024, 1024, 1024, 968] and got == pushed
+
+
 def test_batch_coalescer_push_batch_with_indices_reference(ctx):
     """test_coalasce_push_batch_with_indices (coalesce.rs:2635-2662): 0 .. 2333 pushed plainly, then 2333 .. 23333 REVERSED
     pushed through the reversing indices: one batch 0 .. 23333."""
