@@ -164,6 +164,26 @@ def test_bitmap_set_bits_reference_vectors(ctx):
         assert got.value == n - nulls, (got.value, n - nulls)
 
 
+def test_float_total_order_min_max(ctx):
+    """test_float_total_order_min_max (arrow-array/src/arithmetic.rs:863-897) through lt / gt on the device: the all-ones NaN is
+    below -inf and below -NaN, the all-but-sign NaN above +inf and above NaN, for Float64 / Float32 / Float16."""
+
+    cases = []
+    for dt, ut, nbits in ((A.Float64, np.uint64, 64), (A.Float32, np.uint32, 32), (A.Float16, np.uint16, 16)):
+        fdt = np.dtype(dt.np_dtype)
+        lo = np.array([(1 << nbits) - 1], dtype=ut).view(fdt)            # MIN_TOTAL_ORDER: every bit set (a negative NaN)
+        hi = np.array([(1 << (nbits - 1)) - 1], dtype=ut).view(fdt)      # MAX_TOTAL_ORDER: every bit but the sign (a positive NaN)
+        ninf, pinf = np.array([-np.inf], dtype=fdt), np.array([np.inf], dtype=fdt)
+        nan = np.array([np.nan], dtype=fdt)
+        neg_nan = (nan.view(ut) | ut(1 << (nbits - 1))).view(fdt)
+        cases += [(dt, "lt", lo, ninf), (dt, "lt", lo, neg_nan), (dt, "gt", hi, pinf), (dt, "gt", hi, nan)]
+        assert np.isnan(lo.astype(np.float64))[0] and np.isnan(hi.astype(np.float64))[0]
+    for dt, op, a, b in cases:
+        fn = K.lt if op == "lt" else K.gt
+        assert fn(HostArray(dt, a).to_device(ctx), HostArray(dt, b).to_device(ctx)).to_pylist() == [True], (dt, op)
+        assert fn(HostArray(dt, b).to_device(ctx), HostArray(dt, a).to_device(ctx)).to_pylist() == [False], (dt, op)
+
+
 def test_neg_reference_vectors(ctx):
     """test_neg (arrow-arith/src/numeric.rs:1151-1198), the inline vectors: neg over Int32 / Int64 / the four Duration units /
     Float32, the overflow texts of i32::MIN / i64::MIN / Duration(i64::MIN), neg_wrapping keeping MIN for the plain integers

@@ -894,3 +894,24 @@ def test_count_set_bits_reference_vectors(oracle):
         buf = np.array(list(data) + [0] * 16, dtype=np.uint8)  # (padding: the oracle reads whole words)
         got = oracle.lib.orc_count_set_bits(buf.ctypes.data + byte_off, bit_off, nbits)
         assert got == expected, (data, byte_off, bit_off, nbits, got, expected)
+
+
+def test_float_total_order_min_max_on_the_oracle(oracle):
+    """test_float_total_order_min_max (arrow-array/src/arithmetic.rs:863-897): MIN_TOTAL_ORDER (all bits set) is below -inf and
+    below -NaN, MAX_TOTAL_ORDER (all bits but the sign) above +inf and above NaN, for f64 / f32 / f16 — through lt / gt."""
+    import arrow_rs_amd as A
+    from orc import HostArray
+
+    cases = []
+    for dt, ut, nbits in ((A.Float64, np.uint64, 64), (A.Float32, np.uint32, 32), (A.Float16, np.uint16, 16)):
+        fdt = np.dtype(dt.np_dtype)
+        lo = np.array([(1 << nbits) - 1], dtype=ut).view(fdt)            # MIN_TOTAL_ORDER: every bit set (a negative NaN)
+        hi = np.array([(1 << (nbits - 1)) - 1], dtype=ut).view(fdt)      # MAX_TOTAL_ORDER: every bit but the sign (a positive NaN)
+        ninf, pinf = np.array([-np.inf], dtype=fdt), np.array([np.inf], dtype=fdt)
+        nan = np.array([np.nan], dtype=fdt)
+        neg_nan = (nan.view(ut) | ut(1 << (nbits - 1))).view(fdt)
+        cases += [(dt, "lt", lo, ninf), (dt, "lt", lo, neg_nan), (dt, "gt", hi, pinf), (dt, "gt", hi, nan)]
+        assert np.isnan(lo.astype(np.float64))[0] and np.isnan(hi.astype(np.float64))[0]
+    for dt, op, a, b in cases:
+        r = oracle.compare({"lt": 2, "gt": 4}[op], HostArray(dt, a), HostArray(dt, b))
+        assert r.to_pylist() == [True], (dt, op)
