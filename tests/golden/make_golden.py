@@ -313,6 +313,38 @@ cmp_case("test_primitive_array_eq_scalar_with_slice", "314-322", "eq", arr("Int3
          expected=[N, T, F], rhs_scalar=sc("Int32", 2))
 cmp_case("test_primitive_array_neq", "325-332", "neq", eights, seq, [T, T, F, T, T, T, T, F, T, T])
 cmp_case("test_primitive_array_neq_scalar", "343-350", "neq", seq, expected=[T, T, F, T, T, T, T, F, T, T], rhs_scalar=sc("Int64", 8))
+# round 6: the rest of comparison.rs' scalar-operand tests (lt against a scalar, with nulls; the *_dyn_scalar family over
+# Int32 / Float32 / Float64; the temporal arrays of test_primitive_dyn_scalar; Boolean and Utf8 scalars; signed zeros)
+cmp_case("test_primitive_array_lt_scalar", "611-618", "lt", [6, 7, 8, 9, 10, 6, 7, 8, 9, 10], expected=[T, T, F, F, F, T, T, F, F, F],
+         rhs_scalar=sc("Int64", 8))
+LTN_A, LTN_B = [N, N, 1, 1, N, N, 2, 2], [N, 1, N, 1, N, 3, N, 3]
+cmp_case("test_primitive_array_lt_nulls", "621-636", "lt", LTN_A, LTN_B, [N, N, N, F, N, N, N, T])
+cmp_case("test_primitive_array_lt_nulls_Timestamp(Millisecond, None)", "621-636", "lt", LTN_A, LTN_B, [N, N, N, F, N, N, N, T],
+         t="Timestamp(Millisecond, None)")
+cmp_case("test_primitive_array_lt_scalar_nulls", "639-646", "lt", [N, 1, 2, 3, N, 1, 2, 3, 2, N],
+         expected=[N, T, F, F, N, T, F, F, F, N], rhs_scalar=sc("Int64", 2))
+DYN = [6, 7, 8, 8, 10]
+for op, line_i, line_f, e in [("eq", "1448-1457", "1475-1485", [F, F, T, T, F]), ("lt", "1488-1493", "1511-1521", [T, T, F, F, F]),
+                              ("lt_eq", "1524-1529", "1664-1673", [T, T, T, T, F]), ("gt", "1676-1686", "1704-1713", [F, F, F, F, T]),
+                              ("gt_eq", "1716-1721", "1739-1748", [F, F, T, T, T]), ("neq", "1751-1760", "1777-1787", [T, T, F, F, T])]:
+    cmp_case(f"test_{op}_dyn_scalar", line_i, op, DYN, expected=e, t="Int32", rhs_scalar=sc("Int32", 8))
+    for ft in ("Float32", "Float64"):
+        cmp_case(f"test_{op}_dyn_scalar_float_{ft}", line_f, op, [6.0, 7.0, 8.0, 8.0, 10.0], expected=e, t=ft, rhs_scalar=sc(ft, 8.0))
+PD = [1, N, 8, N, 10]  # test_primitive_dyn_scalar (:1532-1563) against the scalar 8
+for tt, line in [("Date32", "1580-1584"), ("Date64", "1586-1590"), ("Time32(Second)", "1592-1599"), ("Time32(Millisecond)", "1592-1599"),
+                 ("Time64(Microsecond)", "1601-1608"), ("Time64(Nanosecond)", "1601-1608"), ("Duration(Second)", "1634-1644"),
+                 ("Duration(Millisecond)", "1634-1644"), ("Duration(Microsecond)", "1634-1644"), ("Duration(Nanosecond)", "1634-1644"),
+                 ("Timestamp(Second, None)", "1566-1577"), ("Timestamp(Microsecond, None)", "1566-1577"),
+                 ("Timestamp(Nanosecond, None)", "1566-1577")]:
+    for op, e in [("eq", [F, N, T, N, F]), ("gt_eq", [F, N, T, N, T]), ("gt", [F, N, F, N, T]), ("lt_eq", [T, N, T, N, F]), ("lt", [T, N, F, N, F])]:
+        cmp_case(f"test_primitive_dyn_scalar_{tt}_{op}", line, op, PD, expected=e, t=tt, rhs_scalar=sc(tt, 8))
+for op, line, a, e in [("eq", "2077-2085", [T, F, T], [F, T, F]), ("lt", "2088-2096", [T, F, T, N], [F, F, F, N]),
+                       ("gt", "2099-2107", [T, F, T], [T, F, T]), ("lt_eq", "2110-2118", [T, F, T], [F, T, F]),
+                       ("gt_eq", "2121-2129", [T, F, T], [T, T, T]), ("neq", "2132-2140", [T, F, T], [T, F, T])]:
+    cmp_case(f"test_{op}_dyn_bool_scalar", line, op, a, expected=e, t="Boolean", rhs_scalar=sc("Boolean", F))
+cmp_case("test_floating_zeros", "3557-3561", "eq", [0.0, -0.0], [-0.0, 0.0], [F, F], t="Float32")
+cmp_case("test_floating_zeros_scalar_pos", "3564-3567", "eq", [0.0, -0.0], expected=[T, F], t="Float32", rhs_scalar=sc("Float32", 0.0))
+cmp_case("test_floating_zeros_scalar_neg", "3569-3572", "eq", [0.0, -0.0], expected=[F, T], t="Float32", rhs_scalar=sc("Float32", -0.0))
 BA, BB = [T, F, F, T, T, N], [T, T, F, F, N, F]
 for op, line, e in [("eq", "353-366", [T, F, T, F, N, N]), ("neq", "368-381", [F, T, F, T, N, N]),
                     ("lt", "383-396", [F, T, F, F, N, N]), ("lt_eq", "398-411", [T, T, T, F, N, N]),
@@ -1007,6 +1039,10 @@ for opname, line, exp in (("lt", 1311, [T, T, F, F]), ("lt_eq", 1347, [T, T, T, 
                                rhs=["flight"] * 4, expected=exp))
     cmp_utf8_cases.append(dict(name=f"test_utf8_array_{opname}_scalar", source=f"{C_}:{line + 14}", op=opname, lhs=names4,
                                rhs_scalar="flight", expected=exp))
+for opname, line, scalar, exp in (("eq", "1909-1918", "xyz", [F, F, T]), ("lt", "1937-1946", "xyz", [T, T, F]), ("lt_eq", "1965-1974", "def", [T, T, F]),
+                                  ("gt_eq", "1993-2002", "def", [F, T, T]), ("gt", "2021-2030", "def", [F, F, T]), ("neq", "2049-2058", "xyz", [T, T, F])):
+    cmp_utf8_cases.append(dict(name=f"test_{opname}_dyn_utf8_scalar", source=f"{C_}:{line}", op=opname, lhs=["abc", "def", "xyz"],
+                               rhs_scalar=scalar, expected=exp))
 # ---------------------------------------------------------------- like (arrow-string/src/like.rs tests, scalar patterns)
 LK = "arrow-string/src/like.rs"
 like_cases = []
