@@ -2766,6 +2766,18 @@ def test_cmp_utf8_reference_goldens(ctx, case):
         assert got.nulls() is None and got.values_numpy().tolist() == case["expected"]
 
 
+def test_utf8_eq_scalar_on_slice(ctx, oracle):
+    """test_utf8_eq_scalar_on_slice (arrow-ord/src/comparison.rs:1147-1164): ["hi", null, "hello", "world", ""].slice(1, 4) == "hello"
+    and == "" — a sliced string column with a null against a scalar, on the device and on the oracle."""
+    for dt in (A.Utf8, A.LargeUtf8):
+        h = HostArray.from_pylist(["hi", None, "hello", "world", ""], dt)
+        d = h.to_device(ctx).slice(1, 4)
+        for text, exp in (("hello", [None, True, False, False]), ("", [None, False, False, True])):
+            sc = HostArray.from_pylist([text], dt)
+            assert K.eq(d, A.Scalar(sc.to_device(ctx))).to_pylist() == exp
+            assert oracle.compare(0, h.slice(1, 4), sc, r_scalar=True).to_pylist() == exp
+
+
 def test_cmp_strings_fuzz(ctx, oracle):
     """All eight operators, array/array, array/scalar, scalar/array, nulls, long common prefixes (the 8-byte word
     loop and its byte tail), embedded zero bytes, empty strings; then predicate -> filter on the string column."""
